@@ -1,0 +1,542 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the upstream reference.
+
+TEST INFRASTRUCTURE ONLY; runs only in the build container (needs /root/reference).
+The fixtures are DATA: inputs + the outputs the reference produced for them.
+No reference source text is stored.  Re-run with:
+
+    python3 oracle/gen_golden.py [--full]      # --full also renders tiger@2048 / material@4096 (minutes)
+
+Reference entry points exercised (file = /root/reference/svgrasterize.py):
+    line_signed_coverage          S:2213-2304
+    bezier3_flatness/split/flatten_batch   S:2066-2098
+    Transform.__call__            S:531-534
+    Path.mask / Path.fill         S:922-1019
+    Layer.compose / convert / opacity      S:129-207
+    Scene.render                  S:649-752
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_loader  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+DEMO = os.path.join(ref_loader.REF_DIR, "demo")
+
+
+def save(name: str, **arrays) -> None:
+    path = os.path.join(GOLD, name)
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# --------------------------------------------------------------------------------------
+# A. line_signed_coverage known-answer tests
+# --------------------------------------------------------------------------------------
+def gen_coverage(ref) -> None:
+    rng = np.random.default_rng(0xC0FE)
+    cases = []  # (h, w, line(2,2) in (row, col))
+    # hand-written corner cases (rows, cols, p0, p1)
+    hand = [
+        (4, 6, (0.5, 0.25), (3.5, 5.75)),
+        (4, 6, (3.5, 5.75), (0.5, 0.25)),  # reversed: exact negation
+        (3, 4, (-1.0, -2.5), (2.0, -0.5)),  # entirely left of the canvas -> folds into col 0
+        (3, 4, (-1.0, 6.5), (2.0, 9.5)),  # entirely right -> nothing
+        (5, 5, (1.0, 1.0), (1.0, 4.0)),  # horizontal: no coverage
+        (5, 5, (0.0, 2.0), (5.0, 2.0)),  # vertical on a pixel border
+        (5, 5, (0.25, 2.5), (4.75, 2.5)),  # vertical mid pixel
+        (5, 5, (-3.0, 2.5), (9.0, 2.5)),  # vertical crossing top and bottom
+        (5, 8, (1.2, -3.0), (1.9, 12.0)),  # shallow, one row, crosses both sides
+        (5, 8, (1.9, 12.0), (1.2, -3.0)),
+        (6, 8, (0.0, 0.0), (6.0, 8.0)),  # diagonal through pixel corners
+        (6, 8, (0.0, 8.0), (6.0, 0.0)),
+        (6, 8, (2.0, 3.0), (3.0, 4.0)),  # exactly one pixel diagonal
+        (6, 8, (2.0, 3.0), (3.0, 5.0)),  # exactly two pixels
+        (6, 8, (2.0, 3.0), (3.0, 6.0)),  # exactly three pixels
+        (6, 8, (2.5, 7.5), (3.5, 7.9)),  # touches last column
+        (6, 8, (2.5, 7.5), (3.5, 8.4)),  # leaves on the right
+        (6, 8, (5.5, 1.0), (9.5, 3.0)),  # leaves at the bottom
+        (6, 8, (-2.5, 1.0), (0.5, 3.0)),  # enters from the top
+        (1, 1, (0.1, 0.2), (0.9, 0.7)),
+        (2, 3, (1e-9, 0.5), (2 - 1e-9, 2.5)),
+    ]
+    for h, w, p0, p1 in hand:
+        cases.append((h, w, np.array([p0, p1], dtype=np.float64)))
+    # random lines around canvases of different shapes
+    for _ in range(400):
+        h = int(rng.integers(1, 24))
+        w = int(rng.integers(1, 24))
+        lo = np.array([-0.5 * h - 2, -0.5 * w - 2])
+        hi = np.array([1.5 * h + 2, 1.5 * w + 2])
+        line = rng.uniform(lo, hi, size=(2, 2))
+        kind = rng.integers(0, 6)
+        if kind == 0:  # snap endpoints to the pixel grid
+            line = np.round(line)
+        elif kind == 1:  # near-vertical
+            line[1, 1] = line[0, 1] + rng.uniform(-1e-3, 1e-3)
+        elif kind == 2:  # near-horizontal
+            line[1, 0] = line[0, 0] + rng.uniform(-0.3, 0.3)
+        elif kind == 3:  # half-pixel grid
+            line = np.round(line * 2) / 2
+        cases.append((h, w, line.astype(np.float64)))
+    hs = np.array([c[0] for c in cases], dtype=np.int32)
+    ws = np.array([c[1] for c in cases], dtype=np.int32)
+    lines = np.stack([c[2] for c in cases])
+    traces = []
+    for h, w, line in cases:
+        canvas = np.zeros((h, w), dtype=np.float64)
+        ref.line_signed_coverage(canvas, line)
+        traces.append(canvas.ravel())
+    offs = np.cumsum([0] + [t.size for t in traces]).astype(np.int64)
+    save("coverage_kat.npz", h=hs, w=ws, lines=lines, trace=np.concatenate(traces), trace_off=offs)
+
+
+# --------------------------------------------------------------------------------------
+# B. flatten known-answer tests
+# --------------------------------------------------------------------------------------
+def gather_defs(ref, path):
+    """lines_defs / cubics_defs exactly as Path.mask collects them (S:930-945)."""
+    lines, cubics = [], []
+    for sub in path.subpaths:
+        for seg in sub:
+            if seg[0] in ref.PATH_LINES:
+                lines.append(np.asarray(seg[1], dtype=np.float64))
+            elif seg[0] == ref.PATH_CUBIC:
+                cubics.append(np.asarray(seg[1], dtype=np.float64))
+            elif seg[0] == ref.PATH_QUAD:
+                cubics.append(np.asarray(ref.bezier2_to_bezier3(seg[1]), dtype=np.float64))
+            elif seg[0] == ref.PATH_ARC:
+                cubics.extend(np.asarray(ref.arc_to_bezier3(*seg[1]), dtype=np.float64))
+            else:
+                raise ValueError(seg[0])
+    lines = np.array(lines, dtype=np.float64).reshape(-1, 2, 2)
+    cubics = np.array(cubics, dtype=np.float64).reshape(-1, 4, 2)
+    return lines, cubics
+
+
+def gen_flatten(ref, tiger_scene) -> None:
+    rng = np.random.default_rng(0xF1A7)
+    batches = {}
+    batches["rand_small"] = rng.uniform(-20, 60, size=(64, 4, 2))
+    batches["rand_big"] = rng.uniform(-200, 4200, size=(48, 4, 2))
+    wiggle = rng.uniform(0, 512, size=(32, 1, 2)) + rng.normal(0, 3.0, size=(32, 4, 2))
+    batches["tiny_curves"] = wiggle
+    deg = rng.uniform(0, 300, size=(16, 4, 2))
+    deg[:8, 1] = deg[:8, 0]
+    deg[:8, 2] = deg[:8, 3]  # straight lines as cubics
+    deg[8:12, 3] = deg[8:12, 0]  # closed loop cubic
+    deg[12:] = deg[12:, :1]  # all four points equal
+    batches["degenerate"] = deg
+    # real data: first cubics of the tiger at 512 px
+    real = []
+
+    def walk(scene, tr):
+        t, a = scene
+        if t == ref.RENDER_FILL:
+            _l, c = gather_defs(ref, a[0])
+            if len(c):
+                real.append(tr(c))
+        elif t == ref.RENDER_GROUP:
+            for ch in a:
+                walk(ch, tr)
+        elif t == ref.RENDER_TRANSFORM:
+            walk(a[0], tr @ a[1])
+        elif t == ref.RENDER_STROKE:
+            pass
+        else:
+            walk(a[0], tr)
+
+    walk(tiger_scene, ref.Transform().matrix(0, 1, 0, 1, 0, 0).scale(0.25))
+    batches["tiger512"] = np.concatenate(real)[:600]
+    out = {}
+    for name, batch in batches.items():
+        batch = np.ascontiguousarray(batch, dtype=np.float64)
+        out[name + "_in"] = batch
+        out[name + "_flatness"] = ref.bezier3_flatness_batch(batch)
+        out[name + "_split"] = ref.bezier3_split_batch(batch)
+        out[name + "_edges"] = ref.bezier3_flatten_batch(batch, 0.1)
+    # Transform.__call__ vectors
+    ms, pts, res = [], [], []
+    for _ in range(32):
+        m = np.eye(3)
+        m[:2, :] = rng.uniform(-3, 3, size=(2, 3))
+        p = rng.uniform(-700, 700, size=(9, 4, 2))
+        ms.append(m)
+        pts.append(p)
+        res.append(ref.Transform(m)(p))
+    out["tr_m"] = np.stack(ms)
+    out["tr_in"] = np.stack(pts)
+    out["tr_out"] = np.stack(res)
+    # Transform composition (3x3 matmul chain)
+    a = ref.Transform().matrix(0, 1, 0, 1, 0, 0).scale(1.7, 0.6).rotate(0.4).translate(3.5, -2.25).skew(0.1, -0.2)
+    out["tr_chain"] = a.m
+    out["tr_chain_inv"] = a.invert.m
+    save("flatten_kat.npz", **out)
+
+
+# --------------------------------------------------------------------------------------
+# C. Path.mask / Path.fill known-answer tests
+# --------------------------------------------------------------------------------------
+def gen_mask(ref) -> None:
+    rng = np.random.default_rng(0xA5C)
+    swap = ref.Transform().matrix(0, 1, 0, 1, 0, 0)
+    cases = []
+
+    def add(name, d, tr=swap, rule=None, viewport=None, paint=None, linear_rgb=True):
+        cases.append(dict(name=name, d=d, tr=tr, rule=rule, viewport=viewport, paint=paint, linear_rgb=linear_rgb))
+
+    add("tri", "M1,1 L5,1 L3,4 Z")
+    add("nested_nonzero", "M1,1 H7 V7 H1 Z M3,3 H5 V5 H3 Z")
+    add("nested_evenodd", "M1,1 H7 V7 H1 Z M3,3 H5 V5 H3 Z", rule="evenodd")
+    add("nested_cw_ccw", "M1,1 H7 V7 H1 Z M3,3 V5 H5 V3 Z")
+    add("clip_topleft", "M-3,-3 H4 V4 H-3 Z", viewport=[0, 0, 8, 8])
+    add("clip_all_sides", "M-3,-3 H14 V12 H-3 Z", viewport=[2, 1, 6, 7])
+    add("clip_empty", "M1,1 H4 V4 H1 Z", viewport=[10, 10, 5, 5])
+    add("unclosed", "M2,2 L9,3 L4,8")
+    add("quad", "M2,2 Q12,1 10,10 T3,12 Z", tr=swap.scale(1.5))
+    add("cubic_blob", "M10,30 C10,5 40,5 40,30 S70,55 40,60 C20,62 10,50 10,30 Z", tr=swap.scale(0.8).translate(3.3, 1.7))
+    add("arc_circle", "M20,5 A15,15 0 1 1 19.99,5 Z", tr=swap)
+    add("arc_ellipse_rot", "M10,20 A18,9 30 0 1 40,25 L25,40 Z", tr=swap.scale(1.2))
+    add("star_nonzero", "M30,2 L47,56 L2,22 L58,22 L13,56 Z")
+    add("star_evenodd", "M30,2 L47,56 L2,22 L58,22 L13,56 Z", rule="evenodd")
+    add("rot_rect", "M5,5 H40 V25 H5 Z", tr=swap.rotate(0.4).translate(10, 2))
+    add("solid_srgb", "M2,2 C30,-5 40,20 20,30 S-5,20 2,2 Z", paint=np.array([0.2, 0.4, 0.1, 0.5]), linear_rgb=False)
+    add("solid_linear", "M2,2 C30,-5 40,20 20,30 S-5,20 2,2 Z", paint=np.array([0.2, 0.4, 0.1, 0.5]), linear_rgb=True)
+    add("solid_opaque_srgb", "M1,1 H20 V13 H1 Z", paint=np.array([0.001, 0.5, 1.0, 1.0]), linear_rgb=False)
+    add("tiny", "M3.2,3.2 L3.3,3.2 L3.3,3.4 Z")
+    add("hline_only", "M1,1 H9")
+    add("big_coords_clip", "M-500,-300 C2000,-400 900,1800 -200,900 Z", viewport=[16, 16, 48, 40])
+    for i in range(12):
+        k = int(rng.integers(3, 7))
+        pts = rng.uniform(0, 64, size=(k, 3, 2))
+        d = "M{:.3f},{:.3f} ".format(*pts[0, 0])
+        for j in range(k):
+            c0, c1, p = pts[j]
+            d += "C{:.3f},{:.3f} {:.3f},{:.3f} {:.3f},{:.3f} ".format(*c0, *c1, *(pts[(j + 1) % k, 0]))
+        d += "Z"
+        vp = None
+        if i % 3 == 1:
+            vp = [int(rng.integers(0, 20)), int(rng.integers(0, 20)), int(rng.integers(8, 40)), int(rng.integers(8, 40))]
+        paint = np.concatenate([rng.uniform(0, 1, 3), [1.0]]) * rng.uniform(0.2, 1.0) if i % 2 else None
+        add(f"rand{i}", d, rule="evenodd" if i % 4 == 3 else None, viewport=vp, paint=paint, linear_rgb=bool(i % 4 == 1))
+
+    out = {}
+    meta = []
+    for idx, c in enumerate(cases):
+        path = ref.Path.from_svg(c["d"])
+        lines, cubics = gather_defs(ref, path)
+        if c["paint"] is None:
+            res = path.mask(c["tr"], fill_rule=c["rule"], viewport=c["viewport"])
+        else:
+            res = path.fill(c["tr"], c["paint"], fill_rule=c["rule"], viewport=c["viewport"], linear_rgb=c["linear_rgb"])
+        m = dict(
+            name=c["name"], d=c["d"], rule=c["rule"], viewport=c["viewport"], linear_rgb=c["linear_rgb"],
+            has_paint=c["paint"] is not None, none=res is None,
+        )
+        out[f"{idx}_tr"] = c["tr"].m
+        out[f"{idx}_lines"] = lines
+        out[f"{idx}_cubics"] = cubics
+        # segment list (type, points) so the host Path can be built without an SVG parser
+        segt, segp, subs = [], [], []
+        for sub in path.subpaths:
+            subs.append(len(sub))
+            for seg in sub:
+                segt.append(seg[0])
+                if seg[0] == ref.PATH_ARC:
+                    center, rx, ry, phi, eta, eta_delta = seg[1]
+                    segp.append(np.array([center[0], center[1], rx, ry, phi, eta, eta_delta, 0.0]))
+                else:
+                    p = np.asarray(seg[1], dtype=np.float64).ravel()
+                    segp.append(np.concatenate([p, np.zeros(8 - p.size)]))
+        out[f"{idx}_segt"] = np.array(segt, dtype=np.int32)
+        out[f"{idx}_segp"] = np.array(segp, dtype=np.float64).reshape(-1, 8)
+        out[f"{idx}_subs"] = np.array(subs, dtype=np.int32)
+        if c["paint"] is not None:
+            out[f"{idx}_paint"] = c["paint"]
+        if res is not None:
+            layer, hull = res
+            m["offset"] = [int(layer.offset[0]), int(layer.offset[1])]
+            m["pre_alpha"] = bool(layer.pre_alpha)
+            m["layer_linear_rgb"] = bool(layer.linear_rgb)
+            out[f"{idx}_image"] = layer.image
+            out[f"{idx}_hull"] = np.array(hull.points, dtype=np.float64)
+        meta.append(m)
+    out["meta"] = np.array(json.dumps(meta))
+    save("mask_kat.npz", **out)
+
+
+# --------------------------------------------------------------------------------------
+# D. Layer.compose / convert / opacity
+# --------------------------------------------------------------------------------------
+def gen_compose(ref) -> None:
+    rng = np.random.default_rng(0xC0A1)
+    out = {}
+    meta = []
+
+    def rnd_layer(ch, pre_alpha=True, linear_rgb=False):
+        r, c = int(rng.integers(3, 14)), int(rng.integers(3, 14))
+        if ch == 1:
+            img = rng.uniform(0, 1, size=(r, c, 1))
+            img[rng.uniform(size=img.shape) < 0.3] = 0.0
+            img[rng.uniform(size=img.shape) < 0.2] = 1.0
+        else:
+            a = rng.uniform(0, 1, size=(r, c, 1))
+            a[rng.uniform(size=a.shape) < 0.25] = 0.0
+            a[rng.uniform(size=a.shape) < 0.25] = 1.0
+            rgb = rng.uniform(0, 1, size=(r, c, 3))
+            img = np.concatenate([rgb * a if pre_alpha else rgb, a], axis=-1)
+        off = (int(rng.integers(-6, 10)), int(rng.integers(-6, 10)))
+        return ref.Layer(img, off, pre_alpha, linear_rgb)
+
+    def record(tag, layers, result, **kw):
+        idx = len(meta)
+        m = dict(tag=tag, n=len(layers), none=result is None, **kw)
+        m["in"] = [dict(offset=list(map(int, l.offset)), pre_alpha=bool(l.pre_alpha), linear_rgb=bool(l.linear_rgb)) for l in layers]
+        for j, l in enumerate(layers):
+            out[f"{idx}_in{j}"] = l.image
+        if result is not None:
+            m["offset"] = list(map(int, result.offset))
+            m["pre_alpha"] = bool(result.pre_alpha)
+            m["linear_rgb"] = bool(result.linear_rgb)
+            out[f"{idx}_out"] = result.image
+        meta.append(m)
+
+    for trial in range(10):
+        n = int(rng.integers(2, 6))
+        layers = [rnd_layer(4 if rng.uniform() < 0.8 else 1) for _ in range(n)]
+        record("over", layers, ref.Layer.compose(layers, ref.COMPOSE_OVER, False), method=0, linear_rgb=False)
+    for trial in range(6):  # mixed colour spaces: forces convert()
+        layers = [rnd_layer(4, pre_alpha=bool(rng.integers(0, 2)), linear_rgb=bool(rng.integers(0, 2))) for _ in range(3)]
+        lin = bool(trial % 2)
+        record("over_convert", layers, ref.Layer.compose(layers, ref.COMPOSE_OVER, lin), method=0, linear_rgb=lin)
+    for trial in range(10):
+        mask = rnd_layer(1, True, True)
+        img = rnd_layer(4)
+        layers = [mask, img]
+        record("in", layers, ref.Layer.compose(layers, ref.COMPOSE_IN, False), method=2, linear_rgb=False)
+    # disjoint IN -> None
+    a = ref.Layer(np.ones((3, 3, 1)), (0, 0), True, True)
+    b = ref.Layer(np.ones((3, 3, 4)), (10, 10), True, False)
+    record("in_empty", [a, b], ref.Layer.compose([a, b], ref.COMPOSE_IN, False), method=2, linear_rgb=False)
+    for method in (ref.COMPOSE_OUT, ref.COMPOSE_ATOP, ref.COMPOSE_XOR):
+        layers = [rnd_layer(4), rnd_layer(4)]
+        record("full", layers, ref.Layer.compose(layers, method, False), method=int(method), linear_rgb=False)
+    for trial in range(6):
+        l = rnd_layer(4, pre_alpha=bool(trial % 2), linear_rgb=bool((trial // 2) % 2))
+        record("convert", [l], l.convert(pre_alpha=bool((trial + 1) % 2), linear_rgb=bool(trial % 3 == 0)),
+               to_pre_alpha=bool((trial + 1) % 2), to_linear_rgb=bool(trial % 3 == 0))
+    for trial in range(4):
+        l = rnd_layer(4, pre_alpha=bool(trial % 2), linear_rgb=False)
+        record("opacity", [l], l.opacity(0.37 + 0.1 * trial, linear_rgb=bool(trial // 2)), opacity=0.37 + 0.1 * trial,
+               linear_rgb=bool(trial // 2))
+    out["meta"] = np.array(json.dumps(meta))
+    save("compose_kat.npz", **out)
+
+
+# --------------------------------------------------------------------------------------
+# E. scene dumps + golden renders
+# --------------------------------------------------------------------------------------
+class Dumper:
+    """Serialise a reference Scene into plain data (tree JSON + geometry arrays).
+
+    STROKE nodes are stored as FILL nodes of the reference-stroked path (the stroker is
+    out of scope; ``path.stroke`` runs before the transform, S:668, so it is
+    resolution independent)."""
+
+    def __init__(self, ref):
+        self.ref = ref
+        self.lines, self.cubics = [], []
+        self.loff, self.coff = [0], [0]
+        self.unsupported = set()
+
+    def add_path(self, path) -> int:
+        l, c = gather_defs(self.ref, path)
+        self.lines.append(l)
+        self.cubics.append(c)
+        self.loff.append(self.loff[-1] + len(l))
+        self.coff.append(self.coff[-1] + len(c))
+        return len(self.loff) - 2
+
+    def paint(self, p):
+        ref = self.ref
+        if p is None:
+            return None
+        if isinstance(p, np.ndarray):
+            return dict(k="rgba", v=[float(x) for x in p])
+        if isinstance(p, ref.GradLinear):
+            return dict(k="linear", p0=[float(x) for x in p.p0], p1=[float(x) for x in p.p1],
+                        stops=[[float(o), [float(x) for x in c]] for o, c in p.stops],
+                        tr=None if p.transform is None else [float(x) for x in p.transform.m[:2].ravel()],
+                        spread=p.spread, bbox_units=bool(p.bbox_units), linear_rgb=p.linear_rgb)
+        if isinstance(p, ref.GradRadial):
+            return dict(k="radial", center=None if p.center is None else [float(x) for x in p.center],
+                        radius=None if p.radius is None else float(p.radius),
+                        fcenter=None if p.fcenter is None else [float(x) for x in p.fcenter],
+                        fradius=None if p.fradius is None else float(p.fradius),
+                        stops=[[float(o), [float(x) for x in c]] for o, c in p.stops],
+                        tr=None if p.transform is None else [float(x) for x in p.transform.m[:2].ravel()],
+                        spread=p.spread, bbox_units=bool(p.bbox_units), linear_rgb=p.linear_rgb)
+        self.unsupported.add(type(p).__name__)
+        return dict(k="unsupported", name=type(p).__name__)
+
+    def node(self, scene):
+        ref = self.ref
+        t, a = scene
+        if t == ref.RENDER_FILL:
+            path, paint, rule = a
+            return dict(t="fill", path=self.add_path(path), paint=self.paint(paint), rule=rule)
+        if t == ref.RENDER_STROKE:
+            path, paint, width, cap, join = a
+            return dict(t="fill", path=self.add_path(path.stroke(width, cap, join)), paint=self.paint(paint),
+                        rule=None, from_stroke=True)
+        if t == ref.RENDER_GROUP:
+            return dict(t="group", c=[self.node(ch) for ch in a])
+        if t == ref.RENDER_OPACITY:
+            return dict(t="opacity", c=self.node(a[0]), o=float(a[1]))
+        if t == ref.RENDER_CLIP:
+            return dict(t="clip", c=self.node(a[0]), clip=self.node(a[1]), bbox_units=bool(a[2]))
+        if t == ref.RENDER_MASK:
+            return dict(t="mask", c=self.node(a[0]), mask=self.node(a[1]), bbox_units=bool(a[2]))
+        if t == ref.RENDER_TRANSFORM:
+            return dict(t="transform", c=self.node(a[0]), m=[float(x) for x in a[1].m[:2].ravel()])
+        if t == ref.RENDER_FILTER:
+            self.unsupported.add("filter")
+            return dict(t="filter", c=self.node(a[0]), repr=repr(a[1]))
+        raise ValueError(t)
+
+    def arrays(self):
+        cat = lambda xs, shape: np.concatenate(xs) if xs else np.zeros(shape)
+        return dict(
+            lines=cat(self.lines, (0, 2, 2)), cubics=cat(self.cubics, (0, 4, 2)),
+            line_off=np.array(self.loff, dtype=np.int64), cubic_off=np.array(self.coff, dtype=np.int64),
+        )
+
+
+def leaves_with_transform(ref, scene, tr):
+    """Yield (path-or-stroked-path, paint, rule, accumulated transform) in paint order."""
+    t, a = scene
+    if t == ref.RENDER_FILL:
+        yield a[0], a[1], a[2], tr
+    elif t == ref.RENDER_STROKE:
+        yield a[0].stroke(a[2], a[3], a[4]), a[1], None, tr
+    elif t == ref.RENDER_GROUP:
+        for ch in a:
+            yield from leaves_with_transform(ref, ch, tr)
+    elif t == ref.RENDER_TRANSFORM:
+        yield from leaves_with_transform(ref, a[0], tr @ a[1])
+    else:
+        yield from leaves_with_transform(ref, a[0], tr)
+
+
+def sample_pixels(canvas: np.ndarray, rng, n_edge=12000, n_rand=4000):
+    """Sparse pin of a big render: flat indices of 'interesting' + random pixels and values."""
+    a = canvas[..., 3]
+    frac = (a > 1e-6) & (a < 1 - 1e-6)
+    idx_edge = np.flatnonzero(frac.ravel())
+    if idx_edge.size > n_edge:
+        idx_edge = rng.choice(idx_edge, n_edge, replace=False)
+    idx_rand = rng.integers(0, a.size, n_rand)
+    idx = np.unique(np.concatenate([idx_edge, idx_rand])).astype(np.int64)
+    return idx, canvas.reshape(-1, 4)[idx]
+
+
+def f32_hash(canvas) -> str:
+    return hashlib.sha256(np.ascontiguousarray(canvas, dtype=np.float32).tobytes()).hexdigest()
+
+
+def gen_scene(ref, fonts, name, svg, width, small_scales, full, crop=None) -> None:
+    print(f"scene {name} ({svg} @ {width})")
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    scene, _ids, size = ref.svg_scene_from_filepath(os.path.join(DEMO, svg), width=width, fonts=fonts)
+    w, h = size
+    d = Dumper(ref)
+    tree = d.node(scene)
+    out = d.arrays()
+    out["tree"] = np.array(json.dumps(tree))
+    info = dict(name=name, svg=svg, width=width, size=[int(h), int(w)], unsupported=sorted(d.unsupported), renders=[])
+    swap = ref.Transform().matrix(0, 1, 0, 1, 0, 0)
+    for scale in small_scales:
+        tr = swap.scale(scale)
+        hh, ww = int(h * scale), int(w * scale)
+        res = scene.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
+        layer, hull = res
+        canvas = np.zeros((hh, ww, 4))
+        cl = layer.convert(pre_alpha=True, linear_rgb=False)
+        ref.canvas_merge_at(canvas, cl.image, cl.offset)
+        tag = f"s{hh}"
+        out[f"{tag}_canvas"] = canvas
+        out[f"{tag}_layer"] = layer.image
+        info["renders"].append(dict(tag=tag, scale=scale, size=[hh, ww], layer_offset=list(map(int, layer.offset)),
+                                    layer_pre_alpha=bool(layer.pre_alpha), layer_linear_rgb=bool(layer.linear_rgb),
+                                    sha256_f32=f32_hash(canvas)))
+        # per-leaf integer bboxes (solid scenes only: plain group/transform nesting)
+        if not d.unsupported and name == "tiger":
+            boxes = []
+            for path, paint, rule, ltr in leaves_with_transform(ref, scene, tr):
+                r = path.fill(ltr, paint, fill_rule=rule, viewport=[0, 0, hh, ww], linear_rgb=False)
+                boxes.append([-1, -1, -1, -1] if r is None else [int(v) for v in r[0].bbox])
+            out[f"{tag}_leaf_bbox"] = np.array(boxes, dtype=np.int64)
+    if crop is not None:
+        # full-resolution crop through the reference's own viewport mechanism (S:968-971)
+        res = scene.render(swap, viewport=list(crop), linear_rgb=False)
+        if res is not None:
+            layer, _ = res
+            out["crop_layer"] = layer.image
+            info["crop"] = dict(viewport=list(crop), offset=list(map(int, layer.offset)))
+    if full:
+        res = scene.render(swap, viewport=[0, 0, int(h), int(w)], linear_rgb=False)
+        layer, _ = res
+        canvas = np.zeros((int(h), int(w), 4))
+        cl = layer.convert(pre_alpha=True, linear_rgb=False)
+        ref.canvas_merge_at(canvas, cl.image, cl.offset)
+        idx, vals = sample_pixels(canvas, rng)
+        out["full_idx"] = idx
+        out["full_val"] = vals
+        info["full"] = dict(size=[int(h), int(w)], sha256_f32=f32_hash(canvas), layer_offset=list(map(int, layer.offset)),
+                            layer_shape=list(layer.image.shape))
+        print("   full sha256[:16] =", info["full"]["sha256_f32"][:16])
+    out["info"] = np.array(json.dumps(info))
+    save(f"scene_{name}.npz", **out)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true", help="also render the full-size configs (slow)")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    ref = ref_loader.load()
+    fonts = ref.FontsDB()
+    fonts.register_file(ref.DEFAULT_FONTS)
+    todo = lambda k: args.only is None or args.only == k
+    if todo("coverage"):
+        gen_coverage(ref)
+    if todo("flatten"):
+        tiger, _, _ = ref.svg_scene_from_filepath(os.path.join(DEMO, "icons/tiger.svg"), width=2048, fonts=fonts)
+        gen_flatten(ref, tiger)
+    if todo("mask"):
+        gen_mask(ref)
+    if todo("compose"):
+        gen_compose(ref)
+    if todo("tiger"):
+        gen_scene(ref, fonts, "tiger", "icons/tiger.svg", 2048, [1 / 16, 1 / 8], args.full, crop=[900, 700, 96, 128])
+    if todo("material"):
+        gen_scene(ref, fonts, "material", "material-design.svg", 4096, [1 / 16], args.full, crop=[1000, 1000, 160, 192])
+    if todo("icons"):
+        gen_scene(ref, fonts, "icons", "icons.svg", None, [], False)
+    if todo("prompt"):
+        gen_scene(ref, fonts, "prompt", "prompt.svg", 256, [1.0], False)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,47 @@
+"""Shared helpers for the parity tests."""
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def meta(npz, key="meta"):
+    return json.loads(str(npz[key]))
+
+
+def ulp_f32(ref64):
+    """Size of one float32 ULP at float32(ref)."""
+    r = np.abs(np.asarray(ref64, dtype=np.float32))
+    return (np.nextafter(r, np.float32(np.inf)) - r).astype(np.float64)
+
+
+def assert_f32_1ulp(got, ref64, what=""):
+    """The north-star contract: float32 result within 1 ULP of float32(reference f64),
+    with an absolute floor of 2**-24 (ULPs are meaningless next to the 1e-6 -> 0 cut)."""
+    got = np.asarray(got, dtype=np.float64)
+    ref32 = np.asarray(ref64, dtype=np.float32).astype(np.float64)
+    assert got.shape == ref32.shape, f"{what}: shape {got.shape} != {ref32.shape}"
+    tol = np.maximum(ulp_f32(ref64), 2.0 ** -24)
+    err = np.abs(got - ref32)
+    bad = err > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} values beyond 1 ULP(f32); max abs err {err.max():.3e}"
+
+
+def assert_close64(got, ref, atol=1e-12, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} != {ref.shape}"
+    err = np.abs(got - ref)
+    assert err.max(initial=0.0) <= atol, f"{what}: max abs err {err.max():.3e} > {atol}"
+
+
+def sort_edges(e):
+    e = np.asarray(e, dtype=np.float64).reshape(-1, 4)
+    return e[np.lexsort(e.T[::-1])]
