@@ -1,0 +1,185 @@
+/*
+ * svgr.h -- C ABI of libsvgr_hip.so, the MI355X (gfx950) anti-aliased path rasterizer.
+ *
+ * The reference (aslpavel/svgrasterize.py) has no FFI layer: its boundary for this path is three
+ * Python call signatures plus the Layer value type.  Each entry point below names the
+ * reference interface it stands behind ("S:n" = svgrasterize.py line n).  The Python host classes in
+ * svgrasterize.py_amd/ bind these with ctypes; INTEGRATION.md shows the stub a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative svgr_status; svgr_last_error() gives the text
+ *     (thread local).  No C++ exception crosses the boundary.
+ *   - plain pointers and sizes only.  Host pointers are caller-owned; device memory is an opaque
+ *     svgr_buf handle (or a raw device pointer wrapped with svgr_buf_wrap, e.g. torch's data_ptr()).
+ *   - one svgr_ctx per device; calls on one context are serialised by the caller; all kernels of a
+ *     context run on its HIP stream; functions that return host-visible data synchronise that stream.
+ *   - coordinates follow the reference: a point is (row, col) in presentation space; a bbox /
+ *     viewport is {row0, col0, rows, cols} (S:88-89, S:966-975).
+ *   - all pixel arithmetic is IEEE double with the reference's operation order; the canvas can be
+ *     stored as float32 (the contract of BASELINE.json: within 1 ULP of float32(reference)) or double.
+ */
+#ifndef SVGR_H
+#define SVGR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVGR_ABI_VERSION 1
+
+typedef enum {
+    SVGR_OK = 0,
+    SVGR_E_INVALID = -1,   /* bad argument (reference raises ValueError, S:945, S:989, S:298) */
+    SVGR_E_HIP = -2,       /* HIP runtime error */
+    SVGR_E_NOMEM = -3,
+    SVGR_E_NODEVICE = -4,  /* no gfx950 device visible */
+    SVGR_E_OVERFLOW = -5,  /* internal capacity exceeded (re-plan) or flatten depth cap hit */
+    SVGR_E_STATE = -6      /* call order (render before plan, ...) */
+} svgr_status;
+
+typedef struct svgr_ctx svgr_ctx;
+typedef struct svgr_buf svgr_buf;
+typedef struct svgr_batch svgr_batch;
+
+/* segment kinds in svgr_batch_desc.seg_kind */
+#define SVGR_SEG_LINE 0   /* PATH_LINE / PATH_CLOSED / PATH_UNCLOSED (S:865-873): 2 points */
+#define SVGR_SEG_CUBIC 1  /* PATH_CUBIC, and PATH_QUAD / PATH_ARC after host conversion: 4 points */
+
+/* fill rules (S:874-875, S:984-989) */
+#define SVGR_FILL_NONZERO 0
+#define SVGR_FILL_EVENODD 1
+
+/* output kinds of svgr_batch_render */
+#define SVGR_OUT_CANVAS_F32 0  /* (rows, cols, 4) float32, all paths composited OVER in paint order */
+#define SVGR_OUT_CANVAS_F64 1  /* same in double (Layer.image dtype of the reference, S:42) */
+#define SVGR_OUT_MASK_F64 2    /* single path: (rows, cols) double coverage = Path.mask().image[..., 0] */
+#define SVGR_OUT_FILL_F64 3    /* single path: (rows, cols, 4) double = mask * paint (S:1019) */
+
+/* flags of svgr_batch_render */
+#define SVGR_RENDER_CLIP01 1u  /* clip RGBA to [0, 1] on store (canvas_merge_at, S:326) */
+#define SVGR_RENDER_TIMED 2u   /* bracket the stages with HIP events (svgr_batch_timings) */
+
+/* -------------------------------------------------------------------------------------------- */
+/* context + device memory                                                                      */
+/* -------------------------------------------------------------------------------------------- */
+int svgr_abi_version(void);
+const char* svgr_last_error(void);
+int svgr_device_count(void);
+
+int svgr_init(int device_id, svgr_ctx** out);
+int svgr_shutdown(svgr_ctx* ctx);
+/* run the context's kernels on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
+int svgr_set_stream(svgr_ctx* ctx, void* hip_stream);
+int svgr_sync(svgr_ctx* ctx);
+int svgr_device_name(svgr_ctx* ctx, char* out, size_t cap);
+
+int svgr_buf_alloc(svgr_ctx* ctx, size_t bytes, svgr_buf** out);
+int svgr_buf_wrap(svgr_ctx* ctx, void* device_ptr, size_t bytes, svgr_buf** out); /* non-owning */
+int svgr_buf_free(svgr_ctx* ctx, svgr_buf* buf);
+void* svgr_buf_ptr(const svgr_buf* buf);
+size_t svgr_buf_bytes(const svgr_buf* buf);
+int svgr_buf_zero(svgr_ctx* ctx, svgr_buf* buf);
+int svgr_buf_copy(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, size_t bytes); /* device to device, async */
+int svgr_upload(svgr_ctx* ctx, svgr_buf* dst, size_t dst_off, const void* host, size_t bytes);
+int svgr_download(svgr_ctx* ctx, const svgr_buf* src, size_t src_off, void* host, size_t bytes); /* syncs */
+
+/* -------------------------------------------------------------------------------------------- */
+/* batched paths -> coverage -> paint -> composite                                              */
+/*                                                                                              */
+/* Stands behind Path.mask (S:922-993), Path.fill solid branch (S:995-1019) and the OVER merge  */
+/* of a group of fills (Layer.compose -> canvas_merge_union(full=False), S:177-207, S:366-377):  */
+/* rendering paths 0..n-1 into the canvas is the same per-pixel operation sequence as composing */
+/* their fill layers in painter's order.                                                        */
+/* -------------------------------------------------------------------------------------------- */
+typedef struct {
+    /* geometry in USER space; the device applies path_m6 in the reference's fma form (S:531-534) */
+    const double* segs;          /* n_segs x 8: 4 points (x, y); lines use the first two          */
+    const uint8_t* seg_kind;     /* n_segs: SVGR_SEG_*                                            */
+    int64_t n_segs;
+    const int64_t* path_seg_off; /* n_paths + 1 offsets into segs, paint order                    */
+    int64_t n_paths;
+    const double* path_m6;       /* n_paths x 6: rows 0-1 of the 3x3 transform {m00,m01,m02,m10,m11,m12} */
+    const uint8_t* path_rule;    /* n_paths: SVGR_FILL_*                                          */
+    const double* path_paint;    /* n_paths x 4 premultiplied RGBA already in the compositing space
+                                    (the host applies S:1015-1018 to the 4-vector), times opacity   */
+    int64_t viewport[4];         /* {row0, col0, rows, cols}; rows <= 0 means "no viewport"
+                                    (only valid for the single-path outputs)                      */
+    double flatness;             /* 0.1 in the reference (S:955)                                   */
+} svgr_batch_desc;
+
+/* copies the description to HBM; nothing is rendered yet */
+int svgr_batch_create(svgr_ctx* ctx, const svgr_batch_desc* desc, svgr_batch** out);
+int svgr_batch_destroy(svgr_batch* batch);
+
+/* replace per-path paints / transforms of an existing batch (same counts) */
+int svgr_batch_set_paints(svgr_batch* batch, const double* path_paint);
+int svgr_batch_set_transforms(svgr_batch* batch, const double* path_m6);
+
+/* Restrict rendering to row bands {band_first + k * band_step} of the viewport (band = 16 rows):
+ * one rank of an N-GPU job owns bands rank, rank+N, ...  Default (0, 1) = all bands.             */
+int svgr_batch_set_bands(svgr_batch* batch, int band_first, int band_step);
+
+/* Geometry pass with host read-backs: flatten, per-path bbox, band binning; sizes every work
+ * buffer.  Must run once before svgr_batch_render and again after geometry/viewport changes.
+ * Synchronises.                                                                                 */
+int svgr_batch_plan(svgr_batch* batch);
+
+typedef struct {
+    int64_t n_edges;        /* flattened edges E                                                 */
+    int64_t path_pixels;    /* P = sum over paths of clipped bbox rows*cols (SURVEY 8d unit)      */
+    int64_t n_band_segs;    /* edge x band records                                               */
+    int64_t n_path_bands;   /* (path, band) pairs                                                */
+    int64_t n_nonempty;     /* paths with a non-empty clipped bbox                                */
+    int64_t bbox_union[4];  /* union of the non-empty bboxes {row0, col0, rows, cols}             */
+    int64_t tile_rows, tile_cols;
+} svgr_batch_stats;
+int svgr_batch_get_stats(const svgr_batch* batch, svgr_batch_stats* out);
+/* per-path clipped integer bbox {row0, col0, rows, cols}; rows <= 0 = empty (Path.mask -> None) */
+int svgr_batch_get_bboxes(const svgr_batch* batch, int32_t* out /* n_paths x 4 */);
+/* flattened edges in presentation space, (E, 2, 2) doubles, grouped by path; edge_path may be NULL */
+int svgr_batch_get_edges(const svgr_batch* batch, double* edges, int32_t* edge_path, int64_t cap);
+
+/* Full device pipeline, asynchronous on the context stream, no host read-back:
+ * transform+flatten -> bbox -> band binning -> tile kernel (LDS delta-coverage scatter, row scan,
+ * fill rule, paint, source-over) -> store.  `out` must hold the output kind's bytes:
+ *   canvas kinds: owned_rows x viewport cols x 4 (owned_rows = all rows unless bands are restricted,
+ *   then the owned bands packed in order); single-path kinds: bbox rows x cols (x 4).            */
+int svgr_batch_render(svgr_batch* batch, svgr_buf* out, int out_kind, unsigned flags);
+int64_t svgr_batch_owned_rows(const svgr_batch* batch);
+
+/* HIP-event timings accumulated over the SVGR_RENDER_TIMED renders since the last call
+ * (synchronises).  ms_geometry = transform/flatten/bbox/binning kernels, ms_tile = the tile
+ * kernel (the coverage+composite pass).                                                         */
+int svgr_batch_timings(svgr_batch* batch, int* n_renders, double* ms_total, double* ms_geometry, double* ms_tile);
+
+/* -------------------------------------------------------------------------------------------- */
+/* Layer operations on double device images (Layer.image stays in HBM until read)               */
+/* bbox arguments are {row0, col0, rows, cols}; images are (rows, cols, channels) row-major      */
+/* -------------------------------------------------------------------------------------------- */
+/* canvas_merge_union(full=False) step, S:366-377 + S:286: dst(4ch) = src + dst*(1-src_a) on the
+ * overlap; `first` copies instead (S:374-375).  src_channels 1 broadcasts (S:283-286).          */
+int svgr_layer_over(svgr_ctx* ctx, svgr_buf* dst, const int64_t* dst_bbox, const svgr_buf* src,
+                    const int64_t* src_bbox, int src_channels, int first);
+/* canvas_merge_intersect, S:382-416: `out` (4ch, bbox = intersection) initialised from `first`
+ * (1ch broadcast or 4ch crop), then svgr_layer_in multiplies: out = src * out_alpha (S:290).    */
+int svgr_layer_crop4(svgr_ctx* ctx, svgr_buf* out, const int64_t* out_bbox, const svgr_buf* first,
+                     const int64_t* first_bbox, int first_channels);
+int svgr_layer_in(svgr_ctx* ctx, svgr_buf* out, const int64_t* out_bbox, const svgr_buf* src,
+                  const int64_t* src_bbox, int src_channels);
+/* Layer.opacity, S:171-175: image * opacity */
+int svgr_layer_scale(svgr_ctx* ctx, svgr_buf* img, int64_t n_values, double factor);
+/* Layer.convert, S:129-164 + S:471-503, in place on n_px RGBA pixels.
+ * ops bitmask applied in this order: 1 = premultiplied->straight, 2 = sRGB->linear,
+ * 4 = linear->sRGB, 8 = straight->premultiplied                                                */
+int svgr_layer_convert(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, unsigned ops);
+/* float64 -> float32 (optionally clipping to [0,1]) for presentation */
+int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst_f32, const svgr_buf* src_f64, int64_t n_values, int clip01);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVGR_H */

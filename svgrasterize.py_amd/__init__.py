@@ -1,0 +1,23 @@
+"""svgrasterize.py_amd -- MI355X-native anti-aliased path coverage + paint + compositing behind
+the Scene / Path / Transform / Layer API of aslpavel/svgrasterize.py.
+
+Import as ``svgrasterize_amd`` (alias module at the repository root).  Every pixel operation
+runs in hand-written HIP kernels (csrc/svgr_hip.hip) called through the C ABI in include/svgr.h;
+there is no CPU fallback.
+"""
+from ._abi import Context, SvgrError, load_library  # noqa: F401
+from .geometry import (  # noqa: F401
+    ConvexHull, Path, Transform,
+    PATH_LINE, PATH_QUAD, PATH_CUBIC, PATH_ARC, PATH_CLOSED, PATH_UNCLOSED,
+    PATH_FILL_NONZERO, PATH_FILL_EVENODD,
+)
+from .layer import (  # noqa: F401
+    Layer, COMPOSE_OVER, COMPOSE_OUT, COMPOSE_IN, COMPOSE_ATOP, COMPOSE_XOR,
+)
+from .paint import GradLinear, GradRadial  # noqa: F401
+from .scene import (  # noqa: F401
+    Scene, render_canvas, build_batch,
+    RENDER_FILL, RENDER_STROKE, RENDER_GROUP, RENDER_OPACITY, RENDER_CLIP, RENDER_MASK, RENDER_TRANSFORM, RENDER_FILTER,
+)
+
+__all__ = ["Scene", "Path", "Transform", "Layer", "ConvexHull", "render_canvas"]

@@ -1,0 +1,281 @@
+"""ctypes binding of libsvgr_hip.so (include/svgr.h).
+
+There is deliberately no fallback: if the HIP library is missing or no gfx950 device is
+visible, every entry point raises.  The only thing that works without a GPU is loading the
+library and inspecting its symbols (used by the CPU-side ABI test).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+import weakref
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libsvgr_hip.so")
+
+OUT_CANVAS_F32, OUT_CANVAS_F64, OUT_MASK_F64, OUT_FILL_F64 = 0, 1, 2, 3
+RENDER_CLIP01, RENDER_TIMED = 1, 2
+SEG_LINE, SEG_CUBIC = 0, 1
+TILE_ROWS = 16
+
+CONVERT_PRE_TO_STRAIGHT, CONVERT_SRGB_TO_LINEAR, CONVERT_LINEAR_TO_SRGB, CONVERT_STRAIGHT_TO_PRE = 1, 2, 4, 8
+
+
+class SvgrError(RuntimeError):
+    """Raised for every non-zero status of the C ABI except SVGR_E_INVALID (-> ValueError)."""
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [
+        ("segs", C.c_void_p), ("seg_kind", C.c_void_p), ("n_segs", C.c_int64),
+        ("path_seg_off", C.c_void_p), ("n_paths", C.c_int64),
+        ("path_m6", C.c_void_p), ("path_rule", C.c_void_p), ("path_paint", C.c_void_p),
+        ("viewport", C.c_int64 * 4), ("flatness", C.c_double),
+    ]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [
+        ("n_edges", C.c_int64), ("path_pixels", C.c_int64), ("n_band_segs", C.c_int64),
+        ("n_path_bands", C.c_int64), ("n_nonempty", C.c_int64), ("bbox_union", C.c_int64 * 4),
+        ("tile_rows", C.c_int64), ("tile_cols", C.c_int64),
+    ]
+
+
+_P = C.c_void_p
+_PROTOS = {
+    "svgr_abi_version": (C.c_int, []),
+    "svgr_last_error": (C.c_char_p, []),
+    "svgr_device_count": (C.c_int, []),
+    "svgr_init": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "svgr_shutdown": (C.c_int, [_P]),
+    "svgr_set_stream": (C.c_int, [_P, _P]),
+    "svgr_sync": (C.c_int, [_P]),
+    "svgr_device_name": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
+    "svgr_buf_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "svgr_buf_wrap": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(_P)]),
+    "svgr_buf_free": (C.c_int, [_P, _P]),
+    "svgr_buf_ptr": (_P, [_P]),
+    "svgr_buf_bytes": (C.c_size_t, [_P]),
+    "svgr_buf_zero": (C.c_int, [_P, _P]),
+    "svgr_buf_copy": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "svgr_upload": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t]),
+    "svgr_download": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t]),
+    "svgr_batch_create": (C.c_int, [_P, C.POINTER(BatchDesc), C.POINTER(_P)]),
+    "svgr_batch_destroy": (C.c_int, [_P]),
+    "svgr_batch_set_paints": (C.c_int, [_P, _P]),
+    "svgr_batch_set_transforms": (C.c_int, [_P, _P]),
+    "svgr_batch_set_bands": (C.c_int, [_P, C.c_int, C.c_int]),
+    "svgr_batch_plan": (C.c_int, [_P]),
+    "svgr_batch_get_stats": (C.c_int, [_P, C.POINTER(BatchStats)]),
+    "svgr_batch_get_bboxes": (C.c_int, [_P, _P]),
+    "svgr_batch_get_edges": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "svgr_batch_render": (C.c_int, [_P, _P, C.c_int, C.c_uint]),
+    "svgr_batch_owned_rows": (C.c_int64, [_P]),
+    "svgr_batch_timings": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "svgr_layer_over": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int]),
+    "svgr_layer_crop4": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
+    "svgr_layer_in": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
+    "svgr_layer_scale": (C.c_int, [_P, _P, C.c_int64, C.c_double]),
+    "svgr_layer_convert": (C.c_int, [_P, _P, C.c_int64, C.c_uint]),
+    "svgr_layer_to_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int]),
+}
+EXPORTS = tuple(_PROTOS)
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen libsvgr_hip.so and declare prototypes; raises if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise SvgrError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)"
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def _check(rc: int):
+    if rc == 0:
+        return
+    msg = load_library().svgr_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(msg)
+    raise SvgrError(f"svgr status {rc}: {msg}")
+
+
+class Context:
+    """One per device (svgr_ctx)."""
+
+    _by_device: dict[int, "Context"] = {}
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = _P()
+        _check(self.lib.svgr_init(device, C.byref(h)))
+        self.handle = h
+        self.device = device
+        self._fin = weakref.finalize(self, self.lib.svgr_shutdown, h)
+
+    @classmethod
+    def get(cls, device: int | None = None) -> "Context":
+        if device is None:
+            device = int(os.environ.get("SVGR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        ctx = cls._by_device.get(device)
+        if ctx is None:
+            ctx = cls._by_device[device] = Context(device)
+        return ctx
+
+    def name(self) -> str:
+        buf = C.create_string_buffer(160)
+        _check(self.lib.svgr_device_name(self.handle, buf, 160))
+        return buf.value.decode()
+
+    def sync(self):
+        _check(self.lib.svgr_sync(self.handle))
+
+    def set_stream(self, hip_stream: int):
+        _check(self.lib.svgr_set_stream(self.handle, _P(hip_stream)))
+
+    # -- buffers -------------------------------------------------------------------------
+    def alloc(self, nbytes: int) -> "DeviceBuffer":
+        h = _P()
+        _check(self.lib.svgr_buf_alloc(self.handle, nbytes, C.byref(h)))
+        return DeviceBuffer(self, h, nbytes)
+
+    def wrap(self, device_ptr: int, nbytes: int) -> "DeviceBuffer":
+        h = _P()
+        _check(self.lib.svgr_buf_wrap(self.handle, _P(device_ptr), nbytes, C.byref(h)))
+        return DeviceBuffer(self, h, nbytes)
+
+    def from_host(self, arr: np.ndarray) -> "DeviceBuffer":
+        arr = np.ascontiguousarray(arr)
+        buf = self.alloc(arr.nbytes)
+        buf.upload(arr)
+        return buf
+
+
+class DeviceBuffer:
+    def __init__(self, ctx: Context, handle, nbytes: int):
+        self.ctx, self.handle, self.nbytes = ctx, handle, nbytes
+        self._fin = weakref.finalize(self, ctx.lib.svgr_buf_free, ctx.handle, handle)
+
+    @property
+    def ptr(self) -> int:
+        return int(self.ctx.lib.svgr_buf_ptr(self.handle) or 0)
+
+    def zero(self):
+        _check(self.ctx.lib.svgr_buf_zero(self.ctx.handle, self.handle))
+
+    def upload(self, arr: np.ndarray, offset: int = 0):
+        arr = np.ascontiguousarray(arr)
+        _check(self.ctx.lib.svgr_upload(self.ctx.handle, self.handle, offset, arr.ctypes.data_as(_P), arr.nbytes))
+
+    def download(self, shape, dtype, offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        _check(self.ctx.lib.svgr_download(self.ctx.handle, self.handle, offset, out.ctypes.data_as(_P), out.nbytes))
+        return out
+
+    def free(self):
+        self._fin()
+
+
+def _i64x4(v):
+    return (C.c_int64 * 4)(*[int(x) for x in v])
+
+
+class Batch:
+    """svgr_batch: a paint-ordered list of paths resident in HBM."""
+
+    def __init__(self, ctx: Context, segs, seg_kind, path_seg_off, path_m6, path_rule, path_paint,
+                 viewport=None, flatness: float = 0.1):
+        self.ctx = ctx
+        lib = ctx.lib
+        segs = np.ascontiguousarray(segs, dtype=np.float64).reshape(-1, 8)
+        seg_kind = np.ascontiguousarray(seg_kind, dtype=np.uint8).reshape(-1)
+        path_seg_off = np.ascontiguousarray(path_seg_off, dtype=np.int64).reshape(-1)
+        n_paths = len(path_seg_off) - 1
+        path_m6 = np.ascontiguousarray(path_m6, dtype=np.float64).reshape(-1, 6)
+        path_rule = np.ascontiguousarray(path_rule, dtype=np.uint8).reshape(-1)
+        path_paint = np.ascontiguousarray(path_paint, dtype=np.float64).reshape(-1, 4)
+        if len(seg_kind) != len(segs) or len(path_m6) != n_paths or len(path_rule) != n_paths or len(path_paint) != n_paths:
+            raise ValueError("inconsistent batch arrays")
+        d = BatchDesc()
+        d.segs = segs.ctypes.data
+        d.seg_kind = seg_kind.ctypes.data
+        d.n_segs = len(segs)
+        d.path_seg_off = path_seg_off.ctypes.data
+        d.n_paths = n_paths
+        d.path_m6 = path_m6.ctypes.data
+        d.path_rule = path_rule.ctypes.data
+        d.path_paint = path_paint.ctypes.data
+        d.viewport = _i64x4(viewport if viewport is not None else (0, 0, 0, 0))
+        d.flatness = flatness
+        h = _P()
+        _check(lib.svgr_batch_create(ctx.handle, C.byref(d), C.byref(h)))
+        self.handle = h
+        self.n_paths = n_paths
+        self.n_segs = len(segs)
+        self._fin = weakref.finalize(self, lib.svgr_batch_destroy, h)
+        self._stats = None
+
+    def destroy(self):
+        self._fin()
+
+    def plan(self) -> "BatchStats":
+        _check(self.ctx.lib.svgr_batch_plan(self.handle))
+        st = BatchStats()
+        _check(self.ctx.lib.svgr_batch_get_stats(self.handle, C.byref(st)))
+        self._stats = st
+        return st
+
+    @property
+    def stats(self) -> BatchStats:
+        if self._stats is None:
+            self.plan()
+        return self._stats
+
+    def bboxes(self) -> np.ndarray:
+        out = np.empty((self.n_paths, 4), dtype=np.int32)
+        _check(self.ctx.lib.svgr_batch_get_bboxes(self.handle, out.ctypes.data_as(_P)))
+        return out
+
+    def edges(self):
+        n = int(self.stats.n_edges)
+        edges = np.empty((n, 2, 2), dtype=np.float64)
+        edge_path = np.empty(n, dtype=np.int32)
+        _check(self.ctx.lib.svgr_batch_get_edges(self.handle, edges.ctypes.data_as(_P), edge_path.ctypes.data_as(_P), n))
+        return edges, edge_path
+
+    def set_bands(self, first: int, step: int):
+        _check(self.ctx.lib.svgr_batch_set_bands(self.handle, first, step))
+
+    def set_paints(self, paints):
+        paints = np.ascontiguousarray(paints, dtype=np.float64).reshape(self.n_paths, 4)
+        _check(self.ctx.lib.svgr_batch_set_paints(self.handle, paints.ctypes.data_as(_P)))
+
+    def owned_rows(self) -> int:
+        return int(self.ctx.lib.svgr_batch_owned_rows(self.handle))
+
+    def render(self, out: DeviceBuffer, kind: int, flags: int = 0):
+        _check(self.ctx.lib.svgr_batch_render(self.handle, out.handle, kind, flags))
+
+    def timings(self):
+        n = C.c_int()
+        tot, geo, tile = C.c_double(), C.c_double(), C.c_double()
+        _check(self.ctx.lib.svgr_batch_timings(self.handle, C.byref(n), C.byref(tot), C.byref(geo), C.byref(tile)))
+        return dict(n=n.value, ms_total=tot.value, ms_geometry=geo.value, ms_tile=tile.value)

@@ -1,0 +1,246 @@
+// svgr_core.h -- per-lane arithmetic of the hot path, shared by every HIP kernel.
+//
+// Everything here is straight-line double arithmetic written so that one lane reproduces
+// what the reference evaluates for one element (S:n = svgrasterize.py line n of the reference):
+//   xform_point      Transform.__call__            S:531-534
+//   cubic_flatness   bezier3_flatness_batch        S:2071-2088
+//   cubic_split      bezier3_split_batch           S:2066-2068
+//   flatten_cubic    bezier3_flatten_batch         S:2091-2098 (depth-first instead of level-synchronous:
+//                                                   same edge SET, curve order instead of level order)
+//   EdgeWalk         line_signed_coverage          S:2213-2304 (row recurrence + per-row area pieces)
+//   fill_rule_*      Path.mask                     S:984-990
+//   over_px          canvas_compose(OVER)          S:286
+// The functions are SVGR_HD so the same code can be compiled for the host by the unit-test
+// harness (tests/host_harness.cpp); the product only ever runs them inside HIP kernels.
+// Compile with -ffp-contract=off: the reference rounds every operation separately except
+// where an explicit fma() below mirrors what BLAS evaluates for np.dot / @.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SVGR_HD __host__ __device__ __forceinline__
+#else
+#define SVGR_HD static inline
+#endif
+
+namespace svgr {
+
+constexpr int kMaxFlattenDepth = 40;   // reference has no cap; finite input never gets close
+constexpr double kZeroCut = 1e-6;      // S:990
+
+// ------------------------------------------------------------------------------------
+// affine transform of one point: out_r = fma(p1, m_r1, p0*m_r0) + b_r     (dgemm form)
+// m6 = {m00, m01, m02, m10, m11, m12}
+// ------------------------------------------------------------------------------------
+SVGR_HD void xform_point(const double* m6, double p0, double p1, double& o0, double& o1) {
+    o0 = fma(p1, m6[1], p0 * m6[0]) + m6[2];
+    o1 = fma(p1, m6[4], p0 * m6[3]) + m6[5];
+}
+
+// strided-ddot form of np.dot(W(k,4), batch(N,4,2)): fma(w0,x0, w2*x2) + fma(w1,x1, w3*x3)
+SVGR_HD double dot4(double w0, double w1, double w2, double w3, double x0, double x1, double x2, double x3) {
+    return fma(w0, x0, w2 * x2) + fma(w1, x1, w3 * x3);
+}
+
+// c = 4 points (row, col) interleaved: c[2*k + axis]
+SVGR_HD double cubic_flatness(const double* c) {
+    // u = -2 b0 + 3 b1 - b3 ; v = -b0 + 3 b2 - 2 b3 ; f = max(ux^2, uy^2) + max(vx^2, vy^2)
+    double ux = dot4(-2.0, 3.0, 0.0, -1.0, c[0], c[2], c[4], c[6]);
+    double uy = dot4(-2.0, 3.0, 0.0, -1.0, c[1], c[3], c[5], c[7]);
+    double vx = dot4(-1.0, 0.0, 3.0, -2.0, c[0], c[2], c[4], c[6]);
+    double vy = dot4(-1.0, 0.0, 3.0, -2.0, c[1], c[3], c[5], c[7]);
+    double uxx = ux * ux, uyy = uy * uy, vxx = vx * vx, vyy = vy * vy;
+    double mu = uxx > uyy ? uxx : uyy;
+    double mv = vxx > vyy ? vxx : vyy;
+    return mu + mv;
+}
+
+// de Casteljau at t = 1/2 with the reference's 8x4 weight matrix; l/r = 4 points each
+SVGR_HD void cubic_split(const double* c, double* l, double* r) {
+    for (int ax = 0; ax < 2; ++ax) {
+        double x0 = c[ax], x1 = c[2 + ax], x2 = c[4 + ax], x3 = c[6 + ax];
+        l[ax] = dot4(1.0, 0.0, 0.0, 0.0, x0, x1, x2, x3);
+        l[2 + ax] = dot4(0.5, 0.5, 0.0, 0.0, x0, x1, x2, x3);
+        l[4 + ax] = dot4(0.25, 0.5, 0.25, 0.0, x0, x1, x2, x3);
+        l[6 + ax] = dot4(0.125, 0.375, 0.375, 0.125, x0, x1, x2, x3);
+        r[ax] = dot4(0.125, 0.375, 0.375, 0.125, x0, x1, x2, x3);
+        r[2 + ax] = dot4(0.0, 0.25, 0.5, 0.25, x0, x1, x2, x3);
+        r[4 + ax] = dot4(0.0, 0.0, 0.5, 0.5, x0, x1, x2, x3);
+        r[6 + ax] = dot4(0.0, 0.0, 0.0, 1.0, x0, x1, x2, x3);
+    }
+}
+
+// Depth-first adaptive subdivision. `emit(p0r, p0c, p1r, p1c)` is called once per flat piece,
+// in curve order. Returns the number of pieces, or -1 when the depth cap was hit (non-finite
+// or absurd input; the reference would never terminate there).
+template <class Emit>
+SVGR_HD int flatten_cubic(const double* cubic, double thr, Emit&& emit) {
+    double stack[kMaxFlattenDepth][8];
+    double cur[8];
+    for (int i = 0; i < 8; ++i) cur[i] = cubic[i];
+    int sp = 0, n = 0;
+    bool overflow = false;
+    for (;;) {
+        bool flat = cubic_flatness(cur) < thr;
+        if (!flat && sp >= kMaxFlattenDepth) { flat = true; overflow = true; }
+        if (flat) {
+            emit(cur[0], cur[1], cur[6], cur[7]);
+            ++n;
+            if (sp == 0) break;
+            --sp;
+            for (int i = 0; i < 8; ++i) cur[i] = stack[sp][i];
+        } else {
+            double l[8];
+            cubic_split(cur, l, stack[sp]);
+            ++sp;
+            for (int i = 0; i < 8; ++i) cur[i] = l[i];
+        }
+    }
+    return overflow ? -1 : n;
+}
+
+// ------------------------------------------------------------------------------------
+// order-preserving double <-> uint64 key (for integer atomicMin / atomicMax on coordinates)
+// ------------------------------------------------------------------------------------
+SVGR_HD uint64_t f64_key(double v) {
+    union { double d; uint64_t u; } x;
+    x.d = v;
+    return (x.u >> 63) ? ~x.u : (x.u | 0x8000000000000000ull);
+}
+SVGR_HD double key_f64(uint64_t k) {
+    union { double d; uint64_t u; } x;
+    x.u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return x.d;
+}
+
+SVGR_HD int clamp_to_int(double v) {
+    v = v < -1.0e9 ? -1.0e9 : (v > 1.0e9 ? 1.0e9 : v);
+    return (int)v;
+}
+
+// ------------------------------------------------------------------------------------
+// One edge of a path, prepared the way line_signed_coverage prepares it (S:2230-2242):
+// coordinates relative to the layer origin, oriented so rows increase.
+// ------------------------------------------------------------------------------------
+struct EdgeSetup {
+    double p0y, p1y, dxdy, x, dir;  // x = column at the first traced row's entry
+    int y_begin, y_end;             // traced rows [y_begin, y_end) (clipped to [0, rows))
+    bool valid;
+};
+
+SVGR_HD EdgeSetup edge_setup(double ar, double ac, double br, double bc, int rows) {
+    EdgeSetup e;
+    e.valid = false;
+    e.p0y = e.p1y = e.dxdy = e.x = 0.0;
+    e.dir = 1.0;
+    e.y_begin = e.y_end = 0;
+    if (ar == br) return e;  // horizontal: no signed coverage
+    double p0y = ar, p0x = ac, p1y = br, p1x = bc;
+    if (!(ar < br)) {
+        e.dir = -1.0;
+        p0y = br; p0x = bc; p1y = ar; p1x = ac;
+    }
+    e.p0y = p0y;
+    e.p1y = p1y;
+    e.dxdy = (p1x - p0x) / (p1y - p0y);
+    e.x = p0x;
+    e.y_begin = clamp_to_int(p0y > 0.0 ? p0y : 0.0);
+    if (p0y < 0.0) e.x -= p0y * e.dxdy;
+    int yend = clamp_to_int(ceil(p1y));
+    e.y_end = yend < rows ? yend : rows;
+    e.valid = e.y_begin < e.y_end;
+    return e;
+}
+
+// Row recurrence (S:2243-2248). After step(y): x/x_next are the columns where the edge enters
+// and leaves row y, d the signed height.
+struct RowState {
+    double x_next;  // carried between rows
+    double x, d;
+};
+
+SVGR_HD void row_step(RowState& s, int y, double p0y, double p1y, double dxdy, double dir) {
+    s.x = s.x_next;
+    double yhi = (double)(y + 1) < p1y ? (double)(y + 1) : p1y;
+    double ylo = (double)y > p0y ? (double)y : p0y;
+    double dy = yhi - ylo;
+    s.d = dir * dy;
+    s.x_next = s.x + dxdy * dy;
+}
+
+// Area pieces of one row (S:2250-2303). `put(xi, v)` receives the UNCLAMPED column index; it
+// returns false to stop the row (the reference `continue`s once a column is >= w).
+template <class Put>
+SVGR_HD void row_pieces(double x, double x_next, double d, Put&& put) {
+    double x0 = x < x_next ? x : x_next;
+    double x1 = x < x_next ? x_next : x;
+    double x0_floor = floor(x0);
+    int x0i = clamp_to_int(x0_floor);
+    double x1_ceil = ceil(x1);
+    int x1i = clamp_to_int(x1_ceil);
+    if (x1i <= x0i + 1) {
+        double xmf = 0.5 * (x + x_next) - x0_floor;
+        if (!put(x0i, d * (1 - xmf))) return;
+        put(x0i + 1, d * xmf);
+    } else {
+        double s = 1 / (x1 - x0);
+        double x0f = x0 - x0_floor;
+        double x1f = x1 - x1_ceil + 1.0;
+        double o = 1 - x0f;
+        double a0 = 0.5 * s * (o * o);
+        double am = 0.5 * s * (x1f * x1f);
+        if (!put(x0i, d * a0)) return;
+        if (x1i == x0i + 2) {
+            if (!put(x0i + 1, d * (1.0 - a0 - am))) return;
+        } else {
+            double a1 = s * (1.5 - x0f);
+            if (!put(x0i + 1, d * (a1 - a0))) return;
+            double ds = d * s;
+            for (int xi = x0i + 2; xi < x1i - 1; ++xi)
+                if (!put(xi, ds)) return;
+            double a2 = a1 + (double)(x1i - x0i - 3) * s;
+            if (!put(x1i - 1, d * (1.0 - a2 - am))) return;
+        }
+        put(x1i, d * am);
+    }
+}
+
+// column span touched by a row, without computing the pieces: [lo, hi] inclusive
+SVGR_HD void row_span(double x, double x_next, int& lo, int& hi) {
+    double x0 = x < x_next ? x : x_next;
+    double x1 = x < x_next ? x_next : x;
+    lo = clamp_to_int(floor(x0));
+    int x1i = clamp_to_int(ceil(x1));
+    hi = (x1i <= lo + 1) ? lo + 1 : x1i;
+}
+
+// ------------------------------------------------------------------------------------
+// fill rules + zero cut (S:984-990)
+// ------------------------------------------------------------------------------------
+SVGR_HD double fill_nonzero(double s) {
+    double m = fabs(s);
+    m = m > 1.0 ? 1.0 : m;
+    return m < kZeroCut ? 0.0 : m;
+}
+SVGR_HD double fill_evenodd(double s) {
+    double a = s + 1.0;
+    double r = fmod(a, 2.0);       // np.remainder(a, 2.0): sign follows the divisor
+    if (r < 0.0) r += 2.0;
+    double m = fabs(r - 1.0);
+    return m < kZeroCut ? 0.0 : m;
+}
+SVGR_HD double fill_rule(double s, int rule) { return rule ? fill_evenodd(s) : fill_nonzero(s); }
+
+// ------------------------------------------------------------------------------------
+// source-over of one premultiplied pixel: dst = src + dst * (1 - src_a)   (S:286)
+// ------------------------------------------------------------------------------------
+SVGR_HD void over_px(double* dst, double s0, double s1, double s2, double s3) {
+    double k = 1 - s3;
+    dst[0] = s0 + dst[0] * k;
+    dst[1] = s1 + dst[1] * k;
+    dst[2] = s2 + dst[2] * k;
+    dst[3] = s3 + dst[3] * k;
+}
+
+}  // namespace svgr

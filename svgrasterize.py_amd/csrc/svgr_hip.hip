@@ -1,0 +1,1364 @@
+// svgr_hip.hip -- MI355X (gfx950 / CDNA4) anti-aliased path rasterizer: HIP kernels + C ABI.
+//
+// Pipeline of one svgr_batch_render (all on the context stream, no host read-back):
+//
+//   k_seg_count     per segment: transform (fma form) + adaptive subdivision, count flat pieces
+//   scan            exclusive prefix of the counts -> edge offsets
+//   k_seg_emit      per segment: subdivide again, store edges, fold endpoints into per-path min/max
+//   k_path_bbox     per path: integer bbox (floor-1 / ceil+1, clipped to the viewport), band range
+//   scan            (path, band) pair offsets
+//   k_edge_count    per edge: how many 16-row bands it crosses -> per (path, band) counts
+//   scan            band-segment offsets
+//   k_edge_emit     per edge: walk its rows with the reference's x recurrence, cut a record at
+//                   every band entry (so a tile never has to replay rows above it)
+//   k_band_entries  per band: ordered list of the paths whose bbox covers it
+//   k_tile_render   one workgroup per 16x128 canvas tile, canvas tile resident in registers as
+//                   double RGBA; per covering path in paint order: scatter the band segments'
+//                   signed-area pieces into an LDS delta tile (ds_add_f64), row prefix sum
+//                   (8 px per lane serial + DPP row scan across the 16 lanes of a row), fill rule,
+//                   paint, source-over; one store of the finished tile (float32 or double)
+//
+// There is no dense contraction anywhere in this path: no MFMA.  The heavy traffic (delta tile,
+// canvas tile) never leaves the CU; HBM sees the edge records and one canvas store.
+//
+// gfx950 only.  Compile with -ffp-contract=off (see svgr_core.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/svgr.h"
+#include "svgr_core.h"
+
+using namespace svgr;
+
+// ======================================================================================
+// tile geometry
+// ======================================================================================
+constexpr int TR = 16;                     // rows per band / tile
+constexpr int TC = 128;                    // columns per tile
+constexpr int PX = 8;                      // pixels per lane (consecutive columns)
+constexpr int CH = TC / PX;                // lanes per row = 16 = one DPP row
+constexpr int NT = TR * CH;                // 256 threads = 4 waves; a wave covers 4 tile rows
+constexpr int CHUNK_STRIDE = PX + 2;       // doubles; +16 B makes the 16-lane b128 groups conflict free
+constexpr int ROW_STRIDE = CH * CHUNK_STRIDE;
+static_assert(CH == 16, "row scan uses one 16-lane DPP row per tile row");
+static_assert(NT == 256, "tile kernel is written for 256 threads");
+
+struct BandSeg {  // one edge inside one band (40 B)
+    double x;     // column where the edge enters row y0 (carried by the reference recurrence)
+    double dxdy, p0y, p1y;
+    int y0;       // first traced row (layer-local)
+    int y1s;      // one past the last traced row in this band; negative => dir = -1
+};
+
+// ======================================================================================
+// errors
+// ======================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(SVGR_E_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct svgr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char name[128] = {0};
+};
+struct svgr_buf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    bool owned = false;
+};
+
+// small RAII-less device array helper (explicit release keeps the ABI exception free)
+template <class T>
+struct DevArr {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 16;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e != hipSuccess) return fail(SVGR_E_NOMEM, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// ======================================================================================
+// exclusive scan of int32 (n small to a few million)
+// ======================================================================================
+constexpr int SCAN_T = 256, SCAN_I = 8, SCAN_B = SCAN_T * SCAN_I;
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_block(const int* __restrict__ in, int* __restrict__ out, int n,
+                                                       int* __restrict__ block_sums) {
+    __shared__ int s_part[SCAN_T];
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * SCAN_B + tid * SCAN_I;
+    int v[SCAN_I];
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i) {
+        v[i] = (base + i < n) ? in[base + i] : 0;
+        sum += v[i];
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < SCAN_T; d <<= 1) {  // Hillis-Steele over the 256 partials
+        int add = (tid >= d) ? s_part[tid - d] : 0;
+        __syncthreads();
+        s_part[tid] += add;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;  // exclusive prefix of this thread
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (tid == SCAN_T - 1 && block_sums) block_sums[blockIdx.x] = s_part[tid];
+}
+
+__global__ void k_scan_add(int* __restrict__ out, int n, const int* __restrict__ block_offs) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += block_offs[i / SCAN_B];
+}
+
+struct Scanner {
+    DevArr<int> l1, l1s, l2, l2s;
+    int run(hipStream_t st, const int* in, int* out, int n) {
+        if (n <= 0) return 0;
+        int nb = (n + SCAN_B - 1) / SCAN_B;
+        if (nb == 1) {
+            hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(SCAN_T), 0, st, in, out, n, (int*)nullptr);
+            return 0;
+        }
+        if (int rc = l1.ensure(nb)) return rc;
+        if (int rc = l1s.ensure(nb)) return rc;
+        hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(SCAN_T), 0, st, in, out, n, l1.p);
+        int nb2 = (nb + SCAN_B - 1) / SCAN_B;
+        if (nb2 == 1) {
+            hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(SCAN_T), 0, st, (const int*)l1.p, l1s.p, nb, (int*)nullptr);
+        } else {
+            if (nb2 > SCAN_B) return fail(SVGR_E_OVERFLOW, "scan of %d elements is beyond three levels", n);
+            if (int rc = l2.ensure(nb2)) return rc;
+            if (int rc = l2s.ensure(nb2)) return rc;
+            hipLaunchKernelGGL(k_scan_block, dim3(nb2), dim3(SCAN_T), 0, st, (const int*)l1.p, l1s.p, nb, l2.p);
+            hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(SCAN_T), 0, st, (const int*)l2.p, l2s.p, nb2, (int*)nullptr);
+            hipLaunchKernelGGL(k_scan_add, dim3((nb + 255) / 256), dim3(256), 0, st, l1s.p, nb, (const int*)l2s.p);
+        }
+        hipLaunchKernelGGL(k_scan_add, dim3((n + 255) / 256), dim3(256), 0, st, out, n, (const int*)l1s.p);
+        return 0;
+    }
+    void release() { l1.release(); l1s.release(); l2.release(); l2s.release(); }
+};
+
+// ======================================================================================
+// geometry kernels
+// ======================================================================================
+// device-side scalars of a batch
+struct BatchDev {
+    int err;            // bit 0: flatten depth cap, bit 1: edge capacity, bit 2: (path,band) capacity,
+                        // bit 3: band-seg capacity, bit 4: bbox beyond int range
+    int n_nonempty;
+    long long path_pixels;
+    int union_min_r, union_min_c, union_max_r, union_max_c;
+};
+
+__device__ __forceinline__ void load_seg_points(const double* __restrict__ segs, int s, const double* __restrict__ m6,
+                                                int npts, double* c) {
+    for (int k = 0; k < npts; ++k) {
+        double px = segs[8 * (size_t)s + 2 * k], py = segs[8 * (size_t)s + 2 * k + 1];
+        xform_point(m6, px, py, c[2 * k], c[2 * k + 1]);
+    }
+}
+
+__global__ void k_seg_count(const double* __restrict__ segs, const uint8_t* __restrict__ kind,
+                            const int* __restrict__ seg_path, const double* __restrict__ path_m6, int n_segs, double thr,
+                            int* __restrict__ seg_cnt, BatchDev* __restrict__ bd) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n_segs) return;
+    if (s == n_segs) { seg_cnt[s] = 0; return; }  // slot for the scan total
+    int cnt = 1;
+    if (kind[s] == SVGR_SEG_CUBIC) {
+        double c[8];
+        load_seg_points(segs, s, path_m6 + 6 * (size_t)seg_path[s], 4, c);
+        cnt = flatten_cubic(c, thr, [](double, double, double, double) {});
+        if (cnt < 0) { atomicOr(&bd->err, 1); cnt = 0; }
+    }
+    seg_cnt[s] = cnt;
+}
+
+__global__ void k_seg_emit(const double* __restrict__ segs, const uint8_t* __restrict__ kind,
+                           const int* __restrict__ seg_path, const double* __restrict__ path_m6, int n_segs, double thr,
+                           const int* __restrict__ seg_off, double* __restrict__ edges, int* __restrict__ edge_path,
+                           int edge_cap, unsigned long long* __restrict__ pmin, unsigned long long* __restrict__ pmax,
+                           BatchDev* __restrict__ bd) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segs) return;
+    const int p = seg_path[s];
+    const int off = seg_off[s];
+    const int cnt = seg_off[s + 1] - off;
+    if (cnt <= 0) return;
+    if (off + cnt > edge_cap) { atomicOr(&bd->err, 2); return; }
+    double mnr = INFINITY, mnc = INFINITY, mxr = -INFINITY, mxc = -INFINITY;
+    auto track = [&](double r, double c) {
+        mnr = r < mnr ? r : mnr; mxr = r > mxr ? r : mxr;
+        mnc = c < mnc ? c : mnc; mxc = c > mxc ? c : mxc;
+    };
+    const double* m6 = path_m6 + 6 * (size_t)p;
+    if (kind[s] == SVGR_SEG_LINE) {
+        double c[4];
+        load_seg_points(segs, s, m6, 2, c);
+        double* e = edges + 4 * (size_t)off;
+        e[0] = c[0]; e[1] = c[1]; e[2] = c[2]; e[3] = c[3];
+        edge_path[off] = p;
+        track(c[0], c[1]);
+        track(c[2], c[3]);
+    } else {
+        double c[8];
+        load_seg_points(segs, s, m6, 4, c);
+        int i = 0;
+        flatten_cubic(c, thr, [&](double r0, double c0, double r1, double c1) {
+            if (i < cnt) {
+                double* e = edges + 4 * (size_t)(off + i);
+                e[0] = r0; e[1] = c0; e[2] = r1; e[3] = c1;
+                edge_path[off + i] = p;
+            }
+            ++i;
+            track(r0, c0);
+            track(r1, c1);
+        });
+    }
+    atomicMin(&pmin[2 * (size_t)p], f64_key(mnr));
+    atomicMin(&pmin[2 * (size_t)p + 1], f64_key(mnc));
+    atomicMax(&pmax[2 * (size_t)p], f64_key(mxr));
+    atomicMax(&pmax[2 * (size_t)p + 1], f64_key(mxc));
+}
+
+// bbox = {r0, c0, rows, cols}; viewport = same or has_vp = 0
+__global__ void k_path_bbox(const unsigned long long* __restrict__ pmin, const unsigned long long* __restrict__ pmax,
+                            int n_paths, int has_vp, int vr0, int vc0, int vrows, int vcols, int* __restrict__ bbox,
+                            int* __restrict__ b0, int* __restrict__ nb, int* __restrict__ band_cnt,
+                            BatchDev* __restrict__ bd) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > n_paths) return;
+    if (p == n_paths) { nb[p] = 0; return; }  // scan-total slot
+    int out[4] = {0, 0, 0, 0};
+    int pb0 = 0, pnb = 0;
+    unsigned long long kmin_r = pmin[2 * (size_t)p];
+    if (kmin_r != ~0ull) {  // the path produced at least one edge
+        double mnr = key_f64(kmin_r), mnc = key_f64(pmin[2 * (size_t)p + 1]);
+        double mxr = key_f64(pmax[2 * (size_t)p]), mxc = key_f64(pmax[2 * (size_t)p + 1]);
+        const double lim = 1.0e9;
+        if (!(mnr > -lim && mnc > -lim && mxr < lim && mxc < lim)) {
+            atomicOr(&bd->err, 16);
+        } else {
+            long long lo_r = (long long)floor(mnr) - 1, lo_c = (long long)floor(mnc) - 1;
+            long long hi_r = (long long)ceil(mxr) + 1, hi_c = (long long)ceil(mxc) + 1;
+            if (has_vp) {
+                lo_r = lo_r > vr0 ? lo_r : vr0;
+                lo_c = lo_c > vc0 ? lo_c : vc0;
+                hi_r = hi_r < (long long)vr0 + vrows ? hi_r : (long long)vr0 + vrows;
+                hi_c = hi_c < (long long)vc0 + vcols ? hi_c : (long long)vc0 + vcols;
+            }
+            long long rows = hi_r - lo_r, cols = hi_c - lo_c;
+            if (rows > 0 && cols > 0) {
+                out[0] = (int)lo_r; out[1] = (int)lo_c; out[2] = (int)rows; out[3] = (int)cols;
+                int base_r = has_vp ? vr0 : (int)lo_r;
+                pb0 = ((int)lo_r - base_r) / TR;
+                pnb = ((int)(hi_r - 1) - base_r) / TR - pb0 + 1;
+                atomicAdd(&bd->n_nonempty, 1);
+                atomicAdd((unsigned long long*)&bd->path_pixels, (unsigned long long)(rows * cols));
+                atomicMin(&bd->union_min_r, (int)lo_r);
+                atomicMin(&bd->union_min_c, (int)lo_c);
+                atomicMax(&bd->union_max_r, (int)hi_r);
+                atomicMax(&bd->union_max_c, (int)hi_c);
+                if (band_cnt)
+                    for (int b = 0; b < pnb; ++b) atomicAdd(&band_cnt[pb0 + b], 1);
+            } else {
+                const long long big = 1ll << 30;
+                out[0] = (int)(lo_r > big ? big : (lo_r < -big ? -big : lo_r));
+                out[1] = (int)(lo_c > big ? big : (lo_c < -big ? -big : lo_c));
+            }
+        }
+    }
+    bbox[4 * (size_t)p] = out[0]; bbox[4 * (size_t)p + 1] = out[1];
+    bbox[4 * (size_t)p + 2] = out[2]; bbox[4 * (size_t)p + 3] = out[3];
+    b0[p] = pb0;
+    nb[p] = pnb;
+}
+
+// shared by count and emit so both take identical decisions
+__device__ __forceinline__ bool edge_prepare(const double* __restrict__ edges, const int* __restrict__ edge_path,
+                                             const int* __restrict__ bbox, int e, EdgeSetup& es, int& p, int& r0) {
+    p = edge_path[e];
+    const int* bb = bbox + 4 * (size_t)p;
+    r0 = bb[0];
+    const int rows = bb[2], cols = bb[3];
+    if (rows <= 0 || cols <= 0) return false;
+    const double o_r = (double)bb[0], o_c = (double)bb[1];  // `lines - [min_x, min_y]` (S:979)
+    const double* ed = edges + 4 * (size_t)e;
+    double ar = ed[0] - o_r, ac = ed[1] - o_c, br = ed[2] - o_r, bc = ed[3] - o_c;
+    es = edge_setup(ar, ac, br, bc, rows);
+    if (!es.valid) return false;
+    // an edge whose every column is beyond the layer never stores anything (S:2260, S:2274)
+    double cmin = ac < bc ? ac : bc;
+    if (cmin >= (double)cols + 2.0) return false;
+    return true;
+}
+
+__global__ void k_edge_count(const double* __restrict__ edges, const int* __restrict__ edge_path,
+                             const int* __restrict__ n_edges_ptr, const int* __restrict__ bbox,
+                             const int* __restrict__ pb_off, const int* __restrict__ b0, int vr0,
+                             int* __restrict__ pb_cnt) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= *n_edges_ptr) return;
+    EdgeSetup es;
+    int p, r0;
+    if (!edge_prepare(edges, edge_path, bbox, e, es, p, r0)) return;
+    int bf = (r0 + es.y_begin - vr0) / TR, bl = (r0 + es.y_end - 1 - vr0) / TR;
+    int base = pb_off[p] - b0[p];
+    for (int b = bf; b <= bl; ++b) atomicAdd(&pb_cnt[base + b], 1);
+}
+
+__global__ void k_edge_emit(const double* __restrict__ edges, const int* __restrict__ edge_path,
+                            const int* __restrict__ n_edges_ptr, const int* __restrict__ bbox,
+                            const int* __restrict__ pb_off, const int* __restrict__ b0, int vr0,
+                            const int* __restrict__ bseg_off, int* __restrict__ pb_cursor, BandSeg* __restrict__ bsegs,
+                            int bseg_cap, BatchDev* __restrict__ bd) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= *n_edges_ptr) return;
+    EdgeSetup es;
+    int p, r0;
+    if (!edge_prepare(edges, edge_path, bbox, e, es, p, r0)) return;
+    const int base = pb_off[p] - b0[p];
+    RowState st;
+    st.x_next = es.x;
+    st.x = es.x;
+    st.d = 0.0;
+    int y = es.y_begin;
+    while (y < es.y_end) {
+        int band = (r0 + y - vr0) / TR;
+        int band_end_row = (band + 1) * TR + vr0 - r0;  // first layer-local row of the next band
+        int y1 = band_end_row < es.y_end ? band_end_row : es.y_end;
+        int pb = base + band;
+        int slot = bseg_off[pb] + atomicAdd(&pb_cursor[pb], 1);
+        if (slot < bseg_cap) {
+            BandSeg g;
+            g.x = st.x_next;
+            g.dxdy = es.dxdy;
+            g.p0y = es.p0y;
+            g.p1y = es.p1y;
+            g.y0 = y;
+            g.y1s = es.dir < 0.0 ? -y1 : y1;
+            bsegs[slot] = g;
+        } else {
+            atomicOr(&bd->err, 8);
+        }
+        for (; y < y1; ++y) row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);  // carry x exactly as S:2244-2248
+    }
+}
+
+// one workgroup per band: ascending list of the paths whose bbox rows cover the band
+__global__ __launch_bounds__(256) void k_band_entries(const int* __restrict__ b0, const int* __restrict__ nb, int n_paths,
+                                                      const int* __restrict__ band_off, int* __restrict__ entries,
+                                                      int entry_cap, BatchDev* __restrict__ bd) {
+    __shared__ int s_wcnt[4];
+    const int band = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int run = band_off[band];
+    for (int base = 0; base < n_paths; base += 256) {
+        int p = base + tid;
+        bool hit = false;
+        if (p < n_paths) {
+            int f = b0[p], n = nb[p];
+            hit = n > 0 && band >= f && band < f + n;
+        }
+        unsigned long long m = __ballot(hit);
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = 0, total = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) off += s_wcnt[w];
+            total += s_wcnt[w];
+        }
+        if (hit) {
+            int idx = run + off + __popcll(m & ((1ull << lane) - 1ull));
+            if (idx < entry_cap) entries[idx] = p;
+            else atomicOr(&bd->err, 4);
+        }
+        run += total;
+        __syncthreads();
+    }
+}
+
+// ======================================================================================
+// tile kernel
+// ======================================================================================
+template <int N>
+__device__ __forceinline__ double dpp_row_shr(double v) {  // lane i <- lane i-N inside a 16-lane row, else +0.0
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + N, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int lds_index(int trow, int tcol) {
+    return trow * ROW_STRIDE + (tcol / PX) * CHUNK_STRIDE + (tcol % PX);
+}
+
+struct TileArgs {
+    const int* band_off;       // n_bands + 1
+    const int* entries;        // path ids per band, ascending
+    const int* bbox;           // n_paths x 4
+    const int* b0;             // first band of each path
+    const int* pb_off;         // (path, band) pair offsets
+    const int* bseg_off;       // band-seg offsets per pair
+    const BandSeg* bsegs;
+    const uint8_t* rule;       // n_paths
+    const double* paint;       // n_paths x 4
+    void* out;
+    int vr0, vc0, vrows, vcols;  // viewport
+    int band_first, band_step;   // owned bands
+    int out_cols;                // row pitch of `out` in pixels
+    int clip01;
+    int single_r0, single_c0, single_cols;  // single-path outputs: layer origin / pitch
+};
+
+// OUT: 0 = canvas f32, 1 = canvas f64, 2 = mask f64 (single path), 3 = fill f64 (single path)
+template <int OUT>
+__global__ __launch_bounds__(NT) void k_tile_render(const TileArgs a) {
+    __shared__ double s_trace[TR * ROW_STRIDE];
+    __shared__ int s_list[NT];
+    __shared__ int s_wcnt[4];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int trow = tid / CH, chunk = tid % CH;
+    const int band = a.band_first + (int)blockIdx.y * a.band_step;
+    const int tile_r0 = a.vr0 + band * TR;             // absolute row of tile row 0
+    const int tile_c0 = a.vc0 + (int)blockIdx.x * TC;  // absolute column of tile column 0
+    const int tile_c1 = tile_c0 + TC;
+
+    double acc[PX][4];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0;
+
+    for (int i = tid; i < TR * ROW_STRIDE; i += NT) s_trace[i] = 0.0;
+    __syncthreads();
+
+    const int ent_begin = a.band_off[band], ent_end = a.band_off[band + 1];
+    for (int base = ent_begin; base < ent_end; base += NT) {
+        // ---- compact the band's path list down to the paths that touch this tile's columns ----
+        int p_mine = -1;
+        bool hit = false;
+        if (base + tid < ent_end) {
+            p_mine = a.entries[base + tid];
+            int c0 = a.bbox[4 * (size_t)p_mine + 1], cols = a.bbox[4 * (size_t)p_mine + 3];
+            hit = c0 < tile_c1 && c0 + cols > tile_c0;
+        }
+        unsigned long long m = __ballot(hit);
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) off += s_wcnt[w];
+            total += s_wcnt[w];
+        }
+        if (hit) s_list[off + __popcll(m & ((1ull << lane) - 1ull))] = p_mine;
+        __syncthreads();
+
+        for (int li = 0; li < total; ++li) {
+            const int p = s_list[li];
+            const int pb = a.pb_off[p] + band - a.b0[p];
+            const int s0 = a.bseg_off[pb], s1 = a.bseg_off[pb + 1];
+            if (s0 == s1) continue;  // no edge crosses this band: coverage is zero everywhere in it
+            const int r0 = a.bbox[4 * (size_t)p], c0 = a.bbox[4 * (size_t)p + 1];
+            const int rows = a.bbox[4 * (size_t)p + 2], cols = a.bbox[4 * (size_t)p + 3];
+            const int row_shift = r0 - tile_r0;  // layer row y  -> tile row  y + row_shift
+            const int col_shift = c0 - tile_c0;  // layer col x  -> tile col  x + col_shift
+            const int lo_c = col_shift < 0 ? -col_shift : 0;                 // first layer column inside the tile
+            const int hi_c = cols < tile_c1 - c0 ? cols : tile_c1 - c0;      // one past the last
+
+            // ---- scatter: signed-area pieces of every band segment into the LDS delta tile ----
+            for (int s = s0 + tid; s < s1; s += NT) {
+                const BandSeg g = a.bsegs[s];
+                const double dir = g.y1s < 0 ? -1.0 : 1.0;
+                const int y1 = g.y1s < 0 ? -g.y1s : g.y1s;
+                RowState st;
+                st.x_next = g.x;
+                for (int y = g.y0; y < y1; ++y) {
+                    row_step(st, y, g.p0y, g.p1y, g.dxdy, dir);
+                    double* trow_ptr = s_trace + (y + row_shift) * ROW_STRIDE;
+                    int lo, hi;
+                    row_span(st.x, st.x_next, lo, hi);
+                    if (lo >= hi_c) continue;  // everything at or beyond the tile's / layer's right edge
+                    if (hi < lo_c) {
+                        // whole row span left of the tile: the pieces sum to d; fold into the first column
+                        int tc = lo_c + col_shift;
+                        __hip_atomic_fetch_add(trow_ptr + (tc / PX) * CHUNK_STRIDE + (tc % PX), st.d, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                        continue;
+                    }
+                    row_pieces(st.x, st.x_next, st.d, [&](int xi, double v) -> bool {
+                        int c = xi > 0 ? xi : 0;   // left of the layer folds into column 0 (S:2262)
+                        if (c >= hi_c) return false;
+                        c = c > lo_c ? c : lo_c;   // left of the tile folds into its first column (row carry-in)
+                        int tc = c + col_shift;
+                        __hip_atomic_fetch_add(trow_ptr + (tc / PX) * CHUNK_STRIDE + (tc % PX), v, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                        return true;
+                    });
+                }
+            }
+            __syncthreads();
+
+            // ---- row prefix sum + fill rule + paint + source-over ----
+            {
+                double* my = s_trace + trow * ROW_STRIDE + chunk * CHUNK_STRIDE;
+                double t[PX];
+#pragma unroll
+                for (int i = 0; i < PX; ++i) t[i] = my[i];
+#pragma unroll
+                for (int i = 0; i < PX; ++i) my[i] = 0.0;
+                double tot = t[0];
+#pragma unroll
+                for (int i = 1; i < PX; ++i) tot += t[i];
+                double inc = tot;  // inclusive scan of the 16 chunk totals of this tile row
+                inc += dpp_row_shr<1>(inc);
+                inc += dpp_row_shr<2>(inc);
+                inc += dpp_row_shr<4>(inc);
+                inc += dpp_row_shr<8>(inc);
+                double run = dpp_row_shr<1>(inc);  // exclusive: everything left of this chunk
+
+                const int y_layer = trow - row_shift;
+                const bool row_ok = y_layer >= 0 && y_layer < rows;
+                const int x_layer0 = chunk * PX - col_shift;
+                const int rule = a.rule[p];
+                const double p0 = a.paint[4 * (size_t)p], p1 = a.paint[4 * (size_t)p + 1];
+                const double p2 = a.paint[4 * (size_t)p + 2], p3 = a.paint[4 * (size_t)p + 3];
+#pragma unroll
+                for (int i = 0; i < PX; ++i) {
+                    run += t[i];
+                    const int x_layer = x_layer0 + i;
+                    if (row_ok && x_layer >= lo_c && x_layer < hi_c) {
+                        double mval = fill_rule(run, rule);
+                        if (OUT == 2) {
+                            ((double*)a.out)[(size_t)y_layer * a.single_cols + x_layer] = mval;
+                        } else if (OUT == 3) {
+                            double* o = (double*)a.out + 4 * ((size_t)y_layer * a.single_cols + x_layer);
+                            o[0] = mval * p0; o[1] = mval * p1; o[2] = mval * p2; o[3] = mval * p3;
+                        } else if (mval != 0.0) {
+                            over_px(acc[i], mval * p0, mval * p1, mval * p2, mval * p3);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+
+    if (OUT <= 1) {
+        const int row = band * TR + trow;  // viewport-local row
+        const int out_row = (int)blockIdx.y * TR + trow;
+        if (row < a.vrows) {
+            const int col0 = (int)blockIdx.x * TC + chunk * PX;
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                if (col0 + i < a.vcols) {
+                    double v0 = acc[i][0], v1 = acc[i][1], v2 = acc[i][2], v3 = acc[i][3];
+                    if (a.clip01) {
+                        v0 = v0 < 0 ? 0 : (v0 > 1 ? 1 : v0); v1 = v1 < 0 ? 0 : (v1 > 1 ? 1 : v1);
+                        v2 = v2 < 0 ? 0 : (v2 > 1 ? 1 : v2); v3 = v3 < 0 ? 0 : (v3 > 1 ? 1 : v3);
+                    }
+                    size_t o = (size_t)out_row * a.out_cols + col0 + i;
+                    if (OUT == 0) {
+                        ((float4*)a.out)[o] = make_float4((float)v0, (float)v1, (float)v2, (float)v3);
+                    } else {
+                        ((double4*)a.out)[o] = make_double4(v0, v1, v2, v3);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ======================================================================================
+// layer kernels (double images in HBM)
+// ======================================================================================
+__global__ void k_layer_over(double* __restrict__ dst, int dr0, int dc0, int drows, int dcols,
+                             const double* __restrict__ src, int sr0, int sc0, int srows, int scols, int ch, int first) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)srows * scols) return;
+    int r = (int)(i / scols), c = (int)(i % scols);
+    int R = r + sr0 - dr0, C = c + sc0 - dc0;
+    if (R < 0 || R >= drows || C < 0 || C >= dcols) return;
+    double* d = dst + 4 * ((size_t)R * dcols + C);
+    const double* s = src + (size_t)ch * i;
+    double s0 = s[0], s1 = ch == 4 ? s[1] : s0, s2 = ch == 4 ? s[2] : s0, s3 = ch == 4 ? s[3] : s0;
+    if (first) {
+        d[0] = s0; d[1] = s1; d[2] = s2; d[3] = s3;
+    } else {
+        over_px(d, s0, s1, s2, s3);
+    }
+}
+
+__global__ void k_layer_crop4(double* __restrict__ out, int or0, int oc0, int orows, int ocols,
+                              const double* __restrict__ src, int sr0, int sc0, int srows, int scols, int ch) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)orows * ocols) return;
+    int R = (int)(i / ocols), C = (int)(i % ocols);
+    int r = R + or0 - sr0, c = C + oc0 - sc0;
+    double v[4] = {0, 0, 0, 0};
+    if (r >= 0 && r < srows && c >= 0 && c < scols) {
+        const double* s = src + (size_t)ch * ((size_t)r * scols + c);
+        v[0] = s[0]; v[1] = ch == 4 ? s[1] : s[0]; v[2] = ch == 4 ? s[2] : s[0]; v[3] = ch == 4 ? s[3] : s[0];
+    }
+    double* o = out + 4 * i;
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+
+__global__ void k_layer_in(double* __restrict__ out, int or0, int oc0, int orows, int ocols,
+                           const double* __restrict__ src, int sr0, int sc0, int srows, int scols, int ch) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)orows * ocols) return;
+    int R = (int)(i / ocols), C = (int)(i % ocols);
+    int r = R + or0 - sr0, c = C + oc0 - sc0;
+    if (r < 0 || r >= srows || c < 0 || c >= scols) return;
+    double* o = out + 4 * i;
+    const double* s = src + (size_t)ch * ((size_t)r * scols + c);
+    double da = o[3];
+    o[0] = s[0] * da;
+    o[1] = (ch == 4 ? s[1] : s[0]) * da;
+    o[2] = (ch == 4 ? s[2] : s[0]) * da;
+    o[3] = (ch == 4 ? s[3] : s[0]) * da;
+}
+
+__global__ void k_layer_scale(double* __restrict__ img, size_t n, double f) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) img[i] = img[i] * f;
+}
+
+__global__ void k_layer_convert(double* __restrict__ img, size_t n_px, unsigned ops) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_px) return;
+    double* px = img + 4 * i;
+    double v[4] = {px[0], px[1], px[2], px[3]};
+    if (ops & 1u) {  // premultiplied -> straight, S:471-477 (divide where alpha > 1e-4, then clip all 4)
+        double al = v[3];
+        for (int c = 0; c < 4; ++c) {
+            double x = v[c];
+            if (c < 3 && al > 0.0001) x = x / al;
+            v[c] = x < 0 ? 0 : (x > 1 ? 1 : x);
+        }
+    }
+    if (ops & 2u)  // sRGB -> linear, S:496-503
+        for (int c = 0; c < 3; ++c) v[c] = v[c] <= 0.04045 ? v[c] / 12.92 : pow((v[c] + 0.055) / 1.055, 2.4);
+    if (ops & 4u)  // linear -> sRGB, S:486-493
+        for (int c = 0; c < 3; ++c) v[c] = v[c] <= 0.0031308 ? v[c] * 12.92 : 1.055 * pow(v[c], 1.0 / 2.4) - 0.055;
+    if (ops & 8u)  // straight -> premultiplied, S:480-483
+        for (int c = 0; c < 3; ++c) v[c] = v[c] * v[3];
+    px[0] = v[0]; px[1] = v[1]; px[2] = v[2]; px[3] = v[3];
+}
+
+__global__ void k_to_f32(float* __restrict__ dst, const double* __restrict__ src, size_t n, int clip01) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = src[i];
+    if (clip01) v = v < 0 ? 0 : (v > 1 ? 1 : v);
+    dst[i] = (float)v;
+}
+
+// ======================================================================================
+// batch object
+// ======================================================================================
+struct TimedEvents {
+    hipEvent_t e0, e1, e2;  // start, before tile kernel, after tile kernel
+};
+
+struct svgr_batch {
+    svgr_ctx* ctx = nullptr;
+    int64_t n_segs = 0, n_paths = 0;
+    int vp[4] = {0, 0, 0, 0};
+    bool has_vp = false;
+    double thr = 0.16000000000000003;
+    int band_first = 0, band_step = 1;
+    bool planned = false;
+    // inputs
+    DevArr<double> segs, path_m6, path_paint;
+    DevArr<uint8_t> seg_kind, path_rule;
+    DevArr<int> seg_path;
+    // work
+    DevArr<int> seg_cnt, seg_off, edge_path, bbox, b0, nb, pb_off, pb_cnt, bseg_off, pb_cursor, band_cnt, band_off, entries;
+    DevArr<double> edges;
+    DevArr<unsigned long long> pmin, pmax;
+    DevArr<BandSeg> bsegs;
+    DevArr<BatchDev> bd;
+    Scanner scanner;
+    // plan results
+    int64_t n_edges = 0, n_pb = 0, n_bsegs = 0;
+    int n_bands = 0;
+    BatchDev host_bd{};
+    std::vector<int> host_bbox;
+    std::vector<TimedEvents> events;
+    std::vector<hipEvent_t> event_pool;
+
+    void release() {
+        segs.release(); path_m6.release(); path_paint.release(); seg_kind.release(); path_rule.release();
+        seg_path.release(); seg_cnt.release(); seg_off.release(); edge_path.release(); bbox.release(); b0.release();
+        nb.release(); pb_off.release(); pb_cnt.release(); bseg_off.release(); pb_cursor.release(); band_cnt.release();
+        band_off.release(); entries.release(); edges.release(); pmin.release(); pmax.release(); bsegs.release();
+        bd.release(); scanner.release();
+        for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
+        events.clear();
+        for (auto e : event_pool) (void)hipEventDestroy(e);
+        event_pool.clear();
+    }
+};
+
+static inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+// stage A: transform + flatten + per-path min/max.  needs: seg_cnt, seg_off (n_segs+1)
+static int stage_count(svgr_batch* b) {
+    hipStream_t st = b->ctx->stream;
+    const int ns = (int)b->n_segs;
+    HIPCHK(hipMemsetAsync(b->bd.p, 0, sizeof(BatchDev), st));
+    hipLaunchKernelGGL(k_seg_count, grid1(ns + 1), dim3(256), 0, st, (const double*)b->segs.p,
+                       (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
+                       b->seg_cnt.p, b->bd.p);
+    return b->scanner.run(st, b->seg_cnt.p, b->seg_off.p, ns + 1);
+}
+
+static int stage_emit_bbox(svgr_batch* b, bool with_bands) {
+    hipStream_t st = b->ctx->stream;
+    const int ns = (int)b->n_segs, np = (int)b->n_paths;
+    HIPCHK(hipMemsetAsync(b->pmin.p, 0xFF, sizeof(unsigned long long) * 2 * np, st));
+    HIPCHK(hipMemsetAsync(b->pmax.p, 0x00, sizeof(unsigned long long) * 2 * np, st));
+    hipLaunchKernelGGL(k_seg_emit, grid1(ns), dim3(256), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
+                       (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr, (const int*)b->seg_off.p,
+                       b->edges.p, b->edge_path.p, (int)std::min<size_t>(b->edges.cap / 4, 0x7fffffff), b->pmin.p, b->pmax.p,
+                       b->bd.p);
+    // reset the bbox accumulators that k_path_bbox fills
+    BatchDev init{};
+    init.union_min_r = init.union_min_c = 0x7fffffff;
+    init.union_max_r = init.union_max_c = -0x7fffffff;
+    // keep err bits from the previous stage: only overwrite the tail of the struct
+    HIPCHK(hipMemcpyAsync((char*)b->bd.p + offsetof(BatchDev, n_nonempty), (char*)&init + offsetof(BatchDev, n_nonempty),
+                          sizeof(BatchDev) - offsetof(BatchDev, n_nonempty), hipMemcpyHostToDevice, st));
+    int* band_cnt = nullptr;
+    if (with_bands) {
+        HIPCHK(hipMemsetAsync(b->band_cnt.p, 0, sizeof(int) * (b->n_bands + 1), st));
+        band_cnt = b->band_cnt.p;
+    }
+    hipLaunchKernelGGL(k_path_bbox, grid1(np + 1), dim3(256), 0, st, (const unsigned long long*)b->pmin.p,
+                       (const unsigned long long*)b->pmax.p, np, b->has_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3],
+                       b->bbox.p, b->b0.p, b->nb.p, band_cnt, b->bd.p);
+    return 0;
+}
+
+// stage C: binning.  needs n_bands, pb arrays sized for n_pb, bsegs sized
+static int stage_bin_counts(svgr_batch* b) {
+    hipStream_t st = b->ctx->stream;
+    const int np = (int)b->n_paths;
+    if (int rc = b->scanner.run(st, b->nb.p, b->pb_off.p, np + 1)) return rc;
+    if (int rc = b->scanner.run(st, b->band_cnt.p, b->band_off.p, b->n_bands + 1)) return rc;
+    return 0;
+}
+
+static int stage_edge_count(svgr_batch* b) {
+    hipStream_t st = b->ctx->stream;
+    HIPCHK(hipMemsetAsync(b->pb_cnt.p, 0, sizeof(int) * (b->n_pb + 1), st));
+    if (b->n_edges > 0)
+        hipLaunchKernelGGL(k_edge_count, grid1((size_t)b->n_edges), dim3(256), 0, st, (const double*)b->edges.p,
+                           (const int*)b->edge_path.p, (const int*)(b->seg_off.p + b->n_segs), (const int*)b->bbox.p,
+                           (const int*)b->pb_off.p, (const int*)b->b0.p, b->vp[0], b->pb_cnt.p);
+    return b->scanner.run(st, b->pb_cnt.p, b->bseg_off.p, (int)b->n_pb + 1);
+}
+
+static int stage_edge_emit(svgr_batch* b) {
+    hipStream_t st = b->ctx->stream;
+    HIPCHK(hipMemsetAsync(b->pb_cursor.p, 0, sizeof(int) * (b->n_pb + 1), st));
+    if (b->n_edges > 0)
+        hipLaunchKernelGGL(k_edge_emit, grid1((size_t)b->n_edges), dim3(256), 0, st, (const double*)b->edges.p,
+                           (const int*)b->edge_path.p, (const int*)(b->seg_off.p + b->n_segs), (const int*)b->bbox.p,
+                           (const int*)b->pb_off.p, (const int*)b->b0.p, b->vp[0], (const int*)b->bseg_off.p,
+                           b->pb_cursor.p, b->bsegs.p, (int)std::min<size_t>(b->bsegs.cap, 0x7fffffff), b->bd.p);
+    if (b->n_bands > 0)
+        hipLaunchKernelGGL(k_band_entries, dim3(b->n_bands), dim3(256), 0, st, (const int*)b->b0.p, (const int*)b->nb.p,
+                           (int)b->n_paths, (const int*)b->band_off.p, b->entries.p,
+                           (int)std::min<size_t>(b->entries.cap, 0x7fffffff), b->bd.p);
+    return 0;
+}
+
+static int read_i32(svgr_batch* b, const int* dptr, int* out) {
+    HIPCHK(hipMemcpyAsync(out, dptr, sizeof(int), hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+
+static int check_dev_err(svgr_batch* b) {
+    HIPCHK(hipMemcpyAsync(&b->host_bd, b->bd.p, sizeof(BatchDev), hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    HIPCHK(hipGetLastError());
+    int e = b->host_bd.err;
+    if (e & 1) return fail(SVGR_E_OVERFLOW, "flatten depth cap (%d) hit: non-finite or absurd control points", kMaxFlattenDepth);
+    if (e & 16) return fail(SVGR_E_INVALID, "path extent beyond +-1e9 pixels or non-finite");
+    if (e & (2 | 4 | 8)) return fail(SVGR_E_OVERFLOW, "work buffer capacity exceeded (err bits %d): call svgr_batch_plan again", e);
+    return 0;
+}
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+extern "C" {
+
+int svgr_abi_version(void) { return SVGR_ABI_VERSION; }
+const char* svgr_last_error(void) { return g_err.c_str(); }
+
+int svgr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int svgr_init(int device_id, svgr_ctx** out) {
+    if (!out) return fail(SVGR_E_INVALID, "svgr_init: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(SVGR_E_NODEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(SVGR_E_INVALID, "device %d out of range (0..%d)", device_id, n - 1);
+    HIPCHK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SVGR_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    svgr_ctx* c = new (std::nothrow) svgr_ctx();
+    if (!c) return fail(SVGR_E_NOMEM, "out of host memory");
+    c->device = device_id;
+    snprintf(c->name, sizeof c->name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) { delete c; return fail(SVGR_E_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
+    c->own_stream = true;
+    *out = c;
+    return 0;
+}
+
+int svgr_shutdown(svgr_ctx* ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int svgr_set_stream(svgr_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(SVGR_E_INVALID, "ctx is NULL");
+    if (ctx->own_stream && ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return 0;
+}
+
+int svgr_sync(svgr_ctx* ctx) {
+    if (!ctx) return fail(SVGR_E_INVALID, "ctx is NULL");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_device_name(svgr_ctx* ctx, char* out, size_t cap) {
+    if (!ctx || !out || cap == 0) return fail(SVGR_E_INVALID, "bad arguments");
+    snprintf(out, cap, "%s", ctx->name);
+    return 0;
+}
+
+int svgr_buf_alloc(svgr_ctx* ctx, size_t bytes, svgr_buf** out) {
+    if (!ctx || !out) return fail(SVGR_E_INVALID, "bad arguments");
+    *out = nullptr;
+    svgr_buf* b = new (std::nothrow) svgr_buf();
+    if (!b) return fail(SVGR_E_NOMEM, "out of host memory");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(&b->ptr, bytes ? bytes : 16);
+    if (e != hipSuccess) { delete b; return fail(SVGR_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    b->bytes = bytes;
+    b->owned = true;
+    *out = b;
+    return 0;
+}
+
+int svgr_buf_wrap(svgr_ctx* ctx, void* device_ptr, size_t bytes, svgr_buf** out) {
+    if (!ctx || !out || !device_ptr) return fail(SVGR_E_INVALID, "bad arguments");
+    svgr_buf* b = new (std::nothrow) svgr_buf();
+    if (!b) return fail(SVGR_E_NOMEM, "out of host memory");
+    b->ptr = device_ptr;
+    b->bytes = bytes;
+    b->owned = false;
+    *out = b;
+    return 0;
+}
+
+int svgr_buf_free(svgr_ctx* ctx, svgr_buf* buf) {
+    if (!buf) return 0;
+    if (buf->owned && buf->ptr) {
+        if (ctx) (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(buf->ptr);
+    }
+    delete buf;
+    return 0;
+}
+
+void* svgr_buf_ptr(const svgr_buf* buf) { return buf ? buf->ptr : nullptr; }
+size_t svgr_buf_bytes(const svgr_buf* buf) { return buf ? buf->bytes : 0; }
+
+int svgr_buf_zero(svgr_ctx* ctx, svgr_buf* buf) {
+    if (!ctx || !buf) return fail(SVGR_E_INVALID, "bad arguments");
+    HIPCHK(hipMemsetAsync(buf->ptr, 0, buf->bytes, ctx->stream));
+    return 0;
+}
+
+int svgr_buf_copy(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, size_t bytes) {
+    if (!ctx || !dst || !src) return fail(SVGR_E_INVALID, "bad arguments");
+    if (bytes > dst->bytes || bytes > src->bytes) return fail(SVGR_E_INVALID, "copy of %zu bytes overruns a buffer", bytes);
+    if (bytes == 0) return 0;
+    HIPCHK(hipMemcpyAsync(dst->ptr, src->ptr, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+int svgr_upload(svgr_ctx* ctx, svgr_buf* dst, size_t dst_off, const void* host, size_t bytes) {
+    if (!ctx || !dst || (!host && bytes)) return fail(SVGR_E_INVALID, "bad arguments");
+    if (dst_off + bytes > dst->bytes) return fail(SVGR_E_INVALID, "upload of %zu bytes at %zu overruns a %zu byte buffer", bytes, dst_off, dst->bytes);
+    if (bytes == 0) return 0;
+    HIPCHK(hipMemcpyAsync((char*)dst->ptr + dst_off, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // host buffer is caller-owned and may be reused at once
+    return 0;
+}
+
+int svgr_download(svgr_ctx* ctx, const svgr_buf* src, size_t src_off, void* host, size_t bytes) {
+    if (!ctx || !src || (!host && bytes)) return fail(SVGR_E_INVALID, "bad arguments");
+    if (src_off + bytes > src->bytes) return fail(SVGR_E_INVALID, "download of %zu bytes at %zu overruns a %zu byte buffer", bytes, src_off, src->bytes);
+    if (bytes == 0) return 0;
+    HIPCHK(hipMemcpyAsync(host, (const char*)src->ptr + src_off, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch
+// ---------------------------------------------------------------------------------------------
+int svgr_batch_create(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch** out) {
+    if (!ctx || !d || !out) return fail(SVGR_E_INVALID, "bad arguments");
+    *out = nullptr;
+    if (d->n_paths <= 0 || d->n_segs < 0) return fail(SVGR_E_INVALID, "batch needs at least one path");
+    if (d->n_segs > 0x3fffffff || d->n_paths > 0x3fffffff) return fail(SVGR_E_INVALID, "batch too large");
+    if (!d->path_seg_off || !d->path_m6 || !d->path_rule || !d->path_paint || (d->n_segs && (!d->segs || !d->seg_kind)))
+        return fail(SVGR_E_INVALID, "NULL array in batch description");
+    for (int64_t p = 0; p < d->n_paths; ++p) {
+        if (d->path_seg_off[p] > d->path_seg_off[p + 1]) return fail(SVGR_E_INVALID, "path_seg_off not monotone at %lld", (long long)p);
+        if (d->path_rule[p] > 1) return fail(SVGR_E_INVALID, "Invalid fill rule: %d", (int)d->path_rule[p]);  // S:989
+    }
+    if (d->path_seg_off[0] != 0 || d->path_seg_off[d->n_paths] != d->n_segs) return fail(SVGR_E_INVALID, "path_seg_off does not span segs");
+    for (int64_t s = 0; s < d->n_segs; ++s) {
+        if (d->seg_kind[s] > 1) return fail(SVGR_E_INVALID, "unsupported path type: `%d`", (int)d->seg_kind[s]);  // S:945
+        int npts = d->seg_kind[s] == SVGR_SEG_CUBIC ? 8 : 4;
+        for (int k = 0; k < npts; ++k)
+            if (!std::isfinite(d->segs[8 * s + k])) return fail(SVGR_E_INVALID, "non-finite coordinate in segment %lld", (long long)s);
+    }
+    for (int64_t i = 0; i < 6 * d->n_paths; ++i)
+        if (!std::isfinite(d->path_m6[i])) return fail(SVGR_E_INVALID, "non-finite transform");
+    if (!(d->flatness > 0.0) || !std::isfinite(d->flatness)) return fail(SVGR_E_INVALID, "flatness must be positive");
+    if (d->viewport[2] > 0 && (d->viewport[3] <= 0 || d->viewport[2] > (1 << 24) || d->viewport[3] > (1 << 24) ||
+                               std::llabs(d->viewport[0]) > (1 << 28) || std::llabs(d->viewport[1]) > (1 << 28)))
+        return fail(SVGR_E_INVALID, "viewport out of range");
+
+    HIPCHK(hipSetDevice(ctx->device));
+    svgr_batch* b = new (std::nothrow) svgr_batch();
+    if (!b) return fail(SVGR_E_NOMEM, "out of host memory");
+    b->ctx = ctx;
+    b->n_segs = d->n_segs;
+    b->n_paths = d->n_paths;
+    b->has_vp = d->viewport[2] > 0;
+    for (int i = 0; i < 4; ++i) b->vp[i] = b->has_vp ? (int)d->viewport[i] : 0;
+    b->thr = (d->flatness * d->flatness) * 16.0;  // S:2093
+    const size_t ns = (size_t)d->n_segs, np = (size_t)d->n_paths;
+    int rc = 0;
+    std::vector<int> seg_path(ns);
+    for (size_t p = 0; p < np; ++p)
+        for (int64_t s = d->path_seg_off[p]; s < d->path_seg_off[p + 1]; ++s) seg_path[(size_t)s] = (int)p;
+    auto up = [&](auto& arr, const void* src, size_t n, size_t elt) -> int {
+        if (int r = arr.ensure(n ? n : 1)) return r;
+        if (n) {
+            hipError_t e = hipMemcpyAsync(arr.p, src, n * elt, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) return fail(SVGR_E_HIP, "upload: %s", hipGetErrorString(e));
+        }
+        return 0;
+    };
+    rc = rc ? rc : up(b->segs, d->segs, ns * 8, sizeof(double));
+    rc = rc ? rc : up(b->seg_kind, d->seg_kind, ns, 1);
+    rc = rc ? rc : up(b->seg_path, seg_path.data(), ns, sizeof(int));
+    rc = rc ? rc : up(b->path_m6, d->path_m6, np * 6, sizeof(double));
+    rc = rc ? rc : up(b->path_rule, d->path_rule, np, 1);
+    rc = rc ? rc : up(b->path_paint, d->path_paint, np * 4, sizeof(double));
+    rc = rc ? rc : b->seg_cnt.ensure(ns + 1);
+    rc = rc ? rc : b->seg_off.ensure(ns + 1);
+    rc = rc ? rc : b->pmin.ensure(2 * np);
+    rc = rc ? rc : b->pmax.ensure(2 * np);
+    rc = rc ? rc : b->bbox.ensure(4 * np);
+    rc = rc ? rc : b->b0.ensure(np + 1);
+    rc = rc ? rc : b->nb.ensure(np + 1);
+    rc = rc ? rc : b->pb_off.ensure(np + 1);
+    rc = rc ? rc : b->bd.ensure(1);
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);  // seg_path is a local
+        if (e != hipSuccess) rc = fail(SVGR_E_HIP, "sync: %s", hipGetErrorString(e));
+    }
+    if (rc) { b->release(); delete b; return rc; }
+    *out = b;
+    return 0;
+}
+
+int svgr_batch_destroy(svgr_batch* b) {
+    if (!b) return 0;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    b->release();
+    delete b;
+    return 0;
+}
+
+int svgr_batch_set_paints(svgr_batch* b, const double* path_paint) {
+    if (!b || !path_paint) return fail(SVGR_E_INVALID, "bad arguments");
+    HIPCHK(hipMemcpyAsync(b->path_paint.p, path_paint, sizeof(double) * 4 * b->n_paths, hipMemcpyHostToDevice, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+
+int svgr_batch_set_transforms(svgr_batch* b, const double* path_m6) {
+    if (!b || !path_m6) return fail(SVGR_E_INVALID, "bad arguments");
+    for (int64_t i = 0; i < 6 * b->n_paths; ++i)
+        if (!std::isfinite(path_m6[i])) return fail(SVGR_E_INVALID, "non-finite transform");
+    HIPCHK(hipMemcpyAsync(b->path_m6.p, path_m6, sizeof(double) * 6 * b->n_paths, hipMemcpyHostToDevice, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    b->planned = false;
+    return 0;
+}
+
+int svgr_batch_set_bands(svgr_batch* b, int band_first, int band_step) {
+    if (!b || band_first < 0 || band_step <= 0) return fail(SVGR_E_INVALID, "bad band selection");
+    b->band_first = band_first;
+    b->band_step = band_step;
+    return 0;
+}
+
+int svgr_batch_plan(svgr_batch* b) {
+    if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
+    HIPCHK(hipSetDevice(b->ctx->device));
+    b->planned = false;
+    const int ns = (int)b->n_segs, np = (int)b->n_paths;
+    // A: edge count
+    if (int rc = stage_count(b)) return rc;
+    int n_edges = 0;
+    if (int rc = read_i32(b, b->seg_off.p + ns, &n_edges)) return rc;
+    if (int rc = check_dev_err(b)) return rc;
+    b->n_edges = n_edges;
+    if (int rc = b->edges.ensure((size_t)std::max(n_edges, 1) * 4)) return rc;
+    if (int rc = b->edge_path.ensure((size_t)std::max(n_edges, 1))) return rc;
+    // B: edges + bbox (first without band counting when there is no viewport: the single path's own bbox becomes it)
+    if (!b->has_vp) {
+        // no viewport (S:968 `viewport is None`): the union of the unclipped bboxes becomes the canvas
+        if (int rc = stage_emit_bbox(b, false)) return rc;
+        if (int rc = check_dev_err(b)) return rc;
+        if (b->host_bd.n_nonempty > 0) {
+            long long ur = (long long)b->host_bd.union_max_r - b->host_bd.union_min_r;
+            long long uc = (long long)b->host_bd.union_max_c - b->host_bd.union_min_c;
+            if (ur * uc > (1ll << 31) || ur > (1 << 24) || uc > (1 << 24))
+                return fail(SVGR_E_INVALID, "unclipped extent of %lldx%lld pixels is too large; pass a viewport", ur, uc);
+            b->vp[0] = b->host_bd.union_min_r; b->vp[1] = b->host_bd.union_min_c;
+            b->vp[2] = (int)ur; b->vp[3] = (int)uc;
+        } else {
+            b->vp[0] = b->vp[1] = 0; b->vp[2] = b->vp[3] = 0;
+        }
+    }
+    b->n_bands = (b->vp[2] + TR - 1) / TR;
+    if (int rc = b->band_cnt.ensure((size_t)b->n_bands + 1)) return rc;
+    if (int rc = b->band_off.ensure((size_t)b->n_bands + 1)) return rc;
+    const bool saved_has_vp = b->has_vp;
+    b->has_vp = true;  // from here on the (possibly derived) viewport is explicit
+    int rc = stage_emit_bbox(b, true);
+    if (!rc) rc = stage_bin_counts(b);
+    int n_pb = 0;
+    if (!rc) rc = read_i32(b, b->pb_off.p + np, &n_pb);
+    if (!rc) rc = check_dev_err(b);
+    if (rc) { b->has_vp = saved_has_vp; return rc; }
+    b->n_pb = n_pb;
+    rc = b->pb_cnt.ensure((size_t)n_pb + 1);
+    if (!rc) rc = b->bseg_off.ensure((size_t)n_pb + 1);
+    if (!rc) rc = b->pb_cursor.ensure((size_t)n_pb + 1);
+    if (!rc) rc = b->entries.ensure((size_t)std::max(n_pb, 1));
+    if (!rc) rc = stage_edge_count(b);
+    int n_bsegs = 0;
+    if (!rc) rc = read_i32(b, b->bseg_off.p + n_pb, &n_bsegs);
+    if (rc) { b->has_vp = saved_has_vp; return rc; }
+    b->n_bsegs = n_bsegs;
+    rc = b->bsegs.ensure((size_t)std::max(n_bsegs, 1));
+    if (!rc) rc = stage_edge_emit(b);
+    if (!rc) rc = check_dev_err(b);
+    b->host_bbox.resize(4 * (size_t)np);
+    if (!rc) {
+        hipError_t e = hipMemcpy(b->host_bbox.data(), b->bbox.p, sizeof(int) * 4 * np, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(SVGR_E_HIP, "bbox readback: %s", hipGetErrorString(e));
+    }
+    b->has_vp = saved_has_vp;
+    if (rc) return rc;
+    b->planned = true;
+    return 0;
+}
+
+int svgr_batch_get_stats(const svgr_batch* b, svgr_batch_stats* out) {
+    if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
+    if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan has not run");
+    out->n_edges = b->n_edges;
+    out->path_pixels = b->host_bd.path_pixels;
+    out->n_band_segs = b->n_bsegs;
+    out->n_path_bands = b->n_pb;
+    out->n_nonempty = b->host_bd.n_nonempty;
+    if (b->host_bd.n_nonempty > 0) {
+        out->bbox_union[0] = b->host_bd.union_min_r;
+        out->bbox_union[1] = b->host_bd.union_min_c;
+        out->bbox_union[2] = b->host_bd.union_max_r - b->host_bd.union_min_r;
+        out->bbox_union[3] = b->host_bd.union_max_c - b->host_bd.union_min_c;
+    } else {
+        out->bbox_union[0] = out->bbox_union[1] = out->bbox_union[2] = out->bbox_union[3] = 0;
+    }
+    out->tile_rows = TR;
+    out->tile_cols = TC;
+    return 0;
+}
+
+int svgr_batch_get_bboxes(const svgr_batch* b, int32_t* out) {
+    if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
+    if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan has not run");
+    memcpy(out, b->host_bbox.data(), sizeof(int32_t) * 4 * (size_t)b->n_paths);
+    return 0;
+}
+
+int svgr_batch_get_edges(const svgr_batch* b, double* edges, int32_t* edge_path, int64_t cap) {
+    if (!b || !edges) return fail(SVGR_E_INVALID, "bad arguments");
+    if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan has not run");
+    if (cap < b->n_edges) return fail(SVGR_E_INVALID, "edge buffer holds %lld, need %lld", (long long)cap, (long long)b->n_edges);
+    if (b->n_edges == 0) return 0;
+    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    HIPCHK(hipMemcpy(edges, b->edges.p, sizeof(double) * 4 * (size_t)b->n_edges, hipMemcpyDeviceToHost));
+    if (edge_path) HIPCHK(hipMemcpy(edge_path, b->edge_path.p, sizeof(int) * (size_t)b->n_edges, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int64_t svgr_batch_owned_rows(const svgr_batch* b) {
+    if (!b || !b->planned) return -1;
+    if (b->band_first == 0 && b->band_step == 1) return b->vp[2];
+    int owned = 0;
+    for (int band = b->band_first; band < b->n_bands; band += b->band_step) ++owned;
+    return (int64_t)owned * TR;
+}
+
+static int get_event(svgr_batch* b, hipEvent_t* e) {
+    if (!b->event_pool.empty()) { *e = b->event_pool.back(); b->event_pool.pop_back(); return 0; }
+    HIPCHK(hipEventCreate(e));
+    return 0;
+}
+
+int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags) {
+    if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
+    if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan must run before svgr_batch_render");
+    if (out_kind < 0 || out_kind > 3) return fail(SVGR_E_INVALID, "unknown output kind %d", out_kind);
+    const bool single = out_kind >= 2;
+    if (single && b->n_paths != 1) return fail(SVGR_E_INVALID, "mask/fill outputs need a single-path batch");
+    HIPCHK(hipSetDevice(b->ctx->device));
+    hipStream_t st = b->ctx->stream;
+
+    int owned_bands = 0;
+    for (int band = b->band_first; band < b->n_bands; band += b->band_step) ++owned_bands;
+    const int n_ctiles = (b->vp[3] + TC - 1) / TC;
+    size_t need;
+    int single_bb[4] = {0, 0, 0, 0};
+    if (single) {
+        for (int i = 0; i < 4; ++i) single_bb[i] = b->host_bbox[i];
+        need = (size_t)std::max(single_bb[2], 0) * std::max(single_bb[3], 0) * sizeof(double) * (out_kind == 3 ? 4 : 1);
+    } else {
+        const bool all = b->band_first == 0 && b->band_step == 1;
+        size_t rows = all ? (size_t)b->vp[2] : (size_t)owned_bands * TR;
+        need = rows * (size_t)b->vp[3] * 4 * (out_kind == 0 ? sizeof(float) : sizeof(double));
+    }
+    if (out->bytes < need) return fail(SVGR_E_INVALID, "output buffer has %zu bytes, needs %zu", out->bytes, need);
+
+    const bool timed = (flags & SVGR_RENDER_TIMED) != 0;
+    TimedEvents ev{};
+    if (timed) {
+        if (int rc = get_event(b, &ev.e0)) return rc;
+        if (int rc = get_event(b, &ev.e1)) return rc;
+        if (int rc = get_event(b, &ev.e2)) return rc;
+        HIPCHK(hipEventRecord(ev.e0, st));
+    }
+    // geometry, identical to plan but without read-backs (capacities are exact for unchanged input)
+    const bool saved_has_vp = b->has_vp;
+    b->has_vp = true;
+    int rc = stage_count(b);
+    if (!rc) rc = stage_emit_bbox(b, true);
+    if (!rc) rc = stage_bin_counts(b);
+    if (!rc) rc = stage_edge_count(b);
+    if (!rc) rc = stage_edge_emit(b);
+    b->has_vp = saved_has_vp;
+    if (rc) return rc;
+    if (single && need) HIPCHK(hipMemsetAsync(out->ptr, 0, need, st));
+    if (timed) HIPCHK(hipEventRecord(ev.e1, st));
+
+    if (owned_bands > 0 && n_ctiles > 0) {
+        TileArgs a;
+        a.band_off = b->band_off.p; a.entries = b->entries.p; a.bbox = b->bbox.p; a.b0 = b->b0.p;
+        a.pb_off = b->pb_off.p; a.bseg_off = b->bseg_off.p; a.bsegs = b->bsegs.p; a.rule = b->path_rule.p;
+        a.paint = b->path_paint.p; a.out = out->ptr;
+        a.vr0 = b->vp[0]; a.vc0 = b->vp[1]; a.vrows = b->vp[2]; a.vcols = b->vp[3];
+        a.band_first = b->band_first; a.band_step = b->band_step;
+        a.out_cols = b->vp[3];
+        a.clip01 = (flags & SVGR_RENDER_CLIP01) ? 1 : 0;
+        a.single_r0 = single_bb[0]; a.single_c0 = single_bb[1]; a.single_cols = single_bb[3];
+        dim3 grid((unsigned)n_ctiles, (unsigned)owned_bands);
+        switch (out_kind) {
+            case 0: hipLaunchKernelGGL(k_tile_render<0>, grid, dim3(NT), 0, st, a); break;
+            case 1: hipLaunchKernelGGL(k_tile_render<1>, grid, dim3(NT), 0, st, a); break;
+            case 2: hipLaunchKernelGGL(k_tile_render<2>, grid, dim3(NT), 0, st, a); break;
+            default: hipLaunchKernelGGL(k_tile_render<3>, grid, dim3(NT), 0, st, a); break;
+        }
+    }
+    if (timed) {
+        HIPCHK(hipEventRecord(ev.e2, st));
+        b->events.push_back(ev);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_batch_timings(svgr_batch* b, int* n_renders, double* ms_total, double* ms_geometry, double* ms_tile) {
+    if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
+    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    double tg = 0, tt = 0;
+    for (auto& e : b->events) {
+        float g = 0, t = 0;
+        HIPCHK(hipEventElapsedTime(&g, e.e0, e.e1));
+        HIPCHK(hipEventElapsedTime(&t, e.e1, e.e2));
+        tg += g;
+        tt += t;
+        b->event_pool.push_back(e.e0);
+        b->event_pool.push_back(e.e1);
+        b->event_pool.push_back(e.e2);
+    }
+    if (n_renders) *n_renders = (int)b->events.size();
+    if (ms_total) *ms_total = tg + tt;
+    if (ms_geometry) *ms_geometry = tg;
+    if (ms_tile) *ms_tile = tt;
+    b->events.clear();
+    if (int rc = check_dev_err(b)) return rc;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// layer ops
+// ---------------------------------------------------------------------------------------------
+static int bbox_ok(const int64_t* bb) {
+    return bb && bb[2] >= 0 && bb[3] >= 0 && bb[2] < (1ll << 30) && bb[3] < (1ll << 30) && std::llabs(bb[0]) < (1ll << 30) &&
+           std::llabs(bb[1]) < (1ll << 30);
+}
+
+int svgr_layer_over(svgr_ctx* ctx, svgr_buf* dst, const int64_t* db, const svgr_buf* src, const int64_t* sb, int ch, int first) {
+    if (!ctx || !dst || !src || !bbox_ok(db) || !bbox_ok(sb) || (ch != 1 && ch != 4)) return fail(SVGR_E_INVALID, "svgr_layer_over: bad arguments");
+    size_t n = (size_t)sb[2] * sb[3];
+    if (dst->bytes < (size_t)db[2] * db[3] * 32 || src->bytes < n * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_over: buffer too small");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_layer_over, grid1(n), dim3(256), 0, ctx->stream, (double*)dst->ptr, (int)db[0], (int)db[1], (int)db[2],
+                       (int)db[3], (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch, first);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_layer_crop4(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr_buf* src, const int64_t* sb, int ch) {
+    if (!ctx || !out || !src || !bbox_ok(ob) || !bbox_ok(sb) || (ch != 1 && ch != 4)) return fail(SVGR_E_INVALID, "svgr_layer_crop4: bad arguments");
+    size_t n = (size_t)ob[2] * ob[3];
+    if (out->bytes < n * 32 || src->bytes < (size_t)sb[2] * sb[3] * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_crop4: buffer too small");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_layer_crop4, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
+                       (int)ob[3], (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_layer_in(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr_buf* src, const int64_t* sb, int ch) {
+    if (!ctx || !out || !src || !bbox_ok(ob) || !bbox_ok(sb) || (ch != 1 && ch != 4)) return fail(SVGR_E_INVALID, "svgr_layer_in: bad arguments");
+    size_t n = (size_t)ob[2] * ob[3];
+    if (out->bytes < n * 32 || src->bytes < (size_t)sb[2] * sb[3] * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_in: buffer too small");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_layer_in, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
+                       (int)ob[3], (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_layer_scale(svgr_ctx* ctx, svgr_buf* img, int64_t n, double f) {
+    if (!ctx || !img || n < 0 || img->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_scale: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_layer_scale, grid1((size_t)n), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n, f);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_layer_convert(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, unsigned ops) {
+    if (!ctx || !img || n_px < 0 || img->bytes < (size_t)n_px * 32 || (ops & ~15u)) return fail(SVGR_E_INVALID, "svgr_layer_convert: bad arguments");
+    if (n_px == 0 || ops == 0) return 0;
+    hipLaunchKernelGGL(k_layer_convert, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n_px, ops);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t n, int clip01) {
+    if (!ctx || !dst || !src || n < 0 || dst->bytes < (size_t)n * 4 || src->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_to_f32: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_to_f32, grid1((size_t)n), dim3(256), 0, ctx->stream, (float*)dst->ptr, (const double*)src->ptr, (size_t)n, clip01);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,375 @@
+"""Host-side geometry types with the reference's names and call signatures.
+
+Mirrors (reference = svgrasterize.py):
+    Transform    S:509-570     affine 3x3 wrapper (points are row vectors, ``points @ M.T + b``)
+    ConvexHull   S:1963-2029   returned by every Path.mask / Path.fill; built lazily here
+    Path         S:896-1103    ``subpaths`` in the reference's own segment format; ``mask`` and
+                               ``fill`` run on the GPU through the C ABI (no CPU fallback)
+Only what the hot path needs is here: no SVG path-data parser beyond a small convenience one,
+no stroker.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import Callable, Iterable, Sequence
+
+import numpy as np
+
+from . import _abi
+from .layer import Layer
+
+FLOAT = np.float64
+
+PATH_LINE, PATH_QUAD, PATH_CUBIC, PATH_ARC, PATH_CLOSED, PATH_UNCLOSED = 0, 1, 2, 3, 4, 5
+PATH_LINES = {PATH_LINE, PATH_CLOSED, PATH_UNCLOSED}
+PATH_FILL_NONZERO = "nonzero"
+PATH_FILL_EVENODD = "evenodd"
+_RULES = {None: 0, PATH_FILL_NONZERO: 0, PATH_FILL_EVENODD: 1}
+
+FLATNESS = 0.1  # S:955
+
+
+# --------------------------------------------------------------------------------------
+# Transform
+# --------------------------------------------------------------------------------------
+class Transform:
+    __slots__ = ["m", "_m_inv"]
+
+    def __init__(self, matrix=None, matrix_inv=None):
+        if matrix is None:
+            self.m = np.identity(3)
+            self._m_inv = self.m
+        else:
+            self.m = matrix
+            self._m_inv = matrix_inv
+
+    def __matmul__(self, other: "Transform") -> "Transform":
+        return Transform(self.m @ other.m)
+
+    @property
+    def invert(self) -> "Transform":
+        if self._m_inv is None:
+            self._m_inv = np.linalg.inv(self.m)
+        return Transform(self._m_inv, self.m)
+
+    def __call__(self, points):
+        """Host evaluation (used for hull / bbox maths, not for rasterisation: the device
+        applies the matrix itself with the same fma form, see csrc/svgr_core.h)."""
+        points = np.asarray(points, dtype=FLOAT)
+        if len(points) == 0:
+            return points
+        return points @ self.m[:2, :2].T + self.m[:2, 2]
+
+    def _chain(self, rhs) -> "Transform":
+        return Transform(self.m @ np.array(rhs, dtype=FLOAT))
+
+    def matrix(self, m00, m01, m02, m10, m11, m12) -> "Transform":
+        return self._chain([[m00, m01, m02], [m10, m11, m12], [0, 0, 1]])
+
+    def translate(self, tx, ty) -> "Transform":
+        return self._chain([[1, 0, tx], [0, 1, ty], [0, 0, 1]])
+
+    def scale(self, sx, sy=None) -> "Transform":
+        sy = sx if sy is None else sy
+        return self._chain([[sx, 0, 0], [0, sy, 0], [0, 0, 1]])
+
+    def rotate(self, angle) -> "Transform":
+        c, s = math.cos(angle), math.sin(angle)
+        return self._chain([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+    def skew(self, ax, ay) -> "Transform":
+        return self._chain([[1, math.tan(ax), 0], [math.tan(ay), 1, 0], [0, 0, 1]])
+
+    def no_translate(self) -> "Transform":
+        m = self.m.copy()
+        m[0, 2] = 0
+        m[1, 2] = 0
+        return Transform(m)
+
+    def m6(self) -> np.ndarray:
+        """The six numbers the C ABI takes: rows 0-1 of the matrix."""
+        return np.ascontiguousarray(self.m[:2, :], dtype=FLOAT).reshape(6)
+
+    def __repr__(self) -> str:
+        return str(np.around(self.m, 4).tolist()[:2])
+
+
+# --------------------------------------------------------------------------------------
+# ConvexHull (lazy)
+# --------------------------------------------------------------------------------------
+def _graham(points: list) -> list:
+    """Monotone-chain convex hull over (row, col) tuples, same tie rules as S:1977-1992."""
+
+    def turn(p, q, r):
+        return (q[0] - p[0]) * (r[1] - p[1]) - (r[0] - p[0]) * (q[1] - p[1])
+
+    def half(seq):
+        out: list = []
+        for p in seq:
+            while len(out) > 1 and turn(out[-2], out[-1], p) <= 0:
+                out.pop()
+            if not out or out[-1] != p:
+                out.append(p)
+        return out
+
+    pts = sorted(points)
+    left = half(pts)
+    right = half(reversed(pts))
+    left.extend(right[1:-1])
+    return left
+
+
+class ConvexHull:
+    """Convex hull of flattened path points in presentation space.
+
+    The reference builds it eagerly from every flattened endpoint on each mask()/fill()
+    (S:993); almost no caller reads it, so here the point source is a thunk that downloads the
+    device edge list only when ``points`` is first touched."""
+
+    __slots__ = ["_points", "_source"]
+
+    def __init__(self, points=None, _source: Callable[[], np.ndarray] | None = None):
+        self._points = None
+        self._source = _source
+        if points is not None:
+            if isinstance(points, np.ndarray):
+                points = points.reshape(-1, 2).tolist()
+            self._points = _graham([list(p) for p in points])
+
+    @property
+    def points(self) -> list:
+        if self._points is None:
+            src = self._source() if self._source is not None else np.zeros((0, 2))
+            self._points = _graham(np.asarray(src, dtype=FLOAT).reshape(-1, 2).tolist())
+            self._source = None
+        return self._points
+
+    @classmethod
+    def merge(cls, hulls: Iterable["ConvexHull"]) -> "ConvexHull":
+        hulls = list(hulls)
+
+        def gather():
+            pts = []
+            for h in hulls:
+                pts.extend(h.points)
+            return np.array(pts, dtype=FLOAT).reshape(-1, 2)
+
+        return cls(_source=gather)
+
+    def bbox(self, transform: Transform):
+        points = transform.invert(np.array(self.points))
+        min_x, min_y = points.min(axis=0)
+        max_x, max_y = points.max(axis=0)
+        return [min_x, min_y, max_x - min_x, max_y - min_y]
+
+    def bbox_transform(self, transform: Transform) -> Transform:
+        x, y, w, h = self.bbox(transform)
+        if w <= 0 and h <= 0:
+            return transform
+        return transform.translate(x, y).scale(w, h)
+
+
+# --------------------------------------------------------------------------------------
+# curve conversions that stay on the host
+# --------------------------------------------------------------------------------------
+_QUAD_TO_CUBIC = np.array([[1, 0, 0], [1.0 / 3, 2.0 / 3, 0], [0, 2.0 / 3.0, 1.0 / 3], [0, 0, 1]], dtype=FLOAT)
+
+
+def quad_to_cubic(points) -> np.ndarray:
+    """Degree elevation of a quadratic Bezier (S:2052-2054, S:2182-2184)."""
+    return _QUAD_TO_CUBIC @ np.asarray(points, dtype=FLOAT)
+
+
+def arc_to_cubics(center, rx, ry, phi, eta, eta_delta) -> np.ndarray:
+    """Elliptical arc (centre parametrisation) -> cubic Beziers of at most pi/4 each (S:2355-2394)."""
+    rot = np.array([[math.cos(phi), -math.sin(phi)], [math.sin(phi), math.cos(phi)]])
+
+    def point(a):
+        return rot @ [rx * math.cos(a), ry * math.sin(a)] + center
+
+    def deriv(a):
+        return rot @ [-rx * math.sin(a), ry * math.cos(a)]
+
+    count = math.ceil(abs(eta_delta) / (math.pi / 4))
+    etas = np.linspace(eta, eta + eta_delta, count + 1)
+    out = []
+    for e1, e2 in zip(etas, etas[1:]):
+        root = math.sqrt(4 + 3 * math.tan((e2 - e1) / 2) ** 2)
+        alpha = math.sin(e2 - e1) * (root - 1) / 3
+        p0, p3 = point(e1), point(e2)
+        out.append([p0, p0 + alpha * deriv(e1), p3 - alpha * deriv(e2), p3])
+    return np.array(out)
+
+
+# --------------------------------------------------------------------------------------
+# Path
+# --------------------------------------------------------------------------------------
+class Path:
+    """Rendering unit; ``subpaths`` uses the reference's segment tuples (S:899-907)."""
+
+    __slots__ = ["subpaths", "_packed"]
+
+    def __init__(self, subpaths):
+        self.subpaths = subpaths
+        self._packed = None
+
+    def __iter__(self):
+        return iter(self.subpaths)
+
+    def __bool__(self) -> bool:
+        return bool(self.subpaths)
+
+    # -- construction helpers ------------------------------------------------------------
+    @classmethod
+    def from_arrays(cls, lines, cubics) -> "Path":
+        """Build a path from (N,2,2) lines and (M,4,2) cubics (scene dumps, synthetic scenes)."""
+        lines = np.asarray(lines, dtype=FLOAT).reshape(-1, 2, 2)
+        cubics = np.asarray(cubics, dtype=FLOAT).reshape(-1, 4, 2)
+        path = cls([[(PATH_LINE, l) for l in lines] + [(PATH_CUBIC, c) for c in cubics]])
+        segs = np.zeros((len(lines) + len(cubics), 8))
+        segs[: len(lines), :4] = lines.reshape(-1, 4)
+        segs[len(lines):] = cubics.reshape(-1, 8)
+        kinds = np.zeros(len(segs), dtype=np.uint8)
+        kinds[len(lines):] = _abi.SEG_CUBIC
+        path._packed = (segs, kinds)
+        return path
+
+    @classmethod
+    def from_segments(cls, seg_types, seg_params, subpath_sizes) -> "Path":
+        """Rebuild ``subpaths`` from flat arrays (type code, 8 numbers per segment)."""
+        subpaths, k = [], 0
+        for n in subpath_sizes:
+            sub = []
+            for _ in range(int(n)):
+                t, p = int(seg_types[k]), np.asarray(seg_params[k], dtype=FLOAT)
+                if t in PATH_LINES:
+                    sub.append((t, p[:4].reshape(2, 2)))
+                elif t == PATH_QUAD:
+                    sub.append((t, p[:6].reshape(3, 2)))
+                elif t == PATH_CUBIC:
+                    sub.append((t, p[:8].reshape(4, 2)))
+                elif t == PATH_ARC:
+                    sub.append((t, (p[:2].copy(), p[2], p[3], p[4], p[5], p[6])))
+                else:
+                    raise ValueError(f"unsupported path type: `{t}`")
+                k += 1
+            subpaths.append(sub)
+        return cls(subpaths)
+
+    def packed(self):
+        """(segs (n, 8), kinds (n,)) in user space: explicit lines first, then cubics, as the
+        reference gathers ``lines_defs`` / ``cubics_defs`` (S:930-945)."""
+        if self._packed is None:
+            lines, cubics = [], []
+            for sub in self.subpaths:
+                for seg in sub:
+                    t = seg[0]
+                    if t in PATH_LINES:
+                        lines.append(np.asarray(seg[1], dtype=FLOAT).reshape(4))
+                    elif t == PATH_CUBIC:
+                        cubics.append(np.asarray(seg[1], dtype=FLOAT).reshape(8))
+                    elif t == PATH_QUAD:
+                        cubics.append(quad_to_cubic(seg[1]).reshape(8))
+                    elif t == PATH_ARC:
+                        cubics.extend(c.reshape(8) for c in arc_to_cubics(*seg[1]))
+                    else:
+                        raise ValueError(f"unsupported path type: `{t}`")
+            segs = np.zeros((len(lines) + len(cubics), 8))
+            if lines:
+                segs[: len(lines), :4] = np.array(lines)
+            if cubics:
+                segs[len(lines):] = np.array(cubics)
+            kinds = np.zeros(len(segs), dtype=np.uint8)
+            kinds[len(lines):] = _abi.SEG_CUBIC
+            self._packed = (segs, kinds)
+        return self._packed
+
+    # -- the hot path ---------------------------------------------------------------------
+    def _single_batch(self, transform: Transform, fill_rule, viewport, paint=None):
+        if fill_rule not in _RULES:
+            raise ValueError(f"Invalid fill rule: {fill_rule}")
+        segs, kinds = self.packed()
+        if len(segs) == 0:
+            return None
+        ctx = _abi.Context.get()
+        vp = None
+        if viewport is not None:
+            vp = [int(v) for v in viewport]
+        batch = _abi.Batch(
+            ctx, segs, kinds, [0, len(segs)], transform.m6(), [_RULES[fill_rule]],
+            [paint if paint is not None else np.zeros(4)], viewport=vp, flatness=FLATNESS,
+        )
+        batch.plan()
+        bb = batch.bboxes()[0]
+        if bb[2] <= 0 or bb[3] <= 0:
+            batch.destroy()
+            return None
+        return ctx, batch, bb
+
+    def mask(self, transform: Transform, fill_rule: str | None = None, viewport=None):
+        """Render path as a mask (alpha channel only image), S:922-993.
+
+        Returns ``(Layer, ConvexHull)`` or ``None``; the layer's image stays in HBM until read."""
+        res = self._single_batch(transform, fill_rule, viewport)
+        if res is None:
+            return None
+        ctx, batch, bb = res
+        rows, cols = int(bb[2]), int(bb[3])
+        buf = ctx.alloc(rows * cols * 8)
+        batch.render(buf, _abi.OUT_MASK_F64)
+        offset = _offset(bb, viewport)
+        layer = Layer._from_device(buf, (rows, cols, 1), offset, pre_alpha=True, linear_rgb=True)
+        return layer, ConvexHull(_source=lambda: batch.edges()[0])
+
+    def fill(self, transform: Transform, paint, fill_rule: str | None = None, viewport=None, linear_rgb: bool = True):
+        """Render path by fill-ing it, S:995-1103 (solid colours; gradients/patterns: not yet)."""
+        if paint is None:
+            return None
+        if isinstance(paint, np.ndarray) and paint.shape == (4,):
+            paint = solid_paint(paint, linear_rgb)
+            res = self._single_batch(transform, fill_rule, viewport, paint)
+            if res is None:
+                return None
+            ctx, batch, bb = res
+            rows, cols = int(bb[2]), int(bb[3])
+            buf = ctx.alloc(rows * cols * 32)
+            batch.render(buf, _abi.OUT_FILL_F64)
+            layer = Layer._from_device(buf, (rows, cols, 4), _offset(bb, viewport), pre_alpha=True, linear_rgb=linear_rgb)
+            return layer, ConvexHull(_source=lambda: batch.edges()[0])
+        from .paint import is_gradient  # noqa: PLC0415  (kept separate: config 5 work)
+
+        if is_gradient(paint):
+            raise NotImplementedError("gradient paints are the next scope row (SURVEY 8a-a16); not built yet")
+        warnings.warn(f"fill method is not implemented: {paint}")
+        return None
+
+    # -- convenience ------------------------------------------------------------------------
+    @classmethod
+    def from_svg(cls, d: str) -> "Path":
+        from .pathdata import parse_path_data  # noqa: PLC0415
+
+        return cls(parse_path_data(d))
+
+
+def _offset(bb, viewport):
+    """Layer.offset: np.int64 when unclipped, Python int when viewport-clipped."""
+    if viewport is None:
+        return (np.int64(bb[0]), np.int64(bb[1]))
+    return (int(bb[0]), int(bb[1]))
+
+
+def solid_paint(paint: np.ndarray, linear_rgb: bool) -> np.ndarray:
+    """The 4-vector colour step of Path.fill (S:1014-1018): premultiplied linear RGBA ->
+    premultiplied RGBA of the compositing space.  Four numbers, done on the host in double."""
+    out = np.array(paint, dtype=FLOAT)
+    if not linear_rgb:
+        rgb, alpha = out[:3], out[3:]
+        np.divide(rgb, alpha, out=rgb, where=alpha > 0.0001)
+        np.clip(out, 0, 1, out=out)
+        small = rgb <= 0.0031308
+        rgb[small] = rgb[small] * 12.92
+        large = ~small
+        rgb[large] = 1.055 * np.power(rgb[large], 1.0 / 2.4) - 0.055
+        rgb *= alpha
+    return out

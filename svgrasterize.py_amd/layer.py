@@ -1,0 +1,238 @@
+"""Layer: the value type of the hot path (reference S:61-233), with the image resident in HBM.
+
+The reference's Layer is ``NamedTuple(image, offset, pre_alpha, linear_rgb)`` whose image is a
+float64 numpy array of shape (rows, cols, 1|4).  This class keeps the same four fields, the same
+tuple unpacking and the same methods, but the pixels live in a device buffer until somebody
+reads ``.image``; from then on the materialised numpy array is the source of truth (callers such
+as the reference's font_speciment.py mutate it in place) and device ops re-upload it.
+
+compose / convert / opacity run as HIP kernels on double images with the reference's operation
+order (csrc/svgr_hip.hip: k_layer_*).
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+
+from . import _abi
+
+COMPOSE_OVER, COMPOSE_OUT, COMPOSE_IN, COMPOSE_ATOP, COMPOSE_XOR = 0, 1, 2, 3, 4
+COMPOSE_PRE_ALPHA = {COMPOSE_OVER, COMPOSE_OUT, COMPOSE_IN, COMPOSE_ATOP, COMPOSE_XOR}
+FLOAT = np.float64
+
+
+def _bbox_arr(offset, shape):
+    import ctypes as C
+
+    return (C.c_int64 * 4)(int(offset[0]), int(offset[1]), int(shape[0]), int(shape[1]))
+
+
+class Layer:
+    __slots__ = ["_host", "_dev", "_shape", "offset", "pre_alpha", "linear_rgb"]
+
+    def __init__(self, image, offset, pre_alpha: bool, linear_rgb: bool):
+        image = np.asarray(image)
+        if image.ndim != 3 or image.shape[2] not in (1, 4):
+            raise ValueError("Layer image must have shape (rows, cols, 1|4)")
+        self._host = image
+        self._dev = None
+        self._shape = tuple(image.shape)
+        self.offset = offset
+        self.pre_alpha = pre_alpha
+        self.linear_rgb = linear_rgb
+
+    @classmethod
+    def _from_device(cls, buf: "_abi.DeviceBuffer", shape, offset, pre_alpha, linear_rgb) -> "Layer":
+        self = object.__new__(cls)
+        self._host = None
+        self._dev = buf
+        self._shape = tuple(int(s) for s in shape)
+        self.offset = offset
+        self.pre_alpha = pre_alpha
+        self.linear_rgb = linear_rgb
+        return self
+
+    # -- NamedTuple compatibility ---------------------------------------------------------
+    def __iter__(self):
+        yield self.image
+        yield self.offset
+        yield self.pre_alpha
+        yield self.linear_rgb
+
+    def __len__(self):
+        return 4
+
+    def __getitem__(self, i):
+        return (self.image, self.offset, self.pre_alpha, self.linear_rgb)[i]
+
+    @property
+    def image(self) -> np.ndarray:
+        if self._host is None:
+            self._host = self._dev.download(self._shape, FLOAT)
+            self._dev = None  # the host array may be mutated by the caller from now on
+        return self._host
+
+    # -- device residency -----------------------------------------------------------------
+    def _device(self) -> "_abi.DeviceBuffer":
+        """Device buffer holding the current pixels as float64 (uploads a host-resident image)."""
+        if self._host is not None:
+            return _abi.Context.get().from_host(np.ascontiguousarray(self._host, dtype=FLOAT))
+        return self._dev
+
+    @property
+    def on_device(self) -> bool:
+        return self._host is None
+
+    # -- reference properties --------------------------------------------------------------
+    @property
+    def x(self) -> int:
+        return self.offset[0]
+
+    @property
+    def y(self) -> int:
+        return self.offset[1]
+
+    @property
+    def width(self) -> int:
+        return self._shape[1]
+
+    @property
+    def height(self) -> int:
+        return self._shape[0]
+
+    @property
+    def channels(self) -> int:
+        return self._shape[2]
+
+    @property
+    def bbox(self):
+        return (*self.offset, *self._shape[:2])
+
+    def translate(self, x: int, y: int) -> "Layer":
+        out = object.__new__(Layer)
+        out._host, out._dev, out._shape = self._host, self._dev, self._shape
+        out.offset = (self.x + x, self.y + y)
+        out.pre_alpha, out.linear_rgb = self.pre_alpha, self.linear_rgb
+        return out
+
+    def _retag(self, pre_alpha, linear_rgb) -> "Layer":
+        out = object.__new__(Layer)
+        out._host, out._dev, out._shape = self._host, self._dev, self._shape
+        out.offset, out.pre_alpha, out.linear_rgb = self.offset, pre_alpha, linear_rgb
+        return out
+
+    def _copy_device(self) -> "_abi.DeviceBuffer":
+        ctx = _abi.Context.get()
+        if self._host is not None:
+            return ctx.from_host(np.ascontiguousarray(self._host, dtype=FLOAT))
+        n = int(np.prod(self._shape))
+        out = ctx.alloc(n * 8)
+        _abi._check(ctx.lib.svgr_buf_copy(ctx.handle, out.handle, self._dev.handle, n * 8))
+        return out
+
+    # -- Layer.convert  S:129-164 ----------------------------------------------------------
+    def convert(self, pre_alpha: bool | None = None, linear_rgb: bool | None = None) -> "Layer":
+        pre_alpha = self.pre_alpha if pre_alpha is None else pre_alpha
+        linear_rgb = self.linear_rgb if linear_rgb is None else linear_rgb
+        if self.channels == 1:
+            return self._retag(pre_alpha, linear_rgb)  # single channel is alpha: flags only
+        ops = 0
+        cur_pre = self.pre_alpha
+        if self.linear_rgb != linear_rgb:
+            if cur_pre:
+                ops |= _abi.CONVERT_PRE_TO_STRAIGHT
+                cur_pre = False
+            ops |= _abi.CONVERT_SRGB_TO_LINEAR if linear_rgb else _abi.CONVERT_LINEAR_TO_SRGB
+        if cur_pre != pre_alpha:
+            # the kernel applies 1,2,4,8 in that order; "straight -> pre" is last, "pre -> straight" first
+            if pre_alpha:
+                ops |= _abi.CONVERT_STRAIGHT_TO_PRE
+            else:
+                ops |= _abi.CONVERT_PRE_TO_STRAIGHT
+        if ops == 0:
+            return self
+        ctx = _abi.Context.get()
+        buf = self._copy_device()
+        _abi._check(ctx.lib.svgr_layer_convert(ctx.handle, buf.handle, self._shape[0] * self._shape[1], ops))
+        return Layer._from_device(buf, self._shape, self.offset, pre_alpha, linear_rgb)
+
+    # -- Layer.opacity  S:171-175 ----------------------------------------------------------
+    def opacity(self, opacity: float, linear_rgb: bool = False) -> "Layer":
+        layer = self.convert(pre_alpha=True, linear_rgb=linear_rgb)
+        ctx = _abi.Context.get()
+        buf = layer._copy_device()
+        _abi._check(ctx.lib.svgr_layer_scale(ctx.handle, buf.handle, int(np.prod(layer._shape)), float(opacity)))
+        return Layer._from_device(buf, layer._shape, layer.offset, True, linear_rgb)
+
+    # -- Layer.compose  S:177-207 ----------------------------------------------------------
+    @staticmethod
+    def compose(layers: Sequence["Layer"], method: int = COMPOSE_OVER, linear_rgb: bool = False) -> "Layer | None":
+        if not layers:
+            return None
+        if len(layers) == 1:
+            return layers[0]  # returned as is, unconverted (S:190-191)
+        if method not in COMPOSE_PRE_ALPHA:
+            if isinstance(method, tuple) and len(method) == 4:
+                raise NotImplementedError("arithmetic compose (feComposite) is outside the hot path (SURVEY 8f-4)")
+            raise ValueError(f"invalid compose mode: {method}")
+        if method not in (COMPOSE_OVER, COMPOSE_IN):
+            raise NotImplementedError("only COMPOSE_OVER and COMPOSE_IN are on the hot path (SURVEY 8a-a12/a13)")
+        conv = [l.convert(pre_alpha=True, linear_rgb=linear_rgb) for l in layers]
+        ctx = _abi.Context.get()
+        lib = ctx.lib
+        if method == COMPOSE_OVER:
+            r0 = min(int(l.x) for l in conv)
+            c0 = min(int(l.y) for l in conv)
+            r1 = max(int(l.x) + l.height for l in conv)
+            c1 = max(int(l.y) + l.width for l in conv)
+            shape = (r1 - r0, c1 - c0, 4)
+            out = ctx.alloc(shape[0] * shape[1] * 32)
+            out.zero()
+            dbb = _bbox_arr((r0, c0), shape)
+            for i, l in enumerate(conv):
+                src = l._device()
+                _abi._check(lib.svgr_layer_over(ctx.handle, out.handle, dbb, src.handle, _bbox_arr(l.offset, l._shape),
+                                                l.channels, int(i == 0)))
+            offset = (min(l.x for l in conv), min(l.y for l in conv))
+            return Layer._from_device(out, shape, offset, True, linear_rgb)
+        # COMPOSE_IN: intersection, S:382-416
+        r0 = max(int(l.x) for l in conv)
+        c0 = max(int(l.y) for l in conv)
+        r1 = min(int(l.x) + l.height for l in conv)
+        c1 = min(int(l.y) + l.width for l in conv)
+        if r0 >= r1 or c0 >= c1:
+            return None
+        shape = (r1 - r0, c1 - c0, 4)
+        out = ctx.alloc(shape[0] * shape[1] * 32)
+        obb = _bbox_arr((r0, c0), shape)
+        first = conv[0]
+        src = first._device()  # keep the (possibly temporary) buffer referenced while the kernel is enqueued
+        _abi._check(lib.svgr_layer_crop4(ctx.handle, out.handle, obb, src.handle,
+                                         _bbox_arr(first.offset, first._shape), first.channels))
+        for l in conv[1:]:
+            src = l._device()
+            _abi._check(lib.svgr_layer_in(ctx.handle, out.handle, obb, src.handle, _bbox_arr(l.offset, l._shape),
+                                          l.channels))
+        offset = (max(l.x for l in conv), max(l.y for l in conv))
+        return Layer._from_device(out, shape, offset, True, linear_rgb)
+
+    def to_canvas_f32(self, rows: int, cols: int, clip01: bool = True) -> np.ndarray:
+        """Place this layer on a zero (rows, cols, 4) canvas (canvas_merge_at, S:304-327) and
+        return float32 premultiplied RGBA."""
+        ctx = _abi.Context.get()
+        layer = self.convert(pre_alpha=True)
+        canvas = ctx.alloc(rows * cols * 32)
+        canvas.zero()
+        src = layer._device()
+        _abi._check(ctx.lib.svgr_layer_over(ctx.handle, canvas.handle, _bbox_arr((0, 0), (rows, cols)),
+                                            src.handle, _bbox_arr(layer.offset, layer._shape),
+                                            layer.channels, 0))
+        out32 = ctx.alloc(rows * cols * 16)
+        _abi._check(ctx.lib.svgr_layer_to_f32(ctx.handle, out32.handle, canvas.handle, rows * cols * 4, int(clip01)))
+        return out32.download((rows, cols, 4), np.float32)
+
+    def __repr__(self):
+        return "Layer(x={}, y={}, w={}, h={}, pre_alpha={}, linear_rgb={})".format(
+            self.x, self.y, self.width, self.height, self.pre_alpha, self.linear_rgb
+        )

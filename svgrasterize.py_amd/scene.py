@@ -1,0 +1,268 @@
+"""Scene graph + renderer: the caller of the hot path (reference S:576-859).
+
+Same node types, constructors and ``render`` signature as the reference.  ``render`` has two
+routes, both of them HIP:
+
+* batched: a maximal run of solid-colour FILL leaves (under GROUP / TRANSFORM nodes, optionally
+  one OPACITY directly above a leaf) is handed to the device as ONE paint-ordered batch
+  (``svgr_batch_render``) that flattens, bins and composites all of them in a single tile kernel.
+  This is what SURVEY 7-5 asks for: per-path launches cannot win.
+* per node: everything else (CLIP, OPACITY over a group, nested results) is rendered node by node
+  into device-resident Layers and merged with ``Layer.compose`` exactly as the reference does.
+
+Not built yet: STROKE of an un-stroked path (scene dumps carry the
+stroked outline instead), luminance MASK, FILTER, gradient / pattern paints.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _abi
+from .geometry import ConvexHull, Path, Transform, solid_paint, _RULES, FLATNESS
+from .layer import COMPOSE_IN, COMPOSE_OVER, Layer
+
+RENDER_FILL, RENDER_STROKE, RENDER_GROUP, RENDER_OPACITY = 0, 1, 2, 3
+RENDER_CLIP, RENDER_MASK, RENDER_TRANSFORM, RENDER_FILTER = 4, 5, 6, 7
+
+
+class Scene(tuple):
+    __slots__ = []
+
+    def __new__(cls, type, args):
+        return tuple.__new__(cls, (type, args))
+
+    # -- constructors (S:604-647) ----------------------------------------------------------
+    @classmethod
+    def fill(cls, path: Path, paint, fill_rule=None) -> "Scene":
+        return cls(RENDER_FILL, (path, paint, fill_rule))
+
+    @classmethod
+    def stroke(cls, path: Path, paint, width: float, linecap=None, linejoin=None) -> "Scene":
+        return cls(RENDER_STROKE, (path, paint, width, linecap, linejoin))
+
+    @classmethod
+    def group(cls, children) -> "Scene":
+        children = tuple(children)
+        if not children:
+            raise ValueError("group have to contain at least one child")
+        if len(children) == 1:
+            return children[0]
+        return cls(RENDER_GROUP, children)
+
+    def opacity(self, opacity: float) -> "Scene":
+        if opacity > 0.999:
+            return self
+        return Scene(RENDER_OPACITY, (self, opacity))
+
+    def clip(self, clip: "Scene", bbox_units: bool = False) -> "Scene":
+        return Scene(RENDER_CLIP, (self, clip, bbox_units))
+
+    def mask(self, mask: "Scene", bbox_units: bool = False) -> "Scene":
+        return Scene(RENDER_MASK, (self, mask, bbox_units))
+
+    def transform(self, transform: Transform) -> "Scene":
+        type, args = self
+        if type == RENDER_TRANSFORM:
+            target, target_transform = args
+            return Scene(RENDER_TRANSFORM, (target, transform @ target_transform))
+        return Scene(RENDER_TRANSFORM, (self, transform))
+
+    def filter(self, filter) -> "Scene":
+        return Scene(RENDER_FILTER, (self, filter))
+
+    # -- render (S:649-752) ------------------------------------------------------------------
+    def render(self, transform: Transform, mask_only: bool = False, viewport=None, linear_rgb: bool = False):
+        """Render graph; returns ``(Layer, ConvexHull)`` or ``None``."""
+        kind, args = self
+        if kind == RENDER_FILL:
+            path, paint, fill_rule = args
+            if mask_only:
+                return path.mask(transform, fill_rule=fill_rule, viewport=viewport)
+            return path.fill(transform, paint, fill_rule=fill_rule, viewport=viewport, linear_rgb=linear_rgb)
+
+        if kind == RENDER_STROKE:
+            raise NotImplementedError(
+                "Path.stroke is not part of the accelerated path yet (SURVEY 8f-1); "
+                "scene dumps store the stroked outline as a FILL node"
+            )
+
+        if kind == RENDER_GROUP:
+            layers, hulls = [], []
+            run: list = []  # pending batchable leaves: (path, m6, rule, paint4)
+
+            def flush():
+                if not run:
+                    return
+                res = _render_run(run, viewport, linear_rgb)
+                run.clear()
+                if res is not None:
+                    layers.append(res[0])
+                    hulls.append(res[1])
+
+            for child in args:
+                leaves = None if mask_only else _batchable_leaves(child, transform, linear_rgb)
+                if leaves is not None:
+                    run.extend(leaves)
+                    continue
+                flush()
+                res = child.render(transform, mask_only, viewport, linear_rgb)
+                if res is None:
+                    continue
+                layers.append(res[0])
+                hulls.append(res[1])
+            flush()
+            group = Layer.compose(layers, COMPOSE_OVER, linear_rgb)
+            if not group:
+                return None
+            return group, ConvexHull.merge(hulls)
+
+        if kind == RENDER_OPACITY:
+            target, opacity = args
+            res = target.render(transform, mask_only, viewport, linear_rgb)
+            if res is None:
+                return None
+            layer, hull = res
+            return layer.opacity(opacity, linear_rgb), hull
+
+        if kind == RENDER_CLIP:
+            target, clip, bbox_units = args
+            res = target.render(transform, mask_only, viewport, linear_rgb)
+            if res is None:
+                return None
+            image, hull = res
+            if bbox_units:
+                transform = hull.bbox_transform(transform)
+            clip_res = clip.render(transform, True, viewport, linear_rgb)
+            if clip_res is None:
+                return None
+            mask, _ = clip_res
+            result = Layer.compose([mask, image], COMPOSE_IN, linear_rgb)
+            if result is None:
+                return None
+            return result, hull
+
+        if kind == RENDER_TRANSFORM:
+            target, target_transform = args
+            return target.render(transform @ target_transform, mask_only, viewport, linear_rgb)
+
+        if kind == RENDER_MASK:
+            raise NotImplementedError("luminance masks are outside the accelerated path (SURVEY 8f-4)")
+        if kind == RENDER_FILTER:
+            raise NotImplementedError("filters are outside the accelerated path for now (SURVEY 8a-a17 / 8f-4)")
+        raise ValueError(f"unhandled scene type: {kind}")
+
+    # -- whole-scene batched render: the bench / production entry -----------------------------
+    def leaves(self, transform: Transform, linear_rgb: bool = False):
+        """Flatten to paint-ordered solid leaves if the whole scene is batchable, else None."""
+        return _batchable_leaves(self, transform, linear_rgb)
+
+
+def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opacity: float | None = None):
+    """[(path, m6, rule, paint4)] when `scene` is only GROUP / TRANSFORM / solid FILL /
+    OPACITY-directly-over-a-leaf; None otherwise.  Source-over is associative, so flattening
+    nested groups keeps the per-pixel result (to double rounding)."""
+    kind, args = scene
+    if kind == RENDER_FILL:
+        path, paint, rule = args
+        if paint is None:
+            return []
+        if not (isinstance(paint, np.ndarray) and paint.shape == (4,)):
+            return None
+        if rule not in _RULES:
+            raise ValueError(f"Invalid fill rule: {rule}")
+        p4 = solid_paint(paint, linear_rgb)
+        if opacity is not None:
+            p4 = p4 * opacity  # Layer.opacity: image * opacity (S:174)
+        return [(path, transform.m6(), _RULES[rule], p4)]
+    if kind == RENDER_TRANSFORM:
+        return _batchable_leaves(args[0], transform @ args[1], linear_rgb, opacity)
+    if kind == RENDER_OPACITY and opacity is None:
+        target = args[0]
+        while target[0] == RENDER_TRANSFORM:
+            target = target[1][0]
+        if target[0] == RENDER_FILL:  # opacity over a single leaf commutes with the fill
+            return _batchable_leaves(args[0], transform, linear_rgb, args[1])
+        return None
+    if kind == RENDER_GROUP and opacity is None:
+        out = []
+        for child in args:
+            sub = _batchable_leaves(child, transform, linear_rgb)
+            if sub is None:
+                return None
+            out.extend(sub)
+        return out
+    return None
+
+
+def build_batch(leaves, viewport, ctx=None) -> "_abi.Batch":
+    """Pack paint-ordered leaves [(path, m6, rule, paint4)] into one device batch."""
+    ctx = ctx or _abi.Context.get()
+    segs, kinds, offs, m6s, rules, paints = [], [], [0], [], [], []
+    for path, m6, rule, paint in leaves:
+        s, k = path.packed()
+        segs.append(s)
+        kinds.append(k)
+        offs.append(offs[-1] + len(s))
+        m6s.append(m6)
+        rules.append(rule)
+        paints.append(paint)
+    segs = np.concatenate(segs) if segs else np.zeros((0, 8))
+    kinds = np.concatenate(kinds) if kinds else np.zeros(0, dtype=np.uint8)
+    vp = None if viewport is None else [int(v) for v in viewport]
+    return _abi.Batch(ctx, segs, kinds, offs, np.array(m6s), rules, np.array(paints), viewport=vp, flatness=FLATNESS)
+
+
+def _render_run(leaves, viewport, linear_rgb):
+    """One batch -> one Layer covering the union of the leaves' bboxes (what Layer.compose of
+    the individual fill layers returns, S:366-379)."""
+    leaves = [l for l in leaves if len(l[0].packed()[0])]
+    if not leaves:
+        return None
+    ctx = _abi.Context.get()
+    batch = build_batch(leaves, viewport, ctx)
+    st = batch.plan()
+    if st.n_nonempty == 0:
+        batch.destroy()
+        return None
+    ur0, uc0, urows, ucols = (int(v) for v in st.bbox_union)
+    if viewport is None:
+        vp = (ur0, uc0, urows, ucols)
+    else:
+        vp = tuple(int(v) for v in viewport)
+    canvas = ctx.alloc(vp[2] * vp[3] * 32)
+    batch.render(canvas, _abi.OUT_CANVAS_F64)
+    shape = (urows, ucols, 4)
+    if (ur0, uc0, urows, ucols) != vp:
+        out = ctx.alloc(urows * ucols * 32)
+        from .layer import _bbox_arr
+
+        _abi._check(ctx.lib.svgr_layer_crop4(ctx.handle, out.handle, _bbox_arr((ur0, uc0), shape), canvas.handle,
+                                             _bbox_arr(vp[:2], vp[2:]), 4))
+        canvas.free()
+    else:
+        out = canvas
+    layer = Layer._from_device(out, shape, (ur0, uc0), True, linear_rgb)
+    hull = ConvexHull(_source=lambda: batch.edges()[0])
+    return layer, hull
+
+
+def render_canvas(scene_or_leaves, transform: Transform | None, viewport, linear_rgb: bool = False,
+                  out_f64: bool = False, clip01: bool = True):
+    """Production entry: whole scene -> (rows, cols, 4) premultiplied canvas over `viewport`,
+    float32 by default.  Equivalent to the reference CLI's render + ``canvas_merge_at`` on a zero
+    canvas (S:3857-3875) for scenes made of solid fills; returns (canvas ndarray, stats)."""
+    if isinstance(scene_or_leaves, Scene):
+        leaves = _batchable_leaves(scene_or_leaves, transform, linear_rgb)
+        if leaves is None:
+            raise NotImplementedError("scene contains nodes outside the batched path; use Scene.render")
+    else:
+        leaves = scene_or_leaves
+    ctx = _abi.Context.get()
+    batch = build_batch(leaves, viewport, ctx)
+    st = batch.plan()
+    rows, cols = int(viewport[2]), int(viewport[3])
+    out = ctx.alloc(rows * cols * (32 if out_f64 else 16))
+    batch.render(out, _abi.OUT_CANVAS_F64 if out_f64 else _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01 if clip01 else 0)
+    img = out.download((rows, cols, 4), np.float64 if out_f64 else np.float32)
+    batch.destroy()
+    return img, st

@@ -1,0 +1,257 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference's golden fixtures and
+against the CPU oracle on the same seeded inputs.  Run with `pytest -m gpu` on an MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import GOLDEN, assert_close64, assert_f32_1ulp, load, meta, sort_edges
+
+pytestmark = pytest.mark.gpu
+
+F64_TOL = 1e-11  # double results differ from the reference only by summation order (atomics, tile carry-in)
+
+
+@pytest.fixture(scope="module")
+def S():
+    import svgrasterize_amd as S
+
+    S.Context.get()  # fails loudly without a gfx950 device / built library
+    return S
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+
+    oracle.lib()
+    return oracle
+
+
+def test_context(S):
+    name = S.Context.get().name()
+    assert "gfx950" in name, name
+
+
+# ------------------------------------------------------------------------------------------
+# flatten: edge SET is bit-exact with the reference (order is curve order instead of level order)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["rand_small", "rand_big", "tiny_curves", "degenerate", "tiger512"])
+def test_flatten_edge_set_bit_exact(S, name):
+    from svgrasterize_amd import _abi
+
+    g = load("flatten_kat.npz")
+    cubics = g[name + "_in"].reshape(-1, 8)
+    n = len(cubics)
+    ident = np.array([1.0, 0, 0, 0, 1, 0])
+    batch = _abi.Batch(S.Context.get(), cubics, np.ones(n, np.uint8), [0, n], ident, [0], [[0, 0, 0, 1]], viewport=None)
+    st = batch.plan()
+    edges, edge_path = batch.edges()
+    ref = g[name + "_edges"]
+    assert st.n_edges == len(ref)
+    assert np.array_equal(sort_edges(edges), sort_edges(ref))
+    assert not edge_path.any()
+
+
+def test_transform_on_device_bit_exact(S):
+    """Transform.__call__ fma form (S:531-534): straight lines through the device transform."""
+    from svgrasterize_amd import _abi
+
+    g = load("flatten_kat.npz")
+    for m, pts, out in zip(g["tr_m"][:8], g["tr_in"][:8], g["tr_out"][:8]):
+        lines_in = pts.reshape(-1, 2, 2)
+        segs = np.zeros((len(lines_in), 8))
+        segs[:, :4] = lines_in.reshape(-1, 4)
+        batch = _abi.Batch(S.Context.get(), segs, np.zeros(len(segs), np.uint8), [0, len(segs)], m[:2].reshape(6), [0],
+                           [[0, 0, 0, 1]], viewport=None)
+        batch.plan()
+        edges, _ = batch.edges()
+        assert np.array_equal(edges.reshape(-1, 4), out.reshape(-1, 4))
+
+
+# ------------------------------------------------------------------------------------------
+# Path.mask / Path.fill against the reference's own outputs
+# ------------------------------------------------------------------------------------------
+def _cases():
+    g = load("mask_kat.npz")
+    return g, meta(g)
+
+
+def test_mask_fill_kat(S):
+    g, cases = _cases()
+    for idx, m in enumerate(cases):
+        path = S.Path.from_segments(g[f"{idx}_segt"], g[f"{idx}_segp"], g[f"{idx}_subs"])
+        tr = S.Transform(g[f"{idx}_tr"])
+        if m["has_paint"]:
+            res = path.fill(tr, g[f"{idx}_paint"], fill_rule=m["rule"], viewport=m["viewport"], linear_rgb=m["linear_rgb"])
+        else:
+            res = path.mask(tr, fill_rule=m["rule"], viewport=m["viewport"])
+        if m["none"]:
+            assert res is None, m["name"]
+            continue
+        assert res is not None, m["name"]
+        layer, hull = res
+        ref = g[f"{idx}_image"]
+        assert [int(layer.offset[0]), int(layer.offset[1])] == m["offset"], m["name"]  # integer pixel indices: exact
+        assert layer.image.shape == ref.shape, m["name"]
+        assert layer.pre_alpha == m["pre_alpha"] and layer.linear_rgb == m["layer_linear_rgb"]
+        assert_close64(layer.image, ref, atol=F64_TOL, what=m["name"])
+        assert_f32_1ulp(layer.image.astype(np.float32), ref, what=m["name"])
+        if m["viewport"] is None:  # the hull is only compared where arcs/quads are absent or host conversion is exact
+            assert np.allclose(np.array(hull.points), g[f"{idx}_hull"], atol=1e-9), m["name"]
+
+
+def test_mask_errors(S):
+    p = S.Path.from_svg("M1,1 L5,1 L3,4 Z")
+    with pytest.raises(ValueError):
+        p.mask(S.Transform(), fill_rule="bogus")
+    assert S.Path([]).mask(S.Transform()) is None
+    assert p.fill(S.Transform(), None) is None
+
+
+def test_path_data_reader_matches_fixture_segments(S):
+    g, cases = _cases()
+    for idx, m in enumerate(cases):
+        a = S.Path.from_svg(m["d"]).packed()[0]
+        b = S.Path.from_segments(g[f"{idx}_segt"], g[f"{idx}_segp"], g[f"{idx}_subs"]).packed()[0]
+        assert a.shape == b.shape and np.allclose(a, b, atol=1e-9), m["name"]
+
+
+# ------------------------------------------------------------------------------------------
+# Layer.compose / convert / opacity
+# ------------------------------------------------------------------------------------------
+def test_compose_kat(S):
+    g = load("compose_kat.npz")
+    for idx, m in enumerate(meta(g)):
+        ins = [S.Layer(g[f"{idx}_in{j}"].copy(), tuple(d["offset"]), d["pre_alpha"], d["linear_rgb"]) for j, d in enumerate(m["in"])]
+        tag = m["tag"]
+        if tag in ("over", "over_convert", "in", "in_empty"):
+            out = S.Layer.compose(ins, m["method"], m["linear_rgb"])
+        elif tag == "full":
+            with pytest.raises(NotImplementedError):
+                S.Layer.compose(ins, m["method"], m["linear_rgb"])
+            continue
+        elif tag == "convert":
+            out = ins[0].convert(pre_alpha=m["to_pre_alpha"], linear_rgb=m["to_linear_rgb"])
+        elif tag == "opacity":
+            out = ins[0].opacity(m["opacity"], m["linear_rgb"])
+        if m["none"]:
+            assert out is None
+            continue
+        assert list(map(int, out.offset)) == m["offset"], (tag, idx)
+        assert out.pre_alpha == m["pre_alpha"] and out.linear_rgb == m["linear_rgb"], (tag, idx)
+        tol = 0.0 if tag in ("over", "in") else 1e-15  # device pow vs numpy pow: last-bit differences
+        assert_close64(out.image, g[f"{idx}_out"], atol=tol, what=f"{tag} {idx}")
+    with pytest.raises(ValueError):
+        S.Layer.compose(ins * 2, 99)
+    assert S.Layer.compose([]) is None
+
+
+# ------------------------------------------------------------------------------------------
+# scenes
+# ------------------------------------------------------------------------------------------
+def _render_dump(S, name, tag):
+    from svgrasterize_amd import scenedump
+
+    scene, info, z = scenedump.load_scene(os.path.join(GOLDEN, f"scene_{name}.npz"))
+    r = next(r for r in info["renders"] if r["tag"] == tag)
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0).scale(r["scale"])
+    hh, ww = r["size"]
+    return scene, z, r, tr, hh, ww
+
+
+@pytest.mark.parametrize("tag", ["s128", "s256"])
+def test_tiger_small(S, tag):
+    scene, z, r, tr, hh, ww = _render_dump(S, "tiger", tag)
+    res = scene.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
+    layer, _hull = res
+    assert [int(v) for v in layer.offset] == r["layer_offset"]
+    assert layer.image.shape == z[f"{tag}_layer"].shape
+    assert_close64(layer.image, z[f"{tag}_layer"], atol=1e-10, what="tiger group layer")
+    canvas32 = layer.to_canvas_f32(hh, ww)
+    assert_f32_1ulp(canvas32, z[f"{tag}_canvas"], what="tiger canvas f32")
+    # production entry (one batch straight to a float32 canvas)
+    img, st = S.render_canvas(scene, tr, [0, 0, hh, ww], linear_rgb=False)
+    assert_f32_1ulp(img, z[f"{tag}_canvas"], what="tiger render_canvas")
+    # integer bboxes of every leaf are bit-exact
+    from svgrasterize_amd.scene import build_batch
+
+    leaves = scene.leaves(tr, linear_rgb=False)
+    batch = build_batch(leaves, [0, 0, hh, ww])
+    batch.plan()
+    bb = batch.bboxes().astype(np.int64)
+    ref_bb = z[f"{tag}_leaf_bbox"]
+    empty = ref_bb[:, 2] < 0
+    assert np.array_equal(bb[~empty], ref_bb[~empty])
+    assert (bb[empty, 2] <= 0).all() or (bb[empty, 3] <= 0).all()
+
+
+def test_material_small_clips(S):
+    """material-design: 935 clip paths -> per-node route (CLIP = mask IN image) + batched runs."""
+    scene, z, r, tr, hh, ww = _render_dump(S, "material", "s256")
+    layer, _ = scene.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
+    assert [int(v) for v in layer.offset] == r["layer_offset"]
+    assert_close64(layer.image, z["s256_layer"], atol=1e-10, what="material group layer")
+    assert_f32_1ulp(layer.to_canvas_f32(hh, ww), z["s256_canvas"], what="material canvas")
+
+
+def test_tiger_crop_viewport(S):
+    from svgrasterize_amd import scenedump
+
+    scene, info, z = scenedump.load_scene(os.path.join(GOLDEN, "scene_tiger.npz"))
+    vp = info["crop"]["viewport"]
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    layer, _ = scene.render(tr, viewport=vp, linear_rgb=False)
+    assert [int(v) for v in layer.offset] == info["crop"]["offset"]
+    assert_close64(layer.image, z["crop_layer"], atol=1e-10, what="tiger crop")
+
+
+# ------------------------------------------------------------------------------------------
+# synthetic scene vs the CPU oracle (same seeded input)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("size,n", [(256, 48), (700, 300)])
+def test_synthetic_vs_oracle(S, orc, size, n):
+    from svgrasterize_amd import _abi, synth
+
+    sc = synth.make_scene(size, n)
+    ref, P, E = orc.render_solid(synth.presentation_segs(sc), sc["seg_kind"], sc["path_seg_off"], sc["path_rule"],
+                                 sc["path_paint"], sc["viewport"], clip01=True)
+    ctx = S.Context.get()
+    batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
+                       viewport=sc["viewport"])
+    st = batch.plan()
+    assert (st.path_pixels, st.n_edges) == (P, E)
+    out64 = ctx.alloc(size * size * 32)
+    batch.render(out64, _abi.OUT_CANVAS_F64, _abi.RENDER_CLIP01)
+    assert_close64(out64.download((size, size, 4), np.float64), ref, atol=1e-10, what="synthetic f64")
+    out32 = ctx.alloc(size * size * 16)
+    batch.render(out32, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
+    assert_f32_1ulp(out32.download((size, size, 4), np.float32), ref, what="synthetic f32")
+
+
+def test_band_sharding_matches_full(S):
+    """Rows rendered by 'rank r of 3' (bands r, r+3, ...) equal the same rows of the full render."""
+    from svgrasterize_amd import _abi, synth
+
+    size, n, world = 300, 80, 3
+    sc = synth.make_scene(size, n)
+    ctx = S.Context.get()
+    batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
+                       viewport=sc["viewport"])
+    batch.plan()
+    full = ctx.alloc(size * size * 32)
+    batch.render(full, _abi.OUT_CANVAS_F64)
+    full = full.download((size, size, 4), np.float64)
+    tr = _abi.TILE_ROWS
+    for rank in range(world):
+        batch.set_bands(rank, world)
+        rows = batch.owned_rows()
+        part = ctx.alloc(rows * size * 32)
+        batch.render(part, _abi.OUT_CANVAS_F64)
+        part = part.download((rows, size, 4), np.float64)
+        bands = list(range(rank, (size + tr - 1) // tr, world))
+        for k, b in enumerate(bands):
+            r0, r1 = b * tr, min((b + 1) * tr, size)
+            assert_close64(part[k * tr: k * tr + (r1 - r0)], full[r0:r1], atol=1e-12, what=f"rank {rank} band {b}")
+    batch.set_bands(0, 1)
