@@ -414,8 +414,8 @@ ORC_API int orc_render_solid(const double *segs, const uint8_t *seg_kind, const 
     int64_t P = 0, E = 0;
     int64_t ecap = 1024;
     double *edges = (double *)malloc(sizeof(double) * 4 * (size_t)ecap);
-    double *cub = NULL;
-    int64_t ccap = 0;
+    double *cub = NULL, *mask = NULL, *rgba = NULL;
+    int64_t ccap = 0, pxcap = 0;
     if (!edges) return -2;
     int rc = 0;
     for (int64_t p = 0; p < n_paths && rc == 0; ++p) {
@@ -449,15 +449,21 @@ ORC_API int orc_render_solid(const double *segs, const uint8_t *seg_kind, const 
         if (!orc_bbox(edges, ne, viewport, bb)) continue;
         E += ne;
         P += bb[2] * bb[3];
-        double *mask = (double *)malloc(sizeof(double) * (size_t)(bb[2] * bb[3]));
-        double *rgba = (double *)malloc(sizeof(double) * 4 * (size_t)(bb[2] * bb[3]));
-        if (!mask || !rgba) { free(mask); free(rgba); rc = -2; break; }
+        int64_t npx = bb[2] * bb[3];
+        if (npx > pxcap) { /* grow-only scratch: fresh mmap pages per path would time the page-fault path */
+            free(mask);
+            free(rgba);
+            pxcap = npx + npx / 2;
+            mask = (double *)malloc(sizeof(double) * (size_t)pxcap);
+            rgba = (double *)malloc(sizeof(double) * 4 * (size_t)pxcap);
+            if (!mask || !rgba) { rc = -2; break; }
+        }
         orc_mask(edges, ne, bb, bb[2], bb[3], path_rule[p], mask);
-        orc_fill_solid(mask, bb[2] * bb[3], path_paint + 4 * p, rgba);
+        orc_fill_solid(mask, npx, path_paint + 4 * p, rgba);
         orc_compose_over(canvas, viewport, viewport[2], viewport[3], rgba, bb, bb[2], bb[3], 4, 0);
-        free(mask);
-        free(rgba);
     }
+    free(mask);
+    free(rgba);
     if (rc == 0 && clip01) { /* canvas_merge_at(...).clip(0, 1)  S:326 */
         int64_t n = viewport[2] * viewport[3] * 4;
         for (int64_t i = 0; i < n; ++i) canvas[i] = canvas[i] < 0 ? 0 : (canvas[i] > 1 ? 1 : canvas[i]);
