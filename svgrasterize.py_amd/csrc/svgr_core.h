@@ -218,15 +218,25 @@ SVGR_HD void row_span(double x, double x_next, int& lo, int& hi) {
 // ------------------------------------------------------------------------------------
 // fill rules + zero cut (S:984-990)
 // ------------------------------------------------------------------------------------
-SVGR_HD double fill_nonzero(double s) {
+// *_raw: before the zero cut (callers that only need "is it >= 1e-6" skip the select)
+SVGR_HD double fill_nonzero_raw(double s) {
     double m = fabs(s);
-    m = m > 1.0 ? 1.0 : m;
+    return m > 1.0 ? 1.0 : m;
+}
+SVGR_HD double fill_nonzero(double s) {
+    double m = fill_nonzero_raw(s);
     return m < kZeroCut ? 0.0 : m;
 }
-SVGR_HD double fill_evenodd(double s) {
+SVGR_HD double fill_evenodd_raw(double s) {
     double a = s + 1.0;
-    double r = fmod(a, 2.0);       // np.remainder(a, 2.0): sign follows the divisor
-    if (r < 0.0) r += 2.0;
+    double r = a - 2.0 * floor(a * 0.5);
+    return fabs(r - 1.0);
+}
+SVGR_HD double fill_evenodd(double s) {
+    // np.remainder(a, 2.0) (sign follows the divisor) without fmod: a/2, floor, *2 and the final
+    // subtraction are all exact for a power-of-two divisor, so r == a - 2*floor(a/2) bit for bit
+    double a = s + 1.0;
+    double r = a - 2.0 * floor(a * 0.5);
     double m = fabs(r - 1.0);
     return m < kZeroCut ? 0.0 : m;
 }

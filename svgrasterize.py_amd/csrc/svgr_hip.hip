@@ -48,6 +48,7 @@ constexpr int CH = TC / PX;                // lanes per row = 16 = one DPP row
 constexpr int NT = TR * CH;                // 256 threads = 4 waves; a wave covers 4 tile rows
 constexpr int CHUNK_STRIDE = PX + 2;       // doubles; +16 B makes the 16-lane b128 groups conflict free
 constexpr int ROW_STRIDE = CH * CHUNK_STRIDE;
+constexpr int LPS = 4;                     // lanes per band segment in the scatter phase
 static_assert(CH == 16, "row scan uses one 16-lane DPP row per tile row");
 static_assert(NT == 256, "tile kernel is written for 256 threads");
 
@@ -456,7 +457,10 @@ struct TileArgs {
 template <int OUT>
 __global__ __launch_bounds__(NT) void k_tile_render(const TileArgs a) {
     __shared__ double s_trace[TR * ROW_STRIDE];
-    __shared__ int s_list[NT];
+    __shared__ int s_list[NT];      // compacted path ids of this tile
+    __shared__ int s_seg0[NT];      // their band-segment ranges ...
+    __shared__ int s_seg1[NT];
+    __shared__ int4 s_bbox[NT];     // ... and bboxes, fetched by 256 lanes at once (no dependent-load chain per path)
     __shared__ int s_wcnt[4];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -476,12 +480,18 @@ __global__ __launch_bounds__(NT) void k_tile_render(const TileArgs a) {
     const int ent_begin = a.band_off[band], ent_end = a.band_off[band + 1];
     for (int base = ent_begin; base < ent_end; base += NT) {
         // ---- compact the band's path list down to the paths that touch this tile's columns ----
-        int p_mine = -1;
+        int p_mine = -1, seg0 = 0, seg1 = 0;
+        int4 bb = make_int4(0, 0, 0, 0);
         bool hit = false;
         if (base + tid < ent_end) {
             p_mine = a.entries[base + tid];
-            int c0 = a.bbox[4 * (size_t)p_mine + 1], cols = a.bbox[4 * (size_t)p_mine + 3];
-            hit = c0 < tile_c1 && c0 + cols > tile_c0;
+            bb = ((const int4*)a.bbox)[p_mine];  // {r0, c0, rows, cols}
+            if (bb.y < tile_c1 && bb.y + bb.w > tile_c0) {
+                const int pb = a.pb_off[p_mine] + band - a.b0[p_mine];
+                seg0 = a.bseg_off[pb];
+                seg1 = a.bseg_off[pb + 1];
+                hit = seg1 > seg0;  // no edge crosses this band: coverage is zero everywhere in it
+            }
         }
         unsigned long long m = __ballot(hit);
         if (lane == 0) s_wcnt[wave] = __popcll(m);
@@ -492,30 +502,41 @@ __global__ __launch_bounds__(NT) void k_tile_render(const TileArgs a) {
             if (w < wave) off += s_wcnt[w];
             total += s_wcnt[w];
         }
-        if (hit) s_list[off + __popcll(m & ((1ull << lane) - 1ull))] = p_mine;
+        if (hit) {
+            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+            s_list[slot] = p_mine;
+            s_seg0[slot] = seg0;
+            s_seg1[slot] = seg1;
+            s_bbox[slot] = bb;
+        }
         __syncthreads();
 
         for (int li = 0; li < total; ++li) {
             const int p = s_list[li];
-            const int pb = a.pb_off[p] + band - a.b0[p];
-            const int s0 = a.bseg_off[pb], s1 = a.bseg_off[pb + 1];
-            if (s0 == s1) continue;  // no edge crosses this band: coverage is zero everywhere in it
-            const int r0 = a.bbox[4 * (size_t)p], c0 = a.bbox[4 * (size_t)p + 1];
-            const int rows = a.bbox[4 * (size_t)p + 2], cols = a.bbox[4 * (size_t)p + 3];
+            const int s0 = s_seg0[li], s1 = s_seg1[li];
+            const int4 pbb = s_bbox[li];
+            const int r0 = pbb.x, c0 = pbb.y, rows = pbb.z, cols = pbb.w;
             const int row_shift = r0 - tile_r0;  // layer row y  -> tile row  y + row_shift
             const int col_shift = c0 - tile_c0;  // layer col x  -> tile col  x + col_shift
             const int lo_c = col_shift < 0 ? -col_shift : 0;                 // first layer column inside the tile
             const int hi_c = cols < tile_c1 - c0 ? cols : tile_c1 - c0;      // one past the last
+            // paint / rule are only needed after the barrier: issue the loads now
+            const int rule = a.rule[p];
+            const double p0 = a.paint[4 * (size_t)p], p1 = a.paint[4 * (size_t)p + 1];
+            const double p2 = a.paint[4 * (size_t)p + 2], p3 = a.paint[4 * (size_t)p + 3];
 
-            // ---- scatter: signed-area pieces of every band segment into the LDS delta tile ----
-            for (int s = s0 + tid; s < s1; s += NT) {
-                const BandSeg g = a.bsegs[s];
+            // ---- scatter: LPS lanes per band segment, lane j takes rows y0+j, y0+j+LPS, ...; the x
+            //      recurrence is replayed forward from the band entry (cheap), the area pieces go to LDS ----
+            const int n_items = (s1 - s0) * LPS;
+            for (int w = tid; w < n_items; w += NT) {
+                const BandSeg g = a.bsegs[s0 + w / LPS];
                 const double dir = g.y1s < 0 ? -1.0 : 1.0;
                 const int y1 = g.y1s < 0 ? -g.y1s : g.y1s;
                 RowState st;
                 st.x_next = g.x;
-                for (int y = g.y0; y < y1; ++y) {
-                    row_step(st, y, g.p0y, g.p1y, g.dxdy, dir);
+                int yy = g.y0;
+                for (int y = g.y0 + (w % LPS); y < y1; y += LPS) {
+                    for (; yy <= y; ++yy) row_step(st, yy, g.p0y, g.p1y, g.dxdy, dir);
                     double* trow_ptr = s_trace + (y + row_shift) * ROW_STRIDE;
                     int lo, hi;
                     row_span(st.x, st.x_next, lo, hi);
@@ -541,7 +562,10 @@ __global__ __launch_bounds__(NT) void k_tile_render(const TileArgs a) {
             __syncthreads();
 
             // ---- row prefix sum + fill rule + paint + source-over ----
-            {
+            // A wave owns 4 tile rows; skip the phase when the layer has no row among them (its
+            // delta rows are untouched, so there is nothing to read, zero or composite).
+            const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * (64 / CH);
+            if (wrow0 + (64 / CH) > row_shift && wrow0 < row_shift + rows) {
                 double* my = s_trace + trow * ROW_STRIDE + chunk * CHUNK_STRIDE;
                 double t[PX];
 #pragma unroll
@@ -558,25 +582,34 @@ __global__ __launch_bounds__(NT) void k_tile_render(const TileArgs a) {
                 inc += dpp_row_shr<8>(inc);
                 double run = dpp_row_shr<1>(inc);  // exclusive: everything left of this chunk
 
-                const int y_layer = trow - row_shift;
-                const bool row_ok = y_layer >= 0 && y_layer < rows;
-                const int x_layer0 = chunk * PX - col_shift;
-                const int rule = a.rule[p];
-                const double p0 = a.paint[4 * (size_t)p], p1 = a.paint[4 * (size_t)p + 1];
-                const double p2 = a.paint[4 * (size_t)p + 2], p3 = a.paint[4 * (size_t)p + 3];
+                if (OUT <= 1) {
+                    // Canvas: only the layer's right edge needs a test.  Left of / above / below the
+                    // layer the delta tile is zero and so is the running sum, but to the right of it the
+                    // sum is whatever winding an unclosed outline leaves behind (stroker joins leave
+                    // ~1e-5 gaps), and the reference never touches pixels outside the layer's bbox.
+                    const int i_hi = hi_c - (chunk * PX - col_shift);  // pixels [0, i_hi) of this chunk are inside
 #pragma unroll
-                for (int i = 0; i < PX; ++i) {
-                    run += t[i];
-                    const int x_layer = x_layer0 + i;
-                    if (row_ok && x_layer >= lo_c && x_layer < hi_c) {
-                        double mval = fill_rule(run, rule);
-                        if (OUT == 2) {
-                            ((double*)a.out)[(size_t)y_layer * a.single_cols + x_layer] = mval;
-                        } else if (OUT == 3) {
-                            double* o = (double*)a.out + 4 * ((size_t)y_layer * a.single_cols + x_layer);
-                            o[0] = mval * p0; o[1] = mval * p1; o[2] = mval * p2; o[3] = mval * p3;
-                        } else if (mval != 0.0) {
-                            over_px(acc[i], mval * p0, mval * p1, mval * p2, mval * p3);
+                    for (int i = 0; i < PX; ++i) {
+                        run += t[i];
+                        const double mval = rule ? fill_evenodd_raw(run) : fill_nonzero_raw(run);
+                        if (i < i_hi && mval >= kZeroCut) over_px(acc[i], mval * p0, mval * p1, mval * p2, mval * p3);
+                    }
+                } else {
+                    const int y_layer = trow - row_shift;
+                    const bool row_ok = y_layer >= 0 && y_layer < rows;
+                    const int x_layer0 = chunk * PX - col_shift;
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) {
+                        run += t[i];
+                        const int x_layer = x_layer0 + i;
+                        if (row_ok && x_layer >= lo_c && x_layer < hi_c) {
+                            double mval = fill_rule(run, rule);
+                            if (OUT == 2) {
+                                ((double*)a.out)[(size_t)y_layer * a.single_cols + x_layer] = mval;
+                            } else {
+                                double* o = (double*)a.out + 4 * ((size_t)y_layer * a.single_cols + x_layer);
+                                o[0] = mval * p0; o[1] = mval * p1; o[2] = mval * p2; o[3] = mval * p3;
+                            }
                         }
                     }
                 }
