@@ -100,6 +100,64 @@ SVGR_HD int flatten_cubic(const double* cubic, double thr, Emit&& emit) {
     return overflow ? -1 : n;
 }
 
+// the two halves separately (same dot4 rows as cubic_split)
+SVGR_HD void cubic_left(const double* c, double* l) {
+    for (int ax = 0; ax < 2; ++ax) {
+        double x0 = c[ax], x1 = c[2 + ax], x2 = c[4 + ax], x3 = c[6 + ax];
+        l[ax] = dot4(1.0, 0.0, 0.0, 0.0, x0, x1, x2, x3);
+        l[2 + ax] = dot4(0.5, 0.5, 0.0, 0.0, x0, x1, x2, x3);
+        l[4 + ax] = dot4(0.25, 0.5, 0.25, 0.0, x0, x1, x2, x3);
+        l[6 + ax] = dot4(0.125, 0.375, 0.375, 0.125, x0, x1, x2, x3);
+    }
+}
+SVGR_HD void cubic_right(const double* c, double* r) {
+    for (int ax = 0; ax < 2; ++ax) {
+        double x0 = c[ax], x1 = c[2 + ax], x2 = c[4 + ax], x3 = c[6 + ax];
+        r[ax] = dot4(0.125, 0.375, 0.375, 0.125, x0, x1, x2, x3);
+        r[2 + ax] = dot4(0.0, 0.25, 0.5, 0.25, x0, x1, x2, x3);
+        r[4 + ax] = dot4(0.0, 0.0, 0.5, 0.5, x0, x1, x2, x3);
+        r[6 + ax] = dot4(0.0, 0.0, 0.0, 1.0, x0, x1, x2, x3);
+    }
+}
+
+// Stack-free depth-first subdivision of the subtree under `root` (whose ancestors the caller has
+// already found non-flat).  The position is a (level, path-bits) pair; stepping to a right sibling
+// recomputes the node from `root` by `level` half-splits, which is the same sequence of roundings
+// the recursive form performs, so the pieces are bit-identical -- and nothing spills to scratch.
+// `emit(p0r, p0c, p1r, p1c)` once per flat piece in curve order; returns the piece count and sets
+// `overflow` when `max_depth` forced a piece out (non-finite / absurd input).
+template <class Emit>
+SVGR_HD int flatten_subtree(const double* root, double thr, int max_depth, Emit&& emit, bool& overflow) {
+    double cur[8];
+    for (int i = 0; i < 8; ++i) cur[i] = root[i];
+    int level = 0, n = 0;
+    unsigned long long idx = 0;
+    for (;;) {
+        bool flat = cubic_flatness(cur) < thr;
+        if (!flat && level >= max_depth) { flat = true; overflow = true; }
+        if (flat) {
+            emit(cur[0], cur[1], cur[6], cur[7]);
+            ++n;
+            while (level > 0 && (idx & 1ull)) { idx >>= 1; --level; }
+            if (level == 0) break;
+            idx |= 1ull;
+            for (int i = 0; i < 8; ++i) cur[i] = root[i];
+            for (int l = level - 1; l >= 0; --l) {
+                double t[8];
+                if ((idx >> l) & 1ull) cubic_right(cur, t); else cubic_left(cur, t);
+                for (int i = 0; i < 8; ++i) cur[i] = t[i];
+            }
+        } else {
+            double t[8];
+            cubic_left(cur, t);
+            for (int i = 0; i < 8; ++i) cur[i] = t[i];
+            ++level;
+            idx <<= 1;
+        }
+    }
+    return n;
+}
+
 // ------------------------------------------------------------------------------------
 // order-preserving double <-> uint64 key (for integer atomicMin / atomicMax on coordinates)
 // ------------------------------------------------------------------------------------

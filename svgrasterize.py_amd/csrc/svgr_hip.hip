@@ -1,14 +1,15 @@
 // svgr_hip.hip -- MI355X (gfx950 / CDNA4) anti-aliased path rasterizer: HIP kernels + C ABI.
 //
-// Pipeline of one svgr_batch_render (all on the context stream, no host read-back):
+// Pipeline of one svgr_batch_render (8 launches on the context stream, no host read-back):
 //
-//   k_seg_count     per segment: transform (fma form) + adaptive subdivision, count flat pieces
-//   scan            exclusive prefix of the counts -> edge offsets
-//   k_seg_emit      per segment: subdivide again, store edges, fold endpoints into per-path min/max
-//   k_path_bbox     per path: integer bbox (floor-1 / ceil+1, clipped to the viewport), band range
-//   scan            (path, band) pair offsets
-//   k_edge_count    per edge: how many 16-row bands it crosses -> per (path, band) counts
-//   scan            band-segment offsets
+//   memset          one zero-fill of the batch's counter arena
+//   k_flatten       8 lanes per segment: transform (fma form), stack-free adaptive subdivision,
+//                   count -> wave prefix -> ONE atomic per wave reserves the edge slots -> subdivide
+//                   again and store; endpoints folded into per-path min/max keys
+//   k_path_bbox     per path: integer bbox (floor-1 / ceil+1, clipped to the viewport), band range,
+//                   wave-aggregated reservation of its (path, band) pair slots
+//   k_edge_count    per edge: which 16-row bands it crosses -> per-pair counts (run-aggregated atomics)
+//   k_alloc         per pair: wave-aggregated reservation of its band-segment slots
 //   k_edge_emit     per edge: walk its rows with the reference's x recurrence, cut a record at
 //                   every band entry (so a tile never has to replay rows above it)
 //   k_band_entries  per band: ordered list of the paths whose bbox covers it
@@ -114,84 +115,82 @@ struct DevArr {
 };
 
 // ======================================================================================
-// exclusive scan of int32 (n small to a few million)
+// wave-level helpers (wave = 64 lanes)
 // ======================================================================================
-constexpr int SCAN_T = 256, SCAN_I = 8, SCAN_B = SCAN_T * SCAN_I;
-
-__global__ __launch_bounds__(SCAN_T) void k_scan_block(const int* __restrict__ in, int* __restrict__ out, int n,
-                                                       int* __restrict__ block_sums) {
-    __shared__ int s_part[SCAN_T];
-    const int tid = threadIdx.x;
-    const int base = blockIdx.x * SCAN_B + tid * SCAN_I;
-    int v[SCAN_I];
-    int sum = 0;
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
+    int x = v;
 #pragma unroll
-    for (int i = 0; i < SCAN_I; ++i) {
-        v[i] = (base + i < n) ? in[base + i] : 0;
-        sum += v[i];
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
     }
-    s_part[tid] = sum;
+    total = __shfl(x, 63);
+    return x - v;
+}
+
+// every lane of the wave must call this; reserves `n` consecutive slots for the calling lane with a
+// single atomic per wave and returns the lane's first slot
+__device__ __forceinline__ int wave_alloc(int* cursor, int n, int lane) {
+    int total;
+    int excl = wave_excl_scan(n, lane, total);
+    int base = 0;
+    if (lane == 0 && total > 0) base = atomicAdd(cursor, total);
+    return __shfl(base, 0) + excl;
+}
+
+// Block-level form for 1024-thread blocks: one atomic per BLOCK (a hot word serves only ~90 returning
+// atomics per microsecond chip-wide, so per-wave reservations of a big launch would serialise).
+// Every thread of the block must call this.
+__device__ __forceinline__ int block_alloc(int* cursor, int n, int* s_tot /* >= 17 ints of LDS */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    int total;
+    int excl = wave_excl_scan(n, lane, total);
+    if (lane == 0) s_tot[wave] = total;
     __syncthreads();
-    for (int d = 1; d < SCAN_T; d <<= 1) {  // Hillis-Steele over the 256 partials
-        int add = (tid >= d) ? s_part[tid - d] : 0;
-        __syncthreads();
-        s_part[tid] += add;
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+        for (int w = 0; w < nwaves; ++w) { int t = s_tot[w]; s_tot[w] = sum; sum += t; }
+        s_tot[16] = sum > 0 ? atomicAdd(cursor, sum) : 0;
     }
-    int run = s_part[tid] - sum;  // exclusive prefix of this thread
-#pragma unroll
-    for (int i = 0; i < SCAN_I; ++i) {
-        if (base + i < n) out[base + i] = run;
-        run += v[i];
-    }
-    if (tid == SCAN_T - 1 && block_sums) block_sums[blockIdx.x] = s_part[tid];
+    __syncthreads();
+    int base = s_tot[16] + s_tot[wave] + excl;
+    __syncthreads();
+    return base;
 }
 
-__global__ void k_scan_add(int* __restrict__ out, int n, const int* __restrict__ block_offs) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] += block_offs[i / SCAN_B];
+// Runs of consecutive active lanes with equal keys.  For an active lane: `head` = first lane of its
+// run, `len` = length of the run.  Every lane of the wave must call this.
+__device__ __forceinline__ void wave_runs(int key, bool active, int lane, int& head, int& len) {
+    int prev = __shfl_up(key, 1);
+    int prev_act = __shfl_up((int)active, 1);
+    bool is_head = active && (lane == 0 || !prev_act || prev != key);
+    unsigned long long H = __ballot(is_head), A = __ballot(active);
+    unsigned long long B = H | ~A;  // a run cannot continue across these lanes
+    unsigned long long below = H & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    head = below ? 63 - __clzll(below) : lane;
+    unsigned long long above = (B >> head) >> 1;
+    len = above ? __ffsll((long long)above) : 64 - head;
 }
-
-struct Scanner {
-    DevArr<int> l1, l1s, l2, l2s;
-    int run(hipStream_t st, const int* in, int* out, int n) {
-        if (n <= 0) return 0;
-        int nb = (n + SCAN_B - 1) / SCAN_B;
-        if (nb == 1) {
-            hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(SCAN_T), 0, st, in, out, n, (int*)nullptr);
-            return 0;
-        }
-        if (int rc = l1.ensure(nb)) return rc;
-        if (int rc = l1s.ensure(nb)) return rc;
-        hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(SCAN_T), 0, st, in, out, n, l1.p);
-        int nb2 = (nb + SCAN_B - 1) / SCAN_B;
-        if (nb2 == 1) {
-            hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(SCAN_T), 0, st, (const int*)l1.p, l1s.p, nb, (int*)nullptr);
-        } else {
-            if (nb2 > SCAN_B) return fail(SVGR_E_OVERFLOW, "scan of %d elements is beyond three levels", n);
-            if (int rc = l2.ensure(nb2)) return rc;
-            if (int rc = l2s.ensure(nb2)) return rc;
-            hipLaunchKernelGGL(k_scan_block, dim3(nb2), dim3(SCAN_T), 0, st, (const int*)l1.p, l1s.p, nb, l2.p);
-            hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(SCAN_T), 0, st, (const int*)l2.p, l2s.p, nb2, (int*)nullptr);
-            hipLaunchKernelGGL(k_scan_add, dim3((nb + 255) / 256), dim3(256), 0, st, l1s.p, nb, (const int*)l2s.p);
-        }
-        hipLaunchKernelGGL(k_scan_add, dim3((n + 255) / 256), dim3(256), 0, st, out, n, (const int*)l1s.p);
-        return 0;
-    }
-    void release() { l1.release(); l1s.release(); l2.release(); l2s.release(); }
-};
 
 // ======================================================================================
 // geometry kernels
 // ======================================================================================
-// device-side scalars of a batch
+// Device-side scalars of a batch; lives at the start of the zeroed arena, so every field's
+// "nothing yet" value is 0 (minima are stored as biased maxima).
+constexpr int UNION_BIAS = 1 << 30;
 struct BatchDev {
     int err;            // bit 0: flatten depth cap, bit 1: edge capacity, bit 2: (path,band) capacity,
                         // bit 3: band-seg capacity, bit 4: bbox beyond int range
     int n_nonempty;
-    long long path_pixels;
-    int union_min_r, union_min_c, union_max_r, union_max_c;
+    unsigned long long path_pixels;
+    int edge_cursor;    // flattened edges reserved so far
+    int pb_cursor;      // (path, band) pairs
+    int bseg_cursor;    // band segments
+    int entry_cursor;   // band list entries
+    unsigned umin_r, umin_c, umax_r, umax_c;  // union bbox: max(BIAS - lo), max(BIAS + hi)
+    int pad[4];
 };
+static_assert(sizeof(BatchDev) == 64, "BatchDev is the 64-byte head of the zero arena");
 
 __device__ __forceinline__ void load_seg_points(const double* __restrict__ segs, int s, const double* __restrict__ m6,
                                                 int npts, double* c) {
@@ -201,131 +200,183 @@ __device__ __forceinline__ void load_seg_points(const double* __restrict__ segs,
     }
 }
 
-__global__ void k_seg_count(const double* __restrict__ segs, const uint8_t* __restrict__ kind,
-                            const int* __restrict__ seg_path, const double* __restrict__ path_m6, int n_segs, double thr,
-                            int* __restrict__ seg_cnt, BatchDev* __restrict__ bd) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s > n_segs) return;
-    if (s == n_segs) { seg_cnt[s] = 0; return; }  // slot for the scan total
-    int cnt = 1;
-    if (kind[s] == SVGR_SEG_CUBIC) {
-        double c[8];
-        load_seg_points(segs, s, path_m6 + 6 * (size_t)seg_path[s], 4, c);
-        cnt = flatten_cubic(c, thr, [](double, double, double, double) {});
-        if (cnt < 0) { atomicOr(&bd->err, 1); cnt = 0; }
+// 32 lanes per segment.  Lane j owns the depth-5 node whose path bits are j (if the five ancestors
+// above it are not flat; an ancestor that is flat is emitted by the lane whose remaining bits are 0).
+// Per-path keys: {~key(min_r), ~key(min_c), key(max_r), key(max_c)}, all folded with atomicMax.
+constexpr int FL_SUB = 5;       // 32 lanes per segment: the longest lane bounds the kernel, so cut subtrees small
+constexpr int FL_BLOCK = 1024;
+template <bool EMIT>
+__global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__ segs, const uint8_t* __restrict__ kind,
+                                                 const int* __restrict__ seg_path, const double* __restrict__ path_m6,
+                                                 int n_segs, double thr, double* __restrict__ edges,
+                                                 int* __restrict__ edge_path, int edge_cap,
+                                                 unsigned long long* __restrict__ pkeys, BatchDev* __restrict__ bd) {
+    __shared__ int s_tot[17];
+    const int gtid = blockIdx.x * FL_BLOCK + threadIdx.x;
+    const int seg = gtid >> FL_SUB, sub = gtid & ((1 << FL_SUB) - 1);
+    const bool seg_ok = seg < n_segs;
+    double node[8];
+    int mode = 0;  // 0 nothing, 1 one edge node[0..1] -> node[6..7], 2 subtree under node
+    int p = 0;
+    if (seg_ok) {
+        p = seg_path[seg];
+        const double* m6 = path_m6 + 6 * (size_t)p;
+        if (kind[seg] == SVGR_SEG_LINE) {
+            if (sub == 0) {
+                double c[4];
+                load_seg_points(segs, seg, m6, 2, c);
+                node[0] = c[0]; node[1] = c[1]; node[6] = c[2]; node[7] = c[3];
+                mode = 1;
+            }
+        } else {
+            load_seg_points(segs, seg, m6, 4, node);
+            mode = 2;
+            for (int l = 0; l < FL_SUB; ++l) {
+                if (cubic_flatness(node) < thr) {
+                    mode = (sub & ((1 << (FL_SUB - l)) - 1)) == 0 ? 1 : 0;
+                    break;
+                }
+                double t[8];
+                if ((sub >> (FL_SUB - 1 - l)) & 1) cubic_right(node, t); else cubic_left(node, t);
+                for (int i = 0; i < 8; ++i) node[i] = t[i];
+            }
+        }
     }
-    seg_cnt[s] = cnt;
-}
+    int cnt = 0;
+    bool ovf = false;
+    if (mode == 1) cnt = 1;
+    else if (mode == 2) cnt = flatten_subtree(node, thr, kMaxFlattenDepth - FL_SUB, [](double, double, double, double) {}, ovf);
+    if (ovf) atomicOr(&bd->err, 1);
+    const int base = block_alloc(&bd->edge_cursor, cnt, s_tot);
+    if (!EMIT) return;
 
-__global__ void k_seg_emit(const double* __restrict__ segs, const uint8_t* __restrict__ kind,
-                           const int* __restrict__ seg_path, const double* __restrict__ path_m6, int n_segs, double thr,
-                           const int* __restrict__ seg_off, double* __restrict__ edges, int* __restrict__ edge_path,
-                           int edge_cap, unsigned long long* __restrict__ pmin, unsigned long long* __restrict__ pmax,
-                           BatchDev* __restrict__ bd) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_segs) return;
-    const int p = seg_path[s];
-    const int off = seg_off[s];
-    const int cnt = seg_off[s + 1] - off;
-    if (cnt <= 0) return;
-    if (off + cnt > edge_cap) { atomicOr(&bd->err, 2); return; }
     double mnr = INFINITY, mnc = INFINITY, mxr = -INFINITY, mxc = -INFINITY;
     auto track = [&](double r, double c) {
         mnr = r < mnr ? r : mnr; mxr = r > mxr ? r : mxr;
         mnc = c < mnc ? c : mnc; mxc = c > mxc ? c : mxc;
     };
-    const double* m6 = path_m6 + 6 * (size_t)p;
-    if (kind[s] == SVGR_SEG_LINE) {
-        double c[4];
-        load_seg_points(segs, s, m6, 2, c);
-        double* e = edges + 4 * (size_t)off;
-        e[0] = c[0]; e[1] = c[1]; e[2] = c[2]; e[3] = c[3];
-        edge_path[off] = p;
-        track(c[0], c[1]);
-        track(c[2], c[3]);
-    } else {
-        double c[8];
-        load_seg_points(segs, s, m6, 4, c);
-        int i = 0;
-        flatten_cubic(c, thr, [&](double r0, double c0, double r1, double c1) {
-            if (i < cnt) {
-                double* e = edges + 4 * (size_t)(off + i);
-                e[0] = r0; e[1] = c0; e[2] = r1; e[3] = c1;
-                edge_path[off + i] = p;
-            }
-            ++i;
-            track(r0, c0);
-            track(r1, c1);
-        });
+    if (cnt > 0) {
+        if (base + cnt > edge_cap) {
+            atomicOr(&bd->err, 2);
+        } else if (mode == 1) {
+            double* e = edges + 4 * (size_t)base;
+            e[0] = node[0]; e[1] = node[1]; e[2] = node[6]; e[3] = node[7];
+            edge_path[base] = p;
+            track(node[0], node[1]);
+            track(node[6], node[7]);
+        } else {
+            int i = 0;
+            bool o2 = false;
+            flatten_subtree(node, thr, kMaxFlattenDepth - FL_SUB, [&](double r0, double c0, double r1, double c1) {
+                if (i < cnt) {
+                    double* e = edges + 4 * (size_t)(base + i);
+                    e[0] = r0; e[1] = c0; e[2] = r1; e[3] = c1;
+                    edge_path[base + i] = p;
+                }
+                ++i;
+                track(r0, c0);
+                track(r1, c1);
+            }, o2);
+        }
     }
-    atomicMin(&pmin[2 * (size_t)p], f64_key(mnr));
-    atomicMin(&pmin[2 * (size_t)p + 1], f64_key(mnc));
-    atomicMax(&pmax[2 * (size_t)p], f64_key(mxr));
-    atomicMax(&pmax[2 * (size_t)p + 1], f64_key(mxc));
+    // fold the lanes of a segment, then one set of atomics per segment
+#pragma unroll
+    for (int d = 1; d < (1 << FL_SUB); d <<= 1) {
+        double a = __shfl_xor(mnr, d), b = __shfl_xor(mnc, d), c = __shfl_xor(mxr, d), e = __shfl_xor(mxc, d);
+        mnr = a < mnr ? a : mnr; mnc = b < mnc ? b : mnc;
+        mxr = c > mxr ? c : mxr; mxc = e > mxc ? e : mxc;
+    }
+    if (seg_ok && sub == 0 && mnr <= mxr) {
+        unsigned long long* k = pkeys + 4 * (size_t)p;
+        atomicMax(&k[0], ~f64_key(mnr));
+        atomicMax(&k[1], ~f64_key(mnc));
+        atomicMax(&k[2], f64_key(mxr));
+        atomicMax(&k[3], f64_key(mxc));
+    }
 }
 
 // bbox = {r0, c0, rows, cols}; viewport = same or has_vp = 0
-__global__ void k_path_bbox(const unsigned long long* __restrict__ pmin, const unsigned long long* __restrict__ pmax,
-                            int n_paths, int has_vp, int vr0, int vc0, int vrows, int vcols, int* __restrict__ bbox,
-                            int* __restrict__ b0, int* __restrict__ nb, int* __restrict__ band_cnt,
-                            BatchDev* __restrict__ bd) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p > n_paths) return;
-    if (p == n_paths) { nb[p] = 0; return; }  // scan-total slot
+__global__ __launch_bounds__(256) void k_path_bbox(const unsigned long long* __restrict__ pkeys, int n_paths, int has_vp,
+                                                   int vr0, int vc0, int vrows, int vcols, int* __restrict__ bbox,
+                                                   int* __restrict__ b0, int* __restrict__ nb, int* __restrict__ pb_off,
+                                                   BatchDev* __restrict__ bd) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     int out[4] = {0, 0, 0, 0};
     int pb0 = 0, pnb = 0;
-    unsigned long long kmin_r = pmin[2 * (size_t)p];
-    if (kmin_r != ~0ull) {  // the path produced at least one edge
-        double mnr = key_f64(kmin_r), mnc = key_f64(pmin[2 * (size_t)p + 1]);
-        double mxr = key_f64(pmax[2 * (size_t)p]), mxc = key_f64(pmax[2 * (size_t)p + 1]);
-        const double lim = 1.0e9;
-        if (!(mnr > -lim && mnc > -lim && mxr < lim && mxc < lim)) {
-            atomicOr(&bd->err, 16);
-        } else {
-            long long lo_r = (long long)floor(mnr) - 1, lo_c = (long long)floor(mnc) - 1;
-            long long hi_r = (long long)ceil(mxr) + 1, hi_c = (long long)ceil(mxc) + 1;
-            if (has_vp) {
-                lo_r = lo_r > vr0 ? lo_r : vr0;
-                lo_c = lo_c > vc0 ? lo_c : vc0;
-                hi_r = hi_r < (long long)vr0 + vrows ? hi_r : (long long)vr0 + vrows;
-                hi_c = hi_c < (long long)vc0 + vcols ? hi_c : (long long)vc0 + vcols;
-            }
-            long long rows = hi_r - lo_r, cols = hi_c - lo_c;
-            if (rows > 0 && cols > 0) {
-                out[0] = (int)lo_r; out[1] = (int)lo_c; out[2] = (int)rows; out[3] = (int)cols;
-                int base_r = has_vp ? vr0 : (int)lo_r;
-                pb0 = ((int)lo_r - base_r) / TR;
-                pnb = ((int)(hi_r - 1) - base_r) / TR - pb0 + 1;
-                atomicAdd(&bd->n_nonempty, 1);
-                atomicAdd((unsigned long long*)&bd->path_pixels, (unsigned long long)(rows * cols));
-                atomicMin(&bd->union_min_r, (int)lo_r);
-                atomicMin(&bd->union_min_c, (int)lo_c);
-                atomicMax(&bd->union_max_r, (int)hi_r);
-                atomicMax(&bd->union_max_c, (int)hi_c);
-                if (band_cnt)
-                    for (int b = 0; b < pnb; ++b) atomicAdd(&band_cnt[pb0 + b], 1);
+    int st_n = 0;
+    unsigned long long st_px = 0;
+    unsigned st_minr = 0, st_minc = 0, st_maxr = 0, st_maxc = 0;
+    if (p < n_paths) {
+        const unsigned long long* k = pkeys + 4 * (size_t)p;
+        if (k[0] != 0ull) {  // the path produced at least one edge
+            double mnr = key_f64(~k[0]), mnc = key_f64(~k[1]);
+            double mxr = key_f64(k[2]), mxc = key_f64(k[3]);
+            const double lim = 1.0e9;
+            if (!(mnr > -lim && mnc > -lim && mxr < lim && mxc < lim)) {
+                atomicOr(&bd->err, 16);
             } else {
-                const long long big = 1ll << 30;
-                out[0] = (int)(lo_r > big ? big : (lo_r < -big ? -big : lo_r));
-                out[1] = (int)(lo_c > big ? big : (lo_c < -big ? -big : lo_c));
+                long long lo_r = (long long)floor(mnr) - 1, lo_c = (long long)floor(mnc) - 1;
+                long long hi_r = (long long)ceil(mxr) + 1, hi_c = (long long)ceil(mxc) + 1;
+                if (has_vp) {
+                    lo_r = lo_r > vr0 ? lo_r : vr0;
+                    lo_c = lo_c > vc0 ? lo_c : vc0;
+                    hi_r = hi_r < (long long)vr0 + vrows ? hi_r : (long long)vr0 + vrows;
+                    hi_c = hi_c < (long long)vc0 + vcols ? hi_c : (long long)vc0 + vcols;
+                }
+                long long rows = hi_r - lo_r, cols = hi_c - lo_c;
+                if (rows > 0 && cols > 0) {
+                    out[0] = (int)lo_r; out[1] = (int)lo_c; out[2] = (int)rows; out[3] = (int)cols;
+                    int base_r = has_vp ? vr0 : (int)lo_r;
+                    pb0 = ((int)lo_r - base_r) / TR;
+                    pnb = ((int)(hi_r - 1) - base_r) / TR - pb0 + 1;
+                    st_n = 1;
+                    st_px = (unsigned long long)(rows * cols);
+                    st_minr = (unsigned)(UNION_BIAS - (int)lo_r);
+                    st_minc = (unsigned)(UNION_BIAS - (int)lo_c);
+                    st_maxr = (unsigned)(UNION_BIAS + (int)hi_r);
+                    st_maxc = (unsigned)(UNION_BIAS + (int)hi_c);
+                } else {
+                    const long long big = 1ll << 30;
+                    out[0] = (int)(lo_r > big ? big : (lo_r < -big ? -big : lo_r));
+                    out[1] = (int)(lo_c > big ? big : (lo_c < -big ? -big : lo_c));
+                }
             }
         }
     }
-    bbox[4 * (size_t)p] = out[0]; bbox[4 * (size_t)p + 1] = out[1];
-    bbox[4 * (size_t)p + 2] = out[2]; bbox[4 * (size_t)p + 3] = out[3];
-    b0[p] = pb0;
-    nb[p] = pnb;
+    const int off = wave_alloc(&bd->pb_cursor, pnb, lane);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {  // statistics: fold the wave, then one set of atomics
+        st_n += __shfl_xor(st_n, d);
+        st_px += __shfl_xor(st_px, d);
+        unsigned a = __shfl_xor(st_minr, d), b = __shfl_xor(st_minc, d), c = __shfl_xor(st_maxr, d), e = __shfl_xor(st_maxc, d);
+        st_minr = a > st_minr ? a : st_minr; st_minc = b > st_minc ? b : st_minc;
+        st_maxr = c > st_maxr ? c : st_maxr; st_maxc = e > st_maxc ? e : st_maxc;
+    }
+    if (lane == 0 && st_n > 0) {
+        atomicAdd(&bd->n_nonempty, st_n);
+        atomicAdd(&bd->path_pixels, st_px);
+        atomicMax(&bd->umin_r, st_minr);
+        atomicMax(&bd->umin_c, st_minc);
+        atomicMax(&bd->umax_r, st_maxr);
+        atomicMax(&bd->umax_c, st_maxc);
+    }
+    if (p < n_paths) {
+        ((int4*)bbox)[p] = make_int4(out[0], out[1], out[2], out[3]);
+        b0[p] = pb0;
+        nb[p] = pnb;
+        pb_off[p] = off;
+    }
 }
 
 // shared by count and emit so both take identical decisions
 __device__ __forceinline__ bool edge_prepare(const double* __restrict__ edges, const int* __restrict__ edge_path,
                                              const int* __restrict__ bbox, int e, EdgeSetup& es, int& p, int& r0) {
     p = edge_path[e];
-    const int* bb = bbox + 4 * (size_t)p;
-    r0 = bb[0];
-    const int rows = bb[2], cols = bb[3];
+    const int4 bb = ((const int4*)bbox)[p];
+    r0 = bb.x;
+    const int rows = bb.z, cols = bb.w;
     if (rows <= 0 || cols <= 0) return false;
-    const double o_r = (double)bb[0], o_c = (double)bb[1];  // `lines - [min_x, min_y]` (S:979)
+    const double o_r = (double)bb.x, o_c = (double)bb.y;  // `lines - [min_x, min_y]` (S:979)
     const double* ed = edges + 4 * (size_t)e;
     double ar = ed[0] - o_r, ac = ed[1] - o_c, br = ed[2] - o_r, bc = ed[3] - o_c;
     es = edge_setup(ar, ac, br, bc, rows);
@@ -336,42 +387,72 @@ __device__ __forceinline__ bool edge_prepare(const double* __restrict__ edges, c
     return true;
 }
 
-__global__ void k_edge_count(const double* __restrict__ edges, const int* __restrict__ edge_path,
-                             const int* __restrict__ n_edges_ptr, const int* __restrict__ bbox,
-                             const int* __restrict__ pb_off, const int* __restrict__ b0, int vr0,
-                             int* __restrict__ pb_cnt) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= *n_edges_ptr) return;
+__global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ edges, const int* __restrict__ edge_path,
+                                                    const int* __restrict__ bbox, const int* __restrict__ pb_off,
+                                                    const int* __restrict__ b0, int vr0, int pb_cap,
+                                                    int* __restrict__ pb_cnt, BatchDev* __restrict__ bd) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     EdgeSetup es;
-    int p, r0;
-    if (!edge_prepare(edges, edge_path, bbox, e, es, p, r0)) return;
-    int bf = (r0 + es.y_begin - vr0) / TR, bl = (r0 + es.y_end - 1 - vr0) / TR;
-    int base = pb_off[p] - b0[p];
-    for (int b = bf; b <= bl; ++b) atomicAdd(&pb_cnt[base + b], 1);
+    int p = 0, r0 = 0, key = -1, bf = 0, bl = -1;
+    bool ok = e < bd->edge_cursor && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
+    if (ok) {
+        bf = (r0 + es.y_begin - vr0) / TR;
+        bl = (r0 + es.y_end - 1 - vr0) / TR;
+        key = pb_off[p] - b0[p] + bf;
+        if (key < 0 || key + (bl - bf) >= pb_cap) { atomicOr(&bd->err, 4); ok = false; }
+    }
+    int head, len;
+    wave_runs(key, ok, lane, head, len);
+    if (ok) {
+        if (head == lane) atomicAdd(&pb_cnt[key], len);           // first band: one atomic per run of equal pairs
+        for (int b = 1; b <= bl - bf; ++b) atomicAdd(&pb_cnt[key + b], 1);
+    }
 }
 
-__global__ void k_edge_emit(const double* __restrict__ edges, const int* __restrict__ edge_path,
-                            const int* __restrict__ n_edges_ptr, const int* __restrict__ bbox,
-                            const int* __restrict__ pb_off, const int* __restrict__ b0, int vr0,
-                            const int* __restrict__ bseg_off, int* __restrict__ pb_cursor, BandSeg* __restrict__ bsegs,
-                            int bseg_cap, BatchDev* __restrict__ bd) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= *n_edges_ptr) return;
+// per (path, band) pair: reserve its band-segment slots (one atomic per wave)
+__global__ __launch_bounds__(1024) void k_alloc(const int* __restrict__ cnt, int n_cap, int* __restrict__ off,
+                                                BatchDev* __restrict__ bd) {
+    __shared__ int s_tot[17];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = bd->pb_cursor < n_cap ? bd->pb_cursor : n_cap;
+    const int c = i < n ? cnt[i] : 0;
+    const int o = block_alloc(&bd->bseg_cursor, c, s_tot);
+    if (i < n) off[i] = o;
+}
+
+__global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ edges, const int* __restrict__ edge_path,
+                                                   const int* __restrict__ bbox, const int* __restrict__ pb_off,
+                                                   const int* __restrict__ b0, int vr0, int pb_cap,
+                                                   const int* __restrict__ bseg_off, int* __restrict__ pb_cursor,
+                                                   BandSeg* __restrict__ bsegs, int bseg_cap, BatchDev* __restrict__ bd) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     EdgeSetup es;
-    int p, r0;
-    if (!edge_prepare(edges, edge_path, bbox, e, es, p, r0)) return;
-    const int base = pb_off[p] - b0[p];
+    int p = 0, r0 = 0, key = -1;
+    bool ok = e < bd->edge_cursor && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
+    int bf = 0, bl = -1;
+    if (ok) {
+        bf = (r0 + es.y_begin - vr0) / TR;
+        bl = (r0 + es.y_end - 1 - vr0) / TR;
+        key = pb_off[p] - b0[p] + bf;
+        if (key < 0 || key + (bl - bf) >= pb_cap) ok = false;  // flagged by k_edge_count
+    }
+    int head, len;
+    wave_runs(key, ok, lane, head, len);
+    int run_base = 0;
+    if (ok && head == lane) run_base = atomicAdd(&pb_cursor[key], len);
+    run_base = __shfl(run_base, head);
+    if (!ok) return;
     RowState st;
     st.x_next = es.x;
     st.x = es.x;
     st.d = 0.0;
     int y = es.y_begin;
-    while (y < es.y_end) {
-        int band = (r0 + y - vr0) / TR;
-        int band_end_row = (band + 1) * TR + vr0 - r0;  // first layer-local row of the next band
-        int y1 = band_end_row < es.y_end ? band_end_row : es.y_end;
-        int pb = base + band;
-        int slot = bseg_off[pb] + atomicAdd(&pb_cursor[pb], 1);
+    for (int b = 0; y < es.y_end; ++b) {
+        const int band = bf + b;
+        const int band_end_row = (band + 1) * TR + vr0 - r0;  // first layer-local row of the next band
+        const int y1 = band_end_row < es.y_end ? band_end_row : es.y_end;
+        const int pb = key + b;
+        const int slot = bseg_off[pb] + (b == 0 ? run_base + (lane - head) : atomicAdd(&pb_cursor[pb], 1));
         if (slot < bseg_cap) {
             BandSeg g;
             g.x = st.x_next;
@@ -390,11 +471,35 @@ __global__ void k_edge_emit(const double* __restrict__ edges, const int* __restr
 
 // one workgroup per band: ascending list of the paths whose bbox rows cover the band
 __global__ __launch_bounds__(256) void k_band_entries(const int* __restrict__ b0, const int* __restrict__ nb, int n_paths,
-                                                      const int* __restrict__ band_off, int* __restrict__ entries,
-                                                      int entry_cap, BatchDev* __restrict__ bd) {
+                                                      int* __restrict__ band_start, int* __restrict__ band_count,
+                                                      int* __restrict__ entries, int entry_cap, BatchDev* __restrict__ bd) {
     __shared__ int s_wcnt[4];
+    __shared__ int s_start, s_total;
     const int band = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int run = band_off[band];
+    // pass 1: count
+    int mine = 0;
+    for (int p = tid; p < n_paths; p += 256) {
+        int f = b0[p], n = nb[p];
+        mine += (n > 0 && band >= f && band < f + n) ? 1 : 0;
+    }
+    int wtot;
+    wave_excl_scan(mine, lane, wtot);
+    if (lane == 0) s_wcnt[wave] = wtot;
+    __syncthreads();
+    if (tid == 0) {
+        int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        int start = total ? atomicAdd(&bd->entry_cursor, total) : 0;
+        if (start + total > entry_cap) { atomicOr(&bd->err, 4); total = 0; }
+        s_start = start;
+        s_total = total;
+        band_start[band] = start;
+        band_count[band] = total;
+    }
+    __syncthreads();
+    int run = s_start;
+    const bool enabled = s_total > 0;
+    __syncthreads();
+    // pass 2: fill in ascending path order
     for (int base = 0; base < n_paths; base += 256) {
         int p = base + tid;
         bool hit = false;
@@ -410,11 +515,7 @@ __global__ __launch_bounds__(256) void k_band_entries(const int* __restrict__ b0
             if (w < wave) off += s_wcnt[w];
             total += s_wcnt[w];
         }
-        if (hit) {
-            int idx = run + off + __popcll(m & ((1ull << lane) - 1ull));
-            if (idx < entry_cap) entries[idx] = p;
-            else atomicOr(&bd->err, 4);
-        }
+        if (hit && enabled) entries[run + off + __popcll(m & ((1ull << lane) - 1ull))] = p;
         run += total;
         __syncthreads();
     }
@@ -436,12 +537,14 @@ __device__ __forceinline__ int lds_index(int trow, int tcol) {
 }
 
 struct TileArgs {
-    const int* band_off;       // n_bands + 1
+    const int* band_start;     // per band: first entry, number of entries
+    const int* band_count;
     const int* entries;        // path ids per band, ascending
     const int* bbox;           // n_paths x 4
     const int* b0;             // first band of each path
     const int* pb_off;         // (path, band) pair offsets
-    const int* bseg_off;       // band-seg offsets per pair
+    const int* bseg_off;       // per pair: first band segment, number of band segments
+    const int* pb_cnt;
     const BandSeg* bsegs;
     const uint8_t* rule;       // n_paths
     const double* paint;       // n_paths x 4
@@ -477,7 +580,7 @@ __global__ __launch_bounds__(NT) void k_tile_render(const TileArgs a) {
     for (int i = tid; i < TR * ROW_STRIDE; i += NT) s_trace[i] = 0.0;
     __syncthreads();
 
-    const int ent_begin = a.band_off[band], ent_end = a.band_off[band + 1];
+    const int ent_begin = a.band_start[band], ent_end = ent_begin + a.band_count[band];
     for (int base = ent_begin; base < ent_end; base += NT) {
         // ---- compact the band's path list down to the paths that touch this tile's columns ----
         int p_mine = -1, seg0 = 0, seg1 = 0;
@@ -489,7 +592,7 @@ __global__ __launch_bounds__(NT) void k_tile_render(const TileArgs a) {
             if (bb.y < tile_c1 && bb.y + bb.w > tile_c0) {
                 const int pb = a.pb_off[p_mine] + band - a.b0[p_mine];
                 seg0 = a.bseg_off[pb];
-                seg1 = a.bseg_off[pb + 1];
+                seg1 = seg0 + a.pb_cnt[pb];
                 hit = seg1 > seg0;  // no edge crosses this band: coverage is zero everywhere in it
             }
         }
@@ -741,7 +844,7 @@ struct svgr_batch {
     svgr_ctx* ctx = nullptr;
     int64_t n_segs = 0, n_paths = 0;
     int vp[4] = {0, 0, 0, 0};
-    bool has_vp = false;
+    bool has_vp = false;       // as given by the caller
     double thr = 0.16000000000000003;
     int band_first = 0, band_step = 1;
     bool planned = false;
@@ -749,13 +852,14 @@ struct svgr_batch {
     DevArr<double> segs, path_m6, path_paint;
     DevArr<uint8_t> seg_kind, path_rule;
     DevArr<int> seg_path;
-    // work
-    DevArr<int> seg_cnt, seg_off, edge_path, bbox, b0, nb, pb_off, pb_cnt, bseg_off, pb_cursor, band_cnt, band_off, entries;
+    // zeroed once per render: [BatchDev | per-path min/max keys | pb_cnt | pb_cursor]
+    DevArr<unsigned char> arena;
+    size_t arena_bytes = 0, off_pkeys = 0, off_pb_cnt = 0, off_pb_cursor = 0;
+    int pb_cap = 0;
+    // work arrays fully rewritten by every render
+    DevArr<int> edge_path, bbox, b0, nb, pb_off, bseg_off, band_start, band_count, entries;
     DevArr<double> edges;
-    DevArr<unsigned long long> pmin, pmax;
     DevArr<BandSeg> bsegs;
-    DevArr<BatchDev> bd;
-    Scanner scanner;
     // plan results
     int64_t n_edges = 0, n_pb = 0, n_bsegs = 0;
     int n_bands = 0;
@@ -764,12 +868,26 @@ struct svgr_batch {
     std::vector<TimedEvents> events;
     std::vector<hipEvent_t> event_pool;
 
+    BatchDev* bd() const { return (BatchDev*)arena.p; }
+    unsigned long long* pkeys() const { return (unsigned long long*)(arena.p + off_pkeys); }
+    int* pb_cnt() const { return (int*)(arena.p + off_pb_cnt); }
+    int* pb_cursor() const { return (int*)(arena.p + off_pb_cursor); }
+
+    int layout_arena(int new_pb_cap) {
+        pb_cap = new_pb_cap;
+        off_pkeys = sizeof(BatchDev);
+        off_pb_cnt = off_pkeys + sizeof(unsigned long long) * 4 * (size_t)n_paths;
+        off_pb_cursor = off_pb_cnt + sizeof(int) * (size_t)(pb_cap + 1);
+        arena_bytes = off_pb_cursor + sizeof(int) * (size_t)(pb_cap + 1);
+        arena_bytes = (arena_bytes + 255) & ~(size_t)255;
+        return arena.ensure(arena_bytes);
+    }
+
     void release() {
         segs.release(); path_m6.release(); path_paint.release(); seg_kind.release(); path_rule.release();
-        seg_path.release(); seg_cnt.release(); seg_off.release(); edge_path.release(); bbox.release(); b0.release();
-        nb.release(); pb_off.release(); pb_cnt.release(); bseg_off.release(); pb_cursor.release(); band_cnt.release();
-        band_off.release(); entries.release(); edges.release(); pmin.release(); pmax.release(); bsegs.release();
-        bd.release(); scanner.release();
+        seg_path.release(); arena.release(); edge_path.release(); bbox.release(); b0.release(); nb.release();
+        pb_off.release(); bseg_off.release(); band_start.release(); band_count.release(); entries.release();
+        edges.release(); bsegs.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
         for (auto e : event_pool) (void)hipEventDestroy(e);
@@ -778,87 +896,47 @@ struct svgr_batch {
 };
 
 static inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+static inline int cap_i32(size_t n) { return (int)std::min<size_t>(n, 0x7fffffff); }
 
-// stage A: transform + flatten + per-path min/max.  needs: seg_cnt, seg_off (n_segs+1)
-static int stage_count(svgr_batch* b) {
-    hipStream_t st = b->ctx->stream;
-    const int ns = (int)b->n_segs;
-    HIPCHK(hipMemsetAsync(b->bd.p, 0, sizeof(BatchDev), st));
-    hipLaunchKernelGGL(k_seg_count, grid1(ns + 1), dim3(256), 0, st, (const double*)b->segs.p,
-                       (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
-                       b->seg_cnt.p, b->bd.p);
-    return b->scanner.run(st, b->seg_cnt.p, b->seg_off.p, ns + 1);
-}
-
-static int stage_emit_bbox(svgr_batch* b, bool with_bands) {
+// Geometry stages.  `upto`: 1 = flatten (count only), 2 = + emit + bbox, 3 = + edge count + slot
+// reservation, 4 = everything.  `use_vp` = clip bboxes to b->vp and bin relative to it.
+static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     hipStream_t st = b->ctx->stream;
     const int ns = (int)b->n_segs, np = (int)b->n_paths;
-    HIPCHK(hipMemsetAsync(b->pmin.p, 0xFF, sizeof(unsigned long long) * 2 * np, st));
-    HIPCHK(hipMemsetAsync(b->pmax.p, 0x00, sizeof(unsigned long long) * 2 * np, st));
-    hipLaunchKernelGGL(k_seg_emit, grid1(ns), dim3(256), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
-                       (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr, (const int*)b->seg_off.p,
-                       b->edges.p, b->edge_path.p, (int)std::min<size_t>(b->edges.cap / 4, 0x7fffffff), b->pmin.p, b->pmax.p,
-                       b->bd.p);
-    // reset the bbox accumulators that k_path_bbox fills
-    BatchDev init{};
-    init.union_min_r = init.union_min_c = 0x7fffffff;
-    init.union_max_r = init.union_max_c = -0x7fffffff;
-    // keep err bits from the previous stage: only overwrite the tail of the struct
-    HIPCHK(hipMemcpyAsync((char*)b->bd.p + offsetof(BatchDev, n_nonempty), (char*)&init + offsetof(BatchDev, n_nonempty),
-                          sizeof(BatchDev) - offsetof(BatchDev, n_nonempty), hipMemcpyHostToDevice, st));
-    int* band_cnt = nullptr;
-    if (with_bands) {
-        HIPCHK(hipMemsetAsync(b->band_cnt.p, 0, sizeof(int) * (b->n_bands + 1), st));
-        band_cnt = b->band_cnt.p;
+    HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
+    const dim3 fgrid = grid1((size_t)ns << FL_SUB, FL_BLOCK);
+    if (upto == 1) {
+        if (ns > 0)
+            hipLaunchKernelGGL(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
+                               (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns,
+                               b->thr, (double*)nullptr, (int*)nullptr, 0, b->pkeys(), b->bd());
+        return 0;
     }
-    hipLaunchKernelGGL(k_path_bbox, grid1(np + 1), dim3(256), 0, st, (const unsigned long long*)b->pmin.p,
-                       (const unsigned long long*)b->pmax.p, np, b->has_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3],
-                       b->bbox.p, b->b0.p, b->nb.p, band_cnt, b->bd.p);
-    return 0;
-}
-
-// stage C: binning.  needs n_bands, pb arrays sized for n_pb, bsegs sized
-static int stage_bin_counts(svgr_batch* b) {
-    hipStream_t st = b->ctx->stream;
-    const int np = (int)b->n_paths;
-    if (int rc = b->scanner.run(st, b->nb.p, b->pb_off.p, np + 1)) return rc;
-    if (int rc = b->scanner.run(st, b->band_cnt.p, b->band_off.p, b->n_bands + 1)) return rc;
-    return 0;
-}
-
-static int stage_edge_count(svgr_batch* b) {
-    hipStream_t st = b->ctx->stream;
-    HIPCHK(hipMemsetAsync(b->pb_cnt.p, 0, sizeof(int) * (b->n_pb + 1), st));
-    if (b->n_edges > 0)
-        hipLaunchKernelGGL(k_edge_count, grid1((size_t)b->n_edges), dim3(256), 0, st, (const double*)b->edges.p,
-                           (const int*)b->edge_path.p, (const int*)(b->seg_off.p + b->n_segs), (const int*)b->bbox.p,
-                           (const int*)b->pb_off.p, (const int*)b->b0.p, b->vp[0], b->pb_cnt.p);
-    return b->scanner.run(st, b->pb_cnt.p, b->bseg_off.p, (int)b->n_pb + 1);
-}
-
-static int stage_edge_emit(svgr_batch* b) {
-    hipStream_t st = b->ctx->stream;
-    HIPCHK(hipMemsetAsync(b->pb_cursor.p, 0, sizeof(int) * (b->n_pb + 1), st));
-    if (b->n_edges > 0)
-        hipLaunchKernelGGL(k_edge_emit, grid1((size_t)b->n_edges), dim3(256), 0, st, (const double*)b->edges.p,
-                           (const int*)b->edge_path.p, (const int*)(b->seg_off.p + b->n_segs), (const int*)b->bbox.p,
-                           (const int*)b->pb_off.p, (const int*)b->b0.p, b->vp[0], (const int*)b->bseg_off.p,
-                           b->pb_cursor.p, b->bsegs.p, (int)std::min<size_t>(b->bsegs.cap, 0x7fffffff), b->bd.p);
+    if (ns > 0)
+        hipLaunchKernelGGL(k_flatten<true>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
+                           (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
+                           b->edges.p, b->edge_path.p, cap_i32(b->edges.cap / 4), b->pkeys(), b->bd());
+    hipLaunchKernelGGL(k_path_bbox, grid1(np), dim3(256), 0, st, (const unsigned long long*)b->pkeys(), np, use_vp ? 1 : 0,
+                       b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->b0.p, b->nb.p, b->pb_off.p, b->bd());
+    if (upto == 2) return 0;
+    const size_t ne = (size_t)std::max<int64_t>(b->n_edges, 1);
+    hipLaunchKernelGGL(k_edge_count, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
+                       (const int*)b->bbox.p, (const int*)b->pb_off.p, (const int*)b->b0.p, b->vp[0], b->pb_cap, b->pb_cnt(),
+                       b->bd());
+    hipLaunchKernelGGL(k_alloc, grid1((size_t)std::max(b->pb_cap, 1), 1024), dim3(1024), 0, st, (const int*)b->pb_cnt(), b->pb_cap,
+                       b->bseg_off.p, b->bd());
+    if (upto == 3) return 0;
+    hipLaunchKernelGGL(k_edge_emit, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
+                       (const int*)b->bbox.p, (const int*)b->pb_off.p, (const int*)b->b0.p, b->vp[0], b->pb_cap,
+                       (const int*)b->bseg_off.p, b->pb_cursor(), b->bsegs.p, cap_i32(b->bsegs.cap), b->bd());
     if (b->n_bands > 0)
-        hipLaunchKernelGGL(k_band_entries, dim3(b->n_bands), dim3(256), 0, st, (const int*)b->b0.p, (const int*)b->nb.p,
-                           (int)b->n_paths, (const int*)b->band_off.p, b->entries.p,
-                           (int)std::min<size_t>(b->entries.cap, 0x7fffffff), b->bd.p);
-    return 0;
-}
-
-static int read_i32(svgr_batch* b, const int* dptr, int* out) {
-    HIPCHK(hipMemcpyAsync(out, dptr, sizeof(int), hipMemcpyDeviceToHost, b->ctx->stream));
-    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+        hipLaunchKernelGGL(k_band_entries, dim3(b->n_bands), dim3(256), 0, st, (const int*)b->b0.p, (const int*)b->nb.p, np,
+                           b->band_start.p, b->band_count.p, b->entries.p, cap_i32(b->entries.cap), b->bd());
     return 0;
 }
 
 static int check_dev_err(svgr_batch* b) {
-    HIPCHK(hipMemcpyAsync(&b->host_bd, b->bd.p, sizeof(BatchDev), hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipMemcpyAsync(&b->host_bd, b->bd(), sizeof(BatchDev), hipMemcpyDeviceToHost, b->ctx->stream));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
     HIPCHK(hipGetLastError());
     int e = b->host_bd.err;
@@ -1065,15 +1143,11 @@ int svgr_batch_create(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch** out)
     rc = rc ? rc : up(b->path_m6, d->path_m6, np * 6, sizeof(double));
     rc = rc ? rc : up(b->path_rule, d->path_rule, np, 1);
     rc = rc ? rc : up(b->path_paint, d->path_paint, np * 4, sizeof(double));
-    rc = rc ? rc : b->seg_cnt.ensure(ns + 1);
-    rc = rc ? rc : b->seg_off.ensure(ns + 1);
-    rc = rc ? rc : b->pmin.ensure(2 * np);
-    rc = rc ? rc : b->pmax.ensure(2 * np);
     rc = rc ? rc : b->bbox.ensure(4 * np);
     rc = rc ? rc : b->b0.ensure(np + 1);
     rc = rc ? rc : b->nb.ensure(np + 1);
     rc = rc ? rc : b->pb_off.ensure(np + 1);
-    rc = rc ? rc : b->bd.ensure(1);
+    rc = rc ? rc : b->layout_arena(0);
     if (!rc) {
         hipError_t e = hipStreamSynchronize(ctx->stream);  // seg_path is a local
         if (e != hipSuccess) rc = fail(SVGR_E_HIP, "sync: %s", hipGetErrorString(e));
@@ -1120,62 +1194,48 @@ int svgr_batch_plan(svgr_batch* b) {
     if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
     HIPCHK(hipSetDevice(b->ctx->device));
     b->planned = false;
-    const int ns = (int)b->n_segs, np = (int)b->n_paths;
-    // A: edge count
-    if (int rc = stage_count(b)) return rc;
-    int n_edges = 0;
-    if (int rc = read_i32(b, b->seg_off.p + ns, &n_edges)) return rc;
+    const int np = (int)b->n_paths;
+    // 1. count edges
+    if (int rc = b->layout_arena(0)) return rc;
+    if (int rc = run_geometry(b, 1, b->has_vp)) return rc;
     if (int rc = check_dev_err(b)) return rc;
-    b->n_edges = n_edges;
-    if (int rc = b->edges.ensure((size_t)std::max(n_edges, 1) * 4)) return rc;
-    if (int rc = b->edge_path.ensure((size_t)std::max(n_edges, 1))) return rc;
-    // B: edges + bbox (first without band counting when there is no viewport: the single path's own bbox becomes it)
+    b->n_edges = b->host_bd.edge_cursor;
+    if (int rc = b->edges.ensure((size_t)std::max<int64_t>(b->n_edges, 1) * 4)) return rc;
+    if (int rc = b->edge_path.ensure((size_t)std::max<int64_t>(b->n_edges, 1))) return rc;
+    // 2. edges + bboxes.  Without a viewport (S:968 `viewport is None`) the union of the unclipped
+    //    bboxes becomes the canvas.
     if (!b->has_vp) {
-        // no viewport (S:968 `viewport is None`): the union of the unclipped bboxes becomes the canvas
-        if (int rc = stage_emit_bbox(b, false)) return rc;
+        if (int rc = run_geometry(b, 2, false)) return rc;
         if (int rc = check_dev_err(b)) return rc;
         if (b->host_bd.n_nonempty > 0) {
-            long long ur = (long long)b->host_bd.union_max_r - b->host_bd.union_min_r;
-            long long uc = (long long)b->host_bd.union_max_c - b->host_bd.union_min_c;
+            long long r0 = (long long)UNION_BIAS - (long long)b->host_bd.umin_r, c0 = (long long)UNION_BIAS - (long long)b->host_bd.umin_c;
+            long long ur = (long long)b->host_bd.umax_r - UNION_BIAS - r0, uc = (long long)b->host_bd.umax_c - UNION_BIAS - c0;
             if (ur * uc > (1ll << 31) || ur > (1 << 24) || uc > (1 << 24))
                 return fail(SVGR_E_INVALID, "unclipped extent of %lldx%lld pixels is too large; pass a viewport", ur, uc);
-            b->vp[0] = b->host_bd.union_min_r; b->vp[1] = b->host_bd.union_min_c;
-            b->vp[2] = (int)ur; b->vp[3] = (int)uc;
+            b->vp[0] = (int)r0; b->vp[1] = (int)c0; b->vp[2] = (int)ur; b->vp[3] = (int)uc;
         } else {
             b->vp[0] = b->vp[1] = 0; b->vp[2] = b->vp[3] = 0;
         }
     }
     b->n_bands = (b->vp[2] + TR - 1) / TR;
-    if (int rc = b->band_cnt.ensure((size_t)b->n_bands + 1)) return rc;
-    if (int rc = b->band_off.ensure((size_t)b->n_bands + 1)) return rc;
-    const bool saved_has_vp = b->has_vp;
-    b->has_vp = true;  // from here on the (possibly derived) viewport is explicit
-    int rc = stage_emit_bbox(b, true);
-    if (!rc) rc = stage_bin_counts(b);
-    int n_pb = 0;
-    if (!rc) rc = read_i32(b, b->pb_off.p + np, &n_pb);
-    if (!rc) rc = check_dev_err(b);
-    if (rc) { b->has_vp = saved_has_vp; return rc; }
-    b->n_pb = n_pb;
-    rc = b->pb_cnt.ensure((size_t)n_pb + 1);
-    if (!rc) rc = b->bseg_off.ensure((size_t)n_pb + 1);
-    if (!rc) rc = b->pb_cursor.ensure((size_t)n_pb + 1);
-    if (!rc) rc = b->entries.ensure((size_t)std::max(n_pb, 1));
-    if (!rc) rc = stage_edge_count(b);
-    int n_bsegs = 0;
-    if (!rc) rc = read_i32(b, b->bseg_off.p + n_pb, &n_bsegs);
-    if (rc) { b->has_vp = saved_has_vp; return rc; }
-    b->n_bsegs = n_bsegs;
-    rc = b->bsegs.ensure((size_t)std::max(n_bsegs, 1));
-    if (!rc) rc = stage_edge_emit(b);
-    if (!rc) rc = check_dev_err(b);
+    if (int rc = b->band_start.ensure((size_t)b->n_bands + 1)) return rc;
+    if (int rc = b->band_count.ensure((size_t)b->n_bands + 1)) return rc;
+    if (int rc = run_geometry(b, 2, true)) return rc;
+    if (int rc = check_dev_err(b)) return rc;
+    b->n_pb = b->host_bd.pb_cursor;
+    // 3. per-pair counts -> band segments
+    if (int rc = b->layout_arena((int)b->n_pb)) return rc;
+    if (int rc = b->bseg_off.ensure((size_t)b->n_pb + 1)) return rc;
+    if (int rc = b->entries.ensure((size_t)std::max<int64_t>(b->n_pb, 1))) return rc;
+    if (int rc = run_geometry(b, 3, true)) return rc;
+    if (int rc = check_dev_err(b)) return rc;
+    b->n_bsegs = b->host_bd.bseg_cursor;
+    if (int rc = b->bsegs.ensure((size_t)std::max<int64_t>(b->n_bsegs, 1))) return rc;
+    // 4. full geometry once, to validate the capacities and fetch the bboxes
+    if (int rc = run_geometry(b, 4, true)) return rc;
+    if (int rc = check_dev_err(b)) return rc;
     b->host_bbox.resize(4 * (size_t)np);
-    if (!rc) {
-        hipError_t e = hipMemcpy(b->host_bbox.data(), b->bbox.p, sizeof(int) * 4 * np, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(SVGR_E_HIP, "bbox readback: %s", hipGetErrorString(e));
-    }
-    b->has_vp = saved_has_vp;
-    if (rc) return rc;
+    HIPCHK(hipMemcpy(b->host_bbox.data(), b->bbox.p, sizeof(int) * 4 * np, hipMemcpyDeviceToHost));
     b->planned = true;
     return 0;
 }
@@ -1184,15 +1244,16 @@ int svgr_batch_get_stats(const svgr_batch* b, svgr_batch_stats* out) {
     if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
     if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan has not run");
     out->n_edges = b->n_edges;
-    out->path_pixels = b->host_bd.path_pixels;
+    out->path_pixels = (int64_t)b->host_bd.path_pixels;
     out->n_band_segs = b->n_bsegs;
     out->n_path_bands = b->n_pb;
     out->n_nonempty = b->host_bd.n_nonempty;
     if (b->host_bd.n_nonempty > 0) {
-        out->bbox_union[0] = b->host_bd.union_min_r;
-        out->bbox_union[1] = b->host_bd.union_min_c;
-        out->bbox_union[2] = b->host_bd.union_max_r - b->host_bd.union_min_r;
-        out->bbox_union[3] = b->host_bd.union_max_c - b->host_bd.union_min_c;
+        long long r0 = (long long)UNION_BIAS - (long long)b->host_bd.umin_r, c0 = (long long)UNION_BIAS - (long long)b->host_bd.umin_c;
+        out->bbox_union[0] = r0;
+        out->bbox_union[1] = c0;
+        out->bbox_union[2] = (long long)b->host_bd.umax_r - UNION_BIAS - r0;
+        out->bbox_union[3] = (long long)b->host_bd.umax_c - UNION_BIAS - c0;
     } else {
         out->bbox_union[0] = out->bbox_union[1] = out->bbox_union[2] = out->bbox_union[3] = 0;
     }
@@ -1266,23 +1327,18 @@ int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags
         if (int rc = get_event(b, &ev.e2)) return rc;
         HIPCHK(hipEventRecord(ev.e0, st));
     }
-    // geometry, identical to plan but without read-backs (capacities are exact for unchanged input)
-    const bool saved_has_vp = b->has_vp;
-    b->has_vp = true;
-    int rc = stage_count(b);
-    if (!rc) rc = stage_emit_bbox(b, true);
-    if (!rc) rc = stage_bin_counts(b);
-    if (!rc) rc = stage_edge_count(b);
-    if (!rc) rc = stage_edge_emit(b);
-    b->has_vp = saved_has_vp;
-    if (rc) return rc;
+    // geometry, identical to the last plan step but without read-backs (capacities are exact for
+    // unchanged input; the kernels flag an overflow otherwise and svgr_batch_timings / the next
+    // plan reports it)
+    if (int rc = run_geometry(b, 4, true)) return rc;
     if (single && need) HIPCHK(hipMemsetAsync(out->ptr, 0, need, st));
     if (timed) HIPCHK(hipEventRecord(ev.e1, st));
 
     if (owned_bands > 0 && n_ctiles > 0) {
         TileArgs a;
-        a.band_off = b->band_off.p; a.entries = b->entries.p; a.bbox = b->bbox.p; a.b0 = b->b0.p;
-        a.pb_off = b->pb_off.p; a.bseg_off = b->bseg_off.p; a.bsegs = b->bsegs.p; a.rule = b->path_rule.p;
+        a.band_start = b->band_start.p; a.band_count = b->band_count.p; a.entries = b->entries.p; a.bbox = b->bbox.p;
+        a.b0 = b->b0.p; a.pb_off = b->pb_off.p; a.bseg_off = b->bseg_off.p; a.pb_cnt = b->pb_cnt(); a.bsegs = b->bsegs.p;
+        a.rule = b->path_rule.p;
         a.paint = b->path_paint.p; a.out = out->ptr;
         a.vr0 = b->vp[0]; a.vc0 = b->vp[1]; a.vrows = b->vp[2]; a.vcols = b->vp[3];
         a.band_first = b->band_first; a.band_step = b->band_step;

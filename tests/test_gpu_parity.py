@@ -67,7 +67,7 @@ def test_transform_on_device_bit_exact(S):
                            [[0, 0, 0, 1]], viewport=None)
         batch.plan()
         edges, _ = batch.edges()
-        assert np.array_equal(edges.reshape(-1, 4), out.reshape(-1, 4))
+        assert np.array_equal(sort_edges(edges), sort_edges(out))  # slot order depends on which wave reserves first
 
 
 # ------------------------------------------------------------------------------------------
