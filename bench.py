@@ -183,7 +183,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_max = float(tt.item())
         # optional assembly of the full canvas on every rank (equal shards when bands divide evenly)
-        n_bands = (rows + _abi.TILE_ROWS - 1) // _abi.TILE_ROWS
+        n_bands = (rows + _abi.tile_rows() - 1) // _abi.tile_rows()
         if n_bands % world == 0:
             dist.barrier()
             torch.cuda.synchronize()

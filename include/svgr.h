@@ -67,6 +67,8 @@ typedef struct svgr_batch svgr_batch;
 /* context + device memory                                                                      */
 /* -------------------------------------------------------------------------------------------- */
 int svgr_abi_version(void);
+int svgr_tile_rows(void); /* band height: the row granularity of svgr_batch_set_bands */
+int svgr_tile_cols(void);
 const char* svgr_last_error(void);
 int svgr_device_count(void);
 
@@ -119,7 +121,7 @@ int svgr_batch_destroy(svgr_batch* batch);
 int svgr_batch_set_paints(svgr_batch* batch, const double* path_paint);
 int svgr_batch_set_transforms(svgr_batch* batch, const double* path_m6);
 
-/* Restrict rendering to row bands {band_first + k * band_step} of the viewport (band = 16 rows):
+/* Restrict rendering to row bands {band_first + k * band_step} of the viewport (band = svgr_tile_rows() rows):
  * one rank of an N-GPU job owns bands rank, rank+N, ...  Default (0, 1) = all bands.             */
 int svgr_batch_set_bands(svgr_batch* batch, int band_first, int band_step);
 

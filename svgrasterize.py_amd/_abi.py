@@ -19,7 +19,6 @@ LIB_PATH = os.path.join(HERE, "csrc", "libsvgr_hip.so")
 OUT_CANVAS_F32, OUT_CANVAS_F64, OUT_MASK_F64, OUT_FILL_F64 = 0, 1, 2, 3
 RENDER_CLIP01, RENDER_TIMED = 1, 2
 SEG_LINE, SEG_CUBIC = 0, 1
-TILE_ROWS = 16
 
 CONVERT_PRE_TO_STRAIGHT, CONVERT_SRGB_TO_LINEAR, CONVERT_LINEAR_TO_SRGB, CONVERT_STRAIGHT_TO_PRE = 1, 2, 4, 8
 
@@ -48,6 +47,8 @@ class BatchStats(C.Structure):
 _P = C.c_void_p
 _PROTOS = {
     "svgr_abi_version": (C.c_int, []),
+    "svgr_tile_rows": (C.c_int, []),
+    "svgr_tile_cols": (C.c_int, []),
     "svgr_last_error": (C.c_char_p, []),
     "svgr_device_count": (C.c_int, []),
     "svgr_init": (C.c_int, [C.c_int, C.POINTER(_P)]),
@@ -107,6 +108,11 @@ def load_library():
             fn.argtypes = args
         _lib = lib
         return lib
+
+
+def tile_rows() -> int:
+    """Band height of the built library (row granularity of Batch.set_bands)."""
+    return int(load_library().svgr_tile_rows())
 
 
 def _check(rc: int):

@@ -264,6 +264,67 @@ SVGR_HD void row_pieces(double x, double x_next, double d, Put&& put) {
     }
 }
 
+// The same pieces in closed form, so that they can be computed once per edge row and applied by
+// every tile that the row touches:
+//   n == 1 : pieces at x0i (v[0]) and x0i+1 (v[1])                                  (one-pixel case)
+//   n == 2 : x0i (v[0]), x0i+1 (v[1]), x0i+2 (v[4])
+//   n >= 3 : x0i (v[0]), x0i+1 (v[1]), x0i+2 .. x0i+n-2 (v[2] each), x0i+n-1 (v[3]), x0i+n (v[4])
+// where n = x1i - x0i (n = 1 also covers x1i == x0i).  Values are exactly those of row_pieces.
+struct RowPieces {
+    int x0i, n;
+    double v[5];
+};
+
+SVGR_HD RowPieces row_record(double x, double x_next, double d) {
+    RowPieces r;
+    double x0 = x < x_next ? x : x_next;
+    double x1 = x < x_next ? x_next : x;
+    double x0_floor = floor(x0);
+    r.x0i = clamp_to_int(x0_floor);
+    double x1_ceil = ceil(x1);
+    int x1i = clamp_to_int(x1_ceil);
+    r.v[2] = r.v[3] = r.v[4] = 0.0;
+    if (x1i <= r.x0i + 1) {
+        double xmf = 0.5 * (x + x_next) - x0_floor;
+        r.n = 1;
+        r.v[0] = d * (1 - xmf);
+        r.v[1] = d * xmf;
+    } else {
+        double s = 1 / (x1 - x0);
+        double x0f = x0 - x0_floor;
+        double x1f = x1 - x1_ceil + 1.0;
+        double o = 1 - x0f;
+        double a0 = 0.5 * s * (o * o);
+        double am = 0.5 * s * (x1f * x1f);
+        r.n = x1i - r.x0i;
+        r.v[0] = d * a0;
+        r.v[4] = d * am;
+        if (r.n == 2) {
+            r.v[1] = d * (1.0 - a0 - am);
+        } else {
+            double a1 = s * (1.5 - x0f);
+            r.v[1] = d * (a1 - a0);
+            r.v[2] = d * s;
+            double a2 = a1 + (double)(x1i - r.x0i - 3) * s;
+            r.v[3] = d * (1.0 - a2 - am);
+        }
+    }
+    return r;
+}
+
+// feed the pieces of a record to `put(xi, v)` in increasing column order; put returns false to stop
+template <class Put>
+SVGR_HD void apply_record(int x0i, int n, const double* v, Put&& put) {
+    if (!put(x0i, v[0])) return;
+    if (!put(x0i + 1, v[1])) return;
+    if (n >= 3) {
+        for (int xi = x0i + 2; xi < x0i + n - 1; ++xi)
+            if (!put(xi, v[2])) return;
+        if (!put(x0i + n - 1, v[3])) return;
+    }
+    if (n >= 2) put(x0i + n, v[4]);
+}
+
 // column span touched by a row, without computing the pieces: [lo, hi] inclusive
 SVGR_HD void row_span(double x, double x_next, int& lo, int& hi) {
     double x0 = x < x_next ? x : x_next;

@@ -42,23 +42,32 @@ using namespace svgr;
 // ======================================================================================
 // tile geometry
 // ======================================================================================
-constexpr int TR = 16;                     // rows per band / tile
+#ifndef SVGR_TR
+#define SVGR_TR 16
+#endif
+constexpr int TR = SVGR_TR;                // rows per band / tile
 constexpr int TC = 128;                    // columns per tile
 constexpr int PX = 8;                      // pixels per lane (consecutive columns)
 constexpr int CH = TC / PX;                // lanes per row = 16 = one DPP row
 constexpr int NT = TR * CH;                // 256 threads = 4 waves; a wave covers 4 tile rows
 constexpr int CHUNK_STRIDE = PX + 2;       // doubles; +16 B makes the 16-lane b128 groups conflict free
 constexpr int ROW_STRIDE = CH * CHUNK_STRIDE;
-constexpr int LPS = 4;                     // lanes per band segment in the scatter phase
 static_assert(CH == 16, "row scan uses one 16-lane DPP row per tile row");
-static_assert(NT == 256, "tile kernel is written for 256 threads");
+constexpr int NW = NT / 64;                // waves per workgroup; a wave covers 4 tile rows
+static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 1024 threads");
 
-struct BandSeg {  // one edge inside one band (40 B)
-    double x;     // column where the edge enters row y0 (carried by the reference recurrence)
-    double dxdy, p0y, p1y;
-    int y0;       // first traced row (layer-local)
-    int y1s;      // one past the last traced row in this band; negative => dir = -1
+// One row of one edge (the signed-area pieces of line_signed_coverage for that scanline, S:2250-2303),
+// computed once by k_edge_emit and applied by every tile the row reaches.  48 B = 3 x 16 B, so a
+// 4 KiB LDS-DMA block holds 85 of them.
+struct RowRec {
+    int x0i;        // unclamped layer column of the first piece
+    unsigned nrow;  // bits 0-25: n = x1i - x0i (see svgr_core.h RowPieces), bits 26-31: row inside the band
+    double v[5];
 };
+static_assert(sizeof(RowRec) == 48, "RowRec must stay 48 bytes");
+constexpr int PREF_RECS = 85;          // records per prefetch block
+constexpr unsigned SPAN_MAX = (1u << 26) - 1;
+static_assert(SVGR_TR <= 64, "row-in-band is stored in 6 bits");
 
 // ======================================================================================
 // errors
@@ -387,13 +396,20 @@ __device__ __forceinline__ bool edge_prepare(const double* __restrict__ edges, c
     return true;
 }
 
+// rows of an edge inside band `band` (layer-local [ya, yb))
+__device__ __forceinline__ void band_rows(const EdgeSetup& es, int band, int vr0, int r0, int& ya, int& yb) {
+    const int b0row = band * TR + vr0 - r0;
+    ya = es.y_begin > b0row ? es.y_begin : b0row;
+    yb = es.y_end < b0row + TR ? es.y_end : b0row + TR;
+}
+
 __global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ edges, const int* __restrict__ edge_path,
                                                     const int* __restrict__ bbox, const int* __restrict__ pb_off,
                                                     const int* __restrict__ b0, int vr0, int pb_cap,
                                                     int* __restrict__ pb_cnt, BatchDev* __restrict__ bd) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     EdgeSetup es;
-    int p = 0, r0 = 0, key = -1, bf = 0, bl = -1;
+    int p = 0, r0 = 0, key = -1, bf = 0, bl = -1, rows_first = 0;
     bool ok = e < bd->edge_cursor && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
     if (ok) {
         bf = (r0 + es.y_begin - vr0) / TR;
@@ -401,11 +417,24 @@ __global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ e
         key = pb_off[p] - b0[p] + bf;
         if (key < 0 || key + (bl - bf) >= pb_cap) { atomicOr(&bd->err, 4); ok = false; }
     }
-    int head, len;
-    wave_runs(key, ok, lane, head, len);
     if (ok) {
-        if (head == lane) atomicAdd(&pb_cnt[key], len);           // first band: one atomic per run of equal pairs
-        for (int b = 1; b <= bl - bf; ++b) atomicAdd(&pb_cnt[key + b], 1);
+        int ya, yb;
+        band_rows(es, bf, vr0, r0, ya, yb);
+        rows_first = yb - ya;
+    }
+    int head, len, total;
+    wave_runs(key, ok, lane, head, len);
+    const int excl = wave_excl_scan(rows_first, lane, total);
+    const int run_end_incl = __shfl(excl + rows_first, (head + len - 1) & 63);
+    const int run_begin_excl = __shfl(excl, head);
+    if (ok) {
+        // first band: one atomic per run of lanes that share a (path, band) pair
+        if (head == lane) atomicAdd(&pb_cnt[key], run_end_incl - run_begin_excl);
+        for (int b = 1; b <= bl - bf; ++b) {
+            int ya, yb;
+            band_rows(es, bf + b, vr0, r0, ya, yb);
+            atomicAdd(&pb_cnt[key + b], yb - ya);
+        }
     }
 }
 
@@ -424,10 +453,10 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
                                                    const int* __restrict__ bbox, const int* __restrict__ pb_off,
                                                    const int* __restrict__ b0, int vr0, int pb_cap,
                                                    const int* __restrict__ bseg_off, int* __restrict__ pb_cursor,
-                                                   BandSeg* __restrict__ bsegs, int bseg_cap, BatchDev* __restrict__ bd) {
+                                                   RowRec* __restrict__ recs, int rec_cap, BatchDev* __restrict__ bd) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     EdgeSetup es;
-    int p = 0, r0 = 0, key = -1;
+    int p = 0, r0 = 0, key = -1, rows_first = 0;
     bool ok = e < bd->edge_cursor && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
     int bf = 0, bl = -1;
     if (ok) {
@@ -436,10 +465,18 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
         key = pb_off[p] - b0[p] + bf;
         if (key < 0 || key + (bl - bf) >= pb_cap) ok = false;  // flagged by k_edge_count
     }
-    int head, len;
+    if (ok) {
+        int ya, yb;
+        band_rows(es, bf, vr0, r0, ya, yb);
+        rows_first = yb - ya;
+    }
+    int head, len, total;
     wave_runs(key, ok, lane, head, len);
+    const int excl = wave_excl_scan(rows_first, lane, total);
+    const int run_end_incl = __shfl(excl + rows_first, (head + len - 1) & 63);
+    const int run_begin_excl = __shfl(excl, head);
     int run_base = 0;
-    if (ok && head == lane) run_base = atomicAdd(&pb_cursor[key], len);
+    if (ok && head == lane) run_base = atomicAdd(&pb_cursor[key], run_end_incl - run_begin_excl);
     run_base = __shfl(run_base, head);
     if (!ok) return;
     RowState st;
@@ -449,23 +486,23 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
     int y = es.y_begin;
     for (int b = 0; y < es.y_end; ++b) {
         const int band = bf + b;
-        const int band_end_row = (band + 1) * TR + vr0 - r0;  // first layer-local row of the next band
-        const int y1 = band_end_row < es.y_end ? band_end_row : es.y_end;
+        int ya, y1;
+        band_rows(es, band, vr0, r0, ya, y1);
         const int pb = key + b;
-        const int slot = bseg_off[pb] + (b == 0 ? run_base + (lane - head) : atomicAdd(&pb_cursor[pb], 1));
-        if (slot < bseg_cap) {
-            BandSeg g;
-            g.x = st.x_next;
-            g.dxdy = es.dxdy;
-            g.p0y = es.p0y;
-            g.p1y = es.p1y;
-            g.y0 = y;
-            g.y1s = es.dir < 0.0 ? -y1 : y1;
-            bsegs[slot] = g;
-        } else {
-            atomicOr(&bd->err, 8);
+        int slot = bseg_off[pb] + (b == 0 ? run_base + (excl - run_begin_excl) : atomicAdd(&pb_cursor[pb], y1 - ya));
+        const int band_row0 = band * TR + vr0 - r0;
+        for (; y < y1; ++y, ++slot) {
+            row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);  // carry x exactly as S:2244-2248
+            const RowPieces rp = row_record(st.x, st.x_next, st.d);
+            if (slot >= rec_cap) { atomicOr(&bd->err, 8); continue; }
+            unsigned n = (unsigned)rp.n;
+            if (n > SPAN_MAX) { atomicOr(&bd->err, 16); n = SPAN_MAX; }
+            RowRec r;
+            r.x0i = rp.x0i;
+            r.nrow = n | ((unsigned)(y - band_row0) << 26);
+            r.v[0] = rp.v[0]; r.v[1] = rp.v[1]; r.v[2] = rp.v[2]; r.v[3] = rp.v[3]; r.v[4] = rp.v[4];
+            recs[slot] = r;
         }
-        for (; y < y1; ++y) row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);  // carry x exactly as S:2244-2248
     }
 }
 
@@ -524,6 +561,9 @@ __global__ __launch_bounds__(256) void k_band_entries(const int* __restrict__ b0
 // ======================================================================================
 // tile kernel
 // ======================================================================================
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
 template <int N>
 __device__ __forceinline__ double dpp_row_shr(double v) {  // lane i <- lane i-N inside a 16-lane row, else +0.0
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -545,7 +585,7 @@ struct TileArgs {
     const int* pb_off;         // (path, band) pair offsets
     const int* bseg_off;       // per pair: first band segment, number of band segments
     const int* pb_cnt;
-    const BandSeg* bsegs;
+    const RowRec* bsegs;
     const uint8_t* rule;       // n_paths
     const double* paint;       // n_paths x 4
     void* out;
@@ -558,13 +598,15 @@ struct TileArgs {
 
 // OUT: 0 = canvas f32, 1 = canvas f64, 2 = mask f64 (single path), 3 = fill f64 (single path)
 template <int OUT>
-__global__ __launch_bounds__(NT) void k_tile_render(const TileArgs a) {
+__global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
     __shared__ double s_trace[TR * ROW_STRIDE];
     __shared__ int s_list[NT];      // compacted path ids of this tile
     __shared__ int s_seg0[NT];      // their band-segment ranges ...
     __shared__ int s_seg1[NT];
     __shared__ int4 s_bbox[NT];     // ... and bboxes, fetched by 256 lanes at once (no dependent-load chain per path)
-    __shared__ int s_wcnt[4];
+    __shared__ int s_wcnt[NW];
+    // band segments of the current / next path, filled by LDS-DMA (global_load_lds) one path ahead
+    __shared__ __attribute__((aligned(16))) double s_pref[2][512];  // 2 x 4 KiB
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int trow = tid / CH, chunk = tid % CH;
@@ -601,7 +643,7 @@ __global__ __launch_bounds__(NT) void k_tile_render(const TileArgs a) {
         __syncthreads();
         int off = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             if (w < wave) off += s_wcnt[w];
             total += s_wcnt[w];
         }
@@ -614,7 +656,21 @@ __global__ __launch_bounds__(NT) void k_tile_render(const TileArgs a) {
         }
         __syncthreads();
 
+        // LDS-DMA of one path's band segments (up to PREF_SEGS) into s_pref[buf]: 16 B per lane,
+        // each wave fills its own 1 KiB slice; completion = the issuing wave's vmcnt + a barrier
+        auto prefetch = [&](int li_, int buf_) {
+            const int n_bytes = (s_seg1[li_] - s_seg0[li_] < PREF_RECS ? s_seg1[li_] - s_seg0[li_] : PREF_RECS) * 48;
+            if (tid < 256 && tid * 16 < n_bytes) {
+                const char* g = (const char*)(a.bsegs + s_seg0[li_]) + tid * 16;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)((char*)&s_pref[buf_][0] + wave * 1024), 16, 0, 0);
+            }
+        };
+        if (total > 0) prefetch(0, 0);
+
         for (int li = 0; li < total; ++li) {
+            const int cur = li & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // segments of path li have landed; scan of path li-1 is finished
             const int p = s_list[li];
             const int s0 = s_seg0[li], s1 = s_seg1[li];
             const int4 pbb = s_bbox[li];
@@ -628,47 +684,62 @@ __global__ __launch_bounds__(NT) void k_tile_render(const TileArgs a) {
             const double p0 = a.paint[4 * (size_t)p], p1 = a.paint[4 * (size_t)p + 1];
             const double p2 = a.paint[4 * (size_t)p + 2], p3 = a.paint[4 * (size_t)p + 3];
 
-            // ---- scatter: LPS lanes per band segment, lane j takes rows y0+j, y0+j+LPS, ...; the x
-            //      recurrence is replayed forward from the band entry (cheap), the area pieces go to LDS ----
-            const int n_items = (s1 - s0) * LPS;
+            // ---- scatter: one lane per edge-row record; the pieces were computed by k_edge_emit, here
+            //      they are only clamped to the layer / tile and added to the LDS delta tile ----
+#ifdef SVGR_DBG_NOSCATTER
+            const int n_items = 0 * (s1 - s0);
+#else
+            const int n_items = s1 - s0;
+#endif
             for (int w = tid; w < n_items; w += NT) {
-                const BandSeg g = a.bsegs[s0 + w / LPS];
-                const double dir = g.y1s < 0 ? -1.0 : 1.0;
-                const int y1 = g.y1s < 0 ? -g.y1s : g.y1s;
-                RowState st;
-                st.x_next = g.x;
-                int yy = g.y0;
-                for (int y = g.y0 + (w % LPS); y < y1; y += LPS) {
-                    for (; yy <= y; ++yy) row_step(st, yy, g.p0y, g.p1y, g.dxdy, dir);
-                    double* trow_ptr = s_trace + (y + row_shift) * ROW_STRIDE;
-                    int lo, hi;
-                    row_span(st.x, st.x_next, lo, hi);
-                    if (lo >= hi_c) continue;  // everything at or beyond the tile's / layer's right edge
-                    if (hi < lo_c) {
-                        // whole row span left of the tile: the pieces sum to d; fold into the first column
-                        int tc = lo_c + col_shift;
-                        __hip_atomic_fetch_add(trow_ptr + (tc / PX) * CHUNK_STRIDE + (tc % PX), st.d, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-                        continue;
-                    }
-                    row_pieces(st.x, st.x_next, st.d, [&](int xi, double v) -> bool {
-                        int c = xi > 0 ? xi : 0;   // left of the layer folds into column 0 (S:2262)
-                        if (c >= hi_c) return false;
-                        c = c > lo_c ? c : lo_c;   // left of the tile folds into its first column (row carry-in)
-                        int tc = c + col_shift;
-                        __hip_atomic_fetch_add(trow_ptr + (tc / PX) * CHUNK_STRIDE + (tc % PX), v, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-                        return true;
-                    });
+                int x0i;
+                unsigned nrow;
+                double v[5];
+                if (w < PREF_RECS) {
+                    const double* q = &s_pref[cur][w * 6];
+                    const int2 hd = *(const int2*)q;
+                    x0i = hd.x; nrow = (unsigned)hd.y;
+                    v[0] = q[1]; v[1] = q[2]; v[2] = q[3]; v[3] = q[4]; v[4] = q[5];
+                } else {
+                    const RowRec g = a.bsegs[s0 + w];
+                    x0i = g.x0i; nrow = g.nrow;
+                    v[0] = g.v[0]; v[1] = g.v[1]; v[2] = g.v[2]; v[3] = g.v[3]; v[4] = g.v[4];
                 }
+                const int n = (int)(nrow & SPAN_MAX);
+                double* trow_ptr = s_trace + (int)(nrow >> 26) * ROW_STRIDE;
+                if (x0i >= hi_c) continue;  // everything at or beyond the tile's / layer's right edge
+                if (x0i + n < lo_c) {
+                    // whole row span left of the tile: fold the sum of its pieces (= d) into the first column
+                    double sum = v[0] + v[1];
+                    if (n >= 3) sum = sum + (double)(n - 3) * v[2] + v[3];
+                    if (n >= 2) sum = sum + v[4];
+                    const int tc = lo_c + col_shift;
+                    __hip_atomic_fetch_add(trow_ptr + (tc / PX) * CHUNK_STRIDE + (tc % PX), sum, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    continue;
+                }
+                apply_record(x0i, n, v, [&](int xi, double val) -> bool {
+                    int c = xi > 0 ? xi : 0;   // left of the layer folds into column 0 (S:2262)
+                    if (c >= hi_c) return false;
+                    c = c > lo_c ? c : lo_c;   // left of the tile folds into its first column (row carry-in)
+                    const int tc = c + col_shift;
+                    __hip_atomic_fetch_add(trow_ptr + (tc / PX) * CHUNK_STRIDE + (tc % PX), val, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    return true;
+                });
             }
             __syncthreads();
+            if (li + 1 < total) prefetch(li + 1, cur ^ 1);  // lands while this path is scanned and composited
 
             // ---- row prefix sum + fill rule + paint + source-over ----
             // A wave owns 4 tile rows; skip the phase when the layer has no row among them (its
             // delta rows are untouched, so there is nothing to read, zero or composite).
             const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * (64 / CH);
+#ifdef SVGR_DBG_NOSCAN
+            if (false) {
+#else
             if (wrow0 + (64 / CH) > row_shift && wrow0 < row_shift + rows) {
+#endif
                 double* my = s_trace + trow * ROW_STRIDE + chunk * CHUNK_STRIDE;
                 double t[PX];
 #pragma unroll
@@ -717,7 +788,6 @@ __global__ __launch_bounds__(NT) void k_tile_render(const TileArgs a) {
                     }
                 }
             }
-            __syncthreads();
         }
         __syncthreads();
     }
@@ -859,7 +929,7 @@ struct svgr_batch {
     // work arrays fully rewritten by every render
     DevArr<int> edge_path, bbox, b0, nb, pb_off, bseg_off, band_start, band_count, entries;
     DevArr<double> edges;
-    DevArr<BandSeg> bsegs;
+    DevArr<RowRec> bsegs;
     // plan results
     int64_t n_edges = 0, n_pb = 0, n_bsegs = 0;
     int n_bands = 0;
@@ -952,6 +1022,8 @@ static int check_dev_err(svgr_batch* b) {
 extern "C" {
 
 int svgr_abi_version(void) { return SVGR_ABI_VERSION; }
+int svgr_tile_rows(void) { return TR; }
+int svgr_tile_cols(void) { return TC; }
 const char* svgr_last_error(void) { return g_err.c_str(); }
 
 int svgr_device_count(void) {
@@ -1230,7 +1302,7 @@ int svgr_batch_plan(svgr_batch* b) {
     if (int rc = run_geometry(b, 3, true)) return rc;
     if (int rc = check_dev_err(b)) return rc;
     b->n_bsegs = b->host_bd.bseg_cursor;
-    if (int rc = b->bsegs.ensure((size_t)std::max<int64_t>(b->n_bsegs, 1))) return rc;
+    if (int rc = b->bsegs.ensure((size_t)std::max<int64_t>(b->n_bsegs, 1) + PREF_RECS + 1)) return rc;
     // 4. full geometry once, to validate the capacities and fetch the bboxes
     if (int rc = run_geometry(b, 4, true)) return rc;
     if (int rc = check_dev_err(b)) return rc;

@@ -243,7 +243,7 @@ def test_band_sharding_matches_full(S):
     full = ctx.alloc(size * size * 32)
     batch.render(full, _abi.OUT_CANVAS_F64)
     full = full.download((size, size, 4), np.float64)
-    tr = _abi.TILE_ROWS
+    tr = _abi.tile_rows()
     for rank in range(world):
         batch.set_bands(rank, world)
         rows = batch.owned_rows()
