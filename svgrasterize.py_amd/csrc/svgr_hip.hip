@@ -46,13 +46,20 @@ using namespace svgr;
 #define SVGR_TR 16
 #endif
 constexpr int TR = SVGR_TR;                // rows per band / tile
-constexpr int TC = 128;                    // columns per tile
-constexpr int PX = 8;                      // pixels per lane (consecutive columns)
+#ifndef SVGR_PX
+#define SVGR_PX 8
+#endif
+constexpr int PX = SVGR_PX;                // pixels per lane (consecutive columns)
+constexpr int TC = 16 * PX;                // columns per tile: 16 lanes (one DPP row) per tile row
 constexpr int CH = TC / PX;                // lanes per row = 16 = one DPP row
 constexpr int NT = TR * CH;                // 256 threads = 4 waves; a wave covers 4 tile rows
 constexpr int CHUNK_STRIDE = PX + 2;       // doubles; +16 B makes the 16-lane b128 groups conflict free
 constexpr int ROW_STRIDE = CH * CHUNK_STRIDE;
 static_assert(CH == 16, "row scan uses one 16-lane DPP row per tile row");
+constexpr int PREF_WAVES = NT / 64 < 3 ? NT / 64 : 3;   // waves that issue the LDS-DMA of a record block (1 KiB each)
+constexpr int PREF_BYTES = PREF_WAVES * 1024;
+constexpr int PREF_RECS = PREF_BYTES / 48;              // slots per prefetch block (64 for a 256-thread workgroup)
+constexpr int PREF_DEPTH = 3;                           // blocks in flight: paths li, li+1, li+2
 constexpr int NW = NT / 64;                // waves per workgroup; a wave covers 4 tile rows
 static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 1024 threads");
 
@@ -65,7 +72,14 @@ struct RowRec {
     double v[5];
 };
 static_assert(sizeof(RowRec) == 48, "RowRec must stay 48 bytes");
-constexpr int PREF_RECS = 85;          // records per prefetch block
+// Every (path, band) pair's block starts with one header slot of the same size: the path's paint and
+// fill rule, so that the tile kernel gets them from the same LDS-DMA block as the records.
+struct PairHeader {
+    double paint[4];
+    int rule, pad[3];
+};
+static_assert(sizeof(PairHeader) == 48, "PairHeader occupies one record slot");
+constexpr int PREF_RECS_MAX = 85;      // records per 4 KiB prefetch block (the workgroup may be smaller: see PREF_RECS)
 constexpr unsigned SPAN_MAX = (1u << 26) - 1;
 static_assert(SVGR_TR <= 64, "row-in-band is stored in 6 bits");
 
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
 __global__ __launch_bounds__(256) void k_path_bbox(const unsigned long long* __restrict__ pkeys, int n_paths, int has_vp,
                                                    int vr0, int vc0, int vrows, int vcols, int* __restrict__ bbox,
                                                    int* __restrict__ b0, int* __restrict__ nb, int* __restrict__ pb_off,
-                                                   BatchDev* __restrict__ bd) {
+                                                   int* __restrict__ pb_path, int pb_cap, BatchDev* __restrict__ bd) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     int out[4] = {0, 0, 0, 0};
     int pb0 = 0, pnb = 0;
@@ -374,6 +388,8 @@ __global__ __launch_bounds__(256) void k_path_bbox(const unsigned long long* __r
         b0[p] = pb0;
         nb[p] = pnb;
         pb_off[p] = off;
+        if (pb_path)
+            for (int k = 0; k < pnb && off + k < pb_cap; ++k) pb_path[off + k] = p;
     }
 }
 
@@ -440,13 +456,26 @@ __global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ e
 
 // per (path, band) pair: reserve its band-segment slots (one atomic per wave)
 __global__ __launch_bounds__(1024) void k_alloc(const int* __restrict__ cnt, int n_cap, int* __restrict__ off,
+                                                const int* __restrict__ pb_path, const double* __restrict__ path_paint,
+                                                const uint8_t* __restrict__ path_rule, RowRec* __restrict__ recs, int rec_cap,
                                                 BatchDev* __restrict__ bd) {
     __shared__ int s_tot[17];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = bd->pb_cursor < n_cap ? bd->pb_cursor : n_cap;
     const int c = i < n ? cnt[i] : 0;
-    const int o = block_alloc(&bd->bseg_cursor, c, s_tot);
-    if (i < n) off[i] = o;
+    const int o = block_alloc(&bd->bseg_cursor, c > 0 ? c + 1 : 0, s_tot);  // + the header slot
+    if (i < n) {
+        off[i] = o;
+        if (c > 0 && recs && o < rec_cap) {
+            const int p = pb_path[i];
+            PairHeader h;
+            h.paint[0] = path_paint[4 * (size_t)p]; h.paint[1] = path_paint[4 * (size_t)p + 1];
+            h.paint[2] = path_paint[4 * (size_t)p + 2]; h.paint[3] = path_paint[4 * (size_t)p + 3];
+            h.rule = path_rule[p];
+            h.pad[0] = h.pad[1] = h.pad[2] = 0;
+            *(PairHeader*)(recs + o) = h;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ edges, const int* __restrict__ edge_path,
@@ -489,7 +518,7 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
         int ya, y1;
         band_rows(es, band, vr0, r0, ya, y1);
         const int pb = key + b;
-        int slot = bseg_off[pb] + (b == 0 ? run_base + (excl - run_begin_excl) : atomicAdd(&pb_cursor[pb], y1 - ya));
+        int slot = bseg_off[pb] + 1 + (b == 0 ? run_base + (excl - run_begin_excl) : atomicAdd(&pb_cursor[pb], y1 - ya));
         const int band_row0 = band * TR + vr0 - r0;
         for (; y < y1; ++y, ++slot) {
             row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);  // carry x exactly as S:2244-2248
@@ -594,19 +623,29 @@ struct TileArgs {
     int out_cols;                // row pitch of `out` in pixels
     int clip01;
     int single_r0, single_c0, single_cols;  // single-path outputs: layer origin / pitch
+    unsigned long long* dbg;                // diagnostic builds only
 };
 
 // OUT: 0 = canvas f32, 1 = canvas f64, 2 = mask f64 (single path), 3 = fill f64 (single path)
 template <int OUT>
 __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
-    __shared__ double s_trace[TR * ROW_STRIDE];
-    __shared__ int s_list[NT];      // compacted path ids of this tile
-    __shared__ int s_seg0[NT];      // their band-segment ranges ...
-    __shared__ int s_seg1[NT];
-    __shared__ int4 s_bbox[NT];     // ... and bboxes, fetched by 256 lanes at once (no dependent-load chain per path)
-    __shared__ int s_wcnt[NW];
-    // band segments of the current / next path, filled by LDS-DMA (global_load_lds) one path ahead
-    __shared__ __attribute__((aligned(16))) double s_pref[2][512];  // 2 x 4 KiB
+    // ONE __shared__ object, carved by hand: with a second object beside the LDS-DMA staging area
+    // hipcc (ROCm 7.2) drains vmcnt(0) before every ds_read and the record prefetch stops overlapping
+    constexpr int OFF_TRACE = 0;
+    constexpr int OFF_PREF = OFF_TRACE + TR * ROW_STRIDE * 8;          // PREF_DEPTH record blocks (LDS-DMA targets)
+    constexpr int OFF_BBOX = OFF_PREF + PREF_DEPTH * PREF_BYTES;       // int4[NT]: bboxes of the compacted paths
+    constexpr int OFF_LIST = OFF_BBOX + NT * 16;                       // int[NT]: their ids
+    constexpr int OFF_SEG0 = OFF_LIST + NT * 4;                        // int[NT]: first record of the (path, band) pair
+    constexpr int OFF_SEG1 = OFF_SEG0 + NT * 4;                        // int[NT]: one past the last
+    constexpr int OFF_WCNT = OFF_SEG1 + NT * 4;                        // int[NW]
+    constexpr int LDS_BYTES = OFF_WCNT + 16 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[LDS_BYTES];
+    double* const s_trace = (double*)(s_mem + OFF_TRACE);
+    int4* const s_bbox = (int4*)(s_mem + OFF_BBOX);
+    int* const s_list = (int*)(s_mem + OFF_LIST);
+    int* const s_seg0 = (int*)(s_mem + OFF_SEG0);
+    int* const s_seg1 = (int*)(s_mem + OFF_SEG1);
+    int* const s_wcnt = (int*)(s_mem + OFF_WCNT);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int trow = tid / CH, chunk = tid % CH;
@@ -633,9 +672,10 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
             bb = ((const int4*)a.bbox)[p_mine];  // {r0, c0, rows, cols}
             if (bb.y < tile_c1 && bb.y + bb.w > tile_c0) {
                 const int pb = a.pb_off[p_mine] + band - a.b0[p_mine];
+                const int cnt = a.pb_cnt[pb];
                 seg0 = a.bseg_off[pb];
-                seg1 = seg0 + a.pb_cnt[pb];
-                hit = seg1 > seg0;  // no edge crosses this band: coverage is zero everywhere in it
+                seg1 = seg0 + cnt + 1;  // header slot + records
+                hit = cnt > 0;          // no edge crosses this band: coverage is zero everywhere in it
             }
         }
         unsigned long long m = __ballot(hit);
@@ -656,80 +696,147 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
         }
         __syncthreads();
 
-        // LDS-DMA of one path's band segments (up to PREF_SEGS) into s_pref[buf]: 16 B per lane,
-        // each wave fills its own 1 KiB slice; completion = the issuing wave's vmcnt + a barrier
-        auto prefetch = [&](int li_, int buf_) {
-            const int n_bytes = (s_seg1[li_] - s_seg0[li_] < PREF_RECS ? s_seg1[li_] - s_seg0[li_] : PREF_RECS) * 48;
-            if (tid < 256 && tid * 16 < n_bytes) {
-                const char* g = (const char*)(a.bsegs + s_seg0[li_]) + tid * 16;
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)((char*)&s_pref[buf_][0] + wave * 1024), 16, 0, 0);
+        // ------------------------------------------------------------------------------------------
+        // Work items = (path, window of PREF_RECS slots of its record block); slot 0 of a block is
+        // the header (paint, rule), slot k >= 1 record k-1.  Items are streamed through a ring of
+        // PREF_DEPTH LDS blocks by LDS-DMA, two items ahead of the one being scattered.
+        //
+        // The DMA is issued from inline asm on purpose: for a __builtin LDS-DMA hipcc (ROCm 7.2) makes
+        // EVERY later ds_read wait vmcnt(0) ("may alias the DMA"), which would drain the blocks that
+        // are meant to stay in flight.  Ordering is by hand: every wave < PREF_WAVES issues exactly ONE
+        // DMA instruction per item (lanes past the end re-read the last 16 valid bytes), so with item
+        // k+1 issued, "item k has landed" is vmcnt(1) [vmcnt(0) for the last item], followed by a raw
+        // barrier (lgkmcnt only: a __syncthreads() would wait vmcnt(0)).
+        // ------------------------------------------------------------------------------------------
+        auto issue = [&](int li_, int win_, int buf_) {
+            if (wave < PREF_WAVES) {
+                const int left_ = s_seg1[li_] - s_seg0[li_] - win_;
+                const int n_bytes = (left_ < PREF_RECS ? left_ : PREF_RECS) * 48;
+                const int off_ = tid * 16 < n_bytes ? tid * 16 : n_bytes - 16;
+                const char* g = (const char*)(a.bsegs + s_seg0[li_] + win_) + off_;
+                const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(size_t)(lds_ptr_t)(s_mem + OFF_PREF + buf_ * PREF_BYTES + wave * 1024));
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                             :
+                             : "v"(g), "s"(lds_base)
+                             : "memory", "m0");
             }
         };
-        if (total > 0) prefetch(0, 0);
+        // the prefetch cursor runs two items ahead of the work cursor
+        int pf_li = 0, pf_win = 0, pf_k = 0;
+        auto issue_next = [&]() {
+            if (pf_li < total) {
+                issue(pf_li, pf_win, pf_k % PREF_DEPTH);
+                ++pf_k;
+                ++pf_li;  // one item per path: slots past the block are read straight from HBM by the scatter
+            }
+        };
+        issue_next();
+        issue_next();
 
-        for (int li = 0; li < total; ++li) {
-            const int cur = li & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();  // segments of path li have landed; scan of path li-1 is finished
-            const int p = s_list[li];
-            const int s0 = s_seg0[li], s1 = s_seg1[li];
-            const int4 pbb = s_bbox[li];
-            const int r0 = pbb.x, c0 = pbb.y, rows = pbb.z, cols = pbb.w;
-            const int row_shift = r0 - tile_r0;  // layer row y  -> tile row  y + row_shift
-            const int col_shift = c0 - tile_c0;  // layer col x  -> tile col  x + col_shift
-            const int lo_c = col_shift < 0 ? -col_shift : 0;                 // first layer column inside the tile
-            const int hi_c = cols < tile_c1 - c0 ? cols : tile_c1 - c0;      // one past the last
-            // paint / rule are only needed after the barrier: issue the loads now
-            const int rule = a.rule[p];
-            const double p0 = a.paint[4 * (size_t)p], p1 = a.paint[4 * (size_t)p + 1];
-            const double p2 = a.paint[4 * (size_t)p + 2], p3 = a.paint[4 * (size_t)p + 3];
+        // per-path state, set when the first window of the path is reached
+        int row_shift = 0, rows = 0, col_shift = 0, lo_c = 0, hi_c = 0, rule = 0, n_slots = 0;
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        int li = 0;
+        constexpr int win = 0;
+        for (int k = 0; li < total; ++k) {
+            const int cur = k % PREF_DEPTH;
+#ifdef SVGR_DBG_STAMP
+            unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
+            if (pf_k > k + 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SVGR_DBG_STAMP
+            unsigned long long t1_ = __builtin_amdgcn_s_memtime();
+#endif
+            // After this barrier: item k has landed for every wave; everybody is done with item k-1
+            // (its block is free again) and, when this is a first window, with the previous path's scan.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef SVGR_DBG_STAMP
+            unsigned long long t2_ = __builtin_amdgcn_s_memtime();
+#endif
+            issue_next();  // item k+2 into the block that item k-1 used
+            const double* const blk = (const double*)(s_mem + OFF_PREF + cur * PREF_BYTES);
+            if (win == 0) {
+                const int4 pbb = s_bbox[li];
+                const int c0 = pbb.y, cols = pbb.w;
+                n_slots = s_seg1[li] - s_seg0[li];
+                row_shift = pbb.x - tile_r0;  // layer row y  -> tile row  y + row_shift
+                rows = pbb.z;
+                col_shift = c0 - tile_c0;     // layer col x  -> tile col  x + col_shift
+                lo_c = col_shift < 0 ? -col_shift : 0;             // first layer column inside the tile
+                hi_c = cols < tile_c1 - c0 ? cols : tile_c1 - c0;  // one past the last
+                p0 = blk[0]; p1 = blk[1]; p2 = blk[2]; p3 = blk[3];  // header slot: paint, rule
+                rule = *(const int*)(blk + 4);
+            }
 
             // ---- scatter: one lane per edge-row record; the pieces were computed by k_edge_emit, here
             //      they are only clamped to the layer / tile and added to the LDS delta tile ----
+            {
+                const int slot_lo = 1;
+                int slot_hi = n_slots;
 #ifdef SVGR_DBG_NOSCATTER
-            const int n_items = 0 * (s1 - s0);
-#else
-            const int n_items = s1 - s0;
+                slot_hi = slot_lo;
 #endif
-            for (int w = tid; w < n_items; w += NT) {
-                int x0i;
-                unsigned nrow;
-                double v[5];
-                if (w < PREF_RECS) {
-                    const double* q = &s_pref[cur][w * 6];
-                    const int2 hd = *(const int2*)q;
-                    x0i = hd.x; nrow = (unsigned)hd.y;
-                    v[0] = q[1]; v[1] = q[2]; v[2] = q[3]; v[3] = q[4]; v[4] = q[5];
-                } else {
-                    const RowRec g = a.bsegs[s0 + w];
-                    x0i = g.x0i; nrow = g.nrow;
-                    v[0] = g.v[0]; v[1] = g.v[1]; v[2] = g.v[2]; v[3] = g.v[3]; v[4] = g.v[4];
+                for (int sl = slot_lo + tid; sl < slot_hi; sl += NT) {
+                    int x0i;
+                    unsigned nrow;
+                    double v[5];
+                    if (sl < PREF_RECS) {
+                        const double* q = blk + sl * 6;
+                        const int2 hd = *(const int2*)q;
+                        x0i = hd.x; nrow = (unsigned)hd.y;
+                        v[0] = q[1]; v[1] = q[2]; v[2] = q[3]; v[3] = q[4]; v[4] = q[5];
+                    } else {
+                        // pair longer than the prefetch block: the tail comes straight from HBM.  Inline asm, so
+                        // that hipcc does not put a vmcnt(0) wait on the common path (it would for a plain load).
+                        const RowRec* gp = a.bsegs + s_seg0[li] + sl;
+                        double hd_;
+                        asm volatile("global_load_dwordx2 %0, %6, off\n\t"
+                                     "global_load_dwordx2 %1, %6, off offset:8\n\t"
+                                     "global_load_dwordx2 %2, %6, off offset:16\n\t"
+                                     "global_load_dwordx2 %3, %6, off offset:24\n\t"
+                                     "global_load_dwordx2 %4, %6, off offset:32\n\t"
+                                     "global_load_dwordx2 %5, %6, off offset:40\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : "=&v"(hd_), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
+                                     : "v"(gp)
+                                     : "memory");
+                        x0i = __double2loint(hd_);
+                        nrow = (unsigned)__double2hiint(hd_);
+                    }
+                    const int n = (int)(nrow & SPAN_MAX);
+                    double* trow_ptr = s_trace + (int)(nrow >> 26) * ROW_STRIDE;
+                    if (x0i >= hi_c) continue;  // everything at or beyond the tile's / layer's right edge
+                    if (x0i + n < lo_c) {
+                        // whole row span left of the tile: fold the sum of its pieces (= d) into the first column
+                        double sum = v[0] + v[1];
+                        if (n >= 3) sum = sum + (double)(n - 3) * v[2] + v[3];
+                        if (n >= 2) sum = sum + v[4];
+                        const int tc = lo_c + col_shift;
+                        __hip_atomic_fetch_add(trow_ptr + (tc / PX) * CHUNK_STRIDE + (tc % PX), sum, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                        continue;
+                    }
+                    apply_record(x0i, n, v, [&](int xi, double val) -> bool {
+                        int c = xi > 0 ? xi : 0;   // left of the layer folds into column 0 (S:2262)
+                        if (c >= hi_c) return false;
+                        c = c > lo_c ? c : lo_c;   // left of the tile folds into its first column (row carry-in)
+                        const int tc = c + col_shift;
+                        __hip_atomic_fetch_add(trow_ptr + (tc / PX) * CHUNK_STRIDE + (tc % PX), val, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                        return true;
+                    });
                 }
-                const int n = (int)(nrow & SPAN_MAX);
-                double* trow_ptr = s_trace + (int)(nrow >> 26) * ROW_STRIDE;
-                if (x0i >= hi_c) continue;  // everything at or beyond the tile's / layer's right edge
-                if (x0i + n < lo_c) {
-                    // whole row span left of the tile: fold the sum of its pieces (= d) into the first column
-                    double sum = v[0] + v[1];
-                    if (n >= 3) sum = sum + (double)(n - 3) * v[2] + v[3];
-                    if (n >= 2) sum = sum + v[4];
-                    const int tc = lo_c + col_shift;
-                    __hip_atomic_fetch_add(trow_ptr + (tc / PX) * CHUNK_STRIDE + (tc % PX), sum, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                    continue;
-                }
-                apply_record(x0i, n, v, [&](int xi, double val) -> bool {
-                    int c = xi > 0 ? xi : 0;   // left of the layer folds into column 0 (S:2262)
-                    if (c >= hi_c) return false;
-                    c = c > lo_c ? c : lo_c;   // left of the tile folds into its first column (row carry-in)
-                    const int tc = c + col_shift;
-                    __hip_atomic_fetch_add(trow_ptr + (tc / PX) * CHUNK_STRIDE + (tc % PX), val, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                    return true;
-                });
             }
-            __syncthreads();
-            if (li + 1 < total) prefetch(li + 1, cur ^ 1);  // lands while this path is scanned and composited
+#ifdef SVGR_DBG_STAMP
+            unsigned long long t3_ = __builtin_amdgcn_s_memtime();
+#endif
+            ++li;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // delta tile complete
+#ifdef SVGR_DBG_STAMP
+            unsigned long long t4_ = __builtin_amdgcn_s_memtime();
+#endif
 
             // ---- row prefix sum + fill rule + paint + source-over ----
             // A wave owns 4 tile rows; skip the phase when the layer has no row among them (its
@@ -788,7 +895,21 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
                     }
                 }
             }
+#ifdef SVGR_DBG_STAMP
+            {
+                unsigned long long t5_ = __builtin_amdgcn_s_memtime();
+                if (tid == 0 && a.dbg) {
+                    atomicAdd(&a.dbg[0], t1_ - t0_);  // wait for the DMA
+                    atomicAdd(&a.dbg[1], t2_ - t1_);  // barrier A
+                    atomicAdd(&a.dbg[2], t3_ - t2_);  // metadata + scatter
+                    atomicAdd(&a.dbg[3], t4_ - t3_);  // barrier B
+                    atomicAdd(&a.dbg[4], t5_ - t4_);  // scan + composite
+                    atomicAdd(&a.dbg[5], 1ull);
+                }
+            }
+#endif
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -806,6 +927,9 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
                         v2 = v2 < 0 ? 0 : (v2 > 1 ? 1 : v2); v3 = v3 < 0 ? 0 : (v3 > 1 ? 1 : v3);
                     }
                     size_t o = (size_t)out_row * a.out_cols + col0 + i;
+#ifdef SVGR_DBG_NOSTORE
+                    if (v0 + v1 + v2 + v3 != 12345.678) continue;
+#endif
                     if (OUT == 0) {
                         ((float4*)a.out)[o] = make_float4((float)v0, (float)v1, (float)v2, (float)v3);
                     } else {
@@ -927,7 +1051,7 @@ struct svgr_batch {
     size_t arena_bytes = 0, off_pkeys = 0, off_pb_cnt = 0, off_pb_cursor = 0;
     int pb_cap = 0;
     // work arrays fully rewritten by every render
-    DevArr<int> edge_path, bbox, b0, nb, pb_off, bseg_off, band_start, band_count, entries;
+    DevArr<int> edge_path, bbox, b0, nb, pb_off, pb_path, bseg_off, band_start, band_count, entries;
     DevArr<double> edges;
     DevArr<RowRec> bsegs;
     // plan results
@@ -956,7 +1080,7 @@ struct svgr_batch {
     void release() {
         segs.release(); path_m6.release(); path_paint.release(); seg_kind.release(); path_rule.release();
         seg_path.release(); arena.release(); edge_path.release(); bbox.release(); b0.release(); nb.release();
-        pb_off.release(); bseg_off.release(); band_start.release(); band_count.release(); entries.release();
+        pb_off.release(); pb_path.release(); bseg_off.release(); band_start.release(); band_count.release(); entries.release();
         edges.release(); bsegs.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
@@ -987,14 +1111,16 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                            (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
                            b->edges.p, b->edge_path.p, cap_i32(b->edges.cap / 4), b->pkeys(), b->bd());
     hipLaunchKernelGGL(k_path_bbox, grid1(np), dim3(256), 0, st, (const unsigned long long*)b->pkeys(), np, use_vp ? 1 : 0,
-                       b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->b0.p, b->nb.p, b->pb_off.p, b->bd());
+                       b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->b0.p, b->nb.p, b->pb_off.p,
+                       b->pb_cap > 0 ? b->pb_path.p : (int*)nullptr, b->pb_cap, b->bd());
     if (upto == 2) return 0;
     const size_t ne = (size_t)std::max<int64_t>(b->n_edges, 1);
     hipLaunchKernelGGL(k_edge_count, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
                        (const int*)b->bbox.p, (const int*)b->pb_off.p, (const int*)b->b0.p, b->vp[0], b->pb_cap, b->pb_cnt(),
                        b->bd());
     hipLaunchKernelGGL(k_alloc, grid1((size_t)std::max(b->pb_cap, 1), 1024), dim3(1024), 0, st, (const int*)b->pb_cnt(), b->pb_cap,
-                       b->bseg_off.p, b->bd());
+                       b->bseg_off.p, (const int*)b->pb_path.p, (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p,
+                       upto >= 4 ? b->bsegs.p : (RowRec*)nullptr, cap_i32(b->bsegs.cap), b->bd());
     if (upto == 3) return 0;
     hipLaunchKernelGGL(k_edge_emit, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
                        (const int*)b->bbox.p, (const int*)b->pb_off.p, (const int*)b->b0.p, b->vp[0], b->pb_cap,
@@ -1298,11 +1424,12 @@ int svgr_batch_plan(svgr_batch* b) {
     // 3. per-pair counts -> band segments
     if (int rc = b->layout_arena((int)b->n_pb)) return rc;
     if (int rc = b->bseg_off.ensure((size_t)b->n_pb + 1)) return rc;
+    if (int rc = b->pb_path.ensure((size_t)b->n_pb + 1)) return rc;
     if (int rc = b->entries.ensure((size_t)std::max<int64_t>(b->n_pb, 1))) return rc;
     if (int rc = run_geometry(b, 3, true)) return rc;
     if (int rc = check_dev_err(b)) return rc;
     b->n_bsegs = b->host_bd.bseg_cursor;
-    if (int rc = b->bsegs.ensure((size_t)std::max<int64_t>(b->n_bsegs, 1) + PREF_RECS + 1)) return rc;
+    if (int rc = b->bsegs.ensure((size_t)std::max<int64_t>(b->n_bsegs, 1) + PREF_RECS_MAX + 1)) return rc;
     // 4. full geometry once, to validate the capacities and fetch the bboxes
     if (int rc = run_geometry(b, 4, true)) return rc;
     if (int rc = check_dev_err(b)) return rc;
@@ -1417,6 +1544,19 @@ int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags
         a.out_cols = b->vp[3];
         a.clip01 = (flags & SVGR_RENDER_CLIP01) ? 1 : 0;
         a.single_r0 = single_bb[0]; a.single_c0 = single_bb[1]; a.single_cols = single_bb[3];
+        a.dbg = nullptr;
+#ifdef SVGR_DBG_STAMP
+        {
+            static unsigned long long* dbg_buf = nullptr;
+            if (!dbg_buf) { (void)hipMalloc((void**)&dbg_buf, 64); (void)hipMemset(dbg_buf, 0, 64); }
+            a.dbg = dbg_buf;
+            unsigned long long h[8];
+            (void)hipMemcpy(h, dbg_buf, 64, hipMemcpyDeviceToHost);
+            if (h[5]) fprintf(stderr, "[stamp] per iteration (wave 0 cycles): dma_wait %.0f barA %.0f scatter %.0f barB %.0f scan %.0f  (n=%llu)\n",
+                              (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5], h[5]);
+            (void)hipMemset(dbg_buf, 0, 64);
+        }
+#endif
         dim3 grid((unsigned)n_ctiles, (unsigned)owned_bands);
         switch (out_kind) {
             case 0: hipLaunchKernelGGL(k_tile_render<0>, grid, dim3(NT), 0, st, a); break;
