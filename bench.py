@@ -125,8 +125,16 @@ def main():
         import torch
         import torch.distributed as dist
 
+        # rehearsal on a one-GPU box: SVGR_BENCH_BACKEND=gloo SVGR_BENCH_DEVICE=0 puts every rank on GPU 0 and
+        # runs the collectives on CPU tensors (RCCL refuses two ranks on one device)
+        backend = os.environ.get("SVGR_BENCH_BACKEND", "nccl")
+        if "SVGR_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["SVGR_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -149,7 +157,6 @@ def main():
 
         out_t = torch.empty((own_rows, cols, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
         out = ctx.wrap(out_t.data_ptr(), out_t.numel() * 4)
-        gather_t = torch.empty((world,) + tuple(out_t.shape), dtype=torch.float32, device=f"cuda:{local_rank}")
     else:
         out = ctx.alloc(own_rows * cols * 16)
 
@@ -179,19 +186,21 @@ def main():
     if dist is not None:
         import torch
 
-        tt = torch.tensor([t_local], dtype=torch.float64, device=f"cuda:{local_rank}")
+        coll_dev = f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu"
+        tt = torch.tensor([t_local], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_max = float(tt.item())
-        # optional assembly of the full canvas on every rank (equal shards when bands divide evenly)
-        n_bands = (rows + _abi.tile_rows() - 1) // _abi.tile_rows()
-        if n_bands % world == 0:
-            dist.barrier()
-            torch.cuda.synchronize()
-            g0 = time.perf_counter()
-            for _ in range(3):
-                dist.all_gather_into_tensor(gather_t, out_t)
-            torch.cuda.synchronize()
-            gather_ms = (time.perf_counter() - g0) / 3 * 1e3
+        # optional assembly of the full canvas on every rank (svgrasterize.py_amd/dist.py), reported separately
+        from svgrasterize_amd import dist as sdist
+
+        dist.barrier()
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        for _ in range(3):
+            full_t = sdist.gather_canvas(out_t if coll_dev != "cpu" else out_t.cpu(), rows, _abi.tile_rows())
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) / 3 * 1e3
+        del full_t
 
     if rank == 0:
         ms_step = t_max / args.steps * 1e3

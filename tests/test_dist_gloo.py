@@ -1,0 +1,81 @@
+"""N > 1 path on CPU: two gloo ranks shard a canvas by interleaved row bands exactly as bench.py does
+on GPUs (svgrasterize.py_amd/dist.py), each rank rendering ONLY its bands through the reference's own
+viewport mechanism (here with the CPU oracle standing in for the device), then all_gather + assemble.
+The result must equal the single-process render (to double rounding: the reference's viewport restart,
+SURVEY 8e), and exactly after float32 rounding."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from tests.util import assert_f32_1ulp
+
+TILE_ROWS = 16
+SIZE, N_PATHS = 200, 40
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle as orc
+    from svgrasterize_amd import dist as sdist, synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = synth.make_scene(SIZE, N_PATHS)
+    pres = synth.presentation_segs(sc)
+    parts = []
+    for r0, r1 in sdist.owned_row_ranges(SIZE, TILE_ROWS, rank, world):
+        band, _, _ = orc.render_solid(pres, sc["seg_kind"], sc["path_seg_off"], sc["path_rule"], sc["path_paint"],
+                                      (r0, 0, r1 - r0, SIZE), clip01=True)
+        pad = np.zeros((TILE_ROWS - (r1 - r0), SIZE, 4))
+        parts.append(np.concatenate([band, pad]))
+    local = torch.from_numpy(np.concatenate(parts))
+    full = sdist.gather_canvas(local, SIZE, TILE_ROWS)
+    # max-over-ranks reduction of a per-rank clock, as bench.py does
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert t.item() == world
+    if rank == 0:
+        np.save(os.path.join(out_dir, "full.npy"), full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_band_partition_helpers():
+    from svgrasterize_amd import dist as sdist
+
+    for rows, world in [(200, 2), (4096, 8), (17, 3), (16, 4), (1, 2)]:
+        seen = []
+        for r in range(world):
+            seen += sdist.owned_row_ranges(rows, TILE_ROWS, r, world)
+        seen.sort()
+        assert seen[0][0] == 0 and seen[-1][1] == rows
+        assert all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+        assert max(len(sdist.owned_bands(rows, TILE_ROWS, r, world)) for r in range(world)) == sdist.max_owned_bands(rows, TILE_ROWS, world)
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_render_matches_single(tmp_path):
+    import torch.multiprocessing as mp
+
+    from oracle import oracle as orc
+    from svgrasterize_amd import synth
+
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "full.npy")
+    sc = synth.make_scene(SIZE, N_PATHS)
+    ref, _, _ = orc.render_solid(synth.presentation_segs(sc), sc["seg_kind"], sc["path_seg_off"], sc["path_rule"],
+                                 sc["path_paint"], sc["viewport"], clip01=True)
+    assert np.abs(got - ref).max() < 1e-11
+    assert_f32_1ulp(got.astype(np.float32), ref, what="2-rank gloo canvas")
