@@ -596,8 +596,8 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 template <int N>
 __device__ __forceinline__ double dpp_row_shr(double v) {  // lane i <- lane i-N inside a 16-lane row, else +0.0
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + N, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + N, 0xf, 0xf, true);  // bound_ctrl: lanes without a source read 0
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -833,6 +833,14 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
             unsigned long long t3_ = __builtin_amdgcn_s_memtime();
 #endif
             ++li;
+            if (OUT <= 1 && hi_c + col_shift < TC && tid < TR && tid >= row_shift && tid < row_shift + rows) {
+                // The layer's right edge is inside this tile.  Right of it the running sum is whatever winding
+                // an unclosed outline leaves behind (stroker joins leave ~1e-5 gaps) and the reference never
+                // touches pixels outside the layer's bbox: poison the first column past the edge with a NaN, so
+                // that every prefix sum to its right fails the `>= 1e-6` test.  (Nothing else writes that cell:
+                // the scatter drops columns >= hi_c.  Only rows of the layer: their waves scan and re-zero it.)
+                s_trace[lds_index(tid, hi_c + col_shift)] = __builtin_nan("");
+            }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // delta tile complete
 #ifdef SVGR_DBG_STAMP
             unsigned long long t4_ = __builtin_amdgcn_s_memtime();
@@ -864,16 +872,16 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
                 double run = dpp_row_shr<1>(inc);  // exclusive: everything left of this chunk
 
                 if (OUT <= 1) {
-                    // Canvas: only the layer's right edge needs a test.  Left of / above / below the
-                    // layer the delta tile is zero and so is the running sum, but to the right of it the
-                    // sum is whatever winding an unclosed outline leaves behind (stroker joins leave
-                    // ~1e-5 gaps), and the reference never touches pixels outside the layer's bbox.
-                    const int i_hi = hi_c - (chunk * PX - col_shift);  // pixels [0, i_hi) of this chunk are inside
+                    // Canvas: no bounds tests.  Left of / above / below the layer the delta tile is zero and so
+                    // is the running sum; right of the layer it is NaN (sentinel above) or outside the viewport.
 #pragma unroll
                     for (int i = 0; i < PX; ++i) {
                         run += t[i];
                         const double mval = rule ? fill_evenodd_raw(run) : fill_nonzero_raw(run);
-                        if (i < i_hi && mval >= kZeroCut) over_px(acc[i], mval * p0, mval * p1, mval * p2, mval * p3);
+                        if (mval >= kZeroCut) {
+                            if (OUT == 0) over_px_fma(acc[i], mval * p0, mval * p1, mval * p2, mval * p3);
+                            else over_px(acc[i], mval * p0, mval * p1, mval * p2, mval * p3);
+                        }
                     }
                 } else {
                     const int y_layer = trow - row_shift;
