@@ -43,7 +43,7 @@ using namespace svgr;
 // tile geometry
 // ======================================================================================
 #ifndef SVGR_TR
-#define SVGR_TR 16
+#define SVGR_TR 8
 #endif
 constexpr int TR = SVGR_TR;                // rows per band / tile
 #ifndef SVGR_PX
