@@ -150,7 +150,10 @@ def main():
                        viewport=sc["viewport"])
     st = batch.plan()
     P, E = int(st.path_pixels), int(st.n_edges)
-    batch.set_bands(rank, world)
+    strip = int(os.environ.get("SVGR_STRIP_BANDS", "16"))  # 16 bands = 128 scanlines per strip
+    if world > 1:
+        batch.set_bands(rank, world, strip)
+        batch.plan()  # per-rank capacities: each rank keeps only the edges that reach its strips
     own_rows = batch.owned_rows()
     if world > 1:
         import torch
@@ -197,7 +200,7 @@ def main():
         torch.cuda.synchronize()
         g0 = time.perf_counter()
         for _ in range(3):
-            full_t = sdist.gather_canvas(out_t if coll_dev != "cpu" else out_t.cpu(), rows, _abi.tile_rows())
+            full_t = sdist.gather_canvas(out_t if coll_dev != "cpu" else out_t.cpu(), rows, _abi.tile_rows(), strip=strip)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) / 3 * 1e3
         del full_t
@@ -233,7 +236,7 @@ def main():
             "data": "synthetic" if args.workload.startswith("synth") else "real asset (scene dump)",
             "config": {
                 "workload": desc, "canvas": [rows, cols], "paths": int(len(sc["path_seg_off"]) - 1), "edges": E,
-                "path_pixels": P, "sharding": f"{world} x interleaved 16-row bands" if world > 1 else "single GPU",
+                "path_pixels": P, "sharding": f"{world} ranks x interleaved strips of {strip} bands ({strip * _abi.tile_rows()} rows)" if world > 1 else "single GPU",
             },
             "canvas_mpixels_per_s": round(rows * cols / (t_max / args.steps) / 1e6, 1),
             "roofline": {

@@ -121,9 +121,11 @@ int svgr_batch_destroy(svgr_batch* batch);
 int svgr_batch_set_paints(svgr_batch* batch, const double* path_paint);
 int svgr_batch_set_transforms(svgr_batch* batch, const double* path_m6);
 
-/* Restrict rendering to row bands {band_first + k * band_step} of the viewport (band = svgr_tile_rows() rows):
- * one rank of an N-GPU job owns bands rank, rank+N, ...  Default (0, 1) = all bands.             */
-int svgr_batch_set_bands(svgr_batch* batch, int band_first, int band_step);
+/* Multi-GPU sharding: rank `rank` of `world` keeps the strips s with s % world == rank, a strip being
+ * `strip_bands` consecutive bands (band = svgr_tile_rows() scanlines).  The rank still computes every path's
+ * exact bbox, but only flattens-to-memory, bins and renders what reaches its own bands; its output buffer holds
+ * the owned bands packed in increasing order.  Default (0, 1, 1) = everything.  Invalidates the plan.       */
+int svgr_batch_set_bands(svgr_batch* batch, int rank, int world, int strip_bands);
 
 /* Geometry pass with host read-backs: flatten, per-path bbox, band binning; sizes every work
  * buffer.  Must run once before svgr_batch_render and again after geometry/viewport changes.

@@ -69,7 +69,7 @@ _PROTOS = {
     "svgr_batch_destroy": (C.c_int, [_P]),
     "svgr_batch_set_paints": (C.c_int, [_P, _P]),
     "svgr_batch_set_transforms": (C.c_int, [_P, _P]),
-    "svgr_batch_set_bands": (C.c_int, [_P, C.c_int, C.c_int]),
+    "svgr_batch_set_bands": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "svgr_batch_plan": (C.c_int, [_P]),
     "svgr_batch_get_stats": (C.c_int, [_P, C.POINTER(BatchStats)]),
     "svgr_batch_get_bboxes": (C.c_int, [_P, _P]),
@@ -267,8 +267,10 @@ class Batch:
         _check(self.ctx.lib.svgr_batch_get_edges(self.handle, edges.ctypes.data_as(_P), edge_path.ctypes.data_as(_P), n))
         return edges, edge_path
 
-    def set_bands(self, first: int, step: int):
-        _check(self.ctx.lib.svgr_batch_set_bands(self.handle, first, step))
+    def set_bands(self, rank: int, world: int, strip_bands: int = 1):
+        """Shard by interleaved strips of `strip_bands` bands; call plan() again afterwards."""
+        _check(self.ctx.lib.svgr_batch_set_bands(self.handle, rank, world, strip_bands))
+        self._stats = None
 
     def set_paints(self, paints):
         paints = np.ascontiguousarray(paints, dtype=np.float64).reshape(self.n_paths, 4)

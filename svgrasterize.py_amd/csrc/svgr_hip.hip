@@ -196,6 +196,36 @@ __device__ __forceinline__ void wave_runs(int key, bool active, int lane, int& h
 }
 
 // ======================================================================================
+// band ownership (multi-GPU): rank r of `world` owns the strips s with s % world == r, a strip being
+// `strip` consecutive bands.  world == 1 owns everything.
+// ======================================================================================
+struct Owner {
+    int rank, world, strip;
+};
+__host__ __device__ __forceinline__ bool owns_band(const Owner o, int band) {
+    return o.world <= 1 || (band / o.strip) % o.world == o.rank;
+}
+// k-th owned band (k = 0, 1, ...) in increasing order
+__host__ __device__ __forceinline__ int owned_band_at(const Owner o, int k) {
+    if (o.world <= 1) return k;
+    return ((k / o.strip) * o.world + o.rank) * o.strip + (k % o.strip);
+}
+// does [ba, bb] contain an owned band?
+__host__ __device__ __forceinline__ bool owns_any(const Owner o, int ba, int bb) {
+    if (o.world <= 1) return true;
+    const int sa = ba / o.strip, sb = bb / o.strip;
+    if (sb - sa + 1 >= o.world) return true;
+    for (int s = sa; s <= sb; ++s)
+        if (s % o.world == o.rank) return true;
+    return false;
+}
+static int count_owned_bands(const Owner o, int n_bands) {
+    int n = 0;
+    for (int b = 0; b < n_bands; ++b) n += owns_band(o, b) ? 1 : 0;
+    return n;
+}
+
+// ======================================================================================
 // geometry kernels
 // ======================================================================================
 // Device-side scalars of a batch; lives at the start of the zeroed arena, so every field's
@@ -233,7 +263,8 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
                                                  const int* __restrict__ seg_path, const double* __restrict__ path_m6,
                                                  int n_segs, double thr, double* __restrict__ edges,
                                                  int* __restrict__ edge_path, int edge_cap,
-                                                 unsigned long long* __restrict__ pkeys, BatchDev* __restrict__ bd) {
+                                                 unsigned long long* __restrict__ pkeys, BatchDev* __restrict__ bd,
+                                                 Owner own, int vr0, int n_bands) {
     __shared__ int s_tot[17];
     const int gtid = blockIdx.x * FL_BLOCK + threadIdx.x;
     const int seg = gtid >> FL_SUB, sub = gtid & ((1 << FL_SUB) - 1);
@@ -265,28 +296,49 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
             }
         }
     }
-    int cnt = 0;
-    bool ovf = false;
-    if (mode == 1) cnt = 1;
-    else if (mode == 2) cnt = flatten_subtree(node, thr, kMaxFlattenDepth - FL_SUB, [](double, double, double, double) {}, ovf);
-    if (ovf) atomicOr(&bd->err, 1);
-    const int base = block_alloc(&bd->edge_cursor, cnt, s_tot);
-    if (!EMIT) return;
-
+    // Multi-GPU: every rank needs every path's exact bbox (so the first traversal always runs and
+    // tracks min/max), but it only keeps the edges of segments that can reach one of its own bands
+    // (the curve stays inside the row range of its control points; +-1 row of slack).
+    bool keep = true;
+    if (n_bands > 0 && mode != 0) {  // (also drops what lies entirely above / below the viewport)
+        double rlo = node[0] < node[6] ? node[0] : node[6], rhi = node[0] < node[6] ? node[6] : node[0];
+        if (mode == 2) {
+            rlo = fmin(rlo, fmin(node[2], node[4]));
+            rhi = fmax(rhi, fmax(node[2], node[4]));
+        }
+        int ba = (clamp_to_int(floor(rlo)) - 1 - vr0) / TR, bb = (clamp_to_int(ceil(rhi)) + 1 - vr0) / TR;
+        ba = ba < 0 ? 0 : ba;
+        bb = bb > n_bands - 1 ? n_bands - 1 : bb;
+        keep = ba <= bb && owns_any(own, ba, bb);
+    }
     double mnr = INFINITY, mnc = INFINITY, mxr = -INFINITY, mxc = -INFINITY;
     auto track = [&](double r, double c) {
         mnr = r < mnr ? r : mnr; mxr = r > mxr ? r : mxr;
         mnc = c < mnc ? c : mnc; mxc = c > mxc ? c : mxc;
     };
-    if (cnt > 0) {
+    int cnt = 0;
+    bool ovf = false;
+    if (mode == 1) {
+        cnt = 1;
+        track(node[0], node[1]);
+        track(node[6], node[7]);
+    } else if (mode == 2) {
+        cnt = flatten_subtree(node, thr, kMaxFlattenDepth - FL_SUB, [&](double r0, double c0, double r1, double c1) {
+            track(r0, c0);
+            track(r1, c1);
+        }, ovf);
+    }
+    if (ovf) atomicOr(&bd->err, 1);
+    if (!keep) cnt = 0;
+    const int base = block_alloc(&bd->edge_cursor, cnt, s_tot);
+
+    if (EMIT && cnt > 0) {
         if (base + cnt > edge_cap) {
             atomicOr(&bd->err, 2);
         } else if (mode == 1) {
             double* e = edges + 4 * (size_t)base;
             e[0] = node[0]; e[1] = node[1]; e[2] = node[6]; e[3] = node[7];
             edge_path[base] = p;
-            track(node[0], node[1]);
-            track(node[6], node[7]);
         } else {
             int i = 0;
             bool o2 = false;
@@ -297,8 +349,6 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
                     edge_path[base + i] = p;
                 }
                 ++i;
-                track(r0, c0);
-                track(r1, c1);
             }, o2);
         }
     }
@@ -422,7 +472,7 @@ __device__ __forceinline__ void band_rows(const EdgeSetup& es, int band, int vr0
 __global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ edges, const int* __restrict__ edge_path,
                                                     const int* __restrict__ bbox, const int* __restrict__ pb_off,
                                                     const int* __restrict__ b0, int vr0, int pb_cap,
-                                                    int* __restrict__ pb_cnt, BatchDev* __restrict__ bd) {
+                                                    int* __restrict__ pb_cnt, BatchDev* __restrict__ bd, Owner own) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     EdgeSetup es;
     int p = 0, r0 = 0, key = -1, bf = 0, bl = -1, rows_first = 0;
@@ -433,7 +483,7 @@ __global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ e
         key = pb_off[p] - b0[p] + bf;
         if (key < 0 || key + (bl - bf) >= pb_cap) { atomicOr(&bd->err, 4); ok = false; }
     }
-    if (ok) {
+    if (ok && owns_band(own, bf)) {
         int ya, yb;
         band_rows(es, bf, vr0, r0, ya, yb);
         rows_first = yb - ya;
@@ -445,8 +495,9 @@ __global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ e
     const int run_begin_excl = __shfl(excl, head);
     if (ok) {
         // first band: one atomic per run of lanes that share a (path, band) pair
-        if (head == lane) atomicAdd(&pb_cnt[key], run_end_incl - run_begin_excl);
+        if (head == lane && run_end_incl > run_begin_excl) atomicAdd(&pb_cnt[key], run_end_incl - run_begin_excl);
         for (int b = 1; b <= bl - bf; ++b) {
+            if (!owns_band(own, bf + b)) continue;
             int ya, yb;
             band_rows(es, bf + b, vr0, r0, ya, yb);
             atomicAdd(&pb_cnt[key + b], yb - ya);
@@ -482,7 +533,7 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
                                                    const int* __restrict__ bbox, const int* __restrict__ pb_off,
                                                    const int* __restrict__ b0, int vr0, int pb_cap,
                                                    const int* __restrict__ bseg_off, int* __restrict__ pb_cursor,
-                                                   RowRec* __restrict__ recs, int rec_cap, BatchDev* __restrict__ bd) {
+                                                   RowRec* __restrict__ recs, int rec_cap, BatchDev* __restrict__ bd, Owner own) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     EdgeSetup es;
     int p = 0, r0 = 0, key = -1, rows_first = 0;
@@ -494,7 +545,7 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
         key = pb_off[p] - b0[p] + bf;
         if (key < 0 || key + (bl - bf) >= pb_cap) ok = false;  // flagged by k_edge_count
     }
-    if (ok) {
+    if (ok && owns_band(own, bf)) {
         int ya, yb;
         band_rows(es, bf, vr0, r0, ya, yb);
         rows_first = yb - ya;
@@ -505,7 +556,7 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
     const int run_end_incl = __shfl(excl + rows_first, (head + len - 1) & 63);
     const int run_begin_excl = __shfl(excl, head);
     int run_base = 0;
-    if (ok && head == lane) run_base = atomicAdd(&pb_cursor[key], run_end_incl - run_begin_excl);
+    if (ok && head == lane && run_end_incl > run_begin_excl) run_base = atomicAdd(&pb_cursor[key], run_end_incl - run_begin_excl);
     run_base = __shfl(run_base, head);
     if (!ok) return;
     RowState st;
@@ -518,6 +569,10 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
         int ya, y1;
         band_rows(es, band, vr0, r0, ya, y1);
         const int pb = key + b;
+        if (!owns_band(own, band)) {  // another rank's band: only carry x across it
+            for (; y < y1; ++y) row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);
+            continue;
+        }
         int slot = bseg_off[pb] + 1 + (b == 0 ? run_base + (excl - run_begin_excl) : atomicAdd(&pb_cursor[pb], y1 - ya));
         const int band_row0 = band * TR + vr0 - r0;
         for (; y < y1; ++y, ++slot) {
@@ -538,10 +593,11 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
 // one workgroup per band: ascending list of the paths whose bbox rows cover the band
 __global__ __launch_bounds__(256) void k_band_entries(const int* __restrict__ b0, const int* __restrict__ nb, int n_paths,
                                                       int* __restrict__ band_start, int* __restrict__ band_count,
-                                                      int* __restrict__ entries, int entry_cap, BatchDev* __restrict__ bd) {
+                                                      int* __restrict__ entries, int entry_cap, BatchDev* __restrict__ bd,
+                                                      Owner own) {
     __shared__ int s_wcnt[4];
     __shared__ int s_start, s_total;
-    const int band = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int band = owned_band_at(own, blockIdx.x), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // pass 1: count
     int mine = 0;
     for (int p = tid; p < n_paths; p += 256) {
@@ -619,7 +675,7 @@ struct TileArgs {
     const double* paint;       // n_paths x 4
     void* out;
     int vr0, vc0, vrows, vcols;  // viewport
-    int band_first, band_step;   // owned bands
+    Owner own;                   // owned bands
     int out_cols;                // row pitch of `out` in pixels
     int clip01;
     int single_r0, single_c0, single_cols;  // single-path outputs: layer origin / pitch
@@ -649,7 +705,7 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int trow = tid / CH, chunk = tid % CH;
-    const int band = a.band_first + (int)blockIdx.y * a.band_step;
+    const int band = owned_band_at(a.own, (int)blockIdx.y);
     const int tile_r0 = a.vr0 + band * TR;             // absolute row of tile row 0
     const int tile_c0 = a.vc0 + (int)blockIdx.x * TC;  // absolute column of tile column 0
     const int tile_c1 = tile_c0 + TC;
@@ -1048,7 +1104,7 @@ struct svgr_batch {
     int vp[4] = {0, 0, 0, 0};
     bool has_vp = false;       // as given by the caller
     double thr = 0.16000000000000003;
-    int band_first = 0, band_step = 1;
+    Owner own{0, 1, 1};
     bool planned = false;
     // inputs
     DevArr<double> segs, path_m6, path_paint;
@@ -1100,24 +1156,30 @@ struct svgr_batch {
 static inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 static inline int cap_i32(size_t n) { return (int)std::min<size_t>(n, 0x7fffffff); }
 
-// Geometry stages.  `upto`: 1 = flatten (count only), 2 = + emit + bbox, 3 = + edge count + slot
+// Geometry stages.  `upto`: 0 = flatten (count only) + bbox, 1 = flatten (count only), 2 = flatten + emit + bbox, 3 = + edge count + slot
 // reservation, 4 = everything.  `use_vp` = clip bboxes to b->vp and bin relative to it.
 static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     hipStream_t st = b->ctx->stream;
     const int ns = (int)b->n_segs, np = (int)b->n_paths;
     HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
     const dim3 fgrid = grid1((size_t)ns << FL_SUB, FL_BLOCK);
-    if (upto == 1) {
+    if (upto <= 1) {
         if (ns > 0)
             hipLaunchKernelGGL(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                                (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns,
-                               b->thr, (double*)nullptr, (int*)nullptr, 0, b->pkeys(), b->bd());
+                               b->thr, (double*)nullptr, (int*)nullptr, 0, b->pkeys(), b->bd(), b->own, b->vp[0],
+                               use_vp ? (b->vp[2] + TR - 1) / TR : 0);
+        if (upto == 0)  // bboxes only (no edges stored): enough to find the union when there is no viewport
+            hipLaunchKernelGGL(k_path_bbox, grid1(np), dim3(256), 0, st, (const unsigned long long*)b->pkeys(), np,
+                               use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->b0.p, b->nb.p, b->pb_off.p,
+                               (int*)nullptr, 0, b->bd());
         return 0;
     }
     if (ns > 0)
         hipLaunchKernelGGL(k_flatten<true>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                            (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
-                           b->edges.p, b->edge_path.p, cap_i32(b->edges.cap / 4), b->pkeys(), b->bd());
+                           b->edges.p, b->edge_path.p, cap_i32(b->edges.cap / 4), b->pkeys(), b->bd(), b->own, b->vp[0],
+                           use_vp ? (b->vp[2] + TR - 1) / TR : 0);
     hipLaunchKernelGGL(k_path_bbox, grid1(np), dim3(256), 0, st, (const unsigned long long*)b->pkeys(), np, use_vp ? 1 : 0,
                        b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->b0.p, b->nb.p, b->pb_off.p,
                        b->pb_cap > 0 ? b->pb_path.p : (int*)nullptr, b->pb_cap, b->bd());
@@ -1125,17 +1187,18 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     const size_t ne = (size_t)std::max<int64_t>(b->n_edges, 1);
     hipLaunchKernelGGL(k_edge_count, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
                        (const int*)b->bbox.p, (const int*)b->pb_off.p, (const int*)b->b0.p, b->vp[0], b->pb_cap, b->pb_cnt(),
-                       b->bd());
+                       b->bd(), b->own);
     hipLaunchKernelGGL(k_alloc, grid1((size_t)std::max(b->pb_cap, 1), 1024), dim3(1024), 0, st, (const int*)b->pb_cnt(), b->pb_cap,
                        b->bseg_off.p, (const int*)b->pb_path.p, (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p,
                        upto >= 4 ? b->bsegs.p : (RowRec*)nullptr, cap_i32(b->bsegs.cap), b->bd());
     if (upto == 3) return 0;
     hipLaunchKernelGGL(k_edge_emit, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
                        (const int*)b->bbox.p, (const int*)b->pb_off.p, (const int*)b->b0.p, b->vp[0], b->pb_cap,
-                       (const int*)b->bseg_off.p, b->pb_cursor(), b->bsegs.p, cap_i32(b->bsegs.cap), b->bd());
-    if (b->n_bands > 0)
-        hipLaunchKernelGGL(k_band_entries, dim3(b->n_bands), dim3(256), 0, st, (const int*)b->b0.p, (const int*)b->nb.p, np,
-                           b->band_start.p, b->band_count.p, b->entries.p, cap_i32(b->entries.cap), b->bd());
+                       (const int*)b->bseg_off.p, b->pb_cursor(), b->bsegs.p, cap_i32(b->bsegs.cap), b->bd(), b->own);
+    const int owned = count_owned_bands(b->own, b->n_bands);
+    if (owned > 0)
+        hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(256), 0, st, (const int*)b->b0.p, (const int*)b->nb.p, np,
+                           b->band_start.p, b->band_count.p, b->entries.p, cap_i32(b->entries.cap), b->bd(), b->own);
     return 0;
 }
 
@@ -1389,10 +1452,10 @@ int svgr_batch_set_transforms(svgr_batch* b, const double* path_m6) {
     return 0;
 }
 
-int svgr_batch_set_bands(svgr_batch* b, int band_first, int band_step) {
-    if (!b || band_first < 0 || band_step <= 0) return fail(SVGR_E_INVALID, "bad band selection");
-    b->band_first = band_first;
-    b->band_step = band_step;
+int svgr_batch_set_bands(svgr_batch* b, int rank, int world, int strip_bands) {
+    if (!b || world <= 0 || rank < 0 || rank >= world || strip_bands <= 0) return fail(SVGR_E_INVALID, "bad band selection");
+    b->own = Owner{rank, world, strip_bands};
+    b->planned = false;  // the edge / record capacities are per rank
     return 0;
 }
 
@@ -1401,17 +1464,10 @@ int svgr_batch_plan(svgr_batch* b) {
     HIPCHK(hipSetDevice(b->ctx->device));
     b->planned = false;
     const int np = (int)b->n_paths;
-    // 1. count edges
     if (int rc = b->layout_arena(0)) return rc;
-    if (int rc = run_geometry(b, 1, b->has_vp)) return rc;
-    if (int rc = check_dev_err(b)) return rc;
-    b->n_edges = b->host_bd.edge_cursor;
-    if (int rc = b->edges.ensure((size_t)std::max<int64_t>(b->n_edges, 1) * 4)) return rc;
-    if (int rc = b->edge_path.ensure((size_t)std::max<int64_t>(b->n_edges, 1))) return rc;
-    // 2. edges + bboxes.  Without a viewport (S:968 `viewport is None`) the union of the unclipped
-    //    bboxes becomes the canvas.
+    // 1. Without a viewport (S:968 `viewport is None`) the union of the unclipped bboxes becomes the canvas.
     if (!b->has_vp) {
-        if (int rc = run_geometry(b, 2, false)) return rc;
+        if (int rc = run_geometry(b, 0, false)) return rc;
         if (int rc = check_dev_err(b)) return rc;
         if (b->host_bd.n_nonempty > 0) {
             long long r0 = (long long)UNION_BIAS - (long long)b->host_bd.umin_r, c0 = (long long)UNION_BIAS - (long long)b->host_bd.umin_c;
@@ -1423,6 +1479,12 @@ int svgr_batch_plan(svgr_batch* b) {
             b->vp[0] = b->vp[1] = 0; b->vp[2] = b->vp[3] = 0;
         }
     }
+    // 2. count the edges this rank keeps
+    if (int rc = run_geometry(b, 1, true)) return rc;
+    if (int rc = check_dev_err(b)) return rc;
+    b->n_edges = b->host_bd.edge_cursor;
+    if (int rc = b->edges.ensure((size_t)std::max<int64_t>(b->n_edges, 1) * 4)) return rc;
+    if (int rc = b->edge_path.ensure((size_t)std::max<int64_t>(b->n_edges, 1))) return rc;
     b->n_bands = (b->vp[2] + TR - 1) / TR;
     if (int rc = b->band_start.ensure((size_t)b->n_bands + 1)) return rc;
     if (int rc = b->band_count.ensure((size_t)b->n_bands + 1)) return rc;
@@ -1490,10 +1552,8 @@ int svgr_batch_get_edges(const svgr_batch* b, double* edges, int32_t* edge_path,
 
 int64_t svgr_batch_owned_rows(const svgr_batch* b) {
     if (!b || !b->planned) return -1;
-    if (b->band_first == 0 && b->band_step == 1) return b->vp[2];
-    int owned = 0;
-    for (int band = b->band_first; band < b->n_bands; band += b->band_step) ++owned;
-    return (int64_t)owned * TR;
+    if (b->own.world <= 1) return b->vp[2];
+    return (int64_t)count_owned_bands(b->own, b->n_bands) * TR;
 }
 
 static int get_event(svgr_batch* b, hipEvent_t* e) {
@@ -1511,8 +1571,7 @@ int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags
     HIPCHK(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
 
-    int owned_bands = 0;
-    for (int band = b->band_first; band < b->n_bands; band += b->band_step) ++owned_bands;
+    const int owned_bands = count_owned_bands(b->own, b->n_bands);
     const int n_ctiles = (b->vp[3] + TC - 1) / TC;
     size_t need;
     int single_bb[4] = {0, 0, 0, 0};
@@ -1520,7 +1579,7 @@ int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags
         for (int i = 0; i < 4; ++i) single_bb[i] = b->host_bbox[i];
         need = (size_t)std::max(single_bb[2], 0) * std::max(single_bb[3], 0) * sizeof(double) * (out_kind == 3 ? 4 : 1);
     } else {
-        const bool all = b->band_first == 0 && b->band_step == 1;
+        const bool all = b->own.world <= 1;
         size_t rows = all ? (size_t)b->vp[2] : (size_t)owned_bands * TR;
         need = rows * (size_t)b->vp[3] * 4 * (out_kind == 0 ? sizeof(float) : sizeof(double));
     }
@@ -1548,7 +1607,7 @@ int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags
         a.rule = b->path_rule.p;
         a.paint = b->path_paint.p; a.out = out->ptr;
         a.vr0 = b->vp[0]; a.vc0 = b->vp[1]; a.vrows = b->vp[2]; a.vcols = b->vp[3];
-        a.band_first = b->band_first; a.band_step = b->band_step;
+        a.own = b->own;
         a.out_cols = b->vp[3];
         a.clip01 = (flags & SVGR_RENDER_CLIP01) ? 1 : 0;
         a.single_r0 = single_bb[0]; a.single_c0 = single_bb[1]; a.single_cols = single_bb[3];

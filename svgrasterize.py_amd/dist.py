@@ -2,7 +2,7 @@
 
 Rows never interact in this path (the prefix sum runs along a scanline, S:983; compositing is per
 pixel), so rank r of N simply renders the bands {r, r+N, r+2N, ...} of the viewport (band =
-``tile_rows`` scanlines, interleaved for load balance) from the SAME scene description.  An edge that
+``tile_rows`` scanlines; strips of a few bands are interleaved for load balance) from the SAME scene description.  An edge that
 crosses a band border is handed to both owners: duplicated edges are the "halo", no pixel ever
 crosses a GPU, and the data path needs no collective.  The only communication is the optional
 assembly of the finished bands (all_gather over RCCL on GPUs, gloo in the CPU tests).
@@ -16,20 +16,21 @@ def n_bands(rows: int, tile_rows: int) -> int:
     return (rows + tile_rows - 1) // tile_rows
 
 
-def owned_bands(rows: int, tile_rows: int, rank: int, world: int) -> list[int]:
-    return list(range(rank, n_bands(rows, tile_rows), world))
+def owned_bands(rows: int, tile_rows: int, rank: int, world: int, strip: int = 1) -> list[int]:
+    """Bands of rank `rank`: the strips s (of `strip` consecutive bands) with s % world == rank."""
+    return [b for b in range(n_bands(rows, tile_rows)) if (b // strip) % world == rank]
 
 
-def owned_row_ranges(rows: int, tile_rows: int, rank: int, world: int) -> list[tuple[int, int]]:
+def owned_row_ranges(rows: int, tile_rows: int, rank: int, world: int, strip: int = 1) -> list[tuple[int, int]]:
     """[(row0, row1)) of every owned band, in the order they are packed in the rank's buffer."""
-    return [(b * tile_rows, min((b + 1) * tile_rows, rows)) for b in owned_bands(rows, tile_rows, rank, world)]
+    return [(b * tile_rows, min((b + 1) * tile_rows, rows)) for b in owned_bands(rows, tile_rows, rank, world, strip)]
 
 
-def max_owned_bands(rows: int, tile_rows: int, world: int) -> int:
-    return (n_bands(rows, tile_rows) + world - 1) // world
+def max_owned_bands(rows: int, tile_rows: int, world: int, strip: int = 1) -> int:
+    return max(len(owned_bands(rows, tile_rows, r, world, strip)) for r in range(world))
 
 
-def assemble(parts, rows: int, tile_rows: int):
+def assemble(parts, rows: int, tile_rows: int, strip: int = 1):
     """parts[r] = rank r's packed bands, shape (k_r * tile_rows [or more, padded], cols, ch) -> full
     (rows, cols, ch) canvas.  Works on numpy arrays and torch tensors alike."""
     world = len(parts)
@@ -37,12 +38,12 @@ def assemble(parts, rows: int, tile_rows: int):
     out = first.new_zeros((rows,) + tuple(first.shape[1:])) if hasattr(first, "new_zeros") else np.zeros(
         (rows,) + tuple(first.shape[1:]), dtype=first.dtype)
     for r, part in enumerate(parts):
-        for k, (r0, r1) in enumerate(owned_row_ranges(rows, tile_rows, r, world)):
+        for k, (r0, r1) in enumerate(owned_row_ranges(rows, tile_rows, r, world, strip)):
             out[r0:r1] = part[k * tile_rows: k * tile_rows + (r1 - r0)]
     return out
 
 
-def gather_canvas(local, rows: int, tile_rows: int, group=None):
+def gather_canvas(local, rows: int, tile_rows: int, group=None, strip: int = 1):
     """all_gather the ranks' packed bands (torch tensor, CPU/gloo or GPU/RCCL) and assemble the full
     canvas on every rank.  Ranks own at most one band more than others, so buffers are padded to the
     largest shard before the collective."""
@@ -50,7 +51,7 @@ def gather_canvas(local, rows: int, tile_rows: int, group=None):
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    pad_rows = max_owned_bands(rows, tile_rows, world) * tile_rows
+    pad_rows = max_owned_bands(rows, tile_rows, world, strip) * tile_rows
     if local.shape[0] < pad_rows:
         pad = torch.zeros((pad_rows - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], dim=0)
@@ -58,4 +59,4 @@ def gather_canvas(local, rows: int, tile_rows: int, group=None):
     gathered = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
     gathered = gathered.view((world,) + tuple(local.shape))
-    return assemble([gathered[r] for r in range(world)], rows, tile_rows)
+    return assemble([gathered[r] for r in range(world)], rows, tile_rows, strip)
