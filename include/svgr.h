@@ -183,6 +183,35 @@ int svgr_layer_convert(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, unsigned ops)
 /* float64 -> float32 (optionally clipping to [0,1]) for presentation */
 int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst_f32, const svgr_buf* src_f64, int64_t n_values, int clip01);
 
+/* -------------------------------------------------------------------------------------------- */
+/* gradient paint servers and Gaussian blur (config 5)                                          */
+/* -------------------------------------------------------------------------------------------- */
+/* Path.fill, gradient branch (S:1021-1047): out(rows, cols, 4) = gradient(pixel centre) * mask(rows, cols),
+ * GradLinear.fill S:1553-1563, GradRadial.fill S:1577-1650, grad_spread S:1661-1668, grad_interpolate
+ * S:1671-1683.  The host supplies what the reference computes once per fill with numpy: the inverse
+ * transforms, vec / vec.vec, the focal-circle scalars and the stops already converted to the target
+ * colour space (grad_stops_colorspace, S:1686-1695).                                                */
+typedef struct {
+    int kind;            /* 1 linear, 2 radial (one circle), 3 radial with a focal circle                    */
+    int spread;          /* 0 pad, 1 repeat, 2 reflect                                                       */
+    int has_gt;          /* apply gt_m6 (gradientTransform inverse) after user_m6                            */
+    int n_stops;         /* 1..32                                                                            */
+    int excl_enabled;    /* fradius != radius: exclude negative r(t) (S:1642-1644)                           */
+    double user_m6[6];   /* pixel centre -> user space: rows 0-1 of transform.invert.m (S:1023-1027)          */
+    double gt_m6[6];
+    double p0[2], vec[2], vv;                       /* linear: p0, p1 - p0, vec . vec                          */
+    double center[2], radius;                       /* radial                                                 */
+    double fcenter[2], fradius, cd[2], rd, a, frad_rd, frad2, excl_thresh;   /* focal: S:1619-1624, S:1644      */
+    const double* stop_off;                         /* n_stops offsets                                        */
+    const double* stop_rgba;                        /* n_stops x 4 premultiplied colours                      */
+} svgr_gradient;
+int svgr_gradient_fill(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* mask, const int64_t* bbox, svgr_buf* out_rgba);
+
+/* Layer.convolve (S:106-118): full 2-D convolution of a (rows, cols, 4) double image with a host (kw, kh)
+ * kernel (blur_kernel, S:1903-1944, is built on the host); out is (rows + kw - 1, cols + kh - 1, 4).     */
+int svgr_layer_convolve(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, const double* kernel,
+                        int64_t kw, int64_t kh);
+
 #ifdef __cplusplus
 }
 #endif

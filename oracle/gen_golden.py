@@ -344,6 +344,112 @@ def gen_compose(ref) -> None:
 
 
 # --------------------------------------------------------------------------------------
+# D2. gradient fills (S:1021-1047, 1544-1695) and Gaussian blur (S:106-118, 1890-1944)
+# --------------------------------------------------------------------------------------
+def gen_gradient(ref) -> None:
+    rng = np.random.default_rng(0x96AD)
+    swap = ref.Transform().matrix(0, 1, 0, 1, 0, 0)
+    out, meta = {}, []
+
+    def stops(n, alpha=True):
+        offs = np.sort(rng.uniform(0, 1, n))
+        offs[0] = 0.0 if rng.uniform() < 0.5 else offs[0]
+        offs[-1] = 1.0 if rng.uniform() < 0.5 else offs[-1]
+        res = []
+        for o in offs:
+            a = rng.uniform(0.2, 1.0) if alpha else 1.0
+            res.append((float(o), np.concatenate([rng.uniform(0, 1, 3) * a, [a]])))
+        return res
+
+    shapes = ["M4,4 H60 V44 H4 Z", "M32,3 C70,5 62,50 30,46 S-6,30 32,3 Z", "M8,8 L56,12 L40,44 L10,36 Z"]
+    cases = []
+    for i in range(18):
+        d = shapes[i % 3]
+        tr = swap.scale(rng.uniform(0.6, 1.6)).translate(rng.uniform(-3, 3), rng.uniform(-3, 3))
+        if i % 5 == 4:
+            tr = tr.rotate(0.3)
+        gt = None if i % 3 == 0 else ref.Transform().translate(rng.uniform(-5, 5), rng.uniform(-5, 5)).scale(
+            rng.uniform(0.7, 1.4), rng.uniform(0.7, 1.4)).rotate(rng.uniform(-0.5, 0.5))
+        spread = ["pad", "repeat", "reflect"][i % 3]
+        bbox_units = i % 4 == 3
+        lin = [None, True, False][i % 3]
+        if i % 2 == 0:
+            if bbox_units:
+                p0, p1 = np.array([0.1, 0.2]), np.array([0.7, 0.9])
+            else:
+                p0, p1 = rng.uniform(5, 30, 2), rng.uniform(30, 60, 2)
+            paint = ref.GradLinear(p0, p1, stops(int(rng.integers(2, 6))), gt, spread, bbox_units, lin)
+            kind = "linear"
+        else:
+            if bbox_units:
+                c, r = np.array([0.5, 0.45]), 0.4
+                fc = None if i % 3 == 0 else np.array([0.6, 0.5])
+            else:
+                c, r = rng.uniform(20, 40, 2), float(rng.uniform(10, 30))
+                fc = None if i % 3 == 0 else c + rng.uniform(-0.5, 0.5, 2) * r
+            fr = None if fc is None else (0.0 if i % 4 else 0.2 * r)
+            if i == 13:  # focal point outside the circle: det < 0 somewhere
+                fc = c + np.array([1.3 * r, 0.0])
+            paint = ref.GradRadial(c, r, fc, fr, stops(int(rng.integers(2, 6))), gt, spread, bbox_units, lin)
+            kind = "radial"
+        vp = [0, 0, 70, 90] if i % 6 == 5 else None
+        cases.append((d, tr, paint, kind, vp, bool(i % 2)))
+
+    for idx, (d, tr, paint, kind, vp, linear_rgb) in enumerate(cases):
+        path = ref.Path.from_svg(d)
+        lines, cubics = gather_defs(ref, path)
+        res = path.fill(tr, paint, viewport=vp, linear_rgb=linear_rgb)
+        layer, _hull = res
+        m = dict(kind=kind, viewport=vp, linear_rgb=linear_rgb, spread=paint.spread, bbox_units=bool(paint.bbox_units),
+                 paint_linear_rgb=paint.linear_rgb, offset=[int(layer.offset[0]), int(layer.offset[1])],
+                 layer_linear_rgb=bool(layer.linear_rgb), has_gt=paint.transform is not None)
+        out[f"{idx}_tr"] = tr.m
+        out[f"{idx}_lines"] = lines
+        out[f"{idx}_cubics"] = cubics
+        out[f"{idx}_stop_off"] = np.array([o for o, _ in paint.stops])
+        out[f"{idx}_stop_col"] = np.array([c for _, c in paint.stops])
+        if paint.transform is not None:
+            out[f"{idx}_gt"] = paint.transform.m
+        if kind == "linear":
+            out[f"{idx}_p0"], out[f"{idx}_p1"] = np.asarray(paint.p0, float), np.asarray(paint.p1, float)
+        else:
+            out[f"{idx}_center"] = np.asarray(paint.center, float)
+            out[f"{idx}_radius"] = np.array(float(paint.radius))
+            m["has_focal"] = paint.fcenter is not None
+            if paint.fcenter is not None:
+                out[f"{idx}_fcenter"] = np.asarray(paint.fcenter, float)
+                out[f"{idx}_fradius"] = np.array(float(paint.fradius))
+        out[f"{idx}_image"] = layer.image
+        meta.append(m)
+
+    # blur kernels + convolutions
+    bl = []
+    for j in range(8):
+        tr = swap.scale(rng.uniform(0.8, 3.0))
+        if j % 4 == 3:
+            tr = tr.rotate(0.4)
+        if j == 5:
+            tr = swap.scale(2.0, 0.7)
+        sig = (float(rng.uniform(0.3, 2.5)), None if j % 2 else float(rng.uniform(0.3, 2.5)))
+        kernel = ref.blur_kernel(tr, (sig[0], sig[0] if sig[1] is None else sig[1]))
+        a = rng.uniform(0, 1, (int(rng.integers(5, 20)), int(rng.integers(5, 20)), 1))
+        img = np.concatenate([rng.uniform(0, 1, a.shape[:2] + (3,)) * a, a], axis=-1)
+        layer = ref.Layer(img, (int(rng.integers(-5, 9)), int(rng.integers(-5, 9))), True, bool(j % 2))
+        res = ref.filter_blur(tr, *sig)(layer)
+        out[f"b{j}_tr"] = tr.m
+        out[f"b{j}_in"] = img
+        out[f"b{j}_out"] = res.image
+        if kernel is not None:
+            out[f"b{j}_kernel"] = kernel
+        bl.append(dict(sigma=[sig[0], sig[1]], in_offset=[int(v) for v in layer.offset], in_linear_rgb=bool(layer.linear_rgb),
+                       noop=kernel is None, out_offset=[int(v) for v in res.offset], out_pre_alpha=bool(res.pre_alpha),
+                       out_linear_rgb=bool(res.linear_rgb)))
+    # a degenerate blur (both sigmas below half a pixel): no-op
+    out["meta"] = np.array(json.dumps(dict(grad=meta, blur=bl)))
+    save("gradient_blur_kat.npz", **out)
+
+
+# --------------------------------------------------------------------------------------
 # E. scene dumps + golden renders
 # --------------------------------------------------------------------------------------
 class Dumper:
@@ -410,8 +516,14 @@ class Dumper:
         if t == ref.RENDER_TRANSFORM:
             return dict(t="transform", c=self.node(a[0]), m=[float(x) for x in a[1].m[:2].ravel()])
         if t == ref.RENDER_FILTER:
-            self.unsupported.add("filter")
-            return dict(t="filter", c=self.node(a[0]), repr=repr(a[1]))
+            flt = a[1]
+            fl = []
+            for ftype, attrs, inputs in flt.filters:
+                if ftype != ref.FE_GAUSSIAN_BLUR:
+                    self.unsupported.add(f"filter:{ftype}")
+                fl.append(dict(type=int(ftype), attrs=[None if v is None else float(v) for v in attrs]
+                               if ftype == ref.FE_GAUSSIAN_BLUR else repr(attrs), inputs=[int(i) for i in inputs]))
+            return dict(t="filter", c=self.node(a[0]), filters=fl)
         raise ValueError(t)
 
     def arrays(self):
@@ -454,7 +566,7 @@ def f32_hash(canvas) -> str:
     return hashlib.sha256(np.ascontiguousarray(canvas, dtype=np.float32).tobytes()).hexdigest()
 
 
-def gen_scene(ref, fonts, name, svg, width, small_scales, full, crop=None) -> None:
+def gen_scene(ref, fonts, name, svg, width, small_scales, full, crop=None, store_layer=True) -> None:
     print(f"scene {name} ({svg} @ {width})")
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     scene, _ids, size = ref.svg_scene_from_filepath(os.path.join(DEMO, svg), width=width, fonts=fonts)
@@ -475,7 +587,8 @@ def gen_scene(ref, fonts, name, svg, width, small_scales, full, crop=None) -> No
         ref.canvas_merge_at(canvas, cl.image, cl.offset)
         tag = f"s{hh}"
         out[f"{tag}_canvas"] = canvas
-        out[f"{tag}_layer"] = layer.image
+        if store_layer:
+            out[f"{tag}_layer"] = layer.image
         info["renders"].append(dict(tag=tag, scale=scale, size=[hh, ww], layer_offset=list(map(int, layer.offset)),
                                     layer_pre_alpha=bool(layer.pre_alpha), layer_linear_rgb=bool(layer.linear_rgb),
                                     sha256_f32=f32_hash(canvas)))
@@ -528,12 +641,14 @@ def main() -> None:
         gen_mask(ref)
     if todo("compose"):
         gen_compose(ref)
+    if todo("gradient"):
+        gen_gradient(ref)
     if todo("tiger"):
         gen_scene(ref, fonts, "tiger", "icons/tiger.svg", 2048, [1 / 16, 1 / 8], args.full, crop=[900, 700, 96, 128])
     if todo("material"):
         gen_scene(ref, fonts, "material", "material-design.svg", 4096, [1 / 16], args.full, crop=[1000, 1000, 160, 192])
     if todo("icons"):
-        gen_scene(ref, fonts, "icons", "icons.svg", None, [], False)
+        gen_scene(ref, fonts, "icons", "icons.svg", None, [1.0], False, store_layer=False)
     if todo("prompt"):
         gen_scene(ref, fonts, "prompt", "prompt.svg", 256, [1.0], False)
 

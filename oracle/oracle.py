@@ -225,3 +225,80 @@ def render_solid(segs, seg_kind, path_seg_off, path_rule, path_paint, viewport, 
     if rc != 0:
         raise RuntimeError(f"orc_render_solid failed: {rc}")
     return canvas, int(stats[0]), int(stats[1])
+
+
+# --------------------------------------------------------------------------------------
+# gradients and blur (config 5), restated in numpy.  S:n = reference line n.
+# --------------------------------------------------------------------------------------
+def _affine(m, pts):
+    """Transform.__call__ (S:531-534) on an (..., 2) array: numpy's own matmul supplies the fma form."""
+    m = np.asarray(m, dtype=np.float64)
+    return pts @ m[:2, :2].T + m[:2, 2]
+
+
+def gradient_image(kind, bbox, user_m, gt_m, spread, stop_off, stop_rgba, p0=None, p1=None, center=None, radius=None,
+                   fcenter=None, fradius=None):
+    """paint.fill(user_tr(grad_pixels(bbox))) of S:1021-1031 for stops already in the target colour space."""
+    r0, c0, rows, cols = bbox
+    xs, ys = np.indices((rows, cols)).astype(np.float64)
+    px = np.concatenate([xs[..., None], ys[..., None]], axis=2) + [r0 + 0.5, c0 + 0.5]  # grad_pixels S:1653-1658
+    px = _affine(user_m, px)
+    if gt_m is not None:
+        px = _affine(gt_m, px)  # the caller passes the INVERSE gradientTransform (S:1559 / S:1603)
+    mask = None
+    if kind == "linear":
+        vec = np.asarray(p1, float) - np.asarray(p0, float)
+        offset = (px - p0) @ vec / np.dot(vec, vec)
+    elif fcenter is None and fradius is None:
+        offset = (px - center) / radius
+        offset = np.sqrt((offset * offset).sum(axis=-1))
+    else:
+        fc = np.asarray(center if fcenter is None else fcenter, float)
+        fr = fradius or 0
+        cd = np.asarray(center, float) - fc
+        pd = px - fc
+        rd = radius - fr
+        a = (cd ** 2).sum() - rd ** 2
+        b = (pd * cd).sum(axis=-1) + fr * rd
+        c = (pd ** 2).sum(axis=-1) - fr ** 2
+        det = b * b - a * c
+        if (det < 0).any():
+            mask = det >= 0
+        with np.errstate(invalid="ignore"):
+            t0 = np.sqrt(det)
+        off_all = np.maximum((b + t0) / a, (b - t0) / a)
+        if mask is None:
+            offset = off_all
+        else:
+            offset = np.where(mask, off_all, 0.0)
+            if fr != radius:
+                mask = mask & (offset > (fr / (fr - radius)))
+    if spread == "repeat":
+        offset = np.modf(offset)[0]
+    elif spread == "reflect":
+        offset = np.fabs(np.remainder(offset + 1.0, 2.0) - 1.0)
+    elif spread != "pad":
+        raise ValueError(f"invalid spread method: {spread}")
+    out = np.zeros(offset.shape + (4,))
+    out[offset <= stop_off[0]] = stop_rgba[0]
+    out[offset > stop_off[-1]] = stop_rgba[-1]
+    for s in range(len(stop_off) - 1):
+        o0, o1 = stop_off[s], stop_off[s + 1]
+        sel = np.logical_and(offset > o0, offset <= o1)
+        ratio = ((offset[sel] - o0) / (o1 - o0))[..., None]
+        out[sel] += (1 - ratio) * stop_rgba[s] + ratio * stop_rgba[s + 1]
+    if mask is not None:
+        out[~mask] = 0.0
+    return out
+
+
+def convolve_full(image, kernel):
+    """Layer.convolve (S:106-118): full 2-D convolution, direct summation (the reference lets scipy pick
+    FFT, which differs by ~1e-16)."""
+    image = np.asarray(image, dtype=np.float64)
+    kw, kh = kernel.shape
+    out = np.zeros((image.shape[0] + kw - 1, image.shape[1] + kh - 1, image.shape[2]))
+    for i in range(kw):
+        for j in range(kh):
+            out[i: i + image.shape[0], j: j + image.shape[1]] += image * kernel[i, j]
+    return out

@@ -15,6 +15,7 @@ from .layer import (  # noqa: F401
     Layer, COMPOSE_OVER, COMPOSE_OUT, COMPOSE_IN, COMPOSE_ATOP, COMPOSE_XOR,
 )
 from .paint import GradLinear, GradRadial  # noqa: F401
+from .filters import Filter, blur_kernel  # noqa: F401
 from .scene import (  # noqa: F401
     Scene, render_canvas, build_batch,
     RENDER_FILL, RENDER_STROKE, RENDER_GROUP, RENDER_OPACITY, RENDER_CLIP, RENDER_MASK, RENDER_TRANSFORM, RENDER_FILTER,

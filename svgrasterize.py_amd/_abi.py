@@ -44,6 +44,18 @@ class BatchStats(C.Structure):
     ]
 
 
+class Gradient(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int), ("spread", C.c_int), ("has_gt", C.c_int), ("n_stops", C.c_int), ("excl_enabled", C.c_int),
+        ("user_m6", C.c_double * 6), ("gt_m6", C.c_double * 6),
+        ("p0", C.c_double * 2), ("vec", C.c_double * 2), ("vv", C.c_double),
+        ("center", C.c_double * 2), ("radius", C.c_double),
+        ("fcenter", C.c_double * 2), ("fradius", C.c_double), ("cd", C.c_double * 2), ("rd", C.c_double), ("a", C.c_double),
+        ("frad_rd", C.c_double), ("frad2", C.c_double), ("excl_thresh", C.c_double),
+        ("stop_off", C.c_void_p), ("stop_rgba", C.c_void_p),
+    ]
+
+
 _P = C.c_void_p
 _PROTOS = {
     "svgr_abi_version": (C.c_int, []),
@@ -83,6 +95,8 @@ _PROTOS = {
     "svgr_layer_scale": (C.c_int, [_P, _P, C.c_int64, C.c_double]),
     "svgr_layer_convert": (C.c_int, [_P, _P, C.c_int64, C.c_uint]),
     "svgr_layer_to_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int]),
+    "svgr_gradient_fill": (C.c_int, [_P, C.POINTER(Gradient), _P, _P, _P]),
+    "svgr_layer_convolve": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64]),
 }
 EXPORTS = tuple(_PROTOS)
 

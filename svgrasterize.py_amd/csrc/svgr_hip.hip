@@ -1091,6 +1091,138 @@ __global__ void k_to_f32(float* __restrict__ dst, const double* __restrict__ src
     dst[i] = (float)v;
 }
 
+
+// --------------------------------------------------------------------------------------
+// gradients (S:1021-1047, 1544-1695): image = gradient(pixel centre) * mask
+// --------------------------------------------------------------------------------------
+constexpr int GRAD_MAX_STOPS = 32;
+struct GradDev {
+    int kind, spread, has_gt, n_stops;
+    int excl_enabled, pad0, pad1, pad2;
+    double user_m6[6], gt_m6[6];
+    double p0[2], vec[2], vv;
+    double center[2], radius;
+    double fcenter[2], fradius, cd[2], rd, a, frad_rd, frad2, excl_thresh;
+    double stop_off[GRAD_MAX_STOPS];
+    double stop_rgba[GRAD_MAX_STOPS][4];
+};
+
+// position of pixel (i, j) of the layer in gradient space: grad_pixels (S:1653-1658), user transform
+// (S:1023-1027) and the gradient's own transform (S:1559 / S:1603), both in numpy's fma form
+__device__ __forceinline__ void grad_point(const GradDev& g, int r0, int c0, int i, int j, double& x, double& y) {
+    double px = (double)i + ((double)r0 + 0.5), py = (double)j + ((double)c0 + 0.5);
+    xform_point(g.user_m6, px, py, x, y);
+    if (g.has_gt) {
+        double tx, ty;
+        xform_point(g.gt_m6, x, y, tx, ty);
+        x = tx;
+        y = ty;
+    }
+}
+
+// focal radial: b, c, det of S:1619-1626
+__device__ __forceinline__ double grad_focal_det(const GradDev& g, double x, double y, double& b) {
+    double pd0 = x - g.fcenter[0], pd1 = y - g.fcenter[1];
+    b = (pd0 * g.cd[0] + pd1 * g.cd[1]) + g.frad_rd;
+    double c = (pd0 * pd0 + pd1 * pd1) - g.frad2;
+    return b * b - g.a * c;
+}
+
+// does any pixel of the layer have det < 0 ?  (the reference only builds its exclusion mask then, S:1627)
+__global__ void k_gradient_detneg(const GradDev* __restrict__ gp, int r0, int c0, int rows, int cols, int* __restrict__ flag) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * cols) return;
+    const GradDev& g = *gp;
+    double x, y, b;
+    grad_point(g, r0, c0, (int)(idx / cols), (int)(idx % cols), x, y);
+    if (grad_focal_det(g, x, y, b) < 0.0) atomicOr(flag, 1);
+}
+
+__global__ void k_gradient_fill(const GradDev* __restrict__ gp, const double* __restrict__ mask, int r0, int c0, int rows,
+                                int cols, const int* __restrict__ detneg_flag, double* __restrict__ out) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * cols) return;
+    const GradDev& g = *gp;
+    double x, y;
+    grad_point(g, r0, c0, (int)(idx / cols), (int)(idx % cols), x, y);
+    double offset;
+    bool masked = false;  // overlay[~mask] = 0 (S:1648)
+    if (g.kind == 1) {  // linear, S:1561-1562: ((p - p0) @ vec) / (vec . vec), `@` with a 1-D rhs = fma(d0, v0, d1*v1)
+        double d0 = x - g.p0[0], d1 = y - g.p0[1];
+        offset = fma(d0, g.vec[0], d1 * g.vec[1]) / g.vv;
+    } else if (g.kind == 2) {  // radial, S:1606-1607
+        double o0 = (x - g.center[0]) / g.radius, o1 = (y - g.center[1]) / g.radius;
+        offset = sqrt(o0 * o0 + o1 * o1);
+    } else {  // two-circle (focal) radial, S:1619-1644
+        double b;
+        double det = grad_focal_det(g, x, y, b);
+        const bool use_mask = *detneg_flag != 0;
+        if (use_mask && !(det >= 0.0)) {
+            masked = true;
+            offset = 0.0;
+        } else {
+            double t0 = sqrt(det);
+            double t1 = (b + t0) / g.a, t2 = (b - t0) / g.a;
+            offset = t1 > t2 ? t1 : (t2 > t1 ? t2 : (t1 != t1 ? t1 : t2));  // np.maximum (NaN propagates)
+            if (use_mask && g.excl_enabled && !(offset > g.excl_thresh)) masked = true;  // negative r(t), S:1642-1644
+        }
+    }
+    if (g.spread == 1) {  // repeat: np.modf(offset)[0]
+        offset = offset - trunc(offset);
+    } else if (g.spread == 2) {  // reflect
+        double a1 = offset + 1.0;
+        offset = fabs((a1 - 2.0 * floor(a1 * 0.5)) - 1.0);
+    }
+    // grad_interpolate, S:1671-1683
+    double col[4] = {0.0, 0.0, 0.0, 0.0};
+    const int n = g.n_stops;
+    if (offset <= g.stop_off[0]) {
+        for (int k = 0; k < 4; ++k) col[k] = g.stop_rgba[0][k];
+    }
+    if (offset > g.stop_off[n - 1]) {
+        for (int k = 0; k < 4; ++k) col[k] = g.stop_rgba[n - 1][k];
+    }
+    for (int s = 0; s + 1 < n; ++s) {
+        double o0 = g.stop_off[s], o1 = g.stop_off[s + 1];
+        if (offset > o0 && offset <= o1) {
+            double ratio = (offset - o0) / (o1 - o0);
+            for (int k = 0; k < 4; ++k) col[k] = col[k] + ((1 - ratio) * g.stop_rgba[s][k] + ratio * g.stop_rgba[s + 1][k]);
+        }
+    }
+    if (masked) col[0] = col[1] = col[2] = col[3] = 0.0;
+    const double m = mask[idx];  // canvas_compose(COMPOSE_IN, mask, image) = image * mask (S:1046, S:290)
+    double* o = out + 4 * idx;
+    o[0] = col[0] * m; o[1] = col[1] * m; o[2] = col[2] * m; o[3] = col[3] * m;
+}
+
+// --------------------------------------------------------------------------------------
+// full 2-D convolution of a (rows, cols, 4) image with a (kw, kh) kernel (Layer.convolve, S:106-118)
+// --------------------------------------------------------------------------------------
+__global__ void k_layer_convolve(double* __restrict__ out, const double* __restrict__ src, int rows, int cols,
+                                 const double* __restrict__ kern, int kw, int kh) {
+    const int orows = rows + kw - 1, ocols = cols + kh - 1;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)orows * ocols) return;
+    const int R = (int)(idx / ocols), C = (int)(idx % ocols);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int i_lo = R - rows + 1 > 0 ? R - rows + 1 : 0, i_hi = R < kw - 1 ? R : kw - 1;
+    const int j_lo = C - cols + 1 > 0 ? C - cols + 1 : 0, j_hi = C < kh - 1 ? C : kh - 1;
+    for (int i = i_lo; i <= i_hi; ++i) {
+        const double* srow = src + 4 * ((size_t)(R - i) * cols);
+        const double* krow = kern + (size_t)i * kh;
+        for (int j = j_lo; j <= j_hi; ++j) {
+            const double w = krow[j];
+            const double* px = srow + 4 * (C - j);
+            acc[0] = fma(px[0], w, acc[0]);
+            acc[1] = fma(px[1], w, acc[1]);
+            acc[2] = fma(px[2], w, acc[2]);
+            acc[3] = fma(px[3], w, acc[3]);
+        }
+    }
+    double* o = out + 4 * idx;
+    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+}
+
 // ======================================================================================
 // batch object
 // ======================================================================================
@@ -1726,6 +1858,72 @@ int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_to_f32, grid1((size_t)n), dim3(256), 0, ctx->stream, (float*)dst->ptr, (const double*)src->ptr, (size_t)n, clip01);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_gradient_fill(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* mask, const int64_t* bbox, svgr_buf* out) {
+    if (!ctx || !g || !mask || !out || !bbox_ok(bbox)) return fail(SVGR_E_INVALID, "svgr_gradient_fill: bad arguments");
+    if (g->kind < 1 || g->kind > 3 || g->spread < 0 || g->spread > 2) return fail(SVGR_E_INVALID, "invalid gradient kind / spread method");
+    if (g->n_stops < 1 || g->n_stops > GRAD_MAX_STOPS || !g->stop_off || !g->stop_rgba)
+        return fail(SVGR_E_INVALID, "gradient needs 1..%d stops", GRAD_MAX_STOPS);
+    const size_t n = (size_t)bbox[2] * bbox[3];
+    if (mask->bytes < n * 8 || out->bytes < n * 32) return fail(SVGR_E_INVALID, "svgr_gradient_fill: buffer too small");
+    if (n == 0) return 0;
+    GradDev h;
+    memset(&h, 0, sizeof h);
+    h.kind = g->kind; h.spread = g->spread; h.has_gt = g->has_gt; h.n_stops = g->n_stops; h.excl_enabled = g->excl_enabled;
+    memcpy(h.user_m6, g->user_m6, sizeof h.user_m6);
+    memcpy(h.gt_m6, g->gt_m6, sizeof h.gt_m6);
+    h.p0[0] = g->p0[0]; h.p0[1] = g->p0[1]; h.vec[0] = g->vec[0]; h.vec[1] = g->vec[1]; h.vv = g->vv;
+    h.center[0] = g->center[0]; h.center[1] = g->center[1]; h.radius = g->radius;
+    h.fcenter[0] = g->fcenter[0]; h.fcenter[1] = g->fcenter[1]; h.fradius = g->fradius;
+    h.cd[0] = g->cd[0]; h.cd[1] = g->cd[1]; h.rd = g->rd; h.a = g->a; h.frad_rd = g->frad_rd; h.frad2 = g->frad2;
+    h.excl_thresh = g->excl_thresh;
+    for (int i = 0; i < g->n_stops; ++i) {
+        h.stop_off[i] = g->stop_off[i];
+        for (int k = 0; k < 4; ++k) h.stop_rgba[i][k] = g->stop_rgba[4 * i + k];
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    // parameter block + det<0 flag live in one small device allocation for the duration of the call
+    char* dev = nullptr;
+    HIPCHK(hipMalloc((void**)&dev, sizeof(GradDev) + 16));
+    hipError_t e = hipMemcpyAsync(dev, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dev + sizeof(GradDev), 0, 16, ctx->stream);
+    if (e == hipSuccess) {
+        const GradDev* gd = (const GradDev*)dev;
+        int* flag = (int*)(dev + sizeof(GradDev));
+        if (g->kind == 3)
+            hipLaunchKernelGGL(k_gradient_detneg, grid1(n), dim3(256), 0, ctx->stream, gd, (int)bbox[0], (int)bbox[1], (int)bbox[2],
+                               (int)bbox[3], flag);
+        hipLaunchKernelGGL(k_gradient_fill, grid1(n), dim3(256), 0, ctx->stream, gd, (const double*)mask->ptr, (int)bbox[0],
+                           (int)bbox[1], (int)bbox[2], (int)bbox[3], (const int*)flag, (double*)out->ptr);
+        e = hipStreamSynchronize(ctx->stream);  // `h` and `dev` are call-local
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(SVGR_E_HIP, "svgr_gradient_fill: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int svgr_layer_convolve(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, const double* kernel,
+                        int64_t kw, int64_t kh) {
+    if (!ctx || !out || !src || !kernel || rows <= 0 || cols <= 0 || kw <= 0 || kh <= 0 || rows > (1 << 24) || cols > (1 << 24) ||
+        kw > 4096 || kh > 4096)
+        return fail(SVGR_E_INVALID, "svgr_layer_convolve: bad arguments");
+    const size_t n_out = (size_t)(rows + kw - 1) * (size_t)(cols + kh - 1);
+    if (src->bytes < (size_t)rows * cols * 32 || out->bytes < n_out * 32) return fail(SVGR_E_INVALID, "svgr_layer_convolve: buffer too small");
+    HIPCHK(hipSetDevice(ctx->device));
+    double* dk = nullptr;
+    HIPCHK(hipMalloc((void**)&dk, sizeof(double) * (size_t)kw * kh));
+    hipError_t e = hipMemcpyAsync(dk, kernel, sizeof(double) * (size_t)kw * kh, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_layer_convolve, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)src->ptr,
+                           (int)rows, (int)cols, (const double*)dk, (int)kw, (int)kh);
+        e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    (void)hipFree(dk);
+    if (e != hipSuccess) return fail(SVGR_E_HIP, "svgr_layer_convolve: %s", hipGetErrorString(e));
     return 0;
 }
 

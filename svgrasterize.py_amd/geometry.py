@@ -337,10 +337,14 @@ class Path:
             batch.render(buf, _abi.OUT_FILL_F64)
             layer = Layer._from_device(buf, (rows, cols, 4), _offset(bb, viewport), pre_alpha=True, linear_rgb=linear_rgb)
             return layer, ConvexHull(_source=lambda: batch.edges()[0])
-        from .paint import is_gradient  # noqa: PLC0415  (kept separate: config 5 work)
+        from .paint import gradient_fill, is_gradient  # noqa: PLC0415
 
         if is_gradient(paint):
-            raise NotImplementedError("gradient paints are the next scope row (SURVEY 8a-a16); not built yet")
+            res = self.mask(transform, fill_rule, viewport)
+            if res is None:
+                return None
+            mask, hull = res
+            return gradient_fill(paint, mask, hull, transform, linear_rgb), hull
         warnings.warn(f"fill method is not implemented: {paint}")
         return None
 

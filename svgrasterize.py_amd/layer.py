@@ -165,6 +165,24 @@ class Layer:
         _abi._check(ctx.lib.svgr_layer_scale(ctx.handle, buf.handle, int(np.prod(layer._shape)), float(opacity)))
         return Layer._from_device(buf, layer._shape, layer.offset, True, linear_rgb)
 
+    # -- Layer.convolve  S:106-118 ---------------------------------------------------------
+    def convolve(self, kernel: np.ndarray) -> "Layer":
+        """Full 2-D convolution on straight-alpha linear RGBA; offset moves by half the kernel."""
+        if self.channels != 4:
+            raise ValueError("convolve expects an RGBA layer")
+        layer = self.convert(pre_alpha=False, linear_rgb=True)
+        kernel = np.ascontiguousarray(kernel, dtype=FLOAT)
+        kw, kh = kernel.shape
+        ctx = _abi.Context.get()
+        rows, cols = layer.height, layer.width
+        out_shape = (rows + kw - 1, cols + kh - 1, 4)
+        out = ctx.alloc(out_shape[0] * out_shape[1] * 32)
+        src = layer._device()
+        _abi._check(ctx.lib.svgr_layer_convolve(ctx.handle, out.handle, src.handle, rows, cols,
+                                                kernel.ctypes.data_as(_abi._P), kw, kh))
+        offset = (int(layer.x - kw / 2), int(layer.y - kh / 2))
+        return Layer._from_device(out, out_shape, offset, pre_alpha=False, linear_rgb=True)
+
     # -- Layer.compose  S:177-207 ----------------------------------------------------------
     @staticmethod
     def compose(layers: Sequence["Layer"], method: int = COMPOSE_OVER, linear_rgb: bool = False) -> "Layer | None":

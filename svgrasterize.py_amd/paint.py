@@ -1,31 +1,110 @@
-"""Paint servers (reference S:1544-1710).  Gradients are the config-5 scope row;
-the types exist so scene dumps can name them, the device kernels are not built yet."""
+"""Paint servers of the hot path (reference S:1544-1695): linear and radial gradients.
+
+The per-pixel work (pixel centre -> user space -> gradient offset -> spread -> stop interpolation ->
+times mask) runs in the HIP kernel ``k_gradient_fill``; what the reference computes ONCE per fill with
+numpy (inverse transforms, ``vec``, the focal-circle scalars, the colour-space conversion of the stops)
+is computed here with the same numpy expressions and handed over through ``svgr_gradient``."""
 from __future__ import annotations
 
+import ctypes as C
 from typing import NamedTuple
 
+import numpy as np
 
-class GradLinear(NamedTuple):
-    p0: object
-    p1: object
-    stops: list
-    transform: object
-    spread: str
-    bbox_units: bool
-    linear_rgb: object
+from . import _abi
+
+_SPREAD = {"pad": 0, "repeat": 1, "reflect": 2}
 
 
-class GradRadial(NamedTuple):
-    center: object
-    radius: object
-    fcenter: object
-    fradius: object
-    stops: list
-    transform: object
-    spread: str
-    bbox_units: bool
-    linear_rgb: object
+def _stops_colorspace(stops, linear_rgb: bool):
+    """grad_stops_colorspace, S:1686-1695: premultiplied linear RGBA stops -> target colour space."""
+    from .geometry import solid_paint
+
+    return [(float(o), solid_paint(np.asarray(c, dtype=np.float64), linear_rgb)) for o, c in stops]
+
+
+class _GradMixin:
+    def _common(self, g: "_abi.Gradient", user_tr, linear_rgb: bool):
+        if self.spread not in _SPREAD:
+            raise ValueError(f"invalid spread method: {self.spread}")
+        g.spread = _SPREAD[self.spread]
+        g.user_m6 = (C.c_double * 6)(*np.asarray(user_tr.m, dtype=np.float64)[:2].ravel())
+        if self.transform is not None:
+            g.has_gt = 1
+            g.gt_m6 = (C.c_double * 6)(*np.asarray(self.transform.invert.m, dtype=np.float64)[:2].ravel())
+        stops = _stops_colorspace(self.stops, linear_rgb)
+        if not 1 <= len(stops) <= 32:
+            raise ValueError("a gradient needs 1..32 stops")
+        off = np.ascontiguousarray([o for o, _ in stops], dtype=np.float64)
+        col = np.ascontiguousarray([c for _, c in stops], dtype=np.float64).reshape(-1, 4)
+        g.n_stops = len(stops)
+        g.stop_off = off.ctypes.data
+        g.stop_rgba = col.ctypes.data
+        return off, col  # keep alive until the call returns
+
+
+class GradLinear(_GradMixin, NamedTuple("GradLinear", [("p0", object), ("p1", object), ("stops", list), ("transform", object),
+                                                        ("spread", str), ("bbox_units", bool), ("linear_rgb", object)])):
+    def abi(self, user_tr, linear_rgb: bool):
+        g = _abi.Gradient()
+        g.kind = 1
+        keep = self._common(g, user_tr, linear_rgb)
+        vec = np.asarray(self.p1, dtype=np.float64) - np.asarray(self.p0, dtype=np.float64)  # S:1561
+        g.p0 = (C.c_double * 2)(*np.asarray(self.p0, dtype=np.float64))
+        g.vec = (C.c_double * 2)(*vec)
+        g.vv = float(np.dot(vec, vec))
+        return g, keep
+
+
+class GradRadial(_GradMixin, NamedTuple("GradRadial", [("center", object), ("radius", float), ("fcenter", object),
+                                                        ("fradius", object), ("stops", list), ("transform", object),
+                                                        ("spread", str), ("bbox_units", bool), ("linear_rgb", object)])):
+    def abi(self, user_tr, linear_rgb: bool):
+        g = _abi.Gradient()
+        keep = self._common(g, user_tr, linear_rgb)
+        center = np.asarray(self.center, dtype=np.float64)
+        g.center = (C.c_double * 2)(*center)
+        g.radius = float(self.radius)
+        if self.fcenter is None and self.fradius is None:  # S:1605
+            g.kind = 2
+            return g, keep
+        g.kind = 3
+        fcenter = center if self.fcenter is None else np.asarray(self.fcenter, dtype=np.float64)
+        fradius = self.fradius or 0
+        cd = center - fcenter                      # S:1619
+        rd = self.radius - fradius                 # S:1621
+        g.fcenter = (C.c_double * 2)(*fcenter)
+        g.fradius = float(fradius)
+        g.cd = (C.c_double * 2)(*cd)
+        g.rd = float(rd)
+        g.a = float((cd ** 2).sum() - rd ** 2)     # S:1622
+        g.frad_rd = float(fradius * rd)            # S:1623
+        g.frad2 = float(fradius ** 2)              # S:1624
+        g.excl_enabled = int(fradius != self.radius)
+        g.excl_thresh = float(fradius / (fradius - self.radius)) if fradius != self.radius else 0.0  # S:1644
+        return g, keep
 
 
 def is_gradient(paint) -> bool:
     return isinstance(paint, (GradLinear, GradRadial))
+
+
+def gradient_fill(paint, mask_layer, hull, transform, linear_rgb: bool):
+    """Path.fill, gradient branch (S:1021-1047): returns the RGBA Layer = gradient * mask."""
+    from .layer import Layer
+
+    if paint.bbox_units:
+        user_tr = hull.bbox_transform(transform).invert
+    else:
+        user_tr = transform.invert
+    if paint.linear_rgb is not None:
+        linear_rgb = paint.linear_rgb
+    g, keep = paint.abi(user_tr, linear_rgb)
+    ctx = _abi.Context.get()
+    rows, cols = mask_layer.height, mask_layer.width
+    out = ctx.alloc(rows * cols * 32)
+    mbuf = mask_layer._device()
+    bbox = (C.c_int64 * 4)(int(mask_layer.x), int(mask_layer.y), rows, cols)
+    _abi._check(ctx.lib.svgr_gradient_fill(ctx.handle, C.byref(g), mbuf.handle, bbox, out.handle))
+    del keep
+    return Layer._from_device(out, (rows, cols, 4), mask_layer.offset, pre_alpha=True, linear_rgb=linear_rgb)

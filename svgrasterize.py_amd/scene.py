@@ -10,8 +10,9 @@ routes, both of them HIP:
 * per node: everything else (CLIP, OPACITY over a group, nested results) is rendered node by node
   into device-resident Layers and merged with ``Layer.compose`` exactly as the reference does.
 
-Not built yet: STROKE of an un-stroked path (scene dumps carry the
-stroked outline instead), luminance MASK, FILTER, gradient / pattern paints.
+Gradient fills and feGaussianBlur (config 5) go through the per-node route (`paint.py`, `filters.py`).
+Not built: STROKE of an un-stroked path (scene dumps carry the stroked outline instead),
+luminance MASK, the other filter primitives, pattern paints.
 """
 from __future__ import annotations
 
@@ -148,7 +149,12 @@ class Scene(tuple):
         if kind == RENDER_MASK:
             raise NotImplementedError("luminance masks are outside the accelerated path (SURVEY 8f-4)")
         if kind == RENDER_FILTER:
-            raise NotImplementedError("filters are outside the accelerated path for now (SURVEY 8a-a17 / 8f-4)")
+            target, flt = args
+            res = target.render(transform, mask_only, viewport, linear_rgb)
+            if res is None:
+                return None
+            image, hull = res
+            return flt(transform, image), hull
         raise ValueError(f"unhandled scene type: {kind}")
 
     # -- whole-scene batched render: the bench / production entry -----------------------------

@@ -60,7 +60,12 @@ def load_scene(npz_path: str):
         if t == "transform":
             return Scene(6, (node(n["c"]), _tr(n["m"])))
         if t == "filter":
-            return Scene(7, (node(n["c"]), n.get("repr")))
+            from .filters import Filter
+
+            flt = Filter({"SourceAlpha": 0, "SourceGraphic": 1},
+                         [(f["type"], tuple(f["attrs"]) if isinstance(f["attrs"], list) else f["attrs"], list(f["inputs"]))
+                          for f in n["filters"]])
+            return Scene(7, (node(n["c"]), flt))
         raise ValueError(t)
 
     return node(tree), info, z
