@@ -1,0 +1,103 @@
+"""Full-size configurations of BASELINE.json on the GPU.
+
+* tiger@2048 and material-design@4096: sparse pins of the reference's own full-size renders (about 16 k
+  pixels each, biased to anti-aliased edges; oracle/gen_golden.py --full) -- float32 contract per pixel.
+* synthetic 4096 paths @ 4096x4096 (the bench workload): size-independent properties -- the render is
+  independent of how the canvas is sharded, idempotent, and a random subset of paths re-rendered alone
+  through the CPU oracle on a cropped viewport matches the same crop of the GPU canvas.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import GOLDEN, assert_close64, assert_f32_1ulp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import svgrasterize_amd as S
+
+    S.Context.get()
+    return S
+
+
+def _pins(name):
+    from svgrasterize_amd import scenedump
+
+    scene, info, z = scenedump.load_scene(os.path.join(GOLDEN, f"scene_{name}.npz"))
+    return scene, info, z["full_idx"], z["full_val"]
+
+
+def test_tiger_2048_batched(S):
+    scene, info, idx, val = _pins("tiger")
+    h, w = info["full"]["size"]
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    img, st = S.render_canvas(scene, tr, [0, 0, h, w], linear_rgb=False)
+    assert st.path_pixels == 34470049  # path-pixels of tiger@2048
+    got = img.reshape(-1, 4)[idx]
+    assert_f32_1ulp(got, val, what="tiger@2048 pins (batched)")
+    # the reference CLI result is clipped to [0,1]; nothing else may be out of range
+    assert img.min() >= 0.0 and img.max() <= 1.0
+
+
+def test_tiger_2048_scene_render_matches_batched(S):
+    scene, info, idx, val = _pins("tiger")
+    h, w = info["full"]["size"]
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    layer, _ = scene.render(tr, viewport=[0, 0, h, w], linear_rgb=False)
+    assert [int(v) for v in layer.offset] == info["full"]["layer_offset"]
+    assert list(layer.image.shape) == info["full"]["layer_shape"]
+    canvas = layer.to_canvas_f32(h, w)
+    assert_f32_1ulp(canvas.reshape(-1, 4)[idx], val, what="tiger@2048 pins (Scene.render)")
+
+
+def test_material_4096_clips(S):
+    """989 fills + 935 clip paths (per-node route: mask IN image) at the full 4096x4096."""
+    scene, info, idx, val = _pins("material")
+    h, w = info["full"]["size"]
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    layer, _ = scene.render(tr, viewport=[0, 0, h, w], linear_rgb=False)
+    assert [int(v) for v in layer.offset] == info["full"]["layer_offset"]
+    assert list(layer.image.shape) == info["full"]["layer_shape"]
+    canvas = layer.to_canvas_f32(h, w)
+    assert_f32_1ulp(canvas.reshape(-1, 4)[idx], val, what="material@4096 pins")
+
+
+def test_synth_4096_properties(S):
+    from oracle import oracle as orc
+    from svgrasterize_amd import _abi, dist as sdist, synth
+
+    size, n = 4096, 4096
+    sc = synth.make_scene(size, n)
+    ctx = S.Context.get()
+    batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
+                       viewport=sc["viewport"])
+    st = batch.plan()
+    assert st.path_pixels == 160403147
+    out = ctx.alloc(size * size * 16)
+    batch.render(out, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
+    full = out.download((size, size, 4), np.float32)
+    # idempotent: a second render of the same batch gives the same canvas up to LDS-atomic order (1 ULP ties)
+    batch.render(out, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
+    again = out.download((size, size, 4), np.float32)
+    diff = np.abs(full.astype(np.float64) - again)
+    assert (diff > 0).mean() < 1e-6 and diff.max() < 2e-7
+    # sharding-invariant: rank 1 of 4 (strips of 16 bands) reproduces its rows of the full canvas
+    tr = _abi.tile_rows()
+    batch.set_bands(1, 4, 16)
+    batch.plan()
+    part = ctx.alloc(batch.owned_rows() * size * 16)
+    batch.render(part, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
+    part = part.download((batch.owned_rows(), size, 4), np.float32)
+    for k, (r0, r1) in enumerate(sdist.owned_row_ranges(size, tr, 1, 4, 16)):
+        d = np.abs(part[k * tr: k * tr + (r1 - r0)].astype(np.float64) - full[r0:r1])
+        assert d.max() < 2e-7 and (d > 0).mean() < 1e-5
+    # a window of the canvas against the CPU oracle (the reference's own viewport mechanism)
+    r0, c0, hh, ww = 1800, 2100, 160, 224
+    ref, _, _ = orc.render_solid(synth.presentation_segs(sc), sc["seg_kind"], sc["path_seg_off"], sc["path_rule"],
+                                 sc["path_paint"], (r0, c0, hh, ww), clip01=True)
+    assert_f32_1ulp(full[r0:r0 + hh, c0:c0 + ww], ref, what="synth4096 window vs oracle")
