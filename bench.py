@@ -51,14 +51,14 @@ def load_workload(name: str):
         tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
         leaves = scene.leaves(tr, linear_rgb=False)
         segs, kinds, offs = [], [], [0]
-        for path, _m6, _rule, _paint in leaves:
+        for path, _m6, _rule, _paint, _flags in leaves:
             s, k = path.packed()
             segs.append(s)
             kinds.append(k)
             offs.append(offs[-1] + len(s))
         h, w = info["size"]
         sc = dict(segs=np.concatenate(segs), seg_kind=np.concatenate(kinds), path_seg_off=np.array(offs, dtype=np.int64),
-                  path_m6=np.array([l[1] for l in leaves]), path_rule=np.array([l[2] for l in leaves], dtype=np.uint8),
+                  path_m6=np.array([l[1] for l in leaves]), path_rule=np.array([l[2] | (l[4] << 1) for l in leaves], dtype=np.uint8),
                   path_paint=np.array([l[3] for l in leaves]), viewport=(0, 0, h, w))
         return sc, "Ghostscript tiger (scene dump, 182 solid fills incl. pre-stroked outlines) @ 2048x2048"
     raise SystemExit(f"unknown workload {name}")

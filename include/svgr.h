@@ -52,6 +52,10 @@ typedef struct svgr_batch svgr_batch;
 /* fill rules (S:874-875, S:984-989) */
 #define SVGR_FILL_NONZERO 0
 #define SVGR_FILL_EVENODD 1
+/* optional flags or-ed into path_rule (canvas outputs only): a CLIP node whose clip and target are single paths
+ * (Scene.render RENDER_CLIP, S:698-715: `Layer.compose([mask, image], COMPOSE_IN)`) is two consecutive paths:   */
+#define SVGR_PATH_CLIP_SOURCE 2 /* coverage only (Path.mask of the clip path); not painted                        */
+#define SVGR_PATH_CLIPPED 4     /* fill multiplied by the coverage of the PREVIOUS path, which must be a clip source */
 
 /* output kinds of svgr_batch_render */
 #define SVGR_OUT_CANVAS_F32 0  /* (rows, cols, 4) float32, all paths composited OVER in paint order */
@@ -105,7 +109,7 @@ typedef struct {
     const int64_t* path_seg_off; /* n_paths + 1 offsets into segs, paint order                    */
     int64_t n_paths;
     const double* path_m6;       /* n_paths x 6: rows 0-1 of the 3x3 transform {m00,m01,m02,m10,m11,m12} */
-    const uint8_t* path_rule;    /* n_paths: SVGR_FILL_*                                          */
+    const uint8_t* path_rule;    /* n_paths: SVGR_FILL_* | SVGR_PATH_* flags                       */
     const double* path_paint;    /* n_paths x 4 premultiplied RGBA already in the compositing space
                                     (the host applies S:1015-1018 to the 4-vector), times opacity   */
     int64_t viewport[4];         /* {row0, col0, rows, cols}; rows <= 0 means "no viewport"

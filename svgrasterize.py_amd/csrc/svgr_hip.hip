@@ -522,8 +522,9 @@ __global__ __launch_bounds__(1024) void k_alloc(const int* __restrict__ cnt, int
             PairHeader h;
             h.paint[0] = path_paint[4 * (size_t)p]; h.paint[1] = path_paint[4 * (size_t)p + 1];
             h.paint[2] = path_paint[4 * (size_t)p + 2]; h.paint[3] = path_paint[4 * (size_t)p + 3];
-            h.rule = path_rule[p];
-            h.pad[0] = h.pad[1] = h.pad[2] = 0;
+            h.rule = path_rule[p] & 1;
+            h.pad[0] = path_rule[p] >> 1;  // SVGR_PATH_* flags
+            h.pad[1] = h.pad[2] = 0;
             *(PairHeader*)(recs + o) = h;
         }
     }
@@ -683,7 +684,9 @@ struct TileArgs {
 };
 
 // OUT: 0 = canvas f32, 1 = canvas f64, 2 = mask f64 (single path), 3 = fill f64 (single path)
-template <int OUT>
+// CLIP: the batch contains SVGR_PATH_CLIP_SOURCE / SVGR_PATH_CLIPPED paths (one more LDS tile: its own instantiation,
+// so that batches without clips keep their occupancy)
+template <int OUT, bool CLIP = false>
 __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
     // ONE __shared__ object, carved by hand: with a second object beside the LDS-DMA staging area
     // hipcc (ROCm 7.2) drains vmcnt(0) before every ds_read and the record prefetch stops overlapping
@@ -694,7 +697,8 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
     constexpr int OFF_SEG0 = OFF_LIST + NT * 4;                        // int[NT]: first record of the (path, band) pair
     constexpr int OFF_SEG1 = OFF_SEG0 + NT * 4;                        // int[NT]: one past the last
     constexpr int OFF_WCNT = OFF_SEG1 + NT * 4;                        // int[NW]
-    constexpr int LDS_BYTES = OFF_WCNT + 16 * 4;
+    constexpr int OFF_CLIP = OFF_WCNT + 16 * 4;                        // canvas modes: coverage tile of a clip path
+    constexpr int LDS_BYTES = OFF_CLIP + (CLIP ? TR * ROW_STRIDE * 8 : 16);
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[LDS_BYTES];
     double* const s_trace = (double*)(s_mem + OFF_TRACE);
     int4* const s_bbox = (int4*)(s_mem + OFF_BBOX);
@@ -702,6 +706,8 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
     int* const s_seg0 = (int*)(s_mem + OFF_SEG0);
     int* const s_seg1 = (int*)(s_mem + OFF_SEG1);
     int* const s_wcnt = (int*)(s_mem + OFF_WCNT);
+    double* const s_clip = (double*)(s_mem + OFF_CLIP);
+    int clip_tag = -1;  // path whose coverage s_clip holds (canvas modes)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int trow = tid / CH, chunk = tid % CH;
@@ -791,7 +797,7 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
         issue_next();
 
         // per-path state, set when the first window of the path is reached
-        int row_shift = 0, rows = 0, col_shift = 0, lo_c = 0, hi_c = 0, rule = 0, n_slots = 0;
+        int row_shift = 0, rows = 0, col_shift = 0, lo_c = 0, hi_c = 0, rule = 0, n_slots = 0, pflags = 0, pid = 0;
         double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
         int li = 0;
         constexpr int win = 0;
@@ -824,6 +830,8 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
                 hi_c = cols < tile_c1 - c0 ? cols : tile_c1 - c0;  // one past the last
                 p0 = blk[0]; p1 = blk[1]; p2 = blk[2]; p3 = blk[3];  // header slot: paint, rule
                 rule = *(const int*)(blk + 4);
+                pflags = *((const int*)(blk + 4) + 1);
+                pid = s_list[li];
             }
 
             // ---- scatter: one lane per edge-row record; the pieces were computed by k_edge_emit, here
@@ -906,10 +914,16 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
             // A wave owns 4 tile rows; skip the phase when the layer has no row among them (its
             // delta rows are untouched, so there is nothing to read, zero or composite).
             const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * (64 / CH);
+            const bool is_clip_src = CLIP && (pflags & 1);   // coverage only: becomes the clip of the next path
+            const bool is_clipped = CLIP && (pflags & 2);    // multiplied by the coverage of the previous path
+            if (is_clip_src) clip_tag = pid;
+            // a clipped path whose clip did not reach this tile is invisible here (empty intersection, S:403-404),
+            // but its delta rows still have to be read back to zero
+            const bool clip_missing = is_clipped && clip_tag != pid - 1;
 #ifdef SVGR_DBG_NOSCAN
             if (false) {
 #else
-            if (wrow0 + (64 / CH) > row_shift && wrow0 < row_shift + rows) {
+            if (is_clip_src || (wrow0 + (64 / CH) > row_shift && wrow0 < row_shift + rows)) {
 #endif
                 double* my = s_trace + trow * ROW_STRIDE + chunk * CHUNK_STRIDE;
                 double t[PX];
@@ -930,13 +944,27 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
                 if (OUT <= 1) {
                     // Canvas: no bounds tests.  Left of / above / below the layer the delta tile is zero and so
                     // is the running sum; right of the layer it is NaN (sentinel above) or outside the viewport.
+                    double* const myclip = s_clip + trow * ROW_STRIDE + chunk * CHUNK_STRIDE;
+                    // One loop for the three kinds of path (three unrolled copies cost 60 VGPRs and an occupancy step):
+                    //   plain      dst = src OVER dst,  src = mask * paint
+                    //   clip src   Path.mask of a clip path (S:707): keep its coverage (after the 1e-6 cut) for the next path
+                    //   clipped    CLIP: (mask * paint) * clip_alpha on the intersection (S:712, S:290), then OVER
 #pragma unroll
                     for (int i = 0; i < PX; ++i) {
                         run += t[i];
                         const double mval = rule ? fill_evenodd_raw(run) : fill_nonzero_raw(run);
-                        if (mval >= kZeroCut) {
-                            if (OUT == 0) over_px_fma(acc[i], mval * p0, mval * p1, mval * p2, mval * p3);
-                            else over_px(acc[i], mval * p0, mval * p1, mval * p2, mval * p3);
+                        const bool vis = mval >= kZeroCut;
+                        if (is_clip_src) {
+                            myclip[i] = vis ? mval : 0.0;
+                        } else if (vis) {
+                            double s0 = mval * p0, s1 = mval * p1, s2 = mval * p2, s3 = mval * p3;
+                            if (is_clipped) {
+                                const double c = clip_missing ? 0.0 : myclip[i];
+                                if (c == 0.0) continue;
+                                s0 = s0 * c; s1 = s1 * c; s2 = s2 * c; s3 = s3 * c;
+                            }
+                            if (OUT == 0) over_px_fma(acc[i], s0, s1, s2, s3);
+                            else over_px(acc[i], s0, s1, s2, s3);
                         }
                     }
                 } else {
@@ -1238,6 +1266,7 @@ struct svgr_batch {
     double thr = 0.16000000000000003;
     Owner own{0, 1, 1};
     bool planned = false;
+    bool has_clips = false;    // any SVGR_PATH_CLIP_SOURCE / SVGR_PATH_CLIPPED path
     // inputs
     DevArr<double> segs, path_m6, path_paint;
     DevArr<uint8_t> seg_kind, path_rule;
@@ -1500,7 +1529,9 @@ int svgr_batch_create(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch** out)
         return fail(SVGR_E_INVALID, "NULL array in batch description");
     for (int64_t p = 0; p < d->n_paths; ++p) {
         if (d->path_seg_off[p] > d->path_seg_off[p + 1]) return fail(SVGR_E_INVALID, "path_seg_off not monotone at %lld", (long long)p);
-        if (d->path_rule[p] > 1) return fail(SVGR_E_INVALID, "Invalid fill rule: %d", (int)d->path_rule[p]);  // S:989
+        if (d->path_rule[p] > 7) return fail(SVGR_E_INVALID, "Invalid fill rule: %d", (int)d->path_rule[p]);  // S:989
+        if ((d->path_rule[p] & SVGR_PATH_CLIPPED) && (p == 0 || !(d->path_rule[p - 1] & SVGR_PATH_CLIP_SOURCE)))
+            return fail(SVGR_E_INVALID, "path %lld is marked clipped but path %lld is not a clip source", (long long)p, (long long)p - 1);
     }
     if (d->path_seg_off[0] != 0 || d->path_seg_off[d->n_paths] != d->n_segs) return fail(SVGR_E_INVALID, "path_seg_off does not span segs");
     for (int64_t s = 0; s < d->n_segs; ++s) {
@@ -1525,6 +1556,7 @@ int svgr_batch_create(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch** out)
     b->has_vp = d->viewport[2] > 0;
     for (int i = 0; i < 4; ++i) b->vp[i] = b->has_vp ? (int)d->viewport[i] : 0;
     b->thr = (d->flatness * d->flatness) * 16.0;  // S:2093
+    for (int64_t p = 0; p < d->n_paths; ++p) b->has_clips = b->has_clips || (d->path_rule[p] & (SVGR_PATH_CLIP_SOURCE | SVGR_PATH_CLIPPED));
     const size_t ns = (size_t)d->n_segs, np = (size_t)d->n_paths;
     int rc = 0;
     std::vector<int> seg_path(ns);
@@ -1758,8 +1790,14 @@ int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags
 #endif
         dim3 grid((unsigned)n_ctiles, (unsigned)owned_bands);
         switch (out_kind) {
-            case 0: hipLaunchKernelGGL(k_tile_render<0>, grid, dim3(NT), 0, st, a); break;
-            case 1: hipLaunchKernelGGL(k_tile_render<1>, grid, dim3(NT), 0, st, a); break;
+            case 0:
+                if (b->has_clips) hipLaunchKernelGGL((k_tile_render<0, true>), grid, dim3(NT), 0, st, a);
+                else hipLaunchKernelGGL((k_tile_render<0, false>), grid, dim3(NT), 0, st, a);
+                break;
+            case 1:
+                if (b->has_clips) hipLaunchKernelGGL((k_tile_render<1, true>), grid, dim3(NT), 0, st, a);
+                else hipLaunchKernelGGL((k_tile_render<1, false>), grid, dim3(NT), 0, st, a);
+                break;
             case 2: hipLaunchKernelGGL(k_tile_render<2>, grid, dim3(NT), 0, st, a); break;
             default: hipLaunchKernelGGL(k_tile_render<3>, grid, dim3(NT), 0, st, a); break;
         }

@@ -4,7 +4,7 @@ Same node types, constructors and ``render`` signature as the reference.  ``rend
 routes, both of them HIP:
 
 * batched: a maximal run of solid-colour FILL leaves (under GROUP / TRANSFORM nodes, optionally
-  one OPACITY directly above a leaf) is handed to the device as ONE paint-ordered batch
+  one OPACITY directly above a leaf, or a CLIP whose clip and target are single paths) is handed to the device as ONE paint-ordered batch
   (``svgr_batch_render``) that flattens, bins and composites all of them in a single tile kernel.
   This is what SURVEY 7-5 asks for: per-path launches cannot win.
 * per node: everything else (CLIP, OPACITY over a group, nested results) is rendered node by node
@@ -179,7 +179,7 @@ def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opac
         p4 = solid_paint(paint, linear_rgb)
         if opacity is not None:
             p4 = p4 * opacity  # Layer.opacity: image * opacity (S:174)
-        return [(path, transform.m6(), _RULES[rule], p4)]
+        return [(path, transform.m6(), _RULES[rule], p4, 0)]
     if kind == RENDER_TRANSFORM:
         return _batchable_leaves(args[0], transform @ args[1], linear_rgb, opacity)
     if kind == RENDER_OPACITY and opacity is None:
@@ -189,6 +189,16 @@ def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opac
         if target[0] == RENDER_FILL:  # opacity over a single leaf commutes with the fill
             return _batchable_leaves(args[0], transform, linear_rgb, args[1])
         return None
+    if kind == RENDER_CLIP and opacity is None and not args[2]:
+        # CLIP whose target and clip are single paths: two consecutive batch entries, the clip path as a
+        # coverage-only "clip source" and the fill multiplied by it (Layer.compose([mask, image], IN), S:698-715).
+        # (A group under a clip is NOT the same as clipping each child: (A over B)*c != (A*c) over (B*c).)
+        target = _batchable_leaves(args[0], transform, linear_rgb)
+        clip_leaf = _single_mask_leaf(args[1], transform)
+        if target is None or clip_leaf is None or len(target) != 1 or target[0][4] != 0:
+            return None
+        t = target[0]
+        return [clip_leaf, (t[0], t[1], t[2], t[3], 2)]
     if kind == RENDER_GROUP and opacity is None:
         out = []
         for child in args:
@@ -200,17 +210,57 @@ def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opac
     return None
 
 
+def _single_mask_leaf(scene: Scene, transform: Transform):
+    """(path, m6, rule, zeros, 1) when `scene` rendered mask_only is ONE Path.mask (a FILL under transforms)."""
+    kind, args = scene
+    while kind == RENDER_TRANSFORM:
+        transform = transform @ args[1]
+        kind, args = args[0]
+    if kind != RENDER_FILL:
+        return None
+    path, _paint, rule = args
+    if rule not in _RULES:
+        raise ValueError(f"Invalid fill rule: {rule}")
+    return (path, transform.m6(), _RULES[rule], np.zeros(4), 1)
+
+
+def effective_bboxes(leaves, bboxes):
+    """Per painted leaf the bbox its layer would have in the reference: its own clipped bbox, or for a clipped
+    fill the intersection with its clip's bbox (canvas_merge_intersect, S:392-404).  None = nothing to draw."""
+    out = []
+    for i, leaf in enumerate(leaves):
+        flags = leaf[4]
+        if flags == 1:
+            continue
+        r0, c0, rows, cols = (int(v) for v in bboxes[i])
+        if rows <= 0 or cols <= 0:
+            out.append(None)
+            continue
+        r1, c1 = r0 + rows, c0 + cols
+        if flags == 2:
+            q0, d0, qr, qc = (int(v) for v in bboxes[i - 1])
+            if qr <= 0 or qc <= 0:
+                out.append(None)
+                continue
+            r0, c0, r1, c1 = max(r0, q0), max(c0, d0), min(r1, q0 + qr), min(c1, d0 + qc)
+            if r0 >= r1 or c0 >= c1:
+                out.append(None)
+                continue
+        out.append((r0, c0, r1 - r0, c1 - c0))
+    return out
+
+
 def build_batch(leaves, viewport, ctx=None) -> "_abi.Batch":
     """Pack paint-ordered leaves [(path, m6, rule, paint4)] into one device batch."""
     ctx = ctx or _abi.Context.get()
     segs, kinds, offs, m6s, rules, paints = [], [], [0], [], [], []
-    for path, m6, rule, paint in leaves:
+    for path, m6, rule, paint, flags in leaves:
         s, k = path.packed()
         segs.append(s)
         kinds.append(k)
         offs.append(offs[-1] + len(s))
         m6s.append(m6)
-        rules.append(rule)
+        rules.append(rule | (flags << 1))  # SVGR_PATH_CLIP_SOURCE = 2, SVGR_PATH_CLIPPED = 4
         paints.append(paint)
     segs = np.concatenate(segs) if segs else np.zeros((0, 8))
     kinds = np.concatenate(kinds) if kinds else np.zeros(0, dtype=np.uint8)
@@ -221,18 +271,21 @@ def build_batch(leaves, viewport, ctx=None) -> "_abi.Batch":
 def _render_run(leaves, viewport, linear_rgb):
     """One batch -> one Layer covering the union of the leaves' bboxes (what Layer.compose of
     the individual fill layers returns, S:366-379)."""
-    leaves = [l for l in leaves if len(l[0].packed()[0])]
+    leaves = _drop_empty(leaves)
     if not leaves:
         return None
     ctx = _abi.Context.get()
     batch = build_batch(leaves, viewport, ctx)
     st = batch.plan()
-    if st.n_nonempty == 0:
+    boxes = [b for b in effective_bboxes(leaves, batch.bboxes()) if b is not None]
+    if not boxes:
         batch.destroy()
         return None
-    ur0, uc0, urows, ucols = (int(v) for v in st.bbox_union)
+    ur0, uc0 = min(b[0] for b in boxes), min(b[1] for b in boxes)
+    urows = max(b[0] + b[2] for b in boxes) - ur0
+    ucols = max(b[1] + b[3] for b in boxes) - uc0
     if viewport is None:
-        vp = (ur0, uc0, urows, ucols)
+        vp = tuple(int(v) for v in st.bbox_union)  # the canvas the batch planned for (covers the clip paths too)
     else:
         vp = tuple(int(v) for v in viewport)
     canvas = ctx.alloc(vp[2] * vp[3] * 32)
@@ -248,8 +301,30 @@ def _render_run(leaves, viewport, linear_rgb):
     else:
         out = canvas
     layer = Layer._from_device(out, shape, (ur0, uc0), True, linear_rgb)
-    hull = ConvexHull(_source=lambda: batch.edges()[0])
-    return layer, hull
+    painted = np.array([leaf[4] != 1 for leaf in leaves])
+
+    def hull_points():
+        edges, edge_path = batch.edges()
+        return edges[painted[edge_path]]  # the clip paths do not belong to the hull (S:715 returns the target's)
+
+    return layer, ConvexHull(_source=hull_points)
+
+
+def _drop_empty(leaves):
+    """Remove leaves without segments; a clipped fill goes together with its clip source and vice versa."""
+    out, i = [], 0
+    while i < len(leaves):
+        leaf = leaves[i]
+        if leaf[4] == 1:  # clip source + its target
+            pair = leaves[i:i + 2]
+            if all(len(l[0].packed()[0]) for l in pair):
+                out.extend(pair)
+            i += 2
+            continue
+        if len(leaf[0].packed()[0]):
+            out.append(leaf)
+        i += 1
+    return out
 
 
 def render_canvas(scene_or_leaves, transform: Transform | None, viewport, linear_rgb: bool = False,
