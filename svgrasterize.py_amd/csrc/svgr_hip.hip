@@ -114,6 +114,83 @@ struct svgr_buf {
     bool owned = false;
 };
 
+// ======================================================================================
+// device memory: a small size-class cache in front of hipMalloc / hipFree.  The per-node route
+// creates thousands of short-lived buffers (one batch per path, one image per layer); hipMalloc /
+// hipFree cost ~100 us each and hipFree synchronises the device.  Every kernel and copy of this
+// library runs on the context stream and calls are serialised by the caller, so a block can be
+// handed out again as soon as it has been returned: stream order keeps its users apart.
+// ======================================================================================
+#include <map>
+#include <mutex>
+namespace {
+struct DevPool {
+    std::mutex mu;
+    std::map<int, std::multimap<size_t, void*>> free_by_dev;  // per device, by capacity
+    std::map<void*, std::pair<size_t, int>> cap_of;           // capacity and device of every block handed out or cached
+    size_t cached_bytes = 0;
+    static constexpr size_t kMaxCached = 8ull << 30;
+
+    static size_t size_class(size_t n) {
+        size_t c = 256;
+        while (c < n) c += c < (1u << 20) ? c : c / 4;  // x2 up to 1 MiB, then +25 %
+        return c;
+    }
+    hipError_t alloc(void** out, size_t bytes) {
+        const size_t c = size_class(bytes ? bytes : 1);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto& free_blocks = free_by_dev[dev];
+            auto it = free_blocks.lower_bound(c);
+            if (it != free_blocks.end() && it->first <= c + c / 2) {
+                *out = it->second;
+                cached_bytes -= it->first;
+                free_blocks.erase(it);
+                return hipSuccess;
+            }
+        }
+        hipError_t e = hipMalloc(out, c);
+        if (e != hipSuccess) {  // give the cache back to the driver and retry once
+            trim();
+            e = hipMalloc(out, c);
+        }
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> lk(mu);
+            cap_of[*out] = {c, dev};
+        }
+        return e;
+    }
+    void release(void* p) {
+        if (!p) return;
+        std::unique_lock<std::mutex> lk(mu);
+        auto it = cap_of.find(p);
+        if (it == cap_of.end()) { lk.unlock(); (void)hipFree(p); return; }
+        if (cached_bytes + it->second.first > kMaxCached) {
+            cap_of.erase(it);
+            lk.unlock();
+            (void)hipFree(p);
+            return;
+        }
+        free_by_dev[it->second.second].emplace(it->second.first, p);
+        cached_bytes += it->second.first;
+    }
+    void trim() {
+        std::vector<void*> blocks;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto& d : free_by_dev)
+                for (auto& b : d.second) { blocks.push_back(b.second); cap_of.erase(b.second); }
+            free_by_dev.clear();
+            cached_bytes = 0;
+        }
+        for (void* b : blocks) (void)hipFree(b);
+    }
+};
+DevPool g_pool;
+}  // namespace
+
 // small RAII-less device array helper (explicit release keeps the ABI exception free)
 template <class T>
 struct DevArr {
@@ -121,17 +198,17 @@ struct DevArr {
     size_t cap = 0;  // elements
     int ensure(size_t n) {
         if (n <= cap) return 0;
-        if (p) (void)hipFree(p);
+        if (p) g_pool.release(p);
         p = nullptr;
         cap = 0;
         size_t want = n + n / 8 + 16;
-        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        hipError_t e = g_pool.alloc((void**)&p, want * sizeof(T));
         if (e != hipSuccess) return fail(SVGR_E_NOMEM, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
         cap = want;
         return 0;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) g_pool.release(p);
         p = nullptr;
         cap = 0;
     }
@@ -1418,6 +1495,7 @@ int svgr_shutdown(svgr_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    g_pool.trim();
     delete ctx;
     return 0;
 }
@@ -1452,7 +1530,7 @@ int svgr_buf_alloc(svgr_ctx* ctx, size_t bytes, svgr_buf** out) {
     svgr_buf* b = new (std::nothrow) svgr_buf();
     if (!b) return fail(SVGR_E_NOMEM, "out of host memory");
     HIPCHK(hipSetDevice(ctx->device));
-    hipError_t e = hipMalloc(&b->ptr, bytes ? bytes : 16);
+    hipError_t e = g_pool.alloc(&b->ptr, bytes ? bytes : 16);
     if (e != hipSuccess) { delete b; return fail(SVGR_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
     b->bytes = bytes;
     b->owned = true;
@@ -1473,10 +1551,8 @@ int svgr_buf_wrap(svgr_ctx* ctx, void* device_ptr, size_t bytes, svgr_buf** out)
 
 int svgr_buf_free(svgr_ctx* ctx, svgr_buf* buf) {
     if (!buf) return 0;
-    if (buf->owned && buf->ptr) {
-        if (ctx) (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(buf->ptr);
-    }
+    (void)ctx;
+    if (buf->owned && buf->ptr) g_pool.release(buf->ptr);  // stream order protects the next user of the block
     delete buf;
     return 0;
 }
@@ -1924,7 +2000,7 @@ int svgr_gradient_fill(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* ma
     HIPCHK(hipSetDevice(ctx->device));
     // parameter block + det<0 flag live in one small device allocation for the duration of the call
     char* dev = nullptr;
-    HIPCHK(hipMalloc((void**)&dev, sizeof(GradDev) + 16));
+    HIPCHK(g_pool.alloc((void**)&dev, sizeof(GradDev) + 16));
     hipError_t e = hipMemcpyAsync(dev, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(dev + sizeof(GradDev), 0, 16, ctx->stream);
     if (e == hipSuccess) {
@@ -1938,7 +2014,7 @@ int svgr_gradient_fill(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* ma
         e = hipStreamSynchronize(ctx->stream);  // `h` and `dev` are call-local
         if (e == hipSuccess) e = hipGetLastError();
     }
-    (void)hipFree(dev);
+    g_pool.release(dev);
     if (e != hipSuccess) return fail(SVGR_E_HIP, "svgr_gradient_fill: %s", hipGetErrorString(e));
     return 0;
 }
@@ -1952,7 +2028,7 @@ int svgr_layer_convolve(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64
     if (src->bytes < (size_t)rows * cols * 32 || out->bytes < n_out * 32) return fail(SVGR_E_INVALID, "svgr_layer_convolve: buffer too small");
     HIPCHK(hipSetDevice(ctx->device));
     double* dk = nullptr;
-    HIPCHK(hipMalloc((void**)&dk, sizeof(double) * (size_t)kw * kh));
+    HIPCHK(g_pool.alloc((void**)&dk, sizeof(double) * (size_t)kw * kh));
     hipError_t e = hipMemcpyAsync(dk, kernel, sizeof(double) * (size_t)kw * kh, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_layer_convolve, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)src->ptr,
@@ -1960,7 +2036,7 @@ int svgr_layer_convolve(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64
         e = hipStreamSynchronize(ctx->stream);
         if (e == hipSuccess) e = hipGetLastError();
     }
-    (void)hipFree(dk);
+    g_pool.release(dk);
     if (e != hipSuccess) return fail(SVGR_E_HIP, "svgr_layer_convolve: %s", hipGetErrorString(e));
     return 0;
 }
