@@ -58,7 +58,11 @@ constexpr int ROW_STRIDE = CH * CHUNK_STRIDE;
 static_assert(CH == 16, "row scan uses one 16-lane DPP row per tile row");
 constexpr int PREF_WAVES = NT / 64 < 3 ? NT / 64 : 3;   // waves that issue the LDS-DMA of a record block (1 KiB each)
 constexpr int PREF_BYTES = PREF_WAVES * 1024;
-constexpr int PREF_RECS = PREF_BYTES / 48;              // slots per prefetch block (64 for a 256-thread workgroup)
+#ifndef SVGR_REC_BYTES
+#define SVGR_REC_BYTES 48
+#endif
+constexpr int REC_BYTES = SVGR_REC_BYTES;             // 48, or 64 = one full HBM sector per record
+constexpr int PREF_RECS = PREF_BYTES / REC_BYTES;              // slots per prefetch block (64 for a 256-thread workgroup)
 constexpr int PREF_DEPTH = 3;                           // blocks in flight: paths li, li+1, li+2
 constexpr int NW = NT / 64;                // waves per workgroup; a wave covers 4 tile rows
 static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 1024 threads");
@@ -70,15 +74,21 @@ struct RowRec {
     int x0i;        // unclamped layer column of the first piece
     unsigned nrow;  // bits 0-25: n = x1i - x0i (see svgr_core.h RowPieces), bits 26-31: row inside the band
     double v[5];
+#if SVGR_REC_BYTES == 64
+    double pad[2];
+#endif
 };
-static_assert(sizeof(RowRec) == 48, "RowRec must stay 48 bytes");
+static_assert(sizeof(RowRec) == REC_BYTES, "RowRec size");
 // Every (path, band) pair's block starts with one header slot of the same size: the path's paint and
 // fill rule, so that the tile kernel gets them from the same LDS-DMA block as the records.
 struct PairHeader {
     double paint[4];
     int rule, pad[3];
+#if SVGR_REC_BYTES == 64
+    double pad2[2];
+#endif
 };
-static_assert(sizeof(PairHeader) == 48, "PairHeader occupies one record slot");
+static_assert(sizeof(PairHeader) == REC_BYTES, "PairHeader occupies one record slot");
 constexpr int PREF_RECS_MAX = 85;      // records per 4 KiB prefetch block (the workgroup may be smaller: see PREF_RECS)
 constexpr unsigned SPAN_MAX = (1u << 26) - 1;
 static_assert(SVGR_TR <= 64, "row-in-band is stored in 6 bits");
@@ -850,7 +860,7 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
         auto issue = [&](int li_, int win_, int buf_) {
             if (wave < PREF_WAVES) {
                 const int left_ = s_seg1[li_] - s_seg0[li_] - win_;
-                const int n_bytes = (left_ < PREF_RECS ? left_ : PREF_RECS) * 48;
+                const int n_bytes = (left_ < PREF_RECS ? left_ : PREF_RECS) * REC_BYTES;
                 const int off_ = tid * 16 < n_bytes ? tid * 16 : n_bytes - 16;
                 const char* g = (const char*)(a.bsegs + s_seg0[li_] + win_) + off_;
                 const unsigned lds_base = __builtin_amdgcn_readfirstlane(
@@ -924,7 +934,7 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
                     unsigned nrow;
                     double v[5];
                     if (sl < PREF_RECS) {
-                        const double* q = blk + sl * 6;
+                        const double* q = blk + sl * (REC_BYTES / 8);
                         const int2 hd = *(const int2*)q;
                         x0i = hd.x; nrow = (unsigned)hd.y;
                         v[0] = q[1]; v[1] = q[2]; v[2] = q[3]; v[3] = q[4]; v[4] = q[5];

@@ -1,0 +1,103 @@
+"""Edge cases of the hot path on the GPU: the situations the reference answers with None / ValueError, and
+inputs at the limits of the batch ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import svgrasterize_amd as S
+
+    S.Context.get()
+    return S
+
+
+def test_empty_and_degenerate_paths(S):
+    tr = S.Transform()
+    assert S.Path([]).mask(tr) is None                                   # no subpaths (S:958-959)
+    assert S.Path([[]]).mask(tr) is None                                 # an empty subpath is skipped (S:933-934)
+    assert S.Path.from_svg("M1,1 H9").mask(tr, viewport=[50, 50, 4, 4]) is None   # clipped away (S:974-975)
+    # a horizontal line has a bbox but no coverage: the reference returns an all-zero mask, not None
+    layer, _ = S.Path.from_svg("M1,1 H9").mask(tr)
+    assert layer.image.shape[2] == 1 and not layer.image.any()
+    # zero-area closed path
+    layer, _ = S.Path.from_svg("M2,2 L6,6 L2,2 Z").mask(tr)
+    assert np.abs(layer.image).max() < 1e-12
+    # a single point repeated as a cubic
+    layer, _ = S.Path.from_svg("M3,3 C3,3 3,3 3,3 Z").mask(tr)
+    assert not layer.image.any()
+
+
+def test_fill_none_paint_and_unknown_paint(S):
+    p = S.Path.from_svg("M1,1 H9 V9 H1 Z")
+    assert p.fill(S.Transform(), None) is None                           # S:1004-1005
+    with pytest.warns(UserWarning):
+        assert p.fill(S.Transform(), "not a paint") is None              # S:1100-1101
+
+
+def test_invalid_inputs_raise_value_error(S):
+    from svgrasterize_amd import _abi
+
+    p = S.Path.from_svg("M1,1 H9 V9 H1 Z")
+    with pytest.raises(ValueError):
+        p.mask(S.Transform(), fill_rule="winding")                       # S:989
+    with pytest.raises(ValueError):
+        S.Path([[(9, np.zeros((2, 2)))]]).mask(S.Transform())            # S:945 unsupported path type
+    bad = S.Path.from_svg("M1,1 H9 V9 H1 Z")
+    bad.subpaths[0][0][1][0, 0] = np.nan
+    with pytest.raises(ValueError):
+        bad.mask(S.Transform())                                          # the reference would never terminate
+    with pytest.raises(ValueError):
+        S.Layer.compose([S.Layer(np.zeros((2, 2, 4)), (0, 0), True, False)] * 2, method=17)   # S:298
+    ctx = S.Context.get()
+    with pytest.raises(ValueError):   # a multi-path batch without a viewport is fine, a zero-path batch is not
+        _abi.Batch(ctx, np.zeros((0, 8)), np.zeros(0, np.uint8), [0], np.zeros((0, 6)), [], np.zeros((0, 4)), viewport=[0, 0, 8, 8])
+    with pytest.raises(ValueError):   # clipped flag without a clip source in front
+        _abi.Batch(ctx, np.zeros((1, 8)), np.zeros(1, np.uint8), [0, 1], [[1, 0, 0, 0, 1, 0]], [4], [[0, 0, 0, 1]], viewport=[0, 0, 8, 8])
+
+
+def test_huge_unclipped_extent_is_refused_not_allocated(S):
+    p = S.Path.from_svg("M0,0 H3000000 V3000000 H0 Z")
+    with pytest.raises(ValueError):
+        p.mask(S.Transform())                      # 9e12 pixels: the reference would try to allocate them
+    layer, _ = p.mask(S.Transform(), viewport=[10, 10, 32, 48])
+    assert layer.image.shape == (32, 48, 1) and np.all(layer.image == 1.0)
+
+
+def test_ragged_batch_with_empty_and_offscreen_paths(S):
+    """Paths without segments, paths outside the viewport and a path covering everything, in one batch."""
+    from svgrasterize_amd import _abi
+    from oracle import oracle as orc
+
+    rect = lambda x0, y0, x1, y1: np.array([[x0, y0, x1, y0, 0, 0, 0, 0], [x1, y0, x1, y1, 0, 0, 0, 0],
+                                            [x1, y1, x0, y1, 0, 0, 0, 0], [x0, y1, x0, y0, 0, 0, 0, 0]], dtype=np.float64)
+    segs = np.concatenate([rect(-50, -50, 500, 500), rect(1000, 1000, 1100, 1100), rect(10.25, 20.5, 90.75, 70.125)])
+    off = [0, 4, 4, 8, 8, 12]            # path 1 and path 3 have no segments
+    ident = np.tile([1.0, 0, 0, 0, 1, 0], (5, 1))
+    paints = np.array([[0.1, 0.2, 0.3, 0.5], [1, 1, 1, 1], [1, 0, 0, 1], [0, 1, 0, 1], [0.2, 0.1, 0.05, 0.25]])
+    ctx = S.Context.get()
+    vp = (0, 0, 100, 130)
+    batch = _abi.Batch(ctx, segs, np.zeros(12, np.uint8), off, ident, [0, 0, 1, 0, 0], paints, viewport=vp)
+    st = batch.plan()
+    bb = batch.bboxes()
+    assert st.n_nonempty == 2 and (bb[1, 2] <= 0) and (bb[2, 2] <= 0 or bb[2, 3] <= 0) and (bb[3, 2] <= 0)
+    out = ctx.alloc(100 * 130 * 32)
+    batch.render(out, _abi.OUT_CANVAS_F64)
+    got = out.download((100, 130, 4), np.float64)
+    ref, P, _ = orc.render_solid(segs, np.zeros(12, np.uint8), np.array(off), np.array([0, 0, 1, 0, 0], np.uint8), paints, vp,
+                                 clip01=False)
+    assert st.path_pixels == P
+    assert np.abs(got - ref).max() < 1e-13
+
+
+def test_layer_image_is_mutable_after_download(S):
+    """font_speciment.py-style use: callers mutate mask.image in place; later ops must see it."""
+    p = S.Path.from_svg("M1,1 H9 V9 H1 Z")
+    layer, _ = p.fill(S.Transform(), np.array([0.5, 0.25, 0.125, 0.5]), linear_rgb=True)
+    img = layer.image
+    img[...] = 0.0
+    img[2, 2] = [0.1, 0.2, 0.3, 0.4]
+    out = S.Layer.compose([layer, S.Layer(np.zeros((1, 1, 4)), (0, 0), True, True)], S.COMPOSE_OVER, True)
+    assert np.array_equal(out.image[2 + int(layer.x), 2 + int(layer.y)], [0.1, 0.2, 0.3, 0.4])
