@@ -63,7 +63,11 @@ constexpr int PREF_BYTES = PREF_WAVES * 1024;
 #endif
 constexpr int REC_BYTES = SVGR_REC_BYTES;             // 48, or 64 = one full HBM sector per record
 constexpr int PREF_RECS = PREF_BYTES / REC_BYTES;              // slots per prefetch block (64 for a 256-thread workgroup)
-constexpr int PREF_DEPTH = 3;                           // blocks in flight: paths li, li+1, li+2
+#ifndef SVGR_PREF_DEPTH
+#define SVGR_PREF_DEPTH 3
+#endif
+constexpr int PREF_DEPTH = SVGR_PREF_DEPTH;             // record blocks in the ring: paths li, li+1[, li+2]
+constexpr int LCAP = 32;                                // compacted paths of a tile worked off per sub-batch
 constexpr int NW = NT / 64;                // waves per workgroup; a wave covers 4 tile rows
 static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 1024 threads");
 
@@ -678,20 +682,43 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
     }
 }
 
-// one workgroup per band: ascending list of the paths whose bbox rows cover the band
+// One tile-list entry: everything a tile needs to know about a (path, band) pair, so that the tile
+// kernel's compaction is ONE coalesced load per lane instead of a chain of four dependent gathers.
+struct TileEntry {
+    int p;            // path id
+    int c0, cols;     // layer columns (for the tile's column test)
+    int r0, rows;     // layer rows
+    int seg0, cnt;    // record block of the pair: first slot (the header), number of records
+    int pad;
+};
+static_assert(sizeof(TileEntry) == 32, "TileEntry is 32 bytes");
+
+// one workgroup per band: ascending list of the paths that have records in the band
 __global__ __launch_bounds__(256) void k_band_entries(const int* __restrict__ b0, const int* __restrict__ nb, int n_paths,
+                                                      const int* __restrict__ bbox, const int* __restrict__ pb_off,
+                                                      const int* __restrict__ pb_cnt, const int* __restrict__ bseg_off,
                                                       int* __restrict__ band_start, int* __restrict__ band_count,
-                                                      int* __restrict__ entries, int entry_cap, BatchDev* __restrict__ bd,
+                                                      TileEntry* __restrict__ entries, int entry_cap, BatchDev* __restrict__ bd,
                                                       Owner own) {
     __shared__ int s_wcnt[4];
     __shared__ int s_start, s_total;
     const int band = owned_band_at(own, blockIdx.x), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // pass 1: count
+    auto pair_cnt = [&](int p) -> int {  // records of path p in this band (0: bbox does not cover it / no edge crosses it)
+        const int f = b0[p], n = nb[p];
+        if (!(n > 0 && band >= f && band < f + n)) return 0;
+        return pb_cnt[pb_off[p] + band - f];
+    };
+    // pass 1: count (the first KEEP counts per lane are remembered for pass 2: they cost three gathers each)
+    constexpr int KEEP = 32;
+    int kept[KEEP];
     int mine = 0;
-    for (int p = tid; p < n_paths; p += 256) {
-        int f = b0[p], n = nb[p];
-        mine += (n > 0 && band >= f && band < f + n) ? 1 : 0;
+#pragma unroll
+    for (int it = 0; it < KEEP; ++it) {
+        const int p = it * 256 + tid;
+        kept[it] = p < n_paths ? pair_cnt(p) : 0;
+        mine += kept[it] > 0 ? 1 : 0;
     }
+    for (int p = KEEP * 256 + tid; p < n_paths; p += 256) mine += pair_cnt(p) > 0 ? 1 : 0;
     int wtot;
     wave_excl_scan(mine, lane, wtot);
     if (lane == 0) s_wcnt[wave] = wtot;
@@ -710,13 +737,9 @@ __global__ __launch_bounds__(256) void k_band_entries(const int* __restrict__ b0
     const bool enabled = s_total > 0;
     __syncthreads();
     // pass 2: fill in ascending path order
-    for (int base = 0; base < n_paths; base += 256) {
-        int p = base + tid;
-        bool hit = false;
-        if (p < n_paths) {
-            int f = b0[p], n = nb[p];
-            hit = n > 0 && band >= f && band < f + n;
-        }
+    auto fill = [&](int base, int cnt) {
+        const int p = base + tid;
+        const bool hit = cnt > 0;
         unsigned long long m = __ballot(hit);
         if (lane == 0) s_wcnt[wave] = __popcll(m);
         __syncthreads();
@@ -725,10 +748,22 @@ __global__ __launch_bounds__(256) void k_band_entries(const int* __restrict__ b0
             if (w < wave) off += s_wcnt[w];
             total += s_wcnt[w];
         }
-        if (hit && enabled) entries[run + off + __popcll(m & ((1ull << lane) - 1ull))] = p;
+        if (hit && enabled) {
+            const int4 bb = ((const int4*)bbox)[p];
+            TileEntry e;
+            e.p = p; e.c0 = bb.y; e.cols = bb.w; e.r0 = bb.x; e.rows = bb.z;
+            e.seg0 = bseg_off[pb_off[p] + band - b0[p]];
+            e.cnt = cnt;
+            e.pad = 0;
+            entries[run + off + __popcll(m & ((1ull << lane) - 1ull))] = e;
+        }
         run += total;
         __syncthreads();
-    }
+    };
+#pragma unroll
+    for (int it = 0; it < KEEP; ++it)
+        if (it * 256 < n_paths) fill(it * 256, kept[it]);
+    for (int base = KEEP * 256; base < n_paths; base += 256) fill(base, base + tid < n_paths ? pair_cnt(base + tid) : 0);
 }
 
 // ======================================================================================
@@ -752,7 +787,7 @@ __device__ __forceinline__ int lds_index(int trow, int tcol) {
 struct TileArgs {
     const int* band_start;     // per band: first entry, number of entries
     const int* band_count;
-    const int* entries;        // path ids per band, ascending
+    const TileEntry* entries;  // per band: the pairs with records, ascending path id
     const int* bbox;           // n_paths x 4
     const int* b0;             // first band of each path
     const int* pb_off;         // (path, band) pair offsets
@@ -780,10 +815,10 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
     constexpr int OFF_TRACE = 0;
     constexpr int OFF_PREF = OFF_TRACE + TR * ROW_STRIDE * 8;          // PREF_DEPTH record blocks (LDS-DMA targets)
     constexpr int OFF_BBOX = OFF_PREF + PREF_DEPTH * PREF_BYTES;       // int4[NT]: bboxes of the compacted paths
-    constexpr int OFF_LIST = OFF_BBOX + NT * 16;                       // int[NT]: their ids
-    constexpr int OFF_SEG0 = OFF_LIST + NT * 4;                        // int[NT]: first record of the (path, band) pair
-    constexpr int OFF_SEG1 = OFF_SEG0 + NT * 4;                        // int[NT]: one past the last
-    constexpr int OFF_WCNT = OFF_SEG1 + NT * 4;                        // int[NW]
+    constexpr int OFF_LIST = OFF_BBOX + LCAP * 16;                       // int[NT]: their ids
+    constexpr int OFF_SEG0 = OFF_LIST + LCAP * 4;                        // int[NT]: first record of the (path, band) pair
+    constexpr int OFF_SEG1 = OFF_SEG0 + LCAP * 4;                        // int[NT]: one past the last
+    constexpr int OFF_WCNT = OFF_SEG1 + LCAP * 4;                        // int[NW]
     constexpr int OFF_CLIP = OFF_WCNT + 16 * 4;                        // canvas modes: coverage tile of a clip path
     constexpr int LDS_BYTES = OFF_CLIP + (CLIP ? TR * ROW_STRIDE * 8 : 16);
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[LDS_BYTES];
@@ -806,6 +841,10 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
     double acc[PX][4];
 #pragma unroll
     for (int i = 0; i < PX; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0;
+#ifdef SVGR_DBG_STAMP
+    unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tstart_ = __builtin_amdgcn_s_memrealtime();
+#endif
 
     for (int i = tid; i < TR * ROW_STRIDE; i += NT) s_trace[i] = 0.0;
     __syncthreads();
@@ -817,31 +856,31 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
         int4 bb = make_int4(0, 0, 0, 0);
         bool hit = false;
         if (base + tid < ent_end) {
-            p_mine = a.entries[base + tid];
-            bb = ((const int4*)a.bbox)[p_mine];  // {r0, c0, rows, cols}
-            if (bb.y < tile_c1 && bb.y + bb.w > tile_c0) {
-                const int pb = a.pb_off[p_mine] + band - a.b0[p_mine];
-                const int cnt = a.pb_cnt[pb];
-                seg0 = a.bseg_off[pb];
-                seg1 = seg0 + cnt + 1;  // header slot + records
-                hit = cnt > 0;          // no edge crosses this band: coverage is zero everywhere in it
-            }
+            const TileEntry e = a.entries[base + tid];  // one coalesced 32-byte load per lane
+            p_mine = e.p;
+            bb = make_int4(e.r0, e.c0, e.rows, e.cols);
+            seg0 = e.seg0;
+            seg1 = seg0 + e.cnt + 1;  // header slot + records
+            hit = e.c0 < tile_c1 && e.c0 + e.cols > tile_c0;
         }
         unsigned long long m = __ballot(hit);
         if (lane == 0) s_wcnt[wave] = __popcll(m);
         __syncthreads();
-        int off = 0, total = 0;
+        int off = 0, total_all = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             if (w < wave) off += s_wcnt[w];
-            total += s_wcnt[w];
+            total_all += s_wcnt[w];
         }
-        if (hit) {
-            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
-            s_list[slot] = p_mine;
-            s_seg0[slot] = seg0;
-            s_seg1[slot] = seg1;
-            s_bbox[slot] = bb;
+        const int slot = off + __popcll(m & ((1ull << lane) - 1ull));  // rank of this lane's path among the hits
+        // the hits are worked off LCAP at a time (small LDS lists: more resident workgroups)
+        for (int lo = 0; lo < total_all; lo += LCAP) {
+        const int total = total_all - lo < LCAP ? total_all - lo : LCAP;
+        if (hit && slot >= lo && slot < lo + LCAP) {
+            s_list[slot - lo] = p_mine;
+            s_seg0[slot - lo] = seg0;
+            s_seg1[slot - lo] = seg1;
+            s_bbox[slot - lo] = bb;
         }
         __syncthreads();
 
@@ -881,7 +920,7 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
             }
         };
         issue_next();
-        issue_next();
+        if (PREF_DEPTH >= 3) issue_next();
 
         // per-path state, set when the first window of the path is reached
         int row_shift = 0, rows = 0, col_shift = 0, lo_c = 0, hi_c = 0, rule = 0, n_slots = 0, pflags = 0, pid = 0;
@@ -891,18 +930,18 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
         for (int k = 0; li < total; ++k) {
             const int cur = k % PREF_DEPTH;
 #ifdef SVGR_DBG_STAMP
-            unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+            unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();
 #endif
             if (pf_k > k + 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef SVGR_DBG_STAMP
-            unsigned long long t1_ = __builtin_amdgcn_s_memtime();
+            unsigned long long t1_ = __builtin_amdgcn_s_memrealtime();
 #endif
             // After this barrier: item k has landed for every wave; everybody is done with item k-1
             // (its block is free again) and, when this is a first window, with the previous path's scan.
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef SVGR_DBG_STAMP
-            unsigned long long t2_ = __builtin_amdgcn_s_memtime();
+            unsigned long long t2_ = __builtin_amdgcn_s_memrealtime();
 #endif
             issue_next();  // item k+2 into the block that item k-1 used
             const double* const blk = (const double*)(s_mem + OFF_PREF + cur * PREF_BYTES);
@@ -981,7 +1020,7 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
                 }
             }
 #ifdef SVGR_DBG_STAMP
-            unsigned long long t3_ = __builtin_amdgcn_s_memtime();
+            unsigned long long t3_ = __builtin_amdgcn_s_memrealtime();
 #endif
             ++li;
             if (OUT <= 1 && hi_c + col_shift < TC && tid < TR && tid >= row_shift && tid < row_shift + rows) {
@@ -994,7 +1033,7 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // delta tile complete
 #ifdef SVGR_DBG_STAMP
-            unsigned long long t4_ = __builtin_amdgcn_s_memtime();
+            unsigned long long t4_ = __builtin_amdgcn_s_memrealtime();
 #endif
 
             // ---- row prefix sum + fill rule + paint + source-over ----
@@ -1076,22 +1115,28 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
             }
 #ifdef SVGR_DBG_STAMP
             {
-                unsigned long long t5_ = __builtin_amdgcn_s_memtime();
-                if (tid == 0 && a.dbg) {
-                    atomicAdd(&a.dbg[0], t1_ - t0_);  // wait for the DMA
-                    atomicAdd(&a.dbg[1], t2_ - t1_);  // barrier A
-                    atomicAdd(&a.dbg[2], t3_ - t2_);  // metadata + scatter
-                    atomicAdd(&a.dbg[3], t4_ - t3_);  // barrier B
-                    atomicAdd(&a.dbg[4], t5_ - t4_);  // scan + composite
-                    atomicAdd(&a.dbg[5], 1ull);
-                }
+                unsigned long long t5_ = __builtin_amdgcn_s_memrealtime();
+                stamp_[0] += t1_ - t0_;  // wait for the DMA
+                stamp_[1] += t2_ - t1_;  // barrier A
+                stamp_[2] += t3_ - t2_;  // metadata + scatter
+                stamp_[3] += t4_ - t3_;  // barrier B
+                stamp_[4] += t5_ - t4_;  // scan + composite
+                stamp_[5] += 1ull;
             }
 #endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        }  // LCAP sub-batches
     }
 
+#ifdef SVGR_DBG_STAMP
+    if (tid == 0 && a.dbg) {
+        stamp_[6] = __builtin_amdgcn_s_memrealtime() - tstart_;
+        for (int q = 0; q < 7; ++q) atomicAdd(&a.dbg[q], stamp_[q]);
+        atomicAdd(&a.dbg[7], 1ull);
+    }
+#endif
     if (OUT <= 1) {
         const int row = band * TR + trow;  // viewport-local row
         const int out_row = (int)blockIdx.y * TR + trow;
@@ -1363,7 +1408,8 @@ struct svgr_batch {
     size_t arena_bytes = 0, off_pkeys = 0, off_pb_cnt = 0, off_pb_cursor = 0;
     int pb_cap = 0;
     // work arrays fully rewritten by every render
-    DevArr<int> edge_path, bbox, b0, nb, pb_off, pb_path, bseg_off, band_start, band_count, entries;
+    DevArr<int> edge_path, bbox, b0, nb, pb_off, pb_path, bseg_off, band_start, band_count;
+    DevArr<TileEntry> entries;
     DevArr<double> edges;
     DevArr<RowRec> bsegs;
     // plan results
@@ -1446,6 +1492,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     const int owned = count_owned_bands(b->own, b->n_bands);
     if (owned > 0)
         hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(256), 0, st, (const int*)b->b0.p, (const int*)b->nb.p, np,
+                           (const int*)b->bbox.p, (const int*)b->pb_off.p, (const int*)b->pb_cnt(), (const int*)b->bseg_off.p,
                            b->band_start.p, b->band_count.p, b->entries.p, cap_i32(b->entries.cap), b->bd(), b->own);
     return 0;
 }
@@ -1869,16 +1916,19 @@ int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags
             a.dbg = dbg_buf;
             unsigned long long h[8];
             (void)hipMemcpy(h, dbg_buf, 64, hipMemcpyDeviceToHost);
-            if (h[5]) fprintf(stderr, "[stamp] per iteration (wave 0 cycles): dma_wait %.0f barA %.0f scatter %.0f barB %.0f scan %.0f  (n=%llu)\n",
-                              (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5], h[5]);
+            if (h[5]) fprintf(stderr, "[stamp] ns per iteration (wave 0): dma_wait %.0f barA %.0f scatter %.0f barB %.0f scan %.0f | iterations %llu, WGs %llu, "
+                              "mean WG lifetime %.1f us, in-loop share %.2f\n",
+                              10.0 * h[0] / h[5], 10.0 * h[1] / h[5], 10.0 * h[2] / h[5], 10.0 * h[3] / h[5], 10.0 * h[4] / h[5], h[5], h[7],
+                              0.01 * h[6] / h[7], (double)(h[0] + h[1] + h[2] + h[3] + h[4]) / h[6]);
             (void)hipMemset(dbg_buf, 0, 64);
         }
 #endif
         dim3 grid((unsigned)n_ctiles, (unsigned)owned_bands);
+        static const int dyn_lds = getenv("SVGR_DBG_DYNLDS") ? atoi(getenv("SVGR_DBG_DYNLDS")) : 0;  // occupancy experiments
         switch (out_kind) {
             case 0:
                 if (b->has_clips) hipLaunchKernelGGL((k_tile_render<0, true>), grid, dim3(NT), 0, st, a);
-                else hipLaunchKernelGGL((k_tile_render<0, false>), grid, dim3(NT), 0, st, a);
+                else hipLaunchKernelGGL((k_tile_render<0, false>), grid, dim3(NT), dyn_lds, st, a);
                 break;
             case 1:
                 if (b->has_clips) hipLaunchKernelGGL((k_tile_render<1, true>), grid, dim3(NT), 0, st, a);
