@@ -50,12 +50,15 @@ constexpr int TR = SVGR_TR;                // rows per band / tile
 #define SVGR_PX 8
 #endif
 constexpr int PX = SVGR_PX;                // pixels per lane (consecutive columns)
-constexpr int TC = 16 * PX;                // columns per tile: 16 lanes (one DPP row) per tile row
-constexpr int CH = TC / PX;                // lanes per row = 16 = one DPP row
+#ifndef SVGR_CH
+#define SVGR_CH 16
+#endif
+constexpr int CH = SVGR_CH;                // lanes per tile row: 16 (one DPP row) or 32 (two DPP rows)
+constexpr int TC = CH * PX;                // columns per tile
 constexpr int NT = TR * CH;                // 256 threads = 4 waves; a wave covers 4 tile rows
 constexpr int CHUNK_STRIDE = PX + 2;       // doubles; +16 B makes the 16-lane b128 groups conflict free
 constexpr int ROW_STRIDE = CH * CHUNK_STRIDE;
-static_assert(CH == 16, "row scan uses one 16-lane DPP row per tile row");
+static_assert(CH == 16 || CH == 32, "row scan: one or two 16-lane DPP rows per tile row");
 constexpr int PREF_WAVES = NT / 64 < 3 ? NT / 64 : 3;   // waves that issue the LDS-DMA of a record block (1 KiB each)
 constexpr int PREF_BYTES = PREF_WAVES * 1024;
 #ifndef SVGR_REC_BYTES
@@ -780,6 +783,14 @@ __device__ __forceinline__ double dpp_row_shr(double v) {  // lane i <- lane i-N
     return __hiloint2double(hi, lo);
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_ctrl(double v) {  // generic DPP move of a double; lanes without a source / masked rows read 0
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ int lds_index(int trow, int tcol) {
     return trow * ROW_STRIDE + (tcol / PX) * CHUNK_STRIDE + (tcol % PX);
 }
@@ -1065,20 +1076,37 @@ __global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
                 inc += dpp_row_shr<2>(inc);
                 inc += dpp_row_shr<4>(inc);
                 inc += dpp_row_shr<8>(inc);
-                double run = dpp_row_shr<1>(inc);  // exclusive: everything left of this chunk
+                double run;
+                if (CH == 16) {
+                    run = dpp_row_shr<1>(inc);  // exclusive: everything left of this chunk
+                } else {
+                    // a tile row is two DPP rows: add the lower row's total (its lane 15) to the upper row,
+                    // then shift by one lane across the pair; the first lane of a tile row starts at 0
+                    inc += dpp_ctrl<0x142, 0xA>(inc);   // row_bcast:15 into DPP rows 1 and 3
+                    run = dpp_ctrl<0x138, 0xF>(inc);    // wave_shr:1
+                    if ((lane & 31) == 0) run = 0.0;
+                }
 
                 if (OUT <= 1) {
                     // Canvas: no bounds tests.  Left of / above / below the layer the delta tile is zero and so
                     // is the running sum; right of the layer it is NaN (sentinel above) or outside the viewport.
                     double* const myclip = s_clip + trow * ROW_STRIDE + chunk * CHUNK_STRIDE;
-                    // One loop for the three kinds of path (three unrolled copies cost 60 VGPRs and an occupancy step):
+                    // coverage first, in place (t[i] <- mask value), with the fill rule decided ONCE per path: written
+                    // as `rule ? evenodd(x) : nonzero(x)` inside the pixel loop the compiler evaluates both for every pixel
+                    if (rule) {
+#pragma unroll
+                        for (int i = 0; i < PX; ++i) { run += t[i]; t[i] = fill_evenodd_raw(run); }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < PX; ++i) { run += t[i]; t[i] = fill_nonzero_raw(run); }
+                    }
+                    // then one loop for the three kinds of path (three unrolled copies cost 60 VGPRs and an occupancy step):
                     //   plain      dst = src OVER dst,  src = mask * paint
                     //   clip src   Path.mask of a clip path (S:707): keep its coverage (after the 1e-6 cut) for the next path
                     //   clipped    CLIP: (mask * paint) * clip_alpha on the intersection (S:712, S:290), then OVER
 #pragma unroll
                     for (int i = 0; i < PX; ++i) {
-                        run += t[i];
-                        const double mval = rule ? fill_evenodd_raw(run) : fill_nonzero_raw(run);
+                        const double mval = t[i];
                         const bool vis = mval >= kZeroCut;
                         if (is_clip_src) {
                             myclip[i] = vis ? mval : 0.0;
