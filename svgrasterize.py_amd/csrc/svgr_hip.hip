@@ -72,6 +72,9 @@ constexpr int PREF_RECS = PREF_BYTES / REC_BYTES;              // slots per pref
 constexpr int PREF_DEPTH = SVGR_PREF_DEPTH;             // record blocks in the ring: paths li, li+1[, li+2]
 constexpr int LCAP = 32;                                // compacted paths of a tile worked off per sub-batch
 constexpr int NW = NT / 64;                // waves per workgroup; a wave covers 4 tile rows
+#ifndef SVGR_WAVES_PER_EU
+#define SVGR_WAVES_PER_EU 4             // register budget of the tile kernel: 512 / 4 = 128 VGPRs
+#endif
 static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 1024 threads");
 
 // One row of one edge (the signed-area pieces of line_signed_coverage for that scanline, S:2250-2303),
@@ -462,11 +465,19 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
     }
 }
 
+// Per-path binning record, written by k_path_bbox: the bands the (viewport-clipped) bbox covers and the path's
+// first (path, band) pair.  One 16-byte load for the kernels that map an edge / a band to its pair.
+struct PathBin {
+    int b0, nb;   // first band, number of bands (0: empty path)
+    int pb_off;   // pair index of (path, b0); pair of band b = pb_off + b - b0
+    int pad;
+};
+static_assert(sizeof(PathBin) == 16, "PathBin is one dwordx4");
+
 // bbox = {r0, c0, rows, cols}; viewport = same or has_vp = 0
-__global__ __launch_bounds__(256) void k_path_bbox(const unsigned long long* __restrict__ pkeys, int n_paths, int has_vp,
-                                                   int vr0, int vc0, int vrows, int vcols, int* __restrict__ bbox,
-                                                   int* __restrict__ b0, int* __restrict__ nb, int* __restrict__ pb_off,
-                                                   int* __restrict__ pb_path, int pb_cap, BatchDev* __restrict__ bd) {
+__global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __restrict__ pkeys, int n_paths, int has_vp,
+                                                  int vr0, int vc0, int vrows, int vcols, int* __restrict__ bbox,
+                                                  PathBin* __restrict__ bins, BatchDev* __restrict__ bd) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     int out[4] = {0, 0, 0, 0};
     int pb0 = 0, pnb = 0;
@@ -529,11 +540,9 @@ __global__ __launch_bounds__(256) void k_path_bbox(const unsigned long long* __r
     }
     if (p < n_paths) {
         ((int4*)bbox)[p] = make_int4(out[0], out[1], out[2], out[3]);
-        b0[p] = pb0;
-        nb[p] = pnb;
-        pb_off[p] = off;
-        if (pb_path)
-            for (int k = 0; k < pnb && off + k < pb_cap; ++k) pb_path[off + k] = p;
+        PathBin pbin;
+        pbin.b0 = pb0; pbin.nb = pnb; pbin.pb_off = off; pbin.pad = 0;
+        bins[p] = pbin;
     }
 }
 
@@ -564,17 +573,18 @@ __device__ __forceinline__ void band_rows(const EdgeSetup& es, int band, int vr0
 }
 
 __global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ edges, const int* __restrict__ edge_path,
-                                                    const int* __restrict__ bbox, const int* __restrict__ pb_off,
-                                                    const int* __restrict__ b0, int vr0, int pb_cap,
-                                                    int* __restrict__ pb_cnt, BatchDev* __restrict__ bd, Owner own) {
+                                                    const int* __restrict__ bbox, const PathBin* __restrict__ bins,
+                                                    int vr0, int pb_cap, int* __restrict__ pb_cnt, BatchDev* __restrict__ bd,
+                                                    Owner own) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     EdgeSetup es;
     int p = 0, r0 = 0, key = -1, bf = 0, bl = -1, rows_first = 0;
     bool ok = e < bd->edge_cursor && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
     if (ok) {
+        const PathBin pbin = bins[p];
         bf = (r0 + es.y_begin - vr0) / TR;
         bl = (r0 + es.y_end - 1 - vr0) / TR;
-        key = pb_off[p] - b0[p] + bf;
+        key = pbin.pb_off - pbin.b0 + bf;
         if (key < 0 || key + (bl - bf) >= pb_cap) { atomicOr(&bd->err, 4); ok = false; }
     }
     if (ok && owns_band(own, bf)) {
@@ -599,45 +609,128 @@ __global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ e
     }
 }
 
-// per (path, band) pair: reserve its band-segment slots (one atomic per wave)
-__global__ __launch_bounds__(1024) void k_alloc(const int* __restrict__ cnt, int n_cap, int* __restrict__ off,
-                                                const int* __restrict__ pb_path, const double* __restrict__ path_paint,
-                                                const uint8_t* __restrict__ path_rule, RowRec* __restrict__ recs, int rec_cap,
-                                                BatchDev* __restrict__ bd) {
-    __shared__ int s_tot[17];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = bd->pb_cursor < n_cap ? bd->pb_cursor : n_cap;
-    const int c = i < n ? cnt[i] : 0;
-    const int o = block_alloc(&bd->bseg_cursor, c > 0 ? c + 1 : 0, s_tot);  // + the header slot
-    if (i < n) {
-        off[i] = o;
-        if (c > 0 && recs && o < rec_cap) {
-            const int p = pb_path[i];
-            PairHeader h;
-            h.paint[0] = path_paint[4 * (size_t)p]; h.paint[1] = path_paint[4 * (size_t)p + 1];
-            h.paint[2] = path_paint[4 * (size_t)p + 2]; h.paint[3] = path_paint[4 * (size_t)p + 3];
-            h.rule = path_rule[p] & 1;
-            h.pad[0] = path_rule[p] >> 1;  // SVGR_PATH_* flags
-            h.pad[1] = h.pad[2] = 0;
-            *(PairHeader*)(recs + o) = h;
+// One tile-list entry: everything a tile needs to know about a (path, band) pair, so that the tile
+// kernel's compaction is ONE coalesced load per lane instead of a chain of four dependent gathers.
+struct TileEntry {
+    int p;            // path id
+    int c0, cols;     // layer columns (for the tile's column test)
+    int r0, rows;     // layer rows
+    int seg0, cnt;    // record block of the pair: first slot (the header), number of records
+    int pad;
+};
+static_assert(sizeof(TileEntry) == 32, "TileEntry is 32 bytes");
+
+// One workgroup per owned band, after k_edge_count: the ascending list of the paths that have records in the
+// band (TileEntry), and -- in the same pass, from the same counts -- the record block of every such
+// (path, band) pair: 1 header slot + cnt record slots, reserved with ONE atomic per band, so that a band's
+// blocks are contiguous in HBM and in paint order.  The header (paint, fill rule, flags) is written here;
+// k_edge_emit fills the records behind it.
+constexpr int BE_BLOCK = 1024;
+constexpr int BE_KEEP = 4;   // paths per thread whose counts stay in registers between the two passes
+__global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __restrict__ bins, int n_paths,
+                                                           const int* __restrict__ bbox, const int* __restrict__ pb_cnt,
+                                                           const double* __restrict__ path_paint,
+                                                           const uint8_t* __restrict__ path_rule, int* __restrict__ bseg_off,
+                                                           RowRec* __restrict__ recs, int rec_cap,
+                                                           int* __restrict__ band_start, int* __restrict__ band_count,
+                                                           TileEntry* __restrict__ entries, int entry_cap,
+                                                           BatchDev* __restrict__ bd, Owner own) {
+    __shared__ int s_n[BE_BLOCK / 64], s_r[BE_BLOCK / 64];
+    __shared__ int s_ent0, s_rec0, s_ok;
+    const int band = owned_band_at(own, blockIdx.x), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // thread t owns the paths [t * per, (t + 1) * per): consecutive, so ONE block scan orders everything by path id
+    const int per = (n_paths + BE_BLOCK - 1) / BE_BLOCK;
+    const int p_lo = tid * per, p_hi = p_lo + per < n_paths ? p_lo + per : n_paths;
+    auto pair_of = [&](int p, int& pair) -> int {  // records of path p in this band; 0: bbox does not reach it / no edge row
+        const PathBin pbin = bins[p];
+        if (!(pbin.nb > 0 && band >= pbin.b0 && band < pbin.b0 + pbin.nb)) return 0;
+        pair = pbin.pb_off + band - pbin.b0;
+        return pb_cnt[pair];
+    };
+    int kcnt[BE_KEEP], kpair[BE_KEEP];
+    int my_n = 0, my_r = 0;
+#pragma unroll
+    for (int k = 0; k < BE_KEEP; ++k) {
+        kcnt[k] = 0; kpair[k] = 0;
+        if (p_lo + k < p_hi) kcnt[k] = pair_of(p_lo + k, kpair[k]);
+        if (kcnt[k] > 0) { ++my_n; my_r += kcnt[k] + 1; }
+    }
+    for (int p = p_lo + BE_KEEP; p < p_hi; ++p) {
+        int pair;
+        const int c = pair_of(p, pair);
+        if (c > 0) { ++my_n; my_r += c + 1; }
+    }
+    int wn, wr;
+    const int ex_n = wave_excl_scan(my_n, lane, wn), ex_r = wave_excl_scan(my_r, lane, wr);
+    if (lane == 0) { s_n[wave] = wn; s_r[wave] = wr; }
+    __syncthreads();
+    if (tid == 0) {
+        int tn = 0, trc = 0;
+        for (int w = 0; w < BE_BLOCK / 64; ++w) {
+            const int a = s_n[w], c = s_r[w];
+            s_n[w] = tn; s_r[w] = trc;
+            tn += a; trc += c;
         }
+        int e0 = tn ? atomicAdd(&bd->entry_cursor, tn) : 0;
+        int r0 = trc ? atomicAdd(&bd->bseg_cursor, trc) : 0;
+        int ok = 1;
+        if (e0 + tn > entry_cap) { atomicOr(&bd->err, 4); ok = 0; tn = 0; }
+        s_ent0 = e0; s_rec0 = r0; s_ok = ok;
+        band_start[band] = e0;
+        band_count[band] = tn;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    int ent = s_ent0 + s_n[wave] + ex_n, rec = s_rec0 + s_r[wave] + ex_r;
+    auto put = [&](int p, int pair, int c) {
+        const int4 bb = ((const int4*)bbox)[p];
+        TileEntry e;
+        e.p = p; e.c0 = bb.y; e.cols = bb.w; e.r0 = bb.x; e.rows = bb.z;
+        e.seg0 = rec; e.cnt = c; e.pad = 0;
+        entries[ent] = e;
+        bseg_off[pair] = rec;
+        if (recs) {
+            if (rec + c < rec_cap) {
+                PairHeader h;
+                const double4 pa = ((const double4*)path_paint)[p];
+                const int rl = path_rule[p];
+                h.paint[0] = pa.x; h.paint[1] = pa.y; h.paint[2] = pa.z; h.paint[3] = pa.w;
+                h.rule = rl & 1;
+                h.pad[0] = rl >> 1;  // SVGR_PATH_* flags
+                h.pad[1] = h.pad[2] = 0;
+                *(PairHeader*)(recs + rec) = h;
+            } else {
+                atomicOr(&bd->err, 8);
+            }
+        }
+        ++ent;
+        rec += c + 1;
+    };
+#pragma unroll
+    for (int k = 0; k < BE_KEEP; ++k)
+        if (kcnt[k] > 0) put(p_lo + k, kpair[k], kcnt[k]);
+    for (int p = p_lo + BE_KEEP; p < p_hi; ++p) {
+        int pair;
+        const int c = pair_of(p, pair);
+        if (c > 0) put(p, pair, c);
     }
 }
 
 __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ edges, const int* __restrict__ edge_path,
-                                                   const int* __restrict__ bbox, const int* __restrict__ pb_off,
-                                                   const int* __restrict__ b0, int vr0, int pb_cap,
-                                                   const int* __restrict__ bseg_off, int* __restrict__ pb_cursor,
-                                                   RowRec* __restrict__ recs, int rec_cap, BatchDev* __restrict__ bd, Owner own) {
+                                                   const int* __restrict__ bbox, const PathBin* __restrict__ bins,
+                                                   int vr0, int pb_cap, const int* __restrict__ bseg_off,
+                                                   int* __restrict__ pb_cursor, RowRec* __restrict__ recs, int rec_cap,
+                                                   BatchDev* __restrict__ bd, Owner own) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     EdgeSetup es;
     int p = 0, r0 = 0, key = -1, rows_first = 0;
     bool ok = e < bd->edge_cursor && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
     int bf = 0, bl = -1;
     if (ok) {
+        const PathBin pbin = bins[p];
         bf = (r0 + es.y_begin - vr0) / TR;
         bl = (r0 + es.y_end - 1 - vr0) / TR;
-        key = pb_off[p] - b0[p] + bf;
+        key = pbin.pb_off - pbin.b0 + bf;
         if (key < 0 || key + (bl - bf) >= pb_cap) ok = false;  // flagged by k_edge_count
     }
     if (ok && owns_band(own, bf)) {
@@ -685,90 +778,6 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
     }
 }
 
-// One tile-list entry: everything a tile needs to know about a (path, band) pair, so that the tile
-// kernel's compaction is ONE coalesced load per lane instead of a chain of four dependent gathers.
-struct TileEntry {
-    int p;            // path id
-    int c0, cols;     // layer columns (for the tile's column test)
-    int r0, rows;     // layer rows
-    int seg0, cnt;    // record block of the pair: first slot (the header), number of records
-    int pad;
-};
-static_assert(sizeof(TileEntry) == 32, "TileEntry is 32 bytes");
-
-// one workgroup per band: ascending list of the paths that have records in the band
-__global__ __launch_bounds__(256) void k_band_entries(const int* __restrict__ b0, const int* __restrict__ nb, int n_paths,
-                                                      const int* __restrict__ bbox, const int* __restrict__ pb_off,
-                                                      const int* __restrict__ pb_cnt, const int* __restrict__ bseg_off,
-                                                      int* __restrict__ band_start, int* __restrict__ band_count,
-                                                      TileEntry* __restrict__ entries, int entry_cap, BatchDev* __restrict__ bd,
-                                                      Owner own) {
-    __shared__ int s_wcnt[4];
-    __shared__ int s_start, s_total;
-    const int band = owned_band_at(own, blockIdx.x), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    auto pair_cnt = [&](int p) -> int {  // records of path p in this band (0: bbox does not cover it / no edge crosses it)
-        const int f = b0[p], n = nb[p];
-        if (!(n > 0 && band >= f && band < f + n)) return 0;
-        return pb_cnt[pb_off[p] + band - f];
-    };
-    // pass 1: count (the first KEEP counts per lane are remembered for pass 2: they cost three gathers each)
-    constexpr int KEEP = 32;
-    int kept[KEEP];
-    int mine = 0;
-#pragma unroll
-    for (int it = 0; it < KEEP; ++it) {
-        const int p = it * 256 + tid;
-        kept[it] = p < n_paths ? pair_cnt(p) : 0;
-        mine += kept[it] > 0 ? 1 : 0;
-    }
-    for (int p = KEEP * 256 + tid; p < n_paths; p += 256) mine += pair_cnt(p) > 0 ? 1 : 0;
-    int wtot;
-    wave_excl_scan(mine, lane, wtot);
-    if (lane == 0) s_wcnt[wave] = wtot;
-    __syncthreads();
-    if (tid == 0) {
-        int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        int start = total ? atomicAdd(&bd->entry_cursor, total) : 0;
-        if (start + total > entry_cap) { atomicOr(&bd->err, 4); total = 0; }
-        s_start = start;
-        s_total = total;
-        band_start[band] = start;
-        band_count[band] = total;
-    }
-    __syncthreads();
-    int run = s_start;
-    const bool enabled = s_total > 0;
-    __syncthreads();
-    // pass 2: fill in ascending path order
-    auto fill = [&](int base, int cnt) {
-        const int p = base + tid;
-        const bool hit = cnt > 0;
-        unsigned long long m = __ballot(hit);
-        if (lane == 0) s_wcnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = 0, total = 0;
-        for (int w = 0; w < 4; ++w) {
-            if (w < wave) off += s_wcnt[w];
-            total += s_wcnt[w];
-        }
-        if (hit && enabled) {
-            const int4 bb = ((const int4*)bbox)[p];
-            TileEntry e;
-            e.p = p; e.c0 = bb.y; e.cols = bb.w; e.r0 = bb.x; e.rows = bb.z;
-            e.seg0 = bseg_off[pb_off[p] + band - b0[p]];
-            e.cnt = cnt;
-            e.pad = 0;
-            entries[run + off + __popcll(m & ((1ull << lane) - 1ull))] = e;
-        }
-        run += total;
-        __syncthreads();
-    };
-#pragma unroll
-    for (int it = 0; it < KEEP; ++it)
-        if (it * 256 < n_paths) fill(it * 256, kept[it]);
-    for (int base = KEEP * 256; base < n_paths; base += 256) fill(base, base + tid < n_paths ? pair_cnt(base + tid) : 0);
-}
-
 // ======================================================================================
 // tile kernel
 // ======================================================================================
@@ -799,14 +808,7 @@ struct TileArgs {
     const int* band_start;     // per band: first entry, number of entries
     const int* band_count;
     const TileEntry* entries;  // per band: the pairs with records, ascending path id
-    const int* bbox;           // n_paths x 4
-    const int* b0;             // first band of each path
-    const int* pb_off;         // (path, band) pair offsets
-    const int* bseg_off;       // per pair: first band segment, number of band segments
-    const int* pb_cnt;
-    const RowRec* bsegs;
-    const uint8_t* rule;       // n_paths
-    const double* paint;       // n_paths x 4
+    const RowRec* bsegs;       // record blocks: per (path, band) pair one header slot + its edge-row records
     void* out;
     int vr0, vc0, vrows, vcols;  // viewport
     Owner own;                   // owned bands
@@ -820,7 +822,7 @@ struct TileArgs {
 // CLIP: the batch contains SVGR_PATH_CLIP_SOURCE / SVGR_PATH_CLIPPED paths (one more LDS tile: its own instantiation,
 // so that batches without clips keep their occupancy)
 template <int OUT, bool CLIP = false>
-__global__ __launch_bounds__(NT, 4) void k_tile_render(const TileArgs a) {
+__global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const TileArgs a) {
     // ONE __shared__ object, carved by hand: with a second object beside the LDS-DMA staging area
     // hipcc (ROCm 7.2) drains vmcnt(0) before every ds_read and the record prefetch stops overlapping
     constexpr int OFF_TRACE = 0;
@@ -1436,7 +1438,8 @@ struct svgr_batch {
     size_t arena_bytes = 0, off_pkeys = 0, off_pb_cnt = 0, off_pb_cursor = 0;
     int pb_cap = 0;
     // work arrays fully rewritten by every render
-    DevArr<int> edge_path, bbox, b0, nb, pb_off, pb_path, bseg_off, band_start, band_count;
+    DevArr<int> edge_path, bbox, bseg_off, band_start, band_count;
+    DevArr<PathBin> bins;
     DevArr<TileEntry> entries;
     DevArr<double> edges;
     DevArr<RowRec> bsegs;
@@ -1465,8 +1468,8 @@ struct svgr_batch {
 
     void release() {
         segs.release(); path_m6.release(); path_paint.release(); seg_kind.release(); path_rule.release();
-        seg_path.release(); arena.release(); edge_path.release(); bbox.release(); b0.release(); nb.release();
-        pb_off.release(); pb_path.release(); bseg_off.release(); band_start.release(); band_count.release(); entries.release();
+        seg_path.release(); arena.release(); edge_path.release(); bbox.release(); bins.release();
+        bseg_off.release(); band_start.release(); band_count.release(); entries.release();
         edges.release(); bsegs.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
@@ -1492,9 +1495,8 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                                b->thr, (double*)nullptr, (int*)nullptr, 0, b->pkeys(), b->bd(), b->own, b->vp[0],
                                use_vp ? (b->vp[2] + TR - 1) / TR : 0);
         if (upto == 0)  // bboxes only (no edges stored): enough to find the union when there is no viewport
-            hipLaunchKernelGGL(k_path_bbox, grid1(np), dim3(256), 0, st, (const unsigned long long*)b->pkeys(), np,
-                               use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->b0.p, b->nb.p, b->pb_off.p,
-                               (int*)nullptr, 0, b->bd());
+            hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np,
+                               use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd());
         return 0;
     }
     if (ns > 0)
@@ -1502,26 +1504,24 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                            (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
                            b->edges.p, b->edge_path.p, cap_i32(b->edges.cap / 4), b->pkeys(), b->bd(), b->own, b->vp[0],
                            use_vp ? (b->vp[2] + TR - 1) / TR : 0);
-    hipLaunchKernelGGL(k_path_bbox, grid1(np), dim3(256), 0, st, (const unsigned long long*)b->pkeys(), np, use_vp ? 1 : 0,
-                       b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->b0.p, b->nb.p, b->pb_off.p,
-                       b->pb_cap > 0 ? b->pb_path.p : (int*)nullptr, b->pb_cap, b->bd());
+    hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np, use_vp ? 1 : 0,
+                       b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd());
     if (upto == 2) return 0;
     const size_t ne = (size_t)std::max<int64_t>(b->n_edges, 1);
     hipLaunchKernelGGL(k_edge_count, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
-                       (const int*)b->bbox.p, (const int*)b->pb_off.p, (const int*)b->b0.p, b->vp[0], b->pb_cap, b->pb_cnt(),
-                       b->bd(), b->own);
-    hipLaunchKernelGGL(k_alloc, grid1((size_t)std::max(b->pb_cap, 1), 1024), dim3(1024), 0, st, (const int*)b->pb_cnt(), b->pb_cap,
-                       b->bseg_off.p, (const int*)b->pb_path.p, (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p,
-                       upto >= 4 ? b->bsegs.p : (RowRec*)nullptr, cap_i32(b->bsegs.cap), b->bd());
-    if (upto == 3) return 0;
-    hipLaunchKernelGGL(k_edge_emit, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
-                       (const int*)b->bbox.p, (const int*)b->pb_off.p, (const int*)b->b0.p, b->vp[0], b->pb_cap,
-                       (const int*)b->bseg_off.p, b->pb_cursor(), b->bsegs.p, cap_i32(b->bsegs.cap), b->bd(), b->own);
+                       (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->pb_cap, b->pb_cnt(), b->bd(), b->own);
+    // per owned band: tile list + record blocks (upto == 3: sizes only, no headers written)
     const int owned = count_owned_bands(b->own, b->n_bands);
     if (owned > 0)
-        hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(256), 0, st, (const int*)b->b0.p, (const int*)b->nb.p, np,
-                           (const int*)b->bbox.p, (const int*)b->pb_off.p, (const int*)b->pb_cnt(), (const int*)b->bseg_off.p,
-                           b->band_start.p, b->band_count.p, b->entries.p, cap_i32(b->entries.cap), b->bd(), b->own);
+        hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(BE_BLOCK), 0, st, (const PathBin*)b->bins.p, np,
+                           (const int*)b->bbox.p, (const int*)b->pb_cnt(), (const double*)b->path_paint.p,
+                           (const uint8_t*)b->path_rule.p, b->bseg_off.p, upto >= 4 ? b->bsegs.p : (RowRec*)nullptr,
+                           cap_i32(b->bsegs.cap), b->band_start.p, b->band_count.p, b->entries.p, cap_i32(b->entries.cap),
+                           b->bd(), b->own);
+    if (upto == 3) return 0;
+    hipLaunchKernelGGL(k_edge_emit, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
+                       (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->pb_cap, (const int*)b->bseg_off.p,
+                       b->pb_cursor(), b->bsegs.p, cap_i32(b->bsegs.cap), b->bd(), b->own);
     return 0;
 }
 
@@ -1738,9 +1738,7 @@ int svgr_batch_create(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch** out)
     rc = rc ? rc : up(b->path_rule, d->path_rule, np, 1);
     rc = rc ? rc : up(b->path_paint, d->path_paint, np * 4, sizeof(double));
     rc = rc ? rc : b->bbox.ensure(4 * np);
-    rc = rc ? rc : b->b0.ensure(np + 1);
-    rc = rc ? rc : b->nb.ensure(np + 1);
-    rc = rc ? rc : b->pb_off.ensure(np + 1);
+    rc = rc ? rc : b->bins.ensure(np + 1);
     rc = rc ? rc : b->layout_arena(0);
     if (!rc) {
         hipError_t e = hipStreamSynchronize(ctx->stream);  // seg_path is a local
@@ -1819,7 +1817,6 @@ int svgr_batch_plan(svgr_batch* b) {
     // 3. per-pair counts -> band segments
     if (int rc = b->layout_arena((int)b->n_pb)) return rc;
     if (int rc = b->bseg_off.ensure((size_t)b->n_pb + 1)) return rc;
-    if (int rc = b->pb_path.ensure((size_t)b->n_pb + 1)) return rc;
     if (int rc = b->entries.ensure((size_t)std::max<int64_t>(b->n_pb, 1))) return rc;
     if (int rc = run_geometry(b, 3, true)) return rc;
     if (int rc = check_dev_err(b)) return rc;
@@ -1927,10 +1924,7 @@ int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags
 
     if (owned_bands > 0 && n_ctiles > 0) {
         TileArgs a;
-        a.band_start = b->band_start.p; a.band_count = b->band_count.p; a.entries = b->entries.p; a.bbox = b->bbox.p;
-        a.b0 = b->b0.p; a.pb_off = b->pb_off.p; a.bseg_off = b->bseg_off.p; a.pb_cnt = b->pb_cnt(); a.bsegs = b->bsegs.p;
-        a.rule = b->path_rule.p;
-        a.paint = b->path_paint.p; a.out = out->ptr;
+        a.band_start = b->band_start.p; a.band_count = b->band_count.p; a.entries = b->entries.p; a.bsegs = b->bsegs.p; a.out = out->ptr;
         a.vr0 = b->vp[0]; a.vc0 = b->vp[1]; a.vrows = b->vp[2]; a.vcols = b->vp[3];
         a.own = b->own;
         a.out_cols = b->vp[3];
