@@ -333,14 +333,37 @@ struct BatchDev {
                         // bit 3: band-seg capacity, bit 4: bbox beyond int range
     int n_nonempty;
     unsigned long long path_pixels;
-    int edge_cursor;    // flattened edges reserved so far
+    int edge_spare;
     int pb_cursor;      // (path, band) pairs
     int bseg_cursor;    // band segments
     int entry_cursor;   // band list entries
     unsigned umin_r, umin_c, umax_r, umax_c;  // union bbox: max(BIAS - lo), max(BIAS + hi)
-    int pad[4];
+    int pad[4 + 16];
+    // Flattened edges are reserved in NSH independent shards (wave w of the flatten uses shard w % NSH): one hot
+    // cursor serves only ~90 returning atomics per microsecond chip-wide, sixteen serve every wave of the launch.
+    // One 128-byte line per cursor.
+    struct ShardLine {
+        int cursor;
+        int pad[31];
+    } shard[16];
 };
-static_assert(sizeof(BatchDev) == 64, "BatchDev is the 64-byte head of the zero arena");
+constexpr int NSH = 16;
+static_assert(sizeof(BatchDev) == 128 + NSH * 128, "BatchDev is the head of the zero arena");
+
+// Where the shards live in the edge arrays: shard s owns [base[s], base[s] + cap[s]); the capacities are the exact
+// counts found by svgr_batch_plan, so for unchanged input the shards are full and the edge array is dense.
+struct EdgeShards {
+    int base[NSH];
+    int cap[NSH];
+};
+// is edge slot e filled?  (bases ascend; empty shards share a base with their successor)
+__device__ __forceinline__ bool edge_live(int e, const EdgeShards& sh, const BatchDev* __restrict__ bd) {
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < NSH; ++k) s += e >= sh.base[k] ? 1 : 0;
+    const int filled = bd->shard[s].cursor < sh.cap[s] ? bd->shard[s].cursor : sh.cap[s];
+    return e - sh.base[s] < filled;
+}
 
 __device__ __forceinline__ void load_seg_points(const double* __restrict__ segs, int s, const double* __restrict__ m6,
                                                 int npts, double* c) {
@@ -350,27 +373,66 @@ __device__ __forceinline__ void load_seg_points(const double* __restrict__ segs,
     }
 }
 
+// Multi-GPU pre-pass: the rows a path can reach, from the hull of its transformed control points (a cubic and
+// its de Casteljau halves stay inside it; +-1 row of slack for rounding, plus the bbox margin of S:966-975).
+// prow[2p] = max(BIAS - lo), prow[2p + 1] = max(BIAS + hi): zero-initialised like the rest of the arena.
+// k_flatten then skips every segment of a path that cannot reach one of this rank's bands: such a path has no
+// pixel here, and skipping it whole is what lets the flatten scale with 1/ranks.
+__global__ __launch_bounds__(256) void k_path_rows(const double* __restrict__ segs, const uint8_t* __restrict__ kind,
+                                                   const int* __restrict__ seg_path, const double* __restrict__ path_m6,
+                                                   int n_segs, unsigned* __restrict__ prow) {
+    const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg >= n_segs) return;
+    const int p = seg_path[seg];
+    const int npts = kind[seg] == SVGR_SEG_LINE ? 2 : 4;
+    double c[8];
+    load_seg_points(segs, seg, path_m6 + 6 * (size_t)p, npts, c);
+    double rlo = c[0], rhi = c[0];
+    bool finite = c[0] - c[0] == 0.0;
+    for (int k = 1; k < npts; ++k) {
+        rlo = c[2 * k] < rlo ? c[2 * k] : rlo;
+        rhi = c[2 * k] > rhi ? c[2 * k] : rhi;
+        finite = finite && (c[2 * k] - c[2 * k] == 0.0);
+    }
+    int lo = -(1 << 29), hi = 1 << 29;  // not finite: keep the path everywhere (the flatten reports it)
+    if (finite) {
+        lo = clamp_to_int(floor(rlo));
+        hi = clamp_to_int(ceil(rhi));
+        lo = lo < -(1 << 29) ? -(1 << 29) : lo;
+        hi = hi > (1 << 29) ? (1 << 29) : hi;
+    }
+    atomicMax(&prow[2 * (size_t)p], (unsigned)(UNION_BIAS - lo));
+    atomicMax(&prow[2 * (size_t)p + 1], (unsigned)(UNION_BIAS + hi));
+}
+
 // 32 lanes per segment.  Lane j owns the depth-5 node whose path bits are j (if the five ancestors
 // above it are not flat; an ancestor that is flat is emitted by the lane whose remaining bits are 0).
 // Per-path keys: {~key(min_r), ~key(min_c), key(max_r), key(max_c)}, all folded with atomicMax.
 constexpr int FL_SUB = 5;       // 32 lanes per segment: the longest lane bounds the kernel, so cut subtrees small
-constexpr int FL_BLOCK = 1024;
+constexpr int FL_BLOCK = 256;     // waves are independent (no block-level step)
 template <bool EMIT>
 __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__ segs, const uint8_t* __restrict__ kind,
                                                  const int* __restrict__ seg_path, const double* __restrict__ path_m6,
                                                  int n_segs, double thr, double* __restrict__ edges,
-                                                 int* __restrict__ edge_path, int edge_cap,
+                                                 int* __restrict__ edge_path, const EdgeShards sh,
                                                  unsigned long long* __restrict__ pkeys, BatchDev* __restrict__ bd,
-                                                 Owner own, int vr0, int n_bands) {
-    __shared__ int s_tot[17];
+                                                 Owner own, int vr0, int n_bands, const unsigned* __restrict__ prow) {
     const int gtid = blockIdx.x * FL_BLOCK + threadIdx.x;
     const int seg = gtid >> FL_SUB, sub = gtid & ((1 << FL_SUB) - 1);
-    const bool seg_ok = seg < n_segs;
+    bool seg_ok = seg < n_segs;
     double node[8];
     int mode = 0;  // 0 nothing, 1 one edge node[0..1] -> node[6..7], 2 subtree under node
     int p = 0;
+    if (seg_ok) p = seg_path[seg];
+    if (seg_ok && prow) {
+        // multi-GPU: a path none of whose rows can reach this rank's bands is skipped whole (k_path_rows)
+        const int lo = UNION_BIAS - (int)prow[2 * (size_t)p], hi = (int)prow[2 * (size_t)p + 1] - UNION_BIAS;
+        int ba = (lo - 2 - vr0) / TR, bb = (hi + 2 - vr0) / TR;
+        ba = lo - 2 - vr0 < 0 ? 0 : ba;
+        bb = bb > n_bands - 1 ? n_bands - 1 : bb;
+        seg_ok = ba <= bb && owns_any(own, ba, bb);
+    }
     if (seg_ok) {
-        p = seg_path[seg];
         const double* m6 = path_m6 + 6 * (size_t)p;
         if (kind[seg] == SVGR_SEG_LINE) {
             if (sub == 0) {
@@ -393,9 +455,9 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
             }
         }
     }
-    // Multi-GPU: every rank needs every path's exact bbox (so the first traversal always runs and
-    // tracks min/max), but it only keeps the edges of segments that can reach one of its own bands
-    // (the curve stays inside the row range of its control points; +-1 row of slack).
+    // Multi-GPU: a rank needs the exact bbox of every path it keeps (so the first traversal always runs and
+    // tracks min/max over ALL segments of such a path), but it only stores the edges of segments that can
+    // reach one of its own bands (the curve stays inside the row range of its control points; +-1 row of slack).
     bool keep = true;
     if (n_bands > 0 && mode != 0) {  // (also drops what lies entirely above / below the viewport)
         double rlo = node[0] < node[6] ? node[0] : node[6], rhi = node[0] < node[6] ? node[6] : node[0];
@@ -427,10 +489,13 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
     }
     if (ovf) atomicOr(&bd->err, 1);
     if (!keep) cnt = 0;
-    const int base = block_alloc(&bd->edge_cursor, cnt, s_tot);
+    // one reservation per wave, in the wave's shard
+    const int shard = (int)((blockIdx.x * (FL_BLOCK / 64) + (threadIdx.x >> 6)) % NSH);
+    const int in_shard = wave_alloc(&bd->shard[shard].cursor, cnt, threadIdx.x & 63);
+    const int base = sh.base[shard] + in_shard;
 
     if (EMIT && cnt > 0) {
-        if (base + cnt > edge_cap) {
+        if (in_shard + cnt > sh.cap[shard]) {
             atomicOr(&bd->err, 2);
         } else if (mode == 1) {
             double* e = edges + 4 * (size_t)base;
@@ -575,11 +640,11 @@ __device__ __forceinline__ void band_rows(const EdgeSetup& es, int band, int vr0
 __global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ edges, const int* __restrict__ edge_path,
                                                     const int* __restrict__ bbox, const PathBin* __restrict__ bins,
                                                     int vr0, int pb_cap, int* __restrict__ pb_cnt, BatchDev* __restrict__ bd,
-                                                    Owner own) {
+                                                    Owner own, const EdgeShards sh) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     EdgeSetup es;
     int p = 0, r0 = 0, key = -1, bf = 0, bl = -1, rows_first = 0;
-    bool ok = e < bd->edge_cursor && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
+    bool ok = edge_live(e, sh, bd) && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
     if (ok) {
         const PathBin pbin = bins[p];
         bf = (r0 + es.y_begin - vr0) / TR;
@@ -720,11 +785,11 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
                                                    const int* __restrict__ bbox, const PathBin* __restrict__ bins,
                                                    int vr0, int pb_cap, const int* __restrict__ bseg_off,
                                                    int* __restrict__ pb_cursor, RowRec* __restrict__ recs, int rec_cap,
-                                                   BatchDev* __restrict__ bd, Owner own) {
+                                                   BatchDev* __restrict__ bd, Owner own, const EdgeShards sh) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     EdgeSetup es;
     int p = 0, r0 = 0, key = -1, rows_first = 0;
-    bool ok = e < bd->edge_cursor && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
+    bool ok = edge_live(e, sh, bd) && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
     int bf = 0, bl = -1;
     if (ok) {
         const PathBin pbin = bins[p];
@@ -1433,9 +1498,9 @@ struct svgr_batch {
     DevArr<double> segs, path_m6, path_paint;
     DevArr<uint8_t> seg_kind, path_rule;
     DevArr<int> seg_path;
-    // zeroed once per render: [BatchDev | per-path min/max keys | pb_cnt | pb_cursor]
+    // zeroed once per render: [BatchDev | per-path min/max keys | per-path row reach (multi-GPU) | pb_cnt | pb_cursor]
     DevArr<unsigned char> arena;
-    size_t arena_bytes = 0, off_pkeys = 0, off_pb_cnt = 0, off_pb_cursor = 0;
+    size_t arena_bytes = 0, off_pkeys = 0, off_prow = 0, off_pb_cnt = 0, off_pb_cursor = 0;
     int pb_cap = 0;
     // work arrays fully rewritten by every render
     DevArr<int> edge_path, bbox, bseg_off, band_start, band_count;
@@ -1447,19 +1512,22 @@ struct svgr_batch {
     int64_t n_edges = 0, n_pb = 0, n_bsegs = 0;
     int n_bands = 0;
     BatchDev host_bd{};
+    EdgeShards shards{};       // plan result: where each flatten shard's edges live
     std::vector<int> host_bbox;
     std::vector<TimedEvents> events;
     std::vector<hipEvent_t> event_pool;
 
     BatchDev* bd() const { return (BatchDev*)arena.p; }
     unsigned long long* pkeys() const { return (unsigned long long*)(arena.p + off_pkeys); }
+    unsigned* prow() const { return (unsigned*)(arena.p + off_prow); }
     int* pb_cnt() const { return (int*)(arena.p + off_pb_cnt); }
     int* pb_cursor() const { return (int*)(arena.p + off_pb_cursor); }
 
     int layout_arena(int new_pb_cap) {
         pb_cap = new_pb_cap;
         off_pkeys = sizeof(BatchDev);
-        off_pb_cnt = off_pkeys + sizeof(unsigned long long) * 4 * (size_t)n_paths;
+        off_prow = off_pkeys + sizeof(unsigned long long) * 4 * (size_t)n_paths;
+        off_pb_cnt = off_prow + sizeof(unsigned) * 2 * (size_t)n_paths;
         off_pb_cursor = off_pb_cnt + sizeof(int) * (size_t)(pb_cap + 1);
         arena_bytes = off_pb_cursor + sizeof(int) * (size_t)(pb_cap + 1);
         arena_bytes = (arena_bytes + 255) & ~(size_t)255;
@@ -1488,12 +1556,19 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     const int ns = (int)b->n_segs, np = (int)b->n_paths;
     HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
     const dim3 fgrid = grid1((size_t)ns << FL_SUB, FL_BLOCK);
+    // multi-GPU with a viewport: find the rows each path can reach first, so that the flatten skips foreign paths
+    const unsigned* prow = nullptr;
+    if (use_vp && b->own.world > 1 && ns > 0) {
+        hipLaunchKernelGGL(k_path_rows, grid1((size_t)ns), dim3(256), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
+                           (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->prow());
+        prow = b->prow();
+    }
     if (upto <= 1) {
         if (ns > 0)
             hipLaunchKernelGGL(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                                (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns,
-                               b->thr, (double*)nullptr, (int*)nullptr, 0, b->pkeys(), b->bd(), b->own, b->vp[0],
-                               use_vp ? (b->vp[2] + TR - 1) / TR : 0);
+                               b->thr, (double*)nullptr, (int*)nullptr, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
+                               use_vp ? (b->vp[2] + TR - 1) / TR : 0, prow);
         if (upto == 0)  // bboxes only (no edges stored): enough to find the union when there is no viewport
             hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np,
                                use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd());
@@ -1502,14 +1577,14 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     if (ns > 0)
         hipLaunchKernelGGL(k_flatten<true>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                            (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
-                           b->edges.p, b->edge_path.p, cap_i32(b->edges.cap / 4), b->pkeys(), b->bd(), b->own, b->vp[0],
-                           use_vp ? (b->vp[2] + TR - 1) / TR : 0);
+                           b->edges.p, b->edge_path.p, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
+                           use_vp ? (b->vp[2] + TR - 1) / TR : 0, prow);
     hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np, use_vp ? 1 : 0,
                        b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd());
     if (upto == 2) return 0;
     const size_t ne = (size_t)std::max<int64_t>(b->n_edges, 1);
     hipLaunchKernelGGL(k_edge_count, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
-                       (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->pb_cap, b->pb_cnt(), b->bd(), b->own);
+                       (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->pb_cap, b->pb_cnt(), b->bd(), b->own, b->shards);
     // per owned band: tile list + record blocks (upto == 3: sizes only, no headers written)
     const int owned = count_owned_bands(b->own, b->n_bands);
     if (owned > 0)
@@ -1521,7 +1596,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     if (upto == 3) return 0;
     hipLaunchKernelGGL(k_edge_emit, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
                        (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->pb_cap, (const int*)b->bseg_off.p,
-                       b->pb_cursor(), b->bsegs.p, cap_i32(b->bsegs.cap), b->bd(), b->own);
+                       b->pb_cursor(), b->bsegs.p, cap_i32(b->bsegs.cap), b->bd(), b->own, b->shards);
     return 0;
 }
 
@@ -1805,7 +1880,13 @@ int svgr_batch_plan(svgr_batch* b) {
     // 2. count the edges this rank keeps
     if (int rc = run_geometry(b, 1, true)) return rc;
     if (int rc = check_dev_err(b)) return rc;
-    b->n_edges = b->host_bd.edge_cursor;
+    b->n_edges = 0;
+    for (int k = 0; k < NSH; ++k) {  // the shards, back to back
+        b->shards.base[k] = (int)b->n_edges;
+        b->shards.cap[k] = b->host_bd.shard[k].cursor;
+        b->n_edges += b->host_bd.shard[k].cursor;
+    }
+    if (b->n_edges > 0x7fffffff / 4) return fail(SVGR_E_OVERFLOW, "%lld edges: beyond the 32-bit edge index", (long long)b->n_edges);
     if (int rc = b->edges.ensure((size_t)std::max<int64_t>(b->n_edges, 1) * 4)) return rc;
     if (int rc = b->edge_path.ensure((size_t)std::max<int64_t>(b->n_edges, 1))) return rc;
     b->n_bands = (b->vp[2] + TR - 1) / TR;

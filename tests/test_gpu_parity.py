@@ -233,7 +233,8 @@ def test_synthetic_vs_oracle(S, orc, size, n):
 @pytest.mark.parametrize("world,strip", [(3, 1), (2, 4), (4, 2)])
 def test_band_sharding_matches_full(S, world, strip):
     """Rows rendered by 'rank r of N' (interleaved strips of bands, geometry culled to what reaches them)
-    equal the same rows of the full render: identical edges and bboxes, so only summation order differs."""
+    equal the same rows of the full render: identical edges and bboxes for every path the rank keeps (a path
+    that cannot reach the rank's rows is dropped whole and reports an empty bbox), so only summation order differs."""
     from svgrasterize_amd import _abi, dist as sdist, synth
 
     size, n = 300, 80
@@ -251,7 +252,14 @@ def test_band_sharding_matches_full(S, world, strip):
     for rank in range(world):
         batch.set_bands(rank, world, strip)
         st = batch.plan()
-        assert st.path_pixels == st_full.path_pixels and np.array_equal(batch.bboxes(), full_bb)  # bboxes are global
+        bb = batch.bboxes()
+        kept = bb[:, 2] > 0
+        assert np.array_equal(bb[kept], full_bb[kept]) and st.path_pixels <= st_full.path_pixels  # kept paths: the global bbox
+        mine = np.zeros(size + 2, dtype=bool)
+        for r0, r1 in sdist.owned_row_ranges(size, tr, rank, world, strip):
+            mine[r0:r1] = True
+        for q in np.nonzero(~kept & (full_bb[:, 2] > 0))[0]:  # dropped: no edge row (bbox minus its 1-px margins) is ours
+            assert not mine[full_bb[q, 0] + 1: full_bb[q, 0] + full_bb[q, 2] - 1].any(), f"rank {rank} dropped path {q}"
         edges_kept += st.n_edges
         rows = batch.owned_rows()
         assert rows == len(sdist.owned_bands(size, tr, rank, world, strip)) * tr
