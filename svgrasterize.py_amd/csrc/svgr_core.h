@@ -43,32 +43,51 @@ SVGR_HD double dot4(double w0, double w1, double w2, double w3, double x0, doubl
     return fma(w0, x0, w2 * x2) + fma(w1, x1, w3 * x3);
 }
 
+// The weight rows used below contain zeros and ones.  With w == 0 the term fma(0, x, t) is t and 0 * x is +0, with
+// w == 1 fma(1, x, t) is x + t: for finite x the shortened forms give the same bits as the full dot4 (up to the sign
+// of a zero, which nothing downstream can see), at about half the instructions -- the compiler may not drop them
+// itself (0 * x is not 0 for a NaN or an infinity).
+
 // c = 4 points (row, col) interleaved: c[2*k + axis]
 SVGR_HD double cubic_flatness(const double* c) {
     // u = -2 b0 + 3 b1 - b3 ; v = -b0 + 3 b2 - 2 b3 ; f = max(ux^2, uy^2) + max(vx^2, vy^2)
-    double ux = dot4(-2.0, 3.0, 0.0, -1.0, c[0], c[2], c[4], c[6]);
-    double uy = dot4(-2.0, 3.0, 0.0, -1.0, c[1], c[3], c[5], c[7]);
-    double vx = dot4(-1.0, 0.0, 3.0, -2.0, c[0], c[2], c[4], c[6]);
-    double vy = dot4(-1.0, 0.0, 3.0, -2.0, c[1], c[3], c[5], c[7]);
+    // dot4(-2, 3, 0, -1, x) = fma(-2, x0, 0 * x2) + fma(3, x1, -1 * x3) = -2 x0 + fma(3, x1, -x3)
+    // dot4(-1, 0, 3, -2, x) = fma(-1, x0, 3 * x2) + fma(0, x1, -2 * x3) = fma(-1, x0, 3 x2) + -2 x3
+    double ux = -2.0 * c[0] + fma(3.0, c[2], -c[6]);
+    double uy = -2.0 * c[1] + fma(3.0, c[3], -c[7]);
+    double vx = fma(-1.0, c[0], 3.0 * c[4]) + -2.0 * c[6];
+    double vy = fma(-1.0, c[1], 3.0 * c[5]) + -2.0 * c[7];
     double uxx = ux * ux, uyy = uy * uy, vxx = vx * vx, vyy = vy * vy;
     double mu = uxx > uyy ? uxx : uyy;
     double mv = vxx > vyy ? vxx : vyy;
     return mu + mv;
 }
 
-// de Casteljau at t = 1/2 with the reference's 8x4 weight matrix; l/r = 4 points each
-SVGR_HD void cubic_split(const double* c, double* l, double* r) {
+// de Casteljau at t = 1/2 with the reference's 8x4 weight matrix (rows as dot4, shortened as described above):
+//   l0 = (1, 0, 0, 0)              l1 = (.5, .5, 0, 0)   l2 = (.25, .5, .25, 0)   l3 = r0 = (.125, .375, .375, .125)
+//   r1 = (0, .25, .5, .25)         r2 = (0, 0, .5, .5)   r3 = (0, 0, 0, 1)
+SVGR_HD double split_mid(double x0, double x1, double x2, double x3) { return dot4(0.125, 0.375, 0.375, 0.125, x0, x1, x2, x3); }
+SVGR_HD void cubic_left(const double* c, double* l) {
     for (int ax = 0; ax < 2; ++ax) {
         double x0 = c[ax], x1 = c[2 + ax], x2 = c[4 + ax], x3 = c[6 + ax];
-        l[ax] = dot4(1.0, 0.0, 0.0, 0.0, x0, x1, x2, x3);
-        l[2 + ax] = dot4(0.5, 0.5, 0.0, 0.0, x0, x1, x2, x3);
-        l[4 + ax] = dot4(0.25, 0.5, 0.25, 0.0, x0, x1, x2, x3);
-        l[6 + ax] = dot4(0.125, 0.375, 0.375, 0.125, x0, x1, x2, x3);
-        r[ax] = dot4(0.125, 0.375, 0.375, 0.125, x0, x1, x2, x3);
-        r[2 + ax] = dot4(0.0, 0.25, 0.5, 0.25, x0, x1, x2, x3);
-        r[4 + ax] = dot4(0.0, 0.0, 0.5, 0.5, x0, x1, x2, x3);
-        r[6 + ax] = dot4(0.0, 0.0, 0.0, 1.0, x0, x1, x2, x3);
+        l[ax] = x0;
+        l[2 + ax] = 0.5 * x0 + 0.5 * x1;
+        l[4 + ax] = fma(0.25, x0, 0.25 * x2) + 0.5 * x1;
+        l[6 + ax] = split_mid(x0, x1, x2, x3);
     }
+}
+SVGR_HD void cubic_right(const double* c, double* r) {
+    for (int ax = 0; ax < 2; ++ax) {
+        double x0 = c[ax], x1 = c[2 + ax], x2 = c[4 + ax], x3 = c[6 + ax];
+        r[ax] = split_mid(x0, x1, x2, x3);
+        r[2 + ax] = 0.5 * x2 + fma(0.25, x1, 0.25 * x3);
+        r[4 + ax] = 0.5 * x2 + 0.5 * x3;
+        r[6 + ax] = x3;
+    }
+}
+SVGR_HD void cubic_split(const double* c, double* l, double* r) {
+    cubic_left(c, l);
+    cubic_right(c, r);
 }
 
 // Depth-first adaptive subdivision. `emit(p0r, p0c, p1r, p1c)` is called once per flat piece,
@@ -98,26 +117,6 @@ SVGR_HD int flatten_cubic(const double* cubic, double thr, Emit&& emit) {
         }
     }
     return overflow ? -1 : n;
-}
-
-// the two halves separately (same dot4 rows as cubic_split)
-SVGR_HD void cubic_left(const double* c, double* l) {
-    for (int ax = 0; ax < 2; ++ax) {
-        double x0 = c[ax], x1 = c[2 + ax], x2 = c[4 + ax], x3 = c[6 + ax];
-        l[ax] = dot4(1.0, 0.0, 0.0, 0.0, x0, x1, x2, x3);
-        l[2 + ax] = dot4(0.5, 0.5, 0.0, 0.0, x0, x1, x2, x3);
-        l[4 + ax] = dot4(0.25, 0.5, 0.25, 0.0, x0, x1, x2, x3);
-        l[6 + ax] = dot4(0.125, 0.375, 0.375, 0.125, x0, x1, x2, x3);
-    }
-}
-SVGR_HD void cubic_right(const double* c, double* r) {
-    for (int ax = 0; ax < 2; ++ax) {
-        double x0 = c[ax], x1 = c[2 + ax], x2 = c[4 + ax], x3 = c[6 + ax];
-        r[ax] = dot4(0.125, 0.375, 0.375, 0.125, x0, x1, x2, x3);
-        r[2 + ax] = dot4(0.0, 0.25, 0.5, 0.25, x0, x1, x2, x3);
-        r[4 + ax] = dot4(0.0, 0.0, 0.5, 0.5, x0, x1, x2, x3);
-        r[6 + ax] = dot4(0.0, 0.0, 0.0, 1.0, x0, x1, x2, x3);
-    }
 }
 
 // Stack-free depth-first subdivision of the subtree under `root` (whose ancestors the caller has

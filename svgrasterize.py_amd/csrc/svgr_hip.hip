@@ -408,7 +408,10 @@ __global__ __launch_bounds__(256) void k_path_rows(const double* __restrict__ se
 // 32 lanes per segment.  Lane j owns the depth-5 node whose path bits are j (if the five ancestors
 // above it are not flat; an ancestor that is flat is emitted by the lane whose remaining bits are 0).
 // Per-path keys: {~key(min_r), ~key(min_c), key(max_r), key(max_c)}, all folded with atomicMax.
-constexpr int FL_SUB = 5;       // 32 lanes per segment: the longest lane bounds the kernel, so cut subtrees small
+#ifndef SVGR_FL_SUB
+#define SVGR_FL_SUB 5
+#endif
+constexpr int FL_SUB = SVGR_FL_SUB;       // 32 lanes per segment: the longest lane bounds the kernel, so cut subtrees small
 constexpr int FL_BLOCK = 256;     // waves are independent (no block-level step)
 template <bool EMIT>
 __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__ segs, const uint8_t* __restrict__ kind,
@@ -477,14 +480,27 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
     };
     int cnt = 0;
     bool ovf = false;
+    double q1r = 0.0, q1c = 0.0, q2r = 0.0, q2c = 0.0;
+#if defined(SVGR_DBG_FL) && SVGR_DBG_FL == 2
+    if (node[0] != 12345.678) mode = 0;
+#endif
+#if defined(SVGR_DBG_FL) && SVGR_DBG_FL == 3
+    if (node[0] != 12345.678) return;
+#endif
     if (mode == 1) {
         cnt = 1;
         track(node[0], node[1]);
         track(node[6], node[7]);
     } else if (mode == 2) {
-        cnt = flatten_subtree(node, thr, kMaxFlattenDepth - FL_SUB, [&](double r0, double c0, double r1, double c1) {
-            track(r0, c0);
+        // pieces come in curve order and share end points: track the first start and every end.  The ends of the
+        // first two pieces are remembered: nearly every lane has one or two, and then the second traversal is skipped.
+        int seen = 0;
+        track(node[0], node[1]);
+        cnt = flatten_subtree(node, thr, kMaxFlattenDepth - FL_SUB, [&](double, double, double r1, double c1) {
             track(r1, c1);
+            if (seen == 0) { q1r = r1; q1c = c1; }
+            else if (seen == 1) { q2r = r1; q2c = c1; }
+            ++seen;
         }, ovf);
     }
     if (ovf) atomicOr(&bd->err, 1);
@@ -501,6 +517,14 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
             double* e = edges + 4 * (size_t)base;
             e[0] = node[0]; e[1] = node[1]; e[2] = node[6]; e[3] = node[7];
             edge_path[base] = p;
+        } else if (cnt <= 2) {
+            double* e = edges + 4 * (size_t)base;
+            e[0] = node[0]; e[1] = node[1]; e[2] = q1r; e[3] = q1c;
+            edge_path[base] = p;
+            if (cnt == 2) {
+                e[4] = q1r; e[5] = q1c; e[6] = q2r; e[7] = q2c;
+                edge_path[base + 1] = p;
+            }
         } else {
             int i = 0;
             bool o2 = false;
@@ -521,6 +545,9 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
         mnr = a < mnr ? a : mnr; mnc = b < mnc ? b : mnc;
         mxr = c > mxr ? c : mxr; mxc = e > mxc ? e : mxc;
     }
+#if defined(SVGR_DBG_FL) && SVGR_DBG_FL == 1
+    if (mnr == 12345.678)
+#endif
     if (seg_ok && sub == 0 && mnr <= mxr) {
         unsigned long long* k = pkeys + 4 * (size_t)p;
         atomicMax(&k[0], ~f64_key(mnr));
