@@ -808,12 +808,20 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
     }
 }
 
+// One lane per edge; the lanes of a wave walk their rows in lockstep (one row per lane per turn) and every turn's
+// records leave through an LDS transpose: lane j then stores 16-byte chunk j of the turn's records, so that a
+// store instruction covers whole cache lines.  (Each lane storing its own 48-byte record made every dwordx4 store 64
+// separate partial-line writes, and the L2 request rate -- not bytes -- bounded the kernel.)
 __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ edges, const int* __restrict__ edge_path,
                                                    const int* __restrict__ bbox, const PathBin* __restrict__ bins,
                                                    int vr0, int pb_cap, const int* __restrict__ bseg_off,
                                                    int* __restrict__ pb_cursor, RowRec* __restrict__ recs, int rec_cap,
                                                    BatchDev* __restrict__ bd, Owner own, const EdgeShards sh) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    static_assert(REC_BYTES % 16 == 0, "records move as 16-byte chunks");
+    constexpr int CPR = REC_BYTES / 16;  // chunks per record
+    __shared__ uint4 s_stage[4][64 * CPR];
+    __shared__ int s_dest[4][64];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     EdgeSetup es;
     int p = 0, r0 = 0, key = -1, rows_first = 0;
     bool ok = edge_live(e, sh, bd) && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
@@ -838,35 +846,70 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
     int run_base = 0;
     if (ok && head == lane && run_end_incl > run_begin_excl) run_base = atomicAdd(&pb_cursor[key], run_end_incl - run_begin_excl);
     run_base = __shfl(run_base, head);
-    if (!ok) return;
+
     RowState st;
     st.x_next = es.x;
     st.x = es.x;
     st.d = 0.0;
-    int y = es.y_begin;
-    for (int b = 0; y < es.y_end; ++b) {
-        const int band = bf + b;
-        int ya, y1;
-        band_rows(es, band, vr0, r0, ya, y1);
-        const int pb = key + b;
-        if (!owns_band(own, band)) {  // another rank's band: only carry x across it
-            for (; y < y1; ++y) row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);
-            continue;
+    int y = ok ? es.y_begin : 0;
+    const int y_end = ok ? es.y_end : 0;
+    int band = bf - 1, band_end = y, slot = 0, band_row0 = 0;  // "end of band bf - 1": the first turn enters band bf
+    while (__ballot(y < y_end) != 0ull) {
+        bool has = false;
+        RowRec r;
+        int dest = 0;
+        if (y < y_end) {
+            while (y == band_end && y < y_end) {  // enter the next band
+                ++band;
+                int ya, y1;
+                band_rows(es, band, vr0, r0, ya, y1);
+                if (!owns_band(own, band)) {  // another rank's band: only carry x across it (S:2244-2248)
+                    for (; y < y1; ++y) row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);
+                    band_end = y;
+                    continue;
+                }
+                const int pb = key + (band - bf);
+                slot = bseg_off[pb] + 1 + (band == bf ? run_base + (excl - run_begin_excl) : atomicAdd(&pb_cursor[pb], y1 - ya));
+                band_end = y1;
+                band_row0 = band * TR + vr0 - r0;
+            }
+            if (y < y_end) {
+                row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);  // carry x exactly as S:2244-2248
+                const RowPieces rp = row_record(st.x, st.x_next, st.d);
+                unsigned n = (unsigned)rp.n;
+                if (n > SPAN_MAX) { atomicOr(&bd->err, 16); n = SPAN_MAX; }
+                r.x0i = rp.x0i;
+                r.nrow = n | ((unsigned)(y - band_row0) << 26);
+                r.v[0] = rp.v[0]; r.v[1] = rp.v[1]; r.v[2] = rp.v[2]; r.v[3] = rp.v[3]; r.v[4] = rp.v[4];
+                dest = slot;
+                has = slot < rec_cap;
+                if (!has) atomicOr(&bd->err, 8);
+                ++slot;
+                ++y;
+            }
         }
-        int slot = bseg_off[pb] + 1 + (b == 0 ? run_base + (excl - run_begin_excl) : atomicAdd(&pb_cursor[pb], y1 - ya));
-        const int band_row0 = band * TR + vr0 - r0;
-        for (; y < y1; ++y, ++slot) {
-            row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);  // carry x exactly as S:2244-2248
-            const RowPieces rp = row_record(st.x, st.x_next, st.d);
-            if (slot >= rec_cap) { atomicOr(&bd->err, 8); continue; }
-            unsigned n = (unsigned)rp.n;
-            if (n > SPAN_MAX) { atomicOr(&bd->err, 16); n = SPAN_MAX; }
-            RowRec r;
-            r.x0i = rp.x0i;
-            r.nrow = n | ((unsigned)(y - band_row0) << 26);
-            r.v[0] = rp.v[0]; r.v[1] = rp.v[1]; r.v[2] = rp.v[2]; r.v[3] = rp.v[3]; r.v[4] = rp.v[4];
-            recs[slot] = r;
+        // this turn's records, packed by lane rank, then out in 16-byte chunks: chunk j of the turn by lane j % 64
+        const unsigned long long m = __ballot(has);
+        const int n_rec = __popcll(m), rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (has) {
+            const uint4* src = (const uint4*)&r;
+#pragma unroll
+            for (int c = 0; c < CPR; ++c) s_stage[wave][rank * CPR + c] = src[c];
+            s_dest[wave][rank] = dest;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) {
+            const int j = c * 64 + lane;
+            if (j < n_rec * CPR) {
+                const int rr = j / CPR, part = j - rr * CPR;
+                ((uint4*)(recs + s_dest[wave][rr]))[part] = s_stage[wave][j];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
