@@ -718,93 +718,147 @@ static_assert(sizeof(TileEntry) == 32, "TileEntry is 32 bytes");
 // blocks are contiguous in HBM and in paint order.  The header (paint, fill rule, flags) is written here;
 // k_edge_emit fills the records behind it.
 constexpr int BE_BLOCK = 1024;
-constexpr int BE_KEEP = 4;   // paths per thread whose counts stay in registers between the two passes
+constexpr int BE_KEEP = 4;   // 64-path groups per wave whose counts stay in registers between the two passes
 __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __restrict__ bins, int n_paths,
-                                                           const int* __restrict__ bbox, const int* __restrict__ pb_cnt,
-                                                           const double* __restrict__ path_paint,
-                                                           const uint8_t* __restrict__ path_rule, int* __restrict__ bseg_off,
-                                                           RowRec* __restrict__ recs, int rec_cap,
-                                                           int* __restrict__ band_start, int* __restrict__ band_count,
-                                                           TileEntry* __restrict__ entries, int entry_cap,
-                                                           BatchDev* __restrict__ bd, Owner own) {
-    __shared__ int s_n[BE_BLOCK / 64], s_r[BE_BLOCK / 64];
+                                                              const int* __restrict__ bbox, const int* __restrict__ pb_cnt,
+                                                              const double* __restrict__ path_paint,
+                                                              const uint8_t* __restrict__ path_rule, int* __restrict__ bseg_off,
+                                                              RowRec* __restrict__ recs, int rec_cap,
+                                                              int* __restrict__ band_start, int* __restrict__ band_count,
+                                                              TileEntry* __restrict__ entries, int entry_cap,
+                                                              BatchDev* __restrict__ bd, Owner own) {
+    constexpr int NWV = BE_BLOCK / 64;
+    __shared__ int s_n[NWV], s_r[NWV];
     __shared__ int s_ent0, s_rec0, s_ok;
     const int band = owned_band_at(own, blockIdx.x), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // thread t owns the paths [t * per, (t + 1) * per): consecutive, so ONE block scan orders everything by path id
-    const int per = (n_paths + BE_BLOCK - 1) / BE_BLOCK;
-    const int p_lo = tid * per, p_hi = p_lo + per < n_paths ? p_lo + per : n_paths;
+    // Wave w owns the consecutive paths [w * chunk, (w + 1) * chunk), as `groups` groups of 64: lane l of group g has
+    // path w * chunk + g * 64 + l, so every load is coalesced and list order = (wave, group, lane).
+    const int groups = (n_paths + BE_BLOCK - 1) / BE_BLOCK, chunk = groups * 64;
+    const int p_wave = wave * chunk;
     auto pair_of = [&](int p, int& pair) -> int {  // records of path p in this band; 0: bbox does not reach it / no edge row
+        if (p >= n_paths) return 0;
         const PathBin pbin = bins[p];
         if (!(pbin.nb > 0 && band >= pbin.b0 && band < pbin.b0 + pbin.nb)) return 0;
         pair = pbin.pb_off + band - pbin.b0;
         return pb_cnt[pair];
     };
     int kcnt[BE_KEEP], kpair[BE_KEEP];
-    int my_n = 0, my_r = 0;
+    int my_n = 0, my_r = 0;  // this lane's entries / record slots, over all its groups
+    {
+        // the first BE_KEEP groups with every load of a stage in flight together (written with a branch per group, the
+        // compiler waits for each group's two dependent loads in turn: 2 * BE_KEEP round trips instead of 2)
+        PathBin kb[BE_KEEP];
 #pragma unroll
-    for (int k = 0; k < BE_KEEP; ++k) {
-        kcnt[k] = 0; kpair[k] = 0;
-        if (p_lo + k < p_hi) kcnt[k] = pair_of(p_lo + k, kpair[k]);
-        if (kcnt[k] > 0) { ++my_n; my_r += kcnt[k] + 1; }
+        for (int g = 0; g < BE_KEEP; ++g) {
+            const int p = p_wave + g * 64 + lane;
+            kb[g] = bins[g < groups && p < n_paths ? p : 0];
+        }
+        bool member[BE_KEEP];
+#pragma unroll
+        for (int g = 0; g < BE_KEEP; ++g) {
+            const int p = p_wave + g * 64 + lane;
+            member[g] = g < groups && p < n_paths && kb[g].nb > 0 && band >= kb[g].b0 && band < kb[g].b0 + kb[g].nb;
+            kpair[g] = member[g] ? kb[g].pb_off + band - kb[g].b0 : 0;
+        }
+#pragma unroll
+        for (int g = 0; g < BE_KEEP; ++g) kcnt[g] = pb_cnt[kpair[g]];  // unconditional: slot 0 always exists
+#pragma unroll
+        for (int g = 0; g < BE_KEEP; ++g) {
+            kcnt[g] = member[g] ? kcnt[g] : 0;
+            if (kcnt[g] > 0) { ++my_n; my_r += kcnt[g] + 1; }
+        }
     }
-    for (int p = p_lo + BE_KEEP; p < p_hi; ++p) {
+    for (int g = BE_KEEP; g < groups; ++g) {
         int pair;
-        const int c = pair_of(p, pair);
+        const int c = pair_of(p_wave + g * 64 + lane, pair);
         if (c > 0) { ++my_n; my_r += c + 1; }
     }
-    int wn, wr;
-    const int ex_n = wave_excl_scan(my_n, lane, wn), ex_r = wave_excl_scan(my_r, lane, wr);
+#if defined(SVGR_DBG_BE) && SVGR_DBG_BE == 3
+    if (band != 123456) return;
+#endif
+    int wn = my_n, wr = my_r;  // wave totals
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { wn += __shfl_xor(wn, d); wr += __shfl_xor(wr, d); }
     if (lane == 0) { s_n[wave] = wn; s_r[wave] = wr; }
     __syncthreads();
-    if (tid == 0) {
-        int tn = 0, trc = 0;
-        for (int w = 0; w < BE_BLOCK / 64; ++w) {
-            const int a = s_n[w], c = s_r[w];
-            s_n[w] = tn; s_r[w] = trc;
-            tn += a; trc += c;
+    if (wave == 0) {  // exclusive scan of the wave totals by one wave, then the band's two reservations
+        const int a = lane < NWV ? s_n[lane] : 0, c = lane < NWV ? s_r[lane] : 0;
+        int tn, trc;
+        const int ea = wave_excl_scan(a, lane, tn), ec = wave_excl_scan(c, lane, trc);
+        if (lane < NWV) { s_n[lane] = ea; s_r[lane] = ec; }
+        if (lane == 0) {
+            int e0 = tn ? atomicAdd(&bd->entry_cursor, tn) : 0;
+            int r0 = trc ? atomicAdd(&bd->bseg_cursor, trc) : 0;
+            int ok = 1;
+            if (e0 + tn > entry_cap) { atomicOr(&bd->err, 4); ok = 0; tn = 0; }
+            s_ent0 = e0; s_rec0 = r0; s_ok = ok;
+            band_start[band] = e0;
+            band_count[band] = tn;
         }
-        int e0 = tn ? atomicAdd(&bd->entry_cursor, tn) : 0;
-        int r0 = trc ? atomicAdd(&bd->bseg_cursor, trc) : 0;
-        int ok = 1;
-        if (e0 + tn > entry_cap) { atomicOr(&bd->err, 4); ok = 0; tn = 0; }
-        s_ent0 = e0; s_rec0 = r0; s_ok = ok;
-        band_start[band] = e0;
-        band_count[band] = tn;
     }
     __syncthreads();
     if (!s_ok) return;
-    int ent = s_ent0 + s_n[wave] + ex_n, rec = s_rec0 + s_r[wave] + ex_r;
-    auto put = [&](int p, int pair, int c) {
-        const int4 bb = ((const int4*)bbox)[p];
+#if defined(SVGR_DBG_BE) && SVGR_DBG_BE == 1
+    if (band != 123456) return;
+#endif
+    int ent = s_ent0 + s_n[wave], rec = s_rec0 + s_r[wave];  // running bases of the wave, advanced group by group
+    auto place = [&](int c, int& my_ent, int& my_rec) {  // all lanes of the wave, one group: this lane's entry / record block
+        int tn, trc;
+        my_ent = ent + wave_excl_scan(c > 0 ? 1 : 0, lane, tn);
+        my_rec = rec + wave_excl_scan(c > 0 ? c + 1 : 0, lane, trc);
+        ent += tn;
+        rec += trc;
+    };
+    auto store = [&](int p, int pair, int c, int my_ent, int my_rec, const int4 bb, const double4 pa, int rl) {
         TileEntry e;
         e.p = p; e.c0 = bb.y; e.cols = bb.w; e.r0 = bb.x; e.rows = bb.z;
-        e.seg0 = rec; e.cnt = c; e.pad = 0;
-        entries[ent] = e;
-        bseg_off[pair] = rec;
+        e.seg0 = my_rec; e.cnt = c; e.pad = 0;
+        entries[my_ent] = e;
+        bseg_off[pair] = my_rec;
+#if defined(SVGR_DBG_BE) && SVGR_DBG_BE == 2
+        if (band == 123456)
+#endif
         if (recs) {
-            if (rec + c < rec_cap) {
+            if (my_rec + c < rec_cap) {
                 PairHeader h;
-                const double4 pa = ((const double4*)path_paint)[p];
-                const int rl = path_rule[p];
                 h.paint[0] = pa.x; h.paint[1] = pa.y; h.paint[2] = pa.z; h.paint[3] = pa.w;
                 h.rule = rl & 1;
                 h.pad[0] = rl >> 1;  // SVGR_PATH_* flags
                 h.pad[1] = h.pad[2] = 0;
-                *(PairHeader*)(recs + rec) = h;
+                *(PairHeader*)(recs + my_rec) = h;
             } else {
                 atomicOr(&bd->err, 8);
             }
         }
-        ++ent;
-        rec += c + 1;
     };
+    // two groups at a time, so that their bbox / paint / rule loads are in flight together
+    static_assert(BE_KEEP % 2 == 0, "kept groups are written in pairs");
 #pragma unroll
-    for (int k = 0; k < BE_KEEP; ++k)
-        if (kcnt[k] > 0) put(p_lo + k, kpair[k], kcnt[k]);
-    for (int p = p_lo + BE_KEEP; p < p_hi; ++p) {
-        int pair;
+    for (int g = 0; g < BE_KEEP; g += 2) {
+        if (g >= groups) break;
+        int me[2], mr[2], rl[2] = {0, 0};
+        int4 bb[2] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
+        double4 pa[2] = {make_double4(0, 0, 0, 0), make_double4(0, 0, 0, 0)};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            place(kcnt[g + j], me[j], mr[j]);
+            const int p = p_wave + (g + j) * 64 + lane;
+            if (kcnt[g + j] > 0) {
+                bb[j] = ((const int4*)bbox)[p];
+                pa[j] = ((const double4*)path_paint)[p];
+                rl[j] = path_rule[p];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (kcnt[g + j] > 0) store(p_wave + (g + j) * 64 + lane, kpair[g + j], kcnt[g + j], me[j], mr[j], bb[j], pa[j], rl[j]);
+    }
+    for (int g = BE_KEEP; g < groups; ++g) {
+        int pair = 0, me, mr;
+        const int p = p_wave + g * 64 + lane;
         const int c = pair_of(p, pair);
-        if (c > 0) put(p, pair, c);
+        place(c, me, mr);
+        if (c > 0) store(p, pair, c, me, mr, ((const int4*)bbox)[p], ((const double4*)path_paint)[p], path_rule[p]);
     }
 }
 
