@@ -109,11 +109,14 @@ def cpu_baseline(sc, budget_paths: int | None = None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="synth4096")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-paths", type=int, default=None, help="limit the CPU baseline to the first N paths")
+    ap.add_argument("--time-every", type=int, default=4,
+                    help="bracket the stages of every n-th timed step with HIP events (each event drains the queue for ~8 us, "
+                         "so timing every step would slow the thing being measured)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -177,8 +180,9 @@ def main():
     barrier()
     batch.timings()  # drop
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.render(out, _abi.OUT_CANVAS_F32, flags | _abi.RENDER_TIMED)
+    every = max(1, args.time_every)
+    for i in range(args.steps):
+        batch.render(out, _abi.OUT_CANVAS_F32, flags | (_abi.RENDER_TIMED if i % every == 0 else 0))
     ctx.sync()
     t_local = time.perf_counter() - t0
     barrier()
@@ -242,10 +246,11 @@ def main():
             "roofline": {
                 "kernel": "k_tile_render<f32>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "avg_launch_ms": round(tile_ms, 4), "geometry_ms": round(geo_ms, 4),
+                "avg_launch_ms": round(tile_ms, 4), "geometry_ms": round(geo_ms, 4), "launches_timed": int(tm["n"]),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "note": "effective bandwidth: 40 B/path-pixel + 32 B/edge (SURVEY 8d) over the HIP-event duration of the "
-                        "tile kernel; the kernel keeps trace and canvas on chip, so frac may exceed what real HBM traffic could",
+                        "tile kernel (events on the library's stream around every %d-th launch of the timed region); the kernel "
+                        "keeps trace and canvas on chip, so frac may exceed what real HBM traffic could" % every,
             },
         }
         if gather_ms is not None:

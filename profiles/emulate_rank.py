@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--strip", type=int, default=int(os.environ.get("SVGR_STRIP_BANDS", "16")))
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--workload", default="synth4096")
+    ap.add_argument("--timed", action="store_true")
     args = ap.parse_args()
 
     import bench
@@ -49,11 +50,14 @@ def main():
         ctx.sync()
         batch.timings()
         t0 = time.perf_counter()
+        fl = _abi.RENDER_CLIP01 | (_abi.RENDER_TIMED if args.timed else 0)
         for _ in range(args.steps):
-            batch.render(out, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01 | _abi.RENDER_TIMED)
+            batch.render(out, _abi.OUT_CANVAS_F32, fl)
         ctx.sync()
         dt = (time.perf_counter() - t0) / args.steps * 1e3
         tm = batch.timings()
+        if not args.timed:
+            tm = dict(n=1, ms_geometry=0.0, ms_tile=0.0)
         res.append(dict(rank=rank, ms_step=round(dt, 4), ms_geometry=round(tm["ms_geometry"] / tm["n"], 4),
                         ms_tile=round(tm["ms_tile"] / tm["n"], 4), edges=int(st.n_edges), records=int(st.n_band_segs)))
         del out
