@@ -248,6 +248,11 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
     return x - v;
 }
 
+// number of set bits of `m` below the calling lane (v_mbcnt: no 64-bit lane mask to keep in registers)
+__device__ __forceinline__ int mask_rank(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 // every lane of the wave must call this; reserves `n` consecutive slots for the calling lane with a
 // single atomic per wave and returns the lane's first slot
 __device__ __forceinline__ int wave_alloc(int* cursor, int n, int lane) {
@@ -944,7 +949,7 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
         }
         // this turn's records, packed by lane rank, then out in 16-byte chunks: chunk j of the turn by lane j % 64
         const unsigned long long m = __ballot(has);
-        const int n_rec = __popcll(m), rank = __popcll(m & ((1ull << lane) - 1ull));
+        const int n_rec = __popcll(m), rank = mask_rank(m);
         if (has) {
             const uint4* src = (const uint4*)&r;
 #pragma unroll
@@ -1074,7 +1079,7 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
             if (w < wave) off += s_wcnt[w];
             total_all += s_wcnt[w];
         }
-        const int slot = off + __popcll(m & ((1ull << lane) - 1ull));  // rank of this lane's path among the hits
+        const int slot = off + mask_rank(m);  // rank of this lane's path among the hits
         // the hits are worked off LCAP at a time (small LDS lists: more resident workgroups)
         for (int lo = 0; lo < total_all; lo += LCAP) {
         const int total = total_all - lo < LCAP ? total_all - lo : LCAP;
@@ -1360,7 +1365,11 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
         const int row = band * TR + trow;  // viewport-local row
         const int out_row = (int)blockIdx.y * TR + trow;
         if (row < a.vrows) {
-            const int col0 = (int)blockIdx.x * TC + chunk * PX;
+            // (the lane's chunk is recomputed from the thread id here: kept live across the main loop it costs a VGPR
+            // that the register budget does not have, i.e. a scratch spill in every workgroup)
+            int tid2 = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid2));
+            const int col0 = (int)blockIdx.x * TC + (tid2 % CH) * PX;
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
                 if (col0 + i < a.vcols) {
