@@ -1,23 +1,24 @@
 // svgr_hip.hip -- MI355X (gfx950 / CDNA4) anti-aliased path rasterizer: HIP kernels + C ABI.
 //
-// Pipeline of one svgr_batch_render (8 launches on the context stream, no host read-back):
+// Pipeline of one svgr_batch_render (1 memset + 6 launches on the context stream, no host read-back):
 //
 //   memset          one zero-fill of the batch's counter arena
-//   k_flatten       8 lanes per segment: transform (fma form), stack-free adaptive subdivision,
-//                   count -> wave prefix -> ONE atomic per wave reserves the edge slots -> subdivide
-//                   again and store; endpoints folded into per-path min/max keys
+//   [k_path_rows]   multi-GPU only: rows each path's control-point hull can reach (foreign paths are skipped)
+//   k_flatten       32 lanes per segment: transform (fma form), stack-free adaptive subdivision,
+//                   count -> wave prefix -> ONE reservation per wave in one of 16 edge-cursor shards ->
+//                   store the pieces; endpoints folded into per-path min/max keys
 //   k_path_bbox     per path: integer bbox (floor-1 / ceil+1, clipped to the viewport), band range,
 //                   wave-aggregated reservation of its (path, band) pair slots
-//   k_edge_count    per edge: which 16-row bands it crosses -> per-pair counts (run-aggregated atomics)
-//   k_alloc         per pair: wave-aggregated reservation of its band-segment slots
-//   k_edge_emit     per edge: walk its rows with the reference's x recurrence, cut a record at
-//                   every band entry (so a tile never has to replay rows above it)
-//   k_band_entries  per band: ordered list of the paths whose bbox covers it
-//   k_tile_render   one workgroup per 16x128 canvas tile, canvas tile resident in registers as
-//                   double RGBA; per covering path in paint order: scatter the band segments'
-//                   signed-area pieces into an LDS delta tile (ds_add_f64), row prefix sum
-//                   (8 px per lane serial + DPP row scan across the 16 lanes of a row), fill rule,
-//                   paint, source-over; one store of the finished tile (float32 or double)
+//   k_edge_count    per edge: which 8-row bands it crosses -> per-pair record counts (run-aggregated atomics)
+//   k_band_entries  per band: ordered tile list of the pairs with records, reservation of their record
+//                   blocks (contiguous per band), pair headers (paint, fill rule)
+//   k_edge_emit     per edge: walk its rows with the reference's x recurrence; one 48-byte record per
+//                   row with the closed-form signed-area pieces, stored through an LDS transpose
+//   k_tile_render   one 128-thread workgroup per 8x128 canvas tile, canvas tile resident in registers as
+//                   double RGBA; per covering path in paint order: record block by LDS-DMA, scatter the
+//                   pieces into an LDS delta tile (ds_add_f64), row prefix sum (8 px per lane serial +
+//                   DPP row scan across the 16 lanes of a row), fill rule, paint, source-over; one
+//                   store of the finished tile (float32 or double)
 //
 // There is no dense contraction anywhere in this path: no MFMA.  The heavy traffic (delta tile,
 // canvas tile) never leaves the CU; HBM sees the edge records and one canvas store.
@@ -263,26 +264,6 @@ __device__ __forceinline__ int wave_alloc(int* cursor, int n, int lane) {
     return __shfl(base, 0) + excl;
 }
 
-// Block-level form for 1024-thread blocks: one atomic per BLOCK (a hot word serves only ~90 returning
-// atomics per microsecond chip-wide, so per-wave reservations of a big launch would serialise).
-// Every thread of the block must call this.
-__device__ __forceinline__ int block_alloc(int* cursor, int n, int* s_tot /* >= 17 ints of LDS */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    int total;
-    int excl = wave_excl_scan(n, lane, total);
-    if (lane == 0) s_tot[wave] = total;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int sum = 0;
-        for (int w = 0; w < nwaves; ++w) { int t = s_tot[w]; s_tot[w] = sum; sum += t; }
-        s_tot[16] = sum > 0 ? atomicAdd(cursor, sum) : 0;
-    }
-    __syncthreads();
-    int base = s_tot[16] + s_tot[wave] + excl;
-    __syncthreads();
-    return base;
-}
-
 // Runs of consecutive active lanes with equal keys.  For an active lane: `head` = first lane of its
 // run, `len` = length of the run.  Every lane of the wave must call this.
 __device__ __forceinline__ void wave_runs(int key, bool active, int lane, int& head, int& len) {
@@ -486,12 +467,6 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
     int cnt = 0;
     bool ovf = false;
     double q1r = 0.0, q1c = 0.0, q2r = 0.0, q2c = 0.0;
-#if defined(SVGR_DBG_FL) && SVGR_DBG_FL == 2
-    if (node[0] != 12345.678) mode = 0;
-#endif
-#if defined(SVGR_DBG_FL) && SVGR_DBG_FL == 3
-    if (node[0] != 12345.678) return;
-#endif
     if (mode == 1) {
         cnt = 1;
         track(node[0], node[1]);
@@ -550,9 +525,6 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
         mnr = a < mnr ? a : mnr; mnc = b < mnc ? b : mnc;
         mxr = c > mxr ? c : mxr; mxc = e > mxc ? e : mxc;
     }
-#if defined(SVGR_DBG_FL) && SVGR_DBG_FL == 1
-    if (mnr == 12345.678)
-#endif
     if (seg_ok && sub == 0 && mnr <= mxr) {
         unsigned long long* k = pkeys + 4 * (size_t)p;
         atomicMax(&k[0], ~f64_key(mnr));
@@ -778,9 +750,6 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
         const int c = pair_of(p_wave + g * 64 + lane, pair);
         if (c > 0) { ++my_n; my_r += c + 1; }
     }
-#if defined(SVGR_DBG_BE) && SVGR_DBG_BE == 3
-    if (band != 123456) return;
-#endif
     int wn = my_n, wr = my_r;  // wave totals
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { wn += __shfl_xor(wn, d); wr += __shfl_xor(wr, d); }
@@ -803,9 +772,6 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
     }
     __syncthreads();
     if (!s_ok) return;
-#if defined(SVGR_DBG_BE) && SVGR_DBG_BE == 1
-    if (band != 123456) return;
-#endif
     int ent = s_ent0 + s_n[wave], rec = s_rec0 + s_r[wave];  // running bases of the wave, advanced group by group
     auto place = [&](int c, int& my_ent, int& my_rec) {  // all lanes of the wave, one group: this lane's entry / record block
         int tn, trc;
@@ -820,9 +786,6 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
         e.seg0 = my_rec; e.cnt = c; e.pad = 0;
         entries[my_ent] = e;
         bseg_off[pair] = my_rec;
-#if defined(SVGR_DBG_BE) && SVGR_DBG_BE == 2
-        if (band == 123456)
-#endif
         if (recs) {
             if (my_rec + c < rec_cap) {
                 PairHeader h;
