@@ -200,14 +200,18 @@ def main():
         # optional assembly of the full canvas on every rank (svgrasterize.py_amd/dist.py), reported separately
         from svgrasterize_amd import dist as sdist
 
-        dist.barrier()
-        torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        for _ in range(3):
-            full_t = sdist.gather_canvas(out_t if coll_dev != "cpu" else out_t.cpu(), rows, _abi.tile_rows(), strip=strip)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) / 3 * 1e3
-        del full_t
+        try:  # (reported separately; a failure here must not cost the bench line)
+            dist.barrier()
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            for _ in range(3):
+                full_t = sdist.gather_canvas(out_t if coll_dev != "cpu" else out_t.cpu(), rows, _abi.tile_rows(), strip=strip)
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - g0) / 3 * 1e3
+            del full_t
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] rank {rank}: strip all_gather failed: {exc!r}", file=sys.stderr)
+            gather_ms = None
 
     if rank == 0:
         ms_step = t_max / args.steps * 1e3
