@@ -216,6 +216,34 @@ int svgr_gradient_fill(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* ma
 int svgr_layer_convolve(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, const double* kernel,
                         int64_t kw, int64_t kh);
 
+/* -------------------------------------------------------------------------------------------- */
+/* Path.stroke (S:1105-1180), host side: stroke outline of a path as a fill path.               */
+/* Input and output use the reference's segment codes (S:865-872) with 8 doubles per segment    */
+/* (points interleaved x, y; unused slots 0) and per-subpath segment counts, the layout of       */
+/* Path.from_segments.  Quadratic / arc segments must be converted to cubics by the caller      */
+/* (bezier2_to_bezier3 S:2182, arc_to_bezier3 S:2355, exactly as Path.stroke does, S:1133-1140). */
+/* Offsetting: line_offset S:2328, bezier3_offset S:2113-2179; joins S:1495-1522 (miter limit 4), */
+/* caps S:1466-1492.  Output segments are LINE (2 points), QUAD (3, round joins) or CUBIC (4).   */
+/* -------------------------------------------------------------------------------------------- */
+#define SVGR_PATH_LINE 0
+#define SVGR_PATH_QUAD 1
+#define SVGR_PATH_CUBIC 2
+#define SVGR_PATH_ARC 3
+#define SVGR_PATH_CLOSED 4
+#define SVGR_PATH_UNCLOSED 5
+#define SVGR_CAP_BUTT 0    /* STROKE_CAP_BUTT (default, S:1468) */
+#define SVGR_CAP_ROUND 1
+#define SVGR_CAP_SQUARE 2
+#define SVGR_JOIN_MITER 0  /* STROKE_JOIN_MITER (default, S:1497) */
+#define SVGR_JOIN_ROUND 1
+#define SVGR_JOIN_BEVEL 2
+typedef struct svgr_stroke_out svgr_stroke_out;
+int svgr_path_stroke(const int32_t* seg_types, const double* seg_params, const int32_t* subpath_sizes, int64_t n_subpaths,
+                     double width, int linecap, int linejoin, svgr_stroke_out** out);
+int svgr_stroke_out_counts(const svgr_stroke_out* s, int64_t* n_segs, int64_t* n_subpaths);
+int svgr_stroke_out_copy(const svgr_stroke_out* s, int32_t* seg_types, double* seg_params, int32_t* subpath_sizes);
+void svgr_stroke_out_free(svgr_stroke_out* s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -622,6 +622,82 @@ def gen_scene(ref, fonts, name, svg, width, small_scales, full, crop=None, store
     save(f"scene_{name}.npz", **out)
 
 
+
+def pack_segments(ref, path):
+    """(types, params (n, 8), subpath sizes) of a reference Path: the format Path.from_segments reads."""
+    segt, segp, subs = [], [], []
+    for sub in path.subpaths:
+        subs.append(len(sub))
+        for seg in sub:
+            segt.append(seg[0])
+            if seg[0] == ref.PATH_ARC:
+                center, rx, ry, phi, eta, eta_delta = seg[1]
+                segp.append(np.array([center[0], center[1], rx, ry, phi, eta, eta_delta, 0.0]))
+            else:
+                p = np.asarray(seg[1], dtype=np.float64).ravel()
+                segp.append(np.concatenate([p, np.zeros(8 - p.size)]))
+    return (np.array(segt, dtype=np.int32), np.array(segp, dtype=np.float64).reshape(-1, 8),
+            np.array(subs, dtype=np.int32))
+
+
+def gen_stroke(ref, tiger_scene) -> None:
+    """Path.stroke known answers (S:1105-1180): input segments, width, cap, join -> stroked segments.
+    Hand-written shapes for every cap x join, degenerate pieces, quads, arcs, the cusp the reference special-cases
+    (S:2171), and every STROKE node of the tiger with its own width / cap / join."""
+    caps = [None, ref.STROKE_CAP_BUTT, ref.STROKE_CAP_ROUND, ref.STROKE_CAP_SQUARE]
+    joins = [None, ref.STROKE_JOIN_MITER, ref.STROKE_JOIN_ROUND, ref.STROKE_JOIN_BEVEL]
+    shapes = {
+        "polyline": "M10,10 L50,12 L60,40 L20,55",
+        "polygon": "M10,10 L50,12 L60,40 L20,55 Z",
+        "sharp": "M5,5 L60,8 L8,12",                      # beyond the miter limit
+        "collinear": "M0,0 L10,0 L20,0 L20,15",
+        "zero_len": "M3,3 L3,3 L9,7 L9,7 L14,2",
+        "cubic_s": "M10,80 C40,10 65,10 95,80 S150,150 180,80",
+        "cusp": "M0,0 C100,50 0,50 100,0",
+        "loop": "M10,10 C90,90 90,10 10,90",
+        "quad": "M10,80 Q52.5,10 95,80 T180,80",
+        "circle_arcs": "M50,10 A40,40 0 1 1 49.9,10 Z",
+        "ellipse_arc": "M10,50 A30,15 30 0 1 70,40",
+        "closed_cubic": "M20,20 C60,0 100,40 80,80 C60,120 0,100 20,20 Z",
+        "two_subpaths": "M0,0 L30,0 L30,30 Z M50,5 C70,5 70,35 50,35",
+        "tiny": "M0,0 L1e-9,0 L5,5",
+    }
+    cases = []
+    for name, d in shapes.items():
+        path = ref.Path.from_svg(d)
+        for ci, cap in enumerate(caps):
+            for ji, join in enumerate(joins):
+                if name not in ("polyline", "cubic_s", "two_subpaths") and (ci + ji) % 3 != 0:
+                    continue  # the full cap x join grid on three shapes, a diagonal on the rest
+                for width in (1.0, 7.5):
+                    cases.append((f"{name}/{cap}/{join}/{width}", path, width, cap, join))
+
+    def walk(scene):
+        t, a = scene
+        if t == ref.RENDER_STROKE:
+            yield a
+        elif t == ref.RENDER_GROUP:
+            for ch in a:
+                yield from walk(ch)
+        elif t in (ref.RENDER_OPACITY, ref.RENDER_CLIP, ref.RENDER_MASK, ref.RENDER_TRANSFORM, ref.RENDER_FILTER):
+            yield from walk(a[0])
+
+    for k, (path, _paint, width, cap, join) in enumerate(walk(tiger_scene.scene if hasattr(tiger_scene, "scene") else tiger_scene)):
+        cases.append((f"tiger{k}", path, float(width), cap, join))
+
+    out, meta = {}, []
+    for idx, (name, path, width, cap, join) in enumerate(cases):
+        it, ip, isub = pack_segments(ref, path)
+        res = path.stroke(width, cap, join)
+        ot, op, osub = pack_segments(ref, res)
+        out[f"{idx}_it"], out[f"{idx}_ip"], out[f"{idx}_is"] = it, ip, isub
+        out[f"{idx}_ot"], out[f"{idx}_op"], out[f"{idx}_os"] = ot, op, osub
+        meta.append(dict(name=name, width=width, cap=cap, join=join))
+    out["meta"] = np.array(json.dumps(meta))
+    save("stroke_kat.npz", **out)
+    print(f"  stroke: {len(cases)} cases, {sum(len(out[f'{i}_ot']) for i in range(len(cases)))} output segments")
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also render the full-size configs (slow)")
@@ -637,6 +713,9 @@ def main() -> None:
     if todo("flatten"):
         tiger, _, _ = ref.svg_scene_from_filepath(os.path.join(DEMO, "icons/tiger.svg"), width=2048, fonts=fonts)
         gen_flatten(ref, tiger)
+    if todo("stroke"):
+        tiger, _, _ = ref.svg_scene_from_filepath(os.path.join(DEMO, "icons/tiger.svg"), width=2048, fonts=fonts)
+        gen_stroke(ref, tiger)
     if todo("mask"):
         gen_mask(ref)
     if todo("compose"):

@@ -97,6 +97,10 @@ _PROTOS = {
     "svgr_layer_to_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int]),
     "svgr_gradient_fill": (C.c_int, [_P, C.POINTER(Gradient), _P, _P, _P]),
     "svgr_layer_convolve": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64]),
+    "svgr_path_stroke": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, C.c_int, C.c_int, C.POINTER(_P)]),
+    "svgr_stroke_out_counts": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "svgr_stroke_out_copy": (C.c_int, [_P, _P, _P, _P]),
+    "svgr_stroke_out_free": (None, [_P]),
 }
 EXPORTS = tuple(_PROTOS)
 
@@ -301,3 +305,28 @@ class Batch:
         tot, geo, tile = C.c_double(), C.c_double(), C.c_double()
         _check(self.ctx.lib.svgr_batch_timings(self.handle, C.byref(n), C.byref(tot), C.byref(geo), C.byref(tile)))
         return dict(n=n.value, ms_total=tot.value, ms_geometry=geo.value, ms_tile=tile.value)
+
+
+def path_stroke(seg_types, seg_params, subpath_sizes, width: float, linecap: int, linejoin: int):
+    """svgr_path_stroke (host C++, no GPU involved): (types, params (n, 8), sizes) of the stroke outline."""
+    lib = load_library()
+    seg_types = np.ascontiguousarray(seg_types, dtype=np.int32)
+    seg_params = np.ascontiguousarray(seg_params, dtype=np.float64).reshape(-1, 8)
+    subpath_sizes = np.ascontiguousarray(subpath_sizes, dtype=np.int32)
+    if int(subpath_sizes.sum()) != len(seg_types) or len(seg_params) != len(seg_types):
+        raise ValueError("segment arrays do not match the subpath sizes")
+    out = _P()
+    rc = lib.svgr_path_stroke(seg_types.ctypes.data_as(_P), seg_params.ctypes.data_as(_P), subpath_sizes.ctypes.data_as(_P),
+                              len(subpath_sizes), float(width), int(linecap), int(linejoin), C.byref(out))
+    if rc != 0:
+        raise ValueError(f"svgr_path_stroke failed ({rc}): unsupported segment type or bad cap / join")
+    try:
+        n, ns = C.c_int64(), C.c_int64()
+        lib.svgr_stroke_out_counts(out, C.byref(n), C.byref(ns))
+        types = np.empty(n.value, dtype=np.int32)
+        params = np.empty((n.value, 8), dtype=np.float64)
+        sizes = np.empty(ns.value, dtype=np.int32)
+        lib.svgr_stroke_out_copy(out, types.ctypes.data_as(_P), params.ctypes.data_as(_P), sizes.ctypes.data_as(_P))
+    finally:
+        lib.svgr_stroke_out_free(out)
+    return types, params, sizes

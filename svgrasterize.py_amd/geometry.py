@@ -25,6 +25,8 @@ PATH_LINE, PATH_QUAD, PATH_CUBIC, PATH_ARC, PATH_CLOSED, PATH_UNCLOSED = 0, 1, 2
 PATH_LINES = {PATH_LINE, PATH_CLOSED, PATH_UNCLOSED}
 PATH_FILL_NONZERO = "nonzero"
 PATH_FILL_EVENODD = "evenodd"
+STROKE_JOIN_MITER, STROKE_JOIN_ROUND, STROKE_JOIN_BEVEL = "miter", "round", "bevel"  # S:876-878
+STROKE_CAP_BUTT, STROKE_CAP_ROUND, STROKE_CAP_SQUARE = "butt", "round", "square"      # S:879-881
 _RULES = {None: 0, PATH_FILL_NONZERO: 0, PATH_FILL_EVENODD: 1}
 
 FLATNESS = 0.1  # S:955
@@ -349,6 +351,44 @@ class Path:
         return None
 
     # -- convenience ------------------------------------------------------------------------
+    def stroke(self, width: float, linecap: str | None = None, linejoin: str | None = None) -> "Path":
+        """Convert the path to its stroke outline, a fill path (Path.stroke, S:1105-1180).  The work is done by
+        the native stroker (csrc/svgr_stroke.cpp); quadratic and arc segments are turned into cubics first with the
+        same conversions the reference applies (S:1133-1140)."""
+        caps = {None: 0, STROKE_CAP_BUTT: 0, STROKE_CAP_ROUND: 1, STROKE_CAP_SQUARE: 2}
+        joins = {None: 0, STROKE_JOIN_MITER: 0, STROKE_JOIN_ROUND: 1, STROKE_JOIN_BEVEL: 2}
+        if linecap not in caps:
+            raise ValueError(f"unkown line cap type: `{linecap}`")
+        if linejoin not in joins:
+            raise ValueError(f"unknown line join type: `{linejoin}`")
+        types, params, sizes = [], [], []
+        for sub in self.subpaths:
+            if not sub:
+                continue
+            n0 = len(types)
+            for seg in sub:
+                t = seg[0]
+                if t in PATH_LINES:
+                    types.append(t)
+                    params.append(np.concatenate([np.asarray(seg[1], dtype=FLOAT).reshape(4), np.zeros(4)]))
+                elif t == PATH_CUBIC:
+                    types.append(PATH_CUBIC)
+                    params.append(np.asarray(seg[1], dtype=FLOAT).reshape(8))
+                elif t == PATH_QUAD:
+                    types.append(PATH_CUBIC)
+                    params.append(quad_to_cubic(seg[1]).reshape(8))
+                elif t == PATH_ARC:
+                    for c in arc_to_cubics(*seg[1]):
+                        types.append(PATH_CUBIC)
+                        params.append(c.reshape(8))
+                else:
+                    raise ValueError(f"unsupported path type: `{t}`")
+            sizes.append(len(types) - n0)
+        if not types:
+            return Path([])
+        ot, op, osz = _abi.path_stroke(types, np.array(params), sizes, width, caps[linecap], joins[linejoin])
+        return Path.from_segments(ot, op, osz)
+
     @classmethod
     def from_svg(cls, d: str) -> "Path":
         from .pathdata import parse_path_data  # noqa: PLC0415

@@ -11,8 +11,8 @@ routes, both of them HIP:
   into device-resident Layers and merged with ``Layer.compose`` exactly as the reference does.
 
 Gradient fills and feGaussianBlur (config 5) go through the per-node route (`paint.py`, `filters.py`).
-Not built: STROKE of an un-stroked path (scene dumps carry the stroked outline instead),
-luminance MASK, the other filter primitives, pattern paints.
+STROKE nodes are stroked by the native stroker (`Path.stroke`, csrc/svgr_stroke.cpp) and then treated as fills.
+Not built: luminance MASK, the other filter primitives, pattern paints.
 """
 from __future__ import annotations
 
@@ -81,11 +81,12 @@ class Scene(tuple):
                 return path.mask(transform, fill_rule=fill_rule, viewport=viewport)
             return path.fill(transform, paint, fill_rule=fill_rule, viewport=viewport, linear_rgb=linear_rgb)
 
-        if kind == RENDER_STROKE:
-            raise NotImplementedError(
-                "Path.stroke is not part of the accelerated path yet (SURVEY 8f-1); "
-                "scene dumps store the stroked outline as a FILL node"
-            )
+        if kind == RENDER_STROKE:  # S:666-672: stroke outline (native stroker), then an ordinary fill
+            path, paint, width, linecap, linejoin = args
+            stroke = path.stroke(width, linecap, linejoin)
+            if mask_only:
+                return stroke.mask(transform, viewport=viewport)
+            return stroke.fill(transform, paint, viewport=viewport, linear_rgb=linear_rgb)
 
         if kind == RENDER_GROUP:
             layers, hulls = [], []
@@ -163,6 +164,23 @@ class Scene(tuple):
         return _batchable_leaves(self, transform, linear_rgb)
 
 
+_STROKE_CACHE: dict = {}
+
+
+def _stroked(scene: Scene) -> Path:
+    """Outline of a STROKE node, computed once per node object (strokes do not depend on the transform, S:668)."""
+    key = id(scene)
+    hit = _STROKE_CACHE.get(key)
+    if hit is not None and hit[0] is scene:
+        return hit[1]
+    path, _paint, width, linecap, linejoin = scene[1]
+    out = path.stroke(width, linecap, linejoin)
+    if len(_STROKE_CACHE) > 4096:
+        _STROKE_CACHE.clear()
+    _STROKE_CACHE[key] = (scene, out)
+    return out
+
+
 def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opacity: float | None = None):
     """[(path, m6, rule, paint4)] when `scene` is only GROUP / TRANSFORM / solid FILL /
     OPACITY-directly-over-a-leaf; None otherwise.  Source-over is associative, so flattening
@@ -180,13 +198,16 @@ def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opac
         if opacity is not None:
             p4 = p4 * opacity  # Layer.opacity: image * opacity (S:174)
         return [(path, transform.m6(), _RULES[rule], p4, 0)]
+    if kind == RENDER_STROKE:  # a solid stroke is a solid fill of its outline (S:666-672), nonzero rule
+        path, paint, width, linecap, linejoin = args
+        return _batchable_leaves(Scene.fill(_stroked(scene), paint, None), transform, linear_rgb, opacity)
     if kind == RENDER_TRANSFORM:
         return _batchable_leaves(args[0], transform @ args[1], linear_rgb, opacity)
     if kind == RENDER_OPACITY and opacity is None:
         target = args[0]
         while target[0] == RENDER_TRANSFORM:
             target = target[1][0]
-        if target[0] == RENDER_FILL:  # opacity over a single leaf commutes with the fill
+        if target[0] in (RENDER_FILL, RENDER_STROKE):  # opacity over a single leaf commutes with the fill
             return _batchable_leaves(args[0], transform, linear_rgb, args[1])
         return None
     if kind == RENDER_CLIP and opacity is None and not args[2]:
