@@ -46,8 +46,22 @@ def main():
             ctx.sync()
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
-        print(json.dumps({"scene": desc, "canvas": [h, w], "render_s": round(best, 4),
-                          "canvas_mpix_per_s": round(h * w / best / 1e6, 1)}))
+        rec = {"scene": desc, "canvas": [h, w], "render_s": round(best, 4), "canvas_mpix_per_s": round(h * w / best / 1e6, 1)}
+        if name in ("tiger", "material"):
+            # output stage: straight-alpha sRGB + 8-bit quantisation on the device, bytes to the host,
+            # then the PNG container (zlib) on the host
+            full = S.Layer.compose([S.Layer(np.zeros((h, w, 4)), (0, 0), True, False), layer], S.COMPOSE_OVER, linear_rgb=False)
+            full._device()
+            ctx.sync()
+            t0 = time.perf_counter()
+            u8 = full.to_rgba8()
+            rec["to_rgba8_s"] = round(time.perf_counter() - t0, 4)
+            for lvl in (9, 1):
+                t0 = time.perf_counter()
+                n = len(S.canvas_to_png(u8, level=lvl).getvalue())
+                rec[f"png_zlib{lvl}_s"] = round(time.perf_counter() - t0, 3)
+                rec[f"png_zlib{lvl}_bytes"] = n
+        print(json.dumps(rec))
 
 
 if __name__ == "__main__":

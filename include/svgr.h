@@ -190,6 +190,11 @@ int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst_f32, const svgr_buf* src_f64,
 /* -------------------------------------------------------------------------------------------- */
 /* gradient paint servers and Gaussian blur (config 5)                                          */
 /* -------------------------------------------------------------------------------------------- */
+/* Output stage (canvas_to_png, S:262): dst(n_px x 4 uint8) = round-half-even(src(n_px x 4 double) * 255), the
+ * quantisation the reference applies to Layer.convert(pre_alpha=False, linear_rgb=False).image before zlib
+ * (S:209-213).  Values outside [0, 255] saturate.  The PNG container itself is written on the host.      */
+int svgr_layer_to_rgba8(svgr_ctx* ctx, svgr_buf* dst_u8, const svgr_buf* src_f64, int64_t n_px);
+
 /* Path.fill, gradient branch (S:1021-1047): out(rows, cols, 4) = gradient(pixel centre) * mask(rows, cols),
  * GradLinear.fill S:1553-1563, GradRadial.fill S:1577-1650, grad_spread S:1661-1668, grad_interpolate
  * S:1671-1683.  The host supplies what the reference computes once per fill with numpy: the inverse

@@ -698,6 +698,35 @@ def gen_stroke(ref, tiger_scene) -> None:
     print(f"  stroke: {len(cases)} cases, {sum(len(out[f'{i}_ot']) for i in range(len(cases)))} output segments")
 
 
+
+def gen_png(ref) -> None:
+    """Output stage known answers (Layer.write_png S:209-213, canvas_to_png S:249-274): layer (image, flags) ->
+    the uint8 array the reference hands to zlib and the PNG bytes it writes."""
+    rng = np.random.default_rng(20240917)
+    out, meta = {}, []
+    cases = []
+    for k, (shape, pre, lin) in enumerate([((5, 7), True, False), ((16, 9), True, True), ((12, 12), False, False),
+                                            ((9, 20), False, True), ((64, 48), True, False)]):
+        a = rng.uniform(0, 1, shape + (1,))
+        a[rng.uniform(0, 1, shape + (1,)) < 0.2] = 0.0
+        rgb = rng.uniform(0, 1, shape + (3,))
+        img = np.concatenate([rgb * a if pre else rgb, a], axis=-1)
+        if k == 0:
+            img[0, 0] = [0.5 / 255 * 0.4, 1.5 / 255 * 0.4, 2.5 / 255 * 0.4, 0.4]  # ties of the rounding after un-premultiply
+        cases.append((img, pre, lin))
+    for idx, (img, pre, lin) in enumerate(cases):
+        layer = ref.Layer(img, (3, 4), pre_alpha=pre, linear_rgb=lin)
+        conv = layer.convert(pre_alpha=False, linear_rgb=False)
+        u8 = np.round(conv.image * 255.0).astype(np.uint8)
+        png = layer.write_png().getvalue()
+        out[f"{idx}_image"] = img
+        out[f"{idx}_u8"] = u8
+        out[f"{idx}_png"] = np.frombuffer(png, dtype=np.uint8)
+        meta.append(dict(pre_alpha=pre, linear_rgb=lin))
+    out["meta"] = np.array(json.dumps(meta))
+    save("png_kat.npz", **out)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also render the full-size configs (slow)")
@@ -716,6 +745,8 @@ def main() -> None:
     if todo("stroke"):
         tiger, _, _ = ref.svg_scene_from_filepath(os.path.join(DEMO, "icons/tiger.svg"), width=2048, fonts=fonts)
         gen_stroke(ref, tiger)
+    if todo("png"):
+        gen_png(ref)
     if todo("mask"):
         gen_mask(ref)
     if todo("compose"):

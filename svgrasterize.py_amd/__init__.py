@@ -12,7 +12,7 @@ from .geometry import (  # noqa: F401
     PATH_FILL_NONZERO, PATH_FILL_EVENODD,
 )
 from .layer import (  # noqa: F401
-    Layer, COMPOSE_OVER, COMPOSE_OUT, COMPOSE_IN, COMPOSE_ATOP, COMPOSE_XOR,
+    Layer, canvas_to_png, COMPOSE_OVER, COMPOSE_OUT, COMPOSE_IN, COMPOSE_ATOP, COMPOSE_XOR,
 )
 from .paint import GradLinear, GradRadial  # noqa: F401
 from .filters import Filter, blur_kernel  # noqa: F401

@@ -1442,6 +1442,20 @@ __global__ void k_to_f32(float* __restrict__ dst, const double* __restrict__ src
     dst[i] = (float)v;
 }
 
+// output stage (canvas_to_png, S:262): np.round(canvas * 255.0).astype(np.uint8), four channels per thread.
+// np.round is round-half-to-even = rint in the default rounding mode; values outside [0, 255] (not produced by
+// Layer.convert(pre_alpha=False), which clips to [0, 1]) saturate here instead of wrapping.
+__global__ void k_to_rgba8(uchar4* __restrict__ dst, const double4* __restrict__ src, size_t n_px) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_px) return;
+    const double4 v = src[i];
+    auto q = [](double x) -> unsigned char {
+        double r = rint(x * 255.0);
+        r = r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r);
+        return (unsigned char)(int)r;  // (NaN -> 0)
+    };
+    dst[i] = make_uchar4(q(v.x), q(v.y), q(v.z), q(v.w));
+}
 
 // --------------------------------------------------------------------------------------
 // gradients (S:1021-1047, 1544-1695): image = gradient(pixel centre) * mask
@@ -2230,6 +2244,15 @@ int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t
     if (!ctx || !dst || !src || n < 0 || dst->bytes < (size_t)n * 4 || src->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_to_f32: bad arguments");
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_to_f32, grid1((size_t)n), dim3(256), 0, ctx->stream, (float*)dst->ptr, (const double*)src->ptr, (size_t)n, clip01);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_layer_to_rgba8(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t n_px) {
+    if (!ctx || !dst || !src || n_px < 0 || dst->bytes < (size_t)n_px * 4 || src->bytes < (size_t)n_px * 32) return fail(SVGR_E_INVALID, "svgr_layer_to_rgba8: bad arguments");
+    if (n_px == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_to_rgba8, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (uchar4*)dst->ptr, (const double4*)src->ptr, (size_t)n_px);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -250,7 +250,59 @@ class Layer:
         _abi._check(ctx.lib.svgr_layer_to_f32(ctx.handle, out32.handle, canvas.handle, rows * cols * 4, int(clip01)))
         return out32.download((rows, cols, 4), np.float32)
 
+    def to_rgba8(self) -> np.ndarray:
+        """(rows, cols, 4) uint8: straight-alpha sRGB, ``np.round(image * 255).astype(np.uint8)`` (S:211-212, S:262),
+        converted and quantised on the device; only the bytes cross PCIe (4 B per pixel instead of 32)."""
+        if self.channels != 4:
+            raise ValueError("Only RGBA layers are supported")
+        ctx = _abi.Context.get()
+        layer = self.convert(pre_alpha=False, linear_rgb=False)
+        src = layer._device()
+        rows, cols = layer._shape[0], layer._shape[1]
+        out = ctx.alloc(max(rows * cols * 4, 4))
+        _abi._check(ctx.lib.svgr_layer_to_rgba8(ctx.handle, out.handle, src.handle, rows * cols))
+        return out.download((rows, cols, 4), np.uint8)
+
+    def write_png(self, output=None, level: int = 9):
+        """PNG of the layer (Layer.write_png, S:209-213): 8-bit RGBA, filter 0, one IDAT -- byte-identical to the
+        reference's file at the reference's zlib level 9 (``level`` trades size for speed, the pixels are the same)."""
+        return canvas_to_png(self.to_rgba8(), output, level=level)
+
     def __repr__(self):
         return "Layer(x={}, y={}, w={}, h={}, pre_alpha={}, linear_rgb={})".format(
             self.x, self.y, self.width, self.height, self.pre_alpha, self.linear_rgb
         )
+
+
+def canvas_to_png(canvas, output=None, level: int = 9):
+    """(height, width, 4) -> PNG (canvas_to_png, S:249-274).  ``canvas`` is either the uint8 array of
+    ``Layer.to_rgba8`` or float RGBA in [0, 1] (quantised like the reference: ``np.round(canvas * 255)``)."""
+    import io
+    import struct
+    import zlib
+
+    canvas = np.asarray(canvas)
+    if canvas.dtype != np.uint8:
+        canvas = np.round(canvas * 255.0).astype(np.uint8)
+    if canvas.ndim != 3 or canvas.shape[2] != 4:
+        raise ValueError("Only RGBA layers are supported")
+    height, width, _ = canvas.shape
+
+    def pack(out, tag: bytes, data: bytes) -> None:
+        out.write(struct.pack("!I", len(data)))
+        out.write(tag)
+        out.write(data)
+        out.write(struct.pack("!I", 0xFFFFFFFF & zlib.crc32(data, zlib.crc32(tag))))
+
+    # filter byte 0 in front of every scanline, then ONE deflate stream (deflate output does not depend on how the
+    # input is chunked, so one call gives the bytes of the reference's row-by-row loop)
+    rows = np.zeros((height, 1 + width * 4), dtype=np.uint8)
+    rows[:, 1:] = canvas.reshape(height, width * 4)
+    comp = zlib.compressobj(level=level)
+    data = comp.compress(rows.tobytes()) + comp.flush()
+    output = io.BytesIO() if output is None else output
+    output.write(b"\x89PNG\r\n\x1a\n")
+    pack(output, b"IHDR", struct.pack("!2I5B", width, height, 8, 6, 0, 0, 0))
+    pack(output, b"IDAT", data)
+    pack(output, b"IEND", b"")
+    return output
