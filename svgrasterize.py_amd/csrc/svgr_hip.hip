@@ -1618,7 +1618,9 @@ struct svgr_batch {
     DevArr<TileEntry> entries;
     DevArr<double> edges;
     DevArr<RowRec> bsegs;
-    // plan results
+    // plan results (n_edges = edge slots the edge kernels cover = sum of the shard capacities; n_edges_live = filled ones)
+    bool geometry_fresh = false;  // the buffers hold the geometry of the current inputs (set by plan, consumed by render)
+    int64_t n_edges_live = 0;
     int64_t n_edges = 0, n_pb = 0, n_bsegs = 0;
     int n_bands = 0;
     BatchDev host_bd{};
@@ -1710,11 +1712,13 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     return 0;
 }
 
-static int check_dev_err(svgr_batch* b) {
+// `capacity_bits`: when given, capacity overflows (bits 2|4|8) are returned there instead of failing
+static int check_dev_err(svgr_batch* b, int* capacity_bits = nullptr) {
     HIPCHK(hipMemcpyAsync(&b->host_bd, b->bd(), sizeof(BatchDev), hipMemcpyDeviceToHost, b->ctx->stream));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
     HIPCHK(hipGetLastError());
     int e = b->host_bd.err;
+    if (capacity_bits) { *capacity_bits = e & (2 | 4 | 8); e &= ~(2 | 4 | 8); }
     if (e & 1) return fail(SVGR_E_OVERFLOW, "flatten depth cap (%d) hit: non-finite or absurd control points", kMaxFlattenDepth);
     if (e & 16) return fail(SVGR_E_INVALID, "path extent beyond +-1e9 pixels or non-finite");
     if (e & (2 | 4 | 8)) return fail(SVGR_E_OVERFLOW, "work buffer capacity exceeded (err bits %d): call svgr_batch_plan again", e);
@@ -1947,6 +1951,7 @@ int svgr_batch_set_paints(svgr_batch* b, const double* path_paint) {
     if (!b || !path_paint) return fail(SVGR_E_INVALID, "bad arguments");
     HIPCHK(hipMemcpyAsync(b->path_paint.p, path_paint, sizeof(double) * 4 * b->n_paths, hipMemcpyHostToDevice, b->ctx->stream));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    b->geometry_fresh = false;  // the pair headers carry the paint
     return 0;
 }
 
@@ -1967,11 +1972,61 @@ int svgr_batch_set_bands(svgr_batch* b, int rank, int world, int strip_bands) {
     return 0;
 }
 
+// Small batches (Path.mask / Path.fill of one path, a handful of glyphs): instead of the staged plan with a read-back
+// per stage, size every buffer from bounds known on the host -- (path, band) pairs <= paths x bands exactly, edges and
+// records by a generous guess -- run the whole geometry ONCE and read the counters back once.  If a guess was too
+// small the kernels flag it and the staged plan takes over.  Returns 1 when it planned, 0 to fall back, < 0 on error.
+static int plan_speculative(svgr_batch* b) {
+    const int np = (int)b->n_paths;
+    const int64_t ns = b->n_segs;
+    if (!b->has_vp || ns <= 0 || ns > 256 || np <= 0) return 0;
+    const int n_bands = (b->vp[2] + TR - 1) / TR;
+    if ((int64_t)np * n_bands > 65536 || n_bands <= 0) return 0;
+    const int shard_cap = (int)(64 * ns);  // a wave's segments all land in one shard: every shard can take them all
+    b->n_edges = 0;
+    for (int k = 0; k < NSH; ++k) {
+        b->shards.base[k] = (int)b->n_edges;
+        b->shards.cap[k] = shard_cap;
+        b->n_edges += shard_cap;
+    }
+    b->n_bands = n_bands;
+    b->n_pb = (int64_t)np * n_bands;
+    const int64_t rec_guess = 16 * (int64_t)shard_cap + b->n_pb;
+    int rc = b->layout_arena((int)b->n_pb);
+    rc = rc ? rc : b->edges.ensure((size_t)b->n_edges * 4);
+    rc = rc ? rc : b->edge_path.ensure((size_t)b->n_edges);
+    rc = rc ? rc : b->band_start.ensure((size_t)n_bands + 1);
+    rc = rc ? rc : b->band_count.ensure((size_t)n_bands + 1);
+    rc = rc ? rc : b->bseg_off.ensure((size_t)b->n_pb + 1);
+    rc = rc ? rc : b->entries.ensure((size_t)b->n_pb);
+    rc = rc ? rc : b->bsegs.ensure((size_t)rec_guess + PREF_RECS_MAX + 1);
+    if (rc) return rc;
+    if ((rc = run_geometry(b, 4, true))) return rc;
+    int cap_bits = 0;
+    if ((rc = check_dev_err(b, &cap_bits))) return rc;
+    if (cap_bits) return 0;
+    b->n_edges_live = 0;
+    for (int k = 0; k < NSH; ++k) b->n_edges_live += std::min(b->host_bd.shard[k].cursor, shard_cap);
+    b->n_bsegs = b->host_bd.bseg_cursor;
+    b->host_bbox.resize(4 * (size_t)np);
+    HIPCHK(hipMemcpy(b->host_bbox.data(), b->bbox.p, sizeof(int) * 4 * np, hipMemcpyDeviceToHost));
+    b->planned = true;
+    b->geometry_fresh = true;
+    return 1;
+}
+
 int svgr_batch_plan(svgr_batch* b) {
     if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
     HIPCHK(hipSetDevice(b->ctx->device));
     b->planned = false;
+    b->geometry_fresh = false;
     const int np = (int)b->n_paths;
+    {
+        const bool no_spec = getenv("SVGR_NO_SPECULATIVE_PLAN") != nullptr;  // (tests exercise both planners)
+        const int sp = no_spec ? 0 : plan_speculative(b);
+        if (sp < 0) return sp;
+        if (sp > 0) return 0;
+    }
     if (int rc = b->layout_arena(0)) return rc;
     // 1. Without a viewport (S:968 `viewport is None`) the union of the unclipped bboxes becomes the canvas.
     if (!b->has_vp) {
@@ -2018,14 +2073,16 @@ int svgr_batch_plan(svgr_batch* b) {
     if (int rc = check_dev_err(b)) return rc;
     b->host_bbox.resize(4 * (size_t)np);
     HIPCHK(hipMemcpy(b->host_bbox.data(), b->bbox.p, sizeof(int) * 4 * np, hipMemcpyDeviceToHost));
+    b->n_edges_live = b->n_edges;
     b->planned = true;
+    b->geometry_fresh = true;
     return 0;
 }
 
 int svgr_batch_get_stats(const svgr_batch* b, svgr_batch_stats* out) {
     if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
     if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan has not run");
-    out->n_edges = b->n_edges;
+    out->n_edges = b->n_edges_live;
     out->path_pixels = (int64_t)b->host_bd.path_pixels;
     out->n_band_segs = b->n_bsegs;
     out->n_path_bands = b->n_pb;
@@ -2054,12 +2111,18 @@ int svgr_batch_get_bboxes(const svgr_batch* b, int32_t* out) {
 int svgr_batch_get_edges(const svgr_batch* b, double* edges, int32_t* edge_path, int64_t cap) {
     if (!b || !edges) return fail(SVGR_E_INVALID, "bad arguments");
     if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan has not run");
-    if (cap < b->n_edges) return fail(SVGR_E_INVALID, "edge buffer holds %lld, need %lld", (long long)cap, (long long)b->n_edges);
-    if (b->n_edges == 0) return 0;
+    if (cap < b->n_edges_live) return fail(SVGR_E_INVALID, "edge buffer holds %lld, need %lld", (long long)cap, (long long)b->n_edges_live);
+    if (b->n_edges_live == 0) return 0;
     HIPCHK(hipSetDevice(b->ctx->device));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
-    HIPCHK(hipMemcpy(edges, b->edges.p, sizeof(double) * 4 * (size_t)b->n_edges, hipMemcpyDeviceToHost));
-    if (edge_path) HIPCHK(hipMemcpy(edge_path, b->edge_path.p, sizeof(int) * (size_t)b->n_edges, hipMemcpyDeviceToHost));
+    int64_t at = 0;
+    for (int k = 0; k < NSH; ++k) {  // the filled part of every shard, packed
+        const int64_t n = std::min(b->host_bd.shard[k].cursor, b->shards.cap[k]);
+        if (n <= 0) continue;
+        HIPCHK(hipMemcpy(edges + 4 * at, b->edges.p + 4 * (size_t)b->shards.base[k], sizeof(double) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+        if (edge_path) HIPCHK(hipMemcpy(edge_path + at, b->edge_path.p + b->shards.base[k], sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+        at += n;
+    }
     return 0;
 }
 
@@ -2109,7 +2172,10 @@ int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags
     // geometry, identical to the last plan step but without read-backs (capacities are exact for
     // unchanged input; the kernels flag an overflow otherwise and svgr_batch_timings / the next
     // plan reports it)
-    if (int rc = run_geometry(b, 4, true)) return rc;
+    // (the first render after a plan finds the plan's own full geometry pass in the buffers: same inputs, same result)
+    if (!(b->geometry_fresh && !timed))
+        if (int rc = run_geometry(b, 4, true)) return rc;
+    b->geometry_fresh = false;
     if (single && need) HIPCHK(hipMemsetAsync(out->ptr, 0, need, st));
     if (timed) HIPCHK(hipEventRecord(ev.e1, st));
 

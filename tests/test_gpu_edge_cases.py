@@ -3,6 +3,8 @@ inputs at the limits of the batch ABI."""
 import numpy as np
 import pytest
 
+from tests.util import assert_close64, sort_edges
+
 pytestmark = pytest.mark.gpu
 
 
@@ -101,3 +103,43 @@ def test_layer_image_is_mutable_after_download(S):
     img[2, 2] = [0.1, 0.2, 0.3, 0.4]
     out = S.Layer.compose([layer, S.Layer(np.zeros((1, 1, 4)), (0, 0), True, True)], S.COMPOSE_OVER, True)
     assert np.array_equal(out.image[2 + int(layer.x), 2 + int(layer.y)], [0.1, 0.2, 0.3, 0.4])
+
+
+def test_small_batch_planner_matches_staged_planner(S, monkeypatch):
+    """Batches of up to 256 segments are planned speculatively (buffers sized from host-side bounds, ONE geometry pass,
+    one read-back); everything else, and any batch whose guesses were too small, by the staged planner.  Both give the
+    same bboxes, edges and pixels -- including a curve deep enough (> 64 pieces per cubic) to overflow the guess."""
+    from svgrasterize_amd import _abi
+
+    ctx = S.Context.get()
+    swap = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    cases = [
+        (S.Path.from_svg("M10,30 C10,5 40,5 40,30 S70,55 40,60 C20,62 10,50 10,30 Z"), swap, [0, 0, 96, 96]),
+        # one cubic magnified 400x: far more than 64 flattened pieces -> the speculative edge capacity overflows
+        (S.Path.from_svg("M1,1 C9,0 0,9 8,8 C4,9 2,5 1,1 Z"), swap.scale(400.0), [100, 200, 1200, 1500]),
+    ]
+    for path, tr, vp in cases:
+        segs, kinds = path.packed()
+        out = {}
+        for mode in ("speculative", "staged"):
+            if mode == "staged":
+                monkeypatch.setenv("SVGR_NO_SPECULATIVE_PLAN", "1")
+            else:
+                monkeypatch.delenv("SVGR_NO_SPECULATIVE_PLAN", raising=False)
+            b = _abi.Batch(ctx, segs, kinds, [0, len(segs)], tr.m6(), [0], np.array([[0.2, 0.3, 0.1, 0.5]]), viewport=vp)
+            st = b.plan()
+            canvas = ctx.alloc(vp[2] * vp[3] * 32)
+            b.render(canvas, _abi.OUT_CANVAS_F64)           # first render after the plan: reuses the plan's geometry pass
+            first = canvas.download((vp[2], vp[3], 4), np.float64)
+            b.render(canvas, _abi.OUT_CANVAS_F64)           # second: geometry recomputed
+            second = canvas.download((vp[2], vp[3], 4), np.float64)
+            assert np.array_equal(first, second) or np.allclose(first, second, atol=1e-12)
+            e, ep = b.edges()
+            out[mode] = (st.n_edges, b.bboxes().copy(), sort_edges(e), first)
+        monkeypatch.delenv("SVGR_NO_SPECULATIVE_PLAN", raising=False)
+        a, s_ = out["speculative"], out["staged"]
+        assert a[0] == s_[0] and a[0] > 0
+        assert np.array_equal(a[1], s_[1])
+        assert np.array_equal(a[2], s_[2])
+        assert_close64(a[3], s_[3], atol=1e-12, what="speculative vs staged planner")
+    assert out["staged"][0] > 64 * 2  # the second case really was beyond the speculative capacity
