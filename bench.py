@@ -8,7 +8,7 @@ starts: transform + flatten + bbox + band binning + tile kernel (LDS delta scatt
 rule, paint, source-over) -> finished float32 RGBA canvas in HBM.  No host read-back inside a step.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the canvas is sharded by interleaved
-16-row bands (rank r owns bands r, r+N, ...): the same scene, total work fixed -> "strong" scaling.
+strips of 128 scanlines (rank r owns strips r, r+N, ...): the same scene, total work fixed -> "strong" scaling.
 Edges that cross a band border are simply processed by both owners (duplicated edges are the halo;
 no pixel ever crosses a GPU), so the data path needs no collective; RCCL is used for the barrier /
 max-over-ranks clock and for the optional final all_gather of the bands (reported separately).
@@ -153,7 +153,7 @@ def main():
                        viewport=sc["viewport"])
     st = batch.plan()
     P, E = int(st.path_pixels), int(st.n_edges)
-    strip = int(os.environ.get("SVGR_STRIP_BANDS", "16"))  # 16 bands = 128 scanlines per strip
+    strip = int(os.environ.get("SVGR_STRIP_BANDS", str(max(1, 128 // _abi.tile_rows()))))  # 128 scanlines per strip
     if world > 1:
         batch.set_bands(rank, world, strip)
         batch.plan()  # per-rank capacities: each rank keeps only the edges that reach its strips

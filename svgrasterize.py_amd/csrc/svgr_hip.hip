@@ -9,15 +9,15 @@
 //                   store the pieces; endpoints folded into per-path min/max keys
 //   k_path_bbox     per path: integer bbox (floor-1 / ceil+1, clipped to the viewport), band range,
 //                   wave-aggregated reservation of its (path, band) pair slots
-//   k_edge_count    per edge: which 8-row bands it crosses -> per-pair record counts (run-aggregated atomics)
+//   k_edge_count    per edge: which 16-row bands it crosses -> per-pair record counts (run-aggregated atomics)
 //   k_band_entries  per band: ordered tile list of the pairs with records, reservation of their record
 //                   blocks (contiguous per band), pair headers (paint, fill rule)
 //   k_edge_emit     per edge: walk its rows with the reference's x recurrence; one 48-byte record per
 //                   row with the closed-form signed-area pieces, stored through an LDS transpose
-//   k_tile_render   one 128-thread workgroup per 8x128 canvas tile, canvas tile resident in registers as
+//   k_tile_render   one 128-thread workgroup per 16x64 canvas tile, canvas tile resident in registers as
 //                   double RGBA; per covering path in paint order: record block by LDS-DMA, scatter the
 //                   pieces into an LDS delta tile (ds_add_f64), row prefix sum (8 px per lane serial +
-//                   DPP row scan across the 16 lanes of a row), fill rule, paint, source-over; one
+//                   DPP row scan across the 8 lanes of a row), fill rule, paint, source-over; one
 //                   store of the finished tile (float32 or double)
 //
 // There is no dense contraction anywhere in this path: no MFMA.  The heavy traffic (delta tile,
@@ -44,7 +44,7 @@ using namespace svgr;
 // tile geometry
 // ======================================================================================
 #ifndef SVGR_TR
-#define SVGR_TR 8
+#define SVGR_TR 16
 #endif
 constexpr int TR = SVGR_TR;                // rows per band / tile
 #ifndef SVGR_PX
@@ -52,27 +52,31 @@ constexpr int TR = SVGR_TR;                // rows per band / tile
 #endif
 constexpr int PX = SVGR_PX;                // pixels per lane (consecutive columns)
 #ifndef SVGR_CH
-#define SVGR_CH 16
+#define SVGR_CH 8
 #endif
-constexpr int CH = SVGR_CH;                // lanes per tile row: 16 (one DPP row) or 32 (two DPP rows)
+constexpr int CH = SVGR_CH;                // lanes per tile row: 8 (half a DPP row), 16 (one) or 32 (two)
 constexpr int TC = CH * PX;                // columns per tile
-constexpr int NT = TR * CH;                // 256 threads = 4 waves; a wave covers 4 tile rows
-constexpr int CHUNK_STRIDE = PX + 2;       // doubles; +16 B makes the 16-lane b128 groups conflict free
+constexpr int NT = TR * CH;                // threads per workgroup (128 = 2 waves); a wave covers 64 / CH tile rows
+constexpr int CHUNK_STRIDE = PX + 2;       // doubles; +16 B makes the b128 lane groups conflict free
 constexpr int ROW_STRIDE = CH * CHUNK_STRIDE;
-static_assert(CH == 16 || CH == 32, "row scan: one or two 16-lane DPP rows per tile row");
-constexpr int PREF_WAVES = NT / 64 < 3 ? NT / 64 : 3;   // waves that issue the LDS-DMA of a record block (1 KiB each)
-constexpr int PREF_BYTES = PREF_WAVES * 1024;
+static_assert(CH == 8 || CH == 16 || CH == 32, "row scan: half a 16-lane DPP row, one, or two per tile row");
+constexpr int PREF_WAVES = NT / 64 < 3 ? NT / 64 : 3;   // waves that issue the LDS-DMA of a record block
+#ifndef SVGR_DMA_PER_WAVE
+#define SVGR_DMA_PER_WAVE 2
+#endif
+constexpr int DMA_PER_WAVE = SVGR_DMA_PER_WAVE;         // DMA instructions (1 KiB each) per issuing wave and block
+constexpr int PREF_BYTES = PREF_WAVES * DMA_PER_WAVE * 1024;
 #ifndef SVGR_REC_BYTES
 #define SVGR_REC_BYTES 48
 #endif
 constexpr int REC_BYTES = SVGR_REC_BYTES;             // 48, or 64 = one full HBM sector per record
-constexpr int PREF_RECS = PREF_BYTES / REC_BYTES;              // slots per prefetch block (64 for a 256-thread workgroup)
+constexpr int PREF_RECS = PREF_BYTES / REC_BYTES;              // slots per prefetch block (85 = 4 KiB / 48 B)
 #ifndef SVGR_PREF_DEPTH
-#define SVGR_PREF_DEPTH 3
+#define SVGR_PREF_DEPTH 2
 #endif
 constexpr int PREF_DEPTH = SVGR_PREF_DEPTH;             // record blocks in the ring: paths li, li+1[, li+2]
 constexpr int LCAP = 32;                                // compacted paths of a tile worked off per sub-batch
-constexpr int NW = NT / 64;                // waves per workgroup; a wave covers 4 tile rows
+constexpr int NW = NT / 64;                // waves per workgroup
 #ifndef SVGR_WAVES_PER_EU
 #define SVGR_WAVES_PER_EU 4             // register budget of the tile kernel: 512 / 4 = 128 VGPRs
 #endif
@@ -1070,14 +1074,18 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
             if (wave < PREF_WAVES) {
                 const int left_ = s_seg1[li_] - s_seg0[li_] - win_;
                 const int n_bytes = (left_ < PREF_RECS ? left_ : PREF_RECS) * REC_BYTES;
-                const int off_ = tid * 16 < n_bytes ? tid * 16 : n_bytes - 16;
-                const char* g = (const char*)(a.bsegs + s_seg0[li_] + win_) + off_;
-                const unsigned lds_base = __builtin_amdgcn_readfirstlane(
-                    (unsigned)(size_t)(lds_ptr_t)(s_mem + OFF_PREF + buf_ * PREF_BYTES + wave * 1024));
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                             :
-                             : "v"(g), "s"(lds_base)
-                             : "memory", "m0");
+#pragma unroll
+                for (int j = 0; j < DMA_PER_WAVE; ++j) {
+                    const int t_ = (wave * DMA_PER_WAVE + j) * 64 + lane;  // 16-byte chunk of the block this lane fetches
+                    const int off_ = t_ * 16 < n_bytes ? t_ * 16 : n_bytes - 16;
+                    const char* g = (const char*)(a.bsegs + s_seg0[li_] + win_) + off_;
+                    const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+                        (unsigned)(size_t)(lds_ptr_t)(s_mem + OFF_PREF + buf_ * PREF_BYTES + (wave * DMA_PER_WAVE + j) * 1024));
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                                 :
+                                 : "v"(g), "s"(lds_base)
+                                 : "memory", "m0");
+                }
             }
         };
         // the prefetch cursor runs two items ahead of the work cursor
@@ -1102,7 +1110,7 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
 #ifdef SVGR_DBG_STAMP
             unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();
 #endif
-            if (pf_k > k + 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            if (pf_k > k + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef SVGR_DBG_STAMP
             unsigned long long t1_ = __builtin_amdgcn_s_memrealtime();
@@ -1230,20 +1238,31 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
                 double tot = t[0];
 #pragma unroll
                 for (int i = 1; i < PX; ++i) tot += t[i];
-                double inc = tot;  // inclusive scan of the 16 chunk totals of this tile row
-                inc += dpp_row_shr<1>(inc);
-                inc += dpp_row_shr<2>(inc);
-                inc += dpp_row_shr<4>(inc);
-                inc += dpp_row_shr<8>(inc);
+                double inc = tot;  // inclusive scan of the CH chunk totals of this tile row
                 double run;
-                if (CH == 16) {
-                    run = dpp_row_shr<1>(inc);  // exclusive: everything left of this chunk
+                if (CH == 8) {
+                    // a 16-lane DPP row holds TWO tile rows: a shift must not carry lane 7's value into lane 8
+                    const int l8 = lane & 7;
+                    double v;
+                    v = dpp_row_shr<1>(inc); inc += l8 >= 1 ? v : 0.0;
+                    v = dpp_row_shr<2>(inc); inc += l8 >= 2 ? v : 0.0;
+                    v = dpp_row_shr<4>(inc); inc += l8 >= 4 ? v : 0.0;
+                    v = dpp_row_shr<1>(inc);
+                    run = l8 >= 1 ? v : 0.0;  // exclusive: everything left of this chunk
                 } else {
-                    // a tile row is two DPP rows: add the lower row's total (its lane 15) to the upper row,
-                    // then shift by one lane across the pair; the first lane of a tile row starts at 0
-                    inc += dpp_ctrl<0x142, 0xA>(inc);   // row_bcast:15 into DPP rows 1 and 3
-                    run = dpp_ctrl<0x138, 0xF>(inc);    // wave_shr:1
-                    if ((lane & 31) == 0) run = 0.0;
+                    inc += dpp_row_shr<1>(inc);
+                    inc += dpp_row_shr<2>(inc);
+                    inc += dpp_row_shr<4>(inc);
+                    inc += dpp_row_shr<8>(inc);
+                    if (CH == 16) {
+                        run = dpp_row_shr<1>(inc);  // exclusive: everything left of this chunk
+                    } else {
+                        // a tile row is two DPP rows: add the lower row's total (its lane 15) to the upper row,
+                        // then shift by one lane across the pair; the first lane of a tile row starts at 0
+                        inc += dpp_ctrl<0x142, 0xA>(inc);   // row_bcast:15 into DPP rows 1 and 3
+                        run = dpp_ctrl<0x138, 0xF>(inc);    // wave_shr:1
+                        if ((lane & 31) == 0) run = 0.0;
+                    }
                 }
 
                 if (OUT <= 1) {
