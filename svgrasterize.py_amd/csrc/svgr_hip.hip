@@ -59,7 +59,7 @@ constexpr int TC = CH * PX;                // columns per tile
 constexpr int NT = TR * CH;                // threads per workgroup (128 = 2 waves); a wave covers 64 / CH tile rows
 constexpr int CHUNK_STRIDE = PX + 2;       // doubles; +16 B makes the b128 lane groups conflict free
 constexpr int ROW_STRIDE = CH * CHUNK_STRIDE;
-static_assert(CH == 8 || CH == 16 || CH == 32, "row scan: half a 16-lane DPP row, one, or two per tile row");
+static_assert(CH == 4 || CH == 8 || CH == 16 || CH == 32, "row scan: a quarter / half of a 16-lane DPP row, one, or two per tile row");
 constexpr int PREF_WAVES = NT / 64 < 3 ? NT / 64 : 3;   // waves that issue the LDS-DMA of a record block
 #ifndef SVGR_DMA_PER_WAVE
 #define SVGR_DMA_PER_WAVE 2
@@ -685,8 +685,8 @@ __global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ e
 // One tile-list entry: everything a tile needs to know about a (path, band) pair, so that the tile
 // kernel's compaction is ONE coalesced load per lane instead of a chain of four dependent gathers.
 struct TileEntry {
+    int c0, cols;     // layer columns (first: the tile's column test reads just these 8 bytes)
     int p;            // path id
-    int c0, cols;     // layer columns (for the tile's column test)
     int r0, rows;     // layer rows
     int seg0, cnt;    // record block of the pair: first slot (the header), number of records
     int pad;
@@ -1026,16 +1026,12 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
     const int ent_begin = a.band_start[band], ent_end = ent_begin + a.band_count[band];
     for (int base = ent_begin; base < ent_end; base += NT) {
         // ---- compact the band's path list down to the paths that touch this tile's columns ----
-        int p_mine = -1, seg0 = 0, seg1 = 0;
-        int4 bb = make_int4(0, 0, 0, 0);
+        // Only `hit` and the lane's rank stay live across the per-path loop below; the entry itself is read again when its
+        // sub-batch comes up (holding its seven values in registers through the loop cost a scratch spill per workgroup).
         bool hit = false;
         if (base + tid < ent_end) {
-            const TileEntry e = a.entries[base + tid];  // one coalesced 32-byte load per lane
-            p_mine = e.p;
-            bb = make_int4(e.r0, e.c0, e.rows, e.cols);
-            seg0 = e.seg0;
-            seg1 = seg0 + e.cnt + 1;  // header slot + records
-            hit = e.c0 < tile_c1 && e.c0 + e.cols > tile_c0;
+            const int2 cc = *(const int2*)&a.entries[base + tid];  // {c0, cols}
+            hit = cc.x < tile_c1 && cc.x + cc.y > tile_c0;
         }
         unsigned long long m = __ballot(hit);
         if (lane == 0) s_wcnt[wave] = __popcll(m);
@@ -1051,10 +1047,11 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
         for (int lo = 0; lo < total_all; lo += LCAP) {
         const int total = total_all - lo < LCAP ? total_all - lo : LCAP;
         if (hit && slot >= lo && slot < lo + LCAP) {
-            s_list[slot - lo] = p_mine;
-            s_seg0[slot - lo] = seg0;
-            s_seg1[slot - lo] = seg1;
-            s_bbox[slot - lo] = bb;
+            const TileEntry e = a.entries[base + tid];  // one 32-byte load per lane (L2: the tile's neighbours read it too)
+            s_list[slot - lo] = e.p;
+            s_seg0[slot - lo] = e.seg0;
+            s_seg1[slot - lo] = e.seg0 + e.cnt + 1;  // header slot + records
+            s_bbox[slot - lo] = make_int4(e.r0, e.c0, e.rows, e.cols);
         }
         __syncthreads();
 
@@ -1240,15 +1237,15 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
                 for (int i = 1; i < PX; ++i) tot += t[i];
                 double inc = tot;  // inclusive scan of the CH chunk totals of this tile row
                 double run;
-                if (CH == 8) {
-                    // a 16-lane DPP row holds TWO tile rows: a shift must not carry lane 7's value into lane 8
-                    const int l8 = lane & 7;
+                if (CH <= 8) {
+                    // a 16-lane DPP row holds 16 / CH tile rows: a shift must not carry a value across their borders
+                    const int lc = lane & (CH - 1);
                     double v;
-                    v = dpp_row_shr<1>(inc); inc += l8 >= 1 ? v : 0.0;
-                    v = dpp_row_shr<2>(inc); inc += l8 >= 2 ? v : 0.0;
-                    v = dpp_row_shr<4>(inc); inc += l8 >= 4 ? v : 0.0;
+                    v = dpp_row_shr<1>(inc); inc += lc >= 1 ? v : 0.0;
+                    v = dpp_row_shr<2>(inc); inc += lc >= 2 ? v : 0.0;
+                    if (CH == 8) { v = dpp_row_shr<4>(inc); inc += lc >= 4 ? v : 0.0; }
                     v = dpp_row_shr<1>(inc);
-                    run = l8 >= 1 ? v : 0.0;  // exclusive: everything left of this chunk
+                    run = lc >= 1 ? v : 0.0;  // exclusive: everything left of this chunk
                 } else {
                     inc += dpp_row_shr<1>(inc);
                     inc += dpp_row_shr<2>(inc);
