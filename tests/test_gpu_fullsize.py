@@ -101,3 +101,38 @@ def test_synth_4096_properties(S):
     ref, _, _ = orc.render_solid(synth.presentation_segs(sc), sc["seg_kind"], sc["path_seg_off"], sc["path_rule"],
                                  sc["path_paint"], (r0, c0, hh, ww), clip01=True)
     assert_f32_1ulp(full[r0:r0 + hh, c0:c0 + ww], ref, what="synth4096 window vs oracle")
+
+
+def test_synth_8192_config4_windows(S):
+    """BASELINE config 4 (10 000 random cubic paths @ 8192x8192) on one GPU: more paths than one band-list pass keeps in
+    registers, 6 M record slots, a 1 GiB canvas.  Windows of the canvas against the CPU oracle rendered through the
+    reference's own viewport mechanism, plus one rank's strips of an 8-way sharding against the same rows."""
+    from oracle import oracle as orc
+    from svgrasterize_amd import _abi, dist as sdist, synth
+
+    size, n = 8192, 10000
+    sc = synth.make_scene(size, n)
+    ctx = S.Context.get()
+    batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
+                       viewport=sc["viewport"])
+    st = batch.plan()
+    assert st.path_pixels == 399658495 and st.n_nonempty == n
+    out = ctx.alloc(size * size * 16)
+    batch.render(out, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
+    full = out.download((size, size, 4), np.float32)
+    for r0, c0, hh, ww in [(0, 0, 96, 160), (4000, 7900, 200, 292), (8192 - 120, 3000, 120, 200)]:
+        ref, _, _ = orc.render_solid(synth.presentation_segs(sc), sc["seg_kind"], sc["path_seg_off"], sc["path_rule"],
+                                     sc["path_paint"], (r0, c0, hh, ww), clip01=True)
+        assert_f32_1ulp(full[r0:r0 + hh, c0:c0 + ww], ref, what=f"synth8192 window {r0},{c0}")
+    tr = _abi.tile_rows()
+    strip = max(1, 128 // tr)
+    batch.set_bands(5, 8, strip)
+    batch.plan()
+    part = ctx.alloc(batch.owned_rows() * size * 16)
+    batch.render(part, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
+    part = part.download((batch.owned_rows(), size, 4), np.float32)
+    k = 0
+    for r0, r1 in sdist.owned_row_ranges(size, tr, 5, 8, strip):
+        d = np.abs(part[k: k + (r1 - r0)].astype(np.float64) - full[r0:r1])
+        assert d.max() < 2e-7 and (d > 0).mean() < 1e-5
+        k += r1 - r0
