@@ -92,17 +92,29 @@ def cpu_baseline(sc, budget_paths: int | None = None):
     canvas.fill(0.0)  # pre-fault: page faults are not the algorithm
     stats = np.zeros(2, dtype=np.int64)
     L = orc.lib()
+    args = (pres.reshape(-1), np.ascontiguousarray(sc["seg_kind"][: off[-1]]), off, n,
+            np.ascontiguousarray(sc["path_rule"][:n]), np.ascontiguousarray(sc["path_paint"][:n]).reshape(-1), vp, 1,
+            canvas.reshape(-1), stats.ctypes.data_as(C.c_void_p))
     t0 = time.perf_counter()
-    rc = L.orc_render_solid(pres.reshape(-1), np.ascontiguousarray(sc["seg_kind"][: off[-1]]), off, n,
-                            np.ascontiguousarray(sc["path_rule"][:n]), np.ascontiguousarray(sc["path_paint"][:n]).reshape(-1),
-                            vp, 1, canvas.reshape(-1), stats.ctypes.data_as(C.c_void_p))
+    rc = L.orc_render_solid(*args)
     dt = time.perf_counter() - t0
     if rc != 0:
         raise RuntimeError(f"oracle failed: {rc}")
+    P1 = int(stats[0])
+    # the same render cut into row strips, one per thread, on this process's share of the host cores
+    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    canvas.fill(0.0)
+    t0 = time.perf_counter()
+    rc = L.orc_render_solid_strips(*args, threads, threads)
+    dt_mt = time.perf_counter() - t0
+    if rc != 0:
+        raise RuntimeError(f"oracle (strips) failed: {rc}")
     return dict(
-        value=round(float(stats[0]) / dt / 1e6, 3), unit="Mpixels/s (path-pixels)", cores=1, kind="port",
-        sample=f"first {n} of {n_all} paths of the same scene, full viewport, {dt:.2f} s, P={int(stats[0])} "
+        value=round(P1 / dt / 1e6, 3), unit="Mpixels/s (path-pixels)", cores=1, kind="port",
+        sample=f"first {n} of {n_all} paths of the same scene, full viewport, {dt:.2f} s, P={P1} "
                f"(oracle/svgr_oracle.c: pass-by-pass C restatement of the reference, float64, 1 thread of {os.cpu_count()})",
+        all_cores_value=round(int(stats[0]) / dt_mt / 1e6, 3), all_cores=threads,
+        all_cores_sample=f"same render as {threads} row strips (the reference's viewport cropping) on {threads} OpenMP threads, {dt_mt:.2f} s",
     )
 
 

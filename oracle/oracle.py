@@ -52,6 +52,9 @@ def lib():
     L.orc_compose_in.argtypes = [_f64p, _i64p, C.c_int64, C.c_int64, _f64p, _i64p, C.c_int64, C.c_int64, C.c_int]
     L.orc_render_solid.argtypes = [_f64p, _u8p, _i64p, C.c_int64, _u8p, _f64p, _i64p, C.c_int, _f64p, C.c_void_p]
     L.orc_render_solid.restype = C.c_int
+    L.orc_render_solid_strips.argtypes = [_f64p, _u8p, _i64p, C.c_int64, _u8p, _f64p, _i64p, C.c_int, _f64p, C.c_void_p,
+                                          C.c_int, C.c_int]
+    L.orc_render_solid_strips.restype = C.c_int
     _lib = L
     return L
 

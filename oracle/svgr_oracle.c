@@ -473,3 +473,33 @@ ORC_API int orc_render_solid(const double *segs, const uint8_t *seg_kind, const 
     if (stats) { stats[0] = P; stats[1] = E; }
     return rc;
 }
+
+/* The same render with the canvas cut into horizontal strips, one OpenMP thread per strip at a time: every strip is  */
+/* an independent orc_render_solid with its own viewport (the reference's own cropping, S:968-971), so the threads  */
+/* share nothing.  Used only for the "all host cores" CPU baseline of bench.py.  stats[0] = P.          */
+ORC_API int orc_render_solid_strips(const double *segs, const uint8_t *seg_kind, const int64_t *path_seg_off, int64_t n_paths,
+                                    const uint8_t *path_rule, const double *path_paint, const int64_t *viewport,
+                                    int clip01, double *canvas, int64_t *stats, int n_strips, int n_threads)
+{
+    if (n_strips < 1) n_strips = 1;
+    int64_t rows = viewport[2], cols = viewport[3];
+    int64_t h = (rows + n_strips - 1) / n_strips;
+    int rc_all = 0;
+    int64_t P = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : P)
+    for (int s = 0; s < n_strips; ++s) {
+        int64_t r0 = s * h, r1 = r0 + h < rows ? r0 + h : rows;
+        if (r0 >= r1) continue;
+        int64_t vp[4] = {viewport[0] + r0, viewport[1], r1 - r0, cols};
+        int64_t st[2] = {0, 0};
+        int rc = orc_render_solid(segs, seg_kind, path_seg_off, n_paths, path_rule, path_paint, vp, clip01,
+                                  canvas + (size_t)r0 * (size_t)cols * 4, st);
+        if (rc != 0) {
+#pragma omp critical
+            rc_all = rc;
+        }
+        P += st[0];
+    }
+    if (stats) { stats[0] = P; stats[1] = 0; }
+    return rc_all;
+}
