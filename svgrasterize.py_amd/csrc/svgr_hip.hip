@@ -1604,6 +1604,30 @@ __global__ void k_layer_convolve(double* __restrict__ out, const double* __restr
     o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
 }
 
+// One axis of a separable kernel (full convolution along rows or along columns): out = sum_k w[k] * src[.. - k ..].
+// AXIS 0: src (rows, cols, 4) -> out (rows + n - 1, cols, 4); AXIS 1: src (rows, cols, 4) -> out (rows, cols + n - 1, 4).
+template <int AXIS>
+__global__ void k_layer_convolve_1d(double* __restrict__ out, const double* __restrict__ src, int rows, int cols,
+                                    const double* __restrict__ w, int n) {
+    const int orows = AXIS == 0 ? rows + n - 1 : rows, ocols = AXIS == 1 ? cols + n - 1 : cols;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)orows * ocols) return;
+    const int R = (int)(idx / ocols), C = (int)(idx % ocols);
+    const int pos = AXIS == 0 ? R : C, len = AXIS == 0 ? rows : cols;
+    const int k_lo = pos - len + 1 > 0 ? pos - len + 1 : 0, k_hi = pos < n - 1 ? pos : n - 1;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = k_lo; k <= k_hi; ++k) {
+        const double wk = w[k];
+        const double* px = AXIS == 0 ? src + 4 * ((size_t)(R - k) * cols + C) : src + 4 * ((size_t)R * cols + (C - k));
+        acc[0] = fma(px[0], wk, acc[0]);
+        acc[1] = fma(px[1], wk, acc[1]);
+        acc[2] = fma(px[2], wk, acc[2]);
+        acc[3] = fma(px[3], wk, acc[3]);
+    }
+    double* o = out + 4 * idx;
+    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+}
+
 // ======================================================================================
 // batch object
 // ======================================================================================
@@ -2391,16 +2415,54 @@ int svgr_layer_convolve(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64
     const size_t n_out = (size_t)(rows + kw - 1) * (size_t)(cols + kh - 1);
     if (src->bytes < (size_t)rows * cols * 32 || out->bytes < n_out * 32) return fail(SVGR_E_INVALID, "svgr_layer_convolve: buffer too small");
     HIPCHK(hipSetDevice(ctx->device));
-    double* dk = nullptr;
-    HIPCHK(g_pool.alloc((void**)&dk, sizeof(double) * (size_t)kw * kh));
-    hipError_t e = hipMemcpyAsync(dk, kernel, sizeof(double) * (size_t)kw * kh, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_layer_convolve, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)src->ptr,
-                           (int)rows, (int)cols, (const double*)dk, (int)kw, (int)kh);
-        e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess) e = hipGetLastError();
+    // Separable?  blur_kernel (S:1903-1944) is a product of two 1-D Gaussians whenever the transform is axis aligned
+    // (scale, translate, x/y swap): K = u v^T / S with u, v the row / column sums and S the total, to a few ulp.  Then two
+    // 1-D passes do the work of the kw x kh stencil (146 taps instead of 5329 for the largest blur of icons.svg).  A
+    // rotated or skewed blur is not rank 1 and takes the direct 2-D kernel.  (The reference lets scipy pick an FFT here,
+    // which carries ~1e-16 absolute noise itself; both device forms sum in double and stay below that.)
+    std::vector<double> u((size_t)kw, 0.0), v((size_t)kh, 0.0);
+    double total = 0.0, kmax = 0.0;
+    for (int64_t i = 0; i < kw; ++i)
+        for (int64_t j = 0; j < kh; ++j) {
+            const double k = kernel[i * kh + j];
+            u[(size_t)i] += k; v[(size_t)j] += k; total += k;
+            kmax = std::fabs(k) > kmax ? std::fabs(k) : kmax;
+        }
+    bool separable = getenv("SVGR_BLUR_DIRECT") == nullptr && kw > 1 && kh > 1 && std::isfinite(total) && total != 0.0;
+    for (int64_t i = 0; i < kw && separable; ++i)
+        for (int64_t j = 0; j < kh; ++j)
+            if (!(std::fabs(kernel[i * kh + j] - u[(size_t)i] * v[(size_t)j] / total) <= 8 * 2.220446049250313e-16 * kmax)) { separable = false; break; }
+    hipError_t e = hipSuccess;
+    if (separable) {
+        for (auto& x : u) x /= total;  // K = (u / S) v^T
+        double *dw = nullptr, *tmp = nullptr;
+        const size_t n_tmp = (size_t)(rows + kw - 1) * (size_t)cols;
+        HIPCHK(g_pool.alloc((void**)&dw, sizeof(double) * (size_t)(kw + kh)));
+        if (hipError_t a = g_pool.alloc((void**)&tmp, n_tmp * 32); a != hipSuccess) { g_pool.release(dw); HIPCHK(a); }
+        e = hipMemcpyAsync(dw, u.data(), sizeof(double) * (size_t)kw, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dw + kw, v.data(), sizeof(double) * (size_t)kh, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_layer_convolve_1d<0>, grid1(n_tmp), dim3(256), 0, ctx->stream, tmp, (const double*)src->ptr, (int)rows,
+                               (int)cols, (const double*)dw, (int)kw);
+            hipLaunchKernelGGL(k_layer_convolve_1d<1>, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)tmp,
+                               (int)(rows + kw - 1), (int)cols, (const double*)(dw + kw), (int)kh);
+            e = hipStreamSynchronize(ctx->stream);  // (u, v are host vectors of this call)
+            if (e == hipSuccess) e = hipGetLastError();
+        }
+        g_pool.release(tmp);
+        g_pool.release(dw);
+    } else {
+        double* dk = nullptr;
+        HIPCHK(g_pool.alloc((void**)&dk, sizeof(double) * (size_t)kw * kh));
+        e = hipMemcpyAsync(dk, kernel, sizeof(double) * (size_t)kw * kh, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_layer_convolve, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)src->ptr,
+                               (int)rows, (int)cols, (const double*)dk, (int)kw, (int)kh);
+            e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = hipGetLastError();
+        }
+        g_pool.release(dk);
     }
-    g_pool.release(dk);
     if (e != hipSuccess) return fail(SVGR_E_HIP, "svgr_layer_convolve: %s", hipGetErrorString(e));
     return 0;
 }

@@ -119,3 +119,32 @@ def test_gpu_icons_scene():
     tol = np.maximum(np.nextafter(np.abs(ref.astype(np.float32)), np.float32(np.inf)) - np.abs(ref.astype(np.float32)), 2.0 ** -24)
     bad = err > tol
     assert bad.sum() <= 8 and err.max() < 1e-6, (int(bad.sum()), float(err.max()))
+
+
+@pytest.mark.gpu
+def test_gpu_blur_separable_equals_direct(monkeypatch):
+    """feGaussianBlur kernels of axis-aligned transforms are rank 1: svgr_layer_convolve runs them as two 1-D passes.
+    Same result as the direct 2-D stencil to double rounding; a rotated blur (not separable) takes the 2-D stencil."""
+    import svgrasterize_amd as S
+    from svgrasterize_amd.filters import blur_kernel
+
+    rng = np.random.default_rng(5)
+    img = rng.uniform(0, 1, (57, 83, 4))
+    layer = S.Layer(img, (4, 9), pre_alpha=False, linear_rgb=True)
+    swap = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    for tr, expect_sep in [(swap.scale(3.0), True), (swap.scale(2.0, 5.0), True), (swap.rotate(0.4).scale(3.0), False)]:
+        kern = blur_kernel(tr, (1.7, 2.9))
+        assert kern is not None and kern.shape[0] > 3
+        u, v = kern.sum(1), kern.sum(0)
+        rank1 = np.abs(kern - np.outer(u, v) / kern.sum()).max() <= 8 * np.finfo(float).eps * kern.max()
+        assert rank1 == expect_sep
+        monkeypatch.delenv("SVGR_BLUR_DIRECT", raising=False)
+        auto = layer.convolve(kern)
+        monkeypatch.setenv("SVGR_BLUR_DIRECT", "1")
+        direct = layer.convolve(kern)
+        monkeypatch.delenv("SVGR_BLUR_DIRECT", raising=False)
+        assert auto.offset == direct.offset and auto.image.shape == direct.image.shape
+        np.testing.assert_allclose(auto.image, direct.image, rtol=0, atol=4e-16 * kern.size ** 0.5 + 1e-15)
+        from scipy.signal import convolve as sconv
+        want = sconv(img, kern[..., None], mode="full", method="direct")
+        np.testing.assert_allclose(auto.image, want, rtol=0, atol=1e-14)
