@@ -62,6 +62,9 @@ typedef struct svgr_batch svgr_batch;
 #define SVGR_OUT_CANVAS_F64 1  /* same in double (Layer.image dtype of the reference, S:42) */
 #define SVGR_OUT_MASK_F64 2    /* single path: (rows, cols) double coverage = Path.mask().image[..., 0] */
 #define SVGR_OUT_FILL_F64 3    /* single path: (rows, cols, 4) double = mask * paint (S:1019) */
+#define SVGR_OUT_MASKS_F64 4   /* every path of the batch: its Path.mask (rows_p, cols_p) double, back to back in path order;
+                                * layer p starts at sum_{q<p} rows_q*cols_q doubles (clipped bboxes of svgr_batch_get_bboxes,
+                                * empty ones count 0).  One launch for all the masks a scene needs (clips, gradient fills). */
 
 /* flags of svgr_batch_render */
 #define SVGR_RENDER_CLIP01 1u  /* clip RGBA to [0, 1] on store (canvas_merge_at, S:326) */

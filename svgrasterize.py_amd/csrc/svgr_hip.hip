@@ -975,7 +975,7 @@ struct TileArgs {
     Owner own;                   // owned bands
     int out_cols;                // row pitch of `out` in pixels
     int clip01;
-    int single_r0, single_c0, single_cols;  // single-path outputs: layer origin / pitch
+    const long long* layer_off;  // mask / fill outputs of several paths: per path the offset (in pixels) of its layer in `out`
     unsigned long long* dbg;                // diagnostic builds only
 };
 
@@ -1098,7 +1098,8 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
         if (PREF_DEPTH >= 3) issue_next();
 
         // per-path state, set when the first window of the path is reached
-        int row_shift = 0, rows = 0, col_shift = 0, lo_c = 0, hi_c = 0, rule = 0, n_slots = 0, pflags = 0, pid = 0;
+        int row_shift = 0, rows = 0, col_shift = 0, lo_c = 0, hi_c = 0, rule = 0, n_slots = 0, pflags = 0, pid = 0, lcols = 0;
+        long long loff = 0;  // mask / fill outputs: where this path's layer starts in `out`, its row pitch is lcols
         double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
         int li = 0;
         constexpr int win = 0;
@@ -1133,6 +1134,10 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
                 rule = *(const int*)(blk + 4);
                 pflags = *((const int*)(blk + 4) + 1);
                 pid = s_list[li];
+                if (OUT >= 2) {
+                    lcols = cols;
+                    loff = a.layer_off ? a.layer_off[pid] : 0ll;
+                }
             }
 
             // ---- scatter: one lane per edge-row record; the pieces were computed by k_edge_emit, here
@@ -1307,9 +1312,9 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
                         if (row_ok && x_layer >= lo_c && x_layer < hi_c) {
                             double mval = fill_rule(run, rule);
                             if (OUT == 2) {
-                                ((double*)a.out)[(size_t)y_layer * a.single_cols + x_layer] = mval;
+                                ((double*)a.out)[(size_t)loff + (size_t)y_layer * lcols + x_layer] = mval;
                             } else {
-                                double* o = (double*)a.out + 4 * ((size_t)y_layer * a.single_cols + x_layer);
+                                double* o = (double*)a.out + 4 * ((size_t)loff + (size_t)y_layer * lcols + x_layer);
                                 o[0] = mval * p0; o[1] = mval * p1; o[2] = mval * p2; o[3] = mval * p3;
                             }
                         }
@@ -1658,6 +1663,8 @@ struct svgr_batch {
     DevArr<TileEntry> entries;
     DevArr<double> edges;
     DevArr<RowRec> bsegs;
+    DevArr<long long> layer_off;            // SVGR_OUT_MASKS_F64: per path the start of its mask in the output
+    std::vector<long long> host_layer_off;
     // plan results (n_edges = edge slots the edge kernels cover = sum of the shard capacities; n_edges_live = filled ones)
     bool geometry_fresh = false;  // the buffers hold the geometry of the current inputs (set by plan, consumed by render)
     int64_t n_edges_live = 0;
@@ -1690,7 +1697,7 @@ struct svgr_batch {
         segs.release(); path_m6.release(); path_paint.release(); seg_kind.release(); path_rule.release();
         seg_path.release(); arena.release(); edge_path.release(); bbox.release(); bins.release();
         bseg_off.release(); band_start.release(); band_count.release(); entries.release();
-        edges.release(); bsegs.release();
+        edges.release(); bsegs.release(); layer_off.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
         for (auto e : event_pool) (void)hipEventDestroy(e);
@@ -2181,19 +2188,32 @@ static int get_event(svgr_batch* b, hipEvent_t* e) {
 int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags) {
     if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
     if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan must run before svgr_batch_render");
-    if (out_kind < 0 || out_kind > 3) return fail(SVGR_E_INVALID, "unknown output kind %d", out_kind);
+    if (out_kind < 0 || out_kind > 4) return fail(SVGR_E_INVALID, "unknown output kind %d", out_kind);
+    const bool layers = out_kind == SVGR_OUT_MASKS_F64;  // one mask per path, back to back
+    if (layers) out_kind = SVGR_OUT_MASK_F64;
     const bool single = out_kind >= 2;
-    if (single && b->n_paths != 1) return fail(SVGR_E_INVALID, "mask/fill outputs need a single-path batch");
+    if (single && !layers && b->n_paths != 1) return fail(SVGR_E_INVALID, "mask/fill outputs need a single-path batch");
+    if (layers && b->own.world > 1) return fail(SVGR_E_INVALID, "per-path mask output is not sharded");
     HIPCHK(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
 
     const int owned_bands = count_owned_bands(b->own, b->n_bands);
     const int n_ctiles = (b->vp[3] + TC - 1) / TC;
     size_t need;
-    int single_bb[4] = {0, 0, 0, 0};
-    if (single) {
-        for (int i = 0; i < 4; ++i) single_bb[i] = b->host_bbox[i];
-        need = (size_t)std::max(single_bb[2], 0) * std::max(single_bb[3], 0) * sizeof(double) * (out_kind == 3 ? 4 : 1);
+    if (layers) {
+        // layer p starts at the sum of the areas (rows x cols of the clipped bbox, 0 when empty) of the paths before it
+        b->host_layer_off.resize((size_t)b->n_paths);
+        long long at = 0;
+        for (int64_t p = 0; p < b->n_paths; ++p) {
+            b->host_layer_off[(size_t)p] = at;
+            const long long r = b->host_bbox[4 * (size_t)p + 2], c = b->host_bbox[4 * (size_t)p + 3];
+            if (r > 0 && c > 0) at += r * c;
+        }
+        need = (size_t)at * sizeof(double);
+        if (int rc = b->layer_off.ensure((size_t)b->n_paths)) return rc;
+        HIPCHK(hipMemcpyAsync(b->layer_off.p, b->host_layer_off.data(), sizeof(long long) * (size_t)b->n_paths, hipMemcpyHostToDevice, st));
+    } else if (single) {
+        need = (size_t)std::max(b->host_bbox[2], 0) * std::max(b->host_bbox[3], 0) * sizeof(double) * (out_kind == 3 ? 4 : 1);
     } else {
         const bool all = b->own.world <= 1;
         size_t rows = all ? (size_t)b->vp[2] : (size_t)owned_bands * TR;
@@ -2226,7 +2246,7 @@ int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags
         a.own = b->own;
         a.out_cols = b->vp[3];
         a.clip01 = (flags & SVGR_RENDER_CLIP01) ? 1 : 0;
-        a.single_r0 = single_bb[0]; a.single_c0 = single_bb[1]; a.single_cols = single_bb[3];
+        a.layer_off = layers ? b->layer_off.p : nullptr;
         a.dbg = nullptr;
 #ifdef SVGR_DBG_STAMP
         {

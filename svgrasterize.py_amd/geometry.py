@@ -313,6 +313,10 @@ class Path:
         """Render path as a mask (alpha channel only image), S:922-993.
 
         Returns ``(Layer, ConvexHull)`` or ``None``; the layer's image stays in HBM until read."""
+        if MASK_PREFETCH is not None:  # Scene.render rendered every mask it will need in one batch (scene.py)
+            hit = MASK_PREFETCH.get(self, transform, fill_rule, viewport)
+            if hit is not MASK_PREFETCH.MISS:
+                return hit
         res = self._single_batch(transform, fill_rule, viewport)
         if res is None:
             return None
@@ -394,6 +398,76 @@ class Path:
         from .pathdata import parse_path_data  # noqa: PLC0415
 
         return cls(parse_path_data(d))
+
+
+class MaskPrefetch:
+    """Masks of many (path, transform, rule) jobs over ONE viewport, rendered by a single batch
+    (``SVGR_OUT_MASKS_F64``) and handed out by ``Path.mask``.  Purely a cache: a job that was not predicted is
+    rendered on demand as before."""
+
+    MISS = object()
+
+    def __init__(self, jobs, viewport):
+        self.viewport = tuple(int(v) for v in viewport)
+        self.table: dict = {}
+        todo, seen = [], set()
+        for path, transform, rule in jobs:
+            if rule not in _RULES:
+                continue  # Path.mask raises for it
+            key = (id(path), transform.m6().tobytes(), _RULES[rule])
+            if key in seen or len(path.packed()[0]) == 0:
+                continue
+            seen.add(key)
+            todo.append((key, path, transform, rule))
+        self.n_jobs = len(todo)
+        if not todo:
+            return
+        segs, kinds, offs, m6s, rules = [], [], [0], [], []
+        for _key, path, transform, rule in todo:
+            s, k = path.packed()
+            segs.append(s)
+            kinds.append(k)
+            offs.append(offs[-1] + len(s))
+            m6s.append(transform.m6())
+            rules.append(_RULES[rule])
+        ctx = _abi.Context.get()
+        batch = _abi.Batch(ctx, np.concatenate(segs), np.concatenate(kinds), offs, np.array(m6s), rules,
+                           np.zeros((len(todo), 4)), viewport=list(self.viewport), flatness=FLATNESS)
+        batch.plan()
+        bb = batch.bboxes()
+        area = np.where((bb[:, 2] > 0) & (bb[:, 3] > 0), bb[:, 2].astype(np.int64) * bb[:, 3], 0)
+        if int(area.sum()) * 8 > (1 << 31):  # more than 2 GiB of masks at once: leave them to the on-demand route
+            batch.destroy()
+            self.n_jobs = 0
+            return
+        buf, loffs, bb = batch.render_masks()
+        self._keep = (batch, buf)
+        base = buf.ptr
+        edges_cache: list = []
+
+        def edges_of(i):
+            if not edges_cache:
+                edges_cache.append(batch.edges())
+            e, ep = edges_cache[0]
+            return e[ep == i]
+
+        for i, (key, _path, _transform, _rule) in enumerate(todo):
+            rows, cols = int(bb[i, 2]), int(bb[i, 3])
+            if rows <= 0 or cols <= 0:
+                self.table[key] = None
+                continue
+            view = ctx.wrap(base + int(loffs[i]) * 8, rows * cols * 8)
+            view._parent = buf  # the view does not own the memory
+            layer = Layer._from_device(view, (rows, cols, 1), _offset(bb[i], self.viewport), pre_alpha=True, linear_rgb=True)
+            self.table[key] = (layer, ConvexHull(_source=lambda i=i: edges_of(i)))
+
+    def get(self, path, transform, fill_rule, viewport):
+        if viewport is None or fill_rule not in _RULES or tuple(int(v) for v in viewport) != self.viewport:
+            return self.MISS
+        return self.table.get((id(path), transform.m6().tobytes(), _RULES[fill_rule]), self.MISS)
+
+
+MASK_PREFETCH: "MaskPrefetch | None" = None
 
 
 def _offset(bb, viewport):

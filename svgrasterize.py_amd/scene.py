@@ -73,7 +73,27 @@ class Scene(tuple):
 
     # -- render (S:649-752) ------------------------------------------------------------------
     def render(self, transform: Transform, mask_only: bool = False, viewport=None, linear_rgb: bool = False):
-        """Render graph; returns ``(Layer, ConvexHull)`` or ``None``."""
+        """Render graph; returns ``(Layer, ConvexHull)`` or ``None`` (S:649-752).
+
+        The outermost call first renders, in ONE batch, every ``Path.mask`` the per-node route is going to ask for
+        (clip paths, gradient-filled paths): hundreds of single-path launches become one."""
+        from . import geometry  # noqa: PLC0415
+
+        if geometry.MASK_PREFETCH is not None or viewport is None or self[0] in (RENDER_FILL, RENDER_STROKE):
+            return self._render(transform, mask_only, viewport, linear_rgb)
+        global _LEAF_MEMO
+        jobs: list = []
+        _LEAF_MEMO = {}
+        try:
+            _collect_mask_jobs(self, transform, mask_only, linear_rgb, jobs)
+            if len(jobs) >= 4:
+                geometry.MASK_PREFETCH = geometry.MaskPrefetch(jobs, viewport)
+            return self._render(transform, mask_only, viewport, linear_rgb)
+        finally:
+            geometry.MASK_PREFETCH = None
+            _LEAF_MEMO = None
+
+    def _render(self, transform: Transform, mask_only: bool = False, viewport=None, linear_rgb: bool = False):
         kind, args = self
         if kind == RENDER_FILL:
             path, paint, fill_rule = args
@@ -102,12 +122,12 @@ class Scene(tuple):
                     hulls.append(res[1])
 
             for child in args:
-                leaves = None if mask_only else _batchable_leaves(child, transform, linear_rgb)
+                leaves = None if mask_only else _leaves_memo(child, transform, linear_rgb)
                 if leaves is not None:
                     run.extend(leaves)
                     continue
                 flush()
-                res = child.render(transform, mask_only, viewport, linear_rgb)
+                res = child._render(transform, mask_only, viewport, linear_rgb)
                 if res is None:
                     continue
                 layers.append(res[0])
@@ -120,7 +140,7 @@ class Scene(tuple):
 
         if kind == RENDER_OPACITY:
             target, opacity = args
-            res = target.render(transform, mask_only, viewport, linear_rgb)
+            res = target._render(transform, mask_only, viewport, linear_rgb)
             if res is None:
                 return None
             layer, hull = res
@@ -128,13 +148,13 @@ class Scene(tuple):
 
         if kind == RENDER_CLIP:
             target, clip, bbox_units = args
-            res = target.render(transform, mask_only, viewport, linear_rgb)
+            res = target._render(transform, mask_only, viewport, linear_rgb)
             if res is None:
                 return None
             image, hull = res
             if bbox_units:
                 transform = hull.bbox_transform(transform)
-            clip_res = clip.render(transform, True, viewport, linear_rgb)
+            clip_res = clip._render(transform, True, viewport, linear_rgb)
             if clip_res is None:
                 return None
             mask, _ = clip_res
@@ -145,13 +165,13 @@ class Scene(tuple):
 
         if kind == RENDER_TRANSFORM:
             target, target_transform = args
-            return target.render(transform @ target_transform, mask_only, viewport, linear_rgb)
+            return target._render(transform @ target_transform, mask_only, viewport, linear_rgb)
 
         if kind == RENDER_MASK:
             raise NotImplementedError("luminance masks are outside the accelerated path (SURVEY 8f-4)")
         if kind == RENDER_FILTER:
             target, flt = args
-            res = target.render(transform, mask_only, viewport, linear_rgb)
+            res = target._render(transform, mask_only, viewport, linear_rgb)
             if res is None:
                 return None
             image, hull = res
@@ -162,6 +182,51 @@ class Scene(tuple):
     def leaves(self, transform: Transform, linear_rgb: bool = False):
         """Flatten to paint-ordered solid leaves if the whole scene is batchable, else None."""
         return _batchable_leaves(self, transform, linear_rgb)
+
+
+def _collect_mask_jobs(scene: Scene, transform: Transform, mask_only: bool, linear_rgb: bool, jobs: list) -> None:
+    """(path, transform, rule) of every Path.mask the per-node route of `render` will call: leaves rendered
+    ``mask_only`` (clip subtrees) and gradient-filled leaves.  Mirrors the routing of `_render`; a wrong guess only
+    costs an unused mask or an on-demand one."""
+    from .paint import is_gradient  # noqa: PLC0415
+
+    kind, args = scene
+    if kind == RENDER_FILL:
+        path, paint, rule = args
+        if mask_only or is_gradient(paint):
+            jobs.append((path, transform, rule))
+    elif kind == RENDER_STROKE:
+        if mask_only or is_gradient(args[1]):
+            jobs.append((_stroked(scene), transform, None))
+    elif kind == RENDER_GROUP:
+        for child in args:
+            if not mask_only and _leaves_memo(child, transform, linear_rgb, store=True) is not None:
+                continue  # goes into a solid-fill batch
+            _collect_mask_jobs(child, transform, mask_only, linear_rgb, jobs)
+    elif kind == RENDER_TRANSFORM:
+        _collect_mask_jobs(args[0], transform @ args[1], mask_only, linear_rgb, jobs)
+    elif kind in (RENDER_OPACITY, RENDER_FILTER):
+        _collect_mask_jobs(args[0], transform, mask_only, linear_rgb, jobs)
+    elif kind == RENDER_CLIP:
+        target, clip, bbox_units = args
+        _collect_mask_jobs(target, transform, mask_only, linear_rgb, jobs)
+        if not bbox_units:  # (objectBoundingBox clips get their transform from the target's hull: on demand)
+            _collect_mask_jobs(clip, transform, True, linear_rgb, jobs)
+
+
+_LEAF_MEMO: "dict | None" = None  # during one top-level render: what the pre-pass already found out about group children
+
+
+def _leaves_memo(child: Scene, transform: Transform, linear_rgb: bool, store: bool = False):
+    if _LEAF_MEMO is None:
+        return _batchable_leaves(child, transform, linear_rgb)
+    key = (id(child), transform.m6().tobytes(), linear_rgb)
+    if key in _LEAF_MEMO:
+        return _LEAF_MEMO[key]
+    res = _batchable_leaves(child, transform, linear_rgb)
+    if store:
+        _LEAF_MEMO[key] = res
+    return res
 
 
 _STROKE_CACHE: dict = {}

@@ -143,3 +143,48 @@ def test_small_batch_planner_matches_staged_planner(S, monkeypatch):
         assert np.array_equal(a[2], s_[2])
         assert_close64(a[3], s_[3], atol=1e-12, what="speculative vs staged planner")
     assert out["staged"][0] > 64 * 2  # the second case really was beyond the speculative capacity
+
+
+def test_mask_prefetch_is_only_a_cache(S):
+    """Scene.render renders all the Path.mask calls of its per-node route in one SVGR_OUT_MASKS_F64 batch.  Same result as
+    the on-demand single-path masks; a path used twice, an empty path, a clipped-away path and an evenodd rule included."""
+    from svgrasterize_amd import geometry
+
+    swap = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    vp = [0, 0, 120, 140]
+    star = S.Path.from_svg("M60,10 L75,95 L10,40 L110,40 L45,95 Z")
+    blob = S.Path.from_svg("M20,30 C20,5 80,5 80,30 S110,85 60,90 C30,92 20,60 20,30 Z")
+    far = S.Path.from_svg("M500,500 L600,500 L600,600 Z")          # outside the viewport: mask is None
+    grad = S.GradLinear([10, 10], [100, 90], [(0.0, np.array([1.0, 0, 0, 1.0])), (1.0, np.array([0, 0, 1.0, 0.5]))],
+                        None, "pad", False, False)
+    kids = [
+        S.Scene.fill(blob, grad, None),
+        S.Scene.group([S.Scene.fill(star, np.array([0.1, 0.5, 0.2, 0.8]), "evenodd"), S.Scene.fill(blob, grad, None)]).clip(
+            S.Scene.fill(star, np.zeros(4), "evenodd"), False),
+        S.Scene.fill(far, grad, None),
+        S.Scene.fill(star, grad, "evenodd").opacity(0.5),
+        S.Scene.fill(blob, grad, None).transform(S.Transform().translate(15, 5)),
+    ]
+    scene = S.Scene.group(kids)
+    got = scene.render(swap, viewport=vp, linear_rgb=False)
+    # the same render with the prefetch disabled (every mask on demand)
+    geometry.MASK_PREFETCH = type("Off", (), {"MISS": object(), "get": lambda self, *a: self.MISS})()
+    try:
+        want = scene.render(swap, viewport=vp, linear_rgb=False)
+    finally:
+        geometry.MASK_PREFETCH = None
+    assert tuple(got[0].offset) == tuple(want[0].offset) and got[0].image.shape == want[0].image.shape
+    assert_close64(got[0].image, want[0].image, atol=1e-12, what="prefetched vs on-demand masks")
+    # the multi-mask output itself against single-path masks
+    jobs = [(star, swap, "evenodd"), (blob, swap, None), (far, swap, None), (blob, swap.translate(3, 4), None)]
+    pf = geometry.MaskPrefetch(jobs, vp)
+    assert pf.n_jobs == 4
+    for path, tr, rule in jobs:
+        hit = pf.get(path, tr, rule, vp)
+        single = path.mask(tr, rule, viewport=vp)
+        assert (hit is None) == (single is None)
+        if hit is not None:
+            assert tuple(hit[0].offset) == tuple(single[0].offset)
+            assert_close64(hit[0].image, single[0].image, atol=1e-13, what="mask from the batch")
+            assert np.array_equal(np.array(hit[1].points), np.array(single[1].points))
+    assert pf.get(star, swap, "evenodd", [0, 0, 50, 50]) is pf.MISS and pf.get(star, swap.scale(2), "evenodd", vp) is pf.MISS
