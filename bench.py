@@ -225,6 +225,49 @@ def main():
             print(f"[bench] rank {rank}: strip all_gather failed: {exc!r}", file=sys.stderr)
             gather_ms = None
 
+    # Weak-scaling companion (world > 1, synthetic workloads): a drawing `world` times as tall (one block of the bench
+    # scene per GPU, stacked; paths cross the block borders), each GPU renders its own block of rows from the paths that
+    # reach it.  Per-GPU work stays fixed as N grows; reported next to the strong-scaling value, never instead of it.
+    weak = None
+    if dist is not None and args.workload.startswith("synth"):
+        try:
+            from svgrasterize_amd import synth
+
+            size = int(args.workload[5:])
+            n_block = {4096: 4096, 8192: 10000}.get(size, size)
+            tall = synth.make_tall_scene(size, n_block, world)
+            sub, kept = synth.rows_subscene(tall, rank * size, (rank + 1) * size)
+            wb = _abi.Batch(ctx, sub["segs"], sub["seg_kind"], sub["path_seg_off"], sub["path_m6"], sub["path_rule"],
+                            sub["path_paint"], viewport=sub["viewport"])
+            wst = wb.plan()
+            wout = ctx.alloc(size * cols * 16)
+            for _ in range(args.warmup):
+                wb.render(wout, _abi.OUT_CANVAS_F32, flags)
+            barrier()
+            w0 = time.perf_counter()
+            for _ in range(args.steps):
+                wb.render(wout, _abi.OUT_CANVAS_F32, flags)
+            ctx.sync()
+            w_local = time.perf_counter() - w0
+            barrier()
+            acc = torch.tensor([w_local, float(wst.path_pixels), float(len(kept))], dtype=torch.float64, device=coll_dev)
+            tmax_t = acc[:1].clone()
+            dist.all_reduce(tmax_t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            w_t = float(tmax_t.item())
+            weak = {
+                "scaling": "weak", "value": round(float(acc[1].item()) / (w_t / args.steps) / 1e6, 1), "unit": "Mpixels/s",
+                "ms_per_step": round(w_t / args.steps * 1e3, 4), "path_pixels": int(acc[1].item()),
+                "workload": f"{world} stacked blocks of the bench scene ({world * n_block} paths @ {world * size}x{size}); "
+                            f"every GPU renders its own {size}-row block from the paths that reach it "
+                            f"({int(acc[2].item())} path instances over all GPUs: border paths go to both neighbours)",
+            }
+            del wout
+            wb.destroy()
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] rank {rank}: weak-scaling companion failed: {exc!r}", file=sys.stderr)
+            weak = None
+
     if rank == 0:
         ms_step = t_max / args.steps * 1e3
         tile_ms = tm["ms_tile"] / max(tm["n"], 1)
@@ -271,6 +314,8 @@ def main():
         }
         if gather_ms is not None:
             line["all_gather_ms"] = round(gather_ms, 4)
+        if weak is not None:
+            line["weak_scaling"] = weak
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sc, args.cpu_paths)
         print(json.dumps(line))

@@ -83,6 +83,55 @@ def make_scene(size: int, n_paths: int, seed: int = SEED):
     )
 
 
+def make_tall_scene(size: int, n_paths: int, blocks: int):
+    """Weak-scaling workload: `blocks` scenes of `n_paths` paths stacked vertically on a (blocks*size) x size canvas.
+    Block b is make_scene(size, n_paths, seed=SEED + b) moved down by b*size rows; paths near a block border reach
+    into the neighbour block, exactly like paths near a tile border of one big drawing.  Paint order = block, then i."""
+    parts = [make_scene(size, n_paths, seed=SEED + b) for b in range(blocks)]
+    segs = []
+    for b, sc in enumerate(parts):
+        s = sc["segs"].copy()
+        s[:, 1::2] += float(b * size)  # y of every control point (row after the swap transform)
+        segs.append(s)
+    offs = [0]
+    for sc in parts:
+        offs.extend((sc["path_seg_off"][1:] + offs[-1]).tolist())
+    segs = np.concatenate(segs)
+    return dict(
+        segs=segs,
+        seg_kind=np.ones(len(segs), dtype=np.uint8),
+        path_seg_off=np.array(offs, dtype=np.int64),
+        path_m6=np.tile(SWAP_M6, (n_paths * blocks, 1)),
+        path_rule=np.concatenate([sc["path_rule"] for sc in parts]),
+        path_paint=np.concatenate([sc["path_paint"] for sc in parts]),
+        viewport=(0, 0, size * blocks, size),
+    )
+
+
+def rows_subscene(scene, r0: int, r1: int):
+    """The paths of `scene` whose control points reach the rows [r0, r1) (+-2 rows of slack), in paint order, with
+    viewport = that row block: what one GPU of a row-sharded render needs (a path that crosses the border goes to both
+    neighbours).  The curve stays inside the hull of its control points, so nothing that has a pixel in the block is lost."""
+    off = scene["path_seg_off"]
+    y = scene["segs"][:, 1::2]  # rows after the swap transform
+    seg_lo, seg_hi = y.min(axis=1), y.max(axis=1)
+    n = len(off) - 1
+    lo = np.minimum.reduceat(seg_lo, off[:-1]) if n else np.zeros(0)
+    hi = np.maximum.reduceat(seg_hi, off[:-1]) if n else np.zeros(0)
+    keep = np.nonzero((np.floor(lo) - 2 < r1) & (np.ceil(hi) + 2 > r0))[0]
+    seg_idx = np.concatenate([np.arange(off[p], off[p + 1]) for p in keep]) if len(keep) else np.zeros(0, dtype=np.int64)
+    sizes = (off[1:] - off[:-1])[keep]
+    return dict(
+        segs=scene["segs"][seg_idx],
+        seg_kind=scene["seg_kind"][seg_idx],
+        path_seg_off=np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64),
+        path_m6=scene["path_m6"][keep],
+        path_rule=scene["path_rule"][keep],
+        path_paint=scene["path_paint"][keep],
+        viewport=(r0, scene["viewport"][1], r1 - r0, scene["viewport"][3]),
+    ), keep
+
+
 def presentation_segs(scene) -> np.ndarray:
     """The scene's control points after the swap transform, (n, 8) as (row, col) pairs.
     The swap matrix only permutes coordinates (exact in floating point)."""

@@ -272,3 +272,32 @@ def test_band_sharding_matches_full(S, world, strip):
     assert_close64(sdist.assemble(parts, size, tr, strip), full, atol=1e-12, what="assembled")
     assert edges_kept < world * st_full.n_edges  # border edges are duplicated, everything else is shared out
     batch.set_bands(0, 1, 1)
+
+
+def test_row_block_of_a_tall_scene_matches_the_full_render(S):
+    """Weak-scaling decomposition: a GPU that renders rows [r0, r1) of a tall drawing from only the paths that reach
+    them (synth.rows_subscene) gets the same pixels as those rows of the full render."""
+    from svgrasterize_amd import _abi, synth
+
+    size, n, blocks = 192, 40, 3
+    tall = synth.make_tall_scene(size, n, blocks)
+    assert tall["viewport"] == (0, 0, size * blocks, size) and len(tall["path_seg_off"]) == n * blocks + 1
+    ctx = S.Context.get()
+
+    def render(sc):
+        b = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
+                       viewport=sc["viewport"])
+        b.plan()
+        rows, cols = sc["viewport"][2], sc["viewport"][3]
+        out = ctx.alloc(rows * cols * 32)
+        b.render(out, _abi.OUT_CANVAS_F64)
+        return out.download((rows, cols, 4), np.float64)
+
+    full = render(tall)
+    kept_total = 0
+    for k in range(blocks):
+        sub, kept = synth.rows_subscene(tall, k * size, (k + 1) * size)
+        kept_total += len(kept)
+        assert 0 < len(kept) < n * blocks and np.all(np.diff(kept) > 0)  # a proper subset, paint order kept
+        assert_close64(render(sub), full[k * size:(k + 1) * size], atol=1e-12, what=f"row block {k}")
+    assert kept_total > n * blocks  # border paths are rendered by both neighbours
