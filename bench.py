@@ -13,6 +13,10 @@ Edges that cross a band border are simply processed by both owners (duplicated e
 no pixel ever crosses a GPU), so the data path needs no collective; RCCL is used for the barrier /
 max-over-ranks clock and for the optional final all_gather of the bands (reported separately).
 
+For N > 1 the line also carries a `weak_scaling` object, measured right after the strong-scaling steps: a drawing N
+times as tall (one block of the bench scene per GPU, stacked; paths cross the block borders), every GPU rendering its own
+4096-row block from the paths that reach it -- fixed work per GPU.  It never replaces `value`.
+
 Rank 0 prints ONE JSON line (contract in the task statement + `roofline` and `cpu_baseline`).
 """
 from __future__ import annotations
