@@ -7,15 +7,17 @@ One step = one full pass of the hot path over the scene, inputs resident in HBM 
 starts: transform + flatten + bbox + band binning + tile kernel (LDS delta scatter, row scan, fill
 rule, paint, source-over) -> finished float32 RGBA canvas in HBM.  No host read-back inside a step.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the canvas is sharded by interleaved
-strips of 128 scanlines (rank r owns strips r, r+N, ...): the same scene, total work fixed -> "strong" scaling.
-Edges that cross a band border are simply processed by both owners (duplicated edges are the halo;
-no pixel ever crosses a GPU), so the data path needs no collective; RCCL is used for the barrier /
-max-over-ranks clock and for the optional final all_gather of the bands (reported separately).
+N > 1 (launched by torch.distributed.run, one rank per GPU).  The path shards by rows (a scanline never needs another
+scanline), so the headline is WEAK scaling: a drawing N times as tall -- N blocks of the bench scene stacked, paths cross
+the block borders -- and every GPU renders its own 4096 x 4096 block of rows from the paths whose control points reach
+it (border paths go to both neighbours: duplicated geometry is the halo, no pixel ever crosses a GPU, no data-path
+collective).  Per-GPU work is fixed; `value` = path-pixels of all blocks / slowest rank's time.  RCCL is used for the
+barrier / max-over-ranks clock only.
 
-For N > 1 the line also carries a `weak_scaling` object, measured right after the strong-scaling steps: a drawing N
-times as tall (one block of the bench scene per GPU, stacked; paths cross the block borders), every GPU rendering its own
-4096-row block from the paths that reach it -- fixed work per GPU.  It never replaces `value`.
+The same line carries `strong_scaling`, measured right after: the ONE 4096 x 4096 bench scene sharded over the N GPUs by
+interleaved strips of 128 scanlines (`svgr_batch_set_bands`; every rank culls the geometry to what reaches its strips),
+total work fixed, plus the optional all_gather of the strips -- the north star's "tile-parallel speedup" of a
+half-millisecond job, bounded by launch latencies.
 
 Rank 0 prints ONE JSON line (contract in the task statement + `roofline` and `cpu_baseline`).
 """
@@ -138,7 +140,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
+    dist = torch = None
+    coll_dev = "cpu"
     if world > 1:
         # torch first: its bundled HIP runtime must be the one in the process
         import torch
@@ -152,132 +155,144 @@ def main():
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            coll_dev = f"cuda:{local_rank}"
         else:
             dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
-    import numpy as np
+    import numpy as np  # noqa: F401
 
     import svgrasterize_amd as S
-    from svgrasterize_amd import _abi
+    from svgrasterize_amd import _abi, synth
 
     ctx = S.Context.get(local_rank)
-    sc, desc = load_workload(args.workload)
-    rows, cols = int(sc["viewport"][2]), int(sc["viewport"][3])
-    batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
-                       viewport=sc["viewport"])
-    st = batch.plan()
-    P, E = int(st.path_pixels), int(st.n_edges)
-    strip = int(os.environ.get("SVGR_STRIP_BANDS", str(max(1, 128 // _abi.tile_rows()))))  # 128 scanlines per strip
-    if world > 1:
-        batch.set_bands(rank, world, strip)
-        batch.plan()  # per-rank capacities: each rank keeps only the edges that reach its strips
-    own_rows = batch.owned_rows()
-    if world > 1:
-        import torch
-
-        out_t = torch.empty((own_rows, cols, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
-        out = ctx.wrap(out_t.data_ptr(), out_t.numel() * 4)
-    else:
-        out = ctx.alloc(own_rows * cols * 16)
+    every = max(1, args.time_every)
+    flags = _abi.RENDER_CLIP01
 
     def barrier():
         ctx.sync()
         if dist is not None:
-            import torch
-
             dist.barrier()
             torch.cuda.synchronize()
 
-    flags = _abi.RENDER_CLIP01
-    for _ in range(args.warmup):
-        batch.render(out, _abi.OUT_CANVAS_F32, flags)
-    barrier()
-    batch.timings()  # drop
-    t0 = time.perf_counter()
-    every = max(1, args.time_every)
-    for i in range(args.steps):
-        batch.render(out, _abi.OUT_CANVAS_F32, flags | (_abi.RENDER_TIMED if i % every == 0 else 0))
-    ctx.sync()
-    t_local = time.perf_counter() - t0
-    barrier()
-    tm = batch.timings()  # HIP events on the library's stream around the stages of every timed step
+    def reduce(values, op):
+        """all-reduce a list of floats over the ranks (identity for one rank)"""
+        if dist is None:
+            return list(values)
+        t = torch.tensor(list(values), dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=op)
+        return [float(v) for v in t.cpu()]
 
-    t_max = t_local
-    gather_ms = None
-    if dist is not None:
-        import torch
+    def measure(batch, out):
+        """W warm-up steps, barrier, exactly K timed steps, barrier -> (max-over-ranks seconds, stage timings of this rank)"""
+        for _ in range(args.warmup):
+            batch.render(out, _abi.OUT_CANVAS_F32, flags)
+        barrier()
+        batch.timings()  # drop
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            batch.render(out, _abi.OUT_CANVAS_F32, flags | (_abi.RENDER_TIMED if i % every == 0 else 0))
+        ctx.sync()
+        t_local = time.perf_counter() - t0
+        barrier()
+        tm = batch.timings()  # HIP events on the library's stream around the stages of every `every`-th timed step
+        t_max = reduce([t_local], dist.ReduceOp.MAX)[0] if dist is not None else t_local
+        return t_max, tm
 
-        coll_dev = f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu"
-        tt = torch.tensor([t_local], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_max = float(tt.item())
-        # optional assembly of the full canvas on every rank (svgrasterize.py_amd/dist.py), reported separately
-        from svgrasterize_amd import dist as sdist
+    def new_batch(scene):
+        return _abi.Batch(ctx, scene["segs"], scene["seg_kind"], scene["path_seg_off"], scene["path_m6"], scene["path_rule"],
+                          scene["path_paint"], viewport=scene["viewport"])
 
-        try:  # (reported separately; a failure here must not cost the bench line)
-            dist.barrier()
-            torch.cuda.synchronize()
-            g0 = time.perf_counter()
-            for _ in range(3):
-                full_t = sdist.gather_canvas(out_t if coll_dev != "cpu" else out_t.cpu(), rows, _abi.tile_rows(), strip=strip)
-            torch.cuda.synchronize()
-            gather_ms = (time.perf_counter() - g0) / 3 * 1e3
-            del full_t
-        except Exception as exc:  # noqa: BLE001
-            print(f"[bench] rank {rank}: strip all_gather failed: {exc!r}", file=sys.stderr)
-            gather_ms = None
+    sc, desc = load_workload(args.workload)
+    rows, cols = int(sc["viewport"][2]), int(sc["viewport"][3])
+    n_scene_paths = int(len(sc["path_seg_off"]) - 1)
+    weak_mode = world > 1 and args.workload.startswith("synth")
 
-    # Weak-scaling companion (world > 1, synthetic workloads): a drawing `world` times as tall (one block of the bench
-    # scene per GPU, stacked; paths cross the block borders), each GPU renders its own block of rows from the paths that
-    # reach it.  Per-GPU work stays fixed as N grows; reported next to the strong-scaling value, never instead of it.
-    weak = None
-    if dist is not None and args.workload.startswith("synth"):
+    # ---- headline -------------------------------------------------------------------------------------------------
+    if weak_mode:
+        # a drawing `world` times as tall; this rank renders its own block of rows from the paths that reach it
+        tall = synth.make_tall_scene(rows, n_scene_paths, world)
+        mine, kept = synth.rows_subscene(tall, rank * rows, (rank + 1) * rows)
+        batch = new_batch(mine)
+        st = batch.plan()
+        out = ctx.alloc(rows * cols * 16)
+        t_max, tm = measure(batch, out)
+        P_rank, E_rank = int(st.path_pixels), int(st.n_edges)
+        P, E, inst = (int(v) for v in reduce([P_rank, E_rank, len(kept)], dist.ReduceOp.SUM))
+        config = {
+            "workload": f"{world} stacked blocks of: {desc}", "canvas": [rows * world, cols], "paths": n_scene_paths * world,
+            "edges": E, "path_pixels": P,
+            "sharding": f"{world} ranks, each renders its own {rows}-row block from the paths whose control points reach it "
+                        f"({inst} path instances in all: border paths go to both neighbours); no data-path collective",
+        }
+        scaling = "weak"
+        canvas_px = rows * world * cols
+        del out
+        batch.destroy()
+    else:
+        batch = new_batch(sc)
+        st = batch.plan()
+        P = P_rank = int(st.path_pixels)
+        E = E_rank = int(st.n_edges)
+        strip = int(os.environ.get("SVGR_STRIP_BANDS", str(max(1, 128 // _abi.tile_rows()))))  # 128 scanlines per strip
+        if world > 1:  # a real-asset workload on several GPUs: one scene, row strips
+            batch.set_bands(rank, world, strip)
+            batch.plan()
+            P_rank, E_rank = P / world, E / world
+        out = ctx.alloc(max(batch.owned_rows(), 1) * cols * 16)
+        t_max, tm = measure(batch, out)
+        config = {
+            "workload": desc, "canvas": [rows, cols], "paths": n_scene_paths, "edges": E, "path_pixels": P,
+            "sharding": f"{world} ranks x interleaved strips of {strip} bands ({strip * _abi.tile_rows()} rows)" if world > 1 else "single GPU",
+        }
+        # (the N = 1 point of the synthetic series is the same scene as block 0 of the weak-scaling drawing)
+        scaling = "weak" if args.workload.startswith("synth") and world == 1 else "strong"
+        canvas_px = rows * cols
+
+    # ---- companion for N > 1: the ONE bench scene sharded over the ranks (strong scaling) ---------------------------------
+    strong = None
+    if weak_mode:
         try:
-            from svgrasterize_amd import synth
-
-            size = int(args.workload[5:])
-            n_block = {4096: 4096, 8192: 10000}.get(size, size)
-            tall = synth.make_tall_scene(size, n_block, world)
-            sub, kept = synth.rows_subscene(tall, rank * size, (rank + 1) * size)
-            wb = _abi.Batch(ctx, sub["segs"], sub["seg_kind"], sub["path_seg_off"], sub["path_m6"], sub["path_rule"],
-                            sub["path_paint"], viewport=sub["viewport"])
-            wst = wb.plan()
-            wout = ctx.alloc(size * cols * 16)
-            for _ in range(args.warmup):
-                wb.render(wout, _abi.OUT_CANVAS_F32, flags)
-            barrier()
-            w0 = time.perf_counter()
-            for _ in range(args.steps):
-                wb.render(wout, _abi.OUT_CANVAS_F32, flags)
-            ctx.sync()
-            w_local = time.perf_counter() - w0
-            barrier()
-            acc = torch.tensor([w_local, float(wst.path_pixels), float(len(kept))], dtype=torch.float64, device=coll_dev)
-            tmax_t = acc[:1].clone()
-            dist.all_reduce(tmax_t, op=dist.ReduceOp.MAX)
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
-            w_t = float(tmax_t.item())
-            weak = {
-                "scaling": "weak", "value": round(float(acc[1].item()) / (w_t / args.steps) / 1e6, 1), "unit": "Mpixels/s",
-                "ms_per_step": round(w_t / args.steps * 1e3, 4), "path_pixels": int(acc[1].item()),
-                "workload": f"{world} stacked blocks of the bench scene ({world * n_block} paths @ {world * size}x{size}); "
-                            f"every GPU renders its own {size}-row block from the paths that reach it "
-                            f"({int(acc[2].item())} path instances over all GPUs: border paths go to both neighbours)",
+            sb = new_batch(sc)
+            st1 = sb.plan()
+            strip = int(os.environ.get("SVGR_STRIP_BANDS", str(max(1, 128 // _abi.tile_rows()))))
+            sb.set_bands(rank, world, strip)
+            sb.plan()  # per-rank capacities: each rank keeps only the geometry that reaches its strips
+            own_rows = sb.owned_rows()
+            out_t = torch.empty((own_rows, cols, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+            sout = ctx.wrap(out_t.data_ptr(), out_t.numel() * 4)
+            s_max, _stm = measure(sb, sout)
+            strong = {
+                "scaling": "strong", "value": round(int(st1.path_pixels) / (s_max / args.steps) / 1e6, 1), "unit": "Mpixels/s",
+                "ms_per_step": round(s_max / args.steps * 1e3, 4), "path_pixels": int(st1.path_pixels),
+                "workload": f"the single-GPU bench scene ({n_scene_paths} paths @ {rows}x{cols}) sharded over {world} ranks by "
+                            f"interleaved strips of {strip * _abi.tile_rows()} rows",
             }
-            del wout
-            wb.destroy()
-        except Exception as exc:  # noqa: BLE001
-            print(f"[bench] rank {rank}: weak-scaling companion failed: {exc!r}", file=sys.stderr)
-            weak = None
+            try:  # optional assembly of the full canvas on every rank (svgrasterize.py_amd/dist.py)
+                from svgrasterize_amd import dist as sdist
+
+                barrier()
+                g0 = time.perf_counter()
+                for _ in range(3):
+                    full_t = sdist.gather_canvas(out_t if coll_dev != "cpu" else out_t.cpu(), rows, _abi.tile_rows(), strip=strip)
+                torch.cuda.synchronize()
+                strong["all_gather_ms"] = round((time.perf_counter() - g0) / 3 * 1e3, 4)
+                del full_t
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] rank {rank}: strip all_gather failed: {exc!r}", file=sys.stderr)
+            del sout, out_t
+            sb.destroy()
+        except Exception as exc:  # noqa: BLE001  (a companion must not cost the bench line)
+            print(f"[bench] rank {rank}: strong-scaling companion failed: {exc!r}", file=sys.stderr)
+            strong = None
 
     if rank == 0:
-        ms_step = t_max / args.steps * 1e3
-        tile_ms = tm["ms_tile"] / max(tm["n"], 1)
-        geo_ms = tm["ms_geometry"] / max(tm["n"], 1)
-        # per-rank share of the algorithmic bytes: this rank's tile kernel handled ~1/world of the path-pixels
-        alg_bytes = (BYTES_PER_PATH_PIXEL * P + BYTES_PER_EDGE * E) / world
+        n_timed = max(tm["n"], 1)
+        tile_ms = tm["ms_tile"] / n_timed
+        geo_ms = tm["ms_geometry"] / n_timed
+        # the dominant kernel as launched on this rank: its own share of the algorithmic bytes over its own duration
+        alg_bytes = BYTES_PER_PATH_PIXEL * P_rank + BYTES_PER_EDGE * E_rank
         achieved = alg_bytes / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_tile_kernel.json")
@@ -286,7 +301,7 @@ def main():
                 rec = json.load(open(pmc))
                 if rec.get("workload") == args.workload:
                     traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
+            except Exception:  # noqa: BLE001
                 traffic = None
         line = {
             "metric": "Mpixels/sec AA coverage+composite (path-pixels/s; whole step: flatten+binning+coverage+composite)",
@@ -295,31 +310,27 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 4),
+            "ms_per_step": round(t_max / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64 arithmetic, f32 RGBA store",
             "data": "synthetic" if args.workload.startswith("synth") else "real asset (scene dump)",
-            "config": {
-                "workload": desc, "canvas": [rows, cols], "paths": int(len(sc["path_seg_off"]) - 1), "edges": E,
-                "path_pixels": P, "sharding": f"{world} ranks x interleaved strips of {strip} bands ({strip * _abi.tile_rows()} rows)" if world > 1 else "single GPU",
-            },
-            "canvas_mpixels_per_s": round(rows * cols / (t_max / args.steps) / 1e6, 1),
+            "config": config,
+            "canvas_mpixels_per_s": round(canvas_px / (t_max / args.steps) / 1e6, 1),
             "roofline": {
                 "kernel": "k_tile_render<f32>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_ms": round(tile_ms, 4), "geometry_ms": round(geo_ms, 4), "launches_timed": int(tm["n"]),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "note": "effective bandwidth: 40 B/path-pixel + 32 B/edge (SURVEY 8d) over the HIP-event duration of the "
-                        "tile kernel (events on the library's stream around every %d-th launch of the timed region); the kernel "
-                        "keeps trace and canvas on chip, so frac may exceed what real HBM traffic could" % every,
+                        "tile kernel (events on the library's stream around every %d-th launch of the timed region; rank 0's "
+                        "launch and its share of the bytes); the kernel keeps trace and canvas on chip, so frac may exceed "
+                        "what real HBM traffic could" % every,
             },
         }
-        if gather_ms is not None:
-            line["all_gather_ms"] = round(gather_ms, 4)
-        if weak is not None:
-            line["weak_scaling"] = weak
+        if strong is not None:
+            line["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sc, args.cpu_paths)
         print(json.dumps(line))
