@@ -961,14 +961,8 @@ __device__ __forceinline__ double dpp_ctrl(double v) {  // generic DPP move of a
     return __hiloint2double(hi, lo);
 }
 
-// offset of tile column `tcol` (>= 0) inside a padded delta row: every chunk of PX columns is followed by
-// CHUNK_STRIDE - PX pad doubles, i.e. (tcol / PX) * CHUNK_STRIDE + tcol % PX without the multiply
-__device__ __forceinline__ int lds_col(int tcol) {
-    static_assert((PX & (PX - 1)) == 0, "PX is a power of two");
-    return tcol + (int)((unsigned)tcol / PX) * (CHUNK_STRIDE - PX);
-}
 __device__ __forceinline__ int lds_index(int trow, int tcol) {
-    return __mul24(trow, ROW_STRIDE) + lds_col(tcol);
+    return trow * ROW_STRIDE + (tcol / PX) * CHUNK_STRIDE + (tcol % PX);
 }
 
 struct TileArgs {
@@ -1091,16 +1085,13 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
         // ------------------------------------------------------------------------------------------
         auto issue = [&](int li_, int win_, int buf_) {
             if (wave < PREF_WAVES) {
-                // (block bounds are wave-uniform: kept in SGPRs so that the x48 address arithmetic is scalar)
-                const int seg0_ = __builtin_amdgcn_readfirstlane(s_seg0[li_]), seg1_ = __builtin_amdgcn_readfirstlane(s_seg1[li_]);
-                const int left_ = seg1_ - seg0_ - win_;
+                const int left_ = s_seg1[li_] - s_seg0[li_] - win_;
                 const int n_bytes = (left_ < PREF_RECS ? left_ : PREF_RECS) * REC_BYTES;
-                const char* const gbase = (const char*)(a.bsegs + seg0_ + win_);
 #pragma unroll
                 for (int j = 0; j < DMA_PER_WAVE; ++j) {
                     const int t_ = (wave * DMA_PER_WAVE + j) * 64 + lane;  // 16-byte chunk of the block this lane fetches
                     const int off_ = t_ * 16 < n_bytes ? t_ * 16 : n_bytes - 16;
-                    const char* g = gbase + off_;
+                    const char* g = (const char*)(a.bsegs + s_seg0[li_] + win_) + off_;
                     const unsigned lds_base = __builtin_amdgcn_readfirstlane(
                         (unsigned)(size_t)(lds_ptr_t)(s_mem + OFF_PREF + buf_ * PREF_BYTES + (wave * DMA_PER_WAVE + j) * 1024));
                     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
@@ -1178,14 +1169,14 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
                     unsigned nrow;
                     double v[5];
                     if (sl < PREF_RECS) {
-                        const double* q = blk + __mul24(sl, REC_BYTES / 8);
+                        const double* q = blk + sl * (REC_BYTES / 8);
                         const int2 hd = *(const int2*)q;
                         x0i = hd.x; nrow = (unsigned)hd.y;
                         v[0] = q[1]; v[1] = q[2]; v[2] = q[3]; v[3] = q[4]; v[4] = q[5];
                     } else {
                         // pair longer than the prefetch block: the tail comes straight from HBM.  Inline asm, so
                         // that hipcc does not put a vmcnt(0) wait on the common path (it would for a plain load).
-                        const RowRec* gp = a.bsegs + __builtin_amdgcn_readfirstlane(s_seg0[li]) + sl;
+                        const RowRec* gp = a.bsegs + s_seg0[li] + sl;
                         double hd_;
                         asm volatile("global_load_dwordx2 %0, %6, off\n\t"
                                      "global_load_dwordx2 %1, %6, off offset:8\n\t"
@@ -1201,7 +1192,7 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
                         nrow = (unsigned)__double2hiint(hd_);
                     }
                     const int n = (int)(nrow & SPAN_MAX);
-                    double* trow_ptr = s_trace + __mul24((int)(nrow >> 26), ROW_STRIDE);  // (32-bit multiplies are quarter rate)
+                    double* trow_ptr = s_trace + (int)(nrow >> 26) * ROW_STRIDE;
                     if (x0i >= hi_c) continue;  // everything at or beyond the tile's / layer's right edge
                     if (x0i + n < lo_c) {
                         // whole row span left of the tile: fold the sum of its pieces (= d) into the first column
@@ -1209,7 +1200,7 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
                         if (n >= 3) sum = sum + (double)(n - 3) * v[2] + v[3];
                         if (n >= 2) sum = sum + v[4];
                         const int tc = lo_c + col_shift;
-                        __hip_atomic_fetch_add(trow_ptr + lds_col(tc), sum, __ATOMIC_RELAXED,
+                        __hip_atomic_fetch_add(trow_ptr + (tc / PX) * CHUNK_STRIDE + (tc % PX), sum, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_WORKGROUP);
                         continue;
                     }
@@ -1218,7 +1209,7 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
                         if (c >= hi_c) return false;
                         c = c > lo_c ? c : lo_c;   // left of the tile folds into its first column (row carry-in)
                         const int tc = c + col_shift;
-                        __hip_atomic_fetch_add(trow_ptr + lds_col(tc), val, __ATOMIC_RELAXED,
+                        __hip_atomic_fetch_add(trow_ptr + (tc / PX) * CHUNK_STRIDE + (tc % PX), val, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_WORKGROUP);
                         return true;
                     });
@@ -1328,11 +1319,8 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
                         // under the exec mask: a tenth of the pixel slots of a wave have no visible lane at all.
 #pragma unroll
                         for (int i = 0; i < PX; ++i) {
-                            if (__builtin_expect(fabs(t[i]) >= kZeroCut, 1)) {  // (visible falls through)
-                                double mval;  // min(|t|, 1): asm, because fmin() first canonicalises its operand (a v_max)
-                                asm("v_min_f64 %0, |%1|, 1.0" : "=v"(mval) : "v"(t[i]));
-                                blend(i, mval);
-                            }
+                            const double a_ = fabs(t[i]);
+                            if (a_ >= kZeroCut) blend(i, fmin(a_, 1.0));
                         }
                     } else {
                     bool vis[PX];  // the 1e-6 cut (S:990), as lane masks

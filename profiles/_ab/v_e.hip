@@ -1328,11 +1328,8 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
                         // under the exec mask: a tenth of the pixel slots of a wave have no visible lane at all.
 #pragma unroll
                         for (int i = 0; i < PX; ++i) {
-                            if (__builtin_expect(fabs(t[i]) >= kZeroCut, 1)) {  // (visible falls through)
-                                double mval;  // min(|t|, 1): asm, because fmin() first canonicalises its operand (a v_max)
-                                asm("v_min_f64 %0, |%1|, 1.0" : "=v"(mval) : "v"(t[i]));
-                                blend(i, mval);
-                            }
+                            const double a_ = fabs(t[i]);
+                            if (__builtin_expect(a_ >= kZeroCut, 1)) blend(i, fmin(a_, 1.0));  // (visible falls through)
                         }
                     } else {
                     bool vis[PX];  // the 1e-6 cut (S:990), as lane masks
