@@ -1876,7 +1876,7 @@ int svgr_init(int device_id, svgr_ctx** out) {
     svgr_ctx* c = new (std::nothrow) svgr_ctx();
     if (!c) return fail(SVGR_E_NOMEM, "out of host memory");
     c->device = device_id;
-    snprintf(c->name, sizeof c->name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    snprintf(c->name, sizeof c->name, "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD Instinct", prop.gcnArchName, prop.multiProcessorCount);
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return fail(SVGR_E_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
     c->own_stream = true;
