@@ -85,6 +85,26 @@ SVGR_HD void cubic_right(const double* c, double* r) {
         r[6 + ax] = x3;
     }
 }
+// The two halves IN PLACE (same rows, evaluated in an order in which every input is still the old value): no
+// temporary cubic and no copy back, which is a quarter of the instructions of the flatten kernel otherwise.
+SVGR_HD void half_left(double& x0, double& x1, double& x2, double& x3) {
+    x3 = split_mid(x0, x1, x2, x3);
+    x2 = fma(0.25, x0, 0.25 * x2) + 0.5 * x1;
+    x1 = 0.5 * x0 + 0.5 * x1;
+}
+SVGR_HD void half_right(double& x0, double& x1, double& x2, double& x3) {
+    x0 = split_mid(x0, x1, x2, x3);
+    x1 = 0.5 * x2 + fma(0.25, x1, 0.25 * x3);
+    x2 = 0.5 * x2 + 0.5 * x3;
+}
+SVGR_HD void cubic_left_inplace(double* c) {
+    half_left(c[0], c[2], c[4], c[6]);
+    half_left(c[1], c[3], c[5], c[7]);
+}
+SVGR_HD void cubic_right_inplace(double* c) {
+    half_right(c[0], c[2], c[4], c[6]);
+    half_right(c[1], c[3], c[5], c[7]);
+}
 SVGR_HD void cubic_split(const double* c, double* l, double* r) {
     cubic_left(c, l);
     cubic_right(c, r);
@@ -125,35 +145,37 @@ SVGR_HD int flatten_cubic(const double* cubic, double thr, Emit&& emit) {
 // the recursive form performs, so the pieces are bit-identical -- and nothing spills to scratch.
 // `emit(p0r, p0c, p1r, p1c)` once per flat piece in curve order; returns the piece count and sets
 // `overflow` when `max_depth` forced a piece out (non-finite / absurd input).
+// `ends` (optional): the end points of the first two pieces {r1, c1, r2, c2}, so that a caller that first counts and then
+// stores can skip the second traversal for the (very common) subtrees of one or two pieces.
 template <class Emit>
-SVGR_HD int flatten_subtree(const double* root, double thr, int max_depth, Emit&& emit, bool& overflow) {
+SVGR_HD int flatten_subtree(const double* root, double thr, int max_depth, Emit&& emit, bool& overflow, double* ends = nullptr) {
     double cur[8];
     for (int i = 0; i < 8; ++i) cur[i] = root[i];
     int level = 0, n = 0;
     unsigned long long idx = 0;
+    double e0r = 0.0, e0c = 0.0, e1r = 0.0, e1c = 0.0;
     for (;;) {
         bool flat = cubic_flatness(cur) < thr;
         if (!flat && level >= max_depth) { flat = true; overflow = true; }
         if (flat) {
             emit(cur[0], cur[1], cur[6], cur[7]);
+            e0r = n == 0 ? cur[6] : e0r; e0c = n == 0 ? cur[7] : e0c;
+            e1r = n == 1 ? cur[6] : e1r; e1c = n == 1 ? cur[7] : e1c;
             ++n;
             while (level > 0 && (idx & 1ull)) { idx >>= 1; --level; }
             if (level == 0) break;
             idx |= 1ull;
             for (int i = 0; i < 8; ++i) cur[i] = root[i];
             for (int l = level - 1; l >= 0; --l) {
-                double t[8];
-                if ((idx >> l) & 1ull) cubic_right(cur, t); else cubic_left(cur, t);
-                for (int i = 0; i < 8; ++i) cur[i] = t[i];
+                if ((idx >> l) & 1ull) cubic_right_inplace(cur); else cubic_left_inplace(cur);
             }
         } else {
-            double t[8];
-            cubic_left(cur, t);
-            for (int i = 0; i < 8; ++i) cur[i] = t[i];
+            cubic_left_inplace(cur);
             ++level;
             idx <<= 1;
         }
     }
+    if (ends) { ends[0] = e0r; ends[1] = e0c; ends[2] = e1r; ends[3] = e1c; }
     return n;
 }
 

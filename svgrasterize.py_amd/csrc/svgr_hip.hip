@@ -442,9 +442,7 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
                     mode = (sub & ((1 << (FL_SUB - l)) - 1)) == 0 ? 1 : 0;
                     break;
                 }
-                double t[8];
-                if ((sub >> (FL_SUB - 1 - l)) & 1) cubic_right(node, t); else cubic_left(node, t);
-                for (int i = 0; i < 8; ++i) node[i] = t[i];
+                if ((sub >> (FL_SUB - 1 - l)) & 1) cubic_right_inplace(node); else cubic_left_inplace(node);
             }
         }
     }
@@ -478,14 +476,10 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
     } else if (mode == 2) {
         // pieces come in curve order and share end points: track the first start and every end.  The ends of the
         // first two pieces are remembered: nearly every lane has one or two, and then the second traversal is skipped.
-        int seen = 0;
         track(node[0], node[1]);
-        cnt = flatten_subtree(node, thr, kMaxFlattenDepth - FL_SUB, [&](double, double, double r1, double c1) {
-            track(r1, c1);
-            if (seen == 0) { q1r = r1; q1c = c1; }
-            else if (seen == 1) { q2r = r1; q2c = c1; }
-            ++seen;
-        }, ovf);
+        double ends[4];
+        cnt = flatten_subtree(node, thr, kMaxFlattenDepth - FL_SUB, [&](double, double, double r1, double c1) { track(r1, c1); }, ovf, ends);
+        q1r = ends[0]; q1c = ends[1]; q2r = ends[2]; q2c = ends[3];
     }
     if (ovf) atomicOr(&bd->err, 1);
     if (!keep) cnt = 0;
