@@ -193,9 +193,16 @@ SVGR_HD double key_f64(uint64_t k) {
     return x.d;
 }
 
+// double -> int for values that are integral already (floor / ceil results) or get truncated toward zero.
+// On the device v_cvt_i32_f64 saturates by itself (and gives 0 for a NaN); the host build clamps explicitly.
+// Coordinates beyond +-1e9 are rejected before they get here (k_path_bbox), so both forms agree on everything used.
 SVGR_HD int clamp_to_int(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __double2int_rz(v);
+#else
     v = v < -1.0e9 ? -1.0e9 : (v > 1.0e9 ? 1.0e9 : v);
     return (int)v;
+#endif
 }
 
 // ------------------------------------------------------------------------------------
