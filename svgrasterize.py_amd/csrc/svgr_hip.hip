@@ -832,6 +832,9 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
 // records leave through an LDS transpose: lane j then stores 16-byte chunk j of the turn's records, so that a
 // store instruction covers whole cache lines.  (Each lane storing its own 48-byte record made every dwordx4 store 64
 // separate partial-line writes, and the L2 request rate -- not bytes -- bounded the kernel.)
+#ifndef SVGR_EMIT_DIRECT
+#define SVGR_EMIT_DIRECT 12   // turns with fewer records than this skip the LDS transpose
+#endif
 __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ edges, const int* __restrict__ edge_path,
                                                    const int* __restrict__ bbox, const PathBin* __restrict__ bins,
                                                    int vr0, int pb_cap, const int* __restrict__ bseg_off,
@@ -911,6 +914,17 @@ __global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ ed
         // this turn's records, packed by lane rank, then out in 16-byte chunks: chunk j of the turn by lane j % 64
         const unsigned long long m = __ballot(has);
         const int n_rec = __popcll(m), rank = mask_rank(m);
+        if (n_rec < SVGR_EMIT_DIRECT) {
+            // the tail of the longest edges of the wave: a handful of records, stored by their own lanes (the transpose
+            // would cost more than the partial-line writes it saves)
+            if (has) {
+                const uint4* src = (const uint4*)&r;
+                uint4* dst = (uint4*)(recs + dest);
+#pragma unroll
+                for (int c = 0; c < CPR; ++c) dst[c] = src[c];
+            }
+            continue;
+        }
         if (has) {
             const uint4* src = (const uint4*)&r;
 #pragma unroll
