@@ -79,3 +79,36 @@ def test_two_rank_gloo_render_matches_single(tmp_path):
                                  sc["path_paint"], sc["viewport"], clip01=True)
     assert np.abs(got - ref).max() < 1e-11
     assert_f32_1ulp(got.astype(np.float32), ref, what="2-rank gloo canvas")
+
+
+def test_rows_subscene_keeps_exactly_what_can_reach_the_block():
+    """Host-side distribution of the weak-scaling bench (synth.rows_subscene): a path is given to a row block iff the hull
+    of its control points (+-2 rows) reaches the block; order is kept; the blocks together cover every path."""
+    import numpy as np
+
+    from svgrasterize_amd import synth
+
+    size, n, blocks = 300, 50, 4
+    tall = synth.make_tall_scene(size, n, blocks)
+    off = tall["path_seg_off"]
+    assert len(off) == n * blocks + 1 and tall["viewport"] == (0, 0, size * blocks, size)
+    # block b of the tall scene is the single scene of seed b, moved down
+    one = synth.make_scene(size, n, seed=synth.SEED + 2)
+    s2 = tall["segs"][off[2 * n]: off[3 * n]].copy()
+    s2[:, 1::2] -= 2 * size
+    assert np.allclose(s2, one["segs"], rtol=0, atol=1e-9)
+    seen = np.zeros(n * blocks, dtype=int)
+    for b in range(blocks):
+        sub, kept = synth.rows_subscene(tall, b * size, (b + 1) * size)
+        assert np.all(np.diff(kept) > 0) and sub["viewport"] == (b * size, 0, size, size)
+        assert len(sub["path_seg_off"]) == len(kept) + 1 and sub["path_seg_off"][-1] == len(sub["segs"])
+        seen[kept] += 1
+        for p in range(n * blocks):
+            y = tall["segs"][off[p]: off[p + 1], 1::2]
+            reaches = np.floor(y.min()) - 2 < (b + 1) * size and np.ceil(y.max()) + 2 > b * size
+            assert reaches == (p in set(kept.tolist()))
+        # the kept paths carry their own segments, paints and rules
+        k0 = int(kept[0])
+        assert np.array_equal(sub["segs"][: sub["path_seg_off"][1]], tall["segs"][off[k0]: off[k0 + 1]])
+        assert np.array_equal(sub["path_paint"], tall["path_paint"][kept]) and np.array_equal(sub["path_rule"], tall["path_rule"][kept])
+    assert seen.min() >= 1 and seen.max() >= 2  # every path somewhere, border paths in two blocks
