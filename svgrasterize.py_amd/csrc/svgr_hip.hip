@@ -832,10 +832,13 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
 // records leave through an LDS transpose: lane j then stores 16-byte chunk j of the turn's records, so that a
 // store instruction covers whole cache lines.  (Each lane storing its own 48-byte record made every dwordx4 store 64
 // separate partial-line writes, and the L2 request rate -- not bytes -- bounded the kernel.)
+#ifndef SVGR_EMIT_WAVES
+#define SVGR_EMIT_WAVES 6      // waves per SIMD the register budget of k_edge_emit allows (8 would spill)
+#endif
 #ifndef SVGR_EMIT_DIRECT
 #define SVGR_EMIT_DIRECT 12   // turns with fewer records than this skip the LDS transpose
 #endif
-__global__ __launch_bounds__(256) void k_edge_emit(const double* __restrict__ edges, const int* __restrict__ edge_path,
+__global__ __launch_bounds__(256, SVGR_EMIT_WAVES) void k_edge_emit(const double* __restrict__ edges, const int* __restrict__ edge_path,
                                                    const int* __restrict__ bbox, const PathBin* __restrict__ bins,
                                                    int vr0, int pb_cap, const int* __restrict__ bseg_off,
                                                    int* __restrict__ pb_cursor, RowRec* __restrict__ recs, int rec_cap,
@@ -1303,7 +1306,7 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
                 if (OUT <= 1) {
                     // Canvas: no bounds tests.  Left of / above / below the layer the delta tile is zero and so
                     // is the running sum; right of the layer it is NaN (sentinel above) or outside the viewport.
-                    double* const myclip = s_clip + trow * ROW_STRIDE + chunk * CHUNK_STRIDE;
+                    double* const myclip = my + (OFF_CLIP - OFF_TRACE) / 8;  // same cell of the clip tile: a constant offset, no second address register
                     // coverage first, in place (t[i] <- mask value), with the fill rule decided ONCE per path: written
                     // as `rule ? evenodd(x) : nonzero(x)` inside the pixel loop the compiler evaluates both for every pixel
                     if (OUT == 0 && !CLIP) {
