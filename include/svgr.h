@@ -193,6 +193,22 @@ int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst_f32, const svgr_buf* src_f64,
 /* -------------------------------------------------------------------------------------------- */
 /* gradient paint servers and Gaussian blur (config 5)                                          */
 /* -------------------------------------------------------------------------------------------- */
+/* The other canvas_compose modes (S:287-297) on the full union canvas (canvas_merge_union(full=True), S:348-361):
+ * out(4ch, bbox ob) = blend(out, src zero-extended), every pixel of ob.  mode: 1 OUT, 3 ATOP, 4 XOR (the reference's
+ * COMPOSE_* codes, S:48-51), 5 = arithmetic with k4 = {k1, k2, k3, k4}: clip(k1*src*dst + k2*src + k3*dst + k4, 0, 1).
+ * (OVER and IN have their own entry points above; an unknown mode is SVGR_E_INVALID like the ValueError of S:298.)  */
+int svgr_layer_blend(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr_buf* src, const int64_t* sb, int src_channels,
+                     int mode, const double* k4);
+/* Layer.color_matrix (S:95-104) in place on a straight-alpha linear RGBA image: clip(px @ M[:, :4].T + M[:, 4], 0, 1);
+ * m20 = 4 x 5 row-major host matrix.                                                                            */
+int svgr_layer_color_matrix(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, const double* m20);
+/* Layer.morphology (S:120-127, pooling S:419-468): min (is_max 0) / max pooling, window ky rows x kx columns, stride 1,
+ * no padding: out is (rows - ky + 1, cols - kx + 1, 4).                                                          */
+int svgr_layer_morphology(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, int64_t ky, int64_t kx,
+                          int is_max);
+/* Luminance of a straight-alpha RGBA image for RENDER_MASK (S:735): out(n_px doubles) = (rgb . {0.2125, 0.7154, 0.072}) * a */
+int svgr_layer_luminance(svgr_ctx* ctx, svgr_buf* out_1ch, const svgr_buf* src_rgba, int64_t n_px);
+
 /* Output stage (canvas_to_png, S:262): dst(n_px x 4 uint8) = round-half-even(src(n_px x 4 double) * 255), the
  * quantisation the reference applies to Layer.convert(pre_alpha=False, linear_rgb=False).image before zlib
  * (S:209-213).  Values outside [0, 255] saturate.  The PNG container itself is written on the host.      */

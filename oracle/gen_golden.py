@@ -727,6 +727,113 @@ def gen_png(ref) -> None:
     save("png_kat.npz", **out)
 
 
+
+def gen_filters(ref) -> None:
+    """Remaining compose modes / filter primitives / luminance mask: Layer.compose OUT / ATOP / XOR /
+    arithmetic (S:285-297, full-canvas union S:348-365), Layer.color_matrix (S:95-104), Layer.morphology (S:120-127,
+    pooling S:419-468), Filter chains with feOffset / feMerge / feBlend / feComposite / feColorMatrix / feMorphology
+    (S:1749-1887) and Scene MASK (S:721-741)."""
+    rng = np.random.default_rng(77)
+    out, meta = {}, dict(compose=[], cmatrix=[], morph=[], chain=[], mask=[])
+
+    def rand_layer(shape, ch, off, pre, lin):
+        a = rng.uniform(0, 1, shape + (1,))
+        a[rng.uniform(0, 1, shape + (1,)) < 0.25] = 0.0
+        if ch == 1:
+            img = a
+        else:
+            rgb = rng.uniform(0, 1, shape + (3,))
+            img = np.concatenate([rgb * a if pre else rgb, a], axis=-1)
+        return ref.Layer(img, off, pre_alpha=pre, linear_rgb=lin)
+
+    # -- compose modes ------------------------------------------------------------------------------------------
+    modes = [ref.COMPOSE_OUT, ref.COMPOSE_ATOP, ref.COMPOSE_XOR, (0.3, 0.5, 0.7, 0.1), (1.0, 0.0, 0.0, 0.0), (0.0, 1.0, -1.0, 0.2)]
+    k = 0
+    for mode in modes:
+        for variant in range(2):
+            layers = [rand_layer((9, 7), 4, (2, 3), True, False), rand_layer((6, 11), 4, (5, 0), variant == 0, True)]
+            if variant:
+                layers.append(rand_layer((8, 8), 1 if not isinstance(mode, tuple) else 4, (0, 6), True, True))
+            lin = bool(variant)
+            res = ref.Layer.compose(layers, mode, linear_rgb=lin)
+            for j, l in enumerate(layers):
+                out[f"c{k}_in{j}"] = l.image
+            out[f"c{k}_out"] = res.image
+            meta["compose"].append(dict(mode=list(mode) if isinstance(mode, tuple) else int(mode), linear_rgb=lin,
+                                        layers=[dict(offset=[int(v) for v in l.offset], pre_alpha=l.pre_alpha, linear_rgb=l.linear_rgb)
+                                                for l in layers],
+                                        out_offset=[int(v) for v in res.offset], out_pre_alpha=res.pre_alpha, out_linear_rgb=res.linear_rgb))
+            k += 1
+
+    # -- color matrix --------------------------------------------------------------------------------------------------
+    mats = [rng.uniform(-0.5, 1.0, (4, 5)), ref.COLOR_MATRIX_LUM.copy(), np.hstack([np.eye(4), np.zeros((4, 1))])]
+    for j, m in enumerate(mats):
+        l = rand_layer((10, 13), 4, (4, 1), bool(j % 2), bool(j // 2))
+        res = l.color_matrix(m)
+        out[f"m{j}_in"], out[f"m{j}_matrix"], out[f"m{j}_out"] = l.image, m, res.image
+        meta["cmatrix"].append(dict(offset=[int(v) for v in l.offset], pre_alpha=l.pre_alpha, linear_rgb=l.linear_rgb,
+                                    out_pre_alpha=res.pre_alpha, out_linear_rgb=res.linear_rgb))
+
+    # -- morphology --------------------------------------------------------------------------------------------------
+    for j, (kx, ky, method) in enumerate([(1, 1, "max"), (3, 2, "min"), (5, 7, "max"), (2, 6, "min")]):
+        l = rand_layer((14, 17), 4, (3, 3), bool(j % 2), False)
+        res = l.morphology(kx, ky, method)
+        out[f"p{j}_in"], out[f"p{j}_out"] = l.image, res.image
+        meta["morph"].append(dict(x=kx, y=ky, method=method, offset=[int(v) for v in l.offset], pre_alpha=l.pre_alpha,
+                                  linear_rgb=l.linear_rgb, out_offset=[int(v) for v in res.offset],
+                                  out_pre_alpha=res.pre_alpha, out_linear_rgb=res.linear_rgb))
+
+    # -- filter chains -----------------------------------------------------------------------------------------------
+    swap = ref.Transform().matrix(0, 1, 0, 1, 0, 0)
+    chains = [
+        ("drop_shadow", lambda f: f.blur(1.2, input=ref.FE_SOURCE_ALPHA, result="b").offset(2.5, 1.5, input="b", result="o")
+                                   .merge(["o", ref.FE_SOURCE_GRAPHIC]), swap.scale(1.5)),
+        ("composite_ops", lambda f: f.offset(3, -2, result="o").composite(ref.FE_SOURCE_GRAPHIC, "o", ref.COMPOSE_XOR, result="x")
+                                     .composite("x", ref.FE_SOURCE_ALPHA, ref.COMPOSE_ATOP), swap),
+        ("arithmetic", lambda f: f.blur(0.8, result="b").composite(ref.FE_SOURCE_GRAPHIC, "b", (0.2, 0.6, 0.5, 0.05)), swap.scale(2.0)),
+        ("matrix_morph", lambda f: f.color_matrix(ref.FE_SOURCE_GRAPHIC, ref.COLOR_MATRIX_LUM, result="l")
+                                    .morphology(0.8, 1.1, "max", "l", result="m").blend("m", ref.FE_SOURCE_GRAPHIC), swap.scale(2.0)),
+        ("erode", lambda f: f.morphology(1.0, 1.0, "min", ref.FE_SOURCE_GRAPHIC), swap.scale(1.6)),
+    ]
+    import warnings
+    for j, (name, build, tr) in enumerate(chains):
+        flt = build(ref.Filter.empty())
+        src = rand_layer((16, 19), 4, (6, 2), True, False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = flt(tr, src)
+        out[f"f{j}_in"], out[f"f{j}_tr"], out[f"f{j}_out"] = src.image, tr.m, res.image
+        prims = []
+        for ftype, attrs, inputs in flt.filters:
+            a = []
+            for v in attrs:
+                if isinstance(v, np.ndarray):
+                    out[f"f{j}_matrix{len(prims)}"] = v
+                    a.append("matrix")
+                elif isinstance(v, tuple):
+                    a.append(list(v))
+                else:
+                    a.append(v)
+            prims.append(dict(type=int(ftype), attrs=a, inputs=[int(i) for i in inputs]))
+        meta["chain"].append(dict(name=name, prims=prims, in_offset=[int(v) for v in src.offset], out_offset=[int(v) for v in res.offset],
+                                  out_pre_alpha=res.pre_alpha, out_linear_rgb=res.linear_rgb))
+
+    # -- luminance mask ------------------------------------------------------------------------------------------------
+    blob = ref.Path.from_svg("M20,30 C20,5 80,5 80,30 S110,85 60,90 C30,92 20,60 20,30 Z")
+    ring = ref.Path.from_svg("M60,10 L75,95 L10,40 L110,40 L45,95 Z")
+    for j, lin in enumerate([False, True]):
+        target = ref.Scene.fill(blob, np.array([0.2, 0.5, 0.1, 0.9]))
+        mask_scene = ref.Scene.group([ref.Scene.fill(ring, np.array([0.9, 0.9, 0.2, 1.0]), "evenodd"),
+                                      ref.Scene.fill(blob, np.array([0.1, 0.3, 0.6, 0.7]))])
+        scene = target.mask(mask_scene, False)
+        layer, _hull = scene.render(swap, viewport=[0, 0, 120, 140], linear_rgb=lin)
+        out[f"k{j}_out"] = layer.image
+        meta["mask"].append(dict(linear_rgb=lin, offset=[int(v) for v in layer.offset], pre_alpha=layer.pre_alpha,
+                                 out_linear_rgb=layer.linear_rgb))
+    out["meta"] = np.array(json.dumps(meta))
+    save("filter_kat.npz", **out)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also render the full-size configs (slow)")
@@ -747,6 +854,8 @@ def main() -> None:
         gen_stroke(ref, tiger)
     if todo("png"):
         gen_png(ref)
+    if todo("filters"):
+        gen_filters(ref)
     if todo("mask"):
         gen_mask(ref)
     if todo("compose"):

@@ -15,7 +15,10 @@ from .layer import (  # noqa: F401
     Layer, canvas_to_png, COMPOSE_OVER, COMPOSE_OUT, COMPOSE_IN, COMPOSE_ATOP, COMPOSE_XOR,
 )
 from .paint import GradLinear, GradRadial  # noqa: F401
-from .filters import Filter, blur_kernel  # noqa: F401
+from .filters import (  # noqa: F401
+    Filter, blur_kernel, COLOR_MATRIX_LUM, FE_SOURCE_ALPHA, FE_SOURCE_GRAPHIC, FE_BLEND, FE_COLOR_MATRIX, FE_COMPOSITE,
+    FE_GAUSSIAN_BLUR, FE_MERGE, FE_MORPHOLOGY, FE_OFFSET,
+)
 from .scene import (  # noqa: F401
     Scene, render_canvas, build_batch,
     RENDER_FILL, RENDER_STROKE, RENDER_GROUP, RENDER_OPACITY, RENDER_CLIP, RENDER_MASK, RENDER_TRANSFORM, RENDER_FILTER,

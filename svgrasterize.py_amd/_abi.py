@@ -96,6 +96,10 @@ _PROTOS = {
     "svgr_layer_convert": (C.c_int, [_P, _P, C.c_int64, C.c_uint]),
     "svgr_layer_to_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int]),
     "svgr_layer_to_rgba8": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "svgr_layer_blend": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "svgr_layer_color_matrix": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "svgr_layer_morphology": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int]),
+    "svgr_layer_luminance": (C.c_int, [_P, _P, _P, C.c_int64]),
     "svgr_gradient_fill": (C.c_int, [_P, C.POINTER(Gradient), _P, _P, _P]),
     "svgr_layer_convolve": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64]),
     "svgr_path_stroke": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, C.c_int, C.c_int, C.POINTER(_P)]),

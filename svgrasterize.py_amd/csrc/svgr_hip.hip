@@ -1481,6 +1481,86 @@ __global__ void k_layer_over(double* __restrict__ dst, int dr0, int dc0, int dro
     }
 }
 
+// canvas_compose modes other than OVER / IN (S:287-297) on the full union canvas (canvas_merge_union(full=True),
+// S:348-361): out = blend(out, src zero-extended to the canvas), every pixel of the canvas.
+//   mode 1 OUT: src * (1 - dst_a)      3 ATOP: src * dst_a + dst * (1 - src_a)      4 XOR: src * (1 - dst_a) + dst * (1 - src_a)
+//   mode 5 arithmetic (feComposite k1..k4): clip(k1 * src * dst + k2 * src + k3 * dst + k4, 0, 1)
+__global__ void k_layer_blend(double* __restrict__ out, int or0, int oc0, int orows, int ocols, const double* __restrict__ src,
+                              int sr0, int sc0, int srows, int scols, int ch, int mode, double k1, double k2, double k3, double k4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)orows * ocols) return;
+    const int R = (int)(i / ocols), C = (int)(i % ocols);
+    const int r = R + or0 - sr0, c = C + oc0 - sc0;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (r >= 0 && r < srows && c >= 0 && c < scols) {
+        const double* sp = src + (size_t)ch * ((size_t)r * scols + c);
+        s[0] = sp[0]; s[1] = ch == 4 ? sp[1] : sp[0]; s[2] = ch == 4 ? sp[2] : sp[0]; s[3] = ch == 4 ? sp[3] : sp[0];
+    }
+    double* d = out + 4 * i;
+    const double da = d[3], sa = s[3];
+    for (int q = 0; q < 4; ++q) {
+        const double dv = d[q], sv = s[q];
+        double o;
+        if (mode == 1) o = sv * (1 - da);
+        else if (mode == 3) o = sv * da + dv * (1 - sa);
+        else if (mode == 4) o = sv * (1 - da) + dv * (1 - sa);
+        else {
+            o = k1 * sv * dv + k2 * sv + k3 * dv + k4;
+            o = o < 0.0 ? 0.0 : (o > 1.0 ? 1.0 : o);
+        }
+        d[q] = o;
+    }
+}
+
+// Layer.color_matrix (S:95-104): image = clip(image @ M[:, :4].T + M[:, 4], 0, 1) on straight-alpha linear RGBA.
+// m20 = the 4 x 5 matrix row-major.  np.matmul accumulates k = 0..3 with fused multiply-adds (dgemm).
+__global__ void k_layer_color_matrix(double* __restrict__ img, size_t n_px, const double* __restrict__ m20) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_px) return;
+    double* p = img + 4 * i;
+    const double x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3];
+    for (int q = 0; q < 4; ++q) {
+        const double* m = m20 + 5 * q;
+        double o = fma(x3, m[3], fma(x2, m[2], fma(x1, m[1], x0 * m[0]))) + m[4];
+        p[q] = o < 0.0 ? 0.0 : (o > 1.0 ? 1.0 : o);
+    }
+}
+
+// Layer.morphology (S:120-127) = min / max pooling with stride 1, no padding (pooling, S:419-468): out is
+// (rows - ky + 1, cols - kx + 1, 4), out[R, C] = reduce over src[R .. R+ky-1, C .. C+kx-1].  NaNs are skipped (nanmax).
+__global__ void k_layer_morphology(double* __restrict__ out, const double* __restrict__ src, int rows, int cols, int ky, int kx,
+                                   int is_max) {
+    const int orows = rows - ky + 1, ocols = cols - kx + 1;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)orows * ocols) return;
+    const int R = (int)(i / ocols), C = (int)(i % ocols);
+    double a0 = __builtin_nan(""), a1 = a0, a2 = a0, a3 = a0;  // NaN = nothing seen yet (and NaN inputs are skipped: nanmax)
+    auto take = [&](double acc, double v) -> double {
+        if (v != v) return acc;
+        if (acc != acc) return v;
+        return is_max ? (v > acc ? v : acc) : (v < acc ? v : acc);
+    };
+    for (int dy = 0; dy < ky; ++dy) {
+        const double4* row = (const double4*)src + ((size_t)(R + dy) * cols + C);
+        for (int dx = 0; dx < kx; ++dx) {
+            const double4 v = row[dx];
+            a0 = take(a0, v.x); a1 = take(a1, v.y); a2 = take(a2, v.z); a3 = take(a3, v.w);
+        }
+    }
+    double acc[4] = {a0, a1, a2, a3};
+    double* o = out + 4 * i;
+    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+}
+
+// luminance mask (S:735): out(1 channel) = (rgb @ [0.2125, 0.7154, 0.072]) * alpha of a straight-alpha layer
+__global__ void k_layer_luminance(double* __restrict__ out, const double* __restrict__ src, size_t n_px) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_px) return;
+    const double* p = src + 4 * i;
+    const double lum = fma(p[2], 0.072, fma(p[1], 0.7154, p[0] * 0.2125));
+    out[i] = lum * p[3];
+}
+
 __global__ void k_layer_crop4(double* __restrict__ out, int or0, int oc0, int orows, int ocols,
                               const double* __restrict__ src, int sr0, int sc0, int srows, int scols, int ch) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2408,6 +2488,59 @@ int svgr_layer_over(svgr_ctx* ctx, svgr_buf* dst, const int64_t* db, const svgr_
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_layer_over, grid1(n), dim3(256), 0, ctx->stream, (double*)dst->ptr, (int)db[0], (int)db[1], (int)db[2],
                        (int)db[3], (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch, first);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_layer_blend(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr_buf* src, const int64_t* sb, int ch, int mode,
+                     const double* k4) {
+    if (!ctx || !out || !src || !bbox_ok(ob) || !bbox_ok(sb) || (ch != 1 && ch != 4)) return fail(SVGR_E_INVALID, "svgr_layer_blend: bad arguments");
+    if (!(mode == 1 || mode == 3 || mode == 4 || mode == 5) || (mode == 5 && !k4)) return fail(SVGR_E_INVALID, "invalid compose mode: %d", mode);
+    const size_t n = (size_t)ob[2] * ob[3];
+    if (out->bytes < n * 32 || src->bytes < (size_t)sb[2] * sb[3] * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_blend: buffer too small");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_layer_blend, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2], (int)ob[3],
+                       (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch, mode, mode == 5 ? k4[0] : 0.0,
+                       mode == 5 ? k4[1] : 0.0, mode == 5 ? k4[2] : 0.0, mode == 5 ? k4[3] : 0.0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_layer_color_matrix(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, const double* m20) {
+    if (!ctx || !img || !m20 || n_px < 0 || img->bytes < (size_t)n_px * 32) return fail(SVGR_E_INVALID, "svgr_layer_color_matrix: bad arguments");
+    if (n_px == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    double* dm = nullptr;
+    HIPCHK(g_pool.alloc((void**)&dm, sizeof(double) * 20));
+    hipError_t e = hipMemcpyAsync(dm, m20, sizeof(double) * 20, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_layer_color_matrix, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n_px, (const double*)dm);
+        e = hipStreamSynchronize(ctx->stream);  // (m20 is the caller's host memory)
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    g_pool.release(dm);
+    if (e != hipSuccess) return fail(SVGR_E_HIP, "svgr_layer_color_matrix: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int svgr_layer_morphology(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, int64_t ky, int64_t kx, int is_max) {
+    if (!ctx || !out || !src || rows <= 0 || cols <= 0 || ky <= 0 || kx <= 0 || ky > rows || kx > cols || rows > (1 << 24) || cols > (1 << 24))
+        return fail(SVGR_E_INVALID, "svgr_layer_morphology: bad arguments (the window must fit the layer)");
+    const size_t n = (size_t)(rows - ky + 1) * (size_t)(cols - kx + 1);
+    if (src->bytes < (size_t)rows * cols * 32 || out->bytes < n * 32) return fail(SVGR_E_INVALID, "svgr_layer_morphology: buffer too small");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_layer_morphology, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)src->ptr, (int)rows, (int)cols,
+                       (int)ky, (int)kx, is_max);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_layer_luminance(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t n_px) {
+    if (!ctx || !out || !src || n_px < 0 || out->bytes < (size_t)n_px * 8 || src->bytes < (size_t)n_px * 32) return fail(SVGR_E_INVALID, "svgr_layer_luminance: bad arguments");
+    if (n_px == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_layer_luminance, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)src->ptr, (size_t)n_px);
     HIPCHK(hipGetLastError());
     return 0;
 }

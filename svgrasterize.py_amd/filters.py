@@ -1,9 +1,9 @@
-"""feGaussianBlur (reference S:1750-1831, 1890-1944): the only filter primitive on the hot path.
+"""Filter effects (reference S:1716-1944): feGaussianBlur (the one on the hot path) and the other
+primitives the reference implements -- feOffset, feMerge, feBlend, feComposite, feColorMatrix, feMorphology (8f-4).
 
-``Filter`` keeps the reference's (names, filters) structure so scene dumps replay unchanged; of the
-primitive types only FE_GAUSSIAN_BLUR is executed (the others are outside the accelerated path,
-SURVEY 8f-4).  The kernel weights are built on the host exactly like ``blur_kernel`` does (a few
-thousand numbers); the convolution itself runs on the GPU (``svgr_layer_convolve``)."""
+``Filter`` keeps the reference's (names, filters) structure so scene dumps replay unchanged.  The blur weights are
+built on the host exactly like ``blur_kernel`` does (a few thousand numbers); every per-pixel operation runs on the
+GPU (``svgr_layer_convolve``, ``svgr_layer_blend``, ``svgr_layer_color_matrix``, ``svgr_layer_morphology``)."""
 from __future__ import annotations
 
 from typing import NamedTuple
@@ -13,7 +13,12 @@ import numpy as np
 from .geometry import Transform
 from .layer import Layer
 
-FE_GAUSSIAN_BLUR = 8
+import warnings
+
+FE_BLEND, FE_COLOR_MATRIX, FE_COMPONENT_TRANSFER, FE_COMPOSITE, FE_CONVOLVE_MATRIX = 0, 1, 2, 3, 4  # S:1716-1730
+FE_DIFFUSE_LIGHTING, FE_DISPLACEMENT_MAP, FE_FLOOD, FE_GAUSSIAN_BLUR, FE_MERGE = 5, 6, 7, 8, 9
+FE_MORPHOLOGY, FE_OFFSET, FE_SPECULAR_LIGHTING, FE_TILE, FE_TURBULENCE = 10, 11, 12, 13, 14
+COLOR_MATRIX_LUM = np.array([[0, 0, 0, 0, 0], [0, 0, 0, 0, 0], [0, 0, 0, 0, 0], [0.2125, 0.7154, 0.0721, 0, 0]], dtype=np.float64)
 FE_SOURCE_ALPHA = "SourceAlpha"
 FE_SOURCE_GRAPHIC = "SourceGraphic"
 
@@ -66,8 +71,26 @@ class Filter(NamedTuple):
         filters.append((type, attrs, args))
         return Filter(names, filters)
 
+    def offset(self, dx, dy, input=None, result=None) -> "Filter":
+        return self.add_filter(FE_OFFSET, (dx, dy), [input], result)
+
+    def merge(self, inputs, result=None) -> "Filter":
+        return self.add_filter(FE_MERGE, tuple(), inputs, result)
+
     def blur(self, std_x, std_y=None, input=None, result=None) -> "Filter":
         return self.add_filter(FE_GAUSSIAN_BLUR, (std_x, std_y), [input], result)
+
+    def blend(self, in1, in2, mode=None, result=None) -> "Filter":
+        return self.add_filter(FE_BLEND, (mode,), [in1, in2], result)
+
+    def composite(self, in1, in2, mode=None, result=None) -> "Filter":
+        return self.add_filter(FE_COMPOSITE, (mode,), [in1, in2], result)
+
+    def color_matrix(self, input, matrix, result=None) -> "Filter":
+        return self.add_filter(FE_COLOR_MATRIX, (matrix,), [input], result)
+
+    def morphology(self, rx, ry, method, input, result=None) -> "Filter":
+        return self.add_filter(FE_MORPHOLOGY, (rx, ry, method), [input], result)
 
     def __call__(self, transform: Transform, source: Layer) -> Layer:
         """Execute the filter chain on `source` (S:1801-1831)."""
@@ -80,11 +103,36 @@ class Filter(NamedTuple):
             return stack[i]
 
         for ftype, attrs, inputs in self.filters:
-            if ftype != FE_GAUSSIAN_BLUR:
-                raise NotImplementedError(f"filter primitive {ftype} is outside the accelerated path (SURVEY 8f-4)")
-            std_x, std_y = attrs
-            std_y = std_x if std_y is None else std_y
-            layer = get(inputs[0])
-            kernel = blur_kernel(transform, (std_x, std_y))
-            stack.append(layer if kernel is None else layer.convolve(kernel))
+            args = [get(i) for i in inputs]
+            if ftype == FE_GAUSSIAN_BLUR:
+                std_x, std_y = attrs
+                kernel = blur_kernel(transform, (std_x, std_x if std_y is None else std_y))
+                res = args[0] if kernel is None else args[0].convolve(kernel)
+            elif ftype == FE_OFFSET:  # S:1844-1850
+                dx, dy = attrs
+                x, y = args[0].offset
+                tx, ty = transform(transform.invert([x, y]) + [dx, dy])
+                res = args[0].translate(int(tx) - x, int(ty) - y)
+            elif ftype == FE_MERGE:  # S:1867-1871
+                res = Layer.compose(args, linear_rgb=True)
+            elif ftype == FE_BLEND:  # S:1874-1879 (the reference composes OVER whatever the mode)
+                warnings.warn("feBlend is not properly supported")
+                res = Layer.compose([args[1], args[0]], linear_rgb=True)
+            elif ftype == FE_COMPOSITE:  # S:1882-1886
+                res = Layer.compose([args[1], args[0]], attrs[0], linear_rgb=True)
+            elif ftype == FE_COLOR_MATRIX:  # S:1834-1841
+                matrix = attrs[0]
+                if not isinstance(matrix, np.ndarray) or matrix.shape != (4, 5):
+                    warnings.warn(f"invalid color matrix: {matrix}")
+                    res = args[0]
+                else:
+                    res = args[0].color_matrix(matrix)
+            elif ftype == FE_MORPHOLOGY:  # S:1853-1864
+                rx, ry, method = attrs
+                ux, uy = transform([[rx, 0], [0, ry]]) - transform([[0, 0], [0, 0]])
+                x, y = int(np.linalg.norm(ux) * 2), int(np.linalg.norm(uy) * 2)
+                res = args[0] if x < 1 or y < 1 else args[0].morphology(x, y, method)
+            else:
+                raise ValueError(f"unsupported filter type: {ftype}")
+            stack.append(res)
         return get(len(stack) - 1)

@@ -166,6 +166,50 @@ class Layer:
         return Layer._from_device(buf, layer._shape, layer.offset, True, linear_rgb)
 
     # -- Layer.convolve  S:106-118 ---------------------------------------------------------
+    def color_matrix(self, matrix: np.ndarray) -> "Layer":
+        """Apply a 4x5 colour matrix on straight-alpha linear RGBA (Layer.color_matrix, S:95-104)."""
+        if not isinstance(matrix, np.ndarray) or matrix.shape != (4, 5):
+            raise ValueError("expected 4x5 matrix")
+        if self.channels != 4:
+            raise ValueError("color_matrix expects an RGBA layer")
+        layer = self.convert(pre_alpha=False, linear_rgb=True)
+        ctx = _abi.Context.get()
+        buf = layer._copy_device() if layer is self else layer._device()  # (a converted layer owns a fresh buffer)
+        m = np.ascontiguousarray(matrix, dtype=FLOAT)
+        _abi._check(ctx.lib.svgr_layer_color_matrix(ctx.handle, buf.handle, layer.height * layer.width, m.ctypes.data_as(_abi._P)))
+        return Layer._from_device(buf, layer._shape, layer.offset, pre_alpha=False, linear_rgb=True)
+
+    def morphology(self, x: int, y: int, method: str) -> "Layer":
+        """Morphology = min / max pooling with stride 1 (Layer.morphology S:120-127, pooling S:419-468); the window is
+        x rows by y columns of this layer's array, the result shrinks by the window and keeps the offset."""
+        if method not in ("min", "max"):
+            raise ValueError(f"invalid poll method: {method}")
+        if self.channels != 4:
+            raise ValueError("morphology expects an RGBA layer")
+        layer = self.convert(pre_alpha=True, linear_rgb=True)
+        rows, cols = layer.height, layer.width
+        x, y = int(x), int(y)
+        if x < 1 or y < 1 or x > rows or y > cols:
+            raise ValueError("morphology window does not fit the layer")
+        ctx = _abi.Context.get()
+        shape = (rows - x + 1, cols - y + 1, 4)
+        out = ctx.alloc(shape[0] * shape[1] * 32)
+        src = layer._device()
+        _abi._check(ctx.lib.svgr_layer_morphology(ctx.handle, out.handle, src.handle, rows, cols, x, y, int(method == "max")))
+        return Layer._from_device(out, shape, layer.offset, pre_alpha=True, linear_rgb=True)
+
+    def luminance_mask(self, linear_rgb: bool) -> "Layer":
+        """RENDER_MASK's mask layer (S:733-736): luminance of the straight-alpha colour times alpha, one channel."""
+        if self.channels != 4:
+            raise ValueError("luminance mask expects an RGBA layer")
+        layer = self.convert(pre_alpha=False, linear_rgb=linear_rgb)
+        ctx = _abi.Context.get()
+        n = layer.height * layer.width
+        out = ctx.alloc(max(n, 1) * 8)
+        src = layer._device()
+        _abi._check(ctx.lib.svgr_layer_luminance(ctx.handle, out.handle, src.handle, n))
+        return Layer._from_device(out, (layer.height, layer.width, 1), layer.offset, pre_alpha=False, linear_rgb=linear_rgb)
+
     def convolve(self, kernel: np.ndarray) -> "Layer":
         """Full 2-D convolution on straight-alpha linear RGBA; offset moves by half the kernel."""
         if self.channels != 4:
@@ -190,12 +234,34 @@ class Layer:
             return None
         if len(layers) == 1:
             return layers[0]  # returned as is, unconverted (S:190-191)
-        if method not in COMPOSE_PRE_ALPHA:
-            if isinstance(method, tuple) and len(method) == 4:
-                raise NotImplementedError("arithmetic compose (feComposite) is outside the hot path (SURVEY 8f-4)")
+        arithmetic = isinstance(method, tuple) and len(method) == 4
+        if method not in COMPOSE_PRE_ALPHA and not arithmetic:
             raise ValueError(f"invalid compose mode: {method}")
-        if method not in (COMPOSE_OVER, COMPOSE_IN):
-            raise NotImplementedError("only COMPOSE_OVER and COMPOSE_IN are on the hot path (SURVEY 8a-a12/a13)")
+        if arithmetic or method not in (COMPOSE_OVER, COMPOSE_IN):
+            # OUT / ATOP / XOR / feComposite arithmetic: every layer zero-extended to the union canvas, blended one
+            # after the other (canvas_merge_union(full=True), S:348-361).  Arithmetic composes straight alpha (S:193).
+            pre = not arithmetic
+            conv = [l.convert(pre_alpha=pre, linear_rgb=linear_rgb) for l in layers]
+            ctx = _abi.Context.get()
+            r0 = min(int(l.x) for l in conv)
+            c0 = min(int(l.y) for l in conv)
+            r1 = max(int(l.x) + l.height for l in conv)
+            c1 = max(int(l.y) + l.width for l in conv)
+            shape = (r1 - r0, c1 - c0, 4)
+            out = ctx.alloc(shape[0] * shape[1] * 32)
+            out.zero()
+            obb = _bbox_arr((r0, c0), shape)
+            k4 = np.array(method if arithmetic else (0, 0, 0, 0), dtype=FLOAT)
+            for i, l in enumerate(conv):
+                src = l._device()
+                if i == 0:
+                    _abi._check(ctx.lib.svgr_layer_over(ctx.handle, out.handle, obb, src.handle, _bbox_arr(l.offset, l._shape),
+                                                        l.channels, 1))
+                else:
+                    _abi._check(ctx.lib.svgr_layer_blend(ctx.handle, out.handle, obb, src.handle, _bbox_arr(l.offset, l._shape),
+                                                         l.channels, 5 if arithmetic else int(method), k4.ctypes.data_as(_abi._P)))
+            offset = (min(l.x for l in conv), min(l.y for l in conv))
+            return Layer._from_device(out, shape, offset, pre, linear_rgb)
         conv = [l.convert(pre_alpha=True, linear_rgb=linear_rgb) for l in layers]
         ctx = _abi.Context.get()
         lib = ctx.lib

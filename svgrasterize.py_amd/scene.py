@@ -12,7 +12,8 @@ routes, both of them HIP:
 
 Gradient fills and feGaussianBlur (config 5) go through the per-node route (`paint.py`, `filters.py`).
 STROKE nodes are stroked by the native stroker (`Path.stroke`, csrc/svgr_stroke.cpp) and then treated as fills.
-Not built: luminance MASK, the other filter primitives, pattern paints.
+Luminance MASK nodes and the reference's other filter primitives are executed too (layer.py / filters.py).
+Not built: pattern paints.
 """
 from __future__ import annotations
 
@@ -167,8 +168,22 @@ class Scene(tuple):
             target, target_transform = args
             return target._render(transform @ target_transform, mask_only, viewport, linear_rgb)
 
-        if kind == RENDER_MASK:
-            raise NotImplementedError("luminance masks are outside the accelerated path (SURVEY 8f-4)")
+        if kind == RENDER_MASK:  # luminance mask (S:721-741)
+            target, mask_scene, bbox_units = args
+            res = target._render(transform, mask_only, viewport, linear_rgb)
+            if res is None:
+                return None
+            image, hull = res
+            if bbox_units:
+                transform = hull.bbox_transform(transform)
+            mask_res = mask_scene._render(transform, mask_only, viewport, linear_rgb)
+            if mask_res is None:
+                return None
+            mask = mask_res[0].luminance_mask(linear_rgb)
+            result = Layer.compose([mask, image], COMPOSE_IN, linear_rgb)
+            if result is None:
+                return None
+            return result, hull
         if kind == RENDER_FILTER:
             target, flt = args
             res = target._render(transform, mask_only, viewport, linear_rgb)

@@ -126,12 +126,8 @@ def test_compose_kat(S):
     for idx, m in enumerate(meta(g)):
         ins = [S.Layer(g[f"{idx}_in{j}"].copy(), tuple(d["offset"]), d["pre_alpha"], d["linear_rgb"]) for j, d in enumerate(m["in"])]
         tag = m["tag"]
-        if tag in ("over", "over_convert", "in", "in_empty"):
+        if tag in ("over", "over_convert", "in", "in_empty", "full"):  # "full": OUT / ATOP / XOR on the union canvas
             out = S.Layer.compose(ins, m["method"], m["linear_rgb"])
-        elif tag == "full":
-            with pytest.raises(NotImplementedError):
-                S.Layer.compose(ins, m["method"], m["linear_rgb"])
-            continue
         elif tag == "convert":
             out = ins[0].convert(pre_alpha=m["to_pre_alpha"], linear_rgb=m["to_linear_rgb"])
         elif tag == "opacity":
