@@ -993,6 +993,8 @@ struct TileArgs {
     int out_cols;                // row pitch of `out` in pixels
     int clip01;
     const long long* layer_off;  // mask / fill outputs of several paths: per path the offset (in pixels) of its layer in `out`
+    unsigned* arena;             // the batch's counter arena: zeroed here (all but its first word, the sticky error flags) for
+    unsigned arena_words;        // the NEXT render, which then needs no memset launch in front of its flatten (0: leave it)
     unsigned long long* dbg;                // diagnostic builds only
 };
 
@@ -1039,6 +1041,10 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
 
     for (int i = tid; i < TR * ROW_STRIDE; i += NT) s_trace[i] = 0.0;
     __syncthreads();
+    if (a.arena_words) {  // nothing in this kernel reads the arena; the geometry kernels that did are finished
+        const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x, n_wg = gridDim.x * gridDim.y;
+        for (unsigned i = 1 + wg * NT + tid; i < a.arena_words; i += n_wg * NT) a.arena[i] = 0u;
+    }
 
     const int ent_begin = a.band_start[band], ent_end = ent_begin + a.band_count[band];
     // The band's tile list is scanned NT entries at a time; the entries that touch this tile's columns are appended to
@@ -1831,6 +1837,7 @@ struct svgr_batch {
     std::vector<long long> host_layer_off;
     // plan results (n_edges = edge slots the edge kernels cover = sum of the shard capacities; n_edges_live = filled ones)
     bool geometry_fresh = false;  // the buffers hold the geometry of the current inputs (set by plan, consumed by render)
+    bool arena_zeroed = false;    // the last tile kernel left the counter arena zeroed (all but the error word)
     int64_t n_edges_live = 0;
     int64_t n_edges = 0, n_pb = 0, n_bsegs = 0;
     int n_bands = 0;
@@ -1854,6 +1861,7 @@ struct svgr_batch {
         off_pb_cursor = off_pb_cnt + sizeof(int) * (size_t)(pb_cap + 1);
         arena_bytes = off_pb_cursor + sizeof(int) * (size_t)(pb_cap + 1);
         arena_bytes = (arena_bytes + 255) & ~(size_t)255;
+        arena_zeroed = false;  // (new size or new memory)
         return arena.ensure(arena_bytes);
     }
 
@@ -1877,7 +1885,8 @@ static inline int cap_i32(size_t n) { return (int)std::min<size_t>(n, 0x7fffffff
 static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     hipStream_t st = b->ctx->stream;
     const int ns = (int)b->n_segs, np = (int)b->n_paths;
-    HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
+    if (!b->arena_zeroed) HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
+    b->arena_zeroed = false;  // (the kernels below count into it)
     const dim3 fgrid = grid1((size_t)ns << FL_SUB, FL_BLOCK);
     // multi-GPU with a viewport: find the rows each path can reach first, so that the flatten skips foreign paths
     const unsigned* prow = nullptr;
@@ -1924,11 +1933,21 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
 }
 
 // `capacity_bits`: when given, capacity overflows (bits 2|4|8) are returned there instead of failing
-static int check_dev_err(svgr_batch* b, int* capacity_bits = nullptr) {
-    HIPCHK(hipMemcpyAsync(&b->host_bd, b->bd(), sizeof(BatchDev), hipMemcpyDeviceToHost, b->ctx->stream));
-    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+// Read the device-side error flags (and, while planning, all the counters: `whole`).  After renders only the error
+// word is meaningful -- the tile kernel has zeroed the rest of the arena for the next render -- and it is sticky until
+// it has been read here.  `capacity_bits`: when given, capacity overflows (bits 2|4|8) are returned there instead of failing.
+static int check_dev_err(svgr_batch* b, int* capacity_bits = nullptr, bool whole = true) {
+    int e = 0;
+    if (whole) {
+        HIPCHK(hipMemcpyAsync(&b->host_bd, b->bd(), sizeof(BatchDev), hipMemcpyDeviceToHost, b->ctx->stream));
+        HIPCHK(hipStreamSynchronize(b->ctx->stream));
+        e = b->host_bd.err;
+    } else {
+        HIPCHK(hipMemcpyAsync(&e, b->bd(), sizeof(int), hipMemcpyDeviceToHost, b->ctx->stream));
+        HIPCHK(hipStreamSynchronize(b->ctx->stream));
+        if (e) HIPCHK(hipMemsetAsync(b->bd(), 0, sizeof(int), b->ctx->stream));
+    }
     HIPCHK(hipGetLastError());
-    int e = b->host_bd.err;
     if (capacity_bits) { *capacity_bits = e & (2 | 4 | 8); e &= ~(2 | 4 | 8); }
     if (e & 1) return fail(SVGR_E_OVERFLOW, "flatten depth cap (%d) hit: non-finite or absurd control points", kMaxFlattenDepth);
     if (e & 16) return fail(SVGR_E_INVALID, "path extent beyond +-1e9 pixels or non-finite");
@@ -2411,6 +2430,8 @@ int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags
         a.out_cols = b->vp[3];
         a.clip01 = (flags & SVGR_RENDER_CLIP01) ? 1 : 0;
         a.layer_off = layers ? b->layer_off.p : nullptr;
+        a.arena = (unsigned*)b->arena.p;
+        a.arena_words = (unsigned)(b->arena_bytes / 4);
         a.dbg = nullptr;
 #ifdef SVGR_DBG_STAMP
         {
@@ -2440,6 +2461,7 @@ int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags
             case 2: hipLaunchKernelGGL(k_tile_render<2>, grid, dim3(NT), 0, st, a); break;
             default: hipLaunchKernelGGL(k_tile_render<3>, grid, dim3(NT), 0, st, a); break;
         }
+        b->arena_zeroed = true;  // (done by that kernel, see TileArgs::arena)
     }
     if (timed) {
         HIPCHK(hipEventRecord(ev.e2, st));
@@ -2469,7 +2491,7 @@ int svgr_batch_timings(svgr_batch* b, int* n_renders, double* ms_total, double* 
     if (ms_geometry) *ms_geometry = tg;
     if (ms_tile) *ms_tile = tt;
     b->events.clear();
-    if (int rc = check_dev_err(b)) return rc;
+    if (int rc = check_dev_err(b, nullptr, false)) return rc;
     return 0;
 }
 
