@@ -1,8 +1,9 @@
 // svgr_hip.hip -- MI355X (gfx950 / CDNA4) anti-aliased path rasterizer: HIP kernels + C ABI.
 //
-// Pipeline of one svgr_batch_render (1 memset + 6 launches on the context stream, no host read-back):
+// Pipeline of one svgr_batch_render (6 launches on the context stream, no host read-back):
 //
-//   memset          one zero-fill of the batch's counter arena
+//   [memset]        zero-fill of the batch's counter arena: only for the first render after a plan, later ones find
+//                   it zeroed by the previous render's tile kernel
 //   [k_path_rows]   multi-GPU only: rows each path's control-point hull can reach (foreign paths are skipped)
 //   k_flatten       32 lanes per segment: transform (fma form), stack-free adaptive subdivision,
 //                   count -> wave prefix -> ONE reservation per wave in one of 16 edge-cursor shards ->
