@@ -834,6 +834,43 @@ def gen_filters(ref) -> None:
     save("filter_kat.npz", **out)
 
 
+
+def gen_svg(ref, fonts) -> None:
+    """SVG loader known answers (svg_scene, S:2803-3083): the hand-written documents of tests/svg_cases.py loaded by the
+    reference, stored as scene dumps."""
+    import warnings
+    sys.path.insert(0, os.path.dirname(HERE))
+    from tests import svg_cases
+    out, meta = {}, []
+    for idx, (name, text, width) in enumerate(svg_cases.CASES):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            scene, _ids, size = ref.svg_scene_from_str(text, width=width, fonts=ref.FontsDB())  # document fonts only
+        m = dict(name=name, width=width, none=scene is None, size=None if size is None else [float(v) for v in size])
+        if scene is not None:
+            d = Dumper(ref)
+            out[f"{idx}_tree"] = np.array(json.dumps(d.node(scene)))
+            for k, v in d.arrays().items():
+                out[f"{idx}_{k}"] = v
+            m["unsupported"] = sorted(d.unsupported)
+            if size is not None and "str" not in d.unsupported:
+                # what the reference's CLI would draw (S:3836-3870): x/y swap, whole document viewport
+                w, h = int(size[0]), int(size[1])
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    res = scene.render(ref.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=False)
+                if res is not None:
+                    cl = res[0].convert(pre_alpha=True, linear_rgb=False)
+                    canvas = np.zeros((h, w, 4))
+                    ref.canvas_merge_at(canvas, cl.image, cl.offset)
+                    out[f"{idx}_canvas"] = canvas
+                    m["canvas"] = [h, w]
+        meta.append(m)
+    out["meta"] = np.array(json.dumps(meta))
+    save("svg_kat.npz", **out)
+    print("  svg:", [(m["name"], m.get("unsupported")) for m in meta])
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also render the full-size configs (slow)")
@@ -856,6 +893,8 @@ def main() -> None:
         gen_png(ref)
     if todo("filters"):
         gen_filters(ref)
+    if todo("svg"):
+        gen_svg(ref, fonts)
     if todo("mask"):
         gen_mask(ref)
     if todo("compose"):

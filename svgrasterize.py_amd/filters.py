@@ -6,6 +6,7 @@ built on the host exactly like ``blur_kernel`` does (a few thousand numbers); ev
 GPU (``svgr_layer_convolve``, ``svgr_layer_blend``, ``svgr_layer_color_matrix``, ``svgr_layer_morphology``)."""
 from __future__ import annotations
 
+import math
 from typing import NamedTuple
 
 import numpy as np
@@ -19,6 +20,29 @@ FE_BLEND, FE_COLOR_MATRIX, FE_COMPONENT_TRANSFER, FE_COMPOSITE, FE_CONVOLVE_MATR
 FE_DIFFUSE_LIGHTING, FE_DISPLACEMENT_MAP, FE_FLOOD, FE_GAUSSIAN_BLUR, FE_MERGE = 5, 6, 7, 8, 9
 FE_MORPHOLOGY, FE_OFFSET, FE_SPECULAR_LIGHTING, FE_TILE, FE_TURBULENCE = 10, 11, 12, 13, 14
 COLOR_MATRIX_LUM = np.array([[0, 0, 0, 0, 0], [0, 0, 0, 0, 0], [0, 0, 0, 0, 0], [0.2125, 0.7154, 0.0721, 0, 0]], dtype=np.float64)
+# feColorMatrix type="saturate" / "hueRotate" (the SVG 1.1 filter chapter's constants; S:1740-1747): the colour block is
+# _HUE_BASE + cos(a) * _HUE_COS + sin(a) * _HUE_SIN; saturate(s) is the same with (cos, sin) := (s, 0)
+_HUE_BASE = np.array([[0.213, 0.715, 0.072]] * 3, dtype=np.float64)
+_HUE_COS = np.array([[0.787, -0.715, -0.072], [-0.213, 0.285, -0.072], [-0.213, -0.715, 0.928]], dtype=np.float64)
+_HUE_SIN = np.array([[-0.213, -0.715, 0.928], [0.143, 0.140, -0.283], [-0.787, 0.715, 0.072]], dtype=np.float64)
+
+
+def _hue_matrix(c: float, s: float) -> np.ndarray:
+    matrix = np.eye(4, 5)
+    matrix[:3, :3] = np.dot(np.stack([_HUE_BASE, _HUE_COS, _HUE_SIN]).T, [1, c, s]).T
+    return matrix
+
+
+def color_matrix_hue_rotate(angle: float) -> np.ndarray:
+    """4x5 colour matrix of a hue rotation by ``angle`` radians (S:1947-1951)."""
+    return _hue_matrix(math.cos(angle), math.sin(angle))
+
+
+def color_matrix_saturate(value: float) -> np.ndarray:
+    """4x5 colour matrix of feColorMatrix ``saturate`` (S:1954-1957)."""
+    return _hue_matrix(value, 0)
+
+
 FE_SOURCE_ALPHA = "SourceAlpha"
 FE_SOURCE_GRAPHIC = "SourceGraphic"
 

@@ -14,36 +14,55 @@ _TOK = re.compile(r"([MmZzLlHhVvCcSsQqTtAa])|([-+]?(?:\d*\.\d+|\d+\.?)(?:[eE][-+
 _ARGC = dict(M=2, L=2, H=1, V=1, C=6, S=4, Q=4, T=2, A=7, Z=0)
 
 
+def _signed_angle(u, v):
+    """Signed angle from u to v via the normalised dot product (S:2472-2478).
+
+    The acos form is kept on purpose: near 0 and pi it is ill-conditioned, and the
+    reference's arcs carry exactly that rounding, so an atan2 form would differ by ~1e-8.
+    """
+    cosv = np.dot(u, v) / (np.linalg.norm(u) * np.linalg.norm(v))
+    a = math.acos(min(1.0, max(-1.0, cosv)))
+    return -a if np.cross(u, v) < 0 else a
+
+
 def _arc_center(p0, p1, rx, ry, rot_deg, large, sweep):
-    """SVG endpoint -> centre parametrisation (SVG 1.1 appendix F.6.5). Returns None for a degenerate arc."""
+    """SVG endpoint -> centre parametrisation (SVG 1.1 appendix F.6.5, as S:2397-2448 evaluates it).
+
+    Returns None for a degenerate arc.
+    """
     if rx == 0 or ry == 0 or np.allclose(p0, p1):
         return None
     rx, ry = abs(rx), abs(ry)
-    phi = math.radians(rot_deg)
+    p0, p1 = np.asarray(p0, dtype=np.float64), np.asarray(p1, dtype=np.float64)
+    phi = rot_deg * math.pi / 180
     c, s = math.cos(phi), math.sin(phi)
-    dx, dy = (p0[0] - p1[0]) / 2, (p0[1] - p1[1]) / 2
-    x1, y1 = c * dx + s * dy, -s * dx + c * dy
+    rot_inv = np.array([[c, s], [-s, c]])
+    # F.6.5.1: half chord in the ellipse frame
+    x1, y1 = np.matmul(rot_inv, (p0 - p1) / 2)
+    # F.6.6.2: grow radii that cannot span the chord
     lam = (x1 / rx) ** 2 + (y1 / ry) ** 2
     if lam > 1:
-        rx, ry = rx * math.sqrt(lam), ry * math.sqrt(lam)
-    num = rx * rx * ry * ry - rx * rx * y1 * y1 - ry * ry * x1 * x1
-    den = rx * rx * y1 * y1 + ry * ry * x1 * x1
-    k = math.sqrt(max(num / den, 0.0)) * (-1 if large == sweep else 1)
-    cx1, cy1 = k * rx * y1 / ry, -k * ry * x1 / rx
-    cx = c * cx1 - s * cy1 + (p0[0] + p1[0]) / 2
-    cy = s * cx1 + c * cy1 + (p0[1] + p1[1]) / 2
-
-    def ang(ux, uy, vx, vy):
-        a = math.atan2(ux * vy - uy * vx, ux * vx + uy * vy)
-        return a
-
-    eta = ang(1, 0, (x1 - cx1) / rx, (y1 - cy1) / ry)
-    delta = ang((x1 - cx1) / rx, (y1 - cy1) / ry, (-x1 - cx1) / rx, (-y1 - cy1) / ry)
+        lam = math.sqrt(lam)
+        rx *= lam
+        ry *= lam
+    # F.6.5.2: centre in the ellipse frame
+    k = math.sqrt(max(0, (rx * ry) ** 2 / ((rx * y1) ** 2 + (ry * x1) ** 2) - 1))
+    if large == sweep:
+        k = -k
+    centre1 = k * np.array([rx * y1 / ry, -ry * x1 / rx])
+    cx1, cy1 = centre1
+    # F.6.5.3: back to user space
+    centre = np.matmul(rot_inv.T, centre1) + (p1 + p0) / 2
+    # F.6.5.5-6: start angle and sweep
+    u = np.array([(x1 - cx1) / rx, (y1 - cy1) / ry])
+    v = np.array([(-x1 - cx1) / rx, (-y1 - cy1) / ry])
+    eta = _signed_angle(np.array([1, 0]), u)
+    delta = math.fmod(_signed_angle(u, v), 2 * math.pi)
     if not sweep and delta > 0:
         delta -= 2 * math.pi
-    elif sweep and delta < 0:
+    if sweep and delta < 0:
         delta += 2 * math.pi
-    return (np.array([cx, cy]), rx, ry, phi, eta, delta)
+    return (centre, rx, ry, phi, eta, delta)
 
 
 def parse_path_data(d: str):
@@ -55,8 +74,10 @@ def parse_path_data(d: str):
     i = 0
 
     def close(kind):
+        # a moveto / end of data ends a subpath only if it drew something; ``z`` always leaves one behind, so that
+        # ``M x,y z`` is a subpath of a single zero-length closing segment (S:1299-1303, S:1397-1404)
         nonlocal cur
-        if cur:
+        if cur or kind == g.PATH_CLOSED:
             cur.append((kind, np.array([pos.copy(), start.copy()])))
             subpaths.append(cur)
         cur = []
@@ -112,7 +133,11 @@ def parse_path_data(d: str):
         elif C == "A":
             p = base + args[5:7]
             arc = _arc_center(pos, p, args[0], args[1], args[2], bool(args[3]), bool(args[4]))
-            if arc is None:
+            if args[0] == 0 or args[1] == 0:
+                # zero radius: the reference records a zero-length line at the end point and leaves the gap to the
+                # subpath's closing segment (S:1376-1379); kept, so that such documents rasterise the same
+                cur.append((g.PATH_LINE, np.array([p.copy(), p.copy()])))
+            elif arc is None:
                 cur.append((g.PATH_LINE, np.array([pos.copy(), p])))
             else:
                 cur.append((g.PATH_ARC, arc))

@@ -1,0 +1,136 @@
+"""SVG front-end (svgrasterize.py_amd/svg.py): the Scene it builds against the Scene the reference's
+own loader built from the same document -- as scene dumps (tests/golden/scene_*.npz for the reference's demo files, read
+from /root/reference/demo when that exists: the build container only; tests/golden/svg_kat.npz for the hand-written
+documents of tests/svg_cases.py, everywhere)."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from tests import svg_cases
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEMO = "/root/reference/demo"
+
+
+def _compare(scene, tree_ref, arrays_ref, tol=1e-12):
+    from svgrasterize_amd import scenedump
+
+    tree, arrays = scenedump.dump_scene(scene)
+    return scenedump.compare_dumps(tree, arrays, tree_ref, arrays_ref, tol)
+
+
+def test_handwritten_documents_match_reference_loader():
+    from svgrasterize_amd import svg
+
+    z = np.load(os.path.join(GOLD, "svg_kat.npz"))
+    meta = json.loads(str(z["meta"]))
+    assert [m["name"] for m in meta] == [name for name, _text, _w in svg_cases.CASES]
+    for idx, ((name, text, width), m) in enumerate(zip(svg_cases.CASES, meta)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            scene, _ids, size = svg.svg_scene_from_str(text, width=width)
+        if m["none"]:
+            assert scene is None, name
+            continue
+        assert size is None and m["size"] is None or [float(v) for v in size] == m["size"], name
+        arrays = {k: z[f"{idx}_{k}"] for k in ("lines", "cubics", "line_off", "cubic_off")}
+        diffs = _compare(scene, json.loads(str(z[f"{idx}_tree"])), arrays)
+        assert not diffs, f"{name}: " + "; ".join(diffs[:5])
+
+
+@pytest.mark.parametrize("name,svg_file,width", [("tiger", "icons/tiger.svg", 2048), ("material", "material-design.svg", 4096),
+                                                  ("icons", "icons.svg", None)])
+def test_demo_documents_match_reference_dumps(name, svg_file, width):
+    path = os.path.join(DEMO, svg_file)
+    if not os.path.exists(path):
+        pytest.skip("the reference's demo files exist only in the build container")
+    from svgrasterize_amd import svg
+
+    z = np.load(os.path.join(GOLD, f"scene_{name}.npz"))
+    info = json.loads(str(z["info"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        scene, _ids, size = svg.svg_scene_from_filepath(path, width=width)
+    w, h = size
+    assert [int(h), int(w)] == info["size"]
+    arrays = {k: z[k] for k in ("lines", "cubics", "line_off", "cubic_off")}
+    diffs = _compare(scene, json.loads(str(z["tree"])), arrays)
+    assert not diffs, "; ".join(diffs[:8])
+
+
+def test_scalar_parsers():
+    from svgrasterize_amd import svg
+
+    assert svg.parse_size("1in") == 96 and svg.parse_size("2.54cm") == pytest.approx(96) and svg.parse_size("12pt") == 16
+    assert svg.parse_size("3") == 3.0 and svg.parse_size(None, 7) == 7 and svg.parse_size("2em") == 24
+    assert svg.parse_float("50%") == 0.5 and svg.parse_float("3px") == 3.0 and svg.parse_float(None) is None
+    assert svg.parse_floats("1,2  3") == [1.0, 2.0, 3.0]
+    with pytest.raises(ValueError):
+        svg.parse_floats("1 2", 4, 4)
+    t = svg.parse_transform("translate(10, 5) scale(2) rotate(90)")
+    assert np.allclose(t([[1, 0]]), [[10, 7]])
+    with pytest.raises(ValueError):
+        svg.parse_transform("spin(3)")
+    assert np.allclose(svg.parse_color("#fff"), [1, 1, 1, 1]) and np.allclose(svg.parse_color("red"), [1, 0, 0, 1])
+    c = svg.parse_color("rgba(255, 0, 0, 127.5)")
+    assert np.allclose(c, [0.5, 0, 0, 0.5])
+    assert svg.parse_paint("none", {}) is None and svg.parse_paint(None, {}) is None
+
+
+def test_fonts_db_resolution_and_glyph_layout():
+    """fonts.py on its own: family fallbacks, style / weight choice, ligatures, kerning, the missing glyph."""
+    from svgrasterize_amd.fonts import Font, FontsDB, Glyph
+
+    def face(family, weight, style="normal"):
+        f = Font(family, weight, style, 800, -200, 1000)
+        f.glyphs.update({c: Glyph(c, 500.0, "M0,0 H100 V100 z", c) for c in "abf"})
+        f.glyphs["ff"] = Glyph("ff", 800.0, "M0,0 H200 V100 z", "ff")
+        f.missing_glyph = Glyph(None, 300.0, "", "missing-glyph")
+        f.hkern[("a", "b")] = 50.0
+        return f
+
+    db = FontsDB()
+    assert db.resolve("anything") is None
+    regular, bold, italic, mono = face("Serif", 400), face("Serif", 700), face("Serif", 400, "italic"), face("monospace", 400)
+    for f in (regular, bold, italic, mono):
+        db.register(f)
+    db.register(bold, alias="heavy")
+    assert db.resolve(None) is regular and db.resolve("Georgia") is regular and db.resolve("no idea") is regular
+    assert db.resolve("serif", 650) is bold and db.resolve("heavy") is bold
+    assert db.resolve("serif", None, "italic") is italic and db.resolve("serif", None, "oblique") is regular
+    assert db.resolve("Courier") is mono and db.resolve("Some Mono") is mono
+    assert db.resolve("Arial") is None  # no sans family registered, and the fallback of the fallback is absent
+
+    placed, advance = regular.str_to_glyphs("abffa?")
+    assert [(x, g.name) for x, g in placed] == [(0.0, "a"), (450.0, "b"), (950.0, "ff"), (1750.0, "a"), (2250.0, "missing-glyph")]
+    assert advance == 2550.0
+    path, width = regular.str_to_path(20, "ab")
+    assert width == 950.0 * (20 / 1000) and len(path.subpaths) == 2
+    assert np.allclose(np.asarray(path.subpaths[1][0][1]), [[9.0, -0.0], [11.0, -0.0]])
+
+
+@pytest.mark.gpu
+def test_documents_render_like_the_reference():
+    """Whole front-end + hot path: document text -> Scene -> HIP render, against the canvas the reference drew."""
+    import svgrasterize_amd as S
+    from svgrasterize_amd import svg
+    from tests.util import assert_f32_1ulp
+
+    S.Context.get()
+    z = np.load(os.path.join(GOLD, "svg_kat.npz"))
+    meta = json.loads(str(z["meta"]))
+    drawn = 0
+    for idx, ((name, text, width), m) in enumerate(zip(svg_cases.CASES, meta)):
+        if not m.get("canvas"):
+            continue
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            scene, _ids, _size = svg.svg_scene_from_str(text, width=width)
+        h, w = m["canvas"]
+        layer, _hull = scene.render(S.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=False)
+        assert_f32_1ulp(layer.to_canvas_f32(h, w), z[f"{idx}_canvas"], what=f"{name} canvas")
+        drawn += 1
+    assert drawn >= 6
