@@ -235,6 +235,22 @@ typedef struct {
 } svgr_gradient;
 int svgr_gradient_fill(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* mask, const int64_t* bbox, svgr_buf* out_rgba);
 
+/* Path.fill, pattern branch (S:1049-1094): out_rgba = pattern tile looked up per pixel * mask.  `tile` is the
+ * (rows, cols, 4) double image of the pattern's scene rendered once by the caller (Scene.render under the fill's
+ * transform without translation, S:1051-1064); this call does the per-pixel part, S:1066-1094: pixel centre ->
+ * inv_m6 -> np.remainder by the cell -> fwd_m6 -> astype(int) -> minus min_xy -> tile pixel clipped to [0, 1]
+ * (0 outside the tile), times the coverage.  SVGR_E_INVALID if an offset leaves the pattern canvas (numpy: IndexError). */
+typedef struct svgr_pattern {
+    double inv_m6[6];      /* repeat transform inverted: presentation pixels -> pattern space (S:1066-1071)      */
+    double fwd_m6[6];      /* repeat transform, translation removed: pattern space -> pixels                       */
+    double cell[4];        /* Pattern.x, y, width, height                                                         */
+    int64_t min_xy[2];     /* integer minimum over the transformed cell corners (S:1084)                          */
+    int64_t pat_shape[2];  /* (w + 1, h + 1) of the pattern canvas (S:1088)                                       */
+    int64_t tile_bbox[4];  /* tile layer inside that canvas: x - min_x, y - min_y, rows, cols (S:1089)            */
+} svgr_pattern;
+int svgr_pattern_fill(svgr_ctx* ctx, const svgr_pattern* pattern, const svgr_buf* tile, const svgr_buf* mask,
+                      const int64_t* bbox, svgr_buf* out_rgba);
+
 /* Layer.convolve (S:106-118): full 2-D convolution of a (rows, cols, 4) double image with a host (kw, kh)
  * kernel (blur_kernel, S:1903-1944, is built on the host); out is (rows + kw - 1, cols + kh - 1, 4).     */
 int svgr_layer_convolve(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, const double* kernel,

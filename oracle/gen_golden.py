@@ -492,6 +492,11 @@ class Dumper:
                         stops=[[float(o), [float(x) for x in c]] for o, c in p.stops],
                         tr=None if p.transform is None else [float(x) for x in p.transform.m[:2].ravel()],
                         spread=p.spread, bbox_units=bool(p.bbox_units), linear_rgb=p.linear_rgb)
+        if isinstance(p, ref.Pattern):
+            return dict(k="pattern", scene=self.node(p.scene), scene_bbox_units=bool(p.scene_bbox_units),
+                        scene_view_box=None if p.scene_view_box is None else [float(x) for x in p.scene_view_box],
+                        cell=[float(p.x), float(p.y), float(p.width), float(p.height)],
+                        tr=[float(x) for x in p.transform.m[:2].ravel()], bbox_units=bool(p.bbox_units))
         self.unsupported.add(type(p).__name__)
         return dict(k="unsupported", name=type(p).__name__)
 

@@ -56,6 +56,13 @@ class Gradient(C.Structure):
     ]
 
 
+class PatternArgs(C.Structure):  # svgr_pattern
+    _fields_ = [
+        ("inv_m6", C.c_double * 6), ("fwd_m6", C.c_double * 6), ("cell", C.c_double * 4),
+        ("min_xy", C.c_int64 * 2), ("pat_shape", C.c_int64 * 2), ("tile_bbox", C.c_int64 * 4),
+    ]
+
+
 _P = C.c_void_p
 _PROTOS = {
     "svgr_abi_version": (C.c_int, []),
@@ -101,6 +108,7 @@ _PROTOS = {
     "svgr_layer_morphology": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int]),
     "svgr_layer_luminance": (C.c_int, [_P, _P, _P, C.c_int64]),
     "svgr_gradient_fill": (C.c_int, [_P, C.POINTER(Gradient), _P, _P, _P]),
+    "svgr_pattern_fill": (C.c_int, [_P, C.POINTER(PatternArgs), _P, _P, _P, _P]),
     "svgr_layer_convolve": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64]),
     "svgr_path_stroke": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, C.c_int, C.c_int, C.POINTER(_P)]),
     "svgr_stroke_out_counts": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -1753,6 +1753,54 @@ __global__ void k_gradient_fill(const GradDev* __restrict__ gp, const double* __
 }
 
 // --------------------------------------------------------------------------------------
+// Path.fill, pattern branch (S:1066-1094): per pixel, the tile offset of the repeated pattern and tile * mask
+// --------------------------------------------------------------------------------------
+// np.remainder for doubles: C fmod, moved into the divisor's sign range
+__device__ __forceinline__ double np_remainder(double a, double b) {
+    double m = fmod(a, b);
+    if (b == 0.0) return m;
+    if (m != 0.0) {
+        if ((b < 0.0) != (m < 0.0)) m += b;
+    } else {
+        m = copysign(0.0, b);
+    }
+    return m;
+}
+
+// One thread per pixel of the mask.  The pixel centre goes to pattern space (inv), is reduced modulo the cell, comes
+// back (fwd, no translation) and is truncated like ndarray.astype(int); minus the integer corner minimum that is the
+// offset into the (pw, ph) pattern canvas the reference allocates.  That canvas is zero except for the tile merged OVER
+// it and clipped to [0, 1] (canvas_merge_at, S:304-327), so it is never built: the tile is read in place.  Negative
+// offsets wrap like numpy's; an offset past the canvas (numpy: IndexError) raises the flag.
+__global__ void k_pattern_fill(const svgr_pattern pt, const double* __restrict__ tile, const double* __restrict__ mask, int r0,
+                               int c0, int rows, int cols, int* __restrict__ oob, double* __restrict__ out) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * cols) return;
+    const int i = (int)(idx / cols), j = (int)(idx % cols);
+    const double px = (double)i + ((double)r0 + 0.5), py = (double)j + ((double)c0 + 0.5);
+    double ux, uy, tx, ty;
+    xform_point(pt.inv_m6, px, py, ux, uy);
+    const double rx = np_remainder(ux - pt.cell[0], pt.cell[2]), ry = np_remainder(uy - pt.cell[1], pt.cell[3]);
+    xform_point(pt.fwd_m6, rx, ry, tx, ty);
+    long long ox = (long long)tx - pt.min_xy[0], oy = (long long)ty - pt.min_xy[1];
+    if (ox < 0) ox += pt.pat_shape[0];
+    if (oy < 0) oy += pt.pat_shape[1];
+    double4 v = make_double4(0.0, 0.0, 0.0, 0.0);
+    if (ox < 0 || oy < 0 || ox >= pt.pat_shape[0] || oy >= pt.pat_shape[1] || tx != tx || ty != ty) {
+        atomicOr(oob, 1);
+    } else {
+        const long long lx = ox - pt.tile_bbox[0], ly = oy - pt.tile_bbox[1];
+        if (lx >= 0 && ly >= 0 && lx < pt.tile_bbox[2] && ly < pt.tile_bbox[3]) {
+            v = *reinterpret_cast<const double4*>(tile + 4 * ((size_t)lx * (size_t)pt.tile_bbox[3] + (size_t)ly));
+            v.x = fmin(fmax(v.x, 0.0), 1.0); v.y = fmin(fmax(v.y, 0.0), 1.0);
+            v.z = fmin(fmax(v.z, 0.0), 1.0); v.w = fmin(fmax(v.w, 0.0), 1.0);
+        }
+    }
+    const double m = mask[idx];  // canvas_compose(COMPOSE_IN, mask, pattern) = pattern * mask (S:1090, S:290)
+    *reinterpret_cast<double4*>(out + 4 * idx) = make_double4(v.x * m, v.y * m, v.z * m, v.w * m);
+}
+
+// --------------------------------------------------------------------------------------
 // full 2-D convolution of a (rows, cols, 4) image with a (kw, kh) kernel (Layer.convolve, S:106-118)
 // --------------------------------------------------------------------------------------
 __global__ void k_layer_convolve(double* __restrict__ out, const double* __restrict__ src, int rows, int cols,
@@ -2664,6 +2712,34 @@ int svgr_gradient_fill(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* ma
     }
     g_pool.release(dev);
     if (e != hipSuccess) return fail(SVGR_E_HIP, "svgr_gradient_fill: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int svgr_pattern_fill(svgr_ctx* ctx, const svgr_pattern* pt, const svgr_buf* tile, const svgr_buf* mask, const int64_t* bbox,
+                      svgr_buf* out) {
+    if (!ctx || !pt || !tile || !mask || !out || !bbox_ok(bbox)) return fail(SVGR_E_INVALID, "svgr_pattern_fill: bad arguments");
+    if (!(pt->cell[2] == pt->cell[2]) || !(pt->cell[3] == pt->cell[3]) || pt->pat_shape[0] <= 0 || pt->pat_shape[1] <= 0 ||
+        pt->tile_bbox[2] < 0 || pt->tile_bbox[3] < 0 || pt->tile_bbox[2] > (1 << 24) || pt->tile_bbox[3] > (1 << 24))
+        return fail(SVGR_E_INVALID, "svgr_pattern_fill: bad pattern geometry");
+    const size_t n = (size_t)bbox[2] * bbox[3];
+    if (mask->bytes < n * 8 || out->bytes < n * 32 || tile->bytes < (size_t)pt->tile_bbox[2] * (size_t)pt->tile_bbox[3] * 32)
+        return fail(SVGR_E_INVALID, "svgr_pattern_fill: buffer too small");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    int* flag = nullptr;
+    HIPCHK(g_pool.alloc((void**)&flag, 16));
+    int oob = 0;
+    hipError_t e = hipMemsetAsync(flag, 0, 16, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_pattern_fill, grid1(n), dim3(256), 0, ctx->stream, *pt, (const double*)tile->ptr, (const double*)mask->ptr,
+                           (int)bbox[0], (int)bbox[1], (int)bbox[2], (int)bbox[3], flag, (double*)out->ptr);
+        e = hipMemcpyAsync(&oob, flag, sizeof oob, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    g_pool.release(flag);
+    if (e != hipSuccess) return fail(SVGR_E_HIP, "svgr_pattern_fill: %s", hipGetErrorString(e));
+    if (oob) return fail(SVGR_E_INVALID, "svgr_pattern_fill: a tile offset falls outside the pattern canvas");
     return 0;
 }
 

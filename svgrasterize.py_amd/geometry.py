@@ -329,7 +329,7 @@ class Path:
         return layer, ConvexHull(_source=lambda: batch.edges()[0])
 
     def fill(self, transform: Transform, paint, fill_rule: str | None = None, viewport=None, linear_rgb: bool = True):
-        """Render path by fill-ing it, S:995-1103 (solid colours; gradients/patterns: not yet)."""
+        """Render path by fill-ing it, S:995-1103: solid colours, gradients, patterns."""
         if paint is None:
             return None
         if isinstance(paint, np.ndarray) and paint.shape == (4,):
@@ -351,6 +351,15 @@ class Path:
                 return None
             mask, hull = res
             return gradient_fill(paint, mask, hull, transform, linear_rgb), hull
+        from .paint import Pattern, pattern_fill  # noqa: PLC0415
+
+        if isinstance(paint, Pattern):
+            res = self.mask(transform, fill_rule, viewport)
+            if res is None:
+                return None
+            mask, hull = res
+            layer = pattern_fill(paint, mask, hull, transform, linear_rgb)
+            return None if layer is None else (layer, hull)
         warnings.warn(f"fill method is not implemented: {paint}")
         return None
 

@@ -1,4 +1,4 @@
-"""Paint servers of the hot path (reference S:1544-1695): linear and radial gradients.
+"""Paint servers of the hot path (reference S:1544-1712): linear and radial gradients, patterns.
 
 The per-pixel work (pixel centre -> user space -> gradient offset -> spread -> stop interpolation ->
 times mask) runs in the HIP kernel ``k_gradient_fill``; what the reference computes ONCE per fill with
@@ -89,6 +89,11 @@ def is_gradient(paint) -> bool:
     return isinstance(paint, (GradLinear, GradRadial))
 
 
+def needs_mask(paint) -> bool:
+    """Paints that are applied to the path's coverage mask (``Path.mask`` first), i.e. everything but a solid colour."""
+    return isinstance(paint, (GradLinear, GradRadial, Pattern))
+
+
 def gradient_fill(paint, mask_layer, hull, transform, linear_rgb: bool):
     """Path.fill, gradient branch (S:1021-1047): returns the RGBA Layer = gradient * mask."""
     from .layer import Layer
@@ -108,3 +113,74 @@ def gradient_fill(paint, mask_layer, hull, transform, linear_rgb: bool):
     _abi._check(ctx.lib.svgr_gradient_fill(ctx.handle, C.byref(g), mbuf.handle, bbox, out.handle))
     del keep
     return Layer._from_device(out, (rows, cols, 4), mask_layer.offset, pre_alpha=True, linear_rgb=linear_rgb)
+
+
+class Pattern(NamedTuple):
+    """A scene repeated over the plane as a paint (S:1698-1710).  ``x, y, width, height`` is the cell in pattern space,
+    ``transform`` the patternTransform, ``bbox_units`` whether the cell is in objectBoundingBox units; the content is in
+    ``scene_view_box`` coordinates if that is set, else in objectBoundingBox units if ``scene_bbox_units``."""
+
+    scene: object
+    scene_bbox_units: bool
+    scene_view_box: object
+    x: float
+    y: float
+    width: float
+    height: float
+    transform: object
+    bbox_units: bool
+
+    def bbox(self):
+        return (self.x, self.y, self.width, self.height)
+
+
+def pattern_fill(paint: Pattern, mask_layer, hull, transform, linear_rgb: bool):
+    """Path.fill, pattern branch (S:1049-1094): the RGBA Layer = repeated tile * mask, or None for an empty tile.
+
+    The tile is the pattern's scene rendered once (recursively, on the device) under the fill's transform without its
+    translation.  Every pixel centre of the mask is taken to pattern space, reduced modulo the cell, taken back and
+    truncated to an integer offset into the tile; ``k_pattern_fill`` does that per pixel with the reference's
+    operations and multiplies by the coverage.  What is computed once per fill stays here, in the reference's numpy
+    expressions."""
+    from .layer import Layer
+    from .svg import viewbox_transform  # noqa: PLC0415 (svg imports this module)
+
+    pat_tr = transform.no_translate()
+    if paint.scene_view_box:
+        if paint.bbox_units:
+            px, py, pw, ph = paint.bbox()
+            _hx, _hy, hw, hh = hull.bbox(transform)
+            box = (px * hw, py * hh, pw * hw, ph * hh)
+        else:
+            box = paint.bbox()
+        pat_tr = pat_tr @ viewbox_transform(box, paint.scene_view_box)
+    elif paint.scene_bbox_units:
+        pat_tr = hull.bbox_transform(pat_tr)
+    pat_tr = pat_tr @ paint.transform
+    result = paint.scene.render(pat_tr, linear_rgb=linear_rgb)
+    if result is None:
+        return None
+    tile, _tile_hull = result
+
+    repeat_tr = transform
+    if paint.bbox_units:
+        repeat_tr = hull.bbox_transform(repeat_tr)
+    repeat_tr = (repeat_tr @ paint.transform).no_translate()
+    corners = repeat_tr(np.array([[0, 0], [paint.width, 0], [0, paint.height], [paint.width, paint.height]], dtype=np.float64))
+    max_x, max_y = corners.max(axis=0).astype(int)
+    min_x, min_y = corners.min(axis=0).astype(int)
+
+    pat = _abi.PatternArgs()
+    pat.inv_m6 = (C.c_double * 6)(*np.asarray(repeat_tr.invert.m, dtype=np.float64)[:2].ravel())
+    pat.fwd_m6 = (C.c_double * 6)(*np.asarray(repeat_tr.m, dtype=np.float64)[:2].ravel())
+    pat.cell = (C.c_double * 4)(paint.x, paint.y, paint.width, paint.height)
+    pat.min_xy = (C.c_int64 * 2)(int(min_x), int(min_y))
+    pat.pat_shape = (C.c_int64 * 2)(int(max_x - min_x) + 1, int(max_y - min_y) + 1)
+    pat.tile_bbox = (C.c_int64 * 4)(int(tile.x) - int(min_x), int(tile.y) - int(min_y), tile.height, tile.width)
+    ctx = _abi.Context.get()
+    rows, cols = mask_layer.height, mask_layer.width
+    out = ctx.alloc(rows * cols * 32)
+    bbox = (C.c_int64 * 4)(int(mask_layer.x), int(mask_layer.y), rows, cols)
+    _abi._check(ctx.lib.svgr_pattern_fill(ctx.handle, C.byref(pat), tile._device().handle, mask_layer._device().handle, bbox,
+                                          out.handle))
+    return Layer._from_device(out, (rows, cols, 4), mask_layer.offset, pre_alpha=tile.pre_alpha, linear_rgb=tile.linear_rgb)

@@ -203,15 +203,15 @@ def _collect_mask_jobs(scene: Scene, transform: Transform, mask_only: bool, line
     """(path, transform, rule) of every Path.mask the per-node route of `render` will call: leaves rendered
     ``mask_only`` (clip subtrees) and gradient-filled leaves.  Mirrors the routing of `_render`; a wrong guess only
     costs an unused mask or an on-demand one."""
-    from .paint import is_gradient  # noqa: PLC0415
+    from .paint import needs_mask  # noqa: PLC0415
 
     kind, args = scene
     if kind == RENDER_FILL:
         path, paint, rule = args
-        if mask_only or is_gradient(paint):
+        if mask_only or needs_mask(paint):
             jobs.append((path, transform, rule))
     elif kind == RENDER_STROKE:
-        if mask_only or is_gradient(args[1]):
+        if mask_only or needs_mask(args[1]):
             jobs.append((_stroked(scene), transform, None))
     elif kind == RENDER_GROUP:
         for child in args:

@@ -10,7 +10,7 @@ import json
 import numpy as np
 
 from .geometry import Path, Transform
-from .paint import GradLinear, GradRadial
+from .paint import GradLinear, GradRadial, Pattern
 from .scene import Scene
 
 
@@ -35,6 +35,8 @@ def load_scene(npz_path: str):
             return None
         if p["k"] == "rgba":
             return np.array(p["v"], dtype=np.float64)
+        if p["k"] == "pattern":
+            return Pattern(node(p["scene"]), p["scene_bbox_units"], p["scene_view_box"], *p["cell"], _tr(p["tr"]), p["bbox_units"])
         tr = None if p.get("tr") is None else _tr(p["tr"])
         stops = [(o, np.array(c)) for o, c in p["stops"]]
         if p["k"] == "linear":
@@ -96,6 +98,11 @@ def dump_scene(scene: Scene):
             return None
         if isinstance(p, np.ndarray):
             return dict(k="rgba", v=[float(x) for x in p])
+        if isinstance(p, Pattern):
+            return dict(k="pattern", scene=node(p.scene), scene_bbox_units=bool(p.scene_bbox_units),
+                        scene_view_box=None if p.scene_view_box is None else [float(x) for x in p.scene_view_box],
+                        cell=[float(p.x), float(p.y), float(p.width), float(p.height)],
+                        tr=[float(x) for x in p.transform.m[:2].ravel()], bbox_units=bool(p.bbox_units))
         if not isinstance(p, (GradLinear, GradRadial)):
             return dict(k="unsupported", name=type(p).__name__)
         common = dict(stops=[[float(o), [float(x) for x in c]] for o, c in p.stops],

@@ -7,10 +7,10 @@ isolated group, the order filter -> opacity -> clip-path -> mask -> transform), 
 exactly like the scene dumps extracted from the reference (``tests/test_svg_loader.py`` compares the trees).
 
 Supported: svg (nested, viewBox), g, defs, path, rect, circle, ellipse, line, polyline, polygon, use,
-linearGradient / radialGradient / stop, clipPath, mask, filter (feOffset, feGaussianBlur, feMerge, feBlend, feComposite,
+linearGradient / radialGradient / stop, pattern, clipPath, mask, filter (feOffset, feGaussianBlur, feMerge, feBlend, feComposite,
 feColorMatrix matrix / saturate / hueRotate / luminanceToAlpha, feMorphology), text / tspan set in SVG fonts (font, font-face, glyph,
 missing-glyph, hkern; ``fonts.py``), presentation attributes and ``style``.
-Not supported (a warning, the element is skipped): pattern paints, textPath.
+Not supported (a warning, the element is skipped): textPath, image, foreignObject, switch, marker, ...
 """
 from __future__ import annotations
 
@@ -30,7 +30,7 @@ from .geometry import (
     PATH_CLOSED, PATH_FILL_NONZERO, PATH_LINE, STROKE_CAP_BUTT, STROKE_JOIN_MITER, Path, Transform,
 )
 from .layer import COMPOSE_ATOP, COMPOSE_IN, COMPOSE_OUT, COMPOSE_OVER, COMPOSE_XOR
-from .paint import GradLinear, GradRadial
+from .paint import GradLinear, GradRadial, Pattern
 from .scene import Scene
 
 UNITS_USER = "userSpaceOnUse"
@@ -675,6 +675,17 @@ class _Loader:
         elif tag == "filter":
             if attrs.get("id") is not None:
                 ids[attrs["id"]] = _filter(element)
+        elif tag == "pattern":  # S:2914-2951
+            if attrs.get("id") is not None:
+                w, h = parse_float(attrs.get("width")), parse_float(attrs.get("height"))
+                if w is None or h is None:
+                    return []
+                content = Scene.group(self.children(element, inherit))
+                tr = parse_transform(attrs.get("patternTransform"))
+                ids[attrs["id"]] = Pattern(
+                    content, attrs.get("patternContentUnits", UNITS_USER) == UNITS_BBOX,
+                    parse_floats(attrs.get("viewBox"), 4, 4), parse_float(attrs.get("x", "0")), parse_float(attrs.get("y", "0")),
+                    w, h, Transform() if tr is None else tr, attrs.get("patternUnits", UNITS_BBOX) == UNITS_BBOX)
         elif tag == "rect":
             x, y = parse_size(attrs.pop("x", "0")), parse_size(attrs.pop("y", "0"))
             w, h = parse_size(attrs.pop("width")), parse_size(attrs.pop("height"))
@@ -722,7 +733,7 @@ class _Loader:
                 item = ids.get(href[1:])
                 if isinstance(item, Scene):
                     group = [item]
-        else:  # patterns, ...
+        else:
             warnings.warn(f"unsupported element type: {tag}")
 
         if not group:

@@ -57,7 +57,10 @@ CASES = [
       <feComposite in="SourceGraphic" in2="d" operator="arithmetic" k1="0.1" k2="0.8" k3="0.3" k4="0"/>
       <feComposite in2="SourceAlpha" operator="atop"/><feBlend in2="SourceGraphic" mode="multiply"/>
       <feColorMatrix values="1 0 0 0 0  0 1 0 0 0  0 0 1 0 0  0 0 0 0.5 0"/></filter>
+    <filter id="hue"><feColorMatrix type="hueRotate" values="75"/><feColorMatrix type="saturate" values="0.35"/>
+      <feColorMatrix type="hueRotate"/><feColorMatrix type="saturate"/><feColorMatrix type="sepia"/></filter>
   </defs>
+  <path d="M60,70 h35 v25 h-35 z M70,75 v15 h15 z" fill="#3c9" stroke="#b40" filter="url(#hue)"/>
   <circle cx="40" cy="40" r="25" fill="crimson" filter="url(#shadow)"/>
   <g filter="url(#ops)" transform="translate(20 20)"><rect width="50" height="50" fill="#08f"/></g>
 </svg>""", None),
@@ -93,6 +96,34 @@ CASES = [
   <text x="150" y="100" font-family="blocky" font-size="16" text-anchor="middle" stroke="black" stroke-width="0.5">Ao fi</text>
   <text x="290" y="115" font-family="Blocky" font-size="12" text-anchor="end" fill="none" stroke="#00f">oV</text>
   <text x="5" y="115" font-family="Unknown Sans" font-size="12">no such font</text>
+</svg>""", None),
+    ("patterns", """<svg xmlns="http://www.w3.org/2000/svg" width="290" height="160">
+  <defs>
+    <pattern id="dots" x="2" y="3" width="16" height="12" patternUnits="userSpaceOnUse">
+      <rect width="16" height="12" fill="#ffe"/><circle cx="8" cy="6" r="4" fill="#c33"/>
+      <path d="M0,0 L4,0 L0,3 z" fill="navy" fill-opacity="0.6"/>
+    </pattern>
+    <pattern id="tilted" width="20" height="10" patternUnits="userSpaceOnUse" patternTransform="rotate(30) scale(0.8 1.1)">
+      <rect width="10" height="10" fill="teal"/><rect x="10" width="10" height="5" fill="gold"/>
+    </pattern>
+    <pattern id="boxed" width="0.25" height="0.5">
+      <rect width="10" height="14" fill="#484"/><circle cx="12" cy="18" r="6" fill="#a6f" stroke="black"/>
+    </pattern>
+    <pattern id="viewboxed" x="5" y="5" width="24" height="24" patternUnits="userSpaceOnUse" viewBox="0 0 4 4">
+      <rect width="2" height="2" fill="black"/><rect x="2" y="2" width="2" height="2" fill="#888"/>
+    </pattern>
+    <pattern id="content_bbox" width="0.5" height="0.5" patternContentUnits="objectBoundingBox">
+      <rect width="0.25" height="0.5" fill="crimson"/><circle cx="0.375" cy="0.25" r="0.1" fill="blue"/>
+    </pattern>
+    <pattern id="nosize"><rect width="5" height="5"/></pattern>
+  </defs>
+  <rect x="70" y="5" width="90" height="60" fill="url(#dots)" stroke="black"/>
+  <ellipse cx="230" cy="35" rx="50" ry="28" fill="url(#tilted)"/>
+  <path d="M10,80 h80 v60 q-40,25 -80,0 z" fill="url(#boxed)"/>
+  <g transform="translate(110 75) rotate(-10)"><rect width="70" height="50" fill="url(#viewboxed)"/></g>
+  <circle cx="30" cy="30" r="26" fill="url(#content_bbox)" stroke="url(#dots)" stroke-width="5"/>
+  <circle cx="230" cy="120" r="30" fill="url(#dots)" fill-opacity="0.5"/>
+  <rect x="100" y="140" width="20" height="15" fill="url(#nosize)"/>
 </svg>""", None),
     # the reference hands the raw ``color`` string on as the paint (S:3147-3148): loadable, not renderable
     ("current_color", """<svg xmlns="http://www.w3.org/2000/svg" width="20" height="20">

@@ -133,4 +133,4 @@ def test_documents_render_like_the_reference():
         layer, _hull = scene.render(S.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=False)
         assert_f32_1ulp(layer.to_canvas_f32(h, w), z[f"{idx}_canvas"], what=f"{name} canvas")
         drawn += 1
-    assert drawn >= 6
+    assert drawn >= 8
