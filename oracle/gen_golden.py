@@ -876,6 +876,55 @@ def gen_svg(ref, fonts) -> None:
     print("  svg:", [(m["name"], m.get("unsupported")) for m in meta])
 
 
+HOSTUTIL_PATHS = [
+    "M1,2 L3.5,4 H10 V-2.25 z",
+    "M0,0 Q5,10 10,0 T20,0 C25,5 30,-5 35,0 S45,5 50,0",
+    "M10,30 a10,6 30 1 0 20,5 z m 5,5 l 1e-3,2 z",
+    "M0,0 h10 A5,5 0 0 1 20,10 L0,10 z M3,3 v4 h4 z M50,50 z",
+    "M1234.5678,0.000123 L-1e6,1e-7 C1,2 3,4 5.55555555,6 Q1,1 2,2",
+]
+HOSTUTIL_SCENES = ["basic_shapes", "groups_transforms_style", "clip_mask_opacity", "nested_svg_use", "text_svg_font"]
+
+
+def gen_hostutil(ref) -> None:
+    """Host-side conveniences: Path.to_svg (S:1204), Path.__repr__ (S:1436), Path.transform (S:1182), ConvexHull.path
+    (S:2025), Scene.__repr__ (S:796), Scene.to_path (S:754) on the hand-written documents, Layer.background (S:166)."""
+    import warnings
+    sys.path.insert(0, os.path.dirname(HERE))
+    from tests import svg_cases
+    out, meta = {}, dict(paths=[], scenes=[])
+    tr = ref.Transform().translate(3, -2).rotate(0.3).scale(1.5, 0.75)
+    for idx, d in enumerate(HOSTUTIL_PATHS):
+        path = ref.Path.from_svg(d)
+        moved = path.transform(tr)
+        types, params, sizes = pack_segments(ref, moved)
+        out[f"p{idx}_types"], out[f"p{idx}_params"], out[f"p{idx}_sizes"] = types, params, sizes
+        meta["paths"].append(dict(d=d, to_svg=path.to_svg(), repr=repr(path), moved_to_svg=moved.to_svg(), empty=path.is_empty()))
+    meta["tr"] = [float(x) for x in tr.m[:2].ravel()]
+    hull = ref.ConvexHull([[0, 0], [4, 0], [4, 3], [2, 1], [0, 3], [2, 5]])
+    meta["hull"] = dict(points=[[float(x) for x in p] for p in hull.points], repr=repr(hull.path()))
+    cases = {name: (text, width) for name, text, width in svg_cases.CASES}
+    view = ref.Transform().matrix(0, 1, 0, 1, 0, 0).scale(0.5)
+    for idx, name in enumerate(HOSTUTIL_SCENES):
+        text, width = cases[name]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            scene, _ids, _size = ref.svg_scene_from_str(text, width=width, fonts=ref.FontsDB())
+        l, c = gather_defs(ref, scene.to_path(view))
+        out[f"s{idx}_lines"], out[f"s{idx}_cubics"] = l, c
+        meta["scenes"].append(dict(name=name, repr=repr(scene)))
+    rng = np.random.default_rng(4242)
+    a = rng.uniform(0, 1, (9, 7, 1))
+    img = np.concatenate([rng.uniform(0, 1, (9, 7, 3)) * a, a], axis=-1)
+    colour = np.array([0.1, 0.25, 0.05, 0.5])
+    for idx, (pre, lin) in enumerate([(True, True), (False, False), (True, False)]):
+        src = ref.Layer(img if pre else np.concatenate([img[..., :3] / a, a], axis=-1), (2, 5), pre_alpha=pre, linear_rgb=lin)
+        out[f"bg{idx}_in"], out[f"bg{idx}_out"] = src.image, src.background(colour).image
+    meta["bg"] = dict(colour=[float(x) for x in colour], flags=[[True, True], [False, False], [True, False]])
+    out["meta"] = np.array(json.dumps(meta))
+    save("hostutil_kat.npz", **out)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also render the full-size configs (slow)")
@@ -900,6 +949,8 @@ def main() -> None:
         gen_filters(ref)
     if todo("svg"):
         gen_svg(ref, fonts)
+    if todo("hostutil"):
+        gen_hostutil(ref)
     if todo("mask"):
         gen_mask(ref)
     if todo("compose"):

@@ -1604,6 +1604,16 @@ __global__ void k_layer_scale(double* __restrict__ img, size_t n, double f) {
     if (i < n) img[i] = img[i] * f;
 }
 
+// Layer.background (S:166-169): the image OVER a constant colour, canvas_compose(OVER, colour, image) = image + colour * (1 - a)
+__global__ void k_layer_background(double* __restrict__ img, size_t n_px, double c0, double c1, double c2, double c3) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_px) return;
+    double4 v = *reinterpret_cast<double4*>(img + 4 * i);
+    const double k = 1.0 - v.w;
+    v.x = v.x + c0 * k; v.y = v.y + c1 * k; v.z = v.z + c2 * k; v.w = v.w + c3 * k;
+    *reinterpret_cast<double4*>(img + 4 * i) = v;
+}
+
 __global__ void k_layer_convert(double* __restrict__ img, size_t n_px, unsigned ops) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_px) return;
@@ -2642,6 +2652,15 @@ int svgr_layer_scale(svgr_ctx* ctx, svgr_buf* img, int64_t n, double f) {
     if (!ctx || !img || n < 0 || img->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_scale: bad arguments");
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_layer_scale, grid1((size_t)n), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n, f);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_layer_background(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, const double* rgba) {
+    if (!ctx || !img || !rgba || n_px < 0 || img->bytes < (size_t)n_px * 32) return fail(SVGR_E_INVALID, "svgr_layer_background: bad arguments");
+    if (n_px == 0) return 0;
+    hipLaunchKernelGGL(k_layer_background, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n_px, rgba[0],
+                       rgba[1], rgba[2], rgba[3]);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -63,6 +63,11 @@ class Transform:
             return points
         return points @ self.m[:2, :2].T + self.m[:2, 2]
 
+    def apply(self) -> Callable:
+        """The map as a plain function of point arrays, matrix slices taken once (S:536-539)."""
+        lin, shift = self.m[:2, :2].T, self.m[:2, 2]
+        return lambda points: points @ lin + shift
+
     def _chain(self, rhs) -> "Transform":
         return Transform(self.m @ np.array(rhs, dtype=FLOAT))
 
@@ -171,6 +176,12 @@ class ConvexHull:
             return transform
         return transform.translate(x, y).scale(w, h)
 
+    def path(self) -> "Path":
+        """The hull outline as a closed polygon path (S:2025-2029)."""
+        pts = self.points
+        edges = [(PATH_LINE, pair) for pair in zip(pts, pts[1:])] + [(PATH_CLOSED, [pts[-1], pts[0]])]
+        return Path([edges])
+
 
 # --------------------------------------------------------------------------------------
 # curve conversions that stay on the host (SURVEY 8a-a1)
@@ -221,6 +232,75 @@ class Path:
 
     def __bool__(self) -> bool:
         return bool(self.subpaths)
+
+    def is_empty(self) -> bool:
+        return not bool(self.subpaths)
+
+    def transform(self, transform: Transform) -> "Path":
+        """The path with ``transform`` applied on the host (S:1182-1202); arcs become cubics first.  Rendering does not
+        use this: ``mask`` / ``fill`` take the transform and apply it on the device."""
+        out = []
+        for sub in self.subpaths:
+            if not sub:
+                continue
+            moved = []
+            for kind, params in sub:
+                if kind == PATH_ARC:
+                    moved.extend((PATH_CUBIC, c.tolist()) for c in transform(arc_to_cubics(*params)))
+                else:
+                    moved.append((kind, transform(np.array(params)).tolist()))
+            out.append(moved)
+        return Path(out)
+
+    def to_svg(self) -> str:
+        """Path data, one line per subpath, numbers in ``%g`` (S:1204-1251): a segment names its command only when the
+        kind of segment changes, the first one is preceded by a moveto to its start."""
+        lines = []
+        for sub in self.subpaths:
+            if not sub:
+                continue
+            words, last = [], None
+            for kind, params in sub:
+                if kind == PATH_CLOSED:
+                    words.append("Z ")
+                    last = None
+                    continue
+                if kind == PATH_UNCLOSED:
+                    last = None
+                    continue
+                if kind not in (PATH_LINE, PATH_QUAD, PATH_CUBIC, PATH_ARC):
+                    raise ValueError("unhandled path type: `{cmd}`")
+                pieces = arc_to_cubics(*params) if kind == PATH_ARC else [params]
+                for pts in pieces:
+                    (x0, y0), rest = pts[0], pts[1:]
+                    if last != kind:
+                        if last is None:
+                            words.append(f"M{x0:g},{y0:g} ")
+                        if kind == PATH_LINE:
+                            words.append("L" if last is not None else "")
+                        else:
+                            words.append("Q" if kind == PATH_QUAD else "C")
+                    words.append("".join(f"{x:g},{y:g} " for x, y in rest))
+                    last = PATH_CUBIC if kind == PATH_ARC else kind
+            lines.append("".join(words))
+        return "\n".join(lines)
+
+    def __repr__(self) -> str:
+        if not self.subpaths:
+            return "EMPTY"
+        pts = lambda coords: " ".join(f"{x:.4g},{y:.4g}" for x, y in coords)  # noqa: E731
+        names = {PATH_LINE: "LINE", PATH_CUBIC: "CUBIC", PATH_QUAD: "QUAD"}
+        rows = []
+        for sub in self.subpaths:
+            for kind, params in sub:
+                if kind in names:
+                    rows.append(f"{names[kind]} {pts(params)}")
+                elif kind == PATH_ARC:
+                    center, rx, ry, phi, eta, eta_delta = params
+                    rows.append(f"ARC {pts([center])} {rx:.4g} {ry:.4g} {phi:.3g} {eta:.3g} {eta_delta:.3g}")
+                elif kind == PATH_CLOSED:
+                    rows.append("CLOSE")
+        return "\n".join(rows)
 
     # -- construction helpers ------------------------------------------------------------
     @classmethod

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from typing import Sequence
 
+import warnings
+
 import numpy as np
 
 from . import _abi
@@ -156,6 +158,26 @@ class Layer:
         buf = self._copy_device()
         _abi._check(ctx.lib.svgr_layer_convert(ctx.handle, buf.handle, self._shape[0] * self._shape[1], ops))
         return Layer._from_device(buf, self._shape, self.offset, pre_alpha, linear_rgb)
+
+    # -- Layer.background  S:166-169 -------------------------------------------------------
+    def background(self, color) -> "Layer":
+        """The layer over a solid background colour (premultiplied linear RGBA, like every paint)."""
+        layer = self.convert(pre_alpha=True, linear_rgb=True)
+        ctx = _abi.Context.get()
+        buf = layer._copy_device()
+        rgba = np.ascontiguousarray(color, dtype=np.float64).reshape(4)
+        _abi._check(ctx.lib.svgr_layer_background(ctx.handle, buf.handle, layer._shape[0] * layer._shape[1], rgba.ctypes.data))
+        return Layer._from_device(buf, layer._shape, layer.offset, True, True)
+
+    def show(self, format=None) -> None:
+        """Print the layer on the terminal through the optional ``imshow`` module (debugging aid, S:220-232)."""
+        try:
+            from imshow import show  # noqa: PLC0415
+        except ImportError:
+            warnings.warn("to be able to show layer on terminal imshow is required")
+            return
+        show(self.convert(pre_alpha=False, linear_rgb=False).image, format=format)
+        print()
 
     # -- Layer.opacity  S:171-175 ----------------------------------------------------------
     def opacity(self, opacity: float, linear_rgb: bool = False) -> "Layer":

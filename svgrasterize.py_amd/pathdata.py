@@ -22,7 +22,7 @@ def _signed_angle(u, v):
     """
     cosv = np.dot(u, v) / (np.linalg.norm(u) * np.linalg.norm(v))
     a = math.acos(min(1.0, max(-1.0, cosv)))
-    return -a if np.cross(u, v) < 0 else a
+    return -a if u[0] * v[1] - u[1] * v[0] < 0 else a
 
 
 def _arc_center(p0, p1, rx, ry, rot_deg, large, sweep):

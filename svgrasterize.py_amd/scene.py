@@ -17,6 +17,8 @@ Not built: pattern paints.
 """
 from __future__ import annotations
 
+import textwrap
+
 import numpy as np
 
 from . import _abi
@@ -71,6 +73,74 @@ class Scene(tuple):
 
     def filter(self, filter) -> "Scene":
         return Scene(RENDER_FILTER, (self, filter))
+
+    def to_path(self, transform: Transform) -> Path:
+        """All leaf outlines of the scene as one path, transforms applied on the host, strokes outlined after their
+        transform; decorations (opacity, clip, mask, filter) are looked through (S:754-794, a testing aid)."""
+        def outlines(scene, tr):
+            kind, args = scene
+            if kind == RENDER_FILL:
+                yield args[0].transform(tr)
+            elif kind == RENDER_STROKE:
+                path, _paint, width, linecap, linejoin = args
+                yield path.transform(tr).stroke(width, linecap, linejoin)
+            elif kind == RENDER_GROUP:
+                for child in args:
+                    yield from outlines(child, tr)
+            elif kind == RENDER_TRANSFORM:
+                yield from outlines(args[0], tr @ args[1])
+            elif kind in (RENDER_OPACITY, RENDER_CLIP, RENDER_MASK, RENDER_FILTER):
+                yield from outlines(args[0], tr)
+            else:
+                raise ValueError(f"unhandled scene type: {kind}")
+
+        return Path([sub for path in outlines(self, transform) for sub in path.subpaths])
+
+    def __repr__(self) -> str:
+        """Indented tree dump in the reference's wording (S:796-859)."""
+        pad = "  "
+
+        def colour(paint):
+            if isinstance(paint, np.ndarray):  # two hex digits per channel, single digits padded on the right (S:856)
+                return "#" + "".join(f"{c:0<2x}" for c in (paint * 255).astype(np.uint8))
+            return paint
+
+        def dump(scene, depth, out):
+            kind, args = scene
+            head = pad * depth
+            if kind == RENDER_FILL:
+                path, paint, rule = args
+                out.append(f"{head}FILL fill_rule:{rule} paint:{colour(paint)}\n{textwrap.indent(repr(path), pad * (depth + 1))}")
+            elif kind == RENDER_STROKE:
+                path, paint, width, linecap, linejoin = args
+                out.append(f"{head}STROKE width:{width} linecap:{linecap} linejoin:{linejoin} paint:{colour(paint)}\n"
+                           f"{textwrap.indent(repr(path), pad * (depth + 1))}")
+            elif kind == RENDER_GROUP:
+                out.append(f"{head}GROUP")
+                for child in args:
+                    dump(child, depth + 1, out)
+            elif kind == RENDER_OPACITY:
+                out.append(f"{head}OPACITY {args[1]}")
+                dump(args[0], depth + 1, out)
+            elif kind in (RENDER_CLIP, RENDER_MASK):
+                target, shape, bbox_units = args
+                name, shape_name = ("CLIP", "CLIP_PATH") if kind == RENDER_CLIP else ("MASK", "MAKS_PATH")
+                out.append(f"{head}{name} bbox_units:{bbox_units}")
+                out.append(f"{head}{pad}{shape_name}")
+                dump(shape, depth + 2, out)
+                out.append(f"{head}{pad}{name}_TARGET")
+                dump(target, depth + 2, out)
+            elif kind == RENDER_TRANSFORM:
+                out.append(f"{head}TRANSFORM {args[1]}")
+                dump(args[0], depth + 1, out)
+            elif kind == RENDER_FILTER:
+                out.append(f"{head}FILTER {args[1]}")
+                dump(args[0], depth + 1, out)
+            else:
+                raise ValueError(f"unhandled scene scene[0]: {kind}")
+            return out
+
+        return "\n".join(dump(self, 0, []))
 
     # -- render (S:649-752) ------------------------------------------------------------------
     def render(self, transform: Transform, mask_only: bool = False, viewport=None, linear_rgb: bool = False):

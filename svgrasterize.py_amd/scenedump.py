@@ -73,6 +73,12 @@ def load_scene(npz_path: str):
     return node(tree), info, z
 
 
+def gather_path(path: Path):
+    """``(lines (N, 2, 2), cubics (M, 4, 2))`` of a path, in segment order: what Path.mask hands to the device."""
+    segs, kinds = path.packed()
+    return segs[kinds == 0][:, :4].reshape(-1, 2, 2), segs[kinds == 1].reshape(-1, 4, 2)
+
+
 def dump_scene(scene: Scene):
     """The inverse of `load_scene`: a Scene as plain data in the dump format of oracle/gen_golden.py (class Dumper):
     ``(tree, arrays)`` with arrays = lines (N, 2, 2), cubics (M, 4, 2), line_off, cubic_off (per path index).
@@ -84,9 +90,7 @@ def dump_scene(scene: Scene):
     lines, cubics, loff, coff = [], [], [0], [0]
 
     def add_path(path: Path) -> int:
-        segs, kinds = path.packed()
-        l = segs[kinds == 0][:, :4].reshape(-1, 2, 2)
-        c = segs[kinds == 1].reshape(-1, 4, 2)
+        l, c = gather_path(path)
         lines.append(l)
         cubics.append(c)
         loff.append(loff[-1] + len(l))

@@ -1,0 +1,94 @@
+"""Host-side conveniences of the reference API (Path.to_svg / __repr__ / transform / is_empty, ConvexHull.path,
+Scene.__repr__ / to_path, Transform.apply, Layer.background) against what the reference returned for the same inputs
+(tests/golden/hostutil_kat.npz, made by oracle/gen_golden.py --only hostutil)."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from tests import svg_cases
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def kat():
+    z = np.load(os.path.join(GOLD, "hostutil_kat.npz"))
+    return z, json.loads(str(z["meta"]))
+
+
+def _packed(path):
+    from svgrasterize_amd.geometry import PATH_ARC
+
+    types, params, sizes = [], [], []
+    for sub in path.subpaths:
+        sizes.append(len(sub))
+        for kind, args in sub:
+            assert kind != PATH_ARC
+            flat = np.asarray(args, dtype=np.float64).ravel()
+            types.append(kind)
+            params.append(np.concatenate([flat, np.zeros(8 - flat.size)]))
+    return np.array(types), np.array(params).reshape(-1, 8), np.array(sizes)
+
+
+def test_path_text_forms_and_host_transform(kat):
+    from svgrasterize_amd import Path, Transform
+
+    z, meta = kat
+    tr = Transform(np.vstack([np.array(meta["tr"]).reshape(2, 3), [0, 0, 1]]))
+    for idx, want in enumerate(meta["paths"]):
+        path = Path.from_svg(want["d"])
+        assert path.is_empty() == want["empty"]
+        assert path.to_svg() == want["to_svg"], want["d"]
+        assert repr(path) == want["repr"], want["d"]
+        moved = path.transform(tr)
+        types, params, sizes = _packed(moved)
+        assert np.array_equal(types, z[f"p{idx}_types"]) and np.array_equal(sizes, z[f"p{idx}_sizes"])
+        assert np.allclose(params, z[f"p{idx}_params"], rtol=0, atol=1e-12)
+        assert moved.to_svg() == want["moved_to_svg"]
+    assert Path([]).is_empty() and repr(Path([])) == "EMPTY" and Path([]).to_svg() == ""
+    pts = np.array([[1.0, 2.0], [-3.5, 0.25]])
+    assert np.array_equal(tr.apply()(pts), tr(pts))
+
+
+def test_hull_outline(kat):
+    from svgrasterize_amd import ConvexHull
+
+    _z, meta = kat
+    hull = ConvexHull([[0, 0], [4, 0], [4, 3], [2, 1], [0, 3], [2, 5]])
+    assert [[float(x) for x in p] for p in hull.points] == meta["hull"]["points"]
+    assert repr(hull.path()) == meta["hull"]["repr"]
+
+
+def test_scene_repr_and_to_path(kat):
+    from svgrasterize_amd import Transform, svg_scene_from_str
+    from svgrasterize_amd.scenedump import gather_path
+
+    z, meta = kat
+    cases = {name: (text, width) for name, text, width in svg_cases.CASES}
+    view = Transform().matrix(0, 1, 0, 1, 0, 0).scale(0.5)
+    for idx, want in enumerate(meta["scenes"]):
+        text, width = cases[want["name"]]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            scene, _ids, _size = svg_scene_from_str(text, width=width)
+        assert repr(scene) == want["repr"], want["name"]
+        lines, cubics = gather_path(scene.to_path(view))
+        assert lines.shape == z[f"s{idx}_lines"].shape and cubics.shape == z[f"s{idx}_cubics"].shape, want["name"]
+        assert np.allclose(lines, z[f"s{idx}_lines"], rtol=0, atol=1e-9), want["name"]
+        assert np.allclose(cubics, z[f"s{idx}_cubics"], rtol=0, atol=1e-9), want["name"]
+
+
+@pytest.mark.gpu
+def test_layer_background(kat):
+    import svgrasterize_amd as S
+
+    S.Context.get()
+    z, meta = kat
+    colour = np.array(meta["bg"]["colour"])
+    for idx, (pre, lin) in enumerate(meta["bg"]["flags"]):
+        out = S.Layer(z[f"bg{idx}_in"], (2, 5), pre_alpha=pre, linear_rgb=lin).background(colour)
+        assert out.pre_alpha and out.linear_rgb and tuple(out.offset) == (2, 5)
+        assert np.allclose(out.image, z[f"bg{idx}_out"], rtol=0, atol=1e-15)
