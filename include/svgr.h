@@ -183,6 +183,8 @@ int svgr_layer_in(svgr_ctx* ctx, svgr_buf* out, const int64_t* out_bbox, const s
                   const int64_t* src_bbox, int src_channels);
 /* Layer.opacity, S:171-175: image * opacity */
 int svgr_layer_scale(svgr_ctx* ctx, svgr_buf* img, int64_t n_values, double factor);
+/* the clip(0, 1) that ends canvas_merge_at (S:326), in place on n_values doubles */
+int svgr_layer_clip01(svgr_ctx* ctx, svgr_buf* img, int64_t n_values);
 /* Layer.background, S:166-169: premultiplied linear RGBA image OVER the constant colour rgba[4], in place */
 int svgr_layer_background(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, const double* rgba);
 /* Layer.convert, S:129-164 + S:471-503, in place on n_px RGBA pixels.

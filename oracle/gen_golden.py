@@ -870,6 +870,12 @@ def gen_svg(ref, fonts) -> None:
                     ref.canvas_merge_at(canvas, cl.image, cl.offset)
                     out[f"{idx}_canvas"] = canvas
                     m["canvas"] = [h, w]
+                    # ... and the file it would write (S:3866-3877), without and with a background colour
+                    page = ref.Layer(ref.canvas_merge_at(np.zeros((h, w, 4)), cl.image, cl.offset), (0, 0), pre_alpha=True,
+                                     linear_rgb=False)
+                    out[f"{idx}_png"] = np.frombuffer(page.write_png().getvalue(), dtype=np.uint8)
+                    out[f"{idx}_png_bg"] = np.frombuffer(page.background(ref.svg_color("#fdf6e3")).write_png().getvalue(),
+                                                         dtype=np.uint8)
         meta.append(m)
     out["meta"] = np.array(json.dumps(meta))
     save("svg_kat.npz", **out)

@@ -24,7 +24,7 @@ from .scene import (  # noqa: F401
     RENDER_FILL, RENDER_STROKE, RENDER_GROUP, RENDER_OPACITY, RENDER_CLIP, RENDER_MASK, RENDER_TRANSFORM, RENDER_FILTER,
 )
 from .fonts import Font, FontsDB, Glyph  # noqa: F401
-from .svg import svg_scene, svg_scene_from_filepath, svg_scene_from_str  # noqa: F401
+from .svg import render_svg, svg_scene, svg_scene_from_filepath, svg_scene_from_str  # noqa: F401
 
 __all__ = ["Scene", "Path", "Transform", "Layer", "ConvexHull", "render_canvas", "svg_scene", "svg_scene_from_str",
-           "svg_scene_from_filepath", "FontsDB"]
+           "svg_scene_from_filepath", "render_svg", "FontsDB"]

@@ -1604,6 +1604,15 @@ __global__ void k_layer_scale(double* __restrict__ img, size_t n, double f) {
     if (i < n) img[i] = img[i] * f;
 }
 
+// ndarray.clip(0, 1) of canvas_merge_at (S:326): np.clip = min(max(v, 0), 1), NaN stays NaN
+__global__ void k_layer_clip01(double* __restrict__ img, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = img[i];
+    if (v < 0.0) img[i] = 0.0;
+    else if (v > 1.0) img[i] = 1.0;
+}
+
 // Layer.background (S:166-169): the image OVER a constant colour, canvas_compose(OVER, colour, image) = image + colour * (1 - a)
 __global__ void k_layer_background(double* __restrict__ img, size_t n_px, double c0, double c1, double c2, double c3) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2652,6 +2661,14 @@ int svgr_layer_scale(svgr_ctx* ctx, svgr_buf* img, int64_t n, double f) {
     if (!ctx || !img || n < 0 || img->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_scale: bad arguments");
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_layer_scale, grid1((size_t)n), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n, f);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_layer_clip01(svgr_ctx* ctx, svgr_buf* img, int64_t n) {
+    if (!ctx || !img || n < 0 || img->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_clip01: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_layer_clip01, grid1((size_t)n), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n);
     HIPCHK(hipGetLastError());
     return 0;
 }

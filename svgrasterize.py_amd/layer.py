@@ -323,6 +323,18 @@ class Layer:
         offset = (max(l.x for l in conv), max(l.y for l in conv))
         return Layer._from_device(out, shape, offset, True, linear_rgb)
 
+    def on_canvas(self, rows: int, cols: int) -> "Layer":
+        """This layer merged onto a transparent (rows, cols) canvas at the origin and clipped to [0, 1]: the
+        ``canvas_merge_at`` step in front of the PNG writer (S:304-327, S:3866-3870).  Stays on the device."""
+        ctx = _abi.Context.get()
+        layer = self.convert(pre_alpha=True)
+        canvas = ctx.alloc(rows * cols * 32)
+        canvas.zero()
+        _abi._check(ctx.lib.svgr_layer_over(ctx.handle, canvas.handle, _bbox_arr((0, 0), (rows, cols)), layer._device().handle,
+                                            _bbox_arr(layer.offset, layer._shape), layer.channels, 0))
+        _abi._check(ctx.lib.svgr_layer_clip01(ctx.handle, canvas.handle, rows * cols * 4))
+        return Layer._from_device(canvas, (rows, cols, 4), (0, 0), True, layer.linear_rgb)
+
     def to_canvas_f32(self, rows: int, cols: int, clip01: bool = True) -> np.ndarray:
         """Place this layer on a zero (rows, cols, 4) canvas (canvas_merge_at, S:304-327) and
         return float32 premultiplied RGBA."""

@@ -793,3 +793,44 @@ def svg_scene_from_filepath(path: str, fg=None, width=None, fonts=None):
             return svg_scene(f, fg, width, fonts)
     with open(path, encoding="utf-8") as f:
         return svg_scene(f, fg, width, fonts)
+
+
+def render_svg(svg, output=None, bg=None, fg=None, width=None, id=None, transform=None, linear_rgb=False, fonts=None,
+               level: int = 9):
+    """Document in, PNG out: the steps of the reference's command line (S:3796-3877) as one library call, every pixel
+    operation on the device.  ``svg`` is a file path or a file object; ``bg`` / ``fg`` are colours as ``parse_color``
+    returns them; ``id`` renders a single element (on its own bounding box); ``transform`` is applied on top of the x/y
+    swap of presentation space.  Returns the PNG bytes (also written to ``output``: a path or a binary file object)
+    or None when there is nothing to draw."""
+    view = Transform().matrix(0, 1, 0, 1, 0, 0)
+    if transform is not None:
+        view = view @ transform
+    if isinstance(svg, (str, os.PathLike)):
+        scene, ids, size = svg_scene_from_filepath(os.fspath(svg), fg=fg, width=width, fonts=fonts)
+    else:
+        scene, ids, size = svg_scene(svg, fg=fg, width=width, fonts=fonts)
+    if scene is not None and id is not None:
+        scene, size = ids.get(id), None
+        if not isinstance(scene, Scene):
+            raise KeyError(f"no object with id: {id}")
+    if scene is None:
+        return None
+    if size is not None:
+        w, h = size
+        result = scene.render(view, viewport=[0, 0, int(h), int(w)], linear_rgb=linear_rgb)
+    else:
+        result = scene.render(view, linear_rgb=linear_rgb)
+    if result is None:
+        return None
+    layer, _hull = result
+    if size is not None:
+        layer = layer.convert(pre_alpha=True, linear_rgb=linear_rgb).on_canvas(int(h), int(w))
+    if bg is not None:
+        layer = layer.background(bg)
+    png = layer.write_png(None, level).getvalue()
+    if isinstance(output, (str, os.PathLike)):
+        with open(output, "wb") as f:
+            f.write(png)
+    elif output is not None:
+        output.write(png)
+    return png

@@ -134,3 +134,68 @@ def test_documents_render_like_the_reference():
         assert_f32_1ulp(layer.to_canvas_f32(h, w), z[f"{idx}_canvas"], what=f"{name} canvas")
         drawn += 1
     assert drawn >= 8
+
+
+def _png_pixels(png: bytes) -> np.ndarray:
+    import struct
+    import zlib
+
+    pos, idat, shape = 8, b"", None
+    while pos < len(png):
+        n, tag = struct.unpack(">I4s", png[pos:pos + 8])
+        data = png[pos + 8: pos + 8 + n]
+        if tag == b"IHDR":
+            w, h = struct.unpack(">II", data[:8])
+            shape = (h, w)
+        elif tag == b"IDAT":
+            idat += data
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(shape[0], shape[1] * 4 + 1)
+    assert not raw[:, 0].any()  # filter type 0 on every scanline, like the reference's writer
+    return raw[:, 1:].reshape(shape[0], shape[1], 4)
+
+
+@pytest.mark.gpu
+def test_render_svg_writes_the_reference_png():
+    """Document text -> PNG in one call, against the file the reference's command line writes.  Same size, same chunks;
+    a channel may differ by one level only where the value in front of ``round(x * 255)`` sits on a rounding tie
+    (0.5 * 255 = 127.5: coverage 1 - 1e-16 vs 1 decides it, and double sums in another order differ by that much);
+    documents without such ties are byte-identical."""
+    import io
+
+    import svgrasterize_amd as S
+    from svgrasterize_amd import svg
+
+    S.Context.get()
+    z = np.load(os.path.join(GOLD, "svg_kat.npz"))
+    meta = json.loads(str(z["meta"]))
+    bg = svg.parse_color("#fdf6e3")
+    checked, identical = 0, 0
+    for idx, ((name, text, width), m) in enumerate(zip(svg_cases.CASES, meta)):
+        if not m.get("canvas"):
+            continue
+        h, w = m["canvas"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            scene, _ids, _size = svg.svg_scene_from_str(text, width=width)
+            layer, _hull = scene.render(S.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=False)
+            page = layer.convert(pre_alpha=True, linear_rgb=False).on_canvas(h, w)
+            for key, colour in (("png", None), ("png_bg", bg)):
+                png = svg.render_svg(io.StringIO(text), width=width, bg=colour)
+                want = z[f"{idx}_{key}"].tobytes()
+                if png == want:
+                    identical += 1
+                    continue
+                got_px, want_px = _png_pixels(png), _png_pixels(want)
+                assert got_px.shape == want_px.shape == (h, w, 4), name
+                final = page if colour is None else page.background(colour)
+                levels = final.convert(pre_alpha=False, linear_rgb=False).image * 255.0
+                differs = got_px != want_px
+                assert np.abs(got_px.astype(int) - want_px.astype(int)).max() <= 1, name
+                assert (np.abs(levels[differs] - np.floor(levels[differs]) - 0.5) < 1e-6).all(), f"{name}: not a rounding tie"
+                assert differs.any(axis=-1).mean() < 0.05, name
+        checked += 1
+    assert checked >= 8 and identical >= 6
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert svg.render_svg(io.StringIO(svg_cases.CASES[-1][1])) is None  # the empty document
