@@ -66,82 +66,100 @@ def _arc_center(p0, p1, rx, ry, rot_deg, large, sweep):
 
 
 def parse_path_data(d: str):
+    """Path data -> list of subpaths of ``(kind, points)`` segment tuples (S:1253-1433).
+
+    Plain floats and lists throughout (a numpy array per point made this the slowest part of loading a document);
+    every coordinate is produced by the same single addition / ``2 * p - c`` reflection the reference performs."""
     toks = _TOK.findall(d)
+    n_toks = len(toks)
     subpaths, cur = [], []
-    pos = np.zeros(2)
-    start = np.zeros(2)
-    prev_cmd, prev_ctrl = None, None
-    i = 0
-
-    def close(kind):
-        # a moveto / end of data ends a subpath only if it drew something; ``z`` always leaves one behind, so that
-        # ``M x,y z`` is a subpath of a single zero-length closing segment (S:1299-1303, S:1397-1404)
-        nonlocal cur
-        if cur or kind == g.PATH_CLOSED:
-            cur.append((kind, np.array([pos.copy(), start.copy()])))
-            subpaths.append(cur)
-        cur = []
-
-    cmd = None
-    while i < len(toks):
-        if toks[i][0]:
-            cmd = toks[i][0]
+    px = py = sx = sy = 0.0          # current point, start of the subpath
+    cx = cy = 0.0                    # last control point, for S / T
+    prev = None                      # previous command letter (upper case)
+    line, quad, cubic, arc_kind = g.PATH_LINE, g.PATH_QUAD, g.PATH_CUBIC, g.PATH_ARC
+    i, cmd = 0, None
+    while i < n_toks:
+        letter = toks[i][0]
+        if letter:
+            cmd = letter
             i += 1
             if cmd in "Zz":
-                close(g.PATH_CLOSED)
-                pos = start.copy()
-                prev_cmd = "Z"
+                # ``z`` always leaves a subpath behind, so that ``M x,y z`` is a single zero-length closing segment
+                # (S:1397-1404); a moveto / the end of data ends a subpath only if it drew something (S:1299-1303)
+                cur.append((g.PATH_CLOSED, [[px, py], [sx, sy]]))
+                subpaths.append(cur)
+                cur = []
+                px, py = sx, sy
+                prev = "Z"
                 continue
         if cmd is None:
             raise ValueError("path data must start with a command")
-        n = _ARGC[cmd.upper()]
-        args = [float(toks[i + k][1]) for k in range(n)]
-        i += n
-        rel = cmd.islower()
         C = cmd.upper()
-        base = pos if rel else np.zeros(2)
+        n = _ARGC[C]
+        if i + n > n_toks:
+            raise ValueError(f"command '{cmd}' is missing arguments")
+        a = [float(toks[i + k][1]) for k in range(n)]
+        i += n
+        if cmd.islower():
+            bx, by = px, py
+        else:
+            bx = by = 0.0
         if C == "M":
-            close(g.PATH_UNCLOSED)
-            pos = base + args
-            start = pos.copy()
-            cmd = "l" if rel else "L"
-        elif C in "LHV":
-            if C == "L":
-                new = base + args
-            elif C == "H":
-                new = np.array([(pos[0] if rel else 0) + args[0], pos[1]])
-            else:
-                new = np.array([pos[0], (pos[1] if rel else 0) + args[0]])
-            cur.append((g.PATH_LINE, np.array([pos.copy(), new])))
-            pos = new
-        elif C in "CS":
+            if cur:
+                cur.append((g.PATH_UNCLOSED, [[px, py], [sx, sy]]))
+                subpaths.append(cur)
+                cur = []
+            px, py = bx + a[0], by + a[1]
+            sx, sy = px, py
+            cmd = "l" if cmd == "m" else "L"  # further pairs are linetos
+        elif C == "L":
+            nx, ny = bx + a[0], by + a[1]
+            cur.append((line, [[px, py], [nx, ny]]))
+            px, py = nx, ny
+        elif C == "H":
+            nx = bx + a[0]
+            cur.append((line, [[px, py], [nx, py]]))
+            px = nx
+        elif C == "V":
+            ny = by + a[0]
+            cur.append((line, [[px, py], [px, ny]]))
+            py = ny
+        elif C == "C" or C == "S":
             if C == "C":
-                c0, c1, p = base + args[0:2], base + args[2:4], base + args[4:6]
+                c0x, c0y = bx + a[0], by + a[1]
+                a = a[2:]
+            elif prev == "C" or prev == "S":
+                c0x, c0y = px * 2 - cx, py * 2 - cy
             else:
-                c0 = 2 * pos - prev_ctrl if prev_cmd in ("C", "S") else pos.copy()
-                c1, p = base + args[0:2], base + args[2:4]
-            cur.append((g.PATH_CUBIC, np.array([pos.copy(), c0, c1, p])))
-            prev_ctrl, pos = c1, p
-        elif C in "QT":
+                c0x, c0y = px, py
+            cx, cy = bx + a[0], by + a[1]
+            nx, ny = bx + a[2], by + a[3]
+            cur.append((cubic, [[px, py], [c0x, c0y], [cx, cy], [nx, ny]]))
+            px, py = nx, ny
+        elif C == "Q" or C == "T":
             if C == "Q":
-                c0, p = base + args[0:2], base + args[2:4]
+                c0x, c0y = bx + a[0], by + a[1]
+                a = a[2:]
+            elif prev == "Q" or prev == "T":
+                c0x, c0y = px * 2 - cx, py * 2 - cy
             else:
-                c0 = 2 * pos - prev_ctrl if prev_cmd in ("Q", "T") else pos.copy()
-                p = base + args[0:2]
-            cur.append((g.PATH_QUAD, np.array([pos.copy(), c0, p])))
-            prev_ctrl, pos = c0, p
-        elif C == "A":
-            p = base + args[5:7]
-            arc = _arc_center(pos, p, args[0], args[1], args[2], bool(args[3]), bool(args[4]))
-            if args[0] == 0 or args[1] == 0:
+                c0x, c0y = px, py
+            cx, cy = c0x, c0y
+            nx, ny = bx + a[0], by + a[1]
+            cur.append((quad, [[px, py], [c0x, c0y], [nx, ny]]))
+            px, py = nx, ny
+        else:  # A
+            nx, ny = bx + a[5], by + a[6]
+            if a[0] == 0 or a[1] == 0:
                 # zero radius: the reference records a zero-length line at the end point and leaves the gap to the
                 # subpath's closing segment (S:1376-1379); kept, so that such documents rasterise the same
-                cur.append((g.PATH_LINE, np.array([p.copy(), p.copy()])))
-            elif arc is None:
-                cur.append((g.PATH_LINE, np.array([pos.copy(), p])))
+                cur.append((line, [[nx, ny], [nx, ny]]))
             else:
-                cur.append((g.PATH_ARC, arc))
-            pos = p
-        prev_cmd = C
-    close(g.PATH_UNCLOSED)
+                arc = _arc_center((px, py), (nx, ny), a[0], a[1], a[2], a[3] > 0.001, a[4] > 0.001)
+                cur.append((line, [[px, py], [nx, ny]]) if arc is None else (arc_kind, arc))
+            px, py = nx, ny
+        prev = C
+    if cur:
+        cur.append((g.PATH_UNCLOSED, [[px, py], [sx, sy]]))
+        subpaths.append(cur)
     return subpaths
