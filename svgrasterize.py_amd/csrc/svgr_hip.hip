@@ -1705,20 +1705,20 @@ __device__ __forceinline__ double grad_focal_det(const GradDev& g, double x, dou
 }
 
 // does any pixel of the layer have det < 0 ?  (the reference only builds its exclusion mask then, S:1627)
-__global__ void k_gradient_detneg(const GradDev* __restrict__ gp, int r0, int c0, int rows, int cols, int* __restrict__ flag) {
+__global__ void k_gradient_detneg(const GradDev g, int r0, int c0, int rows, int cols, int* __restrict__ flag) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)rows * cols) return;
-    const GradDev& g = *gp;
     double x, y, b;
     grad_point(g, r0, c0, (int)(idx / cols), (int)(idx % cols), x, y);
     if (grad_focal_det(g, x, y, b) < 0.0) atomicOr(flag, 1);
 }
 
-__global__ void k_gradient_fill(const GradDev* __restrict__ gp, const double* __restrict__ mask, int r0, int c0, int rows,
+// The parameter block travels as a kernel argument (1.6 KB of kernarg, read with scalar loads): no device copy of it, and
+// for linear / plain radial gradients nothing the host would have to wait for.
+__global__ void k_gradient_fill(const GradDev g, const double* __restrict__ mask, int r0, int c0, int rows,
                                 int cols, const int* __restrict__ detneg_flag, double* __restrict__ out) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)rows * cols) return;
-    const GradDev& g = *gp;
     double x, y;
     grad_point(g, r0, c0, (int)(idx / cols), (int)(idx % cols), x, y);
     double offset;
@@ -2730,23 +2730,27 @@ int svgr_gradient_fill(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* ma
         for (int k = 0; k < 4; ++k) h.stop_rgba[i][k] = g->stop_rgba[4 * i + k];
     }
     HIPCHK(hipSetDevice(ctx->device));
-    // parameter block + det<0 flag live in one small device allocation for the duration of the call
-    char* dev = nullptr;
-    HIPCHK(g_pool.alloc((void**)&dev, sizeof(GradDev) + 16));
-    hipError_t e = hipMemcpyAsync(dev, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(dev + sizeof(GradDev), 0, 16, ctx->stream);
-    if (e == hipSuccess) {
-        const GradDev* gd = (const GradDev*)dev;
-        int* flag = (int*)(dev + sizeof(GradDev));
-        if (g->kind == 3)
-            hipLaunchKernelGGL(k_gradient_detneg, grid1(n), dim3(256), 0, ctx->stream, gd, (int)bbox[0], (int)bbox[1], (int)bbox[2],
+    hipError_t e = hipSuccess;
+    if (g->kind == 3) {
+        // the two-circle gradient needs a device flag (any det < 0 ?) between its two kernels: a pool word, held until
+        // the stream has drained
+        int* flag = nullptr;
+        HIPCHK(g_pool.alloc((void**)&flag, 16));
+        e = hipMemsetAsync(flag, 0, 16, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_gradient_detneg, grid1(n), dim3(256), 0, ctx->stream, h, (int)bbox[0], (int)bbox[1], (int)bbox[2],
                                (int)bbox[3], flag);
-        hipLaunchKernelGGL(k_gradient_fill, grid1(n), dim3(256), 0, ctx->stream, gd, (const double*)mask->ptr, (int)bbox[0],
-                           (int)bbox[1], (int)bbox[2], (int)bbox[3], (const int*)flag, (double*)out->ptr);
-        e = hipStreamSynchronize(ctx->stream);  // `h` and `dev` are call-local
-        if (e == hipSuccess) e = hipGetLastError();
+            hipLaunchKernelGGL(k_gradient_fill, grid1(n), dim3(256), 0, ctx->stream, h, (const double*)mask->ptr, (int)bbox[0],
+                               (int)bbox[1], (int)bbox[2], (int)bbox[3], (const int*)flag, (double*)out->ptr);
+            e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = hipGetLastError();
+        }
+        g_pool.release(flag);
+    } else {
+        hipLaunchKernelGGL(k_gradient_fill, grid1(n), dim3(256), 0, ctx->stream, h, (const double*)mask->ptr, (int)bbox[0],
+                           (int)bbox[1], (int)bbox[2], (int)bbox[3], (const int*)nullptr, (double*)out->ptr);
+        e = hipGetLastError();
     }
-    g_pool.release(dev);
     if (e != hipSuccess) return fail(SVGR_E_HIP, "svgr_gradient_fill: %s", hipGetErrorString(e));
     return 0;
 }

@@ -16,11 +16,22 @@ from . import _abi
 _SPREAD = {"pad": 0, "repeat": 1, "reflect": 2}
 
 
+_STOPS_MEMO: dict = {}  # (id(stops), linear_rgb) -> (stops, converted): a gradient is usually filled many times
+
+
 def _stops_colorspace(stops, linear_rgb: bool):
     """grad_stops_colorspace, S:1686-1695: premultiplied linear RGBA stops -> target colour space."""
     from .geometry import solid_paint
 
-    return [(float(o), solid_paint(np.asarray(c, dtype=np.float64), linear_rgb)) for o, c in stops]
+    key = (id(stops), bool(linear_rgb))
+    hit = _STOPS_MEMO.get(key)
+    if hit is not None and hit[0] is stops:
+        return hit[1]
+    out = [(float(o), solid_paint(np.asarray(c, dtype=np.float64), linear_rgb)) for o, c in stops]
+    if len(_STOPS_MEMO) > 4096:
+        _STOPS_MEMO.clear()
+    _STOPS_MEMO[key] = (stops, out)
+    return out
 
 
 class _GradMixin:

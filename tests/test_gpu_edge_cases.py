@@ -48,7 +48,7 @@ def test_invalid_inputs_raise_value_error(S):
     with pytest.raises(ValueError):
         S.Path([[(9, np.zeros((2, 2)))]]).mask(S.Transform())            # S:945 unsupported path type
     bad = S.Path.from_svg("M1,1 H9 V9 H1 Z")
-    bad.subpaths[0][0][1][0, 0] = np.nan
+    bad.subpaths[0][0][1][0][0] = np.nan
     with pytest.raises(ValueError):
         bad.mask(S.Transform())                                          # the reference would never terminate
     with pytest.raises(ValueError):
