@@ -1003,7 +1003,7 @@ struct TileArgs {
 // CLIP: the batch contains SVGR_PATH_CLIP_SOURCE / SVGR_PATH_CLIPPED paths (one more LDS tile: its own instantiation,
 // so that batches without clips keep their occupancy)
 template <int OUT, bool CLIP = false>
-__global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const TileArgs a) {
+__global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_EU) void k_tile_render(const TileArgs a) {
     // ONE __shared__ object, carved by hand: with a second object beside the LDS-DMA staging area
     // hipcc (ROCm 7.2) drains vmcnt(0) before every ds_read and the record prefetch stops overlapping
     constexpr int OFF_TRACE = 0;
@@ -1022,7 +1022,6 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
     int* const s_seg0 = (int*)(s_mem + OFF_SEG0);
     int* const s_seg1 = (int*)(s_mem + OFF_SEG1);
     int* const s_wcnt = (int*)(s_mem + OFF_WCNT);
-    double* const s_clip = (double*)(s_mem + OFF_CLIP);
     int clip_tag = -1;  // path whose coverage s_clip holds (canvas modes)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1124,7 +1123,7 @@ __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) void k_tile_render(const Til
                     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                                  :
                                  : "v"(g), "s"(lds_base)
-                                 : "memory", "m0");
+                                 : "memory");  // (m0 is reserved: hipcc never keeps a value in it across statements)
                 }
             }
         };
