@@ -238,6 +238,10 @@ typedef struct {
     const double* stop_rgba;                        /* n_stops x 4 premultiplied colours                      */
 } svgr_gradient;
 int svgr_gradient_fill(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* mask, const int64_t* bbox, svgr_buf* out_rgba);
+/* GradLinear.fill / GradRadial.fill (S:1553-1563, S:1577-1651): the gradient at n_points caller-supplied coordinates
+ * (x, y doubles interleaved; user space, i.e. what Path.fill passes after its own user transform: set user_m6 to the
+ * identity), no mask; out_rgba receives n_points x 4 doubles.                                                     */
+int svgr_gradient_eval(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* points, int64_t n_points, svgr_buf* out_rgba);
 
 /* Path.fill, pattern branch (S:1049-1094): out_rgba = pattern tile looked up per pixel * mask.  `tile` is the
  * (rows, cols, 4) double image of the pattern's scene rendered once by the caller (Scene.render under the fill's

@@ -420,6 +420,11 @@ def gen_gradient(ref) -> None:
                 out[f"{idx}_fcenter"] = np.asarray(paint.fcenter, float)
                 out[f"{idx}_fradius"] = np.array(float(paint.fradius))
         out[f"{idx}_image"] = layer.image
+        # Grad*.fill on explicit coordinates (S:1553, S:1577): user-space points around the shape, both colour spaces
+        pts = np.random.default_rng(1000 + idx).uniform(-0.2, 1.2, (9, 7, 2)) * ([1.0, 1.0] if paint.bbox_units else [70.0, 50.0])
+        out[f"{idx}_eval_pts"] = pts
+        out[f"{idx}_eval_lin"] = paint.fill(pts, linear_rgb=True)
+        out[f"{idx}_eval_srgb"] = paint.fill(pts, linear_rgb=False)
         meta.append(m)
 
     # blur kernels + convolutions

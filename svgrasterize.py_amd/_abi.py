@@ -110,6 +110,7 @@ _PROTOS = {
     "svgr_layer_morphology": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int]),
     "svgr_layer_luminance": (C.c_int, [_P, _P, _P, C.c_int64]),
     "svgr_gradient_fill": (C.c_int, [_P, C.POINTER(Gradient), _P, _P, _P]),
+    "svgr_gradient_eval": (C.c_int, [_P, C.POINTER(Gradient), _P, C.c_int64, _P]),
     "svgr_pattern_fill": (C.c_int, [_P, C.POINTER(PatternArgs), _P, _P, _P, _P]),
     "svgr_layer_convolve": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64]),
     "svgr_path_stroke": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, C.c_int, C.c_int, C.POINTER(_P)]),

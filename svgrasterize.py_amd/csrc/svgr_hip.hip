@@ -1684,8 +1684,16 @@ struct GradDev {
 
 // position of pixel (i, j) of the layer in gradient space: grad_pixels (S:1653-1658), user transform
 // (S:1023-1027) and the gradient's own transform (S:1559 / S:1603), both in numpy's fma form
-__device__ __forceinline__ void grad_point(const GradDev& g, int r0, int c0, int i, int j, double& x, double& y) {
-    double px = (double)i + ((double)r0 + 0.5), py = (double)j + ((double)c0 + 0.5);
+__device__ __forceinline__ void grad_point(const GradDev& g, const double* __restrict__ pts, size_t idx, int r0, int c0, int cols,
+                                           double& x, double& y) {
+    double px, py;
+    if (pts) {  // Grad*.fill on a caller's coordinate array (S:1553, S:1577): the points as given
+        px = pts[2 * idx];
+        py = pts[2 * idx + 1];
+    } else {
+        px = (double)(int)(idx / cols) + ((double)r0 + 0.5);
+        py = (double)(int)(idx % cols) + ((double)c0 + 0.5);
+    }
     xform_point(g.user_m6, px, py, x, y);
     if (g.has_gt) {
         double tx, ty;
@@ -1704,22 +1712,23 @@ __device__ __forceinline__ double grad_focal_det(const GradDev& g, double x, dou
 }
 
 // does any pixel of the layer have det < 0 ?  (the reference only builds its exclusion mask then, S:1627)
-__global__ void k_gradient_detneg(const GradDev g, int r0, int c0, int rows, int cols, int* __restrict__ flag) {
+__global__ void k_gradient_detneg(const GradDev g, const double* __restrict__ pts, int r0, int c0, int rows, int cols,
+                                  int* __restrict__ flag) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)rows * cols) return;
     double x, y, b;
-    grad_point(g, r0, c0, (int)(idx / cols), (int)(idx % cols), x, y);
+    grad_point(g, pts, idx, r0, c0, cols, x, y);
     if (grad_focal_det(g, x, y, b) < 0.0) atomicOr(flag, 1);
 }
 
 // The parameter block travels as a kernel argument (1.6 KB of kernarg, read with scalar loads): no device copy of it, and
 // for linear / plain radial gradients nothing the host would have to wait for.
-__global__ void k_gradient_fill(const GradDev g, const double* __restrict__ mask, int r0, int c0, int rows,
-                                int cols, const int* __restrict__ detneg_flag, double* __restrict__ out) {
+__global__ void k_gradient_fill(const GradDev g, const double* __restrict__ pts, const double* __restrict__ mask, int r0, int c0,
+                                int rows, int cols, const int* __restrict__ detneg_flag, double* __restrict__ out) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)rows * cols) return;
     double x, y;
-    grad_point(g, r0, c0, (int)(idx / cols), (int)(idx % cols), x, y);
+    grad_point(g, pts, idx, r0, c0, cols, x, y);
     double offset;
     bool masked = false;  // overlay[~mask] = 0 (S:1648)
     if (g.kind == 1) {  // linear, S:1561-1562: ((p - p0) @ vec) / (vec . vec), `@` with a 1-D rhs = fma(d0, v0, d1*v1)
@@ -1765,7 +1774,7 @@ __global__ void k_gradient_fill(const GradDev g, const double* __restrict__ mask
         }
     }
     if (masked) col[0] = col[1] = col[2] = col[3] = 0.0;
-    const double m = mask[idx];  // canvas_compose(COMPOSE_IN, mask, image) = image * mask (S:1046, S:290)
+    const double m = mask ? mask[idx] : 1.0;  // canvas_compose(COMPOSE_IN, mask, image) = image * mask (S:1046, S:290)
     double* o = out + 4 * idx;
     o[0] = col[0] * m; o[1] = col[1] * m; o[2] = col[2] * m; o[3] = col[3] * m;
 }
@@ -2706,14 +2715,16 @@ int svgr_layer_to_rgba8(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64
     return 0;
 }
 
-int svgr_gradient_fill(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* mask, const int64_t* bbox, svgr_buf* out) {
-    if (!ctx || !g || !mask || !out || !bbox_ok(bbox)) return fail(SVGR_E_INVALID, "svgr_gradient_fill: bad arguments");
+// the gradient over the pixel grid of `bbox` times `mask` (pts == nullptr), or at the n = bbox[2] * bbox[3] points of `pts`
+static int gradient_run(svgr_ctx* ctx, const svgr_gradient* g, const double* pts, const svgr_buf* mask, const int64_t* bbox,
+                        svgr_buf* out) {
     if (g->kind < 1 || g->kind > 3 || g->spread < 0 || g->spread > 2) return fail(SVGR_E_INVALID, "invalid gradient kind / spread method");
     if (g->n_stops < 1 || g->n_stops > GRAD_MAX_STOPS || !g->stop_off || !g->stop_rgba)
         return fail(SVGR_E_INVALID, "gradient needs 1..%d stops", GRAD_MAX_STOPS);
     const size_t n = (size_t)bbox[2] * bbox[3];
-    if (mask->bytes < n * 8 || out->bytes < n * 32) return fail(SVGR_E_INVALID, "svgr_gradient_fill: buffer too small");
+    if ((mask && mask->bytes < n * 8) || out->bytes < n * 32) return fail(SVGR_E_INVALID, "svgr_gradient_fill: buffer too small");
     if (n == 0) return 0;
+    const double* mptr = mask ? (const double*)mask->ptr : nullptr;
     GradDev h;
     memset(&h, 0, sizeof h);
     h.kind = g->kind; h.spread = g->spread; h.has_gt = g->has_gt; h.n_stops = g->n_stops; h.excl_enabled = g->excl_enabled;
@@ -2737,21 +2748,33 @@ int svgr_gradient_fill(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* ma
         HIPCHK(g_pool.alloc((void**)&flag, 16));
         e = hipMemsetAsync(flag, 0, 16, ctx->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_gradient_detneg, grid1(n), dim3(256), 0, ctx->stream, h, (int)bbox[0], (int)bbox[1], (int)bbox[2],
-                               (int)bbox[3], flag);
-            hipLaunchKernelGGL(k_gradient_fill, grid1(n), dim3(256), 0, ctx->stream, h, (const double*)mask->ptr, (int)bbox[0],
-                               (int)bbox[1], (int)bbox[2], (int)bbox[3], (const int*)flag, (double*)out->ptr);
+            hipLaunchKernelGGL(k_gradient_detneg, grid1(n), dim3(256), 0, ctx->stream, h, pts, (int)bbox[0], (int)bbox[1],
+                               (int)bbox[2], (int)bbox[3], flag);
+            hipLaunchKernelGGL(k_gradient_fill, grid1(n), dim3(256), 0, ctx->stream, h, pts, mptr, (int)bbox[0], (int)bbox[1],
+                               (int)bbox[2], (int)bbox[3], (const int*)flag, (double*)out->ptr);
             e = hipStreamSynchronize(ctx->stream);
             if (e == hipSuccess) e = hipGetLastError();
         }
         g_pool.release(flag);
     } else {
-        hipLaunchKernelGGL(k_gradient_fill, grid1(n), dim3(256), 0, ctx->stream, h, (const double*)mask->ptr, (int)bbox[0],
-                           (int)bbox[1], (int)bbox[2], (int)bbox[3], (const int*)nullptr, (double*)out->ptr);
+        hipLaunchKernelGGL(k_gradient_fill, grid1(n), dim3(256), 0, ctx->stream, h, pts, mptr, (int)bbox[0], (int)bbox[1],
+                           (int)bbox[2], (int)bbox[3], (const int*)nullptr, (double*)out->ptr);
         e = hipGetLastError();
     }
     if (e != hipSuccess) return fail(SVGR_E_HIP, "svgr_gradient_fill: %s", hipGetErrorString(e));
     return 0;
+}
+
+int svgr_gradient_fill(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* mask, const int64_t* bbox, svgr_buf* out) {
+    if (!ctx || !g || !mask || !out || !bbox_ok(bbox)) return fail(SVGR_E_INVALID, "svgr_gradient_fill: bad arguments");
+    return gradient_run(ctx, g, nullptr, mask, bbox, out);
+}
+
+int svgr_gradient_eval(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* points, int64_t n_points, svgr_buf* out) {
+    if (!ctx || !g || !points || !out || n_points < 0 || n_points > ((int64_t)1 << 31) - 1 || points->bytes < (size_t)n_points * 16)
+        return fail(SVGR_E_INVALID, "svgr_gradient_eval: bad arguments");
+    const int64_t as_row[4] = {0, 0, 1, n_points};
+    return gradient_run(ctx, g, (const double*)points->ptr, nullptr, as_row, out);
 }
 
 int svgr_pattern_fill(svgr_ctx* ctx, const svgr_pattern* pt, const svgr_buf* tile, const svgr_buf* mask, const int64_t* bbox,

@@ -54,6 +54,28 @@ class _GradMixin:
         return off, col  # keep alive until the call returns
 
 
+    def fill(self, pixels, linear_rgb: bool = True) -> np.ndarray:
+        """The gradient's colour at each coordinate of ``pixels`` (..., 2), user space: an array (..., 4) of premultiplied
+        RGBA in the requested colour space (GradLinear.fill S:1553-1563, GradRadial.fill S:1577-1651).  Evaluated by the
+        same device code ``Path.fill`` uses on the pixel grid, here on the caller's points."""
+        from .geometry import Transform
+
+        pts = np.ascontiguousarray(pixels, dtype=np.float64)
+        if pts.shape[-1:] != (2,):
+            raise ValueError("pixels must be an array of (x, y) coordinates")
+        n = pts.size // 2
+        if n == 0:
+            return np.zeros(pts.shape[:-1] + (4,))
+        g, keep = self.abi(Transform(), linear_rgb)
+        ctx = _abi.Context.get()
+        src = ctx.alloc(n * 16)
+        src.upload(pts)
+        out = ctx.alloc(n * 32)
+        _abi._check(ctx.lib.svgr_gradient_eval(ctx.handle, C.byref(g), src.handle, n, out.handle))
+        del keep
+        return out.download(pts.shape[:-1] + (4,), np.float64)
+
+
 class GradLinear(_GradMixin, NamedTuple("GradLinear", [("p0", object), ("p1", object), ("stops", list), ("transform", object),
                                                         ("spread", str), ("bbox_units", bool), ("linear_rgb", object)])):
     def abi(self, user_tr, linear_rgb: bool):

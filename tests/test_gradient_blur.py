@@ -83,6 +83,11 @@ def test_gpu_gradient_fills():
         assert layer.linear_rgb == c["layer_linear_rgb"] and layer.pre_alpha
         assert_close64(layer.image, g[f"{idx}_image"], atol=1e-11, what=f"gradient {idx} ({c['kind']}, {c['spread']})")
         assert_f32_1ulp(layer.image.astype(np.float32), g[f"{idx}_image"], what=f"gradient {idx}")
+        # Grad*.fill on the caller's own coordinates (S:1553 / S:1577), both colour spaces
+        pts = g[f"{idx}_eval_pts"]
+        assert_close64(paint.fill(pts, linear_rgb=True), g[f"{idx}_eval_lin"], atol=1e-13, what=f"gradient {idx} eval linear")
+        assert_close64(paint.fill(pts, linear_rgb=False), g[f"{idx}_eval_srgb"], atol=1e-13, what=f"gradient {idx} eval sRGB")
+    assert paint.fill(np.zeros((0, 2))).shape == (0, 4)
 
 
 @pytest.mark.gpu
