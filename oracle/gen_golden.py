@@ -881,6 +881,16 @@ def gen_svg(ref, fonts) -> None:
                     out[f"{idx}_png"] = np.frombuffer(page.write_png().getvalue(), dtype=np.uint8)
                     out[f"{idx}_png_bg"] = np.frombuffer(page.background(ref.svg_color("#fdf6e3")).write_png().getvalue(),
                                                          dtype=np.uint8)
+        if name == "nested_svg_use":
+            # the command line's -id / -t / -fg options (S:3836-3850): one element on its own bounding box, scaled, with a
+            # default foreground for shapes without a fill
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                _scene, ids, _size = ref.svg_scene_from_str(text.replace(' fill="green"', ""), width=width, fonts=ref.FontsDB(),
+                                                            fg=ref.svg_color("#b5651d"))
+                tr = ref.Transform().matrix(0, 1, 0, 1, 0, 0) @ ref.svg_transform("scale(3) rotate(10)")
+                layer, _hull = ids["leaf"].render(tr, linear_rgb=False)
+            out["by_id_png"] = np.frombuffer(layer.write_png().getvalue(), dtype=np.uint8)
         meta.append(m)
     out["meta"] = np.array(json.dumps(meta))
     save("svg_kat.npz", **out)

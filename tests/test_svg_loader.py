@@ -199,3 +199,17 @@ def test_render_svg_writes_the_reference_png():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert svg.render_svg(io.StringIO(svg_cases.CASES[-1][1])) is None  # the empty document
+    # one element by id, on its own bounding box, with an extra transform and a default foreground colour
+    text = dict((n, t) for n, t, _w in svg_cases.CASES)["nested_svg_use"].replace(' fill="green"', "")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        png = svg.render_svg(io.StringIO(text), width=400, id="leaf", fg=svg.parse_color("#b5651d"),
+                             transform=svg.parse_transform("scale(3) rotate(10)"))
+    want = z["by_id_png"].tobytes()
+    if png != want:
+        got_px, want_px = _png_pixels(png), _png_pixels(want)
+        assert got_px.shape == want_px.shape
+        assert np.abs(got_px.astype(int) - want_px.astype(int)).max() <= 1
+        assert (got_px != want_px).any(axis=-1).mean() < 0.02
+    with pytest.raises(KeyError):
+        svg.render_svg(io.StringIO(text), id="no-such-element")
