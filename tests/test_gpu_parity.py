@@ -183,6 +183,15 @@ def test_tiger_small(S, tag):
     assert (bb[empty, 2] <= 0).all() or (bb[empty, 3] <= 0).all()
 
 
+def test_prompt_text_outlines(S):
+    """demo/prompt.svg at width 256: glyph outlines set by the reference's fonts, a 9 x 256 strip."""
+    scene, z, r, tr, hh, ww = _render_dump(S, "prompt", "s9")
+    layer, _ = scene.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
+    assert [int(v) for v in layer.offset] == r["layer_offset"]
+    assert_close64(layer.image, z["s9_layer"], atol=1e-10, what="prompt group layer")
+    assert_f32_1ulp(layer.to_canvas_f32(hh, ww), z["s9_canvas"], what="prompt canvas")
+
+
 def test_material_small_clips(S):
     """material-design: 935 clip paths -> per-node route (CLIP = mask IN image) + batched runs."""
     scene, z, r, tr, hh, ww = _render_dump(S, "material", "s256")

@@ -42,7 +42,7 @@ def test_handwritten_documents_match_reference_loader():
 
 
 @pytest.mark.parametrize("name,svg_file,width", [("tiger", "icons/tiger.svg", 2048), ("material", "material-design.svg", 4096),
-                                                  ("icons", "icons.svg", None)])
+                                                  ("icons", "icons.svg", None), ("prompt", "prompt.svg", 256)])
 def test_demo_documents_match_reference_dumps(name, svg_file, width):
     path = os.path.join(DEMO, svg_file)
     if not os.path.exists(path):
@@ -53,7 +53,9 @@ def test_demo_documents_match_reference_dumps(name, svg_file, width):
     info = json.loads(str(z["info"]))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        scene, _ids, size = svg.svg_scene_from_filepath(path, width=width)
+        fonts = svg.FontsDB()
+        fonts.register_file(os.path.join(os.path.dirname(DEMO), "fonts.svgz"))  # prompt.svg is all text
+        scene, _ids, size = svg.svg_scene_from_filepath(path, width=width, fonts=fonts)
     w, h = size
     assert [int(h), int(w)] == info["size"]
     arrays = {k: z[k] for k in ("lines", "cubics", "line_off", "cubic_off")}
