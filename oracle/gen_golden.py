@@ -903,6 +903,11 @@ HOSTUTIL_PATHS = [
     "M10,30 a10,6 30 1 0 20,5 z m 5,5 l 1e-3,2 z",
     "M0,0 h10 A5,5 0 0 1 20,10 L0,10 z M3,3 v4 h4 z M50,50 z",
     "M1234.5678,0.000123 L-1e6,1e-7 C1,2 3,4 5.55555555,6 Q1,1 2,2",
+    "M.5.5L-1-1 1e1,2E+1 3.e0,4\n\tl+1,-.25e1z",
+    "m1,1 2,2 3,3 m1,1 1,0z l5,5 t1,1 s2,2 3,3",
+    "M0,0 A0,5 0 0 1 5,5 L9,9 a3,0 0 1 1 1,1 A2,2 45 1 1 9,9 z",
+    "M5,5 z z M1,1",
+    "",
 ]
 HOSTUTIL_SCENES = ["basic_shapes", "groups_transforms_style", "clip_mask_opacity", "nested_svg_use", "text_svg_font"]
 
