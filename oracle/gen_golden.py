@@ -989,6 +989,12 @@ def main() -> None:
         gen_scene(ref, fonts, "material", "material-design.svg", 4096, [1 / 16], args.full, crop=[1000, 1000, 160, 192])
     if todo("icons"):
         gen_scene(ref, fonts, "icons", "icons.svg", None, [1.0], False, store_layer=False)
+    if todo("iconset"):
+        # the reference's other demo icons at thumbnail size: real-world mixes of gradients, clips, masks, filters, strokes
+        for svg in sorted(os.listdir(os.path.join(DEMO, "icons"))):
+            if svg.endswith(".svg") and svg != "tiger.svg":
+                gen_scene(ref, fonts, "icon_" + os.path.splitext(svg)[0].replace("-", "_"), "icons/" + svg, 192, [1.0], False,
+                          store_layer=False)
     if todo("prompt"):
         gen_scene(ref, fonts, "prompt", "prompt.svg", 256, [1.0], False)
 

@@ -153,3 +153,28 @@ def test_gpu_blur_separable_equals_direct(monkeypatch):
         from scipy.signal import convolve as sconv
         want = sconv(img, kern[..., None], mode="full", method="direct")
         np.testing.assert_allclose(auto.image, want, rtol=0, atol=1e-14)
+
+
+_ICONSET = sorted(os.path.basename(p)[len("scene_"):-len(".npz")] for p in __import__("glob").glob(os.path.join(GOLDEN, "scene_icon_*.npz")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", _ICONSET)
+def test_gpu_demo_icon_thumbnails(name):
+    """The reference's other demo icons (firefox, inkscape, kde, office, python, ...) at 192 px: whatever mix of
+    gradients, clips, filters, opacity groups and strokes real documents bring, against the reference's canvas."""
+    import svgrasterize_amd as S
+    from svgrasterize_amd import scenedump
+
+    scene, info, z = scenedump.load_scene(os.path.join(GOLDEN, f"scene_{name}.npz"))
+    r = info["renders"][0]
+    hh, ww = r["size"]
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0).scale(r["scale"])
+    layer, _ = scene.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
+    assert [int(v) for v in layer.offset] == r["layer_offset"]
+    canvas = layer.to_canvas_f32(hh, ww)
+    ref = z[f"{r['tag']}_canvas"].astype(np.float32)
+    err = np.abs(canvas.astype(np.float64) - ref)
+    tol = np.maximum(np.nextafter(np.abs(ref), np.float32(np.inf)) - np.abs(ref), 2.0 ** -24)
+    bad = err > tol  # (blurs: the reference's FFT carries ~1e-16 of noise, a handful of float32 ties may flip)
+    assert bad.sum() <= 8 and err.max() < 1e-6, (name, int(bad.sum()), float(err.max()))
