@@ -1,6 +1,8 @@
-"""Minimal SVG path-data reader (M L H V C S Q T A Z, absolute and relative) producing the
-reference's segment tuples.  Convenience for tests and examples only: parsing is host-side
-scene preparation and not part of the accelerated path."""
+"""SVG path-data reader (M L H V C S Q T A Z, absolute and relative) producing the reference's segment tuples
+(``Path.from_svg``, S:1253-1433), including its arc parametrisation (S:2397-2448) and its corner cases: ``z`` always
+leaves a subpath, a zero-radius arc is a zero-length line at its end point, a leading relative moveto is absolute.
+Host-side scene preparation used by the SVG front-end (svg.py, fonts.py); pinned against the reference on every path
+of its demo documents (oracle/check_svg_frontend.py) and on hand-written edge cases (tests/test_host_utils.py)."""
 from __future__ import annotations
 
 import math
