@@ -363,10 +363,10 @@ class Layer:
         _abi._check(ctx.lib.svgr_layer_to_rgba8(ctx.handle, out.handle, src.handle, rows * cols))
         return out.download((rows, cols, 4), np.uint8)
 
-    def write_png(self, output=None, level: int = 9):
+    def write_png(self, output=None, level: int = 9, threads: int = 1):
         """PNG of the layer (Layer.write_png, S:209-213): 8-bit RGBA, filter 0, one IDAT -- byte-identical to the
         reference's file at the reference's zlib level 9 (``level`` trades size for speed, the pixels are the same)."""
-        return canvas_to_png(self.to_rgba8(), output, level=level)
+        return canvas_to_png(self.to_rgba8(), output, level=level, threads=threads)
 
     def __repr__(self):
         return "Layer(x={}, y={}, w={}, h={}, pre_alpha={}, linear_rgb={})".format(
@@ -374,9 +374,36 @@ class Layer:
         )
 
 
-def canvas_to_png(canvas, output=None, level: int = 9):
+def _deflate_parallel(raw: bytes, level: int, threads: int) -> bytes:
+    """A zlib stream of ``raw`` built from independently compressed pieces, one per worker thread at a time (the pigz
+    construction: every piece but the last is a raw deflate stream ended with a sync flush, so the concatenation is one
+    valid deflate stream; zlib header in front, Adler-32 of the whole input behind).  zlib releases the GIL, so the
+    pieces really run side by side.  Decodes to the same bytes as the one-shot stream; only the file bytes differ."""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    piece = max(1 << 20, -(-len(raw) // (threads * 4)))
+    spans = [(o, min(o + piece, len(raw))) for o in range(0, len(raw), piece)] or [(0, 0)]
+    view = memoryview(raw)
+
+    def work(k):
+        lo, hi = spans[k]
+        comp = zlib.compressobj(level, zlib.DEFLATED, -15)
+        return comp.compress(view[lo:hi]) + comp.flush(zlib.Z_FINISH if k == len(spans) - 1 else zlib.Z_SYNC_FLUSH)
+
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        parts = list(pool.map(work, range(len(spans))))
+    # CMF/FLG: deflate, 32 KiB window; FLEVEL is informative only (2 bits), FCHECK makes the pair a multiple of 31
+    cmf, flevel = 0x78, (0 if level < 2 else 1 if level < 6 else 2 if level == 6 else 3) << 6
+    flg = flevel + (31 - ((cmf << 8) + flevel) % 31) % 31
+    return bytes([cmf, flg]) + b"".join(parts) + (zlib.adler32(raw) & 0xFFFFFFFF).to_bytes(4, "big")
+
+
+def canvas_to_png(canvas, output=None, level: int = 9, threads: int = 1):
     """(height, width, 4) -> PNG (canvas_to_png, S:249-274).  ``canvas`` is either the uint8 array of
-    ``Layer.to_rgba8`` or float RGBA in [0, 1] (quantised like the reference: ``np.round(canvas * 255)``)."""
+    ``Layer.to_rgba8`` or float RGBA in [0, 1] (quantised like the reference: ``np.round(canvas * 255)``).
+    ``threads`` > 1 compresses the scanlines in parallel pieces: same pixels, a different (slightly larger) file than the
+    reference's, written several times faster (4096 x 4096 at level 9: seconds -> a few tenths)."""
     import io
     import struct
     import zlib
@@ -398,8 +425,11 @@ def canvas_to_png(canvas, output=None, level: int = 9):
     # input is chunked, so one call gives the bytes of the reference's row-by-row loop)
     rows = np.zeros((height, 1 + width * 4), dtype=np.uint8)
     rows[:, 1:] = canvas.reshape(height, width * 4)
-    comp = zlib.compressobj(level=level)
-    data = comp.compress(rows.tobytes()) + comp.flush()
+    if threads > 1:
+        data = _deflate_parallel(rows.tobytes(), level, threads)
+    else:
+        comp = zlib.compressobj(level=level)
+        data = comp.compress(rows.tobytes()) + comp.flush()
     output = io.BytesIO() if output is None else output
     output.write(b"\x89PNG\r\n\x1a\n")
     pack(output, b"IHDR", struct.pack("!2I5B", width, height, 8, 6, 0, 0, 0))

@@ -48,3 +48,31 @@ def test_write_png_matches_reference(kat):
         assert layer.write_png().getvalue() == z[f"{idx}_png"].tobytes()
     with pytest.raises(ValueError):
         S.Layer(np.zeros((3, 3, 1)), (0, 0), pre_alpha=True, linear_rgb=True).write_png()
+
+
+def test_parallel_png_has_the_same_pixels():
+    """threads > 1: pieces deflated side by side and stitched into one zlib stream.  Not the reference's bytes, but a
+    valid PNG of the same pixels (checksums verified by the decoder); threads = 1 stays the reference's exact file."""
+    import struct
+    import zlib
+
+    from svgrasterize_amd.layer import canvas_to_png
+
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (700, 513, 4), dtype=np.uint8)
+    img[100:600, 50:400] = [12, 200, 7, 255]  # something compressible across piece borders (pieces are >= 1 MiB)
+    one = canvas_to_png(img).getvalue()
+    for threads, level in ((2, 9), (3, 1), (16, 6)):
+        png = canvas_to_png(img, level=level, threads=threads).getvalue()
+        assert png[:8] == one[:8] and png[8:33] == one[8:33]  # signature + IHDR
+        pos, idat = 8, b""
+        while pos < len(png):
+            n, tag = struct.unpack(">I4s", png[pos:pos + 8])
+            body = png[pos + 8: pos + 8 + n]
+            assert struct.unpack(">I", png[pos + 8 + n: pos + 12 + n])[0] == zlib.crc32(body, zlib.crc32(tag)) & 0xFFFFFFFF
+            if tag == b"IDAT":
+                idat += body
+            pos += 12 + n
+        raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(700, 513 * 4 + 1)
+        assert not raw[:, 0].any() and np.array_equal(raw[:, 1:].reshape(700, 513, 4), img)
+    assert canvas_to_png(np.zeros((0, 5, 4), np.uint8), threads=4).getvalue()[:8] == one[:8]  # empty image: one empty piece
