@@ -222,9 +222,17 @@ template <class T>
 struct DevArr {
     T* p = nullptr;
     size_t cap = 0;  // elements
+    bool view = false;  // p points into somebody else's block (the batch's input blob): never released here
+    void point_at(void* base, size_t byte_off, size_t n) {
+        release();
+        p = (T*)((char*)base + byte_off);
+        cap = n;
+        view = true;
+    }
     int ensure(size_t n) {
         if (n <= cap) return 0;
-        if (p) g_pool.release(p);
+        if (p && !view) g_pool.release(p);
+        view = false;
         p = nullptr;
         cap = 0;
         size_t want = n + n / 8 + 16;
@@ -234,9 +242,10 @@ struct DevArr {
         return 0;
     }
     void release() {
-        if (p) g_pool.release(p);
+        if (p && !view) g_pool.release(p);
         p = nullptr;
         cap = 0;
+        view = false;
     }
 };
 
@@ -1899,6 +1908,8 @@ struct svgr_batch {
     DevArr<double> segs, path_m6, path_paint;
     DevArr<uint8_t> seg_kind, path_rule;
     DevArr<int> seg_path;
+    DevArr<unsigned char> in_dev;  // the one block the six input arrays above are views of
+    std::vector<char> in_host;     // its host image: source of the single asynchronous upload, alive as long as the batch
     // zeroed once per render: [BatchDev | per-path min/max keys | per-path row reach (multi-GPU) | pb_cnt | pb_cursor]
     DevArr<unsigned char> arena;
     size_t arena_bytes = 0, off_pkeys = 0, off_prow = 0, off_pb_cnt = 0, off_pb_cursor = 0;
@@ -1943,7 +1954,7 @@ struct svgr_batch {
 
     void release() {
         segs.release(); path_m6.release(); path_paint.release(); seg_kind.release(); path_rule.release();
-        seg_path.release(); arena.release(); edge_path.release(); bbox.release(); bins.release();
+        seg_path.release(); in_dev.release(); arena.release(); edge_path.release(); bbox.release(); bins.release();
         bseg_off.release(); band_start.release(); band_count.release(); entries.release();
         edges.release(); bsegs.release(); layer_off.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
@@ -2012,10 +2023,15 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
 // Read the device-side error flags (and, while planning, all the counters: `whole`).  After renders only the error
 // word is meaningful -- the tile kernel has zeroed the rest of the arena for the next render -- and it is sticky until
 // it has been read here.  `capacity_bits`: when given, capacity overflows (bits 2|4|8) are returned there instead of failing.
-static int check_dev_err(svgr_batch* b, int* capacity_bits = nullptr, bool whole = true) {
+// `with_bboxes`: fetch the per-path bboxes in the same round trip (one synchronisation instead of two)
+static int check_dev_err(svgr_batch* b, int* capacity_bits = nullptr, bool whole = true, bool with_bboxes = false) {
     int e = 0;
     if (whole) {
         HIPCHK(hipMemcpyAsync(&b->host_bd, b->bd(), sizeof(BatchDev), hipMemcpyDeviceToHost, b->ctx->stream));
+        if (with_bboxes) {
+            b->host_bbox.resize(4 * (size_t)b->n_paths);
+            HIPCHK(hipMemcpyAsync(b->host_bbox.data(), b->bbox.p, sizeof(int) * 4 * (size_t)b->n_paths, hipMemcpyDeviceToHost, b->ctx->stream));
+        }
         HIPCHK(hipStreamSynchronize(b->ctx->stream));
         e = b->host_bd.err;
     } else {
@@ -2215,30 +2231,39 @@ int svgr_batch_create(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch** out)
     for (int64_t p = 0; p < d->n_paths; ++p) b->has_clips = b->has_clips || (d->path_rule[p] & (SVGR_PATH_CLIP_SOURCE | SVGR_PATH_CLIPPED));
     const size_t ns = (size_t)d->n_segs, np = (size_t)d->n_paths;
     int rc = 0;
-    std::vector<int> seg_path(ns);
-    for (size_t p = 0; p < np; ++p)
-        for (int64_t s = d->path_seg_off[p]; s < d->path_seg_off[p + 1]; ++s) seg_path[(size_t)s] = (int)p;
-    auto up = [&](auto& arr, const void* src, size_t n, size_t elt) -> int {
-        if (int r = arr.ensure(n ? n : 1)) return r;
-        if (n) {
-            hipError_t e = hipMemcpyAsync(arr.p, src, n * elt, hipMemcpyHostToDevice, ctx->stream);
-            if (e != hipSuccess) return fail(SVGR_E_HIP, "upload: %s", hipGetErrorString(e));
-        }
-        return 0;
-    };
-    rc = rc ? rc : up(b->segs, d->segs, ns * 8, sizeof(double));
-    rc = rc ? rc : up(b->seg_kind, d->seg_kind, ns, 1);
-    rc = rc ? rc : up(b->seg_path, seg_path.data(), ns, sizeof(int));
-    rc = rc ? rc : up(b->path_m6, d->path_m6, np * 6, sizeof(double));
-    rc = rc ? rc : up(b->path_rule, d->path_rule, np, 1);
-    rc = rc ? rc : up(b->path_paint, d->path_paint, np * 4, sizeof(double));
+    // The inputs travel as ONE host blob -> ONE device block (six small pageable copies cost more than the data): the blob
+    // is a member of the batch, so the copy needs no host wait; the device arrays are views into the block.
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_segs = 0, o_m6 = al(o_segs + ns * 64), o_paint = al(o_m6 + np * 48), o_spath = al(o_paint + np * 32),
+                 o_kind = al(o_spath + ns * 4), o_rule = al(o_kind + ns), total = al(o_rule + np);
+    b->in_host.resize(total);
+    char* const hb = b->in_host.data();
+    memcpy(hb + o_segs, d->segs, ns * 64);
+    memcpy(hb + o_m6, d->path_m6, np * 48);
+    memcpy(hb + o_paint, d->path_paint, np * 32);
+    {
+        int* sp = (int*)(hb + o_spath);
+        for (size_t p = 0; p < np; ++p)
+            for (int64_t s = d->path_seg_off[p]; s < d->path_seg_off[p + 1]; ++s) sp[(size_t)s] = (int)p;
+    }
+    memcpy(hb + o_kind, d->seg_kind, ns);
+    memcpy(hb + o_rule, d->path_rule, np);
+    rc = b->in_dev.ensure(total);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(b->in_dev.p, hb, total, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) rc = fail(SVGR_E_HIP, "upload: %s", hipGetErrorString(e));
+    }
+    if (!rc) {
+        b->segs.point_at(b->in_dev.p, o_segs, ns * 8 ? ns * 8 : 1);
+        b->path_m6.point_at(b->in_dev.p, o_m6, np * 6);
+        b->path_paint.point_at(b->in_dev.p, o_paint, np * 4);
+        b->seg_path.point_at(b->in_dev.p, o_spath, ns ? ns : 1);
+        b->seg_kind.point_at(b->in_dev.p, o_kind, ns ? ns : 1);
+        b->path_rule.point_at(b->in_dev.p, o_rule, np);
+    }
     rc = rc ? rc : b->bbox.ensure(4 * np);
     rc = rc ? rc : b->bins.ensure(np + 1);
     rc = rc ? rc : b->layout_arena(0);
-    if (!rc) {
-        hipError_t e = hipStreamSynchronize(ctx->stream);  // seg_path is a local
-        if (e != hipSuccess) rc = fail(SVGR_E_HIP, "sync: %s", hipGetErrorString(e));
-    }
     if (rc) { b->release(); delete b; return rc; }
     *out = b;
     return 0;
@@ -2309,13 +2334,11 @@ static int plan_speculative(svgr_batch* b) {
     if (rc) return rc;
     if ((rc = run_geometry(b, 4, true))) return rc;
     int cap_bits = 0;
-    if ((rc = check_dev_err(b, &cap_bits))) return rc;
+    if ((rc = check_dev_err(b, &cap_bits, true, true))) return rc;
     if (cap_bits) return 0;
     b->n_edges_live = 0;
     for (int k = 0; k < NSH; ++k) b->n_edges_live += std::min(b->host_bd.shard[k].cursor, shard_cap);
     b->n_bsegs = b->host_bd.bseg_cursor;
-    b->host_bbox.resize(4 * (size_t)np);
-    HIPCHK(hipMemcpy(b->host_bbox.data(), b->bbox.p, sizeof(int) * 4 * np, hipMemcpyDeviceToHost));
     b->planned = true;
     b->geometry_fresh = true;
     return 1;
@@ -2326,7 +2349,6 @@ int svgr_batch_plan(svgr_batch* b) {
     HIPCHK(hipSetDevice(b->ctx->device));
     b->planned = false;
     b->geometry_fresh = false;
-    const int np = (int)b->n_paths;
     {
         const bool no_spec = getenv("SVGR_NO_SPECULATIVE_PLAN") != nullptr;  // (tests exercise both planners)
         const int sp = no_spec ? 0 : plan_speculative(b);
@@ -2376,9 +2398,7 @@ int svgr_batch_plan(svgr_batch* b) {
     if (int rc = b->bsegs.ensure((size_t)std::max<int64_t>(b->n_bsegs, 1) + PREF_RECS_MAX + 1)) return rc;
     // 4. full geometry once, to validate the capacities and fetch the bboxes
     if (int rc = run_geometry(b, 4, true)) return rc;
-    if (int rc = check_dev_err(b)) return rc;
-    b->host_bbox.resize(4 * (size_t)np);
-    HIPCHK(hipMemcpy(b->host_bbox.data(), b->bbox.p, sizeof(int) * 4 * np, hipMemcpyDeviceToHost));
+    if (int rc = check_dev_err(b, nullptr, true, true)) return rc;
     b->n_edges_live = b->n_edges;
     b->planned = true;
     b->geometry_fresh = true;
