@@ -326,7 +326,8 @@ def main():
                 "note": "effective bandwidth: 40 B/path-pixel + 32 B/edge (SURVEY 8d) over the HIP-event duration of the "
                         "tile kernel (events on the library's stream around every %d-th launch of the timed region; rank 0's "
                         "launch and its share of the bytes); the kernel keeps trace and canvas on chip, so frac may exceed "
-                        "what real HBM traffic could" % every,
+                        "what real HBM traffic could (`traffic` = measured HBM bytes per launch, rocprofv3 PMC); its own limit "
+                        "is f64 VALU issue (about two thirds of the duration on synth4096, profiles/ + DESIGN.md section 4)" % every,
             },
         }
         if strong is not None:
