@@ -875,6 +875,15 @@ def gen_svg(ref, fonts) -> None:
                     ref.canvas_merge_at(canvas, cl.image, cl.offset)
                     out[f"{idx}_canvas"] = canvas
                     m["canvas"] = [h, w]
+                    if name in ("gradients", "clip_mask_opacity", "filters", "patterns"):
+                        # the same documents composited in linear RGB (the command line's --linear-rgb)
+                        with warnings.catch_warnings():
+                            warnings.simplefilter("ignore")
+                            res_lin = scene.render(ref.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=True)
+                        cl_lin = res_lin[0].convert(pre_alpha=True, linear_rgb=True)
+                        canvas_lin = np.zeros((h, w, 4))
+                        ref.canvas_merge_at(canvas_lin, cl_lin.image, cl_lin.offset)
+                        out[f"{idx}_canvas_lin"] = canvas_lin.astype(np.float32)
                     # ... and the file it would write (S:3866-3877), without and with a background colour
                     page = ref.Layer(ref.canvas_merge_at(np.zeros((h, w, 4)), cl.image, cl.offset), (0, 0), pre_alpha=True,
                                      linear_rgb=False)

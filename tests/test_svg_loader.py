@@ -124,7 +124,7 @@ def test_documents_render_like_the_reference():
     S.Context.get()
     z = np.load(os.path.join(GOLD, "svg_kat.npz"))
     meta = json.loads(str(z["meta"]))
-    drawn = 0
+    drawn = drawn_lin = 0
     for idx, ((name, text, width), m) in enumerate(zip(svg_cases.CASES, meta)):
         if not m.get("canvas"):
             continue
@@ -135,7 +135,13 @@ def test_documents_render_like_the_reference():
         layer, _hull = scene.render(S.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=False)
         assert_f32_1ulp(layer.to_canvas_f32(h, w), z[f"{idx}_canvas"], what=f"{name} canvas")
         drawn += 1
-    assert drawn >= 8
+        if f"{idx}_canvas_lin" in z.files:  # the same document composited in linear RGB (--linear-rgb)
+            layer, _hull = scene.render(S.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=True)
+            assert layer.linear_rgb
+            lin = layer.convert(pre_alpha=True, linear_rgb=True).to_canvas_f32(h, w)
+            assert_f32_1ulp(lin, z[f"{idx}_canvas_lin"], what=f"{name} canvas, linear RGB")
+            drawn_lin += 1
+    assert drawn >= 8 and drawn_lin >= 4
 
 
 def _png_pixels(png: bytes) -> np.ndarray:
