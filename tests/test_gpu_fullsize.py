@@ -136,3 +136,48 @@ def test_synth_8192_config4_windows(S):
         d = np.abs(part[k: k + (r1 - r0)].astype(np.float64) - full[r0:r1])
         assert d.max() < 2e-7 and (d > 0).mean() < 1e-5
         k += r1 - r0
+
+
+@pytest.mark.gpu
+def test_largest_canvas_windows_equal_small_viewport_renders():
+    """A 16384 x 16384 canvas (the planner's tiles x bands at their largest in the configs' spirit): shapes in the four
+    corners and the middle, checked through windows of the big render against renders of the same scene with the window
+    as its viewport (the reference's viewport cropping, S:966-975, is translation of the same pixels)."""
+    import svgrasterize_amd as S
+    from svgrasterize_amd import _abi
+    from svgrasterize_amd.scene import build_batch
+
+    ctx = S.Context.get()
+    size = 16384
+    swap = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    rng = np.random.default_rng(99)
+    leaves, spots = [], [(40, 50), (40, size - 300), (size - 280, 30), (size - 260, size - 270), (size // 2 - 100, size // 2 - 90)]
+    for k, (r0, c0) in enumerate(spots):
+        for j in range(6):
+            cx, cy = c0 + 120 + 30 * rng.uniform(-1, 1), r0 + 110 + 30 * rng.uniform(-1, 1)
+            rad = rng.uniform(40, 110)
+            d = (f"M{cx - rad},{cy} C{cx - rad},{cy - rad * 1.3} {cx + rad * 0.4},{cy - rad} {cx + rad},{cy - 0.2 * rad} "
+                 f"S{cx + 0.3 * rad},{cy + rad * 1.2} {cx - rad},{cy} Z")
+            a = rng.uniform(0.3, 1.0)
+            paint = np.array([*(rng.uniform(0, 1, 3) * a), a])
+            leaves.append((S.Path.from_svg(d), swap.m6(), 1 if j % 3 == 2 else 0, paint, 0))  # (rule 1 = evenodd)
+    # one long diagonal sliver crossing every band and column tile
+    leaves.append((S.Path.from_svg(f"M3,5 L{size - 4},{size - 9} L{size - 9},{size - 3} Z"), swap.m6(), 0, np.array([0.1, 0.2, 0.3, 0.5]), 0))
+
+    def render(viewport):
+        batch = build_batch(leaves, viewport, ctx)
+        batch.plan()
+        out = ctx.alloc(viewport[2] * viewport[3] * 16)
+        batch.render(out, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
+        return batch, out
+
+    big_batch, big = render([0, 0, size, size])
+    assert big_batch.stats.n_edges > 0
+    for r0, c0 in spots + [(8000, 8000)]:
+        r0, c0 = min(max(r0 - 20, 0), size - 320), min(max(c0 - 20, 0), size - 320)
+        _small_batch, small = render([r0, c0, 320, 320])
+        want = small.download((320, 320, 4), np.float32)
+        got = np.stack([big.download((320, 4), np.float32, offset=((r0 + i) * size + c0) * 16) for i in range(320)])
+        # (same pixels up to the order of the double sums: what lies left of a window is folded into its first column)
+        assert_f32_1ulp(got, want.astype(np.float64), what=f"window at ({r0}, {c0})")
+        assert want[..., 3].max() > 0.05  # the window really shows something (the sliver at least)
