@@ -212,6 +212,44 @@ def test_tiger_crop_viewport(S):
     assert_close64(layer.image, z["crop_layer"], atol=1e-10, what="tiger crop")
 
 
+def test_fifty_thousand_small_paths_vs_oracle(S, orc):
+    """Path count at the other extreme from the bench scene: 50 000 paths of a dozen pixels each (lines, quads turned
+    cubics, both fill rules, many per tile: the tile lists run in batches of 32), one batch, against the oracle."""
+    from svgrasterize_amd import _abi
+
+    n, size = 50_000, 1024
+    rng = np.random.default_rng(2024)
+    c = rng.uniform(-4, size + 4, (n, 1, 2))
+    ang = np.sort(rng.uniform(0, 2 * np.pi, (n, 3)), axis=1)
+    tri = c + rng.uniform(2, 9, (n, 3, 1)) * np.stack([np.cos(ang), np.sin(ang)], axis=-1)  # (n, 3, 2) corners, (x, y)
+    segs = np.zeros((n, 3, 8))
+    kinds = np.zeros((n, 3), dtype=np.uint8)
+    for k in range(3):
+        a, b = tri[:, k], tri[:, (k + 1) % 3]
+        curved = (np.arange(n) + k) % 4 == 0
+        segs[:, k, 0:2], segs[:, k, 2:4] = a, b  # a line: two points
+        bulge = 0.5 * (a + b) + rng.uniform(-2, 2, (n, 2))
+        segs[curved, k, 2:4], segs[curved, k, 4:6], segs[curved, k, 6:8] = (a + 2 * (bulge - a) / 3)[curved], (b + 2 * (bulge - b) / 3)[curved], b[curved]
+        kinds[curved, k] = 1
+    segs, kinds = segs.reshape(-1, 8), kinds.reshape(-1)
+    off = np.arange(n + 1, dtype=np.int64) * 3
+    alpha = rng.uniform(0.2, 1.0, (n, 1))
+    paint = np.concatenate([rng.uniform(0, 1, (n, 3)) * alpha, alpha], axis=1)
+    rule = (np.arange(n) % 5 == 0).astype(np.uint8)
+    m6 = np.tile(np.array([0.0, 1, 0, 1, 0, 0]), (n, 1))
+    vp = [0, 0, size, size]
+    pres = segs.copy()
+    pres[:, 0::2], pres[:, 1::2] = segs[:, 1::2], segs[:, 0::2]  # the oracle takes presentation space (row, col)
+    ref, P, _E = orc.render_solid(pres, kinds, off, rule, paint, vp, clip01=True)
+    ctx = S.Context.get()
+    batch = _abi.Batch(ctx, segs, kinds, off, m6, rule, paint, viewport=vp)
+    st = batch.plan()
+    assert st.path_pixels == P
+    out = ctx.alloc(size * size * 32)
+    batch.render(out, _abi.OUT_CANVAS_F64, _abi.RENDER_CLIP01)
+    assert_close64(out.download((size, size, 4), np.float64), ref, atol=1e-10, what="50k small paths")
+
+
 # ------------------------------------------------------------------------------------------
 # synthetic scene vs the CPU oracle (same seeded input)
 # ------------------------------------------------------------------------------------------
