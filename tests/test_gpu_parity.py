@@ -250,6 +250,37 @@ def test_fifty_thousand_small_paths_vs_oracle(S, orc):
     assert_close64(out.download((size, size, 4), np.float64), ref, atol=1e-10, what="50k small paths")
 
 
+def test_one_path_of_twenty_thousand_spikes_vs_oracle(S, orc):
+    """One path, 40 000 line segments, every band crossed by thousands of its edges: the (path, band) record lists run
+    far past one prefetch block (the tail is read straight from HBM), evenodd winding over hundreds of overlaps."""
+    from svgrasterize_amd import _abi
+
+    size, spikes = 1536, 20_000
+    rng = np.random.default_rng(7)
+    ang = np.linspace(0, 2 * np.pi, 2 * spikes, endpoint=False) + rng.uniform(0, 1e-3, 2 * spikes)
+    rad = np.where(np.arange(2 * spikes) % 2 == 0, rng.uniform(500, 760, 2 * spikes), rng.uniform(5, 200, 2 * spikes))
+    pts = np.stack([size / 2 + rad * np.cos(ang), size / 2 + rad * np.sin(ang)], axis=1)  # (x, y)
+    segs = np.zeros((2 * spikes, 8))
+    segs[:, 0:2], segs[:, 2:4] = pts, np.roll(pts, -1, axis=0)
+    kinds = np.zeros(2 * spikes, dtype=np.uint8)
+    off = np.array([0, 2 * spikes], dtype=np.int64)
+    for rule in (1, 0):
+        paint = np.array([[0.3, 0.1, 0.45, 0.6]])
+        vp = [0, 0, size, size]
+        pres = segs.copy()
+        pres[:, 0::2], pres[:, 1::2] = segs[:, 1::2], segs[:, 0::2]
+        ref, P, _E = orc.render_solid(pres, kinds, off, np.array([rule], dtype=np.uint8), paint, vp, clip01=True)
+        ctx = S.Context.get()
+        batch = _abi.Batch(ctx, segs, kinds, off, np.array([[0.0, 1, 0, 1, 0, 0]]), np.array([rule], dtype=np.uint8), paint, viewport=vp)
+        st = batch.plan()
+        assert st.path_pixels == P
+        out = ctx.alloc(size * size * 32)
+        out.zero()
+        batch.render(out, _abi.OUT_CANVAS_F64, _abi.RENDER_CLIP01)
+        # hundreds of windings cancel along a row: the sums differ from the sequential cumsum by their rounding
+        assert_close64(out.download((size, size, 4), np.float64), ref, atol=5e-10, what=f"spikes, rule {rule}")
+
+
 # ------------------------------------------------------------------------------------------
 # synthetic scene vs the CPU oracle (same seeded input)
 # ------------------------------------------------------------------------------------------
