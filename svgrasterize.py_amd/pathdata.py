@@ -32,7 +32,10 @@ def _arc_center(p0, p1, rx, ry, rot_deg, large, sweep):
 
     Returns None for a degenerate arc.
     """
-    if rx == 0 or ry == 0 or np.allclose(p0, p1):
+    if rx == 0 or ry == 0:
+        return None
+    # coincident end points (np.allclose: |a - b| <= 1e-8 + 1e-5 |b| on both coordinates): the arc is omitted
+    if abs(p0[0] - p1[0]) <= 1e-8 + 1e-5 * abs(p1[0]) and abs(p0[1] - p1[1]) <= 1e-8 + 1e-5 * abs(p1[1]):
         return None
     rx, ry = abs(rx), abs(ry)
     p0, p1 = np.asarray(p0, dtype=np.float64), np.asarray(p1, dtype=np.float64)
