@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the SVG front-end against the reference's loader (TEST INFRASTRUCTURE; build container only).
+
+Generates documents from a small grammar -- path data with every command in random number formats, basic shapes,
+nested groups with transforms / style / opacity, gradients, clip paths, masks, patterns, <use>, nested <svg> -- loads
+each with the reference's svg_scene (S:2803) and with svgrasterize_amd.svg, and compares the scene dumps.  A document
+the reference rejects (exception) must be rejected here as well.
+
+    python oracle/fuzz_svg_frontend.py [n_documents] [first_seed]
+"""
+import json
+import os
+import random
+import sys
+import warnings
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import gen_golden  # noqa: E402
+import ref_loader  # noqa: E402
+
+
+def num(r, lo=-60.0, hi=160.0):
+    v = r.uniform(lo, hi)
+    style = r.randrange(6)
+    if style == 0:
+        return str(int(v))
+    if style == 1:
+        return f"{v:.1f}"
+    if style == 2:
+        return f"{v:.4g}"
+    if style == 3:
+        return f"{v:e}"
+    if style == 4:
+        return (f"{v:.3f}").replace("0.", ".") if abs(v) < 1 else f"{v:.3f}"
+    return repr(v)
+
+
+def sep(r):
+    return r.choice([",", " ", " , ", "\n", "\t "])
+
+
+def path_data(r):
+    out = [r.choice("Mm") + num(r) + sep(r) + num(r)]
+    for _ in range(r.randrange(1, 14)):
+        c = r.choice("LlHhVvCcSsQqTtAaZzMm")
+        if c in "Zz":
+            out.append(c)
+            continue
+        n = dict(L=2, H=1, V=1, C=6, S=4, Q=4, T=2, A=7, M=2)[c.upper()]
+        reps = r.choice([1, 1, 1, 2, 3])
+        args = []
+        for _k in range(reps):
+            if c in "Aa":
+                args += [num(r, 0, 40), num(r, 0, 40), num(r, -180, 180), r.choice("01"), r.choice("01"), num(r), num(r)]
+            else:
+                args += [num(r, -30, 30) if c.islower() else num(r) for _j in range(n)]
+        text = c
+        for k, a in enumerate(args):
+            text += ("" if k == 0 and r.random() < 0.5 else sep(r)) + a
+        out.append(text)
+    return r.choice([" ", "", "\n"]).join(out)
+
+
+COLORS = ["red", "#0a3", "#12345678", "rgb(10, 200, 30)", "rgba(10%, 20%, 30%, 0.5)", "none", "black", "#fc0", "#FFf",
+          "currentColor", "url(#g0)", "url(#g1)", "url(#p0)", "url(#nope)", "tomato", "  navy "]
+
+
+def presentation(r):
+    attrs = {}
+    if r.random() < 0.7:
+        attrs["fill"] = r.choice(COLORS)
+    if r.random() < 0.4:
+        attrs["stroke"] = r.choice(COLORS)
+        if r.random() < 0.7:
+            attrs["stroke-width"] = num(r, 0.2, 6)
+        if r.random() < 0.4:
+            attrs["stroke-linecap"] = r.choice(["butt", "round", "square"])
+        if r.random() < 0.4:
+            attrs["stroke-linejoin"] = r.choice(["miter", "round", "bevel"])
+    for key, p in (("fill-opacity", 0.2), ("stroke-opacity", 0.15), ("opacity", 0.2)):
+        if r.random() < p:
+            attrs[key] = f"{r.uniform(0.1, 1.0):.2f}"
+    if r.random() < 0.2:
+        attrs["fill-rule"] = r.choice(["nonzero", "evenodd"])
+    if r.random() < 0.25:
+        ops = []
+        for _ in range(r.randrange(1, 3)):
+            k = r.randrange(6)
+            ops.append([f"translate({num(r, -20, 20)} {num(r, -20, 20)})", f"scale({num(r, 0.5, 2)})", f"scale({num(r, 0.5, 2)}, {num(r, 0.5, 2)})",
+                        f"rotate({num(r, -90, 90)})", f"rotate({num(r, -90, 90)} {num(r, 0, 50)} {num(r, 0, 50)})",
+                        f"matrix({num(r, 0.5, 1.5)} {num(r, -0.3, 0.3)} {num(r, -0.3, 0.3)} {num(r, 0.5, 1.5)} {num(r, -10, 10)} {num(r, -10, 10)})",
+                        ][k])
+        attrs["transform"] = " ".join(ops)
+    if r.random() < 0.1:
+        attrs["clip-path"] = r.choice(["url(#c0)", "url(#c1)"])
+    if r.random() < 0.05:
+        attrs["mask"] = "url(#m0)"
+    if r.random() < 0.3 and attrs:  # move some of them into a style attribute
+        keys = r.sample(sorted(k for k in attrs if k != "transform"), k=min(2, len([k for k in attrs if k != "transform"])))
+        if keys:
+            attrs["style"] = "; ".join(f"{k}: {attrs.pop(k)}" for k in keys) + r.choice(["", ";"])
+    return "".join(f' {k}="{v}"' for k, v in attrs.items())
+
+
+def shape(r):
+    k = r.randrange(8)
+    p = presentation(r)
+    if k == 0:
+        return f'<rect x="{num(r, 0, 80)}" y="{num(r, 0, 80)}" width="{num(r, 1, 60)}" height="{num(r, 1, 60)}"' + \
+               (f' rx="{num(r, 0, 9)}"' if r.random() < 0.4 else "") + (f' ry="{num(r, 0, 9)}"' if r.random() < 0.3 else "") + p + "/>"
+    if k == 1:
+        return f'<circle cx="{num(r, 0, 100)}" cy="{num(r, 0, 100)}" r="{num(r, 1, 40)}"{p}/>'
+    if k == 2:
+        return f'<ellipse cx="{num(r, 0, 100)}" cy="{num(r, 0, 100)}" rx="{num(r, 1, 40)}" ry="{num(r, 1, 30)}"{p}/>'
+    if k == 3:
+        return f'<line x1="{num(r)}" y1="{num(r)}" x2="{num(r)}" y2="{num(r)}"{p}/>'
+    if k == 4:
+        pts = " ".join(f"{num(r, 0, 120)},{num(r, 0, 120)}" for _ in range(r.randrange(3, 7)))
+        return f'<{r.choice(["polygon", "polyline"])} points="{pts}"{p}/>'
+    if k == 5:
+        return f'<use href="#sym" x="{num(r, 0, 60)}" y="{num(r, 0, 60)}"{p}/>'
+    return f'<path d="{path_data(r)}"{p}/>'
+
+
+def group(r, depth):
+    body = []
+    for _ in range(r.randrange(1, 5)):
+        if depth < 3 and r.random() < 0.25:
+            body.append(group(r, depth + 1))
+        elif depth < 2 and r.random() < 0.08:
+            body.append(f'<svg x="{num(r, 0, 50)}" y="{num(r, 0, 50)}" width="{num(r, 20, 90)}" height="{num(r, 20, 90)}"' +
+                        (f' viewBox="0 0 {num(r, 20, 200)} {num(r, 20, 200)}"' if r.random() < 0.6 else "") + ">" + shape(r) + shape(r) + "</svg>")
+        else:
+            body.append(shape(r))
+    return f"<g{presentation(r)}>" + "".join(body) + "</g>"
+
+
+def stops(r):
+    return "".join(f'<stop offset="{r.choice([num(r, 0, 1), str(r.randrange(0, 101)) + "%"])}" stop-color="{r.choice(COLORS[:9])}"' +
+                   (f' stop-opacity="{r.uniform(0.1, 1):.2f}"' if r.random() < 0.3 else "") + "/>" for _ in range(r.randrange(0, 5)))
+
+
+SPREADS = ["", ' spreadMethod="reflect"', ' spreadMethod="repeat"']
+CLIP_RULES = ["", ' clip-rule="evenodd"']
+
+
+def document(r):
+    units = r.choice(["", ' gradientUnits="userSpaceOnUse"'])
+    defs = (f'<linearGradient id="g0" x1="{num(r, 0, 1)}" y1="{num(r, 0, 1)}" x2="{num(r, 0, 1)}" y2="{num(r, 0, 1)}"'
+            f'{r.choice(SPREADS)}>{stops(r)}</linearGradient>'
+            f'<radialGradient id="g1"{units} cx="{num(r, 0, 90)}" cy="{num(r, 0, 90)}" r="{num(r, 5, 60)}"'
+            + (f' fx="{num(r, 0, 90)}" fy="{num(r, 0, 90)}"' if r.random() < 0.5 else "")
+            + (f' gradientTransform="rotate({num(r, 0, 90)})"' if r.random() < 0.4 else "") + f">{stops(r)}</radialGradient>"
+            f'<clipPath id="c0"{r.choice(CLIP_RULES)}>{shape(r)}</clipPath>'
+            f'<clipPath id="c1" clipPathUnits="objectBoundingBox"><rect x="0.1" y="0.2" width="0.7" height="0.6"/></clipPath>'
+            f'<mask id="m0">{shape(r)}{shape(r)}</mask>'
+            f'<pattern id="p0" width="{num(r, 4, 30)}" height="{num(r, 4, 30)}" patternUnits="userSpaceOnUse">{shape(r)}</pattern>'
+            f'<g id="sym">{shape(r)}</g>')
+    head = r.choice(['width="120" height="90"', 'viewBox="0 0 150 100"', 'width="3cm" height="20mm" viewBox="-5 -5 130 95"', 'width="200" height="100" viewBox="0 0 100 50"'])
+    return f'<svg xmlns="http://www.w3.org/2000/svg" {head}><defs>{defs}</defs>' + "".join(group(r, 0) for _ in range(r.randrange(1, 4))) + "</svg>"
+
+
+def main() -> int:
+    from svgrasterize_amd import scenedump, svg
+
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    ref = ref_loader.load()
+    bad = same_error = 0
+    for seed in range(first, first + n):
+        r = random.Random(seed)
+        text = document(r)
+        width = r.choice([None, None, 77, 300])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                want, _, want_size = ref.svg_scene_from_str(text, width=width, fonts=ref.FontsDB())
+                ref_exc = None
+            except Exception as e:  # noqa: BLE001
+                ref_exc = e
+            try:
+                got, _, got_size = svg.svg_scene_from_str(text, width=width)
+                my_exc = None
+            except Exception as e:  # noqa: BLE001
+                my_exc = e
+        if ref_exc is not None or my_exc is not None:
+            if (ref_exc is None) != (my_exc is None):
+                bad += 1
+                print(f"seed {seed}: reference {'raised ' + repr(ref_exc) if ref_exc else 'loaded'}, here {'raised ' + repr(my_exc) if my_exc else 'loaded'}")
+            else:
+                same_error += 1
+            continue
+        if (want is None) != (got is None):
+            bad += 1
+            print(f"seed {seed}: empty scene on one side only")
+            continue
+        if want is None:
+            continue
+        d = gen_golden.Dumper(ref)
+        try:
+            tree_ref = json.loads(json.dumps(d.node(want)))
+        except Exception as e:  # noqa: BLE001  (e.g. a stroke the reference's own stroker cannot outline)
+            same_error += 1
+            continue
+        tree, arrays = scenedump.dump_scene(got)
+        diffs = scenedump.compare_dumps(tree, arrays, tree_ref, d.arrays(), 1e-11)
+        if [float(v) for v in want_size] != [float(v) for v in got_size]:
+            diffs.append(f"size {want_size} vs {got_size}")
+        if diffs:
+            bad += 1
+            print(f"seed {seed}: " + "; ".join(diffs[:3]))
+    print(f"{n} documents, {bad} mismatches, {same_error} rejected by both")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
