@@ -153,6 +153,10 @@ int svgr_batch_get_stats(const svgr_batch* batch, svgr_batch_stats* out);
 int svgr_batch_get_bboxes(const svgr_batch* batch, int32_t* out /* n_paths x 4 */);
 /* flattened edges in presentation space, (E, 2, 2) doubles, grouped by path; edge_path may be NULL */
 int svgr_batch_get_edges(const svgr_batch* batch, double* edges, int32_t* edge_path, int64_t cap);
+/* ALL flattened edges of the batch, also those that cannot reach the viewport: the point set of Path.mask's
+ * ConvexHull(lines) (S:993), from which objectBoundingBox clips, gradients and patterns take their frame.  Call with
+ * edges == NULL to learn the count (*n_edges), then with a buffer of at least that many (2, 2) doubles.          */
+int svgr_batch_all_edges(svgr_batch* batch, double* edges, int32_t* edge_path, int64_t cap, int64_t* n_edges);
 
 /* Full device pipeline, asynchronous on the context stream, no host read-back:
  * transform+flatten -> bbox -> band binning -> tile kernel (LDS delta-coverage scatter, row scan,

@@ -906,6 +906,47 @@ def gen_svg(ref, fonts) -> None:
     print("  svg:", [(m["name"], m.get("unsupported")) for m in meta])
 
 
+def gen_svgfuzz(ref) -> None:
+    """Grammar-generated documents (oracle/fuzz_svg_frontend.py) the reference can draw, with the canvas it draws: random
+    nestings of groups, viewports, clips, masks, patterns, gradients, strokes -- end-to-end pins beyond the hand-written
+    documents.  The document text itself is stored, so that the fixture does not depend on the generator."""
+    import random
+    import warnings
+    import fuzz_svg_frontend as fuzz
+    out, meta = {}, []
+    seed = 0
+    while len(meta) < 24 and seed < 2000:
+        r = random.Random(seed)
+        seed += 1
+        text = fuzz.document(r)
+        width = r.choice([None, None, 77, 300])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                scene, _ids, size = ref.svg_scene_from_str(text, width=width, fonts=ref.FontsDB())
+                if scene is None or size is None:
+                    continue
+                w, h = int(size[0]), int(size[1])
+                if w * h > 400 * 400 or w < 8 or h < 8:
+                    continue
+                res = scene.render(ref.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=False)
+                if res is None:
+                    continue
+                cl = res[0].convert(pre_alpha=True, linear_rgb=False)
+                canvas = np.zeros((h, w, 4))
+                ref.canvas_merge_at(canvas, cl.image, cl.offset)
+            except Exception:  # noqa: BLE001  (a paint the reference cannot draw, an empty group, ...)
+                continue
+        if not np.isfinite(canvas).all() or canvas[..., 3].max() < 0.05:
+            continue
+        k = len(meta)
+        out[f"{k}_canvas"] = canvas.astype(np.float32)
+        meta.append(dict(seed=seed - 1, width=width, size=[h, w], text=text))
+    out["meta"] = np.array(json.dumps(meta))
+    save("svg_fuzz_kat.npz", **out)
+    print("  svg fuzz seeds:", [m["seed"] for m in meta])
+
+
 HOSTUTIL_PATHS = [
     "M1,2 L3.5,4 H10 V-2.25 z",
     "M0,0 Q5,10 10,0 T20,0 C25,5 30,-5 35,0 S45,5 50,0",
@@ -984,6 +1025,8 @@ def main() -> None:
         gen_filters(ref)
     if todo("svg"):
         gen_svg(ref, fonts)
+    if todo("svgfuzz"):
+        gen_svgfuzz(ref)
     if todo("hostutil"):
         gen_hostutil(ref)
     if todo("mask"):

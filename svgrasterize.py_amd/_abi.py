@@ -93,6 +93,7 @@ _PROTOS = {
     "svgr_batch_get_stats": (C.c_int, [_P, C.POINTER(BatchStats)]),
     "svgr_batch_get_bboxes": (C.c_int, [_P, _P]),
     "svgr_batch_get_edges": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "svgr_batch_all_edges": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "svgr_batch_render": (C.c_int, [_P, _P, C.c_int, C.c_uint]),
     "svgr_batch_owned_rows": (C.c_int64, [_P]),
     "svgr_batch_timings": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -299,6 +300,16 @@ class Batch:
         edges = np.empty((n, 2, 2), dtype=np.float64)
         edge_path = np.empty(n, dtype=np.int32)
         _check(self.ctx.lib.svgr_batch_get_edges(self.handle, edges.ctypes.data_as(_P), edge_path.ctypes.data_as(_P), n))
+        return edges, edge_path
+
+    def all_edges(self):
+        """Every flattened edge, also those off the viewport (what the reference builds Path.mask's hull from)."""
+        n = C.c_int64()
+        _check(self.ctx.lib.svgr_batch_all_edges(self.handle, None, None, 0, C.byref(n)))
+        edges = np.empty((n.value, 2, 2), dtype=np.float64)
+        edge_path = np.empty(n.value, dtype=np.int32)
+        if n.value:
+            _check(self.ctx.lib.svgr_batch_all_edges(self.handle, edges.ctypes.data_as(_P), edge_path.ctypes.data_as(_P), n.value, C.byref(n)))
         return edges, edge_path
 
     def set_bands(self, rank: int, world: int, strip_bands: int = 1):

@@ -2452,6 +2452,63 @@ int svgr_batch_get_edges(const svgr_batch* b, double* edges, int32_t* edge_path,
     return 0;
 }
 
+// Every flattened edge of every path, whatever the viewport: ConvexHull(lines) of Path.mask (S:993) is built from all
+// of them, and objectBoundingBox clips / gradients / patterns take their frame from that hull -- a shape that hangs out of
+// the viewport keeps its full bounding box.  (The render keeps only edges that can reach the viewport's rows.)
+// Two flatten passes without row culling into scratch shards: count, then emit.  The batch's own plan stays valid; its
+// counter arena is left dirty, so the next render starts from a fresh geometry pass.
+int svgr_batch_all_edges(svgr_batch* b, double* edges, int32_t* edge_path, int64_t cap, int64_t* n_out) {
+    if (!b || !n_out) return fail(SVGR_E_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(b->ctx->device));
+    hipStream_t st = b->ctx->stream;
+    const int ns = (int)b->n_segs;
+    *n_out = 0;
+    if (ns <= 0) return 0;
+    if (b->arena_bytes == 0)
+        if (int rc = b->layout_arena(0)) return rc;
+    const dim3 fgrid = grid1((size_t)ns << FL_SUB, FL_BLOCK);
+    const Owner whole{0, 1, 1};
+    b->geometry_fresh = false;
+    b->arena_zeroed = false;
+    HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
+    hipLaunchKernelGGL(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
+                       (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr, (double*)nullptr, (int*)nullptr, b->shards,
+                       b->pkeys(), b->bd(), whole, 0, 0, (const unsigned*)nullptr);
+    BatchDev counts;
+    HIPCHK(hipMemcpyAsync(&counts, b->bd(), sizeof counts, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (counts.err & 1) return fail(SVGR_E_OVERFLOW, "flatten depth cap (%d) hit: non-finite or absurd control points", kMaxFlattenDepth);
+    EdgeShards sh{};
+    int64_t total = 0;
+    for (int k = 0; k < NSH; ++k) {
+        sh.base[k] = (int)total;
+        sh.cap[k] = counts.shard[k].cursor;
+        total += counts.shard[k].cursor;
+    }
+    *n_out = total;
+    if (!edges || total == 0) return 0;  // (a size query)
+    if (cap < total) return fail(SVGR_E_INVALID, "edge buffer holds %lld, need %lld", (long long)cap, (long long)total);
+    if (total > 0x7fffffff / 4) return fail(SVGR_E_OVERFLOW, "%lld edges: beyond the 32-bit edge index", (long long)total);
+    double* d_edges = nullptr;
+    int* d_path = nullptr;
+    HIPCHK(g_pool.alloc((void**)&d_edges, sizeof(double) * 4 * (size_t)total));
+    if (hipError_t e = g_pool.alloc((void**)&d_path, sizeof(int) * (size_t)total); e != hipSuccess) { g_pool.release(d_edges); HIPCHK(e); }
+    hipError_t e = hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_flatten<true>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
+                           (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr, d_edges, d_path, sh, b->pkeys(), b->bd(),
+                           whole, 0, 0, (const unsigned*)nullptr);
+        e = hipMemcpyAsync(edges, d_edges, sizeof(double) * 4 * (size_t)total, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && edge_path) e = hipMemcpyAsync(edge_path, d_path, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    g_pool.release(d_edges);
+    g_pool.release(d_path);
+    if (e != hipSuccess) return fail(SVGR_E_HIP, "svgr_batch_all_edges: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int64_t svgr_batch_owned_rows(const svgr_batch* b) {
     if (!b || !b->planned) return -1;
     if (b->own.world <= 1) return b->vp[2];

@@ -406,7 +406,7 @@ class Path:
         batch.render(buf, _abi.OUT_MASK_F64)
         offset = _offset(bb, viewport)
         layer = Layer._from_device(buf, (rows, cols, 1), offset, pre_alpha=True, linear_rgb=True)
-        return layer, ConvexHull(_source=lambda: batch.edges()[0])
+        return layer, ConvexHull(_source=lambda: batch.all_edges()[0])
 
     def fill(self, transform: Transform, paint, fill_rule: str | None = None, viewport=None, linear_rgb: bool = True):
         """Render path by fill-ing it, S:995-1103: solid colours, gradients, patterns."""
@@ -422,7 +422,7 @@ class Path:
             buf = ctx.alloc(rows * cols * 32)
             batch.render(buf, _abi.OUT_FILL_F64)
             layer = Layer._from_device(buf, (rows, cols, 4), _offset(bb, viewport), pre_alpha=True, linear_rgb=linear_rgb)
-            return layer, ConvexHull(_source=lambda: batch.edges()[0])
+            return layer, ConvexHull(_source=lambda: batch.all_edges()[0])
         from .paint import gradient_fill, is_gradient  # noqa: PLC0415
 
         if is_gradient(paint):
@@ -536,7 +536,7 @@ class MaskPrefetch:
 
         def edges_of(i):
             if not edges_cache:
-                edges_cache.append(batch.edges())
+                edges_cache.append(batch.all_edges())  # (unculled: the hull of a mask covers the whole shape, S:993)
             e, ep = edges_cache[0]
             return e[ep == i]
 

@@ -475,7 +475,7 @@ def _render_run(leaves, viewport, linear_rgb):
     painted = np.array([leaf[4] != 1 for leaf in leaves])
 
     def hull_points():
-        edges, edge_path = batch.edges()
+        edges, edge_path = batch.all_edges()  # (also what hangs out of the viewport: the reference's hull has it, S:993)
         return edges[painted[edge_path]]  # the clip paths do not belong to the hull (S:715 returns the target's)
 
     return layer, ConvexHull(_source=hull_points)

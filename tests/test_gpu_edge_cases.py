@@ -188,3 +188,26 @@ def test_mask_prefetch_is_only_a_cache(S):
             assert_close64(hit[0].image, single[0].image, atol=1e-13, what="mask from the batch")
             assert np.array_equal(np.array(hit[1].points), np.array(single[1].points))
     assert pf.get(star, swap, "evenodd", [0, 0, 50, 50]) is pf.MISS and pf.get(star, swap.scale(2), "evenodd", vp) is pf.MISS
+
+
+def test_hull_ignores_the_viewport(S):
+    """Path.mask's hull is built from ALL flattened lines (S:993), not from what reaches the viewport: a shape that hangs
+    out of the viewport keeps its full bounding box, which is the frame of objectBoundingBox clips / gradients / patterns."""
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    path = S.Path.from_svg("M20,10 C90,-40 160,60 110,150 S-30,120 20,10 Z M60,60 h20 v200 h-20 z")
+    _full_layer, full_hull = path.mask(tr)
+    want = np.array(full_hull.points)
+    for vp in ([0, 0, 64, 64], [100, 40, 50, 30], [30, 0, 16, 200]):
+        res = path.mask(tr, viewport=vp)
+        assert res is not None
+        got = np.array(res[1].points)
+        assert got.shape == want.shape and np.array_equal(got, want), vp
+        assert res[1].bbox(tr) == full_hull.bbox(tr)
+    # the same through the scene route (a batched run and a gradient fill)
+    grad = S.GradLinear(np.array([0.0, 0.0]), np.array([1.0, 1.0]), [(0.0, np.array([1.0, 0, 0, 1])), (1.0, np.array([0, 0, 1.0, 1]))],
+                        None, "pad", True, None)
+    for paint in (np.array([0.2, 0.4, 0.6, 0.8]), grad):
+        scene = S.Scene.fill(path, paint)
+        _l0, h0 = scene.render(tr, viewport=[0, 0, 400, 400])
+        _l1, h1 = scene.render(tr, viewport=[100, 40, 50, 30])
+        assert np.array_equal(np.array(h0.points), np.array(h1.points))

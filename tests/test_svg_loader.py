@@ -221,3 +221,25 @@ def test_render_svg_writes_the_reference_png():
         assert (got_px != want_px).any(axis=-1).mean() < 0.02
     with pytest.raises(KeyError):
         svg.render_svg(io.StringIO(text), id="no-such-element")
+
+
+@pytest.mark.gpu
+def test_generated_documents_render_like_the_reference():
+    """24 grammar-generated documents (random nestings of groups, viewports, clips, masks, patterns, gradients, strokes;
+    tests/golden/svg_fuzz_kat.npz stores the text and the canvas the reference drew): loader + hot path end to end."""
+    import svgrasterize_amd as S
+    from svgrasterize_amd import svg
+    from tests.util import assert_f32_1ulp
+
+    S.Context.get()
+    z = np.load(os.path.join(GOLD, "svg_fuzz_kat.npz"))
+    meta = json.loads(str(z["meta"]))
+    assert len(meta) >= 20
+    for k, m in enumerate(meta):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            scene, _ids, size = svg.svg_scene_from_str(m["text"], width=m["width"])
+            h, w = m["size"]
+            assert [int(size[1]), int(size[0])] == [h, w]
+            layer, _hull = scene.render(S.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=False)
+        assert_f32_1ulp(layer.to_canvas_f32(h, w), z[f"{k}_canvas"].astype(np.float64), what=f"generated document {m['seed']}")
