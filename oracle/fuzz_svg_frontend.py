@@ -21,6 +21,33 @@ import gen_golden  # noqa: E402
 import ref_loader  # noqa: E402
 
 
+class TooSlow(Exception):
+    pass
+
+
+class time_limit:
+    """``with time_limit(s):`` raises TooSlow after s seconds (the reference's stroker does not terminate on some inputs)."""
+
+    def __init__(self, seconds: int):
+        self.seconds = seconds
+
+    def __enter__(self):
+        import signal
+
+        def fire(*_a):
+            raise TooSlow()
+
+        self.old = signal.signal(signal.SIGALRM, fire)
+        signal.alarm(self.seconds)
+
+    def __exit__(self, *exc):
+        import signal
+
+        signal.alarm(0)
+        signal.signal(signal.SIGALRM, self.old)
+        return False
+
+
 def num(r, lo=-60.0, hi=160.0):
     v = r.uniform(lo, hi)
     style = r.randrange(6)
@@ -97,6 +124,8 @@ def presentation(r):
         attrs["clip-path"] = r.choice(["url(#c0)", "url(#c1)"])
     if r.random() < 0.05:
         attrs["mask"] = "url(#m0)"
+    if r.random() < 0.07:
+        attrs["filter"] = r.choice(["url(#f0)", "url(#f1)"])
     if r.random() < 0.3 and attrs:  # move some of them into a style attribute
         keys = r.sample(sorted(k for k in attrs if k != "transform"), k=min(2, len([k for k in attrs if k != "transform"])))
         if keys:
@@ -146,6 +175,28 @@ SPREADS = ["", ' spreadMethod="reflect"', ' spreadMethod="repeat"']
 CLIP_RULES = ["", ' clip-rule="evenodd"']
 
 
+def filters(r):
+    shadow = (f'<filter id="f0"><feGaussianBlur in="SourceAlpha" stdDeviation="{num(r, 0.4, 3)}' + (f' {num(r, 0.4, 3)}' if r.random() < 0.4 else "") +
+              f'" result="b"/><feOffset in="b" dx="{num(r, -4, 4)}" dy="{num(r, -4, 4)}" result="o"/>'
+              '<feMerge><feMergeNode in="o"/><feMergeNode in="SourceGraphic"/></feMerge></filter>')
+    ops = []
+    for _ in range(r.randrange(1, 4)):
+        k = r.randrange(6)
+        if k == 0:
+            ops.append(f'<feColorMatrix type="saturate" values="{num(r, 0, 1)}"/>')
+        elif k == 1:
+            ops.append(f'<feColorMatrix type="hueRotate" values="{num(r, 0, 360)}"/>')
+        elif k == 2:
+            ops.append('<feColorMatrix type="luminanceToAlpha"/>')
+        elif k == 3:
+            ops.append(f'<feMorphology operator="{r.choice(["erode", "dilate"])}" radius="{num(r, 0.5, 2.5)}"/>')
+        elif k == 4:
+            ops.append(f'<feComposite in2="SourceGraphic" operator="{r.choice(["over", "in", "out", "atop", "xor"])}"/>')
+        else:
+            ops.append(f'<feComposite in2="SourceAlpha" operator="arithmetic" k1="{num(r, 0, 1)}" k2="{num(r, 0, 1)}" k3="{num(r, 0, 1)}" k4="{num(r, 0, 0.2)}"/>')
+    return shadow + '<filter id="f1">' + "".join(ops) + "</filter>"
+
+
 def document(r):
     units = r.choice(["", ' gradientUnits="userSpaceOnUse"'])
     defs = (f'<linearGradient id="g0" x1="{num(r, 0, 1)}" y1="{num(r, 0, 1)}" x2="{num(r, 0, 1)}" y2="{num(r, 0, 1)}"'
@@ -157,7 +208,7 @@ def document(r):
             f'<clipPath id="c1" clipPathUnits="objectBoundingBox"><rect x="0.1" y="0.2" width="0.7" height="0.6"/></clipPath>'
             f'<mask id="m0">{shape(r)}{shape(r)}</mask>'
             f'<pattern id="p0" width="{num(r, 4, 30)}" height="{num(r, 4, 30)}" patternUnits="userSpaceOnUse">{shape(r)}</pattern>'
-            f'<g id="sym">{shape(r)}</g>')
+            f'<g id="sym">{shape(r)}</g>' + filters(r))
     head = r.choice(['width="120" height="90"', 'viewBox="0 0 150 100"', 'width="3cm" height="20mm" viewBox="-5 -5 130 95"', 'width="200" height="100" viewBox="0 0 100 50"'])
     return f'<svg xmlns="http://www.w3.org/2000/svg" {head}><defs>{defs}</defs>' + "".join(group(r, 0) for _ in range(r.randrange(1, 4))) + "</svg>"
 
@@ -168,7 +219,7 @@ def main() -> int:
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     ref = ref_loader.load()
-    bad = same_error = 0
+    bad = same_error = slow = 0
     for seed in range(first, first + n):
         r = random.Random(seed)
         text = document(r)
@@ -176,8 +227,12 @@ def main() -> int:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             try:
-                want, _, want_size = ref.svg_scene_from_str(text, width=width, fonts=ref.FontsDB())
+                with time_limit(20):
+                    want, _, want_size = ref.svg_scene_from_str(text, width=width, fonts=ref.FontsDB())
                 ref_exc = None
+            except TooSlow:
+                slow += 1
+                continue
             except Exception as e:  # noqa: BLE001
                 ref_exc = e
             try:
@@ -200,8 +255,12 @@ def main() -> int:
             continue
         d = gen_golden.Dumper(ref)
         try:
-            tree_ref = json.loads(json.dumps(d.node(want)))
-        except Exception as e:  # noqa: BLE001  (e.g. a stroke the reference's own stroker cannot outline)
+            with time_limit(20):
+                tree_ref = json.loads(json.dumps(d.node(want)))
+        except TooSlow:  # (the reference's stroker spinning on an outline; the native one here finishes)
+            slow += 1
+            continue
+        except Exception:  # noqa: BLE001  (e.g. a stroke the reference's own stroker cannot outline)
             same_error += 1
             continue
         tree, arrays = scenedump.dump_scene(got)
@@ -211,7 +270,7 @@ def main() -> int:
         if diffs:
             bad += 1
             print(f"seed {seed}: " + "; ".join(diffs[:3]))
-    print(f"{n} documents, {bad} mismatches, {same_error} rejected by both")
+    print(f"{n} documents, {bad} mismatches, {same_error} rejected by both, {slow} given up on (reference > 20 s)")
     return 1 if bad else 0
 
 

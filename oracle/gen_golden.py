@@ -915,7 +915,7 @@ def gen_svgfuzz(ref) -> None:
     import fuzz_svg_frontend as fuzz
     out, meta = {}, []
     seed = 0
-    while len(meta) < 24 and seed < 2000:
+    while len(meta) < 40 and seed < 4000:
         r = random.Random(seed)
         seed += 1
         text = fuzz.document(r)
@@ -923,19 +923,20 @@ def gen_svgfuzz(ref) -> None:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             try:
-                scene, _ids, size = ref.svg_scene_from_str(text, width=width, fonts=ref.FontsDB())
-                if scene is None or size is None:
-                    continue
-                w, h = int(size[0]), int(size[1])
-                if w * h > 400 * 400 or w < 8 or h < 8:
-                    continue
-                res = scene.render(ref.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=False)
-                if res is None:
-                    continue
-                cl = res[0].convert(pre_alpha=True, linear_rgb=False)
-                canvas = np.zeros((h, w, 4))
-                ref.canvas_merge_at(canvas, cl.image, cl.offset)
-            except Exception:  # noqa: BLE001  (a paint the reference cannot draw, an empty group, ...)
+                with fuzz.time_limit(60):
+                    scene, _ids, size = ref.svg_scene_from_str(text, width=width, fonts=ref.FontsDB())
+                    if scene is None or size is None:
+                        continue
+                    w, h = int(size[0]), int(size[1])
+                    if w * h > 400 * 400 or w < 8 or h < 8:
+                        continue
+                    res = scene.render(ref.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=False)
+                    if res is None:
+                        continue
+                    cl = res[0].convert(pre_alpha=True, linear_rgb=False)
+                    canvas = np.zeros((h, w, 4))
+                    ref.canvas_merge_at(canvas, cl.image, cl.offset)
+            except (Exception, fuzz.TooSlow):  # noqa: BLE001  (a paint the reference cannot draw, an empty group, a stroke it never finishes, ...)
                 continue
         if not np.isfinite(canvas).all() or canvas[..., 3].max() < 0.05:
             continue

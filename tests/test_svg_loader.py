@@ -133,7 +133,7 @@ def test_documents_render_like_the_reference():
             scene, _ids, _size = svg.svg_scene_from_str(text, width=width)
         h, w = m["canvas"]
         layer, _hull = scene.render(S.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=False)
-        assert_f32_1ulp(layer.to_canvas_f32(h, w), z[f"{idx}_canvas"], what=f"{name} canvas")
+        assert_f32_1ulp(layer.convert(pre_alpha=True, linear_rgb=False).to_canvas_f32(h, w), z[f"{idx}_canvas"], what=f"{name} canvas")
         drawn += 1
         if f"{idx}_canvas_lin" in z.files:  # the same document composited in linear RGB (--linear-rgb)
             layer, _hull = scene.render(S.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=True)
@@ -225,7 +225,7 @@ def test_render_svg_writes_the_reference_png():
 
 @pytest.mark.gpu
 def test_generated_documents_render_like_the_reference():
-    """24 grammar-generated documents (random nestings of groups, viewports, clips, masks, patterns, gradients, strokes;
+    """40 grammar-generated documents (random nestings of groups, viewports, clips, masks, patterns, gradients, strokes;
     tests/golden/svg_fuzz_kat.npz stores the text and the canvas the reference drew): loader + hot path end to end."""
     import svgrasterize_amd as S
     from svgrasterize_amd import svg
@@ -234,7 +234,7 @@ def test_generated_documents_render_like_the_reference():
     S.Context.get()
     z = np.load(os.path.join(GOLD, "svg_fuzz_kat.npz"))
     meta = json.loads(str(z["meta"]))
-    assert len(meta) >= 20
+    assert len(meta) >= 36
     for k, m in enumerate(meta):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -242,4 +242,4 @@ def test_generated_documents_render_like_the_reference():
             h, w = m["size"]
             assert [int(size[1]), int(size[0])] == [h, w]
             layer, _hull = scene.render(S.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=False)
-        assert_f32_1ulp(layer.to_canvas_f32(h, w), z[f"{k}_canvas"].astype(np.float64), what=f"generated document {m['seed']}")
+        assert_f32_1ulp(layer.convert(pre_alpha=True, linear_rgb=False).to_canvas_f32(h, w), z[f"{k}_canvas"].astype(np.float64), what=f"generated document {m['seed']}")
