@@ -942,6 +942,17 @@ def gen_svgfuzz(ref) -> None:
             continue
         k = len(meta)
         out[f"{k}_canvas"] = canvas.astype(np.float32)
+        if k % 3 == 0:  # every third document also composited in linear RGB
+            try:
+                with warnings.catch_warnings(), fuzz.time_limit(60):
+                    warnings.simplefilter("ignore")
+                    res = scene.render(ref.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=True)
+                    cl = res[0].convert(pre_alpha=True, linear_rgb=True)
+                    lin = np.zeros((h, w, 4))
+                    ref.canvas_merge_at(lin, cl.image, cl.offset)
+                    out[f"{k}_canvas_lin"] = lin.astype(np.float32)
+            except (Exception, fuzz.TooSlow):  # noqa: BLE001
+                pass
         meta.append(dict(seed=seed - 1, width=width, size=[h, w], text=text))
     out["meta"] = np.array(json.dumps(meta))
     save("svg_fuzz_kat.npz", **out)

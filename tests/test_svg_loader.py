@@ -243,3 +243,9 @@ def test_generated_documents_render_like_the_reference():
             assert [int(size[1]), int(size[0])] == [h, w]
             layer, _hull = scene.render(S.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=False)
         assert_f32_1ulp(layer.convert(pre_alpha=True, linear_rgb=False).to_canvas_f32(h, w), z[f"{k}_canvas"].astype(np.float64), what=f"generated document {m['seed']}")
+        if f"{k}_canvas_lin" in z.files:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                layer, _hull = scene.render(S.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=True)
+            assert_f32_1ulp(layer.convert(pre_alpha=True, linear_rgb=True).to_canvas_f32(h, w), z[f"{k}_canvas_lin"].astype(np.float64),
+                            what=f"generated document {m['seed']}, linear RGB")
