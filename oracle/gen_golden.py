@@ -953,7 +953,24 @@ def gen_svgfuzz(ref) -> None:
                     out[f"{k}_canvas_lin"] = lin.astype(np.float32)
             except (Exception, fuzz.TooSlow):  # noqa: BLE001
                 pass
-        meta.append(dict(seed=seed - 1, width=width, size=[h, w], text=text))
+        crop = None
+        if k % 3 == 1:  # every third document also through a window: the viewport cropping of S:966-975 on every leaf
+            rr = random.Random(seed * 7919)
+            rows, cols = rr.randrange(12, max(13, h // 2)), rr.randrange(12, max(13, w // 2))
+            r0, c0 = rr.randrange(-6, h - rows + 6), rr.randrange(-6, w - cols + 6)
+            try:
+                with warnings.catch_warnings(), fuzz.time_limit(60):
+                    warnings.simplefilter("ignore")
+                    res = scene.render(ref.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[r0, c0, rows, cols], linear_rgb=False)
+                    win = np.zeros((rows, cols, 4))
+                    if res is not None:
+                        cl = res[0].convert(pre_alpha=True, linear_rgb=False)
+                        ref.canvas_merge_at(win, cl.image, (cl.offset[0] - r0, cl.offset[1] - c0))
+                    out[f"{k}_canvas_crop"] = win.astype(np.float32)
+                    crop = [r0, c0, rows, cols]
+            except (Exception, fuzz.TooSlow):  # noqa: BLE001
+                crop = None
+        meta.append(dict(seed=seed - 1, width=width, size=[h, w], text=text, crop=crop))
     out["meta"] = np.array(json.dumps(meta))
     save("svg_fuzz_kat.npz", **out)
     print("  svg fuzz seeds:", [m["seed"] for m in meta])

@@ -243,6 +243,15 @@ def test_generated_documents_render_like_the_reference():
             assert [int(size[1]), int(size[0])] == [h, w]
             layer, _hull = scene.render(S.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=False)
         assert_f32_1ulp(layer.convert(pre_alpha=True, linear_rgb=False).to_canvas_f32(h, w), z[f"{k}_canvas"].astype(np.float64), what=f"generated document {m['seed']}")
+        if m.get("crop"):  # the same document through a window somewhere on (or partly off) the page
+            r0, c0, rows, cols = m["crop"]
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                res = scene.render(S.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[r0, c0, rows, cols], linear_rgb=False)
+            win = np.zeros((rows, cols, 4), dtype=np.float32)
+            if res is not None:
+                win = res[0].convert(pre_alpha=True, linear_rgb=False).translate(-r0, -c0).to_canvas_f32(rows, cols)
+            assert_f32_1ulp(win, z[f"{k}_canvas_crop"].astype(np.float64), what=f"generated document {m['seed']}, window {m['crop']}")
         if f"{k}_canvas_lin" in z.files:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
