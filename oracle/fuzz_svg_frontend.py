@@ -133,9 +133,40 @@ def presentation(r):
     return "".join(f' {k}="{v}"' for k, v in attrs.items())
 
 
+FONT = ('<font id="fz" horiz-adv-x="520"><font-face font-family="Fuzz" units-per-em="1000" ascent="800" descent="-200"/>'
+        '<missing-glyph horiz-adv-x="400" d="M40,0 H360 V600 H40 z"/>'
+        '<glyph unicode="a" glyph-name="a" d="M0,0 L200,600 L400,0 H320 L270,150 H130 L80,0 z"/>'
+        '<glyph unicode="b" glyph-name="b" horiz-adv-x="480" d="M60,0 V700 H300 Q420,700 420,540 T300,380 Q440,380 440,190 T300,0 z"/>'
+        '<glyph unicode="c" glyph-name="c" horiz-adv-x="450" d="M400,80 C300,-40 40,-20 40,250 S300,540 400,420 L340,370 C280,450 120,430 120,250 S280,50 340,130 z"/>'
+        '<glyph unicode="ab" glyph-name="ab" horiz-adv-x="800" d="M0,0 L200,600 L400,0 H760 V700 H680 V80 H340 z"/>'
+        '<glyph unicode=" " glyph-name="sp" horiz-adv-x="260" d=""/>'
+        '<hkern u1="a" u2="c" k="60"/><hkern g1="b" g2="a,c" k="-35"/></font>')
+
+
+def text_element(r, p):
+    def words():
+        return "".join(r.choice(["a", "b", "c", "ab", " ", "  ", "x", "\n", "a c"]) for _ in range(r.randrange(1, 7)))
+
+    inner = words()
+    for _ in range(r.randrange(0, 3)):
+        attrs = "".join(f' {k}="{num(r, -8, 8)}"' for k in ("dx", "dy") if r.random() < 0.4)
+        if r.random() < 0.3:
+            attrs += f' x="{num(r, 0, 90)}"'
+        if r.random() < 0.3:
+            attrs += f' fill="{r.choice(COLORS[:9])}"'
+        if r.random() < 0.2:
+            attrs += f' font-size="{num(r, 6, 30)}"'
+        inner += f"<tspan{attrs}>{words()}</tspan>" + (words() if r.random() < 0.5 else "")
+    anchor = r.choice(["", "", ' text-anchor="middle"', ' text-anchor="end"'])
+    family = r.choice(["Fuzz", "fuzz", "Nothing Sans", "Fuzz"])
+    return f'<text x="{num(r, 0, 90)}" y="{num(r, 10, 90)}" font-family="{family}" font-size="{num(r, 8, 36)}"{anchor}{p}>{inner}</text>'
+
+
 def shape(r):
-    k = r.randrange(8)
+    k = r.randrange(9)
     p = presentation(r)
+    if k == 8:
+        return text_element(r, p)
     if k == 0:
         return f'<rect x="{num(r, 0, 80)}" y="{num(r, 0, 80)}" width="{num(r, 1, 60)}" height="{num(r, 1, 60)}"' + \
                (f' rx="{num(r, 0, 9)}"' if r.random() < 0.4 else "") + (f' ry="{num(r, 0, 9)}"' if r.random() < 0.3 else "") + p + "/>"
@@ -208,7 +239,7 @@ def document(r):
             f'<clipPath id="c1" clipPathUnits="objectBoundingBox"><rect x="0.1" y="0.2" width="0.7" height="0.6"/></clipPath>'
             f'<mask id="m0">{shape(r)}{shape(r)}</mask>'
             f'<pattern id="p0" width="{num(r, 4, 30)}" height="{num(r, 4, 30)}" patternUnits="userSpaceOnUse">{shape(r)}</pattern>'
-            f'<g id="sym">{shape(r)}</g>' + filters(r))
+            f'<g id="sym">{shape(r)}</g>' + filters(r) + FONT)
     head = r.choice(['width="120" height="90"', 'viewBox="0 0 150 100"', 'width="3cm" height="20mm" viewBox="-5 -5 130 95"', 'width="200" height="100" viewBox="0 0 100 50"'])
     return f'<svg xmlns="http://www.w3.org/2000/svg" {head}><defs>{defs}</defs>' + "".join(group(r, 0) for _ in range(r.randrange(1, 4))) + "</svg>"
 

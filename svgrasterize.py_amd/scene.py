@@ -448,7 +448,8 @@ def _render_run(leaves, viewport, linear_rgb):
     ctx = _abi.Context.get()
     batch = build_batch(leaves, viewport, ctx)
     st = batch.plan()
-    boxes = [b for b in effective_bboxes(leaves, batch.bboxes()) if b is not None]
+    eff = effective_bboxes(leaves, batch.bboxes())
+    boxes = [b for b in eff if b is not None]
     if not boxes:
         batch.destroy()
         return None
@@ -472,11 +473,15 @@ def _render_run(leaves, viewport, linear_rgb):
     else:
         out = canvas
     layer = Layer._from_device(out, shape, (ur0, uc0), True, linear_rgb)
-    painted = np.array([leaf[4] != 1 for leaf in leaves])
+    # The group's hull merges the hulls of the children that drew something (S:676-684): a leaf whose clipped bbox is
+    # empty returned None there and does not count; one that is partly visible counts with ALL its lines (S:993).  Clip
+    # paths do not belong to it (S:715 returns the target's hull).
+    in_hull = np.zeros(len(leaves), dtype=bool)
+    in_hull[[i for i, leaf in enumerate(leaves) if leaf[4] != 1]] = [b is not None for b in eff]
 
     def hull_points():
-        edges, edge_path = batch.all_edges()  # (also what hangs out of the viewport: the reference's hull has it, S:993)
-        return edges[painted[edge_path]]  # the clip paths do not belong to the hull (S:715 returns the target's)
+        edges, edge_path = batch.all_edges()
+        return edges[in_hull[edge_path]]
 
     return layer, ConvexHull(_source=hull_points)
 
