@@ -914,8 +914,11 @@ def gen_svgfuzz(ref) -> None:
     import warnings
     import fuzz_svg_frontend as fuzz
     out, meta = {}, []
-    seed = 0
-    while len(meta) < 40 and seed < 4000:
+    # (SVGFUZZ_START / SVGFUZZ_COUNT / SVGFUZZ_OUT: ad-hoc sets for hunting, written outside tests/golden)
+    seed = int(os.environ.get("SVGFUZZ_START", "0"))
+    want_n = int(os.environ.get("SVGFUZZ_COUNT", "40"))
+    last_seed = seed + 100 * want_n
+    while len(meta) < want_n and seed < last_seed:
         r = random.Random(seed)
         seed += 1
         text = fuzz.document(r)
@@ -972,7 +975,10 @@ def gen_svgfuzz(ref) -> None:
                 crop = None
         meta.append(dict(seed=seed - 1, width=width, size=[h, w], text=text, crop=crop))
     out["meta"] = np.array(json.dumps(meta))
-    save("svg_fuzz_kat.npz", **out)
+    if os.environ.get("SVGFUZZ_OUT"):
+        np.savez_compressed(os.environ["SVGFUZZ_OUT"], **out)
+    else:
+        save("svg_fuzz_kat.npz", **out)
     print("  svg fuzz seeds:", [m["seed"] for m in meta])
 
 
