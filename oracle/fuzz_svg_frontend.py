@@ -228,6 +228,22 @@ def filters(r):
     return shadow + '<filter id="f1">' + "".join(ops) + "</filter>"
 
 
+def pattern(r):
+    kind = r.randrange(4)
+    extra = f' patternTransform="rotate({num(r, -60, 60)}) scale({num(r, 0.6, 1.6)})"' if r.random() < 0.3 else ""
+    if kind == 0:
+        return f'<pattern id="p0" width="{num(r, 4, 30)}" height="{num(r, 4, 30)}" patternUnits="userSpaceOnUse"{extra}>{shape(r)}</pattern>'
+    if kind == 1:
+        return (f'<pattern id="p0" x="{num(r, 0, 9)}" y="{num(r, 0, 9)}" width="{num(r, 6, 30)}" height="{num(r, 6, 30)}" patternUnits="userSpaceOnUse"'
+                f' viewBox="0 0 {num(r, 4, 40)} {num(r, 4, 40)}"{extra}><rect width="{num(r, 1, 20)}" height="{num(r, 1, 20)}" fill="{r.choice(COLORS[:9])}"/>'
+                f'<circle cx="{num(r, 0, 20)}" cy="{num(r, 0, 20)}" r="{num(r, 1, 9)}" fill="{r.choice(COLORS[:9])}"/></pattern>')
+    if kind == 2:
+        return (f'<pattern id="p0" width="{num(r, 0.1, 0.6)}" height="{num(r, 0.1, 0.6)}"{extra}><rect width="{num(r, 2, 12)}" height="{num(r, 2, 12)}" fill="{r.choice(COLORS[:9])}"/>'
+                f'<circle cx="{num(r, 0, 14)}" cy="{num(r, 0, 14)}" r="{num(r, 1, 6)}" fill="{r.choice(COLORS[:9])}"/></pattern>')
+    return (f'<pattern id="p0" width="{num(r, 0.2, 0.6)}" height="{num(r, 0.2, 0.6)}" patternContentUnits="objectBoundingBox">'
+            f'<rect width="{num(r, 0.05, 0.4)}" height="{num(r, 0.05, 0.4)}" fill="{r.choice(COLORS[:9])}"/></pattern>')
+
+
 def document(r):
     units = r.choice(["", ' gradientUnits="userSpaceOnUse"'])
     defs = (f'<linearGradient id="g0" x1="{num(r, 0, 1)}" y1="{num(r, 0, 1)}" x2="{num(r, 0, 1)}" y2="{num(r, 0, 1)}"'
@@ -238,7 +254,7 @@ def document(r):
             f'<clipPath id="c0"{r.choice(CLIP_RULES)}>{shape(r)}</clipPath>'
             f'<clipPath id="c1" clipPathUnits="objectBoundingBox"><rect x="0.1" y="0.2" width="0.7" height="0.6"/></clipPath>'
             f'<mask id="m0">{shape(r)}{shape(r)}</mask>'
-            f'<pattern id="p0" width="{num(r, 4, 30)}" height="{num(r, 4, 30)}" patternUnits="userSpaceOnUse">{shape(r)}</pattern>'
+            + pattern(r) +
             f'<g id="sym">{shape(r)}</g>' + filters(r) + FONT)
     head = r.choice(['width="120" height="90"', 'viewBox="0 0 150 100"', 'width="3cm" height="20mm" viewBox="-5 -5 130 95"', 'width="200" height="100" viewBox="0 0 100 50"'])
     return f'<svg xmlns="http://www.w3.org/2000/svg" {head}><defs>{defs}</defs>' + "".join(group(r, 0) for _ in range(r.randrange(1, 4))) + "</svg>"
