@@ -973,7 +973,19 @@ def gen_svgfuzz(ref) -> None:
                     crop = [r0, c0, rows, cols]
             except (Exception, fuzz.TooSlow):  # noqa: BLE001
                 crop = None
-        meta.append(dict(seed=seed - 1, width=width, size=[h, w], text=text, crop=crop))
+        free = None
+        if k % 3 == 2:  # every third document also without a viewport: the layer grows to whatever the content reaches
+            try:
+                with warnings.catch_warnings(), fuzz.time_limit(60):
+                    warnings.simplefilter("ignore")
+                    res = scene.render(ref.Transform().matrix(0, 1, 0, 1, 0, 0), linear_rgb=False)
+                    if res is not None and res[0].image.shape[0] * res[0].image.shape[1] <= 600 * 600:
+                        cl = res[0].convert(pre_alpha=True, linear_rgb=False)
+                        out[f"{k}_layer_free"] = cl.image.astype(np.float32)
+                        free = [int(cl.offset[0]), int(cl.offset[1])]
+            except (Exception, fuzz.TooSlow):  # noqa: BLE001
+                free = None
+        meta.append(dict(seed=seed - 1, width=width, size=[h, w], text=text, crop=crop, free=free))
     out["meta"] = np.array(json.dumps(meta))
     if os.environ.get("SVGFUZZ_OUT"):
         np.savez_compressed(os.environ["SVGFUZZ_OUT"], **out)

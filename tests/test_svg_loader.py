@@ -252,6 +252,13 @@ def test_generated_documents_render_like_the_reference():
             if res is not None:
                 win = res[0].convert(pre_alpha=True, linear_rgb=False).translate(-r0, -c0).to_canvas_f32(rows, cols)
             assert_f32_1ulp(win, z[f"{k}_canvas_crop"].astype(np.float64), what=f"generated document {m['seed']}, window {m['crop']}")
+        if m.get("free"):  # ... and without a viewport: the layer grows to whatever the content reaches
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                res = scene.render(S.Transform().matrix(0, 1, 0, 1, 0, 0), linear_rgb=False)
+            free = res[0].convert(pre_alpha=True, linear_rgb=False)
+            assert [int(free.offset[0]), int(free.offset[1])] == m["free"] and free.image.shape == z[f"{k}_layer_free"].shape
+            assert_f32_1ulp(free.image.astype(np.float32), z[f"{k}_layer_free"].astype(np.float64), what=f"generated document {m['seed']}, no viewport")
         if f"{k}_canvas_lin" in z.files:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
