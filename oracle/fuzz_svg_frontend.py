@@ -199,7 +199,7 @@ def group(r, depth):
 
 def stops(r):
     return "".join(f'<stop offset="{r.choice([num(r, 0, 1), str(r.randrange(0, 101)) + "%"])}" stop-color="{r.choice(COLORS[:9])}"' +
-                   (f' stop-opacity="{r.uniform(0.1, 1):.2f}"' if r.random() < 0.3 else "") + "/>" for _ in range(r.randrange(0, 5)))
+                   (f' stop-opacity="{r.uniform(0.1, 1):.2f}"' if r.random() < 0.3 else "") + "/>" for _ in range(r.choice([0, 1, 2, 2, 3, 3, 4, 6, 9])))
 
 
 SPREADS = ["", ' spreadMethod="reflect"', ' spreadMethod="repeat"']
@@ -246,14 +246,22 @@ def pattern(r):
 
 def document(r):
     units = r.choice(["", ' gradientUnits="userSpaceOnUse"'])
-    defs = (f'<linearGradient id="g0" x1="{num(r, 0, 1)}" y1="{num(r, 0, 1)}" x2="{num(r, 0, 1)}" y2="{num(r, 0, 1)}"'
+    lin_units = r.random() < 0.3
+    lin_geo = (f' gradientUnits="userSpaceOnUse" x1="{num(r, 0, 90)}" y1="{num(r, 0, 90)}" x2="{num(r, 0, 90)}" y2="{num(r, 0, 90)}"' if lin_units else
+               f' x1="{num(r, 0, 1)}" y1="{num(r, 0, 1)}" x2="{num(r, 0, 1)}" y2="{num(r, 0, 1)}"')
+    lin_tr = r.choice(["", "", f' gradientTransform="skewX({num(r, -30, 30)}) scale({num(r, 0.5, 1.5)})"', f' gradientTransform="rotate({num(r, 0, 90)} 0.5 0.5)"'])
+    rad_extra = r.choice(SPREADS) + r.choice(["", "", ' color-interpolation="linearRGB"', f' fr="{num(r, 0, 4)}"'])
+    mask_units = r.choice(["", "", ' maskContentUnits="objectBoundingBox"'])
+    mask_body = (f'<rect x="{num(r, 0, 0.5)}" y="{num(r, 0, 0.5)}" width="{num(r, 0.2, 0.9)}" height="{num(r, 0.2, 0.9)}" fill="{r.choice(["white", "#888", "red"])}"/>'
+                 if mask_units else shape(r) + shape(r))
+    defs = (f'<linearGradient id="g0"{lin_geo}{lin_tr}'
             f'{r.choice(SPREADS)}>{stops(r)}</linearGradient>'
             f'<radialGradient id="g1"{units} cx="{num(r, 0, 90)}" cy="{num(r, 0, 90)}" r="{num(r, 5, 60)}"'
             + (f' fx="{num(r, 0, 90)}" fy="{num(r, 0, 90)}"' if r.random() < 0.5 else "")
-            + (f' gradientTransform="rotate({num(r, 0, 90)})"' if r.random() < 0.4 else "") + f">{stops(r)}</radialGradient>"
+            + (f' gradientTransform="rotate({num(r, 0, 90)})"' if r.random() < 0.4 else "") + rad_extra + f">{stops(r)}</radialGradient>"
             f'<clipPath id="c0"{r.choice(CLIP_RULES)}>{shape(r)}</clipPath>'
             f'<clipPath id="c1" clipPathUnits="objectBoundingBox"><rect x="0.1" y="0.2" width="0.7" height="0.6"/></clipPath>'
-            f'<mask id="m0">{shape(r)}{shape(r)}</mask>'
+            f'<mask id="m0"{mask_units}>{mask_body}</mask>'
             + pattern(r) +
             f'<g id="sym">{shape(r)}</g>' + filters(r) + FONT)
     head = r.choice(['width="120" height="90"', 'viewBox="0 0 150 100"', 'width="3cm" height="20mm" viewBox="-5 -5 130 95"', 'width="200" height="100" viewBox="0 0 100 50"'])
