@@ -356,7 +356,9 @@ def path_stroke(seg_types, seg_params, subpath_sizes, width: float, linecap: int
     rc = lib.svgr_path_stroke(seg_types.ctypes.data_as(_P), seg_params.ctypes.data_as(_P), subpath_sizes.ctypes.data_as(_P),
                               len(subpath_sizes), float(width), int(linecap), int(linejoin), C.byref(out))
     if rc != 0:
-        raise ValueError(f"svgr_path_stroke failed ({rc}): unsupported segment type or bad cap / join")
+        why = {-1: "unsupported segment type or bad cap / join", -3: "out of memory"}.get(
+            rc, "the offset of a cubic does not converge (degenerate control points)")
+        raise ValueError(f"svgr_path_stroke failed ({rc}): {why}")
     try:
         n, ns = C.c_int64(), C.c_int64()
         lib.svgr_stroke_out_counts(out, C.byref(n), C.byref(ns))

@@ -181,11 +181,20 @@ static bool should_split(const Curve& c) {
 }
 
 // bezier3_offset (S:2113-2179)
-static void cubic_offset(const Curve& cubic, double distance, std::vector<Curve>& outputs_all) {
+// Returns false when the subdivision does not converge: a piece that keeps asking to be split while producing no
+// offsetable line (e.g. a cubic whose first three points coincide) is halved for ever -- the reference spins on such a
+// curve (S:2141-2145); here the stroke is refused after 65 536 pieces.
+static bool cubic_offset(const Curve& cubic, double distance, std::vector<Curve>& outputs_all) {
     std::vector<Curve> outputs, stack{cubic};
+    int budget = 1 << 16;
     while (!stack.empty()) {
+        if (--budget < 0) return false;
         const Curve c = stack.back();
         stack.pop_back();
+        // A piece whose consecutive points all coincide (to the tolerance below) has no offsetable line, and neither has
+        // any part of it: it contributes nothing, however often the reference goes on halving it.  Dropping it here is
+        // what makes a cubic with coincident leading control points terminate.
+        if (allclose(c.p[0], c.p[1]) && allclose(c.p[1], c.p[2]) && allclose(c.p[2], c.p[3])) continue;
         if (should_split(c) && outputs.size() < 16) {
             Curve l, r;
             split(c, l, r);
@@ -221,6 +230,7 @@ static void cubic_offset(const Curve& cubic, double distance, std::vector<Curve>
         }
     }
     outputs_all.insert(outputs_all.end(), outputs.begin(), outputs.end());
+    return true;
 }
 
 static Curve reversed(const Curve& c) {
@@ -249,8 +259,23 @@ struct svgr_stroke_out {
 
 extern "C" {
 
+static int path_stroke_impl(const int32_t* seg_types, const double* seg_params, const int32_t* subpath_sizes, int64_t n_subpaths,
+                            double width, int linecap, int linejoin, svgr_stroke_out** out);
+
+// No exception crosses the C ABI: running out of memory is a status like any other.
 int svgr_path_stroke(const int32_t* seg_types, const double* seg_params, const int32_t* subpath_sizes, int64_t n_subpaths,
                      double width, int linecap, int linejoin, svgr_stroke_out** out) {
+    try {
+        return path_stroke_impl(seg_types, seg_params, subpath_sizes, n_subpaths, width, linecap, linejoin, out);
+    } catch (const std::bad_alloc&) {
+        return SVGR_E_NOMEM;
+    } catch (...) {
+        return SVGR_E_INVALID;
+    }
+}
+
+static int path_stroke_impl(const int32_t* seg_types, const double* seg_params, const int32_t* subpath_sizes, int64_t n_subpaths,
+                            double width, int linecap, int linejoin, svgr_stroke_out** out) {
     if (!out || n_subpaths < 0 || (n_subpaths > 0 && (!seg_types || !seg_params || !subpath_sizes))) return SVGR_E_INVALID;
     if (linecap < SVGR_CAP_BUTT || linecap > SVGR_CAP_SQUARE || linejoin < SVGR_JOIN_MITER || linejoin > SVGR_JOIN_BEVEL) return SVGR_E_INVALID;
     svgr_stroke_out* res = new (std::nothrow) svgr_stroke_out();
@@ -277,8 +302,10 @@ int svgr_path_stroke(const int32_t* seg_types, const double* seg_params, const i
                 Curve c;
                 c.n = 4;
                 for (int j = 0; j < 4; ++j) c.p[j] = Pt{q[2 * j], q[2 * j + 1]};
-                cubic_offset(c, dist, forward);
-                cubic_offset(c, -dist, backward);
+                if (!cubic_offset(c, dist, forward) || !cubic_offset(c, -dist, backward)) {
+                    delete res;
+                    return SVGR_E_OVERFLOW;  // the offset of this cubic does not converge (degenerate control points)
+                }
             } else if (t == SVGR_PATH_UNCLOSED) {
                 continue;
             } else {

@@ -34,8 +34,9 @@ def _arc_center(p0, p1, rx, ry, rot_deg, large, sweep):
     """
     if rx == 0 or ry == 0:
         return None
-    # coincident end points (np.allclose: |a - b| <= 1e-8 + 1e-5 |b| on both coordinates): the arc is omitted
-    if abs(p0[0] - p1[0]) <= 1e-8 + 1e-5 * abs(p1[0]) and abs(p0[1] - p1[1]) <= 1e-8 + 1e-5 * abs(p1[1]):
+    # identical end points: the arc is omitted (SVG F.6.2; the reference's formula divides 0 by 0 there).  Only exact
+    # identity counts: an arc between points 1e-9 apart is still an arc in the reference, and is one here.
+    if p0[0] == p1[0] and p0[1] == p1[1]:
         return None
     rx, ry = abs(rx), abs(ry)
     p0, p1 = np.asarray(p0, dtype=np.float64), np.asarray(p1, dtype=np.float64)

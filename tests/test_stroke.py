@@ -113,3 +113,18 @@ def test_scene_stroke_nodes_batched_and_per_node():
     m1 = mine[0].render(tr, mask_only=True, viewport=vp)
     m1_ref = ref[0].render(tr, mask_only=True, viewport=vp)
     np.testing.assert_allclose(m1[0].image, m1_ref[0].image, atol=1e-9)
+
+
+def test_degenerate_cubic_terminates():
+    """A cubic whose first three points coincide asks to be split again and again without producing an offsetable piece;
+    in the reference the halving only ends when rounding makes the piece collapse (S:2141-2145).  The native stroker
+    drops a piece with no offsetable line at once: same outline, guaranteed termination, and no exception or
+    allocation failure ever crosses the C ABI."""
+    import svgrasterize_amd as S
+
+    for d in ("M39.468,79.5577 C39.468,79.5577 39.468,79.5577 40.8281,77.7108 L10,10",
+              "M5,5 C5,5 5,5 5,5 L9,9", "M1,1 C1,1 1,1 1,1 z", "M0,0 C0,0 1e-12,1e-12 3,4"):
+        out = S.Path.from_svg(d).stroke(1.0, "round", "round")
+        for sub in out.subpaths:
+            for _kind, pts in sub:
+                assert np.isfinite(np.asarray(pts, dtype=float)).all(), d
