@@ -923,6 +923,8 @@ def gen_svgfuzz(ref) -> None:
         seed += 1
         text = fuzz.document(r)
         width = r.choice([None, None, 77, 300])
+        if os.environ.get("SVGFUZZ_WIDTH"):  # (hunting at larger sizes: more bands and tiles per shape)
+            width = int(os.environ["SVGFUZZ_WIDTH"])
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             try:
@@ -931,7 +933,7 @@ def gen_svgfuzz(ref) -> None:
                     if scene is None or size is None:
                         continue
                     w, h = int(size[0]), int(size[1])
-                    if w * h > 400 * 400 or w < 8 or h < 8:
+                    if w * h > int(os.environ.get("SVGFUZZ_MAXPX", str(400 * 400))) or w < 8 or h < 8:
                         continue
                     res = scene.render(ref.Transform().matrix(0, 1, 0, 1, 0, 0), viewport=[0, 0, h, w], linear_rgb=False)
                     if res is None:
