@@ -59,3 +59,39 @@ def test_random_scene_vs_oracle(S, seed):
         assert (int(bb[p, 0]), int(bb[p, 1])) == (int(off[0]), int(off[1])) and tuple(mask.shape[:2]) == (int(bb[p, 2]), int(bb[p, 3]))
         got = flat[int(offs[p]): int(offs[p + 1])].reshape(int(bb[p, 2]), int(bb[p, 3]))
         assert_close64(got, np.asarray(mask).reshape(got.shape), atol=1e-11, what=f"seed {seed} mask {p}")
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_random_affine_per_path_vs_oracle(S, seed):
+    """Every path under its own random affine map (rotation, skew, non-uniform scale, translation) applied on the device
+    (fma form of S:531-534), against the oracle fed with the same points transformed by numpy on the host."""
+    from oracle import oracle as orc
+    from svgrasterize_amd import _abi, synth
+
+    rng = np.random.default_rng(5000 + seed)
+    size = int(rng.integers(60, 600))
+    n = int(rng.integers(1, 80))
+    sc = synth.make_scene(size, n, seed=synth.SEED + 101 * seed)
+    m6 = np.zeros((n, 6))
+    pres = np.zeros_like(sc["segs"])
+    for p in range(n):
+        ang, shear = rng.uniform(0, 2 * np.pi), rng.uniform(-0.6, 0.6)
+        sx, sy = rng.uniform(0.4, 1.8, 2)
+        lin = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]) @ np.array([[1, shear], [0, 1]]) @ np.diag([sx, sy])
+        c = np.array([size / 2, size / 2])
+        t = c - lin @ c + rng.uniform(-0.2, 0.2, 2) * size
+        user = np.array([[lin[0, 0], lin[0, 1], t[0]], [lin[1, 0], lin[1, 1], t[1]], [0, 0, 1]])
+        tr = S.Transform().matrix(0, 1, 0, 1, 0, 0) @ S.Transform(user)  # presentation space = swap . user map
+        m6[p] = tr.m6()
+        s0, s1 = int(sc["path_seg_off"][p]), int(sc["path_seg_off"][p + 1])
+        pres[s0:s1] = tr(sc["segs"][s0:s1].reshape(-1, 2)).reshape(-1, 8)
+    rows, cols = int(rng.integers(16, size + 40)), int(rng.integers(16, size + 40))
+    vp = (int(rng.integers(-40, size // 2)), int(rng.integers(-40, size // 2)), rows, cols)
+    ref, P, _E = orc.render_solid(pres, sc["seg_kind"], sc["path_seg_off"], sc["path_rule"], sc["path_paint"], vp, clip01=True)
+    ctx = S.Context.get()
+    batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], m6, sc["path_rule"], sc["path_paint"], viewport=vp)
+    st = batch.plan()
+    assert st.path_pixels == P
+    out = ctx.alloc(rows * cols * 32)
+    batch.render(out, _abi.OUT_CANVAS_F64, _abi.RENDER_CLIP01)
+    assert_close64(out.download((rows, cols, 4), np.float64), ref, atol=1e-10, what=f"affine seed {seed}")
