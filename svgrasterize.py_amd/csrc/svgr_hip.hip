@@ -2047,6 +2047,19 @@ static int check_dev_err(svgr_batch* b, int* capacity_bits = nullptr, bool whole
     return 0;
 }
 
+// No C++ exception crosses the ABI (std::vector / std::map growth on the host can throw): the entry points that allocate
+// host memory run their body through this guard.
+template <class F>
+static int abi_guard(const char* what, F&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(SVGR_E_NOMEM, "%s: out of host memory", what);
+    } catch (...) {
+        return fail(SVGR_E_INVALID, "%s: unexpected C++ exception", what);
+    }
+}
+
 // ======================================================================================
 // C ABI
 // ======================================================================================
@@ -2192,7 +2205,12 @@ int svgr_download(svgr_ctx* ctx, const svgr_buf* src, size_t src_off, void* host
 // ---------------------------------------------------------------------------------------------
 // batch
 // ---------------------------------------------------------------------------------------------
+static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch** out);
 int svgr_batch_create(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch** out) {
+    return abi_guard("svgr_batch_create", [&]() { return batch_create_impl(ctx, d, out); });
+}
+
+static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch** out) {
     if (!ctx || !d || !out) return fail(SVGR_E_INVALID, "bad arguments");
     *out = nullptr;
     if (d->n_paths <= 0 || d->n_segs < 0) return fail(SVGR_E_INVALID, "batch needs at least one path");
@@ -2344,7 +2362,12 @@ static int plan_speculative(svgr_batch* b) {
     return 1;
 }
 
+static int batch_plan_impl(svgr_batch* b);
 int svgr_batch_plan(svgr_batch* b) {
+    return abi_guard("svgr_batch_plan", [&]() { return batch_plan_impl(b); });
+}
+
+static int batch_plan_impl(svgr_batch* b) {
     if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
     HIPCHK(hipSetDevice(b->ctx->device));
     b->planned = false;
@@ -2457,7 +2480,12 @@ int svgr_batch_get_edges(const svgr_batch* b, double* edges, int32_t* edge_path,
 // the viewport keeps its full bounding box.  (The render keeps only edges that can reach the viewport's rows.)
 // Two flatten passes without row culling into scratch shards: count, then emit.  The batch's own plan stays valid; its
 // counter arena is left dirty, so the next render starts from a fresh geometry pass.
+static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path, int64_t cap, int64_t* n_out);
 int svgr_batch_all_edges(svgr_batch* b, double* edges, int32_t* edge_path, int64_t cap, int64_t* n_out) {
+    return abi_guard("svgr_batch_all_edges", [&]() { return batch_all_edges_impl(b, edges, edge_path, cap, n_out); });
+}
+
+static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path, int64_t cap, int64_t* n_out) {
     if (!b || !n_out) return fail(SVGR_E_INVALID, "bad arguments");
     HIPCHK(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
@@ -2521,7 +2549,12 @@ static int get_event(svgr_batch* b, hipEvent_t* e) {
     return 0;
 }
 
+static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags);
 int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags) {
+    return abi_guard("svgr_batch_render", [&]() { return batch_render_impl(b, out, out_kind, flags); });
+}
+
+static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags) {
     if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
     if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan must run before svgr_batch_render");
     if (out_kind < 0 || out_kind > 4) return fail(SVGR_E_INVALID, "unknown output kind %d", out_kind);
