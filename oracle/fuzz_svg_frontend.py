@@ -129,7 +129,7 @@ def presentation(r):
         attrs["clip-path"] = r.choice(["url(#c0)", "url(#c1)"])
     if r.random() < 0.05:
         attrs["mask"] = "url(#m0)"
-    if r.random() < 0.07:
+    if r.random() < (0.3 if BIG_FILTERS else 0.07):
         attrs["filter"] = r.choice(["url(#f0)", "url(#f1)"])
     if r.random() < 0.3 and attrs:  # move some of them into a style attribute
         keys = r.sample(sorted(k for k in attrs if k != "transform"), k=min(2, len([k for k in attrs if k != "transform"])))
@@ -211,9 +211,13 @@ SPREADS = ["", ' spreadMethod="reflect"', ' spreadMethod="repeat"']
 CLIP_RULES = ["", ' clip-rule="evenodd"']
 
 
+BIG_FILTERS = os.environ.get("FUZZ_BIGFILTER") == "1"  # blurs, offsets and morphology radii as large as the shapes
+
+
 def filters(r):
-    shadow = (f'<filter id="f0"><feGaussianBlur in="SourceAlpha" stdDeviation="{num(r, 0.4, 3)}' + (f' {num(r, 0.4, 3)}' if r.random() < 0.4 else "") +
-              f'" result="b"/><feOffset in="b" dx="{num(r, -4, 4)}" dy="{num(r, -4, 4)}" result="o"/>'
+    s_hi, o_hi, m_hi = (25, 40, 12) if BIG_FILTERS else (3, 4, 2.5)
+    shadow = (f'<filter id="f0"><feGaussianBlur in="SourceAlpha" stdDeviation="{num(r, 0.4, s_hi)}' + (f' {num(r, 0.4, s_hi)}' if r.random() < 0.4 else "") +
+              f'" result="b"/><feOffset in="b" dx="{num(r, -o_hi, o_hi)}" dy="{num(r, -o_hi, o_hi)}" result="o"/>'
               '<feMerge><feMergeNode in="o"/><feMergeNode in="SourceGraphic"/></feMerge></filter>')
     ops = []
     for _ in range(r.randrange(1, 4)):
@@ -225,7 +229,7 @@ def filters(r):
         elif k == 2:
             ops.append('<feColorMatrix type="luminanceToAlpha"/>')
         elif k == 3:
-            ops.append(f'<feMorphology operator="{r.choice(["erode", "dilate"])}" radius="{num(r, 0.5, 2.5)}"/>')
+            ops.append(f'<feMorphology operator="{r.choice(["erode", "dilate"])}" radius="{num(r, 0.5, m_hi)}"/>')
         elif k == 4:
             ops.append(f'<feComposite in2="SourceGraphic" operator="{r.choice(["over", "in", "out", "atop", "xor"])}"/>')
         else:

@@ -211,9 +211,16 @@ class Layer:
         layer = self.convert(pre_alpha=True, linear_rgb=True)
         rows, cols = layer.height, layer.width
         x, y = int(x), int(y)
-        if x < 1 or y < 1 or x > rows or y > cols:
-            raise ValueError("morphology window does not fit the layer")
+        if x < 1 or y < 1 or x > rows + 1 or y > cols + 1:
+            raise ValueError("morphology window does not fit the layer")  # (the reference: negative dimensions, S:455-461)
         ctx = _abi.Context.get()
+        if x == rows + 1 or y == cols + 1:
+            # One more than the layer: the reference's strided view has a zero-length axis and the result is an empty image
+            # (S:455-466), i.e. the shape is eroded / dilated away.  Layers here hold at least one pixel: a transparent one.
+            shape = (max(rows - x + 1, 1), max(cols - y + 1, 1), 4)
+            out = ctx.alloc(shape[0] * shape[1] * 32)
+            out.zero()
+            return Layer._from_device(out, shape, layer.offset, pre_alpha=True, linear_rgb=True)
         shape = (rows - x + 1, cols - y + 1, 4)
         out = ctx.alloc(shape[0] * shape[1] * 32)
         src = layer._device()
