@@ -189,9 +189,12 @@ def shape(r):
     return f'<path d="{path_data(r)}"{p}/>'
 
 
+MANY = os.environ.get("FUZZ_MANY") == "1"  # dozens of shapes per group: long tile lists, many masks per pre-pass
+
+
 def group(r, depth):
     body = []
-    for _ in range(r.randrange(1, 5)):
+    for _ in range(r.randrange(12, 40) if MANY and depth == 0 else r.randrange(1, 5)):
         if depth < 3 and r.random() < 0.25:
             body.append(group(r, depth + 1))
         elif depth < 2 and r.random() < 0.08:
