@@ -231,7 +231,7 @@ typedef struct {
     int kind;            /* 1 linear, 2 radial (one circle), 3 radial with a focal circle                    */
     int spread;          /* 0 pad, 1 repeat, 2 reflect                                                       */
     int has_gt;          /* apply gt_m6 (gradientTransform inverse) after user_m6                            */
-    int n_stops;         /* 1..32                                                                            */
+    int n_stops;         /* >= 1; no cap (lists longer than 32 travel in a device buffer, S:1671-1683)        */
     int excl_enabled;    /* fradius != radius: exclude negative r(t) (S:1642-1644)                           */
     double user_m6[6];   /* pixel centre -> user space: rows 0-1 of transform.invert.m (S:1023-1027)          */
     double gt_m6[6];

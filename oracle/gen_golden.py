@@ -1050,6 +1050,99 @@ def gen_hostutil(ref) -> None:
     save("hostutil_kat.npz", **out)
 
 
+# --------------------------------------------------------------------------------------
+# module-level canvas functions (S:235-416) called directly on arrays
+# --------------------------------------------------------------------------------------
+def gen_canvasfn(ref) -> None:
+    from functools import partial
+
+    rng = np.random.default_rng(0xCA17A5)
+    out, meta = {}, []
+
+    def image(r, c, ch):
+        a = rng.uniform(0, 1, size=(r, c, 1))
+        a[rng.uniform(size=a.shape) < 0.25] = 0.0
+        a[rng.uniform(size=a.shape) < 0.25] = 1.0
+        return a if ch == 1 else np.concatenate([rng.uniform(0, 1, size=(r, c, 3)) * a, a], axis=-1)
+
+    modes = [ref.COMPOSE_OVER, ref.COMPOSE_OUT, ref.COMPOSE_IN, ref.COMPOSE_ATOP, ref.COMPOSE_XOR, (0.3, 0.5, 0.4, 0.05)]
+    for mode in modes:
+        for chd, chs in ((4, 4), (4, 1), (1, 4), (1, 1)):
+            i = len(meta)
+            d, s_ = image(7, 9, chd), image(7, 9, chs)
+            out[f"{i}_dst"], out[f"{i}_src"] = d, s_
+            out[f"{i}_out"] = ref.canvas_compose(mode, d, s_)
+            meta.append(dict(fn="compose", mode=list(mode) if isinstance(mode, tuple) else int(mode)))
+    for off in ((2, 3), (-3, -2), (9, 11), (40, 2), (-1, 10)):
+        i = len(meta)
+        base, over = image(12, 14, 4), image(6, 5, 4) * 1.5   # (> 1 so that the clip of the touched region shows)
+        out[f"{i}_base"], out[f"{i}_over"] = base.copy(), over
+        res = ref.canvas_merge_at(base, over, off)
+        out[f"{i}_out"] = base
+        meta.append(dict(fn="merge_at", offset=list(off), none=res is None))
+    for mode, full in ((ref.COMPOSE_OVER, False), (ref.COMPOSE_OVER, True), (ref.COMPOSE_XOR, True), (ref.COMPOSE_IN, True)):
+        i = len(meta)
+        layers = [(image(int(rng.integers(3, 9)), int(rng.integers(3, 9)), 4), (int(rng.integers(-4, 6)), int(rng.integers(-4, 6))))
+                  for _ in range(3)]
+        res, roff = ref.canvas_merge_union(layers, full=full, blend=partial(ref.canvas_compose, mode))
+        for j, (im, o) in enumerate(layers):
+            out[f"{i}_in{j}"] = im
+        out[f"{i}_out"] = res
+        meta.append(dict(fn="union", mode=int(mode), full=full, offsets=[list(o) for _, o in layers], offset=[int(v) for v in roff]))
+    for mode, ch0 in ((ref.COMPOSE_IN, 1), (ref.COMPOSE_OVER, 4), (ref.COMPOSE_IN, 4)):
+        i = len(meta)
+        layers = [(image(8, 9, ch0), (0, 1)), (image(7, 8, 4), (2, 0)), (image(9, 9, 4), (1, 2))]
+        res, roff = ref.canvas_merge_intersect(layers, blend=partial(ref.canvas_compose, mode))
+        for j, (im, o) in enumerate(layers):
+            out[f"{i}_in{j}"] = im
+        out[f"{i}_out"] = res
+        meta.append(dict(fn="intersect", mode=int(mode), offsets=[list(o) for _, o in layers], offset=[int(v) for v in roff]))
+    i = len(meta)
+    disjoint = [(image(3, 3, 4), (0, 0)), (image(3, 3, 4), (10, 10))]
+    meta.append(dict(fn="intersect_none", none=ref.canvas_merge_intersect(disjoint) is None))
+    canvas, tr = ref.canvas_create(5, 3, bg=np.array([0.1, 0.2, 0.3, 1.0]))
+    out["create_canvas"], out["create_m"] = canvas, np.asarray(tr.m, dtype=np.float64)
+    out["meta"] = np.array(json.dumps(meta))
+    save("canvasfn_kat.npz", **out)
+
+
+def gen_gradlong(ref) -> None:
+    """Gradients with more stops than the device code carries inline (the reference loops over any number, S:1671-1683)."""
+    rng = np.random.default_rng(0x57095)
+    out, meta = {}, []
+
+    def stops(n):
+        offs = np.sort(rng.uniform(0, 1, size=n))
+        offs[0], offs[-1] = 0.0, 1.0
+        offs[n // 2] = offs[n // 2 - 1]            # a repeated offset (a hard colour step)
+        cols = []
+        for _ in range(n):
+            a = rng.uniform(0.2, 1.0)
+            cols.append(np.concatenate([rng.uniform(0, 1, size=3) * a, [a]]))
+        return [(float(o), c) for o, c in zip(offs, cols)]
+
+    cases = [("linear", 33, "pad"), ("linear", 75, "reflect"), ("radial", 40, "repeat"), ("radial", 200, "pad")]
+    for kind, n, spread in cases:
+        st = stops(n)
+        if kind == "linear":
+            paint = ref.GradLinear(np.array([2.0, 3.0]), np.array([40.0, 25.0]), st, None, spread, False, None)
+        else:
+            paint = ref.GradRadial(np.array([20.0, 18.0]), 17.0, None, None, st, None, spread, False, None)
+        i = len(meta)
+        pts = rng.uniform(-10, 50, size=(400, 2))
+        out[f"{i}_off"] = np.array([o for o, _ in st])
+        out[f"{i}_rgba"] = np.array([c for _, c in st])
+        out[f"{i}_pts"] = pts
+        out[f"{i}_lin"] = paint.fill(pts, linear_rgb=True)
+        out[f"{i}_srgb"] = paint.fill(pts, linear_rgb=False)
+        path = ref.Path.from_svg("M3,2 H45 V38 H3 Z")
+        layer, _ = path.fill(ref.Transform().matrix(0, 1, 0, 1, 0, 0), paint, linear_rgb=False)
+        out[f"{i}_image"] = layer.image
+        meta.append(dict(kind=kind, n=n, spread=spread, offset=[int(v) for v in layer.offset]))
+    out["meta"] = np.array(json.dumps(meta))
+    save("gradlong_kat.npz", **out)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also render the full-size configs (slow)")
@@ -1082,6 +1175,10 @@ def main() -> None:
         gen_mask(ref)
     if todo("compose"):
         gen_compose(ref)
+    if todo("canvasfn"):
+        gen_canvasfn(ref)
+    if todo("gradlong"):
+        gen_gradlong(ref)
     if todo("gradient"):
         gen_gradient(ref)
     if todo("tiger"):

@@ -12,9 +12,10 @@ from .geometry import (  # noqa: F401
     PATH_FILL_NONZERO, PATH_FILL_EVENODD,
 )
 from .layer import (  # noqa: F401
-    Layer, canvas_to_png, COMPOSE_OVER, COMPOSE_OUT, COMPOSE_IN, COMPOSE_ATOP, COMPOSE_XOR,
+    Layer, canvas_to_png, canvas_create, canvas_compose, canvas_merge_at, canvas_merge_union, canvas_merge_intersect,
+    CANVAS_COMPOSE_OVER, COMPOSE_OVER, COMPOSE_OUT, COMPOSE_IN, COMPOSE_ATOP, COMPOSE_XOR,
 )
-from .paint import GradLinear, GradRadial  # noqa: F401
+from .paint import GradLinear, GradRadial, Pattern  # noqa: F401
 from .filters import (  # noqa: F401
     Filter, blur_kernel, COLOR_MATRIX_LUM, FE_SOURCE_ALPHA, FE_SOURCE_GRAPHIC, FE_BLEND, FE_COLOR_MATRIX, FE_COMPOSITE,
     FE_GAUSSIAN_BLUR, FE_MERGE, FE_MORPHOLOGY, FE_OFFSET,

@@ -162,10 +162,10 @@ struct DevPool {
         while (c < n) c += c < (1u << 20) ? c : c / 4;  // x2 up to 1 MiB, then +25 %
         return c;
     }
-    hipError_t alloc(void** out, size_t bytes) {
+    // `dev` = the device the block is for (the caller has made it current); -1: whatever is current
+    hipError_t alloc(void** out, size_t bytes, int dev = -1) {
         const size_t c = size_class(bytes ? bytes : 1);
-        int dev = 0;
-        (void)hipGetDevice(&dev);
+        if (dev < 0) (void)hipGetDevice(&dev);
         {
             std::lock_guard<std::mutex> lk(mu);
             auto& free_blocks = free_by_dev[dev];
@@ -178,8 +178,8 @@ struct DevPool {
             }
         }
         hipError_t e = hipMalloc(out, c);
-        if (e != hipSuccess) {  // give the cache back to the driver and retry once
-            trim();
+        if (e != hipSuccess) {  // give this device's cache back to the driver and retry once
+            trim(dev);
             e = hipMalloc(out, c);
         }
         if (e == hipSuccess) {
@@ -202,14 +202,15 @@ struct DevPool {
         free_by_dev[it->second.second].emplace(it->second.first, p);
         cached_bytes += it->second.first;
     }
-    void trim() {
+    // give the cached blocks of device `dev` back to the driver (other devices' caches belong to other contexts)
+    void trim(int dev) {
         std::vector<void*> blocks;
         {
             std::lock_guard<std::mutex> lk(mu);
-            for (auto& d : free_by_dev)
-                for (auto& b : d.second) { blocks.push_back(b.second); cap_of.erase(b.second); }
-            free_by_dev.clear();
-            cached_bytes = 0;
+            auto d = free_by_dev.find(dev);
+            if (d == free_by_dev.end()) return;
+            for (auto& b : d->second) { blocks.push_back(b.second); cached_bytes -= b.first; cap_of.erase(b.second); }
+            free_by_dev.erase(d);
         }
         for (void* b : blocks) (void)hipFree(b);
     }
@@ -1679,7 +1680,7 @@ __global__ void k_to_rgba8(uchar4* __restrict__ dst, const double4* __restrict__
 // --------------------------------------------------------------------------------------
 // gradients (S:1021-1047, 1544-1695): image = gradient(pixel centre) * mask
 // --------------------------------------------------------------------------------------
-constexpr int GRAD_MAX_STOPS = 32;
+constexpr int GRAD_MAX_STOPS = 32;   // stops carried inside the kernel argument; longer lists travel in a device buffer
 struct GradDev {
     int kind, spread, has_gt, n_stops;
     int excl_enabled, pad0, pad1, pad2;
@@ -1689,6 +1690,7 @@ struct GradDev {
     double fcenter[2], fradius, cd[2], rd, a, frad_rd, frad2, excl_thresh;
     double stop_off[GRAD_MAX_STOPS];
     double stop_rgba[GRAD_MAX_STOPS][4];
+    const double* ext_stops;  // n_stops > GRAD_MAX_STOPS: {offsets[n], rgba[n][4]} in device memory (the reference has no cap, S:1671-1683)
 };
 
 // position of pixel (i, j) of the layer in gradient space: grad_pixels (S:1653-1658), user transform
@@ -1769,17 +1771,19 @@ __global__ void k_gradient_fill(const GradDev g, const double* __restrict__ pts,
     // grad_interpolate, S:1671-1683
     double col[4] = {0.0, 0.0, 0.0, 0.0};
     const int n = g.n_stops;
-    if (offset <= g.stop_off[0]) {
-        for (int k = 0; k < 4; ++k) col[k] = g.stop_rgba[0][k];
+    const double* const soff = g.ext_stops ? g.ext_stops : g.stop_off;               // (wave-uniform: scalar loads either way)
+    const double* const srgba = g.ext_stops ? g.ext_stops + n : &g.stop_rgba[0][0];
+    if (offset <= soff[0]) {
+        for (int k = 0; k < 4; ++k) col[k] = srgba[k];
     }
-    if (offset > g.stop_off[n - 1]) {
-        for (int k = 0; k < 4; ++k) col[k] = g.stop_rgba[n - 1][k];
+    if (offset > soff[n - 1]) {
+        for (int k = 0; k < 4; ++k) col[k] = srgba[4 * (n - 1) + k];
     }
     for (int s = 0; s + 1 < n; ++s) {
-        double o0 = g.stop_off[s], o1 = g.stop_off[s + 1];
+        double o0 = soff[s], o1 = soff[s + 1];
         if (offset > o0 && offset <= o1) {
             double ratio = (offset - o0) / (o1 - o0);
-            for (int k = 0; k < 4; ++k) col[k] = col[k] + ((1 - ratio) * g.stop_rgba[s][k] + ratio * g.stop_rgba[s + 1][k]);
+            for (int k = 0; k < 4; ++k) col[k] = col[k] + ((1 - ratio) * srgba[4 * s + k] + ratio * srgba[4 * (s + 1) + k]);
         }
     }
     if (masked) col[0] = col[1] = col[2] = col[3] = 0.0;
@@ -2104,17 +2108,18 @@ int svgr_shutdown(svgr_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    g_pool.trim();
+    g_pool.trim(ctx->device);
     delete ctx;
     return 0;
 }
 
 int svgr_set_stream(svgr_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(SVGR_E_INVALID, "ctx is NULL");
-    if (ctx->own_stream && ctx->stream) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamDestroy(ctx->stream);
-    }
+    HIPCHK(hipSetDevice(ctx->device));
+    // The block cache hands a freed block to the next caller on the strength of stream order alone, so the outgoing
+    // stream -- owned or the caller's -- must have drained before work is enqueued on another one.
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
     return 0;
@@ -2122,6 +2127,7 @@ int svgr_set_stream(svgr_ctx* ctx, void* hip_stream) {
 
 int svgr_sync(svgr_ctx* ctx) {
     if (!ctx) return fail(SVGR_E_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
     return 0;
@@ -2139,7 +2145,7 @@ int svgr_buf_alloc(svgr_ctx* ctx, size_t bytes, svgr_buf** out) {
     svgr_buf* b = new (std::nothrow) svgr_buf();
     if (!b) return fail(SVGR_E_NOMEM, "out of host memory");
     HIPCHK(hipSetDevice(ctx->device));
-    hipError_t e = g_pool.alloc(&b->ptr, bytes ? bytes : 16);
+    hipError_t e = g_pool.alloc(&b->ptr, bytes ? bytes : 16, ctx->device);
     if (e != hipSuccess) { delete b; return fail(SVGR_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
     b->bytes = bytes;
     b->owned = true;
@@ -2171,6 +2177,7 @@ size_t svgr_buf_bytes(const svgr_buf* buf) { return buf ? buf->bytes : 0; }
 
 int svgr_buf_zero(svgr_ctx* ctx, svgr_buf* buf) {
     if (!ctx || !buf) return fail(SVGR_E_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemsetAsync(buf->ptr, 0, buf->bytes, ctx->stream));
     return 0;
 }
@@ -2179,6 +2186,7 @@ int svgr_buf_copy(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, size_t byte
     if (!ctx || !dst || !src) return fail(SVGR_E_INVALID, "bad arguments");
     if (bytes > dst->bytes || bytes > src->bytes) return fail(SVGR_E_INVALID, "copy of %zu bytes overruns a buffer", bytes);
     if (bytes == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(dst->ptr, src->ptr, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
@@ -2187,6 +2195,7 @@ int svgr_upload(svgr_ctx* ctx, svgr_buf* dst, size_t dst_off, const void* host, 
     if (!ctx || !dst || (!host && bytes)) return fail(SVGR_E_INVALID, "bad arguments");
     if (dst_off + bytes > dst->bytes) return fail(SVGR_E_INVALID, "upload of %zu bytes at %zu overruns a %zu byte buffer", bytes, dst_off, dst->bytes);
     if (bytes == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync((char*)dst->ptr + dst_off, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));  // host buffer is caller-owned and may be reused at once
     return 0;
@@ -2196,6 +2205,7 @@ int svgr_download(svgr_ctx* ctx, const svgr_buf* src, size_t src_off, void* host
     if (!ctx || !src || (!host && bytes)) return fail(SVGR_E_INVALID, "bad arguments");
     if (src_off + bytes > src->bytes) return fail(SVGR_E_INVALID, "download of %zu bytes at %zu overruns a %zu byte buffer", bytes, src_off, src->bytes);
     if (bytes == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(host, (const char*)src->ptr + src_off, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
@@ -2298,6 +2308,7 @@ int svgr_batch_destroy(svgr_batch* b) {
 
 int svgr_batch_set_paints(svgr_batch* b, const double* path_paint) {
     if (!b || !path_paint) return fail(SVGR_E_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(b->ctx->device));
     HIPCHK(hipMemcpyAsync(b->path_paint.p, path_paint, sizeof(double) * 4 * b->n_paths, hipMemcpyHostToDevice, b->ctx->stream));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
     b->geometry_fresh = false;  // the pair headers carry the paint
@@ -2308,6 +2319,7 @@ int svgr_batch_set_transforms(svgr_batch* b, const double* path_m6) {
     if (!b || !path_m6) return fail(SVGR_E_INVALID, "bad arguments");
     for (int64_t i = 0; i < 6 * b->n_paths; ++i)
         if (!std::isfinite(path_m6[i])) return fail(SVGR_E_INVALID, "non-finite transform");
+    HIPCHK(hipSetDevice(b->ctx->device));
     HIPCHK(hipMemcpyAsync(b->path_m6.p, path_m6, sizeof(double) * 6 * b->n_paths, hipMemcpyHostToDevice, b->ctx->stream));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
     b->planned = false;
@@ -2694,6 +2706,7 @@ int svgr_layer_over(svgr_ctx* ctx, svgr_buf* dst, const int64_t* db, const svgr_
     size_t n = (size_t)sb[2] * sb[3];
     if (dst->bytes < (size_t)db[2] * db[3] * 32 || src->bytes < n * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_over: buffer too small");
     if (n == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_layer_over, grid1(n), dim3(256), 0, ctx->stream, (double*)dst->ptr, (int)db[0], (int)db[1], (int)db[2],
                        (int)db[3], (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch, first);
     HIPCHK(hipGetLastError());
@@ -2758,6 +2771,7 @@ int svgr_layer_crop4(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr
     size_t n = (size_t)ob[2] * ob[3];
     if (out->bytes < n * 32 || src->bytes < (size_t)sb[2] * sb[3] * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_crop4: buffer too small");
     if (n == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_layer_crop4, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
                        (int)ob[3], (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch);
     HIPCHK(hipGetLastError());
@@ -2769,6 +2783,7 @@ int svgr_layer_in(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr_bu
     size_t n = (size_t)ob[2] * ob[3];
     if (out->bytes < n * 32 || src->bytes < (size_t)sb[2] * sb[3] * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_in: buffer too small");
     if (n == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_layer_in, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
                        (int)ob[3], (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch);
     HIPCHK(hipGetLastError());
@@ -2778,6 +2793,7 @@ int svgr_layer_in(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr_bu
 int svgr_layer_scale(svgr_ctx* ctx, svgr_buf* img, int64_t n, double f) {
     if (!ctx || !img || n < 0 || img->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_scale: bad arguments");
     if (n == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_layer_scale, grid1((size_t)n), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n, f);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2786,6 +2802,7 @@ int svgr_layer_scale(svgr_ctx* ctx, svgr_buf* img, int64_t n, double f) {
 int svgr_layer_clip01(svgr_ctx* ctx, svgr_buf* img, int64_t n) {
     if (!ctx || !img || n < 0 || img->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_clip01: bad arguments");
     if (n == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_layer_clip01, grid1((size_t)n), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2794,6 +2811,7 @@ int svgr_layer_clip01(svgr_ctx* ctx, svgr_buf* img, int64_t n) {
 int svgr_layer_background(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, const double* rgba) {
     if (!ctx || !img || !rgba || n_px < 0 || img->bytes < (size_t)n_px * 32) return fail(SVGR_E_INVALID, "svgr_layer_background: bad arguments");
     if (n_px == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_layer_background, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n_px, rgba[0],
                        rgba[1], rgba[2], rgba[3]);
     HIPCHK(hipGetLastError());
@@ -2803,6 +2821,7 @@ int svgr_layer_background(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, const doub
 int svgr_layer_convert(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, unsigned ops) {
     if (!ctx || !img || n_px < 0 || img->bytes < (size_t)n_px * 32 || (ops & ~15u)) return fail(SVGR_E_INVALID, "svgr_layer_convert: bad arguments");
     if (n_px == 0 || ops == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_layer_convert, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n_px, ops);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2811,6 +2830,7 @@ int svgr_layer_convert(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, unsigned ops)
 int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t n, int clip01) {
     if (!ctx || !dst || !src || n < 0 || dst->bytes < (size_t)n * 4 || src->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_to_f32: bad arguments");
     if (n == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_to_f32, grid1((size_t)n), dim3(256), 0, ctx->stream, (float*)dst->ptr, (const double*)src->ptr, (size_t)n, clip01);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2829,8 +2849,8 @@ int svgr_layer_to_rgba8(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64
 static int gradient_run(svgr_ctx* ctx, const svgr_gradient* g, const double* pts, const svgr_buf* mask, const int64_t* bbox,
                         svgr_buf* out) {
     if (g->kind < 1 || g->kind > 3 || g->spread < 0 || g->spread > 2) return fail(SVGR_E_INVALID, "invalid gradient kind / spread method");
-    if (g->n_stops < 1 || g->n_stops > GRAD_MAX_STOPS || !g->stop_off || !g->stop_rgba)
-        return fail(SVGR_E_INVALID, "gradient needs 1..%d stops", GRAD_MAX_STOPS);
+    if (g->n_stops < 1 || g->n_stops > (1 << 20) || !g->stop_off || !g->stop_rgba)
+        return fail(SVGR_E_INVALID, "gradient needs at least one stop");
     const size_t n = (size_t)bbox[2] * bbox[3];
     if ((mask && mask->bytes < n * 8) || out->bytes < n * 32) return fail(SVGR_E_INVALID, "svgr_gradient_fill: buffer too small");
     if (n == 0) return 0;
@@ -2845,12 +2865,22 @@ static int gradient_run(svgr_ctx* ctx, const svgr_gradient* g, const double* pts
     h.fcenter[0] = g->fcenter[0]; h.fcenter[1] = g->fcenter[1]; h.fradius = g->fradius;
     h.cd[0] = g->cd[0]; h.cd[1] = g->cd[1]; h.rd = g->rd; h.a = g->a; h.frad_rd = g->frad_rd; h.frad2 = g->frad2;
     h.excl_thresh = g->excl_thresh;
-    for (int i = 0; i < g->n_stops; ++i) {
-        h.stop_off[i] = g->stop_off[i];
-        for (int k = 0; k < 4; ++k) h.stop_rgba[i][k] = g->stop_rgba[4 * i + k];
-    }
     HIPCHK(hipSetDevice(ctx->device));
     hipError_t e = hipSuccess;
+    double* ext = nullptr;  // long stop lists: one device block {offsets, colours}, held until the stream has drained
+    if (g->n_stops <= GRAD_MAX_STOPS) {
+        for (int i = 0; i < g->n_stops; ++i) {
+            h.stop_off[i] = g->stop_off[i];
+            for (int k = 0; k < 4; ++k) h.stop_rgba[i][k] = g->stop_rgba[4 * i + k];
+        }
+    } else {
+        const size_t ns = (size_t)g->n_stops;
+        HIPCHK(g_pool.alloc((void**)&ext, sizeof(double) * 5 * ns, ctx->device));
+        e = hipMemcpyAsync(ext, g->stop_off, sizeof(double) * ns, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ext + ns, g->stop_rgba, sizeof(double) * 4 * ns, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { g_pool.release(ext); return fail(SVGR_E_HIP, "svgr_gradient_fill: %s", hipGetErrorString(e)); }
+        h.ext_stops = ext;
+    }
     if (g->kind == 3) {
         // the two-circle gradient needs a device flag (any det < 0 ?) between its two kernels: a pool word, held until
         // the stream has drained
@@ -2870,6 +2900,10 @@ static int gradient_run(svgr_ctx* ctx, const svgr_gradient* g, const double* pts
         hipLaunchKernelGGL(k_gradient_fill, grid1(n), dim3(256), 0, ctx->stream, h, pts, mptr, (int)bbox[0], (int)bbox[1],
                            (int)bbox[2], (int)bbox[3], (const int*)nullptr, (double*)out->ptr);
         e = hipGetLastError();
+    }
+    if (ext) {  // (the stops are the caller's host arrays: the copies above must have been consumed before returning)
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        g_pool.release(ext);
     }
     if (e != hipSuccess) return fail(SVGR_E_HIP, "svgr_gradient_fill: %s", hipGetErrorString(e));
     return 0;
@@ -2915,8 +2949,16 @@ int svgr_pattern_fill(svgr_ctx* ctx, const svgr_pattern* pt, const svgr_buf* til
     return 0;
 }
 
+static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, const double* kernel,
+                               int64_t kw, int64_t kh);
 int svgr_layer_convolve(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, const double* kernel,
                         int64_t kw, int64_t kh) {
+    // (the separability test builds host vectors: std::bad_alloc must not cross the ABI)
+    return abi_guard("svgr_layer_convolve", [&]() { return layer_convolve_impl(ctx, out, src, rows, cols, kernel, kw, kh); });
+}
+
+static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, const double* kernel,
+                               int64_t kw, int64_t kh) {
     if (!ctx || !out || !src || !kernel || rows <= 0 || cols <= 0 || kw <= 0 || kh <= 0 || rows > (1 << 24) || cols > (1 << 24) ||
         kw > 4096 || kh > 4096)
         return fail(SVGR_E_INVALID, "svgr_layer_convolve: bad arguments");

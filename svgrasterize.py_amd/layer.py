@@ -337,7 +337,8 @@ class Layer:
         layer = self.convert(pre_alpha=True)
         canvas = ctx.alloc(rows * cols * 32)
         canvas.zero()
-        _abi._check(ctx.lib.svgr_layer_over(ctx.handle, canvas.handle, _bbox_arr((0, 0), (rows, cols)), layer._device().handle,
+        src = layer._device()  # (a host-resident layer's upload is a temporary: it must outlive the call)
+        _abi._check(ctx.lib.svgr_layer_over(ctx.handle, canvas.handle, _bbox_arr((0, 0), (rows, cols)), src.handle,
                                             _bbox_arr(layer.offset, layer._shape), layer.channels, 0))
         _abi._check(ctx.lib.svgr_layer_clip01(ctx.handle, canvas.handle, rows * cols * 4))
         return Layer._from_device(canvas, (rows, cols, 4), (0, 0), True, layer.linear_rgb)
@@ -443,3 +444,161 @@ def canvas_to_png(canvas, output=None, level: int = 9, threads: int = 1):
     pack(output, b"IDAT", data)
     pack(output, b"IEND", b"")
     return output
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Module-level canvas functions of the reference (S:235-416) for callers that use them directly on numpy arrays.  The
+# arithmetic runs in the same device kernels as Layer.compose (k_layer_over / k_layer_in / k_layer_blend); the arrays
+# cross PCIe once in each direction per call, so inside a render the Layer methods (which stay in HBM) are the fast way.
+# ---------------------------------------------------------------------------------------------------------------------
+def canvas_create(width, height, bg=None):
+    """(canvas, transform): a float64 (height, width, 4) canvas, transparent or filled with ``bg``, and the transform from
+    (x, y) to its pixel coordinates (canvas_create, S:235-246)."""
+    from .geometry import Transform  # noqa: PLC0415
+
+    if bg is None:
+        canvas = np.zeros((height, width, 4), dtype=FLOAT)
+    else:
+        canvas = np.array(np.broadcast_to(bg, (height, width, 4)), dtype=FLOAT)
+    return canvas, Transform().matrix(0, 1, 0, 1, 0, 0)
+
+
+def _image3(image, what):
+    a = np.asarray(image, dtype=FLOAT)
+    if a.ndim == 2:
+        a = a[..., None]
+    if a.ndim != 3 or a.shape[2] not in (1, 4):
+        raise ValueError(f"{what}: expected an image of shape (rows, cols), (rows, cols, 1) or (rows, cols, 4)")
+    return np.ascontiguousarray(a)
+
+
+def _compose_on_device(mode, dst3, src3):
+    """blend(dst, src) for two images of equal rows x cols on the device; returns the (rows, cols, 4) result buffer."""
+    arithmetic = isinstance(mode, tuple) and len(mode) == 4
+    if mode not in COMPOSE_PRE_ALPHA and not arithmetic:
+        raise ValueError(f"invalid compose mode: {mode}")
+    if dst3.shape[:2] != src3.shape[:2]:
+        raise ValueError("canvas_compose: images must have the same rows x cols")
+    rows, cols = dst3.shape[:2]
+    ctx = _abi.Context.get()
+    lib = ctx.lib
+    bb = _bbox_arr((0, 0), (rows, cols))
+    d_in, s_in = ctx.from_host(dst3), ctx.from_host(src3)
+    out = ctx.alloc(max(rows * cols, 1) * 32)
+    _abi._check(lib.svgr_layer_crop4(ctx.handle, out.handle, bb, d_in.handle, bb, dst3.shape[2]))  # 1 channel -> 4
+    if arithmetic or mode not in (COMPOSE_OVER, COMPOSE_IN):
+        k4 = np.array(mode if arithmetic else (0, 0, 0, 0), dtype=FLOAT)
+        _abi._check(lib.svgr_layer_blend(ctx.handle, out.handle, bb, s_in.handle, bb, src3.shape[2], 5 if arithmetic else int(mode),
+                                         k4.ctypes.data_as(_abi._P)))
+    elif mode == COMPOSE_OVER:
+        _abi._check(lib.svgr_layer_over(ctx.handle, out.handle, bb, s_in.handle, bb, src3.shape[2], 0))
+    else:
+        _abi._check(lib.svgr_layer_in(ctx.handle, out.handle, bb, s_in.handle, bb, src3.shape[2]))
+    return out
+
+
+def canvas_compose(mode, dst, src):
+    """Compose two alpha-premultiplied images, ``src`` onto ``dst`` (canvas_compose, S:277-298): Porter-Duff OVER / OUT /
+    IN / ATOP / XOR or the feComposite ``(k1, k2, k3, k4)`` arithmetic.  Images are (rows, cols[, 1 | 4]) arrays of equal
+    rows x cols; a single channel is alpha and broadcasts over RGBA like numpy would."""
+    d3, s3 = _image3(dst, "dst"), _image3(src, "src")
+    out = _compose_on_device(mode, d3, s3)
+    res = out.download(d3.shape[:2] + (4,), FLOAT)
+    # numpy's broadcast decides the channels of the reference's result: OUT and IN are `src * f(dst_a)` and keep src's,
+    # the other modes add a dst term and take the wider of the two.  An alpha-only result sits in every channel here.
+    only_src = mode in (COMPOSE_OUT, COMPOSE_IN)
+    if s3.shape[2] == 1 and (only_src or d3.shape[2] == 1):
+        res = res[..., 3:]
+        if np.ndim(src) == 2 and (only_src or np.ndim(dst) == 2):
+            res = res[..., 0]
+    return res
+
+
+from functools import partial as _partial  # noqa: E402
+
+CANVAS_COMPOSE_OVER = _partial(canvas_compose, COMPOSE_OVER)
+
+
+def _blend_mode(blend):
+    """The compose mode of a ``partial(canvas_compose, mode)`` (what the reference passes as ``blend``), else None."""
+    if isinstance(blend, _partial) and blend.func is canvas_compose and len(blend.args) == 1 and not blend.keywords:
+        return blend.args[0]
+    return None
+
+
+def canvas_merge_at(base, overlay, offset, blend=CANVAS_COMPOSE_OVER):
+    """Blend ``overlay`` onto ``base`` at ``offset`` = (row, col), in place, clipping the touched region to [0, 1]
+    (canvas_merge_at, S:304-327).  Returns ``base``, or None when nothing overlaps."""
+    x, y = int(offset[0]), int(offset[1])
+    b_h, b_w = base.shape[:2]
+    o_h, o_w = overlay.shape[:2]
+    r0, r1 = min(max(x, 0), b_h), min(max(x + o_h, 0), b_h)
+    c0, c1 = min(max(y, 0), b_w), min(max(y + o_w, 0), b_w)
+    if r1 <= r0 or c1 <= c0:
+        return None
+    region = base[r0:r1, c0:c1]
+    part = overlay[r0 - x:r1 - x, c0 - y:c1 - y]
+    mode = _blend_mode(blend)
+    if mode is None:  # the caller's own blend function
+        region[...] = np.clip(blend(region, part), 0, 1)
+        return base
+    out = _compose_on_device(mode, _image3(region, "base"), _image3(part, "overlay"))
+    ctx = _abi.Context.get()
+    n = (r1 - r0) * (c1 - c0) * 4
+    _abi._check(ctx.lib.svgr_layer_clip01(ctx.handle, out.handle, n))
+    res = out.download((r1 - r0, c1 - c0, 4), FLOAT)
+    region[...] = res if region.ndim == 3 and region.shape[2] == 4 else res[..., 3:].reshape(region.shape)
+    return base
+
+
+def _as_layers(layers):
+    return [Layer(_image3(image, "layer"), (int(offset[0]), int(offset[1])), True, True) for image, offset in layers]
+
+
+def canvas_merge_union(layers, full=True, blend=CANVAS_COMPOSE_OVER):
+    """Blend ``[(image, (row, col)), ...]`` in order into one image that holds them all; returns (image, offset)
+    (canvas_merge_union, S:330-379).  ``full`` picks the reference's formulation (every layer zero-extended to the union
+    first); for source-over both give the same pixels."""
+    if not layers:
+        raise ValueError("can not blend zero layers")
+    if len(layers) == 1:
+        return layers[0]
+    mode = _blend_mode(blend)
+    if mode is not None and mode != COMPOSE_IN:  # (Layer.compose takes IN to the intersection; here it stays on the union)
+        out = Layer.compose(_as_layers(layers), mode, linear_rgb=True)
+        return out.image, (out.x, out.y)
+    r0 = min(int(o[0]) for _, o in layers)
+    c0 = min(int(o[1]) for _, o in layers)
+    r1 = max(int(o[0]) + im.shape[0] for im, o in layers)
+    c1 = max(int(o[1]) + im.shape[1] for im, o in layers)
+    output = None
+    for image, (x, y) in layers:
+        ext = np.zeros((r1 - r0, c1 - c0, 4), dtype=FLOAT)
+        ext[x - r0:x - r0 + image.shape[0], y - c0:y - c0 + image.shape[1]] = image
+        output = ext if output is None else blend(output, ext)
+    return output, (r0, c0)
+
+
+def canvas_merge_intersect(layers, blend=CANVAS_COMPOSE_OVER):
+    """Blend ``[(image, (row, col)), ...]`` on the region covered by all of them; (image, offset) or None when that region
+    is empty (canvas_merge_intersect, S:382-416)."""
+    if not layers:
+        raise ValueError("can not blend zero layers")
+    if len(layers) == 1:
+        return layers[0]
+    r0 = max(int(o[0]) for _, o in layers)
+    c0 = max(int(o[1]) for _, o in layers)
+    r1 = min(int(o[0]) + im.shape[0] for im, o in layers)
+    c1 = min(int(o[1]) + im.shape[1] for im, o in layers)
+    if r0 >= r1 or c0 >= c1:
+        return None
+    crop = lambda im, o: im[r0 - int(o[0]):r1 - int(o[0]), c0 - int(o[1]):c1 - int(o[1])]  # noqa: E731
+    mode = _blend_mode(blend)
+    (first, f_off), *rest = layers
+    output = _image3(crop(first, f_off), "layer")
+    if output.shape[2] == 1:
+        output = np.ascontiguousarray(np.broadcast_to(output, output.shape[:2] + (4,)))
+    for image, off in rest:
+        part = crop(image, off)
+        output = blend(output, part) if mode is None else canvas_compose(mode, output, part)
+    return output, (r0, c0)

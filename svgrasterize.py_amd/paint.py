@@ -44,8 +44,8 @@ class _GradMixin:
             g.has_gt = 1
             g.gt_m6 = (C.c_double * 6)(*np.asarray(self.transform.invert.m, dtype=np.float64)[:2].ravel())
         stops = _stops_colorspace(self.stops, linear_rgb)
-        if not 1 <= len(stops) <= 32:
-            raise ValueError("a gradient needs 1..32 stops")
+        if not stops:
+            raise ValueError("a gradient needs at least one stop")
         off = np.ascontiguousarray([o for o, _ in stops], dtype=np.float64)
         col = np.ascontiguousarray([c for _, c in stops], dtype=np.float64).reshape(-1, 4)
         g.n_stops = len(stops)
@@ -214,6 +214,7 @@ def pattern_fill(paint: Pattern, mask_layer, hull, transform, linear_rgb: bool):
     rows, cols = mask_layer.height, mask_layer.width
     out = ctx.alloc(rows * cols * 32)
     bbox = (C.c_int64 * 4)(int(mask_layer.x), int(mask_layer.y), rows, cols)
-    _abi._check(ctx.lib.svgr_pattern_fill(ctx.handle, C.byref(pat), tile._device().handle, mask_layer._device().handle, bbox,
-                                          out.handle))
+    # (bound to names: a host-resident layer's _device() is a temporary buffer that must outlive the call)
+    tile_buf, mask_buf = tile._device(), mask_layer._device()
+    _abi._check(ctx.lib.svgr_pattern_fill(ctx.handle, C.byref(pat), tile_buf.handle, mask_buf.handle, bbox, out.handle))
     return Layer._from_device(out, (rows, cols, 4), mask_layer.offset, pre_alpha=tile.pre_alpha, linear_rgb=tile.linear_rgb)

@@ -103,3 +103,47 @@ def test_luminance_mask_scene(S, kat):
         layer, _hull = target.mask(mask_scene, False).render(swap, viewport=[0, 0, 120, 140], linear_rgb=m["linear_rgb"])
         assert [int(v) for v in layer.offset] == m["offset"] and (layer.pre_alpha, layer.linear_rgb) == (m["pre_alpha"], m["out_linear_rgb"])
         assert_close64(layer.image, z[f"k{j}_out"], atol=1e-12, what=f"luminance mask {j}")
+
+
+def test_module_level_canvas_functions(S):
+    """canvas_create / canvas_compose / canvas_merge_at / canvas_merge_union / canvas_merge_intersect (S:235-416) called
+    directly on arrays, against the reference's own results (tests/golden/canvasfn_kat.npz, gen_golden.py --only canvasfn)."""
+    from functools import partial
+
+    z = np.load(os.path.join(GOLD, "canvasfn_kat.npz"))
+    meta = json.loads(str(z["meta"]))
+    for i, m in enumerate(meta):
+        fn = m["fn"]
+        mode = tuple(m["mode"]) if isinstance(m.get("mode"), list) else m.get("mode")
+        if fn == "compose":
+            got = S.canvas_compose(mode, z[f"{i}_dst"], z[f"{i}_src"])
+            assert_close64(got, z[f"{i}_out"], atol=1e-15, what=f"canvas_compose case {i} mode {mode}")
+        elif fn == "merge_at":
+            base = z[f"{i}_base"].copy()
+            res = S.canvas_merge_at(base, z[f"{i}_over"], tuple(m["offset"]))
+            assert (res is None) == m["none"] and (res is None or res is base)
+            assert_close64(base, z[f"{i}_out"], atol=1e-15, what=f"canvas_merge_at case {i}")
+        elif fn in ("union", "intersect"):
+            layers = [(z[f"{i}_in{j}"], tuple(o)) for j, o in enumerate(m["offsets"])]
+            blend = partial(S.canvas_compose, mode)
+            if fn == "union":
+                img, off = S.canvas_merge_union(layers, full=m["full"], blend=blend)
+            else:
+                img, off = S.canvas_merge_intersect(layers, blend=blend)
+            assert [int(v) for v in off] == m["offset"]
+            assert_close64(img, z[f"{i}_out"], atol=1e-15, what=f"canvas_merge_{fn} case {i}")
+        elif fn == "intersect_none":
+            assert S.canvas_merge_intersect([(np.ones((3, 3, 4)), (0, 0)), (np.ones((3, 3, 4)), (10, 10))]) is None
+    canvas, tr = S.canvas_create(5, 3, bg=np.array([0.1, 0.2, 0.3, 1.0]))
+    assert np.array_equal(canvas, z["create_canvas"]) and np.array_equal(np.asarray(tr.m, dtype=np.float64), z["create_m"])
+    one = [(np.ones((2, 2, 4)), (1, 1))]
+    assert S.canvas_merge_union(one)[0] is one[0][0] and S.canvas_merge_intersect(one)[0] is one[0][0]
+    for f in (S.canvas_merge_union, S.canvas_merge_intersect):
+        with pytest.raises(ValueError):
+            f([])
+    with pytest.raises(ValueError):
+        S.canvas_compose(17, np.zeros((2, 2, 4)), np.zeros((2, 2, 4)))
+    # a caller's own blend function is honoured as is
+    mine = lambda d, s: d * 0.5 + s * 0.25  # noqa: E731
+    img, off = S.canvas_merge_union([(np.ones((2, 2, 4)), (0, 0)), (np.ones((2, 2, 4)), (1, 1))], blend=mine)
+    assert off == (0, 0) and img[1, 1, 0] == 0.75 and img[0, 0, 0] == 0.5 and img[2, 2, 0] == 0.25

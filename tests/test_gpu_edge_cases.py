@@ -211,3 +211,82 @@ def test_hull_ignores_the_viewport(S):
         _l0, h0 = scene.render(tr, viewport=[0, 0, 400, 400])
         _l1, h1 = scene.render(tr, viewport=[100, 40, 50, 30])
         assert np.array_equal(np.array(h0.points), np.array(h1.points))
+
+
+def test_layer_ops_source_bbox_outside_destination_and_undersized_buffers(S):
+    """svgr_layer_over / crop4 / in with a source partly and wholly outside the destination, and with buffers smaller
+    than their bbox says: the former clip, the latter return SVGR_E_INVALID (ValueError) without launching."""
+    import ctypes as C
+
+    from svgrasterize_amd import _abi
+
+    ctx = S.Context.get()
+    lib = ctx.lib
+    bb = lambda r0, c0, rows, cols: (C.c_int64 * 4)(r0, c0, rows, cols)
+    rng = np.random.default_rng(5)
+    src_img = rng.random((6, 7, 4))
+    src = ctx.from_host(src_img)
+    for (r0, c0) in [(-3, -4), (2, 5), (100, 100), (-50, 2)]:   # partly, partly, wholly, wholly outside
+        dst = ctx.alloc(8 * 9 * 32)
+        dst.zero()
+        _abi._check(lib.svgr_layer_over(ctx.handle, dst.handle, bb(0, 0, 8, 9), src.handle, bb(r0, c0, 6, 7), 4, 1))
+        got = dst.download((8, 9, 4), np.float64)
+        want = np.zeros((8, 9, 4))
+        for r in range(6):
+            for c in range(7):
+                if 0 <= r + r0 < 8 and 0 <= c + c0 < 9:
+                    want[r + r0, c + c0] = src_img[r, c]
+        assert np.array_equal(got, want), (r0, c0)
+        out = ctx.alloc(8 * 9 * 32)
+        _abi._check(lib.svgr_layer_crop4(ctx.handle, out.handle, bb(0, 0, 8, 9), src.handle, bb(r0, c0, 6, 7), 4))
+        assert np.array_equal(out.download((8, 9, 4), np.float64), want), (r0, c0)
+        ones = ctx.from_host(np.ones((8, 9, 4)))
+        _abi._check(lib.svgr_layer_in(ctx.handle, ones.handle, bb(0, 0, 8, 9), src.handle, bb(r0, c0, 6, 7), 4))
+        got = ones.download((8, 9, 4), np.float64)
+        inside = np.zeros((8, 9), dtype=bool)
+        inside[max(r0, 0):max(min(r0 + 6, 8), 0), max(c0, 0):max(min(c0 + 7, 9), 0)] = True
+        assert np.array_equal(got[inside], want[inside]) and np.all(got[~inside] == 1.0)   # (untouched outside the source)
+    small = ctx.alloc(6 * 7 * 32 - 8)
+    dst = ctx.alloc(8 * 9 * 32)
+    for fn in (lambda: lib.svgr_layer_over(ctx.handle, dst.handle, bb(0, 0, 8, 9), small.handle, bb(0, 0, 6, 7), 4, 1),
+               lambda: lib.svgr_layer_over(ctx.handle, small.handle, bb(0, 0, 8, 9), src.handle, bb(0, 0, 6, 7), 4, 1),
+               lambda: lib.svgr_layer_crop4(ctx.handle, small.handle, bb(0, 0, 8, 9), src.handle, bb(0, 0, 6, 7), 4),
+               lambda: lib.svgr_layer_crop4(ctx.handle, dst.handle, bb(0, 0, 8, 9), small.handle, bb(0, 0, 6, 7), 4),
+               lambda: lib.svgr_layer_in(ctx.handle, dst.handle, bb(0, 0, 8, 9), small.handle, bb(0, 0, 6, 7), 4),
+               lambda: lib.svgr_layer_in(ctx.handle, small.handle, bb(0, 0, 8, 9), src.handle, bb(0, 0, 6, 7), 4),
+               lambda: lib.svgr_layer_over(ctx.handle, dst.handle, bb(0, 0, 8, 9), src.handle, bb(0, 0, -1, 7), 4, 1),
+               lambda: lib.svgr_layer_over(ctx.handle, dst.handle, bb(0, 0, 8, 9), src.handle, bb(0, 0, 6, 7), 3, 1)):
+        with pytest.raises(ValueError):
+            _abi._check(fn())
+    ctx.sync()
+
+
+def test_device_ops_on_host_resident_layers(S):
+    """Layers built from numpy arrays (or whose .image was read) upload a temporary buffer per device op; the buffer has
+    to outlive the C call (round 1's bring-up fault was a use-after-free of exactly such a temporary)."""
+    rng = np.random.default_rng(11)
+    img = rng.random((5, 6, 4)) * 0.5
+    img[..., 3] = np.maximum(img[..., 3], img[..., :3].max(axis=2))
+    host_layer = S.Layer(img.copy(), (2, 3), True, False)
+    canvas = host_layer.on_canvas(12, 12).image
+    want = np.zeros((12, 12, 4))
+    want[2:7, 3:9] = img
+    assert_close64(canvas, want, atol=0.0, what="on_canvas of a host layer")
+    f32 = host_layer.to_canvas_f32(12, 12)
+    assert np.array_equal(f32, want.astype(np.float32))
+    # compose of host layers, every method family
+    other = S.Layer(img[::-1].copy(), (4, 1), True, False)
+    for method in (0, 2, 1):
+        out = S.Layer.compose([host_layer, other], method=method)
+        assert out is not None and np.isfinite(out.image).all()
+    # pattern fill with a host-resident mask: Path.fill reads the mask back first
+    tile_scene = S.Scene.fill(S.Path.from_svg("M0,0 H2 V2 H0 Z"), np.array([0.2, 0.4, 0.6, 1.0]))
+    pat = S.Pattern(tile_scene, False, None, 0.0, 0.0, 4.0, 4.0, S.Transform(), False)
+    from svgrasterize_amd import paint as P
+
+    path = S.Path.from_svg("M1,1 H11 V11 H1 Z")
+    mask, hull = path.mask(S.Transform())
+    _ = mask.image  # now host-resident
+    filled = P.pattern_fill(pat, mask, hull, S.Transform(), True)
+    assert filled is not None and filled.image.shape == mask.image.shape[:2] + (4,)
+    assert filled.image[..., 3].max() == 1.0 and filled.image[..., 3].min() == 0.0

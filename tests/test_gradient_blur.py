@@ -178,3 +178,27 @@ def test_gpu_demo_icon_thumbnails(name):
     tol = np.maximum(np.nextafter(np.abs(ref), np.float32(np.inf)) - np.abs(ref), 2.0 ** -24)
     bad = err > tol  # (blurs: the reference's FFT carries ~1e-16 of noise, a handful of float32 ties may flip)
     assert bad.sum() <= 8 and err.max() < 1e-6, (name, int(bad.sum()), float(err.max()))
+
+
+@pytest.mark.gpu
+def test_gpu_gradients_with_many_stops():
+    """33 to 200 stops (the reference loops over any number, S:1671-1683): evaluation at points in both colour spaces and a
+    filled path, against the reference (tests/golden/gradlong_kat.npz, gen_golden.py --only gradlong)."""
+    import json
+
+    import svgrasterize_amd as S
+
+    z = np.load(os.path.join(GOLDEN, "gradlong_kat.npz"))
+    for i, m in enumerate(json.loads(str(z["meta"]))):
+        stops = [(float(o), c) for o, c in zip(z[f"{i}_off"], z[f"{i}_rgba"])]
+        assert len(stops) == m["n"] > 32
+        if m["kind"] == "linear":
+            paint = S.GradLinear(np.array([2.0, 3.0]), np.array([40.0, 25.0]), stops, None, m["spread"], False, None)
+        else:
+            paint = S.GradRadial(np.array([20.0, 18.0]), 17.0, None, None, stops, None, m["spread"], False, None)
+        assert_close64(paint.fill(z[f"{i}_pts"], linear_rgb=True), z[f"{i}_lin"], atol=1e-13, what=f"{m} eval linear")
+        assert_close64(paint.fill(z[f"{i}_pts"], linear_rgb=False), z[f"{i}_srgb"], atol=1e-13, what=f"{m} eval sRGB")
+        layer, _ = S.Path.from_svg("M3,2 H45 V38 H3 Z").fill(S.Transform().matrix(0, 1, 0, 1, 0, 0), paint, linear_rgb=False)
+        assert [int(v) for v in layer.offset] == m["offset"]
+        assert_close64(layer.image, z[f"{i}_image"], atol=1e-11, what=f"{m} fill")
+        assert_f32_1ulp(layer.image.astype(np.float32), z[f"{i}_image"], what=f"{m} fill")
