@@ -71,13 +71,18 @@ constexpr int PREF_BYTES = PREF_WAVES * DMA_PER_WAVE * 1024;
 #define SVGR_REC_BYTES 48
 #endif
 constexpr int REC_BYTES = SVGR_REC_BYTES;             // 48, or 64 = one full HBM sector per record
-constexpr int PREF_RECS = PREF_BYTES / REC_BYTES;              // slots per prefetch block (85 = 4 KiB / 48 B)
+constexpr int HDR_BYTES = 48 + 8 * SVGR_TR;           // CellHdr: paint, rule, flags, class + one carry-in per tile row
+static_assert(HDR_BYTES % 16 == 0, "the cell header moves as 16-byte chunks");
+constexpr int PREF_RECS = (PREF_BYTES - HDR_BYTES) / REC_BYTES;   // records per prefetch block behind the header (81 of 4 KiB)
 #ifndef SVGR_PREF_DEPTH
 #define SVGR_PREF_DEPTH 2
 #endif
 constexpr int PREF_DEPTH = SVGR_PREF_DEPTH;             // record blocks in the ring: paths li, li+1[, li+2]
 constexpr int LCAP = 32;                                // compacted paths of a tile worked off per sub-batch
 constexpr int NW = NT / 64;                // waves per workgroup
+#ifndef SVGR_CLASS1
+#define SVGR_CLASS1 1                   // constant-coverage cells take the composite-only path (0: through scatter + scan)
+#endif
 #ifndef SVGR_WAVES_PER_EU
 #define SVGR_WAVES_PER_EU 4             // register budget of the tile kernel: 512 / 4 = 128 VGPRs
 #endif
@@ -95,17 +100,22 @@ struct RowRec {
 #endif
 };
 static_assert(sizeof(RowRec) == REC_BYTES, "RowRec size");
-// Every (path, band) pair's block starts with one header slot of the same size: the path's paint and
-// fill rule, so that the tile kernel gets them from the same LDS-DMA block as the records.
-struct PairHeader {
+// One (path, band, column tile) CELL, written by k_pair_cells after the records: what the tile needs besides its own
+// records.  `carry[r]` = sum of every piece of the pair's row r that lies LEFT of the tile (the running sum the row
+// scan starts from, np.cumsum S:983); `cls` sorts the cells:
+//   0  no record reaches the tile and every carry-in is below the 1e-6 cut (S:990): nothing to draw, the tile
+//      never sees the cell
+//   1  no record reaches the tile but some row's carry-in is visible: coverage is constant along each row
+//      (rule(carry)), composite without scatter / scan
+//   2  records reach the tile: scatter + scan, the row sums start at the carry-in
+struct CellHdr {
     double paint[4];
-    int rule, pad[3];
-#if SVGR_REC_BYTES == 64
-    double pad2[2];
-#endif
+    int rule, flags;   // fill rule (0 nonzero, 1 evenodd), SVGR_PATH_* flags >> 1
+    int n_own, cls;    // records that touch the tile's columns; class as above
+    double carry[SVGR_TR];
 };
-static_assert(sizeof(PairHeader) == REC_BYTES, "PairHeader occupies one record slot");
-constexpr int PREF_RECS_MAX = 85;      // records per 4 KiB prefetch block (the workgroup may be smaller: see PREF_RECS)
+static_assert(sizeof(CellHdr) == HDR_BYTES, "CellHdr layout");
+constexpr int PREF_RECS_MAX = 85;      // slack records behind the record array (whole-block DMA reads may overrun the last pair)
 constexpr unsigned SPAN_MAX = (1u << 26) - 1;
 static_assert(SVGR_TR <= 64, "row-in-band is stored in 6 bits");
 
@@ -331,7 +341,7 @@ static int count_owned_bands(const Owner o, int n_bands) {
 constexpr int UNION_BIAS = 1 << 30;
 struct BatchDev {
     int err;            // bit 0: flatten depth cap, bit 1: edge capacity, bit 2: (path,band) capacity,
-                        // bit 3: band-seg capacity, bit 4: bbox beyond int range
+                        // bit 3: band-seg capacity, bit 4: bbox beyond int range, bit 5: cell capacity
     int n_nonempty;
     unsigned long long path_pixels;
     int edge_spare;
@@ -339,7 +349,8 @@ struct BatchDev {
     int bseg_cursor;    // band segments
     int entry_cursor;   // band list entries
     unsigned umin_r, umin_c, umax_r, umax_c;  // union bbox: max(BIAS - lo), max(BIAS + hi)
-    int pad[4 + 16];
+    int cell_cursor;    // (path, band, column tile) cells
+    int pad[3 + 16];
     // Flattened edges are reserved in NSH independent shards (wave w of the flatten uses shard w % NSH): one hot
     // cursor serves only ~90 returning atomics per microsecond chip-wide, sixteen serve every wave of the launch.
     // One 128-byte line per cursor.
@@ -548,8 +559,14 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
 struct PathBin {
     int b0, nb;   // first band, number of bands (0: empty path)
     int pb_off;   // pair index of (path, b0); pair of band b = pb_off + b - b0
-    int pad;
+    int cell_off; // first cell of the path: cell of (band b, column tile t) = cell_off + (b - b0) * nct + (t - ct0), with
+                  // ct0 / nct the column tiles the bbox spans (path_ctiles)
 };
+// column tiles [ct0, ct0 + nct) that the layer columns [c0, c0 + cols) of a viewport starting at column vc0 span
+__host__ __device__ __forceinline__ void path_ctiles(int c0, int cols, int vc0, int& ct0, int& nct) {
+    ct0 = (c0 - vc0) / TC;
+    nct = (c0 + cols - 1 - vc0) / TC - ct0 + 1;
+}
 static_assert(sizeof(PathBin) == 16, "PathBin is one dwordx4");
 
 // bbox = {r0, c0, rows, cols}; viewport = same or has_vp = 0
@@ -558,7 +575,7 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
                                                   PathBin* __restrict__ bins, BatchDev* __restrict__ bd) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     int out[4] = {0, 0, 0, 0};
-    int pb0 = 0, pnb = 0;
+    int pb0 = 0, pnb = 0, pnct = 0;
     int st_n = 0;
     unsigned long long st_px = 0;
     unsigned st_minr = 0, st_minc = 0, st_maxr = 0, st_maxc = 0;
@@ -585,6 +602,8 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
                     int base_r = has_vp ? vr0 : (int)lo_r;
                     pb0 = ((int)lo_r - base_r) / TR;
                     pnb = ((int)(hi_r - 1) - base_r) / TR - pb0 + 1;
+                    int ct0_;
+                    path_ctiles((int)lo_c, (int)cols, has_vp ? vc0 : (int)lo_c, ct0_, pnct);
                     st_n = 1;
                     st_px = (unsigned long long)(rows * cols);
                     st_minr = (unsigned)(UNION_BIAS - (int)lo_r);
@@ -600,6 +619,10 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
         }
     }
     const int off = wave_alloc(&bd->pb_cursor, pnb, lane);
+    // (a path of 2^24 x 2^24 pixels has 2^38 cells: such a batch overflows the cursor and is refused, err bit 5)
+    const long long want_cells = has_vp ? (long long)pnb * pnct : 0ll;  // (no viewport yet: the pass only finds the union)
+    if (want_cells > (1ll << 28)) atomicOr(&bd->err, 32);
+    const int cell_off = wave_alloc(&bd->cell_cursor, want_cells > (1ll << 28) ? 0 : (int)want_cells, lane);
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {  // statistics: fold the wave, then one set of atomics
         st_n += __shfl_xor(st_n, d);
@@ -619,7 +642,7 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
     if (p < n_paths) {
         ((int4*)bbox)[p] = make_int4(out[0], out[1], out[2], out[3]);
         PathBin pbin;
-        pbin.b0 = pb0; pbin.nb = pnb; pbin.pb_off = off; pbin.pad = 0;
+        pbin.b0 = pb0; pbin.nb = pnb; pbin.pb_off = off; pbin.cell_off = cell_off;
         bins[p] = pbin;
     }
 }
@@ -690,28 +713,25 @@ __global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ e
 // One tile-list entry: everything a tile needs to know about a (path, band) pair, so that the tile
 // kernel's compaction is ONE coalesced load per lane instead of a chain of four dependent gathers.
 struct TileEntry {
-    int c0, cols;     // layer columns (first: the tile's column test reads just these 8 bytes)
+    int c0, cols;     // layer columns   } the tile's hit test reads just this first
+    int cell0;        // cell of (pair, first column tile of the path): the tile's own cell is cell0 + tile - ct0   } dwordx4
     int p;            // path id
     int r0, rows;     // layer rows
-    int seg0, cnt;    // record block of the pair: first slot (the header), number of records
-    int pad;
+    int seg0, cnt;    // records of the pair: first slot, number of records
 };
 static_assert(sizeof(TileEntry) == 32, "TileEntry is 32 bytes");
 
 // One workgroup per owned band, after k_edge_count: the ascending list of the paths that have records in the
 // band (TileEntry), and -- in the same pass, from the same counts -- the record block of every such
-// (path, band) pair: 1 header slot + cnt record slots, reserved with ONE atomic per band, so that a band's
-// blocks are contiguous in HBM and in paint order.  The header (paint, fill rule, flags) is written here;
-// k_edge_emit fills the records behind it.
+// (path, band) pair: cnt record slots, reserved with ONE atomic per band, so that a band's blocks are contiguous
+// in HBM and in paint order; k_edge_emit fills them, k_pair_cells then sorts the pair's column tiles into classes.
 constexpr int BE_BLOCK = 1024;
 constexpr int BE_KEEP = 4;   // 64-path groups per wave whose counts stay in registers between the two passes
 __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __restrict__ bins, int n_paths,
                                                               const int* __restrict__ bbox, const int* __restrict__ pb_cnt,
-                                                              const double* __restrict__ path_paint,
-                                                              const uint8_t* __restrict__ path_rule, int* __restrict__ bseg_off,
-                                                              RowRec* __restrict__ recs, int rec_cap,
+                                                              int* __restrict__ bseg_off, int rec_cap,
                                                               int* __restrict__ band_start, int* __restrict__ band_count,
-                                                              TileEntry* __restrict__ entries, int entry_cap,
+                                                              TileEntry* __restrict__ entries, int entry_cap, int vc0,
                                                               BatchDev* __restrict__ bd, Owner own) {
     constexpr int NWV = BE_BLOCK / 64;
     __shared__ int s_n[NWV], s_r[NWV];
@@ -729,11 +749,11 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
         return pb_cnt[pair];
     };
     int kcnt[BE_KEEP], kpair[BE_KEEP];
+    PathBin kb[BE_KEEP];
     int my_n = 0, my_r = 0;  // this lane's entries / record slots, over all its groups
     {
         // the first BE_KEEP groups with every load of a stage in flight together (written with a branch per group, the
         // compiler waits for each group's two dependent loads in turn: 2 * BE_KEEP round trips instead of 2)
-        PathBin kb[BE_KEEP];
 #pragma unroll
         for (int g = 0; g < BE_KEEP; ++g) {
             const int p = p_wave + g * 64 + lane;
@@ -751,13 +771,13 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
 #pragma unroll
         for (int g = 0; g < BE_KEEP; ++g) {
             kcnt[g] = member[g] ? kcnt[g] : 0;
-            if (kcnt[g] > 0) { ++my_n; my_r += kcnt[g] + 1; }
+            if (kcnt[g] > 0) { ++my_n; my_r += kcnt[g]; }
         }
     }
     for (int g = BE_KEEP; g < groups; ++g) {
         int pair;
         const int c = pair_of(p_wave + g * 64 + lane, pair);
-        if (c > 0) { ++my_n; my_r += c + 1; }
+        if (c > 0) { ++my_n; my_r += c; }
     }
     int wn = my_n, wr = my_r;  // wave totals
 #pragma unroll
@@ -785,57 +805,44 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
     auto place = [&](int c, int& my_ent, int& my_rec) {  // all lanes of the wave, one group: this lane's entry / record block
         int tn, trc;
         my_ent = ent + wave_excl_scan(c > 0 ? 1 : 0, lane, tn);
-        my_rec = rec + wave_excl_scan(c > 0 ? c + 1 : 0, lane, trc);
+        my_rec = rec + wave_excl_scan(c > 0 ? c : 0, lane, trc);
         ent += tn;
         rec += trc;
     };
-    auto store = [&](int p, int pair, int c, int my_ent, int my_rec, const int4 bb, const double4 pa, int rl) {
+    auto store = [&](int p, int pair, int c, int my_ent, int my_rec, const int4 bb, const PathBin pbin) {
         TileEntry e;
         e.p = p; e.c0 = bb.y; e.cols = bb.w; e.r0 = bb.x; e.rows = bb.z;
-        e.seg0 = my_rec; e.cnt = c; e.pad = 0;
+        e.seg0 = my_rec; e.cnt = c;
+        int ct0, nct;
+        path_ctiles(bb.y, bb.w, vc0, ct0, nct);
+        e.cell0 = pbin.cell_off + (band - pbin.b0) * nct;
         entries[my_ent] = e;
         bseg_off[pair] = my_rec;
-        if (recs) {
-            if (my_rec + c < rec_cap) {
-                PairHeader h;
-                h.paint[0] = pa.x; h.paint[1] = pa.y; h.paint[2] = pa.z; h.paint[3] = pa.w;
-                h.rule = rl & 1;
-                h.pad[0] = rl >> 1;  // SVGR_PATH_* flags
-                h.pad[1] = h.pad[2] = 0;
-                *(PairHeader*)(recs + my_rec) = h;
-            } else {
-                atomicOr(&bd->err, 8);
-            }
-        }
+        if (my_rec + c > rec_cap) atomicOr(&bd->err, 8);
     };
-    // two groups at a time, so that their bbox / paint / rule loads are in flight together
+    // two groups at a time, so that their bbox loads are in flight together
     static_assert(BE_KEEP % 2 == 0, "kept groups are written in pairs");
 #pragma unroll
     for (int g = 0; g < BE_KEEP; g += 2) {
         if (g >= groups) break;
-        int me[2], mr[2], rl[2] = {0, 0};
+        int me[2], mr[2];
         int4 bb[2] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
-        double4 pa[2] = {make_double4(0, 0, 0, 0), make_double4(0, 0, 0, 0)};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             place(kcnt[g + j], me[j], mr[j]);
             const int p = p_wave + (g + j) * 64 + lane;
-            if (kcnt[g + j] > 0) {
-                bb[j] = ((const int4*)bbox)[p];
-                pa[j] = ((const double4*)path_paint)[p];
-                rl[j] = path_rule[p];
-            }
+            if (kcnt[g + j] > 0) bb[j] = ((const int4*)bbox)[p];
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            if (kcnt[g + j] > 0) store(p_wave + (g + j) * 64 + lane, kpair[g + j], kcnt[g + j], me[j], mr[j], bb[j], pa[j], rl[j]);
+            if (kcnt[g + j] > 0) store(p_wave + (g + j) * 64 + lane, kpair[g + j], kcnt[g + j], me[j], mr[j], bb[j], kb[g + j]);
     }
     for (int g = BE_KEEP; g < groups; ++g) {
         int pair = 0, me, mr;
         const int p = p_wave + g * 64 + lane;
         const int c = pair_of(p, pair);
         place(c, me, mr);
-        if (c > 0) store(p, pair, c, me, mr, ((const int4*)bbox)[p], ((const double4*)path_paint)[p], path_rule[p]);
+        if (c > 0) store(p, pair, c, me, mr, ((const int4*)bbox)[p], bins[p]);
     }
 }
 
@@ -906,7 +913,7 @@ __global__ __launch_bounds__(256, SVGR_EMIT_WAVES) void k_edge_emit(const double
                     continue;
                 }
                 const int pb = key + (band - bf);
-                slot = bseg_off[pb] + 1 + (band == bf ? run_base + (excl - run_begin_excl) : atomicAdd(&pb_cursor[pb], y1 - ya));
+                slot = bseg_off[pb] + (band == bf ? run_base + (excl - run_begin_excl) : atomicAdd(&pb_cursor[pb], y1 - ya));
                 band_end = y1;
                 band_row0 = band * TR + vr0 - r0;
             }
@@ -961,6 +968,110 @@ __global__ __launch_bounds__(256, SVGR_EMIT_WAVES) void k_edge_emit(const double
     }
 }
 
+// Sum of the pieces of one edge-row record (apply_record's list: x0i, x0i+1, the middle run, x0i+n-1, x0i+n) whose
+// column -- clamped to 0 from the left like S:2262 -- lies in [ca, cb).  The middle run is counted, not walked.
+__device__ __forceinline__ double record_sum_range(int x0i, int n, const double* v, int ca, int cb) {
+    auto in = [&](int xi) { const int c = xi > 0 ? xi : 0; return c >= ca && c < cb; };
+    double sum = 0.0;
+    if (in(x0i)) sum = v[0];
+    if (in(x0i + 1)) sum = sum + v[1];
+    if (n >= 3) {
+        // xi in [x0i + 2, x0i + n - 2]; negative xi sit in column 0
+        const int lo = ca > 0 ? (x0i + 2 > ca ? x0i + 2 : ca) : x0i + 2;
+        const int hi = x0i + n - 2 < cb - 1 ? x0i + n - 2 : cb - 1;
+        if (hi >= lo) sum = sum + (double)(hi - lo + 1) * v[2];
+        if (in(x0i + n - 1)) sum = sum + v[3];
+    }
+    if (n >= 2 && in(x0i + n)) sum = sum + v[4];
+    return sum;
+}
+
+// is the coverage of a constant running sum visible (S:984-990) ?
+__device__ __forceinline__ bool carry_visible(double c, int rule) {
+    return (rule ? fill_evenodd_raw(c) : fabs(c)) >= kZeroCut;
+}
+
+// After k_edge_emit, one wave per (path, band) pair with records: the pair's column tiles sorted into classes
+// (CellHdr) and the carry-in of every tile row -- the sum of the pieces left of the tile, which the tile kernel used to
+// gather itself by folding every record of the pair, in every tile.  Per record: the pieces that fall into each
+// column tile it touches are summed in closed form and added to a per-wave LDS table [column tile][row]
+// (ds_add_f64), the touched tiles are counted; then 16 lanes (one per row) walk the tiles left to right with the
+// running sum.  Pairs wider than PC_CT column tiles take several passes over their records.
+constexpr int PC_CT = 32;
+constexpr int PC_BLOCK = 256;
+static_assert(TR + 2 <= 64, "k_pair_cells: one lane per tile row plus two for the rest of the header");
+__global__ __launch_bounds__(PC_BLOCK) void k_pair_cells(const TileEntry* __restrict__ entries, const RowRec* __restrict__ recs,
+                                                        const double* __restrict__ path_paint, const uint8_t* __restrict__ path_rule,
+                                                        int vc0, unsigned char* __restrict__ cell_cls, CellHdr* __restrict__ cell_hdr,
+                                                        int cell_cap, BatchDev* __restrict__ bd) {
+    constexpr int NWV = PC_BLOCK / 64;
+    __shared__ double s_sum[NWV][PC_CT][TR];
+    __shared__ int s_cnt[NWV][PC_CT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int e = blockIdx.x * NWV + wave;
+    if (e >= bd->entry_cursor) return;  // (waves are independent: no workgroup barrier below)
+    const TileEntry en = entries[e];
+    int ct0, nct;
+    path_ctiles(en.c0, en.cols, vc0, ct0, nct);
+    const int x_first = vc0 + ct0 * TC - en.c0;  // layer column where the path's first column tile starts (<= 0)
+    const int rl = path_rule[en.p], rule = rl & 1;
+    const double4 paint = ((const double4*)path_paint)[en.p];
+    double run = 0.0;  // lanes < TR: the row's running sum left of the current column tile
+    for (int base = 0; base < nct; base += PC_CT) {
+        const int nc = nct - base < PC_CT ? nct - base : PC_CT;
+        for (int i = lane; i < nc * TR; i += 64) (&s_sum[wave][0][0])[i] = 0.0;
+        if (lane < nc) s_cnt[wave][lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < en.cnt; j += 64) {
+            const RowRec* r = recs + en.seg0 + j;
+            const int4 h = *(const int4*)r;  // {x0i, nrow, v0 lo, v0 hi}
+            const double2 w0 = *(const double2*)((const char*)r + 16), w1 = *(const double2*)((const char*)r + 32);
+            double v[5];
+            v[0] = __hiloint2double(h.w, h.z); v[1] = w0.x; v[2] = w0.y; v[3] = w1.x; v[4] = w1.y;
+            const int x0i = h.x, n = (int)((unsigned)h.y & SPAN_MAX), row = (int)((unsigned)h.y >> 26);
+            if (x0i >= en.cols) continue;  // the whole row lies beyond the layer (S:2260)
+            const int xl = x0i + (n >= 2 ? n : 1);  // column of the last piece
+            const int cf = x0i > 0 ? x0i : 0;
+            int cl = xl > 0 ? xl : 0;
+            cl = cl < en.cols - 1 ? cl : en.cols - 1;
+            int kf = (cf - x_first) / TC - base, kl = (cl - x_first) / TC - base;
+            kf = kf > 0 ? kf : 0;
+            kl = kl < nc - 1 ? kl : nc - 1;
+            for (int k = kf; k <= kl; ++k) {
+                int ca = (base + k) * TC + x_first, cb = ca + TC;
+                ca = ca > 0 ? ca : 0;
+                cb = cb < en.cols ? cb : en.cols;
+                const double part = record_sum_range(x0i, n, v, ca, cb);
+                __hip_atomic_fetch_add(&s_sum[wave][k][row], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_cnt[wave][k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k = 0; k < nc; ++k) {
+            const double part = lane < TR ? s_sum[wave][k][lane] : 0.0;
+            const int own = s_cnt[wave][k];
+            const bool vis = lane < TR && carry_visible(run, rule);
+            const int cls = own > 0 ? 2 : (__ballot(vis) != 0ull ? 1 : 0);
+            const int cell = en.cell0 + base + k;
+            if (cell < cell_cap) {
+                if (lane == 0) cell_cls[cell] = (unsigned char)cls;
+                if (cls != 0) {
+                    CellHdr* h = cell_hdr + cell;
+                    if (lane < TR) h->carry[lane] = run;
+                    if (lane == TR) { h->paint[0] = paint.x; h->paint[1] = paint.y; h->paint[2] = paint.z; h->paint[3] = paint.w; }
+                    if (lane == TR + 1) { h->rule = rule; h->flags = rl >> 1; h->n_own = own; h->cls = cls; }
+                }
+            } else if (lane == 0) {
+                atomicOr(&bd->err, 32);
+            }
+            run += part;
+        }
+    }
+}
+
 // ======================================================================================
 // tile kernel
 // ======================================================================================
@@ -997,7 +1108,10 @@ struct TileArgs {
     const int* band_start;     // per band: first entry, number of entries
     const int* band_count;
     const TileEntry* entries;  // per band: the pairs with records, ascending path id
-    const RowRec* bsegs;       // record blocks: per (path, band) pair one header slot + its edge-row records
+    const RowRec* bsegs;       // record blocks: per (path, band) pair its edge-row records
+    const unsigned char* cell_cls;  // per (pair, column tile) cell: class 0 / 1 / 2 (CellHdr)
+    const CellHdr* cell_hdr;        // ... and, for classes 1 and 2, paint + fill rule + the carry-in of every tile row
+    int cell_cap;                   // cells the two arrays hold (a batch that outgrew its plan is flagged, not read out of bounds)
     void* out;
     int vr0, vc0, vrows, vcols;  // viewport
     Owner own;                   // owned bands
@@ -1022,7 +1136,8 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
     constexpr int OFF_LIST = OFF_BBOX + LCAP * 16;                       // int[NT]: their ids
     constexpr int OFF_SEG0 = OFF_LIST + LCAP * 4;                        // int[NT]: first record of the (path, band) pair
     constexpr int OFF_SEG1 = OFF_SEG0 + LCAP * 4;                        // int[NT]: one past the last
-    constexpr int OFF_WCNT = OFF_SEG1 + LCAP * 4;                        // int[NW]
+    constexpr int OFF_CELL = OFF_SEG1 + LCAP * 4;                        // int[NT]: the tile's cell of the pair | class << 30
+    constexpr int OFF_WCNT = OFF_CELL + LCAP * 4;                        // int[NW]
     constexpr int OFF_CLIP = OFF_WCNT + 16 * 4;                        // canvas modes: coverage tile of a clip path
     constexpr int LDS_BYTES = OFF_CLIP + (CLIP ? TR * ROW_STRIDE * 8 : 16);
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[LDS_BYTES];
@@ -1031,6 +1146,7 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
     int* const s_list = (int*)(s_mem + OFF_LIST);
     int* const s_seg0 = (int*)(s_mem + OFF_SEG0);
     int* const s_seg1 = (int*)(s_mem + OFF_SEG1);
+    int* const s_cell = (int*)(s_mem + OFF_CELL);
     int* const s_wcnt = (int*)(s_mem + OFF_WCNT);
     int clip_tag = -1;  // path whose coverage s_clip holds (canvas modes)
 
@@ -1066,9 +1182,17 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
         // Only `hit` and the lane's rank stay live across the per-path loop below; the entry itself is read again when it
         // is moved to the lists (holding its seven values in registers through the loop cost a scratch spill per workgroup).
         bool hit = false;
+        int cellw = 0;  // the tile's cell of this pair | class << 30
         if (base + tid < ent_end) {
-            const int2 cc = *(const int2*)&a.entries[base + tid];  // {c0, cols}
-            hit = cc.x < tile_c1 && cc.x + cc.y > tile_c0;
+            const int4 cc = *(const int4*)&a.entries[base + tid];  // {c0, cols, cell0, p}
+            if (cc.x < tile_c1 && cc.x + cc.y > tile_c0) {
+                // the pair's bbox reaches the tile: its cell says whether anything of it is visible here (class 0: no
+                // record in these columns and no winding carried in from the left -- a third of the bbox tiles of a blob)
+                const int cell = cc.z + (int)blockIdx.x - (cc.x - a.vc0) / TC;
+                const int cls = cell < a.cell_cap ? a.cell_cls[cell] : 0;
+                hit = cls != 0;
+                cellw = cell | (cls << 30);
+            }
         }
         unsigned long long m = __ballot(hit);
         int* const wcnt = s_wcnt + (batch_no & 1) * NW;
@@ -1091,7 +1215,8 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
             const int at = pending + slot - lo;
             s_list[at] = e.p;
             s_seg0[at] = e.seg0;
-            s_seg1[at] = e.seg0 + e.cnt + 1;  // header slot + records
+            s_seg1[at] = ((unsigned)cellw >> 30) == 2u ? e.seg0 + e.cnt : e.seg0;  // (class 1: no record reaches the tile)
+            s_cell[at] = cellw;
             s_bbox[at] = make_int4(e.r0, e.c0, e.rows, e.cols);
         }
         pending += take;
@@ -1105,9 +1230,10 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
         __syncthreads();
 
         // ------------------------------------------------------------------------------------------
-        // Work items = (path, window of PREF_RECS slots of its record block); slot 0 of a block is
-        // the header (paint, rule), slot k >= 1 record k-1.  Items are streamed through a ring of
-        // PREF_DEPTH LDS blocks by LDS-DMA, two items ahead of the one being scattered.
+        // Work items = the tile's cells of the listed pairs.  An item's block = the cell header (paint, rule,
+        // class, carry-in per tile row) followed by the first PREF_RECS records of the pair (class 2 only).
+        // Items are streamed through a ring of PREF_DEPTH LDS blocks by LDS-DMA, one item ahead of the one
+        // being worked on.
         //
         // The DMA is issued from inline asm on purpose: for a __builtin LDS-DMA hipcc (ROCm 7.2) makes
         // EVERY later ds_read wait vmcnt(0) ("may alias the DMA"), which would drain the blocks that
@@ -1116,18 +1242,23 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
         // k+1 issued, "item k has landed" is vmcnt(1) [vmcnt(0) for the last item], followed by a raw
         // barrier (lgkmcnt only: a __syncthreads() would wait vmcnt(0)).
         // ------------------------------------------------------------------------------------------
-        auto issue = [&](int li_, int win_, int buf_) {
+        auto issue = [&](int li_, int buf_) {
             if (wave < PREF_WAVES) {
-                // (block bounds are wave-uniform: kept in SGPRs so that the x48 address arithmetic is scalar)
+                // (block bounds are wave-uniform: kept in SGPRs so that the address arithmetic is scalar)
                 const int seg0_ = __builtin_amdgcn_readfirstlane(s_seg0[li_]), seg1_ = __builtin_amdgcn_readfirstlane(s_seg1[li_]);
-                const int left_ = seg1_ - seg0_ - win_;
+                const int cell_ = __builtin_amdgcn_readfirstlane(s_cell[li_]) & 0x3fffffff;
+                const int left_ = seg1_ - seg0_;
                 const int n_bytes = (left_ < PREF_RECS ? left_ : PREF_RECS) * REC_BYTES;
-                const char* const gbase = (const char*)(a.bsegs + seg0_ + win_);
+                const char* const hbase = (const char*)(a.cell_hdr + cell_);
+                // chunk t of the block: the cell header first, the pair's records behind it; lanes past the end re-read
+                // the last valid 16 bytes
+                const char* const rbase = n_bytes > 0 ? (const char*)(a.bsegs + seg0_) - HDR_BYTES : hbase;
+                const int last_ = HDR_BYTES + n_bytes - 16;
 #pragma unroll
                 for (int j = 0; j < DMA_PER_WAVE; ++j) {
                     const int t_ = (wave * DMA_PER_WAVE + j) * 64 + lane;  // 16-byte chunk of the block this lane fetches
-                    const int off_ = t_ * 16 < n_bytes ? t_ * 16 : n_bytes - 16;
-                    const char* g = gbase + off_;
+                    const int off_ = t_ * 16 < last_ ? t_ * 16 : last_;
+                    const char* g = (off_ < HDR_BYTES ? hbase : rbase) + off_;
                     const unsigned lds_base = __builtin_amdgcn_readfirstlane(
                         (unsigned)(size_t)(lds_ptr_t)(s_mem + OFF_PREF + buf_ * PREF_BYTES + (wave * DMA_PER_WAVE + j) * 1024));
                     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
@@ -1138,10 +1269,10 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
             }
         };
         // the prefetch cursor runs two items ahead of the work cursor
-        int pf_li = 0, pf_win = 0, pf_k = 0;
+        int pf_li = 0, pf_k = 0;
         auto issue_next = [&]() {
             if (pf_li < total) {
-                issue(pf_li, pf_win, pf_k % PREF_DEPTH);
+                issue(pf_li, pf_k % PREF_DEPTH);
                 ++pf_k;
                 ++pf_li;  // one item per path: slots past the block are read straight from HBM by the scatter
             }
@@ -1149,12 +1280,11 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
         issue_next();
         if (PREF_DEPTH >= 3) issue_next();
 
-        // per-path state, set when the first window of the path is reached
+        // per-path state
         int row_shift = 0, rows = 0, col_shift = 0, lo_c = 0, hi_c = 0, rule = 0, n_slots = 0, pflags = 0, pid = 0, lcols = 0;
         long long loff = 0;  // mask / fill outputs: where this path's layer starts in `out`, its row pitch is lcols
         double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
         int li = 0;
-        constexpr int win = 0;
         for (int k = 0; li < total; ++k) {
             const int cur = k % PREF_DEPTH;
 #ifdef SVGR_DBG_STAMP
@@ -1166,14 +1296,17 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
             unsigned long long t1_ = __builtin_amdgcn_s_memrealtime();
 #endif
             // After this barrier: item k has landed for every wave; everybody is done with item k-1
-            // (its block is free again) and, when this is a first window, with the previous path's scan.
+            // (its block is free again) and with the previous item's scan.
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef SVGR_DBG_STAMP
             unsigned long long t2_ = __builtin_amdgcn_s_memrealtime();
 #endif
-            issue_next();  // item k+2 into the block that item k-1 used
+            issue_next();  // item k+1 (k+2) into the block that item k-1 used
             const double* const blk = (const double*)(s_mem + OFF_PREF + cur * PREF_BYTES);
-            if (win == 0) {
+            const double* const blk_carry = blk + 6;                         // CellHdr::carry
+            const char* const blk_recs = (const char*)blk + HDR_BYTES;       // the pair's first PREF_RECS records
+            const int cls = (int)((unsigned)s_cell[li] >> 30);
+            {
                 const int4 pbb = s_bbox[li];
                 const int c0 = pbb.y, cols = pbb.w;
                 n_slots = s_seg1[li] - s_seg0[li];
@@ -1182,7 +1315,7 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
                 col_shift = c0 - tile_c0;     // layer col x  -> tile col  x + col_shift
                 lo_c = col_shift < 0 ? -col_shift : 0;             // first layer column inside the tile
                 hi_c = cols < tile_c1 - c0 ? cols : tile_c1 - c0;  // one past the last
-                p0 = blk[0]; p1 = blk[1]; p2 = blk[2]; p3 = blk[3];  // header slot: paint, rule
+                p0 = blk[0]; p1 = blk[1]; p2 = blk[2]; p3 = blk[3];  // cell header: paint, rule, flags
                 rule = *(const int*)(blk + 4);
                 pflags = *((const int*)(blk + 4) + 1);
                 pid = s_list[li];
@@ -1191,28 +1324,40 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
                     loff = a.layer_off ? a.layer_off[pid] : 0ll;
                 }
             }
+            ++li;
 
-            // ---- scatter: one lane per edge-row record; the pieces were computed by k_edge_emit, here
-            //      they are only clamped to the layer / tile and added to the LDS delta tile ----
+            // Class 1: no record reaches the tile, so a row's running sum is its carry-in from the layer's first column in
+            // the tile to its last (np.cumsum of zeros, S:983).  No scatter, no second barrier, no delta-tile traffic: the
+            // scan below gets the two deltas (+carry at the first column, -carry behind the last) straight in registers.
+            const bool fast1 = SVGR_CLASS1 && OUT == 0 && !CLIP && cls == 1;
+            if (!fast1) {
+            // ---- scatter: one lane per edge-row record; the pieces were computed by k_edge_emit, here the ones inside
+            //      the tile's columns are added to the LDS delta tile.  What lies left of the tile arrives pre-summed as
+            //      the row's carry-in (k_pair_cells) and goes to the layer's first column in the tile ----
             {
-                const int slot_lo = 1;
                 int slot_hi = n_slots;
 #ifdef SVGR_DBG_NOSCATTER
-                slot_hi = slot_lo;
+                slot_hi = 0;
 #endif
-                for (int sl = slot_lo + tid; sl < slot_hi; sl += NT) {
+                if (tid < TR) {
+                    const double cin = blk_carry[tid];
+                    if (cin != 0.0)
+                        __hip_atomic_fetch_add(s_trace + __mul24(tid, ROW_STRIDE) + lds_col(lo_c + col_shift), cin, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                for (int sl = tid; sl < slot_hi; sl += NT) {
                     int x0i;
                     unsigned nrow;
                     double v[5];
                     if (sl < PREF_RECS) {
-                        const double* q = blk + __mul24(sl, REC_BYTES / 8);
+                        const double* q = (const double*)(blk_recs + __mul24(sl, REC_BYTES));
                         const int2 hd = *(const int2*)q;
                         x0i = hd.x; nrow = (unsigned)hd.y;
                         v[0] = q[1]; v[1] = q[2]; v[2] = q[3]; v[3] = q[4]; v[4] = q[5];
                     } else {
                         // pair longer than the prefetch block: the tail comes straight from HBM.  Inline asm, so
                         // that hipcc does not put a vmcnt(0) wait on the common path (it would for a plain load).
-                        const RowRec* gp = a.bsegs + __builtin_amdgcn_readfirstlane(s_seg0[li]) + sl;
+                        const RowRec* gp = a.bsegs + __builtin_amdgcn_readfirstlane(s_seg0[li - 1]) + sl;
                         double hd_;
                         asm volatile("global_load_dwordx2 %0, %6, off\n\t"
                                      "global_load_dwordx2 %1, %6, off offset:8\n\t"
@@ -1230,31 +1375,37 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
                     const int n = (int)(nrow & SPAN_MAX);
                     double* trow_ptr = s_trace + __mul24((int)(nrow >> 26), ROW_STRIDE);  // (32-bit multiplies are quarter rate)
                     if (x0i >= hi_c) continue;  // everything at or beyond the tile's / layer's right edge
-                    if (x0i + n < lo_c) {
-                        // whole row span left of the tile: fold the sum of its pieces (= d) into the first column
-                        double sum = v[0] + v[1];
-                        if (n >= 3) sum = sum + (double)(n - 3) * v[2] + v[3];
-                        if (n >= 2) sum = sum + v[4];
-                        const int tc = lo_c + col_shift;
-                        __hip_atomic_fetch_add(trow_ptr + lds_col(tc), sum, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-                        continue;
+                    const int xl = x0i + (n >= 2 ? n : 1);  // column of the last piece
+                    if ((xl > 0 ? xl : 0) < lo_c) continue;  // everything left of the tile: part of the carry-in
+                    auto put = [&](int xi, double val) {
+                        const int c = xi > 0 ? xi : 0;   // left of the layer folds into column 0 (S:2262)
+                        if (c >= lo_c && c < hi_c)       // (left of the tile: in the carry-in; right of the layer: dropped, S:2260)
+                            __hip_atomic_fetch_add(trow_ptr + lds_col(c + col_shift), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    };
+                    put(x0i, v[0]);
+                    put(x0i + 1, v[1]);
+                    if (n >= 3) {
+                        int xa = x0i + 2;
+                        const int xb = x0i + n - 2 < hi_c - 1 ? x0i + n - 2 : hi_c - 1;  // middle run, cut at the right edge
+                        if (xa < lo_c) {
+                            // the run starts left of the tile: skip to the tile's first column; when that is the layer's
+                            // column 0 the pieces at negative columns all land there (S:2262)
+                            if (lo_c == 0) {
+                                const int neg = (xb < -1 ? xb : -1) - xa + 1;
+                                if (neg > 0) put(0, (double)neg * v[2]);
+                            }
+                            xa = lo_c;
+                        }
+                        for (int xi = xa; xi <= xb; ++xi)
+                            __hip_atomic_fetch_add(trow_ptr + lds_col(xi + col_shift), v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        put(x0i + n - 1, v[3]);
                     }
-                    apply_record(x0i, n, v, [&](int xi, double val) -> bool {
-                        int c = xi > 0 ? xi : 0;   // left of the layer folds into column 0 (S:2262)
-                        if (c >= hi_c) return false;
-                        c = c > lo_c ? c : lo_c;   // left of the tile folds into its first column (row carry-in)
-                        const int tc = c + col_shift;
-                        __hip_atomic_fetch_add(trow_ptr + lds_col(tc), val, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-                        return true;
-                    });
+                    if (n >= 2) put(x0i + n, v[4]);
                 }
             }
 #ifdef SVGR_DBG_STAMP
             unsigned long long t3_ = __builtin_amdgcn_s_memrealtime();
 #endif
-            ++li;
             if (OUT <= 1 && hi_c + col_shift < TC && tid < TR && tid >= row_shift && tid < row_shift + rows) {
                 // The layer's right edge is inside this tile.  Right of it the running sum is whatever winding
                 // an unclosed outline leaves behind (stroker joins leave ~1e-5 gaps) and the reference never
@@ -1264,6 +1415,7 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
                 s_trace[lds_index(tid, hi_c + col_shift)] = __builtin_nan("");
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // delta tile complete
+            }
 #ifdef SVGR_DBG_STAMP
             unsigned long long t4_ = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1285,10 +1437,17 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
 #endif
                 double* my = s_trace + trow * ROW_STRIDE + chunk * CHUNK_STRIDE;
                 double t[PX];
+                if (fast1) {
+                    const double cin = blk_carry[trow];
+                    const int d0 = lo_c + col_shift - chunk * PX, d1 = hi_c + col_shift - chunk * PX;  // (d1 == TC - ..: no lane)
 #pragma unroll
-                for (int i = 0; i < PX; ++i) t[i] = my[i];
+                    for (int i = 0; i < PX; ++i) t[i] = d0 == i ? cin : (d1 == i ? -cin : 0.0);
+                } else {
 #pragma unroll
-                for (int i = 0; i < PX; ++i) my[i] = 0.0;
+                    for (int i = 0; i < PX; ++i) t[i] = my[i];
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) my[i] = 0.0;
+                }
                 double tot = t[0];
 #pragma unroll
                 for (int i = 1; i < PX; ++i) tot += t[i];
@@ -1924,13 +2083,15 @@ struct svgr_batch {
     DevArr<TileEntry> entries;
     DevArr<double> edges;
     DevArr<RowRec> bsegs;
+    DevArr<unsigned char> cell_cls;         // per (path, band, column tile) cell: class (CellHdr)
+    DevArr<CellHdr> cell_hdr;               // ... and header (classes 1 and 2)
     DevArr<long long> layer_off;            // SVGR_OUT_MASKS_F64: per path the start of its mask in the output
     std::vector<long long> host_layer_off;
     // plan results (n_edges = edge slots the edge kernels cover = sum of the shard capacities; n_edges_live = filled ones)
     bool geometry_fresh = false;  // the buffers hold the geometry of the current inputs (set by plan, consumed by render)
     bool arena_zeroed = false;    // the last tile kernel left the counter arena zeroed (all but the error word)
     int64_t n_edges_live = 0;
-    int64_t n_edges = 0, n_pb = 0, n_bsegs = 0;
+    int64_t n_edges = 0, n_pb = 0, n_bsegs = 0, n_cells = 0, n_entries = 0;
     int n_bands = 0;
     BatchDev host_bd{};
     EdgeShards shards{};       // plan result: where each flatten shard's edges live
@@ -1960,7 +2121,7 @@ struct svgr_batch {
         segs.release(); path_m6.release(); path_paint.release(); seg_kind.release(); path_rule.release();
         seg_path.release(); in_dev.release(); arena.release(); edge_path.release(); bbox.release(); bins.release();
         bseg_off.release(); band_start.release(); band_count.release(); entries.release();
-        edges.release(); bsegs.release(); layer_off.release();
+        edges.release(); bsegs.release(); cell_cls.release(); cell_hdr.release(); layer_off.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
         for (auto e : event_pool) (void)hipEventDestroy(e);
@@ -2012,14 +2173,18 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     const int owned = count_owned_bands(b->own, b->n_bands);
     if (owned > 0)
         hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(BE_BLOCK), 0, st, (const PathBin*)b->bins.p, np,
-                           (const int*)b->bbox.p, (const int*)b->pb_cnt(), (const double*)b->path_paint.p,
-                           (const uint8_t*)b->path_rule.p, b->bseg_off.p, upto >= 4 ? b->bsegs.p : (RowRec*)nullptr,
-                           cap_i32(b->bsegs.cap), b->band_start.p, b->band_count.p, b->entries.p, cap_i32(b->entries.cap),
-                           b->bd(), b->own);
+                           (const int*)b->bbox.p, (const int*)b->pb_cnt(), b->bseg_off.p,
+                           upto >= 4 ? cap_i32(b->bsegs.cap) : 0x7fffffff, b->band_start.p, b->band_count.p, b->entries.p,
+                           cap_i32(b->entries.cap), b->vp[1], b->bd(), b->own);
     if (upto == 3) return 0;
     hipLaunchKernelGGL(k_edge_emit, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
                        (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->pb_cap, (const int*)b->bseg_off.p,
                        b->pb_cursor(), b->bsegs.p, cap_i32(b->bsegs.cap), b->bd(), b->own, b->shards);
+    // per pair with records: classes and carry-ins of its column tiles
+    if (b->n_entries > 0)
+        hipLaunchKernelGGL(k_pair_cells, grid1((size_t)b->n_entries * 64, PC_BLOCK), dim3(PC_BLOCK), 0, st,
+                           (const TileEntry*)b->entries.p, (const RowRec*)b->bsegs.p, (const double*)b->path_paint.p,
+                           (const uint8_t*)b->path_rule.p, b->vp[1], b->cell_cls.p, b->cell_hdr.p, cap_i32(std::min(b->cell_cls.cap, b->cell_hdr.cap)), b->bd());
     return 0;
 }
 
@@ -2044,10 +2209,10 @@ static int check_dev_err(svgr_batch* b, int* capacity_bits = nullptr, bool whole
         if (e) HIPCHK(hipMemsetAsync(b->bd(), 0, sizeof(int), b->ctx->stream));
     }
     HIPCHK(hipGetLastError());
-    if (capacity_bits) { *capacity_bits = e & (2 | 4 | 8); e &= ~(2 | 4 | 8); }
+    if (capacity_bits) { *capacity_bits = e & (2 | 4 | 8 | 32); e &= ~(2 | 4 | 8 | 32); }
     if (e & 1) return fail(SVGR_E_OVERFLOW, "flatten depth cap (%d) hit: non-finite or absurd control points", kMaxFlattenDepth);
     if (e & 16) return fail(SVGR_E_INVALID, "path extent beyond +-1e9 pixels or non-finite");
-    if (e & (2 | 4 | 8)) return fail(SVGR_E_OVERFLOW, "work buffer capacity exceeded (err bits %d): call svgr_batch_plan again", e);
+    if (e & (2 | 4 | 8 | 32)) return fail(SVGR_E_OVERFLOW, "work buffer capacity exceeded (err bits %d): call svgr_batch_plan again", e);
     return 0;
 }
 
@@ -2343,6 +2508,8 @@ static int plan_speculative(svgr_batch* b) {
     if (!b->has_vp || ns <= 0 || ns > 256 || np <= 0) return 0;
     const int n_bands = (b->vp[2] + TR - 1) / TR;
     if ((int64_t)np * n_bands > 65536 || n_bands <= 0) return 0;
+    const int n_ct = (b->vp[3] + TC - 1) / TC + 1;  // (+1: a layer need not start on a tile border)
+    if ((int64_t)np * n_bands * n_ct > 262144) return 0;  // (cells: bounded like the pairs, but by the viewport's width too)
     const int shard_cap = (int)(64 * ns);  // a wave's segments all land in one shard: every shard can take them all
     b->n_edges = 0;
     for (int k = 0; k < NSH; ++k) {
@@ -2352,6 +2519,8 @@ static int plan_speculative(svgr_batch* b) {
     }
     b->n_bands = n_bands;
     b->n_pb = (int64_t)np * n_bands;
+    b->n_cells = b->n_pb * n_ct;
+    b->n_entries = b->n_pb;
     const int64_t rec_guess = 16 * (int64_t)shard_cap + b->n_pb;
     int rc = b->layout_arena((int)b->n_pb);
     rc = rc ? rc : b->edges.ensure((size_t)b->n_edges * 4);
@@ -2361,11 +2530,14 @@ static int plan_speculative(svgr_batch* b) {
     rc = rc ? rc : b->bseg_off.ensure((size_t)b->n_pb + 1);
     rc = rc ? rc : b->entries.ensure((size_t)b->n_pb);
     rc = rc ? rc : b->bsegs.ensure((size_t)rec_guess + PREF_RECS_MAX + 1);
+    rc = rc ? rc : b->cell_cls.ensure((size_t)b->n_cells + 1);
+    rc = rc ? rc : b->cell_hdr.ensure((size_t)b->n_cells + 1);
     if (rc) return rc;
     if ((rc = run_geometry(b, 4, true))) return rc;
     int cap_bits = 0;
     if ((rc = check_dev_err(b, &cap_bits, true, true))) return rc;
     if (cap_bits) return 0;
+    b->n_entries = b->host_bd.entry_cursor;
     b->n_edges_live = 0;
     for (int k = 0; k < NSH; ++k) b->n_edges_live += std::min(b->host_bd.shard[k].cursor, shard_cap);
     b->n_bsegs = b->host_bd.bseg_cursor;
@@ -2423,6 +2595,9 @@ static int batch_plan_impl(svgr_batch* b) {
     if (int rc = run_geometry(b, 2, true)) return rc;
     if (int rc = check_dev_err(b)) return rc;
     b->n_pb = b->host_bd.pb_cursor;
+    b->n_cells = b->host_bd.cell_cursor;
+    if (int rc = b->cell_cls.ensure((size_t)std::max<int64_t>(b->n_cells, 1))) return rc;
+    if (int rc = b->cell_hdr.ensure((size_t)std::max<int64_t>(b->n_cells, 1))) return rc;
     // 3. per-pair counts -> band segments
     if (int rc = b->layout_arena((int)b->n_pb)) return rc;
     if (int rc = b->bseg_off.ensure((size_t)b->n_pb + 1)) return rc;
@@ -2430,6 +2605,7 @@ static int batch_plan_impl(svgr_batch* b) {
     if (int rc = run_geometry(b, 3, true)) return rc;
     if (int rc = check_dev_err(b)) return rc;
     b->n_bsegs = b->host_bd.bseg_cursor;
+    b->n_entries = b->host_bd.entry_cursor;
     if (int rc = b->bsegs.ensure((size_t)std::max<int64_t>(b->n_bsegs, 1) + PREF_RECS_MAX + 1)) return rc;
     // 4. full geometry once, to validate the capacities and fetch the bboxes
     if (int rc = run_geometry(b, 4, true)) return rc;
@@ -2623,6 +2799,8 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
     if (owned_bands > 0 && n_ctiles > 0) {
         TileArgs a;
         a.band_start = b->band_start.p; a.band_count = b->band_count.p; a.entries = b->entries.p; a.bsegs = b->bsegs.p; a.out = out->ptr;
+        a.cell_cls = b->cell_cls.p; a.cell_hdr = b->cell_hdr.p;
+        a.cell_cap = cap_i32(std::min(b->cell_cls.cap, b->cell_hdr.cap));
         a.vr0 = b->vp[0]; a.vc0 = b->vp[1]; a.vrows = b->vp[2]; a.vcols = b->vp[3];
         a.own = b->own;
         a.out_cols = b->vp[3];
