@@ -1,0 +1,28 @@
+#!/bin/bash
+# Collect the judged profile artifacts on the GPU box: profiles/collect2.sh <tag> [workload]     (e.g. r02_c2 synth4096)
+#   gpurun_out/<tag>/bench.json          bench line (N=1)
+#   gpurun_out/<tag>/kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command
+#   gpurun_out/<tag>/pmc_sq.csv          --pmc pass 1: SQ instruction / cycle counters + GRBM_GUI_ACTIVE (clock)
+#   gpurun_out/<tag>/pmc_fetch.csv, pmc_write.csv   --pmc passes 2, 3: FETCH_SIZE, WRITE_SIZE (they do not fit one pass)
+#   gpurun_out/<tag>/pmc_kernels.json    per kernel: average counters per launch (profiles/pmc_json.py); bench.py reads the
+#                                        copy committed as profiles/pmc_kernels_<workload>.json for its roofline block
+# Counter passes carry --kernel-trace only (no other trace domain).  Copy what should be judged into profiles/<round>/.
+set -u
+tag="${1:-run}"; wl="${2:-synth4096}"
+cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+o=gpurun_out/$tag; rm -rf $o; mkdir -p $o
+python3 bench.py --workload $wl > $o/bench.json 2> $o/bench.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/kt -o kt -- python3 bench.py --workload $wl --no-cpu-baseline --steps 50 > $o/kt.log 2>&1 || exit 1
+cp $(find $o/kt -name "*kernel_stats.csv" | head -1) $o/kernel_stats.csv
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $o/ps -o ps -- python3 bench.py --workload $wl --no-cpu-baseline --steps 10 --warmup 2 > $o/ps.log 2>&1 || exit 1
+cp $(find $o/ps -name "*counter_collection.csv" | head -1) $o/pmc_sq.csv
+cp $(find $o/ps -name "*kernel_trace.csv" | head -1) $o/pmc_sq_trace.csv
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/pf -o pf -- python3 bench.py --workload $wl --no-cpu-baseline --steps 10 --warmup 2 > $o/pf.log 2>&1 || exit 1
+cp $(find $o/pf -name "*counter_collection.csv" | head -1) $o/pmc_fetch.csv
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pw -o pw -- python3 bench.py --workload $wl --no-cpu-baseline --steps 10 --warmup 2 > $o/pw.log 2>&1 || exit 1
+cp $(find $o/pw -name "*counter_collection.csv" | head -1) $o/pmc_write.csv
+rm -rf $o/kt $o/pf $o/pw $o/ps
+python3 profiles/pmc_json.py $wl $o > $o/pmc_kernels.json
+cat $o/pmc_kernels.json
+cut -c1-140 $o/kernel_stats.csv | head -10
+cat $o/bench.json

@@ -263,14 +263,19 @@ struct DevArr {
 // ======================================================================================
 // wave-level helpers (wave = 64 lanes)
 // ======================================================================================
+// Exclusive prefix sum over the 64 lanes (every lane must call it), `total` = the wave's sum.  DPP adds: four
+// row_shr steps inside each 16-lane row, then row_bcast:15 / row_bcast:31 carry the row totals upward -- no
+// per-lane index registers (the ds_bpermute form of __shfl_up keeps six of them alive across whatever follows).
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
+    (void)lane;
     int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    total = __shfl(x, 63);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);  // row_bcast:31 into rows 2 and 3
+    total = __builtin_amdgcn_readlane(x, 63);
     return x - v;
 }
 
@@ -350,7 +355,8 @@ struct BatchDev {
     int entry_cursor;   // band list entries
     unsigned umin_r, umin_c, umax_r, umax_c;  // union bbox: max(BIAS - lo), max(BIAS + hi)
     int cell_cursor;    // (path, band, column tile) cells
-    int pad[3 + 16];
+    int max_band_entries;  // longest band list (sizes the tiles' entry bitmasks)
+    int pad[2 + 16];
     // Flattened edges are reserved in NSH independent shards (wave w of the flatten uses shard w % NSH): one hot
     // cursor serves only ~90 returning atomics per microsecond chip-wide, sixteen serve every wave of the launch.
     // One 128-byte line per cursor.
@@ -731,8 +737,8 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
                                                               const int* __restrict__ bbox, const int* __restrict__ pb_cnt,
                                                               int* __restrict__ bseg_off, int rec_cap,
                                                               int* __restrict__ band_start, int* __restrict__ band_count,
-                                                              TileEntry* __restrict__ entries, int entry_cap, int vc0,
-                                                              BatchDev* __restrict__ bd, Owner own) {
+                                                              TileEntry* __restrict__ entries, int2* __restrict__ entry_where,
+                                                              int entry_cap, int vc0, BatchDev* __restrict__ bd, Owner own) {
     constexpr int NWV = BE_BLOCK / 64;
     __shared__ int s_n[NWV], s_r[NWV];
     __shared__ int s_ent0, s_rec0, s_ok;
@@ -794,6 +800,7 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
             int r0 = trc ? atomicAdd(&bd->bseg_cursor, trc) : 0;
             int ok = 1;
             if (e0 + tn > entry_cap) { atomicOr(&bd->err, 4); ok = 0; tn = 0; }
+            if (tn) atomicMax(&bd->max_band_entries, tn);
             s_ent0 = e0; s_rec0 = r0; s_ok = ok;
             band_start[band] = e0;
             band_count[band] = tn;
@@ -817,6 +824,7 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
         path_ctiles(bb.y, bb.w, vc0, ct0, nct);
         e.cell0 = pbin.cell_off + (band - pbin.b0) * nct;
         entries[my_ent] = e;
+        entry_where[my_ent] = make_int2(band, my_ent - s_ent0);  // its band and its place in the band's list
         bseg_off[pair] = my_rec;
         if (my_rec + c > rec_cap) atomicOr(&bd->err, 8);
     };
@@ -992,31 +1000,44 @@ __device__ __forceinline__ bool carry_visible(double c, int rule) {
 }
 
 // After k_edge_emit, one wave per (path, band) pair with records: the pair's column tiles sorted into classes
-// (CellHdr) and the carry-in of every tile row -- the sum of the pieces left of the tile, which the tile kernel used to
-// gather itself by folding every record of the pair, in every tile.  Per record: the pieces that fall into each
-// column tile it touches are summed in closed form and added to a per-wave LDS table [column tile][row]
-// (ds_add_f64), the touched tiles are counted; then 16 lanes (one per row) walk the tiles left to right with the
-// running sum.  Pairs wider than PC_CT column tiles take several passes over their records.
+// (CellHdr), the carry-in of every tile row -- the sum of the pieces left of the tile, which the tile kernel used to
+// gather itself by folding every record of the pair, in every tile -- and the tiles' entry bitmasks.  Per record:
+// the pieces that fall into each column tile it touches are summed in closed form and added to a per-wave LDS table
+// [column tile][row] (ds_add_f64), the touched tiles are counted; then the lanes walk the tiles left to right, four
+// column tiles x 16 rows at a time, with the running sum.  Pairs wider than PC_CT column tiles take several passes
+// over their records.  (TR = 16: four column tiles per step.)  (A persistent, software-pipelined form of this kernel was slower: it is instruction bound, not
+// latency bound -- 46 000 short waves hide their own load chains.)
 constexpr int PC_CT = 32;
 constexpr int PC_BLOCK = 256;
-static_assert(TR + 2 <= 64, "k_pair_cells: one lane per tile row plus two for the rest of the header");
-__global__ __launch_bounds__(PC_BLOCK) void k_pair_cells(const TileEntry* __restrict__ entries, const RowRec* __restrict__ recs,
-                                                        const double* __restrict__ path_paint, const uint8_t* __restrict__ path_rule,
-                                                        int vc0, unsigned char* __restrict__ cell_cls, CellHdr* __restrict__ cell_hdr,
+static_assert(64 % TR == 0, "k_pair_cells walks 64 / TR column tiles per step");
+__global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __restrict__ entries, const int2* __restrict__ entry_where,
+                                                        const RowRec* __restrict__ recs, const double* __restrict__ path_paint,
+                                                        const uint8_t* __restrict__ path_rule, int vc0, int n_ct, int mask_words,
+                                                        unsigned long long* __restrict__ tile_mask, CellHdr* __restrict__ cell_hdr,
                                                         int cell_cap, BatchDev* __restrict__ bd) {
     constexpr int NWV = PC_BLOCK / 64;
     __shared__ double s_sum[NWV][PC_CT][TR];
     __shared__ int s_cnt[NWV][PC_CT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int e = blockIdx.x * NWV + wave;
-    if (e >= bd->entry_cursor) return;  // (waves are independent: no workgroup barrier below)
-    const TileEntry en = entries[e];
+    const TileEntry en = entries[e];      // (both arrays hold the whole grid: loaded before the bound is known)
+    const int2 where = entry_where[e];    // {band, index in the band's list}
+    if (e >= bd->entry_cursor) return;    // (waves are independent: no workgroup barrier below)
     int ct0, nct;
     path_ctiles(en.c0, en.cols, vc0, ct0, nct);
+    // the tiles' entry bitmasks: per (band, column tile) two rows of mask_words words, bit i = entry i of the band's list
+    // has a cell of class >= 1 (row 0) / class 2 (row 1) here.  Classes 0 simply stay unset.
+    unsigned long long* const mrow = tile_mask + ((size_t)where.x * n_ct + ct0) * 2 * mask_words + (where.y >> 6);
+    const unsigned long long mbit = 1ull << (where.y & 63);
+    if ((where.y >> 6) >= mask_words) {  // (the plan sized the masks from the longest band list)
+        if (lane == 0) atomicOr(&bd->err, 32);
+        return;
+    }
     const int x_first = vc0 + ct0 * TC - en.c0;  // layer column where the path's first column tile starts (<= 0)
     const int rl = path_rule[en.p], rule = rl & 1;
     const double4 paint = ((const double4*)path_paint)[en.p];
-    double run = 0.0;  // lanes < TR: the row's running sum left of the current column tile
+    const int row_l = lane & (TR - 1), sub = lane / TR;  // this lane's row and its column tile of the four walked per step
+    double run = 0.0;  // the row's running sum left of the column tiles walked so far
     for (int base = 0; base < nct; base += PC_CT) {
         const int nc = nct - base < PC_CT ? nct - base : PC_CT;
         for (int i = lane; i < nc * TR; i += 64) (&s_sum[wave][0][0])[i] = 0.0;
@@ -1036,6 +1057,17 @@ __global__ __launch_bounds__(PC_BLOCK) void k_pair_cells(const TileEntry* __rest
             int cl = xl > 0 ? xl : 0;
             cl = cl < en.cols - 1 ? cl : en.cols - 1;
             int kf = (cf - x_first) / TC - base, kl = (cl - x_first) / TC - base;
+            if (kf == kl && xl < en.cols) {
+                // the usual case: every piece in one column tile, nothing cut off at the layer's right edge
+                if (kf >= 0 && kf < nc) {
+                    double sum = v[0] + v[1];
+                    if (n >= 3) sum = sum + (double)(n - 3) * v[2] + v[3];
+                    if (n >= 2) sum = sum + v[4];
+                    __hip_atomic_fetch_add(&s_sum[wave][kf][row], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&s_cnt[wave][kf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                continue;
+            }
             kf = kf > 0 ? kf : 0;
             kl = kl < nc - 1 ? kl : nc - 1;
             for (int k = kf; k <= kl; ++k) {
@@ -1050,24 +1082,43 @@ __global__ __launch_bounds__(PC_BLOCK) void k_pair_cells(const TileEntry* __rest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int k = 0; k < nc; ++k) {
-            const double part = lane < TR ? s_sum[wave][k][lane] : 0.0;
-            const int own = s_cnt[wave][k];
-            const bool vis = lane < TR && carry_visible(run, rule);
-            const int cls = own > 0 ? 2 : (__ballot(vis) != 0ull ? 1 : 0);
-            const int cell = en.cell0 + base + k;
-            if (cell < cell_cap) {
-                if (lane == 0) cell_cls[cell] = (unsigned char)cls;
-                if (cls != 0) {
-                    CellHdr* h = cell_hdr + cell;
-                    if (lane < TR) h->carry[lane] = run;
-                    if (lane == TR) { h->paint[0] = paint.x; h->paint[1] = paint.y; h->paint[2] = paint.z; h->paint[3] = paint.w; }
-                    if (lane == TR + 1) { h->rule = rule; h->flags = rl >> 1; h->n_own = own; h->cls = cls; }
-                }
-            } else if (lane == 0) {
-                atomicOr(&bd->err, 32);
+        // four column tiles per step: lane (sub, row) takes column tile k4 + sub; its carry-in = run + the sums of the
+        // column tiles of this step to its left (read back from the table: at most three)
+        for (int k4 = 0; k4 < nc; k4 += 64 / TR) {
+            const int k = k4 + sub;
+            double mine = 0.0, left = 0.0, all = 0.0;
+#pragma unroll
+            for (int q = 0; q < 64 / TR; ++q) {
+                const double sq = k4 + q < nc ? s_sum[wave][k4 + q][row_l] : 0.0;
+                left = q < sub ? left + sq : left;
+                all = all + sq;
+                mine = q == sub ? sq : mine;
             }
-            run += part;
+            (void)mine;
+            const double cin = run + left;
+            const bool live = k < nc;
+            const int own = live ? s_cnt[wave][k] : 0;
+            const bool vis = live && carry_visible(cin, rule);
+            const unsigned long long vm = __ballot(vis);
+            const unsigned long long rows_of_tile = TR == 64 ? ~0ull : ((1ull << (TR & 63)) - 1ull) << ((sub * TR) & 63);
+            const int cls = own > 0 ? 2 : ((vm & rows_of_tile) != 0ull ? 1 : 0);
+            const int cell = en.cell0 + base + k;
+            if (live && cls != 0) {
+                if (cell < cell_cap) {
+                    CellHdr* hd = cell_hdr + cell;
+                    hd->carry[row_l] = cin;
+                    if (row_l == 0) {
+                        unsigned long long* const mw = mrow + (size_t)(base + k) * 2 * mask_words;
+                        atomicOr(mw, mbit);
+                        if (cls == 2) atomicOr(mw + mask_words, mbit);
+                        hd->paint[0] = paint.x; hd->paint[1] = paint.y; hd->paint[2] = paint.z; hd->paint[3] = paint.w;
+                        hd->rule = rule; hd->flags = rl >> 1; hd->n_own = own; hd->cls = cls;
+                    }
+                } else if (row_l == 0) {
+                    atomicOr(&bd->err, 32);
+                }
+            }
+            run = run + all;
         }
     }
 }
@@ -1105,13 +1156,13 @@ __device__ __forceinline__ int lds_index(int trow, int tcol) {
 }
 
 struct TileArgs {
-    const int* band_start;     // per band: first entry, number of entries
-    const int* band_count;
+    const int* band_start;     // per band: first entry of its list
+    unsigned long long* tile_mask;  // per (band, column tile): which entries of the band's list have a visible cell here
+    int mask_words, n_ct;           // (k_pair_cells); each tile reads its words and clears them for the next render
     const TileEntry* entries;  // per band: the pairs with records, ascending path id
     const RowRec* bsegs;       // record blocks: per (path, band) pair its edge-row records
-    const unsigned char* cell_cls;  // per (pair, column tile) cell: class 0 / 1 / 2 (CellHdr)
-    const CellHdr* cell_hdr;        // ... and, for classes 1 and 2, paint + fill rule + the carry-in of every tile row
-    int cell_cap;                   // cells the two arrays hold (a batch that outgrew its plan is flagged, not read out of bounds)
+    const CellHdr* cell_hdr;        // per (pair, column tile) cell of class 1 or 2: paint, fill rule, carry-in of every tile row
+    int cell_cap;                   // cells the array holds (a batch that outgrew its plan is flagged, not read out of bounds)
     void* out;
     int vr0, vc0, vrows, vcols;  // viewport
     Owner own;                   // owned bands
@@ -1149,6 +1200,8 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
     int* const s_cell = (int*)(s_mem + OFF_CELL);
     int* const s_wcnt = (int*)(s_mem + OFF_WCNT);
     int clip_tag = -1;  // path whose coverage s_clip holds (canvas modes)
+    // LDS address of s_mem, once, as a scalar (the cast from the generic pointer carries a null test and a 64-bit lane value)
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)s_mem);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int trow = tid / CH, chunk = tid % CH;
@@ -1172,61 +1225,46 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
         for (unsigned i = 1 + wg * NT + tid; i < a.arena_words; i += n_wg * NT) a.arena[i] = 0u;
     }
 
-    const int ent_begin = a.band_start[band], ent_end = ent_begin + a.band_count[band];
-    // The band's tile list is scanned NT entries at a time; the entries that touch this tile's columns are appended to
-    // the LDS lists, and the per-path pipeline below runs when LCAP of them have gathered or the list ends -- so a
-    // tile usually pays the cold start of the record prefetch once, not once per NT entries of the band list.
-    static_assert(2 * NW <= 16, "s_wcnt is double-buffered by batch parity");
-    int pending = 0, batch_no = 0;
-    for (int base = ent_begin; base < ent_end; base += NT, ++batch_no) {
-        // Only `hit` and the lane's rank stay live across the per-path loop below; the entry itself is read again when it
-        // is moved to the lists (holding its seven values in registers through the loop cost a scratch spill per workgroup).
-        bool hit = false;
-        int cellw = 0;  // the tile's cell of this pair | class << 30
-        if (base + tid < ent_end) {
-            const int4 cc = *(const int4*)&a.entries[base + tid];  // {c0, cols, cell0, p}
-            if (cc.x < tile_c1 && cc.x + cc.y > tile_c0) {
-                // the pair's bbox reaches the tile: its cell says whether anything of it is visible here (class 0: no
-                // record in these columns and no winding carried in from the left -- a third of the bbox tiles of a blob)
-                const int cell = cc.z + (int)blockIdx.x - (cc.x - a.vc0) / TC;
-                const int cls = cell < a.cell_cap ? a.cell_cls[cell] : 0;
-                hit = cls != 0;
-                cellw = cell | (cls << 30);
+    // The tile's work list = the set bits of its entry bitmask (k_pair_cells), in list = paint order.  Every wave reads
+    // the words (one per lane) and ranks them by a wave scan, so that no workgroup barrier is needed to place the items;
+    // a wave then moves the hits of its own words to the LDS lists, LCAP items per round (one round for most tiles).
+    const int W = a.mask_words;
+    unsigned long long* const mw = a.tile_mask + ((size_t)band * a.n_ct + blockIdx.x) * 2 * W;
+    const int ent_begin = a.band_start[band];
+    for (int w0 = 0; w0 < W; w0 += 64) {
+        const int nw = W - w0 < 64 ? W - w0 : 64;
+        int total_all = 1;  // (known after the first round's scan)
+        for (int lo = 0; lo < total_all; lo += LCAP) {
+        int wl = lane;
+        asm volatile("" : "+v"(wl));  // (recompute the word's address here: kept across the item loop it is a scratch spill)
+        const unsigned long long m1 = wl < nw ? mw[w0 + wl] : 0ull;
+        int tot_;
+        const int before = wave_excl_scan(__popcll(m1), lane, tot_);
+        total_all = __builtin_amdgcn_readfirstlane(tot_);
+        if (total_all == 0) break;
+        const int take = total_all - lo < LCAP ? total_all - lo : LCAP;
+        for (int wi = wave; wi < nw; wi += NW) {
+            const unsigned long long mword = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(m1 >> 32), wi) << 32) |
+                                             (unsigned)__builtin_amdgcn_readlane((int)m1, wi);
+            const int bw = __builtin_amdgcn_readlane(before, wi) - lo;  // list slot of the word's first hit in this round
+            if (mword == 0ull || bw >= take || bw + __popcll(mword) <= 0) continue;
+            const int at = bw + mask_rank(mword);
+            if (((mword >> lane) & 1ull) && at >= 0 && at < take) {
+                const TileEntry e = a.entries[ent_begin + (w0 + wi) * 64 + lane];  // one 32-byte load per hit
+                const unsigned cls = ((mw[W + w0 + wi] >> lane) & 1ull) ? 2u : 1u;
+                const int cell = e.cell0 + (int)blockIdx.x - (e.c0 - a.vc0) / TC;
+                s_list[at] = e.p;
+                s_seg0[at] = e.seg0;
+                s_seg1[at] = cls == 2u && cell < a.cell_cap ? e.seg0 + e.cnt : e.seg0;  // (class 1: no record reaches the tile)
+                s_cell[at] = (int)((unsigned)(cell < a.cell_cap ? cell : 0) | (cls << 30));
+                s_bbox[at] = make_int4(e.r0, e.c0, e.rows, e.cols);
             }
         }
-        unsigned long long m = __ballot(hit);
-        int* const wcnt = s_wcnt + (batch_no & 1) * NW;
-        if (lane == 0) wcnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = 0, total_all = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            if (w < wave) off += wcnt[w];
-            total_all += wcnt[w];
-        }
-        const int slot = off + mask_rank(m);  // rank of this lane's path among the hits of this batch
-        const bool last_batch = base + NT >= ent_end;
-        int lo = 0;  // hits of this batch already moved to the lists
-        for (;;) {
-        const int room = LCAP - pending, rest = total_all - lo;
-        const int take = rest < room ? rest : room;
-        if (hit && slot >= lo && slot < lo + take) {
-            const TileEntry e = a.entries[base + tid];  // one 32-byte load per lane (L2: the tile's neighbours read it too)
-            const int at = pending + slot - lo;
-            s_list[at] = e.p;
-            s_seg0[at] = e.seg0;
-            s_seg1[at] = ((unsigned)cellw >> 30) == 2u ? e.seg0 + e.cnt : e.seg0;  // (class 1: no record reaches the tile)
-            s_cell[at] = cellw;
-            s_bbox[at] = make_int4(e.r0, e.c0, e.rows, e.cols);
-        }
-        pending += take;
-        lo += take;
-        if (!(pending == LCAP || (last_batch && lo == total_all && pending > 0))) {
-            if (lo == total_all) break;
-            continue;
-        }
-        const int total = pending;
-        pending = 0;
+#ifdef SVGR_DBG_NOITEMS
+        const int total = 0;  // diagnostic: the tile's fixed cost alone (lists are built, nothing is drawn)
+#else
+        const int total = take;
+#endif
         __syncthreads();
 
         // ------------------------------------------------------------------------------------------
@@ -1259,8 +1297,8 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
                     const int t_ = (wave * DMA_PER_WAVE + j) * 64 + lane;  // 16-byte chunk of the block this lane fetches
                     const int off_ = t_ * 16 < last_ ? t_ * 16 : last_;
                     const char* g = (off_ < HDR_BYTES ? hbase : rbase) + off_;
-                    const unsigned lds_base = __builtin_amdgcn_readfirstlane(
-                        (unsigned)(size_t)(lds_ptr_t)(s_mem + OFF_PREF + buf_ * PREF_BYTES + (wave * DMA_PER_WAVE + j) * 1024));
+                    const unsigned lds_base = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(
+                        OFF_PREF + buf_ * PREF_BYTES + (wave * DMA_PER_WAVE + j) * 1024);
                     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                                  :
                                  : "v"(g), "s"(lds_base)
@@ -1330,6 +1368,9 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
             // the tile to its last (np.cumsum of zeros, S:983).  No scatter, no second barrier, no delta-tile traffic: the
             // scan below gets the two deltas (+carry at the first column, -carry behind the last) straight in registers.
             const bool fast1 = SVGR_CLASS1 && OUT == 0 && !CLIP && cls == 1;
+#ifdef SVGR_DBG_STAMP
+            unsigned long long t3_ = t2_;
+#endif
             if (!fast1) {
             // ---- scatter: one lane per edge-row record; the pieces were computed by k_edge_emit, here the ones inside
             //      the tile's columns are added to the LDS delta tile.  What lies left of the tile arrives pre-summed as
@@ -1404,7 +1445,7 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
                 }
             }
 #ifdef SVGR_DBG_STAMP
-            unsigned long long t3_ = __builtin_amdgcn_s_memrealtime();
+            t3_ = __builtin_amdgcn_s_memrealtime();
 #endif
             if (OUT <= 1 && hi_c + col_shift < TC && tid < TR && tid >= row_shift && tid < row_shift + rows) {
                 // The layer's right edge is inside this tile.  Right of it the running sum is whatever winding
@@ -1593,9 +1634,11 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (lo == total_all) break;
-        }  // lists full / band list finished
-    }
+        }  // rounds of LCAP items
+    }  // 64 mask words at a time
+    // the masks are set bit by bit (atomicOr) by the next render's k_pair_cells: leave them cleared.  This tile is the
+    // only reader of its words and has listed everything.
+    for (int i = tid; i < 2 * W; i += NT) mw[i] = 0ull;
 
 #ifdef SVGR_DBG_STAMP
     if (tid == 0 && a.dbg) {
@@ -2083,8 +2126,11 @@ struct svgr_batch {
     DevArr<TileEntry> entries;
     DevArr<double> edges;
     DevArr<RowRec> bsegs;
-    DevArr<unsigned char> cell_cls;         // per (path, band, column tile) cell: class (CellHdr)
-    DevArr<CellHdr> cell_hdr;               // ... and header (classes 1 and 2)
+    DevArr<CellHdr> cell_hdr;               // per (path, band, column tile) cell: header (classes 1 and 2)
+    DevArr<int2> entry_where;               // per band-list entry: {band, index in the band's list}
+    DevArr<unsigned long long> tile_mask;   // per (band, column tile): 2 x mask_words words over the band's list (k_pair_cells)
+    int mask_words = 1;
+    bool masks_zeroed = false;              // the last tile kernel left the masks cleared
     DevArr<long long> layer_off;            // SVGR_OUT_MASKS_F64: per path the start of its mask in the output
     std::vector<long long> host_layer_off;
     // plan results (n_edges = edge slots the edge kernels cover = sum of the shard capacities; n_edges_live = filled ones)
@@ -2099,6 +2145,14 @@ struct svgr_batch {
     std::vector<TimedEvents> events;
     std::vector<hipEvent_t> event_pool;
 
+    int n_ctiles() const { return (vp[3] + TC - 1) / TC; }
+    size_t mask_bytes() const { return sizeof(unsigned long long) * 2 * (size_t)mask_words * (size_t)n_bands * (size_t)n_ctiles(); }
+    // size the tiles' entry bitmasks for band lists of up to `longest` entries
+    int size_masks(int64_t longest) {
+        mask_words = (int)std::max<int64_t>((longest + 63) / 64, 1);
+        masks_zeroed = false;
+        return tile_mask.ensure(mask_bytes() / sizeof(unsigned long long) + 1);
+    }
     BatchDev* bd() const { return (BatchDev*)arena.p; }
     unsigned long long* pkeys() const { return (unsigned long long*)(arena.p + off_pkeys); }
     unsigned* prow() const { return (unsigned*)(arena.p + off_prow); }
@@ -2121,7 +2175,7 @@ struct svgr_batch {
         segs.release(); path_m6.release(); path_paint.release(); seg_kind.release(); path_rule.release();
         seg_path.release(); in_dev.release(); arena.release(); edge_path.release(); bbox.release(); bins.release();
         bseg_off.release(); band_start.release(); band_count.release(); entries.release();
-        edges.release(); bsegs.release(); cell_cls.release(); cell_hdr.release(); layer_off.release();
+        edges.release(); bsegs.release(); cell_hdr.release(); entry_where.release(); tile_mask.release(); layer_off.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
         for (auto e : event_pool) (void)hipEventDestroy(e);
@@ -2175,16 +2229,20 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
         hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(BE_BLOCK), 0, st, (const PathBin*)b->bins.p, np,
                            (const int*)b->bbox.p, (const int*)b->pb_cnt(), b->bseg_off.p,
                            upto >= 4 ? cap_i32(b->bsegs.cap) : 0x7fffffff, b->band_start.p, b->band_count.p, b->entries.p,
-                           cap_i32(b->entries.cap), b->vp[1], b->bd(), b->own);
+                           b->entry_where.p, cap_i32(std::min(b->entries.cap, b->entry_where.cap)), b->vp[1], b->bd(), b->own);
     if (upto == 3) return 0;
     hipLaunchKernelGGL(k_edge_emit, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
                        (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->pb_cap, (const int*)b->bseg_off.p,
                        b->pb_cursor(), b->bsegs.p, cap_i32(b->bsegs.cap), b->bd(), b->own, b->shards);
     // per pair with records: classes and carry-ins of its column tiles
-    if (b->n_entries > 0)
+    if (b->n_entries > 0) {
+        if (!b->masks_zeroed) HIPCHK(hipMemsetAsync(b->tile_mask.p, 0, b->mask_bytes(), st));
+        b->masks_zeroed = false;  // (bits are set below; the tile kernel clears them again)
         hipLaunchKernelGGL(k_pair_cells, grid1((size_t)b->n_entries * 64, PC_BLOCK), dim3(PC_BLOCK), 0, st,
-                           (const TileEntry*)b->entries.p, (const RowRec*)b->bsegs.p, (const double*)b->path_paint.p,
-                           (const uint8_t*)b->path_rule.p, b->vp[1], b->cell_cls.p, b->cell_hdr.p, cap_i32(std::min(b->cell_cls.cap, b->cell_hdr.cap)), b->bd());
+                           (const TileEntry*)b->entries.p, (const int2*)b->entry_where.p, (const RowRec*)b->bsegs.p,
+                           (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p, b->vp[1], b->n_ctiles(), b->mask_words,
+                           b->tile_mask.p, b->cell_hdr.p, cap_i32(b->cell_hdr.cap), b->bd());
+    }
     return 0;
 }
 
@@ -2530,8 +2588,9 @@ static int plan_speculative(svgr_batch* b) {
     rc = rc ? rc : b->bseg_off.ensure((size_t)b->n_pb + 1);
     rc = rc ? rc : b->entries.ensure((size_t)b->n_pb);
     rc = rc ? rc : b->bsegs.ensure((size_t)rec_guess + PREF_RECS_MAX + 1);
-    rc = rc ? rc : b->cell_cls.ensure((size_t)b->n_cells + 1);
     rc = rc ? rc : b->cell_hdr.ensure((size_t)b->n_cells + 1);
+    rc = rc ? rc : b->entry_where.ensure((size_t)b->n_pb);
+    rc = rc ? rc : b->size_masks(np);
     if (rc) return rc;
     if ((rc = run_geometry(b, 4, true))) return rc;
     int cap_bits = 0;
@@ -2596,16 +2655,17 @@ static int batch_plan_impl(svgr_batch* b) {
     if (int rc = check_dev_err(b)) return rc;
     b->n_pb = b->host_bd.pb_cursor;
     b->n_cells = b->host_bd.cell_cursor;
-    if (int rc = b->cell_cls.ensure((size_t)std::max<int64_t>(b->n_cells, 1))) return rc;
     if (int rc = b->cell_hdr.ensure((size_t)std::max<int64_t>(b->n_cells, 1))) return rc;
     // 3. per-pair counts -> band segments
     if (int rc = b->layout_arena((int)b->n_pb)) return rc;
     if (int rc = b->bseg_off.ensure((size_t)b->n_pb + 1)) return rc;
     if (int rc = b->entries.ensure((size_t)std::max<int64_t>(b->n_pb, 1))) return rc;
+    if (int rc = b->entry_where.ensure((size_t)std::max<int64_t>(b->n_pb, 1))) return rc;
     if (int rc = run_geometry(b, 3, true)) return rc;
     if (int rc = check_dev_err(b)) return rc;
     b->n_bsegs = b->host_bd.bseg_cursor;
     b->n_entries = b->host_bd.entry_cursor;
+    if (int rc = b->size_masks(b->host_bd.max_band_entries)) return rc;
     if (int rc = b->bsegs.ensure((size_t)std::max<int64_t>(b->n_bsegs, 1) + PREF_RECS_MAX + 1)) return rc;
     // 4. full geometry once, to validate the capacities and fetch the bboxes
     if (int rc = run_geometry(b, 4, true)) return rc;
@@ -2798,9 +2858,10 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
 
     if (owned_bands > 0 && n_ctiles > 0) {
         TileArgs a;
-        a.band_start = b->band_start.p; a.band_count = b->band_count.p; a.entries = b->entries.p; a.bsegs = b->bsegs.p; a.out = out->ptr;
-        a.cell_cls = b->cell_cls.p; a.cell_hdr = b->cell_hdr.p;
-        a.cell_cap = cap_i32(std::min(b->cell_cls.cap, b->cell_hdr.cap));
+        a.band_start = b->band_start.p; a.entries = b->entries.p; a.bsegs = b->bsegs.p; a.out = out->ptr;
+        a.cell_hdr = b->cell_hdr.p;
+        a.cell_cap = cap_i32(b->cell_hdr.cap);
+        a.tile_mask = b->tile_mask.p; a.mask_words = b->mask_words; a.n_ct = b->n_ctiles();
         a.vr0 = b->vp[0]; a.vc0 = b->vp[1]; a.vrows = b->vp[2]; a.vcols = b->vp[3];
         a.own = b->own;
         a.out_cols = b->vp[3];
@@ -2838,6 +2899,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
             default: hipLaunchKernelGGL(k_tile_render<3>, grid, dim3(NT), 0, st, a); break;
         }
         b->arena_zeroed = true;  // (done by that kernel, see TileArgs::arena)
+        b->masks_zeroed = true;  // (every tile clears its own words)
     }
     if (timed) {
         HIPCHK(hipEventRecord(ev.e2, st));
