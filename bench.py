@@ -4,22 +4,32 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload synth4096|synth8192|tiger2048]
 
 One step = one full pass of the hot path over the scene, inputs resident in HBM when the clock
-starts: transform + flatten + bbox + band binning + tile kernel (LDS delta scatter, row scan, fill
-rule, paint, source-over) -> finished float32 RGBA canvas in HBM.  No host read-back inside a step.
+starts: transform + flatten + bbox + band binning + cell classification + tile kernel (LDS delta scatter,
+row scan, fill rule, paint, source-over) -> finished float32 RGBA canvas in HBM.  No host read-back inside a step.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU).  The path shards by rows (a scanline never needs another
-scanline), so the headline is WEAK scaling: a drawing N times as tall -- N blocks of the bench scene stacked, paths cross
-the block borders -- and every GPU renders its own 4096 x 4096 block of rows from the paths whose control points reach
-it (border paths go to both neighbours: duplicated geometry is the halo, no pixel ever crosses a GPU, no data-path
-collective).  Per-GPU work is fixed; `value` = path-pixels of all blocks / slowest rank's time.  RCCL is used for the
-barrier / max-over-ranks clock only.
+N = 1: the bench scene (BASELINE.json's metric configuration: 4096 paths @ 4096 x 4096).
 
-The same line carries `strong_scaling`, measured right after: the ONE 4096 x 4096 bench scene sharded over the N GPUs by
-interleaved strips of 128 scanlines (`svgr_batch_set_bands`; every rank culls the geometry to what reaches its strips),
-total work fixed, plus the optional all_gather of the strips -- the north star's "tile-parallel speedup" of a
-half-millisecond job, bounded by launch latencies.
+N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling of BASELINE.json's config 4 -- the ONE
+synthetic 10 000-path drawing @ 8192 x 8192, sharded over the N GPUs by interleaved strips of scanlines
+(`svgr_batch_set_bands`; every rank culls the geometry to what reaches its strips; edges that cross a strip border are
+simply kept by both owners: duplicated geometry is the halo, no pixel crosses a GPU, no data-path collective).  Total work is
+fixed; `value` = the drawing's path-pixels / the slowest rank's time.  RCCL carries the barrier / max-over-ranks clock and
+the optional all_gather of the strips (`all_gather_ms`, reported beside the step, never inside it).  The same line carries
+`single_gpu_same_scene` (rank 0 alone renders the whole drawing while the others wait: the denominator of the
+tile-parallel speed-up, measured in the same run) and `weak_scaling` (N stacked 4096-row blocks, one per GPU).
 
 Rank 0 prints ONE JSON line (contract in the task statement + `roofline` and `cpu_baseline`).
+
+`roofline`: the dominant kernel is k_tile_render.  It keeps the delta tile and the canvas tile on chip, so HBM is not what
+binds it; f64 VALU issue (and the per-item latency chain in front of it) is.  The block therefore reports, for the launch as
+timed live by HIP events in this run:
+  frac / bound "valu"   VALU wave-instructions per launch x 4 cycles / (1024 SIMDs x 2.4 GHz x t)  (SQ_INSTS_VALU, rocprofv3)
+  hbm.frac              measured HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) / t / 8 TB/s
+  hbm.floor_frac        bytes that must move (the canvas once + 32 B per edge) / t / 8 TB/s
+  effective_gbs         SURVEY 8d's algorithmic 40 B/path-pixel + 32 B/edge over t: a throughput figure, NOT a roofline
+                        fraction (the reference's memory passes are what it prices; this kernel never makes them)
+Counter values come from the committed profiles/pmc_kernels_<workload>.json (profiles/collect2.sh, separate --pmc passes
+on the same command); `counters` names the file and the commit it was collected at -- they are not re-measured in this run.
 """
 from __future__ import annotations
 
@@ -34,6 +44,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable copy)
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0  # wave-instructions / ns: 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles, 2.4 GHz
 BYTES_PER_PATH_PIXEL = 40  # read f64 trace 8 + read f32 RGBA 16 + write f32 RGBA 16
 BYTES_PER_EDGE = 32        # 4 doubles, read once
 
@@ -124,13 +135,80 @@ def cpu_baseline(sc, budget_paths: int | None = None):
     )
 
 
+def load_counters(workload: str):
+    """The committed per-kernel counter averages for `workload` (profiles/collect2.sh -> profiles/pmc_json.py), or None."""
+    path = os.path.join(ROOT, "profiles", f"pmc_kernels_{workload}.json")
+    if not os.path.exists(path):
+        return None, None
+    try:
+        rec = json.load(open(path))
+    except Exception:  # noqa: BLE001
+        return None, None
+    if rec.get("workload") != workload:
+        return None, None
+    return rec, os.path.relpath(path, ROOT)
+
+
+def roofline_block(tile_ms, geo_ms, n_timed, every, P_rank, E_rank, canvas_bytes, counters, counters_file, out_kind="f32"):
+    """The dominant kernel's launch, timed live (HIP events on the library's stream), against the limits that can bind it."""
+    t = tile_ms * 1e-3
+    alg_bytes = BYTES_PER_PATH_PIXEL * P_rank + BYTES_PER_EDGE * E_rank
+    floor_bytes = canvas_bytes + BYTES_PER_EDGE * E_rank
+    kern = None
+    if counters is not None:
+        kern = counters["kernels"].get("k_tile_render<0, false>")
+    valu = kern.get("SQ_INSTS_VALU") if kern else None
+    traffic = kern.get("hbm_bytes_per_launch") if kern else None
+    block = {
+        "kernel": f"k_tile_render<{out_kind}>",
+        "avg_launch_ms": round(tile_ms, 4), "geometry_ms": round(geo_ms, 4), "launches_timed": int(n_timed),
+        "timing": "HIP events on the library's stream around every %d-th launch of the timed region (rank 0)" % every,
+        "hbm": {
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "achieved": round(traffic / t / 1e9, 1) if traffic and t > 0 else None,
+            "frac": round(traffic / t / 1e9 / HBM_PEAK_GBS, 4) if traffic and t > 0 else None,
+            "traffic": traffic,
+            "floor_bytes": int(floor_bytes),
+            "floor_frac": round(floor_bytes / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None,
+            "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 --pmc, separate passes; gfx950 counts wide "
+                    "streaming reads at half their bytes); floor = the canvas written once + 32 B per edge: what has to move",
+        },
+        "effective_gbs": round(alg_bytes / t / 1e9, 1) if t > 0 else None,
+        "algorithmic_bytes_per_launch": int(alg_bytes),
+        "traffic": traffic,
+    }
+    if valu and t > 0:
+        achieved = valu / t / 1e9  # G wave-instructions / s
+        block.update({
+            "bound": "valu", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G VALU wave-instructions/s",
+            "frac": round(achieved / VALU_PEAK_GINST, 4),
+            "valu_wave_instructions_per_launch": int(valu),
+        })
+        note = ("bound: f64 VALU issue (every VALU wave-instruction holds its SIMD for 4 cycles; 1024 SIMDs x 2.4 GHz / 4 = "
+                "614.4 G/s) -- the kernel keeps the delta tile and the canvas tile on chip, HBM carries a fraction of its peak "
+                "(hbm.frac).  `effective_gbs` prices SURVEY 8d's 40 B/path-pixel + 32 B/edge, a throughput figure.")
+    else:
+        # no counter file for this workload / sharding: the only fraction that needs none is the HBM floor
+        block.update({
+            "bound": "hbm", "achieved": round(floor_bytes / t / 1e9, 1) if t > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(floor_bytes / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None,
+        })
+        note = ("no committed counter file for this workload / sharding: frac = the bytes that must move (canvas + 32 B/edge) "
+                "over the live launch time against the HBM peak; the kernel's own limit is VALU issue (see the N = 1 line)")
+    block["counters"] = ({"file": counters_file, "collected_at_commit": counters.get("head"), "measured_in_this_run": False}
+                         if counters is not None else None)
+    block["note"] = note
+    return block
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="synth4096")
+    ap.add_argument("--workload", default=None, help="default: synth4096 on one GPU, synth8192 (config 4) on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-companions", action="store_true", help="N > 1: skip the single-GPU reference and the weak-scaling run")
     ap.add_argument("--cpu-paths", type=int, default=None, help="limit the CPU baseline to the first N paths")
     ap.add_argument("--time-every", type=int, default=4,
                     help="bracket the stages of every n-th timed step with HIP events (each event drains the queue for ~8 us, "
@@ -160,6 +238,8 @@ def main():
             dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if args.workload is None:
+        args.workload = "synth4096" if world == 1 else "synth8192"
 
     import numpy as np  # noqa: F401
 
@@ -184,19 +264,24 @@ def main():
         dist.all_reduce(t, op=op)
         return [float(v) for v in t.cpu()]
 
-    def measure(batch, out):
-        """W warm-up steps, barrier, exactly K timed steps, barrier -> (max-over-ranks seconds, stage timings of this rank)"""
-        for _ in range(args.warmup):
-            batch.render(out, _abi.OUT_CANVAS_F32, flags)
+    def measure(batch, out, steps=None, active=True):
+        """W warm-up steps, barrier, exactly K timed steps, barrier -> (max-over-ranks seconds, stage timings of this rank).
+        `active` False: this rank only takes part in the barriers (single-GPU reference inside a multi-rank run)."""
+        steps = args.steps if steps is None else steps
+        if active:
+            for _ in range(args.warmup):
+                batch.render(out, _abi.OUT_CANVAS_F32, flags)
         barrier()
-        batch.timings()  # drop
+        if active:
+            batch.timings()  # drop
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            batch.render(out, _abi.OUT_CANVAS_F32, flags | (_abi.RENDER_TIMED if i % every == 0 else 0))
-        ctx.sync()
+        if active:
+            for i in range(steps):
+                batch.render(out, _abi.OUT_CANVAS_F32, flags | (_abi.RENDER_TIMED if i % every == 0 else 0))
+            ctx.sync()
         t_local = time.perf_counter() - t0
         barrier()
-        tm = batch.timings()  # HIP events on the library's stream around the stages of every `every`-th timed step
+        tm = batch.timings() if active else dict(n=0, ms_geometry=0.0, ms_tile=0.0, ms_total=0.0)
         t_max = reduce([t_local], dist.ReduceOp.MAX)[0] if dist is not None else t_local
         return t_max, tm
 
@@ -207,102 +292,96 @@ def main():
     sc, desc = load_workload(args.workload)
     rows, cols = int(sc["viewport"][2]), int(sc["viewport"][3])
     n_scene_paths = int(len(sc["path_seg_off"]) - 1)
-    weak_mode = world > 1 and args.workload.startswith("synth")
+    strip = int(os.environ.get("SVGR_STRIP_BANDS", str(max(1, 128 // _abi.tile_rows()))))  # 128 scanlines per strip
 
-    # ---- headline -------------------------------------------------------------------------------------------------
-    if weak_mode:
-        # a drawing `world` times as tall; this rank renders its own block of rows from the paths that reach it
-        tall = synth.make_tall_scene(rows, n_scene_paths, world)
-        mine, kept = synth.rows_subscene(tall, rank * rows, (rank + 1) * rows)
-        batch = new_batch(mine)
-        st = batch.plan()
-        out = ctx.alloc(rows * cols * 16)
-        t_max, tm = measure(batch, out)
-        P_rank, E_rank = int(st.path_pixels), int(st.n_edges)
-        P, E, inst = (int(v) for v in reduce([P_rank, E_rank, len(kept)], dist.ReduceOp.SUM))
-        config = {
-            "workload": f"{world} stacked blocks of: {desc}", "canvas": [rows * world, cols], "paths": n_scene_paths * world,
-            "edges": E, "path_pixels": P,
-            "sharding": f"{world} ranks, each renders its own {rows}-row block from the paths whose control points reach it "
-                        f"({inst} path instances in all: border paths go to both neighbours); no data-path collective",
-        }
-        scaling = "weak"
-        canvas_px = rows * world * cols
-        del out
-        batch.destroy()
+    # ---- headline: the ONE scene; N > 1: its rows sharded over the ranks (strong scaling) -----------------------------
+    batch = new_batch(sc)
+    st = batch.plan()
+    P = P_rank = int(st.path_pixels)
+    E = E_rank = int(st.n_edges)
+    if world > 1:
+        batch.set_bands(rank, world, strip)
+        st_r = batch.plan()  # per-rank capacities: each rank keeps only the geometry that reaches its strips
+        P_rank, E_rank = int(st_r.path_pixels), int(st_r.n_edges)  # (this rank's own plan: its clipped bboxes, its edges)
+    own_rows = max(batch.owned_rows(), 1)
+    if world > 1:
+        out_t = torch.empty((own_rows, cols, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+        out = ctx.wrap(out_t.data_ptr(), out_t.numel() * 4)
     else:
-        batch = new_batch(sc)
-        st = batch.plan()
-        P = P_rank = int(st.path_pixels)
-        E = E_rank = int(st.n_edges)
-        strip = int(os.environ.get("SVGR_STRIP_BANDS", str(max(1, 128 // _abi.tile_rows()))))  # 128 scanlines per strip
-        if world > 1:  # a real-asset workload on several GPUs: one scene, row strips
-            batch.set_bands(rank, world, strip)
-            batch.plan()
-            P_rank, E_rank = P / world, E / world
-        out = ctx.alloc(max(batch.owned_rows(), 1) * cols * 16)
-        t_max, tm = measure(batch, out)
-        config = {
-            "workload": desc, "canvas": [rows, cols], "paths": n_scene_paths, "edges": E, "path_pixels": P,
-            "sharding": f"{world} ranks x interleaved strips of {strip} bands ({strip * _abi.tile_rows()} rows)" if world > 1 else "single GPU",
-        }
-        # (the N = 1 point of the synthetic series is the same scene as block 0 of the weak-scaling drawing)
-        scaling = "weak" if args.workload.startswith("synth") and world == 1 else "strong"
-        canvas_px = rows * cols
+        out_t = None
+        out = ctx.alloc(own_rows * cols * 16)
+    t_max, tm = measure(batch, out)
+    config = {
+        "workload": desc, "canvas": [rows, cols], "paths": n_scene_paths, "edges": E, "path_pixels": P,
+        "sharding": (f"{world} ranks x interleaved strips of {strip} bands ({strip * _abi.tile_rows()} rows); no data-path collective"
+                     if world > 1 else "single GPU"),
+    }
+    scaling = "strong" if world > 1 else "weak"  # (N = 1 is the first point of either series)
+    canvas_px = rows * cols
+    extras = {}
+    if world > 1:
+        try:  # optional assembly of the full canvas on every rank (svgrasterize.py_amd/dist.py): beside the step, not in it
+            from svgrasterize_amd import dist as sdist
 
-    # ---- companion for N > 1: the ONE bench scene sharded over the ranks (strong scaling) ---------------------------------
-    strong = None
-    if weak_mode:
+            barrier()
+            g0 = time.perf_counter()
+            for _ in range(3):
+                full_t = sdist.gather_canvas(out_t if coll_dev != "cpu" else out_t.cpu(), rows, _abi.tile_rows(), strip=strip)
+            torch.cuda.synchronize()
+            extras["all_gather_ms"] = round((time.perf_counter() - g0) / 3 * 1e3, 4)
+            del full_t
+        except Exception as exc:  # noqa: BLE001
+            extras["all_gather_ms"] = {"error": repr(exc)}
+    del out
+    out_t = None
+
+    # ---- companions for N > 1 ---------------------------------------------------------------------------------------------
+    if world > 1 and not args.no_companions:
+        # (a) the same drawing on ONE GPU (rank 0 alone, the others wait at the barriers): the speed-up's denominator
         try:
-            sb = new_batch(sc)
-            st1 = sb.plan()
-            strip = int(os.environ.get("SVGR_STRIP_BANDS", str(max(1, 128 // _abi.tile_rows()))))
-            sb.set_bands(rank, world, strip)
-            sb.plan()  # per-rank capacities: each rank keeps only the geometry that reaches its strips
-            own_rows = sb.owned_rows()
-            out_t = torch.empty((own_rows, cols, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
-            sout = ctx.wrap(out_t.data_ptr(), out_t.numel() * 4)
-            s_max, _stm = measure(sb, sout)
-            strong = {
-                "scaling": "strong", "value": round(int(st1.path_pixels) / (s_max / args.steps) / 1e6, 1), "unit": "Mpixels/s",
-                "ms_per_step": round(s_max / args.steps * 1e3, 4), "path_pixels": int(st1.path_pixels),
-                "workload": f"the single-GPU bench scene ({n_scene_paths} paths @ {rows}x{cols}) sharded over {world} ranks by "
-                            f"interleaved strips of {strip * _abi.tile_rows()} rows",
+            batch.set_bands(0, 1, 1)
+            if rank == 0:
+                batch.plan()
+                out1 = ctx.alloc(rows * cols * 16)
+            s1, _tm1 = measure(batch, out1 if rank == 0 else None, steps=max(args.steps // 4, 10), active=rank == 0)
+            n1 = max(args.steps // 4, 10)
+            extras["single_gpu_same_scene"] = {
+                "ms_per_step": round(s1 / n1 * 1e3, 4), "value": round(P / (s1 / n1) / 1e6, 1), "unit": "Mpixels/s", "steps": n1,
+                "speedup_of_the_headline_over_it": round((s1 / n1) / (t_max / args.steps), 3),
             }
-            try:  # optional assembly of the full canvas on every rank (svgrasterize.py_amd/dist.py)
-                from svgrasterize_amd import dist as sdist
-
-                barrier()
-                g0 = time.perf_counter()
-                for _ in range(3):
-                    full_t = sdist.gather_canvas(out_t if coll_dev != "cpu" else out_t.cpu(), rows, _abi.tile_rows(), strip=strip)
-                torch.cuda.synchronize()
-                strong["all_gather_ms"] = round((time.perf_counter() - g0) / 3 * 1e3, 4)
-                del full_t
-            except Exception as exc:  # noqa: BLE001
-                print(f"[bench] rank {rank}: strip all_gather failed: {exc!r}", file=sys.stderr)
-            del sout, out_t
-            sb.destroy()
-        except Exception as exc:  # noqa: BLE001  (a companion must not cost the bench line)
-            print(f"[bench] rank {rank}: strong-scaling companion failed: {exc!r}", file=sys.stderr)
-            strong = None
+            if rank == 0:
+                del out1
+        except Exception as exc:  # noqa: BLE001
+            extras["single_gpu_same_scene"] = {"error": repr(exc)}
+        # (b) weak scaling: a drawing `world` times as tall (stacked 4096-row blocks), every rank renders its own block
+        try:
+            wsc, wdesc = load_workload("synth4096")
+            wrows, wcols = int(wsc["viewport"][2]), int(wsc["viewport"][3])
+            wn = int(len(wsc["path_seg_off"]) - 1)
+            tall = synth.make_tall_scene(wrows, wn, world)
+            mine, kept = synth.rows_subscene(tall, rank * wrows, (rank + 1) * wrows)
+            wb = new_batch(mine)
+            wst = wb.plan()
+            wout = ctx.alloc(wrows * wcols * 16)
+            w_max, _wtm = measure(wb, wout)
+            wP, winst = (int(v) for v in reduce([int(wst.path_pixels), len(kept)], dist.ReduceOp.SUM))
+            extras["weak_scaling"] = {
+                "scaling": "weak", "value": round(wP / (w_max / args.steps) / 1e6, 1), "unit": "Mpixels/s",
+                "ms_per_step": round(w_max / args.steps * 1e3, 4), "path_pixels": wP,
+                "workload": f"{world} stacked blocks of: {wdesc}; each rank renders its own {wrows}-row block from the paths whose "
+                            f"control points reach it ({winst} path instances in all); no data-path collective",
+            }
+            del wout
+            wb.destroy()
+        except Exception as exc:  # noqa: BLE001
+            extras["weak_scaling"] = {"error": repr(exc)}
+    batch.destroy()
 
     if rank == 0:
         n_timed = max(tm["n"], 1)
         tile_ms = tm["ms_tile"] / n_timed
         geo_ms = tm["ms_geometry"] / n_timed
-        # the dominant kernel as launched on this rank: its own share of the algorithmic bytes over its own duration
-        alg_bytes = BYTES_PER_PATH_PIXEL * P_rank + BYTES_PER_EDGE * E_rank
-        achieved = alg_bytes / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_tile_kernel.json")
-        if os.path.exists(pmc) and world == 1:
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("workload") == args.workload:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
+        counters, counters_file = load_counters(args.workload) if world == 1 else (None, None)
         line = {
             "metric": "Mpixels/sec AA coverage+composite (path-pixels/s; whole step: flatten+binning+coverage+composite)",
             "value": round(P / (t_max / args.steps) / 1e6, 1),
@@ -318,20 +397,9 @@ def main():
             "data": "synthetic" if args.workload.startswith("synth") else "real asset (scene dump)",
             "config": config,
             "canvas_mpixels_per_s": round(canvas_px / (t_max / args.steps) / 1e6, 1),
-            "roofline": {
-                "kernel": "k_tile_render<f32>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "avg_launch_ms": round(tile_ms, 4), "geometry_ms": round(geo_ms, 4), "launches_timed": int(tm["n"]),
-                "algorithmic_bytes_per_launch": int(alg_bytes),
-                "note": "effective bandwidth: 40 B/path-pixel + 32 B/edge (SURVEY 8d) over the HIP-event duration of the "
-                        "tile kernel (events on the library's stream around every %d-th launch of the timed region; rank 0's "
-                        "launch and its share of the bytes); the kernel keeps trace and canvas on chip, so frac may exceed "
-                        "what real HBM traffic could (`traffic` = measured HBM bytes per launch, rocprofv3 PMC); its own limit "
-                        "is f64 VALU issue (about two thirds of the duration on synth4096, profiles/ + DESIGN.md section 4)" % every,
-            },
+            "roofline": roofline_block(tile_ms, geo_ms, tm["n"], every, P_rank, E_rank, own_rows * cols * 16, counters, counters_file),
         }
-        if strong is not None:
-            line["strong_scaling"] = strong
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sc, args.cpu_paths)
         print(json.dumps(line))
