@@ -30,7 +30,7 @@ def main():
         ("tiger", "Ghostscript tiger @2048x2048 (182 solid fills, one batch)", 1.0, None),
         ("material", "material-design @4096x4096 (989 fills, 935 clips; per-node + batched runs)", 1.0, None),
         ("icons", "icons.svg @1114x286 native (431 gradients, 65 clips, 37 blurs)", 1.0, None),
-        ("icons", "icons.svg @4096x1051 (scale 3.677)", 4096 / 1114.0, None),
+        ("icons4096", "icons.svg @4096x1051 (config 5: the reference's loader at width 4096)", 1.0, None),
     ]
     for name, desc, scale, _ in cases:
         scene, info, z = scenedump.load_scene(os.path.join(ROOT, "tests", "golden", f"scene_{name}.npz"))

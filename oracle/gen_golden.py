@@ -1187,6 +1187,9 @@ def main() -> None:
         gen_scene(ref, fonts, "material", "material-design.svg", 4096, [1 / 16], args.full, crop=[1000, 1000, 160, 192])
     if todo("icons"):
         gen_scene(ref, fonts, "icons", "icons.svg", None, [1.0], False, store_layer=False)
+    if todo("icons4096"):
+        # config 5 at its stated size (4096 x 1051): scene dump + sparse pins of the reference's full render (--full)
+        gen_scene(ref, fonts, "icons4096", "icons.svg", 4096, [], args.full, store_layer=False)
     if todo("iconset"):
         # the reference's other demo icons at thumbnail size: real-world mixes of gradients, clips, masks, filters, strokes
         for svg in sorted(os.listdir(os.path.join(DEMO, "icons"))):

@@ -2094,6 +2094,68 @@ __global__ void k_layer_convolve_1d(double* __restrict__ out, const double* __re
     o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
 }
 
+// The same two passes for kernels of up to CONV_TAPS taps per axis (every blur of the configs: 73 at most), blocked so that
+// a source pixel is fetched once per block instead of once per tap, with the weights in the kernel argument (no device
+// copy of them, nothing for the host to wait for).  Taps are accumulated in ascending k like the plain kernels above.
+constexpr int CONV_TAPS = 160;
+struct ConvW {
+    int n, pad;
+    double w[CONV_TAPS];
+};
+// along a row (AXIS 1): one workgroup = 256 consecutive output columns of one row, the source span staged in LDS
+__global__ __launch_bounds__(256) void k_convolve_cols(double* __restrict__ out, const double* __restrict__ src, int rows, int cols,
+                                                       const ConvW cw) {
+    __shared__ double4 s_px[256 + CONV_TAPS - 1];
+    const int n = cw.n, ocols = cols + n - 1;
+    const int R = blockIdx.y, C0 = blockIdx.x * 256, tid = threadIdx.x;
+    const double4* srow = (const double4*)src + (size_t)R * cols;
+    for (int i = tid; i < 256 + n - 1; i += 256) {
+        const int c = C0 - (n - 1) + i;  // source column held at s_px[i]
+        s_px[i] = c >= 0 && c < cols ? srow[c] : make_double4(0.0, 0.0, 0.0, 0.0);
+    }
+    __syncthreads();
+    const int C = C0 + tid;
+    if (C >= ocols) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int k = 0; k < n; ++k) {  // out[C] = sum_k w[k] * src[C - k]; (a tap outside the source adds fma(0, w, a) = a)
+        const double wk = cw.w[k];
+        const double4 px = s_px[tid + (n - 1) - k];
+        a0 = fma(px.x, wk, a0); a1 = fma(px.y, wk, a1); a2 = fma(px.z, wk, a2); a3 = fma(px.w, wk, a3);
+    }
+    ((double4*)out)[(size_t)R * ocols + C] = make_double4(a0, a1, a2, a3);
+}
+// along a column (AXIS 0): one thread = CONV_RB consecutive output rows of one column; every source pixel of the
+// column span is loaded once (coalesced across the threads of a row) and feeds the outputs it reaches
+constexpr int CONV_RB = 8;
+__global__ __launch_bounds__(64) void k_convolve_rows(double* __restrict__ out, const double* __restrict__ src, int rows, int cols,
+                                                      const ConvW cw) {
+    const int n = cw.n, orows = rows + n - 1;
+    const int C = blockIdx.x * 64 + threadIdx.x, R0 = blockIdx.y * CONV_RB;
+    if (C >= cols) return;
+    double acc[CONV_RB][4];
+#pragma unroll
+    for (int r = 0; r < CONV_RB; ++r) acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.0;
+    // out[R] = sum_k w[k] * src[R - k]: walking the source rows downwards visits every output's taps in ascending k
+    int j_hi = R0 + CONV_RB - 1, j_lo = R0 - (n - 1);
+    j_hi = j_hi < rows - 1 ? j_hi : rows - 1;
+    j_lo = j_lo > 0 ? j_lo : 0;
+    for (int j = j_hi; j >= j_lo; --j) {
+        const double4 px = ((const double4*)src)[(size_t)j * cols + C];
+#pragma unroll
+        for (int r = 0; r < CONV_RB; ++r) {
+            const int k = R0 + r - j;  // (wave-uniform)
+            if (k >= 0 && k < n) {
+                const double wk = cw.w[k];
+                acc[r][0] = fma(px.x, wk, acc[r][0]); acc[r][1] = fma(px.y, wk, acc[r][1]);
+                acc[r][2] = fma(px.z, wk, acc[r][2]); acc[r][3] = fma(px.w, wk, acc[r][3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < CONV_RB; ++r)
+        if (R0 + r < orows) ((double4*)out)[(size_t)(R0 + r) * cols + C] = make_double4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+}
+
 // ======================================================================================
 // batch object
 // ======================================================================================
@@ -3210,20 +3272,42 @@ static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src
     // 1-D passes do the work of the kw x kh stencil (146 taps instead of 5329 for the largest blur of icons.svg).  A
     // rotated or skewed blur is not rank 1 and takes the direct 2-D kernel.  (The reference lets scipy pick an FFT here,
     // which carries ~1e-16 absolute noise itself; both device forms sum in double and stay below that.)
-    std::vector<double> u((size_t)kw, 0.0), v((size_t)kh, 0.0);
-    double total = 0.0, kmax = 0.0;
+    // (row / column sums in extended precision: summed in plain doubles their own rounding -- not the kernel's rank --
+    // decided the test below for some sizes, and a separable blur then took the 625-tap stencil)
+    std::vector<long double> ul((size_t)kw, 0.0L), vl((size_t)kh, 0.0L);
+    long double total_l = 0.0L;
+    double kmax = 0.0;
     for (int64_t i = 0; i < kw; ++i)
         for (int64_t j = 0; j < kh; ++j) {
             const double k = kernel[i * kh + j];
-            u[(size_t)i] += k; v[(size_t)j] += k; total += k;
+            ul[(size_t)i] += k; vl[(size_t)j] += k; total_l += k;
             kmax = std::fabs(k) > kmax ? std::fabs(k) : kmax;
         }
+    std::vector<double> u((size_t)kw), v((size_t)kh);
+    for (int64_t i = 0; i < kw; ++i) u[(size_t)i] = (double)ul[(size_t)i];
+    for (int64_t j = 0; j < kh; ++j) v[(size_t)j] = (double)vl[(size_t)j];
+    const double total = (double)total_l;
     bool separable = getenv("SVGR_BLUR_DIRECT") == nullptr && kw > 1 && kh > 1 && std::isfinite(total) && total != 0.0;
     for (int64_t i = 0; i < kw && separable; ++i)
         for (int64_t j = 0; j < kh; ++j)
             if (!(std::fabs(kernel[i * kh + j] - u[(size_t)i] * v[(size_t)j] / total) <= 8 * 2.220446049250313e-16 * kmax)) { separable = false; break; }
     hipError_t e = hipSuccess;
-    if (separable) {
+    if (separable && kw <= CONV_TAPS && kh <= CONV_TAPS && rows + kw - 1 <= 65535) {  // (the row index rides in gridDim.y)
+        for (auto& x : u) x /= total;  // K = (u / S) v^T
+        ConvW cu{}, cv{};
+        cu.n = (int)kw; cv.n = (int)kh;
+        for (int64_t i = 0; i < kw; ++i) cu.w[i] = u[(size_t)i];
+        for (int64_t j = 0; j < kh; ++j) cv.w[j] = v[(size_t)j];
+        double* tmp = nullptr;
+        const size_t n_tmp = (size_t)(rows + kw - 1) * (size_t)cols;
+        HIPCHK(g_pool.alloc((void**)&tmp, n_tmp * 32, ctx->device));
+        hipLaunchKernelGGL(k_convolve_rows, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + kw - 1 + CONV_RB - 1) / CONV_RB)), dim3(64), 0,
+                           ctx->stream, tmp, (const double*)src->ptr, (int)rows, (int)cols, cu);
+        hipLaunchKernelGGL(k_convolve_cols, dim3((unsigned)((cols + kh - 1 + 255) / 256), (unsigned)(rows + kw - 1)), dim3(256), 0,
+                           ctx->stream, (double*)out->ptr, (const double*)tmp, (int)(rows + kw - 1), (int)cols, cv);
+        e = hipGetLastError();
+        g_pool.release(tmp);  // (stream order keeps the block's next user behind the two kernels)
+    } else if (separable) {
         for (auto& x : u) x /= total;  // K = (u / S) v^T
         double *dw = nullptr, *tmp = nullptr;
         const size_t n_tmp = (size_t)(rows + kw - 1) * (size_t)cols;

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from tests.util import GOLDEN, assert_close64, assert_f32_1ulp, load
+from tests.util import GOLDEN, assert_close64, assert_f32_1ulp, f32_contract_counts, load
 
 
 def _meta():
@@ -117,13 +117,10 @@ def test_gpu_icons_scene():
     layer, _ = scene.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
     assert [int(v) for v in layer.offset] == r["layer_offset"]
     canvas = layer.to_canvas_f32(hh, ww)
-    ref = z["s286_canvas"]
-    err = np.abs(canvas.astype(np.float64) - ref.astype(np.float32))
-    # blur goes through FFT in the reference (scipy picks it): absolute noise ~1e-16 there, so the same
-    # float32 contract holds; allow the handful of float32 rounding ties an FFT-vs-direct difference can flip
-    tol = np.maximum(np.nextafter(np.abs(ref.astype(np.float32)), np.float32(np.inf)) - np.abs(ref.astype(np.float32)), 2.0 ** -24)
-    bad = err > tol
-    assert bad.sum() <= 8 and err.max() < 1e-6, (int(bad.sum()), float(err.max()))
+    # blur goes through FFT in the reference (scipy picks it): absolute noise ~1e-16 there, so the float32 contract holds
+    # except where that noise decides a float32 rounding tie or the 1e-6 coverage cut; the counts are recorded per class
+    c = f32_contract_counts(canvas, z["s286_canvas"], "icons.svg @1114x286")
+    assert c["other"] == 0 and c["cut"] == 0 and c["tie"] <= 2 and c["max_err"] < 1e-6, c  # (measured: 0 of every class)
 
 
 @pytest.mark.gpu
@@ -173,11 +170,8 @@ def test_gpu_demo_icon_thumbnails(name):
     layer, _ = scene.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
     assert [int(v) for v in layer.offset] == r["layer_offset"]
     canvas = layer.to_canvas_f32(hh, ww)
-    ref = z[f"{r['tag']}_canvas"].astype(np.float32)
-    err = np.abs(canvas.astype(np.float64) - ref)
-    tol = np.maximum(np.nextafter(np.abs(ref), np.float32(np.inf)) - np.abs(ref), 2.0 ** -24)
-    bad = err > tol  # (blurs: the reference's FFT carries ~1e-16 of noise, a handful of float32 ties may flip)
-    assert bad.sum() <= 8 and err.max() < 1e-6, (name, int(bad.sum()), float(err.max()))
+    c = f32_contract_counts(canvas, z[f"{r['tag']}_canvas"], f"{name} @192")  # (classes: see tests/util.py; counts on file)
+    assert c["other"] == 0 and c["cut"] == 0 and c["tie"] <= 2 and c["max_err"] < 1e-6, c  # (measured: 0 of every class)
 
 
 @pytest.mark.gpu
@@ -202,3 +196,23 @@ def test_gpu_gradients_with_many_stops():
         assert [int(v) for v in layer.offset] == m["offset"]
         assert_close64(layer.image, z[f"{i}_image"], atol=1e-11, what=f"{m} fill")
         assert_f32_1ulp(layer.image.astype(np.float32), z[f"{i}_image"], what=f"{m} fill")
+
+
+@pytest.mark.gpu
+def test_gpu_icons_4096():
+    """BASELINE config 5 at its stated size: demo/icons.svg at width 4096 (4096 x 1051; 431 gradient fills, 36 blurs with
+    kernels up to 73 x 73, S:1903-1944) against sparse pins of the reference's own render (sha256 of its float32 canvas
+    63dd9502a69c5a7c; oracle/gen_golden.py --only icons4096 --full)."""
+    import svgrasterize_amd as S
+    from svgrasterize_amd import scenedump
+
+    scene, info, z = scenedump.load_scene(os.path.join(GOLDEN, "scene_icons4096.npz"))
+    assert info["full"]["sha256_f32"].startswith("63dd9502a69c5a7c")
+    h, w = info["full"]["size"]
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    layer, _ = scene.render(tr, viewport=[0, 0, h, w], linear_rgb=False)
+    assert [int(v) for v in layer.offset] == info["full"]["layer_offset"]
+    assert list(layer.image.shape) == info["full"]["layer_shape"]
+    canvas = layer.to_canvas_f32(h, w)
+    c = f32_contract_counts(canvas.reshape(-1, 4)[z["full_idx"]], z["full_val"], f"icons.svg @{w}x{h} ({len(z['full_idx'])} pins)")
+    assert c["other"] == 0 and c["cut"] == 0 and c["tie"] <= 2 and c["max_err"] < 1e-6, c  # (measured: 0 of every class)
