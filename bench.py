@@ -68,8 +68,8 @@ def load_workload(name: str):
         tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
         leaves = scene.leaves(tr, linear_rgb=False)
         segs, kinds, offs = [], [], [0]
-        for path, _m6, _rule, _paint, _flags in leaves:
-            s, k = path.packed()
+        for leaf in leaves:
+            s, k = leaf[0].packed()
             segs.append(s)
             kinds.append(k)
             offs.append(offs[-1] + len(s))
@@ -79,6 +79,61 @@ def load_workload(name: str):
                   path_paint=np.array([l[3] for l in leaves]), viewport=(0, 0, h, w))
         return sc, "Ghostscript tiger (scene dump, 182 solid fills incl. pre-stroked outlines) @ 2048x2048"
     raise SystemExit(f"unknown workload {name}")
+
+
+SCENE_WORKLOADS = {  # real-asset configurations rendered through Scene.render (batched runs + per-node route)
+    "icons4096": ("scene_icons4096.npz", "demo/icons.svg @4096x1051 (config 5: 431 gradient fills, 36 blurs up to 73x73, 123 opacity groups)"),
+    "material4096": ("scene_material.npz", "demo/material-design.svg @4096x4096 (config 3: 989 fills, 935 clips)"),
+}
+
+
+def bench_scene(args):
+    """`--workload icons4096 | material4096`: one step = one Scene.render of the document (host tree walk + every device
+    launch it issues), result resident in HBM.  These configurations are bound by the host-side walk and per-node launch
+    latencies, not by a kernel: the line carries the wall clock and canvas pixels/s; the per-kernel durations and HBM
+    counters of the same command are in profiles/ (kernel_stats_<workload>*.csv, pmc_kernels_<workload>.json)."""
+    import svgrasterize_amd as S
+    from svgrasterize_amd import scenedump
+
+    fname, desc = SCENE_WORKLOADS[args.workload]
+    ctx = S.Context.get(int(os.environ.get("LOCAL_RANK", "0")))
+    scene, info, _z = scenedump.load_scene(os.path.join(ROOT, "tests", "golden", fname))
+    h, w = info["size"]
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+
+    def step():
+        layer, _hull = scene.render(tr, viewport=[0, 0, h, w], linear_rgb=False)
+        return layer._device()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        keep = step()
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    del keep
+    counters, counters_file = load_counters(args.workload)
+    stream = None
+    if counters is not None:  # the streaming kernels of the per-node route: measured bytes over their own durations
+        stream = {}
+        for k, v in counters["kernels"].items():
+            if v.get("hbm_bytes_per_launch") and v.get("counter_pass_avg_ns"):
+                gbs = v["hbm_bytes_per_launch"] / v["counter_pass_avg_ns"]
+                stream[k] = {"avg_us": round(v["counter_pass_avg_ns"] / 1e3, 1), "launches_per_step": v.get("kernel_trace_calls"),
+                             "hbm_gbs": round(gbs, 1), "frac_of_8000": round(gbs / HBM_PEAK_GBS, 4)}
+    print(json.dumps({
+        "metric": "canvas Mpixels/s through Scene.render (host walk + per-node launches; result resident in HBM)",
+        "value": round(h * w / dt / 1e6, 1), "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 arithmetic and f64 layers", "data": "real asset (scene dump)",
+        "config": {"workload": desc, "canvas": [h, w]},
+        "roofline": {"bound": "host", "note": "no kernel binds this configuration: the step is the Python tree walk plus hundreds of "
+                     "latency-bound launches; per-kernel HBM rates of the streaming kernels below", "kernels": stream,
+                     "counters": {"file": counters_file, "collected_at_commit": counters.get("head"), "measured_in_this_run": False}
+                     if counters is not None else None},
+    }))
 
 
 def cpu_baseline(sc, budget_paths: int | None = None):
@@ -240,6 +295,12 @@ def main():
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if args.workload is None:
         args.workload = "synth4096" if world == 1 else "synth8192"
+    if args.workload in SCENE_WORKLOADS:
+        if world > 1:
+            raise SystemExit("the scene workloads run on one GPU")
+        if args.steps == 200:
+            args.steps = 20  # (tens of milliseconds per step)
+        return bench_scene(args)
 
     import numpy as np  # noqa: F401
 

@@ -128,6 +128,15 @@ int svgr_batch_destroy(svgr_batch* batch);
 int svgr_batch_set_paints(svgr_batch* batch, const double* path_paint);
 int svgr_batch_set_transforms(svgr_batch* batch, const double* path_m6);
 
+/* Isolated groups inside one batch (Scene.render CLIP / OPACITY over a GROUP of solid fills, S:674-715; replaces one
+ * Scene.render recursion + Layer.compose round trip per group): path_group[p] = the group path p belongs to, or -1; the
+ * members of a group are consecutive paths.  When a group closes it is, as a whole, multiplied by the coverage of
+ * group_clip_src[g] (a SVGR_PATH_CLIP_SOURCE path right in front of the group's first member; -1: no clip:
+ * `Layer.compose([mask, group], COMPOSE_IN)`, S:712) and by group_opacity[g] (`Layer.opacity`, S:171-175; 1: none), then
+ * composited OVER what lies under it.  Canvas outputs only; n_groups = 0 removes the groups.  Call before svgr_batch_plan. */
+int svgr_batch_set_groups(svgr_batch* batch, const int32_t* path_group, int64_t n_groups, const int32_t* group_clip_src,
+                          const double* group_opacity);
+
 /* Multi-GPU sharding: rank `rank` of `world` keeps the strips s with s % world == rank, a strip being
  * `strip_bands` consecutive bands (band = svgr_tile_rows() scanlines).  The rank still computes every path's
  * exact bbox, but only flattens-to-memory, bins and renders what reaches its own bands; its output buffer holds

@@ -11,8 +11,8 @@ set -u
 tag="${1:-run}"; wl="${2:-synth4096}"
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 o=gpurun_out/$tag; rm -rf $o; mkdir -p $o
-python3 bench.py --workload $wl > $o/bench.json 2> $o/bench.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/kt -o kt -- python3 bench.py --workload $wl --no-cpu-baseline --steps 50 > $o/kt.log 2>&1 || exit 1
+python3 bench.py --workload $wl --steps ${STEPS:-200} > $o/bench.json 2> $o/bench.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/kt -o kt -- python3 bench.py --workload $wl --no-cpu-baseline --steps ${KT_STEPS:-50} > $o/kt.log 2>&1 || exit 1
 cp $(find $o/kt -name "*kernel_stats.csv" | head -1) $o/kernel_stats.csv
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $o/ps -o ps -- python3 bench.py --workload $wl --no-cpu-baseline --steps 10 --warmup 2 > $o/ps.log 2>&1 || exit 1
 cp $(find $o/ps -name "*counter_collection.csv" | head -1) $o/pmc_sq.csv

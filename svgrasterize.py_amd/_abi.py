@@ -89,6 +89,7 @@ _PROTOS = {
     "svgr_batch_set_paints": (C.c_int, [_P, _P]),
     "svgr_batch_set_transforms": (C.c_int, [_P, _P]),
     "svgr_batch_set_bands": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "svgr_batch_set_groups": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     "svgr_batch_plan": (C.c_int, [_P]),
     "svgr_batch_get_stats": (C.c_int, [_P, C.POINTER(BatchStats)]),
     "svgr_batch_get_bboxes": (C.c_int, [_P, _P]),
@@ -315,6 +316,16 @@ class Batch:
     def set_bands(self, rank: int, world: int, strip_bands: int = 1):
         """Shard by interleaved strips of `strip_bands` bands; call plan() again afterwards."""
         _check(self.ctx.lib.svgr_batch_set_bands(self.handle, rank, world, strip_bands))
+        self._stats = None
+
+    def set_groups(self, path_group, group_clip_src, group_opacity):
+        """Isolated groups (CLIP / OPACITY over a GROUP of solid fills): see svgr_batch_set_groups; call before plan()."""
+        pg = np.ascontiguousarray(path_group, dtype=np.int32).reshape(self.n_paths)
+        cs = np.ascontiguousarray(group_clip_src, dtype=np.int32).reshape(-1)
+        op = np.ascontiguousarray(group_opacity, dtype=np.float64).reshape(-1)
+        if len(cs) != len(op):
+            raise ValueError("one clip source and one opacity per group")
+        _check(self.ctx.lib.svgr_batch_set_groups(self.handle, pg.ctypes.data_as(_P), len(cs), cs.ctypes.data_as(_P), op.ctypes.data_as(_P)))
         self._stats = None
 
     def set_paints(self, paints):

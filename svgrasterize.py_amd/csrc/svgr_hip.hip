@@ -111,7 +111,7 @@ static_assert(sizeof(RowRec) == REC_BYTES, "RowRec size");
 struct CellHdr {
     double paint[4];
     int rule, flags;   // fill rule (0 nonzero, 1 evenodd), SVGR_PATH_* flags >> 1
-    int n_own, cls;    // records that touch the tile's columns; class as above
+    int group, cls;    // isolated group the path belongs to (-1: none); class as above
     double carry[SVGR_TR];
 };
 static_assert(sizeof(CellHdr) == HDR_BYTES, "CellHdr layout");
@@ -1012,7 +1012,8 @@ constexpr int PC_BLOCK = 256;
 static_assert(64 % TR == 0, "k_pair_cells walks 64 / TR column tiles per step");
 __global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __restrict__ entries, const int2* __restrict__ entry_where,
                                                         const RowRec* __restrict__ recs, const double* __restrict__ path_paint,
-                                                        const uint8_t* __restrict__ path_rule, int vc0, int n_ct, int mask_words,
+                                                        const uint8_t* __restrict__ path_rule, const int* __restrict__ path_group,
+                                                        int vc0, int n_ct, int mask_words,
                                                         unsigned long long* __restrict__ tile_mask, CellHdr* __restrict__ cell_hdr,
                                                         int cell_cap, BatchDev* __restrict__ bd) {
     constexpr int NWV = PC_BLOCK / 64;
@@ -1035,6 +1036,7 @@ __global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __r
     }
     const int x_first = vc0 + ct0 * TC - en.c0;  // layer column where the path's first column tile starts (<= 0)
     const int rl = path_rule[en.p], rule = rl & 1;
+    const int group = path_group ? path_group[en.p] : -1;
     const double4 paint = ((const double4*)path_paint)[en.p];
     const int row_l = lane & (TR - 1), sub = lane / TR;  // this lane's row and its column tile of the four walked per step
     double run = 0.0;  // the row's running sum left of the column tiles walked so far
@@ -1112,7 +1114,7 @@ __global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __r
                         atomicOr(mw, mbit);
                         if (cls == 2) atomicOr(mw + mask_words, mbit);
                         hd->paint[0] = paint.x; hd->paint[1] = paint.y; hd->paint[2] = paint.z; hd->paint[3] = paint.w;
-                        hd->rule = rule; hd->flags = rl >> 1; hd->n_own = own; hd->cls = cls;
+                        hd->rule = rule; hd->flags = rl >> 1; hd->group = group; hd->cls = cls;
                     }
                 } else if (row_l == 0) {
                     atomicOr(&bd->err, 32);
@@ -1163,6 +1165,8 @@ struct TileArgs {
     const RowRec* bsegs;       // record blocks: per (path, band) pair its edge-row records
     const CellHdr* cell_hdr;        // per (pair, column tile) cell of class 1 or 2: paint, fill rule, carry-in of every tile row
     int cell_cap;                   // cells the array holds (a batch that outgrew its plan is flagged, not read out of bounds)
+    const int* group_clip_src;      // per isolated group: path id of the clip source that clips it as a whole, or -1
+    const double* group_opacity;    // ... and the opacity it is faded with when it closes (1: none)
     void* out;
     int vr0, vc0, vrows, vcols;  // viewport
     Owner own;                   // owned bands
@@ -1177,8 +1181,11 @@ struct TileArgs {
 // OUT: 0 = canvas f32, 1 = canvas f64, 2 = mask f64 (single path), 3 = fill f64 (single path)
 // CLIP: the batch contains SVGR_PATH_CLIP_SOURCE / SVGR_PATH_CLIPPED paths (one more LDS tile: its own instantiation,
 // so that batches without clips keep their occupancy)
-template <int OUT, bool CLIP = false>
-__global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_EU) void k_tile_render(const TileArgs a) {
+// GROUPS (implies CLIP): the batch contains isolated groups (SVGR_PATH_GROUP_MEMBER): a second register tile accumulates
+// the group, which is clipped / faded as a whole when it closes (Scene.render CLIP / OPACITY over a GROUP, S:674-715)
+template <int OUT, bool CLIP = false, bool GROUPS = false>
+__global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_EU)) void k_tile_render(const TileArgs a) {
+    static_assert(!GROUPS || (CLIP && OUT <= 1), "groups live in the canvas variants with the clip tile");
     // ONE __shared__ object, carved by hand: with a second object beside the LDS-DMA staging area
     // hipcc (ROCm 7.2) drains vmcnt(0) before every ds_read and the record prefetch stops overlapping
     constexpr int OFF_TRACE = 0;
@@ -1217,6 +1224,32 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
     unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tstart_ = __builtin_amdgcn_s_memrealtime();
 #endif
+    // Isolated groups: while one is open its members composite into `gacc`; when an item of another group (or of none)
+    // arrives, or the tile's list ends, the group is closed: multiplied by the coverage of its clip path (the clip tile, if
+    // that path reached this tile: else the intersection is empty here, S:403-404), by its opacity, and composited OVER
+    // the canvas tile -- per pixel the reference's sequence: group layer, `Layer.compose([mask, image], IN)` /
+    // `Layer.opacity`, then the parent's OVER (S:674-715).
+    double gacc[GROUPS ? PX : 1][4];
+    int open_g = -1;
+    auto close_group = [&]() {
+        if (GROUPS) {
+            const int cs = a.group_clip_src[open_g];
+            const double al = a.group_opacity[open_g];
+            const double* const myclip = s_trace + trow * ROW_STRIDE + chunk * CHUNK_STRIDE + (OFF_CLIP - OFF_TRACE) / 8;
+            const bool have_clip = cs < 0 || clip_tag == cs;
+#pragma unroll
+            for (int i = 0; i < (GROUPS ? PX : 1); ++i) {
+                double s0 = gacc[i][0], s1 = gacc[i][1], s2 = gacc[i][2], s3 = gacc[i][3];
+                if (cs >= 0) {
+                    const double c = have_clip ? myclip[i] : 0.0;
+                    s0 = s0 * c; s1 = s1 * c; s2 = s2 * c; s3 = s3 * c;
+                }
+                if (al != 1.0) { s0 = s0 * al; s1 = s1 * al; s2 = s2 * al; s3 = s3 * al; }
+                over_px(acc[i], s0, s1, s2, s3);
+            }
+            open_g = -1;
+        }
+    };
 
     for (int i = tid; i < TR * ROW_STRIDE; i += NT) s_trace[i] = 0.0;
     __syncthreads();
@@ -1363,6 +1396,13 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
                 }
             }
             ++li;
+            const int item_g = GROUPS ? *((const int*)(blk + 4) + 2) : -1;  // CellHdr::group
+            if (GROUPS && open_g >= 0 && item_g != open_g) close_group();
+            if (GROUPS && item_g >= 0 && open_g < 0) {
+                open_g = item_g;
+#pragma unroll
+                for (int i = 0; i < (GROUPS ? PX : 1); ++i) gacc[i][0] = gacc[i][1] = gacc[i][2] = gacc[i][3] = 0.0;
+            }
 
             // Class 1: no record reaches the tile, so a row's running sum is its carry-in from the layer's first column in
             // the tile to its last (np.cumsum of zeros, S:983).  No scatter, no second barrier, no delta-tile traffic: the
@@ -1586,7 +1626,9 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
                                 if (c == 0.0) continue;
                                 s0 = s0 * c; s1 = s1 * c; s2 = s2 * c; s3 = s3 * c;
                             }
-                            if (OUT == 0) {
+                            if (GROUPS && item_g >= 0) {
+                                over_px(gacc[GROUPS ? i : 0], s0, s1, s2, s3);  // a member of the open group
+                            } else if (OUT == 0) {
                                 // over_px_fma with the fma written in place (v_fma_f64 acc, acc, k, s): left to the
                                 // compiler it becomes v_fmac into the source register plus a v_mov back, 4 moves per pixel
                                 const double k1 = 1 - s3;
@@ -1636,6 +1678,7 @@ __global__ __launch_bounds__(NT, CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_E
         __syncthreads();
         }  // rounds of LCAP items
     }  // 64 mask words at a time
+    if (GROUPS && open_g >= 0) close_group();
     // the masks are set bit by bit (atomicOr) by the next render's k_pair_cells: leave them cleared.  This tile is the
     // only reader of its words and has listed everything.
     for (int i = tid; i < 2 * W; i += NT) mw[i] = 0ull;
@@ -2172,6 +2215,10 @@ struct svgr_batch {
     Owner own{0, 1, 1};
     bool planned = false;
     bool has_clips = false;    // any SVGR_PATH_CLIP_SOURCE / SVGR_PATH_CLIPPED path
+    int64_t n_groups = 0;      // isolated groups (svgr_batch_set_groups)
+    DevArr<int> path_group, group_clip_src;
+    DevArr<double> group_opacity;
+    std::vector<uint8_t> host_rule;  // the paths' rule / flag bytes (checked against the groups)
     // inputs
     DevArr<double> segs, path_m6, path_paint;
     DevArr<uint8_t> seg_kind, path_rule;
@@ -2237,6 +2284,7 @@ struct svgr_batch {
         segs.release(); path_m6.release(); path_paint.release(); seg_kind.release(); path_rule.release();
         seg_path.release(); in_dev.release(); arena.release(); edge_path.release(); bbox.release(); bins.release();
         bseg_off.release(); band_start.release(); band_count.release(); entries.release();
+        path_group.release(); group_clip_src.release(); group_opacity.release();
         edges.release(); bsegs.release(); cell_hdr.release(); entry_where.release(); tile_mask.release(); layer_off.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
@@ -2297,12 +2345,18 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                        (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->pb_cap, (const int*)b->bseg_off.p,
                        b->pb_cursor(), b->bsegs.p, cap_i32(b->bsegs.cap), b->bd(), b->own, b->shards);
     // per pair with records: classes and carry-ins of its column tiles
+    // (the tiles read their mask words whether or not any pair has records: a batch without entries still needs them clear --
+    //  a block from the cache is not zero)
+    if (!b->masks_zeroed && b->tile_mask.p) {
+        HIPCHK(hipMemsetAsync(b->tile_mask.p, 0, b->mask_bytes(), st));
+        b->masks_zeroed = true;
+    }
     if (b->n_entries > 0) {
-        if (!b->masks_zeroed) HIPCHK(hipMemsetAsync(b->tile_mask.p, 0, b->mask_bytes(), st));
         b->masks_zeroed = false;  // (bits are set below; the tile kernel clears them again)
         hipLaunchKernelGGL(k_pair_cells, grid1((size_t)b->n_entries * 64, PC_BLOCK), dim3(PC_BLOCK), 0, st,
                            (const TileEntry*)b->entries.p, (const int2*)b->entry_where.p, (const RowRec*)b->bsegs.p,
-                           (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p, b->vp[1], b->n_ctiles(), b->mask_words,
+                           (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p,
+                           b->n_groups > 0 ? (const int*)b->path_group.p : (const int*)nullptr, b->vp[1], b->n_ctiles(), b->mask_words,
                            b->tile_mask.p, b->cell_hdr.p, cap_i32(b->cell_hdr.cap), b->bd());
     }
     return 0;
@@ -2542,6 +2596,7 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
     for (int i = 0; i < 4; ++i) b->vp[i] = b->has_vp ? (int)d->viewport[i] : 0;
     b->thr = (d->flatness * d->flatness) * 16.0;  // S:2093
     for (int64_t p = 0; p < d->n_paths; ++p) b->has_clips = b->has_clips || (d->path_rule[p] & (SVGR_PATH_CLIP_SOURCE | SVGR_PATH_CLIPPED));
+    b->host_rule.assign(d->path_rule, d->path_rule + d->n_paths);
     const size_t ns = (size_t)d->n_segs, np = (size_t)d->n_paths;
     int rc = 0;
     // The inputs travel as ONE host blob -> ONE device block (six small pageable copies cost more than the data): the blob
@@ -2615,6 +2670,47 @@ int svgr_batch_set_bands(svgr_batch* b, int rank, int world, int strip_bands) {
     if (!b || world <= 0 || rank < 0 || rank >= world || strip_bands <= 0) return fail(SVGR_E_INVALID, "bad band selection");
     b->own = Owner{rank, world, strip_bands};
     b->planned = false;  // the edge / record capacities are per rank
+    return 0;
+}
+
+// Isolated groups (Scene.render CLIP / OPACITY over a GROUP of solid fills, S:674-715) inside one batch: the members of a
+// group are consecutive paths; when the group closes it is multiplied by the coverage of its clip source (the path right
+// in front of its first member) and / or by its opacity, and composited OVER the canvas as a whole.
+int svgr_batch_set_groups(svgr_batch* b, const int32_t* path_group, int64_t n_groups, const int32_t* group_clip_src,
+                          const double* group_opacity) {
+    if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
+    if (n_groups == 0) { b->n_groups = 0; b->geometry_fresh = false; return 0; }
+    if (n_groups < 0 || n_groups > b->n_paths || !path_group || !group_clip_src || !group_opacity)
+        return fail(SVGR_E_INVALID, "svgr_batch_set_groups: bad arguments");
+    std::vector<int64_t> first((size_t)n_groups, -1), last((size_t)n_groups, -1);
+    for (int64_t p = 0; p < b->n_paths; ++p) {
+        const int g = path_group[p];
+        if (g < -1 || g >= n_groups) return fail(SVGR_E_INVALID, "path %lld: group %d out of range", (long long)p, g);
+        if (g < 0) continue;
+        if (b->host_rule[(size_t)p] & (SVGR_PATH_CLIP_SOURCE | SVGR_PATH_CLIPPED))
+            return fail(SVGR_E_INVALID, "path %lld: a group member cannot be a clip source or a clipped path itself", (long long)p);
+        if (first[(size_t)g] < 0) first[(size_t)g] = p;
+        else if (last[(size_t)g] != p - 1) return fail(SVGR_E_INVALID, "group %d: members must be consecutive paths", g);
+        last[(size_t)g] = p;
+    }
+    for (int64_t g = 0; g < n_groups; ++g) {
+        if (first[(size_t)g] < 0) return fail(SVGR_E_INVALID, "group %lld has no member", (long long)g);
+        const int cs = group_clip_src[g];
+        if (cs != -1 && (cs != first[(size_t)g] - 1 || !(b->host_rule[(size_t)cs] & SVGR_PATH_CLIP_SOURCE)))
+            return fail(SVGR_E_INVALID, "group %lld: its clip source must be the path right in front of its first member", (long long)g);
+        if (!std::isfinite(group_opacity[g])) return fail(SVGR_E_INVALID, "group %lld: opacity is not finite", (long long)g);
+    }
+    HIPCHK(hipSetDevice(b->ctx->device));
+    if (int rc = b->path_group.ensure((size_t)b->n_paths)) return rc;
+    if (int rc = b->group_clip_src.ensure((size_t)n_groups)) return rc;
+    if (int rc = b->group_opacity.ensure((size_t)n_groups)) return rc;
+    hipStream_t st = b->ctx->stream;
+    HIPCHK(hipMemcpyAsync(b->path_group.p, path_group, sizeof(int) * (size_t)b->n_paths, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->group_clip_src.p, group_clip_src, sizeof(int) * (size_t)n_groups, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->group_opacity.p, group_opacity, sizeof(double) * (size_t)n_groups, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // (the arrays are the caller's)
+    b->n_groups = n_groups;
+    b->geometry_fresh = false;  // the cell headers carry the group ids
     return 0;
 }
 
@@ -2872,6 +2968,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
     if (layers) out_kind = SVGR_OUT_MASK_F64;
     const bool single = out_kind >= 2;
     if (single && !layers && b->n_paths != 1) return fail(SVGR_E_INVALID, "mask/fill outputs need a single-path batch");
+    if (single && b->n_groups > 0) return fail(SVGR_E_INVALID, "isolated groups exist in the canvas outputs only");
     if (layers && b->own.world > 1) return fail(SVGR_E_INVALID, "per-path mask output is not sharded");
     HIPCHK(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
@@ -2924,6 +3021,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         a.cell_hdr = b->cell_hdr.p;
         a.cell_cap = cap_i32(b->cell_hdr.cap);
         a.tile_mask = b->tile_mask.p; a.mask_words = b->mask_words; a.n_ct = b->n_ctiles();
+        a.group_clip_src = b->group_clip_src.p; a.group_opacity = b->group_opacity.p;
         a.vr0 = b->vp[0]; a.vc0 = b->vp[1]; a.vrows = b->vp[2]; a.vcols = b->vp[3];
         a.own = b->own;
         a.out_cols = b->vp[3];
@@ -2950,11 +3048,13 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         static const int dyn_lds = getenv("SVGR_DBG_DYNLDS") ? atoi(getenv("SVGR_DBG_DYNLDS")) : 0;  // occupancy experiments
         switch (out_kind) {
             case 0:
-                if (b->has_clips) hipLaunchKernelGGL((k_tile_render<0, true>), grid, dim3(NT), 0, st, a);
+                if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render<0, true, true>), grid, dim3(NT), 0, st, a);
+                else if (b->has_clips) hipLaunchKernelGGL((k_tile_render<0, true>), grid, dim3(NT), 0, st, a);
                 else hipLaunchKernelGGL((k_tile_render<0, false>), grid, dim3(NT), dyn_lds, st, a);
                 break;
             case 1:
-                if (b->has_clips) hipLaunchKernelGGL((k_tile_render<1, true>), grid, dim3(NT), 0, st, a);
+                if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render<1, true, true>), grid, dim3(NT), 0, st, a);
+                else if (b->has_clips) hipLaunchKernelGGL((k_tile_render<1, true>), grid, dim3(NT), 0, st, a);
                 else hipLaunchKernelGGL((k_tile_render<1, false>), grid, dim3(NT), 0, st, a);
                 break;
             case 2: hipLaunchKernelGGL(k_tile_render<2>, grid, dim3(NT), 0, st, a); break;

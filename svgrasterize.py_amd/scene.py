@@ -331,10 +331,27 @@ def _stroked(scene: Scene) -> Path:
     return out
 
 
+_GROUP_SERIAL = [0]
+_BATCH_GROUPS = __import__("os").environ.get("SVGR_NO_BATCH_GROUPS") is None  # (off: isolated groups take the per-node route)
+
+
+def _new_group(opacity: float, clipped: bool):
+    """Tag shared by the members of one isolated group: (serial, opacity, clipped by the clip source in front of it)."""
+    _GROUP_SERIAL[0] += 1
+    return (_GROUP_SERIAL[0], float(opacity), bool(clipped))
+
+
+def _plain(leaves) -> bool:
+    return all(leaf[4] == 0 and leaf[5] is None for leaf in leaves)
+
+
 def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opacity: float | None = None):
-    """[(path, m6, rule, paint4)] when `scene` is only GROUP / TRANSFORM / solid FILL /
-    OPACITY-directly-over-a-leaf; None otherwise.  Source-over is associative, so flattening
-    nested groups keeps the per-pixel result (to double rounding)."""
+    """[(path, m6, rule, paint4, flags, group)] when `scene` is only GROUP / TRANSFORM / solid FILL / OPACITY directly over a
+    leaf, a CLIP by a single path of a leaf or of a group of plain leaves, or an OPACITY over a group of plain leaves;
+    None otherwise.  flags: 0 painted, 1 clip source (coverage only), 2 clipped by the clip source right in front of it;
+    group: None, or the tag of the isolated group the leaf is a member of (the device composites the members into a group
+    tile and clips / fades that as a whole, svgr_batch_set_groups).  Source-over is associative, so flattening nested
+    plain groups keeps the per-pixel result (to double rounding)."""
     kind, args = scene
     if kind == RENDER_FILL:
         path, paint, rule = args
@@ -347,7 +364,7 @@ def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opac
         p4 = solid_paint(paint, linear_rgb)
         if opacity is not None:
             p4 = p4 * opacity  # Layer.opacity: image * opacity (S:174)
-        return [(path, transform.m6(), _RULES[rule], p4, 0)]
+        return [(path, transform.m6(), _RULES[rule], p4, 0, None)]
     if kind == RENDER_STROKE:  # a solid stroke is a solid fill of its outline (S:666-672), nonzero rule
         path, paint, width, linecap, linejoin = args
         return _batchable_leaves(Scene.fill(_stroked(scene), paint, None), transform, linear_rgb, opacity)
@@ -359,17 +376,28 @@ def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opac
             target = target[1][0]
         if target[0] in (RENDER_FILL, RENDER_STROKE):  # opacity over a single leaf commutes with the fill
             return _batchable_leaves(args[0], transform, linear_rgb, args[1])
-        return None
+        # OPACITY over a group of plain leaves (S:690-696): the group is composited on its own and faded as a whole
+        members = _batchable_leaves(args[0], transform, linear_rgb) if _BATCH_GROUPS else None
+        if members is None or not members or not _plain(members):
+            return None
+        tag = _new_group(args[1], False)
+        return [(m[0], m[1], m[2], m[3], 0, tag) for m in members]
     if kind == RENDER_CLIP and opacity is None and not args[2]:
         # CLIP whose target and clip are single paths: two consecutive batch entries, the clip path as a
         # coverage-only "clip source" and the fill multiplied by it (Layer.compose([mask, image], IN), S:698-715).
         # (A group under a clip is NOT the same as clipping each child: (A over B)*c != (A*c) over (B*c).)
         target = _batchable_leaves(args[0], transform, linear_rgb)
         clip_leaf = _single_mask_leaf(args[1], transform)
-        if target is None or clip_leaf is None or len(target) != 1 or target[0][4] != 0:
+        if target is None or clip_leaf is None or not target or not _plain(target):
             return None
-        t = target[0]
-        return [clip_leaf, (t[0], t[1], t[2], t[3], 2)]
+        if len(target) == 1:
+            t = target[0]
+            return [clip_leaf, (t[0], t[1], t[2], t[3], 2, None)]
+        if not _BATCH_GROUPS:
+            return None
+        # a GROUP under the clip: composited on its own, then multiplied by the clip's coverage as a whole
+        tag = _new_group(1.0, True)
+        return [clip_leaf] + [(t[0], t[1], t[2], t[3], 0, tag) for t in target]
     if kind == RENDER_GROUP and opacity is None:
         out = []
         for child in args:
@@ -392,40 +420,41 @@ def _single_mask_leaf(scene: Scene, transform: Transform):
     path, _paint, rule = args
     if rule not in _RULES:
         raise ValueError(f"Invalid fill rule: {rule}")
-    return (path, transform.m6(), _RULES[rule], np.zeros(4), 1)
+    return (path, transform.m6(), _RULES[rule], np.zeros(4), 1, None)
 
 
 def effective_bboxes(leaves, bboxes):
-    """Per painted leaf the bbox its layer would have in the reference: its own clipped bbox, or for a clipped
-    fill the intersection with its clip's bbox (canvas_merge_intersect, S:392-404).  None = nothing to draw."""
+    """Per painted leaf the bbox its layer would have in the reference: its own clipped bbox, or for a clipped fill (and for
+    the members of a clipped group) the intersection with the clip's bbox (canvas_merge_intersect, S:392-404).
+    None = nothing to draw."""
     out = []
+    clip_box = None  # bbox of the last clip source seen (None: empty)
     for i, leaf in enumerate(leaves):
-        flags = leaf[4]
-        if flags == 1:
-            continue
+        flags, group = leaf[4], leaf[5]
         r0, c0, rows, cols = (int(v) for v in bboxes[i])
-        if rows <= 0 or cols <= 0:
-            out.append(None)
+        box = (r0, c0, r0 + rows, c0 + cols) if rows > 0 and cols > 0 else None
+        if flags == 1:
+            clip_box = box
             continue
-        r1, c1 = r0 + rows, c0 + cols
-        if flags == 2:
-            q0, d0, qr, qc = (int(v) for v in bboxes[i - 1])
-            if qr <= 0 or qc <= 0:
-                out.append(None)
-                continue
-            r0, c0, r1, c1 = max(r0, q0), max(c0, d0), min(r1, q0 + qr), min(c1, d0 + qc)
-            if r0 >= r1 or c0 >= c1:
-                out.append(None)
-                continue
-        out.append((r0, c0, r1 - r0, c1 - c0))
+        if box is not None and (flags == 2 or (group is not None and group[2])):
+            if clip_box is None:
+                box = None
+            else:
+                box = (max(box[0], clip_box[0]), max(box[1], clip_box[1]), min(box[2], clip_box[2]), min(box[3], clip_box[3]))
+                if box[0] >= box[2] or box[1] >= box[3]:
+                    box = None
+        out.append(None if box is None else (box[0], box[1], box[2] - box[0], box[3] - box[1]))
     return out
 
 
 def build_batch(leaves, viewport, ctx=None) -> "_abi.Batch":
-    """Pack paint-ordered leaves [(path, m6, rule, paint4)] into one device batch."""
+    """Pack paint-ordered leaves [(path, m6, rule, paint4, flags[, group])] into one device batch."""
     ctx = ctx or _abi.Context.get()
     segs, kinds, offs, m6s, rules, paints = [], [], [0], [], [], []
-    for path, m6, rule, paint, flags in leaves:
+    path_group, group_src, group_op, serial_to_gid = [], [], [], {}
+    for i, leaf in enumerate(leaves):
+        path, m6, rule, paint, flags = leaf[:5]
+        group = leaf[5] if len(leaf) > 5 else None
         s, k = path.packed()
         segs.append(s)
         kinds.append(k)
@@ -433,10 +462,22 @@ def build_batch(leaves, viewport, ctx=None) -> "_abi.Batch":
         m6s.append(m6)
         rules.append(rule | (flags << 1))  # SVGR_PATH_CLIP_SOURCE = 2, SVGR_PATH_CLIPPED = 4
         paints.append(paint)
+        if group is None:
+            path_group.append(-1)
+        else:
+            gid = serial_to_gid.get(group[0])
+            if gid is None:
+                gid = serial_to_gid[group[0]] = len(group_src)
+                group_src.append(i - 1 if group[2] else -1)  # the clip source sits right in front of the first member
+                group_op.append(group[1])
+            path_group.append(gid)
     segs = np.concatenate(segs) if segs else np.zeros((0, 8))
     kinds = np.concatenate(kinds) if kinds else np.zeros(0, dtype=np.uint8)
     vp = None if viewport is None else [int(v) for v in viewport]
-    return _abi.Batch(ctx, segs, kinds, offs, np.array(m6s), rules, np.array(paints), viewport=vp, flatness=FLATNESS)
+    batch = _abi.Batch(ctx, segs, kinds, offs, np.array(m6s), rules, np.array(paints), viewport=vp, flatness=FLATNESS)
+    if group_src:
+        batch.set_groups(path_group, group_src, group_op)
+    return batch
 
 
 def _render_run(leaves, viewport, linear_rgb):
@@ -477,7 +518,7 @@ def _render_run(leaves, viewport, linear_rgb):
     # empty returned None there and does not count; one that is partly visible counts with ALL its lines (S:993).  Clip
     # paths do not belong to it (S:715 returns the target's hull).
     in_hull = np.zeros(len(leaves), dtype=bool)
-    in_hull[[i for i, leaf in enumerate(leaves) if leaf[4] != 1]] = [b is not None for b in eff]
+    in_hull[[i for i, leaf in enumerate(leaves) if leaf[4] != 1]] = [b is not None for b in eff]  # (clip sources: no part of it)
 
     def hull_points():
         edges, edge_path = batch.all_edges()
@@ -487,17 +528,27 @@ def _render_run(leaves, viewport, linear_rgb):
 
 
 def _drop_empty(leaves):
-    """Remove leaves without segments; a clipped fill goes together with its clip source and vice versa."""
+    """Remove leaves without segments.  A clip source goes together with what it clips (the clipped fill, or the members of
+    the clipped group behind it): without the source nothing of them is visible, without them the source is not needed."""
+    has_segs = lambda leaf: len(leaf[0].packed()[0]) > 0  # noqa: E731
     out, i = [], 0
     while i < len(leaves):
         leaf = leaves[i]
-        if leaf[4] == 1:  # clip source + its target
-            pair = leaves[i:i + 2]
-            if all(len(l[0].packed()[0]) for l in pair):
-                out.extend(pair)
-            i += 2
+        if leaf[4] == 1:  # clip source + its dependants
+            j = i + 1
+            if j < len(leaves) and leaves[j][4] == 2:
+                j += 1
+            else:
+                tag = leaves[j][5] if j < len(leaves) else None
+                while j < len(leaves) and leaves[j][5] is not None and leaves[j][5] is tag and tag[2]:
+                    j += 1
+            deps = [l for l in leaves[i + 1:j] if has_segs(l)]
+            if has_segs(leaf) and deps:
+                out.append(leaf)
+                out.extend(deps)
+            i = j
             continue
-        if len(leaf[0].packed()[0]):
+        if has_segs(leaf):
             out.append(leaf)
         i += 1
     return out

@@ -290,3 +290,23 @@ def test_device_ops_on_host_resident_layers(S):
     filled = P.pattern_fill(pat, mask, hull, S.Transform(), True)
     assert filled is not None and filled.image.shape == mask.image.shape[:2] + (4,)
     assert filled.image[..., 3].max() == 1.0 and filled.image[..., 3].min() == 0.0
+
+
+def test_batches_without_any_edge_row_after_busy_ones(S):
+    """A batch whose paths have a bbox but no edge row (horizontal lines) lists nothing for its tiles -- and the tiles must
+    find their entry bitmasks clear even when the batch's buffers come out of the block cache dirty (they did not once:
+    a GPU memory fault in k_tile_render that only showed after other batches had run)."""
+    from svgrasterize_amd import _abi, synth
+
+    ctx = S.Context.get()
+    for _ in range(3):   # leave cached blocks full of set bits / entries behind
+        sc = synth.make_scene(512, 200)
+        b = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
+                       viewport=sc["viewport"])
+        b.plan()      # (geometry only: the masks stay set, then the blocks go back to the cache)
+        b.destroy()
+    for vp in (None, [0, 0, 40, 40]):
+        layer, _ = S.Path.from_svg("M1,1 H9 M2,5 H30").mask(S.Transform(), viewport=vp)
+        assert not layer.image.any()
+        res = S.Path.from_svg("M1,1 H9").fill(S.Transform(), np.array([0.5, 0.25, 0.1, 1.0]), viewport=vp)
+        assert res is not None and not res[0].image.any()
