@@ -23,6 +23,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pw -o pw -- python3 bench.p
 cp $(find $o/pw -name "*counter_collection.csv" | head -1) $o/pmc_write.csv
 rm -rf $o/kt $o/pf $o/pw $o/ps
 python3 profiles/pmc_json.py $wl $o > $o/pmc_kernels.json
+# (scene workloads dispatch thousands of kernels: the raw per-dispatch tables would not fit the 64 MiB that travel back)
+for f in $o/pmc_sq.csv $o/pmc_sq_trace.csv $o/pmc_fetch.csv $o/pmc_write.csv; do [ $(stat -c %s $f) -gt 4000000 ] && rm -f $f; done
 cat $o/pmc_kernels.json
 cut -c1-140 $o/kernel_stats.csv | head -10
 cat $o/bench.json

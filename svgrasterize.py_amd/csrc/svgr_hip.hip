@@ -576,9 +576,11 @@ __host__ __device__ __forceinline__ void path_ctiles(int c0, int cols, int vc0, 
 static_assert(sizeof(PathBin) == 16, "PathBin is one dwordx4");
 
 // bbox = {r0, c0, rows, cols}; viewport = same or has_vp = 0
+// `stats`: fold the batch statistics (non-empty paths, path-pixels, union bbox) into BatchDev: only the plan reads them, and
+// their six atomics per wave on shared addresses are most of this kernel's time when a render repeats the geometry
 __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __restrict__ pkeys, int n_paths, int has_vp,
                                                   int vr0, int vc0, int vrows, int vcols, int* __restrict__ bbox,
-                                                  PathBin* __restrict__ bins, BatchDev* __restrict__ bd) {
+                                                  PathBin* __restrict__ bins, BatchDev* __restrict__ bd, int stats) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     int out[4] = {0, 0, 0, 0};
     int pb0 = 0, pnb = 0, pnct = 0;
@@ -629,6 +631,7 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
     const long long want_cells = has_vp ? (long long)pnb * pnct : 0ll;  // (no viewport yet: the pass only finds the union)
     if (want_cells > (1ll << 28)) atomicOr(&bd->err, 32);
     const int cell_off = wave_alloc(&bd->cell_cursor, want_cells > (1ll << 28) ? 0 : (int)want_cells, lane);
+    if (stats)
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {  // statistics: fold the wave, then one set of atomics
         st_n += __shfl_xor(st_n, d);
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
         st_minr = a > st_minr ? a : st_minr; st_minc = b > st_minc ? b : st_minc;
         st_maxr = c > st_maxr ? c : st_maxr; st_maxc = e > st_maxc ? e : st_maxc;
     }
-    if (lane == 0 && st_n > 0) {
+    if (stats && lane == 0 && st_n > 0) {
         atomicAdd(&bd->n_nonempty, st_n);
         atomicAdd(&bd->path_pixels, st_px);
         atomicMax(&bd->umin_r, st_minr);
@@ -747,13 +750,6 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
     // path w * chunk + g * 64 + l, so every load is coalesced and list order = (wave, group, lane).
     const int groups = (n_paths + BE_BLOCK - 1) / BE_BLOCK, chunk = groups * 64;
     const int p_wave = wave * chunk;
-    auto pair_of = [&](int p, int& pair) -> int {  // records of path p in this band; 0: bbox does not reach it / no edge row
-        if (p >= n_paths) return 0;
-        const PathBin pbin = bins[p];
-        if (!(pbin.nb > 0 && band >= pbin.b0 && band < pbin.b0 + pbin.nb)) return 0;
-        pair = pbin.pb_off + band - pbin.b0;
-        return pb_cnt[pair];
-    };
     int kcnt[BE_KEEP], kpair[BE_KEEP];
     PathBin kb[BE_KEEP];
     int my_n = 0, my_r = 0;  // this lane's entries / record slots, over all its groups
@@ -780,10 +776,32 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
             if (kcnt[g] > 0) { ++my_n; my_r += kcnt[g]; }
         }
     }
-    for (int g = BE_KEEP; g < groups; ++g) {
-        int pair;
-        const int c = pair_of(p_wave + g * 64 + lane, pair);
-        if (c > 0) { ++my_n; my_r += c; }
+    // (more than BE_KEEP * 1024 paths: the rest four groups at a time, again with the loads of a stage in flight together)
+    auto load4 = [&](int g0, PathBin* tb, int* tcnt, int* tpair) {
+        bool mem[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = p_wave + (g0 + j) * 64 + lane;
+            tb[j] = bins[g0 + j < groups && p < n_paths ? p : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = p_wave + (g0 + j) * 64 + lane;
+            mem[j] = g0 + j < groups && p < n_paths && tb[j].nb > 0 && band >= tb[j].b0 && band < tb[j].b0 + tb[j].nb;
+            tpair[j] = mem[j] ? tb[j].pb_off + band - tb[j].b0 : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tcnt[j] = pb_cnt[tpair[j]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tcnt[j] = mem[j] ? tcnt[j] : 0;
+    };
+    for (int g0 = BE_KEEP; g0 < groups; g0 += 4) {
+        PathBin tb[4];
+        int tcnt[4], tpair[4];
+        load4(g0, tb, tcnt, tpair);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (tcnt[j] > 0) { ++my_n; my_r += tcnt[j]; }
     }
     int wn = my_n, wr = my_r;  // wave totals
 #pragma unroll
@@ -845,12 +863,19 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
         for (int j = 0; j < 2; ++j)
             if (kcnt[g + j] > 0) store(p_wave + (g + j) * 64 + lane, kpair[g + j], kcnt[g + j], me[j], mr[j], bb[j], kb[g + j]);
     }
-    for (int g = BE_KEEP; g < groups; ++g) {
-        int pair = 0, me, mr;
-        const int p = p_wave + g * 64 + lane;
-        const int c = pair_of(p, pair);
-        place(c, me, mr);
-        if (c > 0) store(p, pair, c, me, mr, ((const int4*)bbox)[p], bins[p]);
+    for (int g0 = BE_KEEP; g0 < groups; g0 += 4) {
+        PathBin tb[4];
+        int tcnt[4], tpair[4], me[4], mr[4];
+        load4(g0, tb, tcnt, tpair);
+        int4 bb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (g0 + j < groups) place(tcnt[j], me[j], mr[j]);  // (whole groups only: every lane of the wave scans)
+            bb[j] = tcnt[j] > 0 ? ((const int4*)bbox)[p_wave + (g0 + j) * 64 + lane] : make_int4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (tcnt[j] > 0) store(p_wave + (g0 + j) * 64 + lane, tpair[j], tcnt[j], me[j], mr[j], bb[j], tb[j]);
     }
 }
 
@@ -1205,7 +1230,6 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     int* const s_seg0 = (int*)(s_mem + OFF_SEG0);
     int* const s_seg1 = (int*)(s_mem + OFF_SEG1);
     int* const s_cell = (int*)(s_mem + OFF_CELL);
-    int* const s_wcnt = (int*)(s_mem + OFF_WCNT);
     int clip_tag = -1;  // path whose coverage s_clip holds (canvas modes)
     // LDS address of s_mem, once, as a scalar (the cast from the generic pointer carries a null test and a 64-bit lane value)
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)s_mem);
@@ -2319,7 +2343,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                                use_vp ? (b->vp[2] + TR - 1) / TR : 0, prow);
         if (upto == 0)  // bboxes only (no edges stored): enough to find the union when there is no viewport
             hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np,
-                               use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd());
+                               use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), 1);
         return 0;
     }
     if (ns > 0)
@@ -2328,7 +2352,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                            b->edges.p, b->edge_path.p, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
                            use_vp ? (b->vp[2] + TR - 1) / TR : 0, prow);
     hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np, use_vp ? 1 : 0,
-                       b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd());
+                       b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), b->planned ? 0 : 1);
     if (upto == 2) return 0;
     const size_t ne = (size_t)std::max<int64_t>(b->n_edges, 1);
     hipLaunchKernelGGL(k_edge_count, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,

@@ -98,6 +98,10 @@ class Transform:
         """The six numbers the C ABI takes: rows 0-1 of the matrix."""
         return np.ascontiguousarray(self.m[:2, :], dtype=FLOAT).reshape(6)
 
+    def key(self) -> bytes:
+        """The matrix as bytes (memo keys)."""
+        return self.m[:2, :].tobytes()
+
     def __repr__(self) -> str:
         return str(np.around(self.m, 4).tolist()[:2])
 
@@ -566,10 +570,25 @@ def _offset(bb, viewport):
     return (int(bb[0]), int(bb[1]))
 
 
+_PAINT_MEMO: dict = {}  # (4 doubles as bytes, linear_rgb) -> converted paint: documents reuse a handful of colours
+
+
 def solid_paint(paint: np.ndarray, linear_rgb: bool) -> np.ndarray:
     """The 4-vector colour step of Path.fill (S:1014-1018): premultiplied linear RGBA ->
     premultiplied RGBA of the compositing space.  Four numbers, done on the host in double."""
     out = np.array(paint, dtype=FLOAT)
+    key = (out.tobytes(), bool(linear_rgb))
+    hit = _PAINT_MEMO.get(key)
+    if hit is not None:
+        return hit.copy()
+    if len(_PAINT_MEMO) > 8192:
+        _PAINT_MEMO.clear()
+    out = _solid_paint(out, linear_rgb)
+    _PAINT_MEMO[key] = out.copy()
+    return out
+
+
+def _solid_paint(out: np.ndarray, linear_rgb: bool) -> np.ndarray:
     if not linear_rgb:
         rgb, alpha = out[:3], out[3:]
         np.divide(rgb, alpha, out=rgb, where=alpha > 0.0001)

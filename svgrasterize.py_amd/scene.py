@@ -305,7 +305,7 @@ _LEAF_MEMO: "dict | None" = None  # during one top-level render: what the pre-pa
 def _leaves_memo(child: Scene, transform: Transform, linear_rgb: bool, store: bool = False):
     if _LEAF_MEMO is None:
         return _batchable_leaves(child, transform, linear_rgb)
-    key = (id(child), transform.m6().tobytes(), linear_rgb)
+    key = (id(child), transform.key(), linear_rgb)
     if key in _LEAF_MEMO:
         return _LEAF_MEMO[key]
     res = _batchable_leaves(child, transform, linear_rgb)
