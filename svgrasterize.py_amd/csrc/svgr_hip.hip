@@ -80,6 +80,9 @@ constexpr int PREF_RECS = (PREF_BYTES - HDR_BYTES) / REC_BYTES;   // records per
 constexpr int PREF_DEPTH = SVGR_PREF_DEPTH;             // record blocks in the ring: paths li, li+1[, li+2]
 constexpr int LCAP = 32;                                // compacted paths of a tile worked off per sub-batch
 constexpr int NW = NT / 64;                // waves per workgroup
+#ifndef SVGR_TOUCH
+#define SVGR_TOUCH 0                    // 1: warm L2 with the lines of the item after next while the next one's DMA is in flight
+#endif                                  //    (measured on synth4096: tile kernel 0.209 -> 0.219 ms, so off: the wait is not an L2 miss)
 #ifndef SVGR_CLASS1
 #define SVGR_CLASS1 1                   // constant-coverage cells take the composite-only path (0: through scatter + scan)
 #endif
@@ -1220,8 +1223,8 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     constexpr int OFF_SEG0 = OFF_LIST + LCAP * 4;                        // int[NT]: first record of the (path, band) pair
     constexpr int OFF_SEG1 = OFF_SEG0 + LCAP * 4;                        // int[NT]: one past the last
     constexpr int OFF_CELL = OFF_SEG1 + LCAP * 4;                        // int[NT]: the tile's cell of the pair | class << 30
-    constexpr int OFF_WCNT = OFF_CELL + LCAP * 4;                        // int[NW]
-    constexpr int OFF_CLIP = OFF_WCNT + 16 * 4;                        // canvas modes: coverage tile of a clip path
+    constexpr int OFF_TOUCH = OFF_CELL + LCAP * 4;                       // 256 B nobody reads: target of the L2 warm-up loads
+    constexpr int OFF_CLIP = OFF_TOUCH + (SVGR_TOUCH ? 256 : 16);      // canvas modes: coverage tile of a clip path
     constexpr int LDS_BYTES = OFF_CLIP + (CLIP ? TR * ROW_STRIDE * 8 : 16);
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[LDS_BYTES];
     double* const s_trace = (double*)(s_mem + OFF_TRACE);
@@ -1363,13 +1366,36 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
                 }
             }
         };
-        // the prefetch cursor runs two items ahead of the work cursor
+        // L2 warm-up for the item after the one whose DMA was just issued: ONE load instruction of wave 0, a lane per 128-byte
+        // line of that item's header and records, landing in an LDS corner nobody reads (LDS-DMA: no destination register
+        // to keep alive).  The block's own DMA, an item later, then finds its lines in L2 instead of paying the trip to
+        // HBM / the Infinity Cache inside the per-item chain.  It counts in wave 0's vmcnt like any other load.
+        auto touch = [&](int li_) {
+            if (SVGR_TOUCH && wave == 0) {
+                const int seg0_ = __builtin_amdgcn_readfirstlane(s_seg0[li_]), seg1_ = __builtin_amdgcn_readfirstlane(s_seg1[li_]);
+                const int cell_ = __builtin_amdgcn_readfirstlane(s_cell[li_]) & 0x3fffffff;
+                const int left_ = seg1_ - seg0_;
+                const int n_bytes = (left_ < PREF_RECS ? left_ : PREF_RECS) * REC_BYTES;
+                const char* const hbase = (const char*)(a.cell_hdr + cell_);
+                const char* const rbase = (const char*)(a.bsegs + seg0_);
+                // lanes 0-1: the header's lines; lanes 2..: every 128 bytes of the records, the last lane their last bytes
+                int off_ = (lane - 2) * 128;
+                off_ = off_ < n_bytes - 4 ? off_ : n_bytes - 4;
+                const char* g = lane < 2 || n_bytes == 0 ? hbase + (lane == 0 ? 0 : HDR_BYTES - 4) : rbase + off_;
+                const unsigned lds_base = lds0 + OFF_TOUCH;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory");
+            }
+        };
+        // the prefetch cursor runs ahead of the work cursor
         int pf_li = 0, pf_k = 0;
+        bool touched = false;  // the newest load of wave 0 is a warm-up load (one more operation that may stay in flight)
         auto issue_next = [&]() {
+            touched = false;
             if (pf_li < total) {
                 issue(pf_li, pf_k % PREF_DEPTH);
                 ++pf_k;
                 ++pf_li;  // one item per path: slots past the block are read straight from HBM by the scatter
+                if (SVGR_TOUCH && pf_li < total) { touch(pf_li); touched = true; }
             }
         };
         issue_next();
@@ -1385,8 +1411,15 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
 #ifdef SVGR_DBG_STAMP
             unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();
 #endif
-            if (pf_k > k + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // item k has landed when only what was issued after it is still in flight: the next item's DMA (deeper rings) and,
+            // in wave 0, the warm-up load
+            if (pf_k > k + 1) {
+                if (SVGR_TOUCH && touched && wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+            } else {
+                if (SVGR_TOUCH && touched && wave == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
 #ifdef SVGR_DBG_STAMP
             unsigned long long t1_ = __builtin_amdgcn_s_memrealtime();
 #endif
