@@ -310,3 +310,84 @@ def test_batches_without_any_edge_row_after_busy_ones(S):
         assert not layer.image.any()
         res = S.Path.from_svg("M1,1 H9").fill(S.Transform(), np.array([0.5, 0.25, 0.1, 1.0]), viewport=vp)
         assert res is not None and not res[0].image.any()
+
+
+def test_isolated_groups_inside_the_batch_equal_the_per_node_route(S):
+    """CLIP / OPACITY over a GROUP of solid fills: composited on the device inside ONE batch (group tile, clipped / faded as a
+    whole: svgr_batch_set_groups) and, with the switch off, node by node through Layer.compose / Layer.opacity like the
+    reference does (S:674-715).  Same offsets, shapes and pixels."""
+    from svgrasterize_amd import scene as sc
+
+    rng = np.random.default_rng(21)
+
+    def blob(cx, cy, r):
+        return S.Path.from_svg(f"M{cx - r},{cy} C{cx - r},{cy - 1.2 * r} {cx + 0.5 * r},{cy - r} {cx + r},{cy - 0.3 * r} "
+                               f"S{cx + 0.2 * r},{cy + 1.3 * r} {cx - r},{cy} Z")
+
+    def paint():
+        a = rng.uniform(0.3, 1.0)
+        return np.array([*(rng.uniform(0, 1, 3) * a), a])
+
+    def members(cx, cy, n):
+        return S.Scene.group([S.Scene.fill(blob(cx + 25 * rng.uniform(-1, 1), cy + 25 * rng.uniform(-1, 1), rng.uniform(20, 60)), paint(),
+                                           "evenodd" if k % 3 == 2 else None).opacity(0.6 if k % 2 else 1.0) for k in range(n)])
+
+    children = [S.Scene.fill(blob(150, 150, 140), paint())]                                          # plain background shape
+    children.append(members(120, 110, 4).clip(S.Scene.fill(blob(125, 115, 45), np.zeros(4))))        # clip over a group
+    children.append(members(230, 200, 3).opacity(0.45))                                             # opacity over a group
+    children.append(members(60, 240, 3).clip(S.Scene.fill(blob(400, 400, 20), np.zeros(4))))         # clip nowhere near the group
+    children.append(members(300, 60, 2).clip(S.Scene.fill(blob(300, 60, 300), np.zeros(4))))         # clip covering everything
+    children.append(S.Scene.fill(blob(200, 120, 70), paint()))                                       # painted over the groups
+    children.append(members(-40, 150, 3).clip(S.Scene.fill(blob(10, 150, 60), np.zeros(4))))         # hanging out of the viewport
+    doc = S.Scene.group(children)
+    swap = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    for viewport in ([0, 0, 330, 340], [40, 70, 130, 200]):
+        results = []
+        for batched in (True, False):
+            old = sc._BATCH_GROUPS
+            sc._BATCH_GROUPS = batched
+            try:
+                leaves = sc._batchable_leaves(doc, swap, False)
+                assert (leaves is not None) == batched   # (one batch for the whole document, or the node-by-node walk)
+                layer, _hull = doc.render(swap, viewport=viewport, linear_rgb=False)
+            finally:
+                sc._BATCH_GROUPS = old
+            results.append(layer)
+        got, want = results
+        assert tuple(int(v) for v in got.offset) == tuple(int(v) for v in want.offset) and got.image.shape == want.image.shape
+        assert_close64(got.image, want.image, atol=1e-12, what=f"groups in the batch vs per node, viewport {viewport}")
+        assert np.abs(want.image).max() > 0.2
+    # a group under a group's clip is not flat: it takes the per-node route, and still renders the same
+    nested = S.Scene.group([members(100, 100, 2), members(130, 120, 2).opacity(0.5)]).clip(S.Scene.fill(blob(110, 110, 50), np.zeros(4)))
+    assert sc._batchable_leaves(nested, swap, False) is None
+    assert nested.render(swap, viewport=[0, 0, 256, 256], linear_rgb=False) is not None
+
+
+def test_batch_group_description_is_validated(S):
+    from svgrasterize_amd import _abi
+
+    ctx = S.Context.get()
+    sq = lambda x0: np.array([[x0, 0, x0 + 8, 0, 0, 0, 0, 0], [x0 + 8, 0, x0 + 8, 8, 0, 0, 0, 0], [x0 + 8, 8, x0, 8, 0, 0, 0, 0],
+                              [x0, 8, x0, 0, 0, 0, 0, 0]], dtype=np.float64)
+    segs = np.concatenate([sq(0), sq(4), sq(8), sq(12)])
+    make = lambda rules: _abi.Batch(ctx, segs, np.zeros(16, np.uint8), [0, 4, 8, 12, 16], np.tile([1.0, 0, 0, 0, 1, 0], (4, 1)), rules,
+                                    np.tile([0.1, 0.2, 0.3, 0.5], (4, 1)), viewport=[0, 0, 16, 32])
+    b = make([2, 0, 0, 0])   # path 0 is a clip source
+    b.set_groups([-1, 0, 0, -1], [0], [1.0])          # fine: members 1-2 clipped by path 0
+    b.plan()
+    out = ctx.alloc(16 * 32 * 32)
+    b.render(out, _abi.OUT_CANVAS_F64)
+    img = out.download((16, 32, 4), np.float64)
+    # (identity transform: x is the row) members show inside the clip's rows 0-8 only; path 3 (rows 12-16) is not clipped
+    assert img[6, 2, 3] > 0 and img[10, 2, 3] == 0.0 and img[14, 2, 3] > 0
+    for bad in (([-1, 0, -1, 0], [0], [1.0]),          # members not consecutive
+                ([-1, 0, 0, -1], [2], [1.0]),          # clip source is not the path in front of the group
+                ([-1, 1, 1, -1], [0], [1.0]),          # group id out of range
+                ([0, 0, -1, -1], [-1], [1.0]),         # a clip source cannot be a member
+                ([-1, 0, 0, -1], [0], [float("nan")])):
+        with pytest.raises(ValueError):
+            b.set_groups(*bad)
+    with pytest.raises(ValueError):                    # groups exist in the canvas outputs only
+        b.set_groups([-1, 0, 0, -1], [0], [1.0])
+        b.plan()
+        b.render(ctx.alloc(1 << 16), _abi.OUT_MASKS_F64)
