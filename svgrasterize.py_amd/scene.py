@@ -3,17 +3,18 @@
 Same node types, constructors and ``render`` signature as the reference.  ``render`` has two
 routes, both of them HIP:
 
-* batched: a maximal run of solid-colour FILL leaves (under GROUP / TRANSFORM nodes, optionally
-  one OPACITY directly above a leaf, or a CLIP whose clip and target are single paths) is handed to the device as ONE paint-ordered batch
-  (``svgr_batch_render``) that flattens, bins and composites all of them in a single tile kernel.
-  This is what SURVEY 7-5 asks for: per-path launches cannot win.
-* per node: everything else (CLIP, OPACITY over a group, nested results) is rendered node by node
-  into device-resident Layers and merged with ``Layer.compose`` exactly as the reference does.
+* batched: a maximal run of solid-colour leaves is handed to the device as ONE paint-ordered batch
+  (``svgr_batch_render``) that flattens, bins and composites all of them in a single tile kernel
+  (per-path launches cannot win).  A run may contain, besides plain FILL / STROKE leaves under
+  GROUP / TRANSFORM nodes: an OPACITY directly over a leaf (folded into the paint), a CLIP whose clip and
+  target are single paths (clip source + clipped entry), and a CLIP or an OPACITY over a GROUP of plain
+  leaves (an isolated group: its members composite into a group tile on the device, which is clipped /
+  faded as a whole, ``svgr_batch_set_groups``).
+* per node: everything else (gradient and pattern fills, filters, masks, isolated groups that are not flat)
+  is rendered node by node into device-resident Layers and merged with ``Layer.compose`` exactly as the
+  reference does.
 
-Gradient fills and feGaussianBlur (config 5) go through the per-node route (`paint.py`, `filters.py`).
 STROKE nodes are stroked by the native stroker (`Path.stroke`, csrc/svgr_stroke.cpp) and then treated as fills.
-Luminance MASK nodes and the reference's other filter primitives are executed too (layer.py / filters.py).
-Not built: pattern paints.
 """
 from __future__ import annotations
 
