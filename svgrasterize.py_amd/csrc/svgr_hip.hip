@@ -1,25 +1,27 @@
 // svgr_hip.hip -- MI355X (gfx950 / CDNA4) anti-aliased path rasterizer: HIP kernels + C ABI.
 //
-// Pipeline of one svgr_batch_render (6 launches on the context stream, no host read-back):
+// Pipeline of one svgr_batch_render (7 launches on the context stream, no host read-back):
 //
-//   [memset]        zero-fill of the batch's counter arena: only for the first render after a plan, later ones find
-//                   it zeroed by the previous render's tile kernel
+//   [memsets]       zero-fill of the batch's counter arena and of the tiles' entry bitmasks: only for the first render
+//                   after a plan, later ones find both cleared by the previous render's tile kernel
 //   [k_path_rows]   multi-GPU only: rows each path's control-point hull can reach (foreign paths are skipped)
 //   k_flatten       32 lanes per segment: transform (fma form), stack-free adaptive subdivision,
 //                   count -> wave prefix -> ONE reservation per wave in one of 16 edge-cursor shards ->
 //                   store the pieces; endpoints folded into per-path min/max keys
 //   k_path_bbox     per path: integer bbox (floor-1 / ceil+1, clipped to the viewport), band range,
-//                   wave-aggregated reservation of its (path, band) pair slots
+//                   wave-aggregated reservation of its (path, band) pair slots and (path, band, column tile) cells
 //   k_edge_count    per edge: which 16-row bands it crosses -> per-pair record counts (run-aggregated atomics)
-//   k_band_entries  per band: ordered tile list of the pairs with records, reservation of their record
-//                   blocks (contiguous per band), pair headers (paint, fill rule)
+//   k_band_entries  per band: ordered entry list of the pairs with records, reservation of their record
+//                   blocks (contiguous per band)
 //   k_edge_emit     per edge: walk its rows with the reference's x recurrence; one 48-byte record per
 //                   row with the closed-form signed-area pieces, stored through an LDS transpose
+//   k_pair_cells    per pair: the carry-in of every tile row (sum of the pieces left of the tile), the class of every
+//                   cell (nothing visible / constant per row / has records), the tiles' entry bitmasks
 //   k_tile_render   one 128-thread workgroup per 16x64 canvas tile, canvas tile resident in registers as
-//                   double RGBA; per covering path in paint order: record block by LDS-DMA, scatter the
-//                   pieces into an LDS delta tile (ds_add_f64), row prefix sum (8 px per lane serial +
-//                   DPP row scan across the 8 lanes of a row), fill rule, paint, source-over; one
-//                   store of the finished tile (float32 or double)
+//                   double RGBA; per visible cell in paint order: header + record block by LDS-DMA, scatter the
+//                   tile's own pieces into an LDS delta tile (ds_add_f64), row prefix sum from the carry-in (8 px
+//                   per lane serial + DPP row scan across the 8 lanes of a row), fill rule, paint, source-over
+//                   (isolated groups in a second register tile); one store of the finished tile (float32 or double)
 //
 // There is no dense contraction anywhere in this path: no MFMA.  The heavy traffic (delta tile,
 // canvas tile) never leaves the CU; HBM sees the edge records and one canvas store.
@@ -92,8 +94,8 @@ constexpr int NW = NT / 64;                // waves per workgroup
 static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 1024 threads");
 
 // One row of one edge (the signed-area pieces of line_signed_coverage for that scanline, S:2250-2303),
-// computed once by k_edge_emit and applied by every tile the row reaches.  48 B = 3 x 16 B, so a
-// 4 KiB LDS-DMA block holds 85 of them.
+// computed once by k_edge_emit and applied by every tile the row reaches.  48 B = 3 x 16 B: a
+// 4 KiB LDS-DMA block holds the cell header and 81 of them.
 struct RowRec {
     int x0i;        // unclamped layer column of the first piece
     unsigned nrow;  // bits 0-25: n = x1i - x0i (see svgr_core.h RowPieces), bits 26-31: row inside the band
@@ -927,6 +929,23 @@ __global__ __launch_bounds__(256, SVGR_EMIT_WAVES) void k_edge_emit(const double
     if (ok && head == lane && run_end_incl > run_begin_excl) run_base = atomicAdd(&pb_cursor[key], run_end_incl - run_begin_excl);
     run_base = __shfl(run_base, head);
 
+    // The record slots of the first EMIT_PRE bands of the edge are reserved here, before the row loop, with their loads and
+    // (returning) atomics in flight together: reserved on entering each band they stalled the whole wave for a round trip
+    // at every turn in which some lane crossed a band border.
+    constexpr int EMIT_PRE = 4;
+    int pre_slot[EMIT_PRE];
+#pragma unroll
+    for (int i = 0; i < EMIT_PRE; ++i) {
+        pre_slot[i] = 0;
+        const int band_i = bf + i;
+        if (ok && band_i <= bl && owns_band(own, band_i)) {
+            int ya, y1;
+            band_rows(es, band_i, vr0, r0, ya, y1);
+            const int in_block = i == 0 ? run_base + (excl - run_begin_excl) : atomicAdd(&pb_cursor[key + i], y1 - ya);
+            pre_slot[i] = bseg_off[key + i] + in_block;
+        }
+    }
+
     RowState st;
     st.x_next = es.x;
     st.x = es.x;
@@ -948,8 +967,13 @@ __global__ __launch_bounds__(256, SVGR_EMIT_WAVES) void k_edge_emit(const double
                     band_end = y;
                     continue;
                 }
-                const int pb = key + (band - bf);
-                slot = bseg_off[pb] + (band == bf ? run_base + (excl - run_begin_excl) : atomicAdd(&pb_cursor[pb], y1 - ya));
+                const int bi = band - bf;
+                if (bi < EMIT_PRE) {
+                    slot = bi == 0 ? pre_slot[0] : (bi == 1 ? pre_slot[1] : (bi == 2 ? pre_slot[2] : pre_slot[3]));
+                } else {  // (an edge taller than EMIT_PRE bands: the rest as they come)
+                    const int pb = key + bi;
+                    slot = bseg_off[pb] + atomicAdd(&pb_cursor[pb], y1 - ya);
+                }
                 band_end = y1;
                 band_row0 = band * TR + vr0 - r0;
             }
@@ -2708,7 +2732,7 @@ int svgr_batch_set_paints(svgr_batch* b, const double* path_paint) {
     HIPCHK(hipSetDevice(b->ctx->device));
     HIPCHK(hipMemcpyAsync(b->path_paint.p, path_paint, sizeof(double) * 4 * b->n_paths, hipMemcpyHostToDevice, b->ctx->stream));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
-    b->geometry_fresh = false;  // the pair headers carry the paint
+    b->geometry_fresh = false;  // the cell headers carry the paint
     return 0;
 }
 
