@@ -251,6 +251,12 @@ typedef struct {
     const double* stop_rgba;                        /* n_stops x 4 premultiplied colours                      */
 } svgr_gradient;
 int svgr_gradient_fill(svgr_ctx* ctx, const svgr_gradient* g, const svgr_buf* mask, const int64_t* bbox, svgr_buf* out_rgba);
+/* Gradient paints inside a batch (canvas outputs): path_grad[p] = index into grads or -1 (solid).  One description per
+ * gradient-filled path (user_m6 is the fill's own pixel -> user transform), userSpaceOnUse, at most 32 stops; the tile kernel
+ * evaluates it per visible pixel with the code of svgr_gradient_fill and multiplies by the coverage and by path_paint[p]
+ * (all ones, or the opacity of an OPACITY node directly above the leaf).  n_grads = 0 removes them.  Call before
+ * svgr_batch_plan.  The fills of a document then need no Path.mask + svgr_gradient_fill + Layer.compose round trip each. */
+int svgr_batch_set_gradients(svgr_batch* batch, const int32_t* path_grad, int64_t n_grads, const svgr_gradient* grads);
 /* GradLinear.fill / GradRadial.fill (S:1553-1563, S:1577-1651): the gradient at n_points caller-supplied coordinates
  * (x, y doubles interleaved; user space, i.e. what Path.fill passes after its own user transform: set user_m6 to the
  * identity), no mask; out_rgba receives n_points x 4 doubles.                                                     */

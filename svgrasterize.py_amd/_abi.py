@@ -90,6 +90,7 @@ _PROTOS = {
     "svgr_batch_set_transforms": (C.c_int, [_P, _P]),
     "svgr_batch_set_bands": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "svgr_batch_set_groups": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
+    "svgr_batch_set_gradients": (C.c_int, [_P, _P, C.c_int64, _P]),
     "svgr_batch_plan": (C.c_int, [_P]),
     "svgr_batch_get_stats": (C.c_int, [_P, C.POINTER(BatchStats)]),
     "svgr_batch_get_bboxes": (C.c_int, [_P, _P]),
@@ -326,6 +327,14 @@ class Batch:
         if len(cs) != len(op):
             raise ValueError("one clip source and one opacity per group")
         _check(self.ctx.lib.svgr_batch_set_groups(self.handle, pg.ctypes.data_as(_P), len(cs), cs.ctypes.data_as(_P), op.ctypes.data_as(_P)))
+        self._stats = None
+
+    def set_gradients(self, path_grad, grads):
+        """Gradient paints inside the batch: path_grad[p] = index into `grads` (a list of `Gradient` structs, one per
+        gradient-filled path) or -1; see svgr_batch_set_gradients.  Call before plan()."""
+        pg = np.ascontiguousarray(path_grad, dtype=np.int32).reshape(self.n_paths)
+        arr = (Gradient * max(len(grads), 1))(*grads)
+        _check(self.ctx.lib.svgr_batch_set_gradients(self.handle, pg.ctypes.data_as(_P), len(grads), C.cast(arr, _P)))
         self._stats = None
 
     def set_paints(self, paints):

@@ -1065,7 +1065,7 @@ static_assert(64 % TR == 0, "k_pair_cells walks 64 / TR column tiles per step");
 __global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __restrict__ entries, const int2* __restrict__ entry_where,
                                                         const RowRec* __restrict__ recs, const double* __restrict__ path_paint,
                                                         const uint8_t* __restrict__ path_rule, const int* __restrict__ path_group,
-                                                        int vc0, int n_ct, int mask_words,
+                                                        const int* __restrict__ path_grad, int vc0, int n_ct, int mask_words,
                                                         unsigned long long* __restrict__ tile_mask, CellHdr* __restrict__ cell_hdr,
                                                         int cell_cap, BatchDev* __restrict__ bd) {
     constexpr int NWV = PC_BLOCK / 64;
@@ -1089,6 +1089,7 @@ __global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __r
     const int x_first = vc0 + ct0 * TC - en.c0;  // layer column where the path's first column tile starts (<= 0)
     const int rl = path_rule[en.p], rule = rl & 1;
     const int group = path_group ? path_group[en.p] : -1;
+    const int grad1 = path_grad ? path_grad[en.p] + 1 : 0;  // gradient index + 1 (0: solid colour)
     const double4 paint = ((const double4*)path_paint)[en.p];
     const int row_l = lane & (TR - 1), sub = lane / TR;  // this lane's row and its column tile of the four walked per step
     double run = 0.0;  // the row's running sum left of the column tiles walked so far
@@ -1166,7 +1167,7 @@ __global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __r
                         atomicOr(mw, mbit);
                         if (cls == 2) atomicOr(mw + mask_words, mbit);
                         hd->paint[0] = paint.x; hd->paint[1] = paint.y; hd->paint[2] = paint.z; hd->paint[3] = paint.w;
-                        hd->rule = rule; hd->flags = rl >> 1; hd->group = group; hd->cls = cls;
+                        hd->rule = rule; hd->flags = (rl >> 1) | (grad1 << 2); hd->group = group; hd->cls = cls;
                     }
                 } else if (row_l == 0) {
                     atomicOr(&bd->err, 32);
@@ -1175,6 +1176,116 @@ __global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __r
             run = run + all;
         }
     }
+}
+
+// --------------------------------------------------------------------------------------
+// gradients (S:1021-1047, 1544-1695): image = gradient(pixel centre) * mask
+// --------------------------------------------------------------------------------------
+constexpr int GRAD_MAX_STOPS = 32;   // stops carried inside the kernel argument; longer lists travel in a device buffer
+struct GradDev {
+    int kind, spread, has_gt, n_stops;
+    int excl_enabled, pad0, pad1, pad2;
+    double user_m6[6], gt_m6[6];
+    double p0[2], vec[2], vv;
+    double center[2], radius;
+    double fcenter[2], fradius, cd[2], rd, a, frad_rd, frad2, excl_thresh;
+    double stop_off[GRAD_MAX_STOPS];
+    double stop_rgba[GRAD_MAX_STOPS][4];
+    const double* ext_stops;  // n_stops > GRAD_MAX_STOPS: {offsets[n], rgba[n][4]} in device memory (the reference has no cap, S:1671-1683)
+};
+
+// position of pixel (i, j) of the layer in gradient space: grad_pixels (S:1653-1658), user transform
+// (S:1023-1027) and the gradient's own transform (S:1559 / S:1603), both in numpy's fma form
+__device__ __forceinline__ void grad_point(const GradDev& g, const double* __restrict__ pts, size_t idx, int r0, int c0, int cols,
+                                           double& x, double& y) {
+    double px, py;
+    if (pts) {  // Grad*.fill on a caller's coordinate array (S:1553, S:1577): the points as given
+        px = pts[2 * idx];
+        py = pts[2 * idx + 1];
+    } else {
+        px = (double)(int)(idx / cols) + ((double)r0 + 0.5);
+        py = (double)(int)(idx % cols) + ((double)c0 + 0.5);
+    }
+    xform_point(g.user_m6, px, py, x, y);
+    if (g.has_gt) {
+        double tx, ty;
+        xform_point(g.gt_m6, x, y, tx, ty);
+        x = tx;
+        y = ty;
+    }
+}
+
+// focal radial: b, c, det of S:1619-1626
+__device__ __forceinline__ double grad_focal_det(const GradDev& g, double x, double y, double& b) {
+    double pd0 = x - g.fcenter[0], pd1 = y - g.fcenter[1];
+    b = (pd0 * g.cd[0] + pd1 * g.cd[1]) + g.frad_rd;
+    double c = (pd0 * pd0 + pd1 * pd1) - g.frad2;
+    return b * b - g.a * c;
+}
+
+// Colour of the gradient at the user-space point (x, y): offset (S:1561-1562 / S:1606-1607 / S:1619-1644), spread
+// (S:1661-1668), piecewise-linear stops (grad_interpolate, S:1671-1683).  `use_mask`: the focal form found a negative
+// determinant somewhere in the fill's layer and therefore masks (S:1627-1648).  Shared by the per-node kernel
+// (k_gradient_fill) and by the tile kernel's gradient entries, so that both routes give the same bits.
+__device__ __forceinline__ void grad_colour_user(const GradDev& g, double x, double y, bool use_mask, double* col) {
+    double offset;
+    bool masked = false;  // overlay[~mask] = 0 (S:1648)
+    if (g.kind == 1) {  // linear, S:1561-1562: ((p - p0) @ vec) / (vec . vec), `@` with a 1-D rhs = fma(d0, v0, d1*v1)
+        double d0 = x - g.p0[0], d1 = y - g.p0[1];
+        offset = fma(d0, g.vec[0], d1 * g.vec[1]) / g.vv;
+    } else if (g.kind == 2) {  // radial, S:1606-1607
+        double o0 = (x - g.center[0]) / g.radius, o1 = (y - g.center[1]) / g.radius;
+        offset = sqrt(o0 * o0 + o1 * o1);
+    } else {  // two-circle (focal) radial, S:1619-1644
+        double b;
+        double det = grad_focal_det(g, x, y, b);
+        if (use_mask && !(det >= 0.0)) {
+            masked = true;
+            offset = 0.0;
+        } else {
+            double t0 = sqrt(det);
+            double t1 = (b + t0) / g.a, t2 = (b - t0) / g.a;
+            offset = t1 > t2 ? t1 : (t2 > t1 ? t2 : (t1 != t1 ? t1 : t2));  // np.maximum (NaN propagates)
+            if (use_mask && g.excl_enabled && !(offset > g.excl_thresh)) masked = true;  // negative r(t), S:1642-1644
+        }
+    }
+    if (g.spread == 1) {  // repeat: np.modf(offset)[0]
+        offset = offset - trunc(offset);
+    } else if (g.spread == 2) {  // reflect
+        double a1 = offset + 1.0;
+        offset = fabs((a1 - 2.0 * floor(a1 * 0.5)) - 1.0);
+    }
+    col[0] = col[1] = col[2] = col[3] = 0.0;
+    const int n = g.n_stops;
+    const double* const soff = g.ext_stops ? g.ext_stops : g.stop_off;               // (wave-uniform: scalar loads either way)
+    const double* const srgba = g.ext_stops ? g.ext_stops + n : &g.stop_rgba[0][0];
+    if (offset <= soff[0]) {
+        for (int k = 0; k < 4; ++k) col[k] = srgba[k];
+    }
+    if (offset > soff[n - 1]) {
+        for (int k = 0; k < 4; ++k) col[k] = srgba[4 * (n - 1) + k];
+    }
+    for (int s = 0; s + 1 < n; ++s) {
+        double o0 = soff[s], o1 = soff[s + 1];
+        if (offset > o0 && offset <= o1) {
+            double ratio = (offset - o0) / (o1 - o0);
+            for (int k = 0; k < 4; ++k) col[k] = col[k] + ((1 - ratio) * srgba[4 * s + k] + ratio * srgba[4 * (s + 1) + k]);
+        }
+    }
+    if (masked) col[0] = col[1] = col[2] = col[3] = 0.0;
+}
+// ... at the centre of the presentation-space pixel (row, col): grad_pixels (S:1653-1658) + the user transform (S:1023-1027)
+// + the gradient's own transform, both in numpy's fma form
+__device__ __forceinline__ void grad_colour_pixel(const GradDev& g, int row, int col_, bool use_mask, double* col) {
+    double x, y;
+    xform_point(g.user_m6, (double)row + 0.5, (double)col_ + 0.5, x, y);
+    if (g.has_gt) {
+        double tx, ty;
+        xform_point(g.gt_m6, x, y, tx, ty);
+        x = tx;
+        y = ty;
+    }
+    grad_colour_user(g, x, y, use_mask, col);
 }
 
 // ======================================================================================
@@ -1219,6 +1330,8 @@ struct TileArgs {
     int cell_cap;                   // cells the array holds (a batch that outgrew its plan is flagged, not read out of bounds)
     const int* group_clip_src;      // per isolated group: path id of the clip source that clips it as a whole, or -1
     const double* group_opacity;    // ... and the opacity it is faded with when it closes (1: none)
+    const GradDev* grads;           // gradient paints of the batch (CellHdr::flags carries the entry's index + 1 above bit 1)
+    const int* grad_flags;          // per gradient: some pixel of the fill's layer has det < 0 (k_grad_detneg, focal form)
     void* out;
     int vr0, vc0, vrows, vcols;  // viewport
     Owner own;                   // owned bands
@@ -1235,9 +1348,12 @@ struct TileArgs {
 // so that batches without clips keep their occupancy)
 // GROUPS (implies CLIP): the batch contains isolated groups (SVGR_PATH_GROUP_MEMBER): a second register tile accumulates
 // the group, which is clipped / faded as a whole when it closes (Scene.render CLIP / OPACITY over a GROUP, S:674-715)
-template <int OUT, bool CLIP = false, bool GROUPS = false>
+// GRAD (implies GROUPS): the batch contains gradient-painted paths (svgr_batch_set_gradients): their colour is evaluated per
+// visible pixel in the composite (Path.fill's gradient branch, S:1021-1047) instead of being a constant of the path
+template <int OUT, bool CLIP = false, bool GROUPS = false, bool GRAD = false>
 __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_EU)) void k_tile_render(const TileArgs a) {
     static_assert(!GROUPS || (CLIP && OUT <= 1), "groups live in the canvas variants with the clip tile");
+    static_assert(!GRAD || GROUPS, "gradient entries live in the variant with the large register budget");
     // ONE __shared__ object, carved by hand: with a second object beside the LDS-DMA staging area
     // hipcc (ROCm 7.2) drains vmcnt(0) before every ds_read and the record prefetch stops overlapping
     constexpr int OFF_TRACE = 0;
@@ -1469,7 +1585,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
                 hi_c = cols < tile_c1 - c0 ? cols : tile_c1 - c0;  // one past the last
                 p0 = blk[0]; p1 = blk[1]; p2 = blk[2]; p3 = blk[3];  // cell header: paint, rule, flags
                 rule = *(const int*)(blk + 4);
-                pflags = *((const int*)(blk + 4) + 1);
+                pflags = *((const int*)(blk + 4) + 1);  // bits 0-1: clip source / clipped; above: gradient index + 1
                 pid = s_list[li];
                 if (OUT >= 2) {
                     lcols = cols;
@@ -1478,6 +1594,8 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
             }
             ++li;
             const int item_g = GROUPS ? *((const int*)(blk + 4) + 2) : -1;  // CellHdr::group
+            const int grad_id = GRAD ? __builtin_amdgcn_readfirstlane(pflags >> 2) - 1 : -1;
+            const bool grad_mask = GRAD && grad_id >= 0 && a.grads[grad_id].kind == 3 && a.grad_flags[grad_id] != 0;
             if (GROUPS && open_g >= 0 && item_g != open_g) close_group();
             if (GROUPS && item_g >= 0 && open_g < 0) {
                 open_g = item_g;
@@ -1701,7 +1819,16 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
                         if (is_clip_src) {
                             myclip[i] = vis[i] ? mval : 0.0;
                         } else if (vis[i]) {
-                            double s0 = mval * p0, s1 = mval * p1, s2 = mval * p2, s3 = mval * p3;
+                            double s0, s1, s2, s3;
+                            if (GRAD && grad_id >= 0) {
+                                // gradient paint: colour at the pixel centre, times the coverage (canvas_compose(IN, mask, image),
+                                // S:1044-1047), times the entry's opacity multiplier (Layer.opacity over the leaf, S:174)
+                                double gc[4];
+                                grad_colour_pixel(a.grads[grad_id], tile_r0 + trow, tile_c0 + chunk * PX + i, grad_mask, gc);
+                                s0 = (gc[0] * mval) * p0; s1 = (gc[1] * mval) * p1; s2 = (gc[2] * mval) * p2; s3 = (gc[3] * mval) * p3;
+                            } else {
+                                s0 = mval * p0; s1 = mval * p1; s2 = mval * p2; s3 = mval * p3;
+                            }
                             if (is_clipped) {
                                 const double c = clip_missing ? 0.0 : myclip[i];
                                 if (c == 0.0) continue;
@@ -2003,51 +2130,6 @@ __global__ void k_to_rgba8(uchar4* __restrict__ dst, const double4* __restrict__
     dst[i] = make_uchar4(q(v.x), q(v.y), q(v.z), q(v.w));
 }
 
-// --------------------------------------------------------------------------------------
-// gradients (S:1021-1047, 1544-1695): image = gradient(pixel centre) * mask
-// --------------------------------------------------------------------------------------
-constexpr int GRAD_MAX_STOPS = 32;   // stops carried inside the kernel argument; longer lists travel in a device buffer
-struct GradDev {
-    int kind, spread, has_gt, n_stops;
-    int excl_enabled, pad0, pad1, pad2;
-    double user_m6[6], gt_m6[6];
-    double p0[2], vec[2], vv;
-    double center[2], radius;
-    double fcenter[2], fradius, cd[2], rd, a, frad_rd, frad2, excl_thresh;
-    double stop_off[GRAD_MAX_STOPS];
-    double stop_rgba[GRAD_MAX_STOPS][4];
-    const double* ext_stops;  // n_stops > GRAD_MAX_STOPS: {offsets[n], rgba[n][4]} in device memory (the reference has no cap, S:1671-1683)
-};
-
-// position of pixel (i, j) of the layer in gradient space: grad_pixels (S:1653-1658), user transform
-// (S:1023-1027) and the gradient's own transform (S:1559 / S:1603), both in numpy's fma form
-__device__ __forceinline__ void grad_point(const GradDev& g, const double* __restrict__ pts, size_t idx, int r0, int c0, int cols,
-                                           double& x, double& y) {
-    double px, py;
-    if (pts) {  // Grad*.fill on a caller's coordinate array (S:1553, S:1577): the points as given
-        px = pts[2 * idx];
-        py = pts[2 * idx + 1];
-    } else {
-        px = (double)(int)(idx / cols) + ((double)r0 + 0.5);
-        py = (double)(int)(idx % cols) + ((double)c0 + 0.5);
-    }
-    xform_point(g.user_m6, px, py, x, y);
-    if (g.has_gt) {
-        double tx, ty;
-        xform_point(g.gt_m6, x, y, tx, ty);
-        x = tx;
-        y = ty;
-    }
-}
-
-// focal radial: b, c, det of S:1619-1626
-__device__ __forceinline__ double grad_focal_det(const GradDev& g, double x, double y, double& b) {
-    double pd0 = x - g.fcenter[0], pd1 = y - g.fcenter[1];
-    b = (pd0 * g.cd[0] + pd1 * g.cd[1]) + g.frad_rd;
-    double c = (pd0 * pd0 + pd1 * pd1) - g.frad2;
-    return b * b - g.a * c;
-}
-
 // does any pixel of the layer have det < 0 ?  (the reference only builds its exclusion mask then, S:1627)
 __global__ void k_gradient_detneg(const GradDev g, const double* __restrict__ pts, int r0, int c0, int rows, int cols,
                                   int* __restrict__ flag) {
@@ -2058,6 +2140,24 @@ __global__ void k_gradient_detneg(const GradDev g, const double* __restrict__ pt
     if (grad_focal_det(g, x, y, b) < 0.0) atomicOr(flag, 1);
 }
 
+// Batched form for the gradient entries of a batch: block row y = gradient y; only the focal form (kind 3) has a
+// determinant.  The fill's layer = the clipped bbox of its path (device array), like the mask layer of the per-node route.
+__global__ __launch_bounds__(256) void k_grad_detneg(const GradDev* __restrict__ grads, const int* __restrict__ grad_path,
+                                                    const int* __restrict__ bbox, int* __restrict__ flags) {
+    const int gi = blockIdx.y;
+    const GradDev& g = grads[gi];
+    if (g.kind != 3) return;
+    const int4 bb = ((const int4*)bbox)[grad_path[gi]];
+    const long long n = (long long)bb.z * bb.w;
+    bool neg = false;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n && !neg; idx += (long long)gridDim.x * 256) {
+        double x, y, b;
+        grad_point(g, nullptr, (size_t)idx, bb.x, bb.y, bb.w, x, y);
+        neg = grad_focal_det(g, x, y, b) < 0.0;
+    }
+    if (__ballot(neg) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&flags[gi], 1);
+}
+
 // The parameter block travels as a kernel argument (1.6 KB of kernarg, read with scalar loads): no device copy of it, and
 // for linear / plain radial gradients nothing the host would have to wait for.
 __global__ void k_gradient_fill(const GradDev g, const double* __restrict__ pts, const double* __restrict__ mask, int r0, int c0,
@@ -2066,53 +2166,8 @@ __global__ void k_gradient_fill(const GradDev g, const double* __restrict__ pts,
     if (idx >= (size_t)rows * cols) return;
     double x, y;
     grad_point(g, pts, idx, r0, c0, cols, x, y);
-    double offset;
-    bool masked = false;  // overlay[~mask] = 0 (S:1648)
-    if (g.kind == 1) {  // linear, S:1561-1562: ((p - p0) @ vec) / (vec . vec), `@` with a 1-D rhs = fma(d0, v0, d1*v1)
-        double d0 = x - g.p0[0], d1 = y - g.p0[1];
-        offset = fma(d0, g.vec[0], d1 * g.vec[1]) / g.vv;
-    } else if (g.kind == 2) {  // radial, S:1606-1607
-        double o0 = (x - g.center[0]) / g.radius, o1 = (y - g.center[1]) / g.radius;
-        offset = sqrt(o0 * o0 + o1 * o1);
-    } else {  // two-circle (focal) radial, S:1619-1644
-        double b;
-        double det = grad_focal_det(g, x, y, b);
-        const bool use_mask = *detneg_flag != 0;
-        if (use_mask && !(det >= 0.0)) {
-            masked = true;
-            offset = 0.0;
-        } else {
-            double t0 = sqrt(det);
-            double t1 = (b + t0) / g.a, t2 = (b - t0) / g.a;
-            offset = t1 > t2 ? t1 : (t2 > t1 ? t2 : (t1 != t1 ? t1 : t2));  // np.maximum (NaN propagates)
-            if (use_mask && g.excl_enabled && !(offset > g.excl_thresh)) masked = true;  // negative r(t), S:1642-1644
-        }
-    }
-    if (g.spread == 1) {  // repeat: np.modf(offset)[0]
-        offset = offset - trunc(offset);
-    } else if (g.spread == 2) {  // reflect
-        double a1 = offset + 1.0;
-        offset = fabs((a1 - 2.0 * floor(a1 * 0.5)) - 1.0);
-    }
-    // grad_interpolate, S:1671-1683
-    double col[4] = {0.0, 0.0, 0.0, 0.0};
-    const int n = g.n_stops;
-    const double* const soff = g.ext_stops ? g.ext_stops : g.stop_off;               // (wave-uniform: scalar loads either way)
-    const double* const srgba = g.ext_stops ? g.ext_stops + n : &g.stop_rgba[0][0];
-    if (offset <= soff[0]) {
-        for (int k = 0; k < 4; ++k) col[k] = srgba[k];
-    }
-    if (offset > soff[n - 1]) {
-        for (int k = 0; k < 4; ++k) col[k] = srgba[4 * (n - 1) + k];
-    }
-    for (int s = 0; s + 1 < n; ++s) {
-        double o0 = soff[s], o1 = soff[s + 1];
-        if (offset > o0 && offset <= o1) {
-            double ratio = (offset - o0) / (o1 - o0);
-            for (int k = 0; k < 4; ++k) col[k] = col[k] + ((1 - ratio) * srgba[4 * s + k] + ratio * srgba[4 * (s + 1) + k]);
-        }
-    }
-    if (masked) col[0] = col[1] = col[2] = col[3] = 0.0;
+    double col[4];
+    grad_colour_user(g, x, y, g.kind == 3 && *detneg_flag != 0, col);
     const double m = mask ? mask[idx] : 1.0;  // canvas_compose(COMPOSE_IN, mask, image) = image * mask (S:1046, S:290)
     double* o = out + 4 * idx;
     o[0] = col[0] * m; o[1] = col[1] * m; o[2] = col[2] * m; o[3] = col[3] * m;
@@ -2300,6 +2355,10 @@ struct svgr_batch {
     DevArr<int> path_group, group_clip_src;
     DevArr<double> group_opacity;
     std::vector<uint8_t> host_rule;  // the paths' rule / flag bytes (checked against the groups)
+    int64_t n_grads = 0;       // gradient-painted paths (svgr_batch_set_gradients)
+    DevArr<GradDev> grads;
+    DevArr<int> path_grad, grad_path, grad_flags;
+    bool has_focal = false;
     // inputs
     DevArr<double> segs, path_m6, path_paint;
     DevArr<uint8_t> seg_kind, path_rule;
@@ -2366,6 +2425,7 @@ struct svgr_batch {
         seg_path.release(); in_dev.release(); arena.release(); edge_path.release(); bbox.release(); bins.release();
         bseg_off.release(); band_start.release(); band_count.release(); entries.release();
         path_group.release(); group_clip_src.release(); group_opacity.release();
+        grads.release(); path_grad.release(); grad_path.release(); grad_flags.release();
         edges.release(); bsegs.release(); cell_hdr.release(); entry_where.release(); tile_mask.release(); layer_off.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
@@ -2437,7 +2497,8 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
         hipLaunchKernelGGL(k_pair_cells, grid1((size_t)b->n_entries * 64, PC_BLOCK), dim3(PC_BLOCK), 0, st,
                            (const TileEntry*)b->entries.p, (const int2*)b->entry_where.p, (const RowRec*)b->bsegs.p,
                            (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p,
-                           b->n_groups > 0 ? (const int*)b->path_group.p : (const int*)nullptr, b->vp[1], b->n_ctiles(), b->mask_words,
+                           b->n_groups > 0 ? (const int*)b->path_group.p : (const int*)nullptr,
+                           b->n_grads > 0 ? (const int*)b->path_grad.p : (const int*)nullptr, b->vp[1], b->n_ctiles(), b->mask_words,
                            b->tile_mask.p, b->cell_hdr.p, cap_i32(b->cell_hdr.cap), b->bd());
     }
     return 0;
@@ -2482,6 +2543,25 @@ static int abi_guard(const char* what, F&& body) {
     } catch (...) {
         return fail(SVGR_E_INVALID, "%s: unexpected C++ exception", what);
     }
+}
+
+// the scalar part of a gradient description (everything but the stops)
+static void fill_grad_dev(GradDev& h, const svgr_gradient* g) {
+    memset(&h, 0, sizeof h);
+    h.kind = g->kind; h.spread = g->spread; h.has_gt = g->has_gt; h.n_stops = g->n_stops; h.excl_enabled = g->excl_enabled;
+    memcpy(h.user_m6, g->user_m6, sizeof h.user_m6);
+    memcpy(h.gt_m6, g->gt_m6, sizeof h.gt_m6);
+    h.p0[0] = g->p0[0]; h.p0[1] = g->p0[1]; h.vec[0] = g->vec[0]; h.vec[1] = g->vec[1]; h.vv = g->vv;
+    h.center[0] = g->center[0]; h.center[1] = g->center[1]; h.radius = g->radius;
+    h.fcenter[0] = g->fcenter[0]; h.fcenter[1] = g->fcenter[1]; h.fradius = g->fradius;
+    h.cd[0] = g->cd[0]; h.cd[1] = g->cd[1]; h.rd = g->rd; h.a = g->a; h.frad_rd = g->frad_rd; h.frad2 = g->frad2;
+    h.excl_thresh = g->excl_thresh;
+}
+static int check_gradient(const svgr_gradient* g) {
+    if (g->kind < 1 || g->kind > 3 || g->spread < 0 || g->spread > 2) return fail(SVGR_E_INVALID, "invalid gradient kind / spread method");
+    if (g->n_stops < 1 || g->n_stops > (1 << 20) || !g->stop_off || !g->stop_rgba)
+        return fail(SVGR_E_INVALID, "gradient needs at least one stop");
+    return 0;
 }
 
 // ======================================================================================
@@ -2795,6 +2875,57 @@ int svgr_batch_set_groups(svgr_batch* b, const int32_t* path_group, int64_t n_gr
     return 0;
 }
 
+// Gradient paints inside a batch (Path.fill's gradient branch, S:1021-1047, for userSpaceOnUse gradients of up to 32 stops):
+// path_grad[p] = index into `grads` or -1 (solid colour).  A gradient entry's colour is evaluated per visible pixel by the
+// tile kernel -- image = gradient(pixel centre) * coverage -- and multiplied by the entry's path_paint (1 everywhere, or
+// the opacity of an OPACITY node directly above the leaf).  grads[i].user_m6 maps pixel centres to the gradient's user
+// space exactly as for svgr_gradient_fill.
+int svgr_batch_set_gradients(svgr_batch* b, const int32_t* path_grad, int64_t n_grads, const svgr_gradient* grads) {
+    return abi_guard("svgr_batch_set_gradients", [&]() -> int {
+        if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
+        if (n_grads == 0) { b->n_grads = 0; b->geometry_fresh = false; return 0; }
+        if (n_grads < 0 || n_grads > b->n_paths || !path_grad || !grads) return fail(SVGR_E_INVALID, "svgr_batch_set_gradients: bad arguments");
+        std::vector<GradDev> host((size_t)n_grads);
+        std::vector<int> owner((size_t)n_grads, -1);
+        bool focal = false;
+        for (int64_t i = 0; i < n_grads; ++i) {
+            if (int rc = check_gradient(&grads[i])) return rc;
+            if (grads[i].n_stops > GRAD_MAX_STOPS)
+                return fail(SVGR_E_INVALID, "gradient %lld has %d stops: more than %d go through svgr_gradient_fill", (long long)i, grads[i].n_stops, GRAD_MAX_STOPS);
+            fill_grad_dev(host[(size_t)i], &grads[i]);
+            for (int k = 0; k < grads[i].n_stops; ++k) {
+                host[(size_t)i].stop_off[k] = grads[i].stop_off[k];
+                for (int c = 0; c < 4; ++c) host[(size_t)i].stop_rgba[k][c] = grads[i].stop_rgba[4 * k + c];
+            }
+            focal = focal || grads[i].kind == 3;
+        }
+        for (int64_t p = 0; p < b->n_paths; ++p) {
+            const int gi = path_grad[p];
+            if (gi < -1 || gi >= n_grads) return fail(SVGR_E_INVALID, "path %lld: gradient %d out of range", (long long)p, gi);
+            if (gi < 0) continue;
+            if (b->host_rule[(size_t)p] & SVGR_PATH_CLIP_SOURCE) return fail(SVGR_E_INVALID, "path %lld: a clip source has no paint", (long long)p);
+            if (owner[(size_t)gi] >= 0) return fail(SVGR_E_INVALID, "gradient %d is used by two paths (one description per fill: its transform is the fill's)", gi);
+            owner[(size_t)gi] = (int)p;
+        }
+        for (int64_t i = 0; i < n_grads; ++i)
+            if (owner[(size_t)i] < 0) return fail(SVGR_E_INVALID, "gradient %lld is not used by any path", (long long)i);
+        HIPCHK(hipSetDevice(b->ctx->device));
+        if (int rc = b->grads.ensure((size_t)n_grads)) return rc;
+        if (int rc = b->path_grad.ensure((size_t)b->n_paths)) return rc;
+        if (int rc = b->grad_path.ensure((size_t)n_grads)) return rc;
+        if (int rc = b->grad_flags.ensure((size_t)n_grads)) return rc;
+        hipStream_t st = b->ctx->stream;
+        HIPCHK(hipMemcpyAsync(b->grads.p, host.data(), sizeof(GradDev) * (size_t)n_grads, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(b->path_grad.p, path_grad, sizeof(int) * (size_t)b->n_paths, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(b->grad_path.p, owner.data(), sizeof(int) * (size_t)n_grads, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));  // (host vectors of this call)
+        b->n_grads = n_grads;
+        b->has_focal = focal;
+        b->geometry_fresh = false;  // the cell headers carry the gradient indices
+        return 0;
+    });
+}
+
 // Small batches (Path.mask / Path.fill of one path, a handful of glyphs): instead of the staged plan with a read-back
 // per stage, size every buffer from bounds known on the host -- (path, band) pairs <= paths x bands exactly, edges and
 // records by a generous guess -- run the whole geometry ONCE and read the counters back once.  If a guess was too
@@ -3049,7 +3180,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
     if (layers) out_kind = SVGR_OUT_MASK_F64;
     const bool single = out_kind >= 2;
     if (single && !layers && b->n_paths != 1) return fail(SVGR_E_INVALID, "mask/fill outputs need a single-path batch");
-    if (single && b->n_groups > 0) return fail(SVGR_E_INVALID, "isolated groups exist in the canvas outputs only");
+    if (single && (b->n_groups > 0 || b->n_grads > 0)) return fail(SVGR_E_INVALID, "isolated groups and gradient paints exist in the canvas outputs only");
     if (layers && b->own.world > 1) return fail(SVGR_E_INVALID, "per-path mask output is not sharded");
     HIPCHK(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
@@ -3103,6 +3234,13 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         a.cell_cap = cap_i32(b->cell_hdr.cap);
         a.tile_mask = b->tile_mask.p; a.mask_words = b->mask_words; a.n_ct = b->n_ctiles();
         a.group_clip_src = b->group_clip_src.p; a.group_opacity = b->group_opacity.p;
+        a.grads = b->grads.p; a.grad_flags = b->grad_flags.p;
+        if (b->n_grads > 0 && b->has_focal) {
+            // focal radial gradients mask their `det < 0` pixels only if the fill's layer has any (S:1627): one flag per fill
+            HIPCHK(hipMemsetAsync(b->grad_flags.p, 0, sizeof(int) * (size_t)b->n_grads, st));
+            hipLaunchKernelGGL(k_grad_detneg, dim3(64, (unsigned)b->n_grads), dim3(256), 0, st, (const GradDev*)b->grads.p,
+                               (const int*)b->grad_path.p, (const int*)b->bbox.p, b->grad_flags.p);
+        }
         a.vr0 = b->vp[0]; a.vc0 = b->vp[1]; a.vrows = b->vp[2]; a.vcols = b->vp[3];
         a.own = b->own;
         a.out_cols = b->vp[3];
@@ -3129,12 +3267,14 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         static const int dyn_lds = getenv("SVGR_DBG_DYNLDS") ? atoi(getenv("SVGR_DBG_DYNLDS")) : 0;  // occupancy experiments
         switch (out_kind) {
             case 0:
-                if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render<0, true, true>), grid, dim3(NT), 0, st, a);
+                if (b->n_grads > 0) hipLaunchKernelGGL((k_tile_render<0, true, true, true>), grid, dim3(NT), 0, st, a);
+                else if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render<0, true, true>), grid, dim3(NT), 0, st, a);
                 else if (b->has_clips) hipLaunchKernelGGL((k_tile_render<0, true>), grid, dim3(NT), 0, st, a);
                 else hipLaunchKernelGGL((k_tile_render<0, false>), grid, dim3(NT), dyn_lds, st, a);
                 break;
             case 1:
-                if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render<1, true, true>), grid, dim3(NT), 0, st, a);
+                if (b->n_grads > 0) hipLaunchKernelGGL((k_tile_render<1, true, true, true>), grid, dim3(NT), 0, st, a);
+                else if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render<1, true, true>), grid, dim3(NT), 0, st, a);
                 else if (b->has_clips) hipLaunchKernelGGL((k_tile_render<1, true>), grid, dim3(NT), 0, st, a);
                 else hipLaunchKernelGGL((k_tile_render<1, false>), grid, dim3(NT), 0, st, a);
                 break;
@@ -3331,23 +3471,13 @@ int svgr_layer_to_rgba8(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64
 // the gradient over the pixel grid of `bbox` times `mask` (pts == nullptr), or at the n = bbox[2] * bbox[3] points of `pts`
 static int gradient_run(svgr_ctx* ctx, const svgr_gradient* g, const double* pts, const svgr_buf* mask, const int64_t* bbox,
                         svgr_buf* out) {
-    if (g->kind < 1 || g->kind > 3 || g->spread < 0 || g->spread > 2) return fail(SVGR_E_INVALID, "invalid gradient kind / spread method");
-    if (g->n_stops < 1 || g->n_stops > (1 << 20) || !g->stop_off || !g->stop_rgba)
-        return fail(SVGR_E_INVALID, "gradient needs at least one stop");
+    if (int rc = check_gradient(g)) return rc;
     const size_t n = (size_t)bbox[2] * bbox[3];
     if ((mask && mask->bytes < n * 8) || out->bytes < n * 32) return fail(SVGR_E_INVALID, "svgr_gradient_fill: buffer too small");
     if (n == 0) return 0;
     const double* mptr = mask ? (const double*)mask->ptr : nullptr;
     GradDev h;
-    memset(&h, 0, sizeof h);
-    h.kind = g->kind; h.spread = g->spread; h.has_gt = g->has_gt; h.n_stops = g->n_stops; h.excl_enabled = g->excl_enabled;
-    memcpy(h.user_m6, g->user_m6, sizeof h.user_m6);
-    memcpy(h.gt_m6, g->gt_m6, sizeof h.gt_m6);
-    h.p0[0] = g->p0[0]; h.p0[1] = g->p0[1]; h.vec[0] = g->vec[0]; h.vec[1] = g->vec[1]; h.vv = g->vv;
-    h.center[0] = g->center[0]; h.center[1] = g->center[1]; h.radius = g->radius;
-    h.fcenter[0] = g->fcenter[0]; h.fcenter[1] = g->fcenter[1]; h.fradius = g->fradius;
-    h.cd[0] = g->cd[0]; h.cd[1] = g->cd[1]; h.rd = g->rd; h.a = g->a; h.frad_rd = g->frad_rd; h.frad2 = g->frad2;
-    h.excl_thresh = g->excl_thresh;
+    fill_grad_dev(h, g);
     HIPCHK(hipSetDevice(ctx->device));
     hipError_t e = hipSuccess;
     double* ext = nullptr;  // long stop lists: one device block {offsets, colours}, held until the stream has drained
@@ -3365,8 +3495,7 @@ static int gradient_run(svgr_ctx* ctx, const svgr_gradient* g, const double* pts
         h.ext_stops = ext;
     }
     if (g->kind == 3) {
-        // the two-circle gradient needs a device flag (any det < 0 ?) between its two kernels: a pool word, held until
-        // the stream has drained
+        // the two-circle gradient needs a device flag (any det < 0 ?) between its two kernels: a word from the block cache
         int* flag = nullptr;
         HIPCHK(g_pool.alloc((void**)&flag, 16));
         e = hipMemsetAsync(flag, 0, 16, ctx->stream);
@@ -3375,10 +3504,9 @@ static int gradient_run(svgr_ctx* ctx, const svgr_gradient* g, const double* pts
                                (int)bbox[2], (int)bbox[3], flag);
             hipLaunchKernelGGL(k_gradient_fill, grid1(n), dim3(256), 0, ctx->stream, h, pts, mptr, (int)bbox[0], (int)bbox[1],
                                (int)bbox[2], (int)bbox[3], (const int*)flag, (double*)out->ptr);
-            e = hipStreamSynchronize(ctx->stream);
-            if (e == hipSuccess) e = hipGetLastError();
+            e = hipGetLastError();
         }
-        g_pool.release(flag);
+        g_pool.release(flag);  // (stream order keeps the word's next user behind the two kernels: nothing to wait for)
     } else {
         hipLaunchKernelGGL(k_gradient_fill, grid1(n), dim3(256), 0, ctx->stream, h, pts, mptr, (int)bbox[0], (int)bbox[1],
                            (int)bbox[2], (int)bbox[3], (const int*)nullptr, (double*)out->ptr);

@@ -334,6 +334,32 @@ def _stroked(scene: Scene) -> Path:
 
 _GROUP_SERIAL = [0]
 _BATCH_GROUPS = __import__("os").environ.get("SVGR_NO_BATCH_GROUPS") is None  # (off: isolated groups take the per-node route)
+_BATCH_GRADS = __import__("os").environ.get("SVGR_NO_BATCH_GRADIENTS") is None  # (off: gradient fills take the per-node route)
+_ONES = np.ones(4)
+
+
+def _leaf(path, m6, rule, paint4, flags=0, group=None, grad=None):
+    """One batch entry: (path, m6, rule, paint4, flags, group, grad).  flags: 0 painted, 1 clip source, 2 clipped by the
+    clip source in front of it; group: tag of the isolated group it is a member of; grad: (Gradient struct, keep-alive) of a
+    gradient paint -- paint4 is then the multiplier of the evaluated colour (ones, or an opacity)."""
+    return (path, m6, rule, paint4, flags, group, grad)
+
+
+def _gradient_leaf(path, paint, rule, transform: Transform, linear_rgb: bool, opacity):
+    """The batch entry of a gradient-filled path, or None when the fill has to go node by node: objectBoundingBox units
+    (the frame comes from the path's hull), a colour space of its own (the fill layer is converted when composed), more
+    stops than the device block carries.  Path.fill's gradient branch, S:1021-1047."""
+    from .paint import _SPREAD  # noqa: PLC0415
+
+    if not _BATCH_GRADS or paint.bbox_units or not 1 <= len(paint.stops) <= 32:
+        return None
+    if paint.linear_rgb is not None and bool(paint.linear_rgb) != bool(linear_rgb):
+        return None
+    if paint.spread not in _SPREAD:
+        raise ValueError(f"invalid spread method: {paint.spread}")
+    g, keep = paint.abi(transform.invert, linear_rgb)
+    mult = _ONES if opacity is None else _ONES * opacity  # Layer.opacity over the leaf: image * opacity (S:174)
+    return _leaf(path, transform.m6(), _RULES[rule], mult, grad=(g, keep))
 
 
 def _new_group(opacity: float, clipped: bool):
@@ -343,7 +369,7 @@ def _new_group(opacity: float, clipped: bool):
 
 
 def _plain(leaves) -> bool:
-    return all(leaf[4] == 0 and leaf[5] is None for leaf in leaves)
+    return all(leaf[4] == 0 and leaf[5] is None for leaf in leaves)  # (gradient entries are plain too)
 
 
 def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opacity: float | None = None):
@@ -358,14 +384,19 @@ def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opac
         path, paint, rule = args
         if paint is None:
             return []
-        if not (isinstance(paint, np.ndarray) and paint.shape == (4,)):
-            return None
         if rule not in _RULES:
             raise ValueError(f"Invalid fill rule: {rule}")
+        if not (isinstance(paint, np.ndarray) and paint.shape == (4,)):
+            from .paint import is_gradient  # noqa: PLC0415
+
+            if not is_gradient(paint):
+                return None
+            leaf = _gradient_leaf(path, paint, rule, transform, linear_rgb, opacity)
+            return None if leaf is None else [leaf]
         p4 = solid_paint(paint, linear_rgb)
         if opacity is not None:
             p4 = p4 * opacity  # Layer.opacity: image * opacity (S:174)
-        return [(path, transform.m6(), _RULES[rule], p4, 0, None)]
+        return [_leaf(path, transform.m6(), _RULES[rule], p4)]
     if kind == RENDER_STROKE:  # a solid stroke is a solid fill of its outline (S:666-672), nonzero rule
         path, paint, width, linecap, linejoin = args
         return _batchable_leaves(Scene.fill(_stroked(scene), paint, None), transform, linear_rgb, opacity)
@@ -382,7 +413,7 @@ def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opac
         if members is None or not members or not _plain(members):
             return None
         tag = _new_group(args[1], False)
-        return [(m[0], m[1], m[2], m[3], 0, tag) for m in members]
+        return [_leaf(m[0], m[1], m[2], m[3], 0, tag, m[6]) for m in members]
     if kind == RENDER_CLIP and opacity is None and not args[2]:
         # CLIP whose target and clip are single paths: two consecutive batch entries, the clip path as a
         # coverage-only "clip source" and the fill multiplied by it (Layer.compose([mask, image], IN), S:698-715).
@@ -393,12 +424,12 @@ def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opac
             return None
         if len(target) == 1:
             t = target[0]
-            return [clip_leaf, (t[0], t[1], t[2], t[3], 2, None)]
+            return [clip_leaf, _leaf(t[0], t[1], t[2], t[3], 2, None, t[6])]
         if not _BATCH_GROUPS:
             return None
         # a GROUP under the clip: composited on its own, then multiplied by the clip's coverage as a whole
         tag = _new_group(1.0, True)
-        return [clip_leaf] + [(t[0], t[1], t[2], t[3], 0, tag) for t in target]
+        return [clip_leaf] + [_leaf(t[0], t[1], t[2], t[3], 0, tag, t[6]) for t in target]
     if kind == RENDER_GROUP and opacity is None:
         out = []
         for child in args:
@@ -421,7 +452,7 @@ def _single_mask_leaf(scene: Scene, transform: Transform):
     path, _paint, rule = args
     if rule not in _RULES:
         raise ValueError(f"Invalid fill rule: {rule}")
-    return (path, transform.m6(), _RULES[rule], np.zeros(4), 1, None)
+    return _leaf(path, transform.m6(), _RULES[rule], np.zeros(4), 1)
 
 
 def effective_bboxes(leaves, bboxes):
@@ -453,9 +484,17 @@ def build_batch(leaves, viewport, ctx=None) -> "_abi.Batch":
     ctx = ctx or _abi.Context.get()
     segs, kinds, offs, m6s, rules, paints = [], [], [0], [], [], []
     path_group, group_src, group_op, serial_to_gid = [], [], [], {}
+    path_grad, grads, keep_alive = [], [], []
     for i, leaf in enumerate(leaves):
         path, m6, rule, paint, flags = leaf[:5]
         group = leaf[5] if len(leaf) > 5 else None
+        grad = leaf[6] if len(leaf) > 6 else None
+        if grad is None:
+            path_grad.append(-1)
+        else:
+            path_grad.append(len(grads))
+            grads.append(grad[0])
+            keep_alive.append(grad[1])
         s, k = path.packed()
         segs.append(s)
         kinds.append(k)
@@ -478,6 +517,9 @@ def build_batch(leaves, viewport, ctx=None) -> "_abi.Batch":
     batch = _abi.Batch(ctx, segs, kinds, offs, np.array(m6s), rules, np.array(paints), viewport=vp, flatness=FLATNESS)
     if group_src:
         batch.set_groups(path_group, group_src, group_op)
+    if grads:
+        batch.set_gradients(path_grad, grads)  # (copies the descriptions to the device before it returns)
+    del keep_alive
     return batch
 
 
