@@ -2933,12 +2933,16 @@ int svgr_batch_set_gradients(svgr_batch* b, const int32_t* path_grad, int64_t n_
 static int plan_speculative(svgr_batch* b) {
     const int np = (int)b->n_paths;
     const int64_t ns = b->n_segs;
-    if (!b->has_vp || ns <= 0 || ns > 256 || np <= 0) return 0;
+    if (!b->has_vp || ns <= 0 || ns > 4096 || np <= 0) return 0;
     const int n_bands = (b->vp[2] + TR - 1) / TR;
-    if ((int64_t)np * n_bands > 65536 || n_bands <= 0) return 0;
+    if ((int64_t)np * n_bands > (1 << 20) || n_bands <= 0) return 0;
     const int n_ct = (b->vp[3] + TC - 1) / TC + 1;  // (+1: a layer need not start on a tile border)
-    if ((int64_t)np * n_bands * n_ct > 262144) return 0;  // (cells: bounded like the pairs, but by the viewport's width too)
-    const int shard_cap = (int)(64 * ns);  // a wave's segments all land in one shard: every shard can take them all
+    // Two size models.  Up to 256 segments (Path.mask / Path.fill of one path, a handful of glyphs): bounds that cannot be
+    // exceeded except by absurd input.  Up to 4096 segments (the runs of a document's per-node route): guesses a few times
+    // the typical need -- a wrong one costs the staged plan, never a wrong picture.
+    const bool small = ns <= 256;
+    // (small: a wave's segments all land in one shard, so every shard can take them all; larger: waves spread over the shards)
+    const int shard_cap = small ? (int)(64 * ns) : (int)(8 * ns + 512);
     b->n_edges = 0;
     for (int k = 0; k < NSH; ++k) {
         b->shards.base[k] = (int)b->n_edges;
@@ -2947,9 +2951,9 @@ static int plan_speculative(svgr_batch* b) {
     }
     b->n_bands = n_bands;
     b->n_pb = (int64_t)np * n_bands;
-    b->n_cells = b->n_pb * n_ct;
+    b->n_cells = std::min<int64_t>(b->n_pb * n_ct, std::max<int64_t>(262144, small ? 0 : 4 * b->n_pb));  // (overflow is flagged)
     b->n_entries = b->n_pb;
-    const int64_t rec_guess = 16 * (int64_t)shard_cap + b->n_pb;
+    const int64_t rec_guess = small ? 16 * (int64_t)shard_cap + b->n_pb : 256 * ns + 4096;
     int rc = b->layout_arena((int)b->n_pb);
     rc = rc ? rc : b->edges.ensure((size_t)b->n_edges * 4);
     rc = rc ? rc : b->edge_path.ensure((size_t)b->n_edges);

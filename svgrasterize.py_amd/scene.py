@@ -373,6 +373,18 @@ def _plain(leaves) -> bool:
 
 
 def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opacity: float | None = None):
+    """Memo in front of `_batchable_leaves_`: during one top-level render the same (node, transform) is asked about once per
+    enclosing group that turned out not to be batchable."""
+    if _LEAF_MEMO is None or scene[0] == RENDER_FILL:
+        return _batchable_leaves_(scene, transform, linear_rgb, opacity)
+    key = (id(scene), transform.key(), linear_rgb, opacity, "sub")
+    if key in _LEAF_MEMO:
+        return _LEAF_MEMO[key]
+    res = _LEAF_MEMO[key] = _batchable_leaves_(scene, transform, linear_rgb, opacity)
+    return res
+
+
+def _batchable_leaves_(scene: Scene, transform: Transform, linear_rgb: bool, opacity: float | None = None):
     """[(path, m6, rule, paint4, flags, group)] when `scene` is only GROUP / TRANSFORM / solid FILL / OPACITY directly over a
     leaf, a CLIP by a single path of a leaf or of a group of plain leaves, or an OPACITY over a group of plain leaves;
     None otherwise.  flags: 0 painted, 1 clip source (coverage only), 2 clipped by the clip source right in front of it;
