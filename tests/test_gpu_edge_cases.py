@@ -391,3 +391,62 @@ def test_batch_group_description_is_validated(S):
         b.set_groups([-1, 0, 0, -1], [0], [1.0])
         b.plan()
         b.render(ctx.alloc(1 << 16), _abi.OUT_MASKS_F64)
+
+
+def test_gradient_fills_inside_the_batch_equal_the_per_node_route(S):
+    """Gradient-painted leaves as batch entries (colour evaluated per visible pixel by the tile kernel) against the per-node
+    route (Path.mask + svgr_gradient_fill + Layer.compose, what the reference does, S:1021-1047): linear / radial / focal
+    radial with a negative-determinant region, the three spread methods, a gradientTransform, an opacity over the leaf, members
+    of clipped and faded groups, evenodd.  Same offsets, shapes and pixels; objectBoundingBox gradients stay per node."""
+    from svgrasterize_amd import scene as sc
+
+    rng = np.random.default_rng(33)
+
+    def stops(n):
+        offs = np.linspace(0.0, 1.0, n)
+        out = []
+        for o in offs:
+            a = rng.uniform(0.3, 1.0)
+            out.append((float(o), np.array([*(rng.uniform(0, 1, 3) * a), a])))
+        return out
+
+    def blob(cx, cy, r):
+        return S.Path.from_svg(f"M{cx - r},{cy} C{cx - r},{cy - 1.2 * r} {cx + 0.5 * r},{cy - r} {cx + r},{cy - 0.3 * r} "
+                               f"S{cx + 0.2 * r},{cy + 1.3 * r} {cx - r},{cy} Z M{cx - 0.3 * r},{cy} h{0.4 * r} v{0.3 * r} h{-0.4 * r} Z")
+
+    lin = S.GradLinear(np.array([40.0, 30.0]), np.array([220.0, 160.0]), stops(4), None, "pad", False, None)
+    lin_refl = S.GradLinear(np.array([0.0, 0.0]), np.array([40.0, 10.0]), stops(3), S.Transform().rotate(0.3).scale(1.5, 0.8), "reflect", False, None)
+    rad_rep = S.GradRadial(np.array([200.0, 120.0]), 35.0, None, None, stops(5), None, "repeat", False, None)
+    focal = S.GradRadial(np.array([120.0, 200.0]), 60.0, np.array([150.0, 215.0]), 8.0, stops(6), None, "pad", False, None)   # det < 0 outside the cone
+    solid = np.array([0.2, 0.1, 0.4, 0.8])
+    clip = lambda cx, cy, r: S.Scene.fill(blob(cx, cy, r), np.zeros(4))
+    doc = S.Scene.group([
+        S.Scene.fill(blob(130, 110, 120), lin),
+        S.Scene.fill(blob(210, 130, 80), rad_rep, "evenodd").opacity(0.7),
+        S.Scene.group([S.Scene.fill(blob(100, 190, 70), focal), S.Scene.fill(blob(140, 210, 40), solid)]).clip(clip(120, 200, 55)),
+        S.Scene.group([S.Scene.fill(blob(60, 80, 50), lin_refl), S.Scene.fill(blob(90, 90, 30), rad_rep)]).opacity(0.5),
+        S.Scene.fill(blob(250, 220, 60), focal).clip(clip(240, 215, 30)),
+        S.Scene.stroke(S.Path.from_svg("M20,250 C80,200 160,300 290,240"), lin, 9.0),
+    ])
+    swap = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    for tr, viewport in ((swap, [0, 0, 300, 330]), (swap.scale(2.5), [100, 180, 400, 470])):
+        results = []
+        for batched in (True, False):
+            old = sc._BATCH_GRADS
+            sc._BATCH_GRADS = batched
+            try:
+                assert (sc._batchable_leaves(doc, tr, False) is not None) == batched
+                layer, _hull = doc.render(tr, viewport=viewport, linear_rgb=False)
+            finally:
+                sc._BATCH_GRADS = old
+            results.append(layer)
+        got, want = results
+        assert tuple(int(v) for v in got.offset) == tuple(int(v) for v in want.offset) and got.image.shape == want.image.shape
+        assert_close64(got.image, want.image, atol=1e-12, what=f"gradients in the batch vs per node, viewport {viewport}")
+        assert np.abs(want.image).max() > 0.2
+    bbox_grad = S.GradLinear(np.array([0.0, 0.0]), np.array([1.0, 0.0]), stops(2), None, "pad", True, None)
+    own_space = S.GradLinear(np.array([0.0, 0.0]), np.array([100.0, 0.0]), stops(2), None, "pad", False, True)
+    for paint in (bbox_grad, own_space):   # these keep the per-node route (and still render)
+        node = S.Scene.group([S.Scene.fill(blob(100, 100, 60), paint), S.Scene.fill(blob(120, 100, 30), solid)])
+        assert sc._batchable_leaves(node, swap, False) is None
+        assert node.render(swap, viewport=[0, 0, 256, 256], linear_rgb=False) is not None
