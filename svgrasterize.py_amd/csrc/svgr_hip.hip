@@ -366,8 +366,9 @@ struct BatchDev {
     // cursor serves only ~90 returning atomics per microsecond chip-wide, sixteen serve every wave of the launch.
     // One 128-byte line per cursor.
     struct ShardLine {
-        int cursor;
-        int pad[31];
+        int cursor;         // edges (k_flatten)
+        int chunk_cursor;   // extra row chunks of long edges (k_edge_count)
+        int pad[30];
     } shard[16];
 };
 constexpr int NSH = 16;
@@ -378,6 +379,9 @@ static_assert(sizeof(BatchDev) == 128 + NSH * 128, "BatchDev is the head of the 
 struct EdgeShards {
     int base[NSH];
     int cap[NSH];
+    // the same for the extra row chunks of long edges (k_edge_count / k_edge_emit), in the list behind the edge slots
+    int cbase[NSH];
+    int ccap[NSH];
 };
 // is edge slot e filled?  (bases ascend; empty shards share a base with their successor)
 __device__ __forceinline__ bool edge_live(int e, const EdgeShards& sh, const BatchDev* __restrict__ bd) {
@@ -687,10 +691,34 @@ __device__ __forceinline__ void band_rows(const EdgeSetup& es, int band, int vr0
     yb = es.y_end < b0row + TR ? es.y_end : b0row + TR;
 }
 
+// k_edge_emit's work item is a CHUNK of an edge's rows, not the edge: a wave runs as long as its longest item, and real
+// drawings have edges of hundreds of rows next to edges of two (a synthetic blob: mean 3 rows, longest 49).  An edge of up to
+// CHUNK_ROWS rows is one chunk; a longer one is cut into at most CHUNK_MAX equal chunks.  (8, 16 or 32 rows per chunk measure
+// the same on the synthetic scene -- what k_edge_emit gains, k_edge_count pays for the list -- and on the documents, whose
+// wall clock is the host's; the Ghostscript tiger's geometry pass went from 0.33 to 0.12 ms.)  A chunk that does not start at the
+// edge's first row replays the x recurrence from there (S:2244-2248: a dozen instructions per row, against ~150 for a row
+// that is emitted), so every row still sees the bits the sequential walk gives it.
+#ifndef SVGR_CHUNK_ROWS
+#define SVGR_CHUNK_ROWS 16
+#endif
+constexpr int CHUNK_ROWS = SVGR_CHUNK_ROWS, CHUNK_MAX = 16, CHUNK_SHIFT = 27;  // (chunk id: edge | chunk << 27)
+__host__ __device__ __forceinline__ int edge_chunks(int rows) {
+    if (rows <= CHUNK_ROWS) return 1;
+    const int n = (rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
+    return n < CHUNK_MAX ? n : CHUNK_MAX;
+}
+// rows [y_lo, y_hi) of chunk c of an edge that walks the rows [y_begin, y_end)
+__device__ __forceinline__ void chunk_rows(int y_begin, int y_end, int c, int& y_lo, int& y_hi) {
+    const int rows = y_end - y_begin, n = edge_chunks(rows), per = (rows + n - 1) / n;
+    y_lo = y_begin + c * per;
+    y_hi = y_lo + per < y_end ? y_lo + per : y_end;
+    y_lo = y_lo < y_end ? y_lo : y_end;
+}
+
 __global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ edges, const int* __restrict__ edge_path,
                                                     const int* __restrict__ bbox, const PathBin* __restrict__ bins,
                                                     int vr0, int pb_cap, int* __restrict__ pb_cnt, BatchDev* __restrict__ bd,
-                                                    Owner own, const EdgeShards sh) {
+                                                    Owner own, const EdgeShards sh, int* __restrict__ chunks) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     EdgeSetup es;
     int p = 0, r0 = 0, key = -1, bf = 0, bl = -1, rows_first = 0;
@@ -720,6 +748,32 @@ __global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ e
             int ya, yb;
             band_rows(es, bf + b, vr0, r0, ya, yb);
             atomicAdd(&pb_cnt[key + b], yb - ya);
+        }
+    }
+    // The edge's first chunk needs no list: work item e of k_edge_emit is chunk 0 of edge slot e.  The extra chunks of a long
+    // edge go to a list behind the edge slots, reserved per wave in one of NSH shards (a single cursor would serialise the
+    // 12 000 waves of this kernel: ~90 returning atomics per microsecond and address).
+    // The list's shard of an edge is the flatten shard its slot lies in: WHICH edges a flatten shard holds is fixed by the
+    // flatten's wave numbering (where inside the shard they land is not), so the per-shard chunk totals the plan measured
+    // hold for every later pass.  The 64 consecutive slots of a wave lie in one shard, or in two at a shard border.
+    const int extra = ok ? edge_chunks(es.y_end - es.y_begin) - 1 : 0;
+    int my_shard = 0;
+#pragma unroll
+    for (int k = 1; k < NSH; ++k) my_shard += e >= sh.base[k] ? 1 : 0;
+    int at = 0;
+    unsigned long long todo = __ballot(extra > 0);
+    while (todo != 0ull) {
+        const int s0 = __builtin_amdgcn_readlane(my_shard, __ffsll((long long)todo) - 1);
+        const bool mine = extra > 0 && my_shard == s0;
+        const int a = wave_alloc(&bd->shard[s0].chunk_cursor, mine ? extra : 0, lane);
+        at = mine ? a : at;
+        todo &= ~__ballot(mine);
+    }
+    if (chunks && extra > 0) {
+        if (at + extra > sh.ccap[my_shard] || e >= (1 << CHUNK_SHIFT)) {
+            atomicOr(&bd->err, 2);
+        } else {
+            for (int c = 0; c < extra; ++c) chunks[sh.cbase[my_shard] + at + c] = e | ((c + 1) << CHUNK_SHIFT);
         }
     }
 }
@@ -898,26 +952,56 @@ __global__ __launch_bounds__(256, SVGR_EMIT_WAVES) void k_edge_emit(const double
                                                    const int* __restrict__ bbox, const PathBin* __restrict__ bins,
                                                    int vr0, int pb_cap, const int* __restrict__ bseg_off,
                                                    int* __restrict__ pb_cursor, RowRec* __restrict__ recs, int rec_cap,
-                                                   BatchDev* __restrict__ bd, Owner own, const EdgeShards sh) {
+                                                   BatchDev* __restrict__ bd, Owner own, const EdgeShards sh, int n_edges,
+                                                   const int* __restrict__ chunks) {
     static_assert(REC_BYTES % 16 == 0, "records move as 16-byte chunks");
     constexpr int CPR = REC_BYTES / 16;  // chunks per record
     __shared__ uint4 s_stage[4][64 * CPR];
     __shared__ int s_dest[4][64];
-    const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // this lane's work item: rows [y_lo, y_hi) of edge e.  Items 0 .. n_edges-1 are the first chunks of the edge slots, the
+    // rest the extra chunks of long edges in k_edge_count's sharded list
+    int e = ci, cidx = 0;
+    bool ok;
+    if (ci < n_edges) {
+        ok = edge_live(ci, sh, bd);
+    } else {
+        const int x = ci - n_edges;
+        int sd = 0;
+#pragma unroll
+        for (int k = 1; k < NSH; ++k) sd += x >= sh.cbase[k] ? 1 : 0;
+        const int filled = bd->shard[sd].chunk_cursor < sh.ccap[sd] ? bd->shard[sd].chunk_cursor : sh.ccap[sd];
+        ok = x - sh.cbase[sd] < filled;
+        if (ok) {
+            const int w = chunks[x];
+            e = w & ((1 << CHUNK_SHIFT) - 1);
+            cidx = (int)((unsigned)w >> CHUNK_SHIFT);
+            ok = e < n_edges && edge_live(e, sh, bd);  // (a pass that overflowed its list leaves holes: flagged, never followed)
+        }
+    }
     EdgeSetup es;
-    int p = 0, r0 = 0, key = -1, rows_first = 0;
-    bool ok = edge_live(e, sh, bd) && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
+    int p = 0, r0 = 0, key = -1, rows_first = 0, y_lo = 0, y_hi = 0;
+    ok = ok && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
+    if (ok) {
+        chunk_rows(es.y_begin, es.y_end, cidx, y_lo, y_hi);
+        ok = y_lo < y_hi;
+    }
+    auto rows_in = [&](int band_, int& ya, int& yb) {  // the chunk's rows inside band `band_` (layer-local [ya, yb))
+        const int b0row = band_ * TR + vr0 - r0;
+        ya = y_lo > b0row ? y_lo : b0row;
+        yb = y_hi < b0row + TR ? y_hi : b0row + TR;
+    };
     int bf = 0, bl = -1;
     if (ok) {
         const PathBin pbin = bins[p];
-        bf = (r0 + es.y_begin - vr0) / TR;
-        bl = (r0 + es.y_end - 1 - vr0) / TR;
+        bf = (r0 + y_lo - vr0) / TR;
+        bl = (r0 + y_hi - 1 - vr0) / TR;
         key = pbin.pb_off - pbin.b0 + bf;
         if (key < 0 || key + (bl - bf) >= pb_cap) ok = false;  // flagged by k_edge_count
     }
     if (ok && owns_band(own, bf)) {
         int ya, yb;
-        band_rows(es, bf, vr0, r0, ya, yb);
+        rows_in(bf, ya, yb);
         rows_first = yb - ya;
     }
     int head, len, total;
@@ -929,7 +1013,7 @@ __global__ __launch_bounds__(256, SVGR_EMIT_WAVES) void k_edge_emit(const double
     if (ok && head == lane && run_end_incl > run_begin_excl) run_base = atomicAdd(&pb_cursor[key], run_end_incl - run_begin_excl);
     run_base = __shfl(run_base, head);
 
-    // The record slots of the first EMIT_PRE bands of the edge are reserved here, before the row loop, with their loads and
+    // The record slots of the first EMIT_PRE bands of the chunk are reserved here, before the row loop, with their loads and
     // (returning) atomics in flight together: reserved on entering each band they stalled the whole wave for a round trip
     // at every turn in which some lane crossed a band border.
     constexpr int EMIT_PRE = 4;
@@ -940,7 +1024,7 @@ __global__ __launch_bounds__(256, SVGR_EMIT_WAVES) void k_edge_emit(const double
         const int band_i = bf + i;
         if (ok && band_i <= bl && owns_band(own, band_i)) {
             int ya, y1;
-            band_rows(es, band_i, vr0, r0, ya, y1);
+            rows_in(band_i, ya, y1);
             const int in_block = i == 0 ? run_base + (excl - run_begin_excl) : atomicAdd(&pb_cursor[key + i], y1 - ya);
             pre_slot[i] = bseg_off[key + i] + in_block;
         }
@@ -950,8 +1034,11 @@ __global__ __launch_bounds__(256, SVGR_EMIT_WAVES) void k_edge_emit(const double
     st.x_next = es.x;
     st.x = es.x;
     st.d = 0.0;
-    int y = ok ? es.y_begin : 0;
-    const int y_end = ok ? es.y_end : 0;
+    // a later chunk of a long edge: carry x from the edge's first row to the chunk's, exactly as the walk would (S:2244-2248)
+    if (ok)
+        for (int yy = es.y_begin; yy < y_lo; ++yy) row_step(st, yy, es.p0y, es.p1y, es.dxdy, es.dir);
+    int y = ok ? y_lo : 0;
+    const int y_end = ok ? y_hi : 0;
     int band = bf - 1, band_end = y, slot = 0, band_row0 = 0;  // "end of band bf - 1": the first turn enters band bf
     while (__ballot(y < y_end) != 0ull) {
         bool has = false;
@@ -961,7 +1048,7 @@ __global__ __launch_bounds__(256, SVGR_EMIT_WAVES) void k_edge_emit(const double
             while (y == band_end && y < y_end) {  // enter the next band
                 ++band;
                 int ya, y1;
-                band_rows(es, band, vr0, r0, ya, y1);
+                rows_in(band, ya, y1);
                 if (!owns_band(own, band)) {  // another rank's band: only carry x across it (S:2244-2248)
                     for (; y < y1; ++y) row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);
                     band_end = y;
@@ -2377,6 +2464,18 @@ struct svgr_batch {
     DevArr<RowRec> bsegs;
     DevArr<CellHdr> cell_hdr;               // per (path, band, column tile) cell: header (classes 1 and 2)
     DevArr<int2> entry_where;               // per band-list entry: {band, index in the band's list}
+    DevArr<int> chunks;                     // extra row chunks of long edges: edge | chunk << 27, in NSH shards (k_edge_count)
+    int64_t n_chunks = 0;                   // slots of that list (sum of the shard capacities)
+    // lay the chunk shards back to back with the given capacities
+    int size_chunks(const int* caps) {
+        n_chunks = 0;
+        for (int k = 0; k < NSH; ++k) {
+            shards.cbase[k] = (int)n_chunks;
+            shards.ccap[k] = caps[k];
+            n_chunks += caps[k];
+        }
+        return chunks.ensure((size_t)std::max<int64_t>(n_chunks, 1));
+    }
     DevArr<unsigned long long> tile_mask;   // per (band, column tile): 2 x mask_words words over the band's list (k_pair_cells)
     int mask_words = 1;
     bool masks_zeroed = false;              // the last tile kernel left the masks cleared
@@ -2426,7 +2525,7 @@ struct svgr_batch {
         bseg_off.release(); band_start.release(); band_count.release(); entries.release();
         path_group.release(); group_clip_src.release(); group_opacity.release();
         grads.release(); path_grad.release(); grad_path.release(); grad_flags.release();
-        edges.release(); bsegs.release(); cell_hdr.release(); entry_where.release(); tile_mask.release(); layer_off.release();
+        edges.release(); bsegs.release(); cell_hdr.release(); entry_where.release(); tile_mask.release(); chunks.release(); layer_off.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
         for (auto e : event_pool) (void)hipEventDestroy(e);
@@ -2473,7 +2572,8 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     if (upto == 2) return 0;
     const size_t ne = (size_t)std::max<int64_t>(b->n_edges, 1);
     hipLaunchKernelGGL(k_edge_count, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
-                       (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->pb_cap, b->pb_cnt(), b->bd(), b->own, b->shards);
+                       (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->pb_cap, b->pb_cnt(), b->bd(), b->own, b->shards,
+                       upto >= 4 ? b->chunks.p : (int*)nullptr);
     // per owned band: tile list + record blocks (upto == 3: sizes only, no headers written)
     const int owned = count_owned_bands(b->own, b->n_bands);
     if (owned > 0)
@@ -2482,9 +2582,10 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                            upto >= 4 ? cap_i32(b->bsegs.cap) : 0x7fffffff, b->band_start.p, b->band_count.p, b->entries.p,
                            b->entry_where.p, cap_i32(std::min(b->entries.cap, b->entry_where.cap)), b->vp[1], b->bd(), b->own);
     if (upto == 3) return 0;
-    hipLaunchKernelGGL(k_edge_emit, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
-                       (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->pb_cap, (const int*)b->bseg_off.p,
-                       b->pb_cursor(), b->bsegs.p, cap_i32(b->bsegs.cap), b->bd(), b->own, b->shards);
+    hipLaunchKernelGGL(k_edge_emit, grid1((size_t)std::max<int64_t>(b->n_edges + b->n_chunks, 1)), dim3(256), 0, st,
+                       (const double*)b->edges.p, (const int*)b->edge_path.p, (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0],
+                       b->pb_cap, (const int*)b->bseg_off.p, b->pb_cursor(), b->bsegs.p, cap_i32(b->bsegs.cap), b->bd(), b->own,
+                       b->shards, (int)b->n_edges, (const int*)b->chunks.p);
     // per pair with records: classes and carry-ins of its column tiles
     // (the tiles read their mask words whether or not any pair has records: a batch without entries still needs them clear --
     //  a block from the cache is not zero)
@@ -2964,6 +3065,11 @@ static int plan_speculative(svgr_batch* b) {
     rc = rc ? rc : b->bsegs.ensure((size_t)rec_guess + PREF_RECS_MAX + 1);
     rc = rc ? rc : b->cell_hdr.ensure((size_t)b->n_cells + 1);
     rc = rc ? rc : b->entry_where.ensure((size_t)b->n_pb);
+    {
+        int caps[NSH];
+        for (int k = 0; k < NSH; ++k) caps[k] = shard_cap;  // (extra chunks of long edges: a guess like the others)
+        rc = rc ? rc : b->size_chunks(caps);
+    }
     rc = rc ? rc : b->size_masks(np);
     if (rc) return rc;
     if ((rc = run_geometry(b, 4, true))) return rc;
@@ -3039,10 +3145,16 @@ static int batch_plan_impl(svgr_batch* b) {
     if (int rc = check_dev_err(b)) return rc;
     b->n_bsegs = b->host_bd.bseg_cursor;
     b->n_entries = b->host_bd.entry_cursor;
+    {
+        int caps[NSH];
+        for (int k = 0; k < NSH; ++k) caps[k] = b->host_bd.shard[k].chunk_cursor;
+        if (int rc = b->size_chunks(caps)) return rc;
+    }
     if (int rc = b->size_masks(b->host_bd.max_band_entries)) return rc;
     if (int rc = b->bsegs.ensure((size_t)std::max<int64_t>(b->n_bsegs, 1) + PREF_RECS_MAX + 1)) return rc;
     // 4. full geometry once, to validate the capacities and fetch the bboxes
     if (int rc = run_geometry(b, 4, true)) return rc;
+
     if (int rc = check_dev_err(b, nullptr, true, true)) return rc;
     b->n_edges_live = b->n_edges;
     b->planned = true;
