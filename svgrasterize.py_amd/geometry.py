@@ -35,6 +35,9 @@ FLATNESS = 0.1  # S:955
 # --------------------------------------------------------------------------------------
 # Transform
 # --------------------------------------------------------------------------------------
+_INV_MEMO: dict = {}
+
+
 class Transform:
     __slots__ = ["m", "_m_inv"]
 
@@ -52,7 +55,15 @@ class Transform:
     @property
     def invert(self) -> "Transform":
         if self._m_inv is None:
-            self._m_inv = np.linalg.inv(self.m)
+            # (np.linalg.inv like the reference, S:520-523; the leaves of a group share their accumulated matrix, so the
+            #  20 us LAPACK call is looked up by the matrix's bytes: same input, same bits)
+            key = self.m.tobytes()
+            inv = _INV_MEMO.get(key)
+            if inv is None:
+                if len(_INV_MEMO) > 4096:
+                    _INV_MEMO.clear()
+                inv = _INV_MEMO[key] = np.linalg.inv(self.m)
+            self._m_inv = inv
         return Transform(self._m_inv, self.m)
 
     def __call__(self, points):
