@@ -210,8 +210,8 @@ def roofline_block(tile_ms, geo_ms, n_timed, every, P_rank, E_rank, canvas_bytes
     alg_bytes = BYTES_PER_PATH_PIXEL * P_rank + BYTES_PER_EDGE * E_rank
     floor_bytes = canvas_bytes + BYTES_PER_EDGE * E_rank
     kern = None
-    if counters is not None:
-        kern = counters["kernels"].get("k_tile_render<0, false>")
+    if counters is not None:  # (the production instantiation: float32 canvas, no clip tile; further template arguments vary)
+        kern = next((v for k, v in counters["kernels"].items() if k.startswith("k_tile_render<0, false")), None)
     valu = kern.get("SQ_INSTS_VALU") if kern else None
     traffic = kern.get("hbm_bytes_per_launch") if kern else None
     block = {
