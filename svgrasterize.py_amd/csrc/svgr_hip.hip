@@ -432,6 +432,27 @@ __global__ __launch_bounds__(256) void k_path_rows(const double* __restrict__ se
     atomicMax(&prow[2 * (size_t)p + 1], (unsigned)(UNION_BIAS + hi));
 }
 
+// Multi-GPU, at plan time: the segments this rank has to flatten at all -- those of the paths whose row reach (k_path_rows)
+// touches one of its bands -- as a compact list, so that a render's flatten launches over a rank's share of the drawing
+// instead of over all of it (the reach of a path depends on the transforms alone: svgr_batch_set_transforms invalidates the
+// plan).  The same distribution decision synth.rows_subscene makes on the host for the weak-scaling drawing.
+__global__ __launch_bounds__(256) void k_seg_select(const int* __restrict__ seg_path, int n_segs, const unsigned* __restrict__ prow,
+                                                    Owner own, int vr0, int n_bands, int* __restrict__ seg_list,
+                                                    int* __restrict__ cursor) {
+    const int seg = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    bool take = false;
+    if (seg < n_segs) {
+        const int p = seg_path[seg];
+        const int lo = UNION_BIAS - (int)prow[2 * (size_t)p], hi = (int)prow[2 * (size_t)p + 1] - UNION_BIAS;
+        int ba = (lo - 2 - vr0) / TR, bb = (hi + 2 - vr0) / TR;
+        ba = lo - 2 - vr0 < 0 ? 0 : ba;
+        bb = bb > n_bands - 1 ? n_bands - 1 : bb;
+        take = ba <= bb && owns_any(own, ba, bb);
+    }
+    const int at = wave_alloc(cursor, take ? 1 : 0, lane);
+    if (take) seg_list[at] = seg;
+}
+
 // 32 lanes per segment.  Lane j owns the depth-5 node whose path bits are j (if the five ancestors
 // above it are not flat; an ancestor that is flat is emitted by the lane whose remaining bits are 0).
 // Per-path keys: {~key(min_r), ~key(min_c), key(max_r), key(max_c)}, all folded with atomicMax.
@@ -446,9 +467,12 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
                                                  int n_segs, double thr, double* __restrict__ edges,
                                                  int* __restrict__ edge_path, const EdgeShards sh,
                                                  unsigned long long* __restrict__ pkeys, BatchDev* __restrict__ bd,
-                                                 Owner own, int vr0, int n_bands, const unsigned* __restrict__ prow) {
+                                                 Owner own, int vr0, int n_bands, const unsigned* __restrict__ prow,
+                                                 const int* __restrict__ seg_list, int n_list) {
     const int gtid = blockIdx.x * FL_BLOCK + threadIdx.x;
-    const int seg = gtid >> FL_SUB, sub = gtid & ((1 << FL_SUB) - 1);
+    const int item = gtid >> FL_SUB, sub = gtid & ((1 << FL_SUB) - 1);
+    // (multi-GPU: the plan's list of the segments this rank needs; else every segment)
+    const int seg = seg_list ? (item < n_list ? seg_list[item] : n_segs) : item;
     bool seg_ok = seg < n_segs;
     double node[8];
     int mode = 0;  // 0 nothing, 1 one edge node[0..1] -> node[6..7], 2 subtree under node
@@ -2464,6 +2488,8 @@ struct svgr_batch {
     DevArr<RowRec> bsegs;
     DevArr<CellHdr> cell_hdr;               // per (path, band, column tile) cell: header (classes 1 and 2)
     DevArr<int2> entry_where;               // per band-list entry: {band, index in the band's list}
+    DevArr<int> seg_list;                   // multi-GPU: the segments this rank flattens (k_seg_select, at plan time)
+    int64_t n_seg_list = -1;                // (-1: no list, every segment)
     DevArr<int> chunks;                     // extra row chunks of long edges: edge | chunk << 27, in NSH shards (k_edge_count)
     int64_t n_chunks = 0;                   // slots of that list (sum of the shard capacities)
     // lay the chunk shards back to back with the given capacities
@@ -2525,7 +2551,7 @@ struct svgr_batch {
         bseg_off.release(); band_start.release(); band_count.release(); entries.release();
         path_group.release(); group_clip_src.release(); group_opacity.release();
         grads.release(); path_grad.release(); grad_path.release(); grad_flags.release();
-        edges.release(); bsegs.release(); cell_hdr.release(); entry_where.release(); tile_mask.release(); chunks.release(); layer_off.release();
+        edges.release(); bsegs.release(); cell_hdr.release(); entry_where.release(); tile_mask.release(); chunks.release(); seg_list.release(); layer_off.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
         for (auto e : event_pool) (void)hipEventDestroy(e);
@@ -2543,10 +2569,14 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     const int ns = (int)b->n_segs, np = (int)b->n_paths;
     if (!b->arena_zeroed) HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
     b->arena_zeroed = false;  // (the kernels below count into it)
-    const dim3 fgrid = grid1((size_t)ns << FL_SUB, FL_BLOCK);
-    // multi-GPU with a viewport: find the rows each path can reach first, so that the flatten skips foreign paths
+    // multi-GPU with a viewport: the plan listed the segments of the paths whose rows can reach this rank's bands
+    // (build_seg_list); a pass without such a list finds the reach itself and lets the flatten skip foreign paths
+    const bool listed = use_vp && b->own.world > 1 && b->n_seg_list >= 0;
+    const int n_items = listed ? (int)b->n_seg_list : ns;
+    const dim3 fgrid = grid1((size_t)std::max(n_items, 1) << FL_SUB, FL_BLOCK);
+    const int* seg_list = listed ? (const int*)b->seg_list.p : (const int*)nullptr;
     const unsigned* prow = nullptr;
-    if (use_vp && b->own.world > 1 && ns > 0) {
+    if (use_vp && b->own.world > 1 && ns > 0 && !listed) {
         hipLaunchKernelGGL(k_path_rows, grid1((size_t)ns), dim3(256), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
                            (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->prow());
         prow = b->prow();
@@ -2556,7 +2586,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
             hipLaunchKernelGGL(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                                (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns,
                                b->thr, (double*)nullptr, (int*)nullptr, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
-                               use_vp ? (b->vp[2] + TR - 1) / TR : 0, prow);
+                               use_vp ? (b->vp[2] + TR - 1) / TR : 0, prow, seg_list, n_items);
         if (upto == 0)  // bboxes only (no edges stored): enough to find the union when there is no viewport
             hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np,
                                use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), 1);
@@ -2566,7 +2596,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
         hipLaunchKernelGGL(k_flatten<true>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                            (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
                            b->edges.p, b->edge_path.p, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
-                           use_vp ? (b->vp[2] + TR - 1) / TR : 0, prow);
+                           use_vp ? (b->vp[2] + TR - 1) / TR : 0, prow, seg_list, n_items);
     hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np, use_vp ? 1 : 0,
                        b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), b->planned ? 0 : 1);
     if (upto == 2) return 0;
@@ -2932,6 +2962,7 @@ int svgr_batch_set_bands(svgr_batch* b, int rank, int world, int strip_bands) {
     if (!b || world <= 0 || rank < 0 || rank >= world || strip_bands <= 0) return fail(SVGR_E_INVALID, "bad band selection");
     b->own = Owner{rank, world, strip_bands};
     b->planned = false;  // the edge / record capacities are per rank
+    b->n_seg_list = -1;  // ... and so is the list of segments to flatten
     return 0;
 }
 
@@ -3034,7 +3065,7 @@ int svgr_batch_set_gradients(svgr_batch* b, const int32_t* path_grad, int64_t n_
 static int plan_speculative(svgr_batch* b) {
     const int np = (int)b->n_paths;
     const int64_t ns = b->n_segs;
-    if (!b->has_vp || ns <= 0 || ns > 4096 || np <= 0) return 0;
+    if (!b->has_vp || ns <= 0 || ns > 4096 || np <= 0 || b->own.world > 1) return 0;
     const int n_bands = (b->vp[2] + TR - 1) / TR;
     if ((int64_t)np * n_bands > (1 << 20) || n_bands <= 0) return 0;
     const int n_ct = (b->vp[3] + TC - 1) / TC + 1;  // (+1: a layer need not start on a tile border)
@@ -3085,6 +3116,25 @@ static int plan_speculative(svgr_batch* b) {
     return 1;
 }
 
+// k_path_rows + k_seg_select + one read-back: b->seg_list / b->n_seg_list
+static int build_seg_list(svgr_batch* b) {
+    hipStream_t st = b->ctx->stream;
+    const int ns = (int)b->n_segs;
+    if (int rc = b->seg_list.ensure((size_t)ns)) return rc;
+    HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
+    b->arena_zeroed = false;
+    hipLaunchKernelGGL(k_path_rows, grid1((size_t)ns), dim3(256), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
+                       (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->prow());
+    hipLaunchKernelGGL(k_seg_select, grid1((size_t)ns), dim3(256), 0, st, (const int*)b->seg_path.p, ns, (const unsigned*)b->prow(), b->own,
+                       b->vp[0], (b->vp[2] + TR - 1) / TR, b->seg_list.p, &b->bd()->edge_spare);
+    int n = 0;
+    HIPCHK(hipMemcpyAsync(&n, &b->bd()->edge_spare, sizeof n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    b->n_seg_list = n;
+    return 0;
+}
+
 static int batch_plan_impl(svgr_batch* b);
 int svgr_batch_plan(svgr_batch* b) {
     return abi_guard("svgr_batch_plan", [&]() { return batch_plan_impl(b); });
@@ -3115,6 +3165,11 @@ static int batch_plan_impl(svgr_batch* b) {
         } else {
             b->vp[0] = b->vp[1] = 0; b->vp[2] = b->vp[3] = 0;
         }
+    }
+    // 1b. multi-GPU: the segments this rank has to flatten at all (a plan product: the renders launch over the list)
+    b->n_seg_list = -1;
+    if (b->own.world > 1 && b->n_segs > 0 && b->vp[2] > 0) {
+        if (int rc = build_seg_list(b)) return rc;
     }
     // 2. count the edges this rank keeps
     if (int rc = run_geometry(b, 1, true)) return rc;
@@ -3235,7 +3290,7 @@ static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path
     HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
     hipLaunchKernelGGL(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
                        (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr, (double*)nullptr, (int*)nullptr, b->shards,
-                       b->pkeys(), b->bd(), whole, 0, 0, (const unsigned*)nullptr);
+                       b->pkeys(), b->bd(), whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0);
     BatchDev counts;
     HIPCHK(hipMemcpyAsync(&counts, b->bd(), sizeof counts, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -3259,7 +3314,7 @@ static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_flatten<true>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
                            (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr, d_edges, d_path, sh, b->pkeys(), b->bd(),
-                           whole, 0, 0, (const unsigned*)nullptr);
+                           whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0);
         e = hipMemcpyAsync(edges, d_edges, sizeof(double) * 4 * (size_t)total, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && edge_path) e = hipMemcpyAsync(edge_path, d_path, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
