@@ -613,8 +613,13 @@ static_assert(sizeof(PathBin) == 16, "PathBin is one dwordx4");
 // their six atomics per wave on shared addresses are most of this kernel's time when a render repeats the geometry
 __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __restrict__ pkeys, int n_paths, int has_vp,
                                                   int vr0, int vc0, int vrows, int vcols, int* __restrict__ bbox,
-                                                  PathBin* __restrict__ bins, BatchDev* __restrict__ bd, int stats) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+                                                  PathBin* __restrict__ bins, BatchDev* __restrict__ bd, int stats,
+                                                  const int* __restrict__ plist) {
+    // (multi-GPU: thread i takes the i-th path of this rank's list, n_paths = its length; the others keep the empty bbox
+    //  and bins the plan gave them)
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const int p = plist ? (pi < n_paths ? plist[pi] : 0x7fffffff) : pi;
+    if (plist) n_paths = pi < n_paths ? 0x7fffffff : 0;  // (p < n_paths below = "this thread has a path")
     int out[4] = {0, 0, 0, 0};
     int pb0 = 0, pnb = 0, pnct = 0;
     int st_n = 0;
@@ -820,6 +825,7 @@ static_assert(sizeof(TileEntry) == 32, "TileEntry is 32 bytes");
 constexpr int BE_BLOCK = 1024;
 constexpr int BE_KEEP = 4;   // 64-path groups per wave whose counts stay in registers between the two passes
 __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __restrict__ bins, int n_paths,
+                                                              const int* __restrict__ plist,  // multi-GPU: the n_paths paths of this rank, ascending (else nullptr: all)
                                                               const int* __restrict__ bbox, const int* __restrict__ pb_cnt,
                                                               int* __restrict__ bseg_off, int rec_cap,
                                                               int* __restrict__ band_start, int* __restrict__ band_count,
@@ -833,6 +839,7 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
     // path w * chunk + g * 64 + l, so every load is coalesced and list order = (wave, group, lane).
     const int groups = (n_paths + BE_BLOCK - 1) / BE_BLOCK, chunk = groups * 64;
     const int p_wave = wave * chunk;
+    auto path_at = [&](int idx) { return plist ? plist[idx < n_paths ? idx : 0] : idx; };  // (n_paths = length of the list, if any)
     int kcnt[BE_KEEP], kpair[BE_KEEP];
     PathBin kb[BE_KEEP];
     int my_n = 0, my_r = 0;  // this lane's entries / record slots, over all its groups
@@ -842,7 +849,7 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
 #pragma unroll
         for (int g = 0; g < BE_KEEP; ++g) {
             const int p = p_wave + g * 64 + lane;
-            kb[g] = bins[g < groups && p < n_paths ? p : 0];
+            kb[g] = bins[g < groups && p < n_paths ? path_at(p) : 0];
         }
         bool member[BE_KEEP];
 #pragma unroll
@@ -865,7 +872,7 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p = p_wave + (g0 + j) * 64 + lane;
-            tb[j] = bins[g0 + j < groups && p < n_paths ? p : 0];
+            tb[j] = bins[g0 + j < groups && p < n_paths ? path_at(p) : 0];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -939,12 +946,12 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             place(kcnt[g + j], me[j], mr[j]);
-            const int p = p_wave + (g + j) * 64 + lane;
+            const int p = path_at(p_wave + (g + j) * 64 + lane);
             if (kcnt[g + j] > 0) bb[j] = ((const int4*)bbox)[p];
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            if (kcnt[g + j] > 0) store(p_wave + (g + j) * 64 + lane, kpair[g + j], kcnt[g + j], me[j], mr[j], bb[j], kb[g + j]);
+            if (kcnt[g + j] > 0) store(path_at(p_wave + (g + j) * 64 + lane), kpair[g + j], kcnt[g + j], me[j], mr[j], bb[j], kb[g + j]);
     }
     for (int g0 = BE_KEEP; g0 < groups; g0 += 4) {
         PathBin tb[4];
@@ -954,11 +961,11 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (g0 + j < groups) place(tcnt[j], me[j], mr[j]);  // (whole groups only: every lane of the wave scans)
-            bb[j] = tcnt[j] > 0 ? ((const int4*)bbox)[p_wave + (g0 + j) * 64 + lane] : make_int4(0, 0, 0, 0);
+            bb[j] = tcnt[j] > 0 ? ((const int4*)bbox)[path_at(p_wave + (g0 + j) * 64 + lane)] : make_int4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (tcnt[j] > 0) store(p_wave + (g0 + j) * 64 + lane, tpair[j], tcnt[j], me[j], mr[j], bb[j], tb[j]);
+            if (tcnt[j] > 0) store(path_at(p_wave + (g0 + j) * 64 + lane), tpair[j], tcnt[j], me[j], mr[j], bb[j], tb[j]);
     }
 }
 
@@ -2490,6 +2497,8 @@ struct svgr_batch {
     DevArr<int2> entry_where;               // per band-list entry: {band, index in the band's list}
     DevArr<int> seg_list;                   // multi-GPU: the segments this rank flattens (k_seg_select, at plan time)
     int64_t n_seg_list = -1;                // (-1: no list, every segment)
+    DevArr<int> path_list;                  // ... and the paths they belong to, ascending: what k_path_bbox / k_band_entries walk
+    int64_t n_path_list = 0;
     DevArr<int> chunks;                     // extra row chunks of long edges: edge | chunk << 27, in NSH shards (k_edge_count)
     int64_t n_chunks = 0;                   // slots of that list (sum of the shard capacities)
     // lay the chunk shards back to back with the given capacities
@@ -2551,7 +2560,7 @@ struct svgr_batch {
         bseg_off.release(); band_start.release(); band_count.release(); entries.release();
         path_group.release(); group_clip_src.release(); group_opacity.release();
         grads.release(); path_grad.release(); grad_path.release(); grad_flags.release();
-        edges.release(); bsegs.release(); cell_hdr.release(); entry_where.release(); tile_mask.release(); chunks.release(); seg_list.release(); layer_off.release();
+        edges.release(); bsegs.release(); cell_hdr.release(); entry_where.release(); tile_mask.release(); chunks.release(); seg_list.release(); path_list.release(); layer_off.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
         for (auto e : event_pool) (void)hipEventDestroy(e);
@@ -2575,6 +2584,8 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     const int n_items = listed ? (int)b->n_seg_list : ns;
     const dim3 fgrid = grid1((size_t)std::max(n_items, 1) << FL_SUB, FL_BLOCK);
     const int* seg_list = listed ? (const int*)b->seg_list.p : (const int*)nullptr;
+    const int* plist = listed ? (const int*)b->path_list.p : (const int*)nullptr;
+    const int np_walk = listed ? (int)b->n_path_list : np;  // paths k_path_bbox / k_band_entries walk
     const unsigned* prow = nullptr;
     if (use_vp && b->own.world > 1 && ns > 0 && !listed) {
         hipLaunchKernelGGL(k_path_rows, grid1((size_t)ns), dim3(256), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
@@ -2588,8 +2599,8 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                                b->thr, (double*)nullptr, (int*)nullptr, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
                                use_vp ? (b->vp[2] + TR - 1) / TR : 0, prow, seg_list, n_items);
         if (upto == 0)  // bboxes only (no edges stored): enough to find the union when there is no viewport
-            hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np,
-                               use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), 1);
+            hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(),
+                               np_walk, use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), 1, plist);
         return 0;
     }
     if (ns > 0)
@@ -2597,8 +2608,8 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                            (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
                            b->edges.p, b->edge_path.p, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
                            use_vp ? (b->vp[2] + TR - 1) / TR : 0, prow, seg_list, n_items);
-    hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np, use_vp ? 1 : 0,
-                       b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), b->planned ? 0 : 1);
+    hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np_walk,
+                       use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), b->planned ? 0 : 1, plist);
     if (upto == 2) return 0;
     const size_t ne = (size_t)std::max<int64_t>(b->n_edges, 1);
     hipLaunchKernelGGL(k_edge_count, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
@@ -2607,7 +2618,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     // per owned band: tile list + record blocks (upto == 3: sizes only, no headers written)
     const int owned = count_owned_bands(b->own, b->n_bands);
     if (owned > 0)
-        hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(BE_BLOCK), 0, st, (const PathBin*)b->bins.p, np,
+        hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(BE_BLOCK), 0, st, (const PathBin*)b->bins.p, np_walk, plist,
                            (const int*)b->bbox.p, (const int*)b->pb_cnt(), b->bseg_off.p,
                            upto >= 4 ? cap_i32(b->bsegs.cap) : 0x7fffffff, b->band_start.p, b->band_count.p, b->entries.p,
                            b->entry_where.p, cap_i32(std::min(b->entries.cap, b->entry_where.cap)), b->vp[1], b->bd(), b->own);
@@ -3128,10 +3139,30 @@ static int build_seg_list(svgr_batch* b) {
     hipLaunchKernelGGL(k_seg_select, grid1((size_t)ns), dim3(256), 0, st, (const int*)b->seg_path.p, ns, (const unsigned*)b->prow(), b->own,
                        b->vp[0], (b->vp[2] + TR - 1) / TR, b->seg_list.p, &b->bd()->edge_spare);
     int n = 0;
+    std::vector<unsigned> reach(2 * (size_t)b->n_paths);
     HIPCHK(hipMemcpyAsync(&n, &b->bd()->edge_spare, sizeof n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(reach.data(), b->prow(), sizeof(unsigned) * reach.size(), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     b->n_seg_list = n;
+    // the same test per path, in path = paint order (the band lists keep that order)
+    const int n_bands = (b->vp[2] + TR - 1) / TR, vr0 = b->vp[0];
+    std::vector<int> mine;
+    for (int64_t p = 0; p < b->n_paths; ++p) {
+        if (reach[2 * (size_t)p] == 0u) continue;  // (no segment)
+        const int lo = UNION_BIAS - (int)reach[2 * (size_t)p], hi = (int)reach[2 * (size_t)p + 1] - UNION_BIAS;
+        int ba = (lo - 2 - vr0) / TR, bb = (hi + 2 - vr0) / TR;
+        ba = lo - 2 - vr0 < 0 ? 0 : ba;
+        bb = bb > n_bands - 1 ? n_bands - 1 : bb;
+        if (ba <= bb && owns_any(b->own, ba, bb)) mine.push_back((int)p);
+    }
+    b->n_path_list = (int64_t)mine.size();
+    if (int rc = b->path_list.ensure(mine.size() + 1)) return rc;
+    if (!mine.empty()) HIPCHK(hipMemcpyAsync(b->path_list.p, mine.data(), sizeof(int) * mine.size(), hipMemcpyHostToDevice, st));
+    // the paths that are not on the list keep an empty bbox and no bands for good
+    HIPCHK(hipMemsetAsync(b->bbox.p, 0, sizeof(int) * 4 * (size_t)b->n_paths, st));
+    HIPCHK(hipMemsetAsync(b->bins.p, 0, sizeof(PathBin) * (size_t)b->n_paths, st));
+    HIPCHK(hipStreamSynchronize(st));  // (`mine` is a host vector of this call)
     return 0;
 }
 
