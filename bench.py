@@ -353,7 +353,9 @@ def main():
     sc, desc = load_workload(args.workload)
     rows, cols = int(sc["viewport"][2]), int(sc["viewport"][3])
     n_scene_paths = int(len(sc["path_seg_off"]) - 1)
-    strip = int(os.environ.get("SVGR_STRIP_BANDS", str(max(1, 128 // _abi.tile_rows()))))  # 128 scanlines per strip
+    from svgrasterize_amd import dist as sdist_
+
+    strip = int(os.environ.get("SVGR_STRIP_BANDS", str(sdist_.default_strip_bands(rows, _abi.tile_rows(), world))))  # two strips per rank
 
     # ---- headline: the ONE scene; N > 1: its rows sharded over the ranks (strong scaling) -----------------------------
     batch = new_batch(sc)

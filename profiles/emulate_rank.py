@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--all", action="store_true")
-    ap.add_argument("--strip", type=int, default=int(os.environ.get("SVGR_STRIP_BANDS", "0")), help="bands per strip (0: 128 rows)")
+    ap.add_argument("--strip", type=int, default=int(os.environ.get("SVGR_STRIP_BANDS", "0")), help="bands per strip (0: bench.py's default)")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--workload", default="synth4096")
     ap.add_argument("--timed", action="store_true")
@@ -36,9 +36,11 @@ def main():
     from svgrasterize_amd import _abi
 
     ctx = S.Context.get(0)
-    if args.strip <= 0:
-        args.strip = max(1, 128 // _abi.tile_rows())
     sc, _ = bench.load_workload(args.workload)
+    if args.strip <= 0:
+        from svgrasterize_amd import dist as sdist
+
+        args.strip = sdist.default_strip_bands(int(sc["viewport"][2]), _abi.tile_rows(), args.world)
     cols = int(sc["viewport"][3])
     batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
                        viewport=sc["viewport"])

@@ -16,6 +16,13 @@ def n_bands(rows: int, tile_rows: int) -> int:
     return (rows + tile_rows - 1) // tile_rows
 
 
+def default_strip_bands(rows: int, tile_rows: int, world: int) -> int:
+    """Bands per strip when the caller does not choose: two strips per rank (a rank flattens every path that reaches one of
+    its strips, so fewer, taller strips duplicate less geometry; two of them still interleave the ranks over the canvas),
+    never less than 128 scanlines."""
+    return max(max(1, 128 // tile_rows), n_bands(rows, tile_rows) // (2 * max(world, 1)))
+
+
 def owned_bands(rows: int, tile_rows: int, rank: int, world: int, strip: int = 1) -> list[int]:
     """Bands of rank `rank`: the strips s (of `strip` consecutive bands) with s % world == rank."""
     return [b for b in range(n_bands(rows, tile_rows)) if (b // strip) % world == rank]
