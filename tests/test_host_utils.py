@@ -104,3 +104,49 @@ def test_default_strip_bands_two_strips_per_rank():
         strip = sdist.default_strip_bands(rows, 16, world)
         owners = [sum(b in sdist.owned_bands(rows, 16, r, world, strip) for r in range(world)) for b in range(sdist.n_bands(rows, 16))]
         assert owners == [1] * sdist.n_bands(rows, 16)
+
+
+def test_batch_routing_of_scene_nodes_is_host_logic():
+    """Which Scene nodes become entries of ONE device batch (scene._batchable_leaves) and how a run is tidied before it is
+    packed (effective_bboxes, _drop_empty): plain host logic, checked without a GPU."""
+    import svgrasterize_amd as S
+    from svgrasterize_amd import scene as sc
+
+    sq = lambda x, y, w: S.Path.from_svg(f"M{x},{y} h{w} v{w} h{-w} Z")
+    red, blue = np.array([0.5, 0.0, 0.0, 0.5]), np.array([0.0, 0.0, 1.0, 1.0])
+    lin = S.GradLinear(np.array([0.0, 0.0]), np.array([10.0, 0.0]), [(0.0, red), (1.0, blue)], None, "pad", False, None)
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    fill = S.Scene.fill
+    # plain leaves, an opacity over a leaf, a gradient leaf: one entry each; the opacity lands in the paint / the multiplier
+    leaves = sc._batchable_leaves(S.Scene.group([fill(sq(0, 0, 4), red), fill(sq(2, 2, 4), blue).opacity(0.5), fill(sq(1, 1, 3), lin).opacity(0.25)]), tr, True)
+    assert [l[4] for l in leaves] == [0, 0, 0] and [l[5] for l in leaves] == [None] * 3
+    assert np.allclose(leaves[1][3], blue * 0.5) and leaves[0][6] is None and leaves[1][6] is None
+    assert leaves[2][6] is not None and np.allclose(leaves[2][3], 0.25) and leaves[2][6][0].kind == 1
+    # CLIP of a single leaf: clip source + clipped entry; CLIP / OPACITY over a group: members tagged with one group
+    one = sc._batchable_leaves(fill(sq(0, 0, 8), red).clip(fill(sq(2, 2, 3), blue)), tr, True)
+    assert [l[4] for l in one] == [1, 2] and one[1][5] is None
+    grp = S.Scene.group([fill(sq(0, 0, 8), red), fill(sq(1, 1, 2), lin)])
+    clipped = sc._batchable_leaves(grp.clip(fill(sq(2, 2, 3), blue)), tr, True)
+    assert [l[4] for l in clipped] == [1, 0, 0] and clipped[1][5] is clipped[2][5] and clipped[1][5][1:] == (1.0, True)
+    faded = sc._batchable_leaves(grp.opacity(0.3), tr, True)
+    assert [l[4] for l in faded] == [0, 0] and faded[0][5] is faded[1][5] and faded[0][5][1:] == (0.3, False)
+    # what stays on the per-node route
+    bbox_grad = S.GradLinear(np.array([0.0, 0.0]), np.array([1.0, 0.0]), [(0.0, red), (1.0, blue)], None, "pad", True, None)
+    for node in (fill(sq(0, 0, 4), bbox_grad),                                           # objectBoundingBox gradient
+                 S.Scene.group([grp.opacity(0.5), fill(sq(0, 0, 2), red)]).opacity(0.5),  # a group inside a group's opacity
+                 grp.clip(S.Scene.group([fill(sq(0, 0, 2), red), fill(sq(1, 1, 2), red)])),  # a clip that is not one path
+                 fill(sq(0, 0, 4), red).clip(fill(sq(0, 0, 2), red), bbox_units=True)):
+        assert sc._batchable_leaves(node, tr, True) is None
+    with pytest.raises(ValueError):
+        sc._batchable_leaves(fill(sq(0, 0, 4), red, "winding"), tr, True)
+    # effective bboxes: a clipped fill / a member of a clipped group is cut to the clip's bbox; an empty clip hides them
+    run = clipped + one
+    boxes = [(2, 2, 3, 3), (0, 0, 8, 8), (1, 1, 2, 2), (10, 10, 0, 0), (0, 0, 8, 8)]
+    assert sc.effective_bboxes(run, boxes) == [(2, 2, 3, 3), (2, 2, 1, 1), None]
+    # leaves without segments go, and a clip source goes with everything it clips (and the other way round)
+    empty = S.Path([])
+    tag = clipped[1][5]
+    run = [sc._leaf(empty, tr.m6(), 0, np.zeros(4), 1), sc._leaf(sq(0, 0, 2), tr.m6(), 0, red, 0, tag), sc._leaf(sq(0, 0, 3), tr.m6(), 0, red),
+           sc._leaf(sq(0, 0, 2), tr.m6(), 0, np.zeros(4), 1), sc._leaf(empty, tr.m6(), 0, red, 2), sc._leaf(empty, tr.m6(), 0, red)]
+    kept = sc._drop_empty(run)
+    assert len(kept) == 1 and kept[0] is run[2]
