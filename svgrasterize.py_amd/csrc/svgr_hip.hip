@@ -1177,47 +1177,56 @@ __device__ __forceinline__ bool carry_visible(double c, int rule) {
 // column tiles x 16 rows at a time, with the running sum.  Pairs wider than PC_CT column tiles take several passes
 // over their records.  (TR = 16: four column tiles per step.)  (A persistent, software-pipelined form of this kernel was slower: it is instruction bound, not
 // latency bound -- 46 000 short waves hide their own load chains.)
-constexpr int PC_CT = 32;
+constexpr int PC_CT = 16;      // column tiles of a pair per pass
 constexpr int PC_BLOCK = 256;
-static_assert(64 % TR == 0, "k_pair_cells walks 64 / TR column tiles per step");
+constexpr int PC_LANES = 32;   // lanes per pair: TWO pairs per wave.  The kernel is a chain of dependent loads per pair (entry ->
+                               // records / paint -> stores) that 46 000 one-pair waves ran seven rounds deep; half as many waves
+                               // with the same chain each halve the rounds (45 -> see DESIGN section 3)
+static_assert(PC_LANES % TR == 0, "k_pair_cells walks PC_LANES / TR column tiles per step");
 __global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __restrict__ entries, const int2* __restrict__ entry_where,
                                                         const RowRec* __restrict__ recs, const double* __restrict__ path_paint,
                                                         const uint8_t* __restrict__ path_rule, const int* __restrict__ path_group,
                                                         const int* __restrict__ path_grad, int vc0, int n_ct, int mask_words,
                                                         unsigned long long* __restrict__ tile_mask, CellHdr* __restrict__ cell_hdr,
                                                         int cell_cap, BatchDev* __restrict__ bd) {
-    constexpr int NWV = PC_BLOCK / 64;
-    __shared__ double s_sum[NWV][PC_CT][TR];
-    __shared__ int s_cnt[NWV][PC_CT];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int e = blockIdx.x * NWV + wave;
-    const TileEntry en = entries[e];      // (both arrays hold the whole grid: loaded before the bound is known)
+    constexpr int PPW = 64 / PC_LANES, NSLOT = PC_BLOCK / PC_LANES, KSTEP = PC_LANES / TR;
+    __shared__ double s_sum[NSLOT][PC_CT][TR];
+    __shared__ int s_cnt[NSLOT][PC_CT];
+    const int lane = threadIdx.x & 63, hl = lane & (PC_LANES - 1), half = lane / PC_LANES;
+    const int slot = threadIdx.x / PC_LANES;                  // this pair's table in LDS
+    const int e = blockIdx.x * NSLOT + slot;
+    TileEntry en = entries[e];            // (both arrays hold the whole grid: loaded before the bound is known)
     const int2 where = entry_where[e];    // {band, index in the band's list}
-    if (e >= bd->entry_cursor) return;    // (waves are independent: no workgroup barrier below)
-    int ct0, nct;
-    path_ctiles(en.c0, en.cols, vc0, ct0, nct);
+    bool active = e < bd->entry_cursor;   // (pairs are independent: no workgroup barrier below, only wave-level ones)
+    if (active && (where.y >> 6) >= mask_words) {  // (the plan sized the masks from the longest band list)
+        if (hl == 0) atomicOr(&bd->err, 32);
+        active = false;
+    }
+    int ct0 = 0, nct = 0;
+    if (active) path_ctiles(en.c0, en.cols, vc0, ct0, nct);
+    else en.cnt = 0;
     // the tiles' entry bitmasks: per (band, column tile) two rows of mask_words words, bit i = entry i of the band's list
     // has a cell of class >= 1 (row 0) / class 2 (row 1) here.  Classes 0 simply stay unset.
-    unsigned long long* const mrow = tile_mask + ((size_t)where.x * n_ct + ct0) * 2 * mask_words + (where.y >> 6);
+    unsigned long long* const mrow = tile_mask + ((size_t)(active ? where.x : 0) * n_ct + ct0) * 2 * mask_words + (active ? where.y >> 6 : 0);
     const unsigned long long mbit = 1ull << (where.y & 63);
-    if ((where.y >> 6) >= mask_words) {  // (the plan sized the masks from the longest band list)
-        if (lane == 0) atomicOr(&bd->err, 32);
-        return;
-    }
     const int x_first = vc0 + ct0 * TC - en.c0;  // layer column where the path's first column tile starts (<= 0)
-    const int rl = path_rule[en.p], rule = rl & 1;
-    const int group = path_group ? path_group[en.p] : -1;
-    const int grad1 = path_grad ? path_grad[en.p] + 1 : 0;  // gradient index + 1 (0: solid colour)
-    const double4 paint = ((const double4*)path_paint)[en.p];
-    const int row_l = lane & (TR - 1), sub = lane / TR;  // this lane's row and its column tile of the four walked per step
+    const int pth = active ? en.p : 0;
+    const int rl = path_rule[pth], rule = rl & 1;
+    const int group = path_group ? path_group[pth] : -1;
+    const int grad1 = path_grad ? path_grad[pth] + 1 : 0;  // gradient index + 1 (0: solid colour)
+    const double4 paint = ((const double4*)path_paint)[pth];
+    const int row_l = hl & (TR - 1), sub = hl / TR;  // this lane's row and its column tile of the KSTEP walked per step
     double run = 0.0;  // the row's running sum left of the column tiles walked so far
-    for (int base = 0; base < nct; base += PC_CT) {
-        const int nc = nct - base < PC_CT ? nct - base : PC_CT;
-        for (int i = lane; i < nc * TR; i += 64) (&s_sum[wave][0][0])[i] = 0.0;
-        if (lane < nc) s_cnt[wave][lane] = 0;
+    // (the two pairs of a wave may need different numbers of passes: the wave-level barriers are reached by both halves)
+    const int nct_w = max(__builtin_amdgcn_readlane(nct, 0), __builtin_amdgcn_readlane(nct, PC_LANES % 64));
+    for (int base = 0; base < nct_w; base += PC_CT) {
+        int nc = nct - base < PC_CT ? nct - base : PC_CT;
+        nc = nc > 0 ? nc : 0;
+        for (int i = hl; i < nc * TR; i += PC_LANES) (&s_sum[slot][0][0])[i] = 0.0;
+        if (hl < nc) s_cnt[slot][hl] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int j = lane; j < en.cnt; j += 64) {
+        for (int j = hl; j < (nc > 0 ? en.cnt : 0); j += PC_LANES) {
             const RowRec* r = recs + en.seg0 + j;
             const int4 h = *(const int4*)r;  // {x0i, nrow, v0 lo, v0 hi}
             const double2 w0 = *(const double2*)((const char*)r + 16), w1 = *(const double2*)((const char*)r + 32);
@@ -1236,8 +1245,8 @@ __global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __r
                     double sum = v[0] + v[1];
                     if (n >= 3) sum = sum + (double)(n - 3) * v[2] + v[3];
                     if (n >= 2) sum = sum + v[4];
-                    __hip_atomic_fetch_add(&s_sum[wave][kf][row], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&s_cnt[wave][kf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&s_sum[slot][kf][row], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&s_cnt[slot][kf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 continue;
             }
@@ -1248,32 +1257,30 @@ __global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __r
                 ca = ca > 0 ? ca : 0;
                 cb = cb < en.cols ? cb : en.cols;
                 const double part = record_sum_range(x0i, n, v, ca, cb);
-                __hip_atomic_fetch_add(&s_sum[wave][k][row], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&s_cnt[wave][k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_sum[slot][k][row], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_cnt[slot][k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // four column tiles per step: lane (sub, row) takes column tile k4 + sub; its carry-in = run + the sums of the
-        // column tiles of this step to its left (read back from the table: at most three)
-        for (int k4 = 0; k4 < nc; k4 += 64 / TR) {
+        // KSTEP column tiles per step: lane (sub, row) takes column tile k4 + sub; its carry-in = run + the sums of the
+        // column tiles of this step to its left (read back from the table)
+        for (int k4 = 0; k4 < nc; k4 += KSTEP) {
             const int k = k4 + sub;
-            double mine = 0.0, left = 0.0, all = 0.0;
+            double left = 0.0, all = 0.0;
 #pragma unroll
-            for (int q = 0; q < 64 / TR; ++q) {
-                const double sq = k4 + q < nc ? s_sum[wave][k4 + q][row_l] : 0.0;
+            for (int q = 0; q < KSTEP; ++q) {
+                const double sq = k4 + q < nc ? s_sum[slot][k4 + q][row_l] : 0.0;
                 left = q < sub ? left + sq : left;
                 all = all + sq;
-                mine = q == sub ? sq : mine;
             }
-            (void)mine;
             const double cin = run + left;
             const bool live = k < nc;
-            const int own = live ? s_cnt[wave][k] : 0;
+            const int own = live ? s_cnt[slot][k] : 0;
             const bool vis = live && carry_visible(cin, rule);
-            const unsigned long long vm = __ballot(vis);
-            const unsigned long long rows_of_tile = TR == 64 ? ~0ull : ((1ull << (TR & 63)) - 1ull) << ((sub * TR) & 63);
+            const unsigned long long vm = __ballot(vis);  // (lanes of the other pair may be masked off here: their bits are 0)
+            const unsigned long long rows_of_tile = ((1ull << TR) - 1ull) << (half * PC_LANES + sub * TR);
             const int cls = own > 0 ? 2 : ((vm & rows_of_tile) != 0ull ? 1 : 0);
             const int cell = en.cell0 + base + k;
             if (live && cls != 0) {
@@ -1294,6 +1301,7 @@ __global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __r
             run = run + all;
         }
     }
+    (void)PPW;
 }
 
 // --------------------------------------------------------------------------------------
@@ -2636,7 +2644,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     }
     if (b->n_entries > 0) {
         b->masks_zeroed = false;  // (bits are set below; the tile kernel clears them again)
-        hipLaunchKernelGGL(k_pair_cells, grid1((size_t)b->n_entries * 64, PC_BLOCK), dim3(PC_BLOCK), 0, st,
+        hipLaunchKernelGGL(k_pair_cells, grid1((size_t)b->n_entries * PC_LANES, PC_BLOCK), dim3(PC_BLOCK), 0, st,
                            (const TileEntry*)b->entries.p, (const int2*)b->entry_where.p, (const RowRec*)b->bsegs.p,
                            (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p,
                            b->n_groups > 0 ? (const int*)b->path_group.p : (const int*)nullptr,
