@@ -85,6 +85,13 @@ constexpr int NW = NT / 64;                // waves per workgroup
 #ifndef SVGR_TOUCH
 #define SVGR_TOUCH 0                    // 1: warm L2 with the lines of the item after next while the next one's DMA is in flight
 #endif                                  //    (measured on synth4096: tile kernel 0.209 -> 0.219 ms, so off: the wait is not an L2 miss)
+#ifndef SVGR_XCC_MAP
+#define SVGR_XCC_MAP 1                  // tile order per XCD: consecutive tiles to one XCD (0: tile = workgroup id, dealt round-robin)
+#endif
+#ifndef SVGR_TPW
+#define SVGR_TPW 1                      // tiles per workgroup (consecutive tiles of a band, worked off one after the other)
+#endif
+constexpr unsigned TPW = SVGR_TPW;
 #ifndef SVGR_CLASS1
 #define SVGR_CLASS1 1                   // constant-coverage cells take the composite-only path (0: through scatter + scan)
 #endif
@@ -1450,6 +1457,7 @@ struct TileArgs {
     const int* band_start;     // per band: first entry of its list
     unsigned long long* tile_mask;  // per (band, column tile): which entries of the band's list have a visible cell here
     int mask_words, n_ct;           // (k_pair_cells); each tile reads its words and clears them for the next render
+    int n_bands;                    // owned bands: the launch covers n_ct x n_bands tiles
     const TileEntry* entries;  // per band: the pairs with records, ascending path id
     const RowRec* bsegs;       // record blocks: per (path, band) pair its edge-row records
     const CellHdr* cell_hdr;        // per (pair, column tile) cell of class 1 or 2: paint, fill rule, carry-in of every tile row
@@ -1503,11 +1511,25 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     // LDS address of s_mem, once, as a scalar (the cast from the generic pointer carries a null test and a 64-bit lane value)
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)s_mem);
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // Workgroup -> tile, XCD-aware: the hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own
+    // L2), so workgroups w, w + 8, w + 16 ... -- one XCD -- take CONSECUTIVE tiles: the column tiles of a band, which read
+    // the same (path, band) record blocks, then meet in one L2 instead of fetching a block once per XCD.
+    const unsigned wg_lin = blockIdx.x, n_tiles = (unsigned)a.n_ct * (unsigned)a.n_bands;
+    const unsigned per_xcc = (((n_tiles + 7u) >> 3) + TPW - 1u) / TPW * TPW;  // tiles of one XCD's share, whole workgroups
+    for (unsigned tt = 0; tt < TPW; ++tt) {  // TPW consecutive tiles per workgroup, one after the other
+    const unsigned t_lin = SVGR_XCC_MAP ? (wg_lin & 7u) * per_xcc + (wg_lin >> 3) * TPW + tt : wg_lin * TPW + tt;
+    if (t_lin >= n_tiles) break;  // (the grid is rounded up)
+    const int by = __builtin_amdgcn_readfirstlane((int)(t_lin / (unsigned)a.n_ct));
+    const int bx = (int)t_lin - by * a.n_ct;
+    int tid_ = (int)threadIdx.x;
+    if (TPW > 1) asm volatile("" : "+v"(tid_));  // (per tile: nothing derived from the thread id stays live across tiles)
+    const int tid = tid_, wave = tid >> 6, lane = tid & 63;
     const int trow = tid / CH, chunk = tid % CH;
-    const int band = owned_band_at(a.own, (int)blockIdx.y);
+    const int band = owned_band_at(a.own, by);
+    clip_tag = -1;
+    if (tt) __syncthreads();  // (the previous tile's last LDS reads)
     const int tile_r0 = a.vr0 + band * TR;             // absolute row of tile row 0
-    const int tile_c0 = a.vc0 + (int)blockIdx.x * TC;  // absolute column of tile column 0
+    const int tile_c0 = a.vc0 + bx * TC;  // absolute column of tile column 0
     const int tile_c1 = tile_c0 + TC;
 
     double acc[PX][4];
@@ -1516,6 +1538,10 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
 #ifdef SVGR_DBG_STAMP
     unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tstart_ = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef SVGR_DBG_TIMELINE
+    const unsigned long long tl_start_ = __builtin_amdgcn_s_memrealtime();
+    int tl_items_ = 0;
 #endif
     // Isolated groups: while one is open its members composite into `gacc`; when an item of another group (or of none)
     // arrives, or the tile's list ends, the group is closed: multiplied by the coverage of its clip path (the clip tile, if
@@ -1547,7 +1573,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     for (int i = tid; i < TR * ROW_STRIDE; i += NT) s_trace[i] = 0.0;
     __syncthreads();
     if (a.arena_words) {  // nothing in this kernel reads the arena; the geometry kernels that did are finished
-        const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x, n_wg = gridDim.x * gridDim.y;
+        const unsigned wg = t_lin, n_wg = n_tiles;
         for (unsigned i = 1 + wg * NT + tid; i < a.arena_words; i += n_wg * NT) a.arena[i] = 0u;
     }
 
@@ -1555,7 +1581,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     // the words (one per lane) and ranks them by a wave scan, so that no workgroup barrier is needed to place the items;
     // a wave then moves the hits of its own words to the LDS lists, LCAP items per round (one round for most tiles).
     const int W = a.mask_words;
-    unsigned long long* const mw = a.tile_mask + ((size_t)band * a.n_ct + blockIdx.x) * 2 * W;
+    unsigned long long* const mw = a.tile_mask + ((size_t)band * a.n_ct + bx) * 2 * W;
     const int ent_begin = a.band_start[band];
     for (int w0 = 0; w0 < W; w0 += 64) {
         const int nw = W - w0 < 64 ? W - w0 : 64;
@@ -1578,7 +1604,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
             if (((mword >> lane) & 1ull) && at >= 0 && at < take) {
                 const TileEntry e = a.entries[ent_begin + (w0 + wi) * 64 + lane];  // one 32-byte load per hit
                 const unsigned cls = ((mw[W + w0 + wi] >> lane) & 1ull) ? 2u : 1u;
-                const int cell = e.cell0 + (int)blockIdx.x - (e.c0 - a.vc0) / TC;
+                const int cell = e.cell0 + bx - (e.c0 - a.vc0) / TC;
                 s_list[at] = e.p;
                 s_seg0[at] = e.seg0;
                 s_seg1[at] = cls == 2u && cell < a.cell_cap ? e.seg0 + e.cnt : e.seg0;  // (class 1: no record reaches the tile)
@@ -1590,6 +1616,9 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
         const int total = 0;  // diagnostic: the tile's fixed cost alone (lists are built, nothing is drawn)
 #else
         const int total = take;
+#endif
+#ifdef SVGR_DBG_TIMELINE
+        tl_items_ += total;
 #endif
         __syncthreads();
 
@@ -2024,15 +2053,29 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
         atomicAdd(&a.dbg[7], 1ull);
     }
 #endif
+#ifdef SVGR_DBG_TIMELINE
+    // per workgroup {start, end, items, XCC | hardware id} on the 100 MHz clock (profiles/timeline.py)
+    if (tid == 0 && a.dbg) {
+        const unsigned wg_ = t_lin;
+        if (wg_ < (1u << 16)) {
+            unsigned hwid_, xcc_;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid_));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+            unsigned long long* t_ = a.dbg + 8 + 4 * (size_t)wg_;
+            t_[0] = tl_start_; t_[1] = __builtin_amdgcn_s_memrealtime(); t_[2] = (unsigned long long)tl_items_;
+            t_[3] = ((unsigned long long)xcc_ << 32) | hwid_;
+        }
+    }
+#endif
     if (OUT <= 1) {
         const int row = band * TR + trow;  // viewport-local row
-        const int out_row = (int)blockIdx.y * TR + trow;
+        const int out_row = by * TR + trow;
         if (row < a.vrows) {
             // (the lane's chunk is recomputed from the thread id here: kept live across the main loop it costs a VGPR
             // that the register budget does not have, i.e. a scratch spill in every workgroup)
             int tid2 = (int)threadIdx.x;
             asm volatile("" : "+v"(tid2));
-            const int col0 = (int)blockIdx.x * TC + (tid2 % CH) * PX;
+            const int col0 = bx * TC + (tid2 % CH) * PX;
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
                 if (col0 + i < a.vcols) {
@@ -2054,6 +2097,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
             }
         }
     }
+    }  // tiles of this workgroup
 }
 
 // ======================================================================================
@@ -3473,7 +3517,24 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
             (void)hipMemset(dbg_buf, 0, 64);
         }
 #endif
-        dim3 grid((unsigned)n_ctiles, (unsigned)owned_bands);
+#ifdef SVGR_DBG_TIMELINE
+        {
+            // the PREVIOUS render's per-workgroup timeline goes to the file $SVGR_DBG_TIMELINE (raw u64 quadruples)
+            static unsigned long long* tl_buf = nullptr;
+            const size_t tl_bytes = 64 + 32 * (size_t)(1u << 16);
+            HIPCHK(hipStreamSynchronize(st));
+            if (!tl_buf) { (void)hipMalloc((void**)&tl_buf, tl_bytes); (void)hipMemset(tl_buf, 0, tl_bytes); }
+            else if (getenv("SVGR_DBG_TIMELINE")) {
+                std::vector<unsigned long long> tl(tl_bytes / 8);
+                (void)hipMemcpy(tl.data(), tl_buf, tl_bytes, hipMemcpyDeviceToHost);
+                if (FILE* f = fopen(getenv("SVGR_DBG_TIMELINE"), "wb")) { fwrite(tl.data(), 1, tl_bytes, f); fclose(f); }
+            }
+            a.dbg = tl_buf;
+        }
+#endif
+        a.n_bands = owned_bands;
+        const unsigned n_tiles_ = (unsigned)n_ctiles * (unsigned)owned_bands;
+        dim3 grid(8u * ((((n_tiles_ + 7u) >> 3) + TPW - 1u) / TPW));
         static const int dyn_lds = getenv("SVGR_DBG_DYNLDS") ? atoi(getenv("SVGR_DBG_DYNLDS")) : 0;  // occupancy experiments
         switch (out_kind) {
             case 0:

@@ -524,6 +524,9 @@ class MaskPrefetch:
             seen.add(key)
             todo.append((key, path, transform, rule))
         self.n_jobs = len(todo)
+        # the table is keyed by id(path): hold the paths for as long as the table lives, so that the id of a path that
+        # was dropped cannot come back as another path's
+        self._paths = [t[1] for t in todo]
         if not todo:
             return
         segs, kinds, offs, m6s, rules = [], [], [0], [], []
