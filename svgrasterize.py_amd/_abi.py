@@ -241,6 +241,12 @@ def _i64x4(v):
     return (C.c_int64 * 4)(*[int(x) for x in v])
 
 
+def ptr(arr) -> int:
+    """Address of a numpy array's data (``arr.ctypes`` builds a helper object on every access: 4 us that add up over a
+    scene's hundreds of small arrays)."""
+    return arr.__array_interface__["data"][0]
+
+
 class Batch:
     """svgr_batch: a paint-ordered list of paths resident in HBM."""
 
@@ -258,14 +264,14 @@ class Batch:
         if len(seg_kind) != len(segs) or len(path_m6) != n_paths or len(path_rule) != n_paths or len(path_paint) != n_paths:
             raise ValueError("inconsistent batch arrays")
         d = BatchDesc()
-        d.segs = segs.ctypes.data
-        d.seg_kind = seg_kind.ctypes.data
+        d.segs = ptr(segs)
+        d.seg_kind = ptr(seg_kind)
         d.n_segs = len(segs)
-        d.path_seg_off = path_seg_off.ctypes.data
+        d.path_seg_off = ptr(path_seg_off)
         d.n_paths = n_paths
-        d.path_m6 = path_m6.ctypes.data
-        d.path_rule = path_rule.ctypes.data
-        d.path_paint = path_paint.ctypes.data
+        d.path_m6 = ptr(path_m6)
+        d.path_rule = ptr(path_rule)
+        d.path_paint = ptr(path_paint)
         d.viewport = _i64x4(viewport if viewport is not None else (0, 0, 0, 0))
         d.flatness = flatness
         h = _P()
@@ -326,7 +332,7 @@ class Batch:
         op = np.ascontiguousarray(group_opacity, dtype=np.float64).reshape(-1)
         if len(cs) != len(op):
             raise ValueError("one clip source and one opacity per group")
-        _check(self.ctx.lib.svgr_batch_set_groups(self.handle, pg.ctypes.data_as(_P), len(cs), cs.ctypes.data_as(_P), op.ctypes.data_as(_P)))
+        _check(self.ctx.lib.svgr_batch_set_groups(self.handle, C.c_void_p(ptr(pg)), len(cs), C.c_void_p(ptr(cs)), C.c_void_p(ptr(op))))
         self._stats = None
 
     def set_gradients(self, path_grad, grads):
@@ -334,7 +340,7 @@ class Batch:
         gradient-filled path) or -1; see svgr_batch_set_gradients.  Call before plan()."""
         pg = np.ascontiguousarray(path_grad, dtype=np.int32).reshape(self.n_paths)
         arr = (Gradient * max(len(grads), 1))(*grads)
-        _check(self.ctx.lib.svgr_batch_set_gradients(self.handle, pg.ctypes.data_as(_P), len(grads), C.cast(arr, _P)))
+        _check(self.ctx.lib.svgr_batch_set_gradients(self.handle, C.c_void_p(ptr(pg)), len(grads), C.cast(arr, _P)))
         self._stats = None
 
     def set_paints(self, paints):

@@ -89,7 +89,8 @@ constexpr int NW = NT / 64;                // waves per workgroup
 #define SVGR_XCC_MAP 1                  // tile order per XCD: consecutive tiles to one XCD (0: tile = workgroup id, dealt round-robin)
 #endif
 #ifndef SVGR_TPW
-#define SVGR_TPW 1                      // tiles per workgroup (consecutive tiles of a band, worked off one after the other)
+#define SVGR_TPW 1                      // tiles per workgroup (consecutive tiles of a band, one after the other).  Measured on synth4096:
+                                        // 2 -> 0.245 ms, 4 -> 0.276 ms against 0.209: longer workgroups lengthen the tail
 #endif
 constexpr unsigned TPW = SVGR_TPW;
 #ifndef SVGR_CLASS1
@@ -1872,44 +1873,49 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
 #endif
                 double* my = s_trace + trow * ROW_STRIDE + chunk * CHUNK_STRIDE;
                 double t[PX];
+                double run = 0.0;
                 if (fast1) {
+                    // the row's winding is its carry-in on the layer's columns inside the tile and 0 elsewhere: no delta
+                    // tile, no prefix sum -- t[] gets the winding itself (already folded for evenodd)
                     const double cin = blk_carry[trow];
-                    const int d0 = lo_c + col_shift - chunk * PX, d1 = hi_c + col_shift - chunk * PX;  // (d1 == TC - ..: no lane)
+                    const double wnd = rule ? fill_evenodd_raw(cin) : cin;
+                    int lo_i = lo_c + col_shift - chunk * PX, hi_i = hi_c + col_shift - chunk * PX;
+                    lo_i = lo_i < 0 ? 0 : lo_i;
+                    hi_i = hi_i > PX ? PX : hi_i;
 #pragma unroll
-                    for (int i = 0; i < PX; ++i) t[i] = d0 == i ? cin : (d1 == i ? -cin : 0.0);
+                    for (int i = 0; i < PX; ++i) t[i] = i >= lo_i && i < hi_i ? wnd : 0.0;
                 } else {
 #pragma unroll
                     for (int i = 0; i < PX; ++i) t[i] = my[i];
 #pragma unroll
                     for (int i = 0; i < PX; ++i) my[i] = 0.0;
-                }
-                double tot = t[0];
+                    double tot = t[0];
 #pragma unroll
-                for (int i = 1; i < PX; ++i) tot += t[i];
-                double inc = tot;  // inclusive scan of the CH chunk totals of this tile row
-                double run;
-                if (CH <= 8) {
-                    // a 16-lane DPP row holds 16 / CH tile rows: a shift must not carry a value across their borders
-                    const int lc = lane & (CH - 1);
-                    double v;
-                    v = dpp_row_shr<1>(inc); inc += lc >= 1 ? v : 0.0;
-                    v = dpp_row_shr<2>(inc); inc += lc >= 2 ? v : 0.0;
-                    if (CH == 8) { v = dpp_row_shr<4>(inc); inc += lc >= 4 ? v : 0.0; }
-                    v = dpp_row_shr<1>(inc);
-                    run = lc >= 1 ? v : 0.0;  // exclusive: everything left of this chunk
-                } else {
-                    inc += dpp_row_shr<1>(inc);
-                    inc += dpp_row_shr<2>(inc);
-                    inc += dpp_row_shr<4>(inc);
-                    inc += dpp_row_shr<8>(inc);
-                    if (CH == 16) {
-                        run = dpp_row_shr<1>(inc);  // exclusive: everything left of this chunk
+                    for (int i = 1; i < PX; ++i) tot += t[i];
+                    double inc = tot;  // inclusive scan of the CH chunk totals of this tile row
+                    if (CH <= 8) {
+                        // a 16-lane DPP row holds 16 / CH tile rows: a shift must not carry a value across their borders
+                        const int lc = lane & (CH - 1);
+                        double v;
+                        v = dpp_row_shr<1>(inc); inc += lc >= 1 ? v : 0.0;
+                        v = dpp_row_shr<2>(inc); inc += lc >= 2 ? v : 0.0;
+                        if (CH == 8) { v = dpp_row_shr<4>(inc); inc += lc >= 4 ? v : 0.0; }
+                        v = dpp_row_shr<1>(inc);
+                        run = lc >= 1 ? v : 0.0;  // exclusive: everything left of this chunk
                     } else {
-                        // a tile row is two DPP rows: add the lower row's total (its lane 15) to the upper row,
-                        // then shift by one lane across the pair; the first lane of a tile row starts at 0
-                        inc += dpp_ctrl<0x142, 0xA>(inc);   // row_bcast:15 into DPP rows 1 and 3
-                        run = dpp_ctrl<0x138, 0xF>(inc);    // wave_shr:1
-                        if ((lane & 31) == 0) run = 0.0;
+                        inc += dpp_row_shr<1>(inc);
+                        inc += dpp_row_shr<2>(inc);
+                        inc += dpp_row_shr<4>(inc);
+                        inc += dpp_row_shr<8>(inc);
+                        if (CH == 16) {
+                            run = dpp_row_shr<1>(inc);  // exclusive: everything left of this chunk
+                        } else {
+                            // a tile row is two DPP rows: add the lower row's total (its lane 15) to the upper row,
+                            // then shift by one lane across the pair; the first lane of a tile row starts at 0
+                            inc += dpp_ctrl<0x142, 0xA>(inc);   // row_bcast:15 into DPP rows 1 and 3
+                            run = dpp_ctrl<0x138, 0xF>(inc);    // wave_shr:1
+                            if ((lane & 31) == 0) run = 0.0;
+                        }
                     }
                 }
 
@@ -1937,7 +1943,8 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
                         };
                         // First the winding per pixel, in place: the running sum itself for nonzero (its
                         // |.| rides as an operand modifier below), the folded value for evenodd (already in [0, 1]).
-                        if (rule) {
+                        if (fast1) {
+                        } else if (rule) {
 #pragma unroll
                             for (int i = 0; i < PX; ++i) { run += t[i]; t[i] = fill_evenodd_raw(run); }
                         } else {

@@ -49,8 +49,8 @@ class _GradMixin:
         off = np.ascontiguousarray([o for o, _ in stops], dtype=np.float64)
         col = np.ascontiguousarray([c for _, c in stops], dtype=np.float64).reshape(-1, 4)
         g.n_stops = len(stops)
-        g.stop_off = off.ctypes.data
-        g.stop_rgba = col.ctypes.data
+        g.stop_off = _abi.ptr(off)
+        g.stop_rgba = _abi.ptr(col)
         return off, col  # keep alive until the call returns
 
 
