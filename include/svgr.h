@@ -174,6 +174,12 @@ int svgr_batch_all_edges(svgr_batch* batch, double* edges, int32_t* edge_path, i
  *   then the owned bands packed in order); single-path kinds: bbox rows x cols (x 4).            */
 int svgr_batch_render(svgr_batch* batch, svgr_buf* out, int out_kind, unsigned flags);
 int64_t svgr_batch_owned_rows(const svgr_batch* batch);
+/* The same for a window of the canvas: `window` = {row0, col0, rows, cols} in presentation pixels, inside the batch's
+ * viewport (or, without one, inside the union bbox the plan found); `out` holds rows x cols x 4 of the canvas kind.
+ * Only the tiles the window touches are worked on and nothing outside it is written: the layer `Layer.compose` returns for
+ * a run of fills covers the union of their bboxes, not the viewport (canvas_merge_union, S:366-379).  The pixels are
+ * those svgr_batch_render writes at the same positions, bit for bit.  Canvas outputs, unsharded batches.            */
+int svgr_batch_render_window(svgr_batch* batch, svgr_buf* out, int out_kind, unsigned flags, const int32_t* window);
 
 /* HIP-event timings accumulated over the SVGR_RENDER_TIMED renders since the last call
  * (synchronises).  ms_geometry = transform/flatten/bbox/binning kernels, ms_tile = the tile

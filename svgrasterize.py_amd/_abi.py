@@ -97,6 +97,7 @@ _PROTOS = {
     "svgr_batch_get_edges": (C.c_int, [_P, _P, _P, C.c_int64]),
     "svgr_batch_all_edges": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "svgr_batch_render": (C.c_int, [_P, _P, C.c_int, C.c_uint]),
+    "svgr_batch_render_window": (C.c_int, [_P, _P, C.c_int, C.c_uint, _P]),
     "svgr_batch_owned_rows": (C.c_int64, [_P]),
     "svgr_batch_timings": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "svgr_layer_over": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int]),
@@ -350,8 +351,13 @@ class Batch:
     def owned_rows(self) -> int:
         return int(self.ctx.lib.svgr_batch_owned_rows(self.handle))
 
-    def render(self, out: DeviceBuffer, kind: int, flags: int = 0):
-        _check(self.ctx.lib.svgr_batch_render(self.handle, out.handle, kind, flags))
+    def render(self, out: DeviceBuffer, kind: int, flags: int = 0, window=None):
+        """`window` (row0, col0, rows, cols): only that part of the canvas, into a buffer of its size (svgr_batch_render_window)."""
+        if window is None:
+            _check(self.ctx.lib.svgr_batch_render(self.handle, out.handle, kind, flags))
+        else:
+            w = (C.c_int32 * 4)(*[int(v) for v in window])
+            _check(self.ctx.lib.svgr_batch_render_window(self.handle, out.handle, kind, flags, w))
 
     def render_masks(self):
         """SVGR_OUT_MASKS_F64: Path.mask of every path of the batch in one launch.  Returns (buffer, offsets, bboxes):

@@ -1458,7 +1458,10 @@ struct TileArgs {
     const int* band_start;     // per band: first entry of its list
     unsigned long long* tile_mask;  // per (band, column tile): which entries of the band's list have a visible cell here
     int mask_words, n_ct;           // (k_pair_cells); each tile reads its words and clears them for the next render
-    int n_bands;                    // owned bands: the launch covers n_ct x n_bands tiles
+    int n_bands;                    // bands of the launch (all owned bands, or those of the render window)
+    int ct0, win_ct, band0;         // render window in tiles: column tiles [ct0, ct0 + win_ct), bands from band0 (0, n_ct, 0: all)
+    int win_r, win_c;               // ... its first row / column inside its first tile (0 .. TR-1 / TC-1)
+    int win_rows, win_cols;         // ... its size = the extent of `out` (canvas outputs)
     const TileEntry* entries;  // per band: the pairs with records, ascending path id
     const RowRec* bsegs;       // record blocks: per (path, band) pair its edge-row records
     const CellHdr* cell_hdr;        // per (pair, column tile) cell of class 1 or 2: paint, fill rule, carry-in of every tile row
@@ -1515,18 +1518,19 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     // Workgroup -> tile, XCD-aware: the hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own
     // L2), so workgroups w, w + 8, w + 16 ... -- one XCD -- take CONSECUTIVE tiles: the column tiles of a band, which read
     // the same (path, band) record blocks, then meet in one L2 instead of fetching a block once per XCD.
-    const unsigned wg_lin = blockIdx.x, n_tiles = (unsigned)a.n_ct * (unsigned)a.n_bands;
+    const unsigned wg_lin = blockIdx.x, n_tiles = (unsigned)a.win_ct * (unsigned)a.n_bands;
     const unsigned per_xcc = (((n_tiles + 7u) >> 3) + TPW - 1u) / TPW * TPW;  // tiles of one XCD's share, whole workgroups
     for (unsigned tt = 0; tt < TPW; ++tt) {  // TPW consecutive tiles per workgroup, one after the other
     const unsigned t_lin = SVGR_XCC_MAP ? (wg_lin & 7u) * per_xcc + (wg_lin >> 3) * TPW + tt : wg_lin * TPW + tt;
     if (t_lin >= n_tiles) break;  // (the grid is rounded up)
-    const int by = __builtin_amdgcn_readfirstlane((int)(t_lin / (unsigned)a.n_ct));
-    const int bx = (int)t_lin - by * a.n_ct;
+    // (the launch covers the column tiles [ct0, ct0 + win_ct) of the bands [band0, band0 + n_bands): the render window)
+    const int by = __builtin_amdgcn_readfirstlane((int)(t_lin / (unsigned)a.win_ct));
+    const int bx = (int)t_lin - by * a.win_ct + a.ct0;
     int tid_ = (int)threadIdx.x;
     if (TPW > 1) asm volatile("" : "+v"(tid_));  // (per tile: nothing derived from the thread id stays live across tiles)
     const int tid = tid_, wave = tid >> 6, lane = tid & 63;
     const int trow = tid / CH, chunk = tid % CH;
-    const int band = owned_band_at(a.own, by);
+    const int band = owned_band_at(a.own, by + a.band0);
     clip_tag = -1;
     if (tt) __syncthreads();  // (the previous tile's last LDS reads)
     const int tile_r0 = a.vr0 + band * TR;             // absolute row of tile row 0
@@ -2076,16 +2080,16 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
 #endif
     if (OUT <= 1) {
         const int row = band * TR + trow;  // viewport-local row
-        const int out_row = by * TR + trow;
-        if (row < a.vrows) {
+        const int out_row = by * TR + trow - a.win_r;  // row of the output buffer (the window's / the owned bands packed)
+        if (row < a.vrows && out_row >= 0 && out_row < a.win_rows) {
             // (the lane's chunk is recomputed from the thread id here: kept live across the main loop it costs a VGPR
             // that the register budget does not have, i.e. a scratch spill in every workgroup)
             int tid2 = (int)threadIdx.x;
             asm volatile("" : "+v"(tid2));
-            const int col0 = bx * TC + (tid2 % CH) * PX;
+            const int col0 = (bx - a.ct0) * TC + (tid2 % CH) * PX - a.win_c;  // column of the output buffer
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
-                if (col0 + i < a.vcols) {
+                if (col0 + i >= 0 && col0 + i < a.win_cols) {
                     double v0 = acc[i][0], v1 = acc[i][1], v2 = acc[i][2], v3 = acc[i][3];
                     if (a.clip01) {
                         v0 = v0 < 0 ? 0 : (v0 > 1 ? 1 : v0); v1 = v1 < 0 ? 0 : (v1 > 1 ? 1 : v1);
@@ -3428,12 +3432,18 @@ static int get_event(svgr_batch* b, hipEvent_t* e) {
     return 0;
 }
 
-static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags);
+static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags, const int32_t* window);
 int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags) {
-    return abi_guard("svgr_batch_render", [&]() { return batch_render_impl(b, out, out_kind, flags); });
+    return abi_guard("svgr_batch_render", [&]() { return batch_render_impl(b, out, out_kind, flags, nullptr); });
+}
+int svgr_batch_render_window(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags, const int32_t* window) {
+    return abi_guard("svgr_batch_render_window", [&]() {
+        if (!window) return fail(SVGR_E_INVALID, "window is NULL");
+        return batch_render_impl(b, out, out_kind, flags, window);
+    });
 }
 
-static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags) {
+static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags, const int32_t* window) {
     if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
     if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan must run before svgr_batch_render");
     if (out_kind < 0 || out_kind > 4) return fail(SVGR_E_INVALID, "unknown output kind %d", out_kind);
@@ -3443,6 +3453,17 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
     if (single && !layers && b->n_paths != 1) return fail(SVGR_E_INVALID, "mask/fill outputs need a single-path batch");
     if (single && (b->n_groups > 0 || b->n_grads > 0)) return fail(SVGR_E_INVALID, "isolated groups and gradient paints exist in the canvas outputs only");
     if (layers && b->own.world > 1) return fail(SVGR_E_INVALID, "per-path mask output is not sharded");
+    // render window (canvas outputs): viewport-local rectangle {row0, col0, rows, cols} that `out` covers
+    int win[4] = {0, 0, b->vp[2], b->vp[3]};
+    if (window) {
+        if (single) return fail(SVGR_E_INVALID, "a render window applies to the canvas outputs");
+        if (b->own.world > 1) return fail(SVGR_E_INVALID, "a render window and band sharding exclude each other");
+        win[0] = window[0] - b->vp[0]; win[1] = window[1] - b->vp[1]; win[2] = window[2]; win[3] = window[3];
+        if (win[2] <= 0 || win[3] <= 0 || win[0] < 0 || win[1] < 0 || (long long)win[0] + win[2] > b->vp[2] ||
+            (long long)win[1] + win[3] > b->vp[3])
+            return fail(SVGR_E_INVALID, "render window (%d, %d, %d, %d) is empty or not inside the viewport (%d, %d, %d, %d)", window[0],
+                        window[1], window[2], window[3], b->vp[0], b->vp[1], b->vp[2], b->vp[3]);
+    }
     HIPCHK(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
 
@@ -3465,8 +3486,8 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         need = (size_t)std::max(b->host_bbox[2], 0) * std::max(b->host_bbox[3], 0) * sizeof(double) * (out_kind == 3 ? 4 : 1);
     } else {
         const bool all = b->own.world <= 1;
-        size_t rows = all ? (size_t)b->vp[2] : (size_t)owned_bands * TR;
-        need = rows * (size_t)b->vp[3] * 4 * (out_kind == 0 ? sizeof(float) : sizeof(double));
+        size_t rows = all ? (size_t)win[2] : (size_t)owned_bands * TR;
+        need = rows * (size_t)win[3] * 4 * (out_kind == 0 ? sizeof(float) : sizeof(double));
     }
     if (out->bytes < need) return fail(SVGR_E_INVALID, "output buffer has %zu bytes, needs %zu", out->bytes, need);
 
@@ -3504,7 +3525,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         }
         a.vr0 = b->vp[0]; a.vc0 = b->vp[1]; a.vrows = b->vp[2]; a.vcols = b->vp[3];
         a.own = b->own;
-        a.out_cols = b->vp[3];
+        a.out_cols = win[3];
         a.clip01 = (flags & SVGR_RENDER_CLIP01) ? 1 : 0;
         a.layer_off = layers ? b->layer_off.p : nullptr;
         a.arena = (unsigned*)b->arena.p;
@@ -3539,8 +3560,17 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
             a.dbg = tl_buf;
         }
 #endif
-        a.n_bands = owned_bands;
-        const unsigned n_tiles_ = (unsigned)n_ctiles * (unsigned)owned_bands;
+        // the tiles the window touches (everything without one)
+        a.ct0 = win[1] / TC;
+        a.win_ct = (win[1] + win[3] - 1) / TC - a.ct0 + 1;
+        a.band0 = window ? win[0] / TR : 0;
+        a.n_bands = window ? (win[0] + win[2] - 1) / TR - a.band0 + 1 : owned_bands;
+        a.win_r = win[0] - a.band0 * TR;
+        a.win_c = win[1] - a.ct0 * TC;
+        a.win_rows = b->own.world <= 1 ? win[2] : owned_bands * TR;
+        a.win_cols = win[3];
+        const bool whole = a.win_ct == n_ctiles && a.n_bands == owned_bands;
+        const unsigned n_tiles_ = (unsigned)a.win_ct * (unsigned)a.n_bands;
         dim3 grid(8u * ((((n_tiles_ + 7u) >> 3) + TPW - 1u) / TPW));
         static const int dyn_lds = getenv("SVGR_DBG_DYNLDS") ? atoi(getenv("SVGR_DBG_DYNLDS")) : 0;  // occupancy experiments
         switch (out_kind) {
@@ -3560,7 +3590,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
             default: hipLaunchKernelGGL(k_tile_render<3>, grid, dim3(NT), 0, st, a); break;
         }
         b->arena_zeroed = true;  // (done by that kernel, see TileArgs::arena)
-        b->masks_zeroed = true;  // (every tile clears its own words)
+        b->masks_zeroed = whole;  // (every tile clears its own words; those outside a render window never ran)
     }
     if (timed) {
         HIPCHK(hipEventRecord(ev.e2, st));

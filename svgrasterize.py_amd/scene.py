@@ -552,22 +552,11 @@ def _render_run(leaves, viewport, linear_rgb):
     ur0, uc0 = min(b[0] for b in boxes), min(b[1] for b in boxes)
     urows = max(b[0] + b[2] for b in boxes) - ur0
     ucols = max(b[1] + b[3] for b in boxes) - uc0
-    if viewport is None:
-        vp = tuple(int(v) for v in st.bbox_union)  # the canvas the batch planned for (covers the clip paths too)
-    else:
-        vp = tuple(int(v) for v in viewport)
-    canvas = ctx.alloc(vp[2] * vp[3] * 32)
-    batch.render(canvas, _abi.OUT_CANVAS_F64)
+    # only the union of the leaves' bboxes is rendered (a render window of the batch's canvas): the tiles outside it are
+    # not touched, and the layer needs no crop
     shape = (urows, ucols, 4)
-    if (ur0, uc0, urows, ucols) != vp:
-        out = ctx.alloc(urows * ucols * 32)
-        from .layer import _bbox_arr
-
-        _abi._check(ctx.lib.svgr_layer_crop4(ctx.handle, out.handle, _bbox_arr((ur0, uc0), shape), canvas.handle,
-                                             _bbox_arr(vp[:2], vp[2:]), 4))
-        canvas.free()
-    else:
-        out = canvas
+    out = ctx.alloc(urows * ucols * 32)
+    batch.render(out, _abi.OUT_CANVAS_F64, window=(ur0, uc0, urows, ucols))
     layer = Layer._from_device(out, shape, (ur0, uc0), True, linear_rgb)
     # The group's hull merges the hulls of the children that drew something (S:676-684): a leaf whose clipped bbox is
     # empty returned None there and does not count; one that is partly visible counts with ALL its lines (S:993).  Clip

@@ -450,3 +450,44 @@ def test_gradient_fills_inside_the_batch_equal_the_per_node_route(S):
         node = S.Scene.group([S.Scene.fill(blob(100, 100, 60), paint), S.Scene.fill(blob(120, 100, 30), solid)])
         assert sc._batchable_leaves(node, swap, False) is None
         assert node.render(swap, viewport=[0, 0, 256, 256], linear_rgb=False) is not None
+
+
+def test_render_window_equals_the_same_pixels_of_the_whole_canvas(S):
+    """svgr_batch_render_window: a window of the canvas (what Scene.render asks for a run of fills: the union of their
+    bboxes, canvas_merge_union S:366-379) holds the pixels of the whole render -- the same arithmetic on the same tiles, so
+    equal up to the order of the delta tile's LDS atomics (two whole renders differ by as much: DESIGN 5) -- for windows
+    that start and end anywhere inside tiles; a whole render after windowed ones is unchanged (the tiles outside a window
+    never ran and left their list bits behind)."""
+    from svgrasterize_amd import _abi, synth
+
+    ctx = S.Context.get()
+    size = 400
+    sc = synth.make_scene(size, 60)
+    for vp in [(0, 0, size, size), (37, 21, 300, 333)]:
+        batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"], viewport=list(vp))
+        batch.plan()
+        for kind, dt, px in [(_abi.OUT_CANVAS_F64, np.float64, 32), (_abi.OUT_CANVAS_F32, np.float32, 16)]:
+            whole = ctx.alloc(vp[2] * vp[3] * px)
+            batch.render(whole, kind, _abi.RENDER_CLIP01)
+            ref = whole.download((vp[2], vp[3], 4), dt)
+            assert ref.any()
+            tol = 1e-13 if dt is np.float64 else 2.0 ** -23  # (values in [0, 1]: one float32 ULP at most)
+            windows = [(vp[0], vp[1], vp[2], vp[3]), (vp[0] + 5, vp[1] + 70, 1, 1), (vp[0] + 16, vp[1] + 64, 32, 128),
+                       (vp[0] + 15, vp[1] + 63, 18, 66), (vp[0] + vp[2] - 40, vp[1] + vp[3] - 77, 40, 77), (vp[0] + 100, vp[1], 3, vp[3])]
+            for r0, c0, rows, cols in windows:
+                out = ctx.alloc(rows * cols * px)
+                batch.render(out, kind, _abi.RENDER_CLIP01, window=(r0, c0, rows, cols))
+                got = out.download((rows, cols, 4), dt)
+                want = ref[r0 - vp[0]:r0 - vp[0] + rows, c0 - vp[1]:c0 - vp[1] + cols]
+                assert got.shape == want.shape and np.abs(got.astype(np.float64) - want).max() <= tol, (vp, kind, (r0, c0, rows, cols))
+                out.free()
+            batch.render(whole, kind, _abi.RENDER_CLIP01)
+            assert np.abs(whole.download((vp[2], vp[3], 4), dt).astype(np.float64) - ref).max() <= tol
+            whole.free()
+        # a window outside the viewport, an empty one, a window on a single-path output: refused
+        small = ctx.alloc(64 * 64 * 32)
+        for bad in [(vp[0] - 1, vp[1], 8, 8), (vp[0], vp[1], 0, 8), (vp[0] + vp[2] - 4, vp[1], 8, 8)]:
+            with pytest.raises(ValueError):
+                batch.render(small, _abi.OUT_CANVAS_F64, window=bad)
+        small.free()
+        batch.destroy()
