@@ -24,3 +24,4 @@ layer, _ = scene.render(tr, viewport=[0, 0, h, w], linear_rgb=False); layer._dev
 pr.disable()
 print("wall", time.perf_counter() - t0)
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+pstats.Stats(pr).sort_stats("tottime").print_stats(35)

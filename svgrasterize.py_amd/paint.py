@@ -39,10 +39,10 @@ class _GradMixin:
         if self.spread not in _SPREAD:
             raise ValueError(f"invalid spread method: {self.spread}")
         g.spread = _SPREAD[self.spread]
-        g.user_m6 = (C.c_double * 6)(*np.asarray(user_tr.m, dtype=np.float64)[:2].ravel())
+        g.user_m6 = (C.c_double * 6)(*np.asarray(user_tr.m, dtype=np.float64)[:2].ravel().tolist())
         if self.transform is not None:
             g.has_gt = 1
-            g.gt_m6 = (C.c_double * 6)(*np.asarray(self.transform.invert.m, dtype=np.float64)[:2].ravel())
+            g.gt_m6 = (C.c_double * 6)(*np.asarray(self.transform.invert.m, dtype=np.float64)[:2].ravel().tolist())
         stops = _stops_colorspace(self.stops, linear_rgb)
         if not stops:
             raise ValueError("a gradient needs at least one stop")
@@ -82,9 +82,10 @@ class GradLinear(_GradMixin, NamedTuple("GradLinear", [("p0", object), ("p1", ob
         g = _abi.Gradient()
         g.kind = 1
         keep = self._common(g, user_tr, linear_rgb)
-        vec = np.asarray(self.p1, dtype=np.float64) - np.asarray(self.p0, dtype=np.float64)  # S:1561
-        g.p0 = (C.c_double * 2)(*np.asarray(self.p0, dtype=np.float64))
-        g.vec = (C.c_double * 2)(*vec)
+        p0 = np.asarray(self.p0, dtype=np.float64)
+        vec = np.asarray(self.p1, dtype=np.float64) - p0  # S:1561
+        g.p0 = (C.c_double * 2)(*p0.tolist())
+        g.vec = (C.c_double * 2)(*vec.tolist())
         g.vv = float(np.dot(vec, vec))
         return g, keep
 
@@ -96,7 +97,7 @@ class GradRadial(_GradMixin, NamedTuple("GradRadial", [("center", object), ("rad
         g = _abi.Gradient()
         keep = self._common(g, user_tr, linear_rgb)
         center = np.asarray(self.center, dtype=np.float64)
-        g.center = (C.c_double * 2)(*center)
+        g.center = (C.c_double * 2)(*center.tolist())
         g.radius = float(self.radius)
         if self.fcenter is None and self.fradius is None:  # S:1605
             g.kind = 2
@@ -106,9 +107,9 @@ class GradRadial(_GradMixin, NamedTuple("GradRadial", [("center", object), ("rad
         fradius = self.fradius or 0
         cd = center - fcenter                      # S:1619
         rd = self.radius - fradius                 # S:1621
-        g.fcenter = (C.c_double * 2)(*fcenter)
+        g.fcenter = (C.c_double * 2)(*fcenter.tolist())
         g.fradius = float(fradius)
-        g.cd = (C.c_double * 2)(*cd)
+        g.cd = (C.c_double * 2)(*cd.tolist())
         g.rd = float(rd)
         g.a = float((cd ** 2).sum() - rd ** 2)     # S:1622
         g.frad_rd = float(fradius * rd)            # S:1623
