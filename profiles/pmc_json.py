@@ -50,8 +50,9 @@ def main():
         if "GRBM_GUI_ACTIVE" in v and v.get("counter_pass_avg_ns"):
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs; reads high on launches well under 0.3 ms (guide, DVFS section)
             v["clock_ghz_counter_pass"] = round(v["GRBM_GUI_ACTIVE"] / 8.0 / v["counter_pass_avg_ns"], 3)
+    head = os.environ.get("SVGR_HEAD")  # (the GPU box has no .git: the caller names the commit)
     try:
-        head = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        head = head or subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:  # noqa: BLE001  (the GPU box has no .git)
         head = None
     print(json.dumps({"workload": wl, "collected_by": "profiles/collect2.sh", "head": head,
