@@ -250,7 +250,9 @@ def roofline_block(tile_ms, geo_ms, n_timed, every, P_rank, E_rank, canvas_bytes
         })
         note = ("no committed counter file for this workload / sharding: frac = the bytes that must move (canvas + 32 B/edge) "
                 "over the live launch time against the HBM peak; the kernel's own limit is VALU issue (see the N = 1 line)")
-    block["counters"] = ({"file": counters_file, "collected_at_commit": counters.get("head"), "measured_in_this_run": False}
+    block["counters"] = ({"file": counters_file, "collected_at_commit": counters.get("head"), "measured_in_this_run": False,
+                          "of": ("rank 0 of the same N-way sharding, rendered alone on one GPU (profiles/collect_rank.sh)"
+                                 if "_w" in str(counters.get("workload")) else "this workload on one GPU (profiles/collect2.sh)")}
                          if counters is not None else None)
     block["note"] = note
     return block
@@ -444,7 +446,8 @@ def main():
         n_timed = max(tm["n"], 1)
         tile_ms = tm["ms_tile"] / n_timed
         geo_ms = tm["ms_geometry"] / n_timed
-        counters, counters_file = load_counters(args.workload) if world == 1 else (None, None)
+        # (N > 1: the counters of rank 0 of an N-way sharding of the same drawing, collected on one GPU by profiles/collect_rank.sh)
+        counters, counters_file = load_counters(args.workload if world == 1 else f"{args.workload}_w{world}")
         line = {
             "metric": "Mpixels/sec AA coverage+composite (path-pixels/s; whole step: flatten+binning+coverage+composite)",
             "value": round(P / (t_max / args.steps) / 1e6, 1),
