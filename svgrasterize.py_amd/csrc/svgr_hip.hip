@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cmath>
 #include <cstdio>
@@ -153,10 +154,18 @@ static int fail(int code, const char* fmt, ...) {
 
 struct svgr_ctx {
     int device = 0;
+    int id = 0;  // > 0, unique in the process: the block cache keeps every context's blocks apart
     hipStream_t stream = nullptr;
     bool own_stream = false;
     char name[128] = {0};
 };
+// the context whose call is running on this thread (set by enter_ctx at the top of every entry point): the block cache
+// files what is allocated and released under it
+static thread_local int tl_ctx_id = 0;
+static hipError_t enter_ctx(const svgr_ctx* c) {
+    tl_ctx_id = c->id;
+    return hipSetDevice(c->device);
+}
 struct svgr_buf {
     void* ptr = nullptr;
     size_t bytes = 0;
@@ -166,17 +175,22 @@ struct svgr_buf {
 // ======================================================================================
 // device memory: a small size-class cache in front of hipMalloc / hipFree.  The per-node route
 // creates thousands of short-lived buffers (one batch per path, one image per layer); hipMalloc /
-// hipFree cost ~100 us each and hipFree synchronises the device.  Every kernel and copy of this
-// library runs on the context stream and calls are serialised by the caller, so a block can be
-// handed out again as soon as it has been returned: stream order keeps its users apart.
+// hipFree cost ~100 us each and hipFree synchronises the device.  A block that is returned can be
+// handed out again at once ONLY to the context it came from: every kernel and copy of a context
+// runs on that context's stream and its calls are serialised by the caller, so stream order keeps
+// the block's users apart.  Two contexts on one device have two streams: their blocks never mix
+// (svgr_set_stream drains the outgoing stream before the context moves to another one).
 // ======================================================================================
 #include <map>
 #include <mutex>
+#include <set>
 namespace {
 struct DevPool {
+    struct Block { size_t cap; int dev; int ctx; };
     std::mutex mu;
-    std::map<int, std::multimap<size_t, void*>> free_by_dev;  // per device, by capacity
-    std::map<void*, std::pair<size_t, int>> cap_of;           // capacity and device of every block handed out or cached
+    std::map<int, std::multimap<size_t, void*>> free_by_ctx;  // per context, by capacity
+    std::map<void*, Block> cap_of;                             // every block handed out or cached
+    std::set<int> live;                                        // contexts that exist
     size_t cached_bytes = 0;
     static constexpr size_t kMaxCached = 8ull << 30;
 
@@ -185,15 +199,18 @@ struct DevPool {
         while (c < n) c += c < (1u << 20) ? c : c / 4;  // x2 up to 1 MiB, then +25 %
         return c;
     }
-    // `dev` = the device the block is for (the caller has made it current); -1: whatever is current
+    void open(int ctx) { std::lock_guard<std::mutex> lk(mu); live.insert(ctx); }
+    // `dev` = the device the block is for (the caller has made it current); -1: whatever is current.  The block belongs to
+    // the context running on this thread (enter_ctx).
     hipError_t alloc(void** out, size_t bytes, int dev = -1) {
         const size_t c = size_class(bytes ? bytes : 1);
+        const int ctx = tl_ctx_id;
         if (dev < 0) (void)hipGetDevice(&dev);
         {
             std::lock_guard<std::mutex> lk(mu);
-            auto& free_blocks = free_by_dev[dev];
+            auto& free_blocks = free_by_ctx[ctx];
             auto it = free_blocks.lower_bound(c);
-            if (it != free_blocks.end() && it->first <= c + c / 2) {
+            if (it != free_blocks.end() && it->first <= c + c / 2 && cap_of[it->second].dev == dev) {
                 *out = it->second;
                 cached_bytes -= it->first;
                 free_blocks.erase(it);
@@ -207,7 +224,7 @@ struct DevPool {
         }
         if (e == hipSuccess) {
             std::lock_guard<std::mutex> lk(mu);
-            cap_of[*out] = {c, dev};
+            cap_of[*out] = Block{c, dev, ctx};
         }
         return e;
     }
@@ -216,24 +233,40 @@ struct DevPool {
         std::unique_lock<std::mutex> lk(mu);
         auto it = cap_of.find(p);
         if (it == cap_of.end()) { lk.unlock(); (void)hipFree(p); return; }
-        if (cached_bytes + it->second.first > kMaxCached) {
+        // (a block whose context is gone has nobody to go back to; hipFree waits for the device, so late users are safe)
+        if (cached_bytes + it->second.cap > kMaxCached || !live.count(it->second.ctx)) {
             cap_of.erase(it);
             lk.unlock();
             (void)hipFree(p);
             return;
         }
-        free_by_dev[it->second.second].emplace(it->second.first, p);
-        cached_bytes += it->second.first;
+        free_by_ctx[it->second.ctx].emplace(it->second.cap, p);
+        cached_bytes += it->second.cap;
     }
-    // give the cached blocks of device `dev` back to the driver (other devices' caches belong to other contexts)
-    void trim(int dev) {
+    // give cached blocks back to the driver: those of device `dev` (every context's: hipFree waits for the device), or --
+    // close() -- those of one context that is going away
+    void trim(int dev) { drop([&](const Block& b) { return b.dev == dev; }); }
+    void close(int ctx) {
+        { std::lock_guard<std::mutex> lk(mu); live.erase(ctx); }
+        drop([&](const Block& b) { return b.ctx == ctx; });
+    }
+    template <class Pred>
+    void drop(Pred pred) {
         std::vector<void*> blocks;
         {
             std::lock_guard<std::mutex> lk(mu);
-            auto d = free_by_dev.find(dev);
-            if (d == free_by_dev.end()) return;
-            for (auto& b : d->second) { blocks.push_back(b.second); cached_bytes -= b.first; cap_of.erase(b.second); }
-            free_by_dev.erase(d);
+            for (auto& per_ctx : free_by_ctx)
+                for (auto it = per_ctx.second.begin(); it != per_ctx.second.end();) {
+                    auto info = cap_of.find(it->second);
+                    if (info != cap_of.end() && pred(info->second)) {
+                        blocks.push_back(it->second);
+                        cached_bytes -= it->first;
+                        cap_of.erase(info);
+                        it = per_ctx.second.erase(it);
+                    } else {
+                        ++it;
+                    }
+                }
         }
         for (void* b : blocks) (void)hipFree(b);
     }
@@ -2800,6 +2833,10 @@ int svgr_init(int device_id, svgr_ctx** out) {
     svgr_ctx* c = new (std::nothrow) svgr_ctx();
     if (!c) return fail(SVGR_E_NOMEM, "out of host memory");
     c->device = device_id;
+    static std::atomic<int> next_id{1};
+    c->id = next_id.fetch_add(1);
+    g_pool.open(c->id);
+    tl_ctx_id = c->id;
     snprintf(c->name, sizeof c->name, "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD Instinct", prop.gcnArchName, prop.multiProcessorCount);
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return fail(SVGR_E_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
@@ -2810,17 +2847,17 @@ int svgr_init(int device_id, svgr_ctx** out) {
 
 int svgr_shutdown(svgr_ctx* ctx) {
     if (!ctx) return 0;
-    (void)hipSetDevice(ctx->device);
+    (void)enter_ctx(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    g_pool.trim(ctx->device);
+    g_pool.close(ctx->id);  // (its cached blocks; what it still has out is freed on return)
     delete ctx;
     return 0;
 }
 
 int svgr_set_stream(svgr_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(SVGR_E_INVALID, "ctx is NULL");
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     // The block cache hands a freed block to the next caller on the strength of stream order alone, so the outgoing
     // stream -- owned or the caller's -- must have drained before work is enqueued on another one.
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2832,7 +2869,7 @@ int svgr_set_stream(svgr_ctx* ctx, void* hip_stream) {
 
 int svgr_sync(svgr_ctx* ctx) {
     if (!ctx) return fail(SVGR_E_INVALID, "ctx is NULL");
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
     return 0;
@@ -2849,7 +2886,7 @@ int svgr_buf_alloc(svgr_ctx* ctx, size_t bytes, svgr_buf** out) {
     *out = nullptr;
     svgr_buf* b = new (std::nothrow) svgr_buf();
     if (!b) return fail(SVGR_E_NOMEM, "out of host memory");
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     hipError_t e = g_pool.alloc(&b->ptr, bytes ? bytes : 16, ctx->device);
     if (e != hipSuccess) { delete b; return fail(SVGR_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
     b->bytes = bytes;
@@ -2882,7 +2919,7 @@ size_t svgr_buf_bytes(const svgr_buf* buf) { return buf ? buf->bytes : 0; }
 
 int svgr_buf_zero(svgr_ctx* ctx, svgr_buf* buf) {
     if (!ctx || !buf) return fail(SVGR_E_INVALID, "bad arguments");
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     HIPCHK(hipMemsetAsync(buf->ptr, 0, buf->bytes, ctx->stream));
     return 0;
 }
@@ -2891,7 +2928,7 @@ int svgr_buf_copy(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, size_t byte
     if (!ctx || !dst || !src) return fail(SVGR_E_INVALID, "bad arguments");
     if (bytes > dst->bytes || bytes > src->bytes) return fail(SVGR_E_INVALID, "copy of %zu bytes overruns a buffer", bytes);
     if (bytes == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     HIPCHK(hipMemcpyAsync(dst->ptr, src->ptr, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
@@ -2900,7 +2937,7 @@ int svgr_upload(svgr_ctx* ctx, svgr_buf* dst, size_t dst_off, const void* host, 
     if (!ctx || !dst || (!host && bytes)) return fail(SVGR_E_INVALID, "bad arguments");
     if (dst_off + bytes > dst->bytes) return fail(SVGR_E_INVALID, "upload of %zu bytes at %zu overruns a %zu byte buffer", bytes, dst_off, dst->bytes);
     if (bytes == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     HIPCHK(hipMemcpyAsync((char*)dst->ptr + dst_off, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));  // host buffer is caller-owned and may be reused at once
     return 0;
@@ -2910,7 +2947,7 @@ int svgr_download(svgr_ctx* ctx, const svgr_buf* src, size_t src_off, void* host
     if (!ctx || !src || (!host && bytes)) return fail(SVGR_E_INVALID, "bad arguments");
     if (src_off + bytes > src->bytes) return fail(SVGR_E_INVALID, "download of %zu bytes at %zu overruns a %zu byte buffer", bytes, src_off, src->bytes);
     if (bytes == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     HIPCHK(hipMemcpyAsync(host, (const char*)src->ptr + src_off, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
@@ -2952,7 +2989,7 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
                                std::llabs(d->viewport[0]) > (1 << 28) || std::llabs(d->viewport[1]) > (1 << 28)))
         return fail(SVGR_E_INVALID, "viewport out of range");
 
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     svgr_batch* b = new (std::nothrow) svgr_batch();
     if (!b) return fail(SVGR_E_NOMEM, "out of host memory");
     b->ctx = ctx;
@@ -3005,7 +3042,7 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
 
 int svgr_batch_destroy(svgr_batch* b) {
     if (!b) return 0;
-    (void)hipSetDevice(b->ctx->device);
+    (void)enter_ctx(b->ctx);
     (void)hipStreamSynchronize(b->ctx->stream);
     b->release();
     delete b;
@@ -3014,7 +3051,7 @@ int svgr_batch_destroy(svgr_batch* b) {
 
 int svgr_batch_set_paints(svgr_batch* b, const double* path_paint) {
     if (!b || !path_paint) return fail(SVGR_E_INVALID, "bad arguments");
-    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(enter_ctx(b->ctx));
     HIPCHK(hipMemcpyAsync(b->path_paint.p, path_paint, sizeof(double) * 4 * b->n_paths, hipMemcpyHostToDevice, b->ctx->stream));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
     b->geometry_fresh = false;  // the cell headers carry the paint
@@ -3025,7 +3062,7 @@ int svgr_batch_set_transforms(svgr_batch* b, const double* path_m6) {
     if (!b || !path_m6) return fail(SVGR_E_INVALID, "bad arguments");
     for (int64_t i = 0; i < 6 * b->n_paths; ++i)
         if (!std::isfinite(path_m6[i])) return fail(SVGR_E_INVALID, "non-finite transform");
-    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(enter_ctx(b->ctx));
     HIPCHK(hipMemcpyAsync(b->path_m6.p, path_m6, sizeof(double) * 6 * b->n_paths, hipMemcpyHostToDevice, b->ctx->stream));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
     b->planned = false;
@@ -3067,7 +3104,7 @@ int svgr_batch_set_groups(svgr_batch* b, const int32_t* path_group, int64_t n_gr
             return fail(SVGR_E_INVALID, "group %lld: its clip source must be the path right in front of its first member", (long long)g);
         if (!std::isfinite(group_opacity[g])) return fail(SVGR_E_INVALID, "group %lld: opacity is not finite", (long long)g);
     }
-    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(enter_ctx(b->ctx));
     if (int rc = b->path_group.ensure((size_t)b->n_paths)) return rc;
     if (int rc = b->group_clip_src.ensure((size_t)n_groups)) return rc;
     if (int rc = b->group_opacity.ensure((size_t)n_groups)) return rc;
@@ -3115,7 +3152,7 @@ int svgr_batch_set_gradients(svgr_batch* b, const int32_t* path_grad, int64_t n_
         }
         for (int64_t i = 0; i < n_grads; ++i)
             if (owner[(size_t)i] < 0) return fail(SVGR_E_INVALID, "gradient %lld is not used by any path", (long long)i);
-        HIPCHK(hipSetDevice(b->ctx->device));
+        HIPCHK(enter_ctx(b->ctx));
         if (int rc = b->grads.ensure((size_t)n_grads)) return rc;
         if (int rc = b->path_grad.ensure((size_t)b->n_paths)) return rc;
         if (int rc = b->grad_path.ensure((size_t)n_grads)) return rc;
@@ -3236,7 +3273,7 @@ int svgr_batch_plan(svgr_batch* b) {
 
 static int batch_plan_impl(svgr_batch* b) {
     if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
-    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(enter_ctx(b->ctx));
     b->planned = false;
     b->geometry_fresh = false;
     {
@@ -3345,7 +3382,7 @@ int svgr_batch_get_edges(const svgr_batch* b, double* edges, int32_t* edge_path,
     if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan has not run");
     if (cap < b->n_edges_live) return fail(SVGR_E_INVALID, "edge buffer holds %lld, need %lld", (long long)cap, (long long)b->n_edges_live);
     if (b->n_edges_live == 0) return 0;
-    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(enter_ctx(b->ctx));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
     int64_t at = 0;
     for (int k = 0; k < NSH; ++k) {  // the filled part of every shard, packed
@@ -3370,7 +3407,7 @@ int svgr_batch_all_edges(svgr_batch* b, double* edges, int32_t* edge_path, int64
 
 static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path, int64_t cap, int64_t* n_out) {
     if (!b || !n_out) return fail(SVGR_E_INVALID, "bad arguments");
-    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(enter_ctx(b->ctx));
     hipStream_t st = b->ctx->stream;
     const int ns = (int)b->n_segs;
     *n_out = 0;
@@ -3464,7 +3501,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
             return fail(SVGR_E_INVALID, "render window (%d, %d, %d, %d) is empty or not inside the viewport (%d, %d, %d, %d)", window[0],
                         window[1], window[2], window[3], b->vp[0], b->vp[1], b->vp[2], b->vp[3]);
     }
-    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(enter_ctx(b->ctx));
     hipStream_t st = b->ctx->stream;
 
     const int owned_bands = count_owned_bands(b->own, b->n_bands);
@@ -3602,7 +3639,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
 
 int svgr_batch_timings(svgr_batch* b, int* n_renders, double* ms_total, double* ms_geometry, double* ms_tile) {
     if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
-    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(enter_ctx(b->ctx));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
     double tg = 0, tt = 0;
     for (auto& e : b->events) {
@@ -3637,7 +3674,7 @@ int svgr_layer_over(svgr_ctx* ctx, svgr_buf* dst, const int64_t* db, const svgr_
     size_t n = (size_t)sb[2] * sb[3];
     if (dst->bytes < (size_t)db[2] * db[3] * 32 || src->bytes < n * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_over: buffer too small");
     if (n == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     hipLaunchKernelGGL(k_layer_over, grid1(n), dim3(256), 0, ctx->stream, (double*)dst->ptr, (int)db[0], (int)db[1], (int)db[2],
                        (int)db[3], (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch, first);
     HIPCHK(hipGetLastError());
@@ -3651,7 +3688,7 @@ int svgr_layer_blend(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr
     const size_t n = (size_t)ob[2] * ob[3];
     if (out->bytes < n * 32 || src->bytes < (size_t)sb[2] * sb[3] * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_blend: buffer too small");
     if (n == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     hipLaunchKernelGGL(k_layer_blend, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2], (int)ob[3],
                        (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch, mode, mode == 5 ? k4[0] : 0.0,
                        mode == 5 ? k4[1] : 0.0, mode == 5 ? k4[2] : 0.0, mode == 5 ? k4[3] : 0.0);
@@ -3662,7 +3699,7 @@ int svgr_layer_blend(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr
 int svgr_layer_color_matrix(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, const double* m20) {
     if (!ctx || !img || !m20 || n_px < 0 || img->bytes < (size_t)n_px * 32) return fail(SVGR_E_INVALID, "svgr_layer_color_matrix: bad arguments");
     if (n_px == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     double* dm = nullptr;
     HIPCHK(g_pool.alloc((void**)&dm, sizeof(double) * 20));
     hipError_t e = hipMemcpyAsync(dm, m20, sizeof(double) * 20, hipMemcpyHostToDevice, ctx->stream);
@@ -3681,7 +3718,7 @@ int svgr_layer_morphology(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int
         return fail(SVGR_E_INVALID, "svgr_layer_morphology: bad arguments (the window must fit the layer)");
     const size_t n = (size_t)(rows - ky + 1) * (size_t)(cols - kx + 1);
     if (src->bytes < (size_t)rows * cols * 32 || out->bytes < n * 32) return fail(SVGR_E_INVALID, "svgr_layer_morphology: buffer too small");
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     hipLaunchKernelGGL(k_layer_morphology, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)src->ptr, (int)rows, (int)cols,
                        (int)ky, (int)kx, is_max);
     HIPCHK(hipGetLastError());
@@ -3691,7 +3728,7 @@ int svgr_layer_morphology(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int
 int svgr_layer_luminance(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t n_px) {
     if (!ctx || !out || !src || n_px < 0 || out->bytes < (size_t)n_px * 8 || src->bytes < (size_t)n_px * 32) return fail(SVGR_E_INVALID, "svgr_layer_luminance: bad arguments");
     if (n_px == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     hipLaunchKernelGGL(k_layer_luminance, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)src->ptr, (size_t)n_px);
     HIPCHK(hipGetLastError());
     return 0;
@@ -3702,7 +3739,7 @@ int svgr_layer_crop4(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr
     size_t n = (size_t)ob[2] * ob[3];
     if (out->bytes < n * 32 || src->bytes < (size_t)sb[2] * sb[3] * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_crop4: buffer too small");
     if (n == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     hipLaunchKernelGGL(k_layer_crop4, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
                        (int)ob[3], (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch);
     HIPCHK(hipGetLastError());
@@ -3714,7 +3751,7 @@ int svgr_layer_in(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr_bu
     size_t n = (size_t)ob[2] * ob[3];
     if (out->bytes < n * 32 || src->bytes < (size_t)sb[2] * sb[3] * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_in: buffer too small");
     if (n == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     hipLaunchKernelGGL(k_layer_in, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
                        (int)ob[3], (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch);
     HIPCHK(hipGetLastError());
@@ -3724,7 +3761,7 @@ int svgr_layer_in(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr_bu
 int svgr_layer_scale(svgr_ctx* ctx, svgr_buf* img, int64_t n, double f) {
     if (!ctx || !img || n < 0 || img->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_scale: bad arguments");
     if (n == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     hipLaunchKernelGGL(k_layer_scale, grid1((size_t)n), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n, f);
     HIPCHK(hipGetLastError());
     return 0;
@@ -3733,7 +3770,7 @@ int svgr_layer_scale(svgr_ctx* ctx, svgr_buf* img, int64_t n, double f) {
 int svgr_layer_clip01(svgr_ctx* ctx, svgr_buf* img, int64_t n) {
     if (!ctx || !img || n < 0 || img->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_clip01: bad arguments");
     if (n == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     hipLaunchKernelGGL(k_layer_clip01, grid1((size_t)n), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n);
     HIPCHK(hipGetLastError());
     return 0;
@@ -3742,7 +3779,7 @@ int svgr_layer_clip01(svgr_ctx* ctx, svgr_buf* img, int64_t n) {
 int svgr_layer_background(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, const double* rgba) {
     if (!ctx || !img || !rgba || n_px < 0 || img->bytes < (size_t)n_px * 32) return fail(SVGR_E_INVALID, "svgr_layer_background: bad arguments");
     if (n_px == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     hipLaunchKernelGGL(k_layer_background, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n_px, rgba[0],
                        rgba[1], rgba[2], rgba[3]);
     HIPCHK(hipGetLastError());
@@ -3752,7 +3789,7 @@ int svgr_layer_background(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, const doub
 int svgr_layer_convert(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, unsigned ops) {
     if (!ctx || !img || n_px < 0 || img->bytes < (size_t)n_px * 32 || (ops & ~15u)) return fail(SVGR_E_INVALID, "svgr_layer_convert: bad arguments");
     if (n_px == 0 || ops == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     hipLaunchKernelGGL(k_layer_convert, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n_px, ops);
     HIPCHK(hipGetLastError());
     return 0;
@@ -3761,7 +3798,7 @@ int svgr_layer_convert(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, unsigned ops)
 int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t n, int clip01) {
     if (!ctx || !dst || !src || n < 0 || dst->bytes < (size_t)n * 4 || src->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_to_f32: bad arguments");
     if (n == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     hipLaunchKernelGGL(k_to_f32, grid1((size_t)n), dim3(256), 0, ctx->stream, (float*)dst->ptr, (const double*)src->ptr, (size_t)n, clip01);
     HIPCHK(hipGetLastError());
     return 0;
@@ -3770,7 +3807,7 @@ int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t
 int svgr_layer_to_rgba8(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t n_px) {
     if (!ctx || !dst || !src || n_px < 0 || dst->bytes < (size_t)n_px * 4 || src->bytes < (size_t)n_px * 32) return fail(SVGR_E_INVALID, "svgr_layer_to_rgba8: bad arguments");
     if (n_px == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     hipLaunchKernelGGL(k_to_rgba8, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (uchar4*)dst->ptr, (const double4*)src->ptr, (size_t)n_px);
     HIPCHK(hipGetLastError());
     return 0;
@@ -3786,7 +3823,7 @@ static int gradient_run(svgr_ctx* ctx, const svgr_gradient* g, const double* pts
     const double* mptr = mask ? (const double*)mask->ptr : nullptr;
     GradDev h;
     fill_grad_dev(h, g);
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     hipError_t e = hipSuccess;
     double* ext = nullptr;  // long stop lists: one device block {offsets, colours}, held until the stream has drained
     if (g->n_stops <= GRAD_MAX_STOPS) {
@@ -3850,7 +3887,7 @@ int svgr_pattern_fill(svgr_ctx* ctx, const svgr_pattern* pt, const svgr_buf* til
     if (mask->bytes < n * 8 || out->bytes < n * 32 || tile->bytes < (size_t)pt->tile_bbox[2] * (size_t)pt->tile_bbox[3] * 32)
         return fail(SVGR_E_INVALID, "svgr_pattern_fill: buffer too small");
     if (n == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     int* flag = nullptr;
     HIPCHK(g_pool.alloc((void**)&flag, 16));
     int oob = 0;
@@ -3883,7 +3920,7 @@ static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src
         return fail(SVGR_E_INVALID, "svgr_layer_convolve: bad arguments");
     const size_t n_out = (size_t)(rows + kw - 1) * (size_t)(cols + kh - 1);
     if (src->bytes < (size_t)rows * cols * 32 || out->bytes < n_out * 32) return fail(SVGR_E_INVALID, "svgr_layer_convolve: buffer too small");
-    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(enter_ctx(ctx));
     // Separable?  blur_kernel (S:1903-1944) is a product of two 1-D Gaussians whenever the transform is axis aligned
     // (scale, translate, x/y swap): K = u v^T / S with u, v the row / column sums and S the total, to a few ulp.  Then two
     // 1-D passes do the work of the kw x kh stencil (146 taps instead of 5329 for the largest blur of icons.svg).  A

@@ -491,3 +491,39 @@ def test_render_window_equals_the_same_pixels_of_the_whole_canvas(S):
                 batch.render(small, _abi.OUT_CANVAS_F64, window=bad)
         small.free()
         batch.destroy()
+
+
+def test_two_contexts_on_one_device_keep_their_blocks_apart(S):
+    """The block cache hands a returned block straight to the next caller on the strength of stream order -- which only
+    holds inside ONE context (one stream).  Two contexts on a device must never see each other's cached blocks, and work
+    interleaved on both gives the results of either alone."""
+    from svgrasterize_amd import _abi, synth
+
+    a, b = _abi.Context(0), _abi.Context(0)
+    blk = a.alloc(3 << 20)
+    pa = blk.ptr
+    blk.free()
+    other = b.alloc(3 << 20)
+    assert other.ptr != pa                      # not A's block, although it is cached and fits
+    again = a.alloc(3 << 20)
+    assert again.ptr == pa                      # A gets its own block back
+    other.free(); again.free()
+
+    sc = synth.make_scene(512, 120)
+    outs = []
+    batches = [_abi.Batch(c, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
+                          viewport=sc["viewport"]) for c in (a, b)]
+    for bt in batches:
+        bt.plan()
+    bufs = [c.alloc(512 * 512 * 16) for c in (a, b)]
+    for _ in range(5):                          # interleaved, nothing waits in between
+        for bt, o in zip(batches, bufs):
+            bt.render(o, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
+            tmp = bt.ctx.alloc(1 << 20)         # churn the caches while kernels are in flight
+            tmp.free()
+    outs = [o.download((512, 512, 4), np.float32) for o in bufs]
+    assert outs[0].any() and np.abs(outs[0].astype(np.float64) - outs[1]).max() <= 2.0 ** -23
+    for bt in batches:
+        bt.destroy()
+    for o in bufs:
+        o.free()
