@@ -148,6 +148,11 @@ int svgr_batch_set_bands(svgr_batch* batch, int rank, int world, int strip_bands
  * Synchronises.                                                                                 */
 int svgr_batch_plan(svgr_batch* batch);
 
+/* svgr_batch_plan for many batches behind one wait per stream: a document's per-node route plans dozens of small batches
+ * (Scene.render: one per run of fills between two filter nodes, S:674-688), and a plan alone is a device round trip whose
+ * kernels are a fraction of it.  Same result and same errors as calling svgr_batch_plan on each (the first error ends it). */
+int svgr_batch_plan_many(svgr_batch** batches, int64_t n);
+
 typedef struct {
     int64_t n_edges;        /* flattened edges E                                                 */
     int64_t path_pixels;    /* P = sum over paths of clipped bbox rows*cols (SURVEY 8d unit)      */

@@ -98,6 +98,7 @@ _PROTOS = {
     "svgr_batch_all_edges": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "svgr_batch_render": (C.c_int, [_P, _P, C.c_int, C.c_uint]),
     "svgr_batch_render_window": (C.c_int, [_P, _P, C.c_int, C.c_uint, _P]),
+    "svgr_batch_plan_many": (C.c_int, [_P, C.c_int64]),
     "svgr_batch_owned_rows": (C.c_int64, [_P]),
     "svgr_batch_timings": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "svgr_layer_over": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int]),
@@ -292,6 +293,19 @@ class Batch:
         _check(self.ctx.lib.svgr_batch_get_stats(self.handle, C.byref(st)))
         self._stats = st
         return st
+
+    @staticmethod
+    def plan_many(batches) -> None:
+        """svgr_batch_plan for all of `batches` behind one wait (svgr_batch_plan_many); their `stats` are set."""
+        batches = list(batches)
+        if not batches:
+            return
+        arr = (_P * len(batches))(*[b.handle for b in batches])
+        _check(batches[0].ctx.lib.svgr_batch_plan_many(arr, len(batches)))
+        for b in batches:
+            st = BatchStats()
+            _check(b.ctx.lib.svgr_batch_get_stats(b.handle, C.byref(st)))
+            b._stats = st
 
     @property
     def stats(self) -> BatchStats:

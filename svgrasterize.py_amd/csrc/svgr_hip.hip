@@ -158,6 +158,8 @@ struct svgr_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     char name[128] = {0};
+    void* pinned = nullptr;      // page-locked staging for read-backs that must not block the host (svgr_batch_plan_many)
+    size_t pinned_bytes = 0;
 };
 // the context whose call is running on this thread (set by enter_ctx at the top of every entry point): the block cache
 // files what is allocated and released under it
@@ -2747,14 +2749,35 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
 // word is meaningful -- the tile kernel has zeroed the rest of the arena for the next render -- and it is sticky until
 // it has been read here.  `capacity_bits`: when given, capacity overflows (bits 2|4|8) are returned there instead of failing.
 // `with_bboxes`: fetch the per-path bboxes in the same round trip (one synchronisation instead of two)
+// the sticky error word of a geometry pass -> status (capacity overflows are reported apart when the caller can recover)
+static int eval_dev_err(int e, int* capacity_bits) {
+    if (capacity_bits) { *capacity_bits = e & (2 | 4 | 8 | 32); e &= ~(2 | 4 | 8 | 32); }
+    if (e & 1) return fail(SVGR_E_OVERFLOW, "flatten depth cap (%d) hit: non-finite or absurd control points", kMaxFlattenDepth);
+    if (e & 16) return fail(SVGR_E_INVALID, "path extent beyond +-1e9 pixels or non-finite");
+    if (e & (2 | 4 | 8 | 32)) return fail(SVGR_E_OVERFLOW, "work buffer capacity exceeded (err bits %d): call svgr_batch_plan again", e);
+    return 0;
+}
+// enqueue the read-back of a pass's scalars (and bboxes) into the batch's host copies; valid after the stream has drained
+// (`staging`: page-locked memory of sizeof(BatchDev) + 16 bytes per path -- a copy into pageable memory blocks the host until
+//  it is done, which is what svgr_batch_plan_many is there to avoid; take_readback moves it into the host copies afterwards)
+static int issue_readback(svgr_batch* b, bool with_bboxes, void* staging = nullptr) {
+    void* bd_dst = staging ? staging : (void*)&b->host_bd;
+    HIPCHK(hipMemcpyAsync(bd_dst, b->bd(), sizeof(BatchDev), hipMemcpyDeviceToHost, b->ctx->stream));
+    if (with_bboxes) {
+        b->host_bbox.resize(4 * (size_t)b->n_paths);
+        void* bb_dst = staging ? (void*)((char*)staging + sizeof(BatchDev)) : (void*)b->host_bbox.data();
+        HIPCHK(hipMemcpyAsync(bb_dst, b->bbox.p, sizeof(int) * 4 * (size_t)b->n_paths, hipMemcpyDeviceToHost, b->ctx->stream));
+    }
+    return 0;
+}
+static void take_readback(svgr_batch* b, const void* staging) {
+    memcpy(&b->host_bd, staging, sizeof(BatchDev));
+    memcpy(b->host_bbox.data(), (const char*)staging + sizeof(BatchDev), sizeof(int) * 4 * (size_t)b->n_paths);
+}
 static int check_dev_err(svgr_batch* b, int* capacity_bits = nullptr, bool whole = true, bool with_bboxes = false) {
     int e = 0;
     if (whole) {
-        HIPCHK(hipMemcpyAsync(&b->host_bd, b->bd(), sizeof(BatchDev), hipMemcpyDeviceToHost, b->ctx->stream));
-        if (with_bboxes) {
-            b->host_bbox.resize(4 * (size_t)b->n_paths);
-            HIPCHK(hipMemcpyAsync(b->host_bbox.data(), b->bbox.p, sizeof(int) * 4 * (size_t)b->n_paths, hipMemcpyDeviceToHost, b->ctx->stream));
-        }
+        if (int rc = issue_readback(b, with_bboxes)) return rc;
         HIPCHK(hipStreamSynchronize(b->ctx->stream));
         e = b->host_bd.err;
     } else {
@@ -2763,11 +2786,7 @@ static int check_dev_err(svgr_batch* b, int* capacity_bits = nullptr, bool whole
         if (e) HIPCHK(hipMemsetAsync(b->bd(), 0, sizeof(int), b->ctx->stream));
     }
     HIPCHK(hipGetLastError());
-    if (capacity_bits) { *capacity_bits = e & (2 | 4 | 8 | 32); e &= ~(2 | 4 | 8 | 32); }
-    if (e & 1) return fail(SVGR_E_OVERFLOW, "flatten depth cap (%d) hit: non-finite or absurd control points", kMaxFlattenDepth);
-    if (e & 16) return fail(SVGR_E_INVALID, "path extent beyond +-1e9 pixels or non-finite");
-    if (e & (2 | 4 | 8 | 32)) return fail(SVGR_E_OVERFLOW, "work buffer capacity exceeded (err bits %d): call svgr_batch_plan again", e);
-    return 0;
+    return eval_dev_err(e, capacity_bits);
 }
 
 // No C++ exception crosses the ABI (std::vector / std::map growth on the host can throw): the entry points that allocate
@@ -2850,6 +2869,7 @@ int svgr_shutdown(svgr_ctx* ctx) {
     (void)enter_ctx(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     g_pool.close(ctx->id);  // (its cached blocks; what it still has out is freed on return)
     delete ctx;
     return 0;
@@ -3173,7 +3193,9 @@ int svgr_batch_set_gradients(svgr_batch* b, const int32_t* path_grad, int64_t n_
 // per stage, size every buffer from bounds known on the host -- (path, band) pairs <= paths x bands exactly, edges and
 // records by a generous guess -- run the whole geometry ONCE and read the counters back once.  If a guess was too
 // small the kernels flag it and the staged plan takes over.  Returns 1 when it planned, 0 to fall back, < 0 on error.
-static int plan_speculative(svgr_batch* b) {
+// Two halves, so that svgr_batch_plan_many can put the passes of many batches behind ONE wait: spec_issue enqueues the pass
+// and its read-back (1 issued, 0 not eligible), spec_finish reads the verdict once the stream has drained.
+static int spec_issue(svgr_batch* b, void* staging = nullptr) {
     const int np = (int)b->n_paths;
     const int64_t ns = b->n_segs;
     if (!b->has_vp || ns <= 0 || ns > 4096 || np <= 0 || b->own.world > 1) return 0;
@@ -3215,16 +3237,28 @@ static int plan_speculative(svgr_batch* b) {
     rc = rc ? rc : b->size_masks(np);
     if (rc) return rc;
     if ((rc = run_geometry(b, 4, true))) return rc;
+    if ((rc = issue_readback(b, true, staging))) return rc;
+    return 1;
+}
+// 1 planned, 0 a guess was too small (the staged plan takes over), < 0 error
+static int spec_finish(svgr_batch* b) {
     int cap_bits = 0;
-    if ((rc = check_dev_err(b, &cap_bits, true, true))) return rc;
+    if (int rc = eval_dev_err(b->host_bd.err, &cap_bits)) return rc;
     if (cap_bits) return 0;
     b->n_entries = b->host_bd.entry_cursor;
     b->n_edges_live = 0;
-    for (int k = 0; k < NSH; ++k) b->n_edges_live += std::min(b->host_bd.shard[k].cursor, shard_cap);
+    for (int k = 0; k < NSH; ++k) b->n_edges_live += std::min(b->host_bd.shard[k].cursor, b->shards.cap[k]);
     b->n_bsegs = b->host_bd.bseg_cursor;
     b->planned = true;
     b->geometry_fresh = true;
     return 1;
+}
+static int plan_speculative(svgr_batch* b) {
+    const int is = spec_issue(b);
+    if (is <= 0) return is;
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    HIPCHK(hipGetLastError());
+    return spec_finish(b);
 }
 
 // k_path_rows + k_seg_select + one read-back: b->seg_list / b->n_seg_list
@@ -3269,6 +3303,67 @@ static int build_seg_list(svgr_batch* b) {
 static int batch_plan_impl(svgr_batch* b);
 int svgr_batch_plan(svgr_batch* b) {
     return abi_guard("svgr_batch_plan", [&]() { return batch_plan_impl(b); });
+}
+
+// The plans of many batches behind one wait: a document's per-node route plans dozens of small batches (one per run of
+// fills between two filter nodes), and each plan alone is a device round trip of ~0.15 ms of which the kernels are a
+// fraction.  Every batch that qualifies for the single-pass plan has its pass enqueued first; then one wait per stream;
+// the others, and those whose guesses were too small, are planned one by one as svgr_batch_plan would.
+int svgr_batch_plan_many(svgr_batch** batches, int64_t n) {
+    return abi_guard("svgr_batch_plan_many", [&]() {
+        if (n < 0 || (n > 0 && !batches)) return fail(SVGR_E_INVALID, "bad arguments");
+        for (int64_t i = 0; i < n; ++i)
+            if (!batches[i]) return fail(SVGR_E_INVALID, "batch %lld is NULL", (long long)i);
+        const bool no_spec = getenv("SVGR_NO_SPECULATIVE_PLAN") != nullptr;
+        std::vector<char> issued((size_t)n, 0);
+        // page-locked staging for every batch's read-back, carved from its context's slab
+        std::vector<size_t> stage_off((size_t)n, 0);
+        std::map<svgr_ctx*, size_t> stage_need;
+        for (int64_t i = 0; i < n; ++i) {
+            size_t& need = stage_need[batches[i]->ctx];
+            stage_off[(size_t)i] = need;
+            need += (sizeof(BatchDev) + 16 * (size_t)batches[i]->n_paths + 255) & ~(size_t)255;
+        }
+        for (auto& kv : stage_need) {
+            svgr_ctx* c = kv.first;
+            if (c->pinned_bytes >= kv.second) continue;
+            HIPCHK(enter_ctx(c));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (c->pinned) (void)hipHostFree(c->pinned);
+            c->pinned = nullptr;
+            c->pinned_bytes = 0;
+            const size_t want = std::max<size_t>(kv.second + kv.second / 2, 1u << 20);
+            HIPCHK(hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+            c->pinned_bytes = want;
+        }
+        for (int64_t i = 0; i < n; ++i) {
+            svgr_batch* b = batches[i];
+            HIPCHK(enter_ctx(b->ctx));
+            b->planned = false;
+            b->geometry_fresh = false;
+            const int is = no_spec ? 0 : spec_issue(b, (char*)b->ctx->pinned + stage_off[(size_t)i]);
+            if (is < 0) return is;
+            issued[(size_t)i] = (char)is;
+        }
+        for (int64_t i = 0; i < n; ++i)
+            if (issued[(size_t)i]) {
+                HIPCHK(enter_ctx(batches[i]->ctx));
+                HIPCHK(hipStreamSynchronize(batches[i]->ctx->stream));  // (a no-op for the later batches of the same stream)
+                HIPCHK(hipGetLastError());
+                take_readback(batches[i], (const char*)batches[i]->ctx->pinned + stage_off[(size_t)i]);
+            }
+        for (int64_t i = 0; i < n; ++i) {
+            svgr_batch* b = batches[i];
+            int done = 0;
+            if (issued[(size_t)i]) {
+                done = spec_finish(b);
+                if (done < 0) return done;
+            }
+            if (!done)
+                if (int rc = batch_plan_impl(b)) return rc;
+        }
+        return 0;
+    });
 }
 
 static int batch_plan_impl(svgr_batch* b) {

@@ -148,22 +148,30 @@ class Scene(tuple):
         """Render graph; returns ``(Layer, ConvexHull)`` or ``None`` (S:649-752).
 
         The outermost call first renders, in ONE batch, every ``Path.mask`` the per-node route is going to ask for
-        (clip paths, gradient-filled paths): hundreds of single-path launches become one."""
+        (clip paths, gradient-filled paths): hundreds of single-path launches become one.  It also builds the batch of every
+        run of fills the walk will meet and plans them all behind one wait (``svgr_batch_plan_many``)."""
         from . import geometry  # noqa: PLC0415
 
         if geometry.MASK_PREFETCH is not None or viewport is None or self[0] in (RENDER_FILL, RENDER_STROKE):
             return self._render(transform, mask_only, viewport, linear_rgb)
-        global _LEAF_MEMO
+        global _LEAF_MEMO, _RUN_PLANS
         jobs: list = []
+        runs: list = []
         _LEAF_MEMO = {}
         try:
-            _collect_mask_jobs(self, transform, mask_only, linear_rgb, jobs)
+            _collect_mask_jobs(self, transform, mask_only, linear_rgb, jobs, runs)
             if len(jobs) >= 4:
                 geometry.MASK_PREFETCH = geometry.MaskPrefetch(jobs, viewport)
+            if len(runs) >= 2:
+                _RUN_PLANS = _plan_runs(runs, viewport)
             return self._render(transform, mask_only, viewport, linear_rgb)
         finally:
             geometry.MASK_PREFETCH = None
             _LEAF_MEMO = None
+            if _RUN_PLANS:
+                for _leaves, batch in _RUN_PLANS.values():  # (runs the walk did not come to after all)
+                    batch.destroy()
+            _RUN_PLANS = None
 
     def _render(self, transform: Transform, mask_only: bool = False, viewport=None, linear_rgb: bool = False):
         kind, args = self
@@ -270,10 +278,11 @@ class Scene(tuple):
         return _batchable_leaves(self, transform, linear_rgb)
 
 
-def _collect_mask_jobs(scene: Scene, transform: Transform, mask_only: bool, linear_rgb: bool, jobs: list) -> None:
+def _collect_mask_jobs(scene: Scene, transform: Transform, mask_only: bool, linear_rgb: bool, jobs: list, runs=None) -> None:
     """(path, transform, rule) of every Path.mask the per-node route of `render` will call: leaves rendered
     ``mask_only`` (clip subtrees) and gradient-filled leaves.  Mirrors the routing of `_render`; a wrong guess only
-    costs an unused mask or an on-demand one."""
+    costs an unused mask or an on-demand one.  `runs` (a list) also receives every run of batchable leaves a GROUP will
+    flush, in the order of the walk."""
     from .paint import needs_mask  # noqa: PLC0415
 
     kind, args = scene
@@ -285,19 +294,63 @@ def _collect_mask_jobs(scene: Scene, transform: Transform, mask_only: bool, line
         if mask_only or needs_mask(args[1]):
             jobs.append((_stroked(scene), transform, None))
     elif kind == RENDER_GROUP:
+        run: list = []
         for child in args:
-            if not mask_only and _leaves_memo(child, transform, linear_rgb, store=True) is not None:
-                continue  # goes into a solid-fill batch
-            _collect_mask_jobs(child, transform, mask_only, linear_rgb, jobs)
+            leaves = None if mask_only else _leaves_memo(child, transform, linear_rgb, store=True)
+            if leaves is not None:
+                run.extend(leaves)  # goes into a solid-fill batch
+                continue
+            if run and runs is not None:
+                runs.append(run)
+            run = []
+            _collect_mask_jobs(child, transform, mask_only, linear_rgb, jobs, runs)
+        if run and runs is not None:
+            runs.append(run)
     elif kind == RENDER_TRANSFORM:
-        _collect_mask_jobs(args[0], transform @ args[1], mask_only, linear_rgb, jobs)
+        _collect_mask_jobs(args[0], transform @ args[1], mask_only, linear_rgb, jobs, runs)
     elif kind in (RENDER_OPACITY, RENDER_FILTER):
-        _collect_mask_jobs(args[0], transform, mask_only, linear_rgb, jobs)
+        _collect_mask_jobs(args[0], transform, mask_only, linear_rgb, jobs, runs)
     elif kind == RENDER_CLIP:
         target, clip, bbox_units = args
-        _collect_mask_jobs(target, transform, mask_only, linear_rgb, jobs)
+        _collect_mask_jobs(target, transform, mask_only, linear_rgb, jobs, runs)
         if not bbox_units:  # (objectBoundingBox clips get their transform from the target's hull: on demand)
-            _collect_mask_jobs(clip, transform, True, linear_rgb, jobs)
+            _collect_mask_jobs(clip, transform, True, linear_rgb, jobs, runs)
+    elif kind == RENDER_MASK:
+        _collect_mask_jobs(args[0], transform, mask_only, linear_rgb, jobs, runs)
+
+
+_RUN_PLANS: "dict | None" = None  # during one top-level render: run key -> (leaves, planned batch), from the pre-pass
+
+
+def _run_key(run):
+    """Identity of a run of leaves: the leaf tuples come out of the per-render memo, the same objects in both walks."""
+    return (len(run), id(run[0]), id(run[-1]))
+
+
+def _plan_runs(runs, viewport):
+    """Build the batch of every run and plan them all behind one wait.  A run that fails to build is left to `_render_run`
+    (which then raises where the reference would)."""
+    plans, batches = {}, []
+    for run in runs:
+        key = _run_key(run)
+        if key in plans:
+            continue
+        leaves = _drop_empty(run)
+        if not leaves:
+            continue
+        try:
+            batch = build_batch(leaves, viewport)
+        except Exception:  # noqa: BLE001
+            continue
+        plans[key] = (leaves, batch)
+        batches.append(batch)
+    try:
+        _abi.Batch.plan_many(batches)
+    except Exception:  # noqa: BLE001  (one bad batch: let every run plan for itself and report its own error)
+        for b in batches:
+            b.destroy()
+        return {}
+    return plans
 
 
 _LEAF_MEMO: "dict | None" = None  # during one top-level render: what the pre-pass already found out about group children
@@ -538,12 +591,16 @@ def build_batch(leaves, viewport, ctx=None) -> "_abi.Batch":
 def _render_run(leaves, viewport, linear_rgb):
     """One batch -> one Layer covering the union of the leaves' bboxes (what Layer.compose of
     the individual fill layers returns, S:366-379)."""
-    leaves = _drop_empty(leaves)
-    if not leaves:
-        return None
     ctx = _abi.Context.get()
-    batch = build_batch(leaves, viewport, ctx)
-    st = batch.plan()
+    pre = _RUN_PLANS.pop(_run_key(leaves), None) if _RUN_PLANS and leaves else None
+    if pre is not None:
+        leaves, batch = pre  # (built and planned by the pre-pass of Scene.render, together with all the other runs)
+    else:
+        leaves = _drop_empty(leaves)
+        if not leaves:
+            return None
+        batch = build_batch(leaves, viewport, ctx)
+        batch.plan()
     eff = effective_bboxes(leaves, batch.bboxes())
     boxes = [b for b in eff if b is not None]
     if not boxes:

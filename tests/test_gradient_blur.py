@@ -216,3 +216,54 @@ def test_gpu_icons_4096():
     canvas = layer.to_canvas_f32(h, w)
     c = f32_contract_counts(canvas.reshape(-1, 4)[z["full_idx"]], z["full_val"], f"icons.svg @{w}x{h} ({len(z['full_idx'])} pins)")
     assert c["other"] == 0 and c["cut"] == 0 and c["tie"] <= 2 and c["max_err"] < 1e-6, c  # (measured: 0 of every class)
+
+
+@pytest.mark.gpu
+def test_gpu_runs_of_a_document_are_planned_together(monkeypatch):
+    """Scene.render's pre-pass finds every run of fills the walk is going to flush, builds their batches and plans them
+    behind one wait (svgr_batch_plan_many).  The walk must then meet exactly those runs (every pre-planned batch is used,
+    none is planned a second time), and the picture must be the one the run-by-run plans give."""
+    import svgrasterize_amd as S
+    from svgrasterize_amd import _abi, scenedump
+    from svgrasterize_amd import scene as sm
+
+    scene, info, _z = scenedump.load_scene(os.path.join(GOLDEN, "scene_icons.npz"))
+    r = info["renders"][0]
+    hh, ww = r["size"]
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0).scale(r["scale"])
+
+    seen = {"planned": 0, "hits": 0, "runs": 0, "single_plans": 0}
+    orig_plan_runs, orig_render_run, orig_plan = sm._plan_runs, sm._render_run, _abi.Batch.plan
+
+    def plan_runs(runs, viewport):
+        plans = orig_plan_runs(runs, viewport)
+        seen["planned"] = len(plans)
+        return plans
+
+    def render_run(leaves, viewport, linear_rgb):
+        seen["runs"] += 1
+        if sm._RUN_PLANS and leaves and sm._run_key(leaves) in sm._RUN_PLANS:
+            seen["hits"] += 1
+        before = seen["single_plans"]
+        out = orig_render_run(leaves, viewport, linear_rgb)
+        seen["replanned"] = seen.get("replanned", 0) + (seen["single_plans"] - before)
+        return out
+
+    def plan(self):
+        seen["single_plans"] += 1
+        return orig_plan(self)
+
+    monkeypatch.setattr(sm, "_plan_runs", plan_runs)
+    monkeypatch.setattr(sm, "_render_run", render_run)
+    monkeypatch.setattr(_abi.Batch, "plan", plan)
+    layer, _ = scene.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
+    together = layer.to_canvas_f32(hh, ww)
+    assert seen["planned"] >= 10, seen                      # (icons.svg: the 37 filter nodes cut the paint order into runs)
+    assert seen["hits"] == seen["planned"], seen            # every batch of the pre-pass was met by the walk
+    assert seen["replanned"] == 0 or seen["runs"] > seen["hits"], seen
+    assert seen["replanned"] == seen["runs"] - seen["hits"], seen   # only runs the pre-pass did not have plan for themselves
+
+    monkeypatch.setattr(sm, "_plan_runs", lambda runs, viewport: {})
+    layer, _ = scene.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
+    one_by_one = layer.to_canvas_f32(hh, ww)
+    assert np.abs(together.astype(np.float64) - one_by_one).max() <= 2.0 ** -23   # (same kernels; LDS atomic order only)
