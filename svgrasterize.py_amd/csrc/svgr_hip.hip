@@ -2581,6 +2581,27 @@ struct svgr_batch {
     DevArr<int> seg_path;
     DevArr<unsigned char> in_dev;  // the one block the six input arrays above are views of
     std::vector<char> in_host;     // its host image: source of the single asynchronous upload, alive as long as the batch
+    // Uploads never make the host wait for the STREAM (a document's walk enqueues one batch after the other and must stay
+    // ahead of the device): what an asynchronous copy reads is a host copy kept by the batch, an event marks the last
+    // upload enqueued, and only svgr_batch_destroy -- or the next upload into the same array -- waits, for that event alone.
+    std::vector<std::vector<char>> host_keep;
+    hipEvent_t up_ev = nullptr;
+    bool up_pending = false;
+    const void* keep(const void* src, size_t n) {
+        host_keep.emplace_back((const char*)src, (const char*)src + n);
+        return host_keep.back().data();
+    }
+    hipError_t note_upload(hipStream_t st) {
+        if (!up_ev)
+            if (hipError_t e = hipEventCreateWithFlags(&up_ev, hipEventDisableTiming); e != hipSuccess) return e;
+        up_pending = true;
+        return hipEventRecord(up_ev, st);
+    }
+    void wait_uploads() {
+        if (up_pending && up_ev) (void)hipEventSynchronize(up_ev);
+        up_pending = false;
+        host_keep.clear();
+    }
     // zeroed once per render: [BatchDev | per-path min/max keys | per-path row reach (multi-GPU) | pb_cnt | pb_cursor]
     DevArr<unsigned char> arena;
     size_t arena_bytes = 0, off_pkeys = 0, off_prow = 0, off_pb_cnt = 0, off_pb_cursor = 0;
@@ -2663,6 +2684,8 @@ struct svgr_batch {
         events.clear();
         for (auto e : event_pool) (void)hipEventDestroy(e);
         event_pool.clear();
+        if (up_ev) (void)hipEventDestroy(up_ev);
+        up_ev = nullptr;
     }
 };
 
@@ -3042,6 +3065,7 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
     rc = b->in_dev.ensure(total);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(b->in_dev.p, hb, total, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = b->note_upload(ctx->stream);
         if (e != hipSuccess) rc = fail(SVGR_E_HIP, "upload: %s", hipGetErrorString(e));
     }
     if (!rc) {
@@ -3063,7 +3087,9 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
 int svgr_batch_destroy(svgr_batch* b) {
     if (!b) return 0;
     (void)enter_ctx(b->ctx);
-    (void)hipStreamSynchronize(b->ctx->stream);
+    // (kernels still in flight only touch device blocks, and those go back to this context's cache, whose next user is behind
+    //  them on the same stream; what must not go away under a running copy is the batch's HOST memory)
+    b->wait_uploads();
     b->release();
     delete b;
     return 0;
@@ -3072,8 +3098,10 @@ int svgr_batch_destroy(svgr_batch* b) {
 int svgr_batch_set_paints(svgr_batch* b, const double* path_paint) {
     if (!b || !path_paint) return fail(SVGR_E_INVALID, "bad arguments");
     HIPCHK(enter_ctx(b->ctx));
-    HIPCHK(hipMemcpyAsync(b->path_paint.p, path_paint, sizeof(double) * 4 * b->n_paths, hipMemcpyHostToDevice, b->ctx->stream));
-    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    b->wait_uploads();  // (a repeated call: the previous copy of the array may still be the source of a running upload)
+    HIPCHK(hipMemcpyAsync(b->path_paint.p, b->keep(path_paint, sizeof(double) * 4 * (size_t)b->n_paths), sizeof(double) * 4 * b->n_paths,
+                          hipMemcpyHostToDevice, b->ctx->stream));
+    HIPCHK(b->note_upload(b->ctx->stream));
     b->geometry_fresh = false;  // the cell headers carry the paint
     return 0;
 }
@@ -3083,8 +3111,10 @@ int svgr_batch_set_transforms(svgr_batch* b, const double* path_m6) {
     for (int64_t i = 0; i < 6 * b->n_paths; ++i)
         if (!std::isfinite(path_m6[i])) return fail(SVGR_E_INVALID, "non-finite transform");
     HIPCHK(enter_ctx(b->ctx));
-    HIPCHK(hipMemcpyAsync(b->path_m6.p, path_m6, sizeof(double) * 6 * b->n_paths, hipMemcpyHostToDevice, b->ctx->stream));
-    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    b->wait_uploads();
+    HIPCHK(hipMemcpyAsync(b->path_m6.p, b->keep(path_m6, sizeof(double) * 6 * (size_t)b->n_paths), sizeof(double) * 6 * b->n_paths,
+                          hipMemcpyHostToDevice, b->ctx->stream));
+    HIPCHK(b->note_upload(b->ctx->stream));
     b->planned = false;
     return 0;
 }
@@ -3129,10 +3159,11 @@ int svgr_batch_set_groups(svgr_batch* b, const int32_t* path_group, int64_t n_gr
     if (int rc = b->group_clip_src.ensure((size_t)n_groups)) return rc;
     if (int rc = b->group_opacity.ensure((size_t)n_groups)) return rc;
     hipStream_t st = b->ctx->stream;
-    HIPCHK(hipMemcpyAsync(b->path_group.p, path_group, sizeof(int) * (size_t)b->n_paths, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->group_clip_src.p, group_clip_src, sizeof(int) * (size_t)n_groups, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->group_opacity.p, group_opacity, sizeof(double) * (size_t)n_groups, hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));  // (the arrays are the caller's)
+    // (the arrays are the caller's: the uploads read copies the batch keeps)
+    HIPCHK(hipMemcpyAsync(b->path_group.p, b->keep(path_group, sizeof(int) * (size_t)b->n_paths), sizeof(int) * (size_t)b->n_paths, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->group_clip_src.p, b->keep(group_clip_src, sizeof(int) * (size_t)n_groups), sizeof(int) * (size_t)n_groups, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->group_opacity.p, b->keep(group_opacity, sizeof(double) * (size_t)n_groups), sizeof(double) * (size_t)n_groups, hipMemcpyHostToDevice, st));
+    HIPCHK(b->note_upload(st));
     b->n_groups = n_groups;
     b->geometry_fresh = false;  // the cell headers carry the group ids
     return 0;
@@ -3178,10 +3209,11 @@ int svgr_batch_set_gradients(svgr_batch* b, const int32_t* path_grad, int64_t n_
         if (int rc = b->grad_path.ensure((size_t)n_grads)) return rc;
         if (int rc = b->grad_flags.ensure((size_t)n_grads)) return rc;
         hipStream_t st = b->ctx->stream;
-        HIPCHK(hipMemcpyAsync(b->grads.p, host.data(), sizeof(GradDev) * (size_t)n_grads, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(b->path_grad.p, path_grad, sizeof(int) * (size_t)b->n_paths, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(b->grad_path.p, owner.data(), sizeof(int) * (size_t)n_grads, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));  // (host vectors of this call)
+        // (host vectors of this call and the caller's array: the uploads read copies the batch keeps)
+        HIPCHK(hipMemcpyAsync(b->grads.p, b->keep(host.data(), sizeof(GradDev) * (size_t)n_grads), sizeof(GradDev) * (size_t)n_grads, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(b->path_grad.p, b->keep(path_grad, sizeof(int) * (size_t)b->n_paths), sizeof(int) * (size_t)b->n_paths, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(b->grad_path.p, b->keep(owner.data(), sizeof(int) * (size_t)n_grads), sizeof(int) * (size_t)n_grads, hipMemcpyHostToDevice, st));
+        HIPCHK(b->note_upload(st));
         b->n_grads = n_grads;
         b->has_focal = focal;
         b->geometry_fresh = false;  // the cell headers carry the gradient indices
@@ -3604,6 +3636,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
     size_t need;
     if (layers) {
         // layer p starts at the sum of the areas (rows x cols of the clipped bbox, 0 when empty) of the paths before it
+        b->wait_uploads();  // (the previous render's copy of this table may still be running)
         b->host_layer_off.resize((size_t)b->n_paths);
         long long at = 0;
         for (int64_t p = 0; p < b->n_paths; ++p) {
@@ -3614,6 +3647,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         need = (size_t)at * sizeof(double);
         if (int rc = b->layer_off.ensure((size_t)b->n_paths)) return rc;
         HIPCHK(hipMemcpyAsync(b->layer_off.p, b->host_layer_off.data(), sizeof(long long) * (size_t)b->n_paths, hipMemcpyHostToDevice, st));
+        HIPCHK(b->note_upload(st));  // (the source is a member: svgr_batch_destroy waits for it)
     } else if (single) {
         need = (size_t)std::max(b->host_bbox[2], 0) * std::max(b->host_bbox[3], 0) * sizeof(double) * (out_kind == 3 ? 4 : 1);
     } else {
