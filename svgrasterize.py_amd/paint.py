@@ -17,6 +17,8 @@ _SPREAD = {"pad": 0, "repeat": 1, "reflect": 2}
 
 
 _STOPS_MEMO: dict = {}  # (id(stops), linear_rgb) -> (stops, converted): a gradient is usually filled many times
+_STOP_ARRAYS: dict = {}  # ... -> (stops, offsets array, colours array): what the ABI struct points at
+_D6, _D2 = C.c_double * 6, C.c_double * 2
 
 
 def _stops_colorspace(stops, linear_rgb: bool):
@@ -39,16 +41,24 @@ class _GradMixin:
         if self.spread not in _SPREAD:
             raise ValueError(f"invalid spread method: {self.spread}")
         g.spread = _SPREAD[self.spread]
-        g.user_m6 = (C.c_double * 6)(*np.asarray(user_tr.m, dtype=np.float64)[:2].ravel().tolist())
+        g.user_m6 = _D6(*np.asarray(user_tr.m, dtype=np.float64)[:2].ravel().tolist())
         if self.transform is not None:
             g.has_gt = 1
-            g.gt_m6 = (C.c_double * 6)(*np.asarray(self.transform.invert.m, dtype=np.float64)[:2].ravel().tolist())
-        stops = _stops_colorspace(self.stops, linear_rgb)
-        if not stops:
-            raise ValueError("a gradient needs at least one stop")
-        off = np.ascontiguousarray([o for o, _ in stops], dtype=np.float64)
-        col = np.ascontiguousarray([c for _, c in stops], dtype=np.float64).reshape(-1, 4)
-        g.n_stops = len(stops)
+            g.gt_m6 = _D6(*np.asarray(self.transform.invert.m, dtype=np.float64)[:2].ravel().tolist())
+        key = (id(self.stops), bool(linear_rgb))
+        hit = _STOP_ARRAYS.get(key)
+        if hit is not None and hit[0] is self.stops:
+            _stops, off, col = hit
+        else:
+            stops = _stops_colorspace(self.stops, linear_rgb)
+            if not stops:
+                raise ValueError("a gradient needs at least one stop")
+            off = np.ascontiguousarray([o for o, _ in stops], dtype=np.float64)
+            col = np.ascontiguousarray([c for _, c in stops], dtype=np.float64).reshape(-1, 4)
+            if len(_STOP_ARRAYS) > 4096:
+                _STOP_ARRAYS.clear()
+            _STOP_ARRAYS[key] = (self.stops, off, col)
+        g.n_stops = len(off)
         g.stop_off = _abi.ptr(off)
         g.stop_rgba = _abi.ptr(col)
         return off, col  # keep alive until the call returns
@@ -84,8 +94,8 @@ class GradLinear(_GradMixin, NamedTuple("GradLinear", [("p0", object), ("p1", ob
         keep = self._common(g, user_tr, linear_rgb)
         p0 = np.asarray(self.p0, dtype=np.float64)
         vec = np.asarray(self.p1, dtype=np.float64) - p0  # S:1561
-        g.p0 = (C.c_double * 2)(*p0.tolist())
-        g.vec = (C.c_double * 2)(*vec.tolist())
+        g.p0 = _D2(*p0.tolist())
+        g.vec = _D2(*vec.tolist())
         g.vv = float(np.dot(vec, vec))
         return g, keep
 
@@ -97,7 +107,7 @@ class GradRadial(_GradMixin, NamedTuple("GradRadial", [("center", object), ("rad
         g = _abi.Gradient()
         keep = self._common(g, user_tr, linear_rgb)
         center = np.asarray(self.center, dtype=np.float64)
-        g.center = (C.c_double * 2)(*center.tolist())
+        g.center = _D2(*center.tolist())
         g.radius = float(self.radius)
         if self.fcenter is None and self.fradius is None:  # S:1605
             g.kind = 2
@@ -107,9 +117,9 @@ class GradRadial(_GradMixin, NamedTuple("GradRadial", [("center", object), ("rad
         fradius = self.fradius or 0
         cd = center - fcenter                      # S:1619
         rd = self.radius - fradius                 # S:1621
-        g.fcenter = (C.c_double * 2)(*fcenter.tolist())
+        g.fcenter = _D2(*fcenter.tolist())
         g.fradius = float(fradius)
-        g.cd = (C.c_double * 2)(*cd.tolist())
+        g.cd = _D2(*cd.tolist())
         g.rd = float(rd)
         g.a = float((cd ** 2).sum() - rd ** 2)     # S:1622
         g.frad_rd = float(fradius * rd)            # S:1623
