@@ -1365,15 +1365,16 @@ struct GradDev {
 
 // position of pixel (i, j) of the layer in gradient space: grad_pixels (S:1653-1658), user transform
 // (S:1023-1027) and the gradient's own transform (S:1559 / S:1603), both in numpy's fma form
-__device__ __forceinline__ void grad_point(const GradDev& g, const double* __restrict__ pts, size_t idx, int r0, int c0, int cols,
+__device__ __forceinline__ void grad_point(const GradDev& g, const double* __restrict__ pts, int i, int j, int r0, int c0, int cols,
                                            double& x, double& y) {
     double px, py;
     if (pts) {  // Grad*.fill on a caller's coordinate array (S:1553, S:1577): the points as given
+        const size_t idx = (size_t)i * cols + j;
         px = pts[2 * idx];
         py = pts[2 * idx + 1];
     } else {
-        px = (double)(int)(idx / cols) + ((double)r0 + 0.5);
-        py = (double)(int)(idx % cols) + ((double)c0 + 0.5);
+        px = (double)i + ((double)r0 + 0.5);
+        py = (double)j + ((double)c0 + 0.5);
     }
     xform_point(g.user_m6, px, py, x, y);
     if (g.has_gt) {
@@ -1426,20 +1427,30 @@ __device__ __forceinline__ void grad_colour_user(const GradDev& g, double x, dou
     }
     col[0] = col[1] = col[2] = col[3] = 0.0;
     const int n = g.n_stops;
-    const double* const soff = g.ext_stops ? g.ext_stops : g.stop_off;               // (wave-uniform: scalar loads either way)
-    const double* const srgba = g.ext_stops ? g.ext_stops + n : &g.stop_rgba[0][0];
-    if (offset <= soff[0]) {
-        for (int k = 0; k < 4; ++k) col[k] = srgba[k];
-    }
-    if (offset > soff[n - 1]) {
-        for (int k = 0; k < 4; ++k) col[k] = srgba[4 * (n - 1) + k];
-    }
-    for (int s = 0; s + 1 < n; ++s) {
-        double o0 = soff[s], o1 = soff[s + 1];
-        if (offset > o0 && offset <= o1) {
-            double ratio = (offset - o0) / (o1 - o0);
-            for (int k = 0; k < 4; ++k) col[k] = col[k] + ((1 - ratio) * srgba[4 * s + k] + ratio * srgba[4 * (s + 1) + k]);
+    // grad_interpolate (S:1671-1683).  Two instantiations: the stops inside the description (a kernel argument for the
+    // per-node kernel: scalar loads into SGPRs) and the long lists in device memory.  One pointer chosen at run time
+    // would turn BOTH into vector loads with a wait per stop -- the per-node kernel ran at 0.4 of the streaming rate that way.
+    auto interpolate = [&](auto off_at, auto rgba_at) {
+        if (offset <= off_at(0)) {
+            for (int k = 0; k < 4; ++k) col[k] = rgba_at(0, k);
         }
+        if (offset > off_at(n - 1)) {
+            for (int k = 0; k < 4; ++k) col[k] = rgba_at(n - 1, k);
+        }
+        for (int s = 0; s + 1 < n; ++s) {
+            double o0 = off_at(s), o1 = off_at(s + 1);
+            if (offset > o0 && offset <= o1) {
+                double ratio = (offset - o0) / (o1 - o0);
+                for (int k = 0; k < 4; ++k) col[k] = col[k] + ((1 - ratio) * rgba_at(s, k) + ratio * rgba_at(s + 1, k));
+            }
+        }
+    };
+    if (g.ext_stops) {
+        const double* const eo = g.ext_stops;
+        const double* const ec = g.ext_stops + n;
+        interpolate([&](int s) { return eo[s]; }, [&](int s, int k) { return ec[4 * s + k]; });
+    } else {
+        interpolate([&](int s) { return g.stop_off[s]; }, [&](int s, int k) { return g.stop_rgba[s][k]; });
     }
     if (masked) col[0] = col[1] = col[2] = col[3] = 0.0;
 }
@@ -2347,13 +2358,19 @@ __global__ void k_to_rgba8(uchar4* __restrict__ dst, const double4* __restrict__
 }
 
 // does any pixel of the layer have det < 0 ?  (the reference only builds its exclusion mask then, S:1627)
-__global__ void k_gradient_detneg(const GradDev g, const double* __restrict__ pts, int r0, int c0, int rows, int cols,
-                                  int* __restrict__ flag) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)rows * cols) return;
-    double x, y, b;
-    grad_point(g, pts, idx, r0, c0, cols, x, y);
-    if (grad_focal_det(g, x, y, b) < 0.0) atomicOr(flag, 1);
+// (two-dimensional launches: block x = 256 columns, block y strides over the rows -- the row / column of a pixel without the
+//  64-bit division that a flat index needs per thread)
+__global__ __launch_bounds__(256) void k_gradient_detneg(const GradDev g, const double* __restrict__ pts, int r0, int c0, int rows,
+                                                        int cols, int* __restrict__ flag) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    bool neg = false;
+    for (int i = blockIdx.y; i < rows && !neg; i += gridDim.y) {
+        double x, y, b;
+        grad_point(g, pts, i, j, r0, c0, cols, x, y);
+        neg = grad_focal_det(g, x, y, b) < 0.0;
+    }
+    if (neg) atomicOr(flag, 1);
 }
 
 // Batched form for the gradient entries of a batch: block row y = gradient y; only the focal form (kind 3) has a
@@ -2368,7 +2385,7 @@ __global__ __launch_bounds__(256) void k_grad_detneg(const GradDev* __restrict__
     bool neg = false;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n && !neg; idx += (long long)gridDim.x * 256) {
         double x, y, b;
-        grad_point(g, nullptr, (size_t)idx, bb.x, bb.y, bb.w, x, y);
+        grad_point(g, nullptr, (int)(idx / bb.w), (int)(idx % bb.w), bb.x, bb.y, bb.w, x, y);
         neg = grad_focal_det(g, x, y, b) < 0.0;
     }
     if (__ballot(neg) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&flags[gi], 1);
@@ -2376,17 +2393,22 @@ __global__ __launch_bounds__(256) void k_grad_detneg(const GradDev* __restrict__
 
 // The parameter block travels as a kernel argument (1.6 KB of kernarg, read with scalar loads): no device copy of it, and
 // for linear / plain radial gradients nothing the host would have to wait for.
-__global__ void k_gradient_fill(const GradDev g, const double* __restrict__ pts, const double* __restrict__ mask, int r0, int c0,
-                                int rows, int cols, const int* __restrict__ detneg_flag, double* __restrict__ out) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)rows * cols) return;
-    double x, y;
-    grad_point(g, pts, idx, r0, c0, cols, x, y);
-    double col[4];
-    grad_colour_user(g, x, y, g.kind == 3 && *detneg_flag != 0, col);
-    const double m = mask ? mask[idx] : 1.0;  // canvas_compose(COMPOSE_IN, mask, image) = image * mask (S:1046, S:290)
-    double* o = out + 4 * idx;
-    o[0] = col[0] * m; o[1] = col[1] * m; o[2] = col[2] * m; o[3] = col[3] * m;
+__global__ __launch_bounds__(256) void k_gradient_fill(const GradDev g, const double* __restrict__ pts, const double* __restrict__ mask,
+                                                      int r0, int c0, int rows, int cols, const int* __restrict__ detneg_flag,
+                                                      double* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    const bool use_mask = g.kind == 3 && *detneg_flag != 0;
+    for (int i = blockIdx.y; i < rows; i += gridDim.y) {
+        const size_t idx = (size_t)i * cols + j;
+        double x, y;
+        grad_point(g, pts, i, j, r0, c0, cols, x, y);
+        double col[4];
+        grad_colour_user(g, x, y, use_mask, col);
+        const double m = mask ? mask[idx] : 1.0;  // canvas_compose(COMPOSE_IN, mask, image) = image * mask (S:1046, S:290)
+        double4 o = make_double4(col[0] * m, col[1] * m, col[2] * m, col[3] * m);
+        *reinterpret_cast<double4*>(out + 4 * idx) = o;
+    }
 }
 
 // --------------------------------------------------------------------------------------
@@ -3954,6 +3976,7 @@ static int gradient_run(svgr_ctx* ctx, const svgr_gradient* g, const double* pts
     fill_grad_dev(h, g);
     HIPCHK(enter_ctx(ctx));
     hipError_t e = hipSuccess;
+    const dim3 ggrid((unsigned)(((long long)bbox[3] + 255) / 256), (unsigned)std::min<long long>(bbox[2], 32768));
     double* ext = nullptr;  // long stop lists: one device block {offsets, colours}, held until the stream has drained
     if (g->n_stops <= GRAD_MAX_STOPS) {
         for (int i = 0; i < g->n_stops; ++i) {
@@ -3974,15 +3997,15 @@ static int gradient_run(svgr_ctx* ctx, const svgr_gradient* g, const double* pts
         HIPCHK(g_pool.alloc((void**)&flag, 16));
         e = hipMemsetAsync(flag, 0, 16, ctx->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_gradient_detneg, grid1(n), dim3(256), 0, ctx->stream, h, pts, (int)bbox[0], (int)bbox[1],
+            hipLaunchKernelGGL(k_gradient_detneg, ggrid, dim3(256), 0, ctx->stream, h, pts, (int)bbox[0], (int)bbox[1],
                                (int)bbox[2], (int)bbox[3], flag);
-            hipLaunchKernelGGL(k_gradient_fill, grid1(n), dim3(256), 0, ctx->stream, h, pts, mptr, (int)bbox[0], (int)bbox[1],
+            hipLaunchKernelGGL(k_gradient_fill, ggrid, dim3(256), 0, ctx->stream, h, pts, mptr, (int)bbox[0], (int)bbox[1],
                                (int)bbox[2], (int)bbox[3], (const int*)flag, (double*)out->ptr);
             e = hipGetLastError();
         }
         g_pool.release(flag);  // (stream order keeps the word's next user behind the two kernels: nothing to wait for)
     } else {
-        hipLaunchKernelGGL(k_gradient_fill, grid1(n), dim3(256), 0, ctx->stream, h, pts, mptr, (int)bbox[0], (int)bbox[1],
+        hipLaunchKernelGGL(k_gradient_fill, ggrid, dim3(256), 0, ctx->stream, h, pts, mptr, (int)bbox[0], (int)bbox[1],
                            (int)bbox[2], (int)bbox[3], (const int*)nullptr, (double*)out->ptr);
         e = hipGetLastError();
     }
