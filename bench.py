@@ -329,23 +329,37 @@ def main():
 
     def measure(batch, out, steps=None, active=True):
         """W warm-up steps, barrier, exactly K timed steps, barrier -> (max-over-ranks seconds, stage timings of this rank).
-        `active` False: this rank only takes part in the barriers (single-GPU reference inside a multi-rank run)."""
+        `active` False: this rank only takes part in the barriers (single-GPU reference inside a multi-rank run).
+        Every rank passes the same barriers and the same all-reduce whatever happens in between: a rank whose render fails
+        keeps its error until they are behind it (a rank that left early would leave the others waiting in a collective)."""
         steps = args.steps if steps is None else steps
+        err = None
         if active:
-            for _ in range(args.warmup):
-                batch.render(out, _abi.OUT_CANVAS_F32, flags)
+            try:
+                for _ in range(args.warmup):
+                    batch.render(out, _abi.OUT_CANVAS_F32, flags)
+            except Exception as exc:  # noqa: BLE001
+                err, active = exc, False
         barrier()
         if active:
             batch.timings()  # drop
         t0 = time.perf_counter()
         if active:
-            for i in range(steps):
-                batch.render(out, _abi.OUT_CANVAS_F32, flags | (_abi.RENDER_TIMED if i % every == 0 else 0))
-            ctx.sync()
+            try:
+                for i in range(steps):
+                    batch.render(out, _abi.OUT_CANVAS_F32, flags | (_abi.RENDER_TIMED if i % every == 0 else 0))
+                ctx.sync()
+            except Exception as exc:  # noqa: BLE001
+                err, active = exc, False
         t_local = time.perf_counter() - t0
         barrier()
         tm = batch.timings() if active else dict(n=0, ms_geometry=0.0, ms_tile=0.0, ms_total=0.0)
-        t_max = reduce([t_local], dist.ReduceOp.MAX)[0] if dist is not None else t_local
+        t_max, n_bad = (reduce([t_local], dist.ReduceOp.MAX)[0], reduce([1.0 if err else 0.0], dist.ReduceOp.SUM)[0]) if dist is not None \
+            else (t_local, 1.0 if err else 0.0)
+        if err is not None:
+            raise err
+        if n_bad:
+            raise RuntimeError(f"{int(n_bad)} rank(s) failed inside the measured region")
         return t_max, tm
 
     def new_batch(scene):
@@ -404,39 +418,54 @@ def main():
     if world > 1 and not args.no_companions:
         # (a) the same drawing on ONE GPU (rank 0 alone, the others wait at the barriers): the speed-up's denominator
         try:
-            batch.set_bands(0, 1, 1)
-            if rank == 0:
-                batch.plan()
-                out1 = ctx.alloc(rows * cols * 16)
-            s1, _tm1 = measure(batch, out1 if rank == 0 else None, steps=max(args.steps // 4, 10), active=rank == 0)
+            out1, prep_err = None, None
+            try:  # (what only rank 0 does must not keep it from the barriers inside measure())
+                batch.set_bands(0, 1, 1)
+                if rank == 0:
+                    batch.plan()
+                    out1 = ctx.alloc(rows * cols * 16)
+            except Exception as exc:  # noqa: BLE001
+                prep_err = exc
             n1 = max(args.steps // 4, 10)
+            s1, _tm1 = measure(batch, out1, steps=n1, active=rank == 0 and prep_err is None)
+            if prep_err is not None:
+                raise prep_err
             extras["single_gpu_same_scene"] = {
                 "ms_per_step": round(s1 / n1 * 1e3, 4), "value": round(P / (s1 / n1) / 1e6, 1), "unit": "Mpixels/s", "steps": n1,
                 "speedup_of_the_headline_over_it": round((s1 / n1) / (t_max / args.steps), 3),
             }
-            if rank == 0:
-                del out1
+            out1 = None
         except Exception as exc:  # noqa: BLE001
             extras["single_gpu_same_scene"] = {"error": repr(exc)}
         # (b) weak scaling: a drawing `world` times as tall (stacked 4096-row blocks), every rank renders its own block
         try:
-            wsc, wdesc = load_workload("synth4096")
-            wrows, wcols = int(wsc["viewport"][2]), int(wsc["viewport"][3])
-            wn = int(len(wsc["path_seg_off"]) - 1)
-            tall = synth.make_tall_scene(wrows, wn, world)
-            mine, kept = synth.rows_subscene(tall, rank * wrows, (rank + 1) * wrows)
-            wb = new_batch(mine)
-            wst = wb.plan()
-            wout = ctx.alloc(wrows * wcols * 16)
-            w_max, _wtm = measure(wb, wout)
-            wP, winst = (int(v) for v in reduce([int(wst.path_pixels), len(kept)], dist.ReduceOp.SUM))
+            wb = wout = prep_err = None
+            wP_local = kept_local = 0
+            try:
+                wsc, wdesc = load_workload("synth4096")
+                wrows, wcols = int(wsc["viewport"][2]), int(wsc["viewport"][3])
+                wn = int(len(wsc["path_seg_off"]) - 1)
+                tall = synth.make_tall_scene(wrows, wn, world)
+                mine, kept = synth.rows_subscene(tall, rank * wrows, (rank + 1) * wrows)
+                wb = new_batch(mine)
+                wst = wb.plan()
+                wout = ctx.alloc(wrows * wcols * 16)
+                wP_local, kept_local = int(wst.path_pixels), len(kept)
+            except Exception as exc:  # noqa: BLE001
+                prep_err = exc
+            try:
+                w_max, _wtm = measure(wb, wout, active=prep_err is None)
+            finally:
+                wP, winst = (int(v) for v in reduce([wP_local, kept_local], dist.ReduceOp.SUM))
+            if prep_err is not None:
+                raise prep_err
             extras["weak_scaling"] = {
                 "scaling": "weak", "value": round(wP / (w_max / args.steps) / 1e6, 1), "unit": "Mpixels/s",
                 "ms_per_step": round(w_max / args.steps * 1e3, 4), "path_pixels": wP,
                 "workload": f"{world} stacked blocks of: {wdesc}; each rank renders its own {wrows}-row block from the paths whose "
                             f"control points reach it ({winst} path instances in all); no data-path collective",
             }
-            del wout
+            wout = None
             wb.destroy()
         except Exception as exc:  # noqa: BLE001
             extras["weak_scaling"] = {"error": repr(exc)}
