@@ -608,6 +608,10 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
                 edge_path[base + 1] = p;
             }
         } else {
+#ifdef SVGR_DBG_NO_SECOND_TRAVERSAL
+            if (cnt > 1000000)  // diagnostic: what the second traversal costs (edges of long lanes are left unwritten)
+#endif
+            {
             int i = 0;
             bool o2 = false;
             flatten_subtree(node, thr, kMaxFlattenDepth - FL_SUB, [&](double r0, double c0, double r1, double c1) {
@@ -618,6 +622,7 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
                 }
                 ++i;
             }, o2);
+            }
         }
     }
     // fold the lanes of a segment, then one set of atomics per segment
