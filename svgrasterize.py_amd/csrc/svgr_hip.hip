@@ -1626,8 +1626,9 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
         }
     };
 
+    // (no barrier behind the zero-fill: the barrier in front of the item loop covers it, and the mask words' load below
+    //  is in flight meanwhile)
     for (int i = tid; i < TR * ROW_STRIDE; i += NT) s_trace[i] = 0.0;
-    __syncthreads();
     if (a.arena_words) {  // nothing in this kernel reads the arena; the geometry kernels that did are finished
         const unsigned wg = t_lin, n_wg = n_tiles;
         for (unsigned i = 1 + wg * NT + tid; i < a.arena_words; i += n_wg * NT) a.arena[i] = 0u;
