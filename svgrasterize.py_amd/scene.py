@@ -389,6 +389,7 @@ _GROUP_SERIAL = [0]
 _BATCH_GROUPS = __import__("os").environ.get("SVGR_NO_BATCH_GROUPS") is None  # (off: isolated groups take the per-node route)
 _BATCH_GRADS = __import__("os").environ.get("SVGR_NO_BATCH_GRADIENTS") is None  # (off: gradient fills take the per-node route)
 _ONES = np.ones(4)
+_GRAD_ABI_MEMO: dict = {}  # (id(gradient), transform bytes, linear_rgb) -> (gradient, svgr_gradient struct, keep-alive)
 
 
 def _leaf(path, m6, rule, paint4, flags=0, group=None, grad=None):
@@ -410,7 +411,17 @@ def _gradient_leaf(path, paint, rule, transform: Transform, linear_rgb: bool, op
         return None
     if paint.spread not in _SPREAD:
         raise ValueError(f"invalid spread method: {paint.spread}")
-    g, keep = paint.abi(transform.invert, linear_rgb)
+    # the ABI description of (this gradient, this transform) is a pure function of both: packed once (the struct is copied
+    # by Batch.set_gradients, never written to)
+    key = (id(paint), transform.key(), bool(linear_rgb))
+    hit = _GRAD_ABI_MEMO.get(key)
+    if hit is not None and hit[0] is paint:
+        g, keep = hit[1], hit[2]
+    else:
+        g, keep = paint.abi(transform.invert, linear_rgb)
+        if len(_GRAD_ABI_MEMO) > 8192:
+            _GRAD_ABI_MEMO.clear()
+        _GRAD_ABI_MEMO[key] = (paint, g, keep)
     mult = _ONES if opacity is None else _ONES * opacity  # Layer.opacity over the leaf: image * opacity (S:174)
     return _leaf(path, transform.m6(), _RULES[rule], mult, grad=(g, keep))
 
