@@ -429,7 +429,9 @@ class Path:
             return None
         if isinstance(paint, np.ndarray) and paint.shape == (4,):
             paint = solid_paint(paint, linear_rgb)
-            res = self._single_batch(transform, fill_rule, viewport, paint)
+            res = FILL_PLANS.pop(fill_plan_key(self, transform, fill_rule, paint, viewport), _NO_PLAN) if FILL_PLANS else _NO_PLAN
+            if res is _NO_PLAN:  # (else: built and planned by Scene.render's pre-pass together with the document's other batches)
+                res = self._single_batch(transform, fill_rule, viewport, paint)
             if res is None:
                 return None
             ctx, batch, bb = res
@@ -575,6 +577,46 @@ class MaskPrefetch:
 
 
 MASK_PREFETCH: "MaskPrefetch | None" = None
+
+# Single-path solid fills of the per-node route that Scene.render's pre-pass has already built and planned (one wait for the
+# whole document, svgr_batch_plan_many): key -> (ctx, batch, bbox) or None (nothing to draw), consumed by Path.fill.
+FILL_PLANS: "dict | None" = None
+_NO_PLAN = object()
+
+
+def fill_plan_key(path, transform, fill_rule, paint4, viewport):
+    return (id(path), transform.key(), fill_rule, paint4.tobytes(), None if viewport is None else tuple(int(v) for v in viewport))
+
+
+def plan_fills(jobs, viewport):
+    """[(path, transform, rule, converted paint)] -> ({key: [ctx, batch, None]}, [batches]): the single-path batches
+    `Path.fill` would build, unplanned.  `finish_fill_plans` turns the entries into what `_single_batch` returns."""
+    plans, batches = {}, []
+    ctx = _abi.Context.get()
+    vp = None if viewport is None else [int(v) for v in viewport]
+    for path, transform, rule, paint4 in jobs:
+        key = fill_plan_key(path, transform, rule, paint4, viewport)
+        if key in plans or rule not in _RULES:
+            continue
+        segs, kinds = path.packed()
+        if len(segs) == 0:
+            continue
+        batch = _abi.Batch(ctx, segs, kinds, [0, len(segs)], transform.m6(), [_RULES[rule]], [paint4], viewport=vp, flatness=FLATNESS)
+        plans[key] = [ctx, batch, None]
+        batches.append(batch)
+    return plans, batches
+
+
+def finish_fill_plans(plans):
+    for key, entry in list(plans.items()):
+        ctx, batch, _ = entry
+        bb = batch.bboxes()[0]
+        if bb[2] <= 0 or bb[3] <= 0:
+            batch.destroy()
+            plans[key] = None
+        else:
+            plans[key] = (ctx, batch, bb)
+    return plans
 
 
 def _offset(bb, viewport):

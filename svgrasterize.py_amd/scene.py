@@ -157,13 +157,14 @@ class Scene(tuple):
         global _LEAF_MEMO, _RUN_PLANS
         jobs: list = []
         runs: list = []
+        fills: list = []
         _LEAF_MEMO = {}
         try:
-            _collect_mask_jobs(self, transform, mask_only, linear_rgb, jobs, runs)
+            _collect_mask_jobs(self, transform, mask_only, linear_rgb, jobs, runs, fills)
             if len(jobs) >= 4:
                 geometry.MASK_PREFETCH = geometry.MaskPrefetch(jobs, viewport)
-            if len(runs) >= 2:
-                _RUN_PLANS = _plan_runs(runs, viewport)
+            if len(runs) + len(fills) >= 2:
+                _RUN_PLANS, geometry.FILL_PLANS = _plan_runs(runs, fills, viewport, linear_rgb)
             return self._render(transform, mask_only, viewport, linear_rgb)
         finally:
             geometry.MASK_PREFETCH = None
@@ -172,6 +173,11 @@ class Scene(tuple):
                 for _leaves, batch in _RUN_PLANS.values():  # (runs the walk did not come to after all)
                     batch.destroy()
             _RUN_PLANS = None
+            if geometry.FILL_PLANS:
+                for entry in geometry.FILL_PLANS.values():
+                    if entry is not None:
+                        entry[1].destroy()
+            geometry.FILL_PLANS = None
 
     def _render(self, transform: Transform, mask_only: bool = False, viewport=None, linear_rgb: bool = False):
         kind, args = self
@@ -278,11 +284,11 @@ class Scene(tuple):
         return _batchable_leaves(self, transform, linear_rgb)
 
 
-def _collect_mask_jobs(scene: Scene, transform: Transform, mask_only: bool, linear_rgb: bool, jobs: list, runs=None) -> None:
+def _collect_mask_jobs(scene: Scene, transform: Transform, mask_only: bool, linear_rgb: bool, jobs: list, runs=None, fills=None) -> None:
     """(path, transform, rule) of every Path.mask the per-node route of `render` will call: leaves rendered
     ``mask_only`` (clip subtrees) and gradient-filled leaves.  Mirrors the routing of `_render`; a wrong guess only
     costs an unused mask or an on-demand one.  `runs` (a list) also receives every run of batchable leaves a GROUP will
-    flush, in the order of the walk."""
+    flush, in the order of the walk; `fills` the solid fills that go node by node: (path, transform, rule, paint)."""
     from .paint import needs_mask  # noqa: PLC0415
 
     kind, args = scene
@@ -290,9 +296,13 @@ def _collect_mask_jobs(scene: Scene, transform: Transform, mask_only: bool, line
         path, paint, rule = args
         if mask_only or needs_mask(paint):
             jobs.append((path, transform, rule))
+        elif fills is not None and isinstance(paint, np.ndarray) and paint.shape == (4,):
+            fills.append((path, transform, rule, paint))
     elif kind == RENDER_STROKE:
         if mask_only or needs_mask(args[1]):
             jobs.append((_stroked(scene), transform, None))
+        elif fills is not None and isinstance(args[1], np.ndarray) and args[1].shape == (4,):
+            fills.append((_stroked(scene), transform, None, args[1]))
     elif kind == RENDER_GROUP:
         run: list = []
         for child in args:
@@ -303,20 +313,20 @@ def _collect_mask_jobs(scene: Scene, transform: Transform, mask_only: bool, line
             if run and runs is not None:
                 runs.append(run)
             run = []
-            _collect_mask_jobs(child, transform, mask_only, linear_rgb, jobs, runs)
+            _collect_mask_jobs(child, transform, mask_only, linear_rgb, jobs, runs, fills)
         if run and runs is not None:
             runs.append(run)
     elif kind == RENDER_TRANSFORM:
-        _collect_mask_jobs(args[0], transform @ args[1], mask_only, linear_rgb, jobs, runs)
+        _collect_mask_jobs(args[0], transform @ args[1], mask_only, linear_rgb, jobs, runs, fills)
     elif kind in (RENDER_OPACITY, RENDER_FILTER):
-        _collect_mask_jobs(args[0], transform, mask_only, linear_rgb, jobs, runs)
+        _collect_mask_jobs(args[0], transform, mask_only, linear_rgb, jobs, runs, fills)
     elif kind == RENDER_CLIP:
         target, clip, bbox_units = args
-        _collect_mask_jobs(target, transform, mask_only, linear_rgb, jobs, runs)
+        _collect_mask_jobs(target, transform, mask_only, linear_rgb, jobs, runs, fills)
         if not bbox_units:  # (objectBoundingBox clips get their transform from the target's hull: on demand)
-            _collect_mask_jobs(clip, transform, True, linear_rgb, jobs, runs)
+            _collect_mask_jobs(clip, transform, True, linear_rgb, jobs, runs, fills)
     elif kind == RENDER_MASK:
-        _collect_mask_jobs(args[0], transform, mask_only, linear_rgb, jobs, runs)
+        _collect_mask_jobs(args[0], transform, mask_only, linear_rgb, jobs, runs, fills)
 
 
 _RUN_PLANS: "dict | None" = None  # during one top-level render: run key -> (leaves, planned batch), from the pre-pass
@@ -327,9 +337,12 @@ def _run_key(run):
     return (len(run), id(run[0]), id(run[-1]))
 
 
-def _plan_runs(runs, viewport):
-    """Build the batch of every run and plan them all behind one wait.  A run that fails to build is left to `_render_run`
-    (which then raises where the reference would)."""
+def _plan_runs(runs, fills, viewport, linear_rgb):
+    """Build the batch of every run and of every per-node solid fill and plan them all behind one wait.  A batch that fails
+    to build is left to `_render_run` / `Path.fill` (which then raise where the reference would).
+    Returns (run plans, fill plans)."""
+    from . import geometry  # noqa: PLC0415
+
     plans, batches = {}, []
     for run in runs:
         key = _run_key(run)
@@ -345,12 +358,18 @@ def _plan_runs(runs, viewport):
         plans[key] = (leaves, batch)
         batches.append(batch)
     try:
-        _abi.Batch.plan_many(batches)
-    except Exception:  # noqa: BLE001  (one bad batch: let every run plan for itself and report its own error)
-        for b in batches:
+        fill_plans, fill_batches = geometry.plan_fills(
+            [(p, t, r, geometry.solid_paint(c, linear_rgb)) for p, t, r, c in fills], viewport)
+    except Exception:  # noqa: BLE001
+        fill_plans, fill_batches = {}, []
+    try:
+        _abi.Batch.plan_many(batches + fill_batches)
+        geometry.finish_fill_plans(fill_plans)
+    except Exception:  # noqa: BLE001  (one bad batch: let every run / fill plan for itself and report its own error)
+        for b in batches + fill_batches:
             b.destroy()
-        return {}
-    return plans
+        return {}, {}
+    return plans, fill_plans
 
 
 _LEAF_MEMO: "dict | None" = None  # during one top-level render: what the pre-pass already found out about group children

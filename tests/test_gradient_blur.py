@@ -235,10 +235,10 @@ def test_gpu_runs_of_a_document_are_planned_together(monkeypatch):
     seen = {"planned": 0, "hits": 0, "runs": 0, "single_plans": 0}
     orig_plan_runs, orig_render_run, orig_plan = sm._plan_runs, sm._render_run, _abi.Batch.plan
 
-    def plan_runs(runs, viewport):
-        plans = orig_plan_runs(runs, viewport)
-        seen["planned"] = len(plans)
-        return plans
+    def plan_runs(runs, fills, viewport, linear_rgb):
+        plans, fill_plans = orig_plan_runs(runs, fills, viewport, linear_rgb)
+        seen["planned"], seen["fills"] = len(plans), len(fill_plans)
+        return plans, fill_plans
 
     def render_run(leaves, viewport, linear_rgb):
         seen["runs"] += 1
@@ -262,8 +262,13 @@ def test_gpu_runs_of_a_document_are_planned_together(monkeypatch):
     assert seen["hits"] == seen["planned"], seen            # every batch of the pre-pass was met by the walk
     assert seen["replanned"] == 0 or seen["runs"] > seen["hits"], seen
     assert seen["replanned"] == seen["runs"] - seen["hits"], seen   # only runs the pre-pass did not have plan for themselves
+    # the solid fills that go node by node (children of filter nodes ...) were planned in the same wait and all picked up
+    from svgrasterize_amd import geometry as gm
 
-    monkeypatch.setattr(sm, "_plan_runs", lambda runs, viewport: {})
+    assert seen["fills"] >= 5 and gm.FILL_PLANS is None, seen
+    assert seen["single_plans"] <= 3, seen                          # (objectBoundingBox clips and the like plan on demand)
+
+    monkeypatch.setattr(sm, "_plan_runs", lambda runs, fills, viewport, linear_rgb: ({}, {}))
     layer, _ = scene.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
     one_by_one = layer.to_canvas_f32(hh, ww)
     assert np.abs(together.astype(np.float64) - one_by_one).max() <= 2.0 ** -23   # (same kernels; LDS atomic order only)
