@@ -2601,10 +2601,12 @@ struct svgr_batch {
     int64_t n_groups = 0;      // isolated groups (svgr_batch_set_groups)
     DevArr<int> path_group, group_clip_src;
     DevArr<double> group_opacity;
+    DevArr<char> groups_dev;   // ... one block holding the three (views), filled by ONE upload
     std::vector<uint8_t> host_rule;  // the paths' rule / flag bytes (checked against the groups)
     int64_t n_grads = 0;       // gradient-painted paths (svgr_batch_set_gradients)
     DevArr<GradDev> grads;
     DevArr<int> path_grad, grad_path, grad_flags;
+    DevArr<char> grads_dev;    // grads / path_grad / grad_path as views of one block, filled by ONE upload
     bool has_focal = false;
     // inputs
     DevArr<double> segs, path_m6, path_paint;
@@ -2708,8 +2710,8 @@ struct svgr_batch {
         segs.release(); path_m6.release(); path_paint.release(); seg_kind.release(); path_rule.release();
         seg_path.release(); in_dev.release(); arena.release(); edge_path.release(); bbox.release(); bins.release();
         bseg_off.release(); band_start.release(); band_count.release(); entries.release();
-        path_group.release(); group_clip_src.release(); group_opacity.release();
-        grads.release(); path_grad.release(); grad_path.release(); grad_flags.release();
+        path_group.release(); group_clip_src.release(); group_opacity.release(); groups_dev.release();
+        grads.release(); path_grad.release(); grad_path.release(); grad_flags.release(); grads_dev.release();
         edges.release(); bsegs.release(); cell_hdr.release(); entry_where.release(); tile_mask.release(); chunks.release(); seg_list.release(); path_list.release(); layer_off.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
@@ -3186,15 +3188,25 @@ int svgr_batch_set_groups(svgr_batch* b, const int32_t* path_group, int64_t n_gr
         if (!std::isfinite(group_opacity[g])) return fail(SVGR_E_INVALID, "group %lld: opacity is not finite", (long long)g);
     }
     HIPCHK(enter_ctx(b->ctx));
-    if (int rc = b->path_group.ensure((size_t)b->n_paths)) return rc;
-    if (int rc = b->group_clip_src.ensure((size_t)n_groups)) return rc;
-    if (int rc = b->group_opacity.ensure((size_t)n_groups)) return rc;
-    hipStream_t st = b->ctx->stream;
-    // (the arrays are the caller's: the uploads read copies the batch keeps)
-    HIPCHK(hipMemcpyAsync(b->path_group.p, b->keep(path_group, sizeof(int) * (size_t)b->n_paths), sizeof(int) * (size_t)b->n_paths, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->group_clip_src.p, b->keep(group_clip_src, sizeof(int) * (size_t)n_groups), sizeof(int) * (size_t)n_groups, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->group_opacity.p, b->keep(group_opacity, sizeof(double) * (size_t)n_groups), sizeof(double) * (size_t)n_groups, hipMemcpyHostToDevice, st));
-    HIPCHK(b->note_upload(st));
+    {
+        // one host blob -> one device block (three small pageable copies cost more than the data); the arrays are the
+        // caller's: the upload reads the copy the batch keeps
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t np = (size_t)b->n_paths, ng = (size_t)n_groups;
+        const size_t o_pg = 0, o_cs = al(o_pg + np * 4), o_op = al(o_cs + ng * 4), total = al(o_op + ng * 8);
+        std::vector<char> blob(total, 0);
+        memcpy(blob.data() + o_pg, path_group, np * 4);
+        memcpy(blob.data() + o_cs, group_clip_src, ng * 4);
+        memcpy(blob.data() + o_op, group_opacity, ng * 8);
+        b->path_group.release(); b->group_clip_src.release(); b->group_opacity.release();
+        if (int rc = b->groups_dev.ensure(total)) return rc;
+        b->path_group.point_at(b->groups_dev.p, o_pg, np);
+        b->group_clip_src.point_at(b->groups_dev.p, o_cs, ng);
+        b->group_opacity.point_at(b->groups_dev.p, o_op, ng);
+        hipStream_t st = b->ctx->stream;
+        HIPCHK(hipMemcpyAsync(b->groups_dev.p, b->keep(blob.data(), total), total, hipMemcpyHostToDevice, st));
+        HIPCHK(b->note_upload(st));
+    }
     b->n_groups = n_groups;
     b->geometry_fresh = false;  // the cell headers carry the group ids
     return 0;
@@ -3235,16 +3247,25 @@ int svgr_batch_set_gradients(svgr_batch* b, const int32_t* path_grad, int64_t n_
         for (int64_t i = 0; i < n_grads; ++i)
             if (owner[(size_t)i] < 0) return fail(SVGR_E_INVALID, "gradient %lld is not used by any path", (long long)i);
         HIPCHK(enter_ctx(b->ctx));
-        if (int rc = b->grads.ensure((size_t)n_grads)) return rc;
-        if (int rc = b->path_grad.ensure((size_t)b->n_paths)) return rc;
-        if (int rc = b->grad_path.ensure((size_t)n_grads)) return rc;
-        if (int rc = b->grad_flags.ensure((size_t)n_grads)) return rc;
-        hipStream_t st = b->ctx->stream;
-        // (host vectors of this call and the caller's array: the uploads read copies the batch keeps)
-        HIPCHK(hipMemcpyAsync(b->grads.p, b->keep(host.data(), sizeof(GradDev) * (size_t)n_grads), sizeof(GradDev) * (size_t)n_grads, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(b->path_grad.p, b->keep(path_grad, sizeof(int) * (size_t)b->n_paths), sizeof(int) * (size_t)b->n_paths, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(b->grad_path.p, b->keep(owner.data(), sizeof(int) * (size_t)n_grads), sizeof(int) * (size_t)n_grads, hipMemcpyHostToDevice, st));
-        HIPCHK(b->note_upload(st));
+        {
+            // one host blob -> one device block, as for the groups
+            auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+            const size_t np = (size_t)b->n_paths, ng = (size_t)n_grads;
+            const size_t o_g = 0, o_pg = al(o_g + ng * sizeof(GradDev)), o_gp = al(o_pg + np * 4), total = al(o_gp + ng * 4);
+            std::vector<char> blob(total, 0);
+            memcpy(blob.data() + o_g, host.data(), ng * sizeof(GradDev));
+            memcpy(blob.data() + o_pg, path_grad, np * 4);
+            memcpy(blob.data() + o_gp, owner.data(), ng * 4);
+            b->grads.release(); b->path_grad.release(); b->grad_path.release();
+            if (int rc = b->grads_dev.ensure(total)) return rc;
+            b->grads.point_at(b->grads_dev.p, o_g, ng);
+            b->path_grad.point_at(b->grads_dev.p, o_pg, np);
+            b->grad_path.point_at(b->grads_dev.p, o_gp, ng);
+            if (int rc = b->grad_flags.ensure(ng)) return rc;
+            hipStream_t st = b->ctx->stream;
+            HIPCHK(hipMemcpyAsync(b->grads_dev.p, b->keep(blob.data(), total), total, hipMemcpyHostToDevice, st));
+            HIPCHK(b->note_upload(st));
+        }
         b->n_grads = n_grads;
         b->has_focal = focal;
         b->geometry_fresh = false;  // the cell headers carry the gradient indices
