@@ -18,6 +18,8 @@ STROKE nodes are stroked by the native stroker (`Path.stroke`, csrc/svgr_stroke.
 """
 from __future__ import annotations
 
+import gc
+
 import textwrap
 
 import numpy as np
@@ -159,6 +161,11 @@ class Scene(tuple):
         runs: list = []
         fills: list = []
         _LEAF_MEMO = {}
+        # the walk allocates thousands of short-lived tuples and no cycles: the cyclic collector's generation-0 sweeps find
+        # nothing and cost 0.5-2.5 ms of a 17 ms render (profiles/gc_experiment.py), so it pauses for the call
+        gc_paused = _PAUSE_GC and gc.isenabled()
+        if gc_paused:
+            gc.disable()
         try:
             _collect_mask_jobs(self, transform, mask_only, linear_rgb, jobs, runs, fills)
             if len(jobs) >= 4:
@@ -178,6 +185,8 @@ class Scene(tuple):
                     if entry is not None:
                         entry[1].destroy()
             geometry.FILL_PLANS = None
+            if gc_paused:
+                gc.enable()
 
     def _render(self, transform: Transform, mask_only: bool = False, viewport=None, linear_rgb: bool = False):
         kind, args = self
@@ -408,6 +417,7 @@ _GROUP_SERIAL = [0]
 _BATCH_GROUPS = __import__("os").environ.get("SVGR_NO_BATCH_GROUPS") is None  # (off: isolated groups take the per-node route)
 _BATCH_GRADS = __import__("os").environ.get("SVGR_NO_BATCH_GRADIENTS") is None  # (off: gradient fills take the per-node route)
 _ONES = np.ones(4)
+_PAUSE_GC = __import__("os").environ.get("SVGR_KEEP_GC") is None  # (set: leave the cyclic collector alone during Scene.render)
 _GRAD_ABI_MEMO: dict = {}  # (id(gradient), transform bytes, linear_rgb) -> (gradient, svgr_gradient struct, keep-alive)
 
 
