@@ -154,9 +154,10 @@ class Scene(tuple):
         run of fills the walk will meet and plans them all behind one wait (``svgr_batch_plan_many``)."""
         from . import geometry  # noqa: PLC0415
 
-        if geometry.MASK_PREFETCH is not None or viewport is None or self[0] in (RENDER_FILL, RENDER_STROKE):
-            return self._render(transform, mask_only, viewport, linear_rgb)
         global _LEAF_MEMO, _RUN_PLANS
+        # (a render inside a render -- a pattern's tile -- walks without a pre-pass of its own: the outer call's state stays)
+        if _LEAF_MEMO is not None or geometry.MASK_PREFETCH is not None or viewport is None or self[0] in (RENDER_FILL, RENDER_STROKE):
+            return self._render(transform, mask_only, viewport, linear_rgb)
         jobs: list = []
         runs: list = []
         fills: list = []
