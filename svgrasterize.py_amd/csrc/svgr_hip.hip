@@ -1,9 +1,9 @@
 // svgr_hip.hip -- MI355X (gfx950 / CDNA4) anti-aliased path rasterizer: HIP kernels + C ABI.
 //
-// Pipeline of one svgr_batch_render (7 launches on the context stream, no host read-back):
+// Pipeline of one svgr_batch_render (8 launches on the context stream, no host read-back):
 //
 //   [memsets]       zero-fill of the batch's counter arena and of the tiles' entry bitmasks: only for the first render
-//                   after a plan, later ones find both cleared by the previous render's tile kernel
+//                   after a plan, later ones find both cleared by the previous render's kernels
 //   [k_path_rows]   multi-GPU only: rows each path's control-point hull can reach (foreign paths are skipped)
 //   k_flatten       32 lanes per segment: transform (fma form), stack-free adaptive subdivision,
 //                   count -> wave prefix -> ONE reservation per wave in one of 16 edge-cursor shards ->
@@ -12,19 +12,24 @@
 //                   wave-aggregated reservation of its (path, band) pair slots and (path, band, column tile) cells
 //   k_edge_count    per edge: which 16-row bands it crosses -> per-pair record counts (run-aggregated atomics)
 //   k_band_entries  per band: ordered entry list of the pairs with records, reservation of their record
-//                   blocks (contiguous per band)
+//                   blocks and add blocks (contiguous per band), first item slot of the band
 //   k_edge_emit     per edge: walk its rows with the reference's x recurrence; one 48-byte record per
 //                   row with the closed-form signed-area pieces, stored through an LDS transpose
 //   k_pair_cells    per pair: the carry-in of every tile row (sum of the pieces left of the tile), the class of every
-//                   cell (nothing visible / constant per row / has records), the tiles' entry bitmasks
+//                   cell (nothing visible / constant per row / has records), the tiles' entry bitmasks, and -- for the
+//                   cells with records -- the cell's ADD LIST: every piece, carry-in and layer-edge sentinel resolved to
+//                   {offset in the tile's delta tile, value}, so that the tile kernel's scatter is one load + one LDS add
+//   k_tile_lists    per band: bitmasks -> per-tile item lists (cell ids in paint order), the tiles in heaviest-first
+//                   order; clears the bitmasks for the next render
 //   k_tile_render   one 128-thread workgroup per 16x64 canvas tile, canvas tile resident in registers as
-//                   double RGBA; per visible cell in paint order: header + record block by LDS-DMA, scatter the
-//                   tile's own pieces into an LDS delta tile (ds_add_f64), row prefix sum from the carry-in (8 px
-//                   per lane serial + DPP row scan across the 8 lanes of a row), fill rule, paint, source-over
-//                   (isolated groups in a second register tile); one store of the finished tile (float32 or double)
+//                   double RGBA; per item in paint order: header and add list prefetched into registers items ahead;
+//                   the adds of item k+1 go into one LDS delta tile (ds_add_f64) while item k's is scanned
+//                   (8 px per lane serial + DPP row scan across the 8 lanes of a row), fill rule, paint, source-over
+//                   (isolated groups in a second register tile); one barrier per item; the finished tile leaves
+//                   through an LDS transpose as whole 1-KiB rows (float32) or as double
 //
 // There is no dense contraction anywhere in this path: no MFMA.  The heavy traffic (delta tile,
-// canvas tile) never leaves the CU; HBM sees the edge records and one canvas store.
+// canvas tile) never leaves the CU; HBM sees the edge records, the add lists and one canvas store.
 //
 // gfx950 only.  Compile with -ffp-contract=off (see svgr_core.h).
 #include <hip/hip_runtime.h>
@@ -32,6 +37,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdarg>
+#include <cstddef>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -63,39 +69,17 @@ constexpr int TC = CH * PX;                // columns per tile
 constexpr int NT = TR * CH;                // threads per workgroup (128 = 2 waves); a wave covers 64 / CH tile rows
 constexpr int CHUNK_STRIDE = PX + 2;       // doubles; +16 B makes the b128 lane groups conflict free
 constexpr int ROW_STRIDE = CH * CHUNK_STRIDE;
+constexpr int DELTA_BYTES = TR * ROW_STRIDE * 8;   // one delta tile in LDS
 static_assert(CH == 4 || CH == 8 || CH == 16 || CH == 32, "row scan: a quarter / half of a 16-lane DPP row, one, or two per tile row");
-constexpr int PREF_WAVES = NT / 64 < 3 ? NT / 64 : 3;   // waves that issue the LDS-DMA of a record block
-#ifndef SVGR_DMA_PER_WAVE
-#define SVGR_DMA_PER_WAVE 2
-#endif
-constexpr int DMA_PER_WAVE = SVGR_DMA_PER_WAVE;         // DMA instructions (1 KiB each) per issuing wave and block
-constexpr int PREF_BYTES = PREF_WAVES * DMA_PER_WAVE * 1024;
+static_assert(DELTA_BYTES < (1 << 16), "a TileAdd carries its byte offset in 16 bits");
+static_assert(TC <= 64, "a TileAdd carries its run length in 6 bits");
 #ifndef SVGR_REC_BYTES
 #define SVGR_REC_BYTES 48
 #endif
 constexpr int REC_BYTES = SVGR_REC_BYTES;             // 48, or 64 = one full HBM sector per record
-constexpr int HDR_BYTES = 48 + 8 * SVGR_TR;           // CellHdr: paint, rule, flags, class + one carry-in per tile row
-static_assert(HDR_BYTES % 16 == 0, "the cell header moves as 16-byte chunks");
-constexpr int PREF_RECS = (PREF_BYTES - HDR_BYTES) / REC_BYTES;   // records per prefetch block behind the header (81 of 4 KiB)
-#ifndef SVGR_PREF_DEPTH
-#define SVGR_PREF_DEPTH 2
-#endif
-constexpr int PREF_DEPTH = SVGR_PREF_DEPTH;             // record blocks in the ring: paths li, li+1[, li+2]
-constexpr int LCAP = 32;                                // compacted paths of a tile worked off per sub-batch
 constexpr int NW = NT / 64;                // waves per workgroup
-#ifndef SVGR_TOUCH
-#define SVGR_TOUCH 0                    // 1: warm L2 with the lines of the item after next while the next one's DMA is in flight
-#endif                                  //    (measured on synth4096: tile kernel 0.209 -> 0.219 ms, so off: the wait is not an L2 miss)
-#ifndef SVGR_XCC_MAP
-#define SVGR_XCC_MAP 1                  // tile order per XCD: consecutive tiles to one XCD (0: tile = workgroup id, dealt round-robin)
-#endif
-#ifndef SVGR_TPW
-#define SVGR_TPW 1                      // tiles per workgroup (consecutive tiles of a band, one after the other).  Measured on synth4096:
-                                        // 2 -> 0.245 ms, 4 -> 0.276 ms against 0.209: longer workgroups lengthen the tail
-#endif
-constexpr unsigned TPW = SVGR_TPW;
-#ifndef SVGR_CLASS1
-#define SVGR_CLASS1 1                   // constant-coverage cells take the composite-only path (0: through scatter + scan)
+#ifndef SVGR_ORDER
+#define SVGR_ORDER 1                    // whole-canvas launches take their tiles heaviest first (k_tile_lists); 0: in raster order
 #endif
 #ifndef SVGR_WAVES_PER_EU
 #define SVGR_WAVES_PER_EU 4             // register budget of the tile kernel: 512 / 4 = 128 VGPRs
@@ -103,8 +87,7 @@ constexpr unsigned TPW = SVGR_TPW;
 static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 1024 threads");
 
 // One row of one edge (the signed-area pieces of line_signed_coverage for that scanline, S:2250-2303),
-// computed once by k_edge_emit and applied by every tile the row reaches.  48 B = 3 x 16 B: a
-// 4 KiB LDS-DMA block holds the cell header and 81 of them.
+// computed once by k_edge_emit; k_pair_cells turns the records of a (path, band) pair into the add lists of its cells.
 struct RowRec {
     int x0i;        // unclamped layer column of the first piece
     unsigned nrow;  // bits 0-25: n = x1i - x0i (see svgr_core.h RowPieces), bits 26-31: row inside the band
@@ -114,22 +97,37 @@ struct RowRec {
 #endif
 };
 static_assert(sizeof(RowRec) == REC_BYTES, "RowRec size");
-// One (path, band, column tile) CELL, written by k_pair_cells after the records: what the tile needs besides its own
-// records.  `carry[r]` = sum of every piece of the pair's row r that lies LEFT of the tile (the running sum the row
+// One addition into a tile's LDS delta tile: everything the scatter phase of the tile kernel does for it is
+// `ds_add_f64 base + offset, v`.  A run of `len` consecutive tile columns with the same value (the middle pieces of a
+// long span, S:2286-2287) is one entry.  Written by k_pair_cells, per cell contiguous.
+struct TileAdd {
+    unsigned where;  // bits 0-15: byte offset of (tile row, tile column) in the padded delta tile; bits 16-21: len - 1;
+                     // bits 22-24: tile column & (PX - 1) of the first add (the run steps over the chunk padding)
+    unsigned zero;
+    double v;
+};
+static_assert(sizeof(TileAdd) == 16, "TileAdd is one dwordx4");
+// One (path, band, column tile) CELL = one work item of the tile kernel, written by k_pair_cells.
+// `carry[r]` = sum of every piece of the pair's row r that lies LEFT of the tile (the running sum the row
 // scan starts from, np.cumsum S:983); `cls` sorts the cells:
 //   0  no record reaches the tile and every carry-in is below the 1e-6 cut (S:990): nothing to draw, the tile
 //      never sees the cell
 //   1  no record reaches the tile but some row's carry-in is visible: coverage is constant along each row
 //      (rule(carry)), composite without scatter / scan
-//   2  records reach the tile: scatter + scan, the row sums start at the carry-in
+//   2  records reach the tile: its add list (carry-ins included) is scattered, then scan + composite
+// The first 80 bytes travel to the tile kernel as ONE load instruction (a dword per lane).
 struct CellHdr {
     double paint[4];
-    int rule, flags;   // fill rule (0 nonzero, 1 evenodd), SVGR_PATH_* flags >> 1
-    int group, cls;    // isolated group the path belongs to (-1: none); class as above
-    double carry[SVGR_TR];
+    int r0, c0, rows, cols;   // the path's layer (clipped bbox)
+    int bits;                 // bit 0: fill rule (0 nonzero, 1 evenodd); bits 1-2: SVGR_PATH_* flags >> 1; bits 3-4: class;
+                              // bits 5-: gradient index + 1 (0: solid colour)
+    int n_add, add0;          // class 2: its add list
+    int p;                    // path id
+    int group, pad[3];        // isolated group the path belongs to (-1: none)
+    double carry[SVGR_TR];    // class 1 reads them; for class 2 they are in the add list
 };
-static_assert(sizeof(CellHdr) == HDR_BYTES, "CellHdr layout");
-constexpr int PREF_RECS_MAX = 85;      // slack records behind the record array (whole-block DMA reads may overrun the last pair)
+constexpr int HDR_DWORDS = 20;    // what the tile kernel loads of it per item: everything in front of `carry`
+static_assert(sizeof(CellHdr) == 4 * HDR_DWORDS + 8 * SVGR_TR && offsetof(CellHdr, carry) == 4 * HDR_DWORDS, "CellHdr layout");
 constexpr unsigned SPAN_MAX = (1u << 26) - 1;
 static_assert(SVGR_TR <= 64, "row-in-band is stored in 6 bits");
 
@@ -394,7 +392,8 @@ static int count_owned_bands(const Owner o, int n_bands) {
 constexpr int UNION_BIAS = 1 << 30;
 struct BatchDev {
     int err;            // bit 0: flatten depth cap, bit 1: edge capacity, bit 2: (path,band) capacity,
-                        // bit 3: band-seg capacity, bit 4: bbox beyond int range, bit 5: cell capacity
+                        // bit 3: band-seg capacity, bit 4: bbox beyond int range, bit 5: cell capacity,
+                        // bit 6: add / item capacity
     int n_nonempty;
     unsigned long long path_pixels;
     int edge_spare;
@@ -404,7 +403,9 @@ struct BatchDev {
     unsigned umin_r, umin_c, umax_r, umax_c;  // union bbox: max(BIAS - lo), max(BIAS + hi)
     int cell_cursor;    // (path, band, column tile) cells
     int max_band_entries;  // longest band list (sizes the tiles' entry bitmasks)
-    int pad[2 + 16];
+    unsigned long long spare8;
+    int item_cursor;    // tile-list slots reserved (one per cell of a pair with records)
+    int pad[15];
     // Flattened edges are reserved in NSH independent shards (wave w of the flatten uses shard w % NSH): one hot
     // cursor serves only ~90 returning atomics per microsecond chip-wide, sixteen serve every wave of the launch.
     // One 128-byte line per cursor.
@@ -855,11 +856,10 @@ __global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ e
     }
 }
 
-// One tile-list entry: everything a tile needs to know about a (path, band) pair, so that the tile
-// kernel's compaction is ONE coalesced load per lane instead of a chain of four dependent gathers.
+// One band-list entry: a (path, band) pair with records.  k_pair_cells reads it whole; k_tile_lists only the first 16 bytes.
 struct TileEntry {
-    int c0, cols;     // layer columns   } the tile's hit test reads just this first
-    int cell0;        // cell of (pair, first column tile of the path): the tile's own cell is cell0 + tile - ct0   } dwordx4
+    int c0, cols;     // layer columns
+    int cell0;        // cell of (pair, first column tile of the path): the cell of column tile t is cell0 + t - ct0
     int p;            // path id
     int r0, rows;     // layer rows
     int seg0, cnt;    // records of the pair: first slot, number of records
@@ -869,7 +869,8 @@ static_assert(sizeof(TileEntry) == 32, "TileEntry is 32 bytes");
 // One workgroup per owned band, after k_edge_count: the ascending list of the paths that have records in the
 // band (TileEntry), and -- in the same pass, from the same counts -- the record block of every such
 // (path, band) pair: cnt record slots, reserved with ONE atomic per band, so that a band's blocks are contiguous
-// in HBM and in paint order; k_edge_emit fills them, k_pair_cells then sorts the pair's column tiles into classes.
+// in HBM and in paint order (k_edge_emit fills them), and the band's first tile-list slot (one slot per cell of a
+// listed pair: k_tile_lists fills them).
 constexpr int BE_BLOCK = 1024;
 constexpr int BE_KEEP = 4;   // 64-path groups per wave whose counts stay in registers between the two passes
 __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __restrict__ bins, int n_paths,
@@ -877,10 +878,12 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
                                                               const int* __restrict__ bbox, const int* __restrict__ pb_cnt,
                                                               int* __restrict__ bseg_off, int rec_cap,
                                                               int* __restrict__ band_start, int* __restrict__ band_count,
+                                                              int* __restrict__ band_item0,
                                                               TileEntry* __restrict__ entries, int2* __restrict__ entry_where,
-                                                              int entry_cap, int vc0, BatchDev* __restrict__ bd, Owner own) {
+                                                              int entry_cap, int item_cap, int vc0,
+                                                              BatchDev* __restrict__ bd, Owner own) {
     constexpr int NWV = BE_BLOCK / 64;
-    __shared__ int s_n[NWV], s_r[NWV];
+    __shared__ int s_n[NWV], s_r[NWV], s_c[NWV];
     __shared__ int s_ent0, s_rec0, s_ok;
     const int band = owned_band_at(own, blockIdx.x), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // Wave w owns the consecutive paths [w * chunk, (w + 1) * chunk), as `groups` groups of 64: lane l of group g has
@@ -888,16 +891,20 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
     const int groups = (n_paths + BE_BLOCK - 1) / BE_BLOCK, chunk = groups * 64;
     const int p_wave = wave * chunk;
     auto path_at = [&](int idx) { return plist ? plist[idx < n_paths ? idx : 0] : idx; };  // (n_paths = length of the list, if any)
+    auto ctiles_of = [&](const int4 bb) { int ct0, nct; path_ctiles(bb.y, bb.w, vc0, ct0, nct); return nct; };
     int kcnt[BE_KEEP], kpair[BE_KEEP];
     PathBin kb[BE_KEEP];
-    int my_n = 0, my_r = 0;  // this lane's entries / record slots, over all its groups
+    int4 kbb[BE_KEEP];
+    int my_n = 0, my_r = 0, my_c = 0;  // this lane's entries / record slots / cells, over all its groups
     {
         // the first BE_KEEP groups with every load of a stage in flight together (written with a branch per group, the
         // compiler waits for each group's two dependent loads in turn: 2 * BE_KEEP round trips instead of 2)
 #pragma unroll
         for (int g = 0; g < BE_KEEP; ++g) {
             const int p = p_wave + g * 64 + lane;
-            kb[g] = bins[g < groups && p < n_paths ? path_at(p) : 0];
+            const int pa = g < groups && p < n_paths ? path_at(p) : 0;
+            kb[g] = bins[pa];
+            kbb[g] = ((const int4*)bbox)[pa];
         }
         bool member[BE_KEEP];
 #pragma unroll
@@ -911,16 +918,18 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
 #pragma unroll
         for (int g = 0; g < BE_KEEP; ++g) {
             kcnt[g] = member[g] ? kcnt[g] : 0;
-            if (kcnt[g] > 0) { ++my_n; my_r += kcnt[g]; }
+            if (kcnt[g] > 0) { ++my_n; my_r += kcnt[g]; my_c += ctiles_of(kbb[g]); }
         }
     }
     // (more than BE_KEEP * 1024 paths: the rest four groups at a time, again with the loads of a stage in flight together)
-    auto load4 = [&](int g0, PathBin* tb, int* tcnt, int* tpair) {
+    auto load4 = [&](int g0, PathBin* tb, int4* tbb, int* tcnt, int* tpair) {
         bool mem[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p = p_wave + (g0 + j) * 64 + lane;
-            tb[j] = bins[g0 + j < groups && p < n_paths ? path_at(p) : 0];
+            const int pa = g0 + j < groups && p < n_paths ? path_at(p) : 0;
+            tb[j] = bins[pa];
+            tbb[j] = ((const int4*)bbox)[pa];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -935,31 +944,36 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
     };
     for (int g0 = BE_KEEP; g0 < groups; g0 += 4) {
         PathBin tb[4];
+        int4 tbb[4];
         int tcnt[4], tpair[4];
-        load4(g0, tb, tcnt, tpair);
+        load4(g0, tb, tbb, tcnt, tpair);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (tcnt[j] > 0) { ++my_n; my_r += tcnt[j]; }
+            if (tcnt[j] > 0) { ++my_n; my_r += tcnt[j]; my_c += ctiles_of(tbb[j]); }
     }
-    int wn = my_n, wr = my_r;  // wave totals
+    int wn = my_n, wr = my_r, wc = my_c;  // wave totals
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { wn += __shfl_xor(wn, d); wr += __shfl_xor(wr, d); }
-    if (lane == 0) { s_n[wave] = wn; s_r[wave] = wr; }
+    for (int d = 1; d < 64; d <<= 1) { wn += __shfl_xor(wn, d); wr += __shfl_xor(wr, d); wc += __shfl_xor(wc, d); }
+    if (lane == 0) { s_n[wave] = wn; s_r[wave] = wr; s_c[wave] = wc; }
     __syncthreads();
-    if (wave == 0) {  // exclusive scan of the wave totals by one wave, then the band's two reservations
-        const int a = lane < NWV ? s_n[lane] : 0, c = lane < NWV ? s_r[lane] : 0;
-        int tn, trc;
+    if (wave == 0) {  // exclusive scan of the wave totals by one wave, then the band's reservations
+        const int a = lane < NWV ? s_n[lane] : 0, c = lane < NWV ? s_r[lane] : 0, cc = lane < NWV ? s_c[lane] : 0;
+        int tn, trc, tcc;
         const int ea = wave_excl_scan(a, lane, tn), ec = wave_excl_scan(c, lane, trc);
+        (void)wave_excl_scan(cc, lane, tcc);
         if (lane < NWV) { s_n[lane] = ea; s_r[lane] = ec; }
         if (lane == 0) {
             int e0 = tn ? atomicAdd(&bd->entry_cursor, tn) : 0;
             int r0 = trc ? atomicAdd(&bd->bseg_cursor, trc) : 0;
+            int i0 = tcc ? atomicAdd(&bd->item_cursor, tcc) : 0;
             int ok = 1;
             if (e0 + tn > entry_cap) { atomicOr(&bd->err, 4); ok = 0; tn = 0; }
+            if (ok && (long long)i0 + tcc > (long long)item_cap) { atomicOr(&bd->err, 64); ok = 0; tn = 0; }
             if (tn) atomicMax(&bd->max_band_entries, tn);
             s_ent0 = e0; s_rec0 = r0; s_ok = ok;
             band_start[band] = e0;
             band_count[band] = tn;
+            band_item0[band] = i0;
         }
     }
     __syncthreads();
@@ -984,36 +998,24 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
         bseg_off[pair] = my_rec;
         if (my_rec + c > rec_cap) atomicOr(&bd->err, 8);
     };
-    // two groups at a time, so that their bbox loads are in flight together
-    static_assert(BE_KEEP % 2 == 0, "kept groups are written in pairs");
 #pragma unroll
-    for (int g = 0; g < BE_KEEP; g += 2) {
+    for (int g = 0; g < BE_KEEP; ++g) {
         if (g >= groups) break;
-        int me[2], mr[2];
-        int4 bb[2] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            place(kcnt[g + j], me[j], mr[j]);
-            const int p = path_at(p_wave + (g + j) * 64 + lane);
-            if (kcnt[g + j] > 0) bb[j] = ((const int4*)bbox)[p];
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (kcnt[g + j] > 0) store(path_at(p_wave + (g + j) * 64 + lane), kpair[g + j], kcnt[g + j], me[j], mr[j], bb[j], kb[g + j]);
+        int me, mr;
+        place(kcnt[g], me, mr);
+        if (kcnt[g] > 0) store(path_at(p_wave + g * 64 + lane), kpair[g], kcnt[g], me, mr, kbb[g], kb[g]);
     }
     for (int g0 = BE_KEEP; g0 < groups; g0 += 4) {
         PathBin tb[4];
-        int tcnt[4], tpair[4], me[4], mr[4];
-        load4(g0, tb, tcnt, tpair);
-        int4 bb[4];
+        int4 tbb[4];
+        int tcnt[4], tpair[4];
+        load4(g0, tb, tbb, tcnt, tpair);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (g0 + j < groups) place(tcnt[j], me[j], mr[j]);  // (whole groups only: every lane of the wave scans)
-            bb[j] = tcnt[j] > 0 ? ((const int4*)bbox)[path_at(p_wave + (g0 + j) * 64 + lane)] : make_int4(0, 0, 0, 0);
+            int me = 0, mr = 0;
+            if (g0 + j < groups) place(tcnt[j], me, mr);  // (whole groups only: every lane of the wave scans)
+            if (tcnt[j] > 0) store(path_at(p_wave + (g0 + j) * 64 + lane), tpair[j], tcnt[j], me, mr, tbb[j], tb[j]);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (tcnt[j] > 0) store(path_at(p_wave + (g0 + j) * 64 + lane), tpair[j], tcnt[j], me[j], mr[j], bb[j], tb[j]);
     }
 }
 
@@ -1212,34 +1214,80 @@ __device__ __forceinline__ double record_sum_range(int x0i, int n, const double*
     return sum;
 }
 
+// The same pieces as the ADDS a tile makes for them: `single(c, v)` for a piece at layer column c, `run(c, len, v)` for
+// len consecutive columns with the same value.  [ca, cb) are the layer columns of the cell (0 <= ca, cb <= layer width:
+// what lies right of the layer is dropped, S:2260); pieces left of the layer fold into column 0 (S:2262), the part of the
+// middle run that does as ONE add of neg * v[2].  Used twice by k_pair_cells with the same arguments: to count, then to write.
+template <class Single, class Run>
+__device__ __forceinline__ void record_adds(int x0i, int n, const double* v, int ca, int cb, Single&& single, Run&& run) {
+    auto one = [&](int xi, double val) {
+        const int c = xi > 0 ? xi : 0;
+        if (c >= ca && c < cb) single(c, val);
+    };
+    one(x0i, v[0]);
+    one(x0i + 1, v[1]);
+    if (n >= 3) {
+        const int xa = x0i + 2, xb = x0i + n - 2;  // the middle run, inclusive
+        if (xa < 0 && ca == 0) {
+            const int neg = (xb < -1 ? xb : -1) - xa + 1;
+            if (neg > 0) single(0, (double)neg * v[2]);
+        }
+        int lo = xa > 0 ? xa : 0;
+        lo = lo > ca ? lo : ca;
+        const int hi = xb < cb - 1 ? xb : cb - 1;
+        if (hi >= lo) run(lo, hi - lo + 1, v[2]);
+        one(x0i + n - 1, v[3]);
+    }
+    if (n >= 2) one(x0i + n, v[4]);
+}
+
 // is the coverage of a constant running sum visible (S:984-990) ?
 __device__ __forceinline__ bool carry_visible(double c, int rule) {
     return (rule ? fill_evenodd_raw(c) : fabs(c)) >= kZeroCut;
 }
 
-// After k_edge_emit, one wave per (path, band) pair with records: the pair's column tiles sorted into classes
-// (CellHdr), the carry-in of every tile row -- the sum of the pieces left of the tile, which the tile kernel used to
-// gather itself by folding every record of the pair, in every tile -- and the tiles' entry bitmasks.  Per record:
-// the pieces that fall into each column tile it touches are summed in closed form and added to a per-wave LDS table
-// [column tile][row] (ds_add_f64), the touched tiles are counted; then the lanes walk the tiles left to right, four
-// column tiles x 16 rows at a time, with the running sum.  Pairs wider than PC_CT column tiles take several passes
-// over their records.  (TR = 16: four column tiles per step.)  (A persistent, software-pipelined form of this kernel was slower: it is instruction bound, not
-// latency bound -- 46 000 short waves hide their own load chains.)
+// offset of tile column `tcol` (>= 0) inside a padded delta row: every chunk of PX columns is followed by
+// CHUNK_STRIDE - PX pad doubles, i.e. (tcol / PX) * CHUNK_STRIDE + tcol % PX without the multiply
+__device__ __forceinline__ int lds_col(int tcol) {
+    static_assert((PX & (PX - 1)) == 0, "PX is a power of two");
+    return tcol + (int)((unsigned)tcol / PX) * (CHUNK_STRIDE - PX);
+}
+__device__ __forceinline__ int lds_index(int trow, int tcol) {
+    return __mul24(trow, ROW_STRIDE) + lds_col(tcol);
+}
+// TileAdd::where of `len` adds starting at (tile row, tile column)
+__device__ __forceinline__ unsigned add_where(int trow, int tcol, int len) {
+    return (unsigned)(lds_index(trow, tcol) * 8) | ((unsigned)(len - 1) << 16) | ((unsigned)(tcol & (PX - 1)) << 22);
+}
+
+// After k_edge_emit, half a wave per (path, band) pair with records.  Per record: the pieces that fall into each column
+// tile it touches are summed in closed form and added to a per-pair LDS table [column tile][row] (ds_add_f64), the adds
+// they will take counted; then the lanes walk the tiles left to right, two column tiles x 16 rows at a time, with the
+// running sum = the carry-in of every tile row (np.cumsum entering the tile, S:983): class of every cell, and for the cells
+// with records the size of their add list -- carry-ins first (one add per row at the layer's first column in the tile),
+// then the layer-edge sentinels (NaN behind the layer's last column, see k_tile_render), then the pieces.  ONE reservation
+// per pair in the band's add block (the plan measured what every band needs); a second walk writes the headers, the
+// entry-bitmask bits, the carry-ins and sentinels; a second pass over the records writes the pieces.  Pairs wider than
+// PC_CT column tiles take several passes.  `adds` == nullptr: count only (the plan's measuring run).
 constexpr int PC_CT = 16;      // column tiles of a pair per pass
 constexpr int PC_BLOCK = 256;
-constexpr int PC_LANES = 32;   // lanes per pair: TWO pairs per wave.  The kernel is a chain of dependent loads per pair (entry ->
-                               // records / paint -> stores) that 46 000 one-pair waves ran seven rounds deep; half as many waves
-                               // with the same chain each halve the rounds (45 -> see DESIGN section 3)
+constexpr int PC_LANES = 32;   // lanes per pair: TWO pairs per wave (a chain of dependent loads per pair: half as many
+                               // waves with the same chain each halve the rounds)
 static_assert(PC_LANES % TR == 0, "k_pair_cells walks PC_LANES / TR column tiles per step");
-__global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __restrict__ entries, const int2* __restrict__ entry_where,
+#ifndef SVGR_PC_WAVES
+#define SVGR_PC_WAVES 4
+#endif
+__global__ __launch_bounds__(PC_BLOCK, SVGR_PC_WAVES) void k_pair_cells(const TileEntry* __restrict__ entries, const int2* __restrict__ entry_where,
                                                         const RowRec* __restrict__ recs, const double* __restrict__ path_paint,
                                                         const uint8_t* __restrict__ path_rule, const int* __restrict__ path_group,
-                                                        const int* __restrict__ path_grad, int vc0, int n_ct, int mask_words,
+                                                        const int* __restrict__ path_grad, int vr0, int vc0, int n_ct, int mask_words,
                                                         unsigned long long* __restrict__ tile_mask, CellHdr* __restrict__ cell_hdr,
-                                                        int cell_cap, BatchDev* __restrict__ bd) {
-    constexpr int PPW = 64 / PC_LANES, NSLOT = PC_BLOCK / PC_LANES, KSTEP = PC_LANES / TR;
-    __shared__ double s_sum[NSLOT][PC_CT][TR];
-    __shared__ int s_cnt[NSLOT][PC_CT];
+                                                        int cell_cap, const int2* __restrict__ band_adds, int* __restrict__ band_add_cur,
+                                                        TileAdd* __restrict__ adds, BatchDev* __restrict__ bd) {
+    constexpr int NSLOT = PC_BLOCK / PC_LANES, KSTEP = PC_LANES / TR;
+    static_assert(KSTEP == 2, "the add cursor below is advanced for two column tiles per step");
+    __shared__ double s_sum[NSLOT][PC_CT][TR + 1];   // (+1: rows of neighbouring column tiles on different banks)
+    __shared__ int s_cnt[NSLOT][PC_CT], s_pos[NSLOT][PC_CT];
     const int lane = threadIdx.x & 63, hl = lane & (PC_LANES - 1), half = lane / PC_LANES;
     const int slot = threadIdx.x / PC_LANES;                  // this pair's table in LDS
     const int e = blockIdx.x * NSLOT + slot;
@@ -1253,9 +1301,11 @@ __global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __r
     int ct0 = 0, nct = 0;
     if (active) path_ctiles(en.c0, en.cols, vc0, ct0, nct);
     else en.cnt = 0;
+    const int band = active ? where.x : 0;
+    const int2 blk = adds ? band_adds[band] : make_int2(0, 0x7fffffff);  // the band's add block {first slot, slots}
     // the tiles' entry bitmasks: per (band, column tile) two rows of mask_words words, bit i = entry i of the band's list
     // has a cell of class >= 1 (row 0) / class 2 (row 1) here.  Classes 0 simply stay unset.
-    unsigned long long* const mrow = tile_mask + ((size_t)(active ? where.x : 0) * n_ct + ct0) * 2 * mask_words + (active ? where.y >> 6 : 0);
+    unsigned long long* const mrow = tile_mask + ((size_t)band * n_ct + ct0) * 2 * mask_words + (active ? where.y >> 6 : 0);
     const unsigned long long mbit = 1ull << (where.y & 63);
     const int x_first = vc0 + ct0 * TC - en.c0;  // layer column where the path's first column tile starts (<= 0)
     const int pth = active ? en.p : 0;
@@ -1264,92 +1314,311 @@ __global__ __launch_bounds__(PC_BLOCK, 7) void k_pair_cells(const TileEntry* __r
     const int grad1 = path_grad ? path_grad[pth] + 1 : 0;  // gradient index + 1 (0: solid colour)
     const double4 paint = ((const double4*)path_paint)[pth];
     const int row_l = hl & (TR - 1), sub = hl / TR;  // this lane's row and its column tile of the KSTEP walked per step
+    // is this lane's tile row a row of the layer?  (the sentinel behind the layer's last column is set on those only)
+    const int row_abs = vr0 + band * TR + row_l;
+    const bool row_in_layer = row_abs >= en.r0 && row_abs < en.r0 + en.rows;
+    const int shift16 = half * PC_LANES + sub * TR;  // first lane of this lane's 16-lane (column tile) group in the wave
     double run = 0.0;  // the row's running sum left of the column tiles walked so far
+    auto load_rec = [&](int j, int& x0i, int& n, int& row, double* v) {
+        const RowRec* r = recs + en.seg0 + j;
+        const int4 h = *(const int4*)r;  // {x0i, nrow, v0 lo, v0 hi}
+        const double2 w0 = *(const double2*)((const char*)r + 16), w1 = *(const double2*)((const char*)r + 32);
+        v[0] = __hiloint2double(h.w, h.z); v[1] = w0.x; v[2] = w0.y; v[3] = w1.x; v[4] = w1.y;
+        x0i = h.x; n = (int)((unsigned)h.y & SPAN_MAX); row = (int)((unsigned)h.y >> 26);
+    };
+    // the column tiles [kf, kl] of this pass (relative to `base`, clipped to [0, nc)) that record (x0i, n) has pieces in
+    auto rec_tiles = [&](int x0i, int n, int base, int nc, int& kf, int& kl) {
+        const int xl = x0i + (n >= 2 ? n : 1);  // column of the last piece
+        const int cf = x0i > 0 ? x0i : 0;
+        int cl = xl > 0 ? xl : 0;
+        cl = cl < en.cols - 1 ? cl : en.cols - 1;
+        kf = (cf - x_first) / TC - base;
+        kl = (cl - x_first) / TC - base;
+        kf = kf > 0 ? kf : 0;
+        kl = kl < nc - 1 ? kl : nc - 1;
+    };
+    // layer columns [ca, cb) of column tile k of this pass
+    auto tile_cols = [&](int base, int k, int& ca, int& cb) {
+        ca = (base + k) * TC + x_first;
+        cb = ca + TC;
+        ca = ca > 0 ? ca : 0;
+        cb = cb < en.cols ? cb : en.cols;
+    };
     // (the two pairs of a wave may need different numbers of passes: the wave-level barriers are reached by both halves)
     const int nct_w = max(__builtin_amdgcn_readlane(nct, 0), __builtin_amdgcn_readlane(nct, PC_LANES % 64));
     for (int base = 0; base < nct_w; base += PC_CT) {
         int nc = nct - base < PC_CT ? nct - base : PC_CT;
         nc = nc > 0 ? nc : 0;
-        for (int i = hl; i < nc * TR; i += PC_LANES) (&s_sum[slot][0][0])[i] = 0.0;
+        for (int i = hl; i < nc * (TR + 1); i += PC_LANES) (&s_sum[slot][0][0])[i] = 0.0;
         if (hl < nc) s_cnt[slot][hl] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // ---- pass A: per column tile the row sums of the pieces inside it, and how many adds they make ----
         for (int j = hl; j < (nc > 0 ? en.cnt : 0); j += PC_LANES) {
-            const RowRec* r = recs + en.seg0 + j;
-            const int4 h = *(const int4*)r;  // {x0i, nrow, v0 lo, v0 hi}
-            const double2 w0 = *(const double2*)((const char*)r + 16), w1 = *(const double2*)((const char*)r + 32);
+            int x0i, n, row;
             double v[5];
-            v[0] = __hiloint2double(h.w, h.z); v[1] = w0.x; v[2] = w0.y; v[3] = w1.x; v[4] = w1.y;
-            const int x0i = h.x, n = (int)((unsigned)h.y & SPAN_MAX), row = (int)((unsigned)h.y >> 26);
+            load_rec(j, x0i, n, row, v);
             if (x0i >= en.cols) continue;  // the whole row lies beyond the layer (S:2260)
-            const int xl = x0i + (n >= 2 ? n : 1);  // column of the last piece
-            const int cf = x0i > 0 ? x0i : 0;
-            int cl = xl > 0 ? xl : 0;
-            cl = cl < en.cols - 1 ? cl : en.cols - 1;
-            int kf = (cf - x_first) / TC - base, kl = (cl - x_first) / TC - base;
-            if (kf == kl && xl < en.cols) {
-                // the usual case: every piece in one column tile, nothing cut off at the layer's right edge
-                if (kf >= 0 && kf < nc) {
-                    double sum = v[0] + v[1];
-                    if (n >= 3) sum = sum + (double)(n - 3) * v[2] + v[3];
-                    if (n >= 2) sum = sum + v[4];
-                    __hip_atomic_fetch_add(&s_sum[slot][kf][row], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&s_cnt[slot][kf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                continue;
-            }
-            kf = kf > 0 ? kf : 0;
-            kl = kl < nc - 1 ? kl : nc - 1;
+            int kf, kl;
+            rec_tiles(x0i, n, base, nc, kf, kl);
             for (int k = kf; k <= kl; ++k) {
-                int ca = (base + k) * TC + x_first, cb = ca + TC;
-                ca = ca > 0 ? ca : 0;
-                cb = cb < en.cols ? cb : en.cols;
+                int ca, cb;
+                tile_cols(base, k, ca, cb);
                 const double part = record_sum_range(x0i, n, v, ca, cb);
-                __hip_atomic_fetch_add(&s_sum[slot][k][row], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&s_cnt[slot][k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                int ne = 0;
+                record_adds(x0i, n, v, ca, cb, [&](int, double) { ++ne; }, [&](int, int, double) { ++ne; });
+                if (ne > 0) {
+                    __hip_atomic_fetch_add(&s_sum[slot][k][row], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&s_cnt[slot][k], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // KSTEP column tiles per step: lane (sub, row) takes column tile k4 + sub; its carry-in = run + the sums of the
-        // column tiles of this step to its left (read back from the table)
-        for (int k4 = 0; k4 < nc; k4 += KSTEP) {
-            const int k = k4 + sub;
-            double left = 0.0, all = 0.0;
+        // ---- walk the column tiles, twice: KSTEP per step, lane (sub, row) takes column tile k4 + sub; its carry-in =
+        //      run + the sums of the column tiles of this step to its left (read back from the table).  The first walk
+        //      sizes the add lists, the second -- behind the pair's reservation -- writes ----
+        int blk_at = 0;       // first slot of this pass's adds in the band's block
+        bool blk_ok = true;
+        const double run_in = run;
+#pragma unroll 1
+        for (int phase = 0; phase < 2; ++phase) {
+            int cursor = 0;   // adds of the column tiles walked so far
+            run = run_in;
+            for (int k4 = 0; k4 < nc; k4 += KSTEP) {
+                const int k = k4 + sub;
+                double left = 0.0, all = 0.0;
 #pragma unroll
-            for (int q = 0; q < KSTEP; ++q) {
-                const double sq = k4 + q < nc ? s_sum[slot][k4 + q][row_l] : 0.0;
-                left = q < sub ? left + sq : left;
-                all = all + sq;
-            }
-            const double cin = run + left;
-            const bool live = k < nc;
-            const int own = live ? s_cnt[slot][k] : 0;
-            const bool vis = live && carry_visible(cin, rule);
-            const unsigned long long vm = __ballot(vis);  // (lanes of the other pair may be masked off here: their bits are 0)
-            const unsigned long long rows_of_tile = ((1ull << TR) - 1ull) << (half * PC_LANES + sub * TR);
-            const int cls = own > 0 ? 2 : ((vm & rows_of_tile) != 0ull ? 1 : 0);
-            const int cell = en.cell0 + base + k;
-            if (live && cls != 0) {
-                if (cell < cell_cap) {
-                    CellHdr* hd = cell_hdr + cell;
-                    hd->carry[row_l] = cin;
-                    if (row_l == 0) {
-                        unsigned long long* const mw = mrow + (size_t)(base + k) * 2 * mask_words;
-                        atomicOr(mw, mbit);
-                        if (cls == 2) atomicOr(mw + mask_words, mbit);
-                        hd->paint[0] = paint.x; hd->paint[1] = paint.y; hd->paint[2] = paint.z; hd->paint[3] = paint.w;
-                        hd->rule = rule; hd->flags = (rl >> 1) | (grad1 << 2); hd->group = group; hd->cls = cls;
-                    }
-                } else if (row_l == 0) {
-                    atomicOr(&bd->err, 32);
+                for (int q = 0; q < KSTEP; ++q) {
+                    const double sq = k4 + q < nc ? s_sum[slot][k4 + q][row_l] : 0.0;
+                    left = q < sub ? left + sq : left;
+                    all = all + sq;
                 }
+                const double cin = run + left;
+                const bool live = k < nc;
+                const int own = live ? s_cnt[slot][k] : 0;
+                const bool vis = live && carry_visible(cin, rule);
+                const unsigned long long vm = __ballot(vis);  // (lanes of the other pair may be masked off here: their bits are 0)
+                const int cls = own > 0 ? 2 : (((vm >> shift16) & 0xffffull) != 0ull ? 1 : 0);
+                // class 2: the cell's add list = [carry-ins of the rows where it is not zero][sentinels][pieces]
+                const int cell_c0 = (base + k) * TC + x_first;        // layer column of the tile's column 0
+                const int t_first = cell_c0 < 0 ? -cell_c0 : 0;       // tile column of the layer's first column inside the tile
+                const int t_end = en.cols - cell_c0;                  // tile column one past the layer's last column
+                const bool want_carry = cls == 2 && cin != 0.0;
+                const bool want_sent = cls == 2 && t_end < TC && row_in_layer;
+                const unsigned cm = (unsigned)((__ballot(want_carry) >> shift16) & 0xffffull);
+                const unsigned sm = (unsigned)((__ballot(want_sent) >> shift16) & 0xffffull);
+                const int n_carry = __popc(cm), n_sent = __popc(sm);
+                const int n_add = cls == 2 ? n_carry + n_sent + own : 0;
+                // (the cells of one step take their lists in column order: the second one starts behind the first)
+                const int n_add_first = __shfl(n_add, half * PC_LANES);
+                const int off = cursor + (sub ? n_add_first : 0);
+                cursor += n_add_first + __shfl(n_add, half * PC_LANES + TR);
+                const int cell = en.cell0 + base + k;
+                if (phase == 1 && live) {
+                    if (cls != 0 && cell < cell_cap && blk_ok) {
+                        CellHdr* hd = cell_hdr + cell;
+                        hd->carry[row_l] = cin;
+                        const unsigned below = (1u << row_l) - 1u;
+                        TileAdd* const list = adds + (size_t)blk.x + blk_at + off;
+                        if (want_carry && adds) {
+                            TileAdd t;
+                            t.where = add_where(row_l, t_first, 1); t.zero = 0u; t.v = cin;
+                            list[__popc(cm & below)] = t;
+                        }
+                        if (want_sent && adds) {
+                            TileAdd t;
+                            t.where = add_where(row_l, t_end, 1); t.zero = 0u; t.v = __builtin_nan("");
+                            list[n_carry + __popc(sm & below)] = t;
+                        }
+                        if (row_l == 0) {
+                            unsigned long long* const mw = mrow + (size_t)(base + k) * 2 * mask_words;
+                            atomicOr(mw, mbit);
+                            if (cls == 2) atomicOr(mw + mask_words, mbit);
+                            hd->paint[0] = paint.x; hd->paint[1] = paint.y; hd->paint[2] = paint.z; hd->paint[3] = paint.w;
+                            hd->r0 = en.r0; hd->c0 = en.c0; hd->rows = en.rows; hd->cols = en.cols;
+                            hd->bits = rule | (((rl >> 1) & 3) << 1) | (cls << 3) | (grad1 << 5);
+                            hd->n_add = n_add; hd->add0 = blk.x + blk_at + off; hd->p = en.p;
+                            hd->group = group;
+                            s_pos[slot][k] = adds ? blk_at + off + n_carry + n_sent : -1;
+                        }
+                    } else if (row_l == 0) {
+                        if (cls != 0 && cell >= cell_cap) atomicOr(&bd->err, 32);
+                        s_pos[slot][k] = -1;
+                    }
+                }
+                run = run + all;
             }
-            run = run + all;
+            if (phase == 0) {
+                // the pair's reservation in its band's add block (one atomic per pair and pass)
+                int at = 0;
+                if (hl == 0 && cursor > 0) at = atomicAdd(&band_add_cur[band], cursor);
+                blk_at = __shfl(at, half * PC_LANES);
+                blk_ok = (long long)blk_at + cursor <= (long long)blk.y;
+                if (!blk_ok && hl == 0) atomicOr(&bd->err, 64);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- pass B: the pieces as adds, behind the carry-ins and sentinels of their cell ----
+        for (int j = hl; j < (nc > 0 && adds ? en.cnt : 0); j += PC_LANES) {
+            int x0i, n, row;
+            double v[5];
+            load_rec(j, x0i, n, row, v);
+            if (x0i >= en.cols) continue;
+            int kf, kl;
+            rec_tiles(x0i, n, base, nc, kf, kl);
+            for (int k = kf; k <= kl; ++k) {
+                int ca, cb;
+                tile_cols(base, k, ca, cb);
+                int ne = 0;
+                record_adds(x0i, n, v, ca, cb, [&](int, double) { ++ne; }, [&](int, int, double) { ++ne; });
+                if (ne == 0 || s_pos[slot][k] < 0) continue;  // (nothing here, or the cell was refused above)
+                const int pos0 = __hip_atomic_fetch_add(&s_pos[slot][k], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                TileAdd* dst = adds + (size_t)blk.x + pos0;
+                const int cell_c0 = (base + k) * TC + x_first;
+                record_adds(x0i, n, v, ca, cb,
+                            [&](int c, double val) { TileAdd t; t.where = add_where(row, c - cell_c0, 1); t.zero = 0u; t.v = val; *dst++ = t; },
+                            [&](int c, int len, double val) { TileAdd t; t.where = add_where(row, c - cell_c0, len); t.zero = 0u; t.v = val; *dst++ = t; });
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// After k_pair_cells, one workgroup per owned band: the tiles' entry bitmasks become their item lists -- the cell ids of
+// the set bits, in bit = list = paint order (class in the top bits) -- and the band's tiles are sorted by weight (number
+// of items, cells with records counting twice), heaviest first.  The launch order of the tile kernel interleaves the
+// bands' sorted lists (rank-major), which is a global heaviest-first order when the bands are alike: the long tiles
+// start first and the launch ends on short ones.  The bitmasks are cleared for the next render.
+// One lane per ITEM: an item's tile by binary search in the chunk's prefix sums, its bit by a select over the tile's words.
+struct TileSlot {
+    int band, ct;        // the tile: ordinal of its band among the owned bands, column tile
+    int item0, n_items;  // its item list
+};
+constexpr int TL_BLOCK = 1024;
+__device__ __forceinline__ int select_bit(unsigned long long m, int r) {  // position of the r-th (0-based) set bit of m
+    unsigned x = (unsigned)m;
+    int pos = 0;
+    int c = __popc(x);
+    if (r >= c) { r -= c; pos = 32; x = (unsigned)(m >> 32); }
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {
+        const unsigned lo = x & ((1u << w) - 1u);
+        c = __popc(lo);
+        if (r >= c) { r -= c; pos += w; x >>= w; } else { x = lo; }
+    }
+    return pos;
+}
+__global__ __launch_bounds__(TL_BLOCK) void k_tile_lists(const int* __restrict__ band_start, const int* __restrict__ band_item0,
+                                                         const TileEntry* __restrict__ entries, unsigned long long* __restrict__ tile_mask,
+                                                         int mask_words, int n_ct, int vc0, Owner own, int n_owned,
+                                                         int2* __restrict__ tile_info, TileSlot* __restrict__ order,
+                                                         unsigned* __restrict__ items, int item_cap, int cell_cap,
+                                                         BatchDev* __restrict__ bd) {
+    constexpr int NWV = TL_BLOCK / 64;
+    __shared__ int s_base[TL_BLOCK + 1];
+    __shared__ int s_hist[64], s_cur[64], s_wtot[NWV];
+    __shared__ int s_run;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int band = owned_band_at(own, blockIdx.x);
+    const int W = mask_words;
+    const int ent0 = band_start[band], item_band0 = band_item0[band];
+    unsigned long long* const mband = tile_mask + (size_t)band * n_ct * 2 * W;
+    auto count_tile = [&](int ct, int& n, int& n2) {
+        n = 0; n2 = 0;
+        const unsigned long long* mw = mband + (size_t)ct * 2 * W;
+        for (int w = 0; w < W; ++w) { n += __popcll(mw[w]); n2 += __popcll(mw[W + w]); }
+    };
+    auto weight_of = [&](int n, int n2) { const int w = n + n2; return w < 63 ? w : 63; };
+    if (tid < 64) s_hist[tid] = 0;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    // pass 1: histogram of the tile weights
+    for (int c0 = 0; c0 < n_ct; c0 += TL_BLOCK) {
+        const int ct = c0 + tid;
+        if (ct < n_ct) {
+            int n, n2;
+            count_tile(ct, n, n2);
+            atomicAdd(&s_hist[SVGR_ORDER ? weight_of(n, n2) : 0], 1);
         }
     }
-    (void)PPW;
+    __syncthreads();
+    if (tid < 64) {  // first rank of every weight, heaviest first
+        int before = 0;
+        for (int w = 63; w > tid; --w) before += s_hist[w];
+        s_cur[tid] = before;
+    }
+    __syncthreads();
+    // pass 2: per chunk of TL_BLOCK tiles: prefix sums -> the tiles' list slots and ranks, then the items
+    for (int c0 = 0; c0 < n_ct; c0 += TL_BLOCK) {
+        const int ct = c0 + tid;
+        int n = 0, n2 = 0;
+        if (ct < n_ct) count_tile(ct, n, n2);
+        int wtot;
+        const int excl = wave_excl_scan(n, lane, wtot);
+        if (lane == 0) s_wtot[wave] = wtot;
+        __syncthreads();
+        if (wave == 0) {
+            const int t = lane < NWV ? s_wtot[lane] : 0;
+            int tt;
+            const int ex = wave_excl_scan(t, lane, tt);
+            if (lane < NWV) s_wtot[lane] = ex;
+            if (lane == 0) s_base[TL_BLOCK] = tt;  // items of this chunk
+        }
+        __syncthreads();
+        const int run0 = s_run;  // items of the band's earlier chunks
+        const int base = s_wtot[wave] + excl;
+        s_base[tid] = base;
+        if (ct < n_ct) {
+            const int item0 = item_band0 + run0 + base;
+            const bool fits = (long long)item0 + n <= (long long)item_cap;
+            if (!fits) atomicOr(&bd->err, 64);
+            tile_info[(size_t)band * n_ct + ct] = make_int2(item0, fits ? n : 0);
+            const int rank = SVGR_ORDER ? atomicAdd(&s_cur[weight_of(n, n2)], 1) : ct;
+            TileSlot ts;
+            ts.band = (int)blockIdx.x; ts.ct = ct; ts.item0 = item0; ts.n_items = fits ? n : 0;  // (band: its ordinal among the owned ones)
+            order[(size_t)rank * n_owned + blockIdx.x] = ts;
+        }
+        __syncthreads();
+        const int total = s_base[TL_BLOCK];
+        const int n_here = n_ct - c0 < TL_BLOCK ? n_ct - c0 : TL_BLOCK;
+        for (int i = tid; i < total; i += TL_BLOCK) {
+            int lo = 0, hi = n_here;  // the last tile whose first item is <= i
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_base[mid] <= i) lo = mid; else hi = mid;
+            }
+            int r = i - s_base[lo];
+            const int tct = c0 + lo;
+            const unsigned long long* mw = mband + (size_t)tct * 2 * W;
+            int w = 0;
+            unsigned long long m = mw[0];
+            for (;;) {
+                const int c = __popcll(m);
+                if (r < c || w + 1 >= W) break;
+                r -= c;
+                m = mw[++w];
+            }
+            const int bit = select_bit(m, r);
+            const int4 eh = *(const int4*)(entries + ent0 + w * 64 + bit);  // {c0, cols, cell0, p}
+            int cell = eh.z + tct - (eh.x - vc0) / TC;
+            const unsigned cls = ((mw[W + w] >> bit) & 1ull) ? 2u : 1u;
+            cell = cell >= 0 && cell < cell_cap ? cell : 0;
+            const long long at = (long long)item_band0 + run0 + i;
+            if (at < (long long)item_cap) items[at] = (unsigned)cell | (cls << 30);
+        }
+        __syncthreads();
+        if (tid == 0) s_run = run0 + total;
+        if (ct < n_ct) {  // this tile has listed everything: its words are cleared for the next render's atomicOr
+            unsigned long long* mw = mband + (size_t)ct * 2 * W;
+            for (int w = 0; w < 2 * W; ++w) mw[w] = 0ull;
+        }
+        __syncthreads();
+    }
 }
 
 // --------------------------------------------------------------------------------------
@@ -1476,9 +1745,6 @@ __device__ __forceinline__ void grad_colour_pixel(const GradDev& g, int row, int
 // ======================================================================================
 // tile kernel
 // ======================================================================================
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
 template <int N>
 __device__ __forceinline__ double dpp_row_shr(double v) {  // lane i <- lane i-N inside a 16-lane row, else +0.0
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -1495,31 +1761,21 @@ __device__ __forceinline__ double dpp_ctrl(double v) {  // generic DPP move of a
     return __hiloint2double(hi, lo);
 }
 
-// offset of tile column `tcol` (>= 0) inside a padded delta row: every chunk of PX columns is followed by
-// CHUNK_STRIDE - PX pad doubles, i.e. (tcol / PX) * CHUNK_STRIDE + tcol % PX without the multiply
-__device__ __forceinline__ int lds_col(int tcol) {
-    static_assert((PX & (PX - 1)) == 0, "PX is a power of two");
-    return tcol + (int)((unsigned)tcol / PX) * (CHUNK_STRIDE - PX);
-}
-__device__ __forceinline__ int lds_index(int trow, int tcol) {
-    return __mul24(trow, ROW_STRIDE) + lds_col(tcol);
-}
-
 struct TileArgs {
-    const int* band_start;     // per band: first entry of its list
-    unsigned long long* tile_mask;  // per (band, column tile): which entries of the band's list have a visible cell here
-    int mask_words, n_ct;           // (k_pair_cells); each tile reads its words and clears them for the next render
+    const TileSlot* order;          // whole-canvas launches: the tiles in launch order (k_tile_lists: heaviest first)
+    const int2* tile_info;          // per (band, column tile): {first item, items} -- what a window launch looks its tiles up in
+    const unsigned* items;          // the tiles' item lists: cell id | class << 30, in paint order
+    const CellHdr* cell_hdr;        // per cell of class 1 or 2: paint, layer, fill rule, add list, carry-in of every tile row
+    const TileAdd* adds;            // add lists of the class-2 cells
+    int n_ct;                       // column tiles of the viewport
     int n_bands;                    // bands of the launch (all owned bands, or those of the render window)
+    int use_order;                  // 1: workgroup w takes order[w]; 0: the tiles of the window in raster order
     int ct0, win_ct, band0;         // render window in tiles: column tiles [ct0, ct0 + win_ct), bands from band0 (0, n_ct, 0: all)
     int win_r, win_c;               // ... its first row / column inside its first tile (0 .. TR-1 / TC-1)
     int win_rows, win_cols;         // ... its size = the extent of `out` (canvas outputs)
-    const TileEntry* entries;  // per band: the pairs with records, ascending path id
-    const RowRec* bsegs;       // record blocks: per (path, band) pair its edge-row records
-    const CellHdr* cell_hdr;        // per (pair, column tile) cell of class 1 or 2: paint, fill rule, carry-in of every tile row
-    int cell_cap;                   // cells the array holds (a batch that outgrew its plan is flagged, not read out of bounds)
     const int* group_clip_src;      // per isolated group: path id of the clip source that clips it as a whole, or -1
     const double* group_opacity;    // ... and the opacity it is faded with when it closes (1: none)
-    const GradDev* grads;           // gradient paints of the batch (CellHdr::flags carries the entry's index + 1 above bit 1)
+    const GradDev* grads;           // gradient paints of the batch (CellHdr::bits carries the entry's index + 1)
     const int* grad_flags;          // per gradient: some pixel of the fill's layer has det < 0 (k_grad_detneg, focal form)
     void* out;
     int vr0, vc0, vrows, vcols;  // viewport
@@ -1539,65 +1795,56 @@ struct TileArgs {
 // the group, which is clipped / faded as a whole when it closes (Scene.render CLIP / OPACITY over a GROUP, S:674-715)
 // GRAD (implies GROUPS): the batch contains gradient-painted paths (svgr_batch_set_gradients): their colour is evaluated per
 // visible pixel in the composite (Path.fill's gradient branch, S:1021-1047) instead of being a constant of the path
+//
+// The item loop is a software pipeline over the tile's items (cells, in paint order), all of it plain loads into
+// registers -- nothing is staged through LDS but the deltas themselves:
+//   item k+3   its header (80 bytes of CellHdr, one dword per lane of ONE load instruction) is requested
+//   item k+2   its add list (one 16-byte TileAdd per lane) and, class 1, its carry-ins are requested
+//   item k+1   its adds go into delta tile (k+1) & 1 (`ds_add_f64`, fire and forget)
+//   item k     delta tile k & 1 is read back to zero, scanned along the rows, and composited
+// with ONE barrier per item: behind it every wave's adds of item k have landed and the scan of item k-1 has returned
+// its delta tile to zero.  The adds of the next item are in flight in the LDS while this wave's lanes run the composite.
 template <int OUT, bool CLIP = false, bool GROUPS = false, bool GRAD = false>
 __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_EU)) void k_tile_render(const TileArgs a) {
     static_assert(!GROUPS || (CLIP && OUT <= 1), "groups live in the canvas variants with the clip tile");
     static_assert(!GRAD || GROUPS, "gradient entries live in the variant with the large register budget");
-    // ONE __shared__ object, carved by hand: with a second object beside the LDS-DMA staging area
-    // hipcc (ROCm 7.2) drains vmcnt(0) before every ds_read and the record prefetch stops overlapping
-    constexpr int OFF_TRACE = 0;
-    constexpr int OFF_PREF = OFF_TRACE + TR * ROW_STRIDE * 8;          // PREF_DEPTH record blocks (LDS-DMA targets)
-    constexpr int OFF_BBOX = OFF_PREF + PREF_DEPTH * PREF_BYTES;       // int4[NT]: bboxes of the compacted paths
-    constexpr int OFF_LIST = OFF_BBOX + LCAP * 16;                       // int[NT]: their ids
-    constexpr int OFF_SEG0 = OFF_LIST + LCAP * 4;                        // int[NT]: first record of the (path, band) pair
-    constexpr int OFF_SEG1 = OFF_SEG0 + LCAP * 4;                        // int[NT]: one past the last
-    constexpr int OFF_CELL = OFF_SEG1 + LCAP * 4;                        // int[NT]: the tile's cell of the pair | class << 30
-    constexpr int OFF_TOUCH = OFF_CELL + LCAP * 4;                       // 256 B nobody reads: target of the L2 warm-up loads
-    constexpr int OFF_CLIP = OFF_TOUCH + (SVGR_TOUCH ? 256 : 16);      // canvas modes: coverage tile of a clip path
-    constexpr int LDS_BYTES = OFF_CLIP + (CLIP ? TR * ROW_STRIDE * 8 : 16);
+    constexpr int OFF_CLIP = 2 * DELTA_BYTES;                                // canvas modes: coverage tile of a clip path
+    constexpr int LDS_BYTES = OFF_CLIP + (CLIP ? DELTA_BYTES : 0);
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[LDS_BYTES];
-    double* const s_trace = (double*)(s_mem + OFF_TRACE);
-    int4* const s_bbox = (int4*)(s_mem + OFF_BBOX);
-    int* const s_list = (int*)(s_mem + OFF_LIST);
-    int* const s_seg0 = (int*)(s_mem + OFF_SEG0);
-    int* const s_seg1 = (int*)(s_mem + OFF_SEG1);
-    int* const s_cell = (int*)(s_mem + OFF_CELL);
-    int clip_tag = -1;  // path whose coverage s_clip holds (canvas modes)
-    // LDS address of s_mem, once, as a scalar (the cast from the generic pointer carries a null test and a 64-bit lane value)
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)s_mem);
+    int clip_tag = -1;  // path whose coverage the clip tile holds (canvas modes)
 
-    // Workgroup -> tile, XCD-aware: the hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own
-    // L2), so workgroups w, w + 8, w + 16 ... -- one XCD -- take CONSECUTIVE tiles: the column tiles of a band, which read
-    // the same (path, band) record blocks, then meet in one L2 instead of fetching a block once per XCD.
-    const unsigned wg_lin = blockIdx.x, n_tiles = (unsigned)a.win_ct * (unsigned)a.n_bands;
-    const unsigned per_xcc = (((n_tiles + 7u) >> 3) + TPW - 1u) / TPW * TPW;  // tiles of one XCD's share, whole workgroups
-    for (unsigned tt = 0; tt < TPW; ++tt) {  // TPW consecutive tiles per workgroup, one after the other
-    const unsigned t_lin = SVGR_XCC_MAP ? (wg_lin & 7u) * per_xcc + (wg_lin >> 3) * TPW + tt : wg_lin * TPW + tt;
-    if (t_lin >= n_tiles) break;  // (the grid is rounded up)
-    // (the launch covers the column tiles [ct0, ct0 + win_ct) of the bands [band0, band0 + n_bands): the render window)
-    const int by = __builtin_amdgcn_readfirstlane((int)(t_lin / (unsigned)a.win_ct));
-    const int bx = (int)t_lin - by * a.win_ct + a.ct0;
-    int tid_ = (int)threadIdx.x;
-    if (TPW > 1) asm volatile("" : "+v"(tid_));  // (per tile: nothing derived from the thread id stays live across tiles)
-    const int tid = tid_, wave = tid >> 6, lane = tid & 63;
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int trow = tid / CH, chunk = tid % CH;
+    // which tile
+    int by, bx, item0, n_items;
+    if (a.use_order) {
+        const TileSlot ts = a.order[blockIdx.x];
+        by = __builtin_amdgcn_readfirstlane(ts.band);  // (ordinal among the owned bands)
+        bx = __builtin_amdgcn_readfirstlane(ts.ct);
+        item0 = __builtin_amdgcn_readfirstlane(ts.item0);
+        n_items = __builtin_amdgcn_readfirstlane(ts.n_items);
+    } else {
+        // (the launch covers the column tiles [ct0, ct0 + win_ct) of the bands [band0, band0 + n_bands): the render window)
+        const unsigned t_lin = blockIdx.x;
+        by = __builtin_amdgcn_readfirstlane((int)(t_lin / (unsigned)a.win_ct));
+        bx = (int)t_lin - by * a.win_ct + a.ct0;
+        const int2 ti = a.tile_info[(size_t)owned_band_at(a.own, by + a.band0) * a.n_ct + bx];
+        item0 = __builtin_amdgcn_readfirstlane(ti.x);
+        n_items = __builtin_amdgcn_readfirstlane(ti.y);
+    }
     const int band = owned_band_at(a.own, by + a.band0);
-    clip_tag = -1;
-    if (tt) __syncthreads();  // (the previous tile's last LDS reads)
-    const int tile_r0 = a.vr0 + band * TR;             // absolute row of tile row 0
-    const int tile_c0 = a.vc0 + bx * TC;  // absolute column of tile column 0
+    const int tile_r0 = a.vr0 + band * TR;  // absolute row of tile row 0
+    const int tile_c0 = a.vc0 + bx * TC;    // absolute column of tile column 0
     const int tile_c1 = tile_c0 + TC;
+#ifdef SVGR_DBG_NOITEMS
+    n_items = 0;  // diagnostic: the tile's fixed cost alone
+#endif
 
     double acc[PX][4];
 #pragma unroll
     for (int i = 0; i < PX; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0;
-#ifdef SVGR_DBG_STAMP
-    unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long tstart_ = __builtin_amdgcn_s_memrealtime();
-#endif
 #ifdef SVGR_DBG_TIMELINE
     const unsigned long long tl_start_ = __builtin_amdgcn_s_memrealtime();
-    int tl_items_ = 0;
 #endif
     // Isolated groups: while one is open its members composite into `gacc`; when an item of another group (or of none)
     // arrives, or the tile's list ends, the group is closed: multiplied by the coverage of its clip path (the clip tile, if
@@ -1606,11 +1853,12 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     // `Layer.opacity`, then the parent's OVER (S:674-715).
     double gacc[GROUPS ? PX : 1][4];
     int open_g = -1;
+    double* const my0 = (double*)s_mem + trow * ROW_STRIDE + chunk * CHUNK_STRIDE;  // this lane's 8 deltas in delta tile 0
     auto close_group = [&]() {
         if (GROUPS) {
             const int cs = a.group_clip_src[open_g];
             const double al = a.group_opacity[open_g];
-            const double* const myclip = s_trace + trow * ROW_STRIDE + chunk * CHUNK_STRIDE + (OFF_CLIP - OFF_TRACE) / 8;
+            const double* const myclip = my0 + OFF_CLIP / 8;
             const bool have_clip = cs < 0 || clip_tag == cs;
 #pragma unroll
             for (int i = 0; i < (GROUPS ? PX : 1); ++i) {
@@ -1626,506 +1874,317 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
         }
     };
 
-    // (no barrier behind the zero-fill: the barrier in front of the item loop covers it, and the mask words' load below
-    //  is in flight meanwhile)
-    for (int i = tid; i < TR * ROW_STRIDE; i += NT) s_trace[i] = 0.0;
+    // (no barrier behind the zero-fill: the barrier in front of the first scatter covers it)
+    for (int i = tid; i < 2 * TR * ROW_STRIDE; i += NT) ((double*)s_mem)[i] = 0.0;
     if (a.arena_words) {  // nothing in this kernel reads the arena; the geometry kernels that did are finished
-        const unsigned wg = t_lin, n_wg = n_tiles;
-        for (unsigned i = 1 + wg * NT + tid; i < a.arena_words; i += n_wg * NT) a.arena[i] = 0u;
+        for (unsigned i = 1u + blockIdx.x * NT + tid; i < a.arena_words; i += gridDim.x * NT) a.arena[i] = 0u;
     }
 
-    // The tile's work list = the set bits of its entry bitmask (k_pair_cells), in list = paint order.  Every wave reads
-    // the words (one per lane) and ranks them by a wave scan, so that no workgroup barrier is needed to place the items;
-    // a wave then moves the hits of its own words to the LDS lists, LCAP items per round (one round for most tiles).
-    const int W = a.mask_words;
-    unsigned long long* const mw = a.tile_mask + ((size_t)band * a.n_ct + bx) * 2 * W;
-    const int ent_begin = a.band_start[band];
-    for (int w0 = 0; w0 < W; w0 += 64) {
-        const int nw = W - w0 < 64 ? W - w0 : 64;
-        int total_all = 1;  // (known after the first round's scan)
-        for (int lo = 0; lo < total_all; lo += LCAP) {
-        int wl = lane;
-        asm volatile("" : "+v"(wl));  // (recompute the word's address here: kept across the item loop it is a scratch spill)
-        const unsigned long long m1 = wl < nw ? mw[w0 + wl] : 0ull;
-        int tot_;
-        const int before = wave_excl_scan(__popcll(m1), lane, tot_);
-        total_all = __builtin_amdgcn_readfirstlane(tot_);
-        if (total_all == 0) break;
-        const int take = total_all - lo < LCAP ? total_all - lo : LCAP;
-        for (int wi = wave; wi < nw; wi += NW) {
-            const unsigned long long mword = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(m1 >> 32), wi) << 32) |
-                                             (unsigned)__builtin_amdgcn_readlane((int)m1, wi);
-            const int bw = __builtin_amdgcn_readlane(before, wi) - lo;  // list slot of the word's first hit in this round
-            if (mword == 0ull || bw >= take || bw + __popcll(mword) <= 0) continue;
-            const int at = bw + mask_rank(mword);
-            if (((mword >> lane) & 1ull) && at >= 0 && at < take) {
-                const TileEntry e = a.entries[ent_begin + (w0 + wi) * 64 + lane];  // one 32-byte load per hit
-                const unsigned cls = ((mw[W + w0 + wi] >> lane) & 1ull) ? 2u : 1u;
-                const int cell = e.cell0 + bx - (e.c0 - a.vc0) / TC;
-                s_list[at] = e.p;
-                s_seg0[at] = e.seg0;
-                s_seg1[at] = cls == 2u && cell < a.cell_cap ? e.seg0 + e.cnt : e.seg0;  // (class 1: no record reaches the tile)
-                s_cell[at] = (int)((unsigned)(cell < a.cell_cap ? cell : 0) | (cls << 30));
-                s_bbox[at] = make_int4(e.r0, e.c0, e.rows, e.cols);
-            }
+    // ---- the pipeline's loads ----
+    // header of item j of the current round: dword `lane` of its CellHdr (zeros past the end of the list: class 0)
+    unsigned cells_v = 0u;  // lane j: item j of the round (cell id | class << 30)
+    auto load_hdr = [&](int j, int n) -> int {
+        const unsigned cw = (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63);
+        const int* src = (const int*)(a.cell_hdr + (cw & 0x3fffffffu));
+        int h = 0;
+        if (j < n && lane < HDR_DWORDS) h = src[lane];
+        return h;
+    };
+    auto hdr_cls = [&](int h) { return (__builtin_amdgcn_readlane(h, 12) >> 3) & 3; };
+    // class 2: this lane's first add of item j (its later ones, for lists longer than the workgroup, are loaded by the
+    // scatter); class 1: the carry-in of this lane's tile row, in the value half of the same registers
+    auto load_add = [&](int h, int j) -> uint4 {
+        const int n_add = __builtin_amdgcn_readlane(h, 13), add0 = __builtin_amdgcn_readlane(h, 14);
+        const int cls = hdr_cls(h);
+        uint4 e = make_uint4(0u, 0u, 0u, 0u);
+        if (cls == 2) {
+            if (tid < n_add) e = ((const uint4*)a.adds)[(size_t)add0 + tid];
+        } else if (cls == 1) {
+            const unsigned cw = (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63);
+            const uint2 c = *(const uint2*)&a.cell_hdr[cw & 0x3fffffffu].carry[trow];
+            e.z = c.x; e.w = c.y;
         }
-#ifdef SVGR_DBG_NOITEMS
-        const int total = 0;  // diagnostic: the tile's fixed cost alone (lists are built, nothing is drawn)
-#else
-        const int total = take;
-#endif
-#ifdef SVGR_DBG_TIMELINE
-        tl_items_ += total;
-#endif
-        __syncthreads();
-
-        // ------------------------------------------------------------------------------------------
-        // Work items = the tile's cells of the listed pairs.  An item's block = the cell header (paint, rule,
-        // class, carry-in per tile row) followed by the first PREF_RECS records of the pair (class 2 only).
-        // Items are streamed through a ring of PREF_DEPTH LDS blocks by LDS-DMA, one item ahead of the one
-        // being worked on.
-        //
-        // The DMA is issued from inline asm on purpose: for a __builtin LDS-DMA hipcc (ROCm 7.2) makes
-        // EVERY later ds_read wait vmcnt(0) ("may alias the DMA"), which would drain the blocks that
-        // are meant to stay in flight.  Ordering is by hand: every wave < PREF_WAVES issues exactly ONE
-        // DMA instruction per item (lanes past the end re-read the last 16 valid bytes), so with item
-        // k+1 issued, "item k has landed" is vmcnt(1) [vmcnt(0) for the last item], followed by a raw
-        // barrier (lgkmcnt only: a __syncthreads() would wait vmcnt(0)).
-        // ------------------------------------------------------------------------------------------
-        auto issue = [&](int li_, int buf_) {
-            if (wave < PREF_WAVES) {
-                // (block bounds are wave-uniform: kept in SGPRs so that the address arithmetic is scalar)
-                const int seg0_ = __builtin_amdgcn_readfirstlane(s_seg0[li_]), seg1_ = __builtin_amdgcn_readfirstlane(s_seg1[li_]);
-                const int cell_ = __builtin_amdgcn_readfirstlane(s_cell[li_]) & 0x3fffffff;
-                const int left_ = seg1_ - seg0_;
-                const int n_bytes = (left_ < PREF_RECS ? left_ : PREF_RECS) * REC_BYTES;
-                const char* const hbase = (const char*)(a.cell_hdr + cell_);
-                // chunk t of the block: the cell header first, the pair's records behind it; lanes past the end re-read
-                // the last valid 16 bytes
-                const char* const rbase = n_bytes > 0 ? (const char*)(a.bsegs + seg0_) - HDR_BYTES : hbase;
-                const int last_ = HDR_BYTES + n_bytes - 16;
-#pragma unroll
-                for (int j = 0; j < DMA_PER_WAVE; ++j) {
-                    const int t_ = (wave * DMA_PER_WAVE + j) * 64 + lane;  // 16-byte chunk of the block this lane fetches
-                    const int off_ = t_ * 16 < last_ ? t_ * 16 : last_;
-                    const char* g = (off_ < HDR_BYTES ? hbase : rbase) + off_;
-                    const unsigned lds_base = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(
-                        OFF_PREF + buf_ * PREF_BYTES + (wave * DMA_PER_WAVE + j) * 1024);
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                                 :
-                                 : "v"(g), "s"(lds_base)
-                                 : "memory");  // (m0 is reserved: hipcc never keeps a value in it across statements)
-                }
-            }
-        };
-        // L2 warm-up for the item after the one whose DMA was just issued: ONE load instruction of wave 0, a lane per 128-byte
-        // line of that item's header and records, landing in an LDS corner nobody reads (LDS-DMA: no destination register
-        // to keep alive).  The block's own DMA, an item later, then finds its lines in L2 instead of paying the trip to
-        // HBM / the Infinity Cache inside the per-item chain.  It counts in wave 0's vmcnt like any other load.
-        auto touch = [&](int li_) {
-            if (SVGR_TOUCH && wave == 0) {
-                const int seg0_ = __builtin_amdgcn_readfirstlane(s_seg0[li_]), seg1_ = __builtin_amdgcn_readfirstlane(s_seg1[li_]);
-                const int cell_ = __builtin_amdgcn_readfirstlane(s_cell[li_]) & 0x3fffffff;
-                const int left_ = seg1_ - seg0_;
-                const int n_bytes = (left_ < PREF_RECS ? left_ : PREF_RECS) * REC_BYTES;
-                const char* const hbase = (const char*)(a.cell_hdr + cell_);
-                const char* const rbase = (const char*)(a.bsegs + seg0_);
-                // lanes 0-1: the header's lines; lanes 2..: every 128 bytes of the records, the last lane their last bytes
-                int off_ = (lane - 2) * 128;
-                off_ = off_ < n_bytes - 4 ? off_ : n_bytes - 4;
-                const char* g = lane < 2 || n_bytes == 0 ? hbase + (lane == 0 ? 0 : HDR_BYTES - 4) : rbase + off_;
-                const unsigned lds_base = lds0 + OFF_TOUCH;
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory");
-            }
-        };
-        // the prefetch cursor runs ahead of the work cursor
-        int pf_li = 0, pf_k = 0;
-        bool touched = false;  // the newest load of wave 0 is a warm-up load (one more operation that may stay in flight)
-        auto issue_next = [&]() {
-            touched = false;
-            if (pf_li < total) {
-                issue(pf_li, pf_k % PREF_DEPTH);
-                ++pf_k;
-                ++pf_li;  // one item per path: slots past the block are read straight from HBM by the scatter
-                if (SVGR_TOUCH && pf_li < total) { touch(pf_li); touched = true; }
-            }
-        };
-        issue_next();
-        if (PREF_DEPTH >= 3) issue_next();
-
-        // per-path state
-        int row_shift = 0, rows = 0, col_shift = 0, lo_c = 0, hi_c = 0, rule = 0, n_slots = 0, pflags = 0, pid = 0, lcols = 0;
-        long long loff = 0;  // mask / fill outputs: where this path's layer starts in `out`, its row pitch is lcols
-        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-        int li = 0;
-        for (int k = 0; li < total; ++k) {
-            const int cur = k % PREF_DEPTH;
-#ifdef SVGR_DBG_STAMP
-            unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();
-#endif
-            // item k has landed when only what was issued after it is still in flight: the next item's DMA (deeper rings) and,
-            // in wave 0, the warm-up load
-            if (pf_k > k + 1) {
-                if (SVGR_TOUCH && touched && wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 1) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
-            } else {
-                if (SVGR_TOUCH && touched && wave == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-#ifdef SVGR_DBG_STAMP
-            unsigned long long t1_ = __builtin_amdgcn_s_memrealtime();
-#endif
-            // After this barrier: item k has landed for every wave; everybody is done with item k-1
-            // (its block is free again) and with the previous item's scan.
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#ifdef SVGR_DBG_STAMP
-            unsigned long long t2_ = __builtin_amdgcn_s_memrealtime();
-#endif
-            issue_next();  // item k+1 (k+2) into the block that item k-1 used
-            const double* const blk = (const double*)(s_mem + OFF_PREF + cur * PREF_BYTES);
-            const double* const blk_carry = blk + 6;                         // CellHdr::carry
-            const char* const blk_recs = (const char*)blk + HDR_BYTES;       // the pair's first PREF_RECS records
-            const int cls = (int)((unsigned)s_cell[li] >> 30);
-            {
-                const int4 pbb = s_bbox[li];
-                const int c0 = pbb.y, cols = pbb.w;
-                n_slots = s_seg1[li] - s_seg0[li];
-                row_shift = pbb.x - tile_r0;  // layer row y  -> tile row  y + row_shift
-                rows = pbb.z;
-                col_shift = c0 - tile_c0;     // layer col x  -> tile col  x + col_shift
-                lo_c = col_shift < 0 ? -col_shift : 0;             // first layer column inside the tile
-                hi_c = cols < tile_c1 - c0 ? cols : tile_c1 - c0;  // one past the last
-                p0 = blk[0]; p1 = blk[1]; p2 = blk[2]; p3 = blk[3];  // cell header: paint, rule, flags
-                rule = *(const int*)(blk + 4);
-                pflags = *((const int*)(blk + 4) + 1);  // bits 0-1: clip source / clipped; above: gradient index + 1
-                pid = s_list[li];
-                if (OUT >= 2) {
-                    lcols = cols;
-                    loff = a.layer_off ? a.layer_off[pid] : 0ll;
-                }
-            }
-            ++li;
-            const int item_g = GROUPS ? *((const int*)(blk + 4) + 2) : -1;  // CellHdr::group
-            const int grad_id = GRAD ? __builtin_amdgcn_readfirstlane(pflags >> 2) - 1 : -1;
-            const bool grad_mask = GRAD && grad_id >= 0 && a.grads[grad_id].kind == 3 && a.grad_flags[grad_id] != 0;
-            if (GROUPS && open_g >= 0 && item_g != open_g) close_group();
-            if (GROUPS && item_g >= 0 && open_g < 0) {
-                open_g = item_g;
-#pragma unroll
-                for (int i = 0; i < (GROUPS ? PX : 1); ++i) gacc[i][0] = gacc[i][1] = gacc[i][2] = gacc[i][3] = 0.0;
-            }
-
-            // Class 1: no record reaches the tile, so a row's running sum is its carry-in from the layer's first column in
-            // the tile to its last (np.cumsum of zeros, S:983).  No scatter, no second barrier, no delta-tile traffic: the
-            // scan below gets the two deltas (+carry at the first column, -carry behind the last) straight in registers.
-            const bool fast1 = SVGR_CLASS1 && OUT == 0 && !CLIP && cls == 1;
-#ifdef SVGR_DBG_STAMP
-            unsigned long long t3_ = t2_;
-#endif
-            if (!fast1) {
-            // ---- scatter: one lane per edge-row record; the pieces were computed by k_edge_emit, here the ones inside
-            //      the tile's columns are added to the LDS delta tile.  What lies left of the tile arrives pre-summed as
-            //      the row's carry-in (k_pair_cells) and goes to the layer's first column in the tile ----
-            {
-                int slot_hi = n_slots;
+        return e;
+    };
+    // the adds of an item into delta tile `buf`
+    auto scatter = [&](int h, const uint4 first, int buf) {
 #ifdef SVGR_DBG_NOSCATTER
-                slot_hi = 0;
+        return;
 #endif
-                if (tid < TR) {
-                    const double cin = blk_carry[tid];
-                    if (cin != 0.0)
-                        __hip_atomic_fetch_add(s_trace + __mul24(tid, ROW_STRIDE) + lds_col(lo_c + col_shift), cin, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                for (int sl = tid; sl < slot_hi; sl += NT) {
-                    int x0i;
-                    unsigned nrow;
-                    double v[5];
-                    if (sl < PREF_RECS) {
-                        const double* q = (const double*)(blk_recs + __mul24(sl, REC_BYTES));
-                        const int2 hd = *(const int2*)q;
-                        x0i = hd.x; nrow = (unsigned)hd.y;
-                        v[0] = q[1]; v[1] = q[2]; v[2] = q[3]; v[3] = q[4]; v[4] = q[5];
-                    } else {
-                        // pair longer than the prefetch block: the tail comes straight from HBM.  Inline asm, so
-                        // that hipcc does not put a vmcnt(0) wait on the common path (it would for a plain load).
-                        const RowRec* gp = a.bsegs + __builtin_amdgcn_readfirstlane(s_seg0[li - 1]) + sl;
-                        double hd_;
-                        asm volatile("global_load_dwordx2 %0, %6, off\n\t"
-                                     "global_load_dwordx2 %1, %6, off offset:8\n\t"
-                                     "global_load_dwordx2 %2, %6, off offset:16\n\t"
-                                     "global_load_dwordx2 %3, %6, off offset:24\n\t"
-                                     "global_load_dwordx2 %4, %6, off offset:32\n\t"
-                                     "global_load_dwordx2 %5, %6, off offset:40\n\t"
-                                     "s_waitcnt vmcnt(0)"
-                                     : "=&v"(hd_), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
-                                     : "v"(gp)
-                                     : "memory");
-                        x0i = __double2loint(hd_);
-                        nrow = (unsigned)__double2hiint(hd_);
-                    }
-                    const int n = (int)(nrow & SPAN_MAX);
-                    double* trow_ptr = s_trace + __mul24((int)(nrow >> 26), ROW_STRIDE);  // (32-bit multiplies are quarter rate)
-                    if (x0i >= hi_c) continue;  // everything at or beyond the tile's / layer's right edge
-                    const int xl = x0i + (n >= 2 ? n : 1);  // column of the last piece
-                    if ((xl > 0 ? xl : 0) < lo_c) continue;  // everything left of the tile: part of the carry-in
-                    auto put = [&](int xi, double val) {
-                        const int c = xi > 0 ? xi : 0;   // left of the layer folds into column 0 (S:2262)
-                        if (c >= lo_c && c < hi_c)       // (left of the tile: in the carry-in; right of the layer: dropped, S:2260)
-                            __hip_atomic_fetch_add(trow_ptr + lds_col(c + col_shift), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    };
-                    put(x0i, v[0]);
-                    put(x0i + 1, v[1]);
-                    if (n >= 3) {
-                        int xa = x0i + 2;
-                        const int xb = x0i + n - 2 < hi_c - 1 ? x0i + n - 2 : hi_c - 1;  // middle run, cut at the right edge
-                        if (xa < lo_c) {
-                            // the run starts left of the tile: skip to the tile's first column; when that is the layer's
-                            // column 0 the pieces at negative columns all land there (S:2262)
-                            if (lo_c == 0) {
-                                const int neg = (xb < -1 ? xb : -1) - xa + 1;
-                                if (neg > 0) put(0, (double)neg * v[2]);
-                            }
-                            xa = lo_c;
-                        }
-                        for (int xi = xa; xi <= xb; ++xi)
-                            __hip_atomic_fetch_add(trow_ptr + lds_col(xi + col_shift), v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        put(x0i + n - 1, v[3]);
-                    }
-                    if (n >= 2) put(x0i + n, v[4]);
+        if (hdr_cls(h) != 2) return;
+        const int n_add = __builtin_amdgcn_readlane(h, 13), add0 = __builtin_amdgcn_readlane(h, 14);
+        unsigned char* const base = s_mem + buf * DELTA_BYTES;
+        for (int i = tid; i < n_add; i += NT) {
+            uint4 e = first;
+            if (i != tid) e = ((const uint4*)a.adds)[(size_t)add0 + i];
+            unsigned off = e.x & 0xffffu;
+            const double v = __hiloint2double((int)e.w, (int)e.z);
+            __hip_atomic_fetch_add((double*)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int more = (int)((e.x >> 16) & 63u);
+            if (more) {  // a run: the same value into the next `more` columns, stepping over the padding behind every chunk
+                int c8 = (int)((e.x >> 22) & 7u);
+                for (; more > 0; --more) {
+                    off += 8u;
+                    if (++c8 == PX) { c8 = 0; off += (CHUNK_STRIDE - PX) * 8u; }
+                    __hip_atomic_fetch_add((double*)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-#ifdef SVGR_DBG_STAMP
-            t3_ = __builtin_amdgcn_s_memrealtime();
-#endif
-            if (OUT <= 1 && hi_c + col_shift < TC && tid < TR && tid >= row_shift && tid < row_shift + rows) {
-                // The layer's right edge is inside this tile.  Right of it the running sum is whatever winding
-                // an unclosed outline leaves behind (stroker joins leave ~1e-5 gaps) and the reference never
-                // touches pixels outside the layer's bbox: poison the first column past the edge with a NaN, so
-                // that every prefix sum to its right fails the `>= 1e-6` test.  (Nothing else writes that cell:
-                // the scatter drops columns >= hi_c.  Only rows of the layer: their waves scan and re-zero it.)
-                s_trace[lds_index(tid, hi_c + col_shift)] = __builtin_nan("");
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // delta tile complete
-            }
-#ifdef SVGR_DBG_STAMP
-            unsigned long long t4_ = __builtin_amdgcn_s_memrealtime();
-#endif
-
-            // ---- row prefix sum + fill rule + paint + source-over ----
-            // A wave owns 4 tile rows; skip the phase when the layer has no row among them (its
-            // delta rows are untouched, so there is nothing to read, zero or composite).
-            const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * (64 / CH);
-            const bool is_clip_src = CLIP && (pflags & 1);   // coverage only: becomes the clip of the next path
-            const bool is_clipped = CLIP && (pflags & 2);    // multiplied by the coverage of the previous path
-            if (is_clip_src) clip_tag = pid;
-            // a clipped path whose clip did not reach this tile is invisible here (empty intersection, S:403-404),
-            // but its delta rows still have to be read back to zero
-            const bool clip_missing = is_clipped && clip_tag != pid - 1;
-#ifdef SVGR_DBG_NOSCAN
-            if (false) {
-#else
-            if (is_clip_src || (wrow0 + (64 / CH) > row_shift && wrow0 < row_shift + rows)) {
-#endif
-                double* my = s_trace + trow * ROW_STRIDE + chunk * CHUNK_STRIDE;
-                double t[PX];
-                double run = 0.0;
-                if (fast1) {
-                    // the row's winding is its carry-in on the layer's columns inside the tile and 0 elsewhere: no delta
-                    // tile, no prefix sum -- t[] gets the winding itself (already folded for evenodd)
-                    const double cin = blk_carry[trow];
-                    const double wnd = rule ? fill_evenodd_raw(cin) : cin;
-                    int lo_i = lo_c + col_shift - chunk * PX, hi_i = hi_c + col_shift - chunk * PX;
-                    lo_i = lo_i < 0 ? 0 : lo_i;
-                    hi_i = hi_i > PX ? PX : hi_i;
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) t[i] = i >= lo_i && i < hi_i ? wnd : 0.0;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) t[i] = my[i];
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) my[i] = 0.0;
-                    double tot = t[0];
-#pragma unroll
-                    for (int i = 1; i < PX; ++i) tot += t[i];
-                    double inc = tot;  // inclusive scan of the CH chunk totals of this tile row
-                    if (CH <= 8) {
-                        // a 16-lane DPP row holds 16 / CH tile rows: a shift must not carry a value across their borders
-                        const int lc = lane & (CH - 1);
-                        double v;
-                        v = dpp_row_shr<1>(inc); inc += lc >= 1 ? v : 0.0;
-                        v = dpp_row_shr<2>(inc); inc += lc >= 2 ? v : 0.0;
-                        if (CH == 8) { v = dpp_row_shr<4>(inc); inc += lc >= 4 ? v : 0.0; }
-                        v = dpp_row_shr<1>(inc);
-                        run = lc >= 1 ? v : 0.0;  // exclusive: everything left of this chunk
-                    } else {
-                        inc += dpp_row_shr<1>(inc);
-                        inc += dpp_row_shr<2>(inc);
-                        inc += dpp_row_shr<4>(inc);
-                        inc += dpp_row_shr<8>(inc);
-                        if (CH == 16) {
-                            run = dpp_row_shr<1>(inc);  // exclusive: everything left of this chunk
-                        } else {
-                            // a tile row is two DPP rows: add the lower row's total (its lane 15) to the upper row,
-                            // then shift by one lane across the pair; the first lane of a tile row starts at 0
-                            inc += dpp_ctrl<0x142, 0xA>(inc);   // row_bcast:15 into DPP rows 1 and 3
-                            run = dpp_ctrl<0x138, 0xF>(inc);    // wave_shr:1
-                            if ((lane & 31) == 0) run = 0.0;
-                        }
-                    }
-                }
-
-                if (OUT <= 1) {
-                    // Canvas: no bounds tests.  Left of / above / below the layer the delta tile is zero and so
-                    // is the running sum; right of the layer it is NaN (sentinel above) or outside the viewport.
-                    double* const myclip = my + (OFF_CLIP - OFF_TRACE) / 8;  // same cell of the clip tile: a constant offset, no second address register
-                    // coverage first, in place (t[i] <- mask value), with the fill rule decided ONCE per path: written
-                    // as `rule ? evenodd(x) : nonzero(x)` inside the pixel loop the compiler evaluates both for every pixel
-                    if (OUT == 0 && !CLIP) {
-                        // The production variant (float32 canvas, no clip entries), one fused pixel loop per fill rule.
-                        // Composite for a float32 store: dst += m * (paint - dst * paint_a), two fmas per channel written
-                        // in place (the same value as src + dst * (1 - src_a) up to double rounding; the double outputs keep
-                        // the reference's operation order).
-                        auto blend = [&](int i, double mval) {
-                            double t0, t1, t2, t3;
-                            asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t0) : "v"(acc[i][0]), "v"(p3), "v"(p0));
-                            asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t1) : "v"(acc[i][1]), "v"(p3), "v"(p1));
-                            asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t2) : "v"(acc[i][2]), "v"(p3), "v"(p2));
-                            asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t3) : "v"(acc[i][3]), "v"(p3), "v"(p3));
-                            asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i][0]) : "v"(mval), "v"(t0));
-                            asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i][1]) : "v"(mval), "v"(t1));
-                            asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i][2]) : "v"(mval), "v"(t2));
-                            asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i][3]) : "v"(mval), "v"(t3));
-                        };
-                        // First the winding per pixel, in place: the running sum itself for nonzero (its
-                        // |.| rides as an operand modifier below), the folded value for evenodd (already in [0, 1]).
-                        if (fast1) {
-                        } else if (rule) {
-#pragma unroll
-                            for (int i = 0; i < PX; ++i) { run += t[i]; t[i] = fill_evenodd_raw(run); }
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < PX; ++i) { run += t[i]; t[i] = run; }
-                        }
-                        // Then coverage = min(|t|, 1) where |t| >= 1e-6 (S:984-990): the comparison comes first because
-                        // v_min_f64 turns the NaN of the layer-edge sentinel into 1.0.  Pixels below the cut are skipped
-                        // under the exec mask: a tenth of the pixel slots of a wave have no visible lane at all.
-#pragma unroll
-                        for (int i = 0; i < PX; ++i) {
-                            if (__builtin_expect(fabs(t[i]) >= kZeroCut, 1)) {  // (visible falls through)
-                                double mval;  // min(|t|, 1): asm, because fmin() first canonicalises its operand (a v_max)
-                                asm("v_min_f64 %0, |%1|, 1.0" : "=v"(mval) : "v"(t[i]));
-                                blend(i, mval);
-                            }
-                        }
-                    } else {
-                    bool vis[PX];  // the 1e-6 cut (S:990), as lane masks
-                    if (rule) {
-#pragma unroll
-                        for (int i = 0; i < PX; ++i) { run += t[i]; t[i] = fill_evenodd_raw(run); vis[i] = t[i] >= kZeroCut; }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < PX; ++i) { run += t[i]; t[i] = fill_nonzero_raw(run); vis[i] = t[i] >= kZeroCut; }
-                    }
-                    // then one loop for the three kinds of path (three unrolled copies cost 60 VGPRs and an occupancy step):
-                    //   plain      dst = src OVER dst,  src = mask * paint
-                    //   clip src   Path.mask of a clip path (S:707): keep its coverage (after the 1e-6 cut) for the next path
-                    //   clipped    CLIP: (mask * paint) * clip_alpha on the intersection (S:712, S:290), then OVER
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) {
-                        const double mval = t[i];
-                        if (is_clip_src) {
-                            myclip[i] = vis[i] ? mval : 0.0;
-                        } else if (vis[i]) {
-                            double s0, s1, s2, s3;
-                            if (GRAD && grad_id >= 0) {
-                                // gradient paint: colour at the pixel centre, times the coverage (canvas_compose(IN, mask, image),
-                                // S:1044-1047), times the entry's opacity multiplier (Layer.opacity over the leaf, S:174)
-                                double gc[4];
-                                grad_colour_pixel(a.grads[grad_id], tile_r0 + trow, tile_c0 + chunk * PX + i, grad_mask, gc);
-                                s0 = (gc[0] * mval) * p0; s1 = (gc[1] * mval) * p1; s2 = (gc[2] * mval) * p2; s3 = (gc[3] * mval) * p3;
-                            } else {
-                                s0 = mval * p0; s1 = mval * p1; s2 = mval * p2; s3 = mval * p3;
-                            }
-                            if (is_clipped) {
-                                const double c = clip_missing ? 0.0 : myclip[i];
-                                if (c == 0.0) continue;
-                                s0 = s0 * c; s1 = s1 * c; s2 = s2 * c; s3 = s3 * c;
-                            }
-                            if (GROUPS && item_g >= 0) {
-                                over_px(gacc[GROUPS ? i : 0], s0, s1, s2, s3);  // a member of the open group
-                            } else if (OUT == 0) {
-                                // over_px_fma with the fma written in place (v_fma_f64 acc, acc, k, s): left to the
-                                // compiler it becomes v_fmac into the source register plus a v_mov back, 4 moves per pixel
-                                const double k1 = 1 - s3;
-                                asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][0]) : "v"(k1), "v"(s0));
-                                asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][1]) : "v"(k1), "v"(s1));
-                                asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][2]) : "v"(k1), "v"(s2));
-                                asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][3]) : "v"(k1), "v"(s3));
-                            } else {
-                                over_px(acc[i], s0, s1, s2, s3);
-                            }
-                        }
-                    }
-                    }
-                } else {
-                    const int y_layer = trow - row_shift;
-                    const bool row_ok = y_layer >= 0 && y_layer < rows;
-                    const int x_layer0 = chunk * PX - col_shift;
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) {
-                        run += t[i];
-                        const int x_layer = x_layer0 + i;
-                        if (row_ok && x_layer >= lo_c && x_layer < hi_c) {
-                            double mval = fill_rule(run, rule);
-                            if (OUT == 2) {
-                                ((double*)a.out)[(size_t)loff + (size_t)y_layer * lcols + x_layer] = mval;
-                            } else {
-                                double* o = (double*)a.out + 4 * ((size_t)loff + (size_t)y_layer * lcols + x_layer);
-                                o[0] = mval * p0; o[1] = mval * p1; o[2] = mval * p2; o[3] = mval * p3;
-                            }
-                        }
-                    }
-                }
-            }
-#ifdef SVGR_DBG_STAMP
-            {
-                unsigned long long t5_ = __builtin_amdgcn_s_memrealtime();
-                stamp_[0] += t1_ - t0_;  // wait for the DMA
-                stamp_[1] += t2_ - t1_;  // barrier A
-                stamp_[2] += t3_ - t2_;  // metadata + scatter
-                stamp_[3] += t4_ - t3_;  // barrier B
-                stamp_[4] += t5_ - t4_;  // scan + composite
-                stamp_[5] += 1ull;
-            }
-#endif
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        }  // rounds of LCAP items
-    }  // 64 mask words at a time
-    if (GROUPS && open_g >= 0) close_group();
-    // the masks are set bit by bit (atomicOr) by the next render's k_pair_cells: leave them cleared.  This tile is the
-    // only reader of its words and has listed everything.
-    for (int i = tid; i < 2 * W; i += NT) mw[i] = 0ull;
+    };
 
-#ifdef SVGR_DBG_STAMP
-    if (tid == 0 && a.dbg) {
-        stamp_[6] = __builtin_amdgcn_s_memrealtime() - tstart_;
-        for (int q = 0; q < 7; ++q) atomicAdd(&a.dbg[q], stamp_[q]);
-        atomicAdd(&a.dbg[7], 1ull);
-    }
+    // ---- scan + fill rule + paint + source-over of the item whose deltas are in delta tile `buf` ----
+    const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * (64 / CH);  // a wave owns 64 / CH tile rows
+    auto process = [&](int h, double cin1, int buf) {
+        const int bits = __builtin_amdgcn_readlane(h, 12);
+        const int cls = (bits >> 3) & 3;
+        if (cls == 0) return;
+        const int rule = bits & 1, pflags = (bits >> 1) & 3;
+        const double p0 = __hiloint2double(__builtin_amdgcn_readlane(h, 1), __builtin_amdgcn_readlane(h, 0));
+        const double p1 = __hiloint2double(__builtin_amdgcn_readlane(h, 3), __builtin_amdgcn_readlane(h, 2));
+        const double p2 = __hiloint2double(__builtin_amdgcn_readlane(h, 5), __builtin_amdgcn_readlane(h, 4));
+        const double p3 = __hiloint2double(__builtin_amdgcn_readlane(h, 7), __builtin_amdgcn_readlane(h, 6));
+        const int r0 = __builtin_amdgcn_readlane(h, 8), c0 = __builtin_amdgcn_readlane(h, 9);
+        const int rows = __builtin_amdgcn_readlane(h, 10), cols = __builtin_amdgcn_readlane(h, 11);
+        const int pid = __builtin_amdgcn_readlane(h, 15);
+        const int row_shift = r0 - tile_r0;  // layer row y  -> tile row  y + row_shift
+        const int col_shift = c0 - tile_c0;  // layer col x  -> tile col  x + col_shift
+        const int lo_c = col_shift < 0 ? -col_shift : 0;             // first layer column inside the tile
+        const int hi_c = cols < tile_c1 - c0 ? cols : tile_c1 - c0;  // one past the last
+        const int item_g = GROUPS ? __builtin_amdgcn_readlane(h, 16) : -1;  // CellHdr::group
+        const int grad_id = GRAD ? (bits >> 5) - 1 : -1;
+        const bool grad_mask = GRAD && grad_id >= 0 && a.grads[grad_id].kind == 3 && a.grad_flags[grad_id] != 0;
+        if (GROUPS && open_g >= 0 && item_g != open_g) close_group();
+        if (GROUPS && item_g >= 0 && open_g < 0) {
+            open_g = item_g;
+#pragma unroll
+            for (int i = 0; i < (GROUPS ? PX : 1); ++i) gacc[i][0] = gacc[i][1] = gacc[i][2] = gacc[i][3] = 0.0;
+        }
+        const bool is_clip_src = CLIP && (pflags & 1);   // coverage only: becomes the clip of the next path
+        const bool is_clipped = CLIP && (pflags & 2);    // multiplied by the coverage of the previous path
+        if (is_clip_src) clip_tag = pid;
+        // a clipped path whose clip did not reach this tile is invisible here (empty intersection, S:403-404),
+        // but its delta rows still have to be read back to zero
+        const bool clip_missing = is_clipped && clip_tag != pid - 1;
+        // skip the phase when the layer has no row among this wave's (its delta rows are untouched: nothing to read, zero
+        // or composite).  A clip source always runs: its coverage tile must be rewritten whole.
+#ifdef SVGR_DBG_NOSCAN
+        return;
 #endif
+        if (!(is_clip_src || (wrow0 + (64 / CH) > row_shift && wrow0 < row_shift + rows))) return;
+
+        double* const my = my0 + buf * (DELTA_BYTES / 8);
+        double t[PX];  // the winding number of the lane's pixels (np.cumsum along the row, S:983)
+        if (cls == 1) {
+            // No record reaches the tile: a row's running sum is its carry-in from the layer's first column in the tile
+            // to its last (np.cumsum of zeros).  No delta tile, no prefix sum.
+            int lo_i = lo_c + col_shift - chunk * PX, hi_i = hi_c + col_shift - chunk * PX;
+            lo_i = lo_i < 0 ? 0 : lo_i;
+            hi_i = hi_i > PX ? PX : hi_i;
+            if (OUT == 0 && !CLIP) {
+                // production variant: constant coverage along the lane's pixels -> src and 1 - src_a once per lane,
+                // then dst = fma(dst, 1 - src_a, src): four fmas per pixel
+                const double wnd = rule ? fill_evenodd_raw(cin1) : cin1;
+                if (fabs(wnd) >= kZeroCut && lo_i < hi_i) {
+                    double m;
+                    asm("v_min_f64 %0, |%1|, 1.0" : "=v"(m) : "v"(wnd));
+                    const double s0 = m * p0, s1 = m * p1, s2 = m * p2, s3 = m * p3, k1 = 1 - s3;
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) {
+                        if (i >= lo_i && i < hi_i) {
+                            asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][0]) : "v"(k1), "v"(s0));
+                            asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][1]) : "v"(k1), "v"(s1));
+                            asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][2]) : "v"(k1), "v"(s2));
+                            asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][3]) : "v"(k1), "v"(s3));
+                        }
+                    }
+                }
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < PX; ++i) t[i] = i >= lo_i && i < hi_i ? cin1 : 0.0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < PX; ++i) t[i] = my[i];
+#pragma unroll
+            for (int i = 0; i < PX; ++i) my[i] = 0.0;
+            double tot = t[0];
+#pragma unroll
+            for (int i = 1; i < PX; ++i) tot += t[i];
+            double inc = tot;  // inclusive scan of the CH chunk totals of this tile row
+            double run;
+            if (CH <= 8) {
+                // a 16-lane DPP row holds 16 / CH tile rows: a shift must not carry a value across their borders
+                const int lc = lane & (CH - 1);
+                double v;
+                v = dpp_row_shr<1>(inc); inc += lc >= 1 ? v : 0.0;
+                v = dpp_row_shr<2>(inc); inc += lc >= 2 ? v : 0.0;
+                if (CH == 8) { v = dpp_row_shr<4>(inc); inc += lc >= 4 ? v : 0.0; }
+                v = dpp_row_shr<1>(inc);
+                run = lc >= 1 ? v : 0.0;  // exclusive: everything left of this chunk
+            } else {
+                inc += dpp_row_shr<1>(inc);
+                inc += dpp_row_shr<2>(inc);
+                inc += dpp_row_shr<4>(inc);
+                inc += dpp_row_shr<8>(inc);
+                if (CH == 16) {
+                    run = dpp_row_shr<1>(inc);  // exclusive: everything left of this chunk
+                } else {
+                    // a tile row is two DPP rows: add the lower row's total (its lane 15) to the upper row,
+                    // then shift by one lane across the pair; the first lane of a tile row starts at 0
+                    inc += dpp_ctrl<0x142, 0xA>(inc);   // row_bcast:15 into DPP rows 1 and 3
+                    run = dpp_ctrl<0x138, 0xF>(inc);    // wave_shr:1
+                    if ((lane & 31) == 0) run = 0.0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PX; ++i) { run += t[i]; t[i] = run; }
+        }
+
+        if (OUT <= 1) {
+            // Canvas: no bounds tests.  Left of / above / below the layer the delta tile is zero and so
+            // is the running sum; right of the layer it is NaN (the add list's sentinel) or outside the viewport.
+            double* const myclip = my0 + OFF_CLIP / 8;  // same cell of the clip tile
+            if (OUT == 0 && !CLIP) {
+                // The production variant (float32 canvas, no clip entries), one fused pixel loop per fill rule.
+                // Composite for a float32 store: dst += m * (paint - dst * paint_a), two fmas per channel written
+                // in place (the same value as src + dst * (1 - src_a) up to double rounding; the double outputs keep
+                // the reference's operation order).
+                auto blend = [&](int i, double mval) {
+                    double t0, t1, t2, t3;
+                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t0) : "v"(acc[i][0]), "v"(p3), "v"(p0));
+                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t1) : "v"(acc[i][1]), "v"(p3), "v"(p1));
+                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t2) : "v"(acc[i][2]), "v"(p3), "v"(p2));
+                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t3) : "v"(acc[i][3]), "v"(p3), "v"(p3));
+                    asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i][0]) : "v"(mval), "v"(t0));
+                    asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i][1]) : "v"(mval), "v"(t1));
+                    asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i][2]) : "v"(mval), "v"(t2));
+                    asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i][3]) : "v"(mval), "v"(t3));
+                };
+                // the winding per pixel is in t[]: the running sum itself for nonzero (its |.| rides as an operand modifier
+                // below), folded for evenodd (already in [0, 1])
+                if (rule) {
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) t[i] = fill_evenodd_raw(t[i]);
+                }
+                // Then coverage = min(|t|, 1) where |t| >= 1e-6 (S:984-990): the comparison comes first because
+                // v_min_f64 turns the NaN of the layer-edge sentinel into 1.0.  Pixels below the cut are skipped
+                // under the exec mask: a tenth of the pixel slots of a wave have no visible lane at all.
+#pragma unroll
+                for (int i = 0; i < PX; ++i) {
+                    if (__builtin_expect(fabs(t[i]) >= kZeroCut, 1)) {  // (visible falls through)
+                        double mval;  // min(|t|, 1): asm, because fmin() first canonicalises its operand (a v_max)
+                        asm("v_min_f64 %0, |%1|, 1.0" : "=v"(mval) : "v"(t[i]));
+                        blend(i, mval);
+                    }
+                }
+            } else {
+                bool vis[PX];  // the 1e-6 cut (S:990), as lane masks
+                if (rule) {
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) { t[i] = fill_evenodd_raw(t[i]); vis[i] = t[i] >= kZeroCut; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) { t[i] = fill_nonzero_raw(t[i]); vis[i] = t[i] >= kZeroCut; }
+                }
+                // then one loop for the three kinds of path (three unrolled copies cost 60 VGPRs and an occupancy step):
+                //   plain      dst = src OVER dst,  src = mask * paint
+                //   clip src   Path.mask of a clip path (S:707): keep its coverage (after the 1e-6 cut) for the next path
+                //   clipped    CLIP: (mask * paint) * clip_alpha on the intersection (S:712, S:290), then OVER
+#pragma unroll
+                for (int i = 0; i < PX; ++i) {
+                    const double mval = t[i];
+                    if (is_clip_src) {
+                        myclip[i] = vis[i] ? mval : 0.0;
+                    } else if (vis[i]) {
+                        double s0, s1, s2, s3;
+                        if (GRAD && grad_id >= 0) {
+                            // gradient paint: colour at the pixel centre, times the coverage (canvas_compose(IN, mask, image),
+                            // S:1044-1047), times the entry's opacity multiplier (Layer.opacity over the leaf, S:174)
+                            double gc[4];
+                            grad_colour_pixel(a.grads[grad_id], tile_r0 + trow, tile_c0 + chunk * PX + i, grad_mask, gc);
+                            s0 = (gc[0] * mval) * p0; s1 = (gc[1] * mval) * p1; s2 = (gc[2] * mval) * p2; s3 = (gc[3] * mval) * p3;
+                        } else {
+                            s0 = mval * p0; s1 = mval * p1; s2 = mval * p2; s3 = mval * p3;
+                        }
+                        if (is_clipped) {
+                            const double c = clip_missing ? 0.0 : myclip[i];
+                            if (c == 0.0) continue;
+                            s0 = s0 * c; s1 = s1 * c; s2 = s2 * c; s3 = s3 * c;
+                        }
+                        if (GROUPS && item_g >= 0) {
+                            over_px(gacc[GROUPS ? i : 0], s0, s1, s2, s3);  // a member of the open group
+                        } else if (OUT == 0) {
+                            // over_px_fma with the fma written in place (v_fma_f64 acc, acc, k, s): left to the
+                            // compiler it becomes v_fmac into the source register plus a v_mov back, 4 moves per pixel
+                            const double k1 = 1 - s3;
+                            asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][0]) : "v"(k1), "v"(s0));
+                            asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][1]) : "v"(k1), "v"(s1));
+                            asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][2]) : "v"(k1), "v"(s2));
+                            asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][3]) : "v"(k1), "v"(s3));
+                        } else {
+                            over_px(acc[i], s0, s1, s2, s3);
+                        }
+                    }
+                }
+            }
+        } else {
+            const int lcols = cols;
+            const long long loff = a.layer_off ? a.layer_off[pid] : 0ll;  // where this path's layer starts in `out`
+            const int y_layer = trow - row_shift;
+            const bool row_ok = y_layer >= 0 && y_layer < rows;
+            const int x_layer0 = chunk * PX - col_shift;
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                const int x_layer = x_layer0 + i;
+                if (row_ok && x_layer >= lo_c && x_layer < hi_c) {
+                    double mval = fill_rule(t[i], rule);
+                    if (OUT == 2) {
+                        ((double*)a.out)[(size_t)loff + (size_t)y_layer * lcols + x_layer] = mval;
+                    } else {
+                        double* o = (double*)a.out + 4 * ((size_t)loff + (size_t)y_layer * lcols + x_layer);
+                        o[0] = mval * p0; o[1] = mval * p1; o[2] = mval * p2; o[3] = mval * p3;
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- the item loop: rounds of up to 64 items (a round's cell ids sit one per lane) ----
+    for (int r0_ = 0; r0_ < n_items; r0_ += 64) {
+        const int n = n_items - r0_ < 64 ? n_items - r0_ : 64;
+        cells_v = lane < n ? a.items[(size_t)item0 + r0_ + lane] : 0u;
+        int h0 = load_hdr(0, n), h1 = load_hdr(1, n), h2 = load_hdr(2, n);
+        uint4 e0 = load_add(h0, 0);
+        uint4 e1 = load_add(h1, 1);
+        // (first round: the zero-fill of the delta tiles; later ones: the previous round's last scans)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        scatter(h0, e0, 0);
+        for (int k = 0; k < n; ++k) {
+            const int h3 = load_hdr(k + 3, n);
+            const uint4 e2 = load_add(h2, k + 2);
+            // behind this barrier: every wave's adds of item k have landed; everybody's scan of item k-1 has zeroed its tile
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            scatter(h1, e1, (k + 1) & 1);
+            process(h0, __hiloint2double((int)e0.w, (int)e0.z), k & 1);
+            h0 = h1; h1 = h2; h2 = h3;
+            e0 = e1; e1 = e2;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (GROUPS && open_g >= 0) close_group();
+    // (a tile without items has not passed a barrier yet: the other wave's zero-fill must not land on the transposed tile below)
+    if (n_items == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
 #ifdef SVGR_DBG_TIMELINE
     // per workgroup {start, end, items, XCC | hardware id} on the 100 MHz clock (profiles/timeline.py)
     if (tid == 0 && a.dbg) {
-        const unsigned wg_ = t_lin;
+        const unsigned wg_ = blockIdx.x;
         if (wg_ < (1u << 16)) {
             unsigned hwid_, xcc_;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid_));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
             unsigned long long* t_ = a.dbg + 8 + 4 * (size_t)wg_;
-            t_[0] = tl_start_; t_[1] = __builtin_amdgcn_s_memrealtime(); t_[2] = (unsigned long long)tl_items_;
+            t_[0] = tl_start_; t_[1] = __builtin_amdgcn_s_memrealtime(); t_[2] = (unsigned long long)n_items;
             t_[3] = ((unsigned long long)xcc_ << 32) | hwid_;
         }
     }
@@ -2133,34 +2192,52 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     if (OUT <= 1) {
         const int row = band * TR + trow;  // viewport-local row
         const int out_row = by * TR + trow - a.win_r;  // row of the output buffer (the window's / the owned bands packed)
-        if (row < a.vrows && out_row >= 0 && out_row < a.win_rows) {
-            // (the lane's chunk is recomputed from the thread id here: kept live across the main loop it costs a VGPR
-            // that the register budget does not have, i.e. a scratch spill in every workgroup)
-            int tid2 = (int)threadIdx.x;
-            asm volatile("" : "+v"(tid2));
-            const int col0 = (bx - a.ct0) * TC + (tid2 % CH) * PX - a.win_c;  // column of the output buffer
+        if (a.clip01) {
+#pragma unroll
+            for (int i = 0; i < PX; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[i][q] = acc[i][q] < 0 ? 0 : (acc[i][q] > 1 ? 1 : acc[i][q]);
+        }
+#ifdef SVGR_DBG_NOSTORE
+        if (acc[0][0] + acc[1][1] != 12345.678) return;
+#endif
+        if (OUT == 0) {
+            // float32: through an LDS transpose, so that one store instruction covers a whole 1-KiB tile row instead of
+            // 64 separate 16-byte pieces 128 bytes apart.  A wave transposes its own rows: no workgroup barrier (the
+            // delta tiles are free: the last barrier of the item loop is behind every scan).  Slot = 16 bytes; a lane's 8
+            // pixels take 9 slots, so that the 8 lanes a ds_write_b128 serves together fall on different banks.
+            constexpr int T_ROW = CH * (PX + 1);  // slots per transposed tile row
+            static_assert(TR * T_ROW * 16 <= 2 * DELTA_BYTES, "the transposed tile fits the two delta tiles");
+            float4* const tp = (float4*)s_mem;
+#pragma unroll
+            for (int i = 0; i < PX; ++i)
+                tp[trow * T_ROW + chunk * (PX + 1) + i] = make_float4((float)acc[i][0], (float)acc[i][1], (float)acc[i][2], (float)acc[i][3]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int col = (bx - a.ct0) * TC + lane - a.win_c;  // column of the output buffer this lane stores
+            const bool col_ok = col >= 0 && col < a.win_cols;
+#pragma unroll
+            for (int r = 0; r < 64 / CH; ++r) {
+                const int tr_ = wrow0 + r;
+                const int vrow = band * TR + tr_, orow = by * TR + tr_ - a.win_r;
+                if (vrow < a.vrows && orow >= 0 && orow < a.win_rows && col_ok) {
+                    const float4 v = tp[tr_ * T_ROW + lane + lane / PX];
+                    ((float4*)a.out)[(size_t)orow * a.out_cols + col] = v;
+                }
+            }
+            (void)row; (void)out_row;
+        } else if (row < a.vrows && out_row >= 0 && out_row < a.win_rows) {
+            const int col0 = (bx - a.ct0) * TC + chunk * PX - a.win_c;  // column of the output buffer
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
                 if (col0 + i >= 0 && col0 + i < a.win_cols) {
-                    double v0 = acc[i][0], v1 = acc[i][1], v2 = acc[i][2], v3 = acc[i][3];
-                    if (a.clip01) {
-                        v0 = v0 < 0 ? 0 : (v0 > 1 ? 1 : v0); v1 = v1 < 0 ? 0 : (v1 > 1 ? 1 : v1);
-                        v2 = v2 < 0 ? 0 : (v2 > 1 ? 1 : v2); v3 = v3 < 0 ? 0 : (v3 > 1 ? 1 : v3);
-                    }
                     size_t o = (size_t)out_row * a.out_cols + col0 + i;
-#ifdef SVGR_DBG_NOSTORE
-                    if (v0 + v1 + v2 + v3 != 12345.678) continue;
-#endif
-                    if (OUT == 0) {
-                        ((float4*)a.out)[o] = make_float4((float)v0, (float)v1, (float)v2, (float)v3);
-                    } else {
-                        ((double4*)a.out)[o] = make_double4(v0, v1, v2, v3);
-                    }
+                    ((double4*)a.out)[o] = make_double4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
                 }
             }
         }
     }
-    }  // tiles of this workgroup
 }
 
 // ======================================================================================
@@ -2637,7 +2714,7 @@ struct svgr_batch {
     }
     // zeroed once per render: [BatchDev | per-path min/max keys | per-path row reach (multi-GPU) | pb_cnt | pb_cursor]
     DevArr<unsigned char> arena;
-    size_t arena_bytes = 0, off_pkeys = 0, off_prow = 0, off_pb_cnt = 0, off_pb_cursor = 0;
+    size_t arena_bytes = 0, off_pkeys = 0, off_prow = 0, off_pb_cnt = 0, off_pb_cursor = 0, off_band_add = 0;
     int pb_cap = 0;
     // work arrays fully rewritten by every render
     DevArr<int> edge_path, bbox, bseg_off, band_start, band_count;
@@ -2646,6 +2723,37 @@ struct svgr_batch {
     DevArr<double> edges;
     DevArr<RowRec> bsegs;
     DevArr<CellHdr> cell_hdr;               // per (path, band, column tile) cell: header (classes 1 and 2)
+    DevArr<TileAdd> adds;                   // the pairs' add blocks (k_band_entries reserves, k_pair_cells fills)
+    DevArr<unsigned> items;                 // the tiles' item lists: cell id | class << 30 (k_tile_lists)
+    DevArr<int2> tile_info;                 // per (band, column tile): {first item, items}
+    DevArr<TileSlot> order;                 // the owned tiles in launch order (heaviest first)
+    DevArr<int> band_item0;                 // per band: its first item slot
+    DevArr<int2> band_adds;                 // per band: its add block {first slot, slots} (sized by the plan's measuring run)
+    std::vector<int2> host_band_adds;
+    int64_t n_adds = 0;                     // add slots in all the blocks
+    bool count_adds_only = false;           // the plan's measuring run: k_pair_cells sizes the add lists, writes none
+    // lay the bands' add blocks back to back: `need[band]` slots each plus slack (the sizes repeat from render to render except
+    // for carry-ins that are exactly zero in one summation order and not in another), and upload the table
+    int size_band_adds(const int* need, hipStream_t st) {
+        host_band_adds.resize((size_t)n_bands + 1);
+        long long at = 0;
+        for (int k = 0; k < n_bands; ++k) {
+            const long long cap = (long long)need[k] + need[k] / 8 + 64;
+            host_band_adds[(size_t)k] = make_int2((int)std::min<long long>(at, 0x7fffffff), (int)std::min<long long>(cap, 0x7fffffff));
+            at += cap;
+        }
+        if (at > 0x7fffffffll) return fail(SVGR_E_OVERFLOW, "%lld add slots: beyond the 32-bit add index (split the batch)", at);
+        n_adds = at;
+        if (int rc = adds.ensure((size_t)std::max<long long>(at, 1))) return rc;
+        if (int rc = band_adds.ensure((size_t)n_bands + 1)) return rc;
+        if (n_bands > 0) {
+            wait_uploads();
+            HIPCHK(hipMemcpyAsync(band_adds.p, keep(host_band_adds.data(), sizeof(int2) * (size_t)n_bands), sizeof(int2) * (size_t)n_bands,
+                                  hipMemcpyHostToDevice, st));
+            HIPCHK(note_upload(st));
+        }
+        return 0;
+    }
     DevArr<int2> entry_where;               // per band-list entry: {band, index in the band's list}
     DevArr<int> seg_list;                   // multi-GPU: the segments this rank flattens (k_seg_select, at plan time)
     int64_t n_seg_list = -1;                // (-1: no list, every segment)
@@ -2681,6 +2789,14 @@ struct svgr_batch {
     std::vector<hipEvent_t> event_pool;
 
     int n_ctiles() const { return (vp[3] + TC - 1) / TC; }
+    // the arrays k_tile_lists fills, for the planned band / tile / cell counts
+    int size_tile_lists(int owned_bands) {
+        const size_t nt = (size_t)std::max(n_bands, 1) * (size_t)std::max(n_ctiles(), 1);
+        if (int rc = tile_info.ensure(nt)) return rc;
+        if (int rc = order.ensure((size_t)std::max(owned_bands, 1) * (size_t)std::max(n_ctiles(), 1))) return rc;
+        if (int rc = band_item0.ensure((size_t)n_bands + 1)) return rc;
+        return items.ensure((size_t)std::max<int64_t>(n_cells, 1));
+    }
     size_t mask_bytes() const { return sizeof(unsigned long long) * 2 * (size_t)mask_words * (size_t)n_bands * (size_t)n_ctiles(); }
     // size the tiles' entry bitmasks for band lists of up to `longest` entries
     int size_masks(int64_t longest) {
@@ -2693,6 +2809,7 @@ struct svgr_batch {
     unsigned* prow() const { return (unsigned*)(arena.p + off_prow); }
     int* pb_cnt() const { return (int*)(arena.p + off_pb_cnt); }
     int* pb_cursor() const { return (int*)(arena.p + off_pb_cursor); }
+    int* band_add_cur() const { return (int*)(arena.p + off_band_add); }  // per band: add slots taken from its block
 
     int layout_arena(int new_pb_cap) {
         pb_cap = new_pb_cap;
@@ -2700,7 +2817,8 @@ struct svgr_batch {
         off_prow = off_pkeys + sizeof(unsigned long long) * 4 * (size_t)n_paths;
         off_pb_cnt = off_prow + sizeof(unsigned) * 2 * (size_t)n_paths;
         off_pb_cursor = off_pb_cnt + sizeof(int) * (size_t)(pb_cap + 1);
-        arena_bytes = off_pb_cursor + sizeof(int) * (size_t)(pb_cap + 1);
+        off_band_add = off_pb_cursor + sizeof(int) * (size_t)(pb_cap + 1);
+        arena_bytes = off_band_add + sizeof(int) * (size_t)(n_bands + 1);
         arena_bytes = (arena_bytes + 255) & ~(size_t)255;
         arena_zeroed = false;  // (new size or new memory)
         return arena.ensure(arena_bytes);
@@ -2713,6 +2831,7 @@ struct svgr_batch {
         path_group.release(); group_clip_src.release(); group_opacity.release(); groups_dev.release();
         grads.release(); path_grad.release(); grad_path.release(); grad_flags.release(); grads_dev.release();
         edges.release(); bsegs.release(); cell_hdr.release(); entry_where.release(); tile_mask.release(); chunks.release(); seg_list.release(); path_list.release(); layer_off.release();
+        adds.release(); items.release(); tile_info.release(); order.release(); band_item0.release(); band_adds.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
         for (auto e : event_pool) (void)hipEventDestroy(e);
@@ -2774,8 +2893,9 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     if (owned > 0)
         hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(BE_BLOCK), 0, st, (const PathBin*)b->bins.p, np_walk, plist,
                            (const int*)b->bbox.p, (const int*)b->pb_cnt(), b->bseg_off.p,
-                           upto >= 4 ? cap_i32(b->bsegs.cap) : 0x7fffffff, b->band_start.p, b->band_count.p, b->entries.p,
-                           b->entry_where.p, cap_i32(std::min(b->entries.cap, b->entry_where.cap)), b->vp[1], b->bd(), b->own);
+                           upto >= 4 ? cap_i32(b->bsegs.cap) : 0x7fffffff, b->band_start.p, b->band_count.p, b->band_item0.p, b->entries.p,
+                           b->entry_where.p, cap_i32(std::min(b->entries.cap, b->entry_where.cap)),
+                           upto >= 4 ? cap_i32(b->items.cap) : 0x7fffffff, b->vp[1], b->bd(), b->own);
     if (upto == 3) return 0;
     hipLaunchKernelGGL(k_edge_emit, grid1((size_t)std::max<int64_t>(b->n_edges + b->n_chunks, 1)), dim3(256), 0, st,
                        (const double*)b->edges.p, (const int*)b->edge_path.p, (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0],
@@ -2794,8 +2914,16 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                            (const TileEntry*)b->entries.p, (const int2*)b->entry_where.p, (const RowRec*)b->bsegs.p,
                            (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p,
                            b->n_groups > 0 ? (const int*)b->path_group.p : (const int*)nullptr,
-                           b->n_grads > 0 ? (const int*)b->path_grad.p : (const int*)nullptr, b->vp[1], b->n_ctiles(), b->mask_words,
-                           b->tile_mask.p, b->cell_hdr.p, cap_i32(b->cell_hdr.cap), b->bd());
+                           b->n_grads > 0 ? (const int*)b->path_grad.p : (const int*)nullptr, b->vp[0], b->vp[1], b->n_ctiles(), b->mask_words,
+                           b->tile_mask.p, b->cell_hdr.p, cap_i32(b->cell_hdr.cap), (const int2*)b->band_adds.p, b->band_add_cur(),
+                           b->count_adds_only ? (TileAdd*)nullptr : b->adds.p, b->bd());
+    }
+    // per owned band: the tiles' item lists and the launch order of the tile kernel; clears the bitmasks again
+    if (owned > 0 && b->n_ctiles() > 0) {
+        hipLaunchKernelGGL(k_tile_lists, dim3(owned), dim3(TL_BLOCK), 0, st, (const int*)b->band_start.p, (const int*)b->band_item0.p,
+                           (const TileEntry*)b->entries.p, b->tile_mask.p, b->mask_words, b->n_ctiles(), b->vp[1], b->own, owned,
+                           b->tile_info.p, b->order.p, b->items.p, cap_i32(b->items.cap), cap_i32(b->cell_hdr.cap), b->bd());
+        b->masks_zeroed = true;
     }
     return 0;
 }
@@ -2807,10 +2935,10 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
 // `with_bboxes`: fetch the per-path bboxes in the same round trip (one synchronisation instead of two)
 // the sticky error word of a geometry pass -> status (capacity overflows are reported apart when the caller can recover)
 static int eval_dev_err(int e, int* capacity_bits) {
-    if (capacity_bits) { *capacity_bits = e & (2 | 4 | 8 | 32); e &= ~(2 | 4 | 8 | 32); }
+    if (capacity_bits) { *capacity_bits = e & (2 | 4 | 8 | 32 | 64); e &= ~(2 | 4 | 8 | 32 | 64); }
     if (e & 1) return fail(SVGR_E_OVERFLOW, "flatten depth cap (%d) hit: non-finite or absurd control points", kMaxFlattenDepth);
     if (e & 16) return fail(SVGR_E_INVALID, "path extent beyond +-1e9 pixels or non-finite");
-    if (e & (2 | 4 | 8 | 32)) return fail(SVGR_E_OVERFLOW, "work buffer capacity exceeded (err bits %d): call svgr_batch_plan again", e);
+    if (e & (2 | 4 | 8 | 32 | 64)) return fail(SVGR_E_OVERFLOW, "work buffer capacity exceeded (err bits %d): call svgr_batch_plan again", e);
     return 0;
 }
 // enqueue the read-back of a pass's scalars (and bboxes) into the batch's host copies; valid after the stream has drained
@@ -3310,9 +3438,15 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr) {
     rc = rc ? rc : b->band_count.ensure((size_t)n_bands + 1);
     rc = rc ? rc : b->bseg_off.ensure((size_t)b->n_pb + 1);
     rc = rc ? rc : b->entries.ensure((size_t)b->n_pb);
-    rc = rc ? rc : b->bsegs.ensure((size_t)rec_guess + PREF_RECS_MAX + 1);
+    rc = rc ? rc : b->bsegs.ensure((size_t)rec_guess + 1);
     rc = rc ? rc : b->cell_hdr.ensure((size_t)b->n_cells + 1);
     rc = rc ? rc : b->entry_where.ensure((size_t)b->n_pb);
+    rc = rc ? rc : b->size_tile_lists(n_bands);
+    if (!rc) {
+        // add slots: a guess like the others -- a few adds per record, spread evenly over the bands
+        std::vector<int> need((size_t)n_bands, (int)std::min<int64_t>(4 * rec_guess / n_bands + 2048, 1 << 26));
+        rc = b->size_band_adds(need.data(), b->ctx->stream);
+    }
     {
         int caps[NSH];
         for (int k = 0; k < NSH; ++k) caps[k] = shard_cap;  // (extra chunks of long edges: a guess like the others)
@@ -3496,6 +3630,7 @@ static int batch_plan_impl(svgr_batch* b) {
     b->n_bands = (b->vp[2] + TR - 1) / TR;
     if (int rc = b->band_start.ensure((size_t)b->n_bands + 1)) return rc;
     if (int rc = b->band_count.ensure((size_t)b->n_bands + 1)) return rc;
+    if (int rc = b->band_item0.ensure((size_t)b->n_bands + 1)) return rc;
     if (int rc = run_geometry(b, 2, true)) return rc;
     if (int rc = check_dev_err(b)) return rc;
     b->n_pb = b->host_bd.pb_cursor;
@@ -3516,7 +3651,20 @@ static int batch_plan_impl(svgr_batch* b) {
         if (int rc = b->size_chunks(caps)) return rc;
     }
     if (int rc = b->size_masks(b->host_bd.max_band_entries)) return rc;
-    if (int rc = b->bsegs.ensure((size_t)std::max<int64_t>(b->n_bsegs, 1) + PREF_RECS_MAX + 1)) return rc;
+    if (int rc = b->bsegs.ensure((size_t)std::max<int64_t>(b->n_bsegs, 1) + 1)) return rc;
+    if (int rc = b->size_tile_lists(count_owned_bands(b->own, b->n_bands))) return rc;
+    // 3b. the whole geometry once with k_pair_cells only SIZING the add lists: what every band's add block has to hold
+    {
+        b->count_adds_only = true;
+        int rc = run_geometry(b, 4, true);
+        b->count_adds_only = false;
+        if (rc) return rc;
+        std::vector<int> need((size_t)b->n_bands + 1, 0);
+        if (b->n_bands > 0)
+            HIPCHK(hipMemcpyAsync(need.data(), b->band_add_cur(), sizeof(int) * (size_t)b->n_bands, hipMemcpyDeviceToHost, b->ctx->stream));
+        if ((rc = check_dev_err(b))) return rc;
+        if ((rc = b->size_band_adds(need.data(), b->ctx->stream))) return rc;
+    }
     // 4. full geometry once, to validate the capacities and fetch the bboxes
     if (int rc = run_geometry(b, 4, true)) return rc;
 
@@ -3729,10 +3877,9 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
 
     if (owned_bands > 0 && n_ctiles > 0) {
         TileArgs a;
-        a.band_start = b->band_start.p; a.entries = b->entries.p; a.bsegs = b->bsegs.p; a.out = out->ptr;
-        a.cell_hdr = b->cell_hdr.p;
-        a.cell_cap = cap_i32(b->cell_hdr.cap);
-        a.tile_mask = b->tile_mask.p; a.mask_words = b->mask_words; a.n_ct = b->n_ctiles();
+        a.order = b->order.p; a.tile_info = b->tile_info.p; a.items = b->items.p; a.out = out->ptr;
+        a.cell_hdr = b->cell_hdr.p; a.adds = b->adds.p;
+        a.n_ct = b->n_ctiles();
         a.group_clip_src = b->group_clip_src.p; a.group_opacity = b->group_opacity.p;
         a.grads = b->grads.p; a.grad_flags = b->grad_flags.p;
         if (b->n_grads > 0 && b->has_focal) {
@@ -3787,9 +3934,9 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         a.win_c = win[1] - a.ct0 * TC;
         a.win_rows = b->own.world <= 1 ? win[2] : owned_bands * TR;
         a.win_cols = win[3];
-        const bool whole = a.win_ct == n_ctiles && a.n_bands == owned_bands;
-        const unsigned n_tiles_ = (unsigned)a.win_ct * (unsigned)a.n_bands;
-        dim3 grid(8u * ((((n_tiles_ + 7u) >> 3) + TPW - 1u) / TPW));
+        // the whole canvas: the tiles in k_tile_lists' order (heaviest first); a window: its tiles in raster order
+        a.use_order = a.win_ct == n_ctiles && a.n_bands == owned_bands ? 1 : 0;
+        dim3 grid((unsigned)a.win_ct * (unsigned)a.n_bands);
         static const int dyn_lds = getenv("SVGR_DBG_DYNLDS") ? atoi(getenv("SVGR_DBG_DYNLDS")) : 0;  // occupancy experiments
         switch (out_kind) {
             case 0:
@@ -3808,7 +3955,6 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
             default: hipLaunchKernelGGL(k_tile_render<3>, grid, dim3(NT), 0, st, a); break;
         }
         b->arena_zeroed = true;  // (done by that kernel, see TileArgs::arena)
-        b->masks_zeroed = whole;  // (every tile clears its own words; those outside a render window never ran)
     }
     if (timed) {
         HIPCHK(hipEventRecord(ev.e2, st));
