@@ -126,7 +126,9 @@ struct CellHdr {
     int group, pad[3];        // isolated group the path belongs to (-1: none)
     double carry[SVGR_TR];    // class 1 reads them; for class 2 they are in the add list
 };
-constexpr int HDR_DWORDS = 20;    // what the tile kernel loads of it per item: everything in front of `carry`
+constexpr int HDR_DWORDS = 20;    // everything in front of `carry`
+constexpr int HDR_LOAD_DWORDS = HDR_DWORDS + 2 * SVGR_TR;   // what the tile kernel loads per item: all of it, a dword per lane
+static_assert(HDR_LOAD_DWORDS <= 64, "a CellHdr is one dword per lane of one load instruction");
 static_assert(sizeof(CellHdr) == 4 * HDR_DWORDS + 8 * SVGR_TR && offsetof(CellHdr, carry) == 4 * HDR_DWORDS, "CellHdr layout");
 constexpr unsigned SPAN_MAX = (1u << 26) - 1;
 static_assert(SVGR_TR <= 64, "row-in-band is stored in 6 bits");
@@ -1881,33 +1883,50 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     }
 
     // ---- the pipeline's loads ----
-    // header of item j of the current round: dword `lane` of its CellHdr (zeros past the end of the list: class 0)
+    // Issued from inline asm and waited for by hand with counted vmcnt: left to the compiler, every load sits in a branch
+    // ("is there such an item") and each use waits vmcnt(0) -- three exposed round trips per item.  All of them are
+    // unconditional (past the end of the list they read a valid dummy address and the result is discarded), so the queue
+    // of outstanding loads is the same in every iteration: [header k+2, adds k+1] at the top of iteration k.
+    // A register with a load in flight must not be touched until its wait, and the compiler -- which does not know these
+    // are loads -- is free to copy or spill a variable wherever it likes (it did: with the wait written as a read-modify-write
+    // of the target it put a v_mov of the target ABOVE the s_waitcnt).  So a load's target variable has exactly two
+    // appearances: output of the load statement, input of the statement that waits and moves the landed value into an
+    // ordinary variable.  With registers to spare (no spill, no live-range split) the compiler has no reason to touch it in
+    // between; profiles/lint_inflight.py checks the generated loop for any other mention of those registers.
+    // (Landing the loads in AGPRs instead would hide them from the compiler altogether, but a kernel that mentions AGPRs
+    //  gets half its register budget as AGPRs -- 64 VGPRs for a 64-register canvas tile.)
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     unsigned cells_v = 0u;  // lane j: item j of the round (cell id | class << 30)
-    auto load_hdr = [&](int j, int n) -> int {
-        const unsigned cw = (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63);
-        const int* src = (const int*)(a.cell_hdr + (cw & 0x3fffffffu));
-        int h = 0;
-        if (j < n && lane < HDR_DWORDS) h = src[lane];
-        return h;
+    int n_round = 0;        // items of the round
+    const int hdr_lane = lane < HDR_LOAD_DWORDS ? lane : HDR_LOAD_DWORDS - 1;
+    // header of item j of the round: dword `lane` of its CellHdr (lanes 20 .. 51 hold the 16 carry-ins)
+    auto hdr_ptr = [&](int j) -> const int* {
+        const unsigned cw = j < n_round ? (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63) : 0u;
+        return (const int*)(a.cell_hdr + (cw & 0x3fffffffu)) + hdr_lane;
     };
     auto hdr_cls = [&](int h) { return (__builtin_amdgcn_readlane(h, 12) >> 3) & 3; };
-    // class 2: this lane's first add of item j (its later ones, for lists longer than the workgroup, are loaded by the
-    // scatter); class 1: the carry-in of this lane's tile row, in the value half of the same registers
-    auto load_add = [&](int h, int j) -> uint4 {
+    // class 2: this lane's first add of the item (its later ones, for lists longer than the workgroup, are loaded by the
+    // scatter); else the list's first entry: any valid address
+    auto add_ptr = [&](int h) -> const void* {
         const int n_add = __builtin_amdgcn_readlane(h, 13), add0 = __builtin_amdgcn_readlane(h, 14);
-        const int cls = hdr_cls(h);
-        uint4 e = make_uint4(0u, 0u, 0u, 0u);
-        if (cls == 2) {
-            if (tid < n_add) e = ((const uint4*)a.adds)[(size_t)add0 + tid];
-        } else if (cls == 1) {
-            const unsigned cw = (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63);
-            const uint2 c = *(const uint2*)&a.cell_hdr[cw & 0x3fffffffu].carry[trow];
-            e.z = c.x; e.w = c.y;
-        }
-        return e;
+        const TileAdd* p = a.adds;
+        if (hdr_cls(h) == 2) p = a.adds + (size_t)add0 + (tid < n_add ? tid : n_add - 1);
+        return p;
     };
+    // (class 1) the carry-in of this lane's tile row: dwords 20 + 2 row, 21 + 2 row of the header, fetched across the lanes
+    auto carry_of = [&](int h) -> double {
+        const int at = (HDR_DWORDS + 2 * trow) * 4;
+        const int lo = __builtin_amdgcn_ds_bpermute(at, h), hi = __builtin_amdgcn_ds_bpermute(at + 4, h);
+        return __hiloint2double(hi, lo);
+    };
+#define SVGR_HDR_LOAD(tgt, ptr) asm volatile("global_load_dword %0, %1, off" : "=v"(tgt) : "v"(ptr) : "memory")
+#define SVGR_ADD_LOAD(tw, tv, ptr)                                                                                     \
+    asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:8" : "=&v"(tw), "=&v"(tv) : "v"(ptr) : "memory")
+#define SVGR_HDR_TAKE(n, dst, tgt) asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, %1" : "=v"(dst) : "v"(tgt) : "memory")
+#define SVGR_ADD_TAKE(n, dw, dv, tw, tv)                                                                               \
+    asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(dw), "=&v"(dv) : "v"(tw), "v"(tv) : "memory")
     // the adds of an item into delta tile `buf`
-    auto scatter = [&](int h, const uint4 first, int buf) {
+    auto scatter = [&](int h, unsigned long long first_w, double first_v, int buf) {
 #ifdef SVGR_DBG_NOSCATTER
         return;
 #endif
@@ -1915,14 +1934,18 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
         const int n_add = __builtin_amdgcn_readlane(h, 13), add0 = __builtin_amdgcn_readlane(h, 14);
         unsigned char* const base = s_mem + buf * DELTA_BYTES;
         for (int i = tid; i < n_add; i += NT) {
-            uint4 e = first;
-            if (i != tid) e = ((const uint4*)a.adds)[(size_t)add0 + i];
-            unsigned off = e.x & 0xffffu;
-            const double v = __hiloint2double((int)e.w, (int)e.z);
+            unsigned w = (unsigned)first_w;
+            double v = first_v;
+            if (i != tid) {
+                const TileAdd t = a.adds[(size_t)add0 + i];
+                w = t.where;
+                v = t.v;
+            }
+            unsigned off = w & 0xffffu;
             __hip_atomic_fetch_add((double*)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            int more = (int)((e.x >> 16) & 63u);
+            int more = (int)((w >> 16) & 63u);
             if (more) {  // a run: the same value into the next `more` columns, stepping over the padding behind every chunk
-                int c8 = (int)((e.x >> 22) & 7u);
+                int c8 = (int)((w >> 22) & 7u);
                 for (; more > 0; --more) {
                     off += 8u;
                     if (++c8 == PX) { c8 = 0; off += (CHUNK_STRIDE - PX) * 8u; }
@@ -1934,7 +1957,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
 
     // ---- scan + fill rule + paint + source-over of the item whose deltas are in delta tile `buf` ----
     const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * (64 / CH);  // a wave owns 64 / CH tile rows
-    auto process = [&](int h, double cin1, int buf) {
+    auto process = [&](int h, int buf) {
         const int bits = __builtin_amdgcn_readlane(h, 12);
         const int cls = (bits >> 3) & 3;
         if (cls == 0) return;
@@ -1977,29 +2000,12 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
         if (cls == 1) {
             // No record reaches the tile: a row's running sum is its carry-in from the layer's first column in the tile
             // to its last (np.cumsum of zeros).  No delta tile, no prefix sum.
+            const double cin1 = carry_of(h);
             int lo_i = lo_c + col_shift - chunk * PX, hi_i = hi_c + col_shift - chunk * PX;
             lo_i = lo_i < 0 ? 0 : lo_i;
             hi_i = hi_i > PX ? PX : hi_i;
-            if (OUT == 0 && !CLIP) {
-                // production variant: constant coverage along the lane's pixels -> src and 1 - src_a once per lane,
-                // then dst = fma(dst, 1 - src_a, src): four fmas per pixel
-                const double wnd = rule ? fill_evenodd_raw(cin1) : cin1;
-                if (fabs(wnd) >= kZeroCut && lo_i < hi_i) {
-                    double m;
-                    asm("v_min_f64 %0, |%1|, 1.0" : "=v"(m) : "v"(wnd));
-                    const double s0 = m * p0, s1 = m * p1, s2 = m * p2, s3 = m * p3, k1 = 1 - s3;
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) {
-                        if (i >= lo_i && i < hi_i) {
-                            asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][0]) : "v"(k1), "v"(s0));
-                            asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][1]) : "v"(k1), "v"(s1));
-                            asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][2]) : "v"(k1), "v"(s2));
-                            asm("v_fma_f64 %0, %0, %1, %2" : "+v"(acc[i][3]) : "v"(k1), "v"(s3));
-                        }
-                    }
-                }
-                return;
-            }
+            // (a composite loop of its own for this class -- four fmas per pixel instead of eight -- costs 40 VGPRs: the register
+            //  allocator does not keep the canvas tile in place across two unrolled loops that both rewrite it)
 #pragma unroll
             for (int i = 0; i < PX; ++i) t[i] = i >= lo_i && i < hi_i ? cin1 : 0.0;
         } else {
@@ -2051,9 +2057,10 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
                 // the reference's operation order).
                 auto blend = [&](int i, double mval) {
                     double t0, t1, t2, t3;
-                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t0) : "v"(acc[i][0]), "v"(p3), "v"(p0));
-                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t1) : "v"(acc[i][1]), "v"(p3), "v"(p1));
-                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t2) : "v"(acc[i][2]), "v"(p3), "v"(p2));
+                    // (the paint's colour channels ride as scalar operands -- one constant-bus read per instruction --, its alpha in a VGPR)
+                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t0) : "v"(acc[i][0]), "v"(p3), "s"(p0));
+                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t1) : "v"(acc[i][1]), "v"(p3), "s"(p1));
+                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t2) : "v"(acc[i][2]), "v"(p3), "s"(p2));
                     asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t3) : "v"(acc[i][3]), "v"(p3), "v"(p3));
                     asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i][0]) : "v"(mval), "v"(t0));
                     asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i][1]) : "v"(mval), "v"(t1));
@@ -2151,25 +2158,55 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
 
     // ---- the item loop: rounds of up to 64 items (a round's cell ids sit one per lane) ----
     for (int r0_ = 0; r0_ < n_items; r0_ += 64) {
-        const int n = n_items - r0_ < 64 ? n_items - r0_ : 64;
+        n_round = n_items - r0_ < 64 ? n_items - r0_ : 64;
+        const int n = n_round;
         cells_v = lane < n ? a.items[(size_t)item0 + r0_ + lane] : 0u;
-        int h0 = load_hdr(0, n), h1 = load_hdr(1, n), h2 = load_hdr(2, n);
-        uint4 e0 = load_add(h0, 0);
-        uint4 e1 = load_add(h1, 1);
-        // (first round: the zero-fill of the delta tiles; later ones: the previous round's last scans)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        scatter(h0, e0, 0);
+        int hq;                       // load target: the header in flight
+        unsigned long long wq;        // load targets: the add in flight ({where, 0} and its value)
+        double vq;
+        int h_p, h_s, h_a;            // the landed headers of items k, k+1, k+2
+        unsigned long long w_s;       // the landed add of item k+1
+        double v_s;
+        {
+            const int* q0 = hdr_ptr(0);
+            SVGR_HDR_LOAD(hq, q0);
+            SVGR_HDR_TAKE(0, h_p, hq);
+            const int* q1 = hdr_ptr(1);
+            const void* a0 = add_ptr(h_p);
+            SVGR_HDR_LOAD(hq, q1);
+            SVGR_ADD_LOAD(wq, vq, a0);
+            SVGR_HDR_TAKE(0, h_s, hq);
+            SVGR_ADD_TAKE(0, w_s, v_s, wq, vq);
+            h_s = 1 < n ? h_s : 0;
+            // (first round: the zero-fill of the delta tiles; later ones: the previous round's last scans)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            scatter(h_p, w_s, v_s, 0);
+            const int* q2 = hdr_ptr(2);
+            const void* a1 = add_ptr(h_s);
+            SVGR_HDR_LOAD(hq, q2);
+            SVGR_ADD_LOAD(wq, vq, a1);
+        }
         for (int k = 0; k < n; ++k) {
-            const int h3 = load_hdr(k + 3, n);
-            const uint4 e2 = load_add(h2, k + 2);
+            // in flight here: [header k+2, add k+1 (two loads)]; the adds of item k are on their way into delta tile k & 1
+            SVGR_HDR_TAKE(2, h_a, hq);
+            h_a = k + 2 < n ? h_a : 0;
+            {
+                const int* q = hdr_ptr(k + 3);
+                SVGR_HDR_LOAD(hq, q);
+            }
             // behind this barrier: every wave's adds of item k have landed; everybody's scan of item k-1 has zeroed its tile
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            scatter(h1, e1, (k + 1) & 1);
-            process(h0, __hiloint2double((int)e0.w, (int)e0.z), k & 1);
-            h0 = h1; h1 = h2; h2 = h3;
-            e0 = e1; e1 = e2;
+            SVGR_ADD_TAKE(1, w_s, v_s, wq, vq);
+            scatter(h_s, w_s, v_s, (k + 1) & 1);
+            {
+                const void* ap = add_ptr(h_a);
+                SVGR_ADD_LOAD(wq, vq, ap);
+            }
+            process(h_p, k & 1);
+            h_p = h_s; h_s = h_a;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // (nothing may be in flight into registers that are about to mean something else)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" : : "v"(hq), "v"(wq), "v"(vq) : "memory");
     }
     if (GROUPS && open_g >= 0) close_group();
     // (a tile without items has not passed a barrier yet: the other wave's zero-fill must not land on the transposed tile below)
