@@ -73,10 +73,6 @@ constexpr int DELTA_BYTES = TR * ROW_STRIDE * 8;   // one delta tile in LDS
 static_assert(CH == 4 || CH == 8 || CH == 16 || CH == 32, "row scan: a quarter / half of a 16-lane DPP row, one, or two per tile row");
 static_assert(DELTA_BYTES < (1 << 16), "a TileAdd carries its byte offset in 16 bits");
 static_assert(TC <= 64, "a TileAdd carries its run length in 6 bits");
-#ifndef SVGR_REC_BYTES
-#define SVGR_REC_BYTES 48
-#endif
-constexpr int REC_BYTES = SVGR_REC_BYTES;             // 48, or 64 = one full HBM sector per record
 constexpr int NW = NT / 64;                // waves per workgroup
 #ifndef SVGR_ORDER
 #define SVGR_ORDER 1                    // whole-canvas launches take their tiles heaviest first (k_tile_lists); 0: in raster order
@@ -86,17 +82,6 @@ constexpr int NW = NT / 64;                // waves per workgroup
 #endif
 static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 1024 threads");
 
-// One row of one edge (the signed-area pieces of line_signed_coverage for that scanline, S:2250-2303),
-// computed once by k_edge_emit; k_pair_cells turns the records of a (path, band) pair into the add lists of its cells.
-struct RowRec {
-    int x0i;        // unclamped layer column of the first piece
-    unsigned nrow;  // bits 0-25: n = x1i - x0i (see svgr_core.h RowPieces), bits 26-31: row inside the band
-    double v[5];
-#if SVGR_REC_BYTES == 64
-    double pad[2];
-#endif
-};
-static_assert(sizeof(RowRec) == REC_BYTES, "RowRec size");
 // One addition into a tile's LDS delta tile: everything the scatter phase of the tile kernel does for it is
 // `ds_add_f64 base + offset, v`.  A run of `len` consecutive tile columns with the same value (the middle pieces of a
 // long span, S:2286-2287) is one entry.  Written by k_pair_cells, per cell contiguous.
@@ -771,122 +756,32 @@ __device__ __forceinline__ void band_rows(const EdgeSetup& es, int band, int vr0
     yb = es.y_end < b0row + TR ? es.y_end : b0row + TR;
 }
 
-// k_edge_emit's work item is a CHUNK of an edge's rows, not the edge: a wave runs as long as its longest item, and real
-// drawings have edges of hundreds of rows next to edges of two (a synthetic blob: mean 3 rows, longest 49).  An edge of up to
-// CHUNK_ROWS rows is one chunk; a longer one is cut into at most CHUNK_MAX equal chunks.  (8, 16 or 32 rows per chunk measure
-// the same on the synthetic scene -- what k_edge_emit gains, k_edge_count pays for the list -- and on the documents, whose
-// wall clock is the host's; the Ghostscript tiger's device step went from 0.219 to 0.146 ms, its geometry from 0.166 to 0.094.)  A chunk that does not start at the
-// edge's first row replays the x recurrence from there (S:2244-2248: a dozen instructions per row, against ~150 for a row
-// that is emitted), so every row still sees the bits the sequential walk gives it.
-#ifndef SVGR_CHUNK_ROWS
-#define SVGR_CHUNK_ROWS 16
-#endif
-constexpr int CHUNK_ROWS = SVGR_CHUNK_ROWS, CHUNK_MAX = 16, CHUNK_SHIFT = 27;  // (chunk id: edge | chunk << 27)
-__host__ __device__ __forceinline__ int edge_chunks(int rows) {
-    if (rows <= CHUNK_ROWS) return 1;
-    const int n = (rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
-    return n < CHUNK_MAX ? n : CHUNK_MAX;
-}
-// rows [y_lo, y_hi) of chunk c of an edge that walks the rows [y_begin, y_end)
-__device__ __forceinline__ void chunk_rows(int y_begin, int y_end, int c, int& y_lo, int& y_hi) {
-    const int rows = y_end - y_begin, n = edge_chunks(rows), per = (rows + n - 1) / n;
-    y_lo = y_begin + c * per;
-    y_hi = y_lo + per < y_end ? y_lo + per : y_end;
-    y_lo = y_lo < y_end ? y_lo : y_end;
-}
-
-__global__ __launch_bounds__(256) void k_edge_count(const double* __restrict__ edges, const int* __restrict__ edge_path,
-                                                    const int* __restrict__ bbox, const PathBin* __restrict__ bins,
-                                                    int vr0, int pb_cap, int* __restrict__ pb_cnt, BatchDev* __restrict__ bd,
-                                                    Owner own, const EdgeShards sh, int* __restrict__ chunks) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
-    EdgeSetup es;
-    int p = 0, r0 = 0, key = -1, bf = 0, bl = -1, rows_first = 0;
-    bool ok = edge_live(e, sh, bd) && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
-    if (ok) {
-        const PathBin pbin = bins[p];
-        bf = (r0 + es.y_begin - vr0) / TR;
-        bl = (r0 + es.y_end - 1 - vr0) / TR;
-        key = pbin.pb_off - pbin.b0 + bf;
-        if (key < 0 || key + (bl - bf) >= pb_cap) { atomicOr(&bd->err, 4); ok = false; }
-    }
-    if (ok && owns_band(own, bf)) {
-        int ya, yb;
-        band_rows(es, bf, vr0, r0, ya, yb);
-        rows_first = yb - ya;
-    }
-    int head, len, total;
-    wave_runs(key, ok, lane, head, len);
-    const int excl = wave_excl_scan(rows_first, lane, total);
-    const int run_end_incl = __shfl(excl + rows_first, (head + len - 1) & 63);
-    const int run_begin_excl = __shfl(excl, head);
-    if (ok) {
-        // first band: one atomic per run of lanes that share a (path, band) pair
-        if (head == lane && run_end_incl > run_begin_excl) atomicAdd(&pb_cnt[key], run_end_incl - run_begin_excl);
-        for (int b = 1; b <= bl - bf; ++b) {
-            if (!owns_band(own, bf + b)) continue;
-            int ya, yb;
-            band_rows(es, bf + b, vr0, r0, ya, yb);
-            atomicAdd(&pb_cnt[key + b], yb - ya);
-        }
-    }
-    // The edge's first chunk needs no list: work item e of k_edge_emit is chunk 0 of edge slot e.  The extra chunks of a long
-    // edge go to a list behind the edge slots, reserved per wave in one of NSH shards (a single cursor would serialise the
-    // 12 000 waves of this kernel: ~90 returning atomics per microsecond and address).
-    // The list's shard of an edge is the flatten shard its slot lies in: WHICH edges a flatten shard holds is fixed by the
-    // flatten's wave numbering (where inside the shard they land is not), so the per-shard chunk totals the plan measured
-    // hold for every later pass.  The 64 consecutive slots of a wave lie in one shard, or in two at a shard border.
-    const int extra = ok ? edge_chunks(es.y_end - es.y_begin) - 1 : 0;
-    int my_shard = 0;
-#pragma unroll
-    for (int k = 1; k < NSH; ++k) my_shard += e >= sh.base[k] ? 1 : 0;
-    int at = 0;
-    unsigned long long todo = __ballot(extra > 0);
-    while (todo != 0ull) {
-        const int s0 = __builtin_amdgcn_readlane(my_shard, __ffsll((long long)todo) - 1);
-        const bool mine = extra > 0 && my_shard == s0;
-        const int a = wave_alloc(&bd->shard[s0].chunk_cursor, mine ? extra : 0, lane);
-        at = mine ? a : at;
-        todo &= ~__ballot(mine);
-    }
-    if (chunks && extra > 0) {
-        if (at + extra > sh.ccap[my_shard] || e >= (1 << CHUNK_SHIFT)) {
-            atomicOr(&bd->err, 2);
-        } else {
-            for (int c = 0; c < extra; ++c) chunks[sh.cbase[my_shard] + at + c] = e | ((c + 1) << CHUNK_SHIFT);
-        }
-    }
-}
-
-// One band-list entry: a (path, band) pair with records.  k_pair_cells reads it whole; k_tile_lists only the first 16 bytes.
+// One band-list entry: a (path, band) pair.  k_pair_scan reads it whole; k_tile_lists only the first 16 bytes.
 struct TileEntry {
     int c0, cols;     // layer columns
     int cell0;        // cell of (pair, first column tile of the path): the cell of column tile t is cell0 + t - ct0
     int p;            // path id
     int r0, rows;     // layer rows
-    int seg0, cnt;    // records of the pair: first slot, number of records
+    int pad[2];
 };
 static_assert(sizeof(TileEntry) == 32, "TileEntry is 32 bytes");
 
-// One workgroup per owned band, after k_edge_count: the ascending list of the paths that have records in the
-// band (TileEntry), and -- in the same pass, from the same counts -- the record block of every such
-// (path, band) pair: cnt record slots, reserved with ONE atomic per band, so that a band's blocks are contiguous
-// in HBM and in paint order (k_edge_emit fills them), and the band's first tile-list slot (one slot per cell of a
-// listed pair: k_tile_lists fills them).
+// One workgroup per owned band, after k_path_bbox: the ascending (= paint order) list of the paths whose bbox reaches the
+// band (TileEntry), and the band's first tile-list slot (one slot per cell of a listed pair: k_tile_lists fills them).
+// A pair's place in its band's list is the bit that stands for it in the tiles' entry bitmasks.
 constexpr int BE_BLOCK = 1024;
-constexpr int BE_KEEP = 4;   // 64-path groups per wave whose counts stay in registers between the two passes
+constexpr int BE_KEEP = 4;   // 64-path groups per wave whose bins stay in registers between the two passes
 __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __restrict__ bins, int n_paths,
                                                               const int* __restrict__ plist,  // multi-GPU: the n_paths paths of this rank, ascending (else nullptr: all)
-                                                              const int* __restrict__ bbox, const int* __restrict__ pb_cnt,
-                                                              int* __restrict__ bseg_off, int rec_cap,
+                                                              const int* __restrict__ bbox,
                                                               int* __restrict__ band_start, int* __restrict__ band_count,
                                                               int* __restrict__ band_item0,
                                                               TileEntry* __restrict__ entries, int2* __restrict__ entry_where,
                                                               int entry_cap, int item_cap, int vc0,
                                                               BatchDev* __restrict__ bd, Owner own) {
     constexpr int NWV = BE_BLOCK / 64;
-    __shared__ int s_n[NWV], s_r[NWV], s_c[NWV];
-    __shared__ int s_ent0, s_rec0, s_ok;
+    __shared__ int s_n[NWV], s_c[NWV];
+    __shared__ int s_ent0, s_ok;
     const int band = owned_band_at(own, blockIdx.x), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // Wave w owns the consecutive paths [w * chunk, (w + 1) * chunk), as `groups` groups of 64: lane l of group g has
     // path w * chunk + g * 64 + l, so every load is coalesced and list order = (wave, group, lane).
@@ -894,13 +789,12 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
     const int p_wave = wave * chunk;
     auto path_at = [&](int idx) { return plist ? plist[idx < n_paths ? idx : 0] : idx; };  // (n_paths = length of the list, if any)
     auto ctiles_of = [&](const int4 bb) { int ct0, nct; path_ctiles(bb.y, bb.w, vc0, ct0, nct); return nct; };
-    int kcnt[BE_KEEP], kpair[BE_KEEP];
+    bool kmem[BE_KEEP];
     PathBin kb[BE_KEEP];
     int4 kbb[BE_KEEP];
-    int my_n = 0, my_r = 0, my_c = 0;  // this lane's entries / record slots / cells, over all its groups
+    int my_n = 0, my_c = 0;  // this lane's entries / cells, over all its groups
     {
-        // the first BE_KEEP groups with every load of a stage in flight together (written with a branch per group, the
-        // compiler waits for each group's two dependent loads in turn: 2 * BE_KEEP round trips instead of 2)
+        // the first BE_KEEP groups with every load in flight together
 #pragma unroll
         for (int g = 0; g < BE_KEEP; ++g) {
             const int p = p_wave + g * 64 + lane;
@@ -908,24 +802,15 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
             kb[g] = bins[pa];
             kbb[g] = ((const int4*)bbox)[pa];
         }
-        bool member[BE_KEEP];
 #pragma unroll
         for (int g = 0; g < BE_KEEP; ++g) {
             const int p = p_wave + g * 64 + lane;
-            member[g] = g < groups && p < n_paths && kb[g].nb > 0 && band >= kb[g].b0 && band < kb[g].b0 + kb[g].nb;
-            kpair[g] = member[g] ? kb[g].pb_off + band - kb[g].b0 : 0;
-        }
-#pragma unroll
-        for (int g = 0; g < BE_KEEP; ++g) kcnt[g] = pb_cnt[kpair[g]];  // unconditional: slot 0 always exists
-#pragma unroll
-        for (int g = 0; g < BE_KEEP; ++g) {
-            kcnt[g] = member[g] ? kcnt[g] : 0;
-            if (kcnt[g] > 0) { ++my_n; my_r += kcnt[g]; my_c += ctiles_of(kbb[g]); }
+            kmem[g] = g < groups && p < n_paths && kb[g].nb > 0 && band >= kb[g].b0 && band < kb[g].b0 + kb[g].nb;
+            if (kmem[g]) { ++my_n; my_c += ctiles_of(kbb[g]); }
         }
     }
-    // (more than BE_KEEP * 1024 paths: the rest four groups at a time, again with the loads of a stage in flight together)
-    auto load4 = [&](int g0, PathBin* tb, int4* tbb, int* tcnt, int* tpair) {
-        bool mem[4];
+    // (more than BE_KEEP * 1024 paths: the rest four groups at a time, again with the loads in flight together)
+    auto load4 = [&](int g0, PathBin* tb, int4* tbb, bool* mem) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p = p_wave + (g0 + j) * 64 + lane;
@@ -937,42 +822,36 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
         for (int j = 0; j < 4; ++j) {
             const int p = p_wave + (g0 + j) * 64 + lane;
             mem[j] = g0 + j < groups && p < n_paths && tb[j].nb > 0 && band >= tb[j].b0 && band < tb[j].b0 + tb[j].nb;
-            tpair[j] = mem[j] ? tb[j].pb_off + band - tb[j].b0 : 0;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tcnt[j] = pb_cnt[tpair[j]];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tcnt[j] = mem[j] ? tcnt[j] : 0;
     };
     for (int g0 = BE_KEEP; g0 < groups; g0 += 4) {
         PathBin tb[4];
         int4 tbb[4];
-        int tcnt[4], tpair[4];
-        load4(g0, tb, tbb, tcnt, tpair);
+        bool mem[4];
+        load4(g0, tb, tbb, mem);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (tcnt[j] > 0) { ++my_n; my_r += tcnt[j]; my_c += ctiles_of(tbb[j]); }
+            if (mem[j]) { ++my_n; my_c += ctiles_of(tbb[j]); }
     }
-    int wn = my_n, wr = my_r, wc = my_c;  // wave totals
+    int wn = my_n, wc = my_c;  // wave totals
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { wn += __shfl_xor(wn, d); wr += __shfl_xor(wr, d); wc += __shfl_xor(wc, d); }
-    if (lane == 0) { s_n[wave] = wn; s_r[wave] = wr; s_c[wave] = wc; }
+    for (int d = 1; d < 64; d <<= 1) { wn += __shfl_xor(wn, d); wc += __shfl_xor(wc, d); }
+    if (lane == 0) { s_n[wave] = wn; s_c[wave] = wc; }
     __syncthreads();
     if (wave == 0) {  // exclusive scan of the wave totals by one wave, then the band's reservations
-        const int a = lane < NWV ? s_n[lane] : 0, c = lane < NWV ? s_r[lane] : 0, cc = lane < NWV ? s_c[lane] : 0;
-        int tn, trc, tcc;
-        const int ea = wave_excl_scan(a, lane, tn), ec = wave_excl_scan(c, lane, trc);
+        const int a = lane < NWV ? s_n[lane] : 0, cc = lane < NWV ? s_c[lane] : 0;
+        int tn, tcc;
+        const int ea = wave_excl_scan(a, lane, tn);
         (void)wave_excl_scan(cc, lane, tcc);
-        if (lane < NWV) { s_n[lane] = ea; s_r[lane] = ec; }
+        if (lane < NWV) s_n[lane] = ea;
         if (lane == 0) {
             int e0 = tn ? atomicAdd(&bd->entry_cursor, tn) : 0;
-            int r0 = trc ? atomicAdd(&bd->bseg_cursor, trc) : 0;
             int i0 = tcc ? atomicAdd(&bd->item_cursor, tcc) : 0;
             int ok = 1;
             if (e0 + tn > entry_cap) { atomicOr(&bd->err, 4); ok = 0; tn = 0; }
             if (ok && (long long)i0 + tcc > (long long)item_cap) { atomicOr(&bd->err, 64); ok = 0; tn = 0; }
             if (tn) atomicMax(&bd->max_band_entries, tn);
-            s_ent0 = e0; s_rec0 = r0; s_ok = ok;
+            s_ent0 = e0; s_ok = ok;
             band_start[band] = e0;
             band_count[band] = tn;
             band_item0[band] = i0;
@@ -980,221 +859,40 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
     }
     __syncthreads();
     if (!s_ok) return;
-    int ent = s_ent0 + s_n[wave], rec = s_rec0 + s_r[wave];  // running bases of the wave, advanced group by group
-    auto place = [&](int c, int& my_ent, int& my_rec) {  // all lanes of the wave, one group: this lane's entry / record block
-        int tn, trc;
-        my_ent = ent + wave_excl_scan(c > 0 ? 1 : 0, lane, tn);
-        my_rec = rec + wave_excl_scan(c > 0 ? c : 0, lane, trc);
+    int ent = s_ent0 + s_n[wave];  // running base of the wave, advanced group by group
+    auto place = [&](bool m) {  // all lanes of the wave, one group: this lane's entry
+        int tn;
+        const int my_ent = ent + wave_excl_scan(m ? 1 : 0, lane, tn);
         ent += tn;
-        rec += trc;
+        return my_ent;
     };
-    auto store = [&](int p, int pair, int c, int my_ent, int my_rec, const int4 bb, const PathBin pbin) {
+    auto store = [&](int p, int my_ent, const int4 bb, const PathBin pbin) {
         TileEntry e;
         e.p = p; e.c0 = bb.y; e.cols = bb.w; e.r0 = bb.x; e.rows = bb.z;
-        e.seg0 = my_rec; e.cnt = c;
+        e.pad[0] = e.pad[1] = 0;
         int ct0, nct;
         path_ctiles(bb.y, bb.w, vc0, ct0, nct);
         e.cell0 = pbin.cell_off + (band - pbin.b0) * nct;
         entries[my_ent] = e;
         entry_where[my_ent] = make_int2(band, my_ent - s_ent0);  // its band and its place in the band's list
-        bseg_off[pair] = my_rec;
-        if (my_rec + c > rec_cap) atomicOr(&bd->err, 8);
     };
 #pragma unroll
     for (int g = 0; g < BE_KEEP; ++g) {
         if (g >= groups) break;
-        int me, mr;
-        place(kcnt[g], me, mr);
-        if (kcnt[g] > 0) store(path_at(p_wave + g * 64 + lane), kpair[g], kcnt[g], me, mr, kbb[g], kb[g]);
+        const int me = place(kmem[g]);
+        if (kmem[g]) store(path_at(p_wave + g * 64 + lane), me, kbb[g], kb[g]);
     }
     for (int g0 = BE_KEEP; g0 < groups; g0 += 4) {
         PathBin tb[4];
         int4 tbb[4];
-        int tcnt[4], tpair[4];
-        load4(g0, tb, tbb, tcnt, tpair);
+        bool mem[4];
+        load4(g0, tb, tbb, mem);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int me = 0, mr = 0;
-            if (g0 + j < groups) place(tcnt[j], me, mr);  // (whole groups only: every lane of the wave scans)
-            if (tcnt[j] > 0) store(path_at(p_wave + (g0 + j) * 64 + lane), tpair[j], tcnt[j], me, mr, tbb[j], tb[j]);
+            int me = 0;
+            if (g0 + j < groups) me = place(mem[j]);  // (whole groups only: every lane of the wave scans)
+            if (mem[j]) store(path_at(p_wave + (g0 + j) * 64 + lane), me, tbb[j], tb[j]);
         }
-    }
-}
-
-// One lane per edge; the lanes of a wave walk their rows in lockstep (one row per lane per turn) and every turn's
-// records leave through an LDS transpose: lane j then stores 16-byte chunk j of the turn's records, so that a
-// store instruction covers whole cache lines.  (Each lane storing its own 48-byte record made every dwordx4 store 64
-// separate partial-line writes, and the L2 request rate -- not bytes -- bounded the kernel.)
-#ifndef SVGR_EMIT_WAVES
-#define SVGR_EMIT_WAVES 6      // waves per SIMD the register budget of k_edge_emit allows (8 would spill)
-#endif
-#ifndef SVGR_EMIT_DIRECT
-#define SVGR_EMIT_DIRECT 12   // turns with fewer records than this skip the LDS transpose
-#endif
-__global__ __launch_bounds__(256, SVGR_EMIT_WAVES) void k_edge_emit(const double* __restrict__ edges, const int* __restrict__ edge_path,
-                                                   const int* __restrict__ bbox, const PathBin* __restrict__ bins,
-                                                   int vr0, int pb_cap, const int* __restrict__ bseg_off,
-                                                   int* __restrict__ pb_cursor, RowRec* __restrict__ recs, int rec_cap,
-                                                   BatchDev* __restrict__ bd, Owner own, const EdgeShards sh, int n_edges,
-                                                   const int* __restrict__ chunks) {
-    static_assert(REC_BYTES % 16 == 0, "records move as 16-byte chunks");
-    constexpr int CPR = REC_BYTES / 16;  // chunks per record
-    __shared__ uint4 s_stage[4][64 * CPR];
-    __shared__ int s_dest[4][64];
-    const int ci = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // this lane's work item: rows [y_lo, y_hi) of edge e.  Items 0 .. n_edges-1 are the first chunks of the edge slots, the
-    // rest the extra chunks of long edges in k_edge_count's sharded list
-    int e = ci, cidx = 0;
-    bool ok;
-    if (ci < n_edges) {
-        ok = edge_live(ci, sh, bd);
-    } else {
-        const int x = ci - n_edges;
-        int sd = 0;
-#pragma unroll
-        for (int k = 1; k < NSH; ++k) sd += x >= sh.cbase[k] ? 1 : 0;
-        const int filled = bd->shard[sd].chunk_cursor < sh.ccap[sd] ? bd->shard[sd].chunk_cursor : sh.ccap[sd];
-        ok = x - sh.cbase[sd] < filled;
-        if (ok) {
-            const int w = chunks[x];
-            e = w & ((1 << CHUNK_SHIFT) - 1);
-            cidx = (int)((unsigned)w >> CHUNK_SHIFT);
-            ok = e < n_edges && edge_live(e, sh, bd);  // (a pass that overflowed its list leaves holes: flagged, never followed)
-        }
-    }
-    EdgeSetup es;
-    int p = 0, r0 = 0, key = -1, rows_first = 0, y_lo = 0, y_hi = 0;
-    ok = ok && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
-    if (ok) {
-        chunk_rows(es.y_begin, es.y_end, cidx, y_lo, y_hi);
-        ok = y_lo < y_hi;
-    }
-    auto rows_in = [&](int band_, int& ya, int& yb) {  // the chunk's rows inside band `band_` (layer-local [ya, yb))
-        const int b0row = band_ * TR + vr0 - r0;
-        ya = y_lo > b0row ? y_lo : b0row;
-        yb = y_hi < b0row + TR ? y_hi : b0row + TR;
-    };
-    int bf = 0, bl = -1;
-    if (ok) {
-        const PathBin pbin = bins[p];
-        bf = (r0 + y_lo - vr0) / TR;
-        bl = (r0 + y_hi - 1 - vr0) / TR;
-        key = pbin.pb_off - pbin.b0 + bf;
-        if (key < 0 || key + (bl - bf) >= pb_cap) ok = false;  // flagged by k_edge_count
-    }
-    if (ok && owns_band(own, bf)) {
-        int ya, yb;
-        rows_in(bf, ya, yb);
-        rows_first = yb - ya;
-    }
-    int head, len, total;
-    wave_runs(key, ok, lane, head, len);
-    const int excl = wave_excl_scan(rows_first, lane, total);
-    const int run_end_incl = __shfl(excl + rows_first, (head + len - 1) & 63);
-    const int run_begin_excl = __shfl(excl, head);
-    int run_base = 0;
-    if (ok && head == lane && run_end_incl > run_begin_excl) run_base = atomicAdd(&pb_cursor[key], run_end_incl - run_begin_excl);
-    run_base = __shfl(run_base, head);
-
-    // The record slots of the first EMIT_PRE bands of the chunk are reserved here, before the row loop, with their loads and
-    // (returning) atomics in flight together: reserved on entering each band they stalled the whole wave for a round trip
-    // at every turn in which some lane crossed a band border.
-    constexpr int EMIT_PRE = 4;
-    int pre_slot[EMIT_PRE];
-#pragma unroll
-    for (int i = 0; i < EMIT_PRE; ++i) {
-        pre_slot[i] = 0;
-        const int band_i = bf + i;
-        if (ok && band_i <= bl && owns_band(own, band_i)) {
-            int ya, y1;
-            rows_in(band_i, ya, y1);
-            const int in_block = i == 0 ? run_base + (excl - run_begin_excl) : atomicAdd(&pb_cursor[key + i], y1 - ya);
-            pre_slot[i] = bseg_off[key + i] + in_block;
-        }
-    }
-
-    RowState st;
-    st.x_next = es.x;
-    st.x = es.x;
-    st.d = 0.0;
-    // a later chunk of a long edge: carry x from the edge's first row to the chunk's, exactly as the walk would (S:2244-2248)
-    if (ok)
-        for (int yy = es.y_begin; yy < y_lo; ++yy) row_step(st, yy, es.p0y, es.p1y, es.dxdy, es.dir);
-    int y = ok ? y_lo : 0;
-    const int y_end = ok ? y_hi : 0;
-    int band = bf - 1, band_end = y, slot = 0, band_row0 = 0;  // "end of band bf - 1": the first turn enters band bf
-    while (__ballot(y < y_end) != 0ull) {
-        bool has = false;
-        RowRec r;
-        int dest = 0;
-        if (y < y_end) {
-            while (y == band_end && y < y_end) {  // enter the next band
-                ++band;
-                int ya, y1;
-                rows_in(band, ya, y1);
-                if (!owns_band(own, band)) {  // another rank's band: only carry x across it (S:2244-2248)
-                    for (; y < y1; ++y) row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);
-                    band_end = y;
-                    continue;
-                }
-                const int bi = band - bf;
-                if (bi < EMIT_PRE) {
-                    slot = bi == 0 ? pre_slot[0] : (bi == 1 ? pre_slot[1] : (bi == 2 ? pre_slot[2] : pre_slot[3]));
-                } else {  // (an edge taller than EMIT_PRE bands: the rest as they come)
-                    const int pb = key + bi;
-                    slot = bseg_off[pb] + atomicAdd(&pb_cursor[pb], y1 - ya);
-                }
-                band_end = y1;
-                band_row0 = band * TR + vr0 - r0;
-            }
-            if (y < y_end) {
-                row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);  // carry x exactly as S:2244-2248
-                const RowPieces rp = row_record(st.x, st.x_next, st.d);
-                unsigned n = (unsigned)rp.n;
-                if (n > SPAN_MAX) { atomicOr(&bd->err, 16); n = SPAN_MAX; }
-                r.x0i = rp.x0i;
-                r.nrow = n | ((unsigned)(y - band_row0) << 26);
-                r.v[0] = rp.v[0]; r.v[1] = rp.v[1]; r.v[2] = rp.v[2]; r.v[3] = rp.v[3]; r.v[4] = rp.v[4];
-                dest = slot;
-                has = slot < rec_cap;
-                if (!has) atomicOr(&bd->err, 8);
-                ++slot;
-                ++y;
-            }
-        }
-        // this turn's records, packed by lane rank, then out in 16-byte chunks: chunk j of the turn by lane j % 64
-        const unsigned long long m = __ballot(has);
-        const int n_rec = __popcll(m), rank = mask_rank(m);
-        if (n_rec < SVGR_EMIT_DIRECT) {
-            // the tail of the longest edges of the wave: a handful of records, stored by their own lanes (the transpose
-            // would cost more than the partial-line writes it saves)
-            if (has) {
-                const uint4* src = (const uint4*)&r;
-                uint4* dst = (uint4*)(recs + dest);
-#pragma unroll
-                for (int c = 0; c < CPR; ++c) dst[c] = src[c];
-            }
-            continue;
-        }
-        if (has) {
-            const uint4* src = (const uint4*)&r;
-#pragma unroll
-            for (int c = 0; c < CPR; ++c) s_stage[wave][rank * CPR + c] = src[c];
-            s_dest[wave][rank] = dest;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int c = 0; c < CPR; ++c) {
-            const int j = c * 64 + lane;
-            if (j < n_rec * CPR) {
-                const int rr = j / CPR, part = j - rr * CPR;
-                ((uint4*)(recs + s_dest[wave][rr]))[part] = s_stage[wave][j];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1262,47 +960,330 @@ __device__ __forceinline__ unsigned add_where(int trow, int tcol, int len) {
     return (unsigned)(lds_index(trow, tcol) * 8) | ((unsigned)(len - 1) << 16) | ((unsigned)(tcol & (PX - 1)) << 22);
 }
 
-// After k_edge_emit, half a wave per (path, band) pair with records.  Per record: the pieces that fall into each column
-// tile it touches are summed in closed form and added to a per-pair LDS table [column tile][row] (ds_add_f64), the adds
-// they will take counted; then the lanes walk the tiles left to right, two column tiles x 16 rows at a time, with the
-// running sum = the carry-in of every tile row (np.cumsum entering the tile, S:983): class of every cell, and for the cells
-// with records the size of their add list -- carry-ins first (one add per row at the layer's first column in the tile),
-// then the layer-edge sentinels (NaN behind the layer's last column, see k_tile_render), then the pieces.  ONE reservation
-// per pair in the band's add block (the plan measured what every band needs); a second walk writes the headers, the
-// entry-bitmask bits, the carry-ins and sentinels; a second pass over the records writes the pieces.  Pairs wider than
-// PC_CT column tiles take several passes.  `adds` == nullptr: count only (the plan's measuring run).
-constexpr int PC_CT = 16;      // column tiles of a pair per pass
-constexpr int PC_BLOCK = 256;
-constexpr int PC_LANES = 32;   // lanes per pair: TWO pairs per wave (a chain of dependent loads per pair: half as many
-                               // waves with the same chain each halve the rounds)
-static_assert(PC_LANES % TR == 0, "k_pair_cells walks PC_LANES / TR column tiles per step");
-#ifndef SVGR_PC_WAVES
-#define SVGR_PC_WAVES 4
+// ---------------------------------------------------------------------------------------------
+// edge rows -> cells.  Two passes over the edge rows with the scan of the (path, band) pairs between them:
+//   k_edge_cells   per row and cell it touches: how many adds its pieces make there, and their sum (global atomics into
+//                  the cell's counter and into the cell's per-row sums)
+//   k_pair_scan    per pair: the carry-in of every tile row = running sum of the cell sums left of it, the class of every
+//                  cell, the size and place of its add list, its header, its carry-in and layer-edge adds
+//   k_edge_adds    per row again: the pieces as adds, straight into the cell's list
+// Nothing row-sized is stored in between: the second pass recomputes a row's pieces (a few dozen double operations) instead
+// of writing a 48-byte record and reading it back twice.
+// ---------------------------------------------------------------------------------------------
+// What a lane needs of its path to find the cell of a (layer row, layer column)
+struct PathCells {
+    int r0, c0, cols;     // layer origin and width (clipped bbox)
+    int b0, nct;          // first band of the bbox, column tiles it spans
+    int cell_off;         // cell of (b0, first column tile)
+    int x_first;          // layer column at which the path's first column tile starts (<= 0)
+};
+__device__ __forceinline__ PathCells path_cells(const int* __restrict__ bbox, const PathBin* __restrict__ bins, int p, int vc0) {
+    const int4 bb = ((const int4*)bbox)[p];
+    const PathBin pbin = bins[p];
+    PathCells pc;
+    pc.r0 = bb.x; pc.c0 = bb.y; pc.cols = bb.w;
+    pc.b0 = pbin.b0; pc.cell_off = pbin.cell_off;
+    int ct0;
+    path_ctiles(bb.y, bb.w, vc0, ct0, pc.nct);
+    pc.x_first = vc0 + ct0 * TC - bb.y;
+    return pc;
+}
+// the column tiles [kf, kl] (relative to the path's first) that the pieces of a row (x0i, n) fall into; x0i < cols
+__device__ __forceinline__ void row_tiles(const PathCells& pc, int x0i, int n, int& kf, int& kl) {
+    const int xl = x0i + (n >= 2 ? n : 1);  // column of the last piece
+    const int cf = x0i > 0 ? x0i : 0;
+    int cl = xl > 0 ? xl : 0;
+    cl = cl < pc.cols - 1 ? cl : pc.cols - 1;
+    kf = (cf - pc.x_first) / TC;
+    kl = (cl - pc.x_first) / TC;
+}
+// layer columns [ca, cb) of the path's column tile k
+__device__ __forceinline__ void tile_cols(const PathCells& pc, int k, int& ca, int& cb) {
+    ca = k * TC + pc.x_first;
+    cb = ca + TC;
+    ca = ca > 0 ? ca : 0;
+    cb = cb < pc.cols ? cb : pc.cols;
+}
+// how many adds record_adds makes for the row (x0i, n) in the layer columns [ca, cb)
+__device__ __forceinline__ int row_add_count(int x0i, int n, int ca, int cb) {
+    const double none[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    int ne = 0;
+    record_adds(x0i, n, none, ca, cb, [&](int, double) { ++ne; }, [&](int, int, double) { ++ne; });
+    return ne;
+}
+// (x0i, n) of row_record without the pieces
+__device__ __forceinline__ void row_span_n(double x, double x_next, int& x0i, int& n) {
+    const double x0 = x < x_next ? x : x_next, x1 = x < x_next ? x_next : x;
+    x0i = clamp_to_int(floor(x0));
+    const int x1i = clamp_to_int(ceil(x1));
+    n = x1i <= x0i + 1 ? 1 : x1i - x0i;
+}
+
+// The work item of the two row passes is a CHUNK of an edge's rows, not the edge: a wave runs as long as its longest item, and
+// real drawings have edges of hundreds of rows next to edges of two (a synthetic blob: mean 3 rows, longest 49).  An edge of up to
+// CHUNK_ROWS rows is one chunk; a longer one is cut into at most CHUNK_MAX equal chunks.  A chunk that does not start at the
+// edge's first row replays the x recurrence from there (S:2244-2248: a dozen instructions per row, against ~150 for a row
+// whose pieces are computed), so every row still sees the bits the sequential walk gives it.  (The Ghostscript tiger's device
+// step went from 0.219 to 0.146 ms with the chunks.)
+// Items 0 .. n_edges-1 are the first chunks of the edge slots; the extra chunks of long edges sit in a sharded list that the
+// first pass (k_edge_cells<false>) writes while it handles the first chunks.
+#ifndef SVGR_CHUNK_ROWS
+#define SVGR_CHUNK_ROWS 16
 #endif
-__global__ __launch_bounds__(PC_BLOCK, SVGR_PC_WAVES) void k_pair_cells(const TileEntry* __restrict__ entries, const int2* __restrict__ entry_where,
-                                                        const RowRec* __restrict__ recs, const double* __restrict__ path_paint,
-                                                        const uint8_t* __restrict__ path_rule, const int* __restrict__ path_group,
-                                                        const int* __restrict__ path_grad, int vr0, int vc0, int n_ct, int mask_words,
+constexpr int CHUNK_ROWS = SVGR_CHUNK_ROWS, CHUNK_MAX = 16, CHUNK_SHIFT = 27;  // (chunk id: edge | chunk << 27)
+__host__ __device__ __forceinline__ int edge_chunks(int rows) {
+    if (rows <= CHUNK_ROWS) return 1;
+    const int n = (rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
+    return n < CHUNK_MAX ? n : CHUNK_MAX;
+}
+// rows [y_lo, y_hi) of chunk c of an edge that walks the rows [y_begin, y_end)
+__device__ __forceinline__ void chunk_rows(int y_begin, int y_end, int c, int& y_lo, int& y_hi) {
+    const int rows = y_end - y_begin, n = edge_chunks(rows), per = (rows + n - 1) / n;
+    y_lo = y_begin + c * per;
+    y_hi = y_lo + per < y_end ? y_lo + per : y_end;
+    y_lo = y_lo < y_end ? y_lo : y_end;
+}
+// entry x of the chunk list -> {edge, chunk}; false: the slot is not filled
+__device__ __forceinline__ bool chunk_list_item(int x, const EdgeShards& sh, const BatchDev* __restrict__ bd, const int* __restrict__ chunks,
+                                                int n_edges, int& e, int& cidx) {
+    int sd = 0;
+#pragma unroll
+    for (int k = 1; k < NSH; ++k) sd += x >= sh.cbase[k] ? 1 : 0;
+    const int filled = bd->shard[sd].chunk_cursor < sh.ccap[sd] ? bd->shard[sd].chunk_cursor : sh.ccap[sd];
+    if (x - sh.cbase[sd] >= filled) return false;
+    const int w = chunks[x];
+    e = w & ((1 << CHUNK_SHIFT) - 1);
+    cidx = (int)((unsigned)w >> CHUNK_SHIFT);
+    return e < n_edges && edge_live(e, sh, bd);  // (a pass that overflowed its list leaves holes: flagged, never followed)
+}
+
+// First row pass.  EXTRA = false: one lane per edge slot, its first chunk; the extra chunks of long edges go to the sharded
+// list (`chunks` == nullptr: only counted -- the plan's measuring run).  EXTRA = true: one lane per entry of that list.
+// Per row (S:2244-2303) and column tile the row's pieces fall into: the number of adds they make there goes to the cell's
+// counter, their sum to the cell's sum of that tile row -- two fire-and-forget atomics.  The second pass (k_edge_adds) takes
+// the same decisions from the same arithmetic.
+template <bool EXTRA>
+__global__ __launch_bounds__(256) void k_edge_cells(const double* __restrict__ edges, const int* __restrict__ edge_path,
+                                                    const int* __restrict__ bbox, const PathBin* __restrict__ bins, int vr0, int vc0,
+                                                    int cell_cap, int* __restrict__ cell_cnt, double* __restrict__ cell_sum,
+                                                    BatchDev* __restrict__ bd, Owner own, const EdgeShards sh, int n_edges,
+                                                    int* __restrict__ chunks, int stats) {
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    int e = ci, cidx = 0;
+    bool ok;
+    if (!EXTRA) ok = ci < n_edges && edge_live(ci, sh, bd);
+    else ok = chunk_list_item(ci, sh, bd, chunks, n_edges, e, cidx);
+    EdgeSetup es;
+    int p = 0, r0 = 0;
+    ok = ok && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
+    if (!EXTRA) {
+        // The edge's first chunk needs no list: work item e is chunk 0 of edge slot e.  The extra chunks of a long edge go to a
+        // list behind the edge slots, reserved per wave in one of NSH shards (a single cursor would serialise the 12 000 waves
+        // of this kernel: ~90 returning atomics per microsecond and address).  The list's shard of an edge is the flatten shard
+        // its slot lies in: WHICH edges a flatten shard holds is fixed by the flatten's wave numbering (where inside the shard
+        // they land is not), so the per-shard chunk totals the plan measured hold for every later pass.  The 64 consecutive
+        // slots of a wave lie in one shard, or in two at a shard border.
+        const int extra = ok ? edge_chunks(es.y_end - es.y_begin) - 1 : 0;
+        unsigned long long todo = __ballot(extra > 0);
+        if (todo != 0ull) {
+            int my_shard = 0;
+#pragma unroll
+            for (int k = 1; k < NSH; ++k) my_shard += e >= sh.base[k] ? 1 : 0;
+            int at = 0;
+            while (todo != 0ull) {
+                const int s0 = __builtin_amdgcn_readlane(my_shard, __ffsll((long long)todo) - 1);
+                const bool mine = extra > 0 && my_shard == s0;
+                const int a = wave_alloc(&bd->shard[s0].chunk_cursor, mine ? extra : 0, lane);
+                at = mine ? a : at;
+                todo &= ~__ballot(mine);
+            }
+            if (chunks && extra > 0) {
+                if (at + extra > sh.ccap[my_shard] || e >= (1 << CHUNK_SHIFT)) {
+                    atomicOr(&bd->err, 2);
+                } else {
+                    for (int c = 0; c < extra; ++c) chunks[sh.cbase[my_shard] + at + c] = e | ((c + 1) << CHUNK_SHIFT);
+                }
+            }
+        }
+    }
+    int n_rows = 0;
+    if (ok) {
+        int y_lo, y_hi;
+        chunk_rows(es.y_begin, es.y_end, cidx, y_lo, y_hi);
+        const PathCells pc = path_cells(bbox, bins, p, vc0);
+        RowState st;
+        st.x_next = es.x; st.x = es.x; st.d = 0.0;
+        // a later chunk of a long edge: carry x from the edge's first row to the chunk's, exactly as the walk would (S:2244-2248)
+        for (int yy = es.y_begin; yy < y_lo; ++yy) row_step(st, yy, es.p0y, es.p1y, es.dxdy, es.dir);
+        for (int y = y_lo; y < y_hi; ++y) {
+            row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);
+            const int vrow = r0 + y - vr0, band = vrow / TR;
+            if (!owns_band(own, band)) continue;  // another rank's band: only x is carried across it
+            ++n_rows;
+            const RowPieces rp = row_record(st.x, st.x_next, st.d);
+            int n = rp.n;
+            if ((unsigned)n > SPAN_MAX) { atomicOr(&bd->err, 16); n = (int)SPAN_MAX; }
+            if (rp.x0i >= pc.cols) continue;  // the whole row lies beyond the layer (S:2260)
+            int kf, kl;
+            row_tiles(pc, rp.x0i, n, kf, kl);
+            const int cell_row = pc.cell_off + (band - pc.b0) * pc.nct;
+            for (int k = kf; k <= kl; ++k) {
+                int ca, cb;
+                tile_cols(pc, k, ca, cb);
+                const int ne = row_add_count(rp.x0i, n, ca, cb);
+                if (ne == 0) continue;
+                const int cell = cell_row + k;
+                if ((unsigned)cell >= (unsigned)cell_cap) { atomicOr(&bd->err, 32); continue; }
+                const double part = record_sum_range(rp.x0i, n, rp.v, ca, cb);
+                atomicAdd(&cell_cnt[cell], ne);
+                unsafeAtomicAdd(&cell_sum[(size_t)cell * TR + (vrow & (TR - 1))], part);
+            }
+        }
+    }
+    if (stats) {  // (plan only) edge rows of the batch
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) n_rows += __shfl_xor(n_rows, d);
+        if (lane == 0 && n_rows > 0) atomicAdd(&bd->bseg_cursor, n_rows);
+    }
+}
+
+// Second row pass, after k_pair_scan: one lane per chunk again (first chunks and the list's).  A first walk over the chunk's
+// rows finds the cells it touches and how many adds it has for each -- only the spans, no pieces --; the lane then takes its
+// places in those cells' lists (one returning atomic per cell, all in flight together: a chunk stays within a few cells) and
+// walks the rows a second time, now computing the pieces and storing them as adds.
+constexpr int EA_SLOTS = 4;   // cells of a chunk that get their places up front; a chunk that touches more takes the rest row by row
+__global__ __launch_bounds__(256) void k_edge_adds(const double* __restrict__ edges, const int* __restrict__ edge_path,
+                                                   const int* __restrict__ bbox, const PathBin* __restrict__ bins, int vr0, int vc0,
+                                                   int cell_cap, int* __restrict__ cell_pos, TileAdd* __restrict__ adds, int add_cap,
+                                                   BatchDev* __restrict__ bd, Owner own, const EdgeShards sh, int n_edges,
+                                                   const int* __restrict__ chunks) {
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+    int e = ci, cidx = 0;
+    bool ok;
+    if (ci < n_edges) ok = edge_live(ci, sh, bd);
+    else ok = chunk_list_item(ci - n_edges, sh, bd, chunks, n_edges, e, cidx);
+    EdgeSetup es;
+    int p = 0, r0 = 0;
+    ok = ok && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
+    if (!ok) return;
+    int y_lo, y_hi;
+    chunk_rows(es.y_begin, es.y_end, cidx, y_lo, y_hi);
+    const PathCells pc = path_cells(bbox, bins, p, vc0);
+    RowState st0;
+    st0.x_next = es.x; st0.x = es.x; st0.d = 0.0;
+    for (int yy = es.y_begin; yy < y_lo; ++yy) row_step(st0, yy, es.p0y, es.p1y, es.dxdy, es.dir);
+    // ---- walk 1: the cells and their add counts ----
+    int sc[EA_SLOTS], sn[EA_SLOTS];
+#pragma unroll
+    for (int s = 0; s < EA_SLOTS; ++s) { sc[s] = -1; sn[s] = 0; }
+    {
+        RowState st = st0;
+        for (int y = y_lo; y < y_hi; ++y) {
+            row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);
+            const int vrow = r0 + y - vr0, band = vrow / TR;
+            if (!owns_band(own, band)) continue;
+            int x0i, n;
+            row_span_n(st.x, st.x_next, x0i, n);
+            n = (unsigned)n > SPAN_MAX ? (int)SPAN_MAX : n;
+            if (x0i >= pc.cols) continue;
+            int kf, kl;
+            row_tiles(pc, x0i, n, kf, kl);
+            const int cell_row = pc.cell_off + (band - pc.b0) * pc.nct;
+            for (int k = kf; k <= kl; ++k) {
+                int ca, cb;
+                tile_cols(pc, k, ca, cb);
+                const int ne = row_add_count(x0i, n, ca, cb);
+                const int cell = cell_row + k;
+                if (ne == 0 || (unsigned)cell >= (unsigned)cell_cap) continue;
+                bool placed = false;
+#pragma unroll
+                for (int s = 0; s < EA_SLOTS; ++s) {
+                    const bool here = !placed && (sc[s] == cell || sc[s] < 0);
+                    sc[s] = here ? cell : sc[s];
+                    sn[s] += here ? ne : 0;
+                    placed = placed || here;
+                }
+            }
+        }
+    }
+    // ---- the lane's places in those lists (a refused cell keeps a negative position) ----
+    int sp[EA_SLOTS];
+#pragma unroll
+    for (int s = 0; s < EA_SLOTS; ++s) sp[s] = sn[s] > 0 ? atomicAdd(&cell_pos[sc[s]], sn[s]) : 0;
+    // ---- walk 2: the pieces as adds ----
+    RowState st = st0;
+    for (int y = y_lo; y < y_hi; ++y) {
+        row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);
+        const int vrow = r0 + y - vr0, band = vrow / TR;
+        if (!owns_band(own, band)) continue;
+        const RowPieces rp = row_record(st.x, st.x_next, st.d);
+        const int n = (unsigned)rp.n > SPAN_MAX ? (int)SPAN_MAX : rp.n;
+        if (rp.x0i >= pc.cols) continue;
+        int kf, kl;
+        row_tiles(pc, rp.x0i, n, kf, kl);
+        const int cell_row = pc.cell_off + (band - pc.b0) * pc.nct;
+        const int trow = vrow & (TR - 1);
+        for (int k = kf; k <= kl; ++k) {
+            int ca, cb;
+            tile_cols(pc, k, ca, cb);
+            const int ne = row_add_count(rp.x0i, n, ca, cb);
+            const int cell = cell_row + k;
+            if (ne == 0 || (unsigned)cell >= (unsigned)cell_cap) continue;
+            int pos = 0;
+            bool found = false;
+#pragma unroll
+            for (int s = 0; s < EA_SLOTS; ++s) {
+                const bool here = !found && sc[s] == cell;
+                pos = here ? sp[s] : pos;
+                sp[s] += here ? ne : 0;
+                found = found || here;
+            }
+            if (!found) pos = atomicAdd(&cell_pos[cell], ne);  // (the chunk's fifth cell and beyond)
+            if (pos < 0) continue;                              // (k_pair_scan refused the cell: flagged there)
+            if ((long long)pos + ne > (long long)add_cap) { atomicOr(&bd->err, 64); continue; }
+            TileAdd* dst = adds + pos;
+            const int cell_c0 = k * TC + pc.x_first;  // layer column of the tile's column 0
+            record_adds(rp.x0i, n, rp.v, ca, cb,
+                        [&](int c, double val) { TileAdd t; t.where = add_where(trow, c - cell_c0, 1); t.zero = 0u; t.v = val; *dst++ = t; },
+                        [&](int c, int len, double val) { TileAdd t; t.where = add_where(trow, c - cell_c0, len); t.zero = 0u; t.v = val; *dst++ = t; });
+        }
+    }
+}
+
+// Between the two row passes: TR lanes per (path, band) pair of the band lists (lane = tile row), walking the pair's column
+// tiles left to right with the row's running sum = the carry-in of every tile row (np.cumsum entering the tile, S:983).
+// Per cell: its class, the size of its add list -- carry-ins first (one add per row at the layer's first column in the tile),
+// then the layer-edge sentinels (NaN behind the layer's last column, see k_tile_render), then the pieces k_edge_cells counted.
+// ONE reservation per pair in the band's add block (the plan measured what every band needs); a second walk writes the
+// headers, the entry-bitmask bits, the carry-ins and sentinels, and leaves in cell_pos where k_edge_adds continues the list.
+// The cells' counters and sums are returned to zero as they are read: the next render's first pass adds into them again.
+// `adds` == nullptr: count only (the plan's measuring run).
+constexpr int PS_BLOCK = 256;
+constexpr int PS_LANES = TR;            // lanes per pair
+constexpr int PS_STEP = 4;              // column tiles whose counters and sums are loaded together
+static_assert(64 % PS_LANES == 0, "k_pair_scan: whole pairs per wave");
+__global__ __launch_bounds__(PS_BLOCK) void k_pair_scan(const TileEntry* __restrict__ entries, const int2* __restrict__ entry_where,
+                                                        int* __restrict__ cell_cnt, double* __restrict__ cell_sum,
+                                                        const double* __restrict__ path_paint, const uint8_t* __restrict__ path_rule,
+                                                        const int* __restrict__ path_group, const int* __restrict__ path_grad,
+                                                        int vr0, int vc0, int n_ct, int mask_words,
                                                         unsigned long long* __restrict__ tile_mask, CellHdr* __restrict__ cell_hdr,
                                                         int cell_cap, const int2* __restrict__ band_adds, int* __restrict__ band_add_cur,
-                                                        TileAdd* __restrict__ adds, BatchDev* __restrict__ bd) {
-    constexpr int NSLOT = PC_BLOCK / PC_LANES, KSTEP = PC_LANES / TR;
-    static_assert(KSTEP == 2, "the add cursor below is advanced for two column tiles per step");
-    __shared__ double s_sum[NSLOT][PC_CT][TR + 1];   // (+1: rows of neighbouring column tiles on different banks)
-    __shared__ int s_cnt[NSLOT][PC_CT], s_pos[NSLOT][PC_CT];
-    const int lane = threadIdx.x & 63, hl = lane & (PC_LANES - 1), half = lane / PC_LANES;
-    const int slot = threadIdx.x / PC_LANES;                  // this pair's table in LDS
-    const int e = blockIdx.x * NSLOT + slot;
+                                                        TileAdd* __restrict__ adds, int* __restrict__ cell_pos, BatchDev* __restrict__ bd) {
+    constexpr int NSLOT = PS_BLOCK / PS_LANES;
+    constexpr unsigned long long GMASK = PS_LANES == 64 ? ~0ull : ((1ull << PS_LANES) - 1ull);
+    const int lane = threadIdx.x & 63, row_l = lane & (PS_LANES - 1);
+    const int shift = lane & ~(PS_LANES - 1);                 // first lane of this pair's group in the wave
+    const int e = blockIdx.x * NSLOT + threadIdx.x / PS_LANES;
     TileEntry en = entries[e];            // (both arrays hold the whole grid: loaded before the bound is known)
     const int2 where = entry_where[e];    // {band, index in the band's list}
-    bool active = e < bd->entry_cursor;   // (pairs are independent: no workgroup barrier below, only wave-level ones)
+    bool active = e < bd->entry_cursor;
     if (active && (where.y >> 6) >= mask_words) {  // (the plan sized the masks from the longest band list)
-        if (hl == 0) atomicOr(&bd->err, 32);
+        if (row_l == 0) atomicOr(&bd->err, 32);
         active = false;
     }
     int ct0 = 0, nct = 0;
     if (active) path_ctiles(en.c0, en.cols, vc0, ct0, nct);
-    else en.cnt = 0;
     const int band = active ? where.x : 0;
     const int2 blk = adds ? band_adds[band] : make_int2(0, 0x7fffffff);  // the band's add block {first slot, slots}
     // the tiles' entry bitmasks: per (band, column tile) two rows of mask_words words, bit i = entry i of the band's list
@@ -1315,127 +1296,65 @@ __global__ __launch_bounds__(PC_BLOCK, SVGR_PC_WAVES) void k_pair_cells(const Ti
     const int group = path_group ? path_group[pth] : -1;
     const int grad1 = path_grad ? path_grad[pth] + 1 : 0;  // gradient index + 1 (0: solid colour)
     const double4 paint = ((const double4*)path_paint)[pth];
-    const int row_l = hl & (TR - 1), sub = hl / TR;  // this lane's row and its column tile of the KSTEP walked per step
     // is this lane's tile row a row of the layer?  (the sentinel behind the layer's last column is set on those only)
     const int row_abs = vr0 + band * TR + row_l;
     const bool row_in_layer = row_abs >= en.r0 && row_abs < en.r0 + en.rows;
-    const int shift16 = half * PC_LANES + sub * TR;  // first lane of this lane's 16-lane (column tile) group in the wave
-    double run = 0.0;  // the row's running sum left of the column tiles walked so far
-    auto load_rec = [&](int j, int& x0i, int& n, int& row, double* v) {
-        const RowRec* r = recs + en.seg0 + j;
-        const int4 h = *(const int4*)r;  // {x0i, nrow, v0 lo, v0 hi}
-        const double2 w0 = *(const double2*)((const char*)r + 16), w1 = *(const double2*)((const char*)r + 32);
-        v[0] = __hiloint2double(h.w, h.z); v[1] = w0.x; v[2] = w0.y; v[3] = w1.x; v[4] = w1.y;
-        x0i = h.x; n = (int)((unsigned)h.y & SPAN_MAX); row = (int)((unsigned)h.y >> 26);
-    };
-    // the column tiles [kf, kl] of this pass (relative to `base`, clipped to [0, nc)) that record (x0i, n) has pieces in
-    auto rec_tiles = [&](int x0i, int n, int base, int nc, int& kf, int& kl) {
-        const int xl = x0i + (n >= 2 ? n : 1);  // column of the last piece
-        const int cf = x0i > 0 ? x0i : 0;
-        int cl = xl > 0 ? xl : 0;
-        cl = cl < en.cols - 1 ? cl : en.cols - 1;
-        kf = (cf - x_first) / TC - base;
-        kl = (cl - x_first) / TC - base;
-        kf = kf > 0 ? kf : 0;
-        kl = kl < nc - 1 ? kl : nc - 1;
-    };
-    // layer columns [ca, cb) of column tile k of this pass
-    auto tile_cols = [&](int base, int k, int& ca, int& cb) {
-        ca = (base + k) * TC + x_first;
-        cb = ca + TC;
-        ca = ca > 0 ? ca : 0;
-        cb = cb < en.cols ? cb : en.cols;
-    };
-    // (the two pairs of a wave may need different numbers of passes: the wave-level barriers are reached by both halves)
-    const int nct_w = max(__builtin_amdgcn_readlane(nct, 0), __builtin_amdgcn_readlane(nct, PC_LANES % 64));
-    for (int base = 0; base < nct_w; base += PC_CT) {
-        int nc = nct - base < PC_CT ? nct - base : PC_CT;
-        nc = nc > 0 ? nc : 0;
-        for (int i = hl; i < nc * (TR + 1); i += PC_LANES) (&s_sum[slot][0][0])[i] = 0.0;
-        if (hl < nc) s_cnt[slot][hl] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- pass A: per column tile the row sums of the pieces inside it, and how many adds they make ----
-        for (int j = hl; j < (nc > 0 ? en.cnt : 0); j += PC_LANES) {
-            int x0i, n, row;
-            double v[5];
-            load_rec(j, x0i, n, row, v);
-            if (x0i >= en.cols) continue;  // the whole row lies beyond the layer (S:2260)
-            int kf, kl;
-            rec_tiles(x0i, n, base, nc, kf, kl);
-            for (int k = kf; k <= kl; ++k) {
-                int ca, cb;
-                tile_cols(base, k, ca, cb);
-                const double part = record_sum_range(x0i, n, v, ca, cb);
-                int ne = 0;
-                record_adds(x0i, n, v, ca, cb, [&](int, double) { ++ne; }, [&](int, int, double) { ++ne; });
-                if (ne > 0) {
-                    __hip_atomic_fetch_add(&s_sum[slot][k][row], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&s_cnt[slot][k], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- walk the column tiles, twice: KSTEP per step, lane (sub, row) takes column tile k4 + sub; its carry-in =
-        //      run + the sums of the column tiles of this step to its left (read back from the table).  The first walk
-        //      sizes the add lists, the second -- behind the pair's reservation -- writes ----
-        int blk_at = 0;       // first slot of this pass's adds in the band's block
-        bool blk_ok = true;
-        const double run_in = run;
+    int blk_at = 0;       // first slot of this pair's adds in the band's block
+    bool blk_ok = true;
 #pragma unroll 1
-        for (int phase = 0; phase < 2; ++phase) {
-            int cursor = 0;   // adds of the column tiles walked so far
-            run = run_in;
-            for (int k4 = 0; k4 < nc; k4 += KSTEP) {
-                const int k = k4 + sub;
-                double left = 0.0, all = 0.0;
+    for (int phase = 0; phase < 2; ++phase) {
+        int cursor = 0;   // adds of the column tiles walked so far
+        double run = 0.0; // the row's running sum left of the column tile
+        for (int k0 = 0; __ballot(k0 < nct) != 0ull; k0 += PS_STEP) {
+            int own[PS_STEP];
+            double sq[PS_STEP];
 #pragma unroll
-                for (int q = 0; q < KSTEP; ++q) {
-                    const double sq = k4 + q < nc ? s_sum[slot][k4 + q][row_l] : 0.0;
-                    left = q < sub ? left + sq : left;
-                    all = all + sq;
-                }
-                const double cin = run + left;
-                const bool live = k < nc;
-                const int own = live ? s_cnt[slot][k] : 0;
+            for (int j = 0; j < PS_STEP; ++j) {  // (all loads of the step in flight together)
+                const bool live = k0 + j < nct;
+                const int cell = en.cell0 + k0 + j;
+                const bool in = live && (unsigned)cell < (unsigned)cell_cap;
+                own[j] = in ? cell_cnt[cell] : 0;
+                sq[j] = in ? cell_sum[(size_t)cell * TR + row_l] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < PS_STEP; ++j) {
+                const int k = k0 + j;
+                const bool live = k < nct;
+                const double cin = run;
                 const bool vis = live && carry_visible(cin, rule);
-                const unsigned long long vm = __ballot(vis);  // (lanes of the other pair may be masked off here: their bits are 0)
-                const int cls = own > 0 ? 2 : (((vm >> shift16) & 0xffffull) != 0ull ? 1 : 0);
+                const unsigned long long vm = (__ballot(vis) >> shift) & GMASK;
+                const int cls = own[j] > 0 ? 2 : (vm != 0ull ? 1 : 0);
                 // class 2: the cell's add list = [carry-ins of the rows where it is not zero][sentinels][pieces]
-                const int cell_c0 = (base + k) * TC + x_first;        // layer column of the tile's column 0
+                const int cell_c0 = k * TC + x_first;                 // layer column of the tile's column 0
                 const int t_first = cell_c0 < 0 ? -cell_c0 : 0;       // tile column of the layer's first column inside the tile
                 const int t_end = en.cols - cell_c0;                  // tile column one past the layer's last column
-                const bool want_carry = cls == 2 && cin != 0.0;
-                const bool want_sent = cls == 2 && t_end < TC && row_in_layer;
-                const unsigned cm = (unsigned)((__ballot(want_carry) >> shift16) & 0xffffull);
-                const unsigned sm = (unsigned)((__ballot(want_sent) >> shift16) & 0xffffull);
-                const int n_carry = __popc(cm), n_sent = __popc(sm);
-                const int n_add = cls == 2 ? n_carry + n_sent + own : 0;
-                // (the cells of one step take their lists in column order: the second one starts behind the first)
-                const int n_add_first = __shfl(n_add, half * PC_LANES);
-                const int off = cursor + (sub ? n_add_first : 0);
-                cursor += n_add_first + __shfl(n_add, half * PC_LANES + TR);
-                const int cell = en.cell0 + base + k;
+                const bool want_carry = live && cls == 2 && cin != 0.0;
+                const bool want_sent = live && cls == 2 && t_end < TC && row_in_layer;
+                const unsigned long long cm = (__ballot(want_carry) >> shift) & GMASK;
+                const unsigned long long sm = (__ballot(want_sent) >> shift) & GMASK;
+                const int n_carry = __popcll(cm), n_sent = __popcll(sm);
+                const int n_add = cls == 2 ? n_carry + n_sent + own[j] : 0;
+                const int off = cursor;
+                cursor += n_add;
+                const int cell = en.cell0 + k;
                 if (phase == 1 && live) {
                     if (cls != 0 && cell < cell_cap && blk_ok) {
                         CellHdr* hd = cell_hdr + cell;
                         hd->carry[row_l] = cin;
-                        const unsigned below = (1u << row_l) - 1u;
+                        const unsigned long long below = (1ull << row_l) - 1ull;
                         TileAdd* const list = adds + (size_t)blk.x + blk_at + off;
                         if (want_carry && adds) {
                             TileAdd t;
                             t.where = add_where(row_l, t_first, 1); t.zero = 0u; t.v = cin;
-                            list[__popc(cm & below)] = t;
+                            list[__popcll(cm & below)] = t;
                         }
                         if (want_sent && adds) {
                             TileAdd t;
                             t.where = add_where(row_l, t_end, 1); t.zero = 0u; t.v = __builtin_nan("");
-                            list[n_carry + __popc(sm & below)] = t;
+                            list[n_carry + __popcll(sm & below)] = t;
                         }
                         if (row_l == 0) {
-                            unsigned long long* const mw = mrow + (size_t)(base + k) * 2 * mask_words;
+                            unsigned long long* const mw = mrow + (size_t)k * 2 * mask_words;
                             atomicOr(mw, mbit);
                             if (cls == 2) atomicOr(mw + mask_words, mbit);
                             hd->paint[0] = paint.x; hd->paint[1] = paint.y; hd->paint[2] = paint.z; hd->paint[3] = paint.w;
@@ -1443,51 +1362,31 @@ __global__ __launch_bounds__(PC_BLOCK, SVGR_PC_WAVES) void k_pair_cells(const Ti
                             hd->bits = rule | (((rl >> 1) & 3) << 1) | (cls << 3) | (grad1 << 5);
                             hd->n_add = n_add; hd->add0 = blk.x + blk_at + off; hd->p = en.p;
                             hd->group = group;
-                            s_pos[slot][k] = adds ? blk_at + off + n_carry + n_sent : -1;
                         }
-                    } else if (row_l == 0) {
-                        if (cls != 0 && cell >= cell_cap) atomicOr(&bd->err, 32);
-                        s_pos[slot][k] = -1;
+                    }
+                    if (own[j] > 0) {
+                        // the pieces follow the carry-ins and sentinels (k_edge_adds); a refused cell turns them away.  Counter and
+                        // sums go back to zero for the next render.
+                        cell_sum[(size_t)cell * TR + row_l] = 0.0;
+                        if (row_l == 0) {
+                            const bool taken = cell < cell_cap && blk_ok && adds;
+                            cell_pos[cell] = taken ? blk.x + blk_at + off + n_carry + n_sent : (int)0x80000000;
+                            cell_cnt[cell] = 0;
+                            if (cell >= cell_cap) atomicOr(&bd->err, 32);
+                        }
                     }
                 }
-                run = run + all;
-            }
-            if (phase == 0) {
-                // the pair's reservation in its band's add block (one atomic per pair and pass)
-                int at = 0;
-                if (hl == 0 && cursor > 0) at = atomicAdd(&band_add_cur[band], cursor);
-                blk_at = __shfl(at, half * PC_LANES);
-                blk_ok = (long long)blk_at + cursor <= (long long)blk.y;
-                if (!blk_ok && hl == 0) atomicOr(&bd->err, 64);
+                run = run + sq[j];
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- pass B: the pieces as adds, behind the carry-ins and sentinels of their cell ----
-        for (int j = hl; j < (nc > 0 && adds ? en.cnt : 0); j += PC_LANES) {
-            int x0i, n, row;
-            double v[5];
-            load_rec(j, x0i, n, row, v);
-            if (x0i >= en.cols) continue;
-            int kf, kl;
-            rec_tiles(x0i, n, base, nc, kf, kl);
-            for (int k = kf; k <= kl; ++k) {
-                int ca, cb;
-                tile_cols(base, k, ca, cb);
-                int ne = 0;
-                record_adds(x0i, n, v, ca, cb, [&](int, double) { ++ne; }, [&](int, int, double) { ++ne; });
-                if (ne == 0 || s_pos[slot][k] < 0) continue;  // (nothing here, or the cell was refused above)
-                const int pos0 = __hip_atomic_fetch_add(&s_pos[slot][k], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                TileAdd* dst = adds + (size_t)blk.x + pos0;
-                const int cell_c0 = (base + k) * TC + x_first;
-                record_adds(x0i, n, v, ca, cb,
-                            [&](int c, double val) { TileAdd t; t.where = add_where(row, c - cell_c0, 1); t.zero = 0u; t.v = val; *dst++ = t; },
-                            [&](int c, int len, double val) { TileAdd t; t.where = add_where(row, c - cell_c0, len); t.zero = 0u; t.v = val; *dst++ = t; });
-            }
+        if (phase == 0) {
+            // the pair's reservation in its band's add block (one atomic per pair)
+            int at = 0;
+            if (row_l == 0 && cursor > 0) at = atomicAdd(&band_add_cur[band], cursor);
+            blk_at = __shfl(at, shift);
+            blk_ok = (long long)blk_at + cursor <= (long long)blk.y;
+            if (!blk_ok && row_l == 0) atomicOr(&bd->err, 64);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -2749,18 +2648,31 @@ struct svgr_batch {
         up_pending = false;
         host_keep.clear();
     }
-    // zeroed once per render: [BatchDev | per-path min/max keys | per-path row reach (multi-GPU) | pb_cnt | pb_cursor]
+    // zeroed once per render: [BatchDev | per-path min/max keys | per-path row reach (multi-GPU) | per-band add cursors]
     DevArr<unsigned char> arena;
-    size_t arena_bytes = 0, off_pkeys = 0, off_prow = 0, off_pb_cnt = 0, off_pb_cursor = 0, off_band_add = 0;
-    int pb_cap = 0;
+    size_t arena_bytes = 0, off_pkeys = 0, off_prow = 0, off_band_add = 0;
     // work arrays fully rewritten by every render
-    DevArr<int> edge_path, bbox, bseg_off, band_start, band_count;
+    DevArr<int> edge_path, bbox, band_start, band_count;
     DevArr<PathBin> bins;
     DevArr<TileEntry> entries;
     DevArr<double> edges;
-    DevArr<RowRec> bsegs;
     DevArr<CellHdr> cell_hdr;               // per (path, band, column tile) cell: header (classes 1 and 2)
-    DevArr<TileAdd> adds;                   // the pairs' add blocks (k_band_entries reserves, k_pair_cells fills)
+    // per cell: adds counted / per-row sums of its pieces (k_edge_cells adds into them, k_pair_scan reads them and puts them
+    // back to zero), and where k_edge_adds continues its add list
+    DevArr<int> cell_cnt, cell_pos;
+    DevArr<double> cell_sum;
+    bool cells_zeroed = false;              // cell_cnt / cell_sum are all zero (left so by the last k_pair_scan)
+    // a pass that ended with an error flag may have left any of the self-cleaning buffers dirty
+    void invalidate_work() { cells_zeroed = false; masks_zeroed = false; arena_zeroed = false; }
+    int size_cells() {
+        const size_t n = (size_t)std::max<int64_t>(n_cells, 1);
+        if (n > cell_cnt.cap || n * TR > cell_sum.cap) cells_zeroed = false;
+        if (int rc = cell_hdr.ensure(n + 1)) return rc;
+        if (int rc = cell_cnt.ensure(n)) return rc;
+        if (int rc = cell_pos.ensure(n)) return rc;
+        return cell_sum.ensure(n * TR);
+    }
+    DevArr<TileAdd> adds;                   // the bands' add blocks (k_pair_scan reserves per pair; k_pair_scan and k_edge_adds fill)
     DevArr<unsigned> items;                 // the tiles' item lists: cell id | class << 30 (k_tile_lists)
     DevArr<int2> tile_info;                 // per (band, column tile): {first item, items}
     DevArr<TileSlot> order;                 // the owned tiles in launch order (heaviest first)
@@ -2768,7 +2680,7 @@ struct svgr_batch {
     DevArr<int2> band_adds;                 // per band: its add block {first slot, slots} (sized by the plan's measuring run)
     std::vector<int2> host_band_adds;
     int64_t n_adds = 0;                     // add slots in all the blocks
-    bool count_adds_only = false;           // the plan's measuring run: k_pair_cells sizes the add lists, writes none
+    bool count_adds_only = false;           // the plan's measuring run: k_pair_scan sizes the add lists, nothing is written
     // lay the bands' add blocks back to back: `need[band]` slots each plus slack (the sizes repeat from render to render except
     // for carry-ins that are exactly zero in one summation order and not in another), and upload the table
     int size_band_adds(const int* need, hipStream_t st) {
@@ -2796,7 +2708,7 @@ struct svgr_batch {
     int64_t n_seg_list = -1;                // (-1: no list, every segment)
     DevArr<int> path_list;                  // ... and the paths they belong to, ascending: what k_path_bbox / k_band_entries walk
     int64_t n_path_list = 0;
-    DevArr<int> chunks;                     // extra row chunks of long edges: edge | chunk << 27, in NSH shards (k_edge_count)
+    DevArr<int> chunks;                     // extra row chunks of long edges: edge | chunk << 27, in NSH shards (k_edge_cells)
     int64_t n_chunks = 0;                   // slots of that list (sum of the shard capacities)
     // lay the chunk shards back to back with the given capacities
     int size_chunks(const int* caps) {
@@ -2808,7 +2720,7 @@ struct svgr_batch {
         }
         return chunks.ensure((size_t)std::max<int64_t>(n_chunks, 1));
     }
-    DevArr<unsigned long long> tile_mask;   // per (band, column tile): 2 x mask_words words over the band's list (k_pair_cells)
+    DevArr<unsigned long long> tile_mask;   // per (band, column tile): 2 x mask_words words over the band's list (k_pair_scan)
     int mask_words = 1;
     bool masks_zeroed = false;              // the last tile kernel left the masks cleared
     DevArr<long long> layer_off;            // SVGR_OUT_MASKS_F64: per path the start of its mask in the output
@@ -2844,17 +2756,13 @@ struct svgr_batch {
     BatchDev* bd() const { return (BatchDev*)arena.p; }
     unsigned long long* pkeys() const { return (unsigned long long*)(arena.p + off_pkeys); }
     unsigned* prow() const { return (unsigned*)(arena.p + off_prow); }
-    int* pb_cnt() const { return (int*)(arena.p + off_pb_cnt); }
-    int* pb_cursor() const { return (int*)(arena.p + off_pb_cursor); }
     int* band_add_cur() const { return (int*)(arena.p + off_band_add); }  // per band: add slots taken from its block
 
-    int layout_arena(int new_pb_cap) {
-        pb_cap = new_pb_cap;
+    // (n_bands must be final: the per-band add cursors are the arena's tail)
+    int layout_arena() {
         off_pkeys = sizeof(BatchDev);
         off_prow = off_pkeys + sizeof(unsigned long long) * 4 * (size_t)n_paths;
-        off_pb_cnt = off_prow + sizeof(unsigned) * 2 * (size_t)n_paths;
-        off_pb_cursor = off_pb_cnt + sizeof(int) * (size_t)(pb_cap + 1);
-        off_band_add = off_pb_cursor + sizeof(int) * (size_t)(pb_cap + 1);
+        off_band_add = off_prow + sizeof(unsigned) * 2 * (size_t)n_paths;
         arena_bytes = off_band_add + sizeof(int) * (size_t)(n_bands + 1);
         arena_bytes = (arena_bytes + 255) & ~(size_t)255;
         arena_zeroed = false;  // (new size or new memory)
@@ -2864,10 +2772,10 @@ struct svgr_batch {
     void release() {
         segs.release(); path_m6.release(); path_paint.release(); seg_kind.release(); path_rule.release();
         seg_path.release(); in_dev.release(); arena.release(); edge_path.release(); bbox.release(); bins.release();
-        bseg_off.release(); band_start.release(); band_count.release(); entries.release();
+        band_start.release(); band_count.release(); entries.release();
         path_group.release(); group_clip_src.release(); group_opacity.release(); groups_dev.release();
         grads.release(); path_grad.release(); grad_path.release(); grad_flags.release(); grads_dev.release();
-        edges.release(); bsegs.release(); cell_hdr.release(); entry_where.release(); tile_mask.release(); chunks.release(); seg_list.release(); path_list.release(); layer_off.release();
+        edges.release(); cell_hdr.release(); cell_cnt.release(); cell_pos.release(); cell_sum.release(); entry_where.release(); tile_mask.release(); chunks.release(); seg_list.release(); path_list.release(); layer_off.release();
         adds.release(); items.release(); tile_info.release(); order.release(); band_item0.release(); band_adds.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
@@ -2921,40 +2829,54 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np_walk,
                        use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), b->planned ? 0 : 1, plist);
     if (upto == 2) return 0;
-    const size_t ne = (size_t)std::max<int64_t>(b->n_edges, 1);
-    hipLaunchKernelGGL(k_edge_count, grid1(ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
-                       (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->pb_cap, b->pb_cnt(), b->bd(), b->own, b->shards,
-                       upto >= 4 ? b->chunks.p : (int*)nullptr);
-    // per owned band: tile list + record blocks (upto == 3: sizes only, no headers written)
+    // per owned band: its list of (path, band) pairs in paint order, and its first tile-list slot
     const int owned = count_owned_bands(b->own, b->n_bands);
     if (owned > 0)
         hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(BE_BLOCK), 0, st, (const PathBin*)b->bins.p, np_walk, plist,
-                           (const int*)b->bbox.p, (const int*)b->pb_cnt(), b->bseg_off.p,
-                           upto >= 4 ? cap_i32(b->bsegs.cap) : 0x7fffffff, b->band_start.p, b->band_count.p, b->band_item0.p, b->entries.p,
+                           (const int*)b->bbox.p, b->band_start.p, b->band_count.p, b->band_item0.p, b->entries.p,
                            b->entry_where.p, cap_i32(std::min(b->entries.cap, b->entry_where.cap)),
                            upto >= 4 ? cap_i32(b->items.cap) : 0x7fffffff, b->vp[1], b->bd(), b->own);
+    // first row pass: per cell the number of adds and the per-row sums of the pieces that fall into it.  (The cells' counters
+    // and sums are zero on entry: k_pair_scan returns them to zero as it reads them; a pass that stops short of it does not.)
+    if (!b->cells_zeroed) {
+        HIPCHK(hipMemsetAsync(b->cell_cnt.p, 0, sizeof(int) * b->cell_cnt.cap, st));
+        HIPCHK(hipMemsetAsync(b->cell_sum.p, 0, sizeof(double) * b->cell_sum.cap, st));
+    }
+    b->cells_zeroed = false;
+    const int ne = (int)std::max<int64_t>(b->n_edges, 1);
+    const int cell_cap = cap_i32(std::min(std::min(b->cell_cnt.cap, b->cell_pos.cap), std::min(b->cell_hdr.cap, b->cell_sum.cap / TR)));
+    hipLaunchKernelGGL(k_edge_cells<false>, grid1((size_t)ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
+                       (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->vp[1], cell_cap, b->cell_cnt.p, b->cell_sum.p, b->bd(),
+                       b->own, b->shards, (int)b->n_edges, upto >= 4 ? b->chunks.p : (int*)nullptr, b->planned ? 0 : 1);
     if (upto == 3) return 0;
-    hipLaunchKernelGGL(k_edge_emit, grid1((size_t)std::max<int64_t>(b->n_edges + b->n_chunks, 1)), dim3(256), 0, st,
-                       (const double*)b->edges.p, (const int*)b->edge_path.p, (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0],
-                       b->pb_cap, (const int*)b->bseg_off.p, b->pb_cursor(), b->bsegs.p, cap_i32(b->bsegs.cap), b->bd(), b->own,
-                       b->shards, (int)b->n_edges, (const int*)b->chunks.p);
-    // per pair with records: classes and carry-ins of its column tiles
-    // (the tiles read their mask words whether or not any pair has records: a batch without entries still needs them clear --
+    if (b->n_chunks > 0)  // the extra chunks of long edges, from the list the launch above wrote
+        hipLaunchKernelGGL(k_edge_cells<true>, grid1((size_t)b->n_chunks), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
+                           (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->vp[1], cell_cap, b->cell_cnt.p, b->cell_sum.p, b->bd(),
+                           b->own, b->shards, (int)b->n_edges, b->chunks.p, b->planned ? 0 : 1);
+    // per pair: carry-ins, classes, headers, add lists sized and started
+    // (the tiles read their mask words whether or not any pair exists: a batch without entries still needs them clear --
     //  a block from the cache is not zero)
     if (!b->masks_zeroed && b->tile_mask.p) {
         HIPCHK(hipMemsetAsync(b->tile_mask.p, 0, b->mask_bytes(), st));
         b->masks_zeroed = true;
     }
     if (b->n_entries > 0) {
-        b->masks_zeroed = false;  // (bits are set below; the tile kernel clears them again)
-        hipLaunchKernelGGL(k_pair_cells, grid1((size_t)b->n_entries * PC_LANES, PC_BLOCK), dim3(PC_BLOCK), 0, st,
-                           (const TileEntry*)b->entries.p, (const int2*)b->entry_where.p, (const RowRec*)b->bsegs.p,
+        b->masks_zeroed = false;  // (bits are set below; k_tile_lists clears them again)
+        hipLaunchKernelGGL(k_pair_scan, grid1((size_t)b->n_entries * PS_LANES, PS_BLOCK), dim3(PS_BLOCK), 0, st,
+                           (const TileEntry*)b->entries.p, (const int2*)b->entry_where.p, b->cell_cnt.p, b->cell_sum.p,
                            (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p,
                            b->n_groups > 0 ? (const int*)b->path_group.p : (const int*)nullptr,
                            b->n_grads > 0 ? (const int*)b->path_grad.p : (const int*)nullptr, b->vp[0], b->vp[1], b->n_ctiles(), b->mask_words,
-                           b->tile_mask.p, b->cell_hdr.p, cap_i32(b->cell_hdr.cap), (const int2*)b->band_adds.p, b->band_add_cur(),
-                           b->count_adds_only ? (TileAdd*)nullptr : b->adds.p, b->bd());
+                           b->tile_mask.p, b->cell_hdr.p, cell_cap, (const int2*)b->band_adds.p, b->band_add_cur(),
+                           b->count_adds_only ? (TileAdd*)nullptr : b->adds.p, b->cell_pos.p, b->bd());
+        b->cells_zeroed = true;  // (every cell that was counted into belongs to a listed pair)
     }
+    // second row pass: the pieces as adds, into the lists k_pair_scan started
+    if (!b->count_adds_only && b->n_entries > 0)
+        hipLaunchKernelGGL(k_edge_adds, grid1((size_t)std::max<int64_t>(b->n_edges + b->n_chunks, 1)), dim3(256), 0, st,
+                           (const double*)b->edges.p, (const int*)b->edge_path.p, (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0],
+                           b->vp[1], cell_cap, b->cell_pos.p, b->adds.p, cap_i32(b->adds.cap), b->bd(), b->own, b->shards, (int)b->n_edges,
+                           (const int*)b->chunks.p);
     // per owned band: the tiles' item lists and the launch order of the tile kernel; clears the bitmasks again
     if (owned > 0 && b->n_ctiles() > 0) {
         hipLaunchKernelGGL(k_tile_lists, dim3(owned), dim3(TL_BLOCK), 0, st, (const int*)b->band_start.p, (const int*)b->band_item0.p,
@@ -3001,10 +2923,14 @@ static int check_dev_err(svgr_batch* b, int* capacity_bits = nullptr, bool whole
         if (int rc = issue_readback(b, with_bboxes)) return rc;
         HIPCHK(hipStreamSynchronize(b->ctx->stream));
         e = b->host_bd.err;
+        if (e) b->invalidate_work();
     } else {
         HIPCHK(hipMemcpyAsync(&e, b->bd(), sizeof(int), hipMemcpyDeviceToHost, b->ctx->stream));
         HIPCHK(hipStreamSynchronize(b->ctx->stream));
-        if (e) HIPCHK(hipMemsetAsync(b->bd(), 0, sizeof(int), b->ctx->stream));
+        if (e) {
+            HIPCHK(hipMemsetAsync(b->bd(), 0, sizeof(int), b->ctx->stream));
+            b->invalidate_work();
+        }
     }
     HIPCHK(hipGetLastError());
     return eval_dev_err(e, capacity_bits);
@@ -3276,7 +3202,7 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
     }
     rc = rc ? rc : b->bbox.ensure(4 * np);
     rc = rc ? rc : b->bins.ensure(np + 1);
-    rc = rc ? rc : b->layout_arena(0);
+    rc = rc ? rc : b->layout_arena();
     if (rc) { b->release(); delete b; return rc; }
     *out = b;
     return 0;
@@ -3467,21 +3393,19 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr) {
     b->n_pb = (int64_t)np * n_bands;
     b->n_cells = std::min<int64_t>(b->n_pb * n_ct, std::max<int64_t>(262144, small ? 0 : 4 * b->n_pb));  // (overflow is flagged)
     b->n_entries = b->n_pb;
-    const int64_t rec_guess = small ? 16 * (int64_t)shard_cap + b->n_pb : 256 * ns + 4096;
-    int rc = b->layout_arena((int)b->n_pb);
+    const int64_t row_guess = small ? 16 * (int64_t)shard_cap + b->n_pb : 256 * ns + 4096;  // edge rows
+    int rc = b->layout_arena();
     rc = rc ? rc : b->edges.ensure((size_t)b->n_edges * 4);
     rc = rc ? rc : b->edge_path.ensure((size_t)b->n_edges);
     rc = rc ? rc : b->band_start.ensure((size_t)n_bands + 1);
     rc = rc ? rc : b->band_count.ensure((size_t)n_bands + 1);
-    rc = rc ? rc : b->bseg_off.ensure((size_t)b->n_pb + 1);
     rc = rc ? rc : b->entries.ensure((size_t)b->n_pb);
-    rc = rc ? rc : b->bsegs.ensure((size_t)rec_guess + 1);
-    rc = rc ? rc : b->cell_hdr.ensure((size_t)b->n_cells + 1);
+    rc = rc ? rc : b->size_cells();
     rc = rc ? rc : b->entry_where.ensure((size_t)b->n_pb);
     rc = rc ? rc : b->size_tile_lists(n_bands);
     if (!rc) {
-        // add slots: a guess like the others -- a few adds per record, spread evenly over the bands
-        std::vector<int> need((size_t)n_bands, (int)std::min<int64_t>(4 * rec_guess / n_bands + 2048, 1 << 26));
+        // add slots: a guess like the others -- a few adds per edge row, spread evenly over the bands
+        std::vector<int> need((size_t)n_bands, (int)std::min<int64_t>(4 * row_guess / n_bands + 2048, 1 << 26));
         rc = b->size_band_adds(need.data(), b->ctx->stream);
     }
     {
@@ -3498,6 +3422,7 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr) {
 // 1 planned, 0 a guess was too small (the staged plan takes over), < 0 error
 static int spec_finish(svgr_batch* b) {
     int cap_bits = 0;
+    if (b->host_bd.err) b->invalidate_work();
     if (int rc = eval_dev_err(b->host_bd.err, &cap_bits)) return rc;
     if (cap_bits) return 0;
     b->n_entries = b->host_bd.entry_cursor;
@@ -3632,7 +3557,7 @@ static int batch_plan_impl(svgr_batch* b) {
         if (sp < 0) return sp;
         if (sp > 0) return 0;
     }
-    if (int rc = b->layout_arena(0)) return rc;
+    if (int rc = b->layout_arena()) return rc;
     // 1. Without a viewport (S:968 `viewport is None`) the union of the unclipped bboxes becomes the canvas.
     if (!b->has_vp) {
         if (int rc = run_geometry(b, 0, false)) return rc;
@@ -3665,6 +3590,7 @@ static int batch_plan_impl(svgr_batch* b) {
     if (int rc = b->edges.ensure((size_t)std::max<int64_t>(b->n_edges, 1) * 4)) return rc;
     if (int rc = b->edge_path.ensure((size_t)std::max<int64_t>(b->n_edges, 1))) return rc;
     b->n_bands = (b->vp[2] + TR - 1) / TR;
+    if (int rc = b->layout_arena()) return rc;  // (the per-band add cursors: the band count is final now)
     if (int rc = b->band_start.ensure((size_t)b->n_bands + 1)) return rc;
     if (int rc = b->band_count.ensure((size_t)b->n_bands + 1)) return rc;
     if (int rc = b->band_item0.ensure((size_t)b->n_bands + 1)) return rc;
@@ -3672,15 +3598,12 @@ static int batch_plan_impl(svgr_batch* b) {
     if (int rc = check_dev_err(b)) return rc;
     b->n_pb = b->host_bd.pb_cursor;
     b->n_cells = b->host_bd.cell_cursor;
-    if (int rc = b->cell_hdr.ensure((size_t)std::max<int64_t>(b->n_cells, 1))) return rc;
-    // 3. per-pair counts -> band segments
-    if (int rc = b->layout_arena((int)b->n_pb)) return rc;
-    if (int rc = b->bseg_off.ensure((size_t)b->n_pb + 1)) return rc;
+    if (int rc = b->size_cells()) return rc;
+    // 3. the band lists, and the first chunks of the first row pass: how many extra chunks the long edges need
     if (int rc = b->entries.ensure((size_t)std::max<int64_t>(b->n_pb, 1))) return rc;
     if (int rc = b->entry_where.ensure((size_t)std::max<int64_t>(b->n_pb, 1))) return rc;
     if (int rc = run_geometry(b, 3, true)) return rc;
     if (int rc = check_dev_err(b)) return rc;
-    b->n_bsegs = b->host_bd.bseg_cursor;
     b->n_entries = b->host_bd.entry_cursor;
     {
         int caps[NSH];
@@ -3688,9 +3611,8 @@ static int batch_plan_impl(svgr_batch* b) {
         if (int rc = b->size_chunks(caps)) return rc;
     }
     if (int rc = b->size_masks(b->host_bd.max_band_entries)) return rc;
-    if (int rc = b->bsegs.ensure((size_t)std::max<int64_t>(b->n_bsegs, 1) + 1)) return rc;
     if (int rc = b->size_tile_lists(count_owned_bands(b->own, b->n_bands))) return rc;
-    // 3b. the whole geometry once with k_pair_cells only SIZING the add lists: what every band's add block has to hold
+    // 3b. the whole geometry once with k_pair_scan only SIZING the add lists: what every band's add block has to hold
     {
         b->count_adds_only = true;
         int rc = run_geometry(b, 4, true);
@@ -3707,6 +3629,7 @@ static int batch_plan_impl(svgr_batch* b) {
 
     if (int rc = check_dev_err(b, nullptr, true, true)) return rc;
     b->n_edges_live = b->n_edges;
+    b->n_bsegs = b->host_bd.bseg_cursor;
     b->planned = true;
     b->geometry_fresh = true;
     return 0;
@@ -3717,7 +3640,7 @@ int svgr_batch_get_stats(const svgr_batch* b, svgr_batch_stats* out) {
     if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan has not run");
     out->n_edges = b->n_edges_live;
     out->path_pixels = (int64_t)b->host_bd.path_pixels;
-    out->n_band_segs = b->n_bsegs;
+    out->n_band_segs = b->n_bsegs;  // (edge rows)
     out->n_path_bands = b->n_pb;
     out->n_nonempty = b->host_bd.n_nonempty;
     if (b->host_bd.n_nonempty > 0) {
@@ -3777,7 +3700,7 @@ static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path
     *n_out = 0;
     if (ns <= 0) return 0;
     if (b->arena_bytes == 0)
-        if (int rc = b->layout_arena(0)) return rc;
+        if (int rc = b->layout_arena()) return rc;
     const dim3 fgrid = grid1((size_t)ns << FL_SUB, FL_BLOCK);
     const Owner whole{0, 1, 1};
     b->geometry_fresh = false;
