@@ -391,14 +391,15 @@ struct BatchDev {
     int cell_cursor;    // (path, band, column tile) cells
     int max_band_entries;  // longest band list (sizes the tiles' entry bitmasks)
     unsigned long long spare8;
-    int item_cursor;    // tile-list slots reserved (one per cell of a pair with records)
-    int pad[15];
+    int item_cursor;    // tile-list slots reserved (one per cell of a listed pair)
+    int slab_cursor;    // work items of k_path_build (k_path_bbox cuts every path's cells into slabs)
+    int pad[14];
     // Flattened edges are reserved in NSH independent shards (wave w of the flatten uses shard w % NSH): one hot
     // cursor serves only ~90 returning atomics per microsecond chip-wide, sixteen serve every wave of the launch.
     // One 128-byte line per cursor.
     struct ShardLine {
         int cursor;         // edges (k_flatten)
-        int chunk_cursor;   // extra row chunks of long edges (k_edge_count)
+        int add_cursor;     // add slots (k_path_build: the slabs of path p reserve in shard p % n)
         int pad[30];
     } shard[16];
 };
@@ -410,9 +411,12 @@ static_assert(sizeof(BatchDev) == 128 + NSH * 128, "BatchDev is the head of the 
 struct EdgeShards {
     int base[NSH];
     int cap[NSH];
-    // the same for the extra row chunks of long edges (k_edge_count / k_edge_emit), in the list behind the edge slots
-    int cbase[NSH];
-    int ccap[NSH];
+};
+// the same for the add slots k_path_build reserves (the slabs of path p in shard p % n; capacities measured by the plan)
+struct AddShards {
+    int base[NSH];
+    int cap[NSH];
+    int n;          // shards in use (1 .. NSH)
 };
 // is edge slot e filled?  (bases ascend; empty shards share a base with their successor)
 __device__ __forceinline__ bool edge_live(int e, const EdgeShards& sh, const BatchDev* __restrict__ bd) {
@@ -499,7 +503,14 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
                                                  int* __restrict__ edge_path, const EdgeShards sh,
                                                  unsigned long long* __restrict__ pkeys, BatchDev* __restrict__ bd,
                                                  Owner own, int vr0, int n_bands, const unsigned* __restrict__ prow,
-                                                 const int* __restrict__ seg_list, int n_list) {
+                                                 const int* __restrict__ seg_list, int n_list,
+                                                 int* __restrict__ seg_cnt, const int* __restrict__ seg_off, int edge_cap) {
+    // Where the edges go.  `seg_off` given (the renders and the plan's later passes): segment s owns the slots
+    // [seg_off[s], seg_off[s + 1]) -- the exclusive prefix sums of the per-segment counts the plan's counting pass left in
+    // `seg_cnt` -- and its lanes take them in curve order.  The edge array is then in (path, segment, curve) order whatever
+    // the order the waves run in: the edges of a path are one contiguous range (k_path_build walks it), the array is the
+    // same from render to render, and the kernel makes no returning atomic.  Without it (svgr_batch_all_edges): a
+    // reservation per wave in one of NSH sharded cursors.
     const int gtid = blockIdx.x * FL_BLOCK + threadIdx.x;
     const int item = gtid >> FL_SUB, sub = gtid & ((1 << FL_SUB) - 1);
     // (multi-GPU: the plan's list of the segments this rank needs; else every segment)
@@ -575,13 +586,30 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
     }
     if (ovf) atomicOr(&bd->err, 1);
     if (!keep) cnt = 0;
-    // one reservation per wave, in the wave's shard
     const int shard = (int)((blockIdx.x * (FL_BLOCK / 64) + (threadIdx.x >> 6)) % NSH);
-    const int in_shard = wave_alloc(&bd->shard[shard].cursor, cnt, threadIdx.x & 63);
-    const int base = sh.base[shard] + in_shard;
+    int base;
+    bool fits;
+    if (seg_cnt || seg_off) {
+        // this lane's place among the edges of its segment (the 32 lanes of a segment are half a wave), the segment's count
+        const int lane = threadIdx.x & 63;
+        int wtot;
+        const int excl = wave_excl_scan(cnt, lane, wtot);
+        const int seg_first = __shfl(excl, lane & 32), seg_total = __shfl(excl + cnt, lane | 31) - seg_first;
+        if (seg_cnt && seg_ok && sub == 0) seg_cnt[seg] = seg_total;
+        const int s0 = seg_off && seg_ok ? seg_off[seg] : 0, s1 = seg_off && seg_ok ? seg_off[seg + 1] : 0;
+        base = s0 + (excl - seg_first);
+        fits = base + cnt <= s1 && base + cnt <= edge_cap;
+        // (the shard cursors only count here: their sum is the number of edges the pass kept)
+        if (lane == 0 && wtot > 0) atomicAdd(&bd->shard[shard].cursor, wtot);
+    } else {
+        // one reservation per wave, in the wave's shard
+        const int in_shard = wave_alloc(&bd->shard[shard].cursor, cnt, threadIdx.x & 63);
+        base = sh.base[shard] + in_shard;
+        fits = in_shard + cnt <= sh.cap[shard];
+    }
 
     if (EMIT && cnt > 0) {
-        if (in_shard + cnt > sh.cap[shard]) {
+        if (!fits) {
             atomicOr(&bd->err, 2);
         } else if (mode == 1) {
             double* e = edges + 4 * (size_t)base;
@@ -629,6 +657,33 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
     }
 }
 
+// Plan only: exclusive prefix sums of the per-segment edge counts (seg_off[n] = their total).  One workgroup, a chunk of
+// 1024 segments per step with the running total carried along: a plan-time pass over a few thousand to a few million ints.
+__global__ __launch_bounds__(1024) void k_seg_scan(const int* __restrict__ seg_cnt, int n, int* __restrict__ seg_off) {
+    __shared__ int s_w[16];
+    __shared__ int s_run;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + tid;
+        const int v = i < n ? seg_cnt[i] : 0;
+        int wtot;
+        const int excl = wave_excl_scan(v, lane, wtot);
+        if (lane == 0) s_w[wave] = wtot;
+        __syncthreads();
+        const int run0 = s_run;
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { before += w < wave ? s_w[w] : 0; all += s_w[w]; }
+        if (i < n) seg_off[i] = run0 + before + excl;
+        __syncthreads();
+        if (tid == 0) s_run = run0 + all;
+        __syncthreads();
+    }
+    if (tid == 0) seg_off[n] = s_run;
+}
+
 // Per-path binning record, written by k_path_bbox: the bands the (viewport-clipped) bbox covers and the path's
 // first (path, band) pair.  One 16-byte load for the kernels that map an edge / a band to its pair.
 struct PathBin {
@@ -644,13 +699,43 @@ __host__ __device__ __forceinline__ void path_ctiles(int c0, int cols, int vc0, 
 }
 static_assert(sizeof(PathBin) == 16, "PathBin is one dwordx4");
 
+// One work item of k_path_build: the cells of path p in the bands [band0, band0 + nb) x its column tiles [k0, k0 + nk)
+// (k relative to the path's first column tile).  A slab's counters and per-row sums live in LDS, so it holds at most
+// PB_CELLS cells: a path of up to PB_CELLS column tiles is cut into runs of bands, a wider one band by band into runs of
+// column tiles.
+#ifndef SVGR_PB_CELLS
+#define SVGR_PB_CELLS 128
+#endif
+#ifndef SVGR_PB_BANDS
+#define SVGR_PB_BANDS 16
+#endif
+constexpr int PB_THREADS = 256;
+constexpr int PB_CELLS = SVGR_PB_CELLS;
+constexpr int PB_BANDS = SVGR_PB_BANDS;   // bands per slab at most: one TR-lane group of the workgroup scans each
+static_assert(PB_BANDS * SVGR_TR <= PB_THREADS && PB_BANDS <= PB_CELLS, "k_path_build: one lane group per band of the slab");
+struct Slab {
+    int p, band0, nb, k0, nk, pad[3];
+};
+static_assert(sizeof(Slab) == 32, "Slab is 32 bytes");
+// how a path of nb bands x nct column tiles is cut: bands per slab, column-tile runs per band row
+__host__ __device__ __forceinline__ void slab_shape(int nb, int nct, int& bands_per, int& col_runs) {
+    if (nct <= PB_CELLS) {
+        bands_per = PB_CELLS / nct < PB_BANDS ? PB_CELLS / nct : PB_BANDS;
+        col_runs = 1;
+    } else {
+        bands_per = 1;
+        col_runs = (nct + PB_CELLS - 1) / PB_CELLS;
+    }
+    (void)nb;
+}
+
 // bbox = {r0, c0, rows, cols}; viewport = same or has_vp = 0
 // `stats`: fold the batch statistics (non-empty paths, path-pixels, union bbox) into BatchDev: only the plan reads them, and
 // their six atomics per wave on shared addresses are most of this kernel's time when a render repeats the geometry
 __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __restrict__ pkeys, int n_paths, int has_vp,
                                                   int vr0, int vc0, int vrows, int vcols, int* __restrict__ bbox,
                                                   PathBin* __restrict__ bins, BatchDev* __restrict__ bd, int stats,
-                                                  const int* __restrict__ plist) {
+                                                  const int* __restrict__ plist, Slab* __restrict__ slabs, int slab_cap, Owner own) {
     // (multi-GPU: thread i takes the i-th path of this rank's list, n_paths = its length; the others keep the empty bbox
     //  and bins the plan gave them)
     const int pi = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
@@ -722,6 +807,34 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
         atomicMax(&bd->umax_r, st_maxr);
         atomicMax(&bd->umax_c, st_maxc);
     }
+    // the path's slabs (band runs without a band of this rank are left out)
+    int bands_per = 1, col_runs = 1, n_slabs = 0;
+    if (has_vp && pnb > 0 && want_cells <= (1ll << 28)) {
+        slab_shape(pnb, pnct, bands_per, col_runs);
+        for (int bb = 0; bb < pnb; bb += bands_per) {
+            const int be = bb + bands_per < pnb ? bb + bands_per : pnb;
+            if (owns_any(own, pb0 + bb, pb0 + be - 1)) n_slabs += col_runs;
+        }
+    }
+    const int slab0 = wave_alloc(&bd->slab_cursor, n_slabs, lane);
+    if (slabs && n_slabs > 0) {
+        if (slab0 + n_slabs > slab_cap) {
+            atomicOr(&bd->err, 4);
+        } else {
+            int at = slab0;
+            for (int bb = 0; bb < pnb; bb += bands_per) {
+                const int be = bb + bands_per < pnb ? bb + bands_per : pnb;
+                if (!owns_any(own, pb0 + bb, pb0 + be - 1)) continue;
+                for (int c = 0; c < col_runs; ++c) {
+                    Slab sl;
+                    sl.p = p; sl.band0 = pb0 + bb; sl.nb = be - bb;
+                    sl.k0 = c * PB_CELLS; sl.nk = pnct - sl.k0 < PB_CELLS ? pnct - sl.k0 : PB_CELLS;
+                    sl.pad[0] = sl.pad[1] = sl.pad[2] = 0;
+                    slabs[at++] = sl;
+                }
+            }
+        }
+    }
     if (p < n_paths) {
         ((int4*)bbox)[p] = make_int4(out[0], out[1], out[2], out[3]);
         PathBin pbin;
@@ -776,7 +889,7 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
                                                               const int* __restrict__ bbox,
                                                               int* __restrict__ band_start, int* __restrict__ band_count,
                                                               int* __restrict__ band_item0,
-                                                              TileEntry* __restrict__ entries, int2* __restrict__ entry_where,
+                                                              TileEntry* __restrict__ entries, int* __restrict__ pair_idx,
                                                               int entry_cap, int item_cap, int vc0,
                                                               BatchDev* __restrict__ bd, Owner own) {
     constexpr int NWV = BE_BLOCK / 64;
@@ -874,7 +987,7 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
         path_ctiles(bb.y, bb.w, vc0, ct0, nct);
         e.cell0 = pbin.cell_off + (band - pbin.b0) * nct;
         entries[my_ent] = e;
-        entry_where[my_ent] = make_int2(band, my_ent - s_ent0);  // its band and its place in the band's list
+        pair_idx[pbin.pb_off + band - pbin.b0] = my_ent - s_ent0;  // the pair's place in its band's list
     };
 #pragma unroll
     for (int g = 0; g < BE_KEEP; ++g) {
@@ -961,436 +1074,339 @@ __device__ __forceinline__ unsigned add_where(int trow, int tcol, int len) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// edge rows -> cells.  Two passes over the edge rows with the scan of the (path, band) pairs between them:
-//   k_edge_cells   per row and cell it touches: how many adds its pieces make there, and their sum (global atomics into
-//                  the cell's counter and into the cell's per-row sums)
-//   k_pair_scan    per pair: the carry-in of every tile row = running sum of the cell sums left of it, the class of every
-//                  cell, the size and place of its add list, its header, its carry-in and layer-edge adds
-//   k_edge_adds    per row again: the pieces as adds, straight into the cell's list
-// Nothing row-sized is stored in between: the second pass recomputes a row's pieces (a few dozen double operations) instead
-// of writing a 48-byte record and reading it back twice.
+// edges of a path -> the cells of the path: classes, carry-ins, headers, add lists.
+// One workgroup per SLAB of a path's cells (k_path_bbox cuts them: at most PB_CELLS cells, PB_BANDS bands).  The edges of a
+// path are one contiguous range of the edge array (k_flatten), so the workgroup walks exactly the geometry that can reach its
+// cells, and everything it accumulates -- per cell the number of adds, per cell and tile row the sum of the pieces -- lives in
+// LDS: no global atomic but ONE reservation of add slots per slab.
+//   pass A   per edge row of the slab (S:2244-2303) and column tile its pieces fall into: how many adds they make there, and
+//            their sum (ds_add into the cell's counter and the cell's sum of that tile row)
+//   scan     TR lanes per band of the slab walk its cells left to right with the running sum = the carry-in of every tile
+//            row (np.cumsum entering the tile, S:983): class of every cell, size and place of its add list -- carry-ins first
+//            (one add per row at the layer's first column in the tile), then the layer-edge sentinels (NaN behind the
+//            layer's last column, see k_tile_render), then the pieces --, header, entry-bitmask bits
+//   pass B   the rows again: the pieces as adds, each cell's behind its carry-ins and sentinels
+// Nothing row-sized is stored in between: pass B recomputes a row's pieces (a few dozen double operations) instead of
+// writing a 48-byte record and reading it back.
+// The rows are dealt to the lanes one by one, not edge by edge: a lane per edge runs as long as the longest edge of its
+// wave (a synthetic blob: mean 3 rows, longest 49; real drawings: hundreds next to two).  Per batch of PB_THREADS edges the
+// lanes set their edge up (S:2230-2242), carry x to the slab's first row (S:2244-2248), and the prefix sums of the row
+// counts turn a row number into (edge, row) by a two-level 16-way search.
+// `adds` == nullptr: the plan's measuring run (everything but the add lists themselves).
 // ---------------------------------------------------------------------------------------------
-// What a lane needs of its path to find the cell of a (layer row, layer column)
-struct PathCells {
-    int r0, c0, cols;     // layer origin and width (clipped bbox)
-    int b0, nct;          // first band of the bbox, column tiles it spans
-    int cell_off;         // cell of (b0, first column tile)
-    int x_first;          // layer column at which the path's first column tile starts (<= 0)
+struct EdgeLds {
+    double p0y, p1y, dxdy, x, dir;  // as EdgeSetup; x = column at which the edge enters row ya
+    int ya, pad;
 };
-__device__ __forceinline__ PathCells path_cells(const int* __restrict__ bbox, const PathBin* __restrict__ bins, int p, int vc0) {
+static_assert(sizeof(EdgeLds) == 48, "EdgeLds is three 16-byte LDS reads");
+__global__ __launch_bounds__(PB_THREADS) void k_path_build(const Slab* __restrict__ slabs, const double* __restrict__ edges,
+                                                           const int* __restrict__ path_seg0, const int* __restrict__ seg_off,
+                                                           const int* __restrict__ bbox, const PathBin* __restrict__ bins,
+                                                           const int* __restrict__ pair_idx, const double* __restrict__ path_paint,
+                                                           const uint8_t* __restrict__ path_rule, const int* __restrict__ path_group,
+                                                           const int* __restrict__ path_grad, int vr0, int vc0, int n_ct, int mask_words,
+                                                           unsigned long long* __restrict__ tile_mask, CellHdr* __restrict__ cell_hdr,
+                                                           int cell_cap, const AddShards ash, TileAdd* __restrict__ adds,
+                                                           BatchDev* __restrict__ bd, Owner own, int stats) {
+    __shared__ __attribute__((aligned(16))) double s_sum[PB_CELLS * TR];
+    __shared__ double s_left[TR];
+    __shared__ int s_cnt[PB_CELLS], s_pos[PB_CELLS];
+    __shared__ __attribute__((aligned(16))) EdgeLds s_edge[PB_THREADS];
+    __shared__ __attribute__((aligned(16))) int s_pref[PB_THREADS + 16];
+    __shared__ __attribute__((aligned(16))) int s_coarse[16];
+    __shared__ int s_wtot[PB_THREADS / 64];
+    __shared__ int s_ptot[PB_BANDS], s_base, s_ok;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= bd->slab_cursor) return;  // (the grid covers the plan's slab capacity)
+    const Slab sl = slabs[blockIdx.x];
+    const int p = sl.p;
     const int4 bb = ((const int4*)bbox)[p];
     const PathBin pbin = bins[p];
-    PathCells pc;
-    pc.r0 = bb.x; pc.c0 = bb.y; pc.cols = bb.w;
-    pc.b0 = pbin.b0; pc.cell_off = pbin.cell_off;
-    int ct0;
-    path_ctiles(bb.y, bb.w, vc0, ct0, pc.nct);
-    pc.x_first = vc0 + ct0 * TC - bb.y;
-    return pc;
-}
-// the column tiles [kf, kl] (relative to the path's first) that the pieces of a row (x0i, n) fall into; x0i < cols
-__device__ __forceinline__ void row_tiles(const PathCells& pc, int x0i, int n, int& kf, int& kl) {
-    const int xl = x0i + (n >= 2 ? n : 1);  // column of the last piece
-    const int cf = x0i > 0 ? x0i : 0;
-    int cl = xl > 0 ? xl : 0;
-    cl = cl < pc.cols - 1 ? cl : pc.cols - 1;
-    kf = (cf - pc.x_first) / TC;
-    kl = (cl - pc.x_first) / TC;
-}
-// layer columns [ca, cb) of the path's column tile k
-__device__ __forceinline__ void tile_cols(const PathCells& pc, int k, int& ca, int& cb) {
-    ca = k * TC + pc.x_first;
-    cb = ca + TC;
-    ca = ca > 0 ? ca : 0;
-    cb = cb < pc.cols ? cb : pc.cols;
-}
-// how many adds record_adds makes for the row (x0i, n) in the layer columns [ca, cb)
-__device__ __forceinline__ int row_add_count(int x0i, int n, int ca, int cb) {
-    const double none[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    int ne = 0;
-    record_adds(x0i, n, none, ca, cb, [&](int, double) { ++ne; }, [&](int, int, double) { ++ne; });
-    return ne;
-}
-// (x0i, n) of row_record without the pieces
-__device__ __forceinline__ void row_span_n(double x, double x_next, int& x0i, int& n) {
-    const double x0 = x < x_next ? x : x_next, x1 = x < x_next ? x_next : x;
-    x0i = clamp_to_int(floor(x0));
-    const int x1i = clamp_to_int(ceil(x1));
-    n = x1i <= x0i + 1 ? 1 : x1i - x0i;
-}
+    const int r0 = bb.x, c0 = bb.y, rows = bb.z, cols = bb.w;
+    int ct0, nct;
+    path_ctiles(c0, cols, vc0, ct0, nct);
+    const int x_first = vc0 + ct0 * TC - c0;  // layer column at which the path's first column tile starts (<= 0)
+    const int e_begin = seg_off[path_seg0[p]], e_end = seg_off[path_seg0[p + 1]];
+    const int sr0 = vr0 + sl.band0 * TR - r0, sr1 = sr0 + sl.nb * TR;  // layer rows of the slab
+    const int n_cell = sl.nb * sl.nk;
+    const double o_r = (double)r0, o_c = (double)c0;  // `lines - [min_x, min_y]` (S:979)
+    for (int i = tid; i < n_cell * TR; i += PB_THREADS) s_sum[i] = 0.0;
+    for (int i = tid; i < n_cell; i += PB_THREADS) { s_cnt[i] = 0; s_pos[i] = (int)0x80000000; }
+    if (tid < TR) s_left[tid] = 0.0;
+    if (tid < 16) s_pref[PB_THREADS + tid] = 0x7fffffff;
 
-// The work item of the two row passes is a CHUNK of an edge's rows, not the edge: a wave runs as long as its longest item, and
-// real drawings have edges of hundreds of rows next to edges of two (a synthetic blob: mean 3 rows, longest 49).  An edge of up to
-// CHUNK_ROWS rows is one chunk; a longer one is cut into at most CHUNK_MAX equal chunks.  A chunk that does not start at the
-// edge's first row replays the x recurrence from there (S:2244-2248: a dozen instructions per row, against ~150 for a row
-// whose pieces are computed), so every row still sees the bits the sequential walk gives it.  (The Ghostscript tiger's device
-// step went from 0.219 to 0.146 ms with the chunks.)
-// Items 0 .. n_edges-1 are the first chunks of the edge slots; the extra chunks of long edges sit in a sharded list that the
-// first pass (k_edge_cells<false>) writes while it handles the first chunks.
-#ifndef SVGR_CHUNK_ROWS
-#define SVGR_CHUNK_ROWS 16
-#endif
-constexpr int CHUNK_ROWS = SVGR_CHUNK_ROWS, CHUNK_MAX = 16, CHUNK_SHIFT = 27;  // (chunk id: edge | chunk << 27)
-__host__ __device__ __forceinline__ int edge_chunks(int rows) {
-    if (rows <= CHUNK_ROWS) return 1;
-    const int n = (rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
-    return n < CHUNK_MAX ? n : CHUNK_MAX;
-}
-// rows [y_lo, y_hi) of chunk c of an edge that walks the rows [y_begin, y_end)
-__device__ __forceinline__ void chunk_rows(int y_begin, int y_end, int c, int& y_lo, int& y_hi) {
-    const int rows = y_end - y_begin, n = edge_chunks(rows), per = (rows + n - 1) / n;
-    y_lo = y_begin + c * per;
-    y_hi = y_lo + per < y_end ? y_lo + per : y_end;
-    y_lo = y_lo < y_end ? y_lo : y_end;
-}
-// entry x of the chunk list -> {edge, chunk}; false: the slot is not filled
-__device__ __forceinline__ bool chunk_list_item(int x, const EdgeShards& sh, const BatchDev* __restrict__ bd, const int* __restrict__ chunks,
-                                                int n_edges, int& e, int& cidx) {
-    int sd = 0;
-#pragma unroll
-    for (int k = 1; k < NSH; ++k) sd += x >= sh.cbase[k] ? 1 : 0;
-    const int filled = bd->shard[sd].chunk_cursor < sh.ccap[sd] ? bd->shard[sd].chunk_cursor : sh.ccap[sd];
-    if (x - sh.cbase[sd] >= filled) return false;
-    const int w = chunks[x];
-    e = w & ((1 << CHUNK_SHIFT) - 1);
-    cidx = (int)((unsigned)w >> CHUNK_SHIFT);
-    return e < n_edges && edge_live(e, sh, bd);  // (a pass that overflowed its list leaves holes: flagged, never followed)
-}
-
-// First row pass.  EXTRA = false: one lane per edge slot, its first chunk; the extra chunks of long edges go to the sharded
-// list (`chunks` == nullptr: only counted -- the plan's measuring run).  EXTRA = true: one lane per entry of that list.
-// Per row (S:2244-2303) and column tile the row's pieces fall into: the number of adds they make there goes to the cell's
-// counter, their sum to the cell's sum of that tile row -- two fire-and-forget atomics.  The second pass (k_edge_adds) takes
-// the same decisions from the same arithmetic.
-template <bool EXTRA>
-__global__ __launch_bounds__(256) void k_edge_cells(const double* __restrict__ edges, const int* __restrict__ edge_path,
-                                                    const int* __restrict__ bbox, const PathBin* __restrict__ bins, int vr0, int vc0,
-                                                    int cell_cap, int* __restrict__ cell_cnt, double* __restrict__ cell_sum,
-                                                    BatchDev* __restrict__ bd, Owner own, const EdgeShards sh, int n_edges,
-                                                    int* __restrict__ chunks, int stats) {
-    const int ci = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
-    int e = ci, cidx = 0;
-    bool ok;
-    if (!EXTRA) ok = ci < n_edges && edge_live(ci, sh, bd);
-    else ok = chunk_list_item(ci, sh, bd, chunks, n_edges, e, cidx);
-    EdgeSetup es;
-    int p = 0, r0 = 0;
-    ok = ok && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
-    if (!EXTRA) {
-        // The edge's first chunk needs no list: work item e is chunk 0 of edge slot e.  The extra chunks of a long edge go to a
-        // list behind the edge slots, reserved per wave in one of NSH shards (a single cursor would serialise the 12 000 waves
-        // of this kernel: ~90 returning atomics per microsecond and address).  The list's shard of an edge is the flatten shard
-        // its slot lies in: WHICH edges a flatten shard holds is fixed by the flatten's wave numbering (where inside the shard
-        // they land is not), so the per-shard chunk totals the plan measured hold for every later pass.  The 64 consecutive
-        // slots of a wave lie in one shard, or in two at a shard border.
-        const int extra = ok ? edge_chunks(es.y_end - es.y_begin) - 1 : 0;
-        unsigned long long todo = __ballot(extra > 0);
-        if (todo != 0ull) {
-            int my_shard = 0;
-#pragma unroll
-            for (int k = 1; k < NSH; ++k) my_shard += e >= sh.base[k] ? 1 : 0;
-            int at = 0;
-            while (todo != 0ull) {
-                const int s0 = __builtin_amdgcn_readlane(my_shard, __ffsll((long long)todo) - 1);
-                const bool mine = extra > 0 && my_shard == s0;
-                const int a = wave_alloc(&bd->shard[s0].chunk_cursor, mine ? extra : 0, lane);
-                at = mine ? a : at;
-                todo &= ~__ballot(mine);
-            }
-            if (chunks && extra > 0) {
-                if (at + extra > sh.ccap[my_shard] || e >= (1 << CHUNK_SHIFT)) {
-                    atomicOr(&bd->err, 2);
-                } else {
-                    for (int c = 0; c < extra; ++c) chunks[sh.cbase[my_shard] + at + c] = e | ((c + 1) << CHUNK_SHIFT);
+    // a batch of edges: set up, rows inside the slab counted, prefix sums -> number of (edge, row) tasks of the batch
+    auto stage = [&](int eb) -> int {
+        const int e = eb + tid;
+        int cnt = 0;
+        EdgeLds el;
+        el.p0y = el.p1y = el.dxdy = el.x = 0.0; el.dir = 1.0; el.ya = 0; el.pad = 0;
+        if (e < e_end) {
+            const double4 ed = ((const double4*)edges)[e];
+            const double ar = ed.x - o_r, ac = ed.y - o_c, br = ed.z - o_r, bc = ed.w - o_c;
+            const EdgeSetup es = edge_setup(ar, ac, br, bc, rows);
+            // an edge whose every column is beyond the layer never stores anything (S:2260, S:2274)
+            const double cmin = ac < bc ? ac : bc;
+            if (es.valid && !(cmin >= (double)cols + 2.0)) {
+                const int ya = es.y_begin > sr0 ? es.y_begin : sr0, yb = es.y_end < sr1 ? es.y_end : sr1;
+                if (ya < yb) {
+                    cnt = yb - ya;
+                    RowState st;
+                    st.x_next = es.x; st.x = es.x; st.d = 0.0;
+                    // carry x from the edge's first row to the slab's, exactly as the walk would (S:2244-2248)
+                    for (int yy = es.y_begin; yy < ya; ++yy) row_step(st, yy, es.p0y, es.p1y, es.dxdy, es.dir);
+                    el.p0y = es.p0y; el.p1y = es.p1y; el.dxdy = es.dxdy; el.x = st.x_next; el.dir = es.dir; el.ya = ya;
                 }
             }
         }
-    }
-    int n_rows = 0;
-    if (ok) {
-        int y_lo, y_hi;
-        chunk_rows(es.y_begin, es.y_end, cidx, y_lo, y_hi);
-        const PathCells pc = path_cells(bbox, bins, p, vc0);
+        int wtot;
+        const int excl = wave_excl_scan(cnt, lane, wtot);
+        __syncthreads();  // (the previous batch's tasks are done with s_edge / s_pref)
+        if (lane == 0) s_wtot[wave] = wtot;
+        s_edge[tid] = el;
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < PB_THREADS / 64; ++w) { before += w < wave ? s_wtot[w] : 0; all += s_wtot[w]; }
+        s_pref[tid] = before + excl;
+        if ((tid & 15) == 0) s_coarse[tid >> 4] = before + excl;
+        __syncthreads();
+        return all;
+    };
+    // task t of the staged batch -> its edge's LDS slot and its layer row
+    auto find = [&](int t, int& slot, int& y) {
+        const int4* cq = (const int4*)s_coarse;
+        int blk = -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int4 v = cq[q];
+            blk += (v.x <= t) + (v.y <= t) + (v.z <= t) + (v.w <= t);
+        }
+        const int4* fq = (const int4*)(s_pref + 16 * blk);
+        int in = -1, at = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int4 v = fq[q];
+            in += (v.x <= t) + (v.y <= t) + (v.z <= t) + (v.w <= t);
+            at = v.x <= t ? v.x : at; at = v.y <= t ? v.y : at; at = v.z <= t ? v.z : at; at = v.w <= t ? v.w : at;
+        }
+        slot = 16 * blk + in;
+        y = t - at;  // (+ the edge's first row in the slab, added by the caller)
+    };
+    // the row of a task: its pieces (S:2250-2303) and where they fall
+    struct RowAt {
+        RowPieces rp;
+        int n, bl, trow, kf, kl;
+        bool live;
+    };
+    auto row_of = [&](int t) -> RowAt {
+        RowAt ra;
+        int slot, dy;
+        find(t, slot, dy);
+        const EdgeLds el = s_edge[slot];
+        const int y = el.ya + dy;
         RowState st;
-        st.x_next = es.x; st.x = es.x; st.d = 0.0;
-        // a later chunk of a long edge: carry x from the edge's first row to the chunk's, exactly as the walk would (S:2244-2248)
-        for (int yy = es.y_begin; yy < y_lo; ++yy) row_step(st, yy, es.p0y, es.p1y, es.dxdy, es.dir);
-        for (int y = y_lo; y < y_hi; ++y) {
-            row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);
-            const int vrow = r0 + y - vr0, band = vrow / TR;
-            if (!owns_band(own, band)) continue;  // another rank's band: only x is carried across it
-            ++n_rows;
-            const RowPieces rp = row_record(st.x, st.x_next, st.d);
-            int n = rp.n;
-            if ((unsigned)n > SPAN_MAX) { atomicOr(&bd->err, 16); n = (int)SPAN_MAX; }
-            if (rp.x0i >= pc.cols) continue;  // the whole row lies beyond the layer (S:2260)
-            int kf, kl;
-            row_tiles(pc, rp.x0i, n, kf, kl);
-            const int cell_row = pc.cell_off + (band - pc.b0) * pc.nct;
-            for (int k = kf; k <= kl; ++k) {
-                int ca, cb;
-                tile_cols(pc, k, ca, cb);
-                const int ne = row_add_count(rp.x0i, n, ca, cb);
-                if (ne == 0) continue;
-                const int cell = cell_row + k;
-                if ((unsigned)cell >= (unsigned)cell_cap) { atomicOr(&bd->err, 32); continue; }
-                const double part = record_sum_range(rp.x0i, n, rp.v, ca, cb);
-                atomicAdd(&cell_cnt[cell], ne);
-                unsafeAtomicAdd(&cell_sum[(size_t)cell * TR + (vrow & (TR - 1))], part);
-            }
-        }
-    }
-    if (stats) {  // (plan only) edge rows of the batch
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) n_rows += __shfl_xor(n_rows, d);
-        if (lane == 0 && n_rows > 0) atomicAdd(&bd->bseg_cursor, n_rows);
-    }
-}
-
-// Second row pass, after k_pair_scan: one lane per chunk again (first chunks and the list's).  A first walk over the chunk's
-// rows finds the cells it touches and how many adds it has for each -- only the spans, no pieces --; the lane then takes its
-// places in those cells' lists (one returning atomic per cell, all in flight together: a chunk stays within a few cells) and
-// walks the rows a second time, now computing the pieces and storing them as adds.
-constexpr int EA_SLOTS = 4;   // cells of a chunk that get their places up front; a chunk that touches more takes the rest row by row
-__global__ __launch_bounds__(256) void k_edge_adds(const double* __restrict__ edges, const int* __restrict__ edge_path,
-                                                   const int* __restrict__ bbox, const PathBin* __restrict__ bins, int vr0, int vc0,
-                                                   int cell_cap, int* __restrict__ cell_pos, TileAdd* __restrict__ adds, int add_cap,
-                                                   BatchDev* __restrict__ bd, Owner own, const EdgeShards sh, int n_edges,
-                                                   const int* __restrict__ chunks) {
-    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
-    int e = ci, cidx = 0;
-    bool ok;
-    if (ci < n_edges) ok = edge_live(ci, sh, bd);
-    else ok = chunk_list_item(ci - n_edges, sh, bd, chunks, n_edges, e, cidx);
-    EdgeSetup es;
-    int p = 0, r0 = 0;
-    ok = ok && edge_prepare(edges, edge_path, bbox, e, es, p, r0);
-    if (!ok) return;
-    int y_lo, y_hi;
-    chunk_rows(es.y_begin, es.y_end, cidx, y_lo, y_hi);
-    const PathCells pc = path_cells(bbox, bins, p, vc0);
-    RowState st0;
-    st0.x_next = es.x; st0.x = es.x; st0.d = 0.0;
-    for (int yy = es.y_begin; yy < y_lo; ++yy) row_step(st0, yy, es.p0y, es.p1y, es.dxdy, es.dir);
-    // ---- walk 1: the cells and their add counts ----
-    int sc[EA_SLOTS], sn[EA_SLOTS];
-#pragma unroll
-    for (int s = 0; s < EA_SLOTS; ++s) { sc[s] = -1; sn[s] = 0; }
-    {
-        RowState st = st0;
-        for (int y = y_lo; y < y_hi; ++y) {
-            row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);
-            const int vrow = r0 + y - vr0, band = vrow / TR;
-            if (!owns_band(own, band)) continue;
-            int x0i, n;
-            row_span_n(st.x, st.x_next, x0i, n);
-            n = (unsigned)n > SPAN_MAX ? (int)SPAN_MAX : n;
-            if (x0i >= pc.cols) continue;
-            int kf, kl;
-            row_tiles(pc, x0i, n, kf, kl);
-            const int cell_row = pc.cell_off + (band - pc.b0) * pc.nct;
-            for (int k = kf; k <= kl; ++k) {
-                int ca, cb;
-                tile_cols(pc, k, ca, cb);
-                const int ne = row_add_count(x0i, n, ca, cb);
-                const int cell = cell_row + k;
-                if (ne == 0 || (unsigned)cell >= (unsigned)cell_cap) continue;
-                bool placed = false;
-#pragma unroll
-                for (int s = 0; s < EA_SLOTS; ++s) {
-                    const bool here = !placed && (sc[s] == cell || sc[s] < 0);
-                    sc[s] = here ? cell : sc[s];
-                    sn[s] += here ? ne : 0;
-                    placed = placed || here;
-                }
-            }
-        }
-    }
-    // ---- the lane's places in those lists (a refused cell keeps a negative position) ----
-    int sp[EA_SLOTS];
-#pragma unroll
-    for (int s = 0; s < EA_SLOTS; ++s) sp[s] = sn[s] > 0 ? atomicAdd(&cell_pos[sc[s]], sn[s]) : 0;
-    // ---- walk 2: the pieces as adds ----
-    RowState st = st0;
-    for (int y = y_lo; y < y_hi; ++y) {
-        row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);
+        st.x_next = el.x; st.x = el.x; st.d = 0.0;
+        for (int yy = el.ya; yy <= y; ++yy) row_step(st, yy, el.p0y, el.p1y, el.dxdy, el.dir);
         const int vrow = r0 + y - vr0, band = vrow / TR;
-        if (!owns_band(own, band)) continue;
-        const RowPieces rp = row_record(st.x, st.x_next, st.d);
-        const int n = (unsigned)rp.n > SPAN_MAX ? (int)SPAN_MAX : rp.n;
-        if (rp.x0i >= pc.cols) continue;
-        int kf, kl;
-        row_tiles(pc, rp.x0i, n, kf, kl);
-        const int cell_row = pc.cell_off + (band - pc.b0) * pc.nct;
-        const int trow = vrow & (TR - 1);
-        for (int k = kf; k <= kl; ++k) {
-            int ca, cb;
-            tile_cols(pc, k, ca, cb);
-            const int ne = row_add_count(rp.x0i, n, ca, cb);
-            const int cell = cell_row + k;
-            if (ne == 0 || (unsigned)cell >= (unsigned)cell_cap) continue;
-            int pos = 0;
-            bool found = false;
-#pragma unroll
-            for (int s = 0; s < EA_SLOTS; ++s) {
-                const bool here = !found && sc[s] == cell;
-                pos = here ? sp[s] : pos;
-                sp[s] += here ? ne : 0;
-                found = found || here;
+        ra.rp = row_record(st.x, st.x_next, st.d);
+        ra.n = ra.rp.n;
+        if ((unsigned)ra.n > SPAN_MAX) { atomicOr(&bd->err, 16); ra.n = (int)SPAN_MAX; }
+        ra.bl = band - sl.band0;
+        ra.trow = vrow & (TR - 1);
+        ra.live = owns_band(own, band) && ra.rp.x0i < cols;  // (another rank's band; a row wholly beyond the layer, S:2260)
+        // the path's column tiles [kf, kl] the pieces fall into
+        const int xl = ra.rp.x0i + (ra.n >= 2 ? ra.n : 1);  // column of the last piece
+        const int cf = ra.rp.x0i > 0 ? ra.rp.x0i : 0;
+        int cl = xl > 0 ? xl : 0;
+        cl = cl < cols - 1 ? cl : cols - 1;
+        ra.kf = (cf - x_first) / TC;
+        ra.kl = (cl - x_first) / TC;
+        return ra;
+    };
+    // layer columns [ca, cb) of the path's column tile k
+    auto tile_cols = [&](int k, int& ca, int& cb) {
+        ca = k * TC + x_first;
+        cb = ca + TC;
+        ca = ca > 0 ? ca : 0;
+        cb = cb < cols ? cb : cols;
+    };
+    auto add_count = [&](int x0i, int n, int ca, int cb) {
+        const double none[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        int ne = 0;
+        record_adds(x0i, n, none, ca, cb, [&](int, double) { ++ne; }, [&](int, int, double) { ++ne; });
+        return ne;
+    };
+
+    // ---- pass A ----
+    int n_rows = 0;
+    for (int eb = e_begin; eb < e_end; eb += PB_THREADS) {
+        const int total = stage(eb);
+        n_rows += total;
+        for (int t = tid; t < total; t += PB_THREADS) {
+            const RowAt ra = row_of(t);
+            if (!ra.live) continue;
+            int kf = ra.kf, kl = ra.kl;
+            if (sl.k0 > 0 && kf < sl.k0) {
+                // (a slab that is not the first of its band row: what lies left of it is only summed)
+                int ca, cb;
+                tile_cols(sl.k0, ca, cb);
+                const double part = record_sum_range(ra.rp.x0i, ra.n, ra.rp.v, 0, ca);
+                __hip_atomic_fetch_add(&s_left[ra.trow], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                kf = sl.k0;
             }
-            if (!found) pos = atomicAdd(&cell_pos[cell], ne);  // (the chunk's fifth cell and beyond)
-            if (pos < 0) continue;                              // (k_pair_scan refused the cell: flagged there)
-            if ((long long)pos + ne > (long long)add_cap) { atomicOr(&bd->err, 64); continue; }
-            TileAdd* dst = adds + pos;
-            const int cell_c0 = k * TC + pc.x_first;  // layer column of the tile's column 0
-            record_adds(rp.x0i, n, rp.v, ca, cb,
-                        [&](int c, double val) { TileAdd t; t.where = add_where(trow, c - cell_c0, 1); t.zero = 0u; t.v = val; *dst++ = t; },
-                        [&](int c, int len, double val) { TileAdd t; t.where = add_where(trow, c - cell_c0, len); t.zero = 0u; t.v = val; *dst++ = t; });
+            kl = kl < sl.k0 + sl.nk - 1 ? kl : sl.k0 + sl.nk - 1;
+            for (int k = kf; k <= kl; ++k) {
+                int ca, cb;
+                tile_cols(k, ca, cb);
+                const int ne = add_count(ra.rp.x0i, ra.n, ca, cb);
+                if (ne == 0) continue;
+                const int ci = ra.bl * sl.nk + (k - sl.k0);
+                const double part = record_sum_range(ra.rp.x0i, ra.n, ra.rp.v, ca, cb);
+                __hip_atomic_fetch_add(&s_cnt[ci], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_sum[ci * TR + ra.trow], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     }
-}
+    if (stats && tid == 0 && n_rows > 0) atomicAdd(&bd->bseg_cursor, n_rows);  // (plan only: edge rows of the batch)
+    __syncthreads();
 
-// Between the two row passes: TR lanes per (path, band) pair of the band lists (lane = tile row), walking the pair's column
-// tiles left to right with the row's running sum = the carry-in of every tile row (np.cumsum entering the tile, S:983).
-// Per cell: its class, the size of its add list -- carry-ins first (one add per row at the layer's first column in the tile),
-// then the layer-edge sentinels (NaN behind the layer's last column, see k_tile_render), then the pieces k_edge_cells counted.
-// ONE reservation per pair in the band's add block (the plan measured what every band needs); a second walk writes the
-// headers, the entry-bitmask bits, the carry-ins and sentinels, and leaves in cell_pos where k_edge_adds continues the list.
-// The cells' counters and sums are returned to zero as they are read: the next render's first pass adds into them again.
-// `adds` == nullptr: count only (the plan's measuring run).
-constexpr int PS_BLOCK = 256;
-constexpr int PS_LANES = TR;            // lanes per pair
-constexpr int PS_STEP = 4;              // column tiles whose counters and sums are loaded together
-static_assert(64 % PS_LANES == 0, "k_pair_scan: whole pairs per wave");
-__global__ __launch_bounds__(PS_BLOCK) void k_pair_scan(const TileEntry* __restrict__ entries, const int2* __restrict__ entry_where,
-                                                        int* __restrict__ cell_cnt, double* __restrict__ cell_sum,
-                                                        const double* __restrict__ path_paint, const uint8_t* __restrict__ path_rule,
-                                                        const int* __restrict__ path_group, const int* __restrict__ path_grad,
-                                                        int vr0, int vc0, int n_ct, int mask_words,
-                                                        unsigned long long* __restrict__ tile_mask, CellHdr* __restrict__ cell_hdr,
-                                                        int cell_cap, const int2* __restrict__ band_adds, int* __restrict__ band_add_cur,
-                                                        TileAdd* __restrict__ adds, int* __restrict__ cell_pos, BatchDev* __restrict__ bd) {
-    constexpr int NSLOT = PS_BLOCK / PS_LANES;
-    constexpr unsigned long long GMASK = PS_LANES == 64 ? ~0ull : ((1ull << PS_LANES) - 1ull);
-    const int lane = threadIdx.x & 63, row_l = lane & (PS_LANES - 1);
-    const int shift = lane & ~(PS_LANES - 1);                 // first lane of this pair's group in the wave
-    const int e = blockIdx.x * NSLOT + threadIdx.x / PS_LANES;
-    TileEntry en = entries[e];            // (both arrays hold the whole grid: loaded before the bound is known)
-    const int2 where = entry_where[e];    // {band, index in the band's list}
-    bool active = e < bd->entry_cursor;
-    if (active && (where.y >> 6) >= mask_words) {  // (the plan sized the masks from the longest band list)
-        if (row_l == 0) atomicOr(&bd->err, 32);
-        active = false;
-    }
-    int ct0 = 0, nct = 0;
-    if (active) path_ctiles(en.c0, en.cols, vc0, ct0, nct);
-    const int band = active ? where.x : 0;
-    const int2 blk = adds ? band_adds[band] : make_int2(0, 0x7fffffff);  // the band's add block {first slot, slots}
-    // the tiles' entry bitmasks: per (band, column tile) two rows of mask_words words, bit i = entry i of the band's list
-    // has a cell of class >= 1 (row 0) / class 2 (row 1) here.  Classes 0 simply stay unset.
-    unsigned long long* const mrow = tile_mask + ((size_t)band * n_ct + ct0) * 2 * mask_words + (active ? where.y >> 6 : 0);
-    const unsigned long long mbit = 1ull << (where.y & 63);
-    const int x_first = vc0 + ct0 * TC - en.c0;  // layer column where the path's first column tile starts (<= 0)
-    const int pth = active ? en.p : 0;
-    const int rl = path_rule[pth], rule = rl & 1;
-    const int group = path_group ? path_group[pth] : -1;
-    const int grad1 = path_grad ? path_grad[pth] + 1 : 0;  // gradient index + 1 (0: solid colour)
-    const double4 paint = ((const double4*)path_paint)[pth];
-    // is this lane's tile row a row of the layer?  (the sentinel behind the layer's last column is set on those only)
-    const int row_abs = vr0 + band * TR + row_l;
-    const bool row_in_layer = row_abs >= en.r0 && row_abs < en.r0 + en.rows;
-    int blk_at = 0;       // first slot of this pair's adds in the band's block
-    bool blk_ok = true;
+    // ---- scan: TR lanes per band of the slab ----
+    {
+        constexpr unsigned long long GMASK = TR == 64 ? ~0ull : ((1ull << TR) - 1ull);
+        const int g = tid / TR, row_l = tid & (TR - 1);
+        const int shift = lane & ~(TR - 1);          // first lane of this band's group in the wave
+        const int band = sl.band0 + g;
+        const bool active = g < sl.nb && owns_band(own, band);
+        const int rl = path_rule[p], rule = rl & 1;
+        const int group = path_group ? path_group[p] : -1;
+        const int grad1 = path_grad ? path_grad[p] + 1 : 0;  // gradient index + 1 (0: solid colour)
+        const double4 paint = ((const double4*)path_paint)[p];
+        const int idx = active ? pair_idx[pbin.pb_off + band - pbin.b0] : 0;  // the pair's place in its band's list
+        bool mask_ok = active;
+        if (active && (idx >> 6) >= mask_words) {  // (the plan sized the masks from the longest band list)
+            if (row_l == 0) atomicOr(&bd->err, 32);
+            mask_ok = false;
+        }
+        // the tiles' entry bitmasks: per (band, column tile) two rows of mask_words words, bit i = entry i of the band's list
+        // has a cell of class >= 1 (row 0) / class 2 (row 1) here.  Classes 0 simply stay unset.
+        unsigned long long* const mrow = tile_mask + ((size_t)(active ? band : 0) * n_ct + ct0 + sl.k0) * 2 * mask_words + (mask_ok ? idx >> 6 : 0);
+        const unsigned long long mbit = 1ull << (idx & 63);
+        // is this lane's tile row a row of the layer?  (the sentinel behind the layer's last column is set on those only)
+        const int row_abs = vr0 + band * TR + row_l;
+        const bool row_in_layer = row_abs >= r0 && row_abs < r0 + rows;
+        const int cell_row0 = pbin.cell_off + (band - pbin.b0) * nct + sl.k0;  // global cell of the band's first cell in the slab
+        int pair_off = 0;
 #pragma unroll 1
-    for (int phase = 0; phase < 2; ++phase) {
-        int cursor = 0;   // adds of the column tiles walked so far
-        double run = 0.0; // the row's running sum left of the column tile
-        for (int k0 = 0; __ballot(k0 < nct) != 0ull; k0 += PS_STEP) {
-            int own[PS_STEP];
-            double sq[PS_STEP];
-#pragma unroll
-            for (int j = 0; j < PS_STEP; ++j) {  // (all loads of the step in flight together)
-                const bool live = k0 + j < nct;
-                const int cell = en.cell0 + k0 + j;
-                const bool in = live && (unsigned)cell < (unsigned)cell_cap;
-                own[j] = in ? cell_cnt[cell] : 0;
-                sq[j] = in ? cell_sum[(size_t)cell * TR + row_l] : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < PS_STEP; ++j) {
-                const int k = k0 + j;
-                const bool live = k < nct;
+        for (int phase = 0; phase < 2; ++phase) {
+            int cursor = 0;                                    // adds of the column tiles walked so far
+            double run = sl.k0 > 0 ? s_left[row_l] : 0.0;      // the row's running sum left of the column tile
+            for (int k = 0; k < sl.nk; ++k) {
+                const int ci = g * sl.nk + k;
+                const int own_n = active ? s_cnt[ci] : 0;
+                const double sq = active ? s_sum[ci * TR + row_l] : 0.0;
                 const double cin = run;
-                const bool vis = live && carry_visible(cin, rule);
+                const bool vis = active && carry_visible(cin, rule);
                 const unsigned long long vm = (__ballot(vis) >> shift) & GMASK;
-                const int cls = own[j] > 0 ? 2 : (vm != 0ull ? 1 : 0);
+                const int cls = own_n > 0 ? 2 : (vm != 0ull ? 1 : 0);
                 // class 2: the cell's add list = [carry-ins of the rows where it is not zero][sentinels][pieces]
-                const int cell_c0 = k * TC + x_first;                 // layer column of the tile's column 0
+                const int cell_c0 = (sl.k0 + k) * TC + x_first;       // layer column of the tile's column 0
                 const int t_first = cell_c0 < 0 ? -cell_c0 : 0;       // tile column of the layer's first column inside the tile
-                const int t_end = en.cols - cell_c0;                  // tile column one past the layer's last column
-                const bool want_carry = live && cls == 2 && cin != 0.0;
-                const bool want_sent = live && cls == 2 && t_end < TC && row_in_layer;
+                const int t_end = cols - cell_c0;                     // tile column one past the layer's last column
+                const bool want_carry = active && cls == 2 && cin != 0.0;
+                const bool want_sent = active && cls == 2 && t_end < TC && row_in_layer;
                 const unsigned long long cm = (__ballot(want_carry) >> shift) & GMASK;
                 const unsigned long long sm = (__ballot(want_sent) >> shift) & GMASK;
                 const int n_carry = __popcll(cm), n_sent = __popcll(sm);
-                const int n_add = cls == 2 ? n_carry + n_sent + own[j] : 0;
+                const int n_add = cls == 2 ? n_carry + n_sent + own_n : 0;
                 const int off = cursor;
                 cursor += n_add;
-                const int cell = en.cell0 + k;
-                if (phase == 1 && live) {
-                    if (cls != 0 && cell < cell_cap && blk_ok) {
+                if (phase == 1 && active && cls != 0) {
+                    const int cell = cell_row0 + k;
+                    const bool taken = cell < cell_cap && s_ok && mask_ok;
+                    if (taken) {
                         CellHdr* hd = cell_hdr + cell;
                         hd->carry[row_l] = cin;
                         const unsigned long long below = (1ull << row_l) - 1ull;
-                        TileAdd* const list = adds + (size_t)blk.x + blk_at + off;
+                        const int add0 = s_base + pair_off + off;
                         if (want_carry && adds) {
                             TileAdd t;
                             t.where = add_where(row_l, t_first, 1); t.zero = 0u; t.v = cin;
-                            list[__popcll(cm & below)] = t;
+                            adds[(size_t)add0 + __popcll(cm & below)] = t;
                         }
                         if (want_sent && adds) {
                             TileAdd t;
                             t.where = add_where(row_l, t_end, 1); t.zero = 0u; t.v = __builtin_nan("");
-                            list[n_carry + __popcll(sm & below)] = t;
+                            adds[(size_t)add0 + n_carry + __popcll(sm & below)] = t;
                         }
                         if (row_l == 0) {
                             unsigned long long* const mw = mrow + (size_t)k * 2 * mask_words;
                             atomicOr(mw, mbit);
                             if (cls == 2) atomicOr(mw + mask_words, mbit);
                             hd->paint[0] = paint.x; hd->paint[1] = paint.y; hd->paint[2] = paint.z; hd->paint[3] = paint.w;
-                            hd->r0 = en.r0; hd->c0 = en.c0; hd->rows = en.rows; hd->cols = en.cols;
+                            hd->r0 = r0; hd->c0 = c0; hd->rows = rows; hd->cols = cols;
                             hd->bits = rule | (((rl >> 1) & 3) << 1) | (cls << 3) | (grad1 << 5);
-                            hd->n_add = n_add; hd->add0 = blk.x + blk_at + off; hd->p = en.p;
+                            hd->n_add = n_add; hd->add0 = add0; hd->p = p;
                             hd->group = group;
+                            if (cls == 2 && adds) s_pos[ci] = add0 + n_carry + n_sent;  // the pieces follow (pass B)
                         }
-                    }
-                    if (own[j] > 0) {
-                        // the pieces follow the carry-ins and sentinels (k_edge_adds); a refused cell turns them away.  Counter and
-                        // sums go back to zero for the next render.
-                        cell_sum[(size_t)cell * TR + row_l] = 0.0;
-                        if (row_l == 0) {
-                            const bool taken = cell < cell_cap && blk_ok && adds;
-                            cell_pos[cell] = taken ? blk.x + blk_at + off + n_carry + n_sent : (int)0x80000000;
-                            cell_cnt[cell] = 0;
-                            if (cell >= cell_cap) atomicOr(&bd->err, 32);
-                        }
+                    } else if (row_l == 0 && cell >= cell_cap) {
+                        atomicOr(&bd->err, 32);
                     }
                 }
-                run = run + sq[j];
+                run = run + sq;
+            }
+            if (phase == 0) {
+                // the slab's reservation of add slots: ONE atomic, in the slab's shard
+                if (row_l == 0 && g < PB_BANDS) s_ptot[g] = cursor;
+                __syncthreads();
+                int before = 0, all = 0;
+                for (int q = 0; q < sl.nb; ++q) { before += q < g ? s_ptot[q] : 0; all += s_ptot[q]; }
+                pair_off = before;
+                if (tid == 0) {
+                    const int sh = p % ash.n;  // (by path, not by slab: the slabs' order changes from pass to pass, the plan's shard sizes must hold)
+                    int at = 0;
+                    if (all > 0) at = atomicAdd(&bd->shard[sh].add_cursor, all);
+                    int ok = 1;
+                    if (adds && (long long)at + all > (long long)ash.cap[sh]) { atomicOr(&bd->err, 64); ok = 0; }
+                    s_base = ash.base[sh] + at;
+                    s_ok = ok;
+                }
+                __syncthreads();
             }
         }
-        if (phase == 0) {
-            // the pair's reservation in its band's add block (one atomic per pair)
-            int at = 0;
-            if (row_l == 0 && cursor > 0) at = atomicAdd(&band_add_cur[band], cursor);
-            blk_at = __shfl(at, shift);
-            blk_ok = (long long)blk_at + cursor <= (long long)blk.y;
-            if (!blk_ok && row_l == 0) atomicOr(&bd->err, 64);
+    }
+    __syncthreads();
+    if (!adds) return;
+
+    // ---- pass B ----
+    for (int eb = e_begin; eb < e_end; eb += PB_THREADS) {
+        const int total = stage(eb);
+        for (int t = tid; t < total; t += PB_THREADS) {
+            const RowAt ra = row_of(t);
+            if (!ra.live) continue;
+            const int kf = ra.kf > sl.k0 ? ra.kf : sl.k0;
+            const int kl = ra.kl < sl.k0 + sl.nk - 1 ? ra.kl : sl.k0 + sl.nk - 1;
+            for (int k = kf; k <= kl; ++k) {
+                int ca, cb;
+                tile_cols(k, ca, cb);
+                const int ne = add_count(ra.rp.x0i, ra.n, ca, cb);
+                if (ne == 0) continue;
+                const int ci = ra.bl * sl.nk + (k - sl.k0);
+                const int pos = __hip_atomic_fetch_add(&s_pos[ci], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (pos < 0) continue;  // (the cell was refused above: flagged there)
+                TileAdd* dst = adds + pos;
+                const int cell_c0 = k * TC + x_first;  // layer column of the tile's column 0
+                const int trow = ra.trow;
+                record_adds(ra.rp.x0i, ra.n, ra.rp.v, ca, cb,
+                            [&](int c, double val) { TileAdd tt; tt.where = add_where(trow, c - cell_c0, 1); tt.zero = 0u; tt.v = val; *dst++ = tt; },
+                            [&](int c, int len, double val) { TileAdd tt; tt.where = add_where(trow, c - cell_c0, len); tt.zero = 0u; tt.v = val; *dst++ = tt; });
+            }
         }
     }
 }
 
-// After k_pair_cells, one workgroup per owned band: the tiles' entry bitmasks become their item lists -- the cell ids of
+// After k_path_build, one workgroup per owned band: the tiles' entry bitmasks become their item lists -- the cell ids of
 // the set bits, in bit = list = paint order (class in the top bits) -- and the band's tiles are sorted by weight (number
 // of items, cells with records counting twice), heaviest first.  The launch order of the tile kernel interleaves the
 // bands' sorted lists (rank-major), which is a global heaviest-first order when the bands are alike: the long tiles
@@ -2648,79 +2664,50 @@ struct svgr_batch {
         up_pending = false;
         host_keep.clear();
     }
-    // zeroed once per render: [BatchDev | per-path min/max keys | per-path row reach (multi-GPU) | per-band add cursors]
+    // zeroed once per render: [BatchDev | per-path min/max keys | per-path row reach (multi-GPU)]
     DevArr<unsigned char> arena;
-    size_t arena_bytes = 0, off_pkeys = 0, off_prow = 0, off_band_add = 0;
+    size_t arena_bytes = 0, off_pkeys = 0, off_prow = 0;
     // work arrays fully rewritten by every render
     DevArr<int> edge_path, bbox, band_start, band_count;
     DevArr<PathBin> bins;
     DevArr<TileEntry> entries;
     DevArr<double> edges;
     DevArr<CellHdr> cell_hdr;               // per (path, band, column tile) cell: header (classes 1 and 2)
-    // per cell: adds counted / per-row sums of its pieces (k_edge_cells adds into them, k_pair_scan reads them and puts them
-    // back to zero), and where k_edge_adds continues its add list
-    DevArr<int> cell_cnt, cell_pos;
-    DevArr<double> cell_sum;
-    bool cells_zeroed = false;              // cell_cnt / cell_sum are all zero (left so by the last k_pair_scan)
     // a pass that ended with an error flag may have left any of the self-cleaning buffers dirty
-    void invalidate_work() { cells_zeroed = false; masks_zeroed = false; arena_zeroed = false; }
-    int size_cells() {
-        const size_t n = (size_t)std::max<int64_t>(n_cells, 1);
-        if (n > cell_cnt.cap || n * TR > cell_sum.cap) cells_zeroed = false;
-        if (int rc = cell_hdr.ensure(n + 1)) return rc;
-        if (int rc = cell_cnt.ensure(n)) return rc;
-        if (int rc = cell_pos.ensure(n)) return rc;
-        return cell_sum.ensure(n * TR);
-    }
-    DevArr<TileAdd> adds;                   // the bands' add blocks (k_pair_scan reserves per pair; k_pair_scan and k_edge_adds fill)
+    void invalidate_work() { masks_zeroed = false; arena_zeroed = false; }
+    DevArr<TileAdd> adds;                   // the cells' add lists (k_path_build: a slab reserves its cells' lists in one piece)
     DevArr<unsigned> items;                 // the tiles' item lists: cell id | class << 30 (k_tile_lists)
     DevArr<int2> tile_info;                 // per (band, column tile): {first item, items}
     DevArr<TileSlot> order;                 // the owned tiles in launch order (heaviest first)
     DevArr<int> band_item0;                 // per band: its first item slot
-    DevArr<int2> band_adds;                 // per band: its add block {first slot, slots} (sized by the plan's measuring run)
-    std::vector<int2> host_band_adds;
-    int64_t n_adds = 0;                     // add slots in all the blocks
-    bool count_adds_only = false;           // the plan's measuring run: k_pair_scan sizes the add lists, nothing is written
-    // lay the bands' add blocks back to back: `need[band]` slots each plus slack (the sizes repeat from render to render except
-    // for carry-ins that are exactly zero in one summation order and not in another), and upload the table
-    int size_band_adds(const int* need, hipStream_t st) {
-        host_band_adds.resize((size_t)n_bands + 1);
+    AddShards add_shards{};                 // where each shard's add slots live (the slabs of path p reserve in shard p % n)
+    int64_t n_adds = 0;                     // add slots in all the shards
+    bool count_adds_only = false;           // the plan's measuring run: k_path_build sizes the add lists, writes none
+    // lay the add shards back to back: `need[k]` slots each plus slack (the sizes repeat from render to render except for
+    // carry-ins that are exactly zero in one summation order and not in another)
+    int size_adds(const int* need, int n_shards) {
         long long at = 0;
-        for (int k = 0; k < n_bands; ++k) {
-            const long long cap = (long long)need[k] + need[k] / 8 + 64;
-            host_band_adds[(size_t)k] = make_int2((int)std::min<long long>(at, 0x7fffffff), (int)std::min<long long>(cap, 0x7fffffff));
+        add_shards.n = n_shards;
+        for (int k = 0; k < NSH; ++k) {
+            const long long cap = k < n_shards ? (long long)need[k] + need[k] / 8 + 256 : 0;
+            add_shards.base[k] = (int)std::min<long long>(at, 0x7fffffff);
+            add_shards.cap[k] = (int)std::min<long long>(cap, 0x7fffffff);
             at += cap;
         }
         if (at > 0x7fffffffll) return fail(SVGR_E_OVERFLOW, "%lld add slots: beyond the 32-bit add index (split the batch)", at);
         n_adds = at;
-        if (int rc = adds.ensure((size_t)std::max<long long>(at, 1))) return rc;
-        if (int rc = band_adds.ensure((size_t)n_bands + 1)) return rc;
-        if (n_bands > 0) {
-            wait_uploads();
-            HIPCHK(hipMemcpyAsync(band_adds.p, keep(host_band_adds.data(), sizeof(int2) * (size_t)n_bands), sizeof(int2) * (size_t)n_bands,
-                                  hipMemcpyHostToDevice, st));
-            HIPCHK(note_upload(st));
-        }
-        return 0;
+        return adds.ensure((size_t)std::max<long long>(at, 1));
     }
-    DevArr<int2> entry_where;               // per band-list entry: {band, index in the band's list}
+    DevArr<int> pair_idx;                   // per (path, band) pair: its place in its band's list (k_band_entries)
+    DevArr<Slab> slabs;                     // work items of k_path_build (k_path_bbox)
+    int64_t n_slabs = 0;                    // ... the plan's count = the launch's grid
+    DevArr<int> seg_cnt, seg_off;           // per segment: edges it flattens into (the plan's counting pass), their prefix sums
+    DevArr<int> path_seg0;                  // per path its first segment (view of the input blob)
     DevArr<int> seg_list;                   // multi-GPU: the segments this rank flattens (k_seg_select, at plan time)
     int64_t n_seg_list = -1;                // (-1: no list, every segment)
     DevArr<int> path_list;                  // ... and the paths they belong to, ascending: what k_path_bbox / k_band_entries walk
     int64_t n_path_list = 0;
-    DevArr<int> chunks;                     // extra row chunks of long edges: edge | chunk << 27, in NSH shards (k_edge_cells)
-    int64_t n_chunks = 0;                   // slots of that list (sum of the shard capacities)
-    // lay the chunk shards back to back with the given capacities
-    int size_chunks(const int* caps) {
-        n_chunks = 0;
-        for (int k = 0; k < NSH; ++k) {
-            shards.cbase[k] = (int)n_chunks;
-            shards.ccap[k] = caps[k];
-            n_chunks += caps[k];
-        }
-        return chunks.ensure((size_t)std::max<int64_t>(n_chunks, 1));
-    }
-    DevArr<unsigned long long> tile_mask;   // per (band, column tile): 2 x mask_words words over the band's list (k_pair_scan)
+    DevArr<unsigned long long> tile_mask;   // per (band, column tile): 2 x mask_words words over the band's list (k_path_build)
     int mask_words = 1;
     bool masks_zeroed = false;              // the last tile kernel left the masks cleared
     DevArr<long long> layer_off;            // SVGR_OUT_MASKS_F64: per path the start of its mask in the output
@@ -2756,14 +2743,11 @@ struct svgr_batch {
     BatchDev* bd() const { return (BatchDev*)arena.p; }
     unsigned long long* pkeys() const { return (unsigned long long*)(arena.p + off_pkeys); }
     unsigned* prow() const { return (unsigned*)(arena.p + off_prow); }
-    int* band_add_cur() const { return (int*)(arena.p + off_band_add); }  // per band: add slots taken from its block
 
-    // (n_bands must be final: the per-band add cursors are the arena's tail)
     int layout_arena() {
         off_pkeys = sizeof(BatchDev);
         off_prow = off_pkeys + sizeof(unsigned long long) * 4 * (size_t)n_paths;
-        off_band_add = off_prow + sizeof(unsigned) * 2 * (size_t)n_paths;
-        arena_bytes = off_band_add + sizeof(int) * (size_t)(n_bands + 1);
+        arena_bytes = off_prow + sizeof(unsigned) * 2 * (size_t)n_paths;
         arena_bytes = (arena_bytes + 255) & ~(size_t)255;
         arena_zeroed = false;  // (new size or new memory)
         return arena.ensure(arena_bytes);
@@ -2775,8 +2759,8 @@ struct svgr_batch {
         band_start.release(); band_count.release(); entries.release();
         path_group.release(); group_clip_src.release(); group_opacity.release(); groups_dev.release();
         grads.release(); path_grad.release(); grad_path.release(); grad_flags.release(); grads_dev.release();
-        edges.release(); cell_hdr.release(); cell_cnt.release(); cell_pos.release(); cell_sum.release(); entry_where.release(); tile_mask.release(); chunks.release(); seg_list.release(); path_list.release(); layer_off.release();
-        adds.release(); items.release(); tile_info.release(); order.release(); band_item0.release(); band_adds.release();
+        edges.release(); cell_hdr.release(); pair_idx.release(); slabs.release(); seg_cnt.release(); seg_off.release(); path_seg0.release(); tile_mask.release(); seg_list.release(); path_list.release(); layer_off.release();
+        adds.release(); items.release(); tile_info.release(); order.release(); band_item0.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
         for (auto e : event_pool) (void)hipEventDestroy(e);
@@ -2789,8 +2773,8 @@ struct svgr_batch {
 static inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 static inline int cap_i32(size_t n) { return (int)std::min<size_t>(n, 0x7fffffff); }
 
-// Geometry stages.  `upto`: 0 = flatten (count only) + bbox, 1 = flatten (count only), 2 = flatten + emit + bbox, 3 = + edge count + slot
-// reservation, 4 = everything.  `use_vp` = clip bboxes to b->vp and bin relative to it.
+// Geometry stages.  `upto`: 0 = flatten (count only) + bbox, 1 = flatten (count only: per-segment edge counts and their prefix
+// sums), 2 = flatten + emit + bbox, 3 = + band lists, 4 = everything.  `use_vp` = clip bboxes to b->vp and bin relative to it.
 static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     hipStream_t st = b->ctx->stream;
     const int ns = (int)b->n_segs, np = (int)b->n_paths;
@@ -2810,73 +2794,60 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                            (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->prow());
         prow = b->prow();
     }
+    const int n_bands_vp = use_vp ? (b->vp[2] + TR - 1) / TR : 0;
     if (upto <= 1) {
+        if (upto == 1) {  // (segments the pass skips keep a count of zero)
+            if (int rc = b->seg_cnt.ensure((size_t)ns + 1)) return rc;
+            if (int rc = b->seg_off.ensure((size_t)ns + 2)) return rc;
+            HIPCHK(hipMemsetAsync(b->seg_cnt.p, 0, sizeof(int) * ((size_t)ns + 1), st));
+        }
         if (ns > 0)
             hipLaunchKernelGGL(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                                (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns,
                                b->thr, (double*)nullptr, (int*)nullptr, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
-                               use_vp ? (b->vp[2] + TR - 1) / TR : 0, prow, seg_list, n_items);
+                               n_bands_vp, prow, seg_list, n_items, upto == 1 ? b->seg_cnt.p : (int*)nullptr, (const int*)nullptr, 0);
+        if (upto == 1)
+            hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, st, (const int*)b->seg_cnt.p, ns, b->seg_off.p);
         if (upto == 0)  // bboxes only (no edges stored): enough to find the union when there is no viewport
             hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(),
-                               np_walk, use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), 1, plist);
+                               np_walk, use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), 1, plist,
+                               (Slab*)nullptr, 0, b->own);
         return 0;
     }
     if (ns > 0)
         hipLaunchKernelGGL(k_flatten<true>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                            (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
                            b->edges.p, b->edge_path.p, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
-                           use_vp ? (b->vp[2] + TR - 1) / TR : 0, prow, seg_list, n_items);
+                           n_bands_vp, prow, seg_list, n_items, (int*)nullptr, (const int*)b->seg_off.p, cap_i32(b->edge_path.cap));
     hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np_walk,
-                       use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), b->planned ? 0 : 1, plist);
+                       use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), b->planned ? 0 : 1, plist,
+                       upto >= 3 ? b->slabs.p : (Slab*)nullptr, cap_i32(b->slabs.cap), b->own);
     if (upto == 2) return 0;
     // per owned band: its list of (path, band) pairs in paint order, and its first tile-list slot
     const int owned = count_owned_bands(b->own, b->n_bands);
     if (owned > 0)
         hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(BE_BLOCK), 0, st, (const PathBin*)b->bins.p, np_walk, plist,
                            (const int*)b->bbox.p, b->band_start.p, b->band_count.p, b->band_item0.p, b->entries.p,
-                           b->entry_where.p, cap_i32(std::min(b->entries.cap, b->entry_where.cap)),
+                           b->pair_idx.p, cap_i32(std::min(b->entries.cap, b->pair_idx.cap)),
                            upto >= 4 ? cap_i32(b->items.cap) : 0x7fffffff, b->vp[1], b->bd(), b->own);
-    // first row pass: per cell the number of adds and the per-row sums of the pieces that fall into it.  (The cells' counters
-    // and sums are zero on entry: k_pair_scan returns them to zero as it reads them; a pass that stops short of it does not.)
-    if (!b->cells_zeroed) {
-        HIPCHK(hipMemsetAsync(b->cell_cnt.p, 0, sizeof(int) * b->cell_cnt.cap, st));
-        HIPCHK(hipMemsetAsync(b->cell_sum.p, 0, sizeof(double) * b->cell_sum.cap, st));
-    }
-    b->cells_zeroed = false;
-    const int ne = (int)std::max<int64_t>(b->n_edges, 1);
-    const int cell_cap = cap_i32(std::min(std::min(b->cell_cnt.cap, b->cell_pos.cap), std::min(b->cell_hdr.cap, b->cell_sum.cap / TR)));
-    hipLaunchKernelGGL(k_edge_cells<false>, grid1((size_t)ne), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
-                       (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->vp[1], cell_cap, b->cell_cnt.p, b->cell_sum.p, b->bd(),
-                       b->own, b->shards, (int)b->n_edges, upto >= 4 ? b->chunks.p : (int*)nullptr, b->planned ? 0 : 1);
     if (upto == 3) return 0;
-    if (b->n_chunks > 0)  // the extra chunks of long edges, from the list the launch above wrote
-        hipLaunchKernelGGL(k_edge_cells<true>, grid1((size_t)b->n_chunks), dim3(256), 0, st, (const double*)b->edges.p, (const int*)b->edge_path.p,
-                           (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0], b->vp[1], cell_cap, b->cell_cnt.p, b->cell_sum.p, b->bd(),
-                           b->own, b->shards, (int)b->n_edges, b->chunks.p, b->planned ? 0 : 1);
-    // per pair: carry-ins, classes, headers, add lists sized and started
     // (the tiles read their mask words whether or not any pair exists: a batch without entries still needs them clear --
     //  a block from the cache is not zero)
     if (!b->masks_zeroed && b->tile_mask.p) {
         HIPCHK(hipMemsetAsync(b->tile_mask.p, 0, b->mask_bytes(), st));
         b->masks_zeroed = true;
     }
-    if (b->n_entries > 0) {
+    // per slab of a path's cells: carry-ins, classes, headers, add lists
+    if (b->n_slabs > 0) {
         b->masks_zeroed = false;  // (bits are set below; k_tile_lists clears them again)
-        hipLaunchKernelGGL(k_pair_scan, grid1((size_t)b->n_entries * PS_LANES, PS_BLOCK), dim3(PS_BLOCK), 0, st,
-                           (const TileEntry*)b->entries.p, (const int2*)b->entry_where.p, b->cell_cnt.p, b->cell_sum.p,
-                           (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p,
+        hipLaunchKernelGGL(k_path_build, dim3((unsigned)b->n_slabs), dim3(PB_THREADS), 0, st, (const Slab*)b->slabs.p, (const double*)b->edges.p,
+                           (const int*)b->path_seg0.p, (const int*)b->seg_off.p, (const int*)b->bbox.p, (const PathBin*)b->bins.p,
+                           (const int*)b->pair_idx.p, (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p,
                            b->n_groups > 0 ? (const int*)b->path_group.p : (const int*)nullptr,
                            b->n_grads > 0 ? (const int*)b->path_grad.p : (const int*)nullptr, b->vp[0], b->vp[1], b->n_ctiles(), b->mask_words,
-                           b->tile_mask.p, b->cell_hdr.p, cell_cap, (const int2*)b->band_adds.p, b->band_add_cur(),
-                           b->count_adds_only ? (TileAdd*)nullptr : b->adds.p, b->cell_pos.p, b->bd());
-        b->cells_zeroed = true;  // (every cell that was counted into belongs to a listed pair)
+                           b->tile_mask.p, b->cell_hdr.p, cap_i32(b->cell_hdr.cap), b->add_shards,
+                           b->count_adds_only ? (TileAdd*)nullptr : b->adds.p, b->bd(), b->own, b->planned ? 0 : 1);
     }
-    // second row pass: the pieces as adds, into the lists k_pair_scan started
-    if (!b->count_adds_only && b->n_entries > 0)
-        hipLaunchKernelGGL(k_edge_adds, grid1((size_t)std::max<int64_t>(b->n_edges + b->n_chunks, 1)), dim3(256), 0, st,
-                           (const double*)b->edges.p, (const int*)b->edge_path.p, (const int*)b->bbox.p, (const PathBin*)b->bins.p, b->vp[0],
-                           b->vp[1], cell_cap, b->cell_pos.p, b->adds.p, cap_i32(b->adds.cap), b->bd(), b->own, b->shards, (int)b->n_edges,
-                           (const int*)b->chunks.p);
     // per owned band: the tiles' item lists and the launch order of the tile kernel; clears the bitmasks again
     if (owned > 0 && b->n_ctiles() > 0) {
         hipLaunchKernelGGL(k_tile_lists, dim3(owned), dim3(TL_BLOCK), 0, st, (const int*)b->band_start.p, (const int*)b->band_item0.p,
@@ -3173,7 +3144,7 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
     // is a member of the batch, so the copy needs no host wait; the device arrays are views into the block.
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_segs = 0, o_m6 = al(o_segs + ns * 64), o_paint = al(o_m6 + np * 48), o_spath = al(o_paint + np * 32),
-                 o_kind = al(o_spath + ns * 4), o_rule = al(o_kind + ns), total = al(o_rule + np);
+                 o_kind = al(o_spath + ns * 4), o_rule = al(o_kind + ns), o_seg0 = al(o_rule + np), total = al(o_seg0 + (np + 1) * 4);
     b->in_host.resize(total);
     char* const hb = b->in_host.data();
     memcpy(hb + o_segs, d->segs, ns * 64);
@@ -3186,6 +3157,10 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
     }
     memcpy(hb + o_kind, d->seg_kind, ns);
     memcpy(hb + o_rule, d->path_rule, np);
+    {
+        int* s0 = (int*)(hb + o_seg0);
+        for (size_t p = 0; p <= np; ++p) s0[p] = (int)d->path_seg_off[p];
+    }
     rc = b->in_dev.ensure(total);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(b->in_dev.p, hb, total, hipMemcpyHostToDevice, ctx->stream);
@@ -3199,6 +3174,7 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
         b->seg_path.point_at(b->in_dev.p, o_spath, ns ? ns : 1);
         b->seg_kind.point_at(b->in_dev.p, o_kind, ns ? ns : 1);
         b->path_rule.point_at(b->in_dev.p, o_rule, np);
+        b->path_seg0.point_at(b->in_dev.p, o_seg0, np + 1);
     }
     rc = rc ? rc : b->bbox.ensure(4 * np);
     rc = rc ? rc : b->bins.ensure(np + 1);
@@ -3381,40 +3357,41 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr) {
     // exceeded except by absurd input.  Up to 4096 segments (the runs of a document's per-node route): guesses a few times
     // the typical need -- a wrong one costs the staged plan, never a wrong picture.
     const bool small = ns <= 256;
-    // (small: a wave's segments all land in one shard, so every shard can take them all; larger: waves spread over the shards)
-    const int shard_cap = small ? (int)(64 * ns) : (int)(8 * ns + 512);
-    b->n_edges = 0;
-    for (int k = 0; k < NSH; ++k) {
-        b->shards.base[k] = (int)b->n_edges;
-        b->shards.cap[k] = shard_cap;
-        b->n_edges += shard_cap;
+    const int64_t edge_guess = small ? 1024 * ns : 128 * ns + 8192;
+    b->n_edges = edge_guess;
+    for (int k = 0; k < NSH; ++k) {  // (the renders' edge array is one dense block: see k_flatten)
+        b->shards.base[k] = k == 0 ? 0 : (int)b->n_edges;
+        b->shards.cap[k] = k == 0 ? (int)b->n_edges : 0;
     }
     b->n_bands = n_bands;
     b->n_pb = (int64_t)np * n_bands;
     b->n_cells = std::min<int64_t>(b->n_pb * n_ct, std::max<int64_t>(262144, small ? 0 : 4 * b->n_pb));  // (overflow is flagged)
     b->n_entries = b->n_pb;
-    const int64_t row_guess = small ? 16 * (int64_t)shard_cap + b->n_pb : 256 * ns + 4096;  // edge rows
+    // slabs: at most one per (path, band) and run of PB_CELLS column tiles; typically one or two per path
+    b->n_slabs = std::min<int64_t>(b->n_pb * ((n_ct + PB_CELLS - 1) / PB_CELLS), 64 * (int64_t)np + 1024);
+    const int64_t row_guess = small ? 16 * edge_guess + b->n_pb : 256 * ns + 4096;  // edge rows
     int rc = b->layout_arena();
     rc = rc ? rc : b->edges.ensure((size_t)b->n_edges * 4);
     rc = rc ? rc : b->edge_path.ensure((size_t)b->n_edges);
     rc = rc ? rc : b->band_start.ensure((size_t)n_bands + 1);
     rc = rc ? rc : b->band_count.ensure((size_t)n_bands + 1);
     rc = rc ? rc : b->entries.ensure((size_t)b->n_pb);
-    rc = rc ? rc : b->size_cells();
-    rc = rc ? rc : b->entry_where.ensure((size_t)b->n_pb);
+    rc = rc ? rc : b->pair_idx.ensure((size_t)b->n_pb);
+    rc = rc ? rc : b->slabs.ensure((size_t)b->n_slabs);
+    rc = rc ? rc : b->cell_hdr.ensure((size_t)b->n_cells + 1);
     rc = rc ? rc : b->size_tile_lists(n_bands);
     if (!rc) {
-        // add slots: a guess like the others -- a few adds per edge row, spread evenly over the bands
-        std::vector<int> need((size_t)n_bands, (int)std::min<int64_t>(4 * row_guess / n_bands + 2048, 1 << 26));
-        rc = b->size_band_adds(need.data(), b->ctx->stream);
-    }
-    {
-        int caps[NSH];
-        for (int k = 0; k < NSH; ++k) caps[k] = shard_cap;  // (extra chunks of long edges: a guess like the others)
-        rc = rc ? rc : b->size_chunks(caps);
+        // add slots: a guess like the others -- a few adds per edge row.  Few slabs: one shard (a batch of one slab would put
+        // everything into its shard); more: four
+        const int n_sh = small ? 1 : 4;
+        int need[NSH];
+        for (int k = 0; k < NSH; ++k) need[k] = (int)std::min<int64_t>(4 * row_guess / (small ? 1 : 2) + 2048, 1 << 26);
+        rc = b->size_adds(need, n_sh);
     }
     rc = rc ? rc : b->size_masks(np);
     if (rc) return rc;
+    // the per-segment edge counts and their prefix sums, then the whole geometry: both passes behind one read-back
+    if ((rc = run_geometry(b, 1, true))) return rc;
     if ((rc = run_geometry(b, 4, true))) return rc;
     if ((rc = issue_readback(b, true, staging))) return rc;
     return 1;
@@ -3426,8 +3403,9 @@ static int spec_finish(svgr_batch* b) {
     if (int rc = eval_dev_err(b->host_bd.err, &cap_bits)) return rc;
     if (cap_bits) return 0;
     b->n_entries = b->host_bd.entry_cursor;
+    b->n_slabs = b->host_bd.slab_cursor;
     b->n_edges_live = 0;
-    for (int k = 0; k < NSH; ++k) b->n_edges_live += std::min(b->host_bd.shard[k].cursor, b->shards.cap[k]);
+    for (int k = 0; k < NSH; ++k) b->n_edges_live += b->host_bd.shard[k].cursor;
     b->n_bsegs = b->host_bd.bseg_cursor;
     b->planned = true;
     b->geometry_fresh = true;
@@ -3577,20 +3555,19 @@ static int batch_plan_impl(svgr_batch* b) {
     if (b->own.world > 1 && b->n_segs > 0 && b->vp[2] > 0) {
         if (int rc = build_seg_list(b)) return rc;
     }
-    // 2. count the edges this rank keeps
+    // 2. count the edges this rank keeps: per segment, and their prefix sums = where every segment's edges go
     if (int rc = run_geometry(b, 1, true)) return rc;
     if (int rc = check_dev_err(b)) return rc;
     b->n_edges = 0;
-    for (int k = 0; k < NSH; ++k) {  // the shards, back to back
-        b->shards.base[k] = (int)b->n_edges;
-        b->shards.cap[k] = b->host_bd.shard[k].cursor;
-        b->n_edges += b->host_bd.shard[k].cursor;
-    }
+    for (int k = 0; k < NSH; ++k) b->n_edges += b->host_bd.shard[k].cursor;
     if (b->n_edges > 0x7fffffff / 4) return fail(SVGR_E_OVERFLOW, "%lld edges: beyond the 32-bit edge index", (long long)b->n_edges);
+    for (int k = 0; k < NSH; ++k) {  // (the renders' edge array is one dense block: see k_flatten)
+        b->shards.base[k] = k == 0 ? 0 : (int)b->n_edges;
+        b->shards.cap[k] = k == 0 ? (int)b->n_edges : 0;
+    }
     if (int rc = b->edges.ensure((size_t)std::max<int64_t>(b->n_edges, 1) * 4)) return rc;
     if (int rc = b->edge_path.ensure((size_t)std::max<int64_t>(b->n_edges, 1))) return rc;
     b->n_bands = (b->vp[2] + TR - 1) / TR;
-    if (int rc = b->layout_arena()) return rc;  // (the per-band add cursors: the band count is final now)
     if (int rc = b->band_start.ensure((size_t)b->n_bands + 1)) return rc;
     if (int rc = b->band_count.ensure((size_t)b->n_bands + 1)) return rc;
     if (int rc = b->band_item0.ensure((size_t)b->n_bands + 1)) return rc;
@@ -3598,31 +3575,28 @@ static int batch_plan_impl(svgr_batch* b) {
     if (int rc = check_dev_err(b)) return rc;
     b->n_pb = b->host_bd.pb_cursor;
     b->n_cells = b->host_bd.cell_cursor;
-    if (int rc = b->size_cells()) return rc;
-    // 3. the band lists, and the first chunks of the first row pass: how many extra chunks the long edges need
+    b->n_slabs = b->host_bd.slab_cursor;
+    if (int rc = b->cell_hdr.ensure((size_t)std::max<int64_t>(b->n_cells, 1) + 1)) return rc;
+    if (int rc = b->slabs.ensure((size_t)std::max<int64_t>(b->n_slabs, 1))) return rc;
+    // 3. the band lists
     if (int rc = b->entries.ensure((size_t)std::max<int64_t>(b->n_pb, 1))) return rc;
-    if (int rc = b->entry_where.ensure((size_t)std::max<int64_t>(b->n_pb, 1))) return rc;
+    if (int rc = b->pair_idx.ensure((size_t)std::max<int64_t>(b->n_pb, 1))) return rc;
     if (int rc = run_geometry(b, 3, true)) return rc;
     if (int rc = check_dev_err(b)) return rc;
     b->n_entries = b->host_bd.entry_cursor;
-    {
-        int caps[NSH];
-        for (int k = 0; k < NSH; ++k) caps[k] = b->host_bd.shard[k].chunk_cursor;
-        if (int rc = b->size_chunks(caps)) return rc;
-    }
     if (int rc = b->size_masks(b->host_bd.max_band_entries)) return rc;
     if (int rc = b->size_tile_lists(count_owned_bands(b->own, b->n_bands))) return rc;
-    // 3b. the whole geometry once with k_pair_scan only SIZING the add lists: what every band's add block has to hold
+    // 3b. the whole geometry once with k_path_build only SIZING the add lists: what every shard of add slots has to hold
     {
         b->count_adds_only = true;
+        b->add_shards.n = NSH;
         int rc = run_geometry(b, 4, true);
         b->count_adds_only = false;
         if (rc) return rc;
-        std::vector<int> need((size_t)b->n_bands + 1, 0);
-        if (b->n_bands > 0)
-            HIPCHK(hipMemcpyAsync(need.data(), b->band_add_cur(), sizeof(int) * (size_t)b->n_bands, hipMemcpyDeviceToHost, b->ctx->stream));
         if ((rc = check_dev_err(b))) return rc;
-        if ((rc = b->size_band_adds(need.data(), b->ctx->stream))) return rc;
+        int need[NSH];
+        for (int k = 0; k < NSH; ++k) need[k] = b->host_bd.shard[k].add_cursor;
+        if ((rc = b->size_adds(need, NSH))) return rc;
     }
     // 4. full geometry once, to validate the capacities and fetch the bboxes
     if (int rc = run_geometry(b, 4, true)) return rc;
@@ -3671,14 +3645,9 @@ int svgr_batch_get_edges(const svgr_batch* b, double* edges, int32_t* edge_path,
     if (b->n_edges_live == 0) return 0;
     HIPCHK(enter_ctx(b->ctx));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
-    int64_t at = 0;
-    for (int k = 0; k < NSH; ++k) {  // the filled part of every shard, packed
-        const int64_t n = std::min(b->host_bd.shard[k].cursor, b->shards.cap[k]);
-        if (n <= 0) continue;
-        HIPCHK(hipMemcpy(edges + 4 * at, b->edges.p + 4 * (size_t)b->shards.base[k], sizeof(double) * 4 * (size_t)n, hipMemcpyDeviceToHost));
-        if (edge_path) HIPCHK(hipMemcpy(edge_path + at, b->edge_path.p + b->shards.base[k], sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
-        at += n;
-    }
+    // (one dense block in (path, segment, curve) order: see k_flatten)
+    HIPCHK(hipMemcpy(edges, b->edges.p, sizeof(double) * 4 * (size_t)b->n_edges_live, hipMemcpyDeviceToHost));
+    if (edge_path) HIPCHK(hipMemcpy(edge_path, b->edge_path.p, sizeof(int) * (size_t)b->n_edges_live, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -3708,7 +3677,7 @@ static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path
     HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
     hipLaunchKernelGGL(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
                        (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr, (double*)nullptr, (int*)nullptr, b->shards,
-                       b->pkeys(), b->bd(), whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0);
+                       b->pkeys(), b->bd(), whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (const int*)nullptr, 0);
     BatchDev counts;
     HIPCHK(hipMemcpyAsync(&counts, b->bd(), sizeof counts, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -3732,7 +3701,7 @@ static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_flatten<true>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
                            (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr, d_edges, d_path, sh, b->pkeys(), b->bd(),
-                           whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0);
+                           whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (const int*)nullptr, 0);
         e = hipMemcpyAsync(edges, d_edges, sizeof(double) * 4 * (size_t)total, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && edge_path) e = hipMemcpyAsync(edge_path, d_path, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
