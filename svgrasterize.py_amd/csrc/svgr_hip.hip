@@ -713,10 +713,15 @@ constexpr int PB_THREADS = 256;
 constexpr int PB_CELLS = SVGR_PB_CELLS;
 constexpr int PB_BANDS = SVGR_PB_BANDS;   // bands per slab at most: one TR-lane group of the workgroup scans each
 static_assert(PB_BANDS * SVGR_TR <= PB_THREADS && PB_BANDS <= PB_CELLS, "k_path_build: one lane group per band of the slab");
+// It carries everything the workgroup needs of its path (bbox, bins, edge range): one load, then the edges -- looked up by
+// the workgroup itself they were three dependent round trips in front of the first edge.
 struct Slab {
-    int p, band0, nb, k0, nk, pad[3];
+    int p, band0, nb, k0;
+    int nk, e_begin, e_end, pb_off;
+    int r0, c0, rows, cols;       // the path's layer (clipped bbox)
+    int b0, cell_off, pad[2];     // ... its first band, its first cell
 };
-static_assert(sizeof(Slab) == 32, "Slab is 32 bytes");
+static_assert(sizeof(Slab) == 64, "Slab is four dwordx4");
 // how a path of nb bands x nct column tiles is cut: bands per slab, column-tile runs per band row
 __host__ __device__ __forceinline__ void slab_shape(int nb, int nct, int& bands_per, int& col_runs) {
     if (nct <= PB_CELLS) {
@@ -735,7 +740,8 @@ __host__ __device__ __forceinline__ void slab_shape(int nb, int nct, int& bands_
 __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __restrict__ pkeys, int n_paths, int has_vp,
                                                   int vr0, int vc0, int vrows, int vcols, int* __restrict__ bbox,
                                                   PathBin* __restrict__ bins, BatchDev* __restrict__ bd, int stats,
-                                                  const int* __restrict__ plist, Slab* __restrict__ slabs, int slab_cap, Owner own) {
+                                                  const int* __restrict__ plist, Slab* __restrict__ slabs, int slab_cap, Owner own,
+                                                  const int* __restrict__ path_seg0, const int* __restrict__ seg_off) {
     // (multi-GPU: thread i takes the i-th path of this rank's list, n_paths = its length; the others keep the empty bbox
     //  and bins the plan gave them)
     const int pi = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
@@ -822,6 +828,7 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
             atomicOr(&bd->err, 4);
         } else {
             int at = slab0;
+            const int e_begin = seg_off[path_seg0[p]], e_end = seg_off[path_seg0[p + 1]];  // the path's edges (k_flatten)
             for (int bb = 0; bb < pnb; bb += bands_per) {
                 const int be = bb + bands_per < pnb ? bb + bands_per : pnb;
                 if (!owns_any(own, pb0 + bb, pb0 + be - 1)) continue;
@@ -829,7 +836,10 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
                     Slab sl;
                     sl.p = p; sl.band0 = pb0 + bb; sl.nb = be - bb;
                     sl.k0 = c * PB_CELLS; sl.nk = pnct - sl.k0 < PB_CELLS ? pnct - sl.k0 : PB_CELLS;
-                    sl.pad[0] = sl.pad[1] = sl.pad[2] = 0;
+                    sl.e_begin = e_begin; sl.e_end = e_end; sl.pb_off = off;
+                    sl.r0 = out[0]; sl.c0 = out[1]; sl.rows = out[2]; sl.cols = out[3];
+                    sl.b0 = pb0; sl.cell_off = cell_off;
+                    sl.pad[0] = sl.pad[1] = 0;
                     slabs[at++] = sl;
                 }
             }
@@ -1095,90 +1105,128 @@ __device__ __forceinline__ unsigned add_where(int trow, int tcol, int len) {
 // `adds` == nullptr: the plan's measuring run (everything but the add lists themselves).
 // ---------------------------------------------------------------------------------------------
 struct EdgeLds {
-    double p0y, p1y, dxdy, x, dir;  // as EdgeSetup; x = column at which the edge enters row ya
-    int ya, pad;
+    double p0y, p1y, dxdy, x;  // as EdgeSetup; x = column at which the edge enters row ya
+    int ya_dir, pad;           // ya | (dir < 0) << 31
 };
-static_assert(sizeof(EdgeLds) == 48, "EdgeLds is three 16-byte LDS reads");
-__global__ __launch_bounds__(PB_THREADS) void k_path_build(const Slab* __restrict__ slabs, const double* __restrict__ edges,
-                                                           const int* __restrict__ path_seg0, const int* __restrict__ seg_off,
-                                                           const int* __restrict__ bbox, const PathBin* __restrict__ bins,
+static_assert(sizeof(EdgeLds) == 40, "EdgeLds is two 16-byte and one 8-byte LDS read");
+#ifndef SVGR_PB_EPL
+#define SVGR_PB_EPL 2
+#endif
+#ifndef SVGR_PB_KEEP
+#define SVGR_PB_KEEP 3
+#endif
+constexpr int PB_EPL = SVGR_PB_EPL;                // edges per lane and batch
+constexpr int PB_BATCH = PB_THREADS * PB_EPL;      // edges staged together
+constexpr int PB_KEEP = SVGR_PB_KEEP;              // rounds of tasks whose rows stay in registers from pass A to pass B
+constexpr int PB_TAB = PB_THREADS * PB_KEEP;       // tasks that find their edge in a table instead of by search
+static_assert(PB_BATCH % 16 == 0 && PB_BATCH / 16 <= 32, "two-level search: at most 32 coarse entries");
+#ifndef SVGR_PB_WAVES
+#define SVGR_PB_WAVES 3
+#endif
+__global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const Slab* __restrict__ slabs, const double* __restrict__ edges,
                                                            const int* __restrict__ pair_idx, const double* __restrict__ path_paint,
                                                            const uint8_t* __restrict__ path_rule, const int* __restrict__ path_group,
                                                            const int* __restrict__ path_grad, int vr0, int vc0, int n_ct, int mask_words,
                                                            unsigned long long* __restrict__ tile_mask, CellHdr* __restrict__ cell_hdr,
                                                            int cell_cap, const AddShards ash, TileAdd* __restrict__ adds,
-                                                           BatchDev* __restrict__ bd, Owner own, int stats) {
+                                                           BatchDev* __restrict__ bd, Owner own, int stats, unsigned long long* __restrict__ dbg) {
+#ifdef SVGR_DBG_PB_STAMP
+#define PB_STAMP(i) do { if (threadIdx.x == 0 && dbg && blockIdx.x < 8192) dbg[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PB_STAMP(i) do { } while (0)
+#endif
+    PB_STAMP(0);
     __shared__ __attribute__((aligned(16))) double s_sum[PB_CELLS * TR];
     __shared__ double s_left[TR];
     __shared__ int s_cnt[PB_CELLS], s_pos[PB_CELLS];
-    __shared__ __attribute__((aligned(16))) EdgeLds s_edge[PB_THREADS];
-    __shared__ __attribute__((aligned(16))) int s_pref[PB_THREADS + 16];
-    __shared__ __attribute__((aligned(16))) int s_coarse[16];
-    __shared__ int s_wtot[PB_THREADS / 64];
-    __shared__ int s_ptot[PB_BANDS], s_base, s_ok;
+    __shared__ __attribute__((aligned(16))) EdgeLds s_edge[PB_BATCH];
+    __shared__ __attribute__((aligned(16))) int s_pref[PB_BATCH];
+    __shared__ __attribute__((aligned(16))) int s_coarse[32];
+    __shared__ unsigned short s_tab[PB_TAB];
+    __shared__ int s_wtot[PB_EPL][PB_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) int4 s_info[PB_CELLS];
+    __shared__ int s_ptot[PB_BANDS], s_pidx[PB_BANDS], s_base, s_ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x >= bd->slab_cursor) return;  // (the grid covers the plan's slab capacity)
     const Slab sl = slabs[blockIdx.x];
     const int p = sl.p;
-    const int4 bb = ((const int4*)bbox)[p];
-    const PathBin pbin = bins[p];
-    const int r0 = bb.x, c0 = bb.y, rows = bb.z, cols = bb.w;
+    const int r0 = sl.r0, c0 = sl.c0, rows = sl.rows, cols = sl.cols;
     int ct0, nct;
     path_ctiles(c0, cols, vc0, ct0, nct);
     const int x_first = vc0 + ct0 * TC - c0;  // layer column at which the path's first column tile starts (<= 0)
-    const int e_begin = seg_off[path_seg0[p]], e_end = seg_off[path_seg0[p + 1]];
+    const int e_begin = sl.e_begin, e_end = sl.e_end;
     const int sr0 = vr0 + sl.band0 * TR - r0, sr1 = sr0 + sl.nb * TR;  // layer rows of the slab
     const int n_cell = sl.nb * sl.nk;
     const double o_r = (double)r0, o_c = (double)c0;  // `lines - [min_x, min_y]` (S:979)
     for (int i = tid; i < n_cell * TR; i += PB_THREADS) s_sum[i] = 0.0;
-    for (int i = tid; i < n_cell; i += PB_THREADS) { s_cnt[i] = 0; s_pos[i] = (int)0x80000000; }
+    for (int i = tid; i < n_cell; i += PB_THREADS) { s_cnt[i] = 0; s_pos[i] = (int)0x80000000; s_info[i] = make_int4(0, 0, 0, 0); }
     if (tid < TR) s_left[tid] = 0.0;
-    if (tid < 16) s_pref[PB_THREADS + tid] = 0x7fffffff;
 
-    // a batch of edges: set up, rows inside the slab counted, prefix sums -> number of (edge, row) tasks of the batch
+    // a batch of edges (slot = tid + j * PB_THREADS): set up, rows inside the slab counted, prefix sums -> number of
+    // (edge, row) tasks of the batch; the first PB_TAB tasks find their slot in s_tab
     auto stage = [&](int eb) -> int {
-        const int e = eb + tid;
-        int cnt = 0;
-        EdgeLds el;
-        el.p0y = el.p1y = el.dxdy = el.x = 0.0; el.dir = 1.0; el.ya = 0; el.pad = 0;
-        if (e < e_end) {
-            const double4 ed = ((const double4*)edges)[e];
-            const double ar = ed.x - o_r, ac = ed.y - o_c, br = ed.z - o_r, bc = ed.w - o_c;
-            const EdgeSetup es = edge_setup(ar, ac, br, bc, rows);
-            // an edge whose every column is beyond the layer never stores anything (S:2260, S:2274)
-            const double cmin = ac < bc ? ac : bc;
-            if (es.valid && !(cmin >= (double)cols + 2.0)) {
-                const int ya = es.y_begin > sr0 ? es.y_begin : sr0, yb = es.y_end < sr1 ? es.y_end : sr1;
-                if (ya < yb) {
-                    cnt = yb - ya;
-                    RowState st;
-                    st.x_next = es.x; st.x = es.x; st.d = 0.0;
-                    // carry x from the edge's first row to the slab's, exactly as the walk would (S:2244-2248)
-                    for (int yy = es.y_begin; yy < ya; ++yy) row_step(st, yy, es.p0y, es.p1y, es.dxdy, es.dir);
-                    el.p0y = es.p0y; el.p1y = es.p1y; el.dxdy = es.dxdy; el.x = st.x_next; el.dir = es.dir; el.ya = ya;
+        int cnt[PB_EPL];
+        EdgeLds el[PB_EPL];
+#pragma unroll
+        for (int j = 0; j < PB_EPL; ++j) {
+            const int e = eb + tid + j * PB_THREADS;
+            cnt[j] = 0;
+            el[j].p0y = el[j].p1y = el[j].dxdy = el[j].x = 0.0; el[j].ya_dir = 0; el[j].pad = 0;
+            if (e < e_end) {
+                const double4 ed = ((const double4*)edges)[e];
+                const double ar = ed.x - o_r, ac = ed.y - o_c, br = ed.z - o_r, bc = ed.w - o_c;
+                const EdgeSetup es = edge_setup(ar, ac, br, bc, rows);
+                // an edge whose every column is beyond the layer never stores anything (S:2260, S:2274)
+                const double cmin = ac < bc ? ac : bc;
+                if (es.valid && !(cmin >= (double)cols + 2.0)) {
+                    const int ya = es.y_begin > sr0 ? es.y_begin : sr0, yb = es.y_end < sr1 ? es.y_end : sr1;
+                    if (ya < yb) {
+                        cnt[j] = yb - ya;
+                        RowState st;
+                        st.x_next = es.x; st.x = es.x; st.d = 0.0;
+                        // carry x from the edge's first row to the slab's, exactly as the walk would (S:2244-2248)
+                        for (int yy = es.y_begin; yy < ya; ++yy) row_step(st, yy, es.p0y, es.p1y, es.dxdy, es.dir);
+                        el[j].p0y = es.p0y; el[j].p1y = es.p1y; el[j].dxdy = es.dxdy; el[j].x = st.x_next;
+                        el[j].ya_dir = ya | (es.dir < 0.0 ? (int)0x80000000 : 0);  // (ya >= 0)
+                    }
                 }
             }
         }
-        int wtot;
-        const int excl = wave_excl_scan(cnt, lane, wtot);
-        __syncthreads();  // (the previous batch's tasks are done with s_edge / s_pref)
-        if (lane == 0) s_wtot[wave] = wtot;
-        s_edge[tid] = el;
-        __syncthreads();
-        int before = 0, all = 0;
+        int excl[PB_EPL], wtot[PB_EPL];
 #pragma unroll
-        for (int w = 0; w < PB_THREADS / 64; ++w) { before += w < wave ? s_wtot[w] : 0; all += s_wtot[w]; }
-        s_pref[tid] = before + excl;
-        if ((tid & 15) == 0) s_coarse[tid >> 4] = before + excl;
+        for (int j = 0; j < PB_EPL; ++j) excl[j] = wave_excl_scan(cnt[j], lane, wtot[j]);
+        __syncthreads();  // (the previous batch's tasks are done with s_edge / s_pref / s_tab)
+#pragma unroll
+        for (int j = 0; j < PB_EPL; ++j) {
+            if (lane == 0) s_wtot[j][wave] = wtot[j];
+            s_edge[tid + j * PB_THREADS] = el[j];
+        }
+        __syncthreads();
+        int all = 0;
+#pragma unroll
+        for (int j = 0; j < PB_EPL; ++j) {
+            int before = all;
+#pragma unroll
+            for (int w = 0; w < PB_THREADS / 64; ++w) { before += w < wave ? s_wtot[j][w] : 0; all += s_wtot[j][w]; }
+            const int slot = tid + j * PB_THREADS, pre = before + excl[j];
+            s_pref[slot] = pre;
+            if ((slot & 15) == 0) s_coarse[slot >> 4] = pre;
+            for (int q = pre; q < pre + cnt[j] && q < PB_TAB; ++q) s_tab[q] = (unsigned short)slot;
+        }
         __syncthreads();
         return all;
     };
-    // task t of the staged batch -> its edge's LDS slot and its layer row
-    auto find = [&](int t, int& slot, int& y) {
+    // task t of the staged batch -> its edge's LDS slot and its row offset inside the edge's rows of the slab
+    auto find = [&](int t, int& slot, int& dy) {
+        if (t < PB_TAB) {
+            slot = s_tab[t];
+            dy = t - s_pref[slot];
+            return;
+        }
         const int4* cq = (const int4*)s_coarse;
         int blk = -1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < PB_BATCH / 64; ++q) {
             const int4 v = cq[q];
             blk += (v.x <= t) + (v.y <= t) + (v.z <= t) + (v.w <= t);
         }
@@ -1191,38 +1239,42 @@ __global__ __launch_bounds__(PB_THREADS) void k_path_build(const Slab* __restric
             at = v.x <= t ? v.x : at; at = v.y <= t ? v.y : at; at = v.z <= t ? v.z : at; at = v.w <= t ? v.w : at;
         }
         slot = 16 * blk + in;
-        y = t - at;  // (+ the edge's first row in the slab, added by the caller)
+        dy = t - at;
     };
     // the row of a task: its pieces (S:2250-2303) and where they fall
     struct RowAt {
-        RowPieces rp;
-        int n, bl, trow, kf, kl;
-        bool live;
+        int x0i, n;
+        double v[5];
+        int where;   // bl | trow << 8 | live << 16
     };
     auto row_of = [&](int t) -> RowAt {
         RowAt ra;
         int slot, dy;
         find(t, slot, dy);
         const EdgeLds el = s_edge[slot];
-        const int y = el.ya + dy;
+        const int ya = el.ya_dir & 0x7fffffff, y = ya + dy;
+        const double dir = el.ya_dir < 0 ? -1.0 : 1.0;
         RowState st;
         st.x_next = el.x; st.x = el.x; st.d = 0.0;
-        for (int yy = el.ya; yy <= y; ++yy) row_step(st, yy, el.p0y, el.p1y, el.dxdy, el.dir);
+        for (int yy = ya; yy <= y; ++yy) row_step(st, yy, el.p0y, el.p1y, el.dxdy, dir);
         const int vrow = r0 + y - vr0, band = vrow / TR;
-        ra.rp = row_record(st.x, st.x_next, st.d);
-        ra.n = ra.rp.n;
+        const RowPieces rp = row_record(st.x, st.x_next, st.d);
+        ra.x0i = rp.x0i; ra.n = rp.n;
+        ra.v[0] = rp.v[0]; ra.v[1] = rp.v[1]; ra.v[2] = rp.v[2]; ra.v[3] = rp.v[3]; ra.v[4] = rp.v[4];
         if ((unsigned)ra.n > SPAN_MAX) { atomicOr(&bd->err, 16); ra.n = (int)SPAN_MAX; }
-        ra.bl = band - sl.band0;
-        ra.trow = vrow & (TR - 1);
-        ra.live = owns_band(own, band) && ra.rp.x0i < cols;  // (another rank's band; a row wholly beyond the layer, S:2260)
-        // the path's column tiles [kf, kl] the pieces fall into
-        const int xl = ra.rp.x0i + (ra.n >= 2 ? ra.n : 1);  // column of the last piece
-        const int cf = ra.rp.x0i > 0 ? ra.rp.x0i : 0;
+        const bool live = owns_band(own, band) && rp.x0i < cols;  // (another rank's band; a row wholly beyond the layer, S:2260)
+        ra.where = (band - sl.band0) | ((vrow & (TR - 1)) << 8) | ((int)live << 16);
+        return ra;
+    };
+    // the slab's column tiles [kf, kl] (relative to the path's first) the pieces of a row fall into
+    auto row_tiles = [&](const RowAt& ra, int& kf, int& kl) {
+        const int xl = ra.x0i + (ra.n >= 2 ? ra.n : 1);  // column of the last piece
+        const int cf = ra.x0i > 0 ? ra.x0i : 0;
         int cl = xl > 0 ? xl : 0;
         cl = cl < cols - 1 ? cl : cols - 1;
-        ra.kf = (cf - x_first) / TC;
-        ra.kl = (cl - x_first) / TC;
-        return ra;
+        kf = (cf - x_first) / TC;
+        kl = (cl - x_first) / TC;
+        kl = kl < sl.k0 + sl.nk - 1 ? kl : sl.k0 + sl.nk - 1;
     };
     // layer columns [ca, cb) of the path's column tile k
     auto tile_cols = [&](int k, int& ca, int& cb) {
@@ -1231,75 +1283,106 @@ __global__ __launch_bounds__(PB_THREADS) void k_path_build(const Slab* __restric
         ca = ca > 0 ? ca : 0;
         cb = cb < cols ? cb : cols;
     };
-    auto add_count = [&](int x0i, int n, int ca, int cb) {
-        const double none[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        int ne = 0;
-        record_adds(x0i, n, none, ca, cb, [&](int, double) { ++ne; }, [&](int, int, double) { ++ne; });
-        return ne;
+    // pass A of one row: per cell the number of adds its pieces make there and their sum
+    auto count_row = [&](const RowAt& ra) {
+#ifdef SVGR_DBG_PB_NOCOUNT
+        if (ra.x0i != 123456789) return;
+#endif
+        if (!((ra.where >> 16) & 1)) return;
+        const int bl = ra.where & 0xff, trow = (ra.where >> 8) & 0xff;
+        int kf, kl;
+        row_tiles(ra, kf, kl);
+        if (sl.k0 > 0 && kf < sl.k0) {
+            // (a slab that is not the first of its band row: what lies left of it is only summed)
+            int ca, cb;
+            tile_cols(sl.k0, ca, cb);
+            const double part = record_sum_range(ra.x0i, ra.n, ra.v, 0, ca);
+            __hip_atomic_fetch_add(&s_left[trow], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            kf = sl.k0;
+        }
+        for (int k = kf; k <= kl; ++k) {
+            int ca, cb;
+            tile_cols(k, ca, cb);
+            int ne = 0;
+            double part = 0.0;
+            record_adds(ra.x0i, ra.n, ra.v, ca, cb, [&](int, double val) { ++ne; part = part + val; },
+                        [&](int, int len, double val) { ++ne; part = part + (double)len * val; });
+            if (ne == 0) continue;
+            const int ci = bl * sl.nk + (k - sl.k0);
+            __hip_atomic_fetch_add(&s_cnt[ci], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&s_sum[ci * TR + trow], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    // pass B of one row: the pieces as adds, behind what their cells' lists hold already
+    auto emit_row = [&](const RowAt& ra) {
+        if (!((ra.where >> 16) & 1)) return;
+        const int bl = ra.where & 0xff, trow = (ra.where >> 8) & 0xff;
+        int kf, kl;
+        row_tiles(ra, kf, kl);
+        kf = kf > sl.k0 ? kf : sl.k0;
+        for (int k = kf; k <= kl; ++k) {
+            int ca, cb;
+            tile_cols(k, ca, cb);
+            int ne = 0;
+            record_adds(ra.x0i, ra.n, ra.v, ca, cb, [&](int, double) { ++ne; }, [&](int, int, double) { ++ne; });
+            if (ne == 0) continue;
+            const int ci = bl * sl.nk + (k - sl.k0);
+            const int pos = __hip_atomic_fetch_add(&s_pos[ci], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (pos < 0) continue;  // (the cell was refused by the scan: flagged there)
+            TileAdd* dst = adds + pos;
+            const int cell_c0 = k * TC + x_first;  // layer column of the tile's column 0
+            record_adds(ra.x0i, ra.n, ra.v, ca, cb,
+                        [&](int c, double val) { TileAdd tt; tt.where = add_where(trow, c - cell_c0, 1); tt.zero = 0u; tt.v = val; *dst++ = tt; },
+                        [&](int c, int len, double val) { TileAdd tt; tt.where = add_where(trow, c - cell_c0, len); tt.zero = 0u; tt.v = val; *dst++ = tt; });
+        }
     };
 
-    // ---- pass A ----
-    int n_rows = 0;
-    for (int eb = e_begin; eb < e_end; eb += PB_THREADS) {
-        const int total = stage(eb);
+    // ---- pass A ----  (a path of up to PB_BATCH edges is staged once, and its first PB_KEEP rounds of rows stay in registers)
+    const bool one_batch = e_end - e_begin <= PB_BATCH;
+    RowAt kept[PB_KEEP];
+    int total = 0, n_rows = 0;
+    for (int eb = e_begin; eb < e_end; eb += PB_BATCH) {
+        total = stage(eb);
+        PB_STAMP(1);
         n_rows += total;
-        for (int t = tid; t < total; t += PB_THREADS) {
-            const RowAt ra = row_of(t);
-            if (!ra.live) continue;
-            int kf = ra.kf, kl = ra.kl;
-            if (sl.k0 > 0 && kf < sl.k0) {
-                // (a slab that is not the first of its band row: what lies left of it is only summed)
-                int ca, cb;
-                tile_cols(sl.k0, ca, cb);
-                const double part = record_sum_range(ra.rp.x0i, ra.n, ra.rp.v, 0, ca);
-                __hip_atomic_fetch_add(&s_left[ra.trow], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                kf = sl.k0;
-            }
-            kl = kl < sl.k0 + sl.nk - 1 ? kl : sl.k0 + sl.nk - 1;
-            for (int k = kf; k <= kl; ++k) {
-                int ca, cb;
-                tile_cols(k, ca, cb);
-                const int ne = add_count(ra.rp.x0i, ra.n, ca, cb);
-                if (ne == 0) continue;
-                const int ci = ra.bl * sl.nk + (k - sl.k0);
-                const double part = record_sum_range(ra.rp.x0i, ra.n, ra.rp.v, ca, cb);
-                __hip_atomic_fetch_add(&s_cnt[ci], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&s_sum[ci * TR + ra.trow], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef SVGR_DBG_PB_NOTASK
+        total = 0;
+#endif
+        int t = tid;
+        if (one_batch) {
+#pragma unroll
+            for (int r = 0; r < PB_KEEP; ++r, t += PB_THREADS) {
+                if (t < total) {
+                    kept[r] = row_of(t);
+                    count_row(kept[r]);
+                }
             }
         }
+        for (; t < total; t += PB_THREADS) count_row(row_of(t));
     }
     if (stats && tid == 0 && n_rows > 0) atomicAdd(&bd->bseg_cursor, n_rows);  // (plan only: edge rows of the batch)
     __syncthreads();
-
-    // ---- scan: TR lanes per band of the slab ----
+    PB_STAMP(2);
+    // ---- scan ----
+#ifdef SVGR_DBG_PB_NOSCAN
+    if (n_rows != 123456789) return;
+#endif
+    const int rl = path_rule[p], rule = rl & 1;
     {
-        constexpr unsigned long long GMASK = TR == 64 ? ~0ull : ((1ull << TR) - 1ull);
+        // walk: TR lanes per band of the slab (lane = tile row) go through the band's cells left to right.  The row's running
+        // sum replaces the cell's sum in s_sum (what phase 2 needs is the carry-in); per cell: class, adds, and which rows have a
+        // carry-in / a sentinel (as bit masks of the band's TR lanes)
+        static_assert(TR <= 16, "k_path_build packs two TR-bit row masks into one word");
+        constexpr unsigned long long GMASK = (1ull << TR) - 1ull;
         const int g = tid / TR, row_l = tid & (TR - 1);
         const int shift = lane & ~(TR - 1);          // first lane of this band's group in the wave
         const int band = sl.band0 + g;
         const bool active = g < sl.nb && owns_band(own, band);
-        const int rl = path_rule[p], rule = rl & 1;
-        const int group = path_group ? path_group[p] : -1;
-        const int grad1 = path_grad ? path_grad[p] + 1 : 0;  // gradient index + 1 (0: solid colour)
-        const double4 paint = ((const double4*)path_paint)[p];
-        const int idx = active ? pair_idx[pbin.pb_off + band - pbin.b0] : 0;  // the pair's place in its band's list
-        bool mask_ok = active;
-        if (active && (idx >> 6) >= mask_words) {  // (the plan sized the masks from the longest band list)
-            if (row_l == 0) atomicOr(&bd->err, 32);
-            mask_ok = false;
-        }
-        // the tiles' entry bitmasks: per (band, column tile) two rows of mask_words words, bit i = entry i of the band's list
-        // has a cell of class >= 1 (row 0) / class 2 (row 1) here.  Classes 0 simply stay unset.
-        unsigned long long* const mrow = tile_mask + ((size_t)(active ? band : 0) * n_ct + ct0 + sl.k0) * 2 * mask_words + (mask_ok ? idx >> 6 : 0);
-        const unsigned long long mbit = 1ull << (idx & 63);
-        // is this lane's tile row a row of the layer?  (the sentinel behind the layer's last column is set on those only)
         const int row_abs = vr0 + band * TR + row_l;
-        const bool row_in_layer = row_abs >= r0 && row_abs < r0 + rows;
-        const int cell_row0 = pbin.cell_off + (band - pbin.b0) * nct + sl.k0;  // global cell of the band's first cell in the slab
-        int pair_off = 0;
-#pragma unroll 1
-        for (int phase = 0; phase < 2; ++phase) {
-            int cursor = 0;                                    // adds of the column tiles walked so far
+        const bool row_in_layer = row_abs >= r0 && row_abs < r0 + rows;  // (the sentinel is set on rows of the layer only)
+        int cursor = 0;                                    // adds of the column tiles walked so far
+        if (__ballot(active) != 0ull) {  // (a wave none of whose bands exists has nothing to walk)
+            if (active && row_l == 0) s_pidx[g] = pair_idx[sl.pb_off + band - sl.b0];  // the pair's place in its band's list
             double run = sl.k0 > 0 ? s_left[row_l] : 0.0;      // the row's running sum left of the column tile
             for (int k = 0; k < sl.nk; ++k) {
                 const int ci = g * sl.nk + k;
@@ -1310,100 +1393,116 @@ __global__ __launch_bounds__(PB_THREADS) void k_path_build(const Slab* __restric
                 const unsigned long long vm = (__ballot(vis) >> shift) & GMASK;
                 const int cls = own_n > 0 ? 2 : (vm != 0ull ? 1 : 0);
                 // class 2: the cell's add list = [carry-ins of the rows where it is not zero][sentinels][pieces]
-                const int cell_c0 = (sl.k0 + k) * TC + x_first;       // layer column of the tile's column 0
-                const int t_first = cell_c0 < 0 ? -cell_c0 : 0;       // tile column of the layer's first column inside the tile
-                const int t_end = cols - cell_c0;                     // tile column one past the layer's last column
+                const int t_end = cols - ((sl.k0 + k) * TC + x_first);     // tile column one past the layer's last column
                 const bool want_carry = active && cls == 2 && cin != 0.0;
                 const bool want_sent = active && cls == 2 && t_end < TC && row_in_layer;
-                const unsigned long long cm = (__ballot(want_carry) >> shift) & GMASK;
-                const unsigned long long sm = (__ballot(want_sent) >> shift) & GMASK;
-                const int n_carry = __popcll(cm), n_sent = __popcll(sm);
-                const int n_add = cls == 2 ? n_carry + n_sent + own_n : 0;
-                const int off = cursor;
-                cursor += n_add;
-                if (phase == 1 && active && cls != 0) {
-                    const int cell = cell_row0 + k;
-                    const bool taken = cell < cell_cap && s_ok && mask_ok;
-                    if (taken) {
-                        CellHdr* hd = cell_hdr + cell;
-                        hd->carry[row_l] = cin;
-                        const unsigned long long below = (1ull << row_l) - 1ull;
-                        const int add0 = s_base + pair_off + off;
-                        if (want_carry && adds) {
-                            TileAdd t;
-                            t.where = add_where(row_l, t_first, 1); t.zero = 0u; t.v = cin;
-                            adds[(size_t)add0 + __popcll(cm & below)] = t;
-                        }
-                        if (want_sent && adds) {
-                            TileAdd t;
-                            t.where = add_where(row_l, t_end, 1); t.zero = 0u; t.v = __builtin_nan("");
-                            adds[(size_t)add0 + n_carry + __popcll(sm & below)] = t;
-                        }
-                        if (row_l == 0) {
-                            unsigned long long* const mw = mrow + (size_t)k * 2 * mask_words;
-                            atomicOr(mw, mbit);
-                            if (cls == 2) atomicOr(mw + mask_words, mbit);
-                            hd->paint[0] = paint.x; hd->paint[1] = paint.y; hd->paint[2] = paint.z; hd->paint[3] = paint.w;
-                            hd->r0 = r0; hd->c0 = c0; hd->rows = rows; hd->cols = cols;
-                            hd->bits = rule | (((rl >> 1) & 3) << 1) | (cls << 3) | (grad1 << 5);
-                            hd->n_add = n_add; hd->add0 = add0; hd->p = p;
-                            hd->group = group;
-                            if (cls == 2 && adds) s_pos[ci] = add0 + n_carry + n_sent;  // the pieces follow (pass B)
-                        }
-                    } else if (row_l == 0 && cell >= cell_cap) {
-                        atomicOr(&bd->err, 32);
+                const unsigned cm = (unsigned)((__ballot(want_carry) >> shift) & GMASK);
+                const unsigned sm = (unsigned)((__ballot(want_sent) >> shift) & GMASK);
+                const int n_add = cls == 2 ? __popc(cm) + __popc(sm) + own_n : 0;
+                if (active) {
+                    s_sum[ci * TR + row_l] = cin;
+                    if (row_l == 0) {
+                        s_cnt[ci] = n_add;                                   // (the cell's whole list now)
+                        s_info[ci] = make_int4(cursor, cls | (g << 2) | (k << 8), (int)(cm | (sm << 16)), 0);
                     }
                 }
+                cursor += n_add;
                 run = run + sq;
             }
-            if (phase == 0) {
-                // the slab's reservation of add slots: ONE atomic, in the slab's shard
-                if (row_l == 0 && g < PB_BANDS) s_ptot[g] = cursor;
-                __syncthreads();
-                int before = 0, all = 0;
-                for (int q = 0; q < sl.nb; ++q) { before += q < g ? s_ptot[q] : 0; all += s_ptot[q]; }
-                pair_off = before;
-                if (tid == 0) {
-                    const int sh = p % ash.n;  // (by path, not by slab: the slabs' order changes from pass to pass, the plan's shard sizes must hold)
-                    int at = 0;
-                    if (all > 0) at = atomicAdd(&bd->shard[sh].add_cursor, all);
-                    int ok = 1;
-                    if (adds && (long long)at + all > (long long)ash.cap[sh]) { atomicOr(&bd->err, 64); ok = 0; }
-                    s_base = ash.base[sh] + at;
-                    s_ok = ok;
-                }
-                __syncthreads();
+        }
+        // the slab's reservation of add slots: ONE atomic, in the path's shard
+        if (row_l == 0 && g < PB_BANDS) s_ptot[g] = active ? cursor : 0;
+        __syncthreads();
+        if (tid == 0) {
+            int all = 0;
+            for (int q = 0; q < sl.nb; ++q) { const int c = s_ptot[q]; s_ptot[q] = all; all += c; }  // -> the bands' offsets
+            const int sh = p % ash.n;  // (by path, not by slab: the slabs' order changes from pass to pass, the plan's shard sizes must hold)
+            int at = 0;
+            if (all > 0) at = atomicAdd(&bd->shard[sh].add_cursor, all);
+            int ok = 1;
+            if (adds && (long long)at + all > (long long)ash.cap[sh]) { atomicOr(&bd->err, 64); ok = 0; }
+            s_base = ash.base[sh] + at;
+            s_ok = ok;
+        }
+        __syncthreads();
+    }
+    PB_STAMP(3);
+    {
+        // write: one lane per (cell, tile row) -- headers, carry-ins and sentinels, the entry-bitmask bits; no lane idles
+        // through a band that does not exist
+        const int group = path_group ? path_group[p] : -1;
+        const int grad1 = path_grad ? path_grad[p] + 1 : 0;  // gradient index + 1 (0: solid colour)
+        const double4 paint = ((const double4*)path_paint)[p];
+        const bool slab_ok = s_ok != 0;
+        for (int i = tid; i < n_cell * TR; i += PB_THREADS) {
+            const int ci = i / TR, row_l = i & (TR - 1);
+            const int4 info = s_info[ci];
+            const int cls = info.y & 3, g = (info.y >> 2) & 63, k = info.y >> 8;
+            const int band = sl.band0 + g;
+            if (cls == 0 || !owns_band(own, band)) continue;
+            const int cell = sl.cell_off + (band - sl.b0) * nct + sl.k0 + k;
+            const int idx = s_pidx[g];
+            const bool mask_ok = (idx >> 6) < mask_words;  // (the plan sized the masks from the longest band list)
+            if (!(cell < cell_cap && slab_ok && mask_ok)) {
+                if (row_l == 0) atomicOr(&bd->err, 32);
+                continue;
+            }
+            const double cin = s_sum[i];
+            const unsigned cm = (unsigned)info.z & 0xffffu, sm = (unsigned)info.z >> 16;
+            const int n_carry = __popc(cm);
+            CellHdr* hd = cell_hdr + cell;
+            hd->carry[row_l] = cin;
+            const int add0 = s_base + s_ptot[g] + info.x;
+            const int cell_c0 = (sl.k0 + k) * TC + x_first;       // layer column of the tile's column 0
+            const unsigned below = (1u << row_l) - 1u;
+            if (((cm >> row_l) & 1u) && adds) {
+                TileAdd t;
+                t.where = add_where(row_l, cell_c0 < 0 ? -cell_c0 : 0, 1); t.zero = 0u; t.v = cin;  // at the layer's first column in the tile
+                adds[(size_t)add0 + __popc(cm & below)] = t;
+            }
+            if (((sm >> row_l) & 1u) && adds) {
+                TileAdd t;
+                t.where = add_where(row_l, cols - cell_c0, 1); t.zero = 0u; t.v = __builtin_nan("");  // behind the layer's last column
+                adds[(size_t)add0 + n_carry + __popc(sm & below)] = t;
+            }
+            if (row_l == 0) {
+                // the tiles' entry bitmasks: per (band, column tile) two rows of mask_words words, bit i = entry i of the band's
+                // list has a cell of class >= 1 (row 0) / class 2 (row 1) here.  Classes 0 simply stay unset.
+                unsigned long long* const mw = tile_mask + ((size_t)band * n_ct + ct0 + sl.k0 + k) * 2 * mask_words + (idx >> 6);
+                const unsigned long long mbit = 1ull << (idx & 63);
+                atomicOr(mw, mbit);
+                if (cls == 2) atomicOr(mw + mask_words, mbit);
+                hd->paint[0] = paint.x; hd->paint[1] = paint.y; hd->paint[2] = paint.z; hd->paint[3] = paint.w;
+                hd->r0 = r0; hd->c0 = c0; hd->rows = rows; hd->cols = cols;
+                hd->bits = rule | (((rl >> 1) & 3) << 1) | (cls << 3) | (grad1 << 5);
+                hd->n_add = s_cnt[ci]; hd->add0 = add0; hd->p = p;
+                hd->group = group;
+                if (cls == 2 && adds) s_pos[ci] = add0 + n_carry + __popc(sm);  // the pieces follow (pass B)
             }
         }
     }
     __syncthreads();
+    PB_STAMP(4);
     if (!adds) return;
 
     // ---- pass B ----
-    for (int eb = e_begin; eb < e_end; eb += PB_THREADS) {
-        const int total = stage(eb);
-        for (int t = tid; t < total; t += PB_THREADS) {
-            const RowAt ra = row_of(t);
-            if (!ra.live) continue;
-            const int kf = ra.kf > sl.k0 ? ra.kf : sl.k0;
-            const int kl = ra.kl < sl.k0 + sl.nk - 1 ? ra.kl : sl.k0 + sl.nk - 1;
-            for (int k = kf; k <= kl; ++k) {
-                int ca, cb;
-                tile_cols(k, ca, cb);
-                const int ne = add_count(ra.rp.x0i, ra.n, ca, cb);
-                if (ne == 0) continue;
-                const int ci = ra.bl * sl.nk + (k - sl.k0);
-                const int pos = __hip_atomic_fetch_add(&s_pos[ci], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (pos < 0) continue;  // (the cell was refused above: flagged there)
-                TileAdd* dst = adds + pos;
-                const int cell_c0 = k * TC + x_first;  // layer column of the tile's column 0
-                const int trow = ra.trow;
-                record_adds(ra.rp.x0i, ra.n, ra.rp.v, ca, cb,
-                            [&](int c, double val) { TileAdd tt; tt.where = add_where(trow, c - cell_c0, 1); tt.zero = 0u; tt.v = val; *dst++ = tt; },
-                            [&](int c, int len, double val) { TileAdd tt; tt.where = add_where(trow, c - cell_c0, len); tt.zero = 0u; tt.v = val; *dst++ = tt; });
-            }
+#ifdef SVGR_DBG_PB_NOB
+    return;
+#endif
+    if (one_batch) {
+        int t = tid;
+#pragma unroll
+        for (int r = 0; r < PB_KEEP; ++r, t += PB_THREADS)
+            if (t < total) emit_row(kept[r]);
+        for (; t < total; t += PB_THREADS) emit_row(row_of(t));  // (the batch is still staged)
+    } else {
+        for (int eb = e_begin; eb < e_end; eb += PB_BATCH) {
+            const int tot = stage(eb);
+            for (int t = tid; t < tot; t += PB_THREADS) emit_row(row_of(t));
         }
     }
+    PB_STAMP(5);
+    if (threadIdx.x == 0 && dbg && blockIdx.x < 8192) dbg[8 * blockIdx.x + 6] = (unsigned long long)n_rows;
 }
 
 // After k_path_build, one workgroup per owned band: the tiles' entry bitmasks become their item lists -- the cell ids of
@@ -2811,7 +2910,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
         if (upto == 0)  // bboxes only (no edges stored): enough to find the union when there is no viewport
             hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(),
                                np_walk, use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), 1, plist,
-                               (Slab*)nullptr, 0, b->own);
+                               (Slab*)nullptr, 0, b->own, (const int*)nullptr, (const int*)nullptr);
         return 0;
     }
     if (ns > 0)
@@ -2821,7 +2920,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                            n_bands_vp, prow, seg_list, n_items, (int*)nullptr, (const int*)b->seg_off.p, cap_i32(b->edge_path.cap));
     hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np_walk,
                        use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), b->planned ? 0 : 1, plist,
-                       upto >= 3 ? b->slabs.p : (Slab*)nullptr, cap_i32(b->slabs.cap), b->own);
+                       upto >= 3 ? b->slabs.p : (Slab*)nullptr, cap_i32(b->slabs.cap), b->own, (const int*)b->path_seg0.p, (const int*)b->seg_off.p);
     if (upto == 2) return 0;
     // per owned band: its list of (path, band) pairs in paint order, and its first tile-list slot
     const int owned = count_owned_bands(b->own, b->n_bands);
@@ -2838,15 +2937,43 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
         b->masks_zeroed = true;
     }
     // per slab of a path's cells: carry-ins, classes, headers, add lists
+    unsigned long long* pb_dbg = nullptr;
+#ifdef SVGR_DBG_PB_STAMP
+    {
+        static unsigned long long* buf = nullptr;
+        if (!buf) { (void)hipMalloc((void**)&buf, 8 * 8 * 8192); (void)hipMemset(buf, 0, 8 * 8 * 8192); }
+        pb_dbg = buf;
+    }
+#endif
     if (b->n_slabs > 0) {
         b->masks_zeroed = false;  // (bits are set below; k_tile_lists clears them again)
         hipLaunchKernelGGL(k_path_build, dim3((unsigned)b->n_slabs), dim3(PB_THREADS), 0, st, (const Slab*)b->slabs.p, (const double*)b->edges.p,
-                           (const int*)b->path_seg0.p, (const int*)b->seg_off.p, (const int*)b->bbox.p, (const PathBin*)b->bins.p,
                            (const int*)b->pair_idx.p, (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p,
                            b->n_groups > 0 ? (const int*)b->path_group.p : (const int*)nullptr,
                            b->n_grads > 0 ? (const int*)b->path_grad.p : (const int*)nullptr, b->vp[0], b->vp[1], b->n_ctiles(), b->mask_words,
                            b->tile_mask.p, b->cell_hdr.p, cap_i32(b->cell_hdr.cap), b->add_shards,
-                           b->count_adds_only ? (TileAdd*)nullptr : b->adds.p, b->bd(), b->own, b->planned ? 0 : 1);
+                           b->count_adds_only ? (TileAdd*)nullptr : b->adds.p, b->bd(), b->own, b->planned ? 0 : 1, pb_dbg);
+#ifdef SVGR_DBG_PB_STAMP
+        if (pb_dbg && b->planned && !b->count_adds_only) {
+            static int n_dump = 0;
+            if (++n_dump == 20) {  // one render, well into the run
+                HIPCHK(hipStreamSynchronize(st));
+                const size_t n = (size_t)std::min<int64_t>(b->n_slabs, 8192);
+                std::vector<unsigned long long> h(8 * n);
+                HIPCHK(hipMemcpy(h.data(), pb_dbg, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+                double ph[5] = {0, 0, 0, 0, 0}, rows_ = 0;
+                unsigned long long lo = ~0ull, hi = 0;
+                for (size_t i = 0; i < n; ++i) {
+                    for (int q = 0; q < 5; ++q) ph[q] += (double)(h[8 * i + q + 1] - h[8 * i + q]);
+                    rows_ += (double)h[8 * i + 6];
+                    lo = std::min(lo, h[8 * i]); hi = std::max(hi, h[8 * i + 5]);
+                }
+                fprintf(stderr, "[pb stamp] %zu slabs, mean us: stage %.2f  passA %.2f  walk %.2f  write %.2f  passB %.2f | rows/slab %.0f | span %.1f us\n", n,
+                        ph[0] / n / 100, ph[1] / n / 100, ph[2] / n / 100, ph[3] / n / 100, ph[4] / n / 100, rows_ / n, (double)(hi - lo) / 100);
+                if (const char* f = getenv("SVGR_DBG_PB_DUMP")) { if (FILE* fp = fopen(f, "wb")) { fwrite(h.data(), 8, h.size(), fp); fclose(fp); } }
+            }
+        }
+#endif
     }
     // per owned band: the tiles' item lists and the launch order of the tile kernel; clears the bitmasks again
     if (owned > 0 && b->n_ctiles() > 0) {
