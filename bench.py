@@ -20,16 +20,25 @@ tile-parallel speed-up, measured in the same run) and `weak_scaling` (N stacked 
 
 Rank 0 prints ONE JSON line (contract in the task statement + `roofline` and `cpu_baseline`).
 
-`roofline`: the dominant kernel is k_tile_render.  It keeps the delta tile and the canvas tile on chip, so HBM is not what
-binds it; f64 VALU issue (and the per-item latency chain in front of it) is.  The block therefore reports, for the launch as
-timed live by HIP events in this run:
-  frac / bound "valu"   VALU wave-instructions per launch x 4 cycles / (1024 SIMDs x 2.4 GHz x t)  (SQ_INSTS_VALU, rocprofv3)
-  hbm.frac              measured HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) / t / 8 TB/s
-  hbm.floor_frac        bytes that must move (the canvas once + 32 B per edge) / t / 8 TB/s
-  effective_gbs         SURVEY 8d's algorithmic 40 B/path-pixel + 32 B/edge over t: a throughput figure, NOT a roofline
-                        fraction (the reference's memory passes are what it prices; this kernel never makes them)
+`roofline`: the dominant kernel is k_tile_render, timed live by HIP events on the library's stream.  It keeps the delta
+tile and the canvas tile on chip, so what has to cross HBM per launch is the finished canvas once plus the geometry it reads:
+  frac / achieved / peak   ALGORITHMIC floor over the launch time: max(t_hbm, t_f64) / t, where
+                           t_hbm = (canvas bytes + 32 B per edge) / 8 TB/s and
+                           t_f64 = (8 fma + 1 add) x visible path-pixels / 64 lanes x measured cycles per f64 wave-instruction
+                                   / (1024 SIMDs x clock)   (profiles/valu_issue_mi355x.json: profiles/valu_issue.hip on this chip;
+                                   the visible path-pixels come from the CPU oracle's census in the cpu_baseline leg)
+                           `bound` names the larger of the two; with "hbm" achieved = floor bytes / t in GB/s against 8000
+  traffic / hbm            measured HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)
+  issue_utilisation        how busy the VALU issue slots were: the executed instruction mix (counters) priced with the measured
+                           cycles per wave-instruction -- a utilisation, not a roofline fraction (executed, not algorithmic)
+  effective_gbs            SURVEY 8d's algorithmic 40 B/path-pixel + 32 B/edge over t: a throughput figure, NOT a roofline
+                           fraction (the reference's memory passes are what it prices; this kernel never makes them)
 Counter values come from the committed profiles/pmc_kernels_<workload>.json (profiles/collect2.sh, separate --pmc passes
-on the same command); `counters` names the file and the commit it was collected at -- they are not re-measured in this run.
+on the same command); `counters` names the file, the commit and whether the kernel source has changed since (`stale`).
+
+`parity` (N = 1, with the cpu_baseline leg): the canvas of the LAST timed step, downloaded after the clock has stopped, against
+the CPU oracle's canvas of the same scene under the float32 contract |got - f32(ref)| <= max(1 ULP, 2^-24): values, how many
+are outside it, largest error.
 """
 from __future__ import annotations
 
@@ -44,7 +53,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable copy)
-VALU_PEAK_GINST = 1024 * 2.4 / 4.0  # wave-instructions / ns: 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles, 2.4 GHz
+N_SIMD = 1024          # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4        # shader clock under load (profiles/valu_issue.hip reads 2405 s_memtime ticks per microsecond)
 BYTES_PER_PATH_PIXEL = 40  # read f64 trace 8 + read f32 RGBA 16 + write f32 RGBA 16
 BYTES_PER_EDGE = 32        # 4 doubles, read once
 
@@ -131,7 +141,8 @@ def bench_scene(args):
         "config": {"workload": desc, "canvas": [h, w]},
         "roofline": {"bound": "host", "note": "no kernel binds this configuration: the step is the Python tree walk plus hundreds of "
                      "latency-bound launches; per-kernel HBM rates of the streaming kernels below", "kernels": stream,
-                     "counters": {"file": counters_file, "collected_at_commit": counters.get("head"), "measured_in_this_run": False}
+                     "counters": {"file": counters_file, "collected_at_commit": counters.get("head"), "measured_in_this_run": False,
+                                  "stale": counters.get("source_sha256") != source_sha256()}
                      if counters is not None else None},
     }))
 
@@ -167,27 +178,49 @@ def cpu_baseline(sc, budget_paths: int | None = None):
     args = (pres.reshape(-1), np.ascontiguousarray(sc["seg_kind"][: off[-1]]), off, n,
             np.ascontiguousarray(sc["path_rule"][:n]), np.ascontiguousarray(sc["path_paint"][:n]).reshape(-1), vp, 1,
             canvas.reshape(-1), stats.ctypes.data_as(C.c_void_p))
+    # the render cut into row strips, one per thread, on this process's share of the host cores
+    threads = orc.host_threads()
+    t0 = time.perf_counter()
+    rc = L.orc_render_solid_strips(*args, threads, threads)
+    dt_mt = time.perf_counter() - t0
+    if rc != 0:
+        raise RuntimeError(f"oracle (strips) failed: {rc}")
+    P_mt = int(stats[0])
+    # ... and whole, on one thread (this canvas is the one the GPU's is checked against); an untimed census on the side counts
+    # the path-pixels that are visible at all (coverage not cut to zero, S:990): the composite's algorithmic work
+    canvas.fill(0.0)
     t0 = time.perf_counter()
     rc = L.orc_render_solid(*args)
     dt = time.perf_counter() - t0
     if rc != 0:
         raise RuntimeError(f"oracle failed: {rc}")
     P1 = int(stats[0])
-    # the same render cut into row strips, one per thread, on this process's share of the host cores
-    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
-    canvas.fill(0.0)
-    t0 = time.perf_counter()
+    ref_canvas = canvas.copy() if n == n_all else None
+    L.orc_visible_count(1)
     rc = L.orc_render_solid_strips(*args, threads, threads)
-    dt_mt = time.perf_counter() - t0
+    visible = int(L.orc_visible_get())
+    L.orc_visible_count(0)
     if rc != 0:
-        raise RuntimeError(f"oracle (strips) failed: {rc}")
-    return dict(
+        raise RuntimeError(f"oracle (census) failed: {rc}")
+    stats[0] = P_mt
+    return ref_canvas, visible if n == n_all else None, dict(
         value=round(P1 / dt / 1e6, 3), unit="Mpixels/s (path-pixels)", cores=1, kind="port",
         sample=f"first {n} of {n_all} paths of the same scene, full viewport, {dt:.2f} s, P={P1} "
                f"(oracle/svgr_oracle.c: pass-by-pass C restatement of the reference, float64, 1 thread of {os.cpu_count()})",
         all_cores_value=round(int(stats[0]) / dt_mt / 1e6, 3), all_cores=threads,
         all_cores_sample=f"same render as {threads} row strips (the reference's viewport cropping) on {threads} OpenMP threads, {dt_mt:.2f} s",
     )
+
+
+def source_sha256() -> str:
+    """sha256 of the kernel source: what the committed counter files are checked against (`counters.stale`)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("svgr_hip.hip", "svgr_core.h"):
+        with open(os.path.join(ROOT, "svgrasterize.py_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def load_counters(workload: str):
@@ -204,58 +237,113 @@ def load_counters(workload: str):
     return rec, os.path.relpath(path, ROOT)
 
 
-def roofline_block(tile_ms, geo_ms, n_timed, every, P_rank, E_rank, canvas_bytes, counters, counters_file, out_kind="f32"):
-    """The dominant kernel's launch, timed live (HIP events on the library's stream), against the limits that can bind it."""
+def load_issue_table():
+    """Measured cycles per VALU wave-instruction per SIMD on this chip (profiles/valu_issue.hip -> profiles/valu_issue_mi355x.json)."""
+    path = os.path.join(ROOT, "profiles", "valu_issue_mi355x.json")
+    try:
+        t = json.load(open(path))["cycles_per_wave_instruction_per_simd"]
+        at4 = {k: float(v["4_waves_per_simd"]) for k, v in t.items()}
+        return at4, os.path.relpath(path, ROOT)
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
+def roofline_block(tile_ms, geo_ms, n_timed, every, P_rank, E_rank, canvas_bytes, counters, counters_file, visible=None,
+                   out_kind="f32"):
+    """The dominant kernel's launch, timed live (HIP events on the library's stream), against its ALGORITHMIC floors:
+    the bytes that have to cross HBM (the finished canvas once + 32 B per edge) at 8 TB/s, and the composite's double
+    arithmetic (8 fma + 1 add per visible path-pixel) at the measured f64 issue rate.  frac = the larger floor / t."""
     t = tile_ms * 1e-3
     alg_bytes = BYTES_PER_PATH_PIXEL * P_rank + BYTES_PER_EDGE * E_rank
     floor_bytes = canvas_bytes + BYTES_PER_EDGE * E_rank
+    t_hbm = floor_bytes / (HBM_PEAK_GBS * 1e9)
+    issue, issue_file = load_issue_table()
+    c64 = issue["v_fma_f64"] if issue else 4.0       # cycles per f64 wave-instruction per SIMD (4 waves per SIMD)
+    t_f64 = None
+    if visible:
+        t_f64 = 9.0 * visible / 64.0 * c64 / (N_SIMD * CLOCK_GHZ * 1e9)
     kern = None
     if counters is not None:  # (the production instantiation: float32 canvas, no clip tile; further template arguments vary)
         kern = next((v for k, v in counters["kernels"].items() if k.startswith("k_tile_render<0, false")), None)
     valu = kern.get("SQ_INSTS_VALU") if kern else None
     traffic = kern.get("hbm_bytes_per_launch") if kern else None
+    bound_f64 = t_f64 is not None and t_f64 > t_hbm
     block = {
         "kernel": f"k_tile_render<{out_kind}>",
         "avg_launch_ms": round(tile_ms, 4), "geometry_ms": round(geo_ms, 4), "launches_timed": int(n_timed),
         "timing": "HIP events on the library's stream around every %d-th launch of the timed region (rank 0)" % every,
-        "hbm": {
-            "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "achieved": round(traffic / t / 1e9, 1) if traffic and t > 0 else None,
-            "frac": round(traffic / t / 1e9 / HBM_PEAK_GBS, 4) if traffic and t > 0 else None,
-            "traffic": traffic,
-            "floor_bytes": int(floor_bytes),
-            "floor_frac": round(floor_bytes / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None,
-            "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 --pmc, separate passes; gfx950 counts wide "
-                    "streaming reads at half their bytes); floor = the canvas written once + 32 B per edge: what has to move",
-        },
-        "effective_gbs": round(alg_bytes / t / 1e9, 1) if t > 0 else None,
-        "algorithmic_bytes_per_launch": int(alg_bytes),
-        "traffic": traffic,
     }
-    if valu and t > 0:
-        achieved = valu / t / 1e9  # G wave-instructions / s
-        block.update({
-            "bound": "valu", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G VALU wave-instructions/s",
-            "frac": round(achieved / VALU_PEAK_GINST, 4),
-            "valu_wave_instructions_per_launch": int(valu),
-        })
-        note = ("bound: f64 VALU issue (every VALU wave-instruction holds its SIMD for 4 cycles; 1024 SIMDs x 2.4 GHz / 4 = "
-                "614.4 G/s) -- the kernel keeps the delta tile and the canvas tile on chip, HBM carries a fraction of its peak "
-                "(hbm.frac).  `effective_gbs` prices SURVEY 8d's 40 B/path-pixel + 32 B/edge, a throughput figure.")
+    if t > 0 and not bound_f64:
+        block.update({"bound": "hbm", "achieved": round(floor_bytes / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(t_hbm / t, 4)})
+    elif t > 0:
+        ginst = 9.0 * visible / 64.0 / t / 1e9
+        block.update({"bound": "f64-issue", "achieved": round(ginst, 1), "peak": round(N_SIMD * CLOCK_GHZ / c64, 1),
+                      "unit": "G f64 wave-instructions/s", "frac": round(t_f64 / t, 4)})
+    block["traffic"] = traffic
+    block["floor"] = {
+        "hbm_bytes": int(floor_bytes), "hbm_ms": round(t_hbm * 1e3, 4),
+        "f64_ms": round(t_f64 * 1e3, 4) if t_f64 is not None else None, "visible_path_pixels": visible,
+        "f64_cycles_per_wave_instruction": c64, "issue_table": issue_file,
+        "note": "hbm: the canvas written once + 32 B per edge at 8 TB/s; f64: (8 fma + 1 add) per visible path-pixel / 64 lanes x "
+                "measured cycles per f64 wave-instruction / (1024 SIMDs x 2.4 GHz).  frac = max of the two / launch time",
+    }
+    block["hbm"] = {
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic,
+        "achieved": round(traffic / t / 1e9, 1) if traffic and t > 0 else None,
+        "frac": round(traffic / t / 1e9 / HBM_PEAK_GBS, 4) if traffic and t > 0 else None,
+        "note": "measured: 2 x FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 --pmc, separate passes; gfx950 counts wide streaming "
+                "reads at half their bytes)",
+    }
+    if valu and t > 0 and issue:
+        f64n = sum(kern.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
+        have_mix = f64n > 0
+        c32 = issue["v_add_u32"]
+        cyc_avail = N_SIMD * CLOCK_GHZ * 1e9 * t
+        block["issue_utilisation"] = {
+            "valu_wave_instructions_per_launch": int(valu), "f64_wave_instructions_per_launch": int(f64n) if have_mix else None,
+            "low": round(((f64n * c64 + (valu - f64n) * c32) if have_mix else valu * c32) / cyc_avail, 4),
+            "high": round(valu * c64 / cyc_avail, 4),
+            "note": "executed VALU wave-instructions x measured cycles per wave-instruction / (1024 SIMDs x 2.4 GHz x t): `high` prices "
+                    "every instruction like an f64 / VOP3 / DPP one (%.2f cycles), `low` the non-f64 ones like a VOP2 add (%.2f); a "
+                    "utilisation of the issue slots by what was executed, not an algorithmic fraction" % (c64, c32),
+        }
+    block["effective_gbs"] = round(alg_bytes / t / 1e9, 1) if t > 0 else None
+    block["algorithmic_bytes_per_launch"] = int(alg_bytes)
+    if counters is not None:
+        sha = counters.get("source_sha256")
+        block["counters"] = {
+            "file": counters_file, "collected_at_commit": counters.get("head"), "measured_in_this_run": False,
+            "stale": (sha != source_sha256()) if sha else True,
+            "of": ("rank 0 of the same N-way sharding, rendered alone on one GPU (profiles/collect_rank.sh)"
+                   if "_w" in str(counters.get("workload")) else "this workload on one GPU (profiles/collect2.sh)"),
+        }
+        if block["counters"]["stale"]:
+            block["counters"]["note"] = "the kernel source has changed since the counters were collected: counter-derived fields describe an older build"
     else:
-        # no counter file for this workload / sharding: the only fraction that needs none is the HBM floor
-        block.update({
-            "bound": "hbm", "achieved": round(floor_bytes / t / 1e9, 1) if t > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(floor_bytes / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None,
-        })
-        note = ("no committed counter file for this workload / sharding: frac = the bytes that must move (canvas + 32 B/edge) "
-                "over the live launch time against the HBM peak; the kernel's own limit is VALU issue (see the N = 1 line)")
-    block["counters"] = ({"file": counters_file, "collected_at_commit": counters.get("head"), "measured_in_this_run": False,
-                          "of": ("rank 0 of the same N-way sharding, rendered alone on one GPU (profiles/collect_rank.sh)"
-                                 if "_w" in str(counters.get("workload")) else "this workload on one GPU (profiles/collect2.sh)")}
-                         if counters is not None else None)
-    block["note"] = note
+        block["counters"] = None
     return block
+
+
+def contract_counts(got32, ref64):
+    """Values of the float32 canvas `got32` outside |got - f32(ref)| <= max(1 ULP_f32(ref), 2^-24), by row blocks."""
+    import numpy as np
+
+    n = bad = 0
+    max_err = 0.0
+    rows = got32.shape[0]
+    for r0 in range(0, rows, 256):
+        g = got32[r0:r0 + 256].astype(np.float64)
+        r32 = ref64[r0:r0 + 256].astype(np.float32)
+        a = np.abs(r32)
+        ulp = np.maximum((np.nextafter(a, np.float32(np.inf)) - a).astype(np.float64), 2.0 ** -24)
+        err = np.abs(g - r32.astype(np.float64))
+        n += err.size
+        bad += int((err > ulp).sum())
+        max_err = max(max_err, float(err.max(initial=0.0)))
+    return {"values": n, "bad": bad, "max_err": max_err,
+            "contract": "|got - f32(ref)| <= max(1 ULP_f32(ref), 2^-24), ref = CPU oracle (f64) of the same scene, whole canvas",
+            "what": "canvas of the last timed step, downloaded after the clock stopped"}
 
 
 def main():
@@ -304,7 +392,7 @@ def main():
             args.steps = 20  # (tens of milliseconds per step)
         return bench_scene(args)
 
-    import numpy as np  # noqa: F401
+    import numpy as np
 
     import svgrasterize_amd as S
     from svgrasterize_amd import _abi, synth
@@ -411,6 +499,9 @@ def main():
             del full_t
         except Exception as exc:  # noqa: BLE001
             extras["all_gather_ms"] = {"error": repr(exc)}
+    got_canvas = None
+    if world == 1 and not args.no_cpu_baseline and not args.cpu_paths:
+        got_canvas = out.download((own_rows, cols, 4), np.float32)  # (the last timed step's canvas; the clock has stopped)
     del out
     out_t = None
 
@@ -492,11 +583,15 @@ def main():
             "data": "synthetic" if args.workload.startswith("synth") else "real asset (scene dump)",
             "config": config,
             "canvas_mpixels_per_s": round(canvas_px / (t_max / args.steps) / 1e6, 1),
-            "roofline": roofline_block(tile_ms, geo_ms, tm["n"], every, P_rank, E_rank, own_rows * cols * 16, counters, counters_file),
         }
-        line.update(extras)
+        visible = None
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sc, args.cpu_paths)
+            ref_canvas, visible, line["cpu_baseline"] = cpu_baseline(sc, args.cpu_paths)
+            if got_canvas is not None and ref_canvas is not None:
+                line["parity"] = contract_counts(got_canvas, ref_canvas)
+        line["roofline"] = roofline_block(tile_ms, geo_ms, tm["n"], every, P_rank, E_rank, own_rows * cols * 16, counters, counters_file,
+                                          visible=visible)
+        line.update(extras)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define SVGR_ABI_VERSION 1
+/* 2: svgr_batch_set_groups, svgr_batch_set_gradients, svgr_batch_plan_many, svgr_batch_render_window added; svgr_gradient.n_stops
+ *    no longer capped at 32; SVGR_RENDER_DETERMINISTIC */
+#define SVGR_ABI_VERSION 2
 
 typedef enum {
     SVGR_OK = 0,
@@ -69,6 +71,11 @@ typedef struct svgr_batch svgr_batch;
 /* flags of svgr_batch_render */
 #define SVGR_RENDER_CLIP01 1u  /* clip RGBA to [0, 1] on store (canvas_merge_at, S:326) */
 #define SVGR_RENDER_TIMED 2u   /* bracket the stages with HIP events (svgr_batch_timings) */
+/* Bit-reproducible output: the reference's np.cumsum (S:983) adds a row's pieces in one fixed order; the default render
+ * adds them in whatever order the LDS atomics of several waves land (results differ in the last bits of a double, i.e.
+ * in float32 rounding ties).  With this flag one wave per workgroup does every accumulation, in list order: two
+ * renders of the same batch are bit-identical, at roughly half the speed of the geometry and scatter phases. */
+#define SVGR_RENDER_DETERMINISTIC 4u
 
 /* -------------------------------------------------------------------------------------------- */
 /* context + device memory                                                                      */

@@ -55,6 +55,10 @@ def lib():
     L.orc_render_solid_strips.argtypes = [_f64p, _u8p, _i64p, C.c_int64, _u8p, _f64p, _i64p, C.c_int, _f64p, C.c_void_p,
                                           C.c_int, C.c_int]
     L.orc_render_solid_strips.restype = C.c_int
+    L.orc_visible_count.argtypes = [C.c_int]
+    L.orc_visible_count.restype = None
+    L.orc_visible_get.argtypes = []
+    L.orc_visible_get.restype = C.c_int64
     _lib = L
     return L
 
@@ -217,17 +221,31 @@ def compose_in(layers):
     return out, (r0, c0)
 
 
-def render_solid(segs, seg_kind, path_seg_off, path_rule, path_paint, viewport, clip01=True):
-    """Whole solid-fill scene on the CPU. Returns (canvas f64 (rows, cols, 4), P, E)."""
+def render_solid(segs, seg_kind, path_seg_off, path_rule, path_paint, viewport, clip01=True, strips=1, threads=1):
+    """Whole solid-fill scene on the CPU. Returns (canvas f64 (rows, cols, 4), P, E).
+    strips > 1: the canvas as that many row strips, each an independent render through the reference's own viewport
+    cropping (S:968-971), on `threads` OpenMP threads (E is not counted then: 0)."""
     vp = _c(viewport, np.int64)
     canvas = np.zeros((int(vp[2]), int(vp[3]), 4))
     stats = np.zeros(2, dtype=np.int64)
-    rc = lib().orc_render_solid(_c(segs).reshape(-1), _c(seg_kind, np.uint8), _c(path_seg_off, np.int64),
-                                len(path_seg_off) - 1, _c(path_rule, np.uint8), _c(path_paint).reshape(-1), vp,
-                                int(clip01), canvas.reshape(-1), stats.ctypes.data_as(C.c_void_p))
+    args = (_c(segs).reshape(-1), _c(seg_kind, np.uint8), _c(path_seg_off, np.int64), len(path_seg_off) - 1,
+            _c(path_rule, np.uint8), _c(path_paint).reshape(-1), vp, int(clip01), canvas.reshape(-1),
+            stats.ctypes.data_as(C.c_void_p))
+    if strips > 1:
+        rc = lib().orc_render_solid_strips(*args, int(strips), int(max(1, threads)))
+    else:
+        rc = lib().orc_render_solid(*args)
     if rc != 0:
         raise RuntimeError(f"orc_render_solid failed: {rc}")
     return canvas, int(stats[0]), int(stats[1])
+
+
+def host_threads(limit=16):
+    """This process's share of the host cores, capped (the strips of a render are independent: one thread each)."""
+    import os
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(limit, n))
 
 
 # --------------------------------------------------------------------------------------

@@ -407,6 +407,12 @@ ORC_API void orc_compose_in(double *dst, const int64_t *dst_off, int64_t dr, int
 /* stats (optional, 2 x int64): path-pixels P and flattened edges E                    */
 /* returns 0 or a negative error                                                       */
 /* ---------------------------------------------------------------------------------- */
+/* Optional census for bench.py's roofline block: how many path-pixels are visible (coverage != 0 after the cut). */
+static int g_count_visible = 0;
+static int64_t g_visible = 0;
+ORC_API void orc_visible_count(int enable) { g_count_visible = enable; g_visible = 0; }
+ORC_API int64_t orc_visible_get(void) { return g_visible; }
+
 ORC_API int orc_render_solid(const double *segs, const uint8_t *seg_kind, const int64_t *path_seg_off, int64_t n_paths,
                              const uint8_t *path_rule, const double *path_paint, const int64_t *viewport,
                              int clip01, double *canvas, int64_t *stats)
@@ -459,6 +465,12 @@ ORC_API int orc_render_solid(const double *segs, const uint8_t *seg_kind, const 
             if (!mask || !rgba) { rc = -2; break; }
         }
         orc_mask(edges, ne, bb, bb[2], bb[3], path_rule[p], mask);
+        if (g_count_visible) { /* bench.py only: path-pixels whose coverage survives the 1e-6 cut (S:990) */
+            int64_t nv = 0;
+            for (int64_t i = 0; i < npx; ++i) nv += mask[i] != 0.0;
+#pragma omp atomic
+            g_visible += nv;
+        }
         orc_fill_solid(mask, npx, path_paint + 4 * p, rgba);
         orc_compose_over(canvas, viewport, viewport[2], viewport[3], rgba, bb, bb[2], bb[3], 4, 0);
     }

@@ -4,6 +4,7 @@
 #   gpurun_out/<tag>/kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command
 #   gpurun_out/<tag>/pmc_sq.csv          --pmc pass 1: SQ instruction / cycle counters + GRBM_GUI_ACTIVE (clock)
 #   gpurun_out/<tag>/pmc_fetch.csv, pmc_write.csv   --pmc passes 2, 3: FETCH_SIZE, WRITE_SIZE (they do not fit one pass)
+#   gpurun_out/<tag>/pmc_mix.csv         --pmc pass 4: the f64 / int32 split of the VALU instructions
 #   gpurun_out/<tag>/pmc_kernels.json    per kernel: average counters per launch (profiles/pmc_json.py); bench.py reads the
 #                                        copy committed as profiles/pmc_kernels_<workload>.json for its roofline block
 # Counter passes carry --kernel-trace only (no other trace domain).  Copy what should be judged into profiles/<round>/.
@@ -21,10 +22,12 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/pf -o pf -- python3 bench.p
 cp $(find $o/pf -name "*counter_collection.csv" | head -1) $o/pmc_fetch.csv
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pw -o pw -- python3 bench.py --workload $wl --no-cpu-baseline --steps 10 --warmup 2 > $o/pw.log 2>&1 || exit 1
 cp $(find $o/pw -name "*counter_collection.csv" | head -1) $o/pmc_write.csv
-rm -rf $o/kt $o/pf $o/pw $o/ps
+rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT32 --output-format csv -d $o/pm -o pm -- python3 bench.py --workload $wl --no-cpu-baseline --steps 10 --warmup 2 > $o/pm.log 2>&1 || exit 1
+cp $(find $o/pm -name "*counter_collection.csv" | head -1) $o/pmc_mix.csv
+rm -rf $o/kt $o/pf $o/pw $o/ps $o/pm
 python3 profiles/pmc_json.py $wl $o > $o/pmc_kernels.json
 # (scene workloads dispatch thousands of kernels: the raw per-dispatch tables would not fit the 64 MiB that travel back)
-for f in $o/pmc_sq.csv $o/pmc_sq_trace.csv $o/pmc_fetch.csv $o/pmc_write.csv; do [ $(stat -c %s $f) -gt 4000000 ] && rm -f $f; done
+for f in $o/pmc_sq.csv $o/pmc_sq_trace.csv $o/pmc_fetch.csv $o/pmc_write.csv $o/pmc_mix.csv; do [ $(stat -c %s $f) -gt 4000000 ] && rm -f $f; done
 cat $o/pmc_kernels.json
 cut -c1-140 $o/kernel_stats.csv | head -10
 cat $o/bench.json

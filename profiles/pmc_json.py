@@ -27,7 +27,7 @@ def counters(path):
 def main():
     wl, d = sys.argv[1], sys.argv[2]
     out = defaultdict(dict)
-    for f in ("pmc_sq.csv", "pmc_fetch.csv", "pmc_write.csv"):
+    for f in ("pmc_sq.csv", "pmc_fetch.csv", "pmc_write.csv", "pmc_mix.csv"):
         for k, cs in counters(os.path.join(d, f)).items():
             for c, v in cs.items():
                 out[k][c] = round(sum(v) / len(v), 1)
@@ -55,7 +55,14 @@ def main():
         head = head or subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:  # noqa: BLE001  (the GPU box has no .git)
         head = None
-    print(json.dumps({"workload": wl, "collected_by": "profiles/collect2.sh", "head": head,
+    # what the counters were collected FROM: bench.py compares this with the tree it runs in (`counters.stale`)
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("svgr_hip.hip", "svgr_core.h"):
+        with open(os.path.join(root, "svgrasterize.py_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    print(json.dumps({"workload": wl, "collected_by": "profiles/collect2.sh", "head": head, "source_sha256": h.hexdigest(),
                       "units": "FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them; SQ_* raw; *_ns nanoseconds",
                       "kernels": out}, indent=1))
 

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libsvgr_hip.so")
 
 OUT_CANVAS_F32, OUT_CANVAS_F64, OUT_MASK_F64, OUT_FILL_F64, OUT_MASKS_F64 = 0, 1, 2, 3, 4
-RENDER_CLIP01, RENDER_TIMED = 1, 2
+RENDER_CLIP01, RENDER_TIMED, RENDER_DETERMINISTIC = 1, 2, 4
 SEG_LINE, SEG_CUBIC = 0, 1
 
 CONVERT_PRE_TO_STRAIGHT, CONVERT_SRGB_TO_LINEAR, CONVERT_LINEAR_TO_SRGB, CONVERT_STRAIGHT_TO_PRE = 1, 2, 4, 8
@@ -361,6 +361,12 @@ class Batch:
     def set_paints(self, paints):
         paints = np.ascontiguousarray(paints, dtype=np.float64).reshape(self.n_paths, 4)
         _check(self.ctx.lib.svgr_batch_set_paints(self.handle, paints.ctypes.data_as(_P)))
+
+    def set_transforms(self, path_m6):
+        """New transforms for the same geometry (svgr_batch_set_transforms): the plan is void until plan() runs again."""
+        m6 = np.ascontiguousarray(path_m6, dtype=np.float64).reshape(self.n_paths, 6)
+        _check(self.ctx.lib.svgr_batch_set_transforms(self.handle, m6.ctypes.data_as(_P)))
+        self._stats = None
 
     def owned_rows(self) -> int:
         return int(self.ctx.lib.svgr_batch_owned_rows(self.handle))

@@ -741,7 +741,7 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
                                                   int vr0, int vc0, int vrows, int vcols, int* __restrict__ bbox,
                                                   PathBin* __restrict__ bins, BatchDev* __restrict__ bd, int stats,
                                                   const int* __restrict__ plist, Slab* __restrict__ slabs, int slab_cap, Owner own,
-                                                  const int* __restrict__ path_seg0, const int* __restrict__ seg_off) {
+                                                  const int* __restrict__ path_seg0, const int* __restrict__ seg_off, int edge_cap) {
     // (multi-GPU: thread i takes the i-th path of this rank's list, n_paths = its length; the others keep the empty bbox
     //  and bins the plan gave them)
     const int pi = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
@@ -825,10 +825,19 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
     const int slab0 = wave_alloc(&bd->slab_cursor, n_slabs, lane);
     if (slabs && n_slabs > 0) {
         if (slab0 + n_slabs > slab_cap) {
+            // (the launch covers the capacity: what this path would have filled of it must not be followed)
             atomicOr(&bd->err, 4);
+            for (int at = slab0; at < slab_cap; ++at) {
+                Slab sl;
+                memset(&sl, 0, sizeof sl);
+                slabs[at] = sl;
+            }
         } else {
             int at = slab0;
-            const int e_begin = seg_off[path_seg0[p]], e_end = seg_off[path_seg0[p + 1]];  // the path's edges (k_flatten)
+            // the path's edges (k_flatten); a pass whose edge array was too small (flagged there) must not be read beyond it
+            int e_begin = seg_off[path_seg0[p]], e_end = seg_off[path_seg0[p + 1]];
+            e_begin = e_begin < edge_cap ? e_begin : edge_cap;
+            e_end = e_end < edge_cap ? e_end : edge_cap;
             for (int bb = 0; bb < pnb; bb += bands_per) {
                 const int be = bb + bands_per < pnb ? bb + bands_per : pnb;
                 if (!owns_any(own, pb0 + bb, pb0 + be - 1)) continue;
@@ -1129,7 +1138,8 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                                                            const int* __restrict__ path_grad, int vr0, int vc0, int n_ct, int mask_words,
                                                            unsigned long long* __restrict__ tile_mask, CellHdr* __restrict__ cell_hdr,
                                                            int cell_cap, const AddShards ash, TileAdd* __restrict__ adds,
-                                                           BatchDev* __restrict__ bd, Owner own, int stats, unsigned long long* __restrict__ dbg) {
+                                                           BatchDev* __restrict__ bd, Owner own, int stats, int det,
+                                                           unsigned long long* __restrict__ dbg) {
 #ifdef SVGR_DBG_PB_STAMP
 #define PB_STAMP(i) do { if (threadIdx.x == 0 && dbg && blockIdx.x < 8192) dbg[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -1149,6 +1159,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x >= bd->slab_cursor) return;  // (the grid covers the plan's slab capacity)
     const Slab sl = slabs[blockIdx.x];
+    if (sl.nb <= 0 || sl.nk <= 0) return;  // (a slot of a path that did not fit the slab list: flagged by k_path_bbox)
     const int p = sl.p;
     const int r0 = sl.r0, c0 = sl.c0, rows = sl.rows, cols = sl.cols;
     int ct0, nct;
@@ -1338,7 +1349,11 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     };
 
     // ---- pass A ----  (a path of up to PB_BATCH edges is staged once, and its first PB_KEEP rounds of rows stay in registers)
+    // (SVGR_RENDER_DETERMINISTIC: the first wave alone takes the rows, in order -- every sum and every list is then filled in the
+    //  same order from render to render)
+    const int t_first = det ? (tid < 64 ? tid : 0x7fffffff) : tid, t_step = det ? 64 : PB_THREADS;
     const bool one_batch = e_end - e_begin <= PB_BATCH;
+    const bool keep = one_batch && !det;
     RowAt kept[PB_KEEP];
     int total = 0, n_rows = 0;
     for (int eb = e_begin; eb < e_end; eb += PB_BATCH) {
@@ -1348,8 +1363,8 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
 #ifdef SVGR_DBG_PB_NOTASK
         total = 0;
 #endif
-        int t = tid;
-        if (one_batch) {
+        int t = t_first;
+        if (keep) {
 #pragma unroll
             for (int r = 0; r < PB_KEEP; ++r, t += PB_THREADS) {
                 if (t < total) {
@@ -1358,7 +1373,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                 }
             }
         }
-        for (; t < total; t += PB_THREADS) count_row(row_of(t));
+        for (; t < total; t += t_step) count_row(row_of(t));
     }
     if (stats && tid == 0 && n_rows > 0) atomicAdd(&bd->bseg_cursor, n_rows);  // (plan only: edge rows of the batch)
     __syncthreads();
@@ -1442,7 +1457,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             if (cls == 0 || !owns_band(own, band)) continue;
             const int cell = sl.cell_off + (band - sl.b0) * nct + sl.k0 + k;
             const int idx = s_pidx[g];
-            const bool mask_ok = (idx >> 6) < mask_words;  // (the plan sized the masks from the longest band list)
+            const bool mask_ok = (unsigned)(idx >> 6) < (unsigned)mask_words;  // (the plan sized the masks from the longest band list)
             if (!(cell < cell_cap && slab_ok && mask_ok)) {
                 if (row_l == 0) atomicOr(&bd->err, 32);
                 continue;
@@ -1490,15 +1505,17 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     return;
 #endif
     if (one_batch) {
-        int t = tid;
+        int t = t_first;
+        if (keep) {
 #pragma unroll
-        for (int r = 0; r < PB_KEEP; ++r, t += PB_THREADS)
-            if (t < total) emit_row(kept[r]);
-        for (; t < total; t += PB_THREADS) emit_row(row_of(t));  // (the batch is still staged)
+            for (int r = 0; r < PB_KEEP; ++r, t += PB_THREADS)
+                if (t < total) emit_row(kept[r]);
+        }
+        for (; t < total; t += t_step) emit_row(row_of(t));  // (the batch is still staged)
     } else {
         for (int eb = e_begin; eb < e_end; eb += PB_BATCH) {
             const int tot = stage(eb);
-            for (int t = tid; t < tot; t += PB_THREADS) emit_row(row_of(t));
+            for (int t = t_first; t < tot; t += t_step) emit_row(row_of(t));
         }
     }
     PB_STAMP(5);
@@ -1798,6 +1815,7 @@ struct TileArgs {
     Owner own;                   // owned bands
     int out_cols;                // row pitch of `out` in pixels
     int clip01;
+    int det;                     // SVGR_RENDER_DETERMINISTIC: the first wave alone scatters, in list order
     const long long* layer_off;  // mask / fill outputs of several paths: per path the offset (in pixels) of its layer in `out`
     unsigned* arena;             // the batch's counter arena: zeroed here (all but its first word, the sticky error flags) for
     unsigned arena_words;        // the NEXT render, which then needs no memset launch in front of its flatten (0: leave it)
@@ -1945,9 +1963,11 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
         return;
 #endif
         if (hdr_cls(h) != 2) return;
+        if (a.det && wave != 0) return;
         const int n_add = __builtin_amdgcn_readlane(h, 13), add0 = __builtin_amdgcn_readlane(h, 14);
         unsigned char* const base = s_mem + buf * DELTA_BYTES;
-        for (int i = tid; i < n_add; i += NT) {
+        const int i_step = a.det ? 64 : NT;
+        for (int i = tid; i < n_add; i += i_step) {
             unsigned w = (unsigned)first_w;
             double v = first_v;
             if (i != tid) {
@@ -2782,6 +2802,7 @@ struct svgr_batch {
     AddShards add_shards{};                 // where each shard's add slots live (the slabs of path p reserve in shard p % n)
     int64_t n_adds = 0;                     // add slots in all the shards
     bool count_adds_only = false;           // the plan's measuring run: k_path_build sizes the add lists, writes none
+    bool deterministic = false;             // this pass runs for a SVGR_RENDER_DETERMINISTIC render
     // lay the add shards back to back: `need[k]` slots each plus slack (the sizes repeat from render to render except for
     // carry-ins that are exactly zero in one summation order and not in another)
     int size_adds(const int* need, int n_shards) {
@@ -2910,17 +2931,20 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
         if (upto == 0)  // bboxes only (no edges stored): enough to find the union when there is no viewport
             hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(),
                                np_walk, use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), 1, plist,
-                               (Slab*)nullptr, 0, b->own, (const int*)nullptr, (const int*)nullptr);
+                               (Slab*)nullptr, 0, b->own, (const int*)nullptr, (const int*)nullptr, 0);
         return 0;
     }
     if (ns > 0)
         hipLaunchKernelGGL(k_flatten<true>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                            (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
                            b->edges.p, b->edge_path.p, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
-                           n_bands_vp, prow, seg_list, n_items, (int*)nullptr, (const int*)b->seg_off.p, cap_i32(b->edge_path.cap));
+                           n_bands_vp, prow, seg_list, n_items, (int*)nullptr, (const int*)b->seg_off.p,
+                           cap_i32(std::min(b->edge_path.cap, b->edges.cap / 4)));
     hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np_walk,
                        use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), b->planned ? 0 : 1, plist,
-                       upto >= 3 ? b->slabs.p : (Slab*)nullptr, cap_i32(b->slabs.cap), b->own, (const int*)b->path_seg0.p, (const int*)b->seg_off.p);
+                       upto >= 3 ? b->slabs.p : (Slab*)nullptr, (int)std::min<int64_t>(cap_i32(b->slabs.cap), b->n_slabs) /* = k_path_build's grid */, b->own,
+                       (const int*)b->path_seg0.p, (const int*)b->seg_off.p,
+                       cap_i32(std::min(b->edge_path.cap, b->edges.cap / 4)));
     if (upto == 2) return 0;
     // per owned band: its list of (path, band) pairs in paint order, and its first tile-list slot
     const int owned = count_owned_bands(b->own, b->n_bands);
@@ -2952,7 +2976,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                            b->n_groups > 0 ? (const int*)b->path_group.p : (const int*)nullptr,
                            b->n_grads > 0 ? (const int*)b->path_grad.p : (const int*)nullptr, b->vp[0], b->vp[1], b->n_ctiles(), b->mask_words,
                            b->tile_mask.p, b->cell_hdr.p, cap_i32(b->cell_hdr.cap), b->add_shards,
-                           b->count_adds_only ? (TileAdd*)nullptr : b->adds.p, b->bd(), b->own, b->planned ? 0 : 1, pb_dbg);
+                           b->count_adds_only ? (TileAdd*)nullptr : b->adds.p, b->bd(), b->own, b->planned ? 0 : 1, b->deterministic ? 1 : 0, pb_dbg);
 #ifdef SVGR_DBG_PB_STAMP
         if (pb_dbg && b->planned && !b->count_adds_only) {
             static int n_dump = 0;
@@ -3359,51 +3383,53 @@ int svgr_batch_set_bands(svgr_batch* b, int rank, int world, int strip_bands) {
 // in front of its first member) and / or by its opacity, and composited OVER the canvas as a whole.
 int svgr_batch_set_groups(svgr_batch* b, const int32_t* path_group, int64_t n_groups, const int32_t* group_clip_src,
                           const double* group_opacity) {
-    if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
-    if (n_groups == 0) { b->n_groups = 0; b->geometry_fresh = false; return 0; }
-    if (n_groups < 0 || n_groups > b->n_paths || !path_group || !group_clip_src || !group_opacity)
-        return fail(SVGR_E_INVALID, "svgr_batch_set_groups: bad arguments");
-    std::vector<int64_t> first((size_t)n_groups, -1), last((size_t)n_groups, -1);
-    for (int64_t p = 0; p < b->n_paths; ++p) {
-        const int g = path_group[p];
-        if (g < -1 || g >= n_groups) return fail(SVGR_E_INVALID, "path %lld: group %d out of range", (long long)p, g);
-        if (g < 0) continue;
-        if (b->host_rule[(size_t)p] & (SVGR_PATH_CLIP_SOURCE | SVGR_PATH_CLIPPED))
-            return fail(SVGR_E_INVALID, "path %lld: a group member cannot be a clip source or a clipped path itself", (long long)p);
-        if (first[(size_t)g] < 0) first[(size_t)g] = p;
-        else if (last[(size_t)g] != p - 1) return fail(SVGR_E_INVALID, "group %d: members must be consecutive paths", g);
-        last[(size_t)g] = p;
-    }
-    for (int64_t g = 0; g < n_groups; ++g) {
-        if (first[(size_t)g] < 0) return fail(SVGR_E_INVALID, "group %lld has no member", (long long)g);
-        const int cs = group_clip_src[g];
-        if (cs != -1 && (cs != first[(size_t)g] - 1 || !(b->host_rule[(size_t)cs] & SVGR_PATH_CLIP_SOURCE)))
-            return fail(SVGR_E_INVALID, "group %lld: its clip source must be the path right in front of its first member", (long long)g);
-        if (!std::isfinite(group_opacity[g])) return fail(SVGR_E_INVALID, "group %lld: opacity is not finite", (long long)g);
-    }
-    HIPCHK(enter_ctx(b->ctx));
-    {
-        // one host blob -> one device block (three small pageable copies cost more than the data); the arrays are the
-        // caller's: the upload reads the copy the batch keeps
-        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-        const size_t np = (size_t)b->n_paths, ng = (size_t)n_groups;
-        const size_t o_pg = 0, o_cs = al(o_pg + np * 4), o_op = al(o_cs + ng * 4), total = al(o_op + ng * 8);
-        std::vector<char> blob(total, 0);
-        memcpy(blob.data() + o_pg, path_group, np * 4);
-        memcpy(blob.data() + o_cs, group_clip_src, ng * 4);
-        memcpy(blob.data() + o_op, group_opacity, ng * 8);
-        b->path_group.release(); b->group_clip_src.release(); b->group_opacity.release();
-        if (int rc = b->groups_dev.ensure(total)) return rc;
-        b->path_group.point_at(b->groups_dev.p, o_pg, np);
-        b->group_clip_src.point_at(b->groups_dev.p, o_cs, ng);
-        b->group_opacity.point_at(b->groups_dev.p, o_op, ng);
-        hipStream_t st = b->ctx->stream;
-        HIPCHK(hipMemcpyAsync(b->groups_dev.p, b->keep(blob.data(), total), total, hipMemcpyHostToDevice, st));
-        HIPCHK(b->note_upload(st));
-    }
-    b->n_groups = n_groups;
-    b->geometry_fresh = false;  // the cell headers carry the group ids
-    return 0;
+    return abi_guard("svgr_batch_set_groups", [&]() -> int {
+        if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
+        if (n_groups == 0) { b->n_groups = 0; b->geometry_fresh = false; return 0; }
+        if (n_groups < 0 || n_groups > b->n_paths || !path_group || !group_clip_src || !group_opacity)
+            return fail(SVGR_E_INVALID, "svgr_batch_set_groups: bad arguments");
+        std::vector<int64_t> first((size_t)n_groups, -1), last((size_t)n_groups, -1);
+        for (int64_t p = 0; p < b->n_paths; ++p) {
+            const int g = path_group[p];
+            if (g < -1 || g >= n_groups) return fail(SVGR_E_INVALID, "path %lld: group %d out of range", (long long)p, g);
+            if (g < 0) continue;
+            if (b->host_rule[(size_t)p] & (SVGR_PATH_CLIP_SOURCE | SVGR_PATH_CLIPPED))
+                return fail(SVGR_E_INVALID, "path %lld: a group member cannot be a clip source or a clipped path itself", (long long)p);
+            if (first[(size_t)g] < 0) first[(size_t)g] = p;
+            else if (last[(size_t)g] != p - 1) return fail(SVGR_E_INVALID, "group %d: members must be consecutive paths", g);
+            last[(size_t)g] = p;
+        }
+        for (int64_t g = 0; g < n_groups; ++g) {
+            if (first[(size_t)g] < 0) return fail(SVGR_E_INVALID, "group %lld has no member", (long long)g);
+            const int cs = group_clip_src[g];
+            if (cs != -1 && (cs != first[(size_t)g] - 1 || !(b->host_rule[(size_t)cs] & SVGR_PATH_CLIP_SOURCE)))
+                return fail(SVGR_E_INVALID, "group %lld: its clip source must be the path right in front of its first member", (long long)g);
+            if (!std::isfinite(group_opacity[g])) return fail(SVGR_E_INVALID, "group %lld: opacity is not finite", (long long)g);
+        }
+        HIPCHK(enter_ctx(b->ctx));
+        {
+            // one host blob -> one device block (three small pageable copies cost more than the data); the arrays are the
+            // caller's: the upload reads the copy the batch keeps
+            auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+            const size_t np = (size_t)b->n_paths, ng = (size_t)n_groups;
+            const size_t o_pg = 0, o_cs = al(o_pg + np * 4), o_op = al(o_cs + ng * 4), total = al(o_op + ng * 8);
+            std::vector<char> blob(total, 0);
+            memcpy(blob.data() + o_pg, path_group, np * 4);
+            memcpy(blob.data() + o_cs, group_clip_src, ng * 4);
+            memcpy(blob.data() + o_op, group_opacity, ng * 8);
+            b->path_group.release(); b->group_clip_src.release(); b->group_opacity.release();
+            if (int rc = b->groups_dev.ensure(total)) return rc;
+            b->path_group.point_at(b->groups_dev.p, o_pg, np);
+            b->group_clip_src.point_at(b->groups_dev.p, o_cs, ng);
+            b->group_opacity.point_at(b->groups_dev.p, o_op, ng);
+            hipStream_t st = b->ctx->stream;
+            HIPCHK(hipMemcpyAsync(b->groups_dev.p, b->keep(blob.data(), total), total, hipMemcpyHostToDevice, st));
+            HIPCHK(b->note_upload(st));
+        }
+        b->n_groups = n_groups;
+        b->geometry_fresh = false;  // the cell headers carry the group ids
+        return 0;
+    });
 }
 
 // Gradient paints inside a batch (Path.fill's gradient branch, S:1021-1047, for userSpaceOnUse gradients of up to 32 stops):
@@ -3484,7 +3510,12 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr) {
     // exceeded except by absurd input.  Up to 4096 segments (the runs of a document's per-node route): guesses a few times
     // the typical need -- a wrong one costs the staged plan, never a wrong picture.
     const bool small = ns <= 256;
-    const int64_t edge_guess = small ? 1024 * ns : 128 * ns + 8192;
+    // (tests: SVGR_SPEC_SHRINK="e,c,s,a" divides the guesses for edges, cells, slabs and add slots, so that each overflow path
+    //  can be driven on purpose: the kernels must flag it and the staged plan must take over)
+    long long shrink[4] = {1, 1, 1, 1};
+    if (const char* sk = getenv("SVGR_SPEC_SHRINK")) sscanf(sk, "%lld,%lld,%lld,%lld", &shrink[0], &shrink[1], &shrink[2], &shrink[3]);
+    for (auto& v : shrink) v = v < 1 ? 1 : v;
+    const int64_t edge_guess = std::max<int64_t>((small ? 1024 * ns : 128 * ns + 8192) / shrink[0], 1);
     b->n_edges = edge_guess;
     for (int k = 0; k < NSH; ++k) {  // (the renders' edge array is one dense block: see k_flatten)
         b->shards.base[k] = k == 0 ? 0 : (int)b->n_edges;
@@ -3493,9 +3524,11 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr) {
     b->n_bands = n_bands;
     b->n_pb = (int64_t)np * n_bands;
     b->n_cells = std::min<int64_t>(b->n_pb * n_ct, std::max<int64_t>(262144, small ? 0 : 4 * b->n_pb));  // (overflow is flagged)
+    b->n_cells = std::max<int64_t>(b->n_cells / shrink[1], 1);
     b->n_entries = b->n_pb;
     // slabs: at most one per (path, band) and run of PB_CELLS column tiles; typically one or two per path
     b->n_slabs = std::min<int64_t>(b->n_pb * ((n_ct + PB_CELLS - 1) / PB_CELLS), 64 * (int64_t)np + 1024);
+    b->n_slabs = std::max<int64_t>(b->n_slabs / shrink[2], 1);
     const int64_t row_guess = small ? 16 * edge_guess + b->n_pb : 256 * ns + 4096;  // edge rows
     int rc = b->layout_arena();
     rc = rc ? rc : b->edges.ensure((size_t)b->n_edges * 4);
@@ -3512,7 +3545,7 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr) {
         // everything into its shard); more: four
         const int n_sh = small ? 1 : 4;
         int need[NSH];
-        for (int k = 0; k < NSH; ++k) need[k] = (int)std::min<int64_t>(4 * row_guess / (small ? 1 : 2) + 2048, 1 << 26);
+        for (int k = 0; k < NSH; ++k) need[k] = (int)(std::min<int64_t>(4 * row_guess / (small ? 1 : 2) + 2048, 1 << 26) / shrink[3]);
         rc = b->size_adds(need, n_sh);
     }
     rc = rc ? rc : b->size_masks(np);
@@ -3925,8 +3958,13 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
     // unchanged input; the kernels flag an overflow otherwise and svgr_batch_timings / the next
     // plan reports it)
     // (the first render after a plan finds the plan's own full geometry pass in the buffers: same inputs, same result)
-    if (!(b->geometry_fresh && !timed))
-        if (int rc = run_geometry(b, 4, true)) return rc;
+    const bool det = (flags & SVGR_RENDER_DETERMINISTIC) != 0;
+    if (!(b->geometry_fresh && !timed && !det)) {
+        b->deterministic = det;
+        const int rc = run_geometry(b, 4, true);
+        b->deterministic = false;
+        if (rc) return rc;
+    }
     b->geometry_fresh = false;
     if (single && need) HIPCHK(hipMemsetAsync(out->ptr, 0, need, st));
     if (timed) HIPCHK(hipEventRecord(ev.e1, st));
@@ -3948,6 +3986,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         a.own = b->own;
         a.out_cols = win[3];
         a.clip01 = (flags & SVGR_RENDER_CLIP01) ? 1 : 0;
+        a.det = det ? 1 : 0;
         a.layer_off = layers ? b->layer_off.p : nullptr;
         a.arena = (unsigned*)b->arena.p;
         a.arena_words = (unsigned)(b->arena_bytes / 4);

@@ -51,9 +51,44 @@ def assemble(parts, rows: int, tile_rows: int, strip: int = 1):
 
 
 def gather_canvas(local, rows: int, tile_rows: int, group=None, strip: int = 1):
-    """all_gather the ranks' packed bands (torch tensor, CPU/gloo or GPU/RCCL) and assemble the full
-    canvas on every rank.  Ranks own at most one band more than others, so buffers are padded to the
-    largest shard before the collective."""
+    """all_gather the ranks' packed bands (torch tensor, CPU/gloo or GPU/RCCL) into the full canvas on every rank.
+
+    Strips are dealt round-robin, so `world` consecutive strips -- one of each rank, in rank order -- are a contiguous run of
+    canvas rows: exactly the layout all_gather_into_tensor produces.  Every complete round of strips is therefore gathered
+    STRAIGHT into its rows of the final canvas (one collective per round: two with the default two strips per rank), no
+    staging buffer and no assembly copy; only a ragged tail (a last round in which some rank has a short strip or none) takes
+    the padded gather + copy, for its rows alone."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    srows = strip * tile_rows                      # scanlines per strip
+    rounds = rows // (srows * world)               # complete rounds of strips
+    full = torch.empty((rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    local = local.contiguous()
+    for g in range(rounds):
+        dist.all_gather_into_tensor(full[g * world * srows:(g + 1) * world * srows], local[g * srows:(g + 1) * srows], group=group)
+    tail0 = rounds * world * srows
+    if tail0 < rows:
+        # the rest: rank r's share is what it has beyond the complete rounds (possibly nothing), padded to the largest share
+        rank = dist.get_rank(group)
+        shares = [min(max(rows - tail0 - r * srows, 0), srows) for r in range(world)]
+        pad_rows = max(shares)
+        mine = local[rounds * srows: rounds * srows + shares[rank]]
+        if mine.shape[0] < pad_rows:
+            mine = torch.cat([mine, torch.zeros((pad_rows - mine.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
+                                                device=local.device)], dim=0)
+        got = torch.empty((world * pad_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(got, mine.contiguous(), group=group)
+        at = tail0
+        for r in range(world):
+            full[at:at + shares[r]] = got[r * pad_rows: r * pad_rows + shares[r]]
+            at += shares[r]
+    return full
+
+
+def gather_canvas_staged(local, rows: int, tile_rows: int, group=None, strip: int = 1):
+    """The same result through one padded all_gather and an assembly copy (what gather_canvas replaced; kept as its check)."""
     import torch
     import torch.distributed as dist
 

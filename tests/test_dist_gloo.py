@@ -41,6 +41,14 @@ def _worker(rank, world, port, out_dir):
         parts.append(np.concatenate([band, pad]))
     local = torch.from_numpy(np.concatenate(parts))
     full = sdist.gather_canvas(local, SIZE, TILE_ROWS)
+    assert torch.equal(full, sdist.gather_canvas_staged(local, SIZE, TILE_ROWS))  # (direct rounds + ragged tail == padded gather + copy)
+    # ... and with strips of several bands, complete rounds only / a short last strip / ranks without a last strip
+    for rows_, strip_ in ((192, 3), (200, 3), (200, 2), (40, 2), (16, 1)):
+        k = len(sdist.owned_bands(rows_, TILE_ROWS, rank, world, strip_))
+        mine = torch.arange(k * TILE_ROWS * 3 * 2, dtype=torch.float64).reshape(k * TILE_ROWS, 3, 2) + 1000.0 * rank
+        a_ = sdist.gather_canvas(mine, rows_, TILE_ROWS, strip=strip_)
+        b_ = sdist.gather_canvas_staged(mine, rows_, TILE_ROWS, strip=strip_)
+        assert a_.shape[0] == rows_ and torch.equal(a_, b_), (rows_, strip_)
     # max-over-ranks reduction of a per-rank clock, as bench.py does
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -79,6 +87,65 @@ def test_two_rank_gloo_render_matches_single(tmp_path):
                                  sc["path_paint"], sc["viewport"], clip01=True)
     assert np.abs(got - ref).max() < 1e-11
     assert_f32_1ulp(got.astype(np.float32), ref, what="2-rank gloo canvas")
+
+
+GPU_SIZE, GPU_PATHS = 1024, 384
+
+
+def _gpu_worker(rank, world, port, out_dir):
+    """One rank of a 2-rank render in which EVERY rank drives libsvgr_hip.so (both on GPU 0, as a one-GPU box allows): its
+    strips through svgr_batch_set_bands, gloo for the collectives -- the launcher path of bench.py --gpus N minus RCCL."""
+    import torch
+    import torch.distributed as dist
+
+    import svgrasterize_amd as S
+    from svgrasterize_amd import _abi, dist as sdist, synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = S.Context.get(0)
+    sc = synth.make_scene(GPU_SIZE, GPU_PATHS)
+    tr = _abi.tile_rows()
+    strip = sdist.default_strip_bands(GPU_SIZE, tr, world)
+    batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
+                       viewport=sc["viewport"])
+    batch.set_bands(rank, world, strip)
+    batch.plan()
+    own = batch.owned_rows()
+    out = ctx.alloc(max(own, 1) * GPU_SIZE * 16)
+    for _ in range(2):   # (the second render recomputes the geometry instead of reusing the plan's)
+        batch.render(out, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
+    local = torch.from_numpy(out.download((own, GPU_SIZE, 4), np.float32))
+    dist.barrier()
+    full = sdist.gather_canvas(local, GPU_SIZE, tr, strip=strip)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert t.item() == world
+    if rank == 0:
+        np.save(os.path.join(out_dir, "full_gpu.npy"), full.numpy())
+    dist.barrier()
+    batch.destroy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_render_on_the_gpu_matches_the_oracle(tmp_path):
+    """Two processes, each a rank that renders ITS strips with the HIP library on GPU 0; the assembled canvas against the CPU
+    oracle under the float32 contract."""
+    import torch.multiprocessing as mp
+
+    from oracle import oracle as orc
+    from svgrasterize_amd import synth
+
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "full_gpu.npy")
+    sc = synth.make_scene(GPU_SIZE, GPU_PATHS)
+    ref, _, _ = orc.render_solid(synth.presentation_segs(sc), sc["seg_kind"], sc["path_seg_off"], sc["path_rule"],
+                                 sc["path_paint"], sc["viewport"], clip01=True)
+    assert_f32_1ulp(got, ref, what="2-rank canvas rendered on the GPU")
 
 
 def test_rows_subscene_keeps_exactly_what_can_reach_the_block():

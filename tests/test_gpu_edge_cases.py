@@ -145,6 +145,63 @@ def test_small_batch_planner_matches_staged_planner(S, monkeypatch):
     assert out["staged"][0] > 64 * 2  # the second case really was beyond the speculative capacity
 
 
+def test_speculative_plan_overflows_fall_back_cleanly(S, monkeypatch):
+    """Every buffer of the single-pass plan is sized from a guess, and a guess that is too small must cost the staged plan, never
+    a fault or a wrong picture (round 2 lost a test run to an abort inside svgr_batch_plan on the tiger -- the scene with edges
+    of hundreds of rows -- while the list of extra row chunks of long edges was being written; that list is gone, the
+    principle stays).  SVGR_SPEC_SHRINK divides the guesses for edges / cells / slabs / add slots: each overflow is forced
+    in turn on a shape of few segments whose edges span hundreds of rows, the result must equal the staged planner's and
+    the CPU oracle's; then the transform is scaled up under a plan that fitted (set_transforms) and planned again."""
+    from oracle import oracle as orc
+    from svgrasterize_amd import _abi
+
+    ctx = S.Context.get()
+    swap = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    # a tall spike fan: 7 segments, edges of up to 900 rows, next to a curve
+    path = S.Path.from_svg("M20,10 L60,900 L100,30 L140,880 L180,15 C300,200 260,700 200,890 L20,870 Z")
+    segs, kinds = path.packed()
+    vp = [0, 0, 960, 352]
+
+    def render(tr):
+        b = _abi.Batch(ctx, segs, kinds, [0, len(segs)], tr.m6(), [0], np.array([[0.2, 0.3, 0.1, 0.5]]), viewport=vp)
+        st = b.plan()
+        canvas = ctx.alloc(vp[2] * vp[3] * 32)
+        b.render(canvas, _abi.OUT_CANVAS_F64)
+        first = canvas.download((vp[2], vp[3], 4), np.float64)
+        b.render(canvas, _abi.OUT_CANVAS_F64)
+        second = canvas.download((vp[2], vp[3], 4), np.float64)
+        assert np.allclose(first, second, atol=1e-12)
+        return b, st, first
+
+    monkeypatch.setenv("SVGR_NO_SPECULATIVE_PLAN", "1")
+    _, st_ref, ref = render(swap)
+    monkeypatch.delenv("SVGR_NO_SPECULATIVE_PLAN")
+    pres = orc.transform_points(np.array([[0.0, 1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]), segs.reshape(-1, 4, 2)).reshape(-1, 8)
+    want, _, _ = orc.render_solid(pres, kinds, [0, len(segs)], [0], np.array([[0.2, 0.3, 0.1, 0.5]]), vp, clip01=False)
+    assert_close64(ref, want, atol=1e-10, what="staged plan vs oracle")
+    for shrink in ("100000,1,1,1", "1,100000,1,1", "1,1,100000,1", "1,1,1,100000", "1000,1000,1000,1000", "1,1,1,1"):
+        monkeypatch.setenv("SVGR_SPEC_SHRINK", shrink)
+        b, st, got = render(swap)
+        assert st.n_edges == st_ref.n_edges and st.path_pixels == st_ref.path_pixels, shrink
+        assert_close64(got, ref, atol=1e-12, what=f"speculative plan with guesses / ({shrink})")
+    # a plan that fitted, then the drawing grows under it: the old capacities are refused cleanly, the new plan draws it
+    monkeypatch.delenv("SVGR_SPEC_SHRINK")
+    b, st, _ = render(swap)
+    big = swap.scale(3.0)
+    b.set_transforms(big.m6())
+    vp3 = [0, 0, 960, 352]
+    canvas = ctx.alloc(vp3[2] * vp3[3] * 32)
+    with pytest.raises(_abi.SvgrError):   # (the old plan's capacities are not trusted for the new geometry)
+        b.render(canvas, _abi.OUT_CANVAS_F64)
+    b.plan()
+    b.render(canvas, _abi.OUT_CANVAS_F64)
+    got = canvas.download((vp3[2], vp3[3], 4), np.float64)
+    m3 = np.array([[0.0, 3.0, 0.0], [3.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    want, _, _ = orc.render_solid(orc.transform_points(m3, segs.reshape(-1, 4, 2)).reshape(-1, 8), kinds, [0, len(segs)], [0],
+                                  np.array([[0.2, 0.3, 0.1, 0.5]]), vp3, clip01=False)
+    assert_close64(got, want, atol=1e-10, what="re-plan after set_transforms")
+
+
 def test_mask_prefetch_is_only_a_cache(S):
     """Scene.render renders all the Path.mask calls of its per-node route in one SVGR_OUT_MASKS_F64 batch.  Same result as
     the on-demand single-path masks; a path used twice, an empty path, a clipped-away path and an evenodd rule included."""

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.util import GOLDEN, assert_close64, assert_f32_1ulp
+from tests.util import assert_f32_1ulp_rows, GOLDEN, assert_close64, assert_f32_1ulp
 
 pytestmark = pytest.mark.gpu
 
@@ -96,11 +96,39 @@ def test_synth_4096_properties(S):
     for k, (r0, r1) in enumerate(sdist.owned_row_ranges(size, tr, 1, 4, 16)):
         d = np.abs(part[k * tr: k * tr + (r1 - r0)].astype(np.float64) - full[r0:r1])
         assert d.max() < 2e-7 and (d > 0).mean() < 1e-5
-    # a window of the canvas against the CPU oracle (the reference's own viewport mechanism)
-    r0, c0, hh, ww = 1800, 2100, 160, 224
+    # the WHOLE canvas against the CPU oracle (64 row strips through the reference's own viewport mechanism, S:968-971, on the
+    # host's cores): every one of the 67 M values of the bench scene inside the float32 contract
+    ref, P, _ = orc.render_solid(synth.presentation_segs(sc), sc["seg_kind"], sc["path_seg_off"], sc["path_rule"],
+                                 sc["path_paint"], sc["viewport"], clip01=True, strips=64, threads=orc.host_threads())
+    assert_f32_1ulp_rows(full, ref, what="synth4096 whole canvas vs oracle")
+
+
+def test_deterministic_render_is_bit_reproducible(S):
+    """SVGR_RENDER_DETERMINISTIC: one wave per workgroup does every accumulation in list order, so two renders of the same
+    batch are bit-identical (the reference's np.cumsum, S:983, is; the default render is only up to float32 rounding ties).
+    Same pixels as the default render within the contract, and across a re-plan."""
+    from oracle import oracle as orc
+    from svgrasterize_amd import _abi, synth
+
+    size, n = 2048, 1500
+    sc = synth.make_scene(size, n)
+    ctx = S.Context.get()
+    flags = _abi.RENDER_CLIP01 | _abi.RENDER_DETERMINISTIC
+    canv = []
+    for _ in range(2):  # (two batches: a new plan, new buffers)
+        batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
+                           viewport=sc["viewport"])
+        batch.plan()
+        out = ctx.alloc(size * size * 32)
+        for _k in range(3):
+            batch.render(out, _abi.OUT_CANVAS_F64, flags)
+            canv.append(out.download((size, size, 4), np.float64))
+        batch.destroy()
+    for c in canv[1:]:
+        assert np.array_equal(c, canv[0]), "deterministic renders differ"
     ref, _, _ = orc.render_solid(synth.presentation_segs(sc), sc["seg_kind"], sc["path_seg_off"], sc["path_rule"],
-                                 sc["path_paint"], (r0, c0, hh, ww), clip01=True)
-    assert_f32_1ulp(full[r0:r0 + hh, c0:c0 + ww], ref, what="synth4096 window vs oracle")
+                                 sc["path_paint"], sc["viewport"], clip01=True, strips=32, threads=orc.host_threads())
+    assert_close64(canv[0], ref, atol=1e-10, what="deterministic render vs oracle")
 
 
 def test_synth_8192_config4_windows(S):
@@ -120,10 +148,11 @@ def test_synth_8192_config4_windows(S):
     out = ctx.alloc(size * size * 16)
     batch.render(out, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
     full = out.download((size, size, 4), np.float32)
-    for r0, c0, hh, ww in [(0, 0, 96, 160), (4000, 7900, 200, 292), (8192 - 120, 3000, 120, 200)]:
-        ref, _, _ = orc.render_solid(synth.presentation_segs(sc), sc["seg_kind"], sc["path_seg_off"], sc["path_rule"],
-                                     sc["path_paint"], (r0, c0, hh, ww), clip01=True)
-        assert_f32_1ulp(full[r0:r0 + hh, c0:c0 + ww], ref, what=f"synth8192 window {r0},{c0}")
+    # the WHOLE canvas (268 M values) against the CPU oracle, 128 row strips on the host's cores
+    ref, _, _ = orc.render_solid(synth.presentation_segs(sc), sc["seg_kind"], sc["path_seg_off"], sc["path_rule"],
+                                 sc["path_paint"], sc["viewport"], clip01=True, strips=128, threads=orc.host_threads())
+    assert_f32_1ulp_rows(full, ref, what="synth8192 whole canvas vs oracle")
+    del ref
     tr = _abi.tile_rows()
     strip = max(1, 128 // tr)
     batch.set_bands(5, 8, strip)

@@ -34,6 +34,21 @@ def assert_f32_1ulp(got, ref64, what=""):
     assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} values beyond 1 ULP(f32); max abs err {err.max():.3e}"
 
 
+def assert_f32_1ulp_rows(got, ref64, what="", block=256):
+    """assert_f32_1ulp for canvases of hundreds of megapixels: by blocks of rows (the temporaries of the whole-array form would
+    be several times the canvas)."""
+    assert got.shape == ref64.shape, f"{what}: shape {got.shape} != {ref64.shape}"
+    n_bad, worst = 0, 0.0
+    for r0 in range(0, got.shape[0], block):
+        g = np.asarray(got[r0:r0 + block], dtype=np.float64)
+        ref32 = np.asarray(ref64[r0:r0 + block], dtype=np.float32).astype(np.float64)
+        tol = np.maximum(ulp_f32(ref64[r0:r0 + block]), 2.0 ** -24)
+        err = np.abs(g - ref32)
+        n_bad += int((err > tol).sum())
+        worst = max(worst, float(err.max(initial=0.0)))
+    assert n_bad == 0, f"{what}: {n_bad} of {got.size} values beyond 1 ULP(f32); max abs err {worst:.3e}"
+
+
 def assert_close64(got, ref, atol=1e-12, what=""):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
