@@ -11,9 +11,23 @@ import numpy as np
 
 
 def main():
-    raw = np.fromfile(sys.argv[1], dtype=np.uint64)[8:].reshape(-1, 4)
+    allw = np.fromfile(sys.argv[1], dtype=np.uint64)[8:]
+    phases = None
+    if allw.size >= 8 * 65536:   # (newer builds: a second table with the phase stamps of every workgroup)
+        phases = allw[4 * 65536: 8 * 65536].reshape(-1, 4)
+        allw = allw[: 4 * 65536]
+    raw = allw.reshape(-1, 4)
     live = raw[:, 1] > 0
     t = raw[live]
+    if phases is not None:
+        ph = phases[live].astype(np.int64)
+        st_, en_, it_ = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64), t[:, 2].astype(np.int64)
+        has = (it_ > 0) & (ph[:, 0] > 0)
+        if has.any():
+            d0 = (ph[has, 0] - st_[has]) * 10e-3; d1 = (ph[has, 1] - ph[has, 0]) * 10e-3
+            d2 = (ph[has, 2] - ph[has, 1]) * 10e-3; d3 = (en_[has] - ph[has, 2]) * 10e-3
+            print(f"phases (mean us over {int(has.sum())} workgroups with items): start->first header {d0.mean():.2f}, ->first scatter {d1.mean():.2f}, "
+                  f"item loop {d2.mean():.2f} ({(d2 / it_[has]).mean():.3f} per item), epilogue (store) {d3.mean():.2f}")
     start, end, items = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64), t[:, 2].astype(np.int64)
     hw, xcc = (t[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64), (t[:, 3] >> np.uint64(32)).astype(np.int64) & 0xF
     t0 = start.min()

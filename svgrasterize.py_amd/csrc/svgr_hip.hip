@@ -1879,6 +1879,10 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     for (int i = 0; i < PX; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0;
 #ifdef SVGR_DBG_TIMELINE
     const unsigned long long tl_start_ = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tl_ph_[3] = {0, 0, 0};  // first header landed / first scatter issued / item loop done
+#define TL_PHASE(i) do { if (tl_ph_[i] == 0) tl_ph_[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TL_PHASE(i) do { } while (0)
 #endif
     // Isolated groups: while one is open its members composite into `gacc`; when an item of another group (or of none)
     // arrives, or the tile's list ends, the group is closed: multiplied by the coverage of its clip path (the clip tile, if
@@ -2205,6 +2209,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
             const int* q0 = hdr_ptr(0);
             SVGR_HDR_LOAD(hq, q0);
             SVGR_HDR_TAKE(0, h_p, hq);
+            TL_PHASE(0);
             const int* q1 = hdr_ptr(1);
             const void* a0 = add_ptr(h_p);
             SVGR_HDR_LOAD(hq, q1);
@@ -2215,6 +2220,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
             // (first round: the zero-fill of the delta tiles; later ones: the previous round's last scans)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             scatter(h_p, w_s, v_s, 0);
+            TL_PHASE(1);
             const int* q2 = hdr_ptr(2);
             const void* a1 = add_ptr(h_s);
             SVGR_HDR_LOAD(hq, q2);
@@ -2242,6 +2248,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
         // (nothing may be in flight into registers that are about to mean something else)
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" : : "v"(hq), "v"(wq), "v"(vq) : "memory");
     }
+    TL_PHASE(2);
     if (GROUPS && open_g >= 0) close_group();
     // (a tile without items has not passed a barrier yet: the other wave's zero-fill must not land on the transposed tile below)
     if (n_items == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -2257,6 +2264,8 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
             unsigned long long* t_ = a.dbg + 8 + 4 * (size_t)wg_;
             t_[0] = tl_start_; t_[1] = __builtin_amdgcn_s_memrealtime(); t_[2] = (unsigned long long)n_items;
             t_[3] = ((unsigned long long)xcc_ << 32) | hwid_;
+            unsigned long long* p_ = a.dbg + 8 + 4 * (size_t)(1u << 16) + 4 * (size_t)wg_;
+            p_[0] = tl_ph_[0]; p_[1] = tl_ph_[1]; p_[2] = tl_ph_[2]; p_[3] = 0;
         }
     }
 #endif
@@ -4009,7 +4018,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         {
             // the PREVIOUS render's per-workgroup timeline goes to the file $SVGR_DBG_TIMELINE (raw u64 quadruples)
             static unsigned long long* tl_buf = nullptr;
-            const size_t tl_bytes = 64 + 32 * (size_t)(1u << 16);
+            const size_t tl_bytes = 64 + 64 * (size_t)(1u << 16);
             HIPCHK(hipStreamSynchronize(st));
             if (!tl_buf) { (void)hipMalloc((void**)&tl_buf, tl_bytes); (void)hipMemset(tl_buf, 0, tl_bytes); }
             else if (getenv("SVGR_DBG_TIMELINE")) {
