@@ -559,8 +559,12 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
             rlo = fmin(rlo, fmin(node[2], node[4]));
             rhi = fmax(rhi, fmax(node[2], node[4]));
         }
+        // (rows far outside the viewport are brought to its border in double: the integer arithmetic below stays in range)
+        const double v_lo = (double)vr0 - 4.0, v_hi = (double)vr0 + (double)n_bands * TR + 4.0;
+        rlo = rlo < v_lo ? v_lo : (rlo > v_hi ? v_hi : rlo);
+        rhi = rhi < v_lo ? v_lo : (rhi > v_hi ? v_hi : rhi);
         int ba = (clamp_to_int(floor(rlo)) - 1 - vr0) / TR, bb = (clamp_to_int(ceil(rhi)) + 1 - vr0) / TR;
-        ba = ba < 0 ? 0 : ba;
+        ba = clamp_to_int(floor(rlo)) - 1 - vr0 < 0 ? 0 : ba;
         bb = bb > n_bands - 1 ? n_bands - 1 : bb;
         keep = ba <= bb && owns_any(own, ba, bb);
     }
@@ -709,7 +713,10 @@ static_assert(sizeof(PathBin) == 16, "PathBin is one dwordx4");
 #ifndef SVGR_PB_BANDS
 #define SVGR_PB_BANDS 16
 #endif
-constexpr int PB_THREADS = 256;
+#ifndef SVGR_PB_THREADS
+#define SVGR_PB_THREADS 256
+#endif
+constexpr int PB_THREADS = SVGR_PB_THREADS;
 constexpr int PB_CELLS = SVGR_PB_CELLS;
 constexpr int PB_BANDS = SVGR_PB_BANDS;   // bands per slab at most: one TR-lane group of the workgroup scans each
 static_assert(PB_BANDS * SVGR_TR <= PB_THREADS && PB_BANDS <= PB_CELLS, "k_path_build: one lane group per band of the slab");
@@ -758,6 +765,15 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
             double mnr = key_f64(~k[0]), mnc = key_f64(~k[1]);
             double mxr = key_f64(k[2]), mxc = key_f64(k[3]);
             const double lim = 1.0e9;
+            if (has_vp && mnr == mnr && mnc == mnc && mxr == mxr && mxc == mxc) {
+                // With a viewport the bbox is cut to it anyway (S:968-971): an extent beyond the 32-bit pixel range (the
+                // reference computes it in Python integers) is brought to the viewport's border first, in double.  Only a
+                // render WITHOUT a viewport is limited to +-1e9 pixels.
+                const double r_lo = (double)vr0 - 4.0, r_hi = (double)vr0 + (double)vrows + 4.0;
+                const double c_lo = (double)vc0 - 4.0, c_hi = (double)vc0 + (double)vcols + 4.0;
+                mnr = mnr < r_lo ? r_lo : (mnr > r_hi ? r_hi : mnr); mxr = mxr < r_lo ? r_lo : (mxr > r_hi ? r_hi : mxr);
+                mnc = mnc < c_lo ? c_lo : (mnc > c_hi ? c_hi : mnc); mxc = mxc < c_lo ? c_lo : (mxc > c_hi ? c_hi : mxc);
+            }
             if (!(mnr > -lim && mnc > -lim && mxr < lim && mxc < lim)) {
                 atomicOr(&bd->err, 16);
             } else {
@@ -3627,7 +3643,7 @@ static int build_seg_list(svgr_batch* b) {
     return 0;
 }
 
-static int batch_plan_impl(svgr_batch* b);
+static int batch_plan_impl(svgr_batch* b, bool skip_speculative = false);
 int svgr_batch_plan(svgr_batch* b) {
     return abi_guard("svgr_batch_plan", [&]() { return batch_plan_impl(b); });
 }
@@ -3686,21 +3702,21 @@ int svgr_batch_plan_many(svgr_batch** batches, int64_t n) {
                 done = spec_finish(b);
                 if (done < 0) return done;
             }
-            if (!done)
-                if (int rc = batch_plan_impl(b)) return rc;
+            if (!done)  // (not eligible, or a guess was too small: the staged plan directly -- the speculative pass would fail the same way)
+                if (int rc = batch_plan_impl(b, issued[(size_t)i] != 0)) return rc;
         }
         return 0;
     });
 }
 
-static int batch_plan_impl(svgr_batch* b) {
+static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
     if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
     HIPCHK(enter_ctx(b->ctx));
     b->planned = false;
     b->geometry_fresh = false;
     {
         const bool no_spec = getenv("SVGR_NO_SPECULATIVE_PLAN") != nullptr;  // (tests exercise both planners)
-        const int sp = no_spec ? 0 : plan_speculative(b);
+        const int sp = no_spec || skip_speculative ? 0 : plan_speculative(b);
         if (sp < 0) return sp;
         if (sp > 0) return 0;
     }

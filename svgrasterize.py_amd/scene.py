@@ -342,9 +342,16 @@ def _collect_mask_jobs(scene: Scene, transform: Transform, mask_only: bool, line
 _RUN_PLANS: "dict | None" = None  # during one top-level render: run key -> (leaves, planned batch), from the pre-pass
 
 
-def _run_key(run):
-    """Identity of a run of leaves: the leaf tuples come out of the per-render memo, the same objects in both walks."""
-    return (len(run), id(run[0]), id(run[-1]))
+def _run_key(run, viewport):
+    """Identity of a run of leaves: the leaf tuples come out of the per-render memo, the same objects in both walks.  EVERY
+    leaf counts (two runs of shared sub-scenes may agree in their first and last leaf and their length), and so does the
+    viewport the batch was built for (a render inside the render -- a pattern's tile -- has another)."""
+    return (tuple(map(id, run)), tuple(int(v) for v in viewport))
+
+
+# The pre-pass plans at most this many batches up front (each holds its own work buffers until it is drawn: without a cap the
+# device memory in flight grows with the number of fills of the document); the rest plan on demand, as before the pre-pass.
+_PREPLAN_MAX = 192
 
 
 def _plan_runs(runs, fills, viewport, linear_rgb):
@@ -355,7 +362,9 @@ def _plan_runs(runs, fills, viewport, linear_rgb):
 
     plans, batches = {}, []
     for run in runs:
-        key = _run_key(run)
+        if len(batches) >= _PREPLAN_MAX:
+            break
+        key = _run_key(run, viewport)
         if key in plans:
             continue
         leaves = _drop_empty(run)
@@ -369,7 +378,7 @@ def _plan_runs(runs, fills, viewport, linear_rgb):
         batches.append(batch)
     try:
         fill_plans, fill_batches = geometry.plan_fills(
-            [(p, t, r, geometry.solid_paint(c, linear_rgb)) for p, t, r, c in fills], viewport)
+            [(p, t, r, geometry.solid_paint(c, linear_rgb)) for p, t, r, c in fills[: max(_PREPLAN_MAX - len(batches), 0)]], viewport)
     except Exception:  # noqa: BLE001
         fill_plans, fill_batches = {}, []
     try:
@@ -633,7 +642,7 @@ def _render_run(leaves, viewport, linear_rgb):
     """One batch -> one Layer covering the union of the leaves' bboxes (what Layer.compose of
     the individual fill layers returns, S:366-379)."""
     ctx = _abi.Context.get()
-    pre = _RUN_PLANS.pop(_run_key(leaves), None) if _RUN_PLANS and leaves else None
+    pre = _RUN_PLANS.pop(_run_key(leaves, viewport), None) if _RUN_PLANS and leaves and viewport is not None else None
     if pre is not None:
         leaves, batch = pre  # (built and planned by the pre-pass of Scene.render, together with all the other runs)
     else:

@@ -68,6 +68,26 @@ def test_huge_unclipped_extent_is_refused_not_allocated(S):
     assert layer.image.shape == (32, 48, 1) and np.all(layer.image == 1.0)
 
 
+def test_extents_far_beyond_the_viewport_render_inside_it(S):
+    """The reference computes bboxes in Python integers (S:966-975) and cuts them to the viewport: a shape whose corners lie
+    1e11 pixels away still draws its part of the viewport.  The 32-bit pixel arithmetic here first brings such extents to the
+    viewport's border in double; only a render without a viewport is limited to +-1e9 pixels."""
+    from oracle import oracle as orc
+
+    vp = [10, 20, 96, 160]
+    path = S.Path.from_svg("M-1e11,-9e10 L1.2e11,-1e11 L40.25,1e11 Z M30,40 L90,44 L60.5,120 Z")
+    tr = S.Transform()
+    layer, _ = path.mask(tr, viewport=vp)
+    assert [int(v) for v in layer.offset] == [10, 20] and layer.image.shape == (96, 160, 1)
+    segs, kinds = path.packed()
+    pres = orc.transform_points(tr.m, segs.reshape(-1, 4, 2)).reshape(-1, 8)
+    want, _, _ = orc.render_solid(pres, kinds, [0, len(segs)], [0], np.array([[1.0, 1.0, 1.0, 1.0]]), vp, clip01=False)
+    assert_close64(layer.image[..., 0], want[..., 3], atol=1e-9, what="far extents inside the viewport")
+    assert layer.image.max() == 1.0
+    with pytest.raises(ValueError):
+        path.mask(tr)   # without a viewport the canvas itself would be 2e11 pixels wide
+
+
 def test_ragged_batch_with_empty_and_offscreen_paths(S):
     """Paths without segments, paths outside the viewport and a path covering everything, in one batch."""
     from svgrasterize_amd import _abi
