@@ -242,7 +242,7 @@ def test_gpu_runs_of_a_document_are_planned_together(monkeypatch):
 
     def render_run(leaves, viewport, linear_rgb):
         seen["runs"] += 1
-        if sm._RUN_PLANS and leaves and sm._run_key(leaves) in sm._RUN_PLANS:
+        if sm._RUN_PLANS and leaves and sm._run_key(leaves, viewport) in sm._RUN_PLANS:
             seen["hits"] += 1
         before = seen["single_plans"]
         out = orig_render_run(leaves, viewport, linear_rgb)
