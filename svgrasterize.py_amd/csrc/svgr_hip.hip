@@ -807,11 +807,36 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
             }
         }
     }
-    const int off = wave_alloc(&bd->pb_cursor, pnb, lane);
     // (a path of 2^24 x 2^24 pixels has 2^38 cells: such a batch overflows the cursor and is refused, err bit 5)
     const long long want_cells = has_vp ? (long long)pnb * pnct : 0ll;  // (no viewport yet: the pass only finds the union)
     if (want_cells > (1ll << 28)) atomicOr(&bd->err, 32);
-    const int cell_off = wave_alloc(&bd->cell_cursor, want_cells > (1ll << 28) ? 0 : (int)want_cells, lane);
+    // the path's slabs (band runs without a band of this rank are left out)
+    int bands_per = 1, col_runs = 1, n_slabs = 0;
+    if (has_vp && pnb > 0 && want_cells <= (1ll << 28)) {
+        slab_shape(pnb, pnct, bands_per, col_runs);
+        for (int bb = 0; bb < pnb; bb += bands_per) {
+            const int be = bb + bands_per < pnb ? bb + bands_per : pnb;
+            if (owns_any(own, pb0 + bb, pb0 + be - 1)) n_slabs += col_runs;
+        }
+    }
+    // the wave's reservations of pair, cell and slab slots: three returning atomics issued TOGETHER (one round trip, not three
+    // in a row: this kernel is one wave per 64 paths and nothing but latency)
+    int off, cell_off, slab0;
+    {
+        const int n_cells_ = want_cells > (1ll << 28) ? 0 : (int)want_cells;
+        int t_pb, t_cell, t_slab;
+        const int e_pb = wave_excl_scan(pnb, lane, t_pb), e_cell = wave_excl_scan(n_cells_, lane, t_cell),
+                  e_slab = wave_excl_scan(n_slabs, lane, t_slab);
+        int b_pb = 0, b_cell = 0, b_slab = 0;
+        if (lane == 0) {
+            if (t_pb > 0) b_pb = atomicAdd(&bd->pb_cursor, t_pb);
+            if (t_cell > 0) b_cell = atomicAdd(&bd->cell_cursor, t_cell);
+            if (t_slab > 0) b_slab = atomicAdd(&bd->slab_cursor, t_slab);
+        }
+        off = __shfl(b_pb, 0) + e_pb;
+        cell_off = __shfl(b_cell, 0) + e_cell;
+        slab0 = __shfl(b_slab, 0) + e_slab;
+    }
     if (stats)
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {  // statistics: fold the wave, then one set of atomics
@@ -829,16 +854,6 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
         atomicMax(&bd->umax_r, st_maxr);
         atomicMax(&bd->umax_c, st_maxc);
     }
-    // the path's slabs (band runs without a band of this rank are left out)
-    int bands_per = 1, col_runs = 1, n_slabs = 0;
-    if (has_vp && pnb > 0 && want_cells <= (1ll << 28)) {
-        slab_shape(pnb, pnct, bands_per, col_runs);
-        for (int bb = 0; bb < pnb; bb += bands_per) {
-            const int be = bb + bands_per < pnb ? bb + bands_per : pnb;
-            if (owns_any(own, pb0 + bb, pb0 + be - 1)) n_slabs += col_runs;
-        }
-    }
-    const int slab0 = wave_alloc(&bd->slab_cursor, n_slabs, lane);
     if (slabs && n_slabs > 0) {
         if (slab0 + n_slabs > slab_cap) {
             // (the launch covers the capacity: what this path would have filled of it must not be followed)
