@@ -1581,7 +1581,7 @@ __global__ __launch_bounds__(TL_BLOCK) void k_tile_lists(const int* __restrict__
                                                          const TileEntry* __restrict__ entries, unsigned long long* __restrict__ tile_mask,
                                                          int mask_words, int n_ct, int vc0, Owner own, int n_owned,
                                                          int2* __restrict__ tile_info, TileSlot* __restrict__ order,
-                                                         unsigned* __restrict__ items, int item_cap, int cell_cap,
+                                                         uint4* __restrict__ items, const CellHdr* __restrict__ cell_hdr, int item_cap, int cell_cap,
                                                          BatchDev* __restrict__ bd) {
     constexpr int NWV = TL_BLOCK / 64;
     __shared__ int s_base[TL_BLOCK + 1];
@@ -1673,7 +1673,9 @@ __global__ __launch_bounds__(TL_BLOCK) void k_tile_lists(const int* __restrict__
             const unsigned cls = ((mw[W + w] >> bit) & 1ull) ? 2u : 1u;
             cell = cell >= 0 && cell < cell_cap ? cell : 0;
             const long long at = (long long)item_band0 + run0 + i;
-            if (at < (long long)item_cap) items[at] = (unsigned)cell | (cls << 30);
+            // (the item carries its add list: the tile kernel can then ask for an item's header and its adds at the same time)
+            const int4 hd = cls == 2u ? *(const int4*)((const char*)(cell_hdr + cell) + 48) : make_int4(0, 0, 0, 0);  // {bits, n_add, add0, p}
+            if (at < (long long)item_cap) items[at] = make_uint4((unsigned)cell | (cls << 30), (unsigned)hd.z, (unsigned)hd.y, 0u);
         }
         __syncthreads();
         if (tid == 0) s_run = run0 + total;
@@ -1828,7 +1830,7 @@ __device__ __forceinline__ double dpp_ctrl(double v) {  // generic DPP move of a
 struct TileArgs {
     const TileSlot* order;          // whole-canvas launches: the tiles in launch order (k_tile_lists: heaviest first)
     const int2* tile_info;          // per (band, column tile): {first item, items} -- what a window launch looks its tiles up in
-    const unsigned* items;          // the tiles' item lists: cell id | class << 30, in paint order
+    const uint4* items;             // the tiles' item lists, in paint order: {cell id | class << 30, first add, adds, 0}
     const CellHdr* cell_hdr;        // per cell of class 1 or 2: paint, layer, fill rule, add list, carry-in of every tile row
     const TileAdd* adds;            // add lists of the class-2 cells
     int n_ct;                       // column tiles of the viewport
@@ -1964,6 +1966,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     //  gets half its register budget as AGPRs -- 64 VGPRs for a 64-register canvas tile.)
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     unsigned cells_v = 0u;  // lane j: item j of the round (cell id | class << 30)
+    unsigned add0_v = 0u, nadd_v = 0u;  // ... its add list: first add, adds
     int n_round = 0;        // items of the round
     const int hdr_lane = lane < HDR_LOAD_DWORDS ? lane : HDR_LOAD_DWORDS - 1;
     // header of item j of the round: dword `lane` of its CellHdr (lanes 20 .. 51 hold the 16 carry-ins)
@@ -1974,10 +1977,14 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     auto hdr_cls = [&](int h) { return (__builtin_amdgcn_readlane(h, 12) >> 3) & 3; };
     // class 2: this lane's first add of the item (its later ones, for lists longer than the workgroup, are loaded by the
     // scatter); else the list's first entry: any valid address
-    auto add_ptr = [&](int h) -> const void* {
-        const int n_add = __builtin_amdgcn_readlane(h, 13), add0 = __builtin_amdgcn_readlane(h, 14);
+    // (from the item, not from its header: the adds of an item are asked for together with -- not behind -- its header)
+    auto add_ptr = [&](int j) -> const void* {
+        const bool in = j < n_round;
+        const unsigned cw = in ? (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63) : 0u;
+        const int n_add = in ? __builtin_amdgcn_readlane((int)nadd_v, j & 63) : 0;
+        const int add0 = in ? __builtin_amdgcn_readlane((int)add0_v, j & 63) : 0;
         const TileAdd* p = a.adds;
-        if (hdr_cls(h) == 2) p = a.adds + (size_t)add0 + (tid < n_add ? tid : n_add - 1);
+        if ((cw >> 30) == 2u && n_add > 0) p = a.adds + (size_t)add0 + (tid < n_add ? tid : n_add - 1);
         return p;
     };
     // (class 1) the carry-in of this lane's tile row: dwords 20 + 2 row, 21 + 2 row of the header, fetched across the lanes
@@ -1992,6 +1999,10 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
 #define SVGR_HDR_TAKE(n, dst, tgt) asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, %1" : "=v"(dst) : "v"(tgt) : "memory")
 #define SVGR_ADD_TAKE(n, dw, dv, tw, tv)                                                                               \
     asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(dw), "=&v"(dv) : "v"(tw), "v"(tv) : "memory")
+    // the prologue's wait: two headers and an add at once
+#define SVGR_PROLOGUE_TAKE(n, d0, d1, dw, dv, t0, t1, tw, tv)                                                          \
+    asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b64 %2, %6\n\tv_mov_b64 %3, %7"   \
+                 : "=&v"(d0), "=&v"(d1), "=&v"(dw), "=&v"(dv) : "v"(t0), "v"(t1), "v"(tw), "v"(tv) : "memory")
     // the adds of an item into delta tile `buf`
     auto scatter = [&](int h, unsigned long long first_w, double first_v, int buf) {
 #ifdef SVGR_DBG_NOSCATTER
@@ -2075,8 +2086,14 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
             hi_i = hi_i > PX ? PX : hi_i;
             // (a composite loop of its own for this class -- four fmas per pixel instead of eight -- costs 40 VGPRs: the register
             //  allocator does not keep the canvas tile in place across two unrolled loops that both rewrite it)
+            if (lo_c + col_shift <= 0 && hi_c + col_shift >= TC) {
+                // (the tile lies inside the layer's columns -- the usual case, a tile in the middle of a shape: no pixel tests)
 #pragma unroll
-            for (int i = 0; i < PX; ++i) t[i] = i >= lo_i && i < hi_i ? cin1 : 0.0;
+                for (int i = 0; i < PX; ++i) t[i] = cin1;
+            } else {
+#pragma unroll
+                for (int i = 0; i < PX; ++i) t[i] = i >= lo_i && i < hi_i ? cin1 : 0.0;
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < PX; ++i) t[i] = my[i];
@@ -2124,13 +2141,17 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
                 // Composite for a float32 store: dst += m * (paint - dst * paint_a), two fmas per channel written
                 // in place (the same value as src + dst * (1 - src_a) up to double rounding; the double outputs keep
                 // the reference's operation order).
+                // (the paint's alpha is an operand of every first fma, twice of the fourth: in a VGPR once per item -- left to the
+                //  compiler it is moved there from its scalar pair again in every pixel's block)
+                double p3v;
+                asm("v_mov_b64 %0, %1" : "=v"(p3v) : "s"(p3));
                 auto blend = [&](int i, double mval) {
                     double t0, t1, t2, t3;
                     // (the paint's colour channels ride as scalar operands -- one constant-bus read per instruction --, its alpha in a VGPR)
-                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t0) : "v"(acc[i][0]), "v"(p3), "s"(p0));
-                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t1) : "v"(acc[i][1]), "v"(p3), "s"(p1));
-                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t2) : "v"(acc[i][2]), "v"(p3), "s"(p2));
-                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t3) : "v"(acc[i][3]), "v"(p3), "v"(p3));
+                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t0) : "v"(acc[i][0]), "v"(p3v), "s"(p0));
+                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t1) : "v"(acc[i][1]), "v"(p3v), "s"(p1));
+                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t2) : "v"(acc[i][2]), "v"(p3v), "s"(p2));
+                    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(t3) : "v"(acc[i][3]), "v"(p3v), "v"(p3v));
                     asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i][0]) : "v"(mval), "v"(t0));
                     asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i][1]) : "v"(mval), "v"(t1));
                     asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i][2]) : "v"(mval), "v"(t2));
@@ -2229,7 +2250,10 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     for (int r0_ = 0; r0_ < n_items; r0_ += 64) {
         n_round = n_items - r0_ < 64 ? n_items - r0_ : 64;
         const int n = n_round;
-        cells_v = lane < n ? a.items[(size_t)item0 + r0_ + lane] : 0u;
+        {
+            const uint4 it = lane < n ? a.items[(size_t)item0 + r0_ + lane] : make_uint4(0u, 0u, 0u, 0u);
+            cells_v = it.x; add0_v = it.y; nadd_v = it.z;
+        }
         int hq;                       // load target: the header in flight
         unsigned long long wq;        // load targets: the add in flight ({where, 0} and its value)
         double vq;
@@ -2237,25 +2261,28 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
         unsigned long long w_s;       // the landed add of item k+1
         double v_s;
         {
+            // everything the first two items need, and the loop's standing queue [header 2, add 1], asked for in ONE go: the
+            // items carry their add lists, so no load waits for another (it was three round trips in a row)
+            int hq0, hq1;                  // load targets of the prologue
+            unsigned long long wq0;
+            double vq0;
             const int* q0 = hdr_ptr(0);
-            SVGR_HDR_LOAD(hq, q0);
-            SVGR_HDR_TAKE(0, h_p, hq);
-            TL_PHASE(0);
             const int* q1 = hdr_ptr(1);
-            const void* a0 = add_ptr(h_p);
-            SVGR_HDR_LOAD(hq, q1);
-            SVGR_ADD_LOAD(wq, vq, a0);
-            SVGR_HDR_TAKE(0, h_s, hq);
-            SVGR_ADD_TAKE(0, w_s, v_s, wq, vq);
+            const int* q2 = hdr_ptr(2);
+            const void* a0 = add_ptr(0);
+            const void* a1 = add_ptr(1);
+            SVGR_HDR_LOAD(hq0, q0);
+            SVGR_HDR_LOAD(hq1, q1);
+            SVGR_ADD_LOAD(wq0, vq0, a0);
+            SVGR_HDR_LOAD(hq, q2);
+            SVGR_ADD_LOAD(wq, vq, a1);
+            SVGR_PROLOGUE_TAKE(3, h_p, h_s, w_s, v_s, hq0, hq1, wq0, vq0);   // (leaves [header 2, add 1] in flight)
+            TL_PHASE(0);
             h_s = 1 < n ? h_s : 0;
             // (first round: the zero-fill of the delta tiles; later ones: the previous round's last scans)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             scatter(h_p, w_s, v_s, 0);
             TL_PHASE(1);
-            const int* q2 = hdr_ptr(2);
-            const void* a1 = add_ptr(h_s);
-            SVGR_HDR_LOAD(hq, q2);
-            SVGR_ADD_LOAD(wq, vq, a1);
         }
         for (int k = 0; k < n; ++k) {
             // in flight here: [header k+2, add k+1 (two loads)]; the adds of item k are on their way into delta tile k & 1
@@ -2270,7 +2297,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
             SVGR_ADD_TAKE(1, w_s, v_s, wq, vq);
             scatter(h_s, w_s, v_s, (k + 1) & 1);
             {
-                const void* ap = add_ptr(h_a);
+                const void* ap = add_ptr(k + 2);
                 SVGR_ADD_LOAD(wq, vq, ap);
             }
             process(h_p, k & 1);
@@ -2304,10 +2331,13 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
         const int row = band * TR + trow;  // viewport-local row
         const int out_row = by * TR + trow - a.win_r;  // row of the output buffer (the window's / the owned bands packed)
         if (a.clip01) {
+            // clip(0, 1) (S:326) as max / min: two instructions per channel (written as comparisons the compiler turns every
+            // channel into two exec-masked branches -- 250 instructions per tile, a tenth of the kernel's).  A canvas value is
+            // never a NaN (the sentinel's never passes the coverage test), so the NaN rule of v_max does not matter.
 #pragma unroll
             for (int i = 0; i < PX; ++i)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[i][q] = acc[i][q] < 0 ? 0 : (acc[i][q] > 1 ? 1 : acc[i][q]);
+                for (int q = 0; q < 4; ++q) asm("v_max_f64 %0, %0, 0\n\tv_min_f64 %0, %0, 1.0" : "+v"(acc[i][q]));
         }
 #ifdef SVGR_DBG_NOSTORE
         if (acc[0][0] + acc[1][1] != 12345.678) return;
@@ -2835,7 +2865,7 @@ struct svgr_batch {
     // a pass that ended with an error flag may have left any of the self-cleaning buffers dirty
     void invalidate_work() { masks_zeroed = false; arena_zeroed = false; }
     DevArr<TileAdd> adds;                   // the cells' add lists (k_path_build: a slab reserves its cells' lists in one piece)
-    DevArr<unsigned> items;                 // the tiles' item lists: cell id | class << 30 (k_tile_lists)
+    DevArr<uint4> items;                    // the tiles' item lists: {cell id | class << 30, first add, adds, 0} (k_tile_lists)
     DevArr<int2> tile_info;                 // per (band, column tile): {first item, items}
     DevArr<TileSlot> order;                 // the owned tiles in launch order (heaviest first)
     DevArr<int> band_item0;                 // per band: its first item slot
@@ -3043,7 +3073,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     if (owned > 0 && b->n_ctiles() > 0) {
         hipLaunchKernelGGL(k_tile_lists, dim3(owned), dim3(TL_BLOCK), 0, st, (const int*)b->band_start.p, (const int*)b->band_item0.p,
                            (const TileEntry*)b->entries.p, b->tile_mask.p, b->mask_words, b->n_ctiles(), b->vp[1], b->own, owned,
-                           b->tile_info.p, b->order.p, b->items.p, cap_i32(b->items.cap), cap_i32(b->cell_hdr.cap), b->bd());
+                           b->tile_info.p, b->order.p, b->items.p, (const CellHdr*)b->cell_hdr.p, cap_i32(b->items.cap), cap_i32(b->cell_hdr.cap), b->bd());
         b->masks_zeroed = true;
     }
     return 0;
