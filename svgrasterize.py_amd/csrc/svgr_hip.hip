@@ -1563,6 +1563,11 @@ struct TileSlot {
     int band, ct;        // the tile: ordinal of its band among the owned bands, column tile
     int item0, n_items;  // its item list
 };
+// What workgroup w of a whole-canvas launch of the tile kernel asks for first: its PAGE -- the tile it takes (a TileSlot, in
+// the page's last 16 bytes) and a copy of the first PAGE_ITEMS items of that tile's list, PAGE_STRIDE x 16 bytes that ONE load
+// instruction fetches (a lane each).  Tile and items used to be two dependent round trips in front of the first header.
+constexpr int PAGE_ITEMS = 24, PAGE_STRIDE = PAGE_ITEMS + 1;
+static_assert(PAGE_STRIDE <= 64, "a page is one 16-byte load per lane");
 constexpr int TL_BLOCK = 1024;
 __device__ __forceinline__ int select_bit(unsigned long long m, int r) {  // position of the r-th (0-based) set bit of m
     unsigned x = (unsigned)m;
@@ -1580,11 +1585,11 @@ __device__ __forceinline__ int select_bit(unsigned long long m, int r) {  // pos
 __global__ __launch_bounds__(TL_BLOCK) void k_tile_lists(const int* __restrict__ band_start, const int* __restrict__ band_item0,
                                                          const TileEntry* __restrict__ entries, unsigned long long* __restrict__ tile_mask,
                                                          int mask_words, int n_ct, int vc0, Owner own, int n_owned,
-                                                         int2* __restrict__ tile_info, TileSlot* __restrict__ order,
+                                                         int2* __restrict__ tile_info, uint4* __restrict__ pages,
                                                          uint4* __restrict__ items, const CellHdr* __restrict__ cell_hdr, int item_cap, int cell_cap,
                                                          BatchDev* __restrict__ bd) {
     constexpr int NWV = TL_BLOCK / 64;
-    __shared__ int s_base[TL_BLOCK + 1];
+    __shared__ int s_base[TL_BLOCK + 1], s_rank[TL_BLOCK];
     __shared__ int s_hist[64], s_cur[64], s_wtot[NWV];
     __shared__ int s_run;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1643,9 +1648,9 @@ __global__ __launch_bounds__(TL_BLOCK) void k_tile_lists(const int* __restrict__
             if (!fits) atomicOr(&bd->err, 64);
             tile_info[(size_t)band * n_ct + ct] = make_int2(item0, fits ? n : 0);
             const int rank = SVGR_ORDER ? atomicAdd(&s_cur[weight_of(n, n2)], 1) : ct;
-            TileSlot ts;
-            ts.band = (int)blockIdx.x; ts.ct = ct; ts.item0 = item0; ts.n_items = fits ? n : 0;  // (band: its ordinal among the owned ones)
-            order[(size_t)rank * n_owned + blockIdx.x] = ts;
+            s_rank[tid] = rank;
+            // (band: its ordinal among the owned ones)
+            pages[((size_t)rank * n_owned + blockIdx.x) * PAGE_STRIDE + PAGE_ITEMS] = make_uint4(blockIdx.x, (unsigned)ct, (unsigned)item0, (unsigned)(fits ? n : 0));
         }
         __syncthreads();
         const int total = s_base[TL_BLOCK];
@@ -1657,6 +1662,7 @@ __global__ __launch_bounds__(TL_BLOCK) void k_tile_lists(const int* __restrict__
                 if (s_base[mid] <= i) lo = mid; else hi = mid;
             }
             int r = i - s_base[lo];
+            const int r_tile = r;
             const int tct = c0 + lo;
             const unsigned long long* mw = mband + (size_t)tct * 2 * W;
             int w = 0;
@@ -1675,7 +1681,9 @@ __global__ __launch_bounds__(TL_BLOCK) void k_tile_lists(const int* __restrict__
             const long long at = (long long)item_band0 + run0 + i;
             // (the item carries its add list: the tile kernel can then ask for an item's header and its adds at the same time)
             const int4 hd = cls == 2u ? *(const int4*)((const char*)(cell_hdr + cell) + 48) : make_int4(0, 0, 0, 0);  // {bits, n_add, add0, p}
-            if (at < (long long)item_cap) items[at] = make_uint4((unsigned)cell | (cls << 30), (unsigned)hd.z, (unsigned)hd.y, 0u);
+            const uint4 it = make_uint4((unsigned)cell | (cls << 30), (unsigned)hd.z, (unsigned)hd.y, 0u);
+            if (at < (long long)item_cap) items[at] = it;
+            if (r_tile < PAGE_ITEMS) pages[((size_t)s_rank[lo] * n_owned + blockIdx.x) * PAGE_STRIDE + r_tile] = it;
         }
         __syncthreads();
         if (tid == 0) s_run = run0 + total;
@@ -1828,7 +1836,7 @@ __device__ __forceinline__ double dpp_ctrl(double v) {  // generic DPP move of a
 }
 
 struct TileArgs {
-    const TileSlot* order;          // whole-canvas launches: the tiles in launch order (k_tile_lists: heaviest first)
+    const uint4* pages;             // whole-canvas launches: per workgroup, in launch order (k_tile_lists: heaviest first), its page
     const int2* tile_info;          // per (band, column tile): {first item, items} -- what a window launch looks its tiles up in
     const uint4* items;             // the tiles' item lists, in paint order: {cell id | class << 30, first add, adds, 0}
     const CellHdr* cell_hdr;        // per cell of class 1 or 2: paint, layer, fill rule, add list, carry-in of every tile row
@@ -1884,12 +1892,13 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     const int trow = tid / CH, chunk = tid % CH;
     // which tile
     int by, bx, item0, n_items;
+    uint4 page = make_uint4(0u, 0u, 0u, 0u);  // lane j < PAGE_ITEMS: item j of the tile's list
     if (a.use_order) {
-        const TileSlot ts = a.order[blockIdx.x];
-        by = __builtin_amdgcn_readfirstlane(ts.band);  // (ordinal among the owned bands)
-        bx = __builtin_amdgcn_readfirstlane(ts.ct);
-        item0 = __builtin_amdgcn_readfirstlane(ts.item0);
-        n_items = __builtin_amdgcn_readfirstlane(ts.n_items);
+        page = a.pages[(size_t)blockIdx.x * PAGE_STRIDE + (lane < PAGE_STRIDE ? lane : PAGE_ITEMS)];
+        by = __builtin_amdgcn_readlane((int)page.x, PAGE_ITEMS);  // (ordinal among the owned bands)
+        bx = __builtin_amdgcn_readlane((int)page.y, PAGE_ITEMS);
+        item0 = __builtin_amdgcn_readlane((int)page.z, PAGE_ITEMS);
+        n_items = __builtin_amdgcn_readlane((int)page.w, PAGE_ITEMS);
     } else {
         // (the launch covers the column tiles [ct0, ct0 + win_ct) of the bands [band0, band0 + n_bands): the render window)
         const unsigned t_lin = blockIdx.x;
@@ -2247,10 +2256,15 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     };
 
     // ---- the item loop: rounds of up to 64 items (a round's cell ids sit one per lane) ----
-    for (int r0_ = 0; r0_ < n_items; r0_ += 64) {
-        n_round = n_items - r0_ < 64 ? n_items - r0_ : 64;
+    // (a whole-canvas launch has the first PAGE_ITEMS items in hand already: its first round is those)
+    for (int r0_ = 0; r0_ < n_items; r0_ += n_round) {
+        const bool paged = a.use_order && r0_ == 0;
+        const int round_cap = paged ? PAGE_ITEMS : 64;
+        n_round = n_items - r0_ < round_cap ? n_items - r0_ : round_cap;
         const int n = n_round;
-        {
+        if (paged) {
+            cells_v = lane < n ? page.x : 0u; add0_v = page.y; nadd_v = page.z;
+        } else {
             const uint4 it = lane < n ? a.items[(size_t)item0 + r0_ + lane] : make_uint4(0u, 0u, 0u, 0u);
             cells_v = it.x; add0_v = it.y; nadd_v = it.z;
         }
@@ -2867,7 +2881,7 @@ struct svgr_batch {
     DevArr<TileAdd> adds;                   // the cells' add lists (k_path_build: a slab reserves its cells' lists in one piece)
     DevArr<uint4> items;                    // the tiles' item lists: {cell id | class << 30, first add, adds, 0} (k_tile_lists)
     DevArr<int2> tile_info;                 // per (band, column tile): {first item, items}
-    DevArr<TileSlot> order;                 // the owned tiles in launch order (heaviest first)
+    DevArr<uint4> pages;                    // per owned tile, in launch order (heaviest first): its page (k_tile_lists)
     DevArr<int> band_item0;                 // per band: its first item slot
     AddShards add_shards{};                 // where each shard's add slots live (the slabs of path p reserve in shard p % n)
     int64_t n_adds = 0;                     // add slots in all the shards
@@ -2919,7 +2933,7 @@ struct svgr_batch {
     int size_tile_lists(int owned_bands) {
         const size_t nt = (size_t)std::max(n_bands, 1) * (size_t)std::max(n_ctiles(), 1);
         if (int rc = tile_info.ensure(nt)) return rc;
-        if (int rc = order.ensure((size_t)std::max(owned_bands, 1) * (size_t)std::max(n_ctiles(), 1))) return rc;
+        if (int rc = pages.ensure((size_t)std::max(owned_bands, 1) * (size_t)std::max(n_ctiles(), 1) * PAGE_STRIDE)) return rc;
         if (int rc = band_item0.ensure((size_t)n_bands + 1)) return rc;
         return items.ensure((size_t)std::max<int64_t>(n_cells, 1));
     }
@@ -2950,7 +2964,7 @@ struct svgr_batch {
         path_group.release(); group_clip_src.release(); group_opacity.release(); groups_dev.release();
         grads.release(); path_grad.release(); grad_path.release(); grad_flags.release(); grads_dev.release();
         edges.release(); cell_hdr.release(); pair_idx.release(); slabs.release(); seg_cnt.release(); seg_off.release(); path_seg0.release(); tile_mask.release(); seg_list.release(); path_list.release(); layer_off.release();
-        adds.release(); items.release(); tile_info.release(); order.release(); band_item0.release();
+        adds.release(); items.release(); tile_info.release(); pages.release(); band_item0.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
         for (auto e : event_pool) (void)hipEventDestroy(e);
@@ -3073,7 +3087,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     if (owned > 0 && b->n_ctiles() > 0) {
         hipLaunchKernelGGL(k_tile_lists, dim3(owned), dim3(TL_BLOCK), 0, st, (const int*)b->band_start.p, (const int*)b->band_item0.p,
                            (const TileEntry*)b->entries.p, b->tile_mask.p, b->mask_words, b->n_ctiles(), b->vp[1], b->own, owned,
-                           b->tile_info.p, b->order.p, b->items.p, (const CellHdr*)b->cell_hdr.p, cap_i32(b->items.cap), cap_i32(b->cell_hdr.cap), b->bd());
+                           b->tile_info.p, b->pages.p, b->items.p, (const CellHdr*)b->cell_hdr.p, cap_i32(b->items.cap), cap_i32(b->cell_hdr.cap), b->bd());
         b->masks_zeroed = true;
     }
     return 0;
@@ -4041,7 +4055,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
 
     if (owned_bands > 0 && n_ctiles > 0) {
         TileArgs a;
-        a.order = b->order.p; a.tile_info = b->tile_info.p; a.items = b->items.p; a.out = out->ptr;
+        a.pages = b->pages.p; a.tile_info = b->tile_info.p; a.items = b->items.p; a.out = out->ptr;
         a.cell_hdr = b->cell_hdr.p; a.adds = b->adds.p;
         a.n_ct = b->n_ctiles();
         a.group_clip_src = b->group_clip_src.p; a.group_opacity = b->group_opacity.p;
