@@ -708,7 +708,7 @@ static_assert(sizeof(PathBin) == 16, "PathBin is one dwordx4");
 // PB_CELLS cells: a path of up to PB_CELLS column tiles is cut into runs of bands, a wider one band by band into runs of
 // column tiles.
 #ifndef SVGR_PB_CELLS
-#define SVGR_PB_CELLS 128
+#define SVGR_PB_CELLS 120
 #endif
 #ifndef SVGR_PB_BANDS
 #define SVGR_PB_BANDS 16
@@ -1146,14 +1146,13 @@ __device__ __forceinline__ unsigned add_where(int trow, int tcol, int len) {
 // ---------------------------------------------------------------------------------------------
 struct EdgeLds {
     double p0y, p1y, dxdy, x;  // as EdgeSetup; x = column at which the edge enters row ya
-    int ya_dir, pad;           // ya | (dir < 0) << 31
 };
-static_assert(sizeof(EdgeLds) == 40, "EdgeLds is two 16-byte and one 8-byte LDS read");
+static_assert(sizeof(EdgeLds) == 32, "EdgeLds is two 16-byte LDS reads (its first row and direction ride in an int array beside it)");
 #ifndef SVGR_PB_EPL
 #define SVGR_PB_EPL 2
 #endif
 #ifndef SVGR_PB_KEEP
-#define SVGR_PB_KEEP 3
+#define SVGR_PB_KEEP 2
 #endif
 constexpr int PB_EPL = SVGR_PB_EPL;                // edges per lane and batch
 constexpr int PB_BATCH = PB_THREADS * PB_EPL;      // edges staged together
@@ -1161,7 +1160,7 @@ constexpr int PB_KEEP = SVGR_PB_KEEP;              // rounds of tasks whose rows
 constexpr int PB_TAB = PB_THREADS * PB_KEEP;       // tasks that find their edge in a table instead of by search
 static_assert(PB_BATCH % 16 == 0 && PB_BATCH / 16 <= 32, "two-level search: at most 32 coarse entries");
 #ifndef SVGR_PB_WAVES
-#define SVGR_PB_WAVES 3
+#define SVGR_PB_WAVES 4
 #endif
 __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const Slab* __restrict__ slabs, const double* __restrict__ edges,
                                                            const int* __restrict__ pair_idx, const double* __restrict__ path_paint,
@@ -1181,12 +1180,19 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     __shared__ double s_left[TR];
     __shared__ int s_cnt[PB_CELLS], s_pos[PB_CELLS];
     __shared__ __attribute__((aligned(16))) EdgeLds s_edge[PB_BATCH];
+    __shared__ int s_eya[PB_BATCH];              // per staged edge: ya | (dir < 0) << 31
     __shared__ __attribute__((aligned(16))) int s_pref[PB_BATCH];
     __shared__ __attribute__((aligned(16))) int s_coarse[32];
     __shared__ unsigned short s_tab[PB_TAB];
     __shared__ int s_wtot[PB_EPL][PB_THREADS / 64];
-    __shared__ __attribute__((aligned(16))) int4 s_info[PB_CELLS];
+    __shared__ __attribute__((aligned(8))) int2 s_info[PB_CELLS];   // per cell: adds in front of it in its band, class | band << 2 | column tile << 8
+    __shared__ unsigned s_rowm[PB_CELLS];                           // ... rows with a carry-in add | rows with a sentinel << 16
     __shared__ int s_ptot[PB_BANDS], s_pidx[PB_BANDS], s_base, s_ok;
+#ifdef SVGR_DBG_PB_PADLDS
+    __shared__ int s_padlds[SVGR_DBG_PB_PADLDS / 4];   // diagnostic: occupancy experiment
+    if (threadIdx.x == 0 && vr0 == -123456) s_padlds[blockIdx.x & 7] = 1;
+    if (vr0 == -123457) cell_cap = s_padlds[3];
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x >= bd->slab_cursor) return;  // (the grid covers the plan's slab capacity)
     const Slab sl = slabs[blockIdx.x];
@@ -1201,19 +1207,19 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     const int n_cell = sl.nb * sl.nk;
     const double o_r = (double)r0, o_c = (double)c0;  // `lines - [min_x, min_y]` (S:979)
     for (int i = tid; i < n_cell * TR; i += PB_THREADS) s_sum[i] = 0.0;
-    for (int i = tid; i < n_cell; i += PB_THREADS) { s_cnt[i] = 0; s_pos[i] = (int)0x80000000; s_info[i] = make_int4(0, 0, 0, 0); }
+    for (int i = tid; i < n_cell; i += PB_THREADS) { s_cnt[i] = 0; s_pos[i] = (int)0x80000000; s_info[i] = make_int2(0, 0); }
     if (tid < TR) s_left[tid] = 0.0;
 
     // a batch of edges (slot = tid + j * PB_THREADS): set up, rows inside the slab counted, prefix sums -> number of
     // (edge, row) tasks of the batch; the first PB_TAB tasks find their slot in s_tab
     auto stage = [&](int eb) -> int {
-        int cnt[PB_EPL];
+        int cnt[PB_EPL], eya[PB_EPL];
         EdgeLds el[PB_EPL];
 #pragma unroll
         for (int j = 0; j < PB_EPL; ++j) {
             const int e = eb + tid + j * PB_THREADS;
             cnt[j] = 0;
-            el[j].p0y = el[j].p1y = el[j].dxdy = el[j].x = 0.0; el[j].ya_dir = 0; el[j].pad = 0;
+            el[j].p0y = el[j].p1y = el[j].dxdy = el[j].x = 0.0; eya[j] = 0;
             if (e < e_end) {
                 const double4 ed = ((const double4*)edges)[e];
                 const double ar = ed.x - o_r, ac = ed.y - o_c, br = ed.z - o_r, bc = ed.w - o_c;
@@ -1229,7 +1235,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                         // carry x from the edge's first row to the slab's, exactly as the walk would (S:2244-2248)
                         for (int yy = es.y_begin; yy < ya; ++yy) row_step(st, yy, es.p0y, es.p1y, es.dxdy, es.dir);
                         el[j].p0y = es.p0y; el[j].p1y = es.p1y; el[j].dxdy = es.dxdy; el[j].x = st.x_next;
-                        el[j].ya_dir = ya | (es.dir < 0.0 ? (int)0x80000000 : 0);  // (ya >= 0)
+                        eya[j] = ya | (es.dir < 0.0 ? (int)0x80000000 : 0);  // (ya >= 0)
                     }
                 }
             }
@@ -1242,6 +1248,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         for (int j = 0; j < PB_EPL; ++j) {
             if (lane == 0) s_wtot[j][wave] = wtot[j];
             s_edge[tid + j * PB_THREADS] = el[j];
+            s_eya[tid + j * PB_THREADS] = eya[j];
         }
         __syncthreads();
         int all = 0;
@@ -1289,25 +1296,40 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         double v[5];
         int where;   // bl | trow << 8 | live << 16
     };
-    auto row_of = [&](int t) -> RowAt {
-        RowAt ra;
+    // What is kept of a row between the passes: where the edge enters and leaves it, its signed height, its place (7 registers;
+    // the pieces themselves are 13, and three rounds of them cost the kernel a workgroup per CU).  Pass B recomputes the pieces.
+    struct RowKey {
+        double x, x_next, d;
+        int where;   // bl | trow << 8
+    };
+    auto row_key = [&](int t) -> RowKey {
+        RowKey rk;
         int slot, dy;
         find(t, slot, dy);
         const EdgeLds el = s_edge[slot];
-        const int ya = el.ya_dir & 0x7fffffff, y = ya + dy;
-        const double dir = el.ya_dir < 0 ? -1.0 : 1.0;
+        const int ya_dir = s_eya[slot];
+        const int ya = ya_dir & 0x7fffffff, y = ya + dy;
+        const double dir = ya_dir < 0 ? -1.0 : 1.0;
         RowState st;
         st.x_next = el.x; st.x = el.x; st.d = 0.0;
         for (int yy = ya; yy <= y; ++yy) row_step(st, yy, el.p0y, el.p1y, el.dxdy, dir);
         const int vrow = r0 + y - vr0, band = vrow / TR;
-        const RowPieces rp = row_record(st.x, st.x_next, st.d);
+        rk.x = st.x; rk.x_next = st.x_next; rk.d = st.d;
+        rk.where = (band - sl.band0) | ((vrow & (TR - 1)) << 8);
+        return rk;
+    };
+    auto row_at = [&](const RowKey& rk) -> RowAt {
+        RowAt ra;
+        const RowPieces rp = row_record(rk.x, rk.x_next, rk.d);
         ra.x0i = rp.x0i; ra.n = rp.n;
         ra.v[0] = rp.v[0]; ra.v[1] = rp.v[1]; ra.v[2] = rp.v[2]; ra.v[3] = rp.v[3]; ra.v[4] = rp.v[4];
         if ((unsigned)ra.n > SPAN_MAX) { atomicOr(&bd->err, 16); ra.n = (int)SPAN_MAX; }
+        const int band = sl.band0 + (rk.where & 0xff);
         const bool live = owns_band(own, band) && rp.x0i < cols;  // (another rank's band; a row wholly beyond the layer, S:2260)
-        ra.where = (band - sl.band0) | ((vrow & (TR - 1)) << 8) | ((int)live << 16);
+        ra.where = rk.where | ((int)live << 16);
         return ra;
     };
+    auto row_of = [&](int t) -> RowAt { return row_at(row_key(t)); };
     // the slab's column tiles [kf, kl] (relative to the path's first) the pieces of a row fall into
     auto row_tiles = [&](const RowAt& ra, int& kf, int& kl) {
         const int xl = ra.x0i + (ra.n >= 2 ? ra.n : 1);  // column of the last piece
@@ -1385,7 +1407,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     const int t_first = det ? (tid < 64 ? tid : 0x7fffffff) : tid, t_step = det ? 64 : PB_THREADS;
     const bool one_batch = e_end - e_begin <= PB_BATCH;
     const bool keep = one_batch && !det;
-    RowAt kept[PB_KEEP];
+    RowKey kept[PB_KEEP];
     int total = 0, n_rows = 0;
     for (int eb = e_begin; eb < e_end; eb += PB_BATCH) {
         total = stage(eb);
@@ -1399,8 +1421,8 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
 #pragma unroll
             for (int r = 0; r < PB_KEEP; ++r, t += PB_THREADS) {
                 if (t < total) {
-                    kept[r] = row_of(t);
-                    count_row(kept[r]);
+                    kept[r] = row_key(t);
+                    count_row(row_at(kept[r]));
                 }
             }
         }
@@ -1449,7 +1471,8 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                     s_sum[ci * TR + row_l] = cin;
                     if (row_l == 0) {
                         s_cnt[ci] = n_add;                                   // (the cell's whole list now)
-                        s_info[ci] = make_int4(cursor, cls | (g << 2) | (k << 8), (int)(cm | (sm << 16)), 0);
+                        s_info[ci] = make_int2(cursor, cls | (g << 2) | (k << 8));
+                        s_rowm[ci] = cm | (sm << 16);
                     }
                 }
                 cursor += n_add;
@@ -1482,7 +1505,8 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         const bool slab_ok = s_ok != 0;
         for (int i = tid; i < n_cell * TR; i += PB_THREADS) {
             const int ci = i / TR, row_l = i & (TR - 1);
-            const int4 info = s_info[ci];
+            const int2 info = s_info[ci];
+            const unsigned rowm = s_rowm[ci];
             const int cls = info.y & 3, g = (info.y >> 2) & 63, k = info.y >> 8;
             const int band = sl.band0 + g;
             if (cls == 0 || !owns_band(own, band)) continue;
@@ -1494,7 +1518,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                 continue;
             }
             const double cin = s_sum[i];
-            const unsigned cm = (unsigned)info.z & 0xffffu, sm = (unsigned)info.z >> 16;
+            const unsigned cm = rowm & 0xffffu, sm = rowm >> 16;
             const int n_carry = __popc(cm);
             CellHdr* hd = cell_hdr + cell;
             hd->carry[row_l] = cin;
@@ -1540,7 +1564,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         if (keep) {
 #pragma unroll
             for (int r = 0; r < PB_KEEP; ++r, t += PB_THREADS)
-                if (t < total) emit_row(kept[r]);
+                if (t < total) emit_row(row_at(kept[r]));
         }
         for (; t < total; t += t_step) emit_row(row_of(t));  // (the batch is still staged)
     } else {
