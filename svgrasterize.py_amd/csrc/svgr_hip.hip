@@ -516,6 +516,8 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
     // (multi-GPU: the plan's list of the segments this rank needs; else every segment)
     const int seg = seg_list ? (item < n_list ? seg_list[item] : n_segs) : item;
     bool seg_ok = seg < n_segs;
+    // (where the segment's edges go: asked for here, with the segment itself -- behind the traversal it is a round trip of its own)
+    const int so0 = seg_off && seg_ok ? seg_off[seg] : 0, so1 = seg_off && seg_ok ? seg_off[seg + 1] : 0;
     double node[8];
     int mode = 0;  // 0 nothing, 1 one edge node[0..1] -> node[6..7], 2 subtree under node
     int p = 0;
@@ -598,9 +600,10 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
         const int lane = threadIdx.x & 63;
         int wtot;
         const int excl = wave_excl_scan(cnt, lane, wtot);
-        const int seg_first = __shfl(excl, lane & 32), seg_total = __shfl(excl + cnt, lane | 31) - seg_first;
+        constexpr int SEGL = 1 << FL_SUB;  // lanes per segment
+        const int seg_first = __shfl(excl, lane & ~(SEGL - 1)), seg_total = __shfl(excl + cnt, lane | (SEGL - 1)) - seg_first;
         if (seg_cnt && seg_ok && sub == 0) seg_cnt[seg] = seg_total;
-        const int s0 = seg_off && seg_ok ? seg_off[seg] : 0, s1 = seg_off && seg_ok ? seg_off[seg + 1] : 0;
+        const int s0 = so0, s1 = so1;
         base = s0 + (excl - seg_first);
         fits = base + cnt <= s1 && base + cnt <= edge_cap;
         // (the shard cursors only count here: their sum is the number of edges the pass kept)
@@ -748,7 +751,8 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
                                                   int vr0, int vc0, int vrows, int vcols, int* __restrict__ bbox,
                                                   PathBin* __restrict__ bins, BatchDev* __restrict__ bd, int stats,
                                                   const int* __restrict__ plist, Slab* __restrict__ slabs, int slab_cap, Owner own,
-                                                  const int* __restrict__ path_seg0, const int* __restrict__ seg_off, int edge_cap) {
+                                                  const int* __restrict__ path_seg0, const int* __restrict__ seg_off, int edge_cap,
+                                                  const int* __restrict__ slab_at) {
     // (multi-GPU: thread i takes the i-th path of this rank's list, n_paths = its length; the others keep the empty bbox
     //  and bins the plan gave them)
     const int pi = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
@@ -836,6 +840,9 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
         off = __shfl(b_pb, 0) + e_pb;
         cell_off = __shfl(b_cell, 0) + e_cell;
         slab0 = __shfl(b_slab, 0) + e_slab;
+        // A planned render knows where every path's slabs go (svgr_batch::slab_at: the plan's heaviest-first order -- workgroups
+        // are dispatched in slab order, and a launch that ends on its longest slabs ends late); the cursor then only counts.
+        if (slab_at && p < n_paths) slab0 = slab_at[p];
     }
     if (stats)
 #pragma unroll
@@ -2928,6 +2935,9 @@ struct svgr_batch {
     }
     DevArr<int> pair_idx;                   // per (path, band) pair: its place in its band's list (k_band_entries)
     DevArr<Slab> slabs;                     // work items of k_path_build (k_path_bbox)
+    DevArr<int> slab_at;                    // per path: its first slab, heaviest paths first (staged plan; renders only)
+    bool slab_at_valid = false;
+    std::vector<int> slab_at_host;
     int64_t n_slabs = 0;                    // ... the plan's count = the launch's grid
     DevArr<int> seg_cnt, seg_off;           // per segment: edges it flattens into (the plan's counting pass), their prefix sums
     DevArr<int> path_seg0;                  // per path its first segment (view of the input blob)
@@ -2987,7 +2997,7 @@ struct svgr_batch {
         band_start.release(); band_count.release(); entries.release();
         path_group.release(); group_clip_src.release(); group_opacity.release(); groups_dev.release();
         grads.release(); path_grad.release(); grad_path.release(); grad_flags.release(); grads_dev.release();
-        edges.release(); cell_hdr.release(); pair_idx.release(); slabs.release(); seg_cnt.release(); seg_off.release(); path_seg0.release(); tile_mask.release(); seg_list.release(); path_list.release(); layer_off.release();
+        edges.release(); cell_hdr.release(); pair_idx.release(); slabs.release(); slab_at.release(); seg_cnt.release(); seg_off.release(); path_seg0.release(); tile_mask.release(); seg_list.release(); path_list.release(); layer_off.release();
         adds.release(); items.release(); tile_info.release(); pages.release(); band_item0.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
@@ -3039,7 +3049,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
         if (upto == 0)  // bboxes only (no edges stored): enough to find the union when there is no viewport
             hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(),
                                np_walk, use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), 1, plist,
-                               (Slab*)nullptr, 0, b->own, (const int*)nullptr, (const int*)nullptr, 0);
+                               (Slab*)nullptr, 0, b->own, (const int*)nullptr, (const int*)nullptr, 0, (const int*)nullptr);
         return 0;
     }
     if (ns > 0)
@@ -3052,7 +3062,8 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                        use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), b->planned ? 0 : 1, plist,
                        upto >= 3 ? b->slabs.p : (Slab*)nullptr, (int)std::min<int64_t>(cap_i32(b->slabs.cap), b->n_slabs) /* = k_path_build's grid */, b->own,
                        (const int*)b->path_seg0.p, (const int*)b->seg_off.p,
-                       cap_i32(std::min(b->edge_path.cap, b->edges.cap / 4)));
+                       cap_i32(std::min(b->edge_path.cap, b->edges.cap / 4)),
+                       upto >= 4 && b->planned && b->slab_at_valid ? (const int*)b->slab_at.p : (const int*)nullptr);
     if (upto == 2) return 0;
     // per owned band: its list of (path, band) pairs in paint order, and its first tile-list slot
     const int owned = count_owned_bands(b->own, b->n_bands);
@@ -3474,14 +3485,14 @@ int svgr_batch_set_transforms(svgr_batch* b, const double* path_m6) {
     HIPCHK(hipMemcpyAsync(b->path_m6.p, b->keep(path_m6, sizeof(double) * 6 * (size_t)b->n_paths), sizeof(double) * 6 * b->n_paths,
                           hipMemcpyHostToDevice, b->ctx->stream));
     HIPCHK(b->note_upload(b->ctx->stream));
-    b->planned = false;
+    b->planned = false; b->slab_at_valid = false;
     return 0;
 }
 
 int svgr_batch_set_bands(svgr_batch* b, int rank, int world, int strip_bands) {
     if (!b || world <= 0 || rank < 0 || rank >= world || strip_bands <= 0) return fail(SVGR_E_INVALID, "bad band selection");
     b->own = Owner{rank, world, strip_bands};
-    b->planned = false;  // the edge / record capacities are per rank
+    b->planned = false; b->slab_at_valid = false;  // the edge / record capacities are per rank
     b->n_seg_list = -1;  // ... and so is the list of segments to flatten
     return 0;
 }
@@ -3765,7 +3776,7 @@ int svgr_batch_plan_many(svgr_batch** batches, int64_t n) {
         for (int64_t i = 0; i < n; ++i) {
             svgr_batch* b = batches[i];
             HIPCHK(enter_ctx(b->ctx));
-            b->planned = false;
+            b->planned = false; b->slab_at_valid = false;
             b->geometry_fresh = false;
             const int is = no_spec ? 0 : spec_issue(b, (char*)b->ctx->pinned + stage_off[(size_t)i]);
             if (is < 0) return is;
@@ -3792,10 +3803,56 @@ int svgr_batch_plan_many(svgr_batch** batches, int64_t n) {
     });
 }
 
+// Where every path's slabs go in the renders that follow: the paths sorted by the work one of their slabs is (edge rows ~ the
+// rows + columns of the part of the bbox it covers), heaviest first.  k_path_bbox's own count of a path's slabs is the same
+// integer arithmetic on the same bbox (slab_shape, owns_any), so the places tile the list exactly; the geometry cannot change
+// under a plan (set_transforms / set_bands invalidate it).
+static int plan_slab_order(svgr_batch* b) {
+    b->slab_at_valid = false;
+#ifdef SVGR_DBG_NO_SLAB_ORDER
+    return 0;
+#endif
+    const size_t np = (size_t)b->n_paths;
+    if (np == 0 || b->host_bbox.size() < 4 * np || b->n_slabs <= 0 || b->vp[2] <= 0) return 0;
+    std::vector<int> n_sl(np, 0), order;
+    std::vector<float> w(np, 0.f);
+    order.reserve(np);
+    long long total = 0;
+    for (size_t p = 0; p < np; ++p) {
+        const int r0 = b->host_bbox[4 * p], c0 = b->host_bbox[4 * p + 1], rows = b->host_bbox[4 * p + 2], cols = b->host_bbox[4 * p + 3];
+        if (rows <= 0 || cols <= 0) continue;
+        const int pb0 = (r0 - b->vp[0]) / TR, pnb = (r0 + rows - 1 - b->vp[0]) / TR - pb0 + 1;
+        int ct0, pnct;
+        path_ctiles(c0, cols, b->vp[1], ct0, pnct);
+        if ((long long)pnb * pnct > (1ll << 28)) continue;
+        int bands_per, col_runs, n = 0;
+        slab_shape(pnb, pnct, bands_per, col_runs);
+        for (int bb = 0; bb < pnb; bb += bands_per) {
+            const int be = bb + bands_per < pnb ? bb + bands_per : pnb;
+            if (owns_any(b->own, pb0 + bb, pb0 + be - 1)) n += col_runs;
+        }
+        if (n == 0) continue;
+        n_sl[p] = n;
+        w[p] = (float)std::min(rows, bands_per * TR) + (float)cols / (float)col_runs;
+        order.push_back((int)p);
+        total += n;
+    }
+    if (total != b->n_slabs) return 0;  // (not the count the device found: leave the order to the cursor)
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return w[(size_t)a] > w[(size_t)c]; });
+    b->slab_at_host.assign(np, 0);
+    int at = 0;
+    for (int p : order) { b->slab_at_host[(size_t)p] = at; at += n_sl[(size_t)p]; }
+    if (int rc = b->slab_at.ensure(np)) return rc;
+    HIPCHK(hipMemcpyAsync(b->slab_at.p, b->slab_at_host.data(), sizeof(int) * np, hipMemcpyHostToDevice, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    b->slab_at_valid = true;
+    return 0;
+}
+
 static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
     if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
     HIPCHK(enter_ctx(b->ctx));
-    b->planned = false;
+    b->planned = false; b->slab_at_valid = false;
     b->geometry_fresh = false;
     {
         const bool no_spec = getenv("SVGR_NO_SPECULATIVE_PLAN") != nullptr;  // (tests exercise both planners)
@@ -3872,6 +3929,7 @@ static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
     if (int rc = check_dev_err(b, nullptr, true, true)) return rc;
     b->n_edges_live = b->n_edges;
     b->n_bsegs = b->host_bd.bseg_cursor;
+    if (int rc = plan_slab_order(b)) return rc;
     b->planned = true;
     b->geometry_fresh = true;
     return 0;
