@@ -15,11 +15,13 @@ import sys
 
 
 def regs_of(tok):
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    """registers a token names: VGPR n -> n, SGPR n -> 1000 + n (the scalar header load lands in SGPRs)"""
+    m = re.fullmatch(r"([vs])\[(\d+):(\d+)\]", tok)
     if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.fullmatch(r"v(\d+)", tok)
-    return {int(m.group(1))} if m else set()
+        base = 0 if m.group(1) == "v" else 1000
+        return set(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
+    m = re.fullmatch(r"([vs])(\d+)", tok)
+    return {(0 if m.group(1) == "v" else 1000) + int(m.group(2))} if m else set()
 
 
 def parse(line):
@@ -70,8 +72,12 @@ def check(name, text):
         i = work.pop()
         st = set(state_in[i])
         op, ops, is_asm, ln, raw = ins[i]
-        if is_asm and op.startswith("global_load"):
+        if is_asm and (op.startswith("global_load") or op.startswith("s_load")):
             st |= regs_of(ops[0])
+        elif is_asm and op == "s_waitcnt" and "lgkmcnt(0)" in raw:
+            st = {r for r in st if r < 1000}   # every scalar load has landed
+            if "vmcnt(0)" in raw:
+                st.clear()
         elif is_asm and op == "s_waitcnt" and "vmcnt" in raw:
             if "vmcnt(0)" in raw:
                 st.clear()
@@ -84,14 +90,14 @@ def check(name, text):
                 used |= regs_of(t)
             hit = used & st
             if hit:
-                bad[ln] = f"{name}: line {ln}: `{raw}` touches v{sorted(hit)} while a hand-issued load into it is in flight"
+                bad[ln] = f"{name}: line {ln}: `{raw}` touches {['s%d' % (r - 1000) if r >= 1000 else 'v%d' % r for r in sorted(hit)]} while a hand-issued load into it is in flight"
         out = frozenset(st)
         for j in succ[i]:
             new = out if state_in[j] is None else state_in[j] | out
             if new != state_in[j]:
                 state_in[j] = new
                 work.append(j)
-    loads = sum(1 for op, _o, a, _ln, _l in ins if a and op.startswith("global_load"))
+    loads = sum(1 for op, _o, a, _ln, _l in ins if a and (op.startswith("global_load") or op.startswith("s_load")))
     for ln in sorted(bad):
         print(bad[ln])
     return len(bad), loads
