@@ -92,6 +92,17 @@ struct TileAdd {
     double v;
 };
 static_assert(sizeof(TileAdd) == 16, "TileAdd is one dwordx4");
+__device__ __forceinline__ void store_add(TileAdd* p, unsigned where, double v) {
+#ifdef SVGR_NT_ADDS
+    typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
+    u32x4s_t w = {where, 0u, (unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
+    __builtin_nontemporal_store(w, (u32x4s_t*)p);
+#else
+    TileAdd t;
+    t.where = where; t.zero = 0u; t.v = v;
+    *p = t;
+#endif
+}
 // One (path, band, column tile) CELL = one work item of the tile kernel, written by k_pair_cells.
 // `carry[r]` = sum of every piece of the pair's row r that lies LEFT of the tile (the running sum the row
 // scan starts from, np.cumsum S:983); `cls` sorts the cells:
@@ -427,6 +438,17 @@ __device__ __forceinline__ bool edge_live(int e, const EdgeShards& sh, const Bat
     return e - sh.base[s] < filled;
 }
 
+__device__ __forceinline__ void store_edge(double* __restrict__ edges, int at, double r0, double c0, double r1, double c1) {
+    typedef double f64x2e_t __attribute__((ext_vector_type(2)));
+    f64x2e_t lo = {r0, c0}, hi = {r1, c1};
+    f64x2e_t* e = (f64x2e_t*)(edges + 4 * (size_t)at);
+#ifdef SVGR_NT_EDGES
+    __builtin_nontemporal_store(lo, e);
+    __builtin_nontemporal_store(hi, e + 1);
+#else
+    e[0] = lo; e[1] = hi;
+#endif
+}
 __device__ __forceinline__ void load_seg_points(const double* __restrict__ segs, int s, const double* __restrict__ m6,
                                                 int npts, double* c) {
     for (int k = 0; k < npts; ++k) {
@@ -619,15 +641,13 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
         if (!fits) {
             atomicOr(&bd->err, 2);
         } else if (mode == 1) {
-            double* e = edges + 4 * (size_t)base;
-            e[0] = node[0]; e[1] = node[1]; e[2] = node[6]; e[3] = node[7];
+            store_edge(edges, base, node[0], node[1], node[6], node[7]);
             edge_path[base] = p;
         } else if (cnt <= 2) {
-            double* e = edges + 4 * (size_t)base;
-            e[0] = node[0]; e[1] = node[1]; e[2] = q1r; e[3] = q1c;
+            store_edge(edges, base, node[0], node[1], q1r, q1c);
             edge_path[base] = p;
             if (cnt == 2) {
-                e[4] = q1r; e[5] = q1c; e[6] = q2r; e[7] = q2c;
+                store_edge(edges, base + 1, q1r, q1c, q2r, q2c);
                 edge_path[base + 1] = p;
             }
         } else {
@@ -639,8 +659,7 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
             bool o2 = false;
             flatten_subtree(node, thr, kMaxFlattenDepth - FL_SUB, [&](double r0, double c0, double r1, double c1) {
                 if (i < cnt) {
-                    double* e = edges + 4 * (size_t)(base + i);
-                    e[0] = r0; e[1] = c0; e[2] = r1; e[3] = c1;
+                    store_edge(edges, base + i, r0, c0, r1, c1);
                     edge_path[base + i] = p;
                 }
                 ++i;
@@ -1403,8 +1422,8 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             TileAdd* dst = adds + pos;
             const int cell_c0 = k * TC + x_first;  // layer column of the tile's column 0
             record_adds(ra.x0i, ra.n, ra.v, ca, cb,
-                        [&](int c, double val) { TileAdd tt; tt.where = add_where(trow, c - cell_c0, 1); tt.zero = 0u; tt.v = val; *dst++ = tt; },
-                        [&](int c, int len, double val) { TileAdd tt; tt.where = add_where(trow, c - cell_c0, len); tt.zero = 0u; tt.v = val; *dst++ = tt; });
+                        [&](int c, double val) { store_add(dst++, add_where(trow, c - cell_c0, 1), val); },
+                        [&](int c, int len, double val) { store_add(dst++, add_where(trow, c - cell_c0, len), val); });
         }
     };
 
@@ -1533,14 +1552,12 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             const int cell_c0 = (sl.k0 + k) * TC + x_first;       // layer column of the tile's column 0
             const unsigned below = (1u << row_l) - 1u;
             if (((cm >> row_l) & 1u) && adds) {
-                TileAdd t;
-                t.where = add_where(row_l, cell_c0 < 0 ? -cell_c0 : 0, 1); t.zero = 0u; t.v = cin;  // at the layer's first column in the tile
-                adds[(size_t)add0 + __popc(cm & below)] = t;
+                // at the layer's first column in the tile
+                store_add(adds + ((size_t)add0 + __popc(cm & below)), add_where(row_l, cell_c0 < 0 ? -cell_c0 : 0, 1), cin);
             }
             if (((sm >> row_l) & 1u) && adds) {
-                TileAdd t;
-                t.where = add_where(row_l, cols - cell_c0, 1); t.zero = 0u; t.v = __builtin_nan("");  // behind the layer's last column
-                adds[(size_t)add0 + n_carry + __popc(sm & below)] = t;
+                // behind the layer's last column
+                store_add(adds + ((size_t)add0 + n_carry + __popc(sm & below)), add_where(row_l, cols - cell_c0, 1), __builtin_nan(""));
             }
             if (row_l == 0) {
                 // the tiles' entry bitmasks: per (band, column tile) two rows of mask_words words, bit i = entry i of the band's
@@ -1850,6 +1867,18 @@ __device__ __forceinline__ void grad_colour_pixel(const GradDev& g, int row, int
 // ======================================================================================
 // tile kernel
 // ======================================================================================
+// nontemporal (streaming) stores of 16 / 32 bytes: for data this launch writes once and does not read again
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nt_store16(float4* p, const float4 v) {
+    f32x4_t nv = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(nv, (f32x4_t*)p);
+}
+__device__ __forceinline__ void nt_store32(double4* p, double a, double b, double c, double d) {
+    f64x2_t lo = {a, b}, hi = {c, d};
+    __builtin_nontemporal_store(lo, (f64x2_t*)p);
+    __builtin_nontemporal_store(hi, (f64x2_t*)p + 1);
+}
 template <int N>
 __device__ __forceinline__ double dpp_row_shr(double v) {  // lane i <- lane i-N inside a 16-lane row, else +0.0
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -1915,7 +1944,10 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     static_assert(!GROUPS || (CLIP && OUT <= 1), "groups live in the canvas variants with the clip tile");
     static_assert(!GRAD || GROUPS, "gradient entries live in the variant with the large register budget");
     constexpr int OFF_CLIP = 2 * DELTA_BYTES;                                // canvas modes: coverage tile of a clip path
-    constexpr int LDS_BYTES = OFF_CLIP + (CLIP ? DELTA_BYTES : 0);
+#ifndef SVGR_DBG_TILE_PADLDS
+#define SVGR_DBG_TILE_PADLDS 0          // diagnostic: extra LDS per workgroup (occupancy experiment)
+#endif
+    constexpr int LDS_BYTES = OFF_CLIP + (CLIP ? DELTA_BYTES : 0) + SVGR_DBG_TILE_PADLDS;
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[LDS_BYTES];
     int clip_tag = -1;  // path whose coverage the clip tile holds (canvas modes)
 
@@ -2409,7 +2441,14 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
                 const int vrow = band * TR + tr_, orow = by * TR + tr_ - a.win_r;
                 if (vrow < a.vrows && orow >= 0 && orow < a.win_rows && col_ok) {
                     const float4 v = tp[tr_ * T_ROW + lane + lane / PX];
+                    // The canvas is written once and not read again by this launch: a NONTEMPORAL store.  A wave ends only when its
+                    // stores are acknowledged (s_endpgm waits for them), so the write latency is slot time of every workgroup: the
+                    // plain store's was 30 us of the launch (162 -> 132 us, A/B on one box; without any store: 116).
+#ifdef SVGR_DBG_PLAIN_STORE
                     ((float4*)a.out)[(size_t)orow * a.out_cols + col] = v;
+#else
+                    nt_store16((float4*)a.out + ((size_t)orow * a.out_cols + col), v);
+#endif
                 }
             }
             (void)row; (void)out_row;
@@ -2419,7 +2458,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
             for (int i = 0; i < PX; ++i) {
                 if (col0 + i >= 0 && col0 + i < a.win_cols) {
                     size_t o = (size_t)out_row * a.out_cols + col0 + i;
-                    ((double4*)a.out)[o] = make_double4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+                    nt_store32((double4*)a.out + o, acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
                 }
             }
         }
