@@ -2066,8 +2066,13 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
         return __hiloint2double(hi, lo);
     };
 #define SVGR_HDR_LOAD(tgt, ptr) asm volatile("global_load_dword %0, %1, off" : "=v"(tgt) : "v"(ptr) : "memory")
+#ifdef SVGR_DBG_ADD_LOAD_NT
+#define SVGR_ADD_NT " nt"       // diagnostic: the add lists are read once -- a nontemporal load
+#else
+#define SVGR_ADD_NT ""
+#endif
 #define SVGR_ADD_LOAD(tw, tv, ptr)                                                                                     \
-    asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:8" : "=&v"(tw), "=&v"(tv) : "v"(ptr) : "memory")
+    asm volatile("global_load_dwordx2 %0, %2, off" SVGR_ADD_NT "\n\tglobal_load_dwordx2 %1, %2, off offset:8" SVGR_ADD_NT : "=&v"(tw), "=&v"(tv) : "v"(ptr) : "memory")
 #define SVGR_HDR_TAKE(n, dst, tgt) asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, %1" : "=v"(dst) : "v"(tgt) : "memory")
 #define SVGR_ADD_TAKE(n, dw, dv, tw, tv)                                                                               \
     asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(dw), "=&v"(dv) : "v"(tw), "v"(tv) : "memory")
@@ -2082,7 +2087,11 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
 #endif
         if (hdr_cls(h) != 2) return;
         if (a.det && wave != 0) return;
-        const int n_add = __builtin_amdgcn_readlane(h, 13), add0 = __builtin_amdgcn_readlane(h, 14);
+        int n_add = __builtin_amdgcn_readlane(h, 13);
+        const int add0 = __builtin_amdgcn_readlane(h, 14);
+#ifdef SVGR_DBG_SCATTER_FIRST
+        n_add = n_add < NT ? n_add : NT;   // diagnostic: what the adds beyond a lane's first (loaded inside the scatter) cost
+#endif
         unsigned char* const base = s_mem + buf * DELTA_BYTES;
         const int i_step = a.det ? 64 : NT;
         for (int i = tid; i < n_add; i += i_step) {
