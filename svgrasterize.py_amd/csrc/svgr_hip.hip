@@ -777,6 +777,12 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
     const int pi = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const int p = plist ? (pi < n_paths ? plist[pi] : 0x7fffffff) : pi;
     if (plist) n_paths = pi < n_paths ? 0x7fffffff : 0;  // (p < n_paths below = "this thread has a path")
+    // (the path's edge range, for its slabs: asked for here, with the keys -- two dependent loads that used to follow the wave's
+    //  reservations)
+    int e_begin = 0, e_end = 0;
+    if (slabs && p < n_paths) {
+        e_begin = seg_off[path_seg0[p]]; e_end = seg_off[path_seg0[p + 1]];
+    }
     int out[4] = {0, 0, 0, 0};
     int pb0 = 0, pnb = 0, pnct = 0;
     int st_n = 0;
@@ -892,7 +898,6 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
         } else {
             int at = slab0;
             // the path's edges (k_flatten); a pass whose edge array was too small (flagged there) must not be read beyond it
-            int e_begin = seg_off[path_seg0[p]], e_end = seg_off[path_seg0[p + 1]];
             e_begin = e_begin < edge_cap ? e_begin : edge_cap;
             e_end = e_end < edge_cap ? e_end : edge_cap;
             for (int bb = 0; bb < pnb; bb += bands_per) {
