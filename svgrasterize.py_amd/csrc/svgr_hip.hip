@@ -1237,6 +1237,11 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     const int sr0 = vr0 + sl.band0 * TR - r0, sr1 = sr0 + sl.nb * TR;  // layer rows of the slab
     const int n_cell = sl.nb * sl.nk;
     const double o_r = (double)r0, o_c = (double)c0;  // `lines - [min_x, min_y]` (S:979)
+    // (what the later phases need of the path -- scalar loads: asked for here, not behind a barrier each)
+    const int rl = path_rule[p], rule = rl & 1;
+    const int group = path_group ? path_group[p] : -1;
+    const int grad1 = path_grad ? path_grad[p] + 1 : 0;  // gradient index + 1 (0: solid colour)
+    const double4 paint = ((const double4*)path_paint)[p];
     for (int i = tid; i < n_cell * TR; i += PB_THREADS) s_sum[i] = 0.0;
     for (int i = tid; i < n_cell; i += PB_THREADS) { s_cnt[i] = 0; s_pos[i] = (int)0x80000000; s_info[i] = make_int2(0, 0); }
     if (tid < TR) s_left[tid] = 0.0;
@@ -1466,7 +1471,6 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
 #ifdef SVGR_DBG_PB_NOSCAN
     if (n_rows != 123456789) return;
 #endif
-    const int rl = path_rule[p], rule = rl & 1;
     {
         // walk: TR lanes per band of the slab (lane = tile row) go through the band's cells left to right.  The row's running
         // sum replaces the cell's sum in s_sum (what phase 2 needs is the carry-in); per cell: class, adds, and which rows have a
@@ -1513,9 +1517,13 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         // the slab's reservation of add slots: ONE atomic, in the path's shard
         if (row_l == 0 && g < PB_BANDS) s_ptot[g] = active ? cursor : 0;
         __syncthreads();
-        if (tid == 0) {
-            int all = 0;
-            for (int q = 0; q < sl.nb; ++q) { const int c = s_ptot[q]; s_ptot[q] = all; all += c; }  // -> the bands' offsets
+        if (tid < 64) {  // the bands' offsets: an exclusive scan over <= PB_BANDS totals by the first wave
+            static_assert(PB_BANDS <= 64, "one lane per band of the slab");
+            const int c = tid < sl.nb ? s_ptot[tid] : 0;
+            int all;
+            const int ex = wave_excl_scan(c, tid, all);
+            if (tid < sl.nb) s_ptot[tid] = ex;
+            if (tid == 0) {
             const int sh = p % ash.n;  // (by path, not by slab: the slabs' order changes from pass to pass, the plan's shard sizes must hold)
             int at = 0;
             if (all > 0) at = atomicAdd(&bd->shard[sh].add_cursor, all);
@@ -1523,6 +1531,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             if (adds && (long long)at + all > (long long)ash.cap[sh]) { atomicOr(&bd->err, 64); ok = 0; }
             s_base = ash.base[sh] + at;
             s_ok = ok;
+            }
         }
         __syncthreads();
     }
@@ -1530,9 +1539,6 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     {
         // write: one lane per (cell, tile row) -- headers, carry-ins and sentinels, the entry-bitmask bits; no lane idles
         // through a band that does not exist
-        const int group = path_group ? path_group[p] : -1;
-        const int grad1 = path_grad ? path_grad[p] + 1 : 0;  // gradient index + 1 (0: solid colour)
-        const double4 paint = ((const double4*)path_paint)[p];
         const bool slab_ok = s_ok != 0;
         for (int i = tid; i < n_cell * TR; i += PB_THREADS) {
             const int ci = i / TR, row_l = i & (TR - 1);
