@@ -147,20 +147,21 @@ SVGR_HD int flatten_cubic(const double* cubic, double thr, Emit&& emit) {
 // `overflow` when `max_depth` forced a piece out (non-finite / absurd input).
 // `ends` (optional): the end points of the first two pieces {r1, c1, r2, c2}, so that a caller that first counts and then
 // stores can skip the second traversal for the (very common) subtrees of one or two pieces.
-template <class Emit>
+// (`NE`: how many first end points `ends` receives, {r, c} each)
+template <int NE = 2, class Emit>
 SVGR_HD int flatten_subtree(const double* root, double thr, int max_depth, Emit&& emit, bool& overflow, double* ends = nullptr) {
     double cur[8];
     for (int i = 0; i < 8; ++i) cur[i] = root[i];
     int level = 0, n = 0;
     unsigned long long idx = 0;
-    double e0r = 0.0, e0c = 0.0, e1r = 0.0, e1c = 0.0;
+    double er[NE], ec[NE];
+    for (int k = 0; k < NE; ++k) er[k] = ec[k] = 0.0;
     for (;;) {
         bool flat = cubic_flatness(cur) < thr;
         if (!flat && level >= max_depth) { flat = true; overflow = true; }
         if (flat) {
             emit(cur[0], cur[1], cur[6], cur[7]);
-            e0r = n == 0 ? cur[6] : e0r; e0c = n == 0 ? cur[7] : e0c;
-            e1r = n == 1 ? cur[6] : e1r; e1c = n == 1 ? cur[7] : e1c;
+            for (int k = 0; k < NE; ++k) { er[k] = n == k ? cur[6] : er[k]; ec[k] = n == k ? cur[7] : ec[k]; }
             ++n;
             while (level > 0 && (idx & 1ull)) { idx >>= 1; --level; }
             if (level == 0) break;
@@ -175,7 +176,8 @@ SVGR_HD int flatten_subtree(const double* root, double thr, int max_depth, Emit&
             idx <<= 1;
         }
     }
-    if (ends) { ends[0] = e0r; ends[1] = e0c; ends[2] = e1r; ends[3] = e1c; }
+    if (ends)
+        for (int k = 0; k < NE; ++k) { ends[2 * k] = er[k]; ends[2 * k + 1] = ec[k]; }
     return n;
 }
 

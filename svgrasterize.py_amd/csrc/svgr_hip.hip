@@ -519,7 +519,10 @@ __global__ __launch_bounds__(256) void k_seg_select(const int* __restrict__ seg_
 constexpr int FL_SUB = SVGR_FL_SUB;       // 32 lanes per segment: the longest lane bounds the kernel, so cut subtrees small
 constexpr int FL_BLOCK = 256;     // waves are independent (no block-level step)
 template <bool EMIT>
-__global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__ segs, const uint8_t* __restrict__ kind,
+#ifndef SVGR_FL_WAVES
+#define SVGR_FL_WAVES 1
+#endif
+__global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const double* __restrict__ segs, const uint8_t* __restrict__ kind,
                                                  const int* __restrict__ seg_path, const double* __restrict__ path_m6,
                                                  int n_segs, double thr, double* __restrict__ edges,
                                                  int* __restrict__ edge_path, const EdgeShards sh,
@@ -599,7 +602,12 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
     };
     int cnt = 0;
     bool ovf = false;
-    double q1r = 0.0, q1c = 0.0, q2r = 0.0, q2c = 0.0;
+#ifndef SVGR_FL_ENDS
+#define SVGR_FL_ENDS 4
+#endif
+    constexpr int FL_ENDS = SVGR_FL_ENDS;  // pieces a lane remembers from its counting traversal (a wave skips the second one when all its lanes fit)
+    double qe[2 * FL_ENDS];
+    for (int k = 0; k < 2 * FL_ENDS; ++k) qe[k] = 0.0;
     if (mode == 1) {
         cnt = 1;
         track(node[0], node[1]);
@@ -608,9 +616,7 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
         // pieces come in curve order and share end points: track the first start and every end.  The ends of the
         // first two pieces are remembered: nearly every lane has one or two, and then the second traversal is skipped.
         track(node[0], node[1]);
-        double ends[4];
-        cnt = flatten_subtree(node, thr, kMaxFlattenDepth - FL_SUB, [&](double, double, double r1, double c1) { track(r1, c1); }, ovf, ends);
-        q1r = ends[0]; q1c = ends[1]; q2r = ends[2]; q2c = ends[3];
+        cnt = flatten_subtree<FL_ENDS>(node, thr, kMaxFlattenDepth - FL_SUB, [&](double, double, double r1, double c1) { track(r1, c1); }, ovf, qe);
     }
     if (ovf) atomicOr(&bd->err, 1);
     if (!keep) cnt = 0;
@@ -643,13 +649,15 @@ __global__ __launch_bounds__(FL_BLOCK) void k_flatten(const double* __restrict__
         } else if (mode == 1) {
             store_edge(edges, base, node[0], node[1], node[6], node[7]);
             edge_path[base] = p;
-        } else if (cnt <= 2) {
-            store_edge(edges, base, node[0], node[1], q1r, q1c);
+        } else if (cnt <= FL_ENDS) {
+            store_edge(edges, base, node[0], node[1], qe[0], qe[1]);
             edge_path[base] = p;
-            if (cnt == 2) {
-                store_edge(edges, base + 1, q1r, q1c, q2r, q2c);
-                edge_path[base + 1] = p;
-            }
+#pragma unroll
+            for (int k = 1; k < FL_ENDS; ++k)
+                if (k < cnt) {
+                    store_edge(edges, base + k, qe[2 * k - 2], qe[2 * k - 1], qe[2 * k], qe[2 * k + 1]);
+                    edge_path[base + k] = p;
+                }
         } else {
 #ifdef SVGR_DBG_NO_SECOND_TRAVERSAL
             if (cnt > 1000000)  // diagnostic: what the second traversal costs (edges of long lanes are left unwritten)
