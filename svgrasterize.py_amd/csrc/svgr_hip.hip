@@ -3879,6 +3879,7 @@ static int plan_slab_order(svgr_batch* b) {
 #ifdef SVGR_DBG_NO_SLAB_ORDER
     return 0;
 #endif
+    if (getenv("SVGR_NO_SLAB_ORDER")) return 0;  // (tests: the renders then take their slab places from the cursor, in arrival order)
     const size_t np = (size_t)b->n_paths;
     if (np == 0 || b->host_bbox.size() < 4 * np || b->n_slabs <= 0 || b->vp[2] <= 0) return 0;
     std::vector<int> n_sl(np, 0), order;

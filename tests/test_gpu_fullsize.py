@@ -131,6 +131,40 @@ def test_deterministic_render_is_bit_reproducible(S):
     assert_close64(canv[0], ref, atol=1e-10, what="deterministic render vs oracle")
 
 
+def test_planned_slab_places_do_not_change_the_picture(S, monkeypatch):
+    """The staged plan hands every path its slabs' places in k_path_build's work list (heaviest first: host arithmetic that
+    must mirror k_path_bbox's).  With and without it (SVGR_NO_SLAB_ORDER: places from the device's cursor) a deterministic
+    render gives the same bits -- on the whole drawing and on one rank's bands of a two-rank sharding (slabs without an
+    owned band are left out of both counts)."""
+    from svgrasterize_amd import _abi, synth
+
+    size, n = 2048, 1500
+    sc = synth.make_scene(size, n)
+    ctx = S.Context.get()
+    flags = _abi.RENDER_CLIP01 | _abi.RENDER_DETERMINISTIC
+
+    def render(bands):
+        batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
+                           viewport=sc["viewport"])
+        if bands:
+            batch.set_bands(*bands)
+        batch.plan()
+        rows = batch.owned_rows() if bands else size
+        out = ctx.alloc(max(rows, 1) * size * 32)
+        batch.render(out, _abi.OUT_CANVAS_F64, flags)
+        got = out.download((rows, size, 4), np.float64)
+        batch.destroy()
+        return got
+
+    for bands in (None, (1, 2, 16)):
+        monkeypatch.delenv("SVGR_NO_SLAB_ORDER", raising=False)
+        a = render(bands)
+        monkeypatch.setenv("SVGR_NO_SLAB_ORDER", "1")
+        b = render(bands)
+        assert np.abs(a).max() > 0
+        assert np.array_equal(a, b), f"slab places change the picture (bands {bands})"
+
+
 def test_synth_8192_config4_windows(S):
     """BASELINE config 4 (10 000 random cubic paths @ 8192x8192) on one GPU: more paths than one band-list pass keeps in
     registers, 6 M record slots, a 1 GiB canvas.  Windows of the canvas against the CPU oracle rendered through the
