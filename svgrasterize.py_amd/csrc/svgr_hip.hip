@@ -1157,6 +1157,13 @@ __device__ __forceinline__ int lds_col(int tcol) {
 __device__ __forceinline__ int lds_index(int trow, int tcol) {
     return __mul24(trow, ROW_STRIDE) + lds_col(tcol);
 }
+// A run of equal adds is cut at the borders of the PX-column chunks of a tile row: how many pieces `len` columns from tile column
+// `tcol` make.  (The tile kernel's lanes walk a run one column at a time while the rest of the wave waits: a shallow edge's
+// run of 60 columns held its wave for 60 rounds.  Cut to a chunk a run is at most PX columns, its pieces go to different
+// lanes -- an item's add list rarely fills the workgroup -- and a piece never steps over the padding behind a chunk.)
+__device__ __forceinline__ int run_pieces(int tcol, int len) {
+    return ((tcol + len - 1) / PX) - (tcol / PX) + 1;
+}
 // TileAdd::where of `len` adds starting at (tile row, tile column)
 __device__ __forceinline__ unsigned add_where(int trow, int tcol, int len) {
     return (unsigned)(lds_index(trow, tcol) * 8) | ((unsigned)(len - 1) << 16) | ((unsigned)(tcol & (PX - 1)) << 22);
@@ -1413,8 +1420,9 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             tile_cols(k, ca, cb);
             int ne = 0;
             double part = 0.0;
+            const int cell_c0 = k * TC + x_first;  // layer column of the tile's column 0
             record_adds(ra.x0i, ra.n, ra.v, ca, cb, [&](int, double val) { ++ne; part = part + val; },
-                        [&](int, int len, double val) { ++ne; part = part + (double)len * val; });
+                        [&](int c, int len, double val) { ne += run_pieces(c - cell_c0, len); part = part + (double)len * val; });
             if (ne == 0) continue;
             const int ci = bl * sl.nk + (k - sl.k0);
             __hip_atomic_fetch_add(&s_cnt[ci], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1432,16 +1440,24 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             int ca, cb;
             tile_cols(k, ca, cb);
             int ne = 0;
-            record_adds(ra.x0i, ra.n, ra.v, ca, cb, [&](int, double) { ++ne; }, [&](int, int, double) { ++ne; });
+            const int cell_c0 = k * TC + x_first;  // layer column of the tile's column 0
+            record_adds(ra.x0i, ra.n, ra.v, ca, cb, [&](int, double) { ++ne; },
+                        [&](int c, int len, double) { ne += run_pieces(c - cell_c0, len); });
             if (ne == 0) continue;
             const int ci = bl * sl.nk + (k - sl.k0);
             const int pos = __hip_atomic_fetch_add(&s_pos[ci], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (pos < 0) continue;  // (the cell was refused by the scan: flagged there)
             TileAdd* dst = adds + pos;
-            const int cell_c0 = k * TC + x_first;  // layer column of the tile's column 0
             record_adds(ra.x0i, ra.n, ra.v, ca, cb,
                         [&](int c, double val) { store_add(dst++, add_where(trow, c - cell_c0, 1), val); },
-                        [&](int c, int len, double val) { store_add(dst++, add_where(trow, c - cell_c0, len), val); });
+                        [&](int c, int len, double val) {
+                            int tc = c - cell_c0;
+                            while (len > 0) {  // (one piece per chunk of PX columns)
+                                const int n = len < PX - (tc & (PX - 1)) ? len : PX - (tc & (PX - 1));
+                                store_add(dst++, add_where(trow, tc, n), val);
+                                tc += n; len -= n;
+                            }
+                        });
         }
     };
 
@@ -2123,14 +2139,10 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
             }
             unsigned off = w & 0xffffu;
             __hip_atomic_fetch_add((double*)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            int more = (int)((w >> 16) & 63u);
-            if (more) {  // a run: the same value into the next `more` columns, stepping over the padding behind every chunk
-                int c8 = (int)((w >> 22) & 7u);
-                for (; more > 0; --more) {
-                    off += 8u;
-                    if (++c8 == PX) { c8 = 0; off += (CHUNK_STRIDE - PX) * 8u; }
-                    __hip_atomic_fetch_add((double*)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+            // a run: the same value into the next `more` columns -- at most PX - 1, all inside the chunk (k_path_build cuts runs there)
+            for (int more = (int)((w >> 16) & 63u); more > 0; --more) {
+                off += 8u;
+                __hip_atomic_fetch_add((double*)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     };
