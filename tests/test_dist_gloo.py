@@ -179,3 +179,65 @@ def test_rows_subscene_keeps_exactly_what_can_reach_the_block():
         assert np.array_equal(sub["segs"][: sub["path_seg_off"][1]], tall["segs"][off[k0]: off[k0 + 1]])
         assert np.array_equal(sub["path_paint"], tall["path_paint"][kept]) and np.array_equal(sub["path_rule"], tall["path_rule"][kept])
     assert seen.min() >= 1 and seen.max() >= 2  # every path somewhere, border paths in two blocks
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    """bench.py's N > 1 branch on the real back-end, with the one rank a one-GPU box can give RCCL: torch first, the process
+    group on `nccl` with a device id, the render straight into a torch CUDA tensor (ctx.wrap), barrier / all_reduce on GPU
+    tensors, and the strips gathered into the canvas rows by all_gather_into_tensor on the device."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    import svgrasterize_amd as S
+    from svgrasterize_amd import _abi, dist as sdist, synth
+
+    ctx = S.Context.get(0)
+    sc = synth.make_scene(GPU_SIZE, GPU_PATHS)
+    tr = _abi.tile_rows()
+    strip = sdist.default_strip_bands(GPU_SIZE, tr, world)
+    batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
+                       viewport=sc["viewport"])
+    batch.set_bands(rank, world, strip)
+    batch.plan()
+    own = batch.owned_rows()
+    out_t = torch.empty((own, GPU_SIZE, 4), dtype=torch.float32, device="cuda:0")
+    out = ctx.wrap(out_t.data_ptr(), out_t.numel() * 4)
+    batch.render(out, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
+    ctx.sync()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device="cuda:0")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert t.item() == world
+    full = sdist.gather_canvas(out_t, GPU_SIZE, tr, strip=strip)
+    staged = sdist.gather_canvas_staged(out_t, GPU_SIZE, tr, strip=strip)
+    torch.cuda.synchronize()
+    assert torch.equal(full, staged)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "full_rccl.npy"), full.cpu().numpy())
+    dist.barrier()
+    batch.destroy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_one_rank_rccl_group_runs_the_bench_collectives(tmp_path):
+    """`init_process_group("nccl")` and every collective bench.py --gpus N issues, on RCCL itself -- with world size 1, which is
+    what a box with one GPU can give it (RCCL refuses two ranks on one device; the N = 2 data path runs under gloo above)."""
+    import torch.multiprocessing as mp
+
+    from oracle import oracle as orc
+    from svgrasterize_amd import synth
+
+    port = _free_port()
+    mp.spawn(_rccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    got = np.load(tmp_path / "full_rccl.npy")
+    sc = synth.make_scene(GPU_SIZE, GPU_PATHS)
+    ref, _, _ = orc.render_solid(synth.presentation_segs(sc), sc["seg_kind"], sc["path_seg_off"], sc["path_rule"],
+                                 sc["path_paint"], sc["viewport"], clip01=True)
+    assert_f32_1ulp(got, ref, what="1-rank RCCL canvas")
