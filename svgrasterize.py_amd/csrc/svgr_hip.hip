@@ -971,7 +971,10 @@ static_assert(sizeof(TileEntry) == 32, "TileEntry is 32 bytes");
 // One workgroup per owned band, after k_path_bbox: the ascending (= paint order) list of the paths whose bbox reaches the
 // band (TileEntry), and the band's first tile-list slot (one slot per cell of a listed pair: k_tile_lists fills them).
 // A pair's place in its band's list is the bit that stands for it in the tiles' entry bitmasks.
-constexpr int BE_BLOCK = 1024;
+#ifndef SVGR_BE_BLOCK
+#define SVGR_BE_BLOCK 1024
+#endif
+constexpr int BE_BLOCK = SVGR_BE_BLOCK;
 constexpr int BE_KEEP = 4;   // 64-path groups per wave whose bins stay in registers between the two passes
 __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __restrict__ bins, int n_paths,
                                                               const int* __restrict__ plist,  // multi-GPU: the n_paths paths of this rank, ascending (else nullptr: all)
@@ -1651,7 +1654,10 @@ struct TileSlot {
 // instruction fetches (a lane each).  Tile and items used to be two dependent round trips in front of the first header.
 constexpr int PAGE_ITEMS = 24, PAGE_STRIDE = PAGE_ITEMS + 1;
 static_assert(PAGE_STRIDE <= 64, "a page is one 16-byte load per lane");
-constexpr int TL_BLOCK = 1024;
+#ifndef SVGR_TL_BLOCK
+#define SVGR_TL_BLOCK 1024
+#endif
+constexpr int TL_BLOCK = SVGR_TL_BLOCK;
 __device__ __forceinline__ int select_bit(unsigned long long m, int r) {  // position of the r-th (0-based) set bit of m
     unsigned x = (unsigned)m;
     int pos = 0;
