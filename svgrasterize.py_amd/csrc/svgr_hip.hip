@@ -1201,7 +1201,7 @@ static_assert(sizeof(EdgeLds) == 32, "EdgeLds is two 16-byte LDS reads (its firs
 #define SVGR_PB_EPL 2
 #endif
 #ifndef SVGR_PB_KEEP
-#define SVGR_PB_KEEP 2
+#define SVGR_PB_KEEP 3
 #endif
 constexpr int PB_EPL = SVGR_PB_EPL;                // edges per lane and batch
 constexpr int PB_BATCH = PB_THREADS * PB_EPL;      // edges staged together
