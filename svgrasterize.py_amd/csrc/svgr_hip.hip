@@ -1201,7 +1201,7 @@ static_assert(sizeof(EdgeLds) == 32, "EdgeLds is two 16-byte LDS reads (its firs
 #define SVGR_PB_EPL 2
 #endif
 #ifndef SVGR_PB_KEEP
-#define SVGR_PB_KEEP 3
+#define SVGR_PB_KEEP 4
 #endif
 constexpr int PB_EPL = SVGR_PB_EPL;                // edges per lane and batch
 constexpr int PB_BATCH = PB_THREADS * PB_EPL;      // edges staged together
@@ -1352,9 +1352,10 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     };
     // What is kept of a row between the passes: where the edge enters and leaves it, its signed height, its place (7 registers;
     // the pieces themselves are 13, and three rounds of them cost the kernel a workgroup per CU).  Pass B recomputes the pieces.
+    // (x_next is not kept: it is x + dxdy * |d| -- row_step's own expression, |d| = dy exactly -- with dxdy one LDS read away)
     struct RowKey {
-        double x, x_next, d;
-        int where;   // bl | trow << 8
+        double x, d;
+        int where;   // bl | trow << 8 | staged edge << 16
     };
     auto row_key = [&](int t) -> RowKey {
         RowKey rk;
@@ -1368,19 +1369,21 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         st.x_next = el.x; st.x = el.x; st.d = 0.0;
         for (int yy = ya; yy <= y; ++yy) row_step(st, yy, el.p0y, el.p1y, el.dxdy, dir);
         const int vrow = r0 + y - vr0, band = vrow / TR;
-        rk.x = st.x; rk.x_next = st.x_next; rk.d = st.d;
-        rk.where = (band - sl.band0) | ((vrow & (TR - 1)) << 8);
+        rk.x = st.x; rk.d = st.d;
+        static_assert(PB_BATCH <= (1 << 15), "a RowKey carries its staged edge in 15 bits");
+        rk.where = (band - sl.band0) | ((vrow & (TR - 1)) << 8) | (slot << 16);
         return rk;
     };
     auto row_at = [&](const RowKey& rk) -> RowAt {
         RowAt ra;
-        const RowPieces rp = row_record(rk.x, rk.x_next, rk.d);
+        const double x_next = rk.x + s_edge[rk.where >> 16].dxdy * fabs(rk.d);
+        const RowPieces rp = row_record(rk.x, x_next, rk.d);
         ra.x0i = rp.x0i; ra.n = rp.n;
         ra.v[0] = rp.v[0]; ra.v[1] = rp.v[1]; ra.v[2] = rp.v[2]; ra.v[3] = rp.v[3]; ra.v[4] = rp.v[4];
         if ((unsigned)ra.n > SPAN_MAX) { atomicOr(&bd->err, 16); ra.n = (int)SPAN_MAX; }
         const int band = sl.band0 + (rk.where & 0xff);
         const bool live = owns_band(own, band) && rp.x0i < cols;  // (another rank's band; a row wholly beyond the layer, S:2260)
-        ra.where = rk.where | ((int)live << 16);
+        ra.where = (rk.where & 0xffff) | ((int)live << 16);
         return ra;
     };
     auto row_of = [&](int t) -> RowAt { return row_at(row_key(t)); };
