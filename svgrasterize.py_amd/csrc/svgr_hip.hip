@@ -1,35 +1,34 @@
 // svgr_hip.hip -- MI355X (gfx950 / CDNA4) anti-aliased path rasterizer: HIP kernels + C ABI.
 //
-// Pipeline of one svgr_batch_render (8 launches on the context stream, no host read-back):
+// Pipeline of one svgr_batch_render (6 launches on the context stream, no host read-back):
 //
 //   [memsets]       zero-fill of the batch's counter arena and of the tiles' entry bitmasks: only for the first render
 //                   after a plan, later ones find both cleared by the previous render's kernels
-//   [k_path_rows]   multi-GPU only: rows each path's control-point hull can reach (foreign paths are skipped)
-//   k_flatten       32 lanes per segment: transform (fma form), stack-free adaptive subdivision,
-//                   count -> wave prefix -> ONE reservation per wave in one of 16 edge-cursor shards ->
-//                   store the pieces; endpoints folded into per-path min/max keys
-//   k_path_bbox     per path: integer bbox (floor-1 / ceil+1, clipped to the viewport), band range,
-//                   wave-aggregated reservation of its (path, band) pair slots and (path, band, column tile) cells
-//   k_edge_count    per edge: which 16-row bands it crosses -> per-pair record counts (run-aggregated atomics)
-//   k_band_entries  per band: ordered entry list of the pairs with records, reservation of their record
-//                   blocks and add blocks (contiguous per band), first item slot of the band
-//   k_edge_emit     per edge: walk its rows with the reference's x recurrence; one 48-byte record per
-//                   row with the closed-form signed-area pieces, stored through an LDS transpose
-//   k_pair_cells    per pair: the carry-in of every tile row (sum of the pieces left of the tile), the class of every
-//                   cell (nothing visible / constant per row / has records), the tiles' entry bitmasks, and -- for the
-//                   cells with records -- the cell's ADD LIST: every piece, carry-in and layer-edge sentinel resolved to
+//   [k_path_rows]   multi-GPU plans only: rows each path's control-point hull can reach (a rank lists its share)
+//   k_flatten       32 lanes per segment: transform (fma form), stack-free adaptive subdivision; the edges go to the
+//                   plan's per-segment prefix sums -- (path, segment, curve) order, no returning atomic; endpoints
+//                   folded into per-path min/max keys
+//   k_path_bbox     per path: integer bbox (floor-1 / ceil+1, clipped to the viewport), band range, its (path, band)
+//                   pair slots and (path, band, column tile) cells, and its SLABS -- runs of <= 16 bands x <= 120
+//                   column tiles of cells -- at the plan's heaviest-first places
+//   k_band_entries  per band: the paths whose bbox reaches it, in paint order; the band's first item slot
+//   k_path_build    per slab, everything in LDS: per edge row the closed-form signed-area pieces (the reference's x
+//                   recurrence replayed from the edge's first row), per cell the carry-in of every tile row, its
+//                   class (nothing visible / constant per row / has pieces), header, entry-bitmask bits and -- for
+//                   the cells with pieces -- its ADD LIST: every piece, carry-in and layer-edge sentinel resolved to
 //                   {offset in the tile's delta tile, value}, so that the tile kernel's scatter is one load + one LDS add
-//   k_tile_lists    per band: bitmasks -> per-tile item lists (cell ids in paint order), the tiles in heaviest-first
-//                   order; clears the bitmasks for the next render
+//   k_tile_lists    per band: bitmasks -> per-tile item lists (cell ids in paint order, each with its add list), the
+//                   tiles in heaviest-first order, one PAGE per tile (which tile + its first 24 items: one load);
+//                   clears the bitmasks for the next render
 //   k_tile_render   one 128-thread workgroup per 16x64 canvas tile, canvas tile resident in registers as
 //                   double RGBA; per item in paint order: header and add list prefetched into registers items ahead;
 //                   the adds of item k+1 go into one LDS delta tile (ds_add_f64) while item k's is scanned
 //                   (8 px per lane serial + DPP row scan across the 8 lanes of a row), fill rule, paint, source-over
 //                   (isolated groups in a second register tile); one barrier per item; the finished tile leaves
-//                   through an LDS transpose as whole 1-KiB rows (float32) or as double
+//                   through an LDS transpose as whole 1-KiB rows (float32, nontemporal) or as double
 //
 // There is no dense contraction anywhere in this path: no MFMA.  The heavy traffic (delta tile,
-// canvas tile) never leaves the CU; HBM sees the edge records, the add lists and one canvas store.
+// canvas tile) never leaves the CU; HBM sees the edges, the cell headers, the add lists and one canvas store.
 //
 // gfx950 only.  Compile with -ffp-contract=off (see svgr_core.h).
 #include <hip/hip_runtime.h>
