@@ -1242,8 +1242,15 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     if (vr0 == -123457) cell_cap = s_padlds[3];
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if ((int)blockIdx.x >= bd->slab_cursor) return;  // (the grid covers the plan's slab capacity)
+    // (the LDS tables are cleared whole, not just the slab's part of them: that needs nothing of the slab, so it runs while the
+    //  slab record is on its way)
+    for (int i = tid; i < PB_CELLS * TR / 2; i += PB_THREADS) ((double2*)s_sum)[i] = make_double2(0.0, 0.0);
+    for (int i = tid; i < PB_CELLS; i += PB_THREADS) { s_cnt[i] = 0; s_pos[i] = (int)0x80000000; s_info[i] = make_int2(0, 0); }
+    if (tid < TR) s_left[tid] = 0.0;
+    // (both scalar loads asked for together: the slab first, the test of the cursor behind it -- the grid never exceeds the list)
     const Slab sl = slabs[blockIdx.x];
+    const int n_slabs_now = bd->slab_cursor;
+    if ((int)blockIdx.x >= n_slabs_now) return;  // (the grid covers the plan's slab capacity)
     if (sl.nb <= 0 || sl.nk <= 0) return;  // (a slot of a path that did not fit the slab list: flagged by k_path_bbox)
     const int p = sl.p;
     const int r0 = sl.r0, c0 = sl.c0, rows = sl.rows, cols = sl.cols;
@@ -1259,9 +1266,6 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     const int group = path_group ? path_group[p] : -1;
     const int grad1 = path_grad ? path_grad[p] + 1 : 0;  // gradient index + 1 (0: solid colour)
     const double4 paint = ((const double4*)path_paint)[p];
-    for (int i = tid; i < n_cell * TR; i += PB_THREADS) s_sum[i] = 0.0;
-    for (int i = tid; i < n_cell; i += PB_THREADS) { s_cnt[i] = 0; s_pos[i] = (int)0x80000000; s_info[i] = make_int2(0, 0); }
-    if (tid < TR) s_left[tid] = 0.0;
 
     // a batch of edges (slot = tid + j * PB_THREADS): set up, rows inside the slab counted, prefix sums -> number of
     // (edge, row) tasks of the batch; the first PB_TAB tasks find their slot in s_tab
