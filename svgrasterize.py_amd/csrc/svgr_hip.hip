@@ -982,11 +982,16 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
                                                               int* __restrict__ band_item0,
                                                               TileEntry* __restrict__ entries, int* __restrict__ pair_idx,
                                                               int entry_cap, int item_cap, int vc0,
-                                                              BatchDev* __restrict__ bd, Owner own) {
+                                                              BatchDev* __restrict__ bd, Owner own, int reuse) {
     constexpr int NWV = BE_BLOCK / 64;
     __shared__ int s_n[NWV], s_c[NWV];
     __shared__ int s_ent0, s_ok;
     const int band = owned_band_at(own, blockIdx.x), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // `reuse` (a planned render): the band's places in the entry and item arrays are the ones the plan's own pass left in
+    // band_start / band_item0 -- same geometry, same counts.  Asked for here, with the bins; the 256 bands' returning atomics on
+    // two cursors were a quarter of this kernel (a hot address serves ~90 of them per microsecond).
+    int pre_e0 = 0, pre_i0 = 0, pre_tn = -1;
+    if (reuse && tid == 0) { pre_e0 = band_start[band]; pre_tn = band_count[band]; pre_i0 = band_item0[band]; }
     // Wave w owns the consecutive paths [w * chunk, (w + 1) * chunk), as `groups` groups of 64: lane l of group g has
     // path w * chunk + g * 64 + l, so every load is coalesced and list order = (wave, group, lane).
     const int groups = (n_paths + BE_BLOCK - 1) / BE_BLOCK, chunk = groups * 64;
@@ -1049,12 +1054,17 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
         (void)wave_excl_scan(cc, lane, tcc);
         if (lane < NWV) s_n[lane] = ea;
         if (lane == 0) {
-            int e0 = tn ? atomicAdd(&bd->entry_cursor, tn) : 0;
-            int i0 = tcc ? atomicAdd(&bd->item_cursor, tcc) : 0;
-            int ok = 1;
-            if (e0 + tn > entry_cap) { atomicOr(&bd->err, 4); ok = 0; tn = 0; }
+            int e0, i0, ok = 1;
+            if (reuse) {
+                e0 = pre_e0; i0 = pre_i0;
+                if (pre_tn != tn) { atomicOr(&bd->err, 4); ok = 0; tn = 0; }  // (not the plan's count: its places do not hold)
+            } else {
+                e0 = tn ? atomicAdd(&bd->entry_cursor, tn) : 0;
+                i0 = tcc ? atomicAdd(&bd->item_cursor, tcc) : 0;
+            }
+            if (ok && e0 + tn > entry_cap) { atomicOr(&bd->err, 4); ok = 0; tn = 0; }
             if (ok && (long long)i0 + tcc > (long long)item_cap) { atomicOr(&bd->err, 64); ok = 0; tn = 0; }
-            if (tn) atomicMax(&bd->max_band_entries, tn);
+            if (tn && !reuse) atomicMax(&bd->max_band_entries, tn);
             s_ent0 = e0; s_ok = ok;
             band_start[band] = e0;
             band_count[band] = tn;
@@ -3158,7 +3168,8 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
         hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(BE_BLOCK), 0, st, (const PathBin*)b->bins.p, np_walk, plist,
                            (const int*)b->bbox.p, b->band_start.p, b->band_count.p, b->band_item0.p, b->entries.p,
                            b->pair_idx.p, cap_i32(std::min(b->entries.cap, b->pair_idx.cap)),
-                           upto >= 4 ? cap_i32(b->items.cap) : 0x7fffffff, b->vp[1], b->bd(), b->own);
+                           upto >= 4 ? cap_i32(b->items.cap) : 0x7fffffff, b->vp[1], b->bd(), b->own,
+                           upto >= 4 && b->planned && use_vp && getenv("SVGR_NO_BAND_REUSE") == nullptr ? 1 : 0);
     if (upto == 3) return 0;
     // (the tiles read their mask words whether or not any pair exists: a batch without entries still needs them clear --
     //  a block from the cache is not zero)
