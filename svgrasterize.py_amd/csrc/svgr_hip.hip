@@ -790,6 +790,14 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
     if (slabs && p < n_paths) {
         e_begin = seg_off[path_seg0[p]]; e_end = seg_off[path_seg0[p + 1]];
     }
+    // A planned render (`slab_at` given) makes no reservation: the path's pair and cell places are the ones the plan's own pass
+    // left in `bins` -- same geometry, same bbox, same counts (a bbox that differs is an error) --, its slabs' places the plan's
+    // heaviest-first order.  Asked for here, with the keys.
+    const bool reuse = slab_at != nullptr;
+    PathBin old_bin;
+    old_bin.b0 = old_bin.nb = old_bin.pb_off = old_bin.cell_off = 0;
+    int4 old_bb = make_int4(0, 0, 0, 0);
+    if (reuse && p < n_paths) { old_bin = bins[p]; old_bb = ((const int4*)bbox)[p]; }
     int out[4] = {0, 0, 0, 0};
     int pb0 = 0, pnb = 0, pnct = 0;
     int st_n = 0;
@@ -863,18 +871,25 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
         int t_pb, t_cell, t_slab;
         const int e_pb = wave_excl_scan(pnb, lane, t_pb), e_cell = wave_excl_scan(n_cells_, lane, t_cell),
                   e_slab = wave_excl_scan(n_slabs, lane, t_slab);
-        int b_pb = 0, b_cell = 0, b_slab = 0;
-        if (lane == 0) {
-            if (t_pb > 0) b_pb = atomicAdd(&bd->pb_cursor, t_pb);
-            if (t_cell > 0) b_cell = atomicAdd(&bd->cell_cursor, t_cell);
-            if (t_slab > 0) b_slab = atomicAdd(&bd->slab_cursor, t_slab);
+        if (!reuse) {
+            int b_pb = 0, b_cell = 0, b_slab = 0;
+            if (lane == 0) {
+                if (t_pb > 0) b_pb = atomicAdd(&bd->pb_cursor, t_pb);
+                if (t_cell > 0) b_cell = atomicAdd(&bd->cell_cursor, t_cell);
+                if (t_slab > 0) b_slab = atomicAdd(&bd->slab_cursor, t_slab);
+            }
+            off = __shfl(b_pb, 0) + e_pb;
+            cell_off = __shfl(b_cell, 0) + e_cell;
+            slab0 = __shfl(b_slab, 0) + e_slab;
+        } else {
+            // (svgr_batch::slab_at: workgroups are dispatched in slab order, and a launch that ends on its longest slabs ends late)
+            off = old_bin.pb_off;
+            cell_off = old_bin.cell_off;
+            slab0 = p < n_paths ? slab_at[p] : 0;
+            if (p < n_paths && (old_bb.x != out[0] || old_bb.y != out[1] || old_bb.z != out[2] || old_bb.w != out[3] || old_bin.nb != pnb))
+                atomicOr(&bd->err, 32);  // (not the plan's geometry: its places do not hold)
+            if (pi == 0) bd->slab_cursor = slab_cap;  // (k_path_build's grid: the plan's count)
         }
-        off = __shfl(b_pb, 0) + e_pb;
-        cell_off = __shfl(b_cell, 0) + e_cell;
-        slab0 = __shfl(b_slab, 0) + e_slab;
-        // A planned render knows where every path's slabs go (svgr_batch::slab_at: the plan's heaviest-first order -- workgroups
-        // are dispatched in slab order, and a launch that ends on its longest slabs ends late); the cursor then only counts.
-        if (slab_at && p < n_paths) slab0 = slab_at[p];
     }
     if (stats)
 #pragma unroll
