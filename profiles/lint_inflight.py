@@ -36,7 +36,9 @@ def parse(line):
 
 def check(name, text):
     # instructions: (op, operands, in_asm, source line); labels map to instruction indices
-    ins, labels, in_asm = [], {}, False
+    # (an asm statement may park a body out of line: the lines between `.subsection 1` and `.subsection 0` are assembled
+    #  behind the kernel's code, so the textual neighbours of such a region fall through to each other, not into it)
+    ins, labels, in_asm, sub, is_sub, pending = [], {}, False, False, [], []
     for ln, l in enumerate(text):
         if "#ASMSTART" in l:
             in_asm = True
@@ -44,25 +46,40 @@ def check(name, text):
         if "#ASMEND" in l:
             in_asm = False
             continue
-        m = re.match(r"^(\.LBB\w+):", l)
+        m = re.match(r"^(\.L\w+):", l)
         if m:
-            labels[m.group(1)] = len(ins)
+            pending.append((m.group(1), sub))  # (names the next instruction of ITS kind)
+            continue
+        m = re.match(r"^\s*\.subsection\s+(\d+)", l)
+        if m:
+            sub = m.group(1) != "0"
             continue
         op, ops = parse(l)
         if not op or op.startswith(".") or op.endswith(":"):
             continue
+        for name_, kind_ in [x for x in pending if x[1] == sub]:
+            labels[name_] = len(ins)
+        pending = [x for x in pending if x[1] != sub]
         ins.append((op, ops, in_asm, ln + 1, l.strip()))
+        is_sub.append(sub)
     n = len(ins)
     succ = [[] for _ in range(n)]
+
+    def after(i):  # the instruction control falls through to: the next one of the same (in-line / out-of-line) kind
+        j = i + 1
+        while j < n and is_sub[j] != is_sub[i]:
+            j += 1
+        return [j] if j < n else []
+
     for i, (op, ops, _a, _ln, _l) in enumerate(ins):
         if op == "s_branch":
             succ[i] = [labels[ops[0]]]
         elif op.startswith("s_cbranch"):
-            succ[i] = [labels[ops[0]]] + ([i + 1] if i + 1 < n else [])
+            succ[i] = [labels[ops[0]]] + after(i)
         elif op == "s_endpgm":
             succ[i] = []
-        elif i + 1 < n:
-            succ[i] = [i + 1]
+        else:
+            succ[i] = after(i)
     state_in = [None] * n
     state_in[0] = frozenset()
     work = [0]

@@ -80,6 +80,23 @@ constexpr int NW = NT / 64;                // waves per workgroup
 #define SVGR_WAVES_PER_EU 4             // register budget of the tile kernel: 512 / 4 = 128 VGPRs
 #endif
 static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 1024 threads");
+// Round-4 forms of the tile kernel's inner pieces, each behind a switch so that one box can time them against each other
+// (profiles/sweep_trace.sh "name:-DSVGR_X_...=0|1"):
+#ifndef SVGR_X_SCANEXEC
+#define SVGR_X_SCANEXEC 0               // row scan: shifted values added under an EXEC mask instead of selected to zero first
+#endif
+#ifndef SVGR_X_CVTCLAMP
+#define SVGR_X_CVTCLAMP 0               // float32 canvas: clip(0, 1) as the clamp modifier of the f64 -> f32 conversion
+#endif
+#ifndef SVGR_X_C1FAST
+#define SVGR_X_C1FAST 0                 // class-1 items inside the layer's columns: coverage is constant along a lane's pixels
+#endif
+#ifndef SVGR_X_FRACT
+#define SVGR_X_FRACT 0                  // evenodd fold by v_fract_f64 (three instructions instead of seven)
+#endif
+#ifndef SVGR_X_CMPX
+#define SVGR_X_CMPX 0                   // the 1e-6 cut as v_cmpx around the pixel's block instead of a saveexec + branch
+#endif
 
 // One addition into a tile's LDS delta tile: everything the scatter phase of the tile kernel does for it is
 // `ds_add_f64 base + offset, v`.  A run of `len` consecutive tile columns with the same value (the middle pieces of a
@@ -1945,6 +1962,12 @@ __device__ __forceinline__ void nt_store16(float4* p, const float4 v) {
     f32x4_t nv = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(nv, (f32x4_t*)p);
 }
+// evenodd fold |((s + 1) mod 2) - 1| (S:986-988) WITHOUT its outer |.|, in three instructions: (s + 1) / 2 by one fma (halving
+// is exact, so the single rounding is the one of s + 1), its fractional part, and 2 f - 1 (2 f is exact).  Differs from
+// a - 2 floor(a / 2) only where a = s + 1 is a negative number below half an ulp of 2 (v_fract clamps below 1): one ulp.
+__device__ __forceinline__ double evenodd_fract_signed(double s) {
+    return __builtin_fma(__builtin_amdgcn_fract(__builtin_fma(s, 0.5, 0.5)), 2.0, -1.0);
+}
 template <int N>
 __device__ __forceinline__ double dpp_row_shr(double v) {  // lane i <- lane i-N inside a 16-lane row, else +0.0
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -1960,6 +1983,9 @@ __device__ __forceinline__ double dpp_ctrl(double v) {  // generic DPP move of a
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+
+// the lane's pixels, one macro call each (asm blocks with named operands cannot be written in a loop over a constexpr index)
+#define SVGR_ACC_PX(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
 
 struct TileArgs {
     const uint4* pages;             // whole-canvas launches: per workgroup, in launch order (k_tile_lists: heaviest first), its page
@@ -2220,6 +2246,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
 
         double* const my = my0 + buf * (DELTA_BYTES / 8);
         double t[PX];  // the winding number of the lane's pixels (np.cumsum along the row, S:983)
+        int c1fast = 0;  // (production variant) class-1 item inside the layer's columns: t[0..4] = 1 - src_a, src
         if (cls == 1) {
             // No record reaches the tile: a row's running sum is its carry-in from the layer's first column in the tile
             // to its last (np.cumsum of zeros).  No delta tile, no prefix sum.
@@ -2231,8 +2258,26 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
             //  allocator does not keep the canvas tile in place across two unrolled loops that both rewrite it)
             if (lo_c + col_shift <= 0 && hi_c + col_shift >= TC) {
                 // (the tile lies inside the layer's columns -- the usual case, a tile in the middle of a shape: no pixel tests)
+                if (SVGR_X_C1FAST && SVGR_X_CMPX && OUT == 0 && !CLIP && PX >= 5) {
+                    // The coverage is one value for all of the lane's pixels: src = mask * paint (S:1019) and 1 - src_a once per
+                    // lane, then dst = fma(dst, 1 - src_a, src) (S:286) -- four fmas per pixel instead of eight, no comparison.
+                    // A row below the cut gets src = 0 and 1 - src_a = 1: dst stays as it is, bit for bit.
+                    // The five per-lane values ride in t[0..4] into the pixels' blocks below, which branch on `c1fast` INSIDE
+                    // their asm statement: a second C++ loop over the canvas tile makes the register allocator copy the
+                    // tile at the join (168 VGPRs and spills), one statement with two bodies does not.
+                    const double w = rule ? (SVGR_X_FRACT ? evenodd_fract_signed(cin1) : fill_evenodd_raw(cin1)) : cin1;
+                    double mval;
+                    asm("v_min_f64 %0, |%1|, 1.0" : "=v"(mval) : "v"(w));
+                    mval = fabs(w) >= kZeroCut ? mval : 0.0;
+                    t[1] = mval * p0; t[2] = mval * p1; t[3] = mval * p2; t[4] = mval * p3;
+                    t[0] = 1.0 - t[4];
+#pragma unroll
+                    for (int i = 5; i < PX; ++i) t[i] = 0.0;
+                    c1fast = 1;
+                } else {
 #pragma unroll
                 for (int i = 0; i < PX; ++i) t[i] = cin1;
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < PX; ++i) t[i] = i >= lo_i && i < hi_i ? cin1 : 0.0;
@@ -2247,7 +2292,24 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
             for (int i = 1; i < PX; ++i) tot += t[i];
             double inc = tot;  // inclusive scan of the CH chunk totals of this tile row
             double run;
-            if (CH <= 8) {
+            if (CH <= 8 && SVGR_X_SCANEXEC) {
+                // a 16-lane DPP row holds 16 / CH tile rows: a shift must not carry a value across their borders.  The shifted
+                // value is added under an EXEC mask (a scalar move on either side of the add) instead of being selected to zero
+                // first (two VOP3 v_cndmask per step: a fifth of the scan's vector instructions).  The DPP moves themselves run
+                // with every lane enabled: a disabled lane would read as zero on the source side as well.
+                constexpr unsigned long long rep = CH == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
+                constexpr unsigned long long m1 = rep * (CH == 8 ? 0xfeull : 0xeull), m2 = rep * (CH == 8 ? 0xfcull : 0xcull), m4 = rep * 0xf0ull;
+                double v;
+#define SVGR_MASKED_ADD(acc_, v_, m_) asm volatile("s_mov_b64 exec, %2\n\tv_add_f64 %0, %0, %1\n\ts_mov_b64 exec, -1" : "+v"(acc_) : "v"(v_), "s"(m_))
+                v = dpp_row_shr<1>(inc); SVGR_MASKED_ADD(inc, v, m1);
+                v = dpp_row_shr<2>(inc); SVGR_MASKED_ADD(inc, v, m2);
+                if (CH == 8) { v = dpp_row_shr<4>(inc); SVGR_MASKED_ADD(inc, v, m4); }
+                v = dpp_row_shr<1>(inc);  // exclusive: everything left of this chunk (lanes that start a tile row: nothing)
+                SVGR_MASKED_ADD(t[0], v, m1);
+#pragma unroll
+                for (int i = 1; i < PX; ++i) t[i] += t[i - 1];
+                run = 0.0;
+            } else if (CH <= 8) {
                 // a 16-lane DPP row holds 16 / CH tile rows: a shift must not carry a value across their borders
                 const int lc = lane & (CH - 1);
                 double v;
@@ -2271,8 +2333,10 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
                     if ((lane & 31) == 0) run = 0.0;
                 }
             }
+            if (!(CH <= 8 && SVGR_X_SCANEXEC)) {
 #pragma unroll
-            for (int i = 0; i < PX; ++i) { run += t[i]; t[i] = run; }
+                for (int i = 0; i < PX; ++i) { run += t[i]; t[i] = run; }
+            }
         }
 
         if (OUT <= 1) {
@@ -2302,13 +2366,63 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
                 };
                 // the winding per pixel is in t[]: the running sum itself for nonzero (its |.| rides as an operand modifier
                 // below), folded for evenodd (already in [0, 1])
-                if (rule) {
+                if (rule && !c1fast) {
 #pragma unroll
-                    for (int i = 0; i < PX; ++i) t[i] = fill_evenodd_raw(t[i]);
+                    for (int i = 0; i < PX; ++i) t[i] = SVGR_X_FRACT ? evenodd_fract_signed(t[i]) : fill_evenodd_raw(t[i]);
                 }
                 // Then coverage = min(|t|, 1) where |t| >= 1e-6 (S:984-990): the comparison comes first because
                 // v_min_f64 turns the NaN of the layer-edge sentinel into 1.0.  Pixels below the cut are skipped
                 // under the exec mask: a tenth of the pixel slots of a wave have no visible lane at all.
+#if SVGR_X_CMPX
+                // ... as ONE block per pixel: v_cmpx narrows EXEC to the visible lanes, the block runs, a scalar move widens it
+                // again -- no saveexec / branch / restore triple per pixel (three quarters of the kernel's scalar instructions),
+                // no hole in the vector stream.  (EXEC is all ones here: every branch above is wave-uniform.)
+                const double cut = kZeroCut;
+#define SVGR_BLEND_PX(i)                                                                                               \
+    if constexpr (i < PX) {                                                                                            \
+        double t0, t1, t2, t3, mval;                                                                                   \
+        unsigned long long vis_;                                                                                       \
+        asm volatile(                                                                                                  \
+            SVGR_BLEND_C1_HEAD                                                                                         \
+            "v_cmpx_ge_f64_e64 %[vis], |%[t]|, %[cut]\n\t"                                                             \
+            "v_min_f64 %[m], |%[t]|, 1.0\n\t"                                                                          \
+            "v_fma_f64 %[t0], -%[a0], %[pa], %[p0]\n\t"                                                                \
+            "v_fma_f64 %[t1], -%[a1], %[pa], %[p1]\n\t"                                                                \
+            "v_fma_f64 %[t2], -%[a2], %[pa], %[p2]\n\t"                                                                \
+            "v_fma_f64 %[t3], -%[a3], %[pa], %[pa]\n\t"                                                                \
+            "v_fma_f64 %[a0], %[m], %[t0], %[a0]\n\t"                                                                  \
+            "v_fma_f64 %[a1], %[m], %[t1], %[a1]\n\t"                                                                  \
+            "v_fma_f64 %[a2], %[m], %[t2], %[a2]\n\t"                                                                  \
+            "v_fma_f64 %[a3], %[m], %[t3], %[a3]\n\t"                                                                  \
+            "s_mov_b64 exec, -1\n"                                                                                     \
+            SVGR_BLEND_C1_TAIL                                                                                         \
+            : [a0] "+v"(acc[i < PX ? i : 0][0]), [a1] "+v"(acc[i < PX ? i : 0][1]), [a2] "+v"(acc[i < PX ? i : 0][2]),   \
+              [a3] "+v"(acc[i < PX ? i : 0][3]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),          \
+              [m] "=&v"(mval), [vis] "=&s"(vis_)                                                                        \
+            : [t] "v"(t[i < PX ? i : 0]), [pa] "v"(p3v), [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [cut] "s"(cut),        \
+              [fast] "s"(c1fast), [k] "v"(t[0]), [s0] "v"(t[1 % PX]), [s1] "v"(t[2 % PX]), [s2] "v"(t[3 % PX]),           \
+              [s3] "v"(t[4 % PX])                                                                                       \
+            : "scc");                                                                                                  \
+    }
+#if SVGR_X_C1FAST
+                // (the class-1 body sits out of line, behind the kernel's code: `.subsection 1` of the kernel's own section --
+                //  the general body runs without a taken branch)
+#define SVGR_BLEND_C1_HEAD "s_cmp_lg_u32 %[fast], 0\n\ts_cbranch_scc1 .Lc1f_%=\n\t"
+#define SVGR_BLEND_C1_TAIL                                                                                             \
+    ".Lc1b_%=:\n\t.subsection 1\n.Lc1f_%=:\n\t"                                                                        \
+    "v_fma_f64 %[a0], %[a0], %[k], %[s0]\n\tv_fma_f64 %[a1], %[a1], %[k], %[s1]\n\t"                                    \
+    "v_fma_f64 %[a2], %[a2], %[k], %[s2]\n\tv_fma_f64 %[a3], %[a3], %[k], %[s3]\n\t"                                    \
+    "s_branch .Lc1b_%=\n\t.subsection 0"
+#else
+#define SVGR_BLEND_C1_HEAD
+#define SVGR_BLEND_C1_TAIL
+#endif
+                SVGR_ACC_PX(SVGR_BLEND_PX)
+#undef SVGR_BLEND_PX
+#undef SVGR_BLEND_C1_HEAD
+#undef SVGR_BLEND_C1_TAIL
+                (void)blend;
+#else
 #pragma unroll
                 for (int i = 0; i < PX; ++i) {
                     if (__builtin_expect(fabs(t[i]) >= kZeroCut, 1)) {  // (visible falls through)
@@ -2317,6 +2431,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
                         blend(i, mval);
                     }
                 }
+#endif
             } else {
                 bool vis[PX];  // the 1e-6 cut (S:990), as lane masks
                 if (rule) {
@@ -2478,7 +2593,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     if (OUT <= 1) {
         const int row = band * TR + trow;  // viewport-local row
         const int out_row = by * TR + trow - a.win_r;  // row of the output buffer (the window's / the owned bands packed)
-        if (a.clip01) {
+        if (a.clip01 && !(OUT == 0 && SVGR_X_CVTCLAMP)) {
             // clip(0, 1) (S:326) as max / min: two instructions per channel (written as comparisons the compiler turns every
             // channel into two exec-masked branches -- 250 instructions per tile, a tenth of the kernel's).  A canvas value is
             // never a NaN (the sentinel's never passes the coverage test), so the NaN rule of v_max does not matter.
@@ -2498,9 +2613,24 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
             constexpr int T_ROW = CH * (PX + 1);  // slots per transposed tile row
             static_assert(TR * T_ROW * 16 <= 2 * DELTA_BYTES, "the transposed tile fits the two delta tiles");
             float4* const tp = (float4*)s_mem;
+            if (SVGR_X_CVTCLAMP && a.clip01) {
+                // clip(0, 1) (S:326) rides on the conversion as its clamp modifier: rounding to float32 is monotone and 0 and 1
+                // are float32 values, so clamp(round(x)) == round(clamp(x)) -- and 128 double max / min per wave and tile
+                // (as much vector work as one and a half items) are gone
 #pragma unroll
-            for (int i = 0; i < PX; ++i)
-                tp[trow * T_ROW + chunk * (PX + 1) + i] = make_float4((float)acc[i][0], (float)acc[i][1], (float)acc[i][2], (float)acc[i][3]);
+                for (int i = 0; i < PX; ++i) {
+                    float f0, f1, f2, f3;
+                    asm("v_cvt_f32_f64_e64 %0, %1 clamp" : "=v"(f0) : "v"(acc[i][0]));
+                    asm("v_cvt_f32_f64_e64 %0, %1 clamp" : "=v"(f1) : "v"(acc[i][1]));
+                    asm("v_cvt_f32_f64_e64 %0, %1 clamp" : "=v"(f2) : "v"(acc[i][2]));
+                    asm("v_cvt_f32_f64_e64 %0, %1 clamp" : "=v"(f3) : "v"(acc[i][3]));
+                    tp[trow * T_ROW + chunk * (PX + 1) + i] = make_float4(f0, f1, f2, f3);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < PX; ++i)
+                    tp[trow * T_ROW + chunk * (PX + 1) + i] = make_float4((float)acc[i][0], (float)acc[i][1], (float)acc[i][2], (float)acc[i][3]);
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
