@@ -24,7 +24,6 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Name"].startswith(("k
 print("  " + "  ".join(f'{r["Name"].split("(")[0].replace("void ", "").split("<")[0][2:]} {float(r["AverageNs"])/1e3:.1f}' for r in rows),
       " | sum %.1f us" % (sum(float(r["AverageNs"]) for r in rows) / 1e3))
 P
-  tail -1 gpurun_out/s4_$name.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('   step', d['ms_per_step'])" >> $out 2>&1
   rm -rf gpurun_out/s4_$name
 done
 make -s -C svgrasterize.py_amd/csrc clean && make -s -C svgrasterize.py_amd/csrc

@@ -83,19 +83,25 @@ static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 102
 // Round-4 forms of the tile kernel's inner pieces, each behind a switch so that one box can time them against each other
 // (profiles/sweep_trace.sh "name:-DSVGR_X_...=0|1"):
 #ifndef SVGR_X_SCANEXEC
-#define SVGR_X_SCANEXEC 0               // row scan: shifted values added under an EXEC mask instead of selected to zero first
+#define SVGR_X_SCANEXEC 1               // row scan: shifted values added under an EXEC mask instead of selected to zero first
 #endif
 #ifndef SVGR_X_CVTCLAMP
-#define SVGR_X_CVTCLAMP 0               // float32 canvas: clip(0, 1) as the clamp modifier of the f64 -> f32 conversion
+#define SVGR_X_CVTCLAMP 1               // float32 canvas: clip(0, 1) as the clamp modifier of the f64 -> f32 conversion
 #endif
 #ifndef SVGR_X_C1FAST
-#define SVGR_X_C1FAST 0                 // class-1 items inside the layer's columns: coverage is constant along a lane's pixels
+#define SVGR_X_C1FAST 1                 // class-1 items inside the layer's columns: coverage is constant along a lane's pixels
 #endif
 #ifndef SVGR_X_FRACT
-#define SVGR_X_FRACT 0                  // evenodd fold by v_fract_f64 (three instructions instead of seven)
+#define SVGR_X_FRACT 1                  // evenodd fold by v_fract_f64 (three instructions instead of seven)
+#endif
+#ifndef SVGR_X_SCATWAIT
+#define SVGR_X_SCATWAIT 1               // scatter: no compiler-visible load (and so no compiler-placed vmcnt(0)) in front of the adds
+#endif
+#ifndef SVGR_X_RUNS
+#define SVGR_X_RUNS 0                   // scatter: the further columns of a run straight-line under v_cmpx instead of a loop
 #endif
 #ifndef SVGR_X_CMPX
-#define SVGR_X_CMPX 0                   // the 1e-6 cut as v_cmpx around the pixel's block instead of a saveexec + branch
+#define SVGR_X_CMPX 1                   // the 1e-6 cut as v_cmpx around the pixel's block instead of a saveexec + branch
 #endif
 
 // One addition into a tile's LDS delta tile: everything the scatter phase of the tile kernel does for it is
@@ -2186,6 +2192,64 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
 #endif
         unsigned char* const base = s_mem + buf * DELTA_BYTES;
         const int i_step = a.det ? 64 : NT;
+        auto one = [&](unsigned w, double v) {
+            unsigned off = w & 0xffffu;
+            __hip_atomic_fetch_add((double*)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // a run: the same value into the next `more` columns -- at most PX - 1, all inside the chunk (k_path_build cuts runs there)
+#if SVGR_X_RUNS
+            // ... straight-line: v_cmpx narrows EXEC to the lanes whose run reaches one column further (the sets are nested, so
+            // nothing is restored in between), two instructions per column instead of the seven of a loop trip with its
+            // EXEC bookkeeping; no lane with a run: one branch
+            static_assert(PX == 8, "the unrolled run covers seven further columns");
+            {
+                const unsigned more = (w >> 16) & 63u;
+                const unsigned at = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)(base + off));   // (LDS byte address)
+                unsigned long long keep_;
+                asm volatile(
+                    "s_mov_b64 %[keep], exec\n\t"
+                    "v_cmpx_lt_u32_e32 vcc, 0, %[more]\n\t"
+                    "s_cbranch_execz .Lrun_%=\n\t"
+                    "ds_add_f64 %[at], %[v] offset:8\n\t"
+                    "v_cmpx_lt_u32_e32 vcc, 1, %[more]\n\t"
+                    "ds_add_f64 %[at], %[v] offset:16\n\t"
+                    "v_cmpx_lt_u32_e32 vcc, 2, %[more]\n\t"
+                    "ds_add_f64 %[at], %[v] offset:24\n\t"
+                    "v_cmpx_lt_u32_e32 vcc, 3, %[more]\n\t"
+                    "ds_add_f64 %[at], %[v] offset:32\n\t"
+                    "v_cmpx_lt_u32_e32 vcc, 4, %[more]\n\t"
+                    "ds_add_f64 %[at], %[v] offset:40\n\t"
+                    "v_cmpx_lt_u32_e32 vcc, 5, %[more]\n\t"
+                    "ds_add_f64 %[at], %[v] offset:48\n\t"
+                    "v_cmpx_lt_u32_e32 vcc, 6, %[more]\n\t"
+                    "ds_add_f64 %[at], %[v] offset:56\n"
+                    ".Lrun_%=:\n\t"
+                    "s_mov_b64 exec, %[keep]"
+                    : [keep] "=&s"(keep_)
+                    : [more] "v"(more), [at] "v"(at), [v] "v"(v)
+                    : "vcc", "memory");
+            }
+#else
+            for (int more = (int)((w >> 16) & 63u); more > 0; --more) {
+                off += 8u;
+                __hip_atomic_fetch_add((double*)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#endif
+        };
+#if SVGR_X_SCATWAIT
+        // The lane's first add is the one the pipeline brought.  Lists longer than the workgroup (rare) load the rest here, issued
+        // and waited for by hand: a load the COMPILER sees makes it put `s_waitcnt vmcnt(0)` in front of every scatter's first
+        // add -- also of the lists that load nothing --, and that waits for the header requested a moment ago: one exposed
+        // memory round trip per item, the pipeline's depth gone.
+        if (tid < n_add) one((unsigned)first_w, first_v);
+        for (int i = tid + i_step; i < n_add; i += i_step) {
+            unsigned long long w2;
+            double v2;
+            const TileAdd* const q = a.adds + (size_t)add0 + i;
+            asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:8\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(w2), "=&v"(v2) : "v"(q) : "memory");
+            one((unsigned)w2, v2);
+        }
+#else
         for (int i = tid; i < n_add; i += i_step) {
             unsigned w = (unsigned)first_w;
             double v = first_v;
@@ -2194,14 +2258,9 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
                 w = t.where;
                 v = t.v;
             }
-            unsigned off = w & 0xffffu;
-            __hip_atomic_fetch_add((double*)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            // a run: the same value into the next `more` columns -- at most PX - 1, all inside the chunk (k_path_build cuts runs there)
-            for (int more = (int)((w >> 16) & 63u); more > 0; --more) {
-                off += 8u;
-                __hip_atomic_fetch_add((double*)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            one(w, v);
         }
+#endif
     };
 
     // ---- scan + fill rule + paint + source-over of the item whose deltas are in delta tile `buf` ----
