@@ -22,12 +22,16 @@ def main():
     if phases is not None:
         ph = phases[live].astype(np.int64)
         st_, en_, it_ = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64), t[:, 2].astype(np.int64)
-        has = (it_ > 0) & (ph[:, 0] > 0)
+        has = (it_ > 0) & (ph[:, 3] > 0)
         if has.any():
-            d0 = (ph[has, 0] - st_[has]) * 10e-3; d1 = (ph[has, 1] - ph[has, 0]) * 10e-3
-            d2 = (ph[has, 2] - ph[has, 1]) * 10e-3; d3 = (en_[has] - ph[has, 2]) * 10e-3
-            print(f"phases (mean us over {int(has.sum())} workgroups with items): start->first header {d0.mean():.2f}, ->first scatter {d1.mean():.2f}, "
-                  f"item loop {d2.mean():.2f} ({(d2 / it_[has]).mean():.3f} per item), epilogue (store) {d3.mean():.2f}")
+            # (round 4: sums over a workgroup's tiles -- [0] end of a tile's items (launch start) -> the wait for the next tile's first
+            #  loads, [1] that wait, [2] the item rounds; [3] tiles)
+            tiles = ph[has, 3].astype(float)
+            d0 = ph[has, 0] * 10e-3; d1 = ph[has, 1] * 10e-3; d2 = ph[has, 2] * 10e-3
+            life_ = (en_[has] - st_[has]) * 10e-3
+            print(f"phases per TILE (mean us; {int(has.sum())} workgroups, {tiles.mean():.2f} tiles each): switch (stores, next tile's loads issued) "
+                  f"{(d0 / tiles).mean():.2f}, wait for the first loads {(d1 / tiles).mean():.2f}, item rounds {(d2 / tiles).mean():.2f} "
+                  f"({(d2.sum() / it_[has].sum()):.3f} per item), rest of the workgroup's life (last store, exit) {((life_ - d0 - d1 - d2) / tiles).mean():.2f}")
     start, end, items = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64), t[:, 2].astype(np.int64)
     hw, xcc = (t[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64), (t[:, 3] >> np.uint64(32)).astype(np.int64) & 0xF
     t0 = start.min()

@@ -178,6 +178,10 @@ struct svgr_ctx {
     char name[128] = {0};
     void* pinned = nullptr;      // page-locked staging for read-backs that must not block the host (svgr_batch_plan_many)
     size_t pinned_bytes = 0;
+    int n_cu = 256;              // compute units: the tile kernel's persistent launch is sized by it
+    void* trash = nullptr;       // 1 KiB of device memory nobody reads (TileArgs::trash)
+    unsigned* tile_ctr = nullptr;  // two sets of eight tile counters (TileArgs::tile_ctr), used alternately by the launches of this stream
+    int tile_ctr_set = 0;
 };
 // the context whose call is running on this thread (set by enter_ctx at the top of every entry point): the block cache
 // files what is allocated and released under it
@@ -2010,6 +2014,9 @@ struct TileArgs {
     const GradDev* grads;           // gradient paints of the batch (CellHdr::bits carries the entry's index + 1)
     const int* grad_flags;          // per gradient: some pixel of the fill's layer has det < 0 (k_grad_detneg, focal form)
     void* out;
+    void* trash;                 // 1 KiB nobody reads: where the lanes of a float32 row store that lie outside the output write
+    unsigned* tile_ctr;          // persistent launch: 8 counters (one per XCD's workgroups, 128 bytes apart) that deal the tiles behind
+    unsigned* tile_ctr_clear;    // the first two passes; the OTHER set of eight, zeroed by this launch for the next one
     int vr0, vc0, vrows, vcols;  // viewport
     Owner own;                   // owned bands
     int out_cols;                // row pitch of `out` in pixels
@@ -2037,9 +2044,32 @@ struct TileArgs {
 //   item k     delta tile k & 1 is read back to zero, scanned along the rows, and composited
 // with ONE barrier per item: behind it every wave's adds of item k have landed and the scan of item k-1 has returned
 // its delta tile to zero.  The adds of the next item are in flight in the LDS while this wave's lanes run the composite.
-template <int OUT, bool CLIP = false, bool GROUPS = false, bool GRAD = false>
-__global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_EU)) void k_tile_render(const TileArgs a) {
+// The float32 production variant keeps its pipeline's load targets in FIXED registers, v[FIX0 .. 127], which the compiler never
+// allocates (the kernel is compiled for FIX0 VGPRs; the asm statements' clobber lists bring the count back to 128): a register
+// with a load in flight cannot be copied, spilled or recoloured by a compiler that does not have it.  The persistent tile loop
+// needs that: with several statements defining one target variable the allocator joins them with copies -- of registers
+// whose load has not landed.  (The other variants take one tile per workgroup and keep the targets as ordinary variables.)
+#define SVGR_FIX0 116
+// The launch's arguments read AGAIN from the kernel-argument segment: scalar loads that hit the scalar cache, in the place of two
+// dozen SGPRs held across the item loops (the persistent loop ran out of them).  The pointer passes through an empty asm so that
+// the loads stay where they are written; it keeps its address space (constant): through a generic pointer they would be
+// VECTOR loads, their results "divergent", and every branch on them an EXEC-masked one.
+typedef const TileArgs __attribute__((address_space(4))) * KArgsPtr;
+__device__ __forceinline__ void reload_tile_args(TileArgs& A) {
+    KArgsPtr ka = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    A.pages = ka->pages; A.tile_info = ka->tile_info; A.items = ka->items;
+    A.n_ct = ka->n_ct; A.n_bands = ka->n_bands; A.use_order = ka->use_order; A.ct0 = ka->ct0; A.win_ct = ka->win_ct; A.band0 = ka->band0;
+    A.win_r = ka->win_r; A.win_c = ka->win_c; A.win_rows = ka->win_rows; A.win_cols = ka->win_cols;
+    A.out = ka->out; A.trash = ka->trash;
+    A.vr0 = ka->vr0; A.vc0 = ka->vc0; A.vrows = ka->vrows; A.vcols = ka->vcols;
+    A.own.rank = ka->own.rank; A.own.world = ka->own.world; A.own.strip = ka->own.strip;
+    A.out_cols = ka->out_cols; A.clip01 = ka->clip01;
+}
+template <int OUT, bool CLIP, bool GROUPS, bool GRAD>
+__device__ __forceinline__ void tile_body(const TileArgs& a) {
     static_assert(!GROUPS || (CLIP && OUT <= 1), "groups live in the canvas variants with the clip tile");
+    constexpr bool FIXED = OUT == 0 && !CLIP;   // the production variant: fixed load targets, persistent tile loop
     static_assert(!GRAD || GROUPS, "gradient entries live in the variant with the large register budget");
     constexpr int OFF_CLIP = 2 * DELTA_BYTES;                                // canvas modes: coverage tile of a clip path
 #ifndef SVGR_DBG_TILE_PADLDS
@@ -2051,39 +2081,42 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
 
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int trow = tid / CH, chunk = tid % CH;
-    // which tile
-    int by, bx, item0, n_items;
-    uint4 page = make_uint4(0u, 0u, 0u, 0u);  // lane j < PAGE_ITEMS: item j of the tile's list
+    const int lane_ = lane, trow_ = trow, chunk_ = chunk;
+    // ---- which tiles ----
+    // A whole-canvas launch is PERSISTENT: the host launches as many workgroups as the chip holds at once and each walks the
+    // launch order (k_tile_lists' heaviest-first list of pages) in passes of gridDim.x tiles -- forwards in even passes,
+    // backwards in odd ones, so the workgroup that drew the heaviest tile of one pass draws the lightest of the next.  What a
+    // (The first two passes are dealt by position; behind them a workgroup draws its next tile from a counter -- one of eight, by
+    //  blockIdx % 8, over the tiles of that residue: the launch order is heaviest first, so whoever is free takes the heaviest
+    //  tile left.  Dealt by position throughout -- forwards and backwards in turn -- the workgroups' lifetimes spread by a third.)
+    // workgroup that lives for ONE tile cannot overlap is a third of its slot's time: the page's round trip, the first
+    // headers' and adds' round trip, and the acknowledgement of its stores (a wave ends only when they have come back).
+    // Here the next tile's page arrives in the place of the add list of "the item behind the last one" -- a load the pipeline
+    // makes anyway and used to point at a dummy --, and a finished tile's canvas is stored BEHIND the next tile's first
+    // loads: both are on their way while the composite runs.  (Window launches take one tile per workgroup.)
+    int by = 0, bx = 0, item0 = 0, n_items = 0, band = 0;
+    int tile_r0 = 0, tile_c0 = 0, tile_c1 = 0;  // absolute row / column of the tile's first pixel, one past its last column
+    const unsigned n_tiles_ = (unsigned)a.win_ct * (unsigned)a.n_bands;
+    unsigned pass_ = 0u, tile_ = blockIdx.x;
+    unsigned long long page01 = 0ull, page23 = 0ull;  // lane j < PAGE_ITEMS: item j of the tile's list {x, y}, {z, w}; lane PAGE_ITEMS: which tile
     if (a.use_order) {
-        page = a.pages[(size_t)blockIdx.x * PAGE_STRIDE + (lane < PAGE_STRIDE ? lane : PAGE_ITEMS)];
-        by = __builtin_amdgcn_readlane((int)page.x, PAGE_ITEMS);  // (ordinal among the owned bands)
-        bx = __builtin_amdgcn_readlane((int)page.y, PAGE_ITEMS);
-        item0 = __builtin_amdgcn_readlane((int)page.z, PAGE_ITEMS);
-        n_items = __builtin_amdgcn_readlane((int)page.w, PAGE_ITEMS);
-    } else {
-        // (the launch covers the column tiles [ct0, ct0 + win_ct) of the bands [band0, band0 + n_bands): the render window)
-        const unsigned t_lin = blockIdx.x;
-        by = __builtin_amdgcn_readfirstlane((int)(t_lin / (unsigned)a.win_ct));
-        bx = (int)t_lin - by * a.win_ct + a.ct0;
-        const int2 ti = a.tile_info[(size_t)owned_band_at(a.own, by + a.band0) * a.n_ct + bx];
-        item0 = __builtin_amdgcn_readfirstlane(ti.x);
-        n_items = __builtin_amdgcn_readfirstlane(ti.y);
+        const uint4* const pp = a.pages + (size_t)tile_ * PAGE_STRIDE + (lane < PAGE_STRIDE ? lane : PAGE_ITEMS);
+        unsigned long long t01, t23;
+        asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:8\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(t01), "=&v"(t23) : "v"(pp) : "memory");
+        page01 = t01; page23 = t23;
     }
-    const int band = owned_band_at(a.own, by + a.band0);
-    const int tile_r0 = a.vr0 + band * TR;  // absolute row of tile row 0
-    const int tile_c0 = a.vc0 + bx * TC;    // absolute column of tile column 0
-    const int tile_c1 = tile_c0 + TC;
-#ifdef SVGR_DBG_NOITEMS
-    n_items = 0;  // diagnostic: the tile's fixed cost alone
-#endif
 
     double acc[PX][4];
 #pragma unroll
     for (int i = 0; i < PX; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0;
 #ifdef SVGR_DBG_TIMELINE
     const unsigned long long tl_start_ = __builtin_amdgcn_s_memrealtime();
-    unsigned long long tl_ph_[3] = {0, 0, 0};  // first header landed / first scatter issued / item loop done
-#define TL_PHASE(i) do { if (tl_ph_[i] == 0) tl_ph_[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    // sums over the workgroup's tiles: [0] from the end of a tile's items (the launch's start) to the wait for the next tile's
+    // first loads, [1] that wait, [2] the item rounds; tl_mark_: the last stamp
+    unsigned long long tl_ph_[3] = {0, 0, 0};
+    unsigned long long tl_mark_ = tl_start_;
+#define TL_PHASE(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); tl_ph_[i] += now_ - tl_mark_; tl_mark_ = now_; } while (0)
 #else
 #define TL_PHASE(i) do { } while (0)
 #endif
@@ -2115,8 +2148,10 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
         }
     };
 
-    // (no barrier behind the zero-fill: the barrier in front of the first scatter covers it)
+    // (once per workgroup, across the waves: the barrier behind it keeps it off the first transposed tile; between tiles a wave
+    //  re-zeroes what its own transposed rows covered)
     for (int i = tid; i < 2 * TR * ROW_STRIDE; i += NT) ((double*)s_mem)[i] = 0.0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (a.arena_words) {  // nothing in this kernel reads the arena; the geometry kernels that did are finished
         for (unsigned i = 1u + blockIdx.x * NT + tid; i < a.arena_words; i += gridDim.x * NT) a.arena[i] = 0u;
     }
@@ -2134,14 +2169,19 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     // between; profiles/lint_inflight.py checks the generated loop for any other mention of those registers.
     // (Landing the loads in AGPRs instead would hide them from the compiler altogether, but a kernel that mentions AGPRs
     //  gets half its register budget as AGPRs -- 64 VGPRs for a 64-register canvas tile.)
-    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const void* tail_ptr_ = nullptr;  // this lane's entry of the next tile's page while the tile's last round runs, else a dummy in `trash`
     unsigned cells_v = 0u;  // lane j: item j of the round (cell id | class << 30)
     unsigned add0_v = 0u, nadd_v = 0u;  // ... its add list: first add, adds
     int n_round = 0;        // items of the round
-    const int hdr_lane = lane < HDR_LOAD_DWORDS ? lane : HDR_LOAD_DWORDS - 1;
     // header of item j of the round: dword `lane` of its CellHdr (lanes 20 .. 51 hold the 16 carry-ins)
+    // (past the end of the round: a dummy in `trash` -- every tile makes these loads, also one whose batch has no cell at all)
     auto hdr_ptr = [&](int j) -> const int* {
-        const unsigned cw = j < n_round ? (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63) : 0u;
+        int ln = tid;
+        asm volatile("" : "+v"(ln));   // (see process)
+        ln &= 63;
+        const int hdr_lane = ln < HDR_LOAD_DWORDS ? ln : HDR_LOAD_DWORDS - 1;
+        if (j >= n_round) return (const int*)a.trash + hdr_lane;
+        const unsigned cw = (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63);
         return (const int*)(a.cell_hdr + (cw & 0x3fffffffu)) + hdr_lane;
     };
     auto hdr_cls = [&](int h) { return (__builtin_amdgcn_readlane(h, 12) >> 3) & 3; };
@@ -2149,35 +2189,82 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
     // scatter); else the list's first entry: any valid address
     // (from the item, not from its header: the adds of an item are asked for together with -- not behind -- its header)
     auto add_ptr = [&](int j) -> const void* {
-        const bool in = j < n_round;
-        const unsigned cw = in ? (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63) : 0u;
-        const int n_add = in ? __builtin_amdgcn_readlane((int)nadd_v, j & 63) : 0;
-        const int add0 = in ? __builtin_amdgcn_readlane((int)add0_v, j & 63) : 0;
-        const TileAdd* p = a.adds;
+        // (behind the round's items: the 16 bytes this lane would throw away are its entry of the NEXT tile's page while the tile's
+        //  last round runs -- what the loop holds when it ends is the add "of item n + 1" --, a dummy in `trash` otherwise)
+        if (j >= n_round) return tail_ptr_;
+        const unsigned cw = (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63);
+        const int n_add = __builtin_amdgcn_readlane((int)nadd_v, j & 63);
+        const int add0 = __builtin_amdgcn_readlane((int)add0_v, j & 63);
+        const void* p = tail_ptr_;
         if ((cw >> 30) == 2u && n_add > 0) p = a.adds + (size_t)add0 + (tid < n_add ? tid : n_add - 1);
         return p;
     };
     // (class 1) the carry-in of this lane's tile row: dwords 20 + 2 row, 21 + 2 row of the header, fetched across the lanes
-    auto carry_of = [&](int h) -> double {
+    auto carry_of = [&](int h, int trow) -> double {
         const int at = (HDR_DWORDS + 2 * trow) * 4;
         const int lo = __builtin_amdgcn_ds_bpermute(at, h), hi = __builtin_amdgcn_ds_bpermute(at + 4, h);
         return __hiloint2double(hi, lo);
     };
-#define SVGR_HDR_LOAD(tgt, ptr) asm volatile("global_load_dword %0, %1, off" : "=v"(tgt) : "v"(ptr) : "memory")
+    // (names and clobber lists of the fixed targets; the pairs are even-aligned)
+#define hq0_R "v116"
+#define hq0_C "v116"
+#define hq1_R "v117"
+#define hq1_C "v117"
+#define hq_R "v118"
+#define hq_C "v118"
+#define wq0_R "v[120:121]"
+#define wq0_C "v120", "v121"
+#define vq0_R "v[122:123]"
+#define vq0_C "v122", "v123"
+#define wq_R "v[124:125]"
+#define wq_C "v124", "v125"
+#define vq_R "v[126:127]"
+#define vq_C "v126", "v127"
+    static_assert(SVGR_FIX0 == 116, "the register names above");
 #ifdef SVGR_DBG_ADD_LOAD_NT
 #define SVGR_ADD_NT " nt"       // diagnostic: the add lists are read once -- a nontemporal load
 #else
 #define SVGR_ADD_NT ""
 #endif
+#define SVGR_HDR_LOAD(tgt, ptr)                                                                                        \
+    do {                                                                                                               \
+        if constexpr (FIXED) asm volatile("global_load_dword " tgt##_R ", %0, off" : : "v"(ptr) : "memory", tgt##_C);   \
+        else asm volatile("global_load_dword %0, %1, off" : "=v"(tgt) : "v"(ptr) : "memory");                           \
+    } while (0)
 #define SVGR_ADD_LOAD(tw, tv, ptr)                                                                                     \
-    asm volatile("global_load_dwordx2 %0, %2, off" SVGR_ADD_NT "\n\tglobal_load_dwordx2 %1, %2, off offset:8" SVGR_ADD_NT : "=&v"(tw), "=&v"(tv) : "v"(ptr) : "memory")
-#define SVGR_HDR_TAKE(n, dst, tgt) asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, %1" : "=v"(dst) : "v"(tgt) : "memory")
-#define SVGR_ADD_TAKE(n, dw, dv, tw, tv)                                                                               \
-    asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(dw), "=&v"(dv) : "v"(tw), "v"(tv) : "memory")
-    // the prologue's wait: two headers and an add at once
-#define SVGR_PROLOGUE_TAKE(n, d0, d1, dw, dv, t0, t1, tw, tv)                                                          \
-    asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b64 %2, %6\n\tv_mov_b64 %3, %7"   \
-                 : "=&v"(d0), "=&v"(d1), "=&v"(dw), "=&v"(dv) : "v"(t0), "v"(t1), "v"(tw), "v"(tv) : "memory")
+    do {                                                                                                               \
+        if constexpr (FIXED)                                                                                           \
+            asm volatile("global_load_dwordx2 " tw##_R ", %0, off" SVGR_ADD_NT "\n\tglobal_load_dwordx2 " tv##_R ", %0, off offset:8" SVGR_ADD_NT \
+                         : : "v"(ptr) : "memory", tw##_C, tv##_C);                                                     \
+        else                                                                                                           \
+            asm volatile("global_load_dwordx2 %0, %2, off" SVGR_ADD_NT "\n\tglobal_load_dwordx2 %1, %2, off offset:8" SVGR_ADD_NT \
+                         : "=&v"(tw), "=&v"(tv) : "v"(ptr) : "memory");                                                 \
+    } while (0)
+    // the wait at a round's start: ALL its first loads (the two headers and the add the first items need; header 2 and add 1, which
+    // the loop starts with) -- n = what may stay in flight behind them: the previous tile's stores, or nothing
+#define SVGR_ROUND_TAKE(n, d0, d1, dw0, dv0, d2, dw1, dv1)                                                             \
+    do {                                                                                                               \
+        if constexpr (FIXED)                                                                                           \
+            asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, " hq0_R "\n\tv_mov_b32 %1, " hq1_R "\n\tv_mov_b64 %2, " wq0_R "\n\tv_mov_b64 %3, " vq0_R \
+                         "\n\tv_mov_b32 %4, " hq_R "\n\tv_mov_b64 %5, " wq_R "\n\tv_mov_b64 %6, " vq_R                 \
+                         : "=&v"(d0), "=&v"(d1), "=&v"(dw0), "=&v"(dv0), "=&v"(d2), "=&v"(dw1), "=&v"(dv1) : : "memory"); \
+        else                                                                                                           \
+            asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, %7\n\tv_mov_b32 %1, %8\n\tv_mov_b64 %2, %9\n\tv_mov_b64 %3, %10" \
+                         "\n\tv_mov_b32 %4, %11\n\tv_mov_b64 %5, %12\n\tv_mov_b64 %6, %13"                            \
+                         : "=&v"(d0), "=&v"(d1), "=&v"(dw0), "=&v"(dv0), "=&v"(d2), "=&v"(dw1), "=&v"(dv1)              \
+                         : "v"(hq0), "v"(hq1), "v"(wq0), "v"(vq0), "v"(hq), "v"(wq), "v"(vq) : "memory");                \
+    } while (0)
+    // the wait at an iteration's end: the header asked for at its start (three items ahead) and the add asked for in front of its
+    // composite (two ahead) -- everything this wave has in flight, so nothing is counted
+#define SVGR_ITER_TAKE(d2, dw1, dv1)                                                                                   \
+    do {                                                                                                               \
+        if constexpr (FIXED)                                                                                           \
+            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, " hq_R "\n\tv_mov_b64 %1, " wq_R "\n\tv_mov_b64 %2, " vq_R  \
+                         : "=&v"(d2), "=&v"(dw1), "=&v"(dv1) : : "memory");                                             \
+        else                                                                                                           \
+            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %3\n\tv_mov_b64 %1, %4\n\tv_mov_b64 %2, %5"             \
+                         : "=&v"(d2), "=&v"(dw1), "=&v"(dv1) : "v"(hq), "v"(wq), "v"(vq) : "memory");                    \
+    } while (0)
     // the adds of an item into delta tile `buf`
     auto scatter = [&](int h, unsigned long long first_w, double first_v, int buf) {
 #ifdef SVGR_DBG_NOSCATTER
@@ -2265,10 +2352,18 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
 
     // ---- scan + fill rule + paint + source-over of the item whose deltas are in delta tile `buf` ----
     const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * (64 / CH);  // a wave owns 64 / CH tile rows
+    const int wrow0_ = wrow0;
     auto process = [&](int h, int buf) {
         const int bits = __builtin_amdgcn_readlane(h, 12);
         const int cls = (bits >> 3) & 3;
         if (cls == 0) return;
+        // (the lane's coordinates and what hangs on them -- its place in the delta tile, its carry-in's dwords -- are derived from
+        //  the thread id again for every item: a handful of integer instructions instead of registers held, or spilled and
+        //  reloaded behind a vmcnt(0), across the whole loop)
+        int tid_p = tid;
+        asm volatile("" : "+v"(tid_p));
+        const int trow = tid_p / CH, chunk = tid_p % CH, lane = tid_p & 63;
+        double* const my0 = (double*)s_mem + trow * ROW_STRIDE + chunk * CHUNK_STRIDE;
         const int rule = bits & 1, pflags = (bits >> 1) & 3;
         const double p0 = __hiloint2double(__builtin_amdgcn_readlane(h, 1), __builtin_amdgcn_readlane(h, 0));
         const double p1 = __hiloint2double(__builtin_amdgcn_readlane(h, 3), __builtin_amdgcn_readlane(h, 2));
@@ -2309,7 +2404,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
         if (cls == 1) {
             // No record reaches the tile: a row's running sum is its carry-in from the layer's first column in the tile
             // to its last (np.cumsum of zeros).  No delta tile, no prefix sum.
-            const double cin1 = carry_of(h);
+            const double cin1 = carry_of(h, trow);
             int lo_i = lo_c + col_shift - chunk * PX, hi_i = hi_c + col_shift - chunk * PX;
             lo_i = lo_i < 0 ? 0 : lo_i;
             hi_i = hi_i > PX ? PX : hi_i;
@@ -2359,7 +2454,8 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
                 constexpr unsigned long long rep = CH == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
                 constexpr unsigned long long m1 = rep * (CH == 8 ? 0xfeull : 0xeull), m2 = rep * (CH == 8 ? 0xfcull : 0xcull), m4 = rep * 0xf0ull;
                 double v;
-#define SVGR_MASKED_ADD(acc_, v_, m_) asm volatile("s_mov_b64 exec, %2\n\tv_add_f64 %0, %0, %1\n\ts_mov_b64 exec, -1" : "+v"(acc_) : "v"(v_), "s"(m_))
+                const unsigned long long exec_all = __builtin_amdgcn_read_exec();   // (all ones: every branch above is wave-uniform)
+#define SVGR_MASKED_ADD(acc_, v_, m_) asm volatile("s_mov_b64 exec, %2\n\tv_add_f64 %0, %0, %1\n\ts_mov_b64 exec, %3" : "+v"(acc_) : "v"(v_), "s"(m_), "s"(exec_all))
                 v = dpp_row_shr<1>(inc); SVGR_MASKED_ADD(inc, v, m1);
                 v = dpp_row_shr<2>(inc); SVGR_MASKED_ADD(inc, v, m2);
                 if (CH == 8) { v = dpp_row_shr<4>(inc); SVGR_MASKED_ADD(inc, v, m4); }
@@ -2437,6 +2533,7 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
                 // again -- no saveexec / branch / restore triple per pixel (three quarters of the kernel's scalar instructions),
                 // no hole in the vector stream.  (EXEC is all ones here: every branch above is wave-uniform.)
                 const double cut = kZeroCut;
+                const unsigned long long exec_all = __builtin_amdgcn_read_exec();
 #define SVGR_BLEND_PX(i)                                                                                               \
     if constexpr (i < PX) {                                                                                            \
         double t0, t1, t2, t3, mval;                                                                                   \
@@ -2453,13 +2550,13 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
             "v_fma_f64 %[a1], %[m], %[t1], %[a1]\n\t"                                                                  \
             "v_fma_f64 %[a2], %[m], %[t2], %[a2]\n\t"                                                                  \
             "v_fma_f64 %[a3], %[m], %[t3], %[a3]\n\t"                                                                  \
-            "s_mov_b64 exec, -1\n"                                                                                     \
+            "s_mov_b64 exec, %[all]\n"                                                                                 \
             SVGR_BLEND_C1_TAIL                                                                                         \
             : [a0] "+v"(acc[i < PX ? i : 0][0]), [a1] "+v"(acc[i < PX ? i : 0][1]), [a2] "+v"(acc[i < PX ? i : 0][2]),   \
               [a3] "+v"(acc[i < PX ? i : 0][3]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),          \
               [m] "=&v"(mval), [vis] "=&s"(vis_)                                                                        \
             : [t] "v"(t[i < PX ? i : 0]), [pa] "v"(p3v), [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [cut] "s"(cut),        \
-              [fast] "s"(c1fast), [k] "v"(t[0]), [s0] "v"(t[1 % PX]), [s1] "v"(t[2 % PX]), [s2] "v"(t[3 % PX]),           \
+              [all] "s"(exec_all), [fast] "s"(__builtin_amdgcn_readfirstlane(c1fast)), [k] "v"(t[0]), [s0] "v"(t[1 % PX]), [s1] "v"(t[2 % PX]), [s2] "v"(t[3 % PX]),           \
               [s3] "v"(t[4 % PX])                                                                                       \
             : "scc");                                                                                                  \
     }
@@ -2563,99 +2660,23 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
         }
     };
 
-    // ---- the item loop: rounds of up to 64 items (a round's cell ids sit one per lane) ----
-    // (a whole-canvas launch has the first PAGE_ITEMS items in hand already: its first round is those)
-    for (int r0_ = 0; r0_ < n_items; r0_ += n_round) {
-        const bool paged = a.use_order && r0_ == 0;
-        const int round_cap = paged ? PAGE_ITEMS : 64;
-        n_round = n_items - r0_ < round_cap ? n_items - r0_ : round_cap;
-        const int n = n_round;
-        if (paged) {
-            cells_v = lane < n ? page.x : 0u; add0_v = page.y; nadd_v = page.z;
-        } else {
-            const uint4 it = lane < n ? a.items[(size_t)item0 + r0_ + lane] : make_uint4(0u, 0u, 0u, 0u);
-            cells_v = it.x; add0_v = it.y; nadd_v = it.z;
-        }
-        int hq;                       // load target: the header in flight
-        unsigned long long wq;        // load targets: the add in flight ({where, 0} and its value)
-        double vq;
-        int h_p, h_s, h_a;            // the landed headers of items k, k+1, k+2
-        unsigned long long w_s;       // the landed add of item k+1
-        double v_s;
-        {
-            // everything the first two items need, and the loop's standing queue [header 2, add 1], asked for in ONE go: the
-            // items carry their add lists, so no load waits for another (it was three round trips in a row)
-            int hq0, hq1;                  // load targets of the prologue
-            unsigned long long wq0;
-            double vq0;
-            const int* q0 = hdr_ptr(0);
-            const int* q1 = hdr_ptr(1);
-            const int* q2 = hdr_ptr(2);
-            const void* a0 = add_ptr(0);
-            const void* a1 = add_ptr(1);
-            SVGR_HDR_LOAD(hq0, q0);
-            SVGR_HDR_LOAD(hq1, q1);
-            SVGR_ADD_LOAD(wq0, vq0, a0);
-            SVGR_HDR_LOAD(hq, q2);
-            SVGR_ADD_LOAD(wq, vq, a1);
-            SVGR_PROLOGUE_TAKE(3, h_p, h_s, w_s, v_s, hq0, hq1, wq0, vq0);   // (leaves [header 2, add 1] in flight)
-            TL_PHASE(0);
-            h_s = 1 < n ? h_s : 0;
-            // (first round: the zero-fill of the delta tiles; later ones: the previous round's last scans)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            scatter(h_p, w_s, v_s, 0);
-            TL_PHASE(1);
-        }
-        for (int k = 0; k < n; ++k) {
-            // in flight here: [header k+2, add k+1 (two loads)]; the adds of item k are on their way into delta tile k & 1
-            SVGR_HDR_TAKE(2, h_a, hq);
-            h_a = k + 2 < n ? h_a : 0;
-            {
-                const int* q = hdr_ptr(k + 3);
-                SVGR_HDR_LOAD(hq, q);
-            }
-            // behind this barrier: every wave's adds of item k have landed; everybody's scan of item k-1 has zeroed its tile
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            SVGR_ADD_TAKE(1, w_s, v_s, wq, vq);
-            scatter(h_s, w_s, v_s, (k + 1) & 1);
-            {
-                const void* ap = add_ptr(k + 2);
-                SVGR_ADD_LOAD(wq, vq, ap);
-            }
-            process(h_p, k & 1);
-            h_p = h_s; h_s = h_a;
-        }
-        // (nothing may be in flight into registers that are about to mean something else)
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" : : "v"(hq), "v"(wq), "v"(vq) : "memory");
-    }
-    TL_PHASE(2);
-    if (GROUPS && open_g >= 0) close_group();
-    // (a tile without items has not passed a barrier yet: the other wave's zero-fill must not land on the transposed tile below)
-    if (n_items == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-#ifdef SVGR_DBG_TIMELINE
-    // per workgroup {start, end, items, XCC | hardware id} on the 100 MHz clock (profiles/timeline.py)
-    if (tid == 0 && a.dbg) {
-        const unsigned wg_ = blockIdx.x;
-        if (wg_ < (1u << 16)) {
-            unsigned hwid_, xcc_;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid_));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
-            unsigned long long* t_ = a.dbg + 8 + 4 * (size_t)wg_;
-            t_[0] = tl_start_; t_[1] = __builtin_amdgcn_s_memrealtime(); t_[2] = (unsigned long long)n_items;
-            t_[3] = ((unsigned long long)xcc_ << 32) | hwid_;
-            unsigned long long* p_ = a.dbg + 8 + 4 * (size_t)(1u << 16) + 4 * (size_t)wg_;
-            p_[0] = tl_ph_[0]; p_[1] = tl_ph_[1]; p_[2] = tl_ph_[2]; p_[3] = 0;
-        }
-    }
-#endif
-    if (OUT <= 1) {
-        const int row = band * TR + trow;  // viewport-local row
-        const int out_row = by * TR + trow - a.win_r;  // row of the output buffer (the window's / the owned bands packed)
+    // ---- a finished tile goes out: clip, float32, transposed rows, stores (canvas outputs) ----
+    // Returns with its stores in flight.  The float32 variant issues EXACTLY 64 / CH store instructions per wave, every lane
+    // enabled (a lane outside the output writes its 16 bytes to `trash`): the counted waits of the next tile's first
+    // loads step over them by number.
+    auto store_tile_a = [&](int by_, int bx_, int band_) {
+        if (OUT > 1) return;
+        // (the lane's coordinates pass through an empty asm: what is derived from them below is recomputed per tile instead
+        //  of living in registers -- or in scratch -- across the item loops)
+        int lane = lane_, trow = trow_, chunk = chunk_, wrow0 = wrow0_;
+        asm volatile("" : "+v"(lane), "+v"(trow), "+v"(chunk), "+s"(wrow0));
+        // (and the launch's arguments are read again from the kernel-argument segment: reload_tile_args)
+        TileArgs a;
+        reload_tile_args(a);
         if (a.clip01 && !(OUT == 0 && SVGR_X_CVTCLAMP)) {
             // clip(0, 1) (S:326) as max / min: two instructions per channel (written as comparisons the compiler turns every
-            // channel into two exec-masked branches -- 250 instructions per tile, a tenth of the kernel's).  A canvas value is
-            // never a NaN (the sentinel's never passes the coverage test), so the NaN rule of v_max does not matter.
+            // channel into two exec-masked branches).  A canvas value is never a NaN (the sentinel's never passes the
+            // coverage test), so the NaN rule of v_max does not matter.
 #pragma unroll
             for (int i = 0; i < PX; ++i)
 #pragma unroll
@@ -2690,41 +2711,295 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
                 for (int i = 0; i < PX; ++i)
                     tp[trow * T_ROW + chunk * (PX + 1) + i] = make_float4((float)acc[i][0], (float)acc[i][1], (float)acc[i][2], (float)acc[i][3]);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int col = (bx - a.ct0) * TC + lane - a.win_c;  // column of the output buffer this lane stores
-            const bool col_ok = col >= 0 && col < a.win_cols;
+        } else {
+            const int row = band_ * TR + trow;              // viewport-local row
+            const int out_row = by_ * TR + trow - a.win_r;  // row of the output buffer (the window's / the owned bands packed)
+            if (row < a.vrows && out_row >= 0 && out_row < a.win_rows) {
+                const int col0 = (bx_ - a.ct0) * TC + chunk * PX - a.win_c;  // column of the output buffer
 #pragma unroll
-            for (int r = 0; r < 64 / CH; ++r) {
-                const int tr_ = wrow0 + r;
-                const int vrow = band * TR + tr_, orow = by * TR + tr_ - a.win_r;
-                if (vrow < a.vrows && orow >= 0 && orow < a.win_rows && col_ok) {
-                    const float4 v = tp[tr_ * T_ROW + lane + lane / PX];
-                    // The canvas is written once and not read again by this launch: a NONTEMPORAL store.  A wave ends only when its
-                    // stores are acknowledged (s_endpgm waits for them), so the write latency is slot time of every workgroup: the
-                    // plain store's was 30 us of the launch (162 -> 132 us, A/B on one box; without any store: 116).
-#ifdef SVGR_DBG_PLAIN_STORE
-                    ((float4*)a.out)[(size_t)orow * a.out_cols + col] = v;
-#else
-                    nt_store16((float4*)a.out + ((size_t)orow * a.out_cols + col), v);
-#endif
-                }
-            }
-            (void)row; (void)out_row;
-        } else if (row < a.vrows && out_row >= 0 && out_row < a.win_rows) {
-            const int col0 = (bx - a.ct0) * TC + chunk * PX - a.win_c;  // column of the output buffer
-#pragma unroll
-            for (int i = 0; i < PX; ++i) {
-                if (col0 + i >= 0 && col0 + i < a.win_cols) {
-                    size_t o = (size_t)out_row * a.out_cols + col0 + i;
-                    // (plain stores: a lane's pixels are 32 bytes each, 256 bytes from the next lane's -- nontemporal, such pieces
-                    //  reach the memory one by one: material-design's tile kernel 0.22 -> 1.75 ms; the L2 merges them)
-                    ((double4*)a.out)[o] = make_double4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+                for (int i = 0; i < PX; ++i) {
+                    if (col0 + i >= 0 && col0 + i < a.win_cols) {
+                        size_t o = (size_t)out_row * a.out_cols + col0 + i;
+                        // (plain stores: a lane's pixels are 32 bytes each, 256 bytes from the next lane's -- nontemporal, such pieces
+                        //  reach the memory one by one: material-design's tile kernel 0.22 -> 1.75 ms; the L2 merges them)
+                        ((double4*)a.out)[o] = make_double4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+                    }
                 }
             }
         }
+    };
+    auto store_tile_b = [&](int by_, int bx_, int band_) {
+        if (OUT != 0) return;
+#ifdef SVGR_DBG_NOSTORE
+        return;
+#endif
+        int lane = lane_, wrow0 = wrow0_;
+        asm volatile("" : "+v"(lane), "+s"(wrow0));
+        TileArgs a;
+        reload_tile_args(a);
+        {
+            constexpr int T_ROW = CH * (PX + 1);  // slots per transposed tile row
+            float4* const tp = (float4*)s_mem;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int col = (bx_ - a.ct0) * TC + lane - a.win_c;  // column of the output buffer this lane stores
+            const bool col_ok = col >= 0 && col < a.win_cols;
+            float4* const trash = (float4*)a.trash + lane;
+#pragma unroll
+            for (int r = 0; r < 64 / CH; ++r) {
+                const int tr_ = wrow0 + r;
+                const int vrow = band_ * TR + tr_, orow = by_ * TR + tr_ - a.win_r;
+                const bool ok = vrow < a.vrows && orow >= 0 && orow < a.win_rows && col_ok;
+                const float4 v4 = tp[tr_ * T_ROW + lane + lane / PX];
+                const f32x4_t v = {v4.x, v4.y, v4.z, v4.w};
+                float4* const dst = ok ? (float4*)a.out + ((size_t)orow * a.out_cols + col) : trash;
+                // The canvas is written once and not read again by this launch: a NONTEMPORAL store (plain stores pushed the add
+                // lists out of the caches the kernel reads them from: 162 -> 132 us).  Issued by hand: the count is what matters.
+                // (the s_nop: a store of more than 8 bytes reads its data registers a moment AFTER it issues -- a VALU write to them in the
+                //  next cycle lands in the stored value.  The compiler pads its own stores; it does not know this is one.)
+#ifdef SVGR_DBG_PLAIN_STORE
+                asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+#else
+                asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+#endif
+            }
+            // the wave's transposed rows back to zero: they are delta tiles again (its own LDS operations stay in order; the
+            // barrier in front of the next scatter is between this and the other wave's adds)
+            {
+                constexpr int W_SLOTS = (64 / CH) * T_ROW;  // 16-byte slots of one wave's transposed rows
+                float z0 = 0.f;
+                asm volatile("" : "+v"(z0));   // (a zero made here: hoisted out of the tile loop it was spilled and reloaded -- behind a vmcnt(0))
+                const float4 z = make_float4(z0, z0, z0, z0);
+#pragma unroll
+                for (int j = 0; j < (W_SLOTS + 63) / 64; ++j)
+                    if (j * 64 + lane < W_SLOTS) tp[wrow0 * T_ROW + j * 64 + lane] = z;
+            }
+        }
+    };
+    constexpr int N_STORES = 64 / CH;  // store instructions of store_tile<float32> per wave
+
+    // ---- the tiles of this workgroup ----
+    int hq0, hq1, hq;                  // load targets: the first two headers of a round, the header in flight in the loop
+    unsigned long long wq0, wq;        // load targets: the first add of the round's first item / the add in flight ({where, 0})
+    double vq0, vq;                    // ... and their values
+    (void)hq0; (void)hq1; (void)hq; (void)wq0; (void)wq; (void)vq0; (void)vq;
+    unsigned next_tile_ = 0u;
+    bool have_next_ = false;
+#ifdef SVGR_DBG_TIMELINE
+    unsigned long long tl_items_ = 0;
+#endif
+    // a round's items sit one per lane; its first loads: everything the first two items need, and the loop's standing queue
+    // [header 2, add 1], asked for in ONE go (the items carry their add lists, so no load waits for another).  All of them are
+    // unconditional: past the end of the list they read a valid dummy address (or the next tile's page: add_ptr).
+    auto issue_round = [&](int r0) {
+        tail_ptr_ = a.trash;
+        if (have_next_ && r0 + n_round >= n_items) {
+            TileArgs ar;
+            reload_tile_args(ar);
+            int ln = lane_;
+            asm volatile("" : "+v"(ln));
+            tail_ptr_ = ar.pages + (size_t)next_tile_ * PAGE_STRIDE + (ln < PAGE_STRIDE ? ln : PAGE_ITEMS);
+        }
+        const int* q0 = hdr_ptr(0);
+        const int* q1 = hdr_ptr(1);
+        const int* q2 = hdr_ptr(2);
+        const void* a0 = add_ptr(0);
+        const void* a1 = add_ptr(1);
+        SVGR_HDR_LOAD(hq0, q0);
+        SVGR_HDR_LOAD(hq1, q1);
+        SVGR_ADD_LOAD(wq0, vq0, a0);
+        SVGR_HDR_LOAD(hq, q2);
+        SVGR_ADD_LOAD(wq, vq, a1);
+    };
+    // the tile `tile_` (its page in page01 / page23): which one, its first round, and that round's loads on their way
+    auto begin_tile = [&]() {
+        TileArgs a;
+        reload_tile_args(a);
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
+        if (a.use_order) {
+            by = __builtin_amdgcn_readlane((int)(unsigned)page01, PAGE_ITEMS);  // (ordinal among the owned bands)
+            bx = __builtin_amdgcn_readlane((int)(unsigned)(page01 >> 32), PAGE_ITEMS);
+            item0 = __builtin_amdgcn_readlane((int)(unsigned)page23, PAGE_ITEMS);
+            n_items = __builtin_amdgcn_readlane((int)(unsigned)(page23 >> 32), PAGE_ITEMS);
+        } else {
+            // (the launch covers the column tiles [ct0, ct0 + win_ct) of the bands [band0, band0 + n_bands): the render window)
+            by = __builtin_amdgcn_readfirstlane((int)(tile_ / (unsigned)a.win_ct));
+            bx = (int)tile_ - by * a.win_ct + a.ct0;
+            const int2 ti = a.tile_info[(size_t)owned_band_at(a.own, by + a.band0) * a.n_ct + bx];
+            item0 = __builtin_amdgcn_readfirstlane(ti.x);
+            n_items = __builtin_amdgcn_readfirstlane(ti.y);
+        }
+#ifdef SVGR_DBG_NOITEMS
+        n_items = 0;  // diagnostic: the tile's fixed cost alone
+#endif
+        band = owned_band_at(a.own, by + a.band0);
+        tile_r0 = a.vr0 + band * TR;
+        tile_c0 = a.vc0 + bx * TC;
+        tile_c1 = tile_c0 + TC;
+        clip_tag = -1;
+#ifdef SVGR_DBG_TIMELINE
+        tl_items_ += (unsigned long long)n_items;
+#endif
+        // the first round (a whole-canvas launch has the first PAGE_ITEMS items in hand already: its first round is those)
+        const int round_cap = a.use_order ? PAGE_ITEMS : 64;
+        n_round = n_items < round_cap ? n_items : round_cap;
+        if (a.use_order) {
+            cells_v = lane < n_round ? (unsigned)page01 : 0u; add0_v = (unsigned)(page01 >> 32); nadd_v = (unsigned)page23;
+        } else {
+            const uint4 it = lane < n_round ? a.items[(size_t)item0 + lane] : make_uint4(0u, 0u, 0u, 0u);
+            cells_v = it.x; add0_v = it.y; nadd_v = it.z;
+        }
+        // (the fixed-target variant asks for the round's first loads here -- ahead of the previous tile's stores; the others, whose
+        //  targets are variables, have ONE statement per target: the one at the top of a round)
+        if constexpr (FIXED) issue_round(0);
+    };
+    // the tile behind the next one: wave 0 asks a counter for it when a tile begins (a returning atomic of ONE lane, its target the
+    // fixed register v119, issued in front of the tile's first loads: it has landed when they have), leaves it in an LDS word
+    // the tile kernel uses for nothing else (padding of the last delta row) behind the tile's first barrier; both waves read
+    // it when the tile ends
+    constexpr int MAILBOX = 2 * DELTA_BYTES - 16;
+    const bool dealt = FIXED && a.use_order && gridDim.x < n_tiles_;   // (a persistent launch)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    bool asked = false;   // a fetch is in flight into v119 (wave 0)
+    auto ask_tile = [&]() {
+        if constexpr (FIXED) {
+            asked = true;
+            if (wave_s == 0) {
+                unsigned* const ctr = a.tile_ctr + 32 * (blockIdx.x & 7u);
+                const unsigned one = 1u;
+                unsigned long long keep_;
+                asm volatile("s_mov_b64 %[keep], exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add v119, %[p], %[one], off sc0\n\ts_mov_b64 exec, %[keep]"
+                             : [keep] "=&s"(keep_) : [p] "v"(ctr), [one] "v"(one) : "memory", "v119");
+            }
+        }
+    };
+    if (dealt) {
+        if (blockIdx.x == 0 && tid < 8) a.tile_ctr_clear[32 * tid] = 0u;
+        next_tile_ = gridDim.x + blockIdx.x;
+        have_next_ = next_tile_ < n_tiles_;
+        if (have_next_) ask_tile();
     }
+    begin_tile();
+    bool pend = false;   // N_STORES store instructions (the previous tile's canvas) were issued behind the round's first loads
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0;
+        int h_p, h_s, h_a;            // the landed headers of items k, k+1, k+2
+        unsigned long long w_s;       // the landed add of the round's first item
+        double v_s;
+        unsigned long long w_n;       // the landed add of item k+1 -- when the tile's last round ends: the next tile's page {x, y}
+        double v_n;                   // ... {z, w}
+        // ---- the item loop: rounds of up to 64 items ----
+        bool preissued = FIXED;   // the tile's first round: begin_tile has issued its loads
+        int r0_ = 0;
+        do {
+            if (!preissued) {
+                if (r0_ > 0) {   // (the first round's items: begin_tile)
+                    n_round = n_items - r0_ < 64 ? n_items - r0_ : 64;
+                    const uint4 it = lane < n_round ? a.items[(size_t)item0 + r0_ + lane] : make_uint4(0u, 0u, 0u, 0u);
+                    cells_v = it.x; add0_v = it.y; nadd_v = it.z;
+                }
+                issue_round(r0_);
+            }
+            const int n = n_round;
+            static_assert(N_STORES == 8 || OUT != 0, "the wait below steps over eight store instructions");
+            if (r0_ == 0) TL_PHASE(0);
+            if (preissued && pend) SVGR_ROUND_TAKE(8, h_p, h_s, w_s, v_s, h_a, w_n, v_n);   // (N_STORES)
+            else SVGR_ROUND_TAKE(0, h_p, h_s, w_s, v_s, h_a, w_n, v_n);
+            if (r0_ == 0) TL_PHASE(1);
+            h_p = 0 < n ? h_p : 0;
+            h_s = 1 < n ? h_s : 0;
+            h_a = 2 < n ? h_a : 0;
+            // (first tile: the zero-fill of the delta tiles; later: the previous round's last scans / the re-zeroed transposed rows)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (FIXED) {
+                if (asked && r0_ == 0) {
+                    asked = false;
+                    if (wave_s == 0) {
+                        unsigned q;
+                        asm volatile("v_mov_b32 %0, v119" : "=v"(q) : : "memory");   // (landed: older than the loads the wait above covered)
+                        const unsigned t2 = 2u * gridDim.x + 8u * (unsigned)__builtin_amdgcn_readfirstlane((int)q) + (blockIdx.x & 7u);
+                        if (tid == 0) *(volatile unsigned*)(s_mem + MAILBOX) = t2;
+                    }
+                }
+            }
+            scatter(h_p, w_s, v_s, 0);
+            for (int k = 0; k < n; ++k) {
+                // in hand: the headers of items k, k+1, k+2 and the add of item k+1; the adds of item k are on their way into
+                // delta tile k & 1
+                {
+                    const int* q = hdr_ptr(k + 3);
+                    SVGR_HDR_LOAD(hq, q);
+                }
+                // behind this barrier: every wave's adds of item k have landed; everybody's scan of item k-1 has zeroed its tile
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                scatter(h_s, w_n, v_n, (k + 1) & 1);
+                {
+                    const void* ap = add_ptr(k + 2);
+                    SVGR_ADD_LOAD(wq, vq, ap);
+                }
+                process(h_p, k & 1);
+                h_p = h_s; h_s = h_a;
+                SVGR_ITER_TAKE(h_a, w_n, v_n);
+                h_a = k + 3 < n ? h_a : 0;
+            }
+            // (nothing is in flight: the last iteration's wait)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            preissued = false;
+            r0_ += n;
+        } while (r0_ < n_items);
+        TL_PHASE(2);
+        if (GROUPS && open_g >= 0) close_group();
+        // ---- on to the next tile: this tile leaves the registers (float32: into LDS), the next tile's first loads go out, and
+        // behind them the stores ----
+        const int s_by = by, s_bx = bx, s_band = band;
+        const bool go = have_next_;
+        store_tile_a(s_by, s_bx, s_band);
+        if (go) {
+            page01 = w_n;
+            page23 = (unsigned long long)__double_as_longlong(v_n);
+            tile_ = (unsigned)__builtin_amdgcn_readfirstlane((int)next_tile_);   // (scalars, said so: the compiler kept them in VGPRs -- and spilled them)
+            pass_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(pass_ + 1u));
+            next_tile_ = (unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned*)(s_mem + MAILBOX));
+            have_next_ = next_tile_ < n_tiles_;
+            if (have_next_) ask_tile();
+            begin_tile();
+        }
+        store_tile_b(s_by, s_bx, s_band);
+        if (!go) break;
+        pend = OUT == 0;   // (the other outputs stored in front of the loads: their waits cover the stores anyway)
+#ifdef SVGR_DBG_NOPEND
+        pend = false;      // diagnostic: the next tile's first waits also wait for the stores
+#endif
+    }
+
+#ifdef SVGR_DBG_TIMELINE
+    // per workgroup {start, end, items, XCC | hardware id} on the 100 MHz clock (profiles/timeline.py)
+    if (tid == 0 && a.dbg) {
+        const unsigned wg_ = blockIdx.x;
+        if (wg_ < (1u << 16)) {
+            unsigned hwid_, xcc_;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid_));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+            unsigned long long* t_ = a.dbg + 8 + 4 * (size_t)wg_;
+            t_[0] = tl_start_; t_[1] = __builtin_amdgcn_s_memrealtime(); t_[2] = tl_items_;
+            t_[3] = ((unsigned long long)xcc_ << 32) | hwid_;
+            unsigned long long* p_ = a.dbg + 8 + 4 * (size_t)(1u << 16) + 4 * (size_t)wg_;
+            p_[0] = tl_ph_[0]; p_[1] = tl_ph_[1]; p_[2] = tl_ph_[2]; p_[3] = (unsigned long long)(pass_ + 1u);
+        }
+    }
+#endif
+}
+
+template <int OUT, bool CLIP = false, bool GROUPS = false, bool GRAD = false>
+__global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_EU)) void k_tile_render(const TileArgs a) {
+    tile_body<OUT, CLIP, GROUPS, GRAD>(a);
+}
+template <>
+__global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) __attribute__((amdgpu_num_vgpr(SVGR_FIX0 / 2))) void k_tile_render<0, false, false, false>(const TileArgs a) {
+    tile_body<0, false, false, false>(a);
 }
 
 // ======================================================================================
@@ -3550,6 +3825,13 @@ int svgr_init(int device_id, svgr_ctx** out) {
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return fail(SVGR_E_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
     c->own_stream = true;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipMalloc(&c->trash, 1024) != hipSuccess || hipMalloc((void**)&c->tile_ctr, 2 * 8 * 128) != hipSuccess ||
+        hipMemset(c->tile_ctr, 0, 2 * 8 * 128) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(SVGR_E_NOMEM, "out of device memory");
+    }
     *out = c;
     return 0;
 }
@@ -3560,6 +3842,8 @@ int svgr_shutdown(svgr_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->trash) (void)hipFree(ctx->trash);
+    if (ctx->tile_ctr) (void)hipFree(ctx->tile_ctr);
     g_pool.close(ctx->id);  // (its cached blocks; what it still has out is freed on return)
     delete ctx;
     return 0;
@@ -4441,6 +4725,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
     if (owned_bands > 0 && n_ctiles > 0) {
         TileArgs a;
         a.pages = b->pages.p; a.tile_info = b->tile_info.p; a.items = b->items.p; a.out = out->ptr;
+        a.trash = b->ctx->trash;
         a.cell_hdr = b->cell_hdr.p; a.adds = b->adds.p;
         a.n_ct = b->n_ctiles();
         a.group_clip_src = b->group_clip_src.p; a.group_opacity = b->group_opacity.p;
@@ -4500,7 +4785,22 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         a.win_cols = win[3];
         // the whole canvas: the tiles in k_tile_lists' order (heaviest first); a window: its tiles in raster order
         a.use_order = a.win_ct == n_ctiles && a.n_bands == owned_bands ? 1 : 0;
-        dim3 grid((unsigned)a.win_ct * (unsigned)a.n_bands);
+        // A whole-canvas launch is persistent: as many workgroups as the chip holds at once walk the tiles (k_tile_render);
+        // how many a CU holds is the variant's register / LDS budget.  SVGR_TILE_WGS_PER_CU overrides it (0: a workgroup per tile).
+        const unsigned n_tiles = (unsigned)a.win_ct * (unsigned)a.n_bands;
+        static const int wgs_env = getenv("SVGR_TILE_WGS_PER_CU") ? atoi(getenv("SVGR_TILE_WGS_PER_CU")) : -1;
+        const int wgs_variant = std::min((SVGR_WAVES_PER_EU * 4) / NW, (160 * 1024) / (2 * DELTA_BYTES));   // (registers, LDS)
+        const int wgs_per_cu = wgs_env >= 0 ? wgs_env : wgs_variant;
+        const bool production = out_kind == 0 && b->n_grads == 0 && b->n_groups == 0 && !b->has_clips;   // (the variant with the tile loop)
+        unsigned n_wgs = n_tiles;
+        if (a.use_order && production && wgs_per_cu > 0) n_wgs = std::min(n_tiles, (unsigned)wgs_per_cu * (unsigned)b->ctx->n_cu);
+        a.tile_ctr = a.tile_ctr_clear = b->ctx->tile_ctr;
+        if (n_wgs < n_tiles) {   // (a persistent launch: this set of counters, and the other one zeroed for the next such launch)
+            a.tile_ctr = b->ctx->tile_ctr + 256 * b->ctx->tile_ctr_set;
+            b->ctx->tile_ctr_set ^= 1;
+            a.tile_ctr_clear = b->ctx->tile_ctr + 256 * b->ctx->tile_ctr_set;
+        }
+        dim3 grid(n_wgs);
         static const int dyn_lds = getenv("SVGR_DBG_DYNLDS") ? atoi(getenv("SVGR_DBG_DYNLDS")) : 0;  // occupancy experiments
         switch (out_kind) {
             case 0:
