@@ -97,6 +97,9 @@ static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 102
 #ifndef SVGR_X_SCATWAIT
 #define SVGR_X_SCATWAIT 1               // scatter: no compiler-visible load (and so no compiler-placed vmcnt(0)) in front of the adds
 #endif
+#ifndef SVGR_X_RECOMPUTE
+#define SVGR_X_RECOMPUTE 0              // tile kernel: the lane's constants recomputed per item instead of held in registers
+#endif
 #ifndef SVGR_X_RUNS
 #define SVGR_X_RUNS 0                   // scatter: the further columns of a run straight-line under v_cmpx instead of a loop
 #endif
@@ -2173,13 +2176,16 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
     unsigned cells_v = 0u;  // lane j: item j of the round (cell id | class << 30)
     unsigned add0_v = 0u, nadd_v = 0u;  // ... its add list: first add, adds
     int n_round = 0;        // items of the round
+    const int hdr_lane = lane < HDR_LOAD_DWORDS ? lane : HDR_LOAD_DWORDS - 1;
     // header of item j of the round: dword `lane` of its CellHdr (lanes 20 .. 51 hold the 16 carry-ins)
     // (past the end of the round: a dummy in `trash` -- every tile makes these loads, also one whose batch has no cell at all)
     auto hdr_ptr = [&](int j) -> const int* {
+#if SVGR_X_RECOMPUTE
         int ln = tid;
         asm volatile("" : "+v"(ln));   // (see process)
         ln &= 63;
         const int hdr_lane = ln < HDR_LOAD_DWORDS ? ln : HDR_LOAD_DWORDS - 1;
+#endif
         if (j >= n_round) return (const int*)a.trash + hdr_lane;
         const unsigned cw = (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63);
         return (const int*)(a.cell_hdr + (cw & 0x3fffffffu)) + hdr_lane;
@@ -2357,13 +2363,15 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         const int bits = __builtin_amdgcn_readlane(h, 12);
         const int cls = (bits >> 3) & 3;
         if (cls == 0) return;
-        // (the lane's coordinates and what hangs on them -- its place in the delta tile, its carry-in's dwords -- are derived from
-        //  the thread id again for every item: a handful of integer instructions instead of registers held, or spilled and
-        //  reloaded behind a vmcnt(0), across the whole loop)
+#if SVGR_X_RECOMPUTE
+        // (the lane's coordinates and what hangs on them derived from the thread id again for every item: fewer registers held
+        //  across the loop, a dozen more instructions per item)
         int tid_p = tid;
         asm volatile("" : "+v"(tid_p));
         const int trow = tid_p / CH, chunk = tid_p % CH, lane = tid_p & 63;
         double* const my0 = (double*)s_mem + trow * ROW_STRIDE + chunk * CHUNK_STRIDE;
+        (void)lane;
+#endif
         const int rule = bits & 1, pflags = (bits >> 1) & 3;
         const double p0 = __hiloint2double(__builtin_amdgcn_readlane(h, 1), __builtin_amdgcn_readlane(h, 0));
         const double p1 = __hiloint2double(__builtin_amdgcn_readlane(h, 3), __builtin_amdgcn_readlane(h, 2));
@@ -2664,15 +2672,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
     // Returns with its stores in flight.  The float32 variant issues EXACTLY 64 / CH store instructions per wave, every lane
     // enabled (a lane outside the output writes its 16 bytes to `trash`): the counted waits of the next tile's first
     // loads step over them by number.
-    auto store_tile_a = [&](int by_, int bx_, int band_) {
+    auto store_tile_a = [&](const TileArgs& a, int by_, int bx_, int band_) {
         if (OUT > 1) return;
         // (the lane's coordinates pass through an empty asm: what is derived from them below is recomputed per tile instead
         //  of living in registers -- or in scratch -- across the item loops)
         int lane = lane_, trow = trow_, chunk = chunk_, wrow0 = wrow0_;
         asm volatile("" : "+v"(lane), "+v"(trow), "+v"(chunk), "+s"(wrow0));
-        // (and the launch's arguments are read again from the kernel-argument segment: reload_tile_args)
-        TileArgs a;
-        reload_tile_args(a);
+        // (and the launch's arguments were read again from the kernel-argument segment: reload_tile_args)
         if (a.clip01 && !(OUT == 0 && SVGR_X_CVTCLAMP)) {
             // clip(0, 1) (S:326) as max / min: two instructions per channel (written as comparisons the compiler turns every
             // channel into two exec-masked branches).  A canvas value is never a NaN (the sentinel's never passes the
@@ -2728,15 +2734,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
             }
         }
     };
-    auto store_tile_b = [&](int by_, int bx_, int band_) {
+    auto store_tile_b = [&](const TileArgs& a, int by_, int bx_, int band_) {
         if (OUT != 0) return;
 #ifdef SVGR_DBG_NOSTORE
         return;
 #endif
         int lane = lane_, wrow0 = wrow0_;
         asm volatile("" : "+v"(lane), "+s"(wrow0));
-        TileArgs a;
-        reload_tile_args(a);
         {
             constexpr int T_ROW = CH * (PX + 1);  // slots per transposed tile row
             float4* const tp = (float4*)s_mem;
@@ -2744,26 +2748,42 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int col = (bx_ - a.ct0) * TC + lane - a.win_c;  // column of the output buffer this lane stores
-            const bool col_ok = col >= 0 && col < a.win_cols;
-            float4* const trash = (float4*)a.trash + lane;
-#pragma unroll
-            for (int r = 0; r < 64 / CH; ++r) {
-                const int tr_ = wrow0 + r;
-                const int vrow = band_ * TR + tr_, orow = by_ * TR + tr_ - a.win_r;
-                const bool ok = vrow < a.vrows && orow >= 0 && orow < a.win_rows && col_ok;
-                const float4 v4 = tp[tr_ * T_ROW + lane + lane / PX];
-                const f32x4_t v = {v4.x, v4.y, v4.z, v4.w};
-                float4* const dst = ok ? (float4*)a.out + ((size_t)orow * a.out_cols + col) : trash;
-                // The canvas is written once and not read again by this launch: a NONTEMPORAL store (plain stores pushed the add
-                // lists out of the caches the kernel reads them from: 162 -> 132 us).  Issued by hand: the count is what matters.
-                // (the s_nop: a store of more than 8 bytes reads its data registers a moment AFTER it issues -- a VALU write to them in the
-                //  next cycle lands in the stored value.  The compiler pads its own stores; it does not know this is one.)
+            const int orow0 = by_ * TR + wrow0 - a.win_r, vrow0 = band_ * TR + wrow0;   // the wave's first row: of the output / of the viewport
+            const int col0 = (bx_ - a.ct0) * TC - a.win_c;
+            // (the s_nop behind a store: a store of more than 8 bytes reads its data registers a moment AFTER it issues -- a VALU write
+            //  to them in the next cycle lands in the stored value.  The compiler pads its own stores; it does not know these are.)
 #ifdef SVGR_DBG_PLAIN_STORE
-                asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+#define SVGR_ROW_STORE(dst, v) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory")
 #else
-                asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+            // The canvas is written once and not read again by this launch: a NONTEMPORAL store (plain stores pushed the add
+            // lists out of the caches the kernel reads them from: 162 -> 132 us).  Issued by hand: the count is what matters.
+#define SVGR_ROW_STORE(dst, v) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory")
 #endif
+            if (vrow0 + 64 / CH <= a.vrows && orow0 >= 0 && orow0 + 64 / CH <= a.win_rows && col0 >= 0 && col0 + TC <= a.win_cols) {
+                // (the wave's rows lie inside the output -- every tile of a canvas whose size is a multiple of the tile's: no tests)
+                float4* dst = (float4*)a.out + ((size_t)orow0 * a.out_cols + col);
+#pragma unroll
+                for (int r = 0; r < 64 / CH; ++r) {
+                    const float4 v4 = tp[(wrow0 + r) * T_ROW + lane + lane / PX];
+                    const f32x4_t v = {v4.x, v4.y, v4.z, v4.w};
+                    SVGR_ROW_STORE(dst, v);
+                    dst += a.out_cols;
+                }
+            } else {
+                const bool col_ok = col >= 0 && col < a.win_cols;
+                float4* const trash = (float4*)a.trash + lane;
+#pragma unroll
+                for (int r = 0; r < 64 / CH; ++r) {
+                    const int tr_ = wrow0 + r;
+                    const int vrow = band_ * TR + tr_, orow = by_ * TR + tr_ - a.win_r;
+                    const bool ok = vrow < a.vrows && orow >= 0 && orow < a.win_rows && col_ok;
+                    const float4 v4 = tp[tr_ * T_ROW + lane + lane / PX];
+                    const f32x4_t v = {v4.x, v4.y, v4.z, v4.w};
+                    float4* const dst = ok ? (float4*)a.out + ((size_t)orow * a.out_cols + col) : trash;
+                    SVGR_ROW_STORE(dst, v);
+                }
             }
+#undef SVGR_ROW_STORE
             // the wave's transposed rows back to zero: they are delta tiles again (its own LDS operations stay in order; the
             // barrier in front of the next scatter is between this and the other wave's adds)
             {
@@ -2792,14 +2812,12 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
     // a round's items sit one per lane; its first loads: everything the first two items need, and the loop's standing queue
     // [header 2, add 1], asked for in ONE go (the items carry their add lists, so no load waits for another).  All of them are
     // unconditional: past the end of the list they read a valid dummy address (or the next tile's page: add_ptr).
-    auto issue_round = [&](int r0) {
+    auto issue_round = [&](const uint4* pages_, int r0) {
         tail_ptr_ = a.trash;
         if (have_next_ && r0 + n_round >= n_items) {
-            TileArgs ar;
-            reload_tile_args(ar);
             int ln = lane_;
             asm volatile("" : "+v"(ln));
-            tail_ptr_ = ar.pages + (size_t)next_tile_ * PAGE_STRIDE + (ln < PAGE_STRIDE ? ln : PAGE_ITEMS);
+            tail_ptr_ = pages_ + (size_t)next_tile_ * PAGE_STRIDE + (ln < PAGE_STRIDE ? ln : PAGE_ITEMS);
         }
         const int* q0 = hdr_ptr(0);
         const int* q1 = hdr_ptr(1);
@@ -2813,9 +2831,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         SVGR_ADD_LOAD(wq, vq, a1);
     };
     // the tile `tile_` (its page in page01 / page23): which one, its first round, and that round's loads on their way
-    auto begin_tile = [&]() {
-        TileArgs a;
-        reload_tile_args(a);
+    auto begin_tile = [&](const TileArgs& a) {
         int lane = lane_;
         asm volatile("" : "+v"(lane));
         if (a.use_order) {
@@ -2853,7 +2869,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         }
         // (the fixed-target variant asks for the round's first loads here -- ahead of the previous tile's stores; the others, whose
         //  targets are variables, have ONE statement per target: the one at the top of a round)
-        if constexpr (FIXED) issue_round(0);
+        if constexpr (FIXED) issue_round(a.pages, 0);
     };
     // the tile behind the next one: wave 0 asks a counter for it when a tile begins (a returning atomic of ONE lane, its target the
     // fixed register v119, issued in front of the tile's first loads: it has landed when they have), leaves it in an LDS word
@@ -2881,7 +2897,11 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         have_next_ = next_tile_ < n_tiles_;
         if (have_next_) ask_tile();
     }
-    begin_tile();
+    {
+        TileArgs a0;
+        reload_tile_args(a0);
+        begin_tile(a0);
+    }
     bool pend = false;   // N_STORES store instructions (the previous tile's canvas) were issued behind the round's first loads
     for (;;) {
 #pragma unroll
@@ -2901,7 +2921,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
                     const uint4 it = lane < n_round ? a.items[(size_t)item0 + r0_ + lane] : make_uint4(0u, 0u, 0u, 0u);
                     cells_v = it.x; add0_v = it.y; nadd_v = it.z;
                 }
-                issue_round(r0_);
+                issue_round(a.pages, r0_);
             }
             const int n = n_round;
             static_assert(N_STORES == 8 || OUT != 0, "the wait below steps over eight store instructions");
@@ -2956,7 +2976,9 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         // behind them the stores ----
         const int s_by = by, s_bx = bx, s_band = band;
         const bool go = have_next_;
-        store_tile_a(s_by, s_bx, s_band);
+        TileArgs sw;   // (the launch's arguments, read again: reload_tile_args)
+        reload_tile_args(sw);
+        store_tile_a(sw, s_by, s_bx, s_band);
         if (go) {
             page01 = w_n;
             page23 = (unsigned long long)__double_as_longlong(v_n);
@@ -2965,9 +2987,9 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
             next_tile_ = (unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned*)(s_mem + MAILBOX));
             have_next_ = next_tile_ < n_tiles_;
             if (have_next_) ask_tile();
-            begin_tile();
+            begin_tile(sw);
         }
-        store_tile_b(s_by, s_bx, s_band);
+        store_tile_b(sw, s_by, s_bx, s_band);
         if (!go) break;
         pend = OUT == 0;   // (the other outputs stored in front of the loads: their waits cover the stores anyway)
 #ifdef SVGR_DBG_NOPEND
