@@ -499,7 +499,49 @@ def main():
             del full_t
         except Exception as exc:  # noqa: BLE001
             extras["all_gather_ms"] = {"error": repr(exc)}
+    # ---- what a render that is NOT a replay costs (outside the timed region): the reference's only mode is a cold
+    # render (S:3854-3864 times the whole of scene.render, every Path.mask flattens from scratch, S:948-957), the headline above
+    # replays a plan made during warm-up
+    if world == 1 and rank == 0:
+        try:
+            ctx.sync()
+            c0 = time.perf_counter()
+            cb = new_batch(sc)              # host arrays -> svgr_batch_create (packing + upload)
+            cb.plan()                       # the staged plan: geometry passes with read-backs, slab order
+            cb.render(out, _abi.OUT_CANVAS_F32, flags)
+            ctx.sync()
+            extras["cold_ms"] = round((time.perf_counter() - c0) * 1e3, 4)
+            m6 = np.array(sc["path_m6"], dtype=np.float64, copy=True)
+            reps, t_plan, t_replan = 5, 0.0, 0.0
+            for i in range(reps):
+                m6p = m6.copy()
+                m6p[:, 2] += 0.125 * (i + 1)   # every path moved by an eighth of a pixel: new edges, new bboxes, same structure
+                m6p[:, 5] += 0.0625 * (i + 1)
+                ctx.sync()
+                r0 = time.perf_counter()
+                cb.set_transforms(m6p)      # (voids the plan)
+                p0 = time.perf_counter()
+                cb.plan()
+                t_plan += time.perf_counter() - p0
+                cb.render(out, _abi.OUT_CANVAS_F32, flags)
+                ctx.sync()
+                t_replan += time.perf_counter() - r0
+            extras["replan_ms"] = round(t_replan / reps * 1e3, 4)
+            extras["plan_ms"] = round(t_plan / reps * 1e3, 4)
+            extras["replan_over_step"] = round((t_replan / reps) / (t_max / args.steps), 2)
+            extras["cold_replan_what"] = ("cold_ms: host arrays -> svgr_batch_create + plan + first render + sync; replan_ms: set_transforms "
+                                          "(every path moved by a fraction of a pixel) + plan + render + sync, mean of 5; plan_ms: the plan "
+                                          "call alone; none of them is inside the timed region")
+            cb.destroy()
+            # (the canvas the parity check reads is the timed scene's: render it once more)
+            batch.render(out, _abi.OUT_CANVAS_F32, flags)
+            ctx.sync()
+        except Exception as exc:  # noqa: BLE001
+            extras["cold_ms"] = {"error": repr(exc)}
     got_canvas = None
+    got_strips = None
+    if world > 1 and rank == 0 and not args.no_cpu_baseline:
+        got_strips = out_t.cpu().numpy()   # (rank 0's strips, packed in strip order; the clock has stopped)
     if world == 1 and not args.no_cpu_baseline and not args.cpu_paths:
         got_canvas = out.download((own_rows, cols, 4), np.float32)  # (the last timed step's canvas; the clock has stopped)
     del out
@@ -589,6 +631,36 @@ def main():
             ref_canvas, visible, line["cpu_baseline"] = cpu_baseline(sc, args.cpu_paths)
             if got_canvas is not None and ref_canvas is not None:
                 line["parity"] = contract_counts(got_canvas, ref_canvas)
+        if world > 1 and not args.no_cpu_baseline:
+            # the first hardware record checks its own pixels (VERDICT r3 #4c): rank 0's strips against the oracle's render of
+            # exactly those rows (the reference's own viewport cropping, S:968-971), and the CPU baseline on a bounded sample
+            try:
+                from oracle import oracle as orc
+
+                pres = synth.presentation_segs(sc)
+                strip_rows = strip * _abi.tile_rows()
+                n_strips = (rows + strip_rows - 1) // strip_rows
+                mine = [si for si in range(n_strips) if si % world == 0]
+                acc = dict(values=0, bad=0, max_err=0.0)
+                at = 0
+                for si in mine:
+                    r_lo, r_hi = si * strip_rows, min((si + 1) * strip_rows, rows)
+                    ref_s, _P, _E = orc.render_solid(pres, sc["seg_kind"], sc["path_seg_off"], sc["path_rule"], sc["path_paint"],
+                                                     (int(sc["viewport"][0]) + r_lo, int(sc["viewport"][1]), r_hi - r_lo, cols), clip01=True)
+                    cc = contract_counts(got_strips[at:at + (r_hi - r_lo)], ref_s)
+                    at += strip_rows
+                    acc["values"] += cc["values"]; acc["bad"] += cc["bad"]; acc["max_err"] = max(acc["max_err"], cc["max_err"])
+                acc["what"] = (f"rank 0's {len(mine)} strips of the last timed step (rows of strip s with s % {world} == 0), downloaded after the "
+                               "clock stopped, against the CPU oracle's render of those rows")
+                acc["contract"] = "|got - f32(ref)| <= max(1 ULP_f32(ref), 2^-24)"
+                line["parity"] = acc
+            except Exception as exc:  # noqa: BLE001
+                line["parity"] = {"error": repr(exc)}
+            try:
+                n_sample = min(n_scene_paths, 2500)   # (about 10-20 s of one core on the 8192^2 scene)
+                _rc, _vis, line["cpu_baseline"] = cpu_baseline(sc, args.cpu_paths or n_sample)
+            except Exception as exc:  # noqa: BLE001
+                line["cpu_baseline"] = {"error": repr(exc)}
         line["roofline"] = roofline_block(tile_ms, geo_ms, tm["n"], every, P_rank, E_rank, own_rows * cols * 16, counters, counters_file,
                                           visible=visible)
         line.update(extras)

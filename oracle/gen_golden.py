@@ -1143,6 +1143,42 @@ def gen_gradlong(ref) -> None:
     save("gradlong_kat.npz", **out)
 
 
+# --------------------------------------------------------------------------------------
+# S. the headline workload's generator, rendered by the reference itself
+# --------------------------------------------------------------------------------------
+def gen_synth(ref) -> None:
+    """svgrasterize.py_amd/synth.py scenes drawn by the REFERENCE: every path through Path.fill (S:995-1019, linear RGB: the paint
+    is taken as already in the compositing space), the fills through Layer.compose(OVER) (S:177-207) and canvas_merge_at onto a
+    transparent canvas (S:304-327).  Pins oracle.render_solid -- the checker of the bench line -- and the GPU to the reference on
+    the bench's own kind of drawing."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from svgrasterize_amd import synth
+
+    swap = ref.Transform().matrix(0, 1, 0, 1, 0, 0)
+    out = {}
+    meta = []
+    for size, n in ((256, 48), (700, 300)):
+        sc = synth.make_scene(size, n)
+        off = sc["path_seg_off"]
+        layers = []
+        for p in range(n):
+            cub = sc["segs"][off[p]:off[p + 1]].reshape(-1, 4, 2)
+            sub = [(ref.PATH_CUBIC, np.array(c, dtype=np.float64)) for c in cub]
+            path = ref.Path([sub])
+            res = path.fill(swap, sc["path_paint"][p].copy(), fill_rule="evenodd" if sc["path_rule"][p] else None,
+                            viewport=[0, 0, size, size], linear_rgb=True)
+            if res is not None:
+                layers.append(res[0])
+        top = ref.Layer.compose(layers, ref.COMPOSE_OVER, linear_rgb=True)
+        canvas = np.zeros((size, size, 4))
+        ref.canvas_merge_at(canvas, top.image, top.offset)
+        key = f"s{size}_n{n}"
+        out[key + "_canvas"] = canvas
+        meta.append(dict(key=key, size=size, paths=n, layers=len(layers)))
+    out["meta"] = np.array(json.dumps(meta))
+    save("synth_kat.npz", **out)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also render the full-size configs (slow)")
@@ -1171,6 +1207,8 @@ def main() -> None:
         gen_svgfuzz(ref)
     if todo("hostutil"):
         gen_hostutil(ref)
+    if todo("synth"):
+        gen_synth(ref)
     if todo("mask"):
         gen_mask(ref)
     if todo("compose"):

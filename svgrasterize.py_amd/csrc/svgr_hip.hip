@@ -839,7 +839,9 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
             double mnr = key_f64(~k[0]), mnc = key_f64(~k[1]);
             double mxr = key_f64(k[2]), mxc = key_f64(k[3]);
             const double lim = 1.0e9;
-            if (has_vp && mnr == mnr && mnc == mnc && mxr == mxr && mxc == mxc) {
+            // (finite extents only: an infinite or NaN coordinate falls through to the refusal below, as it did before the clamp)
+            const double fmax = 1.7976931348623157e308;
+            if (has_vp && fabs(mnr) <= fmax && fabs(mnc) <= fmax && fabs(mxr) <= fmax && fabs(mxc) <= fmax) {
                 // With a viewport the bbox is cut to it anyway (S:968-971): an extent beyond the 32-bit pixel range (the
                 // reference computes it in Python integers) is brought to the viewport's border first, in double.  Only a
                 // render WITHOUT a viewport is limited to +-1e9 pixels.
@@ -881,6 +883,21 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
             }
         }
     }
+    // A planned render whose geometry is not the plan's (a bbox or band count that differs: every setter voids the plan, so this is
+    // a guard, not a path): the flag fails the render, and the path KEEPS THE PLAN'S bbox and places -- its slabs, pairs and cells
+    // stay inside what the plan reserved, whatever the later kernels make of its edges (they clip to the layer they are given).
+    if (reuse && p < n_paths && (old_bb.x != out[0] || old_bb.y != out[1] || old_bb.z != out[2] || old_bb.w != out[3] || old_bin.nb != pnb)) {
+        atomicOr(&bd->err, 32);
+        out[0] = old_bb.x; out[1] = old_bb.y; out[2] = old_bb.z; out[3] = old_bb.w;
+        pb0 = old_bin.b0; pnb = old_bin.nb; pnct = 0;
+        if (pnb > 0 && out[2] > 0 && out[3] > 0) {
+            int ct0_;
+            path_ctiles(out[1], out[3], vc0, ct0_, pnct);
+        } else {
+            pnb = 0;
+        }
+        st_n = 0;
+    }
     // (a path of 2^24 x 2^24 pixels has 2^38 cells: such a batch overflows the cursor and is refused, err bit 5)
     const long long want_cells = has_vp ? (long long)pnb * pnct : 0ll;  // (no viewport yet: the pass only finds the union)
     if (want_cells > (1ll << 28)) atomicOr(&bd->err, 32);
@@ -916,8 +933,6 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
             off = old_bin.pb_off;
             cell_off = old_bin.cell_off;
             slab0 = p < n_paths ? slab_at[p] : 0;
-            if (p < n_paths && (old_bb.x != out[0] || old_bb.y != out[1] || old_bb.z != out[2] || old_bb.w != out[3] || old_bin.nb != pnb))
-                atomicOr(&bd->err, 32);  // (not the plan's geometry: its places do not hold)
             if (pi == 0) bd->slab_cursor = slab_cap;  // (k_path_build's grid: the plan's count)
         }
     }
@@ -2791,9 +2806,9 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
                 float z0 = 0.f;
                 asm volatile("" : "+v"(z0));   // (a zero made here: hoisted out of the tile loop it was spilled and reloaded -- behind a vmcnt(0))
                 const float4 z = make_float4(z0, z0, z0, z0);
+                static_assert(W_SLOTS % 64 == 0, "whole store instructions");
 #pragma unroll
-                for (int j = 0; j < (W_SLOTS + 63) / 64; ++j)
-                    if (j * 64 + lane < W_SLOTS) tp[wrow0 * T_ROW + j * 64 + lane] = z;
+                for (int j = 0; j < W_SLOTS / 64; ++j) tp[wrow0 * T_ROW + j * 64 + lane] = z;
             }
         }
     };
@@ -3458,6 +3473,7 @@ struct svgr_batch {
     double thr = 0.16000000000000003;
     Owner own{0, 1, 1};
     bool planned = false;
+    bool no_band_reuse = false;   // SVGR_NO_BAND_REUSE as it stood when the plan was made (the A/B switches are read at plan time: all of them)
     bool has_clips = false;    // any SVGR_PATH_CLIP_SOURCE / SVGR_PATH_CLIPPED path
     int64_t n_groups = 0;      // isolated groups (svgr_batch_set_groups)
     DevArr<int> path_group, group_clip_src;
@@ -3670,7 +3686,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                            (const int*)b->bbox.p, b->band_start.p, b->band_count.p, b->band_item0.p, b->entries.p,
                            b->pair_idx.p, cap_i32(std::min(b->entries.cap, b->pair_idx.cap)),
                            upto >= 4 ? cap_i32(b->items.cap) : 0x7fffffff, b->vp[1], b->bd(), b->own,
-                           upto >= 4 && b->planned && use_vp && getenv("SVGR_NO_BAND_REUSE") == nullptr ? 1 : 0);
+                           upto >= 4 && b->planned && use_vp && !b->no_band_reuse ? 1 : 0);
     if (upto == 3) return 0;
     // (the tiles read their mask words whether or not any pair exists: a batch without entries still needs them clear --
     //  a block from the cache is not zero)
@@ -4295,6 +4311,7 @@ static int spec_finish(svgr_batch* b) {
     for (int k = 0; k < NSH; ++k) b->n_edges_live += b->host_bd.shard[k].cursor;
     b->n_bsegs = b->host_bd.bseg_cursor;
     b->planned = true;
+    b->no_band_reuse = getenv("SVGR_NO_BAND_REUSE") != nullptr;
     b->geometry_fresh = true;
     return 1;
 }
@@ -4540,6 +4557,7 @@ static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
     b->n_bsegs = b->host_bd.bseg_cursor;
     if (int rc = plan_slab_order(b)) return rc;
     b->planned = true;
+    b->no_band_reuse = getenv("SVGR_NO_BAND_REUSE") != nullptr;
     b->geometry_fresh = true;
     return 0;
 }

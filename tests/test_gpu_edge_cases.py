@@ -88,6 +88,29 @@ def test_extents_far_beyond_the_viewport_render_inside_it(S):
         path.mask(tr)   # without a viewport the canvas itself would be 2e11 pixels wide
 
 
+def test_infinite_extents_are_refused_with_a_viewport_too(S):
+    """A coordinate that is +-inf (or NaN) is not 'far away': bringing it to the viewport's border would draw a picture the
+    reference never draws (it raises or returns garbage there).  Non-finite input is refused when the batch is made; an
+    extent that only BECOMES infinite on the device (a finite transform that overflows) reports the extent error at plan
+    time, as it does without a viewport."""
+    from svgrasterize_amd import _abi
+
+    ctx = S.Context.get()
+    segs = np.array([[2.0, 3.0, 50.0, 4.0, 0, 0, 0, 0], [50.0, 4.0, 30.0, 60.0, 0, 0, 0, 0], [30.0, 60.0, 2.0, 3.0, 0, 0, 0, 0]])
+    for bad in (np.inf, -np.inf, np.nan):
+        s2 = segs.copy()
+        s2[1, 2] = s2[2, 0] = bad
+        with pytest.raises(ValueError):
+            _abi.Batch(ctx, s2, np.zeros(3, np.uint8), [0, 3], np.array([[1.0, 0, 0, 0, 1, 0]]), [0], np.array([[1.0, 1, 1, 1]]),
+                       viewport=(0, 0, 64, 64))
+    # finite points, finite matrix, infinite product
+    batch = _abi.Batch(ctx, segs, np.zeros(3, np.uint8), [0, 3], np.array([[1e307, 0, 0, 0, 1e307, 0]]), [0], np.array([[1.0, 1, 1, 1]]),
+                       viewport=(0, 0, 64, 64))
+    with pytest.raises(Exception, match="extent|finite"):
+        batch.plan()
+    batch.destroy()
+
+
 def test_ragged_batch_with_empty_and_offscreen_paths(S):
     """Paths without segments, paths outside the viewport and a path covering everything, in one batch."""
     from svgrasterize_amd import _abi

@@ -158,11 +158,21 @@ def test_planned_slab_places_do_not_change_the_picture(S, monkeypatch):
 
     for bands in (None, (1, 2, 16)):
         monkeypatch.delenv("SVGR_NO_SLAB_ORDER", raising=False)
+        monkeypatch.delenv("SVGR_NO_BAND_REUSE", raising=False)
         a = render(bands)
         monkeypatch.setenv("SVGR_NO_SLAB_ORDER", "1")
         b = render(bands)
         assert np.abs(a).max() > 0
         assert np.array_equal(a, b), f"slab places change the picture (bands {bands})"
+        # ... and the band lists' places taken from the plan (reuse) or from the device's cursors again (SVGR_NO_BAND_REUSE, read when
+        # the plan is made): the same bits, with the plan's slab and bin places and without them
+        monkeypatch.setenv("SVGR_NO_BAND_REUSE", "1")
+        c = render(bands)
+        assert np.array_equal(a, c), f"band places from the cursors change the picture (bands {bands})"
+        monkeypatch.delenv("SVGR_NO_SLAB_ORDER", raising=False)
+        d = render(bands)
+        assert np.array_equal(a, d), f"band places from the cursors change the picture under the plan's slab order (bands {bands})"
+        monkeypatch.delenv("SVGR_NO_BAND_REUSE", raising=False)
 
 
 def test_synth_8192_config4_windows(S):

@@ -309,6 +309,31 @@ def test_synthetic_vs_oracle(S, orc, size, n):
     assert_f32_1ulp(out32.download((size, size, 4), np.float32), ref, what="synthetic f32")
 
 
+@pytest.mark.parametrize("key", ["s256_n48", "s700_n300"])
+def test_synthetic_vs_the_reference_render(S, key):
+    """The bench generator's scene drawn by the reference itself (tests/golden/synth_kat.npz, oracle/gen_golden.py --only synth):
+    the float32 canvas of the production kernel within 1 ULP, the double canvas within 1e-10."""
+    import json
+
+    from svgrasterize_amd import _abi, synth
+
+    g = load("synth_kat.npz")
+    m = next(x for x in json.loads(str(g["meta"])) if x["key"] == key)
+    size, n = m["size"], m["paths"]
+    ref = g[key + "_canvas"]
+    sc = synth.make_scene(size, n)
+    ctx = S.Context.get()
+    batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
+                       viewport=sc["viewport"])
+    batch.plan()
+    out32 = ctx.alloc(size * size * 16)
+    batch.render(out32, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
+    assert_f32_1ulp(out32.download((size, size, 4), np.float32), ref, what="synthetic f32 vs the reference")
+    out64 = ctx.alloc(size * size * 32)
+    batch.render(out64, _abi.OUT_CANVAS_F64, _abi.RENDER_CLIP01)
+    assert_close64(out64.download((size, size, 4), np.float64), ref, atol=1e-10, what="synthetic f64 vs the reference")
+
+
 @pytest.mark.parametrize("world,strip", [(3, 1), (2, 4), (4, 2)])
 def test_band_sharding_matches_full(S, world, strip):
     """Rows rendered by 'rank r of N' (interleaved strips of bands, geometry culled to what reaches them)

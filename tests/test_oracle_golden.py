@@ -89,3 +89,61 @@ def test_compose_kat():
             d = m["in"][0]
             out = orc.convert(ins[0][0], d["pre_alpha"], d["linear_rgb"], m["to_pre_alpha"], m["to_linear_rgb"])
             assert_close64(out, g[f"{idx}_out"], atol=4e-16, what=f"convert {idx}")
+
+
+# ------------------------------------------------------------------------------------------
+# the whole CPU render (the checker of the bench line) against the reference's own render
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("key", ["s256_n48", "s700_n300"])
+def test_render_solid_equals_the_reference_on_the_bench_generator(key):
+    """svgrasterize.py_amd/synth.py scenes drawn by the reference (Path.fill + Layer.compose(OVER) + canvas_merge_at, fixture made by
+    oracle/gen_golden.py --only synth) against oracle.render_solid: what bench.py checks the timed canvas with (VERDICT r3 #6)."""
+    import json
+
+    from svgrasterize_amd import synth
+
+    g = load("synth_kat.npz")
+    m = next(x for x in json.loads(str(g["meta"])) if x["key"] == key)
+    sc = synth.make_scene(m["size"], m["paths"])
+    got, P, E = orc.render_solid(synth.presentation_segs(sc), sc["seg_kind"], sc["path_seg_off"], sc["path_rule"], sc["path_paint"],
+                                 sc["viewport"], clip01=True)
+    ref = g[key + "_canvas"]
+    assert got.shape == ref.shape
+    err = np.abs(got - ref)
+    # (sequential OVER per pixel in both; the reference's mask * paint and 1 - src_a are the oracle's: rounding-level agreement)
+    assert err.max() <= 4e-16, f"{key}: max |oracle - reference| = {err.max():.3e}"
+    assert P > 0 and E > 0
+
+
+def test_render_solid_on_the_tiger_leaves_equals_the_reference_canvas():
+    """Ghostscript tiger at 1/16 scale: the scene's paint-ordered leaves (fills and stroked outlines, transforms applied on the host)
+    through oracle.render_solid against the canvas the reference drew (scene_tiger.npz::s128_canvas)."""
+    import os
+
+    import svgrasterize_amd as S
+    from svgrasterize_amd import scenedump
+
+    scene, info, z = scenedump.load_scene(os.path.join(os.path.dirname(__file__), "golden", "scene_tiger.npz"))
+    r = next(r for r in info["renders"] if r["tag"] == "s128")
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0).scale(r["scale"])
+    hh, ww = r["size"]
+    leaves = scene.leaves(tr, linear_rgb=False)
+    assert leaves, "the tiger is solid fills and strokes: one batchable run"
+    segs, kinds, offs, rules, paints = [], [], [0], [], []
+    for leaf in leaves:
+        path, m6, rule, paint, flags = leaf[:5]
+        assert flags == 0
+        s, k = path.packed()
+        m = np.eye(3)
+        m[:2, :] = np.asarray(m6, dtype=np.float64).reshape(2, 3)
+        segs.append(orc.transform_points(m, s.reshape(-1, 4, 2)).reshape(-1, 8))
+        kinds.append(k)
+        offs.append(offs[-1] + len(s))
+        rules.append(rule)
+        paints.append(paint)
+    got, P, E = orc.render_solid(np.concatenate(segs), np.concatenate(kinds), np.array(offs, dtype=np.int64), np.array(rules, dtype=np.uint8),
+                                 np.array(paints), (0, 0, hh, ww), clip01=True)
+    ref = z["s128_canvas"]
+    assert got.shape == ref.shape
+    # (the reference composites group by group, the batch path by path: source-over is associative up to double rounding)
+    assert np.abs(got - ref).max() <= 1e-12
