@@ -3473,6 +3473,8 @@ struct svgr_batch {
     double thr = 0.16000000000000003;
     Owner own{0, 1, 1};
     bool planned = false;
+    bool sized = false;           // a plan has succeeded with the viewport `sized_vp`: the buffers' capacities are a re-plan's guesses
+    int sized_vp[4] = {0, 0, 0, 0};
     bool no_band_reuse = false;   // SVGR_NO_BAND_REUSE as it stood when the plan was made (the A/B switches are read at plan time: all of them)
     bool has_clips = false;    // any SVGR_PATH_CLIP_SOURCE / SVGR_PATH_CLIPPED path
     int64_t n_groups = 0;      // isolated groups (svgr_batch_set_groups)
@@ -4117,6 +4119,7 @@ int svgr_batch_set_bands(svgr_batch* b, int rank, int world, int strip_bands) {
     if (!b || world <= 0 || rank < 0 || rank >= world || strip_bands <= 0) return fail(SVGR_E_INVALID, "bad band selection");
     b->own = Owner{rank, world, strip_bands};
     b->planned = false; b->slab_at_valid = false;  // the edge / record capacities are per rank
+    b->sized = false;
     b->n_seg_list = -1;  // ... and so is the list of segments to flatten
     return 0;
 }
@@ -4242,10 +4245,34 @@ int svgr_batch_set_gradients(svgr_batch* b, const int32_t* path_grad, int64_t n_
 // small the kernels flag it and the staged plan takes over.  Returns 1 when it planned, 0 to fall back, < 0 on error.
 // Two halves, so that svgr_batch_plan_many can put the passes of many batches behind ONE wait: spec_issue enqueues the pass
 // and its read-back (1 issued, 0 not eligible), spec_finish reads the verdict once the stream has drained.
-static int spec_issue(svgr_batch* b, void* staging = nullptr) {
+// `again`: the batch has been planned before with this viewport (svgr_batch_set_transforms / set_paints voided that plan): the
+// capacities are what its buffers hold -- the last plan's exact counts plus the eighth every allocation adds --, whatever the
+// batch's size.  A drawing that moved a little fits them; one that does not is flagged and takes the staged plan, like any
+// other wrong guess.  (A re-plan is then two geometry passes behind ONE read-back instead of five passes and five: VERDICT r3 #3.)
+static int spec_issue(svgr_batch* b, void* staging = nullptr, bool again = false) {
     const int np = (int)b->n_paths;
     const int64_t ns = b->n_segs;
-    if (!b->has_vp || ns <= 0 || ns > 4096 || np <= 0 || b->own.world > 1) return 0;
+    if (!b->has_vp || ns <= 0 || np <= 0 || b->own.world > 1) return 0;
+    if (again) {
+        if (!b->sized || b->sized_vp[0] != b->vp[0] || b->sized_vp[1] != b->vp[1] || b->sized_vp[2] != b->vp[2] || b->sized_vp[3] != b->vp[3]) return 0;
+        b->n_edges = (int64_t)(b->edges.cap / 4);
+        for (int k = 0; k < NSH; ++k) {
+            b->shards.base[k] = k == 0 ? 0 : (int)b->n_edges;
+            b->shards.cap[k] = k == 0 ? (int)b->n_edges : 0;
+        }
+        b->n_pb = (int64_t)std::min(b->entries.cap, b->pair_idx.cap);
+        b->n_entries = b->n_pb;
+        b->n_cells = (int64_t)std::min(b->cell_hdr.cap - 1, b->items.cap);
+        b->n_slabs = (int64_t)b->slabs.cap;
+        if (b->n_edges <= 0 || b->n_pb <= 0 || b->n_cells <= 0 || b->n_slabs <= 0 || b->edge_path.cap < (size_t)b->n_edges) return 0;
+        int rc = b->layout_arena();
+        if (rc) return rc;
+        if ((rc = run_geometry(b, 1, true))) return rc;
+        if ((rc = run_geometry(b, 4, true))) return rc;
+        if ((rc = issue_readback(b, true, staging))) return rc;
+        return 1;
+    }
+    if (ns > 4096) return 0;
     const int n_bands = (b->vp[2] + TR - 1) / TR;
     if ((int64_t)np * n_bands > (1 << 20) || n_bands <= 0) return 0;
     const int n_ct = (b->vp[3] + TC - 1) / TC + 1;  // (+1: a layer need not start on a tile border)
@@ -4311,16 +4338,29 @@ static int spec_finish(svgr_batch* b) {
     for (int k = 0; k < NSH; ++k) b->n_edges_live += b->host_bd.shard[k].cursor;
     b->n_bsegs = b->host_bd.bseg_cursor;
     b->planned = true;
+    b->sized = true;
+    for (int k = 0; k < 4; ++k) b->sized_vp[k] = b->vp[k];
     b->no_band_reuse = getenv("SVGR_NO_BAND_REUSE") != nullptr;
     b->geometry_fresh = true;
     return 1;
 }
+static int plan_slab_order(svgr_batch* b);
 static int plan_speculative(svgr_batch* b) {
-    const int is = spec_issue(b);
-    if (is <= 0) return is;
-    HIPCHK(hipStreamSynchronize(b->ctx->stream));
-    HIPCHK(hipGetLastError());
-    return spec_finish(b);
+    // (first choice: the sizes of the batch's own last plan; then the size models for small batches)
+    for (int again = 1; again >= 0; --again) {
+        const int is = spec_issue(b, nullptr, again != 0);
+        if (is < 0) return is;
+        if (is == 0) continue;
+        HIPCHK(hipStreamSynchronize(b->ctx->stream));
+        HIPCHK(hipGetLastError());
+        const int fin = spec_finish(b);
+        if (fin > 0 && again && b->n_segs > 4096) {
+            if (int rc = plan_slab_order(b)) return rc;   // (large batches: k_path_build's work list heaviest first)
+        }
+        if (fin != 0) return fin;
+        b->planned = false;
+    }
+    return 0;
 }
 
 // k_path_rows + k_seg_select + one read-back: b->seg_list / b->n_seg_list
@@ -4469,8 +4509,10 @@ static int plan_slab_order(svgr_batch* b) {
     int at = 0;
     for (int p : order) { b->slab_at_host[(size_t)p] = at; at += n_sl[(size_t)p]; }
     if (int rc = b->slab_at.ensure(np)) return rc;
+    // (no wait: the renders are behind the copy in the stream; its source is a member, svgr_batch_destroy waits for uploads)
+    b->wait_uploads();
     HIPCHK(hipMemcpyAsync(b->slab_at.p, b->slab_at_host.data(), sizeof(int) * np, hipMemcpyHostToDevice, b->ctx->stream));
-    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    HIPCHK(b->note_upload(b->ctx->stream));
     b->slab_at_valid = true;
     return 0;
 }
@@ -4557,6 +4599,8 @@ static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
     b->n_bsegs = b->host_bd.bseg_cursor;
     if (int rc = plan_slab_order(b)) return rc;
     b->planned = true;
+    b->sized = true;
+    for (int k = 0; k < 4; ++k) b->sized_vp[k] = b->vp[k];
     b->no_band_reuse = getenv("SVGR_NO_BAND_REUSE") != nullptr;
     b->geometry_fresh = true;
     return 0;
