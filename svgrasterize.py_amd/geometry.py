@@ -429,7 +429,11 @@ class Path:
             return None
         if isinstance(paint, np.ndarray) and paint.shape == (4,):
             paint = solid_paint(paint, linear_rgb)
-            res = FILL_PLANS.pop(fill_plan_key(self, transform, fill_rule, paint, viewport), _NO_PLAN) if FILL_PLANS else _NO_PLAN
+            if FILL_PLANS:  # (a retained render keeps the plan for the next one: scene._Retained)
+                fkey = fill_plan_key(self, transform, fill_rule, paint, viewport)
+                res = FILL_PLANS.get(fkey, _NO_PLAN) if FILL_PLANS_KEEP else FILL_PLANS.pop(fkey, _NO_PLAN)
+            else:
+                res = _NO_PLAN
             if res is _NO_PLAN:  # (else: built and planned by Scene.render's pre-pass together with the document's other batches)
                 res = self._single_batch(transform, fill_rule, viewport, paint)
             if res is None:
@@ -513,9 +517,18 @@ class MaskPrefetch:
 
     MISS = object()
 
-    def __init__(self, jobs, viewport):
+    def __init__(self, jobs, viewport, retained: "dict | None" = None):
         self.viewport = tuple(int(v) for v in viewport)
         self.table: dict = {}
+        if retained is not None and retained.get("viewport") == self.viewport:
+            # a later render of the same document (scene._Retained): the job list, the batch and its plan are the first render's;
+            # only the masks themselves are rendered again (their layers are handed out and may be consumed)
+            todo, batch = retained["todo"], retained["keep"]
+            self.n_jobs = len(todo)
+            self._paths = [t[1] for t in todo]
+            if batch is not None:
+                self._fill_table(todo, batch, _abi.Context.get())
+            return
         todo, seen = [], set()
         for path, transform, rule in jobs:
             if rule not in _RULES:
@@ -529,6 +542,9 @@ class MaskPrefetch:
         # the table is keyed by id(path): hold the paths for as long as the table lives, so that the id of a path that
         # was dropped cannot come back as another path's
         self._paths = [t[1] for t in todo]
+        if retained is not None:
+            retained.clear()
+            retained.update(viewport=self.viewport, todo=todo, keep=None)
         if not todo:
             return
         segs, kinds, offs, m6s, rules = [], [], [0], [], []
@@ -549,6 +565,11 @@ class MaskPrefetch:
             batch.destroy()
             self.n_jobs = 0
             return
+        if retained is not None:
+            retained["keep"] = batch
+        self._fill_table(todo, batch, ctx)
+
+    def _fill_table(self, todo, batch, ctx):
         buf, loffs, bb = batch.render_masks()
         self._keep = (batch, buf)
         base = buf.ptr
@@ -581,6 +602,7 @@ MASK_PREFETCH: "MaskPrefetch | None" = None
 # Single-path solid fills of the per-node route that Scene.render's pre-pass has already built and planned (one wait for the
 # whole document, svgr_batch_plan_many): key -> (ctx, batch, bbox) or None (nothing to draw), consumed by Path.fill.
 FILL_PLANS: "dict | None" = None
+FILL_PLANS_KEEP = False   # Path.fill leaves the entry it uses in FILL_PLANS (Scene.render retains the plans between renders)
 _NO_PLAN = object()
 
 

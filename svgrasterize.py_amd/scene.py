@@ -32,6 +32,51 @@ RENDER_FILL, RENDER_STROKE, RENDER_GROUP, RENDER_OPACITY = 0, 1, 2, 3
 RENDER_CLIP, RENDER_MASK, RENDER_TRANSFORM, RENDER_FILTER = 4, 5, 6, 7
 
 
+class _Retained:
+    """What a top-level ``Scene.render`` keeps for the NEXT render of the same (scene, transform, viewport, colour space):
+    the leaf analysis of every group child, the jobs of the mask pre-pass with their built and planned batch, the runs' and
+    the per-node fills' built and planned batches with everything derived from their bboxes.  Scene nodes and paths are
+    immutable (tuples / frozen segment lists), so a second render of an unchanged document is the walk plus launches: no
+    leaf analysis, no batch building, no plan (VERDICT r3 #5a).  Keyed by identity: the entry holds the scene, so its id cannot
+    come back as another scene's.  ``SVGR_RENDER_CACHE`` = entries kept (default 4, 0: off); ``clear_render_cache()`` drops
+    them and their device buffers."""
+
+    __slots__ = ("scene", "leaf_memo", "jobs", "run_plans", "fill_plans", "mask_state")
+
+    def __init__(self, scene):
+        self.scene = scene
+        self.leaf_memo = {}
+        self.jobs = None
+        self.run_plans = {}
+        self.fill_plans = {}
+        self.mask_state = {}
+
+    def destroy(self):
+        for entry in self.run_plans.values():
+            entry[1].destroy()
+        self.run_plans = {}
+        for entry in self.fill_plans.values():
+            if entry is not None:
+                entry[1].destroy()
+        self.fill_plans = {}
+        keep = self.mask_state.get("keep")
+        if keep is not None:
+            keep.destroy()
+        self.mask_state = {}
+
+
+_RETAINED: "dict[tuple, _Retained]" = {}   # (insertion-ordered: the oldest entry goes first)
+_RETAINED_MAX = int(__import__("os").environ.get("SVGR_RENDER_CACHE", "4"))
+_RETAIN: "_Retained | None" = None         # the state of the top-level render that is running
+
+
+def clear_render_cache() -> None:
+    """Drop what ``Scene.render`` retained between renders (and the device buffers of the retained batches)."""
+    for st in _RETAINED.values():
+        st.destroy()
+    _RETAINED.clear()
+
+
 class Scene(tuple):
     __slots__ = []
 
@@ -154,38 +199,52 @@ class Scene(tuple):
         run of fills the walk will meet and plans them all behind one wait (``svgr_batch_plan_many``)."""
         from . import geometry  # noqa: PLC0415
 
-        global _LEAF_MEMO, _RUN_PLANS
+        global _LEAF_MEMO, _RUN_PLANS, _RETAIN
         # (a render inside a render -- a pattern's tile -- walks without a pre-pass of its own: the outer call's state stays)
         if _LEAF_MEMO is not None or geometry.MASK_PREFETCH is not None or viewport is None or self[0] in (RENDER_FILL, RENDER_STROKE):
             return self._render(transform, mask_only, viewport, linear_rgb)
-        jobs: list = []
-        runs: list = []
-        fills: list = []
-        _LEAF_MEMO = {}
+        key = (id(self), transform.key(), tuple(int(v) for v in viewport), bool(linear_rgb), bool(mask_only))
+        st = _RETAINED.pop(key, None) if _RETAINED_MAX > 0 else None   # (popped: re-inserted as the youngest when the render succeeds)
+        warm = st is not None
+        if st is None:
+            st = _Retained(self)
+        _LEAF_MEMO = st.leaf_memo
+        _RETAIN = st if _RETAINED_MAX > 0 else None
         # the walk allocates thousands of short-lived tuples and no cycles: the cyclic collector's generation-0 sweeps find
         # nothing and cost 0.5-2.5 ms of a 17 ms render (profiles/gc_experiment.py), so it pauses for the call
         gc_paused = _PAUSE_GC and gc.isenabled()
         if gc_paused:
             gc.disable()
+        ok = False
         try:
-            _collect_mask_jobs(self, transform, mask_only, linear_rgb, jobs, runs, fills)
-            if len(jobs) >= 4:
-                geometry.MASK_PREFETCH = geometry.MaskPrefetch(jobs, viewport)
-            if len(runs) + len(fills) >= 2:
-                _RUN_PLANS, geometry.FILL_PLANS = _plan_runs(runs, fills, viewport, linear_rgb)
-            return self._render(transform, mask_only, viewport, linear_rgb)
+            if not warm:
+                jobs: list = []
+                runs: list = []
+                fills: list = []
+                _collect_mask_jobs(self, transform, mask_only, linear_rgb, jobs, runs, fills)
+                st.jobs = jobs
+                if len(runs) + len(fills) >= 2:
+                    st.run_plans, st.fill_plans = _plan_runs(runs, fills, viewport, linear_rgb)
+            if len(st.jobs) >= 4:
+                geometry.MASK_PREFETCH = geometry.MaskPrefetch(st.jobs, viewport, st.mask_state if _RETAIN is not None else None)
+            _RUN_PLANS, geometry.FILL_PLANS = st.run_plans, st.fill_plans
+            geometry.FILL_PLANS_KEEP = _RETAIN is not None
+            res = self._render(transform, mask_only, viewport, linear_rgb)
+            ok = True
+            return res
         finally:
             geometry.MASK_PREFETCH = None
             _LEAF_MEMO = None
-            if _RUN_PLANS:
-                for _leaves, batch in _RUN_PLANS.values():  # (runs the walk did not come to after all)
-                    batch.destroy()
             _RUN_PLANS = None
-            if geometry.FILL_PLANS:
-                for entry in geometry.FILL_PLANS.values():
-                    if entry is not None:
-                        entry[1].destroy()
             geometry.FILL_PLANS = None
+            geometry.FILL_PLANS_KEEP = False
+            _RETAIN = None
+            if ok and _RETAINED_MAX > 0:
+                _RETAINED[key] = st
+                while len(_RETAINED) > _RETAINED_MAX:
+                    _RETAINED.pop(next(iter(_RETAINED))).destroy()
+            else:
+                st.destroy()   # (a failed render keeps nothing; with the cache off: the runs the walk did not come to after all)
             if gc_paused:
                 gc.enable()
 
@@ -642,34 +701,48 @@ def _render_run(leaves, viewport, linear_rgb):
     """One batch -> one Layer covering the union of the leaves' bboxes (what Layer.compose of
     the individual fill layers returns, S:366-379)."""
     ctx = _abi.Context.get()
-    pre = _RUN_PLANS.pop(_run_key(leaves, viewport), None) if _RUN_PLANS and leaves and viewport is not None else None
+    rkey = _run_key(leaves, viewport) if leaves and viewport is not None and (_RUN_PLANS is not None) else None
+    pre = None
+    if rkey is not None:
+        pre = _RUN_PLANS.get(rkey) if _RETAIN is not None else _RUN_PLANS.pop(rkey, None)
     if pre is not None:
-        leaves, batch = pre  # (built and planned by the pre-pass of Scene.render, together with all the other runs)
+        leaves, batch = pre[0], pre[1]  # (built and planned by the pre-pass of Scene.render -- of this render or of an earlier one)
     else:
         leaves = _drop_empty(leaves)
         if not leaves:
             return None
         batch = build_batch(leaves, viewport, ctx)
         batch.plan()
-    eff = effective_bboxes(leaves, batch.bboxes())
-    boxes = [b for b in eff if b is not None]
-    if not boxes:
-        batch.destroy()
+        if _RETAIN is not None and rkey is not None:
+            pre = _RUN_PLANS[rkey] = [leaves, batch]
+    if pre is not None and len(pre) > 2:
+        win, in_hull = pre[2], pre[3]   # (a retained run: its window and hull membership were worked out by the first render)
+    else:
+        eff = effective_bboxes(leaves, batch.bboxes())
+        boxes = [b for b in eff if b is not None]
+        win = None
+        if boxes:
+            ur0, uc0 = min(b[0] for b in boxes), min(b[1] for b in boxes)
+            win = (ur0, uc0, max(b[0] + b[2] for b in boxes) - ur0, max(b[1] + b[3] for b in boxes) - uc0)
+        # The group's hull merges the hulls of the children that drew something (S:676-684): a leaf whose clipped bbox is
+        # empty returned None there and does not count; one that is partly visible counts with ALL its lines (S:993).  Clip
+        # paths do not belong to it (S:715 returns the target's hull).
+        in_hull = np.zeros(len(leaves), dtype=bool)
+        in_hull[[i for i, leaf in enumerate(leaves) if leaf[4] != 1]] = [b is not None for b in eff]  # (clip sources: no part of it)
+        if pre is not None and _RETAIN is not None:
+            if len(pre) == 2:
+                pre = _RUN_PLANS[rkey] = [pre[0], pre[1], win, in_hull]
+    if win is None:
+        if pre is None or _RETAIN is None:
+            batch.destroy()
         return None
-    ur0, uc0 = min(b[0] for b in boxes), min(b[1] for b in boxes)
-    urows = max(b[0] + b[2] for b in boxes) - ur0
-    ucols = max(b[1] + b[3] for b in boxes) - uc0
+    ur0, uc0, urows, ucols = win
     # only the union of the leaves' bboxes is rendered (a render window of the batch's canvas): the tiles outside it are
     # not touched, and the layer needs no crop
     shape = (urows, ucols, 4)
     out = ctx.alloc(urows * ucols * 32)
     batch.render(out, _abi.OUT_CANVAS_F64, window=(ur0, uc0, urows, ucols))
     layer = Layer._from_device(out, shape, (ur0, uc0), True, linear_rgb)
-    # The group's hull merges the hulls of the children that drew something (S:676-684): a leaf whose clipped bbox is
-    # empty returned None there and does not count; one that is partly visible counts with ALL its lines (S:993).  Clip
-    # paths do not belong to it (S:715 returns the target's hull).
-    in_hull = np.zeros(len(leaves), dtype=bool)
-    in_hull[[i for i, leaf in enumerate(leaves) if leaf[4] != 1]] = [b is not None for b in eff]  # (clip sources: no part of it)
 
     def hull_points():
         edges, edge_path = batch.all_edges()

@@ -183,6 +183,40 @@ def test_tiger_small(S, tag):
     assert (bb[empty, 2] <= 0).all() or (bb[empty, 3] <= 0).all()
 
 
+@pytest.mark.parametrize("name,tag", [("tiger", "s128"), ("material", "s256"), ("icons", "s286")])
+def test_a_second_render_of_an_unchanged_scene_reuses_the_first_ones_plans(S, name, tag):
+    """Scene.render retains the leaf analysis and the built + planned batches of a (scene, transform, viewport) between
+    renders (scene._Retained): the second and third render give the first one's picture, with the cache and without it."""
+    from svgrasterize_amd import scene as scene_mod, scenedump
+
+    sc, info, z = scenedump.load_scene(os.path.join(GOLDEN, f"scene_{name}.npz"))
+    r = next((r for r in info["renders"] if r["tag"] == tag), info["renders"][0])
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0).scale(r["scale"])
+    hh, ww = r["size"]
+    S.clear_render_cache()
+    shots = []
+    for _ in range(3):
+        layer, hull = sc.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
+        shots.append((np.array(layer.image), tuple(int(v) for v in layer.offset), np.array(hull.points)))
+    assert len(scene_mod._RETAINED) == 1
+    st = next(iter(scene_mod._RETAINED.values()))
+    assert st.scene is sc and (st.run_plans or st.fill_plans or st.jobs)
+    S.clear_render_cache()
+    assert not scene_mod._RETAINED
+    keep = scene_mod._RETAINED_MAX
+    scene_mod._RETAINED_MAX = 0
+    try:
+        layer, hull = sc.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
+        shots.append((np.array(layer.image), tuple(int(v) for v in layer.offset), np.array(hull.points)))
+        assert not scene_mod._RETAINED
+    finally:
+        scene_mod._RETAINED_MAX = keep
+    for img, off, pts in shots[1:]:
+        assert off == shots[0][1] and img.shape == shots[0][0].shape
+        assert np.abs(img - shots[0][0]).max() <= 1e-12   # (the order of the LDS atomics: double rounding)
+        assert np.array_equal(pts, shots[0][2])
+
+
 def test_prompt_text_outlines(S):
     """demo/prompt.svg at width 256: glyph outlines set by the reference's fonts, a 9 x 256 strip."""
     scene, z, r, tr, hh, ww = _render_dump(S, "prompt", "s9")
