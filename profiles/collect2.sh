@@ -12,7 +12,6 @@ set -u
 tag="${1:-run}"; wl="${2:-synth4096}"
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 o=gpurun_out/$tag; rm -rf $o; mkdir -p $o
-python3 bench.py --workload $wl --steps ${STEPS:-200} > $o/bench.json 2> $o/bench.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/kt -o kt -- python3 bench.py --workload $wl --no-cpu-baseline --steps ${KT_STEPS:-50} > $o/kt.log 2>&1 || exit 1
 cp $(find $o/kt -name "*kernel_stats.csv" | head -1) $o/kernel_stats.csv
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $o/ps -o ps -- python3 bench.py --workload $wl --no-cpu-baseline --steps 10 --warmup 2 > $o/ps.log 2>&1 || exit 1
@@ -26,6 +25,9 @@ rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F6
 cp $(find $o/pm -name "*counter_collection.csv" | head -1) $o/pmc_mix.csv
 rm -rf $o/kt $o/pf $o/pw $o/ps $o/pm
 python3 profiles/pmc_json.py $wl $o > $o/pmc_kernels.json
+# the bench line LAST, priced with the counters just collected (it used to run first and reported the previous build's)
+cp $o/pmc_kernels.json profiles/pmc_kernels_$wl.json
+python3 bench.py --workload $wl --steps ${STEPS:-200} > $o/bench.json 2> $o/bench.err || exit 1
 # (scene workloads dispatch thousands of kernels: the raw per-dispatch tables would not fit the 64 MiB that travel back)
 for f in $o/pmc_sq.csv $o/pmc_sq_trace.csv $o/pmc_fetch.csv $o/pmc_write.csv $o/pmc_mix.csv; do [ $(stat -c %s $f) -gt 4000000 ] && rm -f $f; done
 cat $o/pmc_kernels.json

@@ -47,32 +47,51 @@ FE_SOURCE_ALPHA = "SourceAlpha"
 FE_SOURCE_GRAPHIC = "SourceGraphic"
 
 
+_KERNEL_MEMO: dict = {}   # (matrix bytes, sigma) -> weights: a document's blurs repeat from render to render (and among its nodes)
+
+
 def blur_kernel(transform: Transform, sigma):
-    """Gaussian weights on the pixel grid for a blur given in user space (S:1903-1944); None = no-op."""
-    sigma_x, sigma_y = sigma
-    scale_x, scale_y = np.linalg.norm(transform(np.eye(2)) - transform([0, 0]), axis=1)
-    if scale_x * sigma_x < 0.5 and scale_y * sigma_y < 0.5:
-        return None  # below half a pixel in both directions
-    elif scale_x * sigma_x < 0.5:
-        sigma_x = 0.5 / scale_x
-    elif scale_y * sigma_y < 0.5:
-        sigma_y = 0.5 / scale_y
-    sig = np.array([sigma_x, sigma_y])
-    ext = 2.5  # support in sigmas
-    corners = [[-ext * sigma_x, -ext * sigma_y], [-ext * sigma_x, ext * sigma_y],
-               [ext * sigma_x, ext * sigma_y], [ext * sigma_x, -ext * sigma_y]]
-    box = transform(corners) - transform([0, 0])
-    lo_x, lo_y = box.min(axis=0).astype(int)
-    hi_x, hi_y = box.max(axis=0).astype(int)
-    kw, kh = hi_x - lo_x, hi_y - lo_y
-    kw += ~kw & 1  # odd sizes
-    kh += ~kh & 1
-    inv = transform.invert
-    xs, ys = np.indices((kw, kh)).astype(np.float64)
-    grid = np.concatenate([xs[..., None], ys[..., None]], axis=2) + [-kw / 2 + 0.5, -kh / 2 + 0.5]  # pixel centres
-    pts = inv(grid)
-    pts -= inv([0, 0])  # drop the translation
-    weights = np.exp(-np.square(pts) / (2 * np.square(sig))).prod(axis=-1)
+    """Gaussian weights on the pixel grid for a blur given in user space (S:1903-1944); None = no-op.
+
+    The values are the reference's own numpy expressions (its fixtures pin them bit for bit: numpy's vectorised ``exp``
+    and its pairwise ``sum`` have no counterpart in libm), evaluated once per (matrix, sigma): the 37 blurs of icons.svg
+    cost a dictionary look-up each on every render after the first."""
+    memo_key = (transform.key(), float(sigma[0]), float(sigma[1]))
+    hit = _KERNEL_MEMO.get(memo_key, _KERNEL_MEMO)
+    if hit is not _KERNEL_MEMO:
+        return hit
+    if len(_KERNEL_MEMO) > 1024:
+        _KERNEL_MEMO.clear()
+    weights = _KERNEL_MEMO[memo_key] = _blur_weights(transform, float(sigma[0]), float(sigma[1]))
+    if weights is not None:
+        weights.setflags(write=False)   # (shared between the renders that look it up)
+    return weights
+
+
+def _blur_weights(transform: Transform, sigma_x: float, sigma_y: float):
+    origin = transform([0, 0])
+    # device pixels per user unit along the two axes; a deviation below half a pixel is raised to half a pixel unless BOTH are
+    # (then the blur is the identity)
+    per_x, per_y = np.linalg.norm(transform(np.eye(2)) - origin, axis=1)
+    small_x, small_y = per_x * sigma_x < 0.5, per_y * sigma_y < 0.5
+    if small_x and small_y:
+        return None
+    if small_x:
+        sigma_x = 0.5 / per_x
+    elif small_y:
+        sigma_y = 0.5 / per_y
+    # the kernel's footprint: 2.5 deviations to either side, mapped to the pixel grid, made odd in both directions
+    reach_x, reach_y = 2.5 * sigma_x, 2.5 * sigma_y
+    frame = transform([[-reach_x, -reach_y], [-reach_x, reach_y], [reach_x, reach_y], [reach_x, -reach_y]]) - origin
+    low, high = frame.min(axis=0).astype(int), frame.max(axis=0).astype(int)
+    kw, kh = (int(n) + (~int(n) & 1) for n in high - low)
+    # pixel centres of the footprint, taken back to user space without the translation
+    back = transform.invert
+    ix, iy = np.indices((kw, kh)).astype(np.float64)
+    centres = np.concatenate([ix[..., None], iy[..., None]], axis=2) + [-kw / 2 + 0.5, -kh / 2 + 0.5]
+    user = back(centres)
+    user -= back([0, 0])
+    weights = np.exp(-np.square(user) / (2 * np.square(np.array([sigma_x, sigma_y])))).prod(axis=-1)
     return weights / weights.sum()
 
 
