@@ -12,7 +12,9 @@ import numpy as np
 
 def main():
     allw = np.fromfile(sys.argv[1], dtype=np.uint64)[8:]
-    phases = None
+    phases = sub = None
+    if allw.size >= 12 * 65536:  # (round 4: a third table with the parts of the tile switch)
+        sub = allw[8 * 65536: 12 * 65536].reshape(-1, 4)
     if allw.size >= 8 * 65536:   # (newer builds: a second table with the phase stamps of every workgroup)
         phases = allw[4 * 65536: 8 * 65536].reshape(-1, 4)
         allw = allw[: 4 * 65536]
@@ -29,6 +31,10 @@ def main():
             tiles = ph[has, 3].astype(float)
             d0 = ph[has, 0] * 10e-3; d1 = ph[has, 1] * 10e-3; d2 = ph[has, 2] * 10e-3
             life_ = (en_[has] - st_[has]) * 10e-3
+            if sub is not None:
+                sb = sub[live][has].astype(float) * 10e-3
+                print(f"  of the switch: registers -> float32 -> LDS {(sb[:, 0] / tiles).mean():.2f}, next tile's page taken + its first loads issued "
+                      f"{(sb[:, 1] / tiles).mean():.2f}, rows LDS -> stores + re-zero {(sb[:, 2] / tiles).mean():.2f} (the rest: accumulators zeroed, loop exit)")
             print(f"phases per TILE (mean us; {int(has.sum())} workgroups, {tiles.mean():.2f} tiles each): switch (stores, next tile's loads issued) "
                   f"{(d0 / tiles).mean():.2f}, wait for the first loads {(d1 / tiles).mean():.2f}, item rounds {(d2 / tiles).mean():.2f} "
                   f"({(d2.sum() / it_[has].sum()):.3f} per item), rest of the workgroup's life (last store, exit) {((life_ - d0 - d1 - d2) / tiles).mean():.2f}")

@@ -2132,8 +2132,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
     const unsigned long long tl_start_ = __builtin_amdgcn_s_memrealtime();
     // sums over the workgroup's tiles: [0] from the end of a tile's items (the launch's start) to the wait for the next tile's
     // first loads, [1] that wait, [2] the item rounds; tl_mark_: the last stamp
-    unsigned long long tl_ph_[3] = {0, 0, 0};
-    unsigned long long tl_mark_ = tl_start_;
+    unsigned long long tl_ph_[6] = {0, 0, 0, 0, 0, 0};   // ([3..5]: parts of [0]: registers -> LDS, next tile's loads issued, stores)
+    unsigned long long tl_mark_ = tl_start_, tl_sub_ = tl_start_;
 #define TL_PHASE(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); tl_ph_[i] += now_ - tl_mark_; tl_mark_ = now_; } while (0)
 #else
 #define TL_PHASE(i) do { } while (0)
@@ -2994,6 +2994,9 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         TileArgs sw;   // (the launch's arguments, read again: reload_tile_args)
         reload_tile_args(sw);
         store_tile_a(sw, s_by, s_bx, s_band);
+#ifdef SVGR_DBG_TIMELINE
+        { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tl_ph_[3] += n_ - tl_mark_; tl_sub_ = n_; }
+#endif
         if (go) {
             page01 = w_n;
             page23 = (unsigned long long)__double_as_longlong(v_n);
@@ -3004,7 +3007,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
             if (have_next_) ask_tile();
             begin_tile(sw);
         }
+#ifdef SVGR_DBG_TIMELINE
+        { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tl_ph_[4] += n_ - tl_sub_; tl_sub_ = n_; }
+#endif
         store_tile_b(sw, s_by, s_bx, s_band);
+#ifdef SVGR_DBG_TIMELINE
+        { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tl_ph_[5] += n_ - tl_sub_; }
+#endif
         if (!go) break;
         pend = OUT == 0;   // (the other outputs stored in front of the loads: their waits cover the stores anyway)
 #ifdef SVGR_DBG_NOPEND
@@ -3025,6 +3034,9 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
             t_[3] = ((unsigned long long)xcc_ << 32) | hwid_;
             unsigned long long* p_ = a.dbg + 8 + 4 * (size_t)(1u << 16) + 4 * (size_t)wg_;
             p_[0] = tl_ph_[0]; p_[1] = tl_ph_[1]; p_[2] = tl_ph_[2]; p_[3] = (unsigned long long)(pass_ + 1u);
+            // (the parts of the switch: a third table)
+            unsigned long long* q_ = a.dbg + 8 + 8 * (size_t)(1u << 16) + 4 * (size_t)wg_;
+            q_[0] = tl_ph_[3]; q_[1] = tl_ph_[4]; q_[2] = tl_ph_[5]; q_[3] = 0;
         }
     }
 #endif
@@ -4847,7 +4859,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         {
             // the PREVIOUS render's per-workgroup timeline goes to the file $SVGR_DBG_TIMELINE (raw u64 quadruples)
             static unsigned long long* tl_buf = nullptr;
-            const size_t tl_bytes = 64 + 64 * (size_t)(1u << 16);
+            const size_t tl_bytes = 64 + 96 * (size_t)(1u << 16);
             HIPCHK(hipStreamSynchronize(st));
             if (!tl_buf) { (void)hipMalloc((void**)&tl_buf, tl_bytes); (void)hipMemset(tl_buf, 0, tl_bytes); }
             else if (getenv("SVGR_DBG_TIMELINE")) {
