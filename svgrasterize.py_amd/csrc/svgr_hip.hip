@@ -100,6 +100,9 @@ static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 102
 #ifndef SVGR_X_RECOMPUTE
 #define SVGR_X_RECOMPUTE 0              // tile kernel: the lane's constants recomputed per item instead of held in registers
 #endif
+#ifndef SVGR_X_ADDEARLY
+#define SVGR_X_ADDEARLY 0               // tile kernel: an iteration's add load issued at its top, beside its header load
+#endif
 #ifndef SVGR_X_RUNS
 #define SVGR_X_RUNS 0                   // scatter: the further columns of a run straight-line under v_cmpx instead of a loop
 #endif
@@ -2777,10 +2780,14 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
             if (vrow0 + 64 / CH <= a.vrows && orow0 >= 0 && orow0 + 64 / CH <= a.win_rows && col0 >= 0 && col0 + TC <= a.win_cols) {
                 // (the wave's rows lie inside the output -- every tile of a canvas whose size is a multiple of the tile's: no tests)
                 float4* dst = (float4*)a.out + ((size_t)orow0 * a.out_cols + col);
+                // (all the rows out of the LDS first, then the stores: a store statement is a memory barrier to the compiler, and a read
+                //  behind each one exposed the LDS latency eight times per tile)
+                float4 v4[64 / CH];
+#pragma unroll
+                for (int r = 0; r < 64 / CH; ++r) v4[r] = tp[(wrow0 + r) * T_ROW + lane + lane / PX];
 #pragma unroll
                 for (int r = 0; r < 64 / CH; ++r) {
-                    const float4 v4 = tp[(wrow0 + r) * T_ROW + lane + lane / PX];
-                    const f32x4_t v = {v4.x, v4.y, v4.z, v4.w};
+                    const f32x4_t v = {v4[r].x, v4[r].y, v4[r].z, v4[r].w};
                     SVGR_ROW_STORE(dst, v);
                     dst += a.out_cols;
                 }
@@ -2965,16 +2972,26 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
                 // in hand: the headers of items k, k+1, k+2 and the add of item k+1; the adds of item k are on their way into
                 // delta tile k & 1
                 {
+#if SVGR_X_ADDEARLY
+                    // (both loads of the iteration at its top: the add gets the barrier's and the scatter's time on top of the composite's)
+                    const int* q = hdr_ptr(k + 3);
+                    const void* ap = add_ptr(k + 2);
+                    SVGR_HDR_LOAD(hq, q);
+                    SVGR_ADD_LOAD(wq, vq, ap);
+#else
                     const int* q = hdr_ptr(k + 3);
                     SVGR_HDR_LOAD(hq, q);
+#endif
                 }
                 // behind this barrier: every wave's adds of item k have landed; everybody's scan of item k-1 has zeroed its tile
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 scatter(h_s, w_n, v_n, (k + 1) & 1);
+#if !SVGR_X_ADDEARLY
                 {
                     const void* ap = add_ptr(k + 2);
                     SVGR_ADD_LOAD(wq, vq, ap);
                 }
+#endif
                 process(h_p, k & 1);
                 h_p = h_s; h_s = h_a;
                 SVGR_ITER_TAKE(h_a, w_n, v_n);
