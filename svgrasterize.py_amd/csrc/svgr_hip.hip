@@ -103,6 +103,9 @@ static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 102
 #ifndef SVGR_X_ADDEARLY
 #define SVGR_X_ADDEARLY 0               // tile kernel: an iteration's add load issued at its top, beside its header load
 #endif
+#ifndef SVGR_X_CARRY1
+#define SVGR_X_CARRY1 1                 // class-2 cells: the carry-in block of the header neither written (k_path_build) nor fetched (tile kernel)
+#endif
 #ifndef SVGR_X_RUNS
 #define SVGR_X_RUNS 0                   // scatter: the further columns of a run straight-line under v_cmpx instead of a loop
 #endif
@@ -1664,7 +1667,11 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             const unsigned cm = rowm & 0xffffu, sm = rowm >> 16;
             const int n_carry = __popc(cm);
             CellHdr* hd = cell_hdr + cell;
+#if SVGR_X_CARRY1
+            if (cls == 1) hd->carry[row_l] = cin;   // (a class-2 cell's carry-ins are adds of its list: the tile kernel does not load this part of its header)
+#else
             hd->carry[row_l] = cin;
+#endif
             const int add0 = s_base + s_ptot[g] + info.x;
             const int cell_c0 = (sl.k0 + k) * TC + x_first;       // layer column of the tile's column 0
             const unsigned below = (1u << row_l) - 1u;
@@ -2206,7 +2213,14 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
 #endif
         if (j >= n_round) return (const int*)a.trash + hdr_lane;
         const unsigned cw = (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63);
+#if SVGR_X_CARRY1
+        // (class 2: the lanes behind the 20 scalar dwords ask for dword 19 again -- the 128 bytes of carry-ins, which for this class
+        //  are in the add list, are neither written nor fetched)
+        const int hl = (cw >> 30) == 2u ? (hdr_lane < HDR_DWORDS ? hdr_lane : HDR_DWORDS - 1) : hdr_lane;
+        return (const int*)(a.cell_hdr + (cw & 0x3fffffffu)) + hl;
+#else
         return (const int*)(a.cell_hdr + (cw & 0x3fffffffu)) + hdr_lane;
+#endif
     };
     auto hdr_cls = [&](int h) { return (__builtin_amdgcn_readlane(h, 12) >> 3) & 3; };
     // class 2: this lane's first add of the item (its later ones, for lists longer than the workgroup, are loaded by the
