@@ -104,6 +104,9 @@ static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 102
 #define SVGR_X_ADDEARLY 0               // tile kernel: an iteration's add load issued at its top, beside its header load
 #endif
 #ifndef SVGR_X_CARRY1
+#ifndef SVGR_X_ADD12
+#define SVGR_X_ADD12 0                  // a TileAdd of 12 bytes {value, where} (no padding word): 46 MB less traffic per step, but entries straddle cache lines -- tile kernel +2.5 us, k_path_build -1 us (A/B twice): off
+#endif
 #define SVGR_X_CARRY1 1                 // class-2 cells: the carry-in block of the header neither written (k_path_build) nor fetched (tile kernel)
 #endif
 #ifndef SVGR_X_RUNS
@@ -116,24 +119,31 @@ static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 102
 // One addition into a tile's LDS delta tile: everything the scatter phase of the tile kernel does for it is
 // `ds_add_f64 base + offset, v`.  A run of `len` consecutive tile columns with the same value (the middle pieces of a
 // long span, S:2286-2287) is one entry.  Written by k_pair_cells, per cell contiguous.
+#if SVGR_X_ADD12
 struct TileAdd {
+    unsigned v_lo, v_hi;   // the value (a double, at a 4-byte boundary; in front: a register tuple starts at an even register, and so must a double)
     unsigned where;  // bits 0-15: byte offset of (tile row, tile column) in the padded delta tile; bits 16-21: len - 1;
                      // bits 22-24: tile column & (PX - 1) of the first add (the run steps over the chunk padding)
+};
+static_assert(sizeof(TileAdd) == 12, "TileAdd is one dwordx3");
+typedef unsigned u32x3s_t __attribute__((ext_vector_type(3), aligned(4)));
+__device__ __forceinline__ void store_add(TileAdd* p, unsigned where, double v) {
+    const u32x3s_t w = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v), where};
+    *(u32x3s_t*)p = w;
+}
+#else
+struct TileAdd {
+    unsigned where;
     unsigned zero;
     double v;
 };
 static_assert(sizeof(TileAdd) == 16, "TileAdd is one dwordx4");
 __device__ __forceinline__ void store_add(TileAdd* p, unsigned where, double v) {
-#ifdef SVGR_NT_ADDS
-    typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
-    u32x4s_t w = {where, 0u, (unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
-    __builtin_nontemporal_store(w, (u32x4s_t*)p);
-#else
     TileAdd t;
     t.where = where; t.zero = 0u; t.v = v;
     *p = t;
-#endif
 }
+#endif
 // One (path, band, column tile) CELL = one work item of the tile kernel, written by k_pair_cells.
 // `carry[r]` = sum of every piece of the pair's row r that lies LEFT of the tile (the running sum the row
 // scan starts from, np.cumsum S:983); `cls` sorts the cells:
@@ -1739,7 +1749,7 @@ struct TileSlot {
 // the page's last 16 bytes) and a copy of the first PAGE_ITEMS items of that tile's list, PAGE_STRIDE x 16 bytes that ONE load
 // instruction fetches (a lane each).  Tile and items used to be two dependent round trips in front of the first header.
 constexpr int PAGE_ITEMS = 24, PAGE_STRIDE = PAGE_ITEMS + 1;
-static_assert(PAGE_STRIDE <= 64, "a page is one 16-byte load per lane");
+static_assert(PAGE_STRIDE + 1 <= 64, "a page is one load per lane (and one more lane for the last word of the tile's entry)");
 #ifndef SVGR_TL_BLOCK
 #define SVGR_TL_BLOCK 1024
 #endif
@@ -2250,14 +2260,31 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
 #define hq1_C "v117"
 #define hq_R "v118"
 #define hq_C "v118"
+#if SVGR_X_ADD12
+#define wq0_R "v122"            // (an add lands in three registers: {value} {where})
+#define wq0_C "v122"
+#define aq0_R "v[120:122]"
+#define vq0_R "v[120:121]"
+#define vq0_C "v120", "v121"
+#define wq_R "v126"
+#define wq_C "v126"
+#define aq_R "v[124:126]"
+#define vq_R "v[124:125]"
+#define vq_C "v124", "v125"
+#define SVGR_WMOV "v_mov_b32"
+    typedef unsigned addw_t;
+#else
+#define SVGR_WMOV "v_mov_b64"
+    typedef unsigned long long addw_t;
 #define wq0_R "v[120:121]"
 #define wq0_C "v120", "v121"
-#define vq0_R "v[122:123]"
-#define vq0_C "v122", "v123"
 #define wq_R "v[124:125]"
 #define wq_C "v124", "v125"
+#define vq0_R "v[122:123]"
+#define vq0_C "v122", "v123"
 #define vq_R "v[126:127]"
 #define vq_C "v126", "v127"
+#endif
     static_assert(SVGR_FIX0 == 116, "the register names above");
 #ifdef SVGR_DBG_ADD_LOAD_NT
 #define SVGR_ADD_NT " nt"       // diagnostic: the add lists are read once -- a nontemporal load
@@ -2269,6 +2296,23 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         if constexpr (FIXED) asm volatile("global_load_dword " tgt##_R ", %0, off" : : "v"(ptr) : "memory", tgt##_C);   \
         else asm volatile("global_load_dword %0, %1, off" : "=v"(tgt) : "v"(ptr) : "memory");                           \
     } while (0)
+#if SVGR_X_ADD12
+#ifdef SVGR_X_ADD12_SPLIT
+#define SVGR_ADD12_INS(tw, tv) "global_load_dwordx2 " tv##_R ", %0, off" SVGR_ADD_NT "\n\tglobal_load_dword " tw##_R ", %0, off offset:8" SVGR_ADD_NT
+#else
+#define SVGR_ADD12_INS(tw, tv) "global_load_dwordx3 " tw##_A ", %0, off" SVGR_ADD_NT
+#endif
+#define SVGR_ADD_LOAD(tw, tv, ptr)                                                                                     \
+    do {                                                                                                               \
+        if constexpr (FIXED)                                                                                           \
+            asm volatile(SVGR_ADD12_INS(tw, tv) : : "v"(ptr) : "memory", tw##_C, tv##_C);                            \
+        else                                                                                                           \
+            asm volatile("global_load_dword %0, %2, off offset:8" SVGR_ADD_NT "\n\tglobal_load_dwordx2 %1, %2, off" SVGR_ADD_NT \
+                         : "=&v"(tw), "=&v"(tv) : "v"(ptr) : "memory");                                                 \
+    } while (0)
+#define wq0_A aq0_R
+#define wq_A aq_R
+#else
 #define SVGR_ADD_LOAD(tw, tv, ptr)                                                                                     \
     do {                                                                                                               \
         if constexpr (FIXED)                                                                                           \
@@ -2278,17 +2322,18 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
             asm volatile("global_load_dwordx2 %0, %2, off" SVGR_ADD_NT "\n\tglobal_load_dwordx2 %1, %2, off offset:8" SVGR_ADD_NT \
                          : "=&v"(tw), "=&v"(tv) : "v"(ptr) : "memory");                                                 \
     } while (0)
+#endif
     // the wait at a round's start: ALL its first loads (the two headers and the add the first items need; header 2 and add 1, which
     // the loop starts with) -- n = what may stay in flight behind them: the previous tile's stores, or nothing
 #define SVGR_ROUND_TAKE(n, d0, d1, dw0, dv0, d2, dw1, dv1)                                                             \
     do {                                                                                                               \
         if constexpr (FIXED)                                                                                           \
-            asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, " hq0_R "\n\tv_mov_b32 %1, " hq1_R "\n\tv_mov_b64 %2, " wq0_R "\n\tv_mov_b64 %3, " vq0_R \
-                         "\n\tv_mov_b32 %4, " hq_R "\n\tv_mov_b64 %5, " wq_R "\n\tv_mov_b64 %6, " vq_R                 \
+            asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, " hq0_R "\n\tv_mov_b32 %1, " hq1_R "\n\t" SVGR_WMOV " %2, " wq0_R "\n\tv_mov_b64 %3, " vq0_R \
+                         "\n\tv_mov_b32 %4, " hq_R "\n\t" SVGR_WMOV " %5, " wq_R "\n\tv_mov_b64 %6, " vq_R                 \
                          : "=&v"(d0), "=&v"(d1), "=&v"(dw0), "=&v"(dv0), "=&v"(d2), "=&v"(dw1), "=&v"(dv1) : : "memory"); \
         else                                                                                                           \
-            asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, %7\n\tv_mov_b32 %1, %8\n\tv_mov_b64 %2, %9\n\tv_mov_b64 %3, %10" \
-                         "\n\tv_mov_b32 %4, %11\n\tv_mov_b64 %5, %12\n\tv_mov_b64 %6, %13"                            \
+            asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, %7\n\tv_mov_b32 %1, %8\n\t" SVGR_WMOV " %2, %9\n\tv_mov_b64 %3, %10" \
+                         "\n\tv_mov_b32 %4, %11\n\t" SVGR_WMOV " %5, %12\n\tv_mov_b64 %6, %13"                            \
                          : "=&v"(d0), "=&v"(d1), "=&v"(dw0), "=&v"(dv0), "=&v"(d2), "=&v"(dw1), "=&v"(dv1)              \
                          : "v"(hq0), "v"(hq1), "v"(wq0), "v"(vq0), "v"(hq), "v"(wq), "v"(vq) : "memory");                \
     } while (0)
@@ -2297,14 +2342,14 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
 #define SVGR_ITER_TAKE(d2, dw1, dv1)                                                                                   \
     do {                                                                                                               \
         if constexpr (FIXED)                                                                                           \
-            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, " hq_R "\n\tv_mov_b64 %1, " wq_R "\n\tv_mov_b64 %2, " vq_R  \
+            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, " hq_R "\n\t" SVGR_WMOV " %1, " wq_R "\n\tv_mov_b64 %2, " vq_R  \
                          : "=&v"(d2), "=&v"(dw1), "=&v"(dv1) : : "memory");                                             \
         else                                                                                                           \
-            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %3\n\tv_mov_b64 %1, %4\n\tv_mov_b64 %2, %5"             \
+            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %3\n\t" SVGR_WMOV " %1, %4\n\tv_mov_b64 %2, %5"             \
                          : "=&v"(d2), "=&v"(dw1), "=&v"(dv1) : "v"(hq), "v"(wq), "v"(vq) : "memory");                    \
     } while (0)
     // the adds of an item into delta tile `buf`
-    auto scatter = [&](int h, unsigned long long first_w, double first_v, int buf) {
+    auto scatter = [&](int h, addw_t first_w, double first_v, int buf) {
 #ifdef SVGR_DBG_NOSCATTER
         return;
 #endif
@@ -2367,11 +2412,16 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         // memory round trip per item, the pipeline's depth gone.
         if (tid < n_add) one((unsigned)first_w, first_v);
         for (int i = tid + i_step; i < n_add; i += i_step) {
-            unsigned long long w2;
+            addw_t w2;
             double v2;
             const TileAdd* const q = a.adds + (size_t)add0 + i;
+#if SVGR_X_ADD12
+            asm volatile("global_load_dword %0, %2, off offset:8\n\tglobal_load_dwordx2 %1, %2, off\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(w2), "=&v"(v2) : "v"(q) : "memory");
+#else
             asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:8\n\ts_waitcnt vmcnt(0)"
                          : "=&v"(w2), "=&v"(v2) : "v"(q) : "memory");
+#endif
             one((unsigned)w2, v2);
         }
 #else
@@ -2381,7 +2431,11 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
             if (i != tid) {
                 const TileAdd t = a.adds[(size_t)add0 + i];
                 w = t.where;
+#if SVGR_X_ADD12
+                v = __hiloint2double((int)t.v_hi, (int)t.v_lo);
+#else
                 v = t.v;
+#endif
             }
             one(w, v);
         }
@@ -2837,7 +2891,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
 
     // ---- the tiles of this workgroup ----
     int hq0, hq1, hq;                  // load targets: the first two headers of a round, the header in flight in the loop
-    unsigned long long wq0, wq;        // load targets: the first add of the round's first item / the add in flight ({where, 0})
+    addw_t wq0, wq;                    // load targets: the first add of the round's first item / the add in flight ({where, 0})
     double vq0, vq;                    // ... and their values
     (void)hq0; (void)hq1; (void)hq; (void)wq0; (void)wq; (void)vq0; (void)vq;
     unsigned next_tile_ = 0u;
@@ -2853,7 +2907,11 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         if (have_next_ && r0 + n_round >= n_items) {
             int ln = lane_;
             asm volatile("" : "+v"(ln));
+#if SVGR_X_ADD12
+            tail_ptr_ = (const unsigned*)(pages_ + (size_t)next_tile_ * PAGE_STRIDE + (ln < PAGE_STRIDE ? ln : PAGE_ITEMS)) + (ln == PAGE_STRIDE ? 1 : 0);
+#else
             tail_ptr_ = pages_ + (size_t)next_tile_ * PAGE_STRIDE + (ln < PAGE_STRIDE ? ln : PAGE_ITEMS);
+#endif
         }
         const int* q0 = hdr_ptr(0);
         const int* q1 = hdr_ptr(1);
@@ -2943,9 +3001,9 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
 #pragma unroll
         for (int i = 0; i < PX; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0;
         int h_p, h_s, h_a;            // the landed headers of items k, k+1, k+2
-        unsigned long long w_s;       // the landed add of the round's first item
+        addw_t w_s;                   // the landed add of the round's first item
         double v_s;
-        unsigned long long w_n;       // the landed add of item k+1 -- when the tile's last round ends: the next tile's page {x, y}
+        addw_t w_n;                   // the landed add of item k+1 -- when the tile's last round ends: the next tile's page {x, y}
         double v_n;                   // ... {z, w}
         // ---- the item loop: rounds of up to 64 items ----
         bool preissued = FIXED;   // the tile's first round: begin_tile has issued its loads
@@ -3029,8 +3087,17 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tl_ph_[3] += n_ - tl_mark_; tl_sub_ = n_; }
 #endif
         if (go) {
+#if SVGR_X_ADD12
+            {   // (a lane took 12 bytes of its page entry: {x, y, z}; what the tile's lane holds in w -- its item count -- came to the
+                //  lane behind it, which read from 4 bytes further on: tail_ptr_)
+                const unsigned n_ = (unsigned)__builtin_amdgcn_readlane((int)w_n, PAGE_ITEMS + 1);
+                page01 = (unsigned long long)__double_as_longlong(v_n);
+                page23 = (unsigned long long)w_n | ((unsigned long long)n_ << 32);
+            }
+#else
             page01 = w_n;
             page23 = (unsigned long long)__double_as_longlong(v_n);
+#endif
             tile_ = (unsigned)__builtin_amdgcn_readfirstlane((int)next_tile_);   // (scalars, said so: the compiler kept them in VGPRs -- and spilled them)
             pass_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(pass_ + 1u));
             next_tile_ = (unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned*)(s_mem + MAILBOX));
