@@ -35,6 +35,12 @@ def main():
                 sb = sub[live][has].astype(float) * 10e-3
                 print(f"  of the switch: registers -> float32 -> LDS {(sb[:, 0] / tiles).mean():.2f}, next tile's page taken + its first loads issued "
                       f"{(sb[:, 1] / tiles).mean():.2f}, rows LDS -> stores + re-zero {(sb[:, 2] / tiles).mean():.2f} (the rest: accumulators zeroed, loop exit)")
+                wq = sub[live][has][:, 3]
+                if wq.any():   # (-DSVGR_DBG_TL_WAITS: shader cycles of wave 0 in the loop's barrier / in the wait for the iteration's loads)
+                    wb = (wq & np.uint64(0xFFFFFFFF)).astype(float); wi = (wq >> np.uint64(32)).astype(float)
+                    n_it = it_[has].sum()
+                    print(f"  waits of wave 0 per item (shader cycles, the two clock reads included): barrier {wb.sum() / n_it:.0f}, iteration's loads {wi.sum() / n_it:.0f}"
+                          f"  (an item: {d2.sum() / n_it * 2400:.0f} cycles at 2.4 GHz)")
             print(f"phases per TILE (mean us; {int(has.sum())} workgroups, {tiles.mean():.2f} tiles each): switch (stores, next tile's loads issued) "
                   f"{(d0 / tiles).mean():.2f}, wait for the first loads {(d1 / tiles).mean():.2f}, item rounds {(d2 / tiles).mean():.2f} "
                   f"({(d2.sum() / it_[has].sum()):.3f} per item), rest of the workgroup's life (last store, exit) {((life_ - d0 - d1 - d2) / tiles).mean():.2f}")

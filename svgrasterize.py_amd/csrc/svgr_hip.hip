@@ -2154,6 +2154,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
     // first loads, [1] that wait, [2] the item rounds; tl_mark_: the last stamp
     unsigned long long tl_ph_[6] = {0, 0, 0, 0, 0, 0};   // ([3..5]: parts of [0]: registers -> LDS, next tile's loads issued, stores)
     unsigned long long tl_mark_ = tl_start_, tl_sub_ = tl_start_;
+    unsigned long long tl_wb_ = 0, tl_wi_ = 0;   // (SVGR_DBG_TL_WAITS) shader cycles in the loop's barrier / in the wait for the iteration's loads
 #define TL_PHASE(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); tl_ph_[i] += now_ - tl_mark_; tl_mark_ = now_; } while (0)
 #else
 #define TL_PHASE(i) do { } while (0)
@@ -3056,7 +3057,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
 #endif
                 }
                 // behind this barrier: every wave's adds of item k have landed; everybody's scan of item k-1 has zeroed its tile
+#if defined(SVGR_DBG_TIMELINE) && defined(SVGR_DBG_TL_WAITS)
+                const unsigned long long cb0_ = __builtin_readcyclecounter();
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if defined(SVGR_DBG_TIMELINE) && defined(SVGR_DBG_TL_WAITS)
+                tl_wb_ += __builtin_readcyclecounter() - cb0_;
+#endif
                 scatter(h_s, w_n, v_n, (k + 1) & 1);
 #if !SVGR_X_ADDEARLY
                 {
@@ -3066,7 +3073,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
 #endif
                 process(h_p, k & 1);
                 h_p = h_s; h_s = h_a;
+#if defined(SVGR_DBG_TIMELINE) && defined(SVGR_DBG_TL_WAITS)
+                const unsigned long long ci0_ = __builtin_readcyclecounter();
+#endif
                 SVGR_ITER_TAKE(h_a, w_n, v_n);
+#if defined(SVGR_DBG_TIMELINE) && defined(SVGR_DBG_TL_WAITS)
+                tl_wi_ += __builtin_readcyclecounter() - ci0_;
+#endif
                 h_a = k + 3 < n ? h_a : 0;
             }
             // (nothing is in flight: the last iteration's wait)
@@ -3134,7 +3147,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
             p_[0] = tl_ph_[0]; p_[1] = tl_ph_[1]; p_[2] = tl_ph_[2]; p_[3] = (unsigned long long)(pass_ + 1u);
             // (the parts of the switch: a third table)
             unsigned long long* q_ = a.dbg + 8 + 8 * (size_t)(1u << 16) + 4 * (size_t)wg_;
-            q_[0] = tl_ph_[3]; q_[1] = tl_ph_[4]; q_[2] = tl_ph_[5]; q_[3] = 0;
+            q_[0] = tl_ph_[3]; q_[1] = tl_ph_[4]; q_[2] = tl_ph_[5]; q_[3] = (tl_wb_ & 0xffffffffull) | (tl_wi_ << 32);
         }
     }
 #endif
