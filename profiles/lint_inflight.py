@@ -46,7 +46,7 @@ def check(name, text):
         if "#ASMEND" in l:
             in_asm = False
             continue
-        m = re.match(r"^(\.L\w+):", l)
+        m = re.match(r"^\s*(\.L\w+):", l)
         if m:
             pending.append((m.group(1), sub))  # (names the next instruction of ITS kind)
             continue

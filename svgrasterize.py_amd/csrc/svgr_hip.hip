@@ -107,6 +107,12 @@ static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 102
 #ifndef SVGR_X_ADD12
 #define SVGR_X_ADD12 0                  // a TileAdd of 12 bytes {value, where} (no padding word): 46 MB less traffic per step, but entries straddle cache lines -- tile kernel +2.5 us, k_path_build -1 us (A/B twice): off
 #endif
+#ifndef SVGR_X_MASK64
+#define SVGR_X_MASK64 1                 // the scan's exec masks held as whole scalar pairs
+#endif
+#ifndef SVGR_X_BLEND2
+#define SVGR_X_BLEND2 1                 // the production blend: two pixels per asm statement (one class-1 test for both)
+#endif
 #define SVGR_X_CARRY1 1                 // class-2 cells: the carry-in block of the header neither written (k_path_build) nor fetched (tile kernel)
 #endif
 #ifndef SVGR_X_RUNS
@@ -2446,6 +2452,16 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
     // ---- scan + fill rule + paint + source-over of the item whose deltas are in delta tile `buf` ----
     const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * (64 / CH);  // a wave owns 64 / CH tile rows
     const int wrow0_ = wrow0;
+#if SVGR_X_MASK64
+    // the scan's three lane masks as whole scalar pairs, opaque to the compiler: as constants it keeps one half of each and builds
+    // the pair again in front of every use (their halves are equal)
+    unsigned long long sm1_, sm2_, sm4_;
+    {
+        constexpr unsigned long long rep = CH == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
+        sm1_ = rep * (CH == 8 ? 0xfeull : 0xeull); sm2_ = rep * (CH == 8 ? 0xfcull : 0xcull); sm4_ = rep * 0xf0ull;
+        asm volatile("" : "+s"(sm1_), "+s"(sm2_), "+s"(sm4_));
+    }
+#endif
     auto process = [&](int h, int buf) {
         const int bits = __builtin_amdgcn_readlane(h, 12);
         const int cls = (bits >> 3) & 3;
@@ -2547,9 +2563,16 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
                 // first (two VOP3 v_cndmask per step: a fifth of the scan's vector instructions).  The DPP moves themselves run
                 // with every lane enabled: a disabled lane would read as zero on the source side as well.
                 constexpr unsigned long long rep = CH == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
+#if SVGR_X_MASK64
+                (void)rep;
+#else
                 constexpr unsigned long long m1 = rep * (CH == 8 ? 0xfeull : 0xeull), m2 = rep * (CH == 8 ? 0xfcull : 0xcull), m4 = rep * 0xf0ull;
+#endif
                 double v;
                 const unsigned long long exec_all = __builtin_amdgcn_read_exec();   // (all ones: every branch above is wave-uniform)
+#if SVGR_X_MASK64
+                const unsigned long long m1 = sm1_, m2 = sm2_, m4 = sm4_;   // (whole scalar pairs made once: see their definition)
+#endif
 #define SVGR_MASKED_ADD(acc_, v_, m_) asm volatile("s_mov_b64 exec, %2\n\tv_add_f64 %0, %0, %1\n\ts_mov_b64 exec, %3" : "+v"(acc_) : "v"(v_), "s"(m_), "s"(exec_all))
                 v = dpp_row_shr<1>(inc); SVGR_MASKED_ADD(inc, v, m1);
                 v = dpp_row_shr<2>(inc); SVGR_MASKED_ADD(inc, v, m2);
@@ -2668,7 +2691,51 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
 #define SVGR_BLEND_C1_HEAD
 #define SVGR_BLEND_C1_TAIL
 #endif
+#if SVGR_X_BLEND2
+                // two pixels per statement: one class-1 test (and, out of line, one way back) for both
+#define SVGR_BLEND_ONE(a0, a1, a2, a3, t)                                                                              \
+            "v_cmpx_ge_f64_e64 %[vis], |%[" #t "]|, %[cut]\n\t"                                                         \
+            "v_min_f64 %[m], |%[" #t "]|, 1.0\n\t"                                                                      \
+            "v_fma_f64 %[t0], -%[" #a0 "], %[pa], %[p0]\n\t"                                                            \
+            "v_fma_f64 %[t1], -%[" #a1 "], %[pa], %[p1]\n\t"                                                            \
+            "v_fma_f64 %[t2], -%[" #a2 "], %[pa], %[p2]\n\t"                                                            \
+            "v_fma_f64 %[t3], -%[" #a3 "], %[pa], %[pa]\n\t"                                                            \
+            "v_fma_f64 %[" #a0 "], %[m], %[t0], %[" #a0 "]\n\t"                                                          \
+            "v_fma_f64 %[" #a1 "], %[m], %[t1], %[" #a1 "]\n\t"                                                          \
+            "v_fma_f64 %[" #a2 "], %[m], %[t2], %[" #a2 "]\n\t"                                                          \
+            "v_fma_f64 %[" #a3 "], %[m], %[t3], %[" #a3 "]\n\t"                                                          \
+            "s_mov_b64 exec, %[all]\n\t"
+#define SVGR_BLEND_FAST(a0, a1, a2, a3)                                                                                \
+    "v_fma_f64 %[" #a0 "], %[" #a0 "], %[k], %[s0]\n\tv_fma_f64 %[" #a1 "], %[" #a1 "], %[k], %[s1]\n\t"                \
+    "v_fma_f64 %[" #a2 "], %[" #a2 "], %[k], %[s2]\n\tv_fma_f64 %[" #a3 "], %[" #a3 "], %[k], %[s3]\n\t"
+#define SVGR_BLEND_2PX(i)                                                                                              \
+    {                                                                                                                  \
+        double t0, t1, t2, t3, mval;                                                                                   \
+        unsigned long long vis_;                                                                                       \
+        asm volatile(                                                                                                  \
+            "s_cmp_lg_u32 %[fast], 0\n\ts_cbranch_scc1 .Lc1f_%=\n\t"                                                  \
+            SVGR_BLEND_ONE(a0, a1, a2, a3, ta)                                                                         \
+            SVGR_BLEND_ONE(b0, b1, b2, b3, tb)                                                                         \
+            ".Lc1b_%=:\n\t.subsection 1\n.Lc1f_%=:\n\t"                                                              \
+            SVGR_BLEND_FAST(a0, a1, a2, a3)                                                                            \
+            SVGR_BLEND_FAST(b0, b1, b2, b3)                                                                            \
+            "s_branch .Lc1b_%=\n\t.subsection 0"                                                                      \
+            : [a0] "+v"(acc[i][0]), [a1] "+v"(acc[i][1]), [a2] "+v"(acc[i][2]), [a3] "+v"(acc[i][3]),                    \
+              [b0] "+v"(acc[i + 1][0]), [b1] "+v"(acc[i + 1][1]), [b2] "+v"(acc[i + 1][2]), [b3] "+v"(acc[i + 1][3]),    \
+              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [m] "=&v"(mval), [vis] "=&s"(vis_)        \
+            : [ta] "v"(t[i]), [tb] "v"(t[i + 1]), [pa] "v"(p3v), [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [cut] "s"(cut), \
+              [all] "s"(exec_all), [fast] "s"(__builtin_amdgcn_readfirstlane(c1fast)), [k] "v"(t[0]), [s0] "v"(t[1]),   \
+              [s1] "v"(t[2]), [s2] "v"(t[3]), [s3] "v"(t[4])                                                            \
+            : "scc");                                                                                                  \
+    }
+                static_assert(PX == 8, "four statements of two pixels");
+                SVGR_BLEND_2PX(0) SVGR_BLEND_2PX(2) SVGR_BLEND_2PX(4) SVGR_BLEND_2PX(6)
+#undef SVGR_BLEND_2PX
+#undef SVGR_BLEND_ONE
+#undef SVGR_BLEND_FAST
+#else
                 SVGR_ACC_PX(SVGR_BLEND_PX)
+#endif
 #undef SVGR_BLEND_PX
 #undef SVGR_BLEND_C1_HEAD
 #undef SVGR_BLEND_C1_TAIL
