@@ -3038,6 +3038,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
     // the tile kernel uses for nothing else (padding of the last delta row) behind the tile's first barrier; both waves read
     // it when the tile ends
     constexpr int MAILBOX = 2 * DELTA_BYTES - 16;
+    // (read and written as LDS: through a generic volatile pointer it was a FLAT access with system scope and a wait for every counter)
+    typedef volatile __attribute__((address_space(3))) unsigned lds_vu32_t;
     const bool dealt = FIXED && a.use_order && gridDim.x < n_tiles_;   // (a persistent launch)
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     bool asked = false;   // a fetch is in flight into v119 (wave 0)
@@ -3103,7 +3105,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
                         unsigned q;
                         asm volatile("v_mov_b32 %0, v119" : "=v"(q) : : "memory");   // (landed: older than the loads the wait above covered)
                         const unsigned t2 = 2u * gridDim.x + 8u * (unsigned)__builtin_amdgcn_readfirstlane((int)q) + (blockIdx.x & 7u);
-                        if (tid == 0) *(volatile unsigned*)(s_mem + MAILBOX) = t2;
+                        if (tid == 0) *(lds_vu32_t*)(s_mem + MAILBOX) = t2;
                     }
                 }
             }
@@ -3180,7 +3182,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
 #endif
             tile_ = (unsigned)__builtin_amdgcn_readfirstlane((int)next_tile_);   // (scalars, said so: the compiler kept them in VGPRs -- and spilled them)
             pass_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(pass_ + 1u));
-            next_tile_ = (unsigned)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned*)(s_mem + MAILBOX));
+            next_tile_ = (unsigned)__builtin_amdgcn_readfirstlane((int)*(lds_vu32_t*)(s_mem + MAILBOX));
             have_next_ = next_tile_ < n_tiles_;
             if (have_next_) ask_tile();
             begin_tile(sw);
