@@ -76,6 +76,11 @@ typedef struct svgr_batch svgr_batch;
  * in float32 rounding ties).  With this flag one wave per workgroup does every accumulation, in list order: two
  * renders of the same batch are bit-identical, at roughly half the speed of the geometry and scatter phases. */
 #define SVGR_RENDER_DETERMINISTIC 4u
+/* svgr_batch_render_window only: this window belongs to the same picture as the window the previous render of this batch drew
+ * -- no input of the batch has changed in between --, so the geometry kernels' results are taken as they are instead of being
+ * produced again (a document whose runs of fills share one batch draws each run's window from ONE geometry pass).  Ignored
+ * (the pass runs) after any svgr_batch_set_* / plan since that render. */
+#define SVGR_RENDER_SAME_GEOMETRY 8u
 
 /* -------------------------------------------------------------------------------------------- */
 /* context + device memory                                                                      */

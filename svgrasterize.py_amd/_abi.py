@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libsvgr_hip.so")
 
 OUT_CANVAS_F32, OUT_CANVAS_F64, OUT_MASK_F64, OUT_FILL_F64, OUT_MASKS_F64 = 0, 1, 2, 3, 4
-RENDER_CLIP01, RENDER_TIMED, RENDER_DETERMINISTIC = 1, 2, 4
+RENDER_CLIP01, RENDER_TIMED, RENDER_DETERMINISTIC, RENDER_SAME_GEOMETRY = 1, 2, 4, 8
 SEG_LINE, SEG_CUBIC = 0, 1
 
 CONVERT_PRE_TO_STRAIGHT, CONVERT_SRGB_TO_LINEAR, CONVERT_LINEAR_TO_SRGB, CONVERT_STRAIGHT_TO_PRE = 1, 2, 4, 8
@@ -152,6 +152,11 @@ def load_library():
 def tile_rows() -> int:
     """Band height of the built library (row granularity of Batch.set_bands)."""
     return int(load_library().svgr_tile_rows())
+
+
+def tile_cols() -> int:
+    """Tile width of the built library."""
+    return int(load_library().svgr_tile_cols())
 
 
 def _check(rc: int):

@@ -3760,6 +3760,7 @@ struct svgr_batch {
     std::vector<long long> host_layer_off;
     // plan results (n_edges = edge slots the edge kernels cover = sum of the shard capacities; n_edges_live = filled ones)
     bool geometry_fresh = false;  // the buffers hold the geometry of the current inputs (set by plan, consumed by render)
+    bool geometry_current = false;  // ... and still do: no input has changed since the last geometry pass (SVGR_RENDER_SAME_GEOMETRY)
     bool arena_zeroed = false;    // the last tile kernel left the counter arena zeroed (all but the error word)
     int64_t n_edges_live = 0;
     int64_t n_edges = 0, n_pb = 0, n_bsegs = 0, n_cells = 0, n_entries = 0;
@@ -4290,7 +4291,7 @@ int svgr_batch_set_paints(svgr_batch* b, const double* path_paint) {
     HIPCHK(hipMemcpyAsync(b->path_paint.p, b->keep(path_paint, sizeof(double) * 4 * (size_t)b->n_paths), sizeof(double) * 4 * b->n_paths,
                           hipMemcpyHostToDevice, b->ctx->stream));
     HIPCHK(b->note_upload(b->ctx->stream));
-    b->geometry_fresh = false;  // the cell headers carry the paint
+    b->geometry_fresh = false; b->geometry_current = false;  // the cell headers carry the paint
     return 0;
 }
 
@@ -4323,7 +4324,7 @@ int svgr_batch_set_groups(svgr_batch* b, const int32_t* path_group, int64_t n_gr
                           const double* group_opacity) {
     return abi_guard("svgr_batch_set_groups", [&]() -> int {
         if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
-        if (n_groups == 0) { b->n_groups = 0; b->geometry_fresh = false; return 0; }
+        if (n_groups == 0) { b->n_groups = 0; b->geometry_fresh = false; b->geometry_current = false; return 0; }
         if (n_groups < 0 || n_groups > b->n_paths || !path_group || !group_clip_src || !group_opacity)
             return fail(SVGR_E_INVALID, "svgr_batch_set_groups: bad arguments");
         std::vector<int64_t> first((size_t)n_groups, -1), last((size_t)n_groups, -1);
@@ -4365,7 +4366,7 @@ int svgr_batch_set_groups(svgr_batch* b, const int32_t* path_group, int64_t n_gr
             HIPCHK(b->note_upload(st));
         }
         b->n_groups = n_groups;
-        b->geometry_fresh = false;  // the cell headers carry the group ids
+        b->geometry_fresh = false; b->geometry_current = false;  // the cell headers carry the group ids
         return 0;
     });
 }
@@ -4378,7 +4379,7 @@ int svgr_batch_set_groups(svgr_batch* b, const int32_t* path_group, int64_t n_gr
 int svgr_batch_set_gradients(svgr_batch* b, const int32_t* path_grad, int64_t n_grads, const svgr_gradient* grads) {
     return abi_guard("svgr_batch_set_gradients", [&]() -> int {
         if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
-        if (n_grads == 0) { b->n_grads = 0; b->geometry_fresh = false; return 0; }
+        if (n_grads == 0) { b->n_grads = 0; b->geometry_fresh = false; b->geometry_current = false; return 0; }
         if (n_grads < 0 || n_grads > b->n_paths || !path_grad || !grads) return fail(SVGR_E_INVALID, "svgr_batch_set_gradients: bad arguments");
         std::vector<GradDev> host((size_t)n_grads);
         std::vector<int> owner((size_t)n_grads, -1);
@@ -4426,7 +4427,7 @@ int svgr_batch_set_gradients(svgr_batch* b, const int32_t* path_grad, int64_t n_
         }
         b->n_grads = n_grads;
         b->has_focal = focal;
-        b->geometry_fresh = false;  // the cell headers carry the gradient indices
+        b->geometry_fresh = false; b->geometry_current = false;  // the cell headers carry the gradient indices
         return 0;
     });
 }
@@ -4533,7 +4534,7 @@ static int spec_finish(svgr_batch* b) {
     b->sized = true;
     for (int k = 0; k < 4; ++k) b->sized_vp[k] = b->vp[k];
     b->no_band_reuse = getenv("SVGR_NO_BAND_REUSE") != nullptr;
-    b->geometry_fresh = true;
+    b->geometry_fresh = true; b->geometry_current = true;
     return 1;
 }
 static int plan_slab_order(svgr_batch* b);
@@ -4634,7 +4635,7 @@ int svgr_batch_plan_many(svgr_batch** batches, int64_t n) {
             svgr_batch* b = batches[i];
             HIPCHK(enter_ctx(b->ctx));
             b->planned = false; b->slab_at_valid = false;
-            b->geometry_fresh = false;
+            b->geometry_fresh = false; b->geometry_current = false;
             const int is = no_spec ? 0 : spec_issue(b, (char*)b->ctx->pinned + stage_off[(size_t)i]);
             if (is < 0) return is;
             issued[(size_t)i] = (char)is;
@@ -4713,7 +4714,7 @@ static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
     if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
     HIPCHK(enter_ctx(b->ctx));
     b->planned = false; b->slab_at_valid = false;
-    b->geometry_fresh = false;
+    b->geometry_fresh = false; b->geometry_current = false;
     {
         const bool no_spec = getenv("SVGR_NO_SPECULATIVE_PLAN") != nullptr;  // (tests exercise both planners)
         const int sp = no_spec || skip_speculative ? 0 : plan_speculative(b);
@@ -4794,7 +4795,7 @@ static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
     b->sized = true;
     for (int k = 0; k < 4; ++k) b->sized_vp[k] = b->vp[k];
     b->no_band_reuse = getenv("SVGR_NO_BAND_REUSE") != nullptr;
-    b->geometry_fresh = true;
+    b->geometry_fresh = true; b->geometry_current = true;
     return 0;
 }
 
@@ -4861,7 +4862,7 @@ static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path
         if (int rc = b->layout_arena()) return rc;
     const dim3 fgrid = grid1((size_t)ns << FL_SUB, FL_BLOCK);
     const Owner whole{0, 1, 1};
-    b->geometry_fresh = false;
+    b->geometry_fresh = false; b->geometry_current = false;
     b->arena_zeroed = false;
     HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
     hipLaunchKernelGGL(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
@@ -4988,11 +4989,16 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
     // plan reports it)
     // (the first render after a plan finds the plan's own full geometry pass in the buffers: same inputs, same result)
     const bool det = (flags & SVGR_RENDER_DETERMINISTIC) != 0;
-    if (!(b->geometry_fresh && !timed && !det)) {
+    // (SVGR_RENDER_SAME_GEOMETRY: another window of the canvas the previous render of this batch drew a window of -- the tile
+    //  kernel only reads what the geometry kernels left, so the pass is not repeated; ignored when an input has changed since)
+    const bool same = (flags & SVGR_RENDER_SAME_GEOMETRY) != 0 && b->geometry_current && window != nullptr && !timed && !det;
+    if (!(b->geometry_fresh && !timed && !det) && !same) {
         b->deterministic = det;
+        b->geometry_current = false;
         const int rc = run_geometry(b, 4, true);
         b->deterministic = false;
         if (rc) return rc;
+        b->geometry_current = true;
     }
     b->geometry_fresh = false;
     if (single && need) HIPCHK(hipMemsetAsync(out->ptr, 0, need, st));

@@ -236,11 +236,12 @@ def arc_to_cubics(center, rx, ry, phi, eta, eta_delta) -> np.ndarray:
 class Path:
     """Rendering unit; ``subpaths`` uses the reference's segment tuples (S:899-907)."""
 
-    __slots__ = ["subpaths", "_packed"]
+    __slots__ = ["subpaths", "_packed", "_user_box"]
 
     def __init__(self, subpaths):
         self.subpaths = subpaths
         self._packed = None
+        self._user_box = False
 
     def __iter__(self):
         return iter(self.subpaths)
@@ -381,6 +382,23 @@ class Path:
             kinds[len(lines):] = _abi.SEG_CUBIC
             self._packed = (segs, kinds)
         return self._packed
+
+    def user_box(self):
+        """(x0, y0, x1, y1) of the control points in user space (every curve lies inside its control polygon); None: no
+        segment, or a coordinate that is not finite.  Computed once."""
+        if self._user_box is False:
+            segs, kinds = self.packed()
+            box = None
+            if len(segs):
+                pts = segs.reshape(-1, 4, 2)
+                cubic = kinds != 0
+                xs = np.concatenate([pts[:, :2, 0].ravel(), pts[cubic][:, 2:, 0].ravel()])
+                ys = np.concatenate([pts[:, :2, 1].ravel(), pts[cubic][:, 2:, 1].ravel()])
+                box = (float(xs.min()), float(ys.min()), float(xs.max()), float(ys.max()))
+                if not all(math.isfinite(v) for v in box):
+                    box = None
+            self._user_box = box
+        return self._user_box
 
     # -- the hot path ---------------------------------------------------------------------
     def _single_batch(self, transform: Transform, fill_rule, viewport, paint=None):

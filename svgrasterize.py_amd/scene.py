@@ -210,6 +210,7 @@ class Scene(tuple):
             st = _Retained(self)
         _LEAF_MEMO = st.leaf_memo
         _RETAIN = st if _RETAINED_MAX > 0 else None
+        _RENDER_SERIAL[0] += 1
         # the walk allocates thousands of short-lived tuples and no cycles: the cyclic collector's generation-0 sweeps find
         # nothing and cost 0.5-2.5 ms of a 17 ms render (profiles/gc_experiment.py), so it pauses for the call
         gc_paused = _PAUSE_GC and gc.isenabled()
@@ -399,6 +400,180 @@ def _collect_mask_jobs(scene: Scene, transform: Transform, mask_only: bool, line
 
 
 _RUN_PLANS: "dict | None" = None  # during one top-level render: run key -> (leaves, planned batch), from the pre-pass
+_RENDER_SERIAL = [0]               # counts top-level renders: a shared batch runs its geometry once per render
+
+# The runs of a document share ONE device batch (the filter nodes cut icons.svg's paint order into dozens of
+# runs, each a batch of its own with its own five geometry launches and its own plan).  Every run gets a range of rows of a
+# tall canvas to itself -- its leaves' matrices are moved down by a whole number of bands --, the geometry kernels run once
+# for all of them, and a run's layer is a render window of its range (svgr_batch_render_window, SVGR_RENDER_SAME_GEOMETRY).
+# A run whose geometry reaches far beyond the viewport's rows keeps a batch of its own (the range would be mostly air).
+_MERGE_RUNS = __import__("os").environ.get("SVGR_NO_MERGED_RUNS") is None
+_MERGE_MAX_TILES = 1 << 19     # tiles of the tall canvas (its per-tile tables grow with them); what does not fit starts another one
+_ROW_PAD = 4                   # rows kept free around a run's geometry (the anti-aliasing reaches one pixel)
+MERGE_STATS = {"shared_batches": 0, "runs_sharing": 0, "runs_alone": 0}   # counted since import (tests, profiles)
+
+
+class _SharedBatch:
+    """A batch several runs draw from."""
+
+    __slots__ = ("batch", "refs", "serial", "_bboxes", "_edges")
+
+    def __init__(self, batch, refs):
+        self.batch, self.refs, self.serial, self._bboxes, self._edges = batch, refs, -1, None, None
+
+    def bboxes(self):
+        if self._bboxes is None:
+            self._bboxes = self.batch.bboxes()
+        return self._bboxes
+
+    def all_edges(self):
+        if self._edges is None:
+            self._edges = self.batch.all_edges()
+        return self._edges
+
+
+class _RunView:
+    """A run's part of a shared batch: the paths [lo, hi) and the rows its geometry was moved down by.  Quacks like the
+    batch `_render_run` used to hold for the run alone."""
+
+    __slots__ = ("shared", "lo", "hi", "shift", "vrows", "dead")
+
+    def __init__(self, shared, lo, hi, shift, vrows):
+        self.shared, self.lo, self.hi, self.shift, self.vrows, self.dead = shared, lo, hi, shift, vrows, False
+
+    def bboxes(self):
+        """The run's bboxes in the viewport's own rows, clipped to them (the shared canvas is taller than the viewport)."""
+        bb = self.shared.bboxes()[self.lo:self.hi].astype(np.int64)
+        r0 = bb[:, 0] - self.shift
+        r1 = r0 + np.maximum(bb[:, 2], 0)
+        v0, v1 = self.vrows
+        c0, c1 = np.maximum(r0, v0), np.minimum(r1, v1)
+        out = bb.copy()
+        out[:, 0] = c0
+        out[:, 2] = np.where((bb[:, 2] > 0) & (c1 > c0), c1 - c0, 0)
+        return out
+
+    def all_edges(self):
+        edges, edge_path = self.shared.all_edges()
+        mine = (edge_path >= self.lo) & (edge_path < self.hi)
+        e = edges[mine].copy()
+        e[:, :, 0] -= self.shift
+        return e, edge_path[mine] - self.lo
+
+    def render(self, out, kind, flags=0, window=None):
+        sh = self.shared
+        if sh.serial == _RENDER_SERIAL[0]:
+            flags |= _abi.RENDER_SAME_GEOMETRY   # (another run of the same render drew from this batch already)
+        sh.serial = _RENDER_SERIAL[0]
+        r0, c0, rows, cols = window
+        sh.batch.render(out, kind, flags, window=(r0 + self.shift, c0, rows, cols))
+
+    def destroy(self):
+        if not self.dead:
+            self.dead = True
+            self.shared.refs -= 1
+            if self.shared.refs <= 0:
+                self.shared.batch.destroy()
+
+
+def _row_extent(leaf):
+    """Rows (first device coordinate) the control points of a leaf's path can reach: the corners of the path's box in user
+    space under the leaf's matrix (a superset).  None: not finite."""
+    path, m6 = leaf[0], leaf[1]
+    box = path.user_box()
+    if box is None:
+        return None
+    x0, y0, x1, y1 = box
+    a, b, t = float(m6[0]), float(m6[1]), float(m6[2])
+    r = (a * x0 + b * y0 + t, a * x1 + b * y0 + t, a * x0 + b * y1 + t, a * x1 + b * y1 + t)
+    lo, hi = min(r), max(r)
+    if not (lo == lo and hi == hi) or hi - lo > 1e9 or abs(lo) > 1e9:
+        return None
+    return lo, hi
+
+
+def _shift_leaf(leaf, shift):
+    """The leaf moved down by `shift` rows (a whole number of bands)."""
+    if shift == 0:
+        return leaf
+    path, m6, rule, paint4, flags, group, grad = leaf
+    m6 = np.array(m6, dtype=np.float64)
+    m6[2] += shift
+    if grad is not None:
+        _g, _keep, paint, transform, lin = grad
+        moved = Transform(np.array([[1.0, 0.0, float(shift)], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]) @ transform.m)
+        g, keep = paint.abi(moved.invert, lin)
+        grad = (g, keep, paint, transform, lin)
+    return (path, m6, rule, paint4, flags, group, grad)
+
+
+def _merge_runs(todo, viewport):
+    """[(key, leaves)] -> {key: [leaves, batch or _RunView]} with the runs that can share a batch sharing one (per
+    _MERGE_MAX_ROWS of canvas), the others alone.  Returns (plans, batches to plan)."""
+    plans, batches = {}, []
+    v0, vrows = int(viewport[0]), int(viewport[2])
+    v1 = v0 + vrows
+    over = max(vrows, 2048)      # how far beyond the viewport's rows a run's geometry may reach and still share
+    tr = _abi.tile_rows()
+    max_rows = max(_MERGE_MAX_TILES // max(-(-int(viewport[3]) // _abi.tile_cols()), 1), 1) * tr
+    packs, cur, base = [], [], 0
+    for key, leaves in todo:
+        lo, hi = float(v0), float(v1)
+        ok = _MERGE_RUNS and len(todo) > 1
+        if ok:
+            for leaf in leaves:
+                ext = _row_extent(leaf)
+                # (a two-circle gradient asks "any pixel of the fill's LAYER with det < 0" (S:1627), and the layer is the bbox
+                #  clipped to the batch's viewport: such a fill shares only when it lies inside the viewport's rows anyway)
+                if ext is None or (leaf[6] is not None and leaf[6][0].kind == 3 and (ext[0] < v0 + 1 or ext[1] > v1 - 1)):
+                    ok = False
+                    break
+                lo, hi = min(lo, ext[0]), max(hi, ext[1])
+            ok = ok and v0 - lo <= over and hi - v1 <= over
+        if not ok:
+            try:
+                batch = build_batch(leaves, viewport)
+            except Exception:  # noqa: BLE001
+                continue
+            plans[key] = [leaves, batch]
+            batches.append(batch)
+            MERGE_STATS["runs_alone"] += 1
+            continue
+        lo_b = (int(np.floor(lo)) - _ROW_PAD) // tr * tr          # the run's range starts at a band border ...
+        height = -(-(int(np.ceil(hi)) + _ROW_PAD - lo_b) // tr) * tr
+        if cur and base + height > max_rows:
+            packs.append((cur, base))
+            cur, base = [], 0
+        cur.append((key, leaves, base - lo_b))                    # ... and its rows move down by a whole number of bands
+        base += height
+    if cur:
+        packs.append((cur, base))
+    for members, total in packs:
+        if len(members) == 1:
+            key, leaves, _shift = members[0]
+            try:
+                batch = build_batch(leaves, viewport)
+            except Exception:  # noqa: BLE001
+                continue
+            plans[key] = [leaves, batch]
+            batches.append(batch)
+            continue
+        merged, spans = [], []
+        for key, leaves, shift in members:
+            spans.append((key, leaves, len(merged), len(merged) + len(leaves), shift))
+            merged.extend(_shift_leaf(leaf, shift) for leaf in leaves)
+        try:
+            batch = build_batch(merged, [0, int(viewport[1]), total, int(viewport[3])])
+        except Exception:  # noqa: BLE001  (the runs then plan for themselves, on demand)
+            continue
+        shared = _SharedBatch(batch, len(spans))
+        MERGE_STATS["shared_batches"] += 1
+        MERGE_STATS["runs_sharing"] += len(spans)
+        for key, leaves, lo_p, hi_p, shift in spans:
+            plans[key] = [leaves, _RunView(shared, lo_p, hi_p, shift, (v0, v1))]
+        batches.append(batch)
+    return plans, batches
+
 
 
 def _run_key(run, viewport):
@@ -419,22 +594,19 @@ def _plan_runs(runs, fills, viewport, linear_rgb):
     Returns (run plans, fill plans)."""
     from . import geometry  # noqa: PLC0415
 
-    plans, batches = {}, []
+    todo, seen = [], set()
     for run in runs:
-        if len(batches) >= _PREPLAN_MAX:
+        if len(todo) >= _PREPLAN_MAX:
             break
         key = _run_key(run, viewport)
-        if key in plans:
+        if key in seen:
             continue
         leaves = _drop_empty(run)
         if not leaves:
             continue
-        try:
-            batch = build_batch(leaves, viewport)
-        except Exception:  # noqa: BLE001
-            continue
-        plans[key] = (leaves, batch)
-        batches.append(batch)
+        seen.add(key)
+        todo.append((key, leaves))
+    plans, batches = _merge_runs(todo, viewport)
     try:
         fill_plans, fill_batches = geometry.plan_fills(
             [(p, t, r, geometry.solid_paint(c, linear_rgb)) for p, t, r, c in fills[: max(_PREPLAN_MAX - len(batches), 0)]], viewport)
@@ -446,7 +618,7 @@ def _plan_runs(runs, fills, viewport, linear_rgb):
     except Exception:  # noqa: BLE001  (one bad batch: let every run / fill plan for itself and report its own error)
         for b in batches + fill_batches:
             b.destroy()
-        return {}, {}
+        return {}, {}   # (views of a destroyed shared batch are dropped with the dict)
     return plans, fill_plans
 
 
@@ -521,7 +693,7 @@ def _gradient_leaf(path, paint, rule, transform: Transform, linear_rgb: bool, op
             _GRAD_ABI_MEMO.clear()
         _GRAD_ABI_MEMO[key] = (paint, g, keep)
     mult = _ONES if opacity is None else _ONES * opacity  # Layer.opacity over the leaf: image * opacity (S:174)
-    return _leaf(path, transform.m6(), _RULES[rule], mult, grad=(g, keep))
+    return _leaf(path, transform.m6(), _RULES[rule], mult, grad=(g, keep, paint, transform, bool(linear_rgb)))
 
 
 def _new_group(opacity: float, clipped: bool):
