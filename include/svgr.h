@@ -219,6 +219,9 @@ int svgr_layer_in(svgr_ctx* ctx, svgr_buf* out, const int64_t* out_bbox, const s
                   const int64_t* src_bbox, int src_channels);
 /* Layer.opacity, S:171-175: image * opacity */
 int svgr_layer_scale(svgr_ctx* ctx, svgr_buf* img, int64_t n_values, double factor);
+/* ... into another buffer (dst may be src): Layer.opacity returns a new layer, and a copy followed by the in-place form
+ * reads and writes the image twice */
+int svgr_layer_scale_to(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t n_values, double factor);
 /* the clip(0, 1) that ends canvas_merge_at (S:326), in place on n_values doubles */
 int svgr_layer_clip01(svgr_ctx* ctx, svgr_buf* img, int64_t n_values);
 /* Layer.background, S:166-169: premultiplied linear RGBA image OVER the constant colour rgba[4], in place */
@@ -227,6 +230,8 @@ int svgr_layer_background(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, const doub
  * ops bitmask applied in this order: 1 = premultiplied->straight, 2 = sRGB->linear,
  * 4 = linear->sRGB, 8 = straight->premultiplied                                                */
 int svgr_layer_convert(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, unsigned ops);
+/* ... into another buffer (dst may be src) */
+int svgr_layer_convert_to(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t n_px, unsigned ops);
 /* float64 -> float32 (optionally clipping to [0,1]) for presentation */
 int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst_f32, const svgr_buf* src_f64, int64_t n_values, int clip01);
 

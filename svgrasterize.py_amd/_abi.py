@@ -105,9 +105,11 @@ _PROTOS = {
     "svgr_layer_crop4": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     "svgr_layer_in": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     "svgr_layer_scale": (C.c_int, [_P, _P, C.c_int64, C.c_double]),
+    "svgr_layer_scale_to": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double]),
     "svgr_layer_background": (C.c_int, [_P, _P, C.c_int64, _P]),
     "svgr_layer_clip01": (C.c_int, [_P, _P, C.c_int64]),
     "svgr_layer_convert": (C.c_int, [_P, _P, C.c_int64, C.c_uint]),
+    "svgr_layer_convert_to": (C.c_int, [_P, _P, _P, C.c_int64, C.c_uint]),
     "svgr_layer_to_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int]),
     "svgr_layer_to_rgba8": (C.c_int, [_P, _P, _P, C.c_int64]),
     "svgr_layer_blend": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),

@@ -43,6 +43,8 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <memory>
+#include <unordered_map>
 
 #include "../../include/svgr.h"
 #include "svgr_core.h"
@@ -241,7 +243,7 @@ struct DevPool {
     std::map<void*, Block> cap_of;                             // every block handed out or cached
     std::set<int> live;                                        // contexts that exist
     size_t cached_bytes = 0;
-    static constexpr size_t kMaxCached = 8ull << 30;
+    static constexpr size_t kMaxCached = 64ull << 30;   // (of 288 GB: a 4096-wide document holds dozens of 138 MB layers at a time, and a block given back to the driver costs a hipFree -- which waits for the device -- and a hipMalloc the next time)
 
     static size_t size_class(size_t n) {
         size_t c = 256;
@@ -3362,9 +3364,10 @@ __global__ void k_layer_in(double* __restrict__ out, int or0, int oc0, int orows
     o[3] = (ch == 4 ? s[3] : s[0]) * da;
 }
 
-__global__ void k_layer_scale(double* __restrict__ img, size_t n, double f) {
+// (dst may be src: in place)
+__global__ void k_layer_scale(double* dst, const double* src, size_t n, double f) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) img[i] = img[i] * f;
+    if (i < n) dst[i] = src[i] * f;
 }
 
 // ndarray.clip(0, 1) of canvas_merge_at (S:326): np.clip = min(max(v, 0), 1), NaN stays NaN
@@ -3386,11 +3389,12 @@ __global__ void k_layer_background(double* __restrict__ img, size_t n_px, double
     *reinterpret_cast<double4*>(img + 4 * i) = v;
 }
 
-__global__ void k_layer_convert(double* __restrict__ img, size_t n_px, unsigned ops) {
+__global__ void k_layer_convert(double* dst, const double* src, size_t n_px, unsigned ops) {   // (dst may be src)
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_px) return;
-    double* px = img + 4 * i;
-    double v[4] = {px[0], px[1], px[2], px[3]};
+    double* px = dst + 4 * i;
+    const double* sp = src + 4 * i;
+    double v[4] = {sp[0], sp[1], sp[2], sp[3]};
     if (ops & 1u) {  // premultiplied -> straight, S:471-477 (divide where alpha > 1e-4, then clip all 4)
         double al = v[3];
         for (int c = 0; c < 4; ++c) {
@@ -5012,7 +5016,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         a.n_ct = b->n_ctiles();
         a.group_clip_src = b->group_clip_src.p; a.group_opacity = b->group_opacity.p;
         a.grads = b->grads.p; a.grad_flags = b->grad_flags.p;
-        if (b->n_grads > 0 && b->has_focal) {
+        if (b->n_grads > 0 && b->has_focal && !same) {   // (another window of the same picture: the flags are the previous render's)
             // focal radial gradients mask their `det < 0` pixels only if the fill's layer has any (S:1627): one flag per fill
             HIPCHK(hipMemsetAsync(b->grad_flags.p, 0, sizeof(int) * (size_t)b->n_grads, st));
             hipLaunchKernelGGL(k_grad_detneg, dim3(64, (unsigned)b->n_grads), dim3(256), 0, st, (const GradDev*)b->grads.p,
@@ -5231,14 +5235,16 @@ int svgr_layer_in(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr_bu
     return 0;
 }
 
-int svgr_layer_scale(svgr_ctx* ctx, svgr_buf* img, int64_t n, double f) {
-    if (!ctx || !img || n < 0 || img->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_scale: bad arguments");
+int svgr_layer_scale_to(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t n, double f) {
+    if (!ctx || !dst || !src || n < 0 || dst->bytes < (size_t)n * 8 || src->bytes < (size_t)n * 8)
+        return fail(SVGR_E_INVALID, "svgr_layer_scale: bad arguments");
     if (n == 0) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_layer_scale, grid1((size_t)n), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n, f);
+    hipLaunchKernelGGL(k_layer_scale, grid1((size_t)n), dim3(256), 0, ctx->stream, (double*)dst->ptr, (const double*)src->ptr, (size_t)n, f);
     HIPCHK(hipGetLastError());
     return 0;
 }
+int svgr_layer_scale(svgr_ctx* ctx, svgr_buf* img, int64_t n, double f) { return svgr_layer_scale_to(ctx, img, img, n, f); }
 
 int svgr_layer_clip01(svgr_ctx* ctx, svgr_buf* img, int64_t n) {
     if (!ctx || !img || n < 0 || img->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_clip01: bad arguments");
@@ -5259,14 +5265,16 @@ int svgr_layer_background(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, const doub
     return 0;
 }
 
-int svgr_layer_convert(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, unsigned ops) {
-    if (!ctx || !img || n_px < 0 || img->bytes < (size_t)n_px * 32 || (ops & ~15u)) return fail(SVGR_E_INVALID, "svgr_layer_convert: bad arguments");
-    if (n_px == 0 || ops == 0) return 0;
+int svgr_layer_convert_to(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t n_px, unsigned ops) {
+    if (!ctx || !dst || !src || n_px < 0 || dst->bytes < (size_t)n_px * 32 || src->bytes < (size_t)n_px * 32 || (ops & ~15u))
+        return fail(SVGR_E_INVALID, "svgr_layer_convert: bad arguments");
+    if (n_px == 0 || (ops == 0 && dst->ptr == src->ptr)) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_layer_convert, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n_px, ops);
+    hipLaunchKernelGGL(k_layer_convert, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)dst->ptr, (const double*)src->ptr, (size_t)n_px, ops);
     HIPCHK(hipGetLastError());
     return 0;
 }
+int svgr_layer_convert(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, unsigned ops) { return svgr_layer_convert_to(ctx, img, img, n_px, ops); }
 
 int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t n, int clip01) {
     if (!ctx || !dst || !src || n < 0 || dst->bytes < (size_t)n * 4 || src->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_to_f32: bad arguments");
@@ -5402,23 +5410,53 @@ static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src
     // which carries ~1e-16 absolute noise itself; both device forms sum in double and stay below that.)
     // (row / column sums in extended precision: summed in plain doubles their own rounding -- not the kernel's rank --
     // decided the test below for some sizes, and a separable blur then took the 625-tap stencil)
-    std::vector<long double> ul((size_t)kw, 0.0L), vl((size_t)kh, 0.0L);
-    long double total_l = 0.0L;
-    double kmax = 0.0;
-    for (int64_t i = 0; i < kw; ++i)
-        for (int64_t j = 0; j < kh; ++j) {
-            const double k = kernel[i * kh + j];
-            ul[(size_t)i] += k; vl[(size_t)j] += k; total_l += k;
-            kmax = std::fabs(k) > kmax ? std::fabs(k) : kmax;
-        }
-    std::vector<double> u((size_t)kw), v((size_t)kh);
-    for (int64_t i = 0; i < kw; ++i) u[(size_t)i] = (double)ul[(size_t)i];
-    for (int64_t j = 0; j < kh; ++j) v[(size_t)j] = (double)vl[(size_t)j];
-    const double total = (double)total_l;
-    bool separable = getenv("SVGR_BLUR_DIRECT") == nullptr && kw > 1 && kh > 1 && std::isfinite(total) && total != 0.0;
-    for (int64_t i = 0; i < kw && separable; ++i)
-        for (int64_t j = 0; j < kh; ++j)
-            if (!(std::fabs(kernel[i * kh + j] - u[(size_t)i] * v[(size_t)j] / total) <= 8 * 2.220446049250313e-16 * kmax)) { separable = false; break; }
+    // (the analysis of a kernel is kept: a document's blurs come back with every render, and the row / column sums of a
+    //  73 x 73 kernel are 5 000 long-double additions and as many comparisons -- 26 us of host time per call)
+    struct Analysed { std::vector<double> k, u, v; double total; bool separable; };
+    static std::mutex an_mu;
+    static std::unordered_map<unsigned long long, std::shared_ptr<const Analysed>> an_cache;
+    unsigned long long hkey = 1469598103934665603ull ^ (unsigned long long)kw * 1099511628211ull ^ ((unsigned long long)kh << 32);
+    {
+        const unsigned long long* w64 = (const unsigned long long*)kernel;   // (doubles: 8 bytes each)
+        for (int64_t i = 0; i < kw * kh; ++i) hkey = (hkey ^ w64[i]) * 1099511628211ull;
+    }
+    std::shared_ptr<const Analysed> an;
+    {
+        std::lock_guard<std::mutex> lk(an_mu);
+        auto it = an_cache.find(hkey);
+        if (it != an_cache.end() && it->second->u.size() == (size_t)kw && it->second->v.size() == (size_t)kh &&
+            memcmp(it->second->k.data(), kernel, sizeof(double) * (size_t)kw * kh) == 0)
+            an = it->second;
+    }
+    if (!an) {
+        auto fresh = std::make_shared<Analysed>();
+        std::vector<long double> ul((size_t)kw, 0.0L), vl((size_t)kh, 0.0L);
+        long double total_l = 0.0L;
+        double kmax = 0.0;
+        for (int64_t i = 0; i < kw; ++i)
+            for (int64_t j = 0; j < kh; ++j) {
+                const double k = kernel[i * kh + j];
+                ul[(size_t)i] += k; vl[(size_t)j] += k; total_l += k;
+                kmax = std::fabs(k) > kmax ? std::fabs(k) : kmax;
+            }
+        fresh->u.resize((size_t)kw); fresh->v.resize((size_t)kh);
+        for (int64_t i = 0; i < kw; ++i) fresh->u[(size_t)i] = (double)ul[(size_t)i];
+        for (int64_t j = 0; j < kh; ++j) fresh->v[(size_t)j] = (double)vl[(size_t)j];
+        fresh->total = (double)total_l;
+        bool sep = kw > 1 && kh > 1 && std::isfinite(fresh->total) && fresh->total != 0.0;
+        for (int64_t i = 0; i < kw && sep; ++i)
+            for (int64_t j = 0; j < kh; ++j)
+                if (!(std::fabs(kernel[i * kh + j] - fresh->u[(size_t)i] * fresh->v[(size_t)j] / fresh->total) <= 8 * 2.220446049250313e-16 * kmax)) { sep = false; break; }
+        fresh->separable = sep;
+        fresh->k.assign(kernel, kernel + kw * kh);
+        std::lock_guard<std::mutex> lk(an_mu);
+        if (an_cache.size() > 256) an_cache.clear();
+        an_cache[hkey] = fresh;
+        an = fresh;
+    }
+    std::vector<double> u = an->u, v = an->v;
+    const double total = an->total;
+    const bool separable = an->separable && getenv("SVGR_BLUR_DIRECT") == nullptr;
     hipError_t e = hipSuccess;
     if (separable && kw <= CONV_TAPS && kh <= CONV_TAPS && rows + kw - 1 <= 65535) {  // (the row index rides in gridDim.y)
         for (auto& x : u) x /= total;  // K = (u / S) v^T

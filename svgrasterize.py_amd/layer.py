@@ -155,8 +155,12 @@ class Layer:
         if ops == 0:
             return self
         ctx = _abi.Context.get()
-        buf = self._copy_device()
-        _abi._check(ctx.lib.svgr_layer_convert(ctx.handle, buf.handle, self._shape[0] * self._shape[1], ops))
+        if self._host is not None:
+            buf = self._copy_device()
+            _abi._check(ctx.lib.svgr_layer_convert(ctx.handle, buf.handle, self._shape[0] * self._shape[1], ops))
+        else:   # (device-resident: converted straight into the new layer's buffer, no copy in front of an in-place pass)
+            buf = ctx.alloc(int(np.prod(self._shape)) * 8)
+            _abi._check(ctx.lib.svgr_layer_convert_to(ctx.handle, buf.handle, self._dev.handle, self._shape[0] * self._shape[1], ops))
         return Layer._from_device(buf, self._shape, self.offset, pre_alpha, linear_rgb)
 
     # -- Layer.background  S:166-169 -------------------------------------------------------
@@ -183,8 +187,12 @@ class Layer:
     def opacity(self, opacity: float, linear_rgb: bool = False) -> "Layer":
         layer = self.convert(pre_alpha=True, linear_rgb=linear_rgb)
         ctx = _abi.Context.get()
-        buf = layer._copy_device()
-        _abi._check(ctx.lib.svgr_layer_scale(ctx.handle, buf.handle, int(np.prod(layer._shape)), float(opacity)))
+        if layer._host is not None:
+            buf = layer._copy_device()
+            _abi._check(ctx.lib.svgr_layer_scale(ctx.handle, buf.handle, int(np.prod(layer._shape)), float(opacity)))
+        else:
+            buf = ctx.alloc(int(np.prod(layer._shape)) * 8)
+            _abi._check(ctx.lib.svgr_layer_scale_to(ctx.handle, buf.handle, layer._dev.handle, int(np.prod(layer._shape)), float(opacity)))
         return Layer._from_device(buf, layer._shape, layer.offset, True, linear_rgb)
 
     # -- Layer.convolve  S:106-118 ---------------------------------------------------------
