@@ -67,6 +67,9 @@ typedef struct svgr_batch svgr_batch;
 #define SVGR_OUT_MASKS_F64 4   /* every path of the batch: its Path.mask (rows_p, cols_p) double, back to back in path order;
                                 * layer p starts at sum_{q<p} rows_q*cols_q doubles (clipped bboxes of svgr_batch_get_bboxes,
                                 * empty ones count 0).  One launch for all the masks a scene needs (clips, gradient fills). */
+#define SVGR_OUT_FILLS_F64 5   /* every path of the batch: its Path.fill layer (rows_p, cols_p, 4) double = mask * paint, back to back in
+                                * path order (layer p starts at 4 * sum_{q<p} rows_q*cols_q doubles): the solid fills a document
+                                * draws node by node (children of filter / mask nodes) in one launch. */
 
 /* flags of svgr_batch_render */
 #define SVGR_RENDER_CLIP01 1u  /* clip RGBA to [0, 1] on store (canvas_merge_at, S:326) */

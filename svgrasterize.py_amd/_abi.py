@@ -16,7 +16,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libsvgr_hip.so")
 
-OUT_CANVAS_F32, OUT_CANVAS_F64, OUT_MASK_F64, OUT_FILL_F64, OUT_MASKS_F64 = 0, 1, 2, 3, 4
+OUT_CANVAS_F32, OUT_CANVAS_F64, OUT_MASK_F64, OUT_FILL_F64, OUT_MASKS_F64, OUT_FILLS_F64 = 0, 1, 2, 3, 4, 5
 RENDER_CLIP01, RENDER_TIMED, RENDER_DETERMINISTIC, RENDER_SAME_GEOMETRY = 1, 2, 4, 8
 SEG_LINE, SEG_CUBIC = 0, 1
 
@@ -394,6 +394,16 @@ class Batch:
         offs = np.concatenate([[0], np.cumsum(area)]).astype(np.int64)
         buf = self.ctx.alloc(max(int(offs[-1]) * 8, 8))
         self.render(buf, OUT_MASKS_F64)
+        return buf, offs, bb
+
+    def render_fills(self):
+        """SVGR_OUT_FILLS_F64: Path.fill of every path of the batch (its own solid paint) in one launch.  Returns (buffer,
+        offsets, bboxes): path p's (rows_p, cols_p, 4) doubles start `4 * offsets[p]` doubles into `buffer`."""
+        bb = self.bboxes()
+        area = np.where((bb[:, 2] > 0) & (bb[:, 3] > 0), bb[:, 2].astype(np.int64) * bb[:, 3], 0)
+        offs = np.concatenate([[0], np.cumsum(area)]).astype(np.int64)
+        buf = self.ctx.alloc(max(int(offs[-1]) * 32, 32))
+        self.render(buf, OUT_FILLS_F64)
         return buf, offs, bb
 
     def timings(self):

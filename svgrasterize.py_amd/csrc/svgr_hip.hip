@@ -4933,9 +4933,9 @@ int svgr_batch_render_window(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
 static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags, const int32_t* window) {
     if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
     if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan must run before svgr_batch_render");
-    if (out_kind < 0 || out_kind > 4) return fail(SVGR_E_INVALID, "unknown output kind %d", out_kind);
-    const bool layers = out_kind == SVGR_OUT_MASKS_F64;  // one mask per path, back to back
-    if (layers) out_kind = SVGR_OUT_MASK_F64;
+    if (out_kind < 0 || out_kind > 5) return fail(SVGR_E_INVALID, "unknown output kind %d", out_kind);
+    const bool layers = out_kind == SVGR_OUT_MASKS_F64 || out_kind == SVGR_OUT_FILLS_F64;  // one mask / fill layer per path, back to back
+    if (layers) out_kind = out_kind == SVGR_OUT_MASKS_F64 ? SVGR_OUT_MASK_F64 : SVGR_OUT_FILL_F64;
     const bool single = out_kind >= 2;
     if (single && !layers && b->n_paths != 1) return fail(SVGR_E_INVALID, "mask/fill outputs need a single-path batch");
     if (single && (b->n_groups > 0 || b->n_grads > 0)) return fail(SVGR_E_INVALID, "isolated groups and gradient paints exist in the canvas outputs only");
@@ -4967,7 +4967,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
             const long long r = b->host_bbox[4 * (size_t)p + 2], c = b->host_bbox[4 * (size_t)p + 3];
             if (r > 0 && c > 0) at += r * c;
         }
-        need = (size_t)at * sizeof(double);
+        need = (size_t)at * sizeof(double) * (out_kind == SVGR_OUT_FILL_F64 ? 4 : 1);
         if (int rc = b->layer_off.ensure((size_t)b->n_paths)) return rc;
         HIPCHK(hipMemcpyAsync(b->layer_off.p, b->host_layer_off.data(), sizeof(long long) * (size_t)b->n_paths, hipMemcpyHostToDevice, st));
         HIPCHK(b->note_upload(st));  // (the source is a member: svgr_batch_destroy waits for it)

@@ -458,8 +458,11 @@ class Path:
                 return None
             ctx, batch, bb = res
             rows, cols = int(bb[2]), int(bb[3])
-            buf = ctx.alloc(rows * cols * 32)
-            batch.render(buf, _abi.OUT_FILL_F64)
+            if isinstance(batch, FillView):   # (one of the document's node-by-node fills: they share a batch and ONE launch per render)
+                buf = batch.layer_buffer()
+            else:
+                buf = ctx.alloc(rows * cols * 32)
+                batch.render(buf, _abi.OUT_FILL_F64)
             layer = Layer._from_device(buf, (rows, cols, 4), _offset(bb, viewport), pre_alpha=True, linear_rgb=linear_rgb)
             return layer, ConvexHull(_source=lambda: batch.all_edges()[0])
         from .paint import gradient_fill, is_gradient  # noqa: PLC0415
@@ -628,12 +631,69 @@ def fill_plan_key(path, transform, fill_rule, paint4, viewport):
     return (id(path), transform.key(), fill_rule, paint4.tobytes(), None if viewport is None else tuple(int(v) for v in viewport))
 
 
+RENDER_SERIAL = [0]   # counts top-level Scene.render calls (scene.py): the shared fills are drawn once per render
+_SHARE_FILLS = __import__("os").environ.get("SVGR_NO_SHARED_FILLS") is None
+
+
+class _FillSet:
+    """The solid fills a document draws node by node (children of filter / mask / bbox-clip nodes), in ONE batch: one plan,
+    and per render one geometry pass and one tile launch that writes every fill's layer (SVGR_OUT_FILLS_F64)."""
+
+    __slots__ = ("batch", "refs", "serial", "buf", "offs", "_edges")
+
+    def __init__(self, batch, refs):
+        self.batch, self.refs, self.serial, self.buf, self.offs, self._edges = batch, refs, -1, None, None, None
+
+    def draw(self):
+        if self.serial != RENDER_SERIAL[0] or self.buf is None:
+            self.buf, self.offs, _bb = self.batch.render_fills()   # (a fresh buffer: the layers of the last render may still be in use)
+            self.serial = RENDER_SERIAL[0]
+        return self.buf, self.offs
+
+    def all_edges(self):
+        if self._edges is None:
+            self._edges = self.batch.all_edges()
+        return self._edges
+
+
+class FillView:
+    """One fill of a `_FillSet`: what `Path.fill` holds in the place of the fill's own batch."""
+
+    __slots__ = ("fills", "index", "rows", "cols", "dead")
+
+    def __init__(self, fills, index):
+        self.fills, self.index, self.rows, self.cols, self.dead = fills, index, 0, 0, False
+
+    def layer_buffer(self):
+        buf, offs = self.fills.draw()
+        view = buf.ctx.wrap(buf.ptr + int(offs[self.index]) * 32, self.rows * self.cols * 32)
+        view._parent = buf   # (the view does not own the memory)
+        return view
+
+    def all_edges(self):
+        e, ep = self.fills.all_edges()
+        mine = ep == self.index
+        return e[mine], ep[mine] * 0
+
+    def bboxes(self):
+        return self.fills.batch.bboxes()[self.index:self.index + 1]
+
+    def destroy(self):
+        if not self.dead:
+            self.dead = True
+            self.fills.refs -= 1
+            if self.fills.refs <= 0:
+                self.fills.batch.destroy()
+
+
 def plan_fills(jobs, viewport):
-    """[(path, transform, rule, converted paint)] -> ({key: [ctx, batch, None]}, [batches]): the single-path batches
-    `Path.fill` would build, unplanned.  `finish_fill_plans` turns the entries into what `_single_batch` returns."""
+    """[(path, transform, rule, converted paint)] -> ({key: [ctx, batch or FillView, None]}, [batches to plan]): what
+    `Path.fill` would build, unplanned -- one batch for all of them (two or more), each fill a `FillView` of it.
+    `finish_fill_plans` turns the entries into what `_single_batch` returns."""
     plans, batches = {}, []
     ctx = _abi.Context.get()
     vp = None if viewport is None else [int(v) for v in viewport]
+    todo = []
     for path, transform, rule, paint4 in jobs:
         key = fill_plan_key(path, transform, rule, paint4, viewport)
         if key in plans or rule not in _RULES:
@@ -641,20 +701,51 @@ def plan_fills(jobs, viewport):
         segs, kinds = path.packed()
         if len(segs) == 0:
             continue
-        batch = _abi.Batch(ctx, segs, kinds, [0, len(segs)], transform.m6(), [_RULES[rule]], [paint4], viewport=vp, flatness=FLATNESS)
-        plans[key] = [ctx, batch, None]
+        plans[key] = None
+        todo.append((key, segs, kinds, transform.m6(), _RULES[rule], paint4))
+    if len(todo) >= 2 and _SHARE_FILLS and vp is not None:
+        offs = [0]
+        for t in todo:
+            offs.append(offs[-1] + len(t[1]))
+        batch = _abi.Batch(ctx, np.concatenate([t[1] for t in todo]), np.concatenate([t[2] for t in todo]), offs,
+                           np.array([t[3] for t in todo]), [t[4] for t in todo], np.array([t[5] for t in todo]), viewport=vp, flatness=FLATNESS)
+        fills = _FillSet(batch, len(todo))
+        for i, t in enumerate(todo):
+            plans[t[0]] = [ctx, FillView(fills, i), None]
         batches.append(batch)
+    else:
+        for key, segs, kinds, m6, rule, paint4 in todo:
+            batch = _abi.Batch(ctx, segs, kinds, [0, len(segs)], m6, [rule], [paint4], viewport=vp, flatness=FLATNESS)
+            plans[key] = [ctx, batch, None]
+            batches.append(batch)
     return plans, batches
 
 
 def finish_fill_plans(plans):
+    shared_bb, too_big = {}, set()
     for key, entry in list(plans.items()):
         ctx, batch, _ = entry
-        bb = batch.bboxes()[0]
+        if isinstance(batch, FillView):
+            fs = batch.fills
+            if id(fs) not in shared_bb:
+                bb_all = fs.batch.bboxes()
+                shared_bb[id(fs)] = bb_all
+                area = np.where((bb_all[:, 2] > 0) & (bb_all[:, 3] > 0), bb_all[:, 2].astype(np.int64) * bb_all[:, 3], 0)
+                if int(area.sum()) * 32 > (1 << 32):   # more than 4 GiB of fill layers at once: each fill for itself, on demand
+                    too_big.add(id(fs))
+            if id(fs) in too_big:
+                batch.destroy()
+                del plans[key]
+                continue
+            bb = shared_bb[id(fs)][batch.index]
+        else:
+            bb = batch.bboxes()[0]
         if bb[2] <= 0 or bb[3] <= 0:
             batch.destroy()
             plans[key] = None
         else:
+            if isinstance(batch, FillView):
+                batch.rows, batch.cols = int(bb[2]), int(bb[3])
             plans[key] = (ctx, batch, bb)
     return plans
 

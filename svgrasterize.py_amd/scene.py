@@ -211,6 +211,7 @@ class Scene(tuple):
         _LEAF_MEMO = st.leaf_memo
         _RETAIN = st if _RETAINED_MAX > 0 else None
         _RENDER_SERIAL[0] += 1
+        geometry.RENDER_SERIAL[0] = _RENDER_SERIAL[0]
         # the walk allocates thousands of short-lived tuples and no cycles: the cyclic collector's generation-0 sweeps find
         # nothing and cost 0.5-2.5 ms of a 17 ms render (profiles/gc_experiment.py), so it pauses for the call
         gc_paused = _PAUSE_GC and gc.isenabled()

@@ -311,3 +311,44 @@ def test_gpu_runs_sharing_one_batch_draw_what_their_own_batches_draw(name, tag, 
         assert h1.shape == h2.shape and float(np.abs(h1 - h2).max(initial=0.0)) <= 1e-9   # (hull points: moved down and back)
     if name == "icons":
         assert sm.MERGE_STATS["runs_sharing"] - before["runs_sharing"] >= 10, sm.MERGE_STATS
+
+
+@pytest.mark.gpu
+def test_gpu_node_by_node_fills_sharing_one_batch_draw_what_their_own_batches_draw(monkeypatch):
+    """The solid fills icons.svg draws node by node (children of its filter nodes) share one batch and one launch per render
+    (SVGR_OUT_FILLS_F64): the picture is the one their single-path batches give (positions unchanged: to the order of the
+    LDS atomics), on the first and on the retained render; and there were such fills."""
+    import svgrasterize_amd as S
+    from svgrasterize_amd import geometry as gm, scenedump
+
+    scene, info, _z = scenedump.load_scene(os.path.join(GOLDEN, "scene_icons.npz"))
+    r = info["renders"][0]
+    hh, ww = r["size"]
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0).scale(r["scale"])
+    seen = {"views": 0}
+    orig = gm.FillView.layer_buffer
+
+    def layer_buffer(self):
+        seen["views"] += 1
+        return orig(self)
+
+    monkeypatch.setattr(gm.FillView, "layer_buffer", layer_buffer)
+
+    def draw():
+        S.clear_render_cache()
+        out = []
+        for _ in range(2):
+            layer, _hull = scene.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
+            out.append(([int(v) for v in layer.offset], np.array(layer.image)))
+        S.clear_render_cache()
+        return out
+
+    monkeypatch.setattr(gm, "_SHARE_FILLS", False)
+    alone = draw()
+    assert seen["views"] == 0
+    monkeypatch.setattr(gm, "_SHARE_FILLS", True)
+    shared = draw()
+    assert seen["views"] >= 10, seen
+    for (o1, a), (o2, b) in zip(alone, shared):
+        assert o1 == o2 and a.shape == b.shape
+        assert float(np.abs(a - b).max(initial=0.0)) <= 1e-12
