@@ -30,8 +30,9 @@ extern "C" {
 #endif
 
 /* 2: svgr_batch_set_groups, svgr_batch_set_gradients, svgr_batch_plan_many, svgr_batch_render_window added; svgr_gradient.n_stops
- *    no longer capped at 32; SVGR_RENDER_DETERMINISTIC */
-#define SVGR_ABI_VERSION 2
+ *    no longer capped at 32; SVGR_RENDER_DETERMINISTIC
+ * 3: SVGR_RENDER_SAME_GEOMETRY, SVGR_OUT_FILLS_F64, svgr_layer_convert_to, svgr_layer_scale_to added (nothing changed or removed) */
+#define SVGR_ABI_VERSION 3
 
 typedef enum {
     SVGR_OK = 0,
