@@ -31,7 +31,8 @@ extern "C" {
 
 /* 2: svgr_batch_set_groups, svgr_batch_set_gradients, svgr_batch_plan_many, svgr_batch_render_window added; svgr_gradient.n_stops
  *    no longer capped at 32; SVGR_RENDER_DETERMINISTIC
- * 3: SVGR_RENDER_SAME_GEOMETRY, SVGR_OUT_FILLS_F64, svgr_layer_convert_to, svgr_layer_scale_to added (nothing changed or removed) */
+ * 3: SVGR_RENDER_SAME_GEOMETRY, SVGR_OUT_FILLS_F64, svgr_layer_convert_to, svgr_layer_scale_to, svgr_batch_render_windows added
+ *    (nothing changed or removed) */
 #define SVGR_ABI_VERSION 3
 
 typedef enum {
@@ -201,6 +202,12 @@ int64_t svgr_batch_owned_rows(const svgr_batch* batch);
  * a run of fills covers the union of their bboxes, not the viewport (canvas_merge_union, S:366-379).  The pixels are
  * those svgr_batch_render writes at the same positions, bit for bit.  Canvas outputs, unsharded batches.            */
 int svgr_batch_render_window(svgr_batch* batch, svgr_buf* out, int out_kind, unsigned flags, const int32_t* window);
+/* n windows of the same picture -- `windows` = n x {row0, col0, rows, cols}, outs[i] holds window i -- from ONE geometry pass,
+ * drawn side by side: a window of a few dozen tiles takes as long as its heaviest tile, and a document's runs of fills are
+ * dozens of such windows.  Everything enqueued on the context's stream before the call is in front of the windows, everything
+ * enqueued after it behind them.  Canvas outputs, unsharded batches; not with SVGR_RENDER_TIMED / _DETERMINISTIC. */
+int svgr_batch_render_windows(svgr_batch* batch, int64_t n, svgr_buf* const* outs, int out_kind, unsigned flags,
+                              const int32_t* windows);
 
 /* HIP-event timings accumulated over the SVGR_RENDER_TIMED renders since the last call
  * (synchronises).  ms_geometry = transform/flatten/bbox/binning kernels, ms_tile = the tile

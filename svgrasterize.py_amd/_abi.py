@@ -98,6 +98,7 @@ _PROTOS = {
     "svgr_batch_all_edges": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "svgr_batch_render": (C.c_int, [_P, _P, C.c_int, C.c_uint]),
     "svgr_batch_render_window": (C.c_int, [_P, _P, C.c_int, C.c_uint, _P]),
+    "svgr_batch_render_windows": (C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_uint, _P]),
     "svgr_batch_plan_many": (C.c_int, [_P, C.c_int64]),
     "svgr_batch_owned_rows": (C.c_int64, [_P]),
     "svgr_batch_timings": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -385,6 +386,15 @@ class Batch:
         else:
             w = (C.c_int32 * 4)(*[int(v) for v in window])
             _check(self.ctx.lib.svgr_batch_render_window(self.handle, out.handle, kind, flags, w))
+
+    def render_windows(self, outs, kind: int, windows, flags: int = 0):
+        """svgr_batch_render_windows: `windows[i]` (row0, col0, rows, cols) into `outs[i]`, all from one geometry pass, side by side."""
+        n = len(outs)
+        if n == 0:
+            return
+        arr = (_P * n)(*[o.handle for o in outs])
+        w = (C.c_int32 * (4 * n))(*[int(v) for win in windows for v in win])
+        _check(self.ctx.lib.svgr_batch_render_windows(self.handle, n, arr, kind, flags, w))
 
     def render_masks(self):
         """SVGR_OUT_MASKS_F64: Path.mask of every path of the batch in one launch.  Returns (buffer, offsets, bboxes):

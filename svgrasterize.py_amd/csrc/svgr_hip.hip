@@ -209,6 +209,13 @@ struct svgr_ctx {
     void* trash = nullptr;       // 1 KiB of device memory nobody reads (TileArgs::trash)
     unsigned* tile_ctr = nullptr;  // two sets of eight tile counters (TileArgs::tile_ctr), used alternately by the launches of this stream
     int tile_ctr_set = 0;
+    // svgr_batch_render_windows: the windows of one picture are drawn side by side -- each is a launch of a few dozen workgroups
+    // whose duration is its heaviest tile's -- on streams of their own, between two events of the context's stream
+    static constexpr int N_SIDE = 8;
+    hipStream_t side[N_SIDE] = {};
+    hipEvent_t side_ev[N_SIDE] = {};
+    hipEvent_t fork_ev = nullptr;
+    bool side_ready = false;
 };
 // the context whose call is running on this thread (set by enter_ctx at the top of every entry point): the block cache
 // files what is allocated and released under it
@@ -4078,6 +4085,11 @@ int svgr_shutdown(svgr_ctx* ctx) {
     (void)enter_ctx(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (int k = 0; k < svgr_ctx::N_SIDE; ++k) {
+        if (ctx->side[k]) { (void)hipStreamSynchronize(ctx->side[k]); (void)hipStreamDestroy(ctx->side[k]); }
+        if (ctx->side_ev[k]) (void)hipEventDestroy(ctx->side_ev[k]);
+    }
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->trash) (void)hipFree(ctx->trash);
     if (ctx->tile_ctr) (void)hipFree(ctx->tile_ctr);
@@ -4919,7 +4931,9 @@ static int get_event(svgr_batch* b, hipEvent_t* e) {
     return 0;
 }
 
-static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags, const int32_t* window);
+// phase 0: geometry (unless it is current) and the tile launch; 1: the geometry part alone; 2: the tile launch alone, on `tile_st`
+static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags, const int32_t* window, int phase = 0,
+                             hipStream_t tile_st = nullptr);
 int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags) {
     return abi_guard("svgr_batch_render", [&]() { return batch_render_impl(b, out, out_kind, flags, nullptr); });
 }
@@ -4930,7 +4944,42 @@ int svgr_batch_render_window(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
     });
 }
 
-static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags, const int32_t* window) {
+int svgr_batch_render_windows(svgr_batch* b, int64_t n, svgr_buf* const* outs, int out_kind, unsigned flags, const int32_t* windows) {
+    return abi_guard("svgr_batch_render_windows", [&]() {
+        if (!b || n < 0 || (n > 0 && (!outs || !windows))) return fail(SVGR_E_INVALID, "bad arguments");
+        if (n == 0) return 0;
+        for (int64_t i = 0; i < n; ++i)
+            if (!outs[i]) return fail(SVGR_E_INVALID, "output %lld is NULL", (long long)i);
+        if (flags & (SVGR_RENDER_TIMED | SVGR_RENDER_DETERMINISTIC)) return fail(SVGR_E_INVALID, "timed / deterministic renders draw one window at a time");
+        svgr_ctx* c = b->ctx;
+        HIPCHK(enter_ctx(c));
+        if (!c->side_ready) {
+            for (int k = 0; k < svgr_ctx::N_SIDE; ++k) {
+                if (!c->side[k]) HIPCHK(hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking));
+                if (!c->side_ev[k]) HIPCHK(hipEventCreateWithFlags(&c->side_ev[k], hipEventDisableTiming));
+            }
+            if (!c->fork_ev) HIPCHK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+            c->side_ready = true;
+        }
+        // the geometry kernels (unless the caller vouches for the previous pass) and the gradients' flags, on the context's stream
+        if (int rc = batch_render_impl(b, outs[0], out_kind, flags, windows, 1)) return rc;
+        const int used = (int)std::min<int64_t>(n, svgr_ctx::N_SIDE);
+        HIPCHK(hipEventRecord(c->fork_ev, c->stream));
+        for (int k = 0; k < used; ++k) HIPCHK(hipStreamWaitEvent(c->side[k], c->fork_ev, 0));
+        // (everything the context's stream did before -- also the last use of a recycled output block -- is in front of the windows)
+        int rc = 0;
+        for (int64_t i = 0; i < n && rc == 0; ++i)
+            rc = batch_render_impl(b, outs[i], out_kind, flags, windows + 4 * i, 2, c->side[i % svgr_ctx::N_SIDE]);
+        // ... and the windows in front of everything it does next, whether all of them were launched or not
+        for (int k = 0; k < used; ++k) {
+            HIPCHK(hipEventRecord(c->side_ev[k], c->side[k]));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->side_ev[k], 0));
+        }
+        return rc;
+    });
+}
+
+static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags, const int32_t* window, int phase, hipStream_t tile_st) {
     if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
     if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan must run before svgr_batch_render");
     if (out_kind < 0 || out_kind > 5) return fail(SVGR_E_INVALID, "unknown output kind %d", out_kind);
@@ -4995,7 +5044,8 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
     const bool det = (flags & SVGR_RENDER_DETERMINISTIC) != 0;
     // (SVGR_RENDER_SAME_GEOMETRY: another window of the canvas the previous render of this batch drew a window of -- the tile
     //  kernel only reads what the geometry kernels left, so the pass is not repeated; ignored when an input has changed since)
-    const bool same = (flags & SVGR_RENDER_SAME_GEOMETRY) != 0 && b->geometry_current && window != nullptr && !timed && !det;
+    if (phase == 2 && !b->geometry_current) return fail(SVGR_E_STATE, "a tile launch without its geometry pass");
+    const bool same = phase == 2 || ((flags & SVGR_RENDER_SAME_GEOMETRY) != 0 && b->geometry_current && window != nullptr && !timed && !det);
     if (!(b->geometry_fresh && !timed && !det) && !same) {
         b->deterministic = det;
         b->geometry_current = false;
@@ -5022,6 +5072,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
             hipLaunchKernelGGL(k_grad_detneg, dim3(64, (unsigned)b->n_grads), dim3(256), 0, st, (const GradDev*)b->grads.p,
                                (const int*)b->grad_path.p, (const int*)b->bbox.p, b->grad_flags.p);
         }
+        if (phase == 1) return 0;   // (the geometry kernels and the gradients' flags are on the stream: the windows follow)
         a.vr0 = b->vp[0]; a.vc0 = b->vp[1]; a.vrows = b->vp[2]; a.vcols = b->vp[3];
         a.own = b->own;
         a.out_cols = win[3];
@@ -5087,22 +5138,23 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
             a.tile_ctr_clear = b->ctx->tile_ctr + 256 * b->ctx->tile_ctr_set;
         }
         dim3 grid(n_wgs);
+        hipStream_t lst = tile_st ? tile_st : st;   // (svgr_batch_render_windows: a stream per window)
         static const int dyn_lds = getenv("SVGR_DBG_DYNLDS") ? atoi(getenv("SVGR_DBG_DYNLDS")) : 0;  // occupancy experiments
         switch (out_kind) {
             case 0:
-                if (b->n_grads > 0) hipLaunchKernelGGL((k_tile_render<0, true, true, true>), grid, dim3(NT), 0, st, a);
-                else if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render<0, true, true>), grid, dim3(NT), 0, st, a);
-                else if (b->has_clips) hipLaunchKernelGGL((k_tile_render<0, true>), grid, dim3(NT), 0, st, a);
-                else hipLaunchKernelGGL((k_tile_render<0, false>), grid, dim3(NT), dyn_lds, st, a);
+                if (b->n_grads > 0) hipLaunchKernelGGL((k_tile_render<0, true, true, true>), grid, dim3(NT), 0, lst, a);
+                else if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render<0, true, true>), grid, dim3(NT), 0, lst, a);
+                else if (b->has_clips) hipLaunchKernelGGL((k_tile_render<0, true>), grid, dim3(NT), 0, lst, a);
+                else hipLaunchKernelGGL((k_tile_render<0, false>), grid, dim3(NT), dyn_lds, lst, a);
                 break;
             case 1:
-                if (b->n_grads > 0) hipLaunchKernelGGL((k_tile_render<1, true, true, true>), grid, dim3(NT), 0, st, a);
-                else if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render<1, true, true>), grid, dim3(NT), 0, st, a);
-                else if (b->has_clips) hipLaunchKernelGGL((k_tile_render<1, true>), grid, dim3(NT), 0, st, a);
-                else hipLaunchKernelGGL((k_tile_render<1, false>), grid, dim3(NT), 0, st, a);
+                if (b->n_grads > 0) hipLaunchKernelGGL((k_tile_render<1, true, true, true>), grid, dim3(NT), 0, lst, a);
+                else if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render<1, true, true>), grid, dim3(NT), 0, lst, a);
+                else if (b->has_clips) hipLaunchKernelGGL((k_tile_render<1, true>), grid, dim3(NT), 0, lst, a);
+                else hipLaunchKernelGGL((k_tile_render<1, false>), grid, dim3(NT), 0, lst, a);
                 break;
-            case 2: hipLaunchKernelGGL(k_tile_render<2>, grid, dim3(NT), 0, st, a); break;
-            default: hipLaunchKernelGGL(k_tile_render<3>, grid, dim3(NT), 0, st, a); break;
+            case 2: hipLaunchKernelGGL(k_tile_render<2>, grid, dim3(NT), 0, lst, a); break;
+            default: hipLaunchKernelGGL(k_tile_render<3>, grid, dim3(NT), 0, lst, a); break;
         }
         b->arena_zeroed = true;  // (done by that kernel, see TileArgs::arena)
     }

@@ -231,6 +231,7 @@ class Scene(tuple):
                 geometry.MASK_PREFETCH = geometry.MaskPrefetch(st.jobs, viewport, st.mask_state if _RETAIN is not None else None)
             _RUN_PLANS, geometry.FILL_PLANS = st.run_plans, st.fill_plans
             geometry.FILL_PLANS_KEEP = _RETAIN is not None
+            _prefetch_windows(st.run_plans)
             res = self._render(transform, mask_only, viewport, linear_rgb)
             ok = True
             return res
@@ -437,10 +438,11 @@ class _RunView:
     """A run's part of a shared batch: the paths [lo, hi) and the rows its geometry was moved down by.  Quacks like the
     batch `_render_run` used to hold for the run alone."""
 
-    __slots__ = ("shared", "lo", "hi", "shift", "vrows", "dead")
+    __slots__ = ("shared", "lo", "hi", "shift", "vrows", "dead", "ready")
 
     def __init__(self, shared, lo, hi, shift, vrows):
         self.shared, self.lo, self.hi, self.shift, self.vrows, self.dead = shared, lo, hi, shift, vrows, False
+        self.ready = None   # (render serial, buffer): the run's window as `_prefetch_windows` drew it for this render
 
     def bboxes(self):
         """The run's bboxes in the viewport's own rows, clipped to them (the shared canvas is taller than the viewport)."""
@@ -889,19 +891,9 @@ def _render_run(leaves, viewport, linear_rgb):
         if _RETAIN is not None and rkey is not None:
             pre = _RUN_PLANS[rkey] = [leaves, batch]
     if pre is not None and len(pre) > 2:
-        win, in_hull = pre[2], pre[3]   # (a retained run: its window and hull membership were worked out by the first render)
+        win, in_hull = pre[2], pre[3]   # (its window and hull membership were worked out by the pre-pass or by the first render)
     else:
-        eff = effective_bboxes(leaves, batch.bboxes())
-        boxes = [b for b in eff if b is not None]
-        win = None
-        if boxes:
-            ur0, uc0 = min(b[0] for b in boxes), min(b[1] for b in boxes)
-            win = (ur0, uc0, max(b[0] + b[2] for b in boxes) - ur0, max(b[1] + b[3] for b in boxes) - uc0)
-        # The group's hull merges the hulls of the children that drew something (S:676-684): a leaf whose clipped bbox is
-        # empty returned None there and does not count; one that is partly visible counts with ALL its lines (S:993).  Clip
-        # paths do not belong to it (S:715 returns the target's hull).
-        in_hull = np.zeros(len(leaves), dtype=bool)
-        in_hull[[i for i, leaf in enumerate(leaves) if leaf[4] != 1]] = [b is not None for b in eff]  # (clip sources: no part of it)
+        win, in_hull = _run_window(leaves, batch)
         if pre is not None and _RETAIN is not None:
             if len(pre) == 2:
                 pre = _RUN_PLANS[rkey] = [pre[0], pre[1], win, in_hull]
@@ -913,8 +905,12 @@ def _render_run(leaves, viewport, linear_rgb):
     # only the union of the leaves' bboxes is rendered (a render window of the batch's canvas): the tiles outside it are
     # not touched, and the layer needs no crop
     shape = (urows, ucols, 4)
-    out = ctx.alloc(urows * ucols * 32)
-    batch.render(out, _abi.OUT_CANVAS_F64, window=(ur0, uc0, urows, ucols))
+    ready = getattr(batch, "ready", None)
+    if ready is not None and ready[0] == _RENDER_SERIAL[0]:
+        out, batch.ready = ready[1], None   # (drawn by `_prefetch_windows` together with the document's other runs)
+    else:
+        out = ctx.alloc(urows * ucols * 32)
+        batch.render(out, _abi.OUT_CANVAS_F64, window=(ur0, uc0, urows, ucols))
     layer = Layer._from_device(out, shape, (ur0, uc0), True, linear_rgb)
 
     def hull_points():
@@ -922,6 +918,62 @@ def _render_run(leaves, viewport, linear_rgb):
         return edges[in_hull[edge_path]]
 
     return layer, ConvexHull(_source=hull_points)
+
+
+def _run_window(leaves, batch):
+    """(window, hull membership) of a planned run: the union of its leaves' effective bboxes (None: nothing to draw)."""
+    eff = effective_bboxes(leaves, batch.bboxes())
+    boxes = [b for b in eff if b is not None]
+    win = None
+    if boxes:
+        ur0, uc0 = min(b[0] for b in boxes), min(b[1] for b in boxes)
+        win = (ur0, uc0, max(b[0] + b[2] for b in boxes) - ur0, max(b[1] + b[3] for b in boxes) - uc0)
+    # The group's hull merges the hulls of the children that drew something (S:676-684): a leaf whose clipped bbox is
+    # empty returned None there and does not count; one that is partly visible counts with ALL its lines (S:993).  Clip
+    # paths do not belong to it (S:715 returns the target's hull).
+    in_hull = np.zeros(len(leaves), dtype=bool)
+    in_hull[[i for i, leaf in enumerate(leaves) if leaf[4] != 1]] = [b is not None for b in eff]  # (clip sources: no part of it)
+    return win, in_hull
+
+
+# (off by default: it takes 0.85 ms of GPU time off an icons.svg render -- 30 window launches 1.59 -> 0.73 ms, four hardware queues
+#  deep -- but the render is bound by the host's walk and its 800 library calls, and there the up-front launches cost 0.1-0.2 ms)
+_PREFETCH_WINDOWS = __import__("os").environ.get("SVGR_WINDOW_PREFETCH") is not None
+_PREFETCH_MAX_BYTES = 4 << 30   # of run layers drawn ahead of the walk; beyond it the runs are drawn when the walk meets them
+
+
+def _prefetch_windows(run_plans):
+    """Draw the windows of all the runs that share a batch NOW, side by side (svgr_batch_render_windows): a run's window is a
+    launch of a few dozen workgroups that lasts as long as its heaviest tile -- icons.svg: 30 launches, 1.6 ms one after the
+    other, the longest alone 0.23 --, and no run depends on anything the walk produces.  `_render_run` hands the layers out."""
+    if not _PREFETCH_WINDOWS or not run_plans:
+        return
+    ctx = _abi.Context.get()
+    by_batch: dict = {}
+    total = 0
+    for entry in run_plans.values():
+        view = entry[1]
+        if not isinstance(view, _RunView) or view.dead:
+            continue
+        if len(entry) == 2:
+            entry.extend(_run_window(entry[0], view))
+        win = entry[2]
+        if win is None:
+            continue
+        total += int(win[2]) * int(win[3]) * 32
+        by_batch.setdefault(id(view.shared), (view.shared, []))[1].append((view, win))
+    if total > _PREFETCH_MAX_BYTES:
+        return
+    serial = _RENDER_SERIAL[0]
+    for shared, items in by_batch.values():
+        if len(items) < 2:
+            continue
+        outs = [ctx.alloc(int(w[2]) * int(w[3]) * 32) for _v, w in items]
+        wins = [(w[0] + v.shift, w[1], w[2], w[3]) for v, w in items]
+        shared.batch.render_windows(outs, _abi.OUT_CANVAS_F64, wins, _abi.RENDER_SAME_GEOMETRY if shared.serial == serial else 0)
+        shared.serial = serial
+        for (v, _w), out in zip(items, outs):
+            v.ready = (serial, out)
 
 
 def _drop_empty(leaves):

@@ -352,3 +352,45 @@ def test_gpu_node_by_node_fills_sharing_one_batch_draw_what_their_own_batches_dr
     for (o1, a), (o2, b) in zip(alone, shared):
         assert o1 == o2 and a.shape == b.shape
         assert float(np.abs(a - b).max(initial=0.0)) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_run_windows_drawn_side_by_side_are_the_windows_drawn_one_by_one(monkeypatch):
+    """svgr_batch_render_windows (the runs' windows of one render on streams of their own, between two events of the context's
+    stream; `SVGR_WINDOW_PREFETCH`): the same layers as one svgr_batch_render_window after the other, twice in a row."""
+    import svgrasterize_amd as S
+    from svgrasterize_amd import _abi, scenedump
+    from svgrasterize_amd import scene as sm
+
+    scene, info, _z = scenedump.load_scene(os.path.join(GOLDEN, "scene_icons.npz"))
+    r = info["renders"][0]
+    hh, ww = r["size"]
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0).scale(r["scale"])
+    seen = {"calls": 0, "windows": 0}
+    orig = _abi.Batch.render_windows
+
+    def render_windows(self, outs, kind, windows, flags=0):
+        seen["calls"] += 1
+        seen["windows"] += len(outs)
+        return orig(self, outs, kind, windows, flags)
+
+    monkeypatch.setattr(_abi.Batch, "render_windows", render_windows)
+
+    def draw():
+        S.clear_render_cache()
+        out = []
+        for _ in range(2):
+            layer, _hull = scene.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
+            out.append(([int(v) for v in layer.offset], np.array(layer.image)))
+        S.clear_render_cache()
+        return out
+
+    monkeypatch.setattr(sm, "_PREFETCH_WINDOWS", False)
+    one_by_one = draw()
+    assert seen["calls"] == 0
+    monkeypatch.setattr(sm, "_PREFETCH_WINDOWS", True)
+    together = draw()
+    assert seen["calls"] >= 2 and seen["windows"] >= 20, seen
+    for (o1, a), (o2, b) in zip(one_by_one, together):
+        assert o1 == o2 and a.shape == b.shape
+        assert float(np.abs(a - b).max(initial=0.0)) <= 1e-12
