@@ -184,10 +184,17 @@ class Context:
         self.device = device
         self._fin = weakref.finalize(self, self.lib.svgr_shutdown, h)
 
+    _default: "Context | None" = None   # the context of $SVGR_DEVICE / $LOCAL_RANK, resolved once (a document render asks 200 times)
+
     @classmethod
     def get(cls, device: int | None = None) -> "Context":
         if device is None:
-            device = int(os.environ.get("SVGR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            ctx = cls._default
+            if ctx is not None:
+                return ctx
+            device = int(os.environ.get("SVGR_DEVICE") or os.environ.get("LOCAL_RANK") or "0")
+            ctx = cls._default = cls.get(device)
+            return ctx
         ctx = cls._by_device.get(device)
         if ctx is None:
             ctx = cls._by_device[device] = Context(device)
