@@ -99,12 +99,6 @@ static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 102
 #ifndef SVGR_X_SCATWAIT
 #define SVGR_X_SCATWAIT 1               // scatter: no compiler-visible load (and so no compiler-placed vmcnt(0)) in front of the adds
 #endif
-#ifndef SVGR_X_RECOMPUTE
-#define SVGR_X_RECOMPUTE 0              // tile kernel: the lane's constants recomputed per item instead of held in registers
-#endif
-#ifndef SVGR_X_ADDEARLY
-#define SVGR_X_ADDEARLY 0               // tile kernel: an iteration's add load issued at its top, beside its header load
-#endif
 #ifndef SVGR_X_CARRY1
 #ifndef SVGR_X_ADD12
 #define SVGR_X_ADD12 0                  // a TileAdd of 12 bytes {value, where} (no padding word): 46 MB less traffic per step, but entries straddle cache lines -- tile kernel +2.5 us, k_path_build -1 us (A/B twice): off
@@ -116,9 +110,6 @@ static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 102
 #define SVGR_X_BLEND2 1                 // the production blend: two pixels per asm statement (one class-1 test for both)
 #endif
 #define SVGR_X_CARRY1 1                 // class-2 cells: the carry-in block of the header neither written (k_path_build) nor fetched (tile kernel)
-#endif
-#ifndef SVGR_X_RUNS
-#define SVGR_X_RUNS 0                   // scatter: the further columns of a run straight-line under v_cmpx instead of a loop
 #endif
 #ifndef SVGR_X_CMPX
 #define SVGR_X_CMPX 1                   // the 1e-6 cut as v_cmpx around the pixel's block instead of a saveexec + branch
@@ -2231,12 +2222,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
     // header of item j of the round: dword `lane` of its CellHdr (lanes 20 .. 51 hold the 16 carry-ins)
     // (past the end of the round: a dummy in `trash` -- every tile makes these loads, also one whose batch has no cell at all)
     auto hdr_ptr = [&](int j) -> const int* {
-#if SVGR_X_RECOMPUTE
-        int ln = tid;
-        asm volatile("" : "+v"(ln));   // (see process)
-        ln &= 63;
-        const int hdr_lane = ln < HDR_LOAD_DWORDS ? ln : HDR_LOAD_DWORDS - 1;
-#endif
         if (j >= n_round) return (const int*)a.trash + hdr_lane;
         const unsigned cw = (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63);
 #if SVGR_X_CARRY1
@@ -2382,44 +2367,10 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
             unsigned off = w & 0xffffu;
             __hip_atomic_fetch_add((double*)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             // a run: the same value into the next `more` columns -- at most PX - 1, all inside the chunk (k_path_build cuts runs there)
-#if SVGR_X_RUNS
-            // ... straight-line: v_cmpx narrows EXEC to the lanes whose run reaches one column further (the sets are nested, so
-            // nothing is restored in between), two instructions per column instead of the seven of a loop trip with its
-            // EXEC bookkeeping; no lane with a run: one branch
-            static_assert(PX == 8, "the unrolled run covers seven further columns");
-            {
-                const unsigned more = (w >> 16) & 63u;
-                const unsigned at = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)(base + off));   // (LDS byte address)
-                unsigned long long keep_;
-                asm volatile(
-                    "s_mov_b64 %[keep], exec\n\t"
-                    "v_cmpx_lt_u32_e32 vcc, 0, %[more]\n\t"
-                    "s_cbranch_execz .Lrun_%=\n\t"
-                    "ds_add_f64 %[at], %[v] offset:8\n\t"
-                    "v_cmpx_lt_u32_e32 vcc, 1, %[more]\n\t"
-                    "ds_add_f64 %[at], %[v] offset:16\n\t"
-                    "v_cmpx_lt_u32_e32 vcc, 2, %[more]\n\t"
-                    "ds_add_f64 %[at], %[v] offset:24\n\t"
-                    "v_cmpx_lt_u32_e32 vcc, 3, %[more]\n\t"
-                    "ds_add_f64 %[at], %[v] offset:32\n\t"
-                    "v_cmpx_lt_u32_e32 vcc, 4, %[more]\n\t"
-                    "ds_add_f64 %[at], %[v] offset:40\n\t"
-                    "v_cmpx_lt_u32_e32 vcc, 5, %[more]\n\t"
-                    "ds_add_f64 %[at], %[v] offset:48\n\t"
-                    "v_cmpx_lt_u32_e32 vcc, 6, %[more]\n\t"
-                    "ds_add_f64 %[at], %[v] offset:56\n"
-                    ".Lrun_%=:\n\t"
-                    "s_mov_b64 exec, %[keep]"
-                    : [keep] "=&s"(keep_)
-                    : [more] "v"(more), [at] "v"(at), [v] "v"(v)
-                    : "vcc", "memory");
-            }
-#else
             for (int more = (int)((w >> 16) & 63u); more > 0; --more) {
                 off += 8u;
                 __hip_atomic_fetch_add((double*)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-#endif
         };
 #if SVGR_X_SCATWAIT
         // The lane's first add is the one the pipeline brought.  Lists longer than the workgroup (rare) load the rest here, issued
@@ -2475,15 +2426,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         const int bits = __builtin_amdgcn_readlane(h, 12);
         const int cls = (bits >> 3) & 3;
         if (cls == 0) return;
-#if SVGR_X_RECOMPUTE
-        // (the lane's coordinates and what hangs on them derived from the thread id again for every item: fewer registers held
-        //  across the loop, a dozen more instructions per item)
-        int tid_p = tid;
-        asm volatile("" : "+v"(tid_p));
-        const int trow = tid_p / CH, chunk = tid_p % CH, lane = tid_p & 63;
-        double* const my0 = (double*)s_mem + trow * ROW_STRIDE + chunk * CHUNK_STRIDE;
-        (void)lane;
-#endif
         const int rule = bits & 1, pflags = (bits >> 1) & 3;
         const double p0 = __hiloint2double(__builtin_amdgcn_readlane(h, 1), __builtin_amdgcn_readlane(h, 0));
         const double p1 = __hiloint2double(__builtin_amdgcn_readlane(h, 3), __builtin_amdgcn_readlane(h, 2));
@@ -3123,16 +3065,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
                 // in hand: the headers of items k, k+1, k+2 and the add of item k+1; the adds of item k are on their way into
                 // delta tile k & 1
                 {
-#if SVGR_X_ADDEARLY
-                    // (both loads of the iteration at its top: the add gets the barrier's and the scatter's time on top of the composite's)
-                    const int* q = hdr_ptr(k + 3);
-                    const void* ap = add_ptr(k + 2);
-                    SVGR_HDR_LOAD(hq, q);
-                    SVGR_ADD_LOAD(wq, vq, ap);
-#else
                     const int* q = hdr_ptr(k + 3);
                     SVGR_HDR_LOAD(hq, q);
-#endif
                 }
                 // behind this barrier: every wave's adds of item k have landed; everybody's scan of item k-1 has zeroed its tile
 #if defined(SVGR_DBG_TIMELINE) && defined(SVGR_DBG_TL_WAITS)
@@ -3143,12 +3077,10 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
                 tl_wb_ += __builtin_readcyclecounter() - cb0_;
 #endif
                 scatter(h_s, w_n, v_n, (k + 1) & 1);
-#if !SVGR_X_ADDEARLY
                 {
                     const void* ap = add_ptr(k + 2);
                     SVGR_ADD_LOAD(wq, vq, ap);
                 }
-#endif
                 process(h_p, k & 1);
                 h_p = h_s; h_s = h_a;
 #if defined(SVGR_DBG_TIMELINE) && defined(SVGR_DBG_TL_WAITS)
