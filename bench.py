@@ -10,7 +10,7 @@ row scan, fill rule, paint, source-over) -> finished float32 RGBA canvas in HBM.
 N = 1: the bench scene (BASELINE.json's metric configuration: 4096 paths @ 4096 x 4096).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling of BASELINE.json's config 4 -- the ONE
-synthetic 10 000-path drawing @ 8192 x 8192, sharded over the N GPUs by interleaved strips of scanlines
+synthetic 10 000-path drawing @ 8192 x 8192, sharded over the N GPUs by strips of scanlines (one per GPU by default)
 (`svgr_batch_set_bands`; every rank culls the geometry to what reaches its strips; edges that cross a strip border are
 simply kept by both owners: duplicated geometry is the halo, no pixel crosses a GPU, no data-path collective).  Total work is
 fixed; `value` = the drawing's path-pixels / the slowest rank's time.  RCCL carries the barrier / max-over-ranks clock and
@@ -479,7 +479,7 @@ def main():
     n_scene_paths = int(len(sc["path_seg_off"]) - 1)
     from svgrasterize_amd import dist as sdist_
 
-    strip = int(os.environ.get("SVGR_STRIP_BANDS", str(sdist_.default_strip_bands(rows, _abi.tile_rows(), world))))  # two strips per rank
+    strip = int(os.environ.get("SVGR_STRIP_BANDS", str(sdist_.default_strip_bands(rows, _abi.tile_rows(), world))))  # one strip per rank
 
     # ---- headline: the ONE scene; N > 1: its rows sharded over the ranks (strong scaling) -----------------------------
     batch = new_batch(sc)
@@ -500,7 +500,7 @@ def main():
     t_max, tm = measure(batch, out)
     config = {
         "workload": desc, "canvas": [rows, cols], "paths": n_scene_paths, "edges": E, "path_pixels": P,
-        "sharding": (f"{world} ranks x interleaved strips of {strip} bands ({strip * _abi.tile_rows()} rows); no data-path collective"
+        "sharding": (f"{world} ranks x strips of {strip} bands ({strip * _abi.tile_rows()} rows); no data-path collective"
                      if world > 1 else "single GPU"),
     }
     scaling = "strong" if world > 1 else "weak"  # (N = 1 is the first point of either series)

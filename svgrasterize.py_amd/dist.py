@@ -17,10 +17,12 @@ def n_bands(rows: int, tile_rows: int) -> int:
 
 
 def default_strip_bands(rows: int, tile_rows: int, world: int) -> int:
-    """Bands per strip when the caller does not choose: two strips per rank (a rank flattens every path that reaches one of
-    its strips, so fewer, taller strips duplicate less geometry; two of them still interleave the ranks over the canvas),
-    never less than 128 scanlines."""
-    return max(max(1, 128 // tile_rows), n_bands(rows, tile_rows) // (2 * max(world, 1)))
+    """Bands per strip when the caller does not choose: ONE strip per rank -- a rank flattens every path that reaches one of its
+    strips completely, so the tallest strips duplicate the least geometry (round 4, emulated on one GPU, config 4: the slowest of
+    8 / 4 / 2 ranks 0.1249 -> 0.1225, 0.1972 -> 0.1925, 0.3551 -> 0.3489 ms against two interleaved strips per rank) --, never
+    less than 128 scanlines.  A drawing whose content is bunched in a few rows wants `SVGR_STRIP_BANDS` smaller."""
+    nb = n_bands(rows, tile_rows)
+    return max(max(1, 128 // tile_rows), -(-nb // max(world, 1)))
 
 
 def owned_bands(rows: int, tile_rows: int, rank: int, world: int, strip: int = 1) -> list[int]:
@@ -55,7 +57,7 @@ def gather_canvas(local, rows: int, tile_rows: int, group=None, strip: int = 1):
 
     Strips are dealt round-robin, so `world` consecutive strips -- one of each rank, in rank order -- are a contiguous run of
     canvas rows: exactly the layout all_gather_into_tensor produces.  Every complete round of strips is therefore gathered
-    STRAIGHT into its rows of the final canvas (one collective per round: two with the default two strips per rank), no
+    STRAIGHT into its rows of the final canvas (one collective per round: one with the default of a strip per rank), no
     staging buffer and no assembly copy; only a ragged tail (a last round in which some rank has a short strip or none) takes
     the padded gather + copy, for its rows alone."""
     import torch

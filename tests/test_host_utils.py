@@ -94,12 +94,13 @@ def test_layer_background(kat):
         assert np.allclose(out.image, z[f"bg{idx}_out"], rtol=0, atol=1e-15)
 
 
-def test_default_strip_bands_two_strips_per_rank():
-    """The bench's sharding default: two interleaved strips per rank, never under 128 scanlines; every band has one owner."""
+def test_default_strip_bands_one_strip_per_rank():
+    """The bench's sharding default: one strip per rank, never under 128 scanlines; every band has one owner."""
     from svgrasterize_amd import dist as sdist
 
-    assert sdist.default_strip_bands(8192, 16, 8) == 32 and sdist.default_strip_bands(8192, 16, 2) == 128
-    assert sdist.default_strip_bands(4096, 16, 8) == 16 and sdist.default_strip_bands(512, 16, 8) == 8
+    assert sdist.default_strip_bands(8192, 16, 8) == 64 and sdist.default_strip_bands(8192, 16, 2) == 256
+    assert sdist.default_strip_bands(4096, 16, 8) == 32 and sdist.default_strip_bands(512, 16, 8) == 8
+    assert sdist.default_strip_bands(4096, 16, 3) == 86
     for rows, world in ((8192, 8), (4096, 3), (1000, 4), (100, 2)):
         strip = sdist.default_strip_bands(rows, 16, world)
         owners = [sum(b in sdist.owned_bands(rows, 16, r, world, strip) for r in range(world)) for b in range(sdist.n_bands(rows, 16))]
