@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--workload", default="synth4096")
     ap.add_argument("--timed", action="store_true")
+    ap.add_argument("--reverse", action="store_true", help="with --all: the last rank first (is the first one measured slower, or rank 0?)")
     args = ap.parse_args()
 
     import bench
@@ -45,7 +46,10 @@ def main():
     batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
                        viewport=sc["viewport"])
     res = []
-    for rank in (range(args.world) if args.all else [args.rank]):
+    order = list(range(args.world)) if args.all else [args.rank]
+    if args.reverse:
+        order.reverse()
+    for rank in order:
         batch.set_bands(rank, args.world, args.strip)
         st = batch.plan()
         out = ctx.alloc(max(batch.owned_rows(), 1) * cols * 16)
