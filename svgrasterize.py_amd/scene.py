@@ -503,9 +503,13 @@ def _shift_leaf(leaf, shift):
     m6 = np.array(m6, dtype=np.float64)
     m6[2] += shift
     if grad is not None:
-        _g, _keep, paint, transform, lin = grad
-        moved = Transform(np.array([[1.0, 0.0, float(shift)], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]) @ transform.m)
-        g, keep = paint.abi(moved.invert, lin)
+        # the gradient's frame moves with the path: user = A (row - shift, col) + t, i.e. the same matrix with t - A[:, 0] * shift
+        # (only the device -> user matrix of the description depends on the render transform: paint._common)
+        g0, keep, paint, transform, lin = grad
+        g = type(g0).from_buffer_copy(g0)
+        u = g.user_m6
+        u[2] -= u[0] * shift
+        u[5] -= u[3] * shift
         grad = (g, keep, paint, transform, lin)
     return (path, m6, rule, paint4, flags, group, grad)
 
