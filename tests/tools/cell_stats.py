@@ -1,5 +1,5 @@
 """Offline statistics of the bench scene's cells (CPU, oracle masks): what fraction of the tile kernel's item-waves could be
-skipped or take a cheaper path if a cell carried a class per 8-row half.  profiles/scratch/cell_stats.py [size] [paths]"""
+skipped or take a cheaper path if a cell carried a class per 8-row half.  tests/tools/cell_stats.py [size] [paths]"""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))

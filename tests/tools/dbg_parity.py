@@ -1,4 +1,4 @@
-"""Where does the GPU canvas differ from the oracle?  profiles/scratch/dbg_parity.py [size] [paths]"""
+"""Where does the GPU canvas differ from the oracle?  tests/tools/dbg_parity.py [size] [paths]"""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
