@@ -184,7 +184,7 @@ def test_tiger_small(S, tag):
 
 
 @pytest.mark.parametrize("name,tag", [("tiger", "s128"), ("material", "s256"), ("icons", "s286")])
-def test_a_second_render_of_an_unchanged_scene_reuses_the_first_ones_plans(S, name, tag):
+def test_a_second_render_of_an_unchanged_scene_reuses_the_first_ones_plans(S, name, tag, monkeypatch):
     """Scene.render retains the leaf analysis and the built + planned batches of a (scene, transform, viewport) between
     renders (scene._Retained): the second and third render give the first one's picture, with the cache and without it."""
     from svgrasterize_amd import scene as scene_mod, scenedump
@@ -194,6 +194,7 @@ def test_a_second_render_of_an_unchanged_scene_reuses_the_first_ones_plans(S, na
     tr = S.Transform().matrix(0, 1, 0, 1, 0, 0).scale(r["scale"])
     hh, ww = r["size"]
     S.clear_render_cache()
+    monkeypatch.setattr(scene_mod, "_RETAINED_MAX", 4)   # (whatever $SVGR_RENDER_CACHE says)
     shots = []
     for _ in range(3):
         layer, hull = sc.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
@@ -203,14 +204,10 @@ def test_a_second_render_of_an_unchanged_scene_reuses_the_first_ones_plans(S, na
     assert st.scene is sc and (st.run_plans or st.fill_plans or st.jobs)
     S.clear_render_cache()
     assert not scene_mod._RETAINED
-    keep = scene_mod._RETAINED_MAX
-    scene_mod._RETAINED_MAX = 0
-    try:
-        layer, hull = sc.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
-        shots.append((np.array(layer.image), tuple(int(v) for v in layer.offset), np.array(hull.points)))
-        assert not scene_mod._RETAINED
-    finally:
-        scene_mod._RETAINED_MAX = keep
+    monkeypatch.setattr(scene_mod, "_RETAINED_MAX", 0)
+    layer, hull = sc.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
+    shots.append((np.array(layer.image), tuple(int(v) for v in layer.offset), np.array(hull.points)))
+    assert not scene_mod._RETAINED
     for img, off, pts in shots[1:]:
         assert off == shots[0][1] and img.shape == shots[0][0].shape
         assert np.abs(img - shots[0][0]).max() <= 1e-12   # (the order of the LDS atomics: double rounding)

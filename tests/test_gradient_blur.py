@@ -385,6 +385,7 @@ def test_gpu_run_windows_drawn_side_by_side_are_the_windows_drawn_one_by_one(mon
         S.clear_render_cache()
         return out
 
+    monkeypatch.setattr(sm, "_MERGE_RUNS", True)   # (whatever the environment's switches say)
     monkeypatch.setattr(sm, "_PREFETCH_WINDOWS", False)
     one_by_one = draw()
     assert seen["calls"] == 0
