@@ -42,6 +42,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include <memory>
 #include <unordered_map>
@@ -1267,22 +1268,38 @@ __device__ __forceinline__ unsigned add_where(int trow, int tcol, int len) {
 // edges of a path -> the cells of the path: classes, carry-ins, headers, add lists.
 // One workgroup per SLAB of a path's cells (k_path_bbox cuts them: at most PB_CELLS cells, PB_BANDS bands).  The edges of a
 // path are one contiguous range of the edge array (k_flatten), so the workgroup walks exactly the geometry that can reach its
-// cells, and everything it accumulates -- per cell the number of adds, per cell and tile row the sum of the pieces -- lives in
-// LDS: no global atomic but ONE reservation of add slots per slab.
+// cells, and everything it accumulates -- per cell the number of adds, per cell and tile row the sum of the pieces, which tile
+// rows have a piece at all -- lives in LDS.
+//
+// A cell's add list is [the pieces of every edge row that reaches the cell][one carry-in add per tile row that has a piece
+// anywhere LEFT of the cell, at the layer's first column in the tile][the layer-edge sentinels: NaN behind the layer's last
+// column, see k_tile_render].  Every one of the three counts follows from the geometry's integers alone (which columns an edge
+// row's pieces fall into), not from a rounded sum: the list of a cell has the same length and the same place in every pass
+// over unchanged geometry, whatever order the LDS atomics ran in.  (Round 4 asked `carry != 0.0`: a sum that cancels in one
+// order and leaves 1e-17 in another made the lists' sizes wobble, and their places had to be reserved again in every render.)
+//
+// PLANNED = false (the plan's passes, and renders of a batch whose plan left no add places):
 //   pass A   per edge row of the slab (S:2244-2303) and column tile its pieces fall into: how many adds they make there, and
 //            their sum (ds_add into the cell's counter and the cell's sum of that tile row)
-//   scan     TR lanes per band of the slab walk its cells left to right with the running sum = the carry-in of every tile
-//            row (np.cumsum entering the tile, S:983): class of every cell, size and place of its add list -- carry-ins first
-//            (one add per row at the layer's first column in the tile), then the layer-edge sentinels (NaN behind the
-//            layer's last column, see k_tile_render), then the pieces --, header, entry-bitmask bits
-//   pass B   the rows again: the pieces as adds, each cell's behind its carry-ins and sentinels
-// Nothing row-sized is stored in between: pass B recomputes a row's pieces (a few dozen double operations) instead of
-// writing a 48-byte record and reading it back.
-// The rows are dealt to the lanes one by one, not edge by edge: a lane per edge runs as long as the longest edge of its
-// wave (a synthetic blob: mean 3 rows, longest 49; real drawings: hundreds next to two).  Per batch of PB_THREADS edges the
-// lanes set their edge up (S:2230-2242), carry x to the slab's first row (S:2244-2248), and the prefix sums of the row
-// counts turn a row number into (edge, row) by a two-level 16-way search.
-// `adds` == nullptr: the plan's measuring run (everything but the add lists themselves).
+//   walk     TR lanes per band of the slab walk its cells left to right with the running sum = the carry-in of every tile
+//            row (np.cumsum entering the tile, S:983): class of every cell, size of its add list; ONE reservation of add slots
+//            per slab (a global atomic in the path's shard)
+//   write    headers, carry-in adds, sentinels, entry-bitmask bits; per cell {first add, pieces} into `cell_plan`
+//   pass B   the rows again: the pieces as adds (`adds` == nullptr, the plan's measuring run: no pass B, nothing written to
+//            the lists)
+// PLANNED = true (every render of a planned batch): the cells' places are the ones the plan's own full pass left in
+// `cell_plan` -- same geometry, same counts.  A row's pieces are computed ONCE: pass A adds the counts and sums AND stores the
+// adds at `first add + ds_add_rtn(cell counter)`; the walk only produces carry-ins, classes and headers and CHECKS every
+// cell's count against the plan's (a mismatch is the sticky error bit 32, as in k_path_bbox; an add that would land beyond
+// the cell's planned pieces is not written).  No pass B, no global atomic.
+//
+// The rows are dealt to the lanes as RUNS of consecutive (edge, row) tasks, not edge by edge (a lane per edge runs as long as
+// the longest edge of its wave: a synthetic blob has mean 3 rows, longest 49; real drawings hundreds next to two) and not row
+// by row either (a lane that starts in the middle of an edge replays the reference's x recurrence, S:2244-2248, from the
+// edge's first row: per task that was a tenth of the kernel): a lane finds its first task's edge by a two-level 16-way search
+// in the prefix sums of the staged edges' row counts, replays to its row once, and from there on takes ONE row_step per task,
+// moving to the next staged edge when the edge's rows end.  Staged edges are compacted -- only those with a row inside the
+// slab are kept -- so "the next edge" is the next slot.
 // ---------------------------------------------------------------------------------------------
 struct EdgeLds {
     double p0y, p1y, dxdy, x;  // as EdgeSetup; x = column at which the edge enters row ya
@@ -1291,24 +1308,21 @@ static_assert(sizeof(EdgeLds) == 32, "EdgeLds is two 16-byte LDS reads (its firs
 #ifndef SVGR_PB_EPL
 #define SVGR_PB_EPL 2
 #endif
-#ifndef SVGR_PB_KEEP
-#define SVGR_PB_KEEP 4
-#endif
 constexpr int PB_EPL = SVGR_PB_EPL;                // edges per lane and batch
 constexpr int PB_BATCH = PB_THREADS * PB_EPL;      // edges staged together
-constexpr int PB_KEEP = SVGR_PB_KEEP;              // rounds of tasks whose rows stay in registers from pass A to pass B
-constexpr int PB_TAB = PB_THREADS * PB_KEEP;       // tasks that find their edge in a table instead of by search
-static_assert(PB_BATCH % 16 == 0 && PB_BATCH / 16 <= 32, "two-level search: at most 32 coarse entries");
+static_assert(PB_BATCH % 64 == 0 && PB_BATCH / 16 <= 32, "two-level search: at most 32 coarse entries, read four at a time");
+static_assert(PB_BANDS * SVGR_TR * PB_BATCH < (1 << 20) && PB_BATCH < (1 << 11), "stage() scans row counts and live flags in one packed word");
 #ifndef SVGR_PB_WAVES
 #define SVGR_PB_WAVES 4
 #endif
+template <bool PLANNED>
 __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const Slab* __restrict__ slabs, const double* __restrict__ edges,
                                                            const int* __restrict__ pair_idx, const double* __restrict__ path_paint,
                                                            const uint8_t* __restrict__ path_rule, const int* __restrict__ path_group,
                                                            const int* __restrict__ path_grad, int vr0, int vc0, int n_ct, int mask_words,
                                                            unsigned long long* __restrict__ tile_mask, CellHdr* __restrict__ cell_hdr,
                                                            int cell_cap, const AddShards ash, TileAdd* __restrict__ adds,
-                                                           BatchDev* __restrict__ bd, Owner own, int stats, int det,
+                                                           int2* __restrict__ cell_plan, BatchDev* __restrict__ bd, Owner own, int stats, int det,
                                                            unsigned long long* __restrict__ dbg) {
 #ifdef SVGR_DBG_PB_STAMP
 #define PB_STAMP(i) do { if (threadIdx.x == 0 && dbg && blockIdx.x < 8192) dbg[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -1318,12 +1332,12 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     PB_STAMP(0);
     __shared__ __attribute__((aligned(16))) double s_sum[PB_CELLS * TR];
     __shared__ double s_left[TR];
-    __shared__ int s_cnt[PB_CELLS], s_pos[PB_CELLS];
+    __shared__ int s_cnt[PB_CELLS], s_pos[PB_CELLS], s_plan_n[PB_CELLS];
+    __shared__ unsigned s_rowb[PB_CELLS + 1];                       // per cell: tile rows with a piece ([PB_CELLS]: left of the slab)
     __shared__ __attribute__((aligned(16))) EdgeLds s_edge[PB_BATCH];
     __shared__ int s_eya[PB_BATCH];              // per staged edge: ya | (dir < 0) << 31
-    __shared__ __attribute__((aligned(16))) int s_pref[PB_BATCH];
+    __shared__ __attribute__((aligned(16))) int s_pref[PB_BATCH + 4];
     __shared__ __attribute__((aligned(16))) int s_coarse[32];
-    __shared__ unsigned short s_tab[PB_TAB];
     __shared__ int s_wtot[PB_EPL][PB_THREADS / 64];
     __shared__ __attribute__((aligned(8))) int2 s_info[PB_CELLS];   // per cell: adds in front of it in its band, class | band << 2 | column tile << 8
     __shared__ unsigned s_rowm[PB_CELLS];                           // ... rows with a carry-in add | rows with a sentinel << 16
@@ -1337,8 +1351,11 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     // (the LDS tables are cleared whole, not just the slab's part of them: that needs nothing of the slab, so it runs while the
     //  slab record is on its way)
     for (int i = tid; i < PB_CELLS * TR / 2; i += PB_THREADS) ((double2*)s_sum)[i] = make_double2(0.0, 0.0);
-    for (int i = tid; i < PB_CELLS; i += PB_THREADS) { s_cnt[i] = 0; s_pos[i] = (int)0x80000000; s_info[i] = make_int2(0, 0); }
+    for (int i = tid; i < PB_CELLS; i += PB_THREADS) {
+        s_cnt[i] = 0; s_pos[i] = (int)0x80000000; s_plan_n[i] = 0; s_rowb[i] = 0u; s_info[i] = make_int2(0, 0);
+    }
     if (tid < TR) s_left[tid] = 0.0;
+    if (tid == 0) { s_rowb[PB_CELLS] = 0u; s_pref[PB_BATCH] = 0x7fffffff; }
     // (both scalar loads asked for together: the slab first, the test of the cursor behind it -- the grid never exceeds the list)
     const Slab sl = slabs[blockIdx.x];
     const int n_slabs_now = bd->slab_cursor;
@@ -1358,9 +1375,23 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     const int group = path_group ? path_group[p] : -1;
     const int grad1 = path_grad ? path_grad[p] + 1 : 0;  // gradient index + 1 (0: solid colour)
     const double4 paint = ((const double4*)path_paint)[p];
+    // global index of the slab's cell i (band-major inside the slab)
+    auto cell_of = [&](int g, int k) { return sl.cell_off + (sl.band0 + g - sl.b0) * nct + sl.k0 + k; };
+    // PLANNED: the cells' places {first add, pieces}, asked for here -- in front of the edges, so they have landed when the
+    // edges have -- and put into LDS by the first stage()
+    int2 my_plan = make_int2((int)0x80000000, 0);
+    bool plan_pending = false;
+    if (PLANNED) {
+        if (tid < n_cell) {
+            const int g = tid / sl.nk, k = tid - g * sl.nk;
+            const int cell = cell_of(g, k);
+            if (cell < cell_cap) my_plan = cell_plan[cell];
+        }
+        plan_pending = true;
+    }
 
-    // a batch of edges (slot = tid + j * PB_THREADS): set up, rows inside the slab counted, prefix sums -> number of
-    // (edge, row) tasks of the batch; the first PB_TAB tasks find their slot in s_tab
+    // a batch of edges (slot = tid + j * PB_THREADS): set up, rows inside the slab counted; the edges that have any are kept,
+    // in order, with the prefix sums of their row counts -> number of (edge, row) tasks of the batch
     auto stage = [&](int eb) -> int {
         int cnt[PB_EPL], eya[PB_EPL];
         EdgeLds el[PB_EPL];
@@ -1389,38 +1420,50 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                 }
             }
         }
+        // one scan for both prefix sums: rows in bits 0-19, kept edges in bits 20-
         int excl[PB_EPL], wtot[PB_EPL];
 #pragma unroll
-        for (int j = 0; j < PB_EPL; ++j) excl[j] = wave_excl_scan(cnt[j], lane, wtot[j]);
-        __syncthreads();  // (the previous batch's tasks are done with s_edge / s_pref / s_tab)
-#pragma unroll
-        for (int j = 0; j < PB_EPL; ++j) {
-            if (lane == 0) s_wtot[j][wave] = wtot[j];
-            s_edge[tid + j * PB_THREADS] = el[j];
-            s_eya[tid + j * PB_THREADS] = eya[j];
+        for (int j = 0; j < PB_EPL; ++j) excl[j] = wave_excl_scan(cnt[j] | ((cnt[j] > 0 ? 1 : 0) << 20), lane, wtot[j]);
+        __syncthreads();  // (the previous batch's tasks are done with s_edge / s_pref)
+        if (PLANNED && plan_pending) {
+            if (tid < PB_CELLS) { s_pos[tid] = my_plan.x; s_plan_n[tid] = my_plan.y; }
+            plan_pending = false;
         }
+#pragma unroll
+        for (int j = 0; j < PB_EPL; ++j)
+            if (lane == 0) s_wtot[j][wave] = wtot[j];
         __syncthreads();
         int all = 0;
+        int pre[PB_EPL];
 #pragma unroll
         for (int j = 0; j < PB_EPL; ++j) {
             int before = all;
 #pragma unroll
             for (int w = 0; w < PB_THREADS / 64; ++w) { before += w < wave ? s_wtot[j][w] : 0; all += s_wtot[j][w]; }
-            const int slot = tid + j * PB_THREADS, pre = before + excl[j];
-            s_pref[slot] = pre;
-            if ((slot & 15) == 0) s_coarse[slot >> 4] = pre;
-            for (int q = pre; q < pre + cnt[j] && q < PB_TAB; ++q) s_tab[q] = (unsigned short)slot;
+            pre[j] = before + excl[j];
+        }
+        const int n_live = all >> 20, total = all & 0xfffff;
+#pragma unroll
+        for (int j = 0; j < PB_EPL; ++j) {
+            if (cnt[j] > 0) {
+                const int cs = pre[j] >> 20, tp = pre[j] & 0xfffff;
+                s_edge[cs] = el[j];
+                s_eya[cs] = eya[j];
+                s_pref[cs] = tp;
+                if ((cs & 15) == 0) s_coarse[cs >> 4] = tp;
+            }
+            // (behind the kept edges: larger than any task number, so that the searches stop in front of them)
+            const int us = tid + j * PB_THREADS;
+            if (us >= n_live) {
+                s_pref[us] = 0x7fffffff;
+                if ((us & 15) == 0) s_coarse[us >> 4] = 0x7fffffff;
+            }
         }
         __syncthreads();
-        return all;
+        return total;
     };
     // task t of the staged batch -> its edge's LDS slot and its row offset inside the edge's rows of the slab
     auto find = [&](int t, int& slot, int& dy) {
-        if (t < PB_TAB) {
-            slot = s_tab[t];
-            dy = t - s_pref[slot];
-            return;
-        }
         const int4* cq = (const int4*)s_coarse;
         int blk = -1;
 #pragma unroll
@@ -1445,43 +1488,50 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         double v[5];
         int where;   // bl | trow << 8 | live << 16
     };
-    // What is kept of a row between the passes: where the edge enters and leaves it, its signed height, its place (7 registers;
-    // the pieces themselves are 13, and three rounds of them cost the kernel a workgroup per CU).  Pass B recomputes the pieces.
-    // (x_next is not kept: it is x + dxdy * |d| -- row_step's own expression, |d| = dy exactly -- with dxdy one LDS read away)
-    struct RowKey {
-        double x, d;
-        int where;   // bl | trow << 8 | staged edge << 16
-    };
-    auto row_key = [&](int t) -> RowKey {
-        RowKey rk;
-        int slot, dy;
-        find(t, slot, dy);
-        const EdgeLds el = s_edge[slot];
-        const int ya_dir = s_eya[slot];
-        const int ya = ya_dir & 0x7fffffff, y = ya + dy;
-        const double dir = ya_dir < 0 ? -1.0 : 1.0;
-        RowState st;
-        st.x_next = el.x; st.x = el.x; st.d = 0.0;
-        for (int yy = ya; yy <= y; ++yy) row_step(st, yy, el.p0y, el.p1y, el.dxdy, dir);
-        const int vrow = r0 + y - vr0, band = vrow / TR;
-        rk.x = st.x; rk.d = st.d;
-        static_assert(PB_BATCH <= (1 << 15), "a RowKey carries its staged edge in 15 bits");
-        rk.where = (band - sl.band0) | ((vrow & (TR - 1)) << 8) | (slot << 16);
-        return rk;
-    };
-    auto row_at = [&](const RowKey& rk) -> RowAt {
+    auto row_at = [&](double x, double x_next, double d, int y) -> RowAt {
         RowAt ra;
-        const double x_next = rk.x + s_edge[rk.where >> 16].dxdy * fabs(rk.d);
-        const RowPieces rp = row_record(rk.x, x_next, rk.d);
+        const RowPieces rp = row_record(x, x_next, d);
         ra.x0i = rp.x0i; ra.n = rp.n;
         ra.v[0] = rp.v[0]; ra.v[1] = rp.v[1]; ra.v[2] = rp.v[2]; ra.v[3] = rp.v[3]; ra.v[4] = rp.v[4];
         if ((unsigned)ra.n > SPAN_MAX) { atomicOr(&bd->err, 16); ra.n = (int)SPAN_MAX; }
-        const int band = sl.band0 + (rk.where & 0xff);
+        const int vrow = r0 + y - vr0, band = vrow / TR;
         const bool live = owns_band(own, band) && rp.x0i < cols;  // (another rank's band; a row wholly beyond the layer, S:2260)
-        ra.where = (rk.where & 0xffff) | ((int)live << 16);
+        ra.where = (band - sl.band0) | ((vrow & (TR - 1)) << 8) | ((int)live << 16);
         return ra;
     };
-    auto row_of = [&](int t) -> RowAt { return row_at(row_key(t)); };
+    // The `total` tasks of the staged batch, every lane a run of consecutive ones: body(RowAt).
+    // (SVGR_RENDER_DETERMINISTIC: the first wave alone takes the rows -- every sum and every list is then filled in the same
+    //  order from render to render, and in the same order by the plan's passes and by the planned renders)
+    auto for_rows = [&](int total, auto&& body) {
+        const int nl = det ? 64 : PB_THREADS;
+        const int per = (total + nl - 1) / nl;
+        int t = tid * per;
+        const int t1 = t + per < total ? t + per : total;
+        if (tid >= nl || t >= t1) return;
+        int slot, dy;
+        find(t, slot, dy);
+        EdgeLds el = s_edge[slot];
+        int ya_dir = s_eya[slot];
+        int y = ya_dir & 0x7fffffff;
+        double dir = ya_dir < 0 ? -1.0 : 1.0;
+        int t_next = s_pref[slot + 1];   // first task of the next kept edge
+        RowState st;
+        st.x_next = el.x; st.x = el.x; st.d = 0.0;
+        for (const int y1 = y + dy; y < y1; ++y) row_step(st, y, el.p0y, el.p1y, el.dxdy, dir);
+        for (; t < t1; ++t, ++y) {
+            if (t == t_next) {
+                ++slot;
+                el = s_edge[slot];
+                ya_dir = s_eya[slot];
+                y = ya_dir & 0x7fffffff;
+                dir = ya_dir < 0 ? -1.0 : 1.0;
+                t_next = s_pref[slot + 1];
+                st.x_next = el.x;
+            }
+            row_step(st, y, el.p0y, el.p1y, el.dxdy, dir);
+            body(row_at(st.x, st.x_next, st.d, y));
+        }
+    };
     // the slab's column tiles [kf, kl] (relative to the path's first) the pieces of a row fall into
     auto row_tiles = [&](const RowAt& ra, int& kf, int& kl) {
         const int xl = ra.x0i + (ra.n >= 2 ? ra.n : 1);  // column of the last piece
@@ -1499,8 +1549,23 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         ca = ca > 0 ? ca : 0;
         cb = cb < cols ? cb : cols;
     };
-    // pass A of one row: per cell the number of adds its pieces make there and their sum
-    auto count_row = [&](const RowAt& ra) {
+    // the pieces of a row that fall into the cell of column tile k, as adds behind `dst`
+    auto store_pieces = [&](const RowAt& ra, int trow, int ca, int cb, int cell_c0, TileAdd* dst) {
+        record_adds(ra.x0i, ra.n, ra.v, ca, cb,
+                    [&](int c, double val) { store_add(dst++, add_where(trow, c - cell_c0, 1), val); },
+                    [&](int c, int len, double val) {
+                        int tc = c - cell_c0;
+                        while (len > 0) {  // (one piece per chunk of PX columns)
+                            const int n = len < PX - (tc & (PX - 1)) ? len : PX - (tc & (PX - 1));
+                            store_add(dst++, add_where(trow, tc, n), val);
+                            tc += n; len -= n;
+                        }
+                    });
+    };
+    // One row, per cell its pieces fall into: the number of adds they make there, their sum, the row's bit.
+    // STORE (a planned render): the adds themselves too, at the cell's planned place + what the counter held.
+    auto count_row = [&](const RowAt& ra, auto store) {
+        constexpr bool STORE = decltype(store)::value;
 #ifdef SVGR_DBG_PB_NOCOUNT
         if (ra.x0i != 123456789) return;
 #endif
@@ -1514,6 +1579,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             tile_cols(sl.k0, ca, cb);
             const double part = record_sum_range(ra.x0i, ra.n, ra.v, 0, ca);
             __hip_atomic_fetch_add(&s_left[trow], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(&s_rowb[PB_CELLS], 1u << trow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             kf = sl.k0;
         }
         for (int k = kf; k <= kl; ++k) {
@@ -1526,11 +1592,18 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                         [&](int c, int len, double val) { ne += run_pieces(c - cell_c0, len); part = part + (double)len * val; });
             if (ne == 0) continue;
             const int ci = bl * sl.nk + (k - sl.k0);
-            __hip_atomic_fetch_add(&s_cnt[ci], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int pos = __hip_atomic_fetch_add(&s_cnt[ci], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&s_sum[ci * TR + trow], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(&s_rowb[ci], 1u << trow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (STORE) {
+                const int first = s_pos[ci];
+                // (more pieces than the plan counted here, or a cell the plan has no place for: the walk flags the cell)
+                if (first < 0 || pos + ne > s_plan_n[ci]) continue;
+                store_pieces(ra, trow, ca, cb, cell_c0, adds + ((size_t)first + pos));
+            }
         }
     };
-    // pass B of one row: the pieces as adds, behind what their cells' lists hold already
+    // pass B of one row (PLANNED = false): the pieces as adds, behind what their cells' lists hold already
     auto emit_row = [&](const RowAt& ra) {
         if (!((ra.where >> 16) & 1)) return;
         const int bl = ra.where & 0xff, trow = (ra.where >> 8) & 0xff;
@@ -1547,28 +1620,13 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             if (ne == 0) continue;
             const int ci = bl * sl.nk + (k - sl.k0);
             const int pos = __hip_atomic_fetch_add(&s_pos[ci], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (pos < 0) continue;  // (the cell was refused by the scan: flagged there)
-            TileAdd* dst = adds + pos;
-            record_adds(ra.x0i, ra.n, ra.v, ca, cb,
-                        [&](int c, double val) { store_add(dst++, add_where(trow, c - cell_c0, 1), val); },
-                        [&](int c, int len, double val) {
-                            int tc = c - cell_c0;
-                            while (len > 0) {  // (one piece per chunk of PX columns)
-                                const int n = len < PX - (tc & (PX - 1)) ? len : PX - (tc & (PX - 1));
-                                store_add(dst++, add_where(trow, tc, n), val);
-                                tc += n; len -= n;
-                            }
-                        });
+            if (pos < 0) continue;  // (the cell was refused by the walk: flagged there)
+            store_pieces(ra, trow, ca, cb, cell_c0, adds + pos);
         }
     };
 
-    // ---- pass A ----  (a path of up to PB_BATCH edges is staged once, and its first PB_KEEP rounds of rows stay in registers)
-    // (SVGR_RENDER_DETERMINISTIC: the first wave alone takes the rows, in order -- every sum and every list is then filled in the
-    //  same order from render to render)
-    const int t_first = det ? (tid < 64 ? tid : 0x7fffffff) : tid, t_step = det ? 64 : PB_THREADS;
+    // ---- pass A ----
     const bool one_batch = e_end - e_begin <= PB_BATCH;
-    const bool keep = one_batch && !det;
-    RowKey kept[PB_KEEP];
     int total = 0, n_rows = 0;
     for (int eb = e_begin; eb < e_end; eb += PB_BATCH) {
         total = stage(eb);
@@ -1577,29 +1635,20 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
 #ifdef SVGR_DBG_PB_NOTASK
         total = 0;
 #endif
-        int t = t_first;
-        if (keep) {
-#pragma unroll
-            for (int r = 0; r < PB_KEEP; ++r, t += PB_THREADS) {
-                if (t < total) {
-                    kept[r] = row_key(t);
-                    count_row(row_at(kept[r]));
-                }
-            }
-        }
-        for (; t < total; t += t_step) count_row(row_of(t));
+        if (PLANNED) for_rows(total, [&](const RowAt& ra) { count_row(ra, std::true_type{}); });
+        else for_rows(total, [&](const RowAt& ra) { count_row(ra, std::false_type{}); });
     }
     if (stats && tid == 0 && n_rows > 0) atomicAdd(&bd->bseg_cursor, n_rows);  // (plan only: edge rows of the batch)
     __syncthreads();
     PB_STAMP(2);
-    // ---- scan ----
+    // ---- walk ----
 #ifdef SVGR_DBG_PB_NOSCAN
     if (n_rows != 123456789) return;
 #endif
     {
-        // walk: TR lanes per band of the slab (lane = tile row) go through the band's cells left to right.  The row's running
-        // sum replaces the cell's sum in s_sum (what phase 2 needs is the carry-in); per cell: class, adds, and which rows have a
-        // carry-in / a sentinel (as bit masks of the band's TR lanes)
+        // TR lanes per band of the slab (lane = tile row) go through the band's cells left to right.  The row's running sum
+        // replaces the cell's sum in s_sum (what the write phase needs is the carry-in); per cell: class, adds, and which rows
+        // have a carry-in / a sentinel (as bit masks of the band's TR lanes)
         static_assert(TR <= 16, "k_path_build packs two TR-bit row masks into one word");
         constexpr unsigned long long GMASK = (1ull << TR) - 1ull;
         const int g = tid / TR, row_l = tid & (TR - 1);
@@ -1609,27 +1658,29 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         const int row_abs = vr0 + band * TR + row_l;
         const bool row_in_layer = row_abs >= r0 && row_abs < r0 + rows;  // (the sentinel is set on rows of the layer only)
         int cursor = 0;                                    // adds of the column tiles walked so far
+        bool mismatch = false;
         if (__ballot(active) != 0ull) {  // (a wave none of whose bands exists has nothing to walk)
             if (active && row_l == 0) s_pidx[g] = pair_idx[sl.pb_off + band - sl.b0];  // the pair's place in its band's list
             double run = sl.k0 > 0 ? s_left[row_l] : 0.0;      // the row's running sum left of the column tile
+            unsigned had = sl.k0 > 0 ? s_rowb[PB_CELLS] : 0u;  // tile rows with a piece left of the column tile (bit row_l: this lane's)
             for (int k = 0; k < sl.nk; ++k) {
                 const int ci = g * sl.nk + k;
                 const int own_n = active ? s_cnt[ci] : 0;
                 const double sq = active ? s_sum[ci * TR + row_l] : 0.0;
+                const unsigned rb = active ? s_rowb[ci] : 0u;
                 const double cin = run;
                 const bool vis = active && carry_visible(cin, rule);
                 const unsigned long long vm = (__ballot(vis) >> shift) & GMASK;
                 const int cls = own_n > 0 ? 2 : (vm != 0ull ? 1 : 0);
-                // class 2: the cell's add list = [carry-ins of the rows where it is not zero][sentinels][pieces]
+                // class 2: the cell's add list = [pieces][a carry-in for every row with a piece left of the cell][sentinels]
                 const int t_end = cols - ((sl.k0 + k) * TC + x_first);     // tile column one past the layer's last column
-                const bool want_carry = active && cls == 2 && cin != 0.0;
-                const bool want_sent = active && cls == 2 && t_end < TC && row_in_layer;
-                const unsigned cm = (unsigned)((__ballot(want_carry) >> shift) & GMASK);
-                const unsigned sm = (unsigned)((__ballot(want_sent) >> shift) & GMASK);
+                const unsigned cm = cls == 2 ? had & (unsigned)GMASK : 0u;
+                const unsigned sm = cls == 2 && t_end < TC ? (unsigned)((__ballot(active && row_in_layer) >> shift) & GMASK) : 0u;
                 const int n_add = cls == 2 ? __popc(cm) + __popc(sm) + own_n : 0;
                 if (active) {
                     s_sum[ci * TR + row_l] = cin;
                     if (row_l == 0) {
+                        if (PLANNED && own_n != s_plan_n[ci]) mismatch = true;
                         s_cnt[ci] = n_add;                                   // (the cell's whole list now)
                         s_info[ci] = make_int2(cursor, cls | (g << 2) | (k << 8));
                         s_rowm[ci] = cm | (sm << 16);
@@ -1637,28 +1688,35 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                 }
                 cursor += n_add;
                 run = run + sq;
+                had |= rb;
             }
         }
-        // the slab's reservation of add slots: ONE atomic, in the path's shard
-        if (row_l == 0 && g < PB_BANDS) s_ptot[g] = active ? cursor : 0;
-        __syncthreads();
-        if (tid < 64) {  // the bands' offsets: an exclusive scan over <= PB_BANDS totals by the first wave
-            static_assert(PB_BANDS <= 64, "one lane per band of the slab");
-            const int c = tid < sl.nb ? s_ptot[tid] : 0;
-            int all;
-            const int ex = wave_excl_scan(c, tid, all);
-            if (tid < sl.nb) s_ptot[tid] = ex;
-            if (tid == 0) {
-            const int sh = p % ash.n;  // (by path, not by slab: the slabs' order changes from pass to pass, the plan's shard sizes must hold)
-            int at = 0;
-            if (all > 0) at = atomicAdd(&bd->shard[sh].add_cursor, all);
-            int ok = 1;
-            if (adds && (long long)at + all > (long long)ash.cap[sh]) { atomicOr(&bd->err, 64); ok = 0; }
-            s_base = ash.base[sh] + at;
-            s_ok = ok;
+        if (PLANNED) {
+            if (mismatch) atomicOr(&bd->err, 32);  // (not the plan's geometry: its places do not hold -- as in k_path_bbox)
+            if (tid == 0) { s_base = 0; s_ok = 1; }
+            __syncthreads();
+        } else {
+            // the slab's reservation of add slots: ONE atomic, in the path's shard
+            if (row_l == 0 && g < PB_BANDS) s_ptot[g] = active ? cursor : 0;
+            __syncthreads();
+            if (tid < 64) {  // the bands' offsets: an exclusive scan over <= PB_BANDS totals by the first wave
+                static_assert(PB_BANDS <= 64, "one lane per band of the slab");
+                const int c = tid < sl.nb ? s_ptot[tid] : 0;
+                int all;
+                const int ex = wave_excl_scan(c, tid, all);
+                if (tid < sl.nb) s_ptot[tid] = ex;
+                if (tid == 0) {
+                    const int sh = p % ash.n;  // (by path, not by slab: the slabs' order changes from pass to pass, the plan's shard sizes must hold)
+                    int at = 0;
+                    if (all > 0) at = atomicAdd(&bd->shard[sh].add_cursor, all);
+                    int ok = 1;
+                    if (adds && (long long)at + all > (long long)ash.cap[sh]) { atomicOr(&bd->err, 64); ok = 0; }
+                    s_base = ash.base[sh] + at;
+                    s_ok = ok;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     PB_STAMP(3);
     {
@@ -1671,33 +1729,38 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             const unsigned rowm = s_rowm[ci];
             const int cls = info.y & 3, g = (info.y >> 2) & 63, k = info.y >> 8;
             const int band = sl.band0 + g;
-            if (cls == 0 || !owns_band(own, band)) continue;
-            const int cell = sl.cell_off + (band - sl.b0) * nct + sl.k0 + k;
+            if (!owns_band(own, band)) continue;
+            // (a cell the walk never reached -- g beyond the slab's bands cannot happen: n_cell = nb x nk)
+            const int cell = cell_of(g, k);
+            const int n_list = s_cnt[ci];
+            const unsigned cm = rowm & 0xffffu, sm = rowm >> 16;
+            const int n_carry = __popc(cm), n_sent = __popc(sm);
+            const int own_n = n_list - n_carry - n_sent;                    // (class 2: its pieces)
+            const int add0 = PLANNED ? s_pos[ci] : s_base + s_ptot[g] + info.x;
+            if (!PLANNED && row_l == 0 && cell < cell_cap) cell_plan[cell] = make_int2(cls == 2 && slab_ok ? add0 : (int)0x80000000, cls == 2 ? own_n : 0);
+            if (cls == 0) continue;
             const int idx = s_pidx[g];
             const bool mask_ok = (unsigned)(idx >> 6) < (unsigned)mask_words;  // (the plan sized the masks from the longest band list)
-            if (!(cell < cell_cap && slab_ok && mask_ok)) {
+            if (!(cell < cell_cap && slab_ok && mask_ok) || (PLANNED && cls == 2 && add0 < 0)) {
                 if (row_l == 0) atomicOr(&bd->err, 32);
                 continue;
             }
             const double cin = s_sum[i];
-            const unsigned cm = rowm & 0xffffu, sm = rowm >> 16;
-            const int n_carry = __popc(cm);
             CellHdr* hd = cell_hdr + cell;
 #if SVGR_X_CARRY1
             if (cls == 1) hd->carry[row_l] = cin;   // (a class-2 cell's carry-ins are adds of its list: the tile kernel does not load this part of its header)
 #else
             hd->carry[row_l] = cin;
 #endif
-            const int add0 = s_base + s_ptot[g] + info.x;
             const int cell_c0 = (sl.k0 + k) * TC + x_first;       // layer column of the tile's column 0
             const unsigned below = (1u << row_l) - 1u;
             if (((cm >> row_l) & 1u) && adds) {
                 // at the layer's first column in the tile
-                store_add(adds + ((size_t)add0 + __popc(cm & below)), add_where(row_l, cell_c0 < 0 ? -cell_c0 : 0, 1), cin);
+                store_add(adds + ((size_t)add0 + own_n + __popc(cm & below)), add_where(row_l, cell_c0 < 0 ? -cell_c0 : 0, 1), cin);
             }
             if (((sm >> row_l) & 1u) && adds) {
                 // behind the layer's last column
-                store_add(adds + ((size_t)add0 + n_carry + __popc(sm & below)), add_where(row_l, cols - cell_c0, 1), __builtin_nan(""));
+                store_add(adds + ((size_t)add0 + own_n + n_carry + __popc(sm & below)), add_where(row_l, cols - cell_c0, 1), __builtin_nan(""));
             }
             if (row_l == 0) {
                 // the tiles' entry bitmasks: per (band, column tile) two rows of mask_words words, bit i = entry i of the band's
@@ -1709,32 +1772,26 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                 hd->paint[0] = paint.x; hd->paint[1] = paint.y; hd->paint[2] = paint.z; hd->paint[3] = paint.w;
                 hd->r0 = r0; hd->c0 = c0; hd->rows = rows; hd->cols = cols;
                 hd->bits = rule | (((rl >> 1) & 3) << 1) | (cls << 3) | (grad1 << 5);
-                hd->n_add = s_cnt[ci]; hd->add0 = add0; hd->p = p;
+                hd->n_add = n_list; hd->add0 = add0; hd->p = p;
                 hd->group = group;
-                if (cls == 2 && adds) s_pos[ci] = add0 + n_carry + __popc(sm);  // the pieces follow (pass B)
+                if (!PLANNED && cls == 2 && adds) s_pos[ci] = add0;  // the pieces come first (pass B)
             }
         }
     }
-    __syncthreads();
     PB_STAMP(4);
-    if (!adds) return;
+    if (PLANNED || !adds) return;
+    __syncthreads();
 
-    // ---- pass B ----
+    // ---- pass B ----  (PLANNED = false only)
 #ifdef SVGR_DBG_PB_NOB
     return;
 #endif
     if (one_batch) {
-        int t = t_first;
-        if (keep) {
-#pragma unroll
-            for (int r = 0; r < PB_KEEP; ++r, t += PB_THREADS)
-                if (t < total) emit_row(row_at(kept[r]));
-        }
-        for (; t < total; t += t_step) emit_row(row_of(t));  // (the batch is still staged)
+        for_rows(total, emit_row);  // (the batch is still staged)
     } else {
         for (int eb = e_begin; eb < e_end; eb += PB_BATCH) {
             const int tot = stage(eb);
-            for (int t = t_first; t < tot; t += t_step) emit_row(row_of(t));
+            for_rows(tot, emit_row);
         }
     }
     PB_STAMP(5);
@@ -3658,6 +3715,8 @@ struct svgr_batch {
     DevArr<TileEntry> entries;
     DevArr<double> edges;
     DevArr<CellHdr> cell_hdr;               // per (path, band, column tile) cell: header (classes 1 and 2)
+    DevArr<int2> cell_plan;                 // ... and where its add list lives: {first add, pieces}, left by the plan's full pass (k_path_build)
+    bool add_places = false;                // `cell_plan` holds the places of the current plan: the renders take them (k_path_build<true>)
     // a pass that ended with an error flag may have left any of the self-cleaning buffers dirty
     void invalidate_work() { masks_zeroed = false; arena_zeroed = false; }
     DevArr<TileAdd> adds;                   // the cells' add lists (k_path_build: a slab reserves its cells' lists in one piece)
@@ -3749,7 +3808,7 @@ struct svgr_batch {
         band_start.release(); band_count.release(); entries.release();
         path_group.release(); group_clip_src.release(); group_opacity.release(); groups_dev.release();
         grads.release(); path_grad.release(); grad_path.release(); grad_flags.release(); grads_dev.release();
-        edges.release(); cell_hdr.release(); pair_idx.release(); slabs.release(); slab_at.release(); seg_cnt.release(); seg_off.release(); path_seg0.release(); tile_mask.release(); seg_list.release(); path_list.release(); layer_off.release();
+        edges.release(); cell_hdr.release(); cell_plan.release(); pair_idx.release(); slabs.release(); slab_at.release(); seg_cnt.release(); seg_off.release(); path_seg0.release(); tile_mask.release(); seg_list.release(); path_list.release(); layer_off.release();
         adds.release(); items.release(); tile_info.release(); pages.release(); band_item0.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
@@ -3843,12 +3902,19 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
 #endif
     if (b->n_slabs > 0) {
         b->masks_zeroed = false;  // (bits are set below; k_tile_lists clears them again)
-        hipLaunchKernelGGL(k_path_build, dim3((unsigned)b->n_slabs), dim3(PB_THREADS), 0, st, (const Slab*)b->slabs.p, (const double*)b->edges.p,
-                           (const int*)b->pair_idx.p, (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p,
-                           b->n_groups > 0 ? (const int*)b->path_group.p : (const int*)nullptr,
-                           b->n_grads > 0 ? (const int*)b->path_grad.p : (const int*)nullptr, b->vp[0], b->vp[1], b->n_ctiles(), b->mask_words,
-                           b->tile_mask.p, b->cell_hdr.p, cap_i32(b->cell_hdr.cap), b->add_shards,
-                           b->count_adds_only ? (TileAdd*)nullptr : b->adds.p, b->bd(), b->own, b->planned ? 0 : 1, b->deterministic ? 1 : 0, pb_dbg);
+        // (a planned render takes every cell's add places from the plan's own full pass: one pass over the edge rows, no reservation)
+        // (the places are per cell: they hold as long as the paths keep the plan's cell places, i.e. under the plan's slab order)
+        const bool placed = b->planned && b->add_places && b->slab_at_valid && !b->count_adds_only && b->cell_plan.p != nullptr;
+        auto launch_pb = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)b->n_slabs), dim3(PB_THREADS), 0, st, (const Slab*)b->slabs.p, (const double*)b->edges.p,
+                               (const int*)b->pair_idx.p, (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p,
+                               b->n_groups > 0 ? (const int*)b->path_group.p : (const int*)nullptr,
+                               b->n_grads > 0 ? (const int*)b->path_grad.p : (const int*)nullptr, b->vp[0], b->vp[1], b->n_ctiles(), b->mask_words,
+                               b->tile_mask.p, b->cell_hdr.p, cap_i32(std::min(b->cell_hdr.cap, b->cell_plan.cap)), b->add_shards,
+                               b->count_adds_only ? (TileAdd*)nullptr : b->adds.p, b->cell_plan.p, b->bd(), b->own, b->planned ? 0 : 1,
+                               b->deterministic ? 1 : 0, pb_dbg);
+        };
+        if (placed) launch_pb(k_path_build<true>); else launch_pb(k_path_build<false>);
 #ifdef SVGR_DBG_PB_STAMP
         if (pb_dbg && b->planned && !b->count_adds_only) {
             static int n_dump = 0;
@@ -4403,7 +4469,8 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr, bool again = false
         }
         b->n_pb = (int64_t)std::min(b->entries.cap, b->pair_idx.cap);
         b->n_entries = b->n_pb;
-        b->n_cells = (int64_t)std::min(b->cell_hdr.cap - 1, b->items.cap);
+        if (b->cell_plan.cap == 0) return 0;
+        b->n_cells = (int64_t)std::min(std::min(b->cell_hdr.cap, b->cell_plan.cap) - 1, b->items.cap);
         b->n_slabs = (int64_t)b->slabs.cap;
         if (b->n_edges <= 0 || b->n_pb <= 0 || b->n_cells <= 0 || b->n_slabs <= 0 || b->edge_path.cap < (size_t)b->n_edges) return 0;
         int rc = b->layout_arena();
@@ -4450,6 +4517,7 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr, bool again = false
     rc = rc ? rc : b->pair_idx.ensure((size_t)b->n_pb);
     rc = rc ? rc : b->slabs.ensure((size_t)b->n_slabs);
     rc = rc ? rc : b->cell_hdr.ensure((size_t)b->n_cells + 1);
+    rc = rc ? rc : b->cell_plan.ensure((size_t)b->n_cells + 1);
     rc = rc ? rc : b->size_tile_lists(n_bands);
     if (!rc) {
         // add slots: a guess like the others -- a few adds per edge row.  Few slabs: one shard (a batch of one slab would put
@@ -4482,6 +4550,7 @@ static int spec_finish(svgr_batch* b) {
     b->sized = true;
     for (int k = 0; k < 4; ++k) b->sized_vp[k] = b->vp[k];
     b->no_band_reuse = getenv("SVGR_NO_BAND_REUSE") != nullptr;
+    b->add_places = getenv("SVGR_NO_ADD_PLACES") == nullptr;   // (the pass behind this plan was a full one: it left every cell's add places)
     b->geometry_fresh = true; b->geometry_current = true;
     return 1;
 }
@@ -4711,6 +4780,7 @@ static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
     b->n_cells = b->host_bd.cell_cursor;
     b->n_slabs = b->host_bd.slab_cursor;
     if (int rc = b->cell_hdr.ensure((size_t)std::max<int64_t>(b->n_cells, 1) + 1)) return rc;
+    if (int rc = b->cell_plan.ensure((size_t)std::max<int64_t>(b->n_cells, 1) + 1)) return rc;
     if (int rc = b->slabs.ensure((size_t)std::max<int64_t>(b->n_slabs, 1))) return rc;
     // 3. the band lists
     if (int rc = b->entries.ensure((size_t)std::max<int64_t>(b->n_pb, 1))) return rc;
@@ -4743,6 +4813,7 @@ static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
     b->sized = true;
     for (int k = 0; k < 4; ++k) b->sized_vp[k] = b->vp[k];
     b->no_band_reuse = getenv("SVGR_NO_BAND_REUSE") != nullptr;
+    b->add_places = getenv("SVGR_NO_ADD_PLACES") == nullptr;   // (step 4 was a full pass: it left every cell's add places)
     b->geometry_fresh = true; b->geometry_current = true;
     return 0;
 }

@@ -173,6 +173,13 @@ def test_planned_slab_places_do_not_change_the_picture(S, monkeypatch):
         d = render(bands)
         assert np.array_equal(a, d), f"band places from the cursors change the picture under the plan's slab order (bands {bands})"
         monkeypatch.delenv("SVGR_NO_BAND_REUSE", raising=False)
+        # ... and the cells' add places: a planned render stores every edge row's adds in ONE pass at the places the plan's own
+        # full pass left per cell (k_path_build<true>); with SVGR_NO_ADD_PLACES (read when the plan is made) it reserves them
+        # again and writes them in a second pass (k_path_build<false>): the same lists, the same bits
+        monkeypatch.setenv("SVGR_NO_ADD_PLACES", "1")
+        e = render(bands)
+        assert np.array_equal(a, e), f"add places from the plan change the picture (bands {bands})"
+        monkeypatch.delenv("SVGR_NO_ADD_PLACES", raising=False)
 
 
 def test_synth_8192_config4_windows(S):
