@@ -9,7 +9,7 @@ row scan, fill rule, paint, source-over) -> finished float32 RGBA canvas in HBM.
 
 N = 1: the bench scene (BASELINE.json's metric configuration: 4096 paths @ 4096 x 4096).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling of BASELINE.json's config 4 -- the ONE
+N > 1 (launched by torch.distributed.run, one rank per GPU -- or, without a launcher, by this file itself: launch_ranks): STRONG scaling of BASELINE.json's config 4 -- the ONE
 synthetic 10 000-path drawing @ 8192 x 8192, sharded over the N GPUs by strips of scanlines (one per GPU by default)
 (`svgr_batch_set_bands`; every rank culls the geometry to what reaches its strips; edges that cross a strip border are
 simply kept by both owners: duplicated geometry is the halo, no pixel crosses a GPU, no data-path collective).  Total work is
@@ -366,6 +366,52 @@ def contract_counts(got32, ref64):
             "what": "canvas of the last timed step, downloaded after the clock stopped"}
 
 
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): this process -- which has made no GPU
+    call and never makes one -- starts the N ranks itself, one fresh child per GPU with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set exactly as `torch.distributed.run --nnodes=1 --nproc-per-node N` would, relays rank 0's one
+    JSON line, and exits non-zero if any child does.  It refuses instead of printing a one-GPU line under `"n_gpus": 1`
+    when the box does not have N devices (unless the run is the one-GPU rehearsal: SVGR_BENCH_DEVICE + SVGR_BENCH_BACKEND=gloo)."""
+    import socket
+    import subprocess
+
+    if "SVGR_BENCH_DEVICE" not in os.environ:
+        try:
+            import torch  # (device_count() does not initialise the GPU on this image)
+
+            have = torch.cuda.device_count()
+        except Exception as exc:  # noqa: BLE001
+            raise SystemExit(f"[bench] --gpus {n}: cannot count the GPUs ({exc!r})")
+        if have < n:
+            raise SystemExit(f"[bench] --gpus {n}: this box has {have} GPU(s); not printing a smaller run under that flag "
+                             "(rehearsal on one GPU: SVGR_BENCH_BACKEND=gloo SVGR_BENCH_DEVICE=0)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    worker = os.environ.get("SVGR_BENCH_WORKER")   # (tests: a stub in the place of this file)
+    cmd = [sys.executable, worker or os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    if any(codes):
+        sys.stderr.write(f"[bench] rank exit codes {codes}\n")
+        for ln in lines:
+            sys.stderr.write(ln + "\n")
+        raise SystemExit(next(c for c in codes if c) if all(isinstance(c, int) for c in codes) else 1)
+    js = [ln for ln in lines if ln.lstrip().startswith("{")]
+    if len(js) != 1:
+        sys.stderr.write("\n".join(lines) + "\n")
+        raise SystemExit(f"[bench] rank 0 printed {len(js)} JSON lines, expected one")
+    print(js[0])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -380,6 +426,8 @@ def main():
                          "so timing every step would slow the thing being measured)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -401,7 +449,7 @@ def main():
             coll_dev = f"cuda:{local_rank}"
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
+    if args.gpus != world and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if args.workload is None:
         args.workload = "synth4096" if world == 1 else "synth8192"
@@ -691,4 +739,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

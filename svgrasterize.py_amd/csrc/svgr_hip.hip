@@ -1339,7 +1339,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     __shared__ __attribute__((aligned(16))) int s_pref[PB_BATCH + 4];
     __shared__ __attribute__((aligned(16))) int s_coarse[32];
     __shared__ int s_wtot[PB_EPL][PB_THREADS / 64];
-    __shared__ __attribute__((aligned(8))) int2 s_info[PB_CELLS];   // per cell: adds in front of it in its band, class | band << 2 | column tile << 8
+    __shared__ __attribute__((aligned(8))) int2 s_info[PB_CELLS];   // per cell: adds in front of it in its band, class
     __shared__ unsigned s_rowm[PB_CELLS];                           // ... rows with a carry-in add | rows with a sentinel << 16
     __shared__ int s_ptot[PB_BANDS], s_pidx[PB_BANDS], s_base, s_ok;
 #ifdef SVGR_DBG_PB_PADLDS
@@ -1682,7 +1682,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                     if (row_l == 0) {
                         if (PLANNED && own_n != s_plan_n[ci]) mismatch = true;
                         s_cnt[ci] = n_add;                                   // (the cell's whole list now)
-                        s_info[ci] = make_int2(cursor, cls | (g << 2) | (k << 8));
+                        s_info[ci] = make_int2(cursor, cls);
                         s_rowm[ci] = cm | (sm << 16);
                     }
                 }
@@ -1727,10 +1727,9 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             const int ci = i / TR, row_l = i & (TR - 1);
             const int2 info = s_info[ci];
             const unsigned rowm = s_rowm[ci];
-            const int cls = info.y & 3, g = (info.y >> 2) & 63, k = info.y >> 8;
+            const int cls = info.y & 3, g = ci / sl.nk, k = ci - g * sl.nk;   // (a cell of another rank's band was never walked: its s_info is empty)
             const int band = sl.band0 + g;
             if (!owns_band(own, band)) continue;
-            // (a cell the walk never reached -- g beyond the slab's bands cannot happen: n_cell = nb x nk)
             const int cell = cell_of(g, k);
             const int n_list = s_cnt[ci];
             const unsigned cm = rowm & 0xffffu, sm = rowm >> 16;
