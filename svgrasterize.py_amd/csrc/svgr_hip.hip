@@ -1304,12 +1304,25 @@ __device__ __forceinline__ unsigned add_where(int trow, int tcol, int len) {
 struct EdgeLds {
     double p0y, p1y, dxdy, x;  // as EdgeSetup; x = column at which the edge enters row ya
 };
+// x after the `n` rows y, y + 1, ... of the reference's recurrence (S:2244-2248), none of them the edge's last row: the column at
+// which the edge enters row y + n.  Only the first of them can be a partial row (the edge's first row: ylo = p0y); in every
+// later one dy = (y + 1) - y = 1.0 exactly, dxdy * 1.0 is dxdy, and row_step's `x + dxdy * dy` is `x + dxdy` bit for bit -- one
+// addition per replayed row instead of the whole step.
+__device__ __forceinline__ double replay_rows(double x, int y, int n, double p0y, double p1y, double dxdy) {
+    if (n <= 0) return x;
+    RowState st;
+    st.x_next = x; st.x = x; st.d = 0.0;
+    row_step(st, y, p0y, p1y, dxdy, 1.0);
+    double xn = st.x_next;
+    for (int k = 1; k < n; ++k) xn = xn + dxdy;
+    return xn;
+}
 static_assert(sizeof(EdgeLds) == 32, "EdgeLds is two 16-byte LDS reads (its first row and direction ride in an int array beside it)");
-#ifndef SVGR_PB_EPL
-#define SVGR_PB_EPL 2
+#ifndef SVGR_PB_BATCH
+#define SVGR_PB_BATCH 512
 #endif
-constexpr int PB_EPL = SVGR_PB_EPL;                // edges per lane and batch
-constexpr int PB_BATCH = PB_THREADS * PB_EPL;      // edges staged together
+constexpr int PB_BATCH = SVGR_PB_BATCH;            // edges staged together
+constexpr int PB_EPL = (PB_BATCH + PB_THREADS - 1) / PB_THREADS;   // edges per lane and batch
 static_assert(PB_BATCH % 64 == 0 && PB_BATCH / 16 <= 32, "two-level search: at most 32 coarse entries, read four at a time");
 static_assert(PB_BANDS * SVGR_TR * PB_BATCH < (1 << 20) && PB_BATCH < (1 << 11), "stage() scans row counts and live flags in one packed word");
 #ifndef SVGR_PB_WAVES
@@ -1381,6 +1394,10 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     // edges have -- and put into LDS by the first stage()
     int2 my_plan = make_int2((int)0x80000000, 0);
     bool plan_pending = false;
+    // (the place of the (path, band) pair of this lane's band in its band's list -- what the walk's lane 0 of every band sets
+    //  the entry-bitmask bits with: asked for here, a global load that has long landed when the walk starts)
+    int my_pidx = 0;
+    if ((tid & (TR - 1)) == 0 && tid / TR < sl.nb && owns_band(own, sl.band0 + tid / TR)) my_pidx = pair_idx[sl.pb_off + sl.band0 + tid / TR - sl.b0];
     if (PLANNED) {
         if (tid < n_cell) {
             const int g = tid / sl.nk, k = tid - g * sl.nk;
@@ -1400,7 +1417,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             const int e = eb + tid + j * PB_THREADS;
             cnt[j] = 0;
             el[j].p0y = el[j].p1y = el[j].dxdy = el[j].x = 0.0; eya[j] = 0;
-            if (e < e_end) {
+            if (e < e_end && tid + j * PB_THREADS < PB_BATCH) {
                 const double4 ed = ((const double4*)edges)[e];
                 const double ar = ed.x - o_r, ac = ed.y - o_c, br = ed.z - o_r, bc = ed.w - o_c;
                 const EdgeSetup es = edge_setup(ar, ac, br, bc, rows);
@@ -1410,11 +1427,8 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                     const int ya = es.y_begin > sr0 ? es.y_begin : sr0, yb = es.y_end < sr1 ? es.y_end : sr1;
                     if (ya < yb) {
                         cnt[j] = yb - ya;
-                        RowState st;
-                        st.x_next = es.x; st.x = es.x; st.d = 0.0;
                         // carry x from the edge's first row to the slab's, exactly as the walk would (S:2244-2248)
-                        for (int yy = es.y_begin; yy < ya; ++yy) row_step(st, yy, es.p0y, es.p1y, es.dxdy, es.dir);
-                        el[j].p0y = es.p0y; el[j].p1y = es.p1y; el[j].dxdy = es.dxdy; el[j].x = st.x_next;
+                        el[j].p0y = es.p0y; el[j].p1y = es.p1y; el[j].dxdy = es.dxdy; el[j].x = replay_rows(es.x, es.y_begin, ya - es.y_begin, es.p0y, es.p1y, es.dxdy);
                         eya[j] = ya | (es.dir < 0.0 ? (int)0x80000000 : 0);  // (ya >= 0)
                     }
                 }
@@ -1454,7 +1468,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             }
             // (behind the kept edges: larger than any task number, so that the searches stop in front of them)
             const int us = tid + j * PB_THREADS;
-            if (us >= n_live) {
+            if (us >= n_live && us < PB_BATCH) {
                 s_pref[us] = 0x7fffffff;
                 if ((us & 15) == 0) s_coarse[us >> 4] = 0x7fffffff;
             }
@@ -1516,8 +1530,9 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         double dir = ya_dir < 0 ? -1.0 : 1.0;
         int t_next = s_pref[slot + 1];   // first task of the next kept edge
         RowState st;
-        st.x_next = el.x; st.x = el.x; st.d = 0.0;
-        for (const int y1 = y + dy; y < y1; ++y) row_step(st, y, el.p0y, el.p1y, el.dxdy, dir);
+        st.x_next = replay_rows(el.x, y, dy, el.p0y, el.p1y, el.dxdy);
+        st.x = st.x_next; st.d = 0.0;
+        y += dy;
         for (; t < t1; ++t, ++y) {
             if (t == t_next) {
                 ++slot;
@@ -1595,7 +1610,11 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             const int pos = __hip_atomic_fetch_add(&s_cnt[ci], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&s_sum[ci * TR + trow], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_or(&s_rowb[ci], 1u << trow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef SVGR_DBG_PB_NOSTORE
+            if (STORE && ra.x0i == 123456789) {
+#else
             if (STORE) {
+#endif
                 const int first = s_pos[ci];
                 // (more pieces than the plan counted here, or a cell the plan has no place for: the walk flags the cell)
                 if (first < 0 || pos + ne > s_plan_n[ci]) continue;
@@ -1645,10 +1664,55 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
 #ifdef SVGR_DBG_PB_NOSCAN
     if (n_rows != 123456789) return;
 #endif
+    // what one lane (tile row row_l) writes of a cell of class 1 or 2: its carry-in (class 1: into the header; class 2: an add at
+    // the layer's first column in the tile, if any row piece lies left of the cell), its sentinel (behind the layer's last
+    // column), and -- lane 0 of the cell -- the header and the entry-bitmask bits
+    auto write_cell = [&](int g, int k, int cls, double cin, unsigned cm, unsigned sm, int own_n, int n_list, int add0, int row_l, int idx,
+                          bool slab_ok) -> bool {
+        const int band = sl.band0 + g;
+        const int cell = cell_of(g, k);
+        const bool mask_ok = (unsigned)(idx >> 6) < (unsigned)mask_words;  // (the plan sized the masks from the longest band list)
+        if (!(cell < cell_cap && slab_ok && mask_ok) || (PLANNED && cls == 2 && add0 < 0)) {
+            if (row_l == 0) atomicOr(&bd->err, 32);
+            return false;
+        }
+        CellHdr* hd = cell_hdr + cell;
+#if SVGR_X_CARRY1
+        if (cls == 1) hd->carry[row_l] = cin;   // (a class-2 cell's carry-ins are adds of its list: the tile kernel does not load this part of its header)
+#else
+        hd->carry[row_l] = cin;
+#endif
+        const int cell_c0 = (sl.k0 + k) * TC + x_first;       // layer column of the tile's column 0
+        const unsigned below = (1u << row_l) - 1u;
+        const int n_carry = __popc(cm);
+        if (((cm >> row_l) & 1u) && adds) {
+            // at the layer's first column in the tile
+            store_add(adds + ((size_t)add0 + own_n + __popc(cm & below)), add_where(row_l, cell_c0 < 0 ? -cell_c0 : 0, 1), cin);
+        }
+        if (((sm >> row_l) & 1u) && adds) {
+            // behind the layer's last column
+            store_add(adds + ((size_t)add0 + own_n + n_carry + __popc(sm & below)), add_where(row_l, cols - cell_c0, 1), __builtin_nan(""));
+        }
+        if (row_l == 0) {
+            // the tiles' entry bitmasks: per (band, column tile) two rows of mask_words words, bit i = entry i of the band's
+            // list has a cell of class >= 1 (row 0) / class 2 (row 1) here.  Classes 0 simply stay unset.
+            unsigned long long* const mw = tile_mask + ((size_t)band * n_ct + ct0 + sl.k0 + k) * 2 * mask_words + (idx >> 6);
+            const unsigned long long mbit = 1ull << (idx & 63);
+            atomicOr(mw, mbit);
+            if (cls == 2) atomicOr(mw + mask_words, mbit);
+            hd->paint[0] = paint.x; hd->paint[1] = paint.y; hd->paint[2] = paint.z; hd->paint[3] = paint.w;
+            hd->r0 = r0; hd->c0 = c0; hd->rows = rows; hd->cols = cols;
+            hd->bits = rule | (((rl >> 1) & 3) << 1) | (cls << 3) | (grad1 << 5);
+            hd->n_add = n_list; hd->add0 = add0; hd->p = p;
+            hd->group = group;
+        }
+        return true;
+    };
     {
-        // TR lanes per band of the slab (lane = tile row) go through the band's cells left to right.  The row's running sum
-        // replaces the cell's sum in s_sum (what the write phase needs is the carry-in); per cell: class, adds, and which rows
-        // have a carry-in / a sentinel (as bit masks of the band's TR lanes)
+        // TR lanes per band of the slab (lane = tile row) go through the band's cells left to right with the row's running sum
+        // = the carry-in; per cell: class, adds, and which rows have a carry-in / a sentinel (as bit masks of the band's TR lanes).
+        // PLANNED: the cell's place is known, so the lanes write the cell at once.  Else the row's running sum replaces the
+        // cell's sum in s_sum and the cell's description goes to LDS: the write phase needs the slab's reservation first.
         static_assert(TR <= 16, "k_path_build packs two TR-bit row masks into one word");
         constexpr unsigned long long GMASK = (1ull << TR) - 1ull;
         const int g = tid / TR, row_l = tid & (TR - 1);
@@ -1660,9 +1724,11 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         int cursor = 0;                                    // adds of the column tiles walked so far
         bool mismatch = false;
         if (__ballot(active) != 0ull) {  // (a wave none of whose bands exists has nothing to walk)
-            if (active && row_l == 0) s_pidx[g] = pair_idx[sl.pb_off + band - sl.b0];  // the pair's place in its band's list
+            const int idx = my_pidx;                           // the pair's place in its band's list
+            if (!PLANNED && active && row_l == 0) s_pidx[g] = idx;
             double run = sl.k0 > 0 ? s_left[row_l] : 0.0;      // the row's running sum left of the column tile
-            unsigned had = sl.k0 > 0 ? s_rowb[PB_CELLS] : 0u;  // tile rows with a piece left of the column tile (bit row_l: this lane's)
+            unsigned had = sl.k0 > 0 ? s_rowb[PB_CELLS] : 0u;  // tile rows with a piece left of the column tile
+            const unsigned sent_rows = (unsigned)((__ballot(active && row_in_layer) >> shift) & GMASK);
             for (int k = 0; k < sl.nk; ++k) {
                 const int ci = g * sl.nk + k;
                 const int own_n = active ? s_cnt[ci] : 0;
@@ -1675,15 +1741,19 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                 // class 2: the cell's add list = [pieces][a carry-in for every row with a piece left of the cell][sentinels]
                 const int t_end = cols - ((sl.k0 + k) * TC + x_first);     // tile column one past the layer's last column
                 const unsigned cm = cls == 2 ? had & (unsigned)GMASK : 0u;
-                const unsigned sm = cls == 2 && t_end < TC ? (unsigned)((__ballot(active && row_in_layer) >> shift) & GMASK) : 0u;
+                const unsigned sm = cls == 2 && t_end < TC ? sent_rows : 0u;
                 const int n_add = cls == 2 ? __popc(cm) + __popc(sm) + own_n : 0;
                 if (active) {
-                    s_sum[ci * TR + row_l] = cin;
-                    if (row_l == 0) {
-                        if (PLANNED && own_n != s_plan_n[ci]) mismatch = true;
-                        s_cnt[ci] = n_add;                                   // (the cell's whole list now)
-                        s_info[ci] = make_int2(cursor, cls);
-                        s_rowm[ci] = cm | (sm << 16);
+                    if (PLANNED) {
+                        if (row_l == 0 && own_n != s_plan_n[ci]) mismatch = true;
+                        if (cls != 0) write_cell(g, k, cls, cin, cm, sm, own_n, n_add, s_pos[ci], row_l, idx, true);
+                    } else {
+                        s_sum[ci * TR + row_l] = cin;
+                        if (row_l == 0) {
+                            s_cnt[ci] = n_add;                                   // (the cell's whole list now)
+                            s_info[ci] = make_int2(cursor, cls);
+                            s_rowm[ci] = cm | (sm << 16);
+                        }
                     }
                 }
                 cursor += n_add;
@@ -1693,8 +1763,6 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         }
         if (PLANNED) {
             if (mismatch) atomicOr(&bd->err, 32);  // (not the plan's geometry: its places do not hold -- as in k_path_bbox)
-            if (tid == 0) { s_base = 0; s_ok = 1; }
-            __syncthreads();
         } else {
             // the slab's reservation of add slots: ONE atomic, in the path's shard
             if (row_l == 0 && g < PB_BANDS) s_ptot[g] = active ? cursor : 0;
@@ -1719,66 +1787,33 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         }
     }
     PB_STAMP(3);
-    {
-        // write: one lane per (cell, tile row) -- headers, carry-ins and sentinels, the entry-bitmask bits; no lane idles
-        // through a band that does not exist
+    if (!PLANNED) {
+        // write: one lane per (cell, tile row); no lane idles through a band that does not exist.  Per cell {first add, pieces}
+        // into `cell_plan`: what the renders of this plan take their places from.
         const bool slab_ok = s_ok != 0;
         for (int i = tid; i < n_cell * TR; i += PB_THREADS) {
             const int ci = i / TR, row_l = i & (TR - 1);
             const int2 info = s_info[ci];
             const unsigned rowm = s_rowm[ci];
             const int cls = info.y & 3, g = ci / sl.nk, k = ci - g * sl.nk;   // (a cell of another rank's band was never walked: its s_info is empty)
-            const int band = sl.band0 + g;
-            if (!owns_band(own, band)) continue;
+            if (!owns_band(own, sl.band0 + g)) continue;
             const int cell = cell_of(g, k);
             const int n_list = s_cnt[ci];
             const unsigned cm = rowm & 0xffffu, sm = rowm >> 16;
-            const int n_carry = __popc(cm), n_sent = __popc(sm);
-            const int own_n = n_list - n_carry - n_sent;                    // (class 2: its pieces)
-            const int add0 = PLANNED ? s_pos[ci] : s_base + s_ptot[g] + info.x;
-            if (!PLANNED && row_l == 0 && cell < cell_cap) cell_plan[cell] = make_int2(cls == 2 && slab_ok ? add0 : (int)0x80000000, cls == 2 ? own_n : 0);
+            const int own_n = n_list - __popc(cm) - __popc(sm);                    // (class 2: its pieces)
+            const int add0 = s_base + s_ptot[g] + info.x;
+            if (row_l == 0 && cell < cell_cap) cell_plan[cell] = make_int2(cls == 2 && slab_ok ? add0 : (int)0x80000000, cls == 2 ? own_n : 0);
             if (cls == 0) continue;
-            const int idx = s_pidx[g];
-            const bool mask_ok = (unsigned)(idx >> 6) < (unsigned)mask_words;  // (the plan sized the masks from the longest band list)
-            if (!(cell < cell_cap && slab_ok && mask_ok) || (PLANNED && cls == 2 && add0 < 0)) {
-                if (row_l == 0) atomicOr(&bd->err, 32);
-                continue;
-            }
-            const double cin = s_sum[i];
-            CellHdr* hd = cell_hdr + cell;
-#if SVGR_X_CARRY1
-            if (cls == 1) hd->carry[row_l] = cin;   // (a class-2 cell's carry-ins are adds of its list: the tile kernel does not load this part of its header)
-#else
-            hd->carry[row_l] = cin;
-#endif
-            const int cell_c0 = (sl.k0 + k) * TC + x_first;       // layer column of the tile's column 0
-            const unsigned below = (1u << row_l) - 1u;
-            if (((cm >> row_l) & 1u) && adds) {
-                // at the layer's first column in the tile
-                store_add(adds + ((size_t)add0 + own_n + __popc(cm & below)), add_where(row_l, cell_c0 < 0 ? -cell_c0 : 0, 1), cin);
-            }
-            if (((sm >> row_l) & 1u) && adds) {
-                // behind the layer's last column
-                store_add(adds + ((size_t)add0 + own_n + n_carry + __popc(sm & below)), add_where(row_l, cols - cell_c0, 1), __builtin_nan(""));
-            }
-            if (row_l == 0) {
-                // the tiles' entry bitmasks: per (band, column tile) two rows of mask_words words, bit i = entry i of the band's
-                // list has a cell of class >= 1 (row 0) / class 2 (row 1) here.  Classes 0 simply stay unset.
-                unsigned long long* const mw = tile_mask + ((size_t)band * n_ct + ct0 + sl.k0 + k) * 2 * mask_words + (idx >> 6);
-                const unsigned long long mbit = 1ull << (idx & 63);
-                atomicOr(mw, mbit);
-                if (cls == 2) atomicOr(mw + mask_words, mbit);
-                hd->paint[0] = paint.x; hd->paint[1] = paint.y; hd->paint[2] = paint.z; hd->paint[3] = paint.w;
-                hd->r0 = r0; hd->c0 = c0; hd->rows = rows; hd->cols = cols;
-                hd->bits = rule | (((rl >> 1) & 3) << 1) | (cls << 3) | (grad1 << 5);
-                hd->n_add = n_list; hd->add0 = add0; hd->p = p;
-                hd->group = group;
-                if (!PLANNED && cls == 2 && adds) s_pos[ci] = add0;  // the pieces come first (pass B)
-            }
+            const bool ok = write_cell(g, k, cls, s_sum[i], cm, sm, own_n, n_list, add0, row_l, s_pidx[g], slab_ok);
+            if (ok && row_l == 0 && cls == 2 && adds) s_pos[ci] = add0;  // the pieces come first (pass B); a refused cell keeps "no place"
         }
     }
     PB_STAMP(4);
-    if (PLANNED || !adds) return;
+    if (PLANNED || !adds) {
+        PB_STAMP(5);
+        if (threadIdx.x == 0 && dbg && blockIdx.x < 8192) dbg[8 * blockIdx.x + 6] = (unsigned long long)n_rows;
+        return;
+    }
     __syncthreads();
 
     // ---- pass B ----  (PLANNED = false only)
