@@ -102,12 +102,17 @@ def bench_scene(args):
     launch it issues), result resident in HBM.  These configurations are bound by the host-side walk and per-node launch
     latencies, not by a kernel: the line carries the wall clock and canvas pixels/s; the per-kernel durations and HBM
     counters of the same command are in profiles/ (kernel_stats_<workload>*.csv, pmc_kernels_<workload>.json)."""
+    # (the cyclic collector pauses while a top-level Scene.render runs: opt-in, asked for here -- read when the package is imported)
+    os.environ.setdefault("SVGR_PAUSE_GC", "1")
+    import numpy as np
+
     import svgrasterize_amd as S
     from svgrasterize_amd import scenedump
 
     fname, desc = SCENE_WORKLOADS[args.workload]
+    S.set_render_cache(4)   # (opt-in: `ms_per_step` below is the re-render of an unchanged document; `cold_ms` what the default pays)
     ctx = S.Context.get(int(os.environ.get("LOCAL_RANK", "0")))
-    scene, info, _z = scenedump.load_scene(os.path.join(ROOT, "tests", "golden", fname))
+    scene, info, pins = scenedump.load_scene(os.path.join(ROOT, "tests", "golden", fname))
     h, w = info["size"]
     tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
 
@@ -140,6 +145,23 @@ def bench_scene(args):
     ctx.sync()
     dt = (time.perf_counter() - t0) / args.steps
     del keep
+    # the picture of a warm render against the reference's own (sparse pins of its full-size float32 canvas, made by
+    # oracle/gen_golden.py --full from the imported reference): after the clock has stopped
+    parity = None
+    try:
+        if "full_idx" in pins and "full_val" in pins:
+            layer, _hull = scene.render(tr, viewport=[0, 0, h, w], linear_rgb=False)
+            got = layer.to_canvas_f32(h, w).reshape(-1, 4)[pins["full_idx"]].astype(np.float64)
+            ref32 = np.asarray(pins["full_val"], dtype=np.float32)
+            a = np.abs(ref32)
+            ulp = np.maximum((np.nextafter(a, np.float32(np.inf)) - a).astype(np.float64), 2.0 ** -24)
+            err = np.abs(got - ref32.astype(np.float64))
+            parity = {"values": int(err.size), "bad": int((err > ulp).sum()), "max_err": float(err.max(initial=0.0)),
+                      "contract": "|got - f32(ref)| <= max(1 ULP_f32(ref), 2^-24)",
+                      "what": "pins of the REFERENCE's own render of this document at this size (tests/golden, sha256 of its canvas "
+                              f"{str(info.get('full', {}).get('sha256_f32', ''))[:16]}), checked on a warm render after the clock stopped"}
+    except Exception as exc:  # noqa: BLE001
+        parity = {"error": repr(exc)}
     counters, counters_file = load_counters(args.workload)
     stream = None
     if counters is not None:  # the streaming kernels of the per-node route: measured bytes over their own durations
@@ -157,6 +179,11 @@ def bench_scene(args):
         "warm_what": "ms_per_step re-renders an unchanged document: Scene.render retains the leaf analysis and the built + planned batches "
                      "of a (scene, transform, viewport) between renders; cold_ms drops that state before the render (best of 3), "
                      "first_render_ms is the process's very first render (library and kernel code loaded on the way)",
+        "parity": parity,
+        "host_options": {"SVGR_PAUSE_GC": os.environ.get("SVGR_PAUSE_GC"), "render_cache": "set_render_cache(4): OPT-IN, off by default",
+                         "SVGR_RENDER_CACHE_TRUST": os.environ.get("SVGR_RENDER_CACHE_TRUST"),
+                         "note": "a warm render compares the bytes of every paint array of the document before it reuses the retained "
+                                 "batches; cold_ms is what Scene.render costs with the cache off (the default)"},
         "dtype": "f64 arithmetic and f64 layers", "data": "real asset (scene dump)",
         "config": {"workload": desc, "canvas": [h, w]},
         "roofline": {"bound": "host", "note": "no kernel binds this configuration: the step is the Python tree walk plus hundreds of "

@@ -46,7 +46,8 @@ def main():
             ctx.sync()
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
-        rec = {"scene": desc, "canvas": [h, w], "render_s": round(best, 4), "canvas_mpix_per_s": round(h * w / best / 1e6, 1)}
+        rec = {"scene": desc, "canvas": [h, w], "render_s": round(best, 4), "canvas_mpix_per_s": round(h * w / best / 1e6, 1),
+               "render_cache": "off (the default: every render builds and plans its batches; S.set_render_cache(n) keeps them)"}
         if name in ("tiger", "material"):
             # output stage: straight-alpha sRGB + 8-bit quantisation on the device, bytes to the host,
             # then the PNG container (zlib) on the host

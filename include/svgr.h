@@ -32,8 +32,9 @@ extern "C" {
 /* 2: svgr_batch_set_groups, svgr_batch_set_gradients, svgr_batch_plan_many, svgr_batch_render_window added; svgr_gradient.n_stops
  *    no longer capped at 32; SVGR_RENDER_DETERMINISTIC
  * 3: SVGR_RENDER_SAME_GEOMETRY, SVGR_OUT_FILLS_F64, svgr_layer_convert_to, svgr_layer_scale_to, svgr_batch_render_windows added
- *    (nothing changed or removed) */
-#define SVGR_ABI_VERSION 3
+ *    (nothing changed or removed)
+ * 4: svgr_hash_buffers added (nothing changed or removed) */
+#define SVGR_ABI_VERSION 4
 
 typedef enum {
     SVGR_OK = 0,
@@ -102,6 +103,11 @@ int svgr_shutdown(svgr_ctx* ctx);
 int svgr_set_stream(svgr_ctx* ctx, void* hip_stream);
 int svgr_sync(svgr_ctx* ctx);
 int svgr_device_name(svgr_ctx* ctx, char* out, size_t cap);
+/* Host only, no GPU involved: a 64-bit hash over the bytes of `n` host buffers (ptrs[i], nbytes[i]), in order.  What the
+ * caller's retained renders guard themselves with: the reference's Scene.render (S:649-752) keeps nothing between calls, so a
+ * paint or a segment array edited in place is simply drawn with its new values; a caller that keeps built batches between
+ * renders of one document checks this hash of the document's arrays before it reuses them. */
+int svgr_hash_buffers(const void* const* ptrs, const int64_t* nbytes, int64_t n, uint64_t* out);
 
 int svgr_buf_alloc(svgr_ctx* ctx, size_t bytes, svgr_buf** out);
 int svgr_buf_wrap(svgr_ctx* ctx, void* device_ptr, size_t bytes, svgr_buf** out); /* non-owning */

@@ -21,11 +21,11 @@ from .filters import (  # noqa: F401
     FE_GAUSSIAN_BLUR, FE_MERGE, FE_MORPHOLOGY, FE_OFFSET,
 )
 from .scene import (  # noqa: F401
-    Scene, render_canvas, build_batch, clear_render_cache,
+    Scene, render_canvas, build_batch, clear_render_cache, set_render_cache,
     RENDER_FILL, RENDER_STROKE, RENDER_GROUP, RENDER_OPACITY, RENDER_CLIP, RENDER_MASK, RENDER_TRANSFORM, RENDER_FILTER,
 )
 from .fonts import Font, FontsDB, Glyph  # noqa: F401
 from .svg import render_svg, svg_scene, svg_scene_from_filepath, svg_scene_from_str  # noqa: F401
 
 __all__ = ["Scene", "Path", "Transform", "Layer", "ConvexHull", "render_canvas", "svg_scene", "svg_scene_from_str",
-           "svg_scene_from_filepath", "render_svg", "FontsDB", "clear_render_cache"]
+           "svg_scene_from_filepath", "render_svg", "FontsDB", "clear_render_cache", "set_render_cache"]

@@ -66,6 +66,7 @@ class PatternArgs(C.Structure):  # svgr_pattern
 _P = C.c_void_p
 _PROTOS = {
     "svgr_abi_version": (C.c_int, []),
+    "svgr_hash_buffers": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_uint64)]),
     "svgr_tile_rows": (C.c_int, []),
     "svgr_tile_cols": (C.c_int, []),
     "svgr_last_error": (C.c_char_p, []),
@@ -300,7 +301,10 @@ class Batch:
         self._stats = None
 
     def destroy(self):
+        """Free the batch now.  (Dropping the last reference does the same: callers that hand out lazy views of a batch -- the
+        hulls of Path.mask / Scene.render -- simply let go of it.)  A destroyed batch refuses every later call."""
         self._fin()
+        self.handle = None
 
     def plan(self) -> "BatchStats":
         _check(self.ctx.lib.svgr_batch_plan(self.handle))
@@ -428,6 +432,15 @@ class Batch:
         tot, geo, tile = C.c_double(), C.c_double(), C.c_double()
         _check(self.ctx.lib.svgr_batch_timings(self.handle, C.byref(n), C.byref(tot), C.byref(geo), C.byref(tile)))
         return dict(n=n.value, ms_total=tot.value, ms_geometry=geo.value, ms_tile=tile.value)
+
+
+def hash_buffers(ptrs: np.ndarray, sizes: np.ndarray) -> int:
+    """svgr_hash_buffers (host only): 64-bit hash over the bytes of the buffers (ptrs uint64, sizes int64)."""
+    lib = load_library()
+    out = C.c_uint64()
+    n = len(ptrs)
+    _check(lib.svgr_hash_buffers(ptrs.ctypes.data_as(_P), sizes.ctypes.data_as(_P), n, C.byref(out)))
+    return int(out.value)
 
 
 def path_stroke(seg_types, seg_params, subpath_sizes, width: float, linecap: int, linejoin: int):

@@ -790,7 +790,7 @@ static_assert(sizeof(PathBin) == 16, "PathBin is one dwordx4");
 // PB_CELLS cells: a path of up to PB_CELLS column tiles is cut into runs of bands, a wider one band by band into runs of
 // column tiles.
 #ifndef SVGR_PB_CELLS
-#define SVGR_PB_CELLS 120
+#define SVGR_PB_CELLS 80
 #endif
 #ifndef SVGR_PB_BANDS
 #define SVGR_PB_BANDS 16
@@ -1319,14 +1319,14 @@ __device__ __forceinline__ double replay_rows(double x, int y, int n, double p0y
 }
 static_assert(sizeof(EdgeLds) == 32, "EdgeLds is two 16-byte LDS reads (its first row and direction ride in an int array beside it)");
 #ifndef SVGR_PB_BATCH
-#define SVGR_PB_BATCH 512
+#define SVGR_PB_BATCH 256
 #endif
 constexpr int PB_BATCH = SVGR_PB_BATCH;            // edges staged together
 constexpr int PB_EPL = (PB_BATCH + PB_THREADS - 1) / PB_THREADS;   // edges per lane and batch
 static_assert(PB_BATCH % 64 == 0 && PB_BATCH / 16 <= 32, "two-level search: at most 32 coarse entries, read four at a time");
 static_assert(PB_BANDS * SVGR_TR * PB_BATCH < (1 << 20) && PB_BATCH < (1 << 11), "stage() scans row counts and live flags in one packed word");
 #ifndef SVGR_PB_WAVES
-#define SVGR_PB_WAVES 4
+#define SVGR_PB_WAVES 6
 #endif
 template <bool PLANNED>
 __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const Slab* __restrict__ slabs, const double* __restrict__ edges,
@@ -1374,6 +1374,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     const int n_slabs_now = bd->slab_cursor;
     if ((int)blockIdx.x >= n_slabs_now) return;  // (the grid covers the plan's slab capacity)
     if (sl.nb <= 0 || sl.nk <= 0) return;  // (a slot of a path that did not fit the slab list: flagged by k_path_bbox)
+    PB_STAMP(7);
     const int p = sl.p;
     const int r0 = sl.r0, c0 = sl.c0, rows = sl.rows, cols = sl.cols;
     int ct0, nct;
@@ -1434,6 +1435,9 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                 }
             }
         }
+#ifdef SVGR_DBG_PB_STAMP
+        if (PLANNED && eb == e_begin) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PB_STAMP(5); }
+#endif
         // one scan for both prefix sums: rows in bits 0-19, kept edges in bits 20-
         int excl[PB_EPL], wtot[PB_EPL];
 #pragma unroll
@@ -1810,7 +1814,9 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     }
     PB_STAMP(4);
     if (PLANNED || !adds) {
+#ifndef SVGR_DBG_PB_STAMP
         PB_STAMP(5);
+#endif
         if (threadIdx.x == 0 && dbg && blockIdx.x < 8192) dbg[8 * blockIdx.x + 6] = (unsigned long long)n_rows;
         return;
     }
@@ -3962,10 +3968,12 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                 for (size_t i = 0; i < n; ++i) {
                     for (int q = 0; q < 5; ++q) ph[q] += (double)(h[8 * i + q + 1] - h[8 * i + q]);
                     rows_ += (double)h[8 * i + 6];
-                    lo = std::min(lo, h[8 * i]); hi = std::max(hi, h[8 * i + 5]);
+                    lo = std::min(lo, h[8 * i]); hi = std::max(hi, h[8 * i + 3]);
                 }
-                fprintf(stderr, "[pb stamp] %zu slabs, mean us: stage %.2f  passA %.2f  walk %.2f  write %.2f  passB %.2f | rows/slab %.0f | span %.1f us\n", n,
-                        ph[0] / n / 100, ph[1] / n / 100, ph[2] / n / 100, ph[3] / n / 100, ph[4] / n / 100, rows_ / n, (double)(hi - lo) / 100);
+                double s_rec = 0, s_edges = 0;
+                for (size_t i = 0; i < n; ++i) { s_rec += (double)(h[8 * i + 7] - h[8 * i]); s_edges += (double)(h[8 * i + 5] - h[8 * i + 7]); }
+                fprintf(stderr, "[pb stamp] %zu slabs, mean us: stage %.2f (slab record %.2f, edges landed +%.2f)  passA %.2f  walk %.2f | rows/slab %.0f | span %.1f us\n", n,
+                        ph[0] / n / 100, s_rec / n / 100, s_edges / n / 100, ph[1] / n / 100, ph[2] / n / 100, rows_ / n, (double)(hi - lo) / 100);
                 if (const char* f = getenv("SVGR_DBG_PB_DUMP")) { if (FILE* fp = fopen(f, "wb")) { fwrite(h.data(), 8, h.size(), fp); fclose(fp); } }
             }
         }
@@ -4068,6 +4076,41 @@ static int check_gradient(const svgr_gradient* g) {
 extern "C" {
 
 int svgr_abi_version(void) { return SVGR_ABI_VERSION; }
+
+// 64-bit hash of host buffers (see svgr.h): eight bytes at a time through a multiply-xorshift mixer, the tail and every
+// buffer's length folded in.  Not cryptographic: it tells "edited in place" from "untouched".
+int svgr_hash_buffers(const void* const* ptrs, const int64_t* nbytes, int64_t n, uint64_t* out) {
+    if (n < 0 || !out || (n > 0 && (!ptrs || !nbytes))) return fail(SVGR_E_INVALID, "bad arguments");
+    auto mix = [](uint64_t h, uint64_t v) {
+        h ^= v * 0x9e3779b97f4a7c15ull;
+        h = (h ^ (h >> 29)) * 0xbf58476d1ce4e5b9ull;
+        return h ^ (h >> 32);
+    };
+    uint64_t h = 0x243f6a8885a308d3ull;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t len = nbytes[i];
+        if (len < 0 || (len > 0 && !ptrs[i])) return fail(SVGR_E_INVALID, "buffer %lld: bad pointer or size", (long long)i);
+        const unsigned char* p = (const unsigned char*)ptrs[i];
+        // four independent lanes: the multiplies of one word do not wait for the previous word's
+        uint64_t a = h, b = h ^ 0x13198a2e03707344ull, c = h ^ 0xa4093822299f31d0ull, d = h ^ 0x082efa98ec4e6c89ull;
+        int64_t k = 0;
+        for (; k + 32 <= len; k += 32) {
+            uint64_t w[4];
+            memcpy(w, p + k, 32);
+            a = mix(a, w[0]); b = mix(b, w[1]); c = mix(c, w[2]); d = mix(d, w[3]);
+        }
+        for (; k + 8 <= len; k += 8) {
+            uint64_t w;
+            memcpy(&w, p + k, 8);
+            a = mix(a, w);
+        }
+        uint64_t tail = 0;
+        if (k < len) memcpy(&tail, p + k, (size_t)(len - k));
+        h = mix(mix(mix(mix(mix(a, b), c), d), tail), (uint64_t)len);
+    }
+    *out = h;
+    return 0;
+}
 int svgr_tile_rows(void) { return TR; }
 int svgr_tile_cols(void) { return TC; }
 const char* svgr_last_error(void) { return g_err.c_str(); }

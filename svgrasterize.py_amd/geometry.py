@@ -17,6 +17,7 @@ from typing import Callable, Iterable, Sequence
 import numpy as np
 
 from . import _abi
+from ._state import STATE
 from .layer import Layer
 
 FLOAT = np.float64
@@ -426,9 +427,10 @@ class Path:
         """Render path as a mask (alpha channel only image), S:922-993.
 
         Returns ``(Layer, ConvexHull)`` or ``None``; the layer's image stays in HBM until read."""
-        if MASK_PREFETCH is not None:  # Scene.render rendered every mask it will need in one batch (scene.py)
-            hit = MASK_PREFETCH.get(self, transform, fill_rule, viewport)
-            if hit is not MASK_PREFETCH.MISS:
+        prefetch = STATE.mask_prefetch
+        if prefetch is not None:  # Scene.render rendered every mask it will need in one batch (scene.py)
+            hit = prefetch.get(self, transform, fill_rule, viewport)
+            if hit is not prefetch.MISS:
                 return hit
         res = self._single_batch(transform, fill_rule, viewport)
         if res is None:
@@ -447,9 +449,10 @@ class Path:
             return None
         if isinstance(paint, np.ndarray) and paint.shape == (4,):
             paint = solid_paint(paint, linear_rgb)
-            if FILL_PLANS:  # (a retained render keeps the plan for the next one: scene._Retained)
+            plans = STATE.fill_plans
+            if plans:  # (a retained render keeps the plan for the next one: scene._Retained)
                 fkey = fill_plan_key(self, transform, fill_rule, paint, viewport)
-                res = FILL_PLANS.get(fkey, _NO_PLAN) if FILL_PLANS_KEEP else FILL_PLANS.pop(fkey, _NO_PLAN)
+                res = plans.get(fkey, _NO_PLAN) if STATE.fill_plans_keep else plans.pop(fkey, _NO_PLAN)
             else:
                 res = _NO_PLAN
             if res is _NO_PLAN:  # (else: built and planned by Scene.render's pre-pass together with the document's other batches)
@@ -618,12 +621,8 @@ class MaskPrefetch:
         return self.table.get((id(path), transform.m6().tobytes(), _RULES[fill_rule]), self.MISS)
 
 
-MASK_PREFETCH: "MaskPrefetch | None" = None
-
-# Single-path solid fills of the per-node route that Scene.render's pre-pass has already built and planned (one wait for the
-# whole document, svgr_batch_plan_many): key -> (ctx, batch, bbox) or None (nothing to draw), consumed by Path.fill.
-FILL_PLANS: "dict | None" = None
-FILL_PLANS_KEEP = False   # Path.fill leaves the entry it uses in FILL_PLANS (Scene.render retains the plans between renders)
+# (the running render's MaskPrefetch and its pre-planned single-path fills -- key -> (ctx, batch, bbox) or None (nothing to draw),
+#  consumed by Path.fill -- live in _state.STATE, per thread: STATE.mask_prefetch, STATE.fill_plans, STATE.fill_plans_keep)
 _NO_PLAN = object()
 
 
@@ -631,7 +630,7 @@ def fill_plan_key(path, transform, fill_rule, paint4, viewport):
     return (id(path), transform.key(), fill_rule, paint4.tobytes(), None if viewport is None else tuple(int(v) for v in viewport))
 
 
-RENDER_SERIAL = [0]   # counts top-level Scene.render calls (scene.py): the shared fills are drawn once per render
+# (STATE.serial numbers the top-level Scene.render calls (scene.py): the shared fills are drawn once per render)
 _SHARE_FILLS = __import__("os").environ.get("SVGR_NO_SHARED_FILLS") is None
 
 
@@ -645,9 +644,9 @@ class _FillSet:
         self.batch, self.refs, self.serial, self.buf, self.offs, self._edges = batch, refs, -1, None, None, None
 
     def draw(self):
-        if self.serial != RENDER_SERIAL[0] or self.buf is None:
+        if self.serial != STATE.serial or self.buf is None:
             self.buf, self.offs, _bb = self.batch.render_fills()   # (a fresh buffer: the layers of the last render may still be in use)
-            self.serial = RENDER_SERIAL[0]
+            self.serial = STATE.serial
         return self.buf, self.offs
 
     def all_edges(self):

@@ -25,6 +25,7 @@ import textwrap
 import numpy as np
 
 from . import _abi
+from ._state import STATE, next_serial
 from .geometry import ConvexHull, Path, Transform, solid_paint, _RULES, FLATNESS
 from .layer import COMPOSE_IN, COMPOSE_OVER, Layer
 
@@ -35,13 +36,26 @@ RENDER_CLIP, RENDER_MASK, RENDER_TRANSFORM, RENDER_FILTER = 4, 5, 6, 7
 class _Retained:
     """What a top-level ``Scene.render`` keeps for the NEXT render of the same (scene, transform, viewport, colour space):
     the leaf analysis of every group child, the jobs of the mask pre-pass with their built and planned batch, the runs' and
-    the per-node fills' built and planned batches with everything derived from their bboxes.  Scene nodes and paths are
-    immutable (tuples / frozen segment lists), so a second render of an unchanged document is the walk plus launches: no
-    leaf analysis, no batch building, no plan (VERDICT r3 #5a).  Keyed by identity: the entry holds the scene, so its id cannot
-    come back as another scene's.  ``SVGR_RENDER_CACHE`` = entries kept (default 4, 0: off); ``clear_render_cache()`` drops
-    them and their device buffers."""
+    the per-node fills' built and planned batches with everything derived from their bboxes.  A second render of an unchanged
+    document is the walk plus launches: no leaf analysis, no batch building, no plan (VERDICT r3 #5a).
 
-    __slots__ = ("scene", "leaf_memo", "jobs", "run_plans", "fill_plans", "mask_state")
+    OPT-IN (``SVGR_RENDER_CACHE`` = entries kept, or ``set_render_cache(n)``; default 0): the reference's ``Scene.render``
+    keeps nothing between calls (S:649-752), and a document whose arrays are edited in place between two renders is simply drawn
+    with the new values.  A caller who turns the cache on promises to treat a rendered scene as a value.  Half of that promise is
+    checked anyway: the entry is keyed by identity (it holds the scene, so its id cannot come back as another scene's) and
+    GUARDED by content for the paints -- every ``np.ndarray`` reachable from the scene outside its paths (solid colours,
+    gradient vectors, stop colours) is listed when the entry is made and their bytes are compared before the entry is used
+    again (solid colours stacked into one array, the rest through `svgr_hash_buffers`); on a mismatch the render starts over.
+    Path geometry is NOT re-read: a `Path` is a value type here as in the reference (S:899-907: its methods return new paths)
+    and has kept a packed copy of its segments since round 1 (`Path.packed`), with or without this cache -- listing the
+    ~30 000 segment arrays of material-design.svg costs more than rendering it.  ``SVGR_RENDER_CACHE_TRUST`` skips the check;
+    ``clear_render_cache()`` drops the entries.
+
+    Dropping an entry only drops references: a batch frees its device memory when its last user is gone
+    (`_abi.Batch`'s finalizer) -- the lazy hulls of layers handed out by earlier renders read their batch's edges on first use,
+    possibly after the entry that built the batch has been evicted."""
+
+    __slots__ = ("scene", "leaf_memo", "jobs", "run_plans", "fill_plans", "mask_state", "colours", "others", "ptrs", "sizes", "digest")
 
     def __init__(self, scene):
         self.scene = scene
@@ -50,31 +64,76 @@ class _Retained:
         self.run_plans = {}
         self.fill_plans = {}
         self.mask_state = {}
+        self.colours = self.others = self.ptrs = self.sizes = self.digest = None
 
-    def destroy(self):
-        for entry in self.run_plans.values():
-            entry[1].destroy()
+    def fingerprint(self):
+        """List the scene's paint arrays (first call) and take their bytes / hash them."""
+        if self.colours is None:
+            arrays, seen = [], set()
+            _paint_arrays(self.scene, arrays, seen)
+            self.colours = [a for a in arrays if a.shape == (4,) and a.dtype == np.float64]
+            self.others = [a for a in arrays if not (a.shape == (4,) and a.dtype == np.float64)]
+            self.ptrs = np.array([a.__array_interface__["data"][0] for a in self.others], dtype=np.uint64)
+            self.sizes = np.array([a.nbytes for a in self.others], dtype=np.int64)
+        stacked = np.array(self.colours).tobytes() if self.colours else b""
+        return (stacked, _abi.hash_buffers(self.ptrs, self.sizes) if len(self.others) else 0)
+
+    def release(self):
         self.run_plans = {}
-        for entry in self.fill_plans.values():
-            if entry is not None:
-                entry[1].destroy()
         self.fill_plans = {}
-        keep = self.mask_state.get("keep")
-        if keep is not None:
-            keep.destroy()
         self.mask_state = {}
+        self.leaf_memo = {}
+
+    def sweep_on_demand(self, serial):
+        """Runs that were built during a render, not by the pre-pass (inside bbox-relative masks, pattern tiles, ...), are kept
+        only while their key keeps coming back: leaves that the walk makes afresh in every render never match again, and
+        their batches would pile up."""
+        dead = [k for k, e in self.run_plans.items() if len(e) > 4 and e[4] != serial]
+        for k in dead:
+            del self.run_plans[k]
+
+
+def _paint_arrays(obj, arrays, seen, depth=0):
+    """Every C-contiguous ndarray reachable from a scene tree OUTSIDE its paths: solid paints, gradient fields, stop colours."""
+    if isinstance(obj, np.ndarray):
+        if id(obj) not in seen and obj.flags.c_contiguous and obj.dtype != object:
+            seen.add(id(obj))
+            arrays.append(obj)
+        return
+    if isinstance(obj, Path):
+        return
+    if isinstance(obj, (tuple, list)) and depth < 64:
+        for item in obj:
+            if not isinstance(item, (int, float, str, bool, type(None))):
+                _paint_arrays(item, arrays, seen, depth + 1)
+        return
+    sub = getattr(obj, "scene", None)      # a Pattern's tile
+    if isinstance(sub, tuple):
+        _paint_arrays(sub, arrays, seen, depth + 1)
 
 
 _RETAINED: "dict[tuple, _Retained]" = {}   # (insertion-ordered: the oldest entry goes first)
-_RETAINED_MAX = int(__import__("os").environ.get("SVGR_RENDER_CACHE", "4"))
-_RETAIN: "_Retained | None" = None         # the state of the top-level render that is running
+_RETAINED_LOCK = __import__("threading").Lock()
+_RETAINED_MAX = int(__import__("os").environ.get("SVGR_RENDER_CACHE", "0"))   # (opt-in: see _Retained)
+_RETAINED_TRUST = __import__("os").environ.get("SVGR_RENDER_CACHE_TRUST") is not None
+
+
+def set_render_cache(entries: int) -> None:
+    """Keep the built and planned batches of the last `entries` (scene, transform, viewport) renders for the next render of
+    the same one (0: off, the default -- see `_Retained` for what the caller promises)."""
+    global _RETAINED_MAX
+    _RETAINED_MAX = max(int(entries), 0)
+    if _RETAINED_MAX == 0:
+        clear_render_cache()
 
 
 def clear_render_cache() -> None:
-    """Drop what ``Scene.render`` retained between renders (and the device buffers of the retained batches)."""
-    for st in _RETAINED.values():
-        st.destroy()
-    _RETAINED.clear()
+    """Drop what ``Scene.render`` retained between renders (the device buffers go when their last user does)."""
+    with _RETAINED_LOCK:
+        entries = list(_RETAINED.values())
+        _RETAINED.clear()
+    for st in entries:
+        st.release()
 
 
 class Scene(tuple):
@@ -199,21 +258,27 @@ class Scene(tuple):
         run of fills the walk will meet and plans them all behind one wait (``svgr_batch_plan_many``)."""
         from . import geometry  # noqa: PLC0415
 
-        global _LEAF_MEMO, _RUN_PLANS, _RETAIN
         # (a render inside a render -- a pattern's tile -- walks without a pre-pass of its own: the outer call's state stays)
-        if _LEAF_MEMO is not None or geometry.MASK_PREFETCH is not None or viewport is None or self[0] in (RENDER_FILL, RENDER_STROKE):
+        if STATE.leaf_memo is not None or STATE.mask_prefetch is not None or viewport is None or self[0] in (RENDER_FILL, RENDER_STROKE):
             return self._render(transform, mask_only, viewport, linear_rgb)
         key = (id(self), transform.key(), tuple(int(v) for v in viewport), bool(linear_rgb), bool(mask_only))
-        st = _RETAINED.pop(key, None) if _RETAINED_MAX > 0 else None   # (popped: re-inserted as the youngest when the render succeeds)
+        st = None
+        if _RETAINED_MAX > 0:
+            with _RETAINED_LOCK:
+                st = _RETAINED.pop(key, None)   # (taken out: re-inserted as the youngest when the render succeeds)
+        if st is not None and not _RETAINED_TRUST and st.fingerprint() != st.digest:
+            # a paint of the document was edited in place since the entry was made: the reference would draw the new values
+            st.release()
+            st = None
         warm = st is not None
         if st is None:
             st = _Retained(self)
-        _LEAF_MEMO = st.leaf_memo
-        _RETAIN = st if _RETAINED_MAX > 0 else None
-        _RENDER_SERIAL[0] += 1
-        geometry.RENDER_SERIAL[0] = _RENDER_SERIAL[0]
+        STATE.leaf_memo = st.leaf_memo
+        STATE.retain = st if _RETAINED_MAX > 0 else None
+        STATE.serial = next_serial()
         # the walk allocates thousands of short-lived tuples and no cycles: the cyclic collector's generation-0 sweeps find
-        # nothing and cost 0.5-2.5 ms of a 17 ms render (profiles/gc_experiment.py), so it pauses for the call
+        # nothing and cost 0.5-2.5 ms of a 17 ms render (profiles/gc_experiment.py).  Pausing it is a side effect on the
+        # caller's process, so it is opt-in: SVGR_PAUSE_GC=1 (bench.py's scene workloads set it and say so)
         gc_paused = _PAUSE_GC and gc.isenabled()
         if gc_paused:
             gc.disable()
@@ -228,26 +293,32 @@ class Scene(tuple):
                 if len(runs) + len(fills) >= 2:
                     st.run_plans, st.fill_plans = _plan_runs(runs, fills, viewport, linear_rgb)
             if len(st.jobs) >= 4:
-                geometry.MASK_PREFETCH = geometry.MaskPrefetch(st.jobs, viewport, st.mask_state if _RETAIN is not None else None)
-            _RUN_PLANS, geometry.FILL_PLANS = st.run_plans, st.fill_plans
-            geometry.FILL_PLANS_KEEP = _RETAIN is not None
+                STATE.mask_prefetch = geometry.MaskPrefetch(st.jobs, viewport, st.mask_state if STATE.retain is not None else None)
+            STATE.run_plans, STATE.fill_plans = st.run_plans, st.fill_plans
+            STATE.fill_plans_keep = STATE.retain is not None
             _prefetch_windows(st.run_plans)
             res = self._render(transform, mask_only, viewport, linear_rgb)
             ok = True
             return res
         finally:
-            geometry.MASK_PREFETCH = None
-            _LEAF_MEMO = None
-            _RUN_PLANS = None
-            geometry.FILL_PLANS = None
-            geometry.FILL_PLANS_KEEP = False
-            _RETAIN = None
+            serial = STATE.serial
+            STATE.mask_prefetch = None
+            STATE.leaf_memo = None
+            STATE.run_plans = None
+            STATE.fill_plans = None
+            STATE.fill_plans_keep = False
+            STATE.retain = None
             if ok and _RETAINED_MAX > 0:
-                _RETAINED[key] = st
-                while len(_RETAINED) > _RETAINED_MAX:
-                    _RETAINED.pop(next(iter(_RETAINED))).destroy()
+                st.sweep_on_demand(serial)
+                if not warm and not _RETAINED_TRUST:
+                    st.digest = st.fingerprint()
+                with _RETAINED_LOCK:
+                    _RETAINED[key] = st
+                    evicted = [_RETAINED.pop(next(iter(_RETAINED))) for _ in range(max(len(_RETAINED) - _RETAINED_MAX, 0))]
+                for old_st in evicted:
+                    old_st.release()
             else:
-                st.destroy()   # (a failed render keeps nothing; with the cache off: the runs the walk did not come to after all)
+                st.release()   # (a failed render keeps nothing; with the cache off: the runs the walk did not come to after all)
             if gc_paused:
                 gc.enable()
 
@@ -401,8 +472,8 @@ def _collect_mask_jobs(scene: Scene, transform: Transform, mask_only: bool, line
         _collect_mask_jobs(args[0], transform, mask_only, linear_rgb, jobs, runs, fills)
 
 
-_RUN_PLANS: "dict | None" = None  # during one top-level render: run key -> (leaves, planned batch), from the pre-pass
-_RENDER_SERIAL = [0]               # counts top-level renders: a shared batch runs its geometry once per render
+# (STATE.run_plans: during one top-level render, run key -> [leaves, planned batch, ...] from the pre-pass; STATE.serial numbers the
+#  top-level renders: a shared batch runs its geometry once per render)
 
 # The runs of a document share ONE device batch (the filter nodes cut icons.svg's paint order into dozens of
 # runs, each a batch of its own with its own five geometry launches and its own plan).  Every run gets a range of rows of a
@@ -465,9 +536,9 @@ class _RunView:
 
     def render(self, out, kind, flags=0, window=None):
         sh = self.shared
-        if sh.serial == _RENDER_SERIAL[0]:
+        if sh.serial == STATE.serial:
             flags |= _abi.RENDER_SAME_GEOMETRY   # (another run of the same render drew from this batch already)
-        sh.serial = _RENDER_SERIAL[0]
+        sh.serial = STATE.serial
         r0, c0, rows, cols = window
         sh.batch.render(out, kind, flags, window=(r0 + self.shift, c0, rows, cols))
 
@@ -629,18 +700,18 @@ def _plan_runs(runs, fills, viewport, linear_rgb):
     return plans, fill_plans
 
 
-_LEAF_MEMO: "dict | None" = None  # during one top-level render: what the pre-pass already found out about group children
 
 
 def _leaves_memo(child: Scene, transform: Transform, linear_rgb: bool, store: bool = False):
-    if _LEAF_MEMO is None:
+    memo = STATE.leaf_memo
+    if memo is None:
         return _batchable_leaves(child, transform, linear_rgb)
     key = (id(child), transform.key(), linear_rgb)
-    if key in _LEAF_MEMO:
-        return _LEAF_MEMO[key]
+    if key in memo:
+        return memo[key]
     res = _batchable_leaves(child, transform, linear_rgb)
     if store:
-        _LEAF_MEMO[key] = res
+        memo[key] = res
     return res
 
 
@@ -665,7 +736,7 @@ _GROUP_SERIAL = [0]
 _BATCH_GROUPS = __import__("os").environ.get("SVGR_NO_BATCH_GROUPS") is None  # (off: isolated groups take the per-node route)
 _BATCH_GRADS = __import__("os").environ.get("SVGR_NO_BATCH_GRADIENTS") is None  # (off: gradient fills take the per-node route)
 _ONES = np.ones(4)
-_PAUSE_GC = __import__("os").environ.get("SVGR_KEEP_GC") is None  # (set: leave the cyclic collector alone during Scene.render)
+_PAUSE_GC = __import__("os").environ.get("SVGR_PAUSE_GC") is not None  # (set: the cyclic collector pauses for the duration of a top-level Scene.render)
 _GRAD_ABI_MEMO: dict = {}  # (id(gradient), transform bytes, linear_rgb) -> (gradient, svgr_gradient struct, keep-alive)
 
 
@@ -716,12 +787,13 @@ def _plain(leaves) -> bool:
 def _batchable_leaves(scene: Scene, transform: Transform, linear_rgb: bool, opacity: float | None = None):
     """Memo in front of `_batchable_leaves_`: during one top-level render the same (node, transform) is asked about once per
     enclosing group that turned out not to be batchable."""
-    if _LEAF_MEMO is None or scene[0] == RENDER_FILL:
+    memo = STATE.leaf_memo
+    if memo is None or scene[0] == RENDER_FILL:
         return _batchable_leaves_(scene, transform, linear_rgb, opacity)
     key = (id(scene), transform.key(), linear_rgb, opacity, "sub")
-    if key in _LEAF_MEMO:
-        return _LEAF_MEMO[key]
-    res = _LEAF_MEMO[key] = _batchable_leaves_(scene, transform, linear_rgb, opacity)
+    if key in memo:
+        return memo[key]
+    res = memo[key] = _batchable_leaves_(scene, transform, linear_rgb, opacity)
     return res
 
 
@@ -880,29 +952,35 @@ def _render_run(leaves, viewport, linear_rgb):
     """One batch -> one Layer covering the union of the leaves' bboxes (what Layer.compose of
     the individual fill layers returns, S:366-379)."""
     ctx = _abi.Context.get()
-    rkey = _run_key(leaves, viewport) if leaves and viewport is not None and (_RUN_PLANS is not None) else None
+    run_plans, retain, serial = STATE.run_plans, STATE.retain, STATE.serial
+    rkey = _run_key(leaves, viewport) if leaves and viewport is not None and (run_plans is not None) else None
     pre = None
     if rkey is not None:
-        pre = _RUN_PLANS.get(rkey) if _RETAIN is not None else _RUN_PLANS.pop(rkey, None)
+        pre = run_plans.get(rkey) if retain is not None else run_plans.pop(rkey, None)
     if pre is not None:
         leaves, batch = pre[0], pre[1]  # (built and planned by the pre-pass of Scene.render -- of this render or of an earlier one)
+        if len(pre) > 4:
+            pre[4] = serial             # (an on-demand entry that came back: it stays for another render)
     else:
         leaves = _drop_empty(leaves)
         if not leaves:
             return None
         batch = build_batch(leaves, viewport, ctx)
         batch.plan()
-        if _RETAIN is not None and rkey is not None:
-            pre = _RUN_PLANS[rkey] = [leaves, batch]
-    if pre is not None and len(pre) > 2:
+        if retain is not None and rkey is not None:
+            # (built on demand: kept as long as its key keeps coming back, _Retained.sweep_on_demand)
+            pre = run_plans[rkey] = [leaves, batch, None, None, serial]
+    if pre is not None and len(pre) > 2 and pre[3] is not None:
         win, in_hull = pre[2], pre[3]   # (its window and hull membership were worked out by the pre-pass or by the first render)
     else:
         win, in_hull = _run_window(leaves, batch)
-        if pre is not None and _RETAIN is not None:
+        if pre is not None and retain is not None:
             if len(pre) == 2:
-                pre = _RUN_PLANS[rkey] = [pre[0], pre[1], win, in_hull]
+                pre = run_plans[rkey] = [pre[0], pre[1], win, in_hull]
+            else:
+                pre[2], pre[3] = win, in_hull
     if win is None:
-        if pre is None or _RETAIN is None:
+        if pre is None or retain is None:
             batch.destroy()
         return None
     ur0, uc0, urows, ucols = win
@@ -910,7 +988,7 @@ def _render_run(leaves, viewport, linear_rgb):
     # not touched, and the layer needs no crop
     shape = (urows, ucols, 4)
     ready = getattr(batch, "ready", None)
-    if ready is not None and ready[0] == _RENDER_SERIAL[0]:
+    if ready is not None and ready[0] == serial:
         out, batch.ready = ready[1], None   # (drawn by `_prefetch_windows` together with the document's other runs)
     else:
         out = ctx.alloc(urows * ucols * 32)
@@ -968,7 +1046,7 @@ def _prefetch_windows(run_plans):
         by_batch.setdefault(id(view.shared), (view.shared, []))[1].append((view, win))
     if total > _PREFETCH_MAX_BYTES:
         return
-    serial = _RENDER_SERIAL[0]
+    serial = STATE.serial
     for shared, items in by_batch.values():
         if len(items) < 2:
             continue

@@ -268,11 +268,13 @@ def test_mask_prefetch_is_only_a_cache(S):
     scene = S.Scene.group(kids)
     got = scene.render(swap, viewport=vp, linear_rgb=False)
     # the same render with the prefetch disabled (every mask on demand)
-    geometry.MASK_PREFETCH = type("Off", (), {"MISS": object(), "get": lambda self, *a: self.MISS})()
+    from svgrasterize_amd._state import STATE
+
+    STATE.mask_prefetch = type("Off", (), {"MISS": object(), "get": lambda self, *a: self.MISS})()
     try:
         want = scene.render(swap, viewport=vp, linear_rgb=False)
     finally:
-        geometry.MASK_PREFETCH = None
+        STATE.mask_prefetch = None
     assert tuple(got[0].offset) == tuple(want[0].offset) and got[0].image.shape == want[0].image.shape
     assert_close64(got[0].image, want[0].image, atol=1e-12, what="prefetched vs on-demand masks")
     # the multi-mask output itself against single-path masks

@@ -214,6 +214,90 @@ def test_a_second_render_of_an_unchanged_scene_reuses_the_first_ones_plans(S, na
         assert np.array_equal(pts, shots[0][2])
 
 
+def _two_blobs(S, colour):
+    a = S.Path.from_svg("M10,10 C40,0 70,20 60,50 C50,80 20,70 10,40 Z")
+    a = S.Path([[(t, np.array(pts, dtype=np.float64)) for t, pts in sub] for sub in a.subpaths])   # (segments as arrays, S:899-907)
+    b = S.Path.from_svg("M30,30 L90,35 L85,90 L35,85 Z")
+    return S.Scene.group([S.Scene.fill(a, colour, None), S.Scene.fill(b, np.array([0.1, 0.2, 0.6, 0.7]), "evenodd"),
+                          S.Scene.fill(a, np.array([0.0, 0.3, 0.0, 0.3]), None).transform(S.Transform().translate(20, 15))]), a, b
+
+
+def test_the_retained_render_notices_arrays_edited_in_place(S, monkeypatch):
+    """The reference keeps nothing between renders (S:649-752): a paint edited in place is drawn with its new values.  The
+    (opt-in) retained entry of a scene is guarded by the bytes of the scene's paint arrays: after an in-place edit the next
+    render is a cold one, and its picture is the new one.  (Path geometry is a value: `Path.packed` has kept a copy since
+    round 1, with or without the cache.)"""
+    from svgrasterize_amd import scene as scene_mod
+
+    monkeypatch.setattr(scene_mod, "_RETAINED_MAX", 4)
+    monkeypatch.setattr(scene_mod, "_RETAINED_TRUST", False)
+    S.clear_render_cache()
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    vp = [0, 0, 128, 128]
+    colour = np.array([0.8, 0.1, 0.1, 0.9])
+    scene, _a, _b = _two_blobs(S, colour)
+    first = np.array(scene.render(tr, viewport=vp)[0].image)
+    again = np.array(scene.render(tr, viewport=vp)[0].image)      # (warm: the retained batches)
+    assert np.abs(first - again).max() <= 1e-12
+    # a paint edited in place
+    colour[:] = [0.1, 0.7, 0.2, 0.8]
+    got = scene.render(tr, viewport=vp)[0]
+    fresh_scene, _a2, _b2 = _two_blobs(S, colour.copy())
+    S.clear_render_cache()
+    want = fresh_scene.render(tr, viewport=vp)[0]
+    assert tuple(got.offset) == tuple(want.offset) and got.image.shape == want.image.shape
+    assert np.abs(np.array(got.image) - np.array(want.image)).max() <= 1e-12
+    assert np.abs(np.array(got.image) - first).max() > 0.05        # (and it is not the old picture)
+    S.clear_render_cache()
+
+
+def test_hulls_outlive_the_retained_entry_that_built_their_batch(S, monkeypatch):
+    """`Scene.render` returns a LAZY hull: it reads its batch's edges on first use.  Clearing the cache (or evicting the
+    entry) only drops references; the batch lives until the hull does (it used to be freed under the hull)."""
+    from svgrasterize_amd import scene as scene_mod
+
+    monkeypatch.setattr(scene_mod, "_RETAINED_MAX", 1)
+    S.clear_render_cache()
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    vp = [0, 0, 128, 128]
+    scene, _a, _b = _two_blobs(S, np.array([0.8, 0.1, 0.1, 0.9]))
+    _layer, hull = scene.render(tr, viewport=vp)
+    other, _a2, _b2 = _two_blobs(S, np.array([0.3, 0.3, 0.1, 0.5]))
+    other.render(tr.translate(1, 1), viewport=vp)                   # (evicts the first entry: the cache holds one)
+    S.clear_render_cache()
+    pts = np.array(hull.points)                                     # first use of the hull: after eviction AND clear
+    _layer2, hull2 = scene.render(tr, viewport=vp)
+    assert pts.shape[0] >= 3 and np.array_equal(pts, np.array(hull2.points))
+    S.clear_render_cache()
+
+
+def test_runs_built_on_demand_do_not_pile_up_in_a_retained_entry(S, monkeypatch):
+    """A run the pre-pass does not see (inside an objectBoundingBox mask: its transform comes from the target's hull) is built
+    while the walk runs, from leaves that are made afresh in every render: its key never comes back.  The retained entry keeps
+    such a run for one render at most (the entry used to grow by one planned batch per render)."""
+    from svgrasterize_amd import scene as scene_mod
+
+    monkeypatch.setattr(scene_mod, "_RETAINED_MAX", 4)
+    S.clear_render_cache()
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    vp = [0, 0, 128, 128]
+    scene, a, b = _two_blobs(S, np.array([0.8, 0.1, 0.1, 0.9]))
+    unit = S.Path.from_svg("M0.1,0.1 L0.9,0.1 L0.9,0.9 L0.1,0.9 Z")
+    unit2 = S.Path.from_svg("M0.3,0.2 L0.8,0.3 L0.6,0.8 Z")
+    mask_scene = S.Scene.group([S.Scene.fill(unit, np.array([1.0, 1.0, 1.0, 1.0]), None), S.Scene.fill(unit2, np.array([0.2, 0.2, 0.2, 1.0]), None)])
+    doc = S.Scene.group([scene, S.Scene.fill(b, np.array([0.5, 0.1, 0.5, 0.8]), None).mask(mask_scene, True), scene.transform(S.Transform().translate(3, 2))])
+    sizes, shots = [], []
+    for _ in range(5):
+        layer, _hull = doc.render(tr, viewport=vp)
+        shots.append(np.array(layer.image))
+        st = next(iter(scene_mod._RETAINED.values()))
+        sizes.append(len(st.run_plans))
+    assert max(sizes[1:]) == min(sizes[1:]), sizes                  # stable from the second render on
+    for img in shots[1:]:
+        assert np.abs(img - shots[0]).max() <= 1e-12
+    S.clear_render_cache()
+
+
 def test_prompt_text_outlines(S):
     """demo/prompt.svg at width 256: glyph outlines set by the reference's fonts, a 9 x 256 strip."""
     scene, z, r, tr, hh, ww = _render_dump(S, "prompt", "s9")

@@ -242,7 +242,7 @@ def test_gpu_runs_of_a_document_are_planned_together(monkeypatch):
 
     def render_run(leaves, viewport, linear_rgb):
         seen["runs"] += 1
-        if sm._RUN_PLANS and leaves and sm._run_key(leaves, viewport) in sm._RUN_PLANS:
+        if sm.STATE.run_plans and leaves and sm._run_key(leaves, viewport) in sm.STATE.run_plans:
             seen["hits"] += 1
         before = seen["single_plans"]
         out = orig_render_run(leaves, viewport, linear_rgb)
@@ -265,7 +265,7 @@ def test_gpu_runs_of_a_document_are_planned_together(monkeypatch):
     # the solid fills that go node by node (children of filter nodes ...) were planned in the same wait and all picked up
     from svgrasterize_amd import geometry as gm
 
-    assert seen["fills"] >= 5 and gm.FILL_PLANS is None, seen
+    assert seen["fills"] >= 5 and gm.STATE.fill_plans is None, seen
     assert seen["single_plans"] <= 3, seen                          # (objectBoundingBox clips and the like plan on demand)
 
     monkeypatch.setattr(sm, "_plan_runs", lambda runs, fills, viewport, linear_rgb: ({}, {}))
