@@ -40,6 +40,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -463,7 +464,8 @@ struct BatchDev {
     struct ShardLine {
         int cursor;         // edges (k_flatten)
         int add_cursor;     // add slots (k_path_build: the slabs of path p reserve in shard p % n)
-        int pad[30];
+        unsigned rows_crossed, cols_crossed;   // the plan's counting pass: rows / columns the kept edges cross (sizes the add lists' first guess)
+        int pad[28];
     } shard[16];
 };
 constexpr int NSH = 16;
@@ -660,19 +662,40 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
     constexpr int FL_ENDS = SVGR_FL_ENDS;  // pieces a lane remembers from its counting traversal (a wave skips the second one when all its lanes fit)
     double qe[2 * FL_ENDS];
     for (int k = 0; k < 2 * FL_ENDS; ++k) qe[k] = 0.0;
+    // (the plan's counting pass also adds up the rows and columns the kept pieces cross: what the first guess of the add lists'
+    //  size is made from -- batch_plan_two_pass)
+    const bool census = !EMIT && seg_cnt != nullptr;
+    float rows_x = 0.f, cols_x = 0.f;
+    const float span_cap = (float)(n_bands > 0 ? n_bands * TR + 8 : 1 << 20);
+    auto crossed = [&](double r0_, double c0_, double r1_, double c1_) {
+        rows_x += fminf((float)fabs(r1_ - r0_), span_cap) + 1.f;
+        cols_x += fminf((float)fabs(c1_ - c0_), 1048576.f) + 1.f;
+    };
     if (mode == 1) {
         cnt = 1;
         track(node[0], node[1]);
         track(node[6], node[7]);
+        if (census) crossed(node[0], node[1], node[6], node[7]);
     } else if (mode == 2) {
         // pieces come in curve order and share end points: track the first start and every end.  The ends of the
         // first two pieces are remembered: nearly every lane has one or two, and then the second traversal is skipped.
         track(node[0], node[1]);
-        cnt = flatten_subtree<FL_ENDS>(node, thr, kMaxFlattenDepth - FL_SUB, [&](double, double, double r1, double c1) { track(r1, c1); }, ovf, qe);
+        cnt = flatten_subtree<FL_ENDS>(node, thr, kMaxFlattenDepth - FL_SUB, [&](double r0_, double c0_, double r1, double c1) {
+            track(r1, c1);
+            if (census) crossed(r0_, c0_, r1, c1);
+        }, ovf, qe);
     }
     if (ovf) atomicOr(&bd->err, 1);
-    if (!keep) cnt = 0;
+    if (!keep) { cnt = 0; rows_x = cols_x = 0.f; }
     const int shard = (int)((blockIdx.x * (FL_BLOCK / 64) + (threadIdx.x >> 6)) % NSH);
+    if (census) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { rows_x += __shfl_xor(rows_x, d); cols_x += __shfl_xor(cols_x, d); }
+        if ((threadIdx.x & 63) == 0 && rows_x > 0.f) {
+            atomicAdd(&bd->shard[shard].rows_crossed, (unsigned)fminf(rows_x, 1.0e9f));
+            atomicAdd(&bd->shard[shard].cols_crossed, (unsigned)fminf(cols_x, 1.0e9f));
+        }
+    }
     int base;
     bool fits;
     if (seg_cnt || seg_off) {
@@ -746,23 +769,46 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
 // Plan only: exclusive prefix sums of the per-segment edge counts (seg_off[n] = their total).  One workgroup, a chunk of
 // 1024 segments per step with the running total carried along: a plan-time pass over a few thousand to a few million ints.
 __global__ __launch_bounds__(1024) void k_seg_scan(const int* __restrict__ seg_cnt, int n, int* __restrict__ seg_off) {
+    // (eight consecutive counts per lane: a chunk is 8192 segments, a few barrier rounds for a drawing of tens of thousands --
+    //  one count per lane was 23 rounds and 17.6 us for the bench scene's 22 703)
+    constexpr int PER = 8;
     __shared__ int s_w[16];
     __shared__ int s_run;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_run = 0;
     __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += 1024) {
-        const int i = c0 + tid;
-        const int v = i < n ? seg_cnt[i] : 0;
+    for (int c0 = 0; c0 < n; c0 += 1024 * PER) {
+        const int i0 = c0 + tid * PER;
+        int v[PER], mine = 0;
+        if (i0 + PER <= n) {   // (the arrays are allocated in 256-byte blocks and i0 is a multiple of eight: two aligned 16-byte loads)
+            const int4 a = ((const int4*)(seg_cnt + i0))[0], c = ((const int4*)(seg_cnt + i0))[1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) v[k] = i0 + k < n ? seg_cnt[i0 + k] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) mine += v[k];
         int wtot;
-        const int excl = wave_excl_scan(v, lane, wtot);
+        const int excl = wave_excl_scan(mine, lane, wtot);
         if (lane == 0) s_w[wave] = wtot;
         __syncthreads();
         const int run0 = s_run;
         int before = 0, all = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) { before += w < wave ? s_w[w] : 0; all += s_w[w]; }
-        if (i < n) seg_off[i] = run0 + before + excl;
+        int at = run0 + before + excl;
+        int o[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { o[k] = at; at += v[k]; }
+        if (i0 + PER <= n) {
+            ((int4*)(seg_off + i0))[0] = make_int4(o[0], o[1], o[2], o[3]);
+            ((int4*)(seg_off + i0))[1] = make_int4(o[4], o[5], o[6], o[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (i0 + k < n) seg_off[i0 + k] = o[k];
+        }
         __syncthreads();
         if (tid == 0) s_run = run0 + all;
         __syncthreads();
@@ -3725,6 +3771,7 @@ struct svgr_batch {
     DevArr<int> seg_path;
     DevArr<unsigned char> in_dev;  // the one block the six input arrays above are views of
     std::vector<char> in_host;     // its host image: source of the single asynchronous upload, alive as long as the batch
+    size_t o_segs = 0, o_m6 = 0, o_kind = 0, o_seg0 = 0;   // ... where its arrays start (the host-side size estimate of a first plan reads them)
     // Uploads never make the host wait for the STREAM (a document's walk enqueues one batch after the other and must stay
     // ahead of the device): what an asynchronous copy reads is a host copy kept by the batch, an event marks the last
     // upload enqueued, and only svgr_batch_destroy -- or the next upload into the same array -- waits, for that event alone.
@@ -3767,6 +3814,7 @@ struct svgr_batch {
     AddShards add_shards{};                 // where each shard's add slots live (the slabs of path p reserve in shard p % n)
     int64_t n_adds = 0;                     // add slots in all the shards
     bool count_adds_only = false;           // the plan's measuring run: k_path_build sizes the add lists, writes none
+    bool census_bbox = false;               // the two-pass plan's first pass: the counting flatten is followed by k_path_bbox (pairs, cells, slabs counted)
     bool deterministic = false;             // this pass runs for a SVGR_RENDER_DETERMINISTIC render
     // lay the add shards back to back: `need[k]` slots each plus slack (the sizes repeat from render to render except for
     // carry-ins that are exactly zero in one summation order and not in another)
@@ -3897,7 +3945,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                                n_bands_vp, prow, seg_list, n_items, upto == 1 ? b->seg_cnt.p : (int*)nullptr, (const int*)nullptr, 0);
         if (upto == 1)
             hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, st, (const int*)b->seg_cnt.p, ns, b->seg_off.p);
-        if (upto == 0)  // bboxes only (no edges stored): enough to find the union when there is no viewport
+        if (upto == 0 || (upto == 1 && b->census_bbox))  // bboxes only (no edges stored): the union when there is no viewport; the two-pass plan's census
             hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(),
                                np_walk, use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), 1, plist,
                                (Slab*)nullptr, 0, b->own, (const int*)nullptr, (const int*)nullptr, 0, (const int*)nullptr);
@@ -4326,6 +4374,7 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
     const size_t o_segs = 0, o_m6 = al(o_segs + ns * 64), o_paint = al(o_m6 + np * 48), o_spath = al(o_paint + np * 32),
                  o_kind = al(o_spath + ns * 4), o_rule = al(o_kind + ns), o_seg0 = al(o_rule + np), total = al(o_seg0 + (np + 1) * 4);
     b->in_host.resize(total);
+    b->o_segs = o_segs; b->o_m6 = o_m6; b->o_kind = o_kind; b->o_seg0 = o_seg0;
     char* const hb = b->in_host.data();
     memcpy(hb + o_segs, d->segs, ns * 64);
     memcpy(hb + o_m6, d->path_m6, np * 48);
@@ -4392,8 +4441,10 @@ int svgr_batch_set_transforms(svgr_batch* b, const double* path_m6) {
         if (!std::isfinite(path_m6[i])) return fail(SVGR_E_INVALID, "non-finite transform");
     HIPCHK(enter_ctx(b->ctx));
     b->wait_uploads();
-    HIPCHK(hipMemcpyAsync(b->path_m6.p, b->keep(path_m6, sizeof(double) * 6 * (size_t)b->n_paths), sizeof(double) * 6 * b->n_paths,
-                          hipMemcpyHostToDevice, b->ctx->stream));
+    // (the batch's host image stays current: it is the source of this upload, and what a first plan's size estimate reads)
+    void* const hm = b->in_host.data() + b->o_m6;
+    memcpy(hm, path_m6, sizeof(double) * 6 * (size_t)b->n_paths);
+    HIPCHK(hipMemcpyAsync(b->path_m6.p, hm, sizeof(double) * 6 * b->n_paths, hipMemcpyHostToDevice, b->ctx->stream));
     HIPCHK(b->note_upload(b->ctx->stream));
     b->planned = false; b->slab_at_valid = false;
     return 0;
@@ -4616,6 +4667,14 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr, bool again = false
 static int spec_finish(svgr_batch* b) {
     int cap_bits = 0;
     if (b->host_bd.err) b->invalidate_work();
+    if (getenv("SVGR_DBG_PLAN")) {   // (diagnostic: what the single pass was given and what it used)
+        long long e = 0, a = 0;
+        for (int k = 0; k < NSH; ++k) { e += b->host_bd.shard[k].cursor; a += b->host_bd.shard[k].add_cursor; }
+        fprintf(stderr, "[plan] single pass: err %d | edges %lld of %lld, pairs %d of %lld, cells %d of %lld, slabs %d of %lld, adds %lld of %lld (shard 0: %d of %d), entries %d, longest band list %d (mask words %d)\n",
+                b->host_bd.err, e, (long long)b->n_edges, b->host_bd.pb_cursor, (long long)b->n_pb, b->host_bd.cell_cursor, (long long)b->n_cells,
+                b->host_bd.slab_cursor, (long long)b->n_slabs, a, (long long)b->n_adds, b->host_bd.shard[0].add_cursor, b->add_shards.cap[0],
+                b->host_bd.entry_cursor, b->host_bd.max_band_entries, b->mask_words);
+    }
     if (int rc = eval_dev_err(b->host_bd.err, &cap_bits)) return rc;
     if (cap_bits) return 0;
     b->n_entries = b->host_bd.entry_cursor;
@@ -4641,7 +4700,7 @@ static int plan_speculative(svgr_batch* b) {
         HIPCHK(hipStreamSynchronize(b->ctx->stream));
         HIPCHK(hipGetLastError());
         const int fin = spec_finish(b);
-        if (fin > 0 && again && b->n_segs > 4096) {
+        if (fin > 0 && b->n_segs > 4096) {
             if (int rc = plan_slab_order(b)) return rc;   // (large batches: k_path_build's work list heaviest first)
         }
         if (fin != 0) return fin;
@@ -4747,6 +4806,8 @@ int svgr_batch_plan_many(svgr_batch** batches, int64_t n) {
             if (issued[(size_t)i]) {
                 done = spec_finish(b);
                 if (done < 0) return done;
+                if (done > 0 && b->n_segs > 4096)
+                    if (int rc = plan_slab_order(b)) return rc;
             }
             if (!done)  // (not eligible, or a guess was too small: the staged plan directly -- the speculative pass would fail the same way)
                 if (int rc = batch_plan_impl(b, issued[(size_t)i] != 0)) return rc;
@@ -4791,10 +4852,17 @@ static int plan_slab_order(svgr_batch* b) {
         total += n;
     }
     if (total != b->n_slabs) return 0;  // (not the count the device found: leave the order to the cursor)
-    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return w[(size_t)a] > w[(size_t)c]; });
+    // heaviest first, paint order among equals: a counting sort over the weights in whole pixels (a comparison sort of a few
+    // thousand paths was 0.15 ms of a 0.5 ms plan)
     b->slab_at_host.assign(np, 0);
-    int at = 0;
-    for (int p : order) { b->slab_at_host[(size_t)p] = at; at += n_sl[(size_t)p]; }
+    {
+        constexpr int KEYS = 1 << 16;
+        std::vector<int> first((size_t)KEYS + 1, 0);
+        auto key_of = [&](int p) { const float v = w[(size_t)p]; return KEYS - 1 - (v < (float)(KEYS - 1) ? (int)v : KEYS - 1); };   // (descending)
+        for (int p : order) first[(size_t)key_of(p) + 1] += n_sl[(size_t)p];
+        for (int k = 0; k < KEYS; ++k) first[(size_t)k + 1] += first[(size_t)k];
+        for (int p : order) { const int k = key_of(p); b->slab_at_host[(size_t)p] = first[(size_t)k]; first[(size_t)k] += n_sl[(size_t)p]; }
+    }
     if (int rc = b->slab_at.ensure(np)) return rc;
     // (no wait: the renders are behind the copy in the stream; its source is a member, svgr_batch_destroy waits for uploads)
     b->wait_uploads();
@@ -4802,6 +4870,111 @@ static int plan_slab_order(svgr_batch* b) {
     HIPCHK(b->note_upload(b->ctx->stream));
     b->slab_at_valid = true;
     return 0;
+}
+
+// The FIRST plan of a batch in two passes behind two read-backs (the staged plan below: five and five).
+//   pass 1  the counting flatten (per-segment edge counts -> their prefix sums = where every segment's edges go; the rows and
+//           columns the kept pieces cross) and k_path_bbox on its min / max keys: the bboxes, and with them -- the kernel's own
+//           reservations -- the exact numbers of (path, band) pairs, cells and slabs
+//   host    every buffer sized exactly, but the add lists: a guess from the rows / columns crossed and the cells
+//   pass 2  the whole geometry (k_path_build<false>: it leaves every cell's add places): validated by its own error word
+// An add-list guess that was too small is flagged by the kernels and the staged plan (which MEASURES the lists) takes over.
+// 1 planned, 0 fall back, < 0 error.
+static double now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+static int plan_two_pass(svgr_batch* b) {
+    const double t_0 = now_ms();
+    if (!b->has_vp || b->own.world > 1 || b->n_segs <= 0 || b->vp[2] <= 0 || b->vp[3] <= 0) return 0;
+    if (getenv("SVGR_NO_TWO_PASS_PLAN")) return 0;   // (tests: the staged plan stays exercised)
+    if (int rc = b->layout_arena()) return rc;
+    b->n_seg_list = -1;
+    b->census_bbox = true;
+    int rc = run_geometry(b, 1, true);
+    b->census_bbox = false;
+    if (rc) return rc;
+    const double t_1 = now_ms();
+    if ((rc = check_dev_err(b, nullptr, true, true))) return rc;
+    const double t_2 = now_ms();
+    long long n_edges = 0, rows_x = 0, cols_x = 0;
+    for (int k = 0; k < NSH; ++k) {
+        n_edges += b->host_bd.shard[k].cursor;
+        rows_x += b->host_bd.shard[k].rows_crossed;
+        cols_x += b->host_bd.shard[k].cols_crossed;
+    }
+    if (n_edges > 0x7fffffff / 4) return fail(SVGR_E_OVERFLOW, "%lld edges: beyond the 32-bit edge index", n_edges);
+    b->n_edges = n_edges;
+    for (int k = 0; k < NSH; ++k) {  // (the renders' edge array is one dense block: see k_flatten)
+        b->shards.base[k] = k == 0 ? 0 : (int)b->n_edges;
+        b->shards.cap[k] = k == 0 ? (int)b->n_edges : 0;
+    }
+    b->n_bands = (b->vp[2] + TR - 1) / TR;
+    b->n_pb = b->host_bd.pb_cursor;
+    b->n_cells = b->host_bd.cell_cursor;
+    b->n_slabs = b->host_bd.slab_cursor;
+    b->n_entries = b->n_pb;
+    // the longest band list (sizes the tiles' entry bitmasks): the bands every clipped bbox reaches
+    std::vector<int> diff((size_t)b->n_bands + 1, 0);
+    for (size_t p = 0; p < (size_t)b->n_paths; ++p) {
+        const int r0 = b->host_bbox[4 * p], rows = b->host_bbox[4 * p + 2], cols = b->host_bbox[4 * p + 3];
+        if (rows <= 0 || cols <= 0) continue;
+        const int b0 = (r0 - b->vp[0]) / TR, b1 = (r0 + rows - 1 - b->vp[0]) / TR;
+        if (b0 < 0 || b1 >= b->n_bands) return 0;
+        diff[(size_t)b0] += 1;
+        diff[(size_t)b1 + 1] -= 1;
+    }
+    int longest = 0, run = 0;
+    for (int k = 0; k < b->n_bands; ++k) { run += diff[(size_t)k]; longest = std::max(longest, run); }
+    rc = b->edges.ensure((size_t)std::max<int64_t>(b->n_edges, 1) * 4);
+    rc = rc ? rc : b->edge_path.ensure((size_t)std::max<int64_t>(b->n_edges, 1));
+    rc = rc ? rc : b->band_start.ensure((size_t)b->n_bands + 1);
+    rc = rc ? rc : b->band_count.ensure((size_t)b->n_bands + 1);
+    rc = rc ? rc : b->band_item0.ensure((size_t)b->n_bands + 1);
+    rc = rc ? rc : b->cell_hdr.ensure((size_t)std::max<int64_t>(b->n_cells, 1) + 1);
+    rc = rc ? rc : b->cell_plan.ensure((size_t)std::max<int64_t>(b->n_cells, 1) + 1);
+    rc = rc ? rc : b->slabs.ensure((size_t)std::max<int64_t>(b->n_slabs, 1));
+    rc = rc ? rc : b->entries.ensure((size_t)std::max<int64_t>(b->n_pb, 1));
+    rc = rc ? rc : b->pair_idx.ensure((size_t)std::max<int64_t>(b->n_pb, 1));
+    rc = rc ? rc : b->size_masks(std::max(longest, 1));
+    rc = rc ? rc : b->size_tile_lists(count_owned_bands(b->own, b->n_bands));
+    if (rc) return rc;
+    {
+        // add slots: a few pieces per edge row (more for shallow rows: a piece per PX columns), up to 2 x TR carry-ins and
+        // sentinels per cell with pieces.  (synth4096: 7.6 M adds; this guess 17 M)
+        const double guess = 5.0 * (double)rows_x + 0.25 * (double)cols_x + 20.0 * (double)b->n_cells + 65536.0;
+        if (guess > (double)(1ll << 29)) return 0;
+        int need[NSH];
+        for (int k = 0; k < NSH; ++k) need[k] = (int)(guess * 1.25 / NSH) + 8192;
+        if ((rc = b->size_adds(need, NSH))) return rc;
+    }
+    const double t_3 = now_ms();
+    if ((rc = run_geometry(b, 4, true))) return rc;
+    const double t_4 = now_ms();
+    int cap_bits = 0;
+    if ((rc = check_dev_err(b, &cap_bits, true, true))) return rc;
+    const double t_5 = now_ms();
+    if (getenv("SVGR_DBG_PLAN")) {
+        fprintf(stderr, "[plan] two passes, ms: pass 1 issued %.3f, drained %.3f, buffers sized %.3f, pass 2 issued %.3f, drained %.3f\n", t_1 - t_0, t_2 - t_1, t_3 - t_2,
+                t_4 - t_3, t_5 - t_4);
+        long long a = 0;
+        for (int k = 0; k < NSH; ++k) a += b->host_bd.shard[k].add_cursor;
+        fprintf(stderr, "[plan] two passes: capacity bits %d | edges %lld, rows crossed %lld, columns %lld, pairs %lld, cells %lld, slabs %lld, adds %lld of %lld, longest band list %d\n",
+                cap_bits, n_edges, rows_x, cols_x, (long long)b->n_pb, (long long)b->n_cells, (long long)b->n_slabs, a, (long long)b->n_adds, longest);
+    }
+    if (cap_bits) return 0;
+    b->n_entries = b->host_bd.entry_cursor;
+    b->n_edges_live = b->n_edges;
+    b->n_bsegs = b->host_bd.bseg_cursor;
+    if ((rc = plan_slab_order(b))) return rc;
+    b->planned = true;
+    b->sized = true;
+    for (int k = 0; k < 4; ++k) b->sized_vp[k] = b->vp[k];
+    b->no_band_reuse = getenv("SVGR_NO_BAND_REUSE") != nullptr;
+    b->add_places = getenv("SVGR_NO_ADD_PLACES") == nullptr;   // (pass 2 was a full one: it left every cell's add places)
+    b->geometry_fresh = true; b->geometry_current = true;
+    return 1;
 }
 
 static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
@@ -4814,6 +4987,13 @@ static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
         const int sp = no_spec || skip_speculative ? 0 : plan_speculative(b);
         if (sp < 0) return sp;
         if (sp > 0) return 0;
+    }
+    {
+        const int tp = plan_two_pass(b);
+        if (tp < 0) return tp;
+        if (tp > 0) return 0;
+        b->planned = false; b->slab_at_valid = false;
+        b->geometry_fresh = false; b->geometry_current = false;
     }
     if (int rc = b->layout_arena()) return rc;
     // 1. Without a viewport (S:968 `viewport is None`) the union of the unclipped bboxes becomes the canvas.
