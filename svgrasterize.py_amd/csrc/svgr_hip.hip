@@ -357,6 +357,19 @@ struct DevArr {
     }
 };
 
+// Several arrays out of one device block: first pass (base == nullptr) adds up the sizes, second pass points the arrays at
+// their places.  Every array gets the eighth of slack an allocation of its own would have (DevArr::ensure).
+struct Carver {
+    unsigned char* base = nullptr;
+    size_t at = 0;
+    template <class T>
+    void take(DevArr<T>& a, size_t n) {
+        n = n + n / 8 + 16;
+        if (base) a.point_at(base, at, n);
+        at += (n * sizeof(T) + 255) & ~(size_t)255;
+    }
+};
+
 // ======================================================================================
 // wave-level helpers (wave = 64 lanes)
 // ======================================================================================
@@ -464,8 +477,8 @@ struct BatchDev {
     struct ShardLine {
         int cursor;         // edges (k_flatten)
         int add_cursor;     // add slots (k_path_build: the slabs of path p reserve in shard p % n)
-        unsigned rows_crossed, cols_crossed;   // the plan's counting pass: rows / columns the kept edges cross (sizes the add lists' first guess)
-        int pad[28];
+        unsigned rows_crossed;   // the plan's counting pass: rows the kept edges cross (sizes the add lists' first guess)
+        int pad[29];
     } shard[16];
 };
 constexpr int NSH = 16;
@@ -665,36 +678,31 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
     // (the plan's counting pass also adds up the rows and columns the kept pieces cross: what the first guess of the add lists'
     //  size is made from -- batch_plan_two_pass)
     const bool census = !EMIT && seg_cnt != nullptr;
-    float rows_x = 0.f, cols_x = 0.f;
-    const float span_cap = (float)(n_bands > 0 ? n_bands * TR + 8 : 1 << 20);
-    auto crossed = [&](double r0_, double c0_, double r1_, double c1_) {
-        rows_x += fminf((float)fabs(r1_ - r0_), span_cap) + 1.f;
-        cols_x += fminf((float)fabs(c1_ - c0_), 1048576.f) + 1.f;
-    };
+    double rows_x = 0.0;
     if (mode == 1) {
         cnt = 1;
         track(node[0], node[1]);
         track(node[6], node[7]);
-        if (census) crossed(node[0], node[1], node[6], node[7]);
+        if (census) rows_x = fabs(node[6] - node[0]);
     } else if (mode == 2) {
         // pieces come in curve order and share end points: track the first start and every end.  The ends of the
         // first two pieces are remembered: nearly every lane has one or two, and then the second traversal is skipped.
         track(node[0], node[1]);
-        cnt = flatten_subtree<FL_ENDS>(node, thr, kMaxFlattenDepth - FL_SUB, [&](double r0_, double c0_, double r1, double c1) {
+        cnt = flatten_subtree<FL_ENDS>(node, thr, kMaxFlattenDepth - FL_SUB, [&](double r0_, double, double r1, double c1) {
             track(r1, c1);
-            if (census) crossed(r0_, c0_, r1, c1);
+            if (census) rows_x += fabs(r1 - r0_);
         }, ovf, qe);
     }
     if (ovf) atomicOr(&bd->err, 1);
-    if (!keep) { cnt = 0; rows_x = cols_x = 0.f; }
+    if (!keep) { cnt = 0; rows_x = 0.0; }
     const int shard = (int)((blockIdx.x * (FL_BLOCK / 64) + (threadIdx.x >> 6)) % NSH);
     if (census) {
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { rows_x += __shfl_xor(rows_x, d); cols_x += __shfl_xor(cols_x, d); }
-        if ((threadIdx.x & 63) == 0 && rows_x > 0.f) {
-            atomicAdd(&bd->shard[shard].rows_crossed, (unsigned)fminf(rows_x, 1.0e9f));
-            atomicAdd(&bd->shard[shard].cols_crossed, (unsigned)fminf(cols_x, 1.0e9f));
-        }
+        // (a piece crosses |dr| + 1 rows at most; what lies outside the viewport's rows is counted too: a guess's upper side)
+        const double cap = (double)(n_bands > 0 ? (n_bands * TR + 8) * (cnt > 0 ? cnt : 1) : 1 << 22);
+        const int mine = cnt > 0 ? (int)(rows_x < cap ? rows_x : cap) + cnt : 0;
+        int wrows;
+        (void)wave_excl_scan(mine < (1 << 24) ? mine : (1 << 24), threadIdx.x & 63, wrows);
+        if ((threadIdx.x & 63) == 0 && wrows > 0) atomicAdd(&bd->shard[shard].rows_crossed, (unsigned)wrows);
     }
     int base;
     bool fits;
@@ -3802,6 +3810,7 @@ struct svgr_batch {
     DevArr<TileEntry> entries;
     DevArr<double> edges;
     DevArr<CellHdr> cell_hdr;               // per (path, band, column tile) cell: header (classes 1 and 2)
+    DevArr<unsigned char> work_block;       // a first plan's work arrays in ONE block (two dozen hipMallocs were half of a cold render): the arrays below are then views of it
     DevArr<int2> cell_plan;                 // ... and where its add list lives: {first add, pieces}, left by the plan's full pass (k_path_build)
     bool add_places = false;                // `cell_plan` holds the places of the current plan: the renders take them (k_path_build<true>)
     // a pass that ended with an error flag may have left any of the self-cleaning buffers dirty
@@ -3819,6 +3828,10 @@ struct svgr_batch {
     // lay the add shards back to back: `need[k]` slots each plus slack (the sizes repeat from render to render except for
     // carry-ins that are exactly zero in one summation order and not in another)
     int size_adds(const int* need, int n_shards) {
+        if (int rc = layout_adds(need, n_shards)) return rc;
+        return adds.ensure((size_t)std::max<int64_t>(n_adds, 1));
+    }
+    int layout_adds(const int* need, int n_shards) {
         long long at = 0;
         add_shards.n = n_shards;
         for (int k = 0; k < NSH; ++k) {
@@ -3829,7 +3842,7 @@ struct svgr_batch {
         }
         if (at > 0x7fffffffll) return fail(SVGR_E_OVERFLOW, "%lld add slots: beyond the 32-bit add index (split the batch)", at);
         n_adds = at;
-        return adds.ensure((size_t)std::max<long long>(at, 1));
+        return 0;
     }
     DevArr<int> pair_idx;                   // per (path, band) pair: its place in its band's list (k_band_entries)
     DevArr<Slab> slabs;                     // work items of k_path_build (k_path_bbox)
@@ -3897,7 +3910,7 @@ struct svgr_batch {
         path_group.release(); group_clip_src.release(); group_opacity.release(); groups_dev.release();
         grads.release(); path_grad.release(); grad_path.release(); grad_flags.release(); grads_dev.release();
         edges.release(); cell_hdr.release(); cell_plan.release(); pair_idx.release(); slabs.release(); slab_at.release(); seg_cnt.release(); seg_off.release(); path_seg0.release(); tile_mask.release(); seg_list.release(); path_list.release(); layer_off.release();
-        adds.release(); items.release(); tile_info.release(); pages.release(); band_item0.release();
+        adds.release(); items.release(); tile_info.release(); pages.release(); band_item0.release(); work_block.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
         for (auto e : event_pool) (void)hipEventDestroy(e);
@@ -4898,11 +4911,10 @@ static int plan_two_pass(svgr_batch* b) {
     const double t_1 = now_ms();
     if ((rc = check_dev_err(b, nullptr, true, true))) return rc;
     const double t_2 = now_ms();
-    long long n_edges = 0, rows_x = 0, cols_x = 0;
+    long long n_edges = 0, rows_x = 0;
     for (int k = 0; k < NSH; ++k) {
         n_edges += b->host_bd.shard[k].cursor;
         rows_x += b->host_bd.shard[k].rows_crossed;
-        cols_x += b->host_bd.shard[k].cols_crossed;
     }
     if (n_edges > 0x7fffffff / 4) return fail(SVGR_E_OVERFLOW, "%lld edges: beyond the 32-bit edge index", n_edges);
     b->n_edges = n_edges;
@@ -4927,27 +4939,52 @@ static int plan_two_pass(svgr_batch* b) {
     }
     int longest = 0, run = 0;
     for (int k = 0; k < b->n_bands; ++k) { run += diff[(size_t)k]; longest = std::max(longest, run); }
-    rc = b->edges.ensure((size_t)std::max<int64_t>(b->n_edges, 1) * 4);
-    rc = rc ? rc : b->edge_path.ensure((size_t)std::max<int64_t>(b->n_edges, 1));
-    rc = rc ? rc : b->band_start.ensure((size_t)b->n_bands + 1);
-    rc = rc ? rc : b->band_count.ensure((size_t)b->n_bands + 1);
-    rc = rc ? rc : b->band_item0.ensure((size_t)b->n_bands + 1);
-    rc = rc ? rc : b->cell_hdr.ensure((size_t)std::max<int64_t>(b->n_cells, 1) + 1);
-    rc = rc ? rc : b->cell_plan.ensure((size_t)std::max<int64_t>(b->n_cells, 1) + 1);
-    rc = rc ? rc : b->slabs.ensure((size_t)std::max<int64_t>(b->n_slabs, 1));
-    rc = rc ? rc : b->entries.ensure((size_t)std::max<int64_t>(b->n_pb, 1));
-    rc = rc ? rc : b->pair_idx.ensure((size_t)std::max<int64_t>(b->n_pb, 1));
-    rc = rc ? rc : b->size_masks(std::max(longest, 1));
-    rc = rc ? rc : b->size_tile_lists(count_owned_bands(b->own, b->n_bands));
-    if (rc) return rc;
     {
         // add slots: a few pieces per edge row (more for shallow rows: a piece per PX columns), up to 2 x TR carry-ins and
-        // sentinels per cell with pieces.  (synth4096: 7.6 M adds; this guess 17 M)
-        const double guess = 5.0 * (double)rows_x + 0.25 * (double)cols_x + 20.0 * (double)b->n_cells + 65536.0;
+        // sentinels per cell with pieces.  (synth4096: 7.6 M adds, 2.5 M edge rows, 0.8 M edges, 0.2 M cells: the guess is 11 M -- fresh device memory is cleared before its first use, a cold render pays for every megabyte it asks for)
+        const double guess = 3.0 * (double)rows_x + 1.0 * (double)n_edges + 8.0 * (double)b->n_cells + 65536.0;
         if (guess > (double)(1ll << 29)) return 0;
         int need[NSH];
         for (int k = 0; k < NSH; ++k) need[k] = (int)(guess * 1.25 / NSH) + 8192;
-        if ((rc = b->size_adds(need, NSH))) return rc;
+        if ((rc = b->layout_adds(need, NSH))) return rc;
+    }
+    b->mask_words = (int)std::max<int64_t>(((int64_t)std::max(longest, 1) + 63) / 64, 1);
+    b->masks_zeroed = false;
+    {
+        // every work array of the batch out of ONE device block (each with the eighth of slack an allocation of its own would
+        // have: a re-plan of a drawing that moved a little fits the same arrays, spec_issue(again))
+        const size_t n_e = (size_t)std::max<int64_t>(b->n_edges, 1), n_c = (size_t)std::max<int64_t>(b->n_cells, 1);
+        const size_t n_pairs = (size_t)std::max<int64_t>(b->n_pb, 1), n_bd = (size_t)b->n_bands + 1;
+        const size_t n_tiles = (size_t)std::max(b->n_bands, 1) * (size_t)std::max(b->n_ctiles(), 1);
+        const size_t owned = (size_t)std::max(count_owned_bands(b->own, b->n_bands), 1);
+        auto layout = [&](Carver& c) {
+            c.take(b->edges, n_e * 4);
+            c.take(b->edge_path, n_e);
+            c.take(b->band_start, n_bd);
+            c.take(b->band_count, n_bd);
+            c.take(b->band_item0, n_bd);
+            c.take(b->cell_hdr, n_c + 1);
+            c.take(b->cell_plan, n_c + 1);
+            c.take(b->slabs, (size_t)std::max<int64_t>(b->n_slabs, 1));
+            c.take(b->entries, n_pairs);
+            c.take(b->pair_idx, n_pairs);
+            c.take(b->tile_mask, b->mask_bytes() / sizeof(unsigned long long) + 1);
+            c.take(b->tile_info, n_tiles);
+            c.take(b->pages, owned * (size_t)std::max(b->n_ctiles(), 1) * PAGE_STRIDE);
+            c.take(b->items, n_c);
+            c.take(b->adds, (size_t)std::max<int64_t>(b->n_adds, 1));
+        };
+        Carver sizing;
+        layout(sizing);
+        // (the arrays may be views of an earlier block of this batch: let go of them before the block)
+        b->edges.release(); b->edge_path.release(); b->band_start.release(); b->band_count.release(); b->band_item0.release();
+        b->cell_hdr.release(); b->cell_plan.release(); b->slabs.release(); b->entries.release(); b->pair_idx.release();
+        b->tile_mask.release(); b->tile_info.release(); b->pages.release(); b->items.release(); b->adds.release();
+        b->work_block.release();
+        if ((rc = b->work_block.ensure(sizing.at))) return rc;
+        Carver carve;
+        carve.base = b->work_block.p;
+        layout(carve);
     }
     const double t_3 = now_ms();
     if ((rc = run_geometry(b, 4, true))) return rc;
@@ -4960,8 +4997,8 @@ static int plan_two_pass(svgr_batch* b) {
                 t_4 - t_3, t_5 - t_4);
         long long a = 0;
         for (int k = 0; k < NSH; ++k) a += b->host_bd.shard[k].add_cursor;
-        fprintf(stderr, "[plan] two passes: capacity bits %d | edges %lld, rows crossed %lld, columns %lld, pairs %lld, cells %lld, slabs %lld, adds %lld of %lld, longest band list %d\n",
-                cap_bits, n_edges, rows_x, cols_x, (long long)b->n_pb, (long long)b->n_cells, (long long)b->n_slabs, a, (long long)b->n_adds, longest);
+        fprintf(stderr, "[plan] two passes: capacity bits %d | edges %lld, rows crossed %lld, pairs %lld, cells %lld, slabs %lld, adds %lld of %lld, longest band list %d\n",
+                cap_bits, n_edges, rows_x, (long long)b->n_pb, (long long)b->n_cells, (long long)b->n_slabs, a, (long long)b->n_adds, longest);
     }
     if (cap_bits) return 0;
     b->n_entries = b->host_bd.entry_cursor;
