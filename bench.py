@@ -226,7 +226,7 @@ def cpu_baseline(sc, budget_paths: int | None = None):
             np.ascontiguousarray(sc["path_rule"][:n]), np.ascontiguousarray(sc["path_paint"][:n]).reshape(-1), vp, 1,
             canvas.reshape(-1), stats.ctypes.data_as(C.c_void_p))
     # the render cut into row strips, one per thread, on this process's share of the host cores
-    threads = orc.host_threads()
+    threads = orc.host_threads(64)
     t0 = time.perf_counter()
     rc = L.orc_render_solid_strips(*args, threads, threads)
     dt_mt = time.perf_counter() - t0
@@ -255,6 +255,8 @@ def cpu_baseline(sc, budget_paths: int | None = None):
         sample=f"first {n} of {n_all} paths of the same scene, full viewport, {dt:.2f} s, P={P1} "
                f"(oracle/svgr_oracle.c: pass-by-pass C restatement of the reference, float64, 1 thread of {os.cpu_count()})",
         all_cores_value=round(int(stats[0]) / dt_mt / 1e6, 3), all_cores=threads,
+        all_cores_what=(f"{threads} threads = the CPUs this process may run on (os.sched_getaffinity: {len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else '?'}"
+                        f"; a one-GPU box hands a job its share of the host) of the host's {os.cpu_count()} logical CPUs; capped at 64"),
         all_cores_sample=f"same render as {threads} row strips (the reference's viewport cropping) on {threads} OpenMP threads, {dt_mt:.2f} s",
     )
 

@@ -101,7 +101,6 @@ static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 102
 #ifndef SVGR_X_SCATWAIT
 #define SVGR_X_SCATWAIT 1               // scatter: no compiler-visible load (and so no compiler-placed vmcnt(0)) in front of the adds
 #endif
-#ifndef SVGR_X_CARRY1
 #ifndef SVGR_X_ADD12
 #define SVGR_X_ADD12 0                  // a TileAdd of 12 bytes {value, where} (no padding word): 46 MB less traffic per step, but entries straddle cache lines -- tile kernel +2.5 us, k_path_build -1 us (A/B twice): off
 #endif
@@ -111,6 +110,7 @@ static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 102
 #ifndef SVGR_X_BLEND2
 #define SVGR_X_BLEND2 1                 // the production blend: two pixels per asm statement (one class-1 test for both)
 #endif
+#ifndef SVGR_X_CARRY1
 #define SVGR_X_CARRY1 1                 // class-2 cells: the carry-in block of the header neither written (k_path_build) nor fetched (tile kernel)
 #endif
 #ifndef SVGR_X_CMPX
