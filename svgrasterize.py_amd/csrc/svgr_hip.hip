@@ -585,7 +585,10 @@ __global__ __launch_bounds__(256) void k_seg_select(const int* __restrict__ seg_
 #endif
 constexpr int FL_SUB = SVGR_FL_SUB;       // 32 lanes per segment: the longest lane bounds the kernel, so cut subtrees small
 constexpr int FL_BLOCK = 256;     // waves are independent (no block-level step)
-template <bool EMIT>
+// PLACED (with EMIT): the pass stores the edges at the places the plan's counting pass left PER LANE (`lane_off`: a lane's first
+// edge inside its segment's slots) -- one traversal that stores as it goes: no remembered end points, no prefix sum over the
+// lanes, no second traversal for the lanes with many pieces.  The count a lane finds is checked against its place's size.
+template <bool EMIT, bool PLACED = false>
 #ifndef SVGR_FL_WAVES
 #define SVGR_FL_WAVES 1
 #endif
@@ -596,7 +599,9 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
                                                  unsigned long long* __restrict__ pkeys, BatchDev* __restrict__ bd,
                                                  Owner own, int vr0, int n_bands, const unsigned* __restrict__ prow,
                                                  const int* __restrict__ seg_list, int n_list,
-                                                 int* __restrict__ seg_cnt, const int* __restrict__ seg_off, int edge_cap) {
+                                                 int* __restrict__ seg_cnt, const int* __restrict__ seg_off, int edge_cap,
+                                                 int* __restrict__ lane_off) {
+    static_assert(!PLACED || EMIT, "places are what an emitting pass takes");
     // Where the edges go.  `seg_off` given (the renders and the plan's later passes): segment s owns the slots
     // [seg_off[s], seg_off[s + 1]) -- the exclusive prefix sums of the per-segment counts the plan's counting pass left in
     // `seg_cnt` -- and its lanes take them in curve order.  The edge array is then in (path, segment, curve) order whatever
@@ -677,6 +682,41 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
     for (int k = 0; k < 2 * FL_ENDS; ++k) qe[k] = 0.0;
     // (the plan's counting pass also adds up the rows and columns the kept pieces cross: what the first guess of the add lists'
     //  size is made from -- batch_plan_two_pass)
+    constexpr int SEGL_ = 1 << FL_SUB;  // lanes per segment
+    if constexpr (PLACED) {
+        // this lane's place: [first, first + n_plan) of its segment's slots
+        int first = seg_ok ? lane_off[(size_t)seg * SEGL_ + sub] : 0;
+        int nxt = __shfl_down(first, 1);
+        if (sub == SEGL_ - 1) nxt = so1 - so0;
+        const int n_plan = seg_ok ? nxt - first : 0;
+        const int base_p = so0 + first;
+        int n_found = 0;
+        if (mode == 1) {
+            track(node[0], node[1]);
+            track(node[6], node[7]);
+            n_found = 1;
+            if (n_plan >= 1 && base_p < edge_cap) {
+                store_edge(edges, base_p, node[0], node[1], node[6], node[7]);
+                edge_path[base_p] = p;
+            }
+        } else if (mode == 2) {
+            track(node[0], node[1]);
+            int at = 0;
+            n_found = flatten_subtree<1>(node, thr, kMaxFlattenDepth - FL_SUB, [&](double r0_, double c0_, double r1, double c1) {
+                track(r1, c1);
+                if (at < n_plan && base_p + at < edge_cap) {
+                    store_edge(edges, base_p + at, r0_, c0_, r1, c1);
+                    edge_path[base_p + at] = p;
+                }
+                ++at;
+            }, ovf);
+        }
+        if (ovf) atomicOr(&bd->err, 1);
+        // (a lane whose pieces cannot reach this rank's rows has an empty place; any other count that differs is not the plan's geometry)
+        if (keep && n_found != n_plan) atomicOr(&bd->err, 2);
+        // (the shard cursors only count: their sum is the number of edges the pass kept)
+        if (seg_ok && sub == 0 && so1 > so0) atomicAdd(&bd->shard[(int)((blockIdx.x * (FL_BLOCK / 64) + (threadIdx.x >> 6)) % NSH)].cursor, so1 - so0);
+    } else {
     const bool census = !EMIT && seg_cnt != nullptr;
     double rows_x = 0.0;
     if (mode == 1) {
@@ -714,6 +754,7 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
         constexpr int SEGL = 1 << FL_SUB;  // lanes per segment
         const int seg_first = __shfl(excl, lane & ~(SEGL - 1)), seg_total = __shfl(excl + cnt, lane | (SEGL - 1)) - seg_first;
         if (seg_cnt && seg_ok && sub == 0) seg_cnt[seg] = seg_total;
+        if (seg_cnt && lane_off && seg_ok) lane_off[(size_t)seg * SEGL + sub] = excl - seg_first;   // (the lane's place inside its segment's slots)
         const int s0 = so0, s1 = so1;
         base = s0 + (excl - seg_first);
         fits = base + cnt <= s1 && base + cnt <= edge_cap;
@@ -758,6 +799,7 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
             }
         }
     }
+    }  // (!PLACED)
     // fold the lanes of a segment, then one set of atomics per segment
 #pragma unroll
     for (int d = 1; d < (1 << FL_SUB); d <<= 1) {
@@ -2190,7 +2232,13 @@ __device__ __forceinline__ double dpp_ctrl(double v) {  // generic DPP move of a
 }
 
 // the lane's pixels, one macro call each (asm blocks with named operands cannot be written in a loop over a constexpr index)
+#if SVGR_PX == 16
+#define SVGR_ACC_PX(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
+#define SVGR_ACC_PX2(F) F(0) F(2) F(4) F(6) F(8) F(10) F(12) F(14)
+#else
 #define SVGR_ACC_PX(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
+#define SVGR_ACC_PX2(F) F(0) F(2) F(4) F(6)
+#endif
 
 struct TileArgs {
     const uint4* pages;             // whole-canvas launches: per workgroup, in launch order (k_tile_lists: heaviest first), its page
@@ -2244,7 +2292,51 @@ struct TileArgs {
 // with a load in flight cannot be copied, spilled or recoloured by a compiler that does not have it.  The persistent tile loop
 // needs that: with several statements defining one target variable the allocator joins them with copies -- of registers
 // whose load has not landed.  (The other variants take one tile per workgroup and keep the targets as ordinary variables.)
+#if SVGR_WAVES_PER_EU == 4
 #define SVGR_FIX0 116
+#define SVGR_FR(k) SVGR_FR_##k
+#define SVGR_FR_0 "v116"
+#define SVGR_FR_1 "v117"
+#define SVGR_FR_2 "v118"
+#define SVGR_FR_3 "v119"
+#define SVGR_FR_4 "v120"
+#define SVGR_FR_5 "v121"
+#define SVGR_FR_6 "v122"
+#define SVGR_FR_7 "v123"
+#define SVGR_FR_8 "v124"
+#define SVGR_FR_9 "v125"
+#define SVGR_FR_10 "v126"
+#define SVGR_FR_11 "v127"
+#define SVGR_FP_45 "v[120:121]"
+#define SVGR_FP_67 "v[122:123]"
+#define SVGR_FP_89 "v[124:125]"
+#define SVGR_FP_1011 "v[126:127]"
+#define SVGR_FP_456 "v[120:122]"
+#define SVGR_FP_8910 "v[124:126]"
+#elif SVGR_WAVES_PER_EU == 2
+#define SVGR_FIX0 244
+#define SVGR_FR(k) SVGR_FR_##k
+#define SVGR_FR_0 "v244"
+#define SVGR_FR_1 "v245"
+#define SVGR_FR_2 "v246"
+#define SVGR_FR_3 "v247"
+#define SVGR_FR_4 "v248"
+#define SVGR_FR_5 "v249"
+#define SVGR_FR_6 "v250"
+#define SVGR_FR_7 "v251"
+#define SVGR_FR_8 "v252"
+#define SVGR_FR_9 "v253"
+#define SVGR_FR_10 "v254"
+#define SVGR_FR_11 "v255"
+#define SVGR_FP_45 "v[248:249]"
+#define SVGR_FP_67 "v[250:251]"
+#define SVGR_FP_89 "v[252:253]"
+#define SVGR_FP_1011 "v[254:255]"
+#define SVGR_FP_456 "v[248:250]"
+#define SVGR_FP_8910 "v[252:254]"
+#else
+#error "the tile kernel's fixed load targets are named for 4 or 2 waves per SIMD"
+#endif
 // The launch's arguments read AGAIN from the kernel-argument segment: scalar loads that hit the scalar cache, in the place of two
 // dozen SGPRs held across the item loops (the persistent loop ran out of them).  The pointer passes through an empty asm so that
 // the loads stay where they are written; it keeps its address space (constant): through a generic pointer they would be
@@ -2406,38 +2498,39 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         return __hiloint2double(hi, lo);
     };
     // (names and clobber lists of the fixed targets; the pairs are even-aligned)
-#define hq0_R "v116"
-#define hq0_C "v116"
-#define hq1_R "v117"
-#define hq1_C "v117"
-#define hq_R "v118"
-#define hq_C "v118"
+#define hq0_R SVGR_FR(0)
+#define hq0_C SVGR_FR(0)
+#define hq1_R SVGR_FR(1)
+#define hq1_C SVGR_FR(1)
+#define hq_R SVGR_FR(2)
+#define hq_C SVGR_FR(2)
+#define ctr_R SVGR_FR(3)
 #if SVGR_X_ADD12
-#define wq0_R "v122"            // (an add lands in three registers: {value} {where})
-#define wq0_C "v122"
-#define aq0_R "v[120:122]"
-#define vq0_R "v[120:121]"
-#define vq0_C "v120", "v121"
-#define wq_R "v126"
-#define wq_C "v126"
-#define aq_R "v[124:126]"
-#define vq_R "v[124:125]"
-#define vq_C "v124", "v125"
+#define wq0_R SVGR_FR(6)            // (an add lands in three registers: {value} {where})
+#define wq0_C SVGR_FR(6)
+#define aq0_R SVGR_FP_456
+#define vq0_R SVGR_FP_45
+#define vq0_C SVGR_FR(4), SVGR_FR(5)
+#define wq_R SVGR_FR(10)
+#define wq_C SVGR_FR(10)
+#define aq_R SVGR_FP_8910
+#define vq_R SVGR_FP_89
+#define vq_C SVGR_FR(8), SVGR_FR(9)
 #define SVGR_WMOV "v_mov_b32"
     typedef unsigned addw_t;
 #else
 #define SVGR_WMOV "v_mov_b64"
     typedef unsigned long long addw_t;
-#define wq0_R "v[120:121]"
-#define wq0_C "v120", "v121"
-#define wq_R "v[124:125]"
-#define wq_C "v124", "v125"
-#define vq0_R "v[122:123]"
-#define vq0_C "v122", "v123"
-#define vq_R "v[126:127]"
-#define vq_C "v126", "v127"
+#define wq0_R SVGR_FP_45
+#define wq0_C SVGR_FR(4), SVGR_FR(5)
+#define wq_R SVGR_FP_89
+#define wq_C SVGR_FR(8), SVGR_FR(9)
+#define vq0_R SVGR_FP_67
+#define vq0_C SVGR_FR(6), SVGR_FR(7)
+#define vq_R SVGR_FP_1011
+#define vq_C SVGR_FR(10), SVGR_FR(11)
 #endif
-    static_assert(SVGR_FIX0 == 116, "the register names above");
+    static_assert(SVGR_FIX0 == 512 / SVGR_WAVES_PER_EU - 12, "the register names above: the top twelve of the budget");
 #ifdef SVGR_DBG_ADD_LOAD_NT
 #define SVGR_ADD_NT " nt"       // diagnostic: the add lists are read once -- a nontemporal load
 #else
@@ -2477,14 +2570,21 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
 #endif
     // the wait at a round's start: ALL its first loads (the two headers and the add the first items need; header 2 and add 1, which
     // the loop starts with) -- n = what may stay in flight behind them: the previous tile's stores, or nothing
+#define SVGR_STR_(x) #x
+#define SVGR_STR(x) SVGR_STR_(x)
+#if SVGR_CH == 4
+#define SVGR_N_STORES 16
+#else
+#define SVGR_N_STORES 8
+#endif
 #define SVGR_ROUND_TAKE(n, d0, d1, dw0, dv0, d2, dw1, dv1)                                                             \
     do {                                                                                                               \
         if constexpr (FIXED)                                                                                           \
-            asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, " hq0_R "\n\tv_mov_b32 %1, " hq1_R "\n\t" SVGR_WMOV " %2, " wq0_R "\n\tv_mov_b64 %3, " vq0_R \
+            asm volatile("s_waitcnt vmcnt(" SVGR_STR(n) ")\n\tv_mov_b32 %0, " hq0_R "\n\tv_mov_b32 %1, " hq1_R "\n\t" SVGR_WMOV " %2, " wq0_R "\n\tv_mov_b64 %3, " vq0_R \
                          "\n\tv_mov_b32 %4, " hq_R "\n\t" SVGR_WMOV " %5, " wq_R "\n\tv_mov_b64 %6, " vq_R                 \
                          : "=&v"(d0), "=&v"(d1), "=&v"(dw0), "=&v"(dv0), "=&v"(d2), "=&v"(dw1), "=&v"(dv1) : : "memory"); \
         else                                                                                                           \
-            asm volatile("s_waitcnt vmcnt(" #n ")\n\tv_mov_b32 %0, %7\n\tv_mov_b32 %1, %8\n\t" SVGR_WMOV " %2, %9\n\tv_mov_b64 %3, %10" \
+            asm volatile("s_waitcnt vmcnt(" SVGR_STR(n) ")\n\tv_mov_b32 %0, %7\n\tv_mov_b32 %1, %8\n\t" SVGR_WMOV " %2, %9\n\tv_mov_b64 %3, %10" \
                          "\n\tv_mov_b32 %4, %11\n\t" SVGR_WMOV " %5, %12\n\tv_mov_b64 %6, %13"                            \
                          : "=&v"(d0), "=&v"(d1), "=&v"(dw0), "=&v"(dv0), "=&v"(d2), "=&v"(dw1), "=&v"(dv1)              \
                          : "v"(hq0), "v"(hq1), "v"(wq0), "v"(vq0), "v"(hq), "v"(wq), "v"(vq) : "memory");                \
@@ -2830,8 +2930,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
               [s1] "v"(t[2]), [s2] "v"(t[3]), [s3] "v"(t[4])                                                            \
             : "scc");                                                                                                  \
     }
-                static_assert(PX == 8, "four statements of two pixels");
-                SVGR_BLEND_2PX(0) SVGR_BLEND_2PX(2) SVGR_BLEND_2PX(4) SVGR_BLEND_2PX(6)
+                static_assert(PX == 8 || PX == 16, "statements of two pixels");
+                SVGR_ACC_PX2(SVGR_BLEND_2PX)
 #undef SVGR_BLEND_2PX
 #undef SVGR_BLEND_ONE
 #undef SVGR_BLEND_FAST
@@ -3152,8 +3252,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
                 unsigned* const ctr = a.tile_ctr + 32 * (blockIdx.x & 7u);
                 const unsigned one = 1u;
                 unsigned long long keep_;
-                asm volatile("s_mov_b64 %[keep], exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add v119, %[p], %[one], off sc0\n\ts_mov_b64 exec, %[keep]"
-                             : [keep] "=&s"(keep_) : [p] "v"(ctr), [one] "v"(one) : "memory", "v119");
+                asm volatile("s_mov_b64 %[keep], exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add " ctr_R ", %[p], %[one], off sc0\n\ts_mov_b64 exec, %[keep]"
+                             : [keep] "=&s"(keep_) : [p] "v"(ctr), [one] "v"(one) : "memory", ctr_R);
             }
         }
     };
@@ -3190,9 +3290,9 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
                 issue_round(a.pages, r0_);
             }
             const int n = n_round;
-            static_assert(N_STORES == 8 || OUT != 0, "the wait below steps over eight store instructions");
+            static_assert(N_STORES == SVGR_N_STORES || OUT != 0, "the wait below steps over the previous tile's store instructions");
             if (r0_ == 0) TL_PHASE(0);
-            if (preissued && pend) SVGR_ROUND_TAKE(8, h_p, h_s, w_s, v_s, h_a, w_n, v_n);   // (N_STORES)
+            if (preissued && pend) SVGR_ROUND_TAKE(SVGR_N_STORES, h_p, h_s, w_s, v_s, h_a, w_n, v_n);
             else SVGR_ROUND_TAKE(0, h_p, h_s, w_s, v_s, h_a, w_n, v_n);
             if (r0_ == 0) TL_PHASE(1);
             h_p = 0 < n ? h_p : 0;
@@ -3205,7 +3305,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
                     asked = false;
                     if (wave_s == 0) {
                         unsigned q;
-                        asm volatile("v_mov_b32 %0, v119" : "=v"(q) : : "memory");   // (landed: older than the loads the wait above covered)
+                        asm volatile("v_mov_b32 %0, " ctr_R : "=v"(q) : : "memory");   // (landed: older than the loads the wait above covered)
                         const unsigned t2 = 2u * gridDim.x + 8u * (unsigned)__builtin_amdgcn_readfirstlane((int)q) + (blockIdx.x & 7u);
                         if (tid == 0) *(lds_vu32_t*)(s_mem + MAILBOX) = t2;
                     }
@@ -3851,6 +3951,7 @@ struct svgr_batch {
     std::vector<int> slab_at_host;
     int64_t n_slabs = 0;                    // ... the plan's count = the launch's grid
     DevArr<int> seg_cnt, seg_off;           // per segment: edges it flattens into (the plan's counting pass), their prefix sums
+    DevArr<int> lane_off;                   // per (segment, lane of its 2^FL_SUB): the lane's first edge inside the segment's slots (same pass)
     DevArr<int> path_seg0;                  // per path its first segment (view of the input blob)
     DevArr<int> seg_list;                   // multi-GPU: the segments this rank flattens (k_seg_select, at plan time)
     int64_t n_seg_list = -1;                // (-1: no list, every segment)
@@ -3909,7 +4010,7 @@ struct svgr_batch {
         band_start.release(); band_count.release(); entries.release();
         path_group.release(); group_clip_src.release(); group_opacity.release(); groups_dev.release();
         grads.release(); path_grad.release(); grad_path.release(); grad_flags.release(); grads_dev.release();
-        edges.release(); cell_hdr.release(); cell_plan.release(); pair_idx.release(); slabs.release(); slab_at.release(); seg_cnt.release(); seg_off.release(); path_seg0.release(); tile_mask.release(); seg_list.release(); path_list.release(); layer_off.release();
+        edges.release(); cell_hdr.release(); cell_plan.release(); pair_idx.release(); slabs.release(); slab_at.release(); seg_cnt.release(); seg_off.release(); lane_off.release(); path_seg0.release(); tile_mask.release(); seg_list.release(); path_list.release(); layer_off.release();
         adds.release(); items.release(); tile_info.release(); pages.release(); band_item0.release(); work_block.release();
         for (auto& t : events) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
         events.clear();
@@ -3949,13 +4050,15 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
         if (upto == 1) {  // (segments the pass skips keep a count of zero)
             if (int rc = b->seg_cnt.ensure((size_t)ns + 1)) return rc;
             if (int rc = b->seg_off.ensure((size_t)ns + 2)) return rc;
+            if (int rc = b->lane_off.ensure(((size_t)ns << FL_SUB) + 1)) return rc;
             HIPCHK(hipMemsetAsync(b->seg_cnt.p, 0, sizeof(int) * ((size_t)ns + 1), st));
         }
         if (ns > 0)
             hipLaunchKernelGGL(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                                (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns,
                                b->thr, (double*)nullptr, (int*)nullptr, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
-                               n_bands_vp, prow, seg_list, n_items, upto == 1 ? b->seg_cnt.p : (int*)nullptr, (const int*)nullptr, 0);
+                               n_bands_vp, prow, seg_list, n_items, upto == 1 ? b->seg_cnt.p : (int*)nullptr, (const int*)nullptr, 0,
+                               upto == 1 ? b->lane_off.p : (int*)nullptr);
         if (upto == 1)
             hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, st, (const int*)b->seg_cnt.p, ns, b->seg_off.p);
         if (upto == 0 || (upto == 1 && b->census_bbox))  // bboxes only (no edges stored): the union when there is no viewport; the two-pass plan's census
@@ -3964,12 +4067,19 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                                (Slab*)nullptr, 0, b->own, (const int*)nullptr, (const int*)nullptr, 0, (const int*)nullptr);
         return 0;
     }
-    if (ns > 0)
-        hipLaunchKernelGGL(k_flatten<true>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
-                           (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
-                           b->edges.p, b->edge_path.p, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
-                           n_bands_vp, prow, seg_list, n_items, (int*)nullptr, (const int*)b->seg_off.p,
-                           cap_i32(std::min(b->edge_path.cap, b->edges.cap / 4)));
+    if (ns > 0) {
+        // (the counting pass that made `seg_off` left every lane's place inside its segment's slots beside it)
+        static const bool lane_places = getenv("SVGR_NO_LANE_PLACES") == nullptr;
+        auto launch_fl = [&](auto kern, int* places) {
+            hipLaunchKernelGGL(kern, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
+                               (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
+                               b->edges.p, b->edge_path.p, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
+                               n_bands_vp, prow, seg_list, n_items, (int*)nullptr, (const int*)b->seg_off.p,
+                               cap_i32(std::min(b->edge_path.cap, b->edges.cap / 4)), places);
+        };
+        if (lane_places && b->lane_off.p && b->lane_off.cap >= ((size_t)ns << FL_SUB)) launch_fl(k_flatten<true, true>, b->lane_off.p);
+        else launch_fl(k_flatten<true, false>, (int*)nullptr);
+    }
     hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np_walk,
                        use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), b->planned ? 0 : 1, plist,
                        upto >= 3 ? b->slabs.p : (Slab*)nullptr, (int)std::min<int64_t>(cap_i32(b->slabs.cap), b->n_slabs) /* = k_path_build's grid */, b->own,
@@ -5180,7 +5290,7 @@ static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path
     HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
     hipLaunchKernelGGL(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
                        (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr, (double*)nullptr, (int*)nullptr, b->shards,
-                       b->pkeys(), b->bd(), whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (const int*)nullptr, 0);
+                       b->pkeys(), b->bd(), whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (const int*)nullptr, 0, (int*)nullptr);
     BatchDev counts;
     HIPCHK(hipMemcpyAsync(&counts, b->bd(), sizeof counts, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -5204,7 +5314,7 @@ static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_flatten<true>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
                            (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr, d_edges, d_path, sh, b->pkeys(), b->bd(),
-                           whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (const int*)nullptr, 0);
+                           whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (const int*)nullptr, 0, (int*)nullptr);
         e = hipMemcpyAsync(edges, d_edges, sizeof(double) * 4 * (size_t)total, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && edge_path) e = hipMemcpyAsync(edge_path, d_path, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
