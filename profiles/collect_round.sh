@@ -12,7 +12,7 @@ for w in 2 4 8; do bash profiles/collect_rank.sh synth8192 $w > gpurun_out/${tag
 for w in 1 2 4 8; do python profiles/emulate_rank.py --world $w --all --workload synth8192 --steps 40 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps(dict(world=d['world'], strip_bands=d['strip_bands'], slowest_ms=d['slowest']['ms_step'], ranks_ms=[r['ms_step'] for r in d['ranks']])))"; done > gpurun_out/${tag}_emulate_synth8192.jsonl
 python bench_scenes.py --repeat 5 > gpurun_out/${tag}_scenes.jsonl 2> gpurun_out/${tag}_scenes.err
 for wl in material4096 icons4096; do python bench.py --workload $wl 2> /dev/null | tail -1 > gpurun_out/${tag}_bench_$wl.json; done
-HSA_ENABLE_IPC_MODE_LEGACY=0 SVGR_BENCH_BACKEND=gloo SVGR_BENCH_DEVICE=0 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 4 --steps 20 --warmup 3 2> gpurun_out/${tag}_rehearse4.err | tail -1 > gpurun_out/${tag}_rehearse4.json
+HSA_ENABLE_IPC_MODE_LEGACY=0 SVGR_BENCH_BACKEND=gloo SVGR_BENCH_DEVICE=0 timeout -k 10 400 python bench.py --gpus 4 --steps 20 --warmup 3 2> gpurun_out/${tag}_rehearse4.err | tail -1 > gpurun_out/${tag}_rehearse4.json   # (bench.py starts its own four ranks)
 bash profiles/timeline.sh > gpurun_out/${tag}_timeline.log 2>&1; cp gpurun_out/timeline.txt gpurun_out/${tag}_timeline_tile.txt
 bash profiles/pb_stamp.sh > gpurun_out/${tag}_pb_stamp.txt 2>&1
 echo "--- bench"; python - <<P
