@@ -1971,7 +1971,7 @@ __global__ __launch_bounds__(TL_BLOCK) void k_tile_lists(const int* __restrict__
                                                          int mask_words, int n_ct, int vc0, Owner own, int n_owned,
                                                          int2* __restrict__ tile_info, uint4* __restrict__ pages,
                                                          uint4* __restrict__ items, const CellHdr* __restrict__ cell_hdr, int item_cap, int cell_cap,
-                                                         BatchDev* __restrict__ bd) {
+                                                         BatchDev* __restrict__ bd, const PathBin* __restrict__ bins, const int* __restrict__ bbox) {
     constexpr int NWV = TL_BLOCK / 64;
     __shared__ int s_base[TL_BLOCK + 1], s_rank[TL_BLOCK];
     __shared__ int s_hist[64], s_cur[64], s_wtot[NWV];
@@ -1990,12 +1990,16 @@ __global__ __launch_bounds__(TL_BLOCK) void k_tile_lists(const int* __restrict__
     if (tid < 64) s_hist[tid] = 0;
     if (tid == 0) s_run = 0;
     __syncthreads();
-    // pass 1: histogram of the tile weights
+    // pass 1: histogram of the tile weights  (a band of up to TL_BLOCK tiles -- every canvas up to 65 536 columns -- keeps its
+    // tiles' counts in registers for pass 2: reading the mask words twice was a memory round trip of a 9-us latency chain)
+    const bool one_chunk = n_ct <= TL_BLOCK;
+    int n_keep = 0, n2_keep = 0;
     for (int c0 = 0; c0 < n_ct; c0 += TL_BLOCK) {
         const int ct = c0 + tid;
         if (ct < n_ct) {
             int n, n2;
             count_tile(ct, n, n2);
+            n_keep = n; n2_keep = n2;
             atomicAdd(&s_hist[SVGR_ORDER ? weight_of(n, n2) : 0], 1);
         }
     }
@@ -2010,7 +2014,8 @@ __global__ __launch_bounds__(TL_BLOCK) void k_tile_lists(const int* __restrict__
     for (int c0 = 0; c0 < n_ct; c0 += TL_BLOCK) {
         const int ct = c0 + tid;
         int n = 0, n2 = 0;
-        if (ct < n_ct) count_tile(ct, n, n2);
+        if (one_chunk) { n = n_keep; n2 = n2_keep; }
+        else if (ct < n_ct) count_tile(ct, n, n2);
         int wtot;
         const int excl = wave_excl_scan(n, lane, wtot);
         if (lane == 0) s_wtot[wave] = wtot;
@@ -2058,8 +2063,21 @@ __global__ __launch_bounds__(TL_BLOCK) void k_tile_lists(const int* __restrict__
                 m = mw[++w];
             }
             const int bit = select_bit(m, r);
-            const int4 eh = *(const int4*)(entries + ent0 + w * 64 + bit);  // {c0, cols, cell0, p}
-            int cell = eh.z + tct - (eh.x - vc0) / TC;
+            int cell;
+            if (bins) {
+                // A planned render (round 5): the band's list -- which path stands at which place -- is the plan's, and k_band_entries
+                // is not launched: it found the same lists again in every render (256 workgroups that each read every path's bins,
+                // 7 us of latency).  What an entry says about its path is read from THIS render's bbox and bins instead.
+                const int ep = entries[ent0 + w * 64 + bit].p;
+                const PathBin pbin = bins[ep];
+                const int4 bb = ((const int4*)bbox)[ep];
+                int ct0_, nct_;
+                path_ctiles(bb.y, bb.w, vc0, ct0_, nct_);
+                cell = pbin.cell_off + (band - pbin.b0) * nct_ + (tct - ct0_);
+            } else {
+                const int4 eh = *(const int4*)(entries + ent0 + w * 64 + bit);  // {c0, cols, cell0, p}
+                cell = eh.z + tct - (eh.x - vc0) / TC;
+            }
             const unsigned cls = ((mw[W + w] >> bit) & 1ull) ? 2u : 1u;
             cell = cell >= 0 && cell < cell_cap ? cell : 0;
             const long long at = (long long)item_band0 + run0 + i;
@@ -4089,7 +4107,10 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     if (upto == 2) return 0;
     // per owned band: its list of (path, band) pairs in paint order, and its first tile-list slot
     const int owned = count_owned_bands(b->own, b->n_bands);
-    if (owned > 0)
+    // (a planned render under the plan's places keeps the plan's band lists: k_tile_lists reads the paths' bboxes and bins itself)
+    static const bool always_entries = getenv("SVGR_ALWAYS_BAND_ENTRIES") != nullptr;
+    const bool keep_lists = upto >= 4 && b->planned && b->slab_at_valid && use_vp && !b->no_band_reuse && !always_entries;
+    if (owned > 0 && !keep_lists)
         hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(BE_BLOCK), 0, st, (const PathBin*)b->bins.p, np_walk, plist,
                            (const int*)b->bbox.p, b->band_start.p, b->band_count.p, b->band_item0.p, b->entries.p,
                            b->pair_idx.p, cap_i32(std::min(b->entries.cap, b->pair_idx.cap)),
@@ -4154,7 +4175,8 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     if (owned > 0 && b->n_ctiles() > 0) {
         hipLaunchKernelGGL(k_tile_lists, dim3(owned), dim3(TL_BLOCK), 0, st, (const int*)b->band_start.p, (const int*)b->band_item0.p,
                            (const TileEntry*)b->entries.p, b->tile_mask.p, b->mask_words, b->n_ctiles(), b->vp[1], b->own, owned,
-                           b->tile_info.p, b->pages.p, b->items.p, (const CellHdr*)b->cell_hdr.p, cap_i32(b->items.cap), cap_i32(b->cell_hdr.cap), b->bd());
+                           b->tile_info.p, b->pages.p, b->items.p, (const CellHdr*)b->cell_hdr.p, cap_i32(b->items.cap), cap_i32(b->cell_hdr.cap), b->bd(),
+                           keep_lists ? (const PathBin*)b->bins.p : (const PathBin*)nullptr, (const int*)b->bbox.p);
         b->masks_zeroed = true;
     }
     return 0;
