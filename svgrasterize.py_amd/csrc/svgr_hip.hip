@@ -1424,6 +1424,14 @@ static_assert(PB_BANDS * SVGR_TR * PB_BATCH < (1 << 20) && PB_BATCH < (1 << 11),
 #ifndef SVGR_PB_WAVES
 #define SVGR_PB_WAVES 6
 #endif
+// The barriers of k_path_build order LDS traffic only -- nothing one wave writes to global memory is read by another inside the
+// kernel --, so they wait for the wave's LDS operations and not, as __syncthreads() does, for its global stores as well: behind
+// pass A those are the add lists on their way out, and a wave that waits for their acknowledgement stands still for a microsecond.
+#ifdef SVGR_DBG_PB_SYNCTHREADS
+__device__ __forceinline__ void pb_barrier() { __syncthreads(); }
+#else
+__device__ __forceinline__ void pb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 template <bool PLANNED>
 __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const Slab* __restrict__ slabs, const double* __restrict__ edges,
                                                            const int* __restrict__ pair_idx, const double* __restrict__ path_paint,
@@ -1538,7 +1546,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         int excl[PB_EPL], wtot[PB_EPL];
 #pragma unroll
         for (int j = 0; j < PB_EPL; ++j) excl[j] = wave_excl_scan(cnt[j] | ((cnt[j] > 0 ? 1 : 0) << 20), lane, wtot[j]);
-        __syncthreads();  // (the previous batch's tasks are done with s_edge / s_pref)
+        pb_barrier();  // (the previous batch's tasks are done with s_edge / s_pref)
         if (PLANNED && plan_pending) {
             if (tid < PB_CELLS) { s_pos[tid] = my_plan.x; s_plan_n[tid] = my_plan.y; }
             plan_pending = false;
@@ -1546,7 +1554,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
 #pragma unroll
         for (int j = 0; j < PB_EPL; ++j)
             if (lane == 0) s_wtot[j][wave] = wtot[j];
-        __syncthreads();
+        pb_barrier();
         int all = 0;
         int pre[PB_EPL];
 #pragma unroll
@@ -1573,7 +1581,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                 if ((us & 15) == 0) s_coarse[us >> 4] = 0x7fffffff;
             }
         }
-        __syncthreads();
+        pb_barrier();
         return total;
     };
     // task t of the staged batch -> its edge's LDS slot and its row offset inside the edge's rows of the slab
@@ -1758,7 +1766,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         else for_rows(total, [&](const RowAt& ra) { count_row(ra, std::false_type{}); });
     }
     if (stats && tid == 0 && n_rows > 0) atomicAdd(&bd->bseg_cursor, n_rows);  // (plan only: edge rows of the batch)
-    __syncthreads();
+    pb_barrier();
     PB_STAMP(2);
     // ---- walk ----
 #ifdef SVGR_DBG_PB_NOSCAN
@@ -1866,7 +1874,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         } else {
             // the slab's reservation of add slots: ONE atomic, in the path's shard
             if (row_l == 0 && g < PB_BANDS) s_ptot[g] = active ? cursor : 0;
-            __syncthreads();
+            pb_barrier();
             if (tid < 64) {  // the bands' offsets: an exclusive scan over <= PB_BANDS totals by the first wave
                 static_assert(PB_BANDS <= 64, "one lane per band of the slab");
                 const int c = tid < sl.nb ? s_ptot[tid] : 0;
@@ -1883,7 +1891,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                     s_ok = ok;
                 }
             }
-            __syncthreads();
+            pb_barrier();
         }
     }
     PB_STAMP(3);
@@ -1916,7 +1924,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         if (threadIdx.x == 0 && dbg && blockIdx.x < 8192) dbg[8 * blockIdx.x + 6] = (unsigned long long)n_rows;
         return;
     }
-    __syncthreads();
+    pb_barrier();
 
     // ---- pass B ----  (PLANNED = false only)
 #ifdef SVGR_DBG_PB_NOB
@@ -5074,7 +5082,8 @@ static int plan_two_pass(svgr_batch* b) {
     {
         // add slots: a few pieces per edge row (more for shallow rows: a piece per PX columns), up to 2 x TR carry-ins and
         // sentinels per cell with pieces.  (synth4096: 7.6 M adds, 2.5 M edge rows, 0.8 M edges, 0.2 M cells: the guess is 11 M -- fresh device memory is cleared before its first use, a cold render pays for every megabyte it asks for)
-        const double guess = 3.0 * (double)rows_x + 1.0 * (double)n_edges + 8.0 * (double)b->n_cells + 65536.0;
+        double guess = 3.0 * (double)rows_x + 1.0 * (double)n_edges + 8.0 * (double)b->n_cells + 65536.0;
+        if (const char* sk = getenv("SVGR_TWO_PASS_SHRINK")) guess /= std::max(atof(sk), 1.0);   // (tests: a guess that is too small on purpose)
         if (guess > (double)(1ll << 29)) return 0;
         int need[NSH];
         for (int k = 0; k < NSH; ++k) need[k] = (int)(guess * 1.25 / NSH) + 8192;

@@ -245,6 +245,44 @@ def test_speculative_plan_overflows_fall_back_cleanly(S, monkeypatch):
     assert_close64(got, want, atol=1e-10, what="re-plan after set_transforms")
 
 
+def test_two_pass_plan_falls_back_when_its_add_guess_is_small(S, monkeypatch):
+    """The first plan of a large batch sizes the add lists by a guess (svgr_hip.hip: plan_two_pass).  With the guess divided on
+    purpose (SVGR_TWO_PASS_SHRINK) the second pass overflows its lists, the kernels flag it instead of writing, and the staged plan
+    -- which measures the lists -- takes over: the same picture as with the guess intact, and as with the staged plan alone."""
+    from svgrasterize_amd import _abi, synth
+
+    size, n = 1536, 1200     # (more than 4096 segments: not the small-batch planner)
+    sc = synth.make_scene(size, n)
+    assert len(sc["segs"]) > 4096
+    ctx = S.Context.get()
+
+    def render():
+        batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
+                           viewport=sc["viewport"])
+        st = batch.plan()
+        out = ctx.alloc(size * size * 32)
+        batch.render(out, _abi.OUT_CANVAS_F64, _abi.RENDER_CLIP01 | _abi.RENDER_DETERMINISTIC)
+        got = out.download((size, size, 4), np.float64)
+        batch.render(out, _abi.OUT_CANVAS_F64, _abi.RENDER_CLIP01 | _abi.RENDER_DETERMINISTIC)   # (a planned render after the fall-back)
+        again = out.download((size, size, 4), np.float64)
+        batch.destroy()
+        assert np.array_equal(got, again)
+        return got, int(st.path_pixels), int(st.n_edges)
+
+    want, P, E = render()
+    assert np.abs(want).max() > 0
+    monkeypatch.setenv("SVGR_TWO_PASS_SHRINK", "64")
+    got, P2, E2 = render()
+    monkeypatch.delenv("SVGR_TWO_PASS_SHRINK")
+    assert (P2, E2) == (P, E)
+    assert np.array_equal(got, want), "the staged fall-back draws another picture"
+    monkeypatch.setenv("SVGR_NO_TWO_PASS_PLAN", "1")
+    staged, P3, E3 = render()
+    monkeypatch.delenv("SVGR_NO_TWO_PASS_PLAN")
+    assert (P3, E3) == (P, E)
+    assert np.array_equal(staged, want), "the two-pass plan and the staged plan draw different pictures"
+
+
 def test_mask_prefetch_is_only_a_cache(S):
     """Scene.render renders all the Path.mask calls of its per-node route in one SVGR_OUT_MASKS_F64 batch.  Same result as
     the on-demand single-path masks; a path used twice, an empty path, a clipped-away path and an evenodd rule included."""
