@@ -3414,8 +3414,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
 #endif
         if (!go) break;
         pend = OUT == 0;   // (the other outputs stored in front of the loads: their waits cover the stores anyway)
-#ifdef SVGR_DBG_NOPEND
-        pend = false;      // diagnostic: the next tile's first waits also wait for the stores
+#if defined(SVGR_DBG_NOPEND) || defined(SVGR_DBG_NOSTORE)
+        pend = false;      // diagnostic: the next tile's first waits also wait for the stores (NOSTORE: there are none to step over)
 #endif
     }
 
@@ -5568,7 +5568,9 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         const int wgs_per_cu = wgs_env >= 0 ? wgs_env : wgs_variant;
         const bool production = out_kind == 0 && b->n_grads == 0 && b->n_groups == 0 && !b->has_clips;   // (the variant with the tile loop)
         unsigned n_wgs = n_tiles;
-        if (a.use_order && production && wgs_per_cu > 0) n_wgs = std::min(n_tiles, (unsigned)wgs_per_cu * (unsigned)b->ctx->n_cu);
+        // (windows launched side by side on streams of their own take a workgroup per tile: the persistent launch's two sets of tile
+        //  counters alternate per launch, which is only sound for launches that follow each other on ONE stream)
+        if (a.use_order && production && wgs_per_cu > 0 && tile_st == nullptr) n_wgs = std::min(n_tiles, (unsigned)wgs_per_cu * (unsigned)b->ctx->n_cu);
         a.tile_ctr = a.tile_ctr_clear = b->ctx->tile_ctr;
         if (n_wgs < n_tiles) {   // (a persistent launch: this set of counters, and the other one zeroed for the next such launch)
             a.tile_ctr = b->ctx->tile_ctr + 256 * b->ctx->tile_ctr_set;

@@ -19,10 +19,16 @@ def n_bands(rows: int, tile_rows: int) -> int:
 def default_strip_bands(rows: int, tile_rows: int, world: int) -> int:
     """Bands per strip when the caller does not choose: ONE strip per rank -- a rank flattens every path that reaches one of its
     strips completely, so the tallest strips duplicate the least geometry (round 4, emulated on one GPU, config 4: the slowest of
-    8 / 4 / 2 ranks 0.1249 -> 0.1225, 0.1972 -> 0.1925, 0.3551 -> 0.3489 ms against two interleaved strips per rank) --, never
-    less than 128 scanlines.  A drawing whose content is bunched in a few rows wants `SVGR_STRIP_BANDS` smaller."""
-    nb = n_bands(rows, tile_rows)
-    return max(max(1, 128 // tile_rows), -(-nb // max(world, 1)))
+    8 / 4 / 2 ranks 0.1249 -> 0.1225, 0.1972 -> 0.1925, 0.3551 -> 0.3489 ms against two interleaved strips per rank) --, not
+    under 128 scanlines where the canvas allows it, and never so tall that a rank is left without rows.  A drawing whose content is bunched in a few rows wants `SVGR_STRIP_BANDS` smaller."""
+    nb, world = n_bands(rows, tile_rows), max(world, 1)
+    strip = -(-nb // world)                       # one strip per rank ...
+    if nb >= world and -(-nb // strip) < world:   # ... unless rounding up leaves a rank without rows (17 bands on 8 ranks: strips of 3
+        strip = nb // world                       #     are 6 strips): then the shorter strip, and some ranks own two
+    floor_ = max(1, 128 // tile_rows)             # (not under 128 scanlines -- as long as that does not idle a rank either)
+    if strip < floor_ and -(-nb // floor_) >= min(world, nb):
+        strip = floor_
+    return max(strip, 1)
 
 
 def owned_bands(rows: int, tile_rows: int, rank: int, world: int, strip: int = 1) -> list[int]:

@@ -99,12 +99,16 @@ def test_default_strip_bands_one_strip_per_rank():
     from svgrasterize_amd import dist as sdist
 
     assert sdist.default_strip_bands(8192, 16, 8) == 64 and sdist.default_strip_bands(8192, 16, 2) == 256
-    assert sdist.default_strip_bands(4096, 16, 8) == 32 and sdist.default_strip_bands(512, 16, 8) == 8
+    assert sdist.default_strip_bands(4096, 16, 8) == 32 and sdist.default_strip_bands(512, 16, 8) == 4   # (8 would idle four ranks)
     assert sdist.default_strip_bands(4096, 16, 3) == 86
-    for rows, world in ((8192, 8), (4096, 3), (1000, 4), (100, 2)):
+    assert sdist.default_strip_bands(17 * 16, 16, 8) == 2      # (rounding up: strips of 3 = 6 strips for 8 ranks)
+    for rows, world in ((8192, 8), (4096, 3), (1000, 4), (100, 2), (17 * 16, 8), (512, 8), (40, 8), (16 * 9, 8)):
         strip = sdist.default_strip_bands(rows, 16, world)
-        owners = [sum(b in sdist.owned_bands(rows, 16, r, world, strip) for r in range(world)) for b in range(sdist.n_bands(rows, 16))]
-        assert owners == [1] * sdist.n_bands(rows, 16)
+        nb = sdist.n_bands(rows, 16)
+        owned = [sdist.owned_bands(rows, 16, r, world, strip) for r in range(world)]
+        owners = [sum(b in o for o in owned) for b in range(nb)]
+        assert owners == [1] * nb                                   # every band has one owner
+        assert sum(1 for o in owned if o) == min(world, nb), (rows, world, strip)   # and no rank idles while there are bands to own
 
 
 def test_batch_routing_of_scene_nodes_is_host_logic():
