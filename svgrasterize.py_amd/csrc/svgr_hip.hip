@@ -113,6 +113,9 @@ static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 102
 #ifndef SVGR_X_CARRY1
 #define SVGR_X_CARRY1 1                 // class-2 cells: the carry-in block of the header neither written (k_path_build) nor fetched (tile kernel)
 #endif
+#ifndef SVGR_X_SHDR
+#define SVGR_X_SHDR 0                   // production tile kernel: the uniform 64 bytes of an item's header by a SCALAR load (an item ahead) instead of 16 v_readlane of the vector load (measured in round 5: see DESIGN section 4)
+#endif
 #ifndef SVGR_X_CMPX
 #define SVGR_X_CMPX 1                   // the 1e-6 cut as v_cmpx around the pixel's block instead of a saveexec + branch
 #endif
@@ -2502,6 +2505,23 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         return (const int*)(a.cell_hdr + (cw & 0x3fffffffu)) + hdr_lane;
 #endif
     };
+    struct SHdr { int w[16]; };
+    // the first 64 bytes of the header of item j of the round, by scalar loads (past the round's end: of cell 0 -- any valid header)
+    auto load_shdr = [&](int j) -> SHdr {
+        SHdr o;
+        if constexpr (FIXED && SVGR_X_SHDR) {
+            typedef const int __attribute__((address_space(4))) * CIntPtr;
+            const unsigned cw = j < n_round ? (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63) : 0u;
+            CIntPtr hp = (CIntPtr)(const int*)(a.cell_hdr + (cw & 0x3fffffffu));
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o.w[q] = hp[q];
+            if (j >= n_round) o.w[12] = 0;   // (class 0: nothing to do)
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o.w[q] = 0;
+        }
+        return o;
+    };
     auto hdr_cls = [&](int h) { return (__builtin_amdgcn_readlane(h, 12) >> 3) & 3; };
     // class 2: this lane's first add of the item (its later ones, for lists longer than the workgroup, are loaded by the
     // scatter); else the list's first entry: any valid address
@@ -2699,18 +2719,22 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         asm volatile("" : "+s"(sm1_), "+s"(sm2_), "+s"(sm4_));
     }
 #endif
-    auto process = [&](int h, int buf) {
-        const int bits = __builtin_amdgcn_readlane(h, 12);
+    // (SVGR_X_SHDR, production variant: the sixteen uniform dwords of the header come from a scalar load issued an item ahead --
+    //  `sh` -- instead of sixteen v_readlane of the vector load `h`, which then only carries the class-1 carry-ins)
+    auto process = [&](int h, const SHdr& sh, int buf) {
+        constexpr bool SH = FIXED && SVGR_X_SHDR;
+        auto hw = [&](int j) { return SH ? sh.w[j] : __builtin_amdgcn_readlane(h, j); };
+        const int bits = hw(12);
         const int cls = (bits >> 3) & 3;
         if (cls == 0) return;
         const int rule = bits & 1, pflags = (bits >> 1) & 3;
-        const double p0 = __hiloint2double(__builtin_amdgcn_readlane(h, 1), __builtin_amdgcn_readlane(h, 0));
-        const double p1 = __hiloint2double(__builtin_amdgcn_readlane(h, 3), __builtin_amdgcn_readlane(h, 2));
-        const double p2 = __hiloint2double(__builtin_amdgcn_readlane(h, 5), __builtin_amdgcn_readlane(h, 4));
-        const double p3 = __hiloint2double(__builtin_amdgcn_readlane(h, 7), __builtin_amdgcn_readlane(h, 6));
-        const int r0 = __builtin_amdgcn_readlane(h, 8), c0 = __builtin_amdgcn_readlane(h, 9);
-        const int rows = __builtin_amdgcn_readlane(h, 10), cols = __builtin_amdgcn_readlane(h, 11);
-        const int pid = __builtin_amdgcn_readlane(h, 15);
+        const double p0 = __hiloint2double(hw(1), hw(0));
+        const double p1 = __hiloint2double(hw(3), hw(2));
+        const double p2 = __hiloint2double(hw(5), hw(4));
+        const double p3 = __hiloint2double(hw(7), hw(6));
+        const int r0 = hw(8), c0 = hw(9);
+        const int rows = hw(10), cols = hw(11);
+        const int pid = hw(15);
         const int row_shift = r0 - tile_r0;  // layer row y  -> tile row  y + row_shift
         const int col_shift = c0 - tile_c0;  // layer col x  -> tile col  x + col_shift
         const int lo_c = col_shift < 0 ? -col_shift : 0;             // first layer column inside the tile
@@ -3338,6 +3362,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
                 }
             }
             scatter(h_p, w_s, v_s, 0);
+            SHdr sh_cur = load_shdr(0);
             for (int k = 0; k < n; ++k) {
                 // in hand: the headers of items k, k+1, k+2 and the add of item k+1; the adds of item k are on their way into
                 // delta tile k & 1
@@ -3358,7 +3383,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
                     const void* ap = add_ptr(k + 2);
                     SVGR_ADD_LOAD(wq, vq, ap);
                 }
-                process(h_p, k & 1);
+                process(h_p, sh_cur, k & 1);
+                sh_cur = load_shdr(k + 1);   // (asked for behind the item's last use of its own: one set of sixteen scalar registers)
                 h_p = h_s; h_s = h_a;
 #if defined(SVGR_DBG_TIMELINE) && defined(SVGR_DBG_TL_WAITS)
                 const unsigned long long ci0_ = __builtin_readcyclecounter();
