@@ -3914,6 +3914,13 @@ struct svgr_batch {
     bool sized = false;           // a plan has succeeded with the viewport `sized_vp`: the buffers' capacities are a re-plan's guesses
     int sized_vp[4] = {0, 0, 0, 0};
     bool no_band_reuse = false;   // SVGR_NO_BAND_REUSE as it stood when the plan was made (the A/B switches are read at plan time: all of them)
+    bool no_lane_places = false, always_entries = false;   // SVGR_NO_LANE_PLACES, SVGR_ALWAYS_BAND_ENTRIES: likewise
+    void read_switches() {
+        no_band_reuse = getenv("SVGR_NO_BAND_REUSE") != nullptr;
+        no_lane_places = getenv("SVGR_NO_LANE_PLACES") != nullptr;
+        always_entries = getenv("SVGR_ALWAYS_BAND_ENTRIES") != nullptr;
+        add_places = getenv("SVGR_NO_ADD_PLACES") == nullptr;   // (every planner ends in a full pass: it left every cell's add places)
+    }
     bool has_clips = false;    // any SVGR_PATH_CLIP_SOURCE / SVGR_PATH_CLIPPED path
     int64_t n_groups = 0;      // isolated groups (svgr_batch_set_groups)
     DevArr<int> path_group, group_clip_src;
@@ -4121,7 +4128,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     }
     if (ns > 0) {
         // (the counting pass that made `seg_off` left every lane's place inside its segment's slots beside it)
-        static const bool lane_places = getenv("SVGR_NO_LANE_PLACES") == nullptr;
+        const bool lane_places = !b->no_lane_places;
         auto launch_fl = [&](auto kern, int* places) {
             hipLaunchKernelGGL(kern, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                                (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
@@ -4142,8 +4149,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     // per owned band: its list of (path, band) pairs in paint order, and its first tile-list slot
     const int owned = count_owned_bands(b->own, b->n_bands);
     // (a planned render under the plan's places keeps the plan's band lists: k_tile_lists reads the paths' bboxes and bins itself)
-    static const bool always_entries = getenv("SVGR_ALWAYS_BAND_ENTRIES") != nullptr;
-    const bool keep_lists = upto >= 4 && b->planned && b->slab_at_valid && use_vp && !b->no_band_reuse && !always_entries;
+    const bool keep_lists = upto >= 4 && b->planned && b->slab_at_valid && use_vp && !b->no_band_reuse && !b->always_entries;
     if (owned > 0 && !keep_lists)
         hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(BE_BLOCK), 0, st, (const PathBin*)b->bins.p, np_walk, plist,
                            (const int*)b->bbox.p, b->band_start.p, b->band_count.p, b->band_item0.p, b->entries.p,
@@ -4864,8 +4870,7 @@ static int spec_finish(svgr_batch* b) {
     b->planned = true;
     b->sized = true;
     for (int k = 0; k < 4; ++k) b->sized_vp[k] = b->vp[k];
-    b->no_band_reuse = getenv("SVGR_NO_BAND_REUSE") != nullptr;
-    b->add_places = getenv("SVGR_NO_ADD_PLACES") == nullptr;   // (the pass behind this plan was a full one: it left every cell's add places)
+    b->read_switches();
     b->geometry_fresh = true; b->geometry_current = true;
     return 1;
 }
@@ -5175,8 +5180,7 @@ static int plan_two_pass(svgr_batch* b) {
     b->planned = true;
     b->sized = true;
     for (int k = 0; k < 4; ++k) b->sized_vp[k] = b->vp[k];
-    b->no_band_reuse = getenv("SVGR_NO_BAND_REUSE") != nullptr;
-    b->add_places = getenv("SVGR_NO_ADD_PLACES") == nullptr;   // (pass 2 was a full one: it left every cell's add places)
+    b->read_switches();
     b->geometry_fresh = true; b->geometry_current = true;
     return 1;
 }
@@ -5273,8 +5277,7 @@ static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
     b->planned = true;
     b->sized = true;
     for (int k = 0; k < 4; ++k) b->sized_vp[k] = b->vp[k];
-    b->no_band_reuse = getenv("SVGR_NO_BAND_REUSE") != nullptr;
-    b->add_places = getenv("SVGR_NO_ADD_PLACES") == nullptr;   // (step 4 was a full pass: it left every cell's add places)
+    b->read_switches();
     b->geometry_fresh = true; b->geometry_current = true;
     return 0;
 }

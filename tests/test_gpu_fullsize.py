@@ -180,6 +180,16 @@ def test_planned_slab_places_do_not_change_the_picture(S, monkeypatch):
         e = render(bands)
         assert np.array_equal(a, e), f"add places from the plan change the picture (bands {bands})"
         monkeypatch.delenv("SVGR_NO_ADD_PLACES", raising=False)
+        # ... the lanes' edge places in k_flatten (from the counting pass, or by a prefix sum again), and the band lists (kept from
+        # the plan, k_tile_lists reading bboxes and bins -- or k_band_entries launched in every render): the same bits
+        monkeypatch.setenv("SVGR_NO_LANE_PLACES", "1")
+        g = render(bands)
+        assert np.array_equal(a, g), f"lane places in k_flatten change the picture (bands {bands})"
+        monkeypatch.delenv("SVGR_NO_LANE_PLACES", raising=False)
+        monkeypatch.setenv("SVGR_ALWAYS_BAND_ENTRIES", "1")
+        h = render(bands)
+        assert np.array_equal(a, h), f"band lists kept from the plan change the picture (bands {bands})"
+        monkeypatch.delenv("SVGR_ALWAYS_BAND_ENTRIES", raising=False)
 
 
 def test_synth_8192_config4_windows(S):
