@@ -137,6 +137,56 @@ def test_ragged_batch_with_empty_and_offscreen_paths(S):
     assert np.abs(got - ref).max() < 1e-13
 
 
+def test_paths_wider_than_a_slab_and_taller_than_a_slab(S):
+    """k_path_build works on slabs of a path's cells: at most 80 cells, at most 16 bands.  A path wider than 80 column tiles
+    (5120 px) is cut band by band into RUNS of column tiles -- the later runs of a band row start from the sum of everything
+    left of them, and from the rows that have a piece there --, a tall one into runs of bands, a long batch of edges (more than
+    256 per path) is staged in several batches.  Shallow and steep edges, both fill rules, planned renders and the plan's own
+    pass, against the CPU oracle."""
+    from svgrasterize_amd import _abi
+    from oracle import oracle as orc
+
+    W, H = 6400, 400
+    rng = np.random.default_rng(11)
+
+    def poly(pts):
+        pts = np.asarray(pts, dtype=np.float64)
+        nxt = np.roll(pts, -1, axis=0)
+        out = np.zeros((len(pts), 8))
+        out[:, 0:2], out[:, 2:4] = pts, nxt       # (row, col) pairs: lines use the first four numbers
+        return out
+
+    # a sliver across the whole width (shallow edges: hundreds of columns per row), a zig-zag band with ~600 edges, a tall wedge,
+    # a self-overlapping star (evenodd), a rectangle hanging out of the viewport on the left and right
+    sliver = poly([(50.3, 3.7), (61.9, 6390.2), (80.5, 6395.8), (64.2, 9.1)])
+    zz = [(120.0 + 30 * (i % 2) + 0.37 * i % 7, 10.0 + i * (W - 20) / 300) for i in range(301)]
+    zz += [(220.0 + 25 * (i % 2), 10.0 + i * (W - 20) / 300) for i in range(300, -1, -1)]
+    zigzag = poly(zz)
+    wedge = poly([(5.5, 3000.25), (395.5, 3100.75), (390.25, 2890.5)])
+    star = poly([(200 + 180 * np.cos(2 * np.pi * 2 * k / 5), 5200 + 900 * np.sin(2 * np.pi * 2 * k / 5)) for k in range(5)])
+    hang = poly([(300.5, -700.0), (300.5, W + 500.0), (340.25, W + 500.0), (340.25, -700.0)])
+    parts = [sliver, zigzag, wedge, star, hang]
+    segs = np.concatenate(parts)
+    off = np.concatenate([[0], np.cumsum([len(p) for p in parts])])
+    kinds = np.zeros(len(segs), np.uint8)
+    rules = np.array([0, 0, 0, 1, 0], np.uint8)
+    paints = rng.uniform(0.1, 0.9, size=(5, 4))
+    paints[:, :3] *= paints[:, 3:]
+    ident = np.tile([1.0, 0, 0, 0, 1, 0], (5, 1))
+    vp = (0, 0, H, W)
+    ctx = S.Context.get()
+    batch = _abi.Batch(ctx, segs, kinds, off, ident, rules, paints, viewport=vp)
+    st = batch.plan()
+    out = ctx.alloc(H * W * 32)
+    ref, P, _ = orc.render_solid(segs, kinds, off, rules, paints, vp, clip01=False)
+    assert st.path_pixels == P
+    for _ in range(3):   # (the plan's own geometry, then two planned renders)
+        batch.render(out, _abi.OUT_CANVAS_F64)
+        got = out.download((H, W, 4), np.float64)
+        assert np.abs(got - ref).max() < 1e-11, np.abs(got - ref).max()
+    batch.destroy()
+
+
 def test_layer_image_is_mutable_after_download(S):
     """font_speciment.py-style use: callers mutate mask.image in place; later ops must see it."""
     p = S.Path.from_svg("M1,1 H9 V9 H1 Z")
