@@ -40,7 +40,7 @@ _INV_MEMO: dict = {}
 
 
 class Transform:
-    __slots__ = ["m", "_m_inv"]
+    __slots__ = ["m", "_m_inv", "_m6", "_key"]
 
     def __init__(self, matrix=None, matrix_inv=None):
         if matrix is None:
@@ -49,6 +49,7 @@ class Transform:
         else:
             self.m = matrix
             self._m_inv = matrix_inv
+        self._m6 = self._key = None   # (made on first use: the leaves of a group share their accumulated transform)
 
     def __matmul__(self, other: "Transform") -> "Transform":
         return Transform(self.m @ other.m)
@@ -108,11 +109,16 @@ class Transform:
 
     def m6(self) -> np.ndarray:
         """The six numbers the C ABI takes: rows 0-1 of the matrix."""
-        return np.ascontiguousarray(self.m[:2, :], dtype=FLOAT).reshape(6)
+        if self._m6 is None:
+            self._m6 = np.ascontiguousarray(self.m[:2, :], dtype=FLOAT).reshape(6)
+            self._m6.flags.writeable = False   # (handed out to many leaves: the matrix of a Transform does not change)
+        return self._m6
 
     def key(self) -> bytes:
         """The matrix as bytes (memo keys)."""
-        return self.m[:2, :].tobytes()
+        if self._key is None:
+            self._key = self.m[:2, :].tobytes()
+        return self._key
 
     def __repr__(self) -> str:
         return str(np.around(self.m, 4).tolist()[:2])

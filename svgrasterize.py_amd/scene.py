@@ -736,6 +736,8 @@ _GROUP_SERIAL = [0]
 _BATCH_GROUPS = __import__("os").environ.get("SVGR_NO_BATCH_GROUPS") is None  # (off: isolated groups take the per-node route)
 _BATCH_GRADS = __import__("os").environ.get("SVGR_NO_BATCH_GRADIENTS") is None  # (off: gradient fills take the per-node route)
 _ONES = np.ones(4)
+_ZERO4 = np.zeros(4)
+_ZERO4.flags.writeable = False   # (the paint of every clip source)
 _PAUSE_GC = __import__("os").environ.get("SVGR_PAUSE_GC") is not None  # (set: the cyclic collector pauses for the duration of a top-level Scene.render)
 _GRAD_ABI_MEMO: dict = {}  # (id(gradient), transform bytes, linear_rgb) -> (gradient, svgr_gradient struct, keep-alive)
 
@@ -807,6 +809,9 @@ def _batchable_leaves_(scene: Scene, transform: Transform, linear_rgb: bool, opa
     tile and clips / fades that as a whole, svgr_batch_set_groups).  Source-over is associative, so flattening nested
     plain groups keeps the per-pixel result (to double rounding)."""
     kind, args = scene
+    while kind == RENDER_TRANSFORM:   # (a chain of transforms over a node: unwrapped here, not by a call per level)
+        transform = transform @ args[1]
+        kind, args = scene = args[0]
     if kind == RENDER_FILL:
         path, paint, rule = args
         if paint is None:
@@ -827,8 +832,6 @@ def _batchable_leaves_(scene: Scene, transform: Transform, linear_rgb: bool, opa
     if kind == RENDER_STROKE:  # a solid stroke is a solid fill of its outline (S:666-672), nonzero rule
         path, paint, width, linecap, linejoin = args
         return _batchable_leaves(Scene.fill(_stroked(scene), paint, None), transform, linear_rgb, opacity)
-    if kind == RENDER_TRANSFORM:
-        return _batchable_leaves(args[0], transform @ args[1], linear_rgb, opacity)
     if kind == RENDER_OPACITY and opacity is None:
         target = args[0]
         while target[0] == RENDER_TRANSFORM:
@@ -847,11 +850,15 @@ def _batchable_leaves_(scene: Scene, transform: Transform, linear_rgb: bool, opa
         # (A group under a clip is NOT the same as clipping each child: (A over B)*c != (A*c) over (B*c).)
         target = _batchable_leaves(args[0], transform, linear_rgb)
         clip_leaf = _single_mask_leaf(args[1], transform)
-        if target is None or clip_leaf is None or not target or not _plain(target):
+        if target is None or clip_leaf is None or not target:
             return None
         if len(target) == 1:
             t = target[0]
-            return [clip_leaf, _leaf(t[0], t[1], t[2], t[3], 2, None, t[6])]
+            if t[4] != 0 or t[5] is not None:
+                return None
+            return [clip_leaf, (t[0], t[1], t[2], t[3], 2, None, t[6])]
+        if not _plain(target):
+            return None
         if not _BATCH_GROUPS:
             return None
         # a GROUP under the clip: composited on its own, then multiplied by the clip's coverage as a whole
@@ -879,7 +886,7 @@ def _single_mask_leaf(scene: Scene, transform: Transform):
     path, _paint, rule = args
     if rule not in _RULES:
         raise ValueError(f"Invalid fill rule: {rule}")
-    return _leaf(path, transform.m6(), _RULES[rule], np.zeros(4), 1)
+    return (path, transform.m6(), _RULES[rule], _ZERO4, 1, None, None)
 
 
 def _effective_boxes(leaves, bboxes):
