@@ -1395,8 +1395,8 @@ __device__ __forceinline__ unsigned add_where(int trow, int tcol, int len) {
 // The rows are dealt to the lanes as RUNS of consecutive (edge, row) tasks, not edge by edge (a lane per edge runs as long as
 // the longest edge of its wave: a synthetic blob has mean 3 rows, longest 49; real drawings hundreds next to two) and not row
 // by row either (a lane that starts in the middle of an edge replays the reference's x recurrence, S:2244-2248, from the
-// edge's first row: per task that was a tenth of the kernel): a lane finds its first task's edge by a two-level 16-way search
-// in the prefix sums of the staged edges' row counts, replays to its row once, and from there on takes ONE row_step per task,
+// edge's first row: per task that was a tenth of the kernel): a lane reads its first task's edge from `s_start` (written by the
+// staged edge whose rows hold that task), replays to its row once, and from there on takes ONE row_step per task,
 // moving to the next staged edge when the edge's rows end.  Staged edges are compacted -- only those with a row inside the
 // slab are kept -- so "the next edge" is the next slot.
 // ---------------------------------------------------------------------------------------------
@@ -1457,7 +1457,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     __shared__ __attribute__((aligned(16))) EdgeLds s_edge[PB_BATCH];
     __shared__ int s_eya[PB_BATCH];              // per staged edge: ya | (dir < 0) << 31
     __shared__ __attribute__((aligned(16))) int s_pref[PB_BATCH + 4];
-    __shared__ __attribute__((aligned(16))) int s_coarse[32];
+    __shared__ unsigned short s_start[PB_THREADS];   // per lane: the staged edge that holds the first task of its run
     __shared__ int s_wtot[PB_EPL][PB_THREADS / 64];
     __shared__ __attribute__((aligned(8))) int2 s_info[PB_CELLS];   // per cell: adds in front of it in its band, class
     __shared__ unsigned s_rowm[PB_CELLS];                           // ... rows with a carry-in add | rows with a sentinel << 16
@@ -1475,7 +1475,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         s_cnt[i] = 0; s_pos[i] = (int)0x80000000; s_plan_n[i] = 0; s_rowb[i] = 0u; s_info[i] = make_int2(0, 0);
     }
     if (tid < TR) s_left[tid] = 0.0;
-    if (tid == 0) { s_rowb[PB_CELLS] = 0u; s_pref[PB_BATCH] = 0x7fffffff; }
+    if (tid == 0) s_rowb[PB_CELLS] = 0u;
     // (both scalar loads asked for together: the slab first, the test of the cursor behind it -- the grid never exceeds the list)
     const Slab sl = slabs[blockIdx.x];
     const int n_slabs_now = bd->slab_cursor;
@@ -1500,6 +1500,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     auto cell_of = [&](int g, int k) { return sl.cell_off + (sl.band0 + g - sl.b0) * nct + sl.k0 + k; };
     // PLANNED: the cells' places {first add, pieces}, asked for here -- in front of the edges, so they have landed when the
     // edges have -- and put into LDS by the first stage()
+    int s_per = 0;   // tasks per lane of the staged batch (stage -> for_rows)
     int2 my_plan = make_int2((int)0x80000000, 0);
     bool plan_pending = false;
     // (the place of the (path, band) pair of this lane's band in its band's list -- what the walk's lane 0 of every band sets
@@ -1568,6 +1569,13 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             pre[j] = before + excl[j];
         }
         const int n_live = all >> 20, total = all & 0xfffff;
+        // the tasks are dealt as runs of `per` (for_rows): the run of lane k starts at task k * per -- the edge that holds that task
+        // says so itself (`s_start[k]`: a lane reads where it starts instead of searching the prefix sums: 90 vector instructions
+        // and two dependent rounds of LDS reads per wave)
+        const int nl = det ? 64 : PB_THREADS;
+        const int per = (total + nl - 1) / nl;
+        s_per = per;
+        const float inv_per = per > 0 ? 1.0f / (float)per : 0.f;
 #pragma unroll
         for (int j = 0; j < PB_EPL; ++j) {
             if (cnt[j] > 0) {
@@ -1575,37 +1583,16 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                 s_edge[cs] = el[j];
                 s_eya[cs] = eya[j];
                 s_pref[cs] = tp;
-                if ((cs & 15) == 0) s_coarse[cs >> 4] = tp;
-            }
-            // (behind the kept edges: larger than any task number, so that the searches stop in front of them)
-            const int us = tid + j * PB_THREADS;
-            if (us >= n_live && us < PB_BATCH) {
-                s_pref[us] = 0x7fffffff;
-                if ((us & 15) == 0) s_coarse[us >> 4] = 0x7fffffff;
+                if (cs == n_live - 1) s_pref[n_live] = 0x7fffffff;   // (behind the last kept edge: larger than any task number)
+                // k0 = ceil(tp / per): a float estimate (tp < 2^20, exact in float), put right by two compares
+                int k0 = (int)((float)tp * inv_per);
+                k0 += k0 * per < tp ? 1 : 0;
+                k0 -= (k0 - 1) * per >= tp ? 1 : 0;
+                for (int k = k0; k * per < tp + cnt[j]; ++k) s_start[k] = (unsigned short)cs;
             }
         }
         pb_barrier();
         return total;
-    };
-    // task t of the staged batch -> its edge's LDS slot and its row offset inside the edge's rows of the slab
-    auto find = [&](int t, int& slot, int& dy) {
-        const int4* cq = (const int4*)s_coarse;
-        int blk = -1;
-#pragma unroll
-        for (int q = 0; q < PB_BATCH / 64; ++q) {
-            const int4 v = cq[q];
-            blk += (v.x <= t) + (v.y <= t) + (v.z <= t) + (v.w <= t);
-        }
-        const int4* fq = (const int4*)(s_pref + 16 * blk);
-        int in = -1, at = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int4 v = fq[q];
-            in += (v.x <= t) + (v.y <= t) + (v.z <= t) + (v.w <= t);
-            at = v.x <= t ? v.x : at; at = v.y <= t ? v.y : at; at = v.z <= t ? v.z : at; at = v.w <= t ? v.w : at;
-        }
-        slot = 16 * blk + in;
-        dy = t - at;
     };
     // the row of a task: its pieces (S:2250-2303) and where they fall
     struct RowAt {
@@ -1629,12 +1616,13 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     //  order from render to render, and in the same order by the plan's passes and by the planned renders)
     auto for_rows = [&](int total, auto&& body) {
         const int nl = det ? 64 : PB_THREADS;
-        const int per = (total + nl - 1) / nl;
+        const int per = s_per;
         int t = tid * per;
         const int t1 = t + per < total ? t + per : total;
         if (tid >= nl || t >= t1) return;
-        int slot, dy;
-        find(t, slot, dy);
+        const int slot0 = s_start[tid];
+        int slot = slot0;
+        const int dy = t - s_pref[slot0];
         EdgeLds el = s_edge[slot];
         int ya_dir = s_eya[slot];
         int y = ya_dir & 0x7fffffff;
