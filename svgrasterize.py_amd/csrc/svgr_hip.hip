@@ -587,11 +587,15 @@ __global__ __launch_bounds__(256) void k_seg_select(const int* __restrict__ seg_
 #define SVGR_FL_SUB 5
 #endif
 constexpr int FL_SUB = SVGR_FL_SUB;       // 32 lanes per segment: the longest lane bounds the kernel, so cut subtrees small
-constexpr int FL_BLOCK = 256;     // waves are independent (no block-level step)
+constexpr int FL_BLOCK = 256;     // (the waves are independent up to the last step: the segments of a workgroup fold their extents per path)
 // PLACED (with EMIT): the pass stores the edges at the places the plan's counting pass left PER LANE (`lane_off`: a lane's first
 // edge inside its segment's slots) -- one traversal that stores as it goes: no remembered end points, no prefix sum over the
 // lanes, no second traversal for the lanes with many pieces.  The count a lane finds is checked against its place's size.
-template <bool EMIT, bool PLACED = false>
+// SUB: log2 of the lanes a segment is cut over.  5 (32 lanes, two segments per wave) when the launch fills the chip: more lanes
+// per segment repeat the upper levels for nothing (64 lanes: 39 against 28.8 us on the bench scene, round 4).  6 (a wave per
+// segment) when it does NOT -- a drawing of a few thousand segments, one rank's share of a large one: the launch then lasts as
+// long as its longest lane, and a lane of a 64-way cut has half the subtree (the tiger @ 2048: 31.5 us for 3 000 segments).
+template <bool EMIT, bool PLACED = false, int SUB = SVGR_FL_SUB>
 #ifndef SVGR_FL_WAVES
 #define SVGR_FL_WAVES 1
 #endif
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
     // same from render to render, and the kernel makes no returning atomic.  Without it (svgr_batch_all_edges): a
     // reservation per wave in one of NSH sharded cursors.
     const int gtid = blockIdx.x * FL_BLOCK + threadIdx.x;
-    const int item = gtid >> FL_SUB, sub = gtid & ((1 << FL_SUB) - 1);
+    const int item = gtid >> SUB, sub = gtid & ((1 << SUB) - 1);
     // (multi-GPU: the plan's list of the segments this rank needs; else every segment)
     const int seg = seg_list ? (item < n_list ? seg_list[item] : n_segs) : item;
     bool seg_ok = seg < n_segs;
@@ -642,12 +646,12 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
         } else {
             load_seg_points(segs, seg, m6, 4, node);
             mode = 2;
-            for (int l = 0; l < FL_SUB; ++l) {
+            for (int l = 0; l < SUB; ++l) {
                 if (cubic_flatness(node) < thr) {
-                    mode = (sub & ((1 << (FL_SUB - l)) - 1)) == 0 ? 1 : 0;
+                    mode = (sub & ((1 << (SUB - l)) - 1)) == 0 ? 1 : 0;
                     break;
                 }
-                if ((sub >> (FL_SUB - 1 - l)) & 1) cubic_right_inplace(node); else cubic_left_inplace(node);
+                if ((sub >> (SUB - 1 - l)) & 1) cubic_right_inplace(node); else cubic_left_inplace(node);
             }
         }
     }
@@ -685,7 +689,7 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
     for (int k = 0; k < 2 * FL_ENDS; ++k) qe[k] = 0.0;
     // (the plan's counting pass also adds up the rows and columns the kept pieces cross: what the first guess of the add lists'
     //  size is made from -- batch_plan_two_pass)
-    constexpr int SEGL_ = 1 << FL_SUB;  // lanes per segment
+    constexpr int SEGL_ = 1 << SUB;  // lanes per segment
     if constexpr (PLACED) {
         // this lane's place: [first, first + n_plan) of its segment's slots
         int first = seg_ok ? lane_off[(size_t)seg * SEGL_ + sub] : 0;
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
         } else if (mode == 2) {
             track(node[0], node[1]);
             int at = 0;
-            n_found = flatten_subtree<1>(node, thr, kMaxFlattenDepth - FL_SUB, [&](double r0_, double c0_, double r1, double c1) {
+            n_found = flatten_subtree<1>(node, thr, kMaxFlattenDepth - SUB, [&](double r0_, double c0_, double r1, double c1) {
                 track(r1, c1);
                 if (at < n_plan && base_p + at < edge_cap) {
                     store_edge(edges, base_p + at, r0_, c0_, r1, c1);
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
         // pieces come in curve order and share end points: track the first start and every end.  The ends of the
         // first two pieces are remembered: nearly every lane has one or two, and then the second traversal is skipped.
         track(node[0], node[1]);
-        cnt = flatten_subtree<FL_ENDS>(node, thr, kMaxFlattenDepth - FL_SUB, [&](double r0_, double, double r1, double c1) {
+        cnt = flatten_subtree<FL_ENDS>(node, thr, kMaxFlattenDepth - SUB, [&](double r0_, double, double r1, double c1) {
             track(r1, c1);
             if (census) rows_x += fabs(r1 - r0_);
         }, ovf, qe);
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
         const int lane = threadIdx.x & 63;
         int wtot;
         const int excl = wave_excl_scan(cnt, lane, wtot);
-        constexpr int SEGL = 1 << FL_SUB;  // lanes per segment
+        constexpr int SEGL = 1 << SUB;  // lanes per segment
         const int seg_first = __shfl(excl, lane & ~(SEGL - 1)), seg_total = __shfl(excl + cnt, lane | (SEGL - 1)) - seg_first;
         if (seg_cnt && seg_ok && sub == 0) seg_cnt[seg] = seg_total;
         if (seg_cnt && lane_off && seg_ok) lane_off[(size_t)seg * SEGL + sub] = excl - seg_first;   // (the lane's place inside its segment's slots)
@@ -792,7 +796,7 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
             {
             int i = 0;
             bool o2 = false;
-            flatten_subtree(node, thr, kMaxFlattenDepth - FL_SUB, [&](double r0, double c0, double r1, double c1) {
+            flatten_subtree(node, thr, kMaxFlattenDepth - SUB, [&](double r0, double c0, double r1, double c1) {
                 if (i < cnt) {
                     store_edge(edges, base + i, r0, c0, r1, c1);
                     edge_path[base + i] = p;
@@ -805,12 +809,32 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
     }  // (!PLACED)
     // fold the lanes of a segment, then one set of atomics per segment
 #pragma unroll
-    for (int d = 1; d < (1 << FL_SUB); d <<= 1) {
+    for (int d = 1; d < (1 << SUB); d <<= 1) {
         double a = __shfl_xor(mnr, d), b = __shfl_xor(mnc, d), c = __shfl_xor(mxr, d), e = __shfl_xor(mxc, d);
         mnr = a < mnr ? a : mnr; mnc = b < mnc ? b : mnc;
         mxr = c > mxr ? c : mxr; mxc = e > mxc ? e : mxc;
     }
-    if (seg_ok && sub == 0 && mnr <= mxr) {
+    // ... then the workgroup's segments of ONE path together (they are consecutive): a path of hundreds of segments -- the
+    // tiger's outlines -- made hundreds of atomics on the same four addresses, which the memory side serves one after the other:
+    // 25 of the 31 us the tiger's flatten took (round 5: the same launch without the atomics 8.8 us)
+    constexpr int NSEG = FL_BLOCK >> SUB;   // segments of a workgroup
+    __shared__ double s_mm[NSEG][4];
+    __shared__ int s_mp[NSEG];
+    const int sidx = (int)threadIdx.x >> SUB;
+    if (sub == 0) {
+        s_mp[sidx] = seg_ok && mnr <= mxr ? p : -1;
+        s_mm[sidx][0] = mnr; s_mm[sidx][1] = mnc; s_mm[sidx][2] = mxr; s_mm[sidx][3] = mxc;
+    }
+    __syncthreads();
+#ifdef SVGR_DBG_FL_NOATOMIC
+    if (sub == 0 && s_mp[sidx] >= 0 && thr < 0.0) {   // diagnostic: what the per-path min / max atomics cost
+#else
+    if (sub == 0 && s_mp[sidx] >= 0 && (sidx == 0 || s_mp[sidx - 1] != s_mp[sidx])) {   // (the first segment of a run of one path's)
+#endif
+        for (int j = sidx + 1; j < NSEG && s_mp[j] == p; ++j) {
+            mnr = s_mm[j][0] < mnr ? s_mm[j][0] : mnr; mnc = s_mm[j][1] < mnc ? s_mm[j][1] : mnc;
+            mxr = s_mm[j][2] > mxr ? s_mm[j][2] : mxr; mxc = s_mm[j][3] > mxc ? s_mm[j][3] : mxc;
+        }
         unsigned long long* k = pkeys + 4 * (size_t)p;
         atomicMax(&k[0], ~f64_key(mnr));
         atomicMax(&k[1], ~f64_key(mnc));
@@ -1075,7 +1099,49 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
         atomicMax(&bd->umax_r, st_maxr);
         atomicMax(&bd->umax_c, st_maxc);
     }
-    if (slabs && n_slabs > 0) {
+    // One GPU (every band owned): the wave's slabs are dealt to its lanes one each -- slab i belongs to the lane whose run of slabs
+    // it falls into -- instead of every lane writing its own path's one after the other (a large path is dozens of slabs: the
+    // tiger @ 2048 spent 10 us here for 182 paths).
+#ifdef SVGR_DBG_NO_COOP_SLABS
+    const bool coop = false;
+#else
+    const bool coop = slabs != nullptr && own.world <= 1;
+#endif
+    if (coop) {
+        const bool fits = n_slabs > 0 && slab0 + n_slabs <= slab_cap;
+        int t_sl;
+        const int e_sl = wave_excl_scan(fits ? n_slabs : 0, lane, t_sl);
+        const int eb = e_begin < edge_cap ? e_begin : edge_cap, ee = e_end < edge_cap ? e_end : edge_cap;
+        for (int base = 0; base < t_sl; base += 64) {
+            const int i = base + lane;
+            int owner = 0;   // the last lane whose first slab is <= i (a lane without slabs shares its first slab with its successor)
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int cand = owner + step;
+                const int first = __shfl(e_sl, cand & 63);
+                if (cand < 64 && first <= i) owner = cand;
+            }
+            const int o_first = __shfl(e_sl, owner), o_slab0 = __shfl(slab0, owner), o_p = __shfl(p, owner);
+            const int o_pb0 = __shfl(pb0, owner), o_pnb = __shfl(pnb, owner), o_pnct = __shfl(pnct, owner);
+            const int o_bper = __shfl(bands_per, owner), o_cruns = __shfl(col_runs, owner);
+            const int o_eb = __shfl(eb, owner), o_ee = __shfl(ee, owner), o_off = __shfl(off, owner), o_cell = __shfl(cell_off, owner);
+            const int o_r0 = __shfl(out[0], owner), o_c0 = __shfl(out[1], owner), o_rows = __shfl(out[2], owner), o_cols = __shfl(out[3], owner);
+            if (i < t_sl) {
+                const int j = i - o_first;
+                const int br = o_cruns == 1 ? j : j / o_cruns, c = o_cruns == 1 ? 0 : j - br * o_cruns;
+                const int bb = br * o_bper, be = bb + o_bper < o_pnb ? bb + o_bper : o_pnb;
+                Slab sl;
+                sl.p = o_p; sl.band0 = o_pb0 + bb; sl.nb = be - bb;
+                sl.k0 = c * PB_CELLS; sl.nk = o_pnct - sl.k0 < PB_CELLS ? o_pnct - sl.k0 : PB_CELLS;
+                sl.e_begin = o_eb; sl.e_end = o_ee; sl.pb_off = o_off;
+                sl.r0 = o_r0; sl.c0 = o_c0; sl.rows = o_rows; sl.cols = o_cols;
+                sl.b0 = o_pb0; sl.cell_off = o_cell;
+                sl.pad[0] = sl.pad[1] = 0;
+                slabs[o_slab0 + j] = sl;
+            }
+        }
+    }
+    if (slabs && n_slabs > 0 && !(coop && slab0 + n_slabs <= slab_cap)) {
         if (slab0 + n_slabs > slab_cap) {
             // (the launch covers the capacity: what this path would have filled of it must not be followed)
             atomicOr(&bd->err, 4);
@@ -3998,7 +4064,8 @@ struct svgr_batch {
     std::vector<int> slab_at_host;
     int64_t n_slabs = 0;                    // ... the plan's count = the launch's grid
     DevArr<int> seg_cnt, seg_off;           // per segment: edges it flattens into (the plan's counting pass), their prefix sums
-    DevArr<int> lane_off;                   // per (segment, lane of its 2^FL_SUB): the lane's first edge inside the segment's slots (same pass)
+    int fl_sub = SVGR_FL_SUB;               // log2 of the lanes k_flatten cuts a segment over (5, or 6 when the launch does not fill the chip: run_geometry)
+    DevArr<int> lane_off;                   // per (segment, lane of its 2^fl_sub): the lane's first edge inside the segment's slots (same pass)
     DevArr<int> path_seg0;                  // per path its first segment (view of the input blob)
     DevArr<int> seg_list;                   // multi-GPU: the segments this rank flattens (k_seg_select, at plan time)
     int64_t n_seg_list = -1;                // (-1: no list, every segment)
@@ -4082,7 +4149,15 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     // (build_seg_list); a pass without such a list finds the reach itself and lets the flatten skip foreign paths
     const bool listed = use_vp && b->own.world > 1 && b->n_seg_list >= 0;
     const int n_items = listed ? (int)b->n_seg_list : ns;
-    const dim3 fgrid = grid1((size_t)std::max(n_items, 1) << FL_SUB, FL_BLOCK);
+    // (how many lanes a segment is cut over: decided when the counting pass runs -- the per-lane places follow it -- and kept for
+    //  the passes that use its places)
+    if (upto == 1) {
+        static const int sub_env = getenv("SVGR_FL_SUB") ? atoi(getenv("SVGR_FL_SUB")) : 0;
+        const size_t waves32 = ((size_t)std::max(n_items, 1) << 5) / 64, slots = (size_t)b->ctx->n_cu * 4 * 6;   // (six waves per SIMD)
+        b->fl_sub = sub_env == 5 || sub_env == 6 ? sub_env : (waves32 * 2 <= slots ? 6 : 5);
+    }
+    const int fl_sub = b->fl_sub;
+    const dim3 fgrid = grid1((size_t)std::max(n_items, 1) << fl_sub, FL_BLOCK);
     const int* seg_list = listed ? (const int*)b->seg_list.p : (const int*)nullptr;
     const int* plist = listed ? (const int*)b->path_list.p : (const int*)nullptr;
     const int np_walk = listed ? (int)b->n_path_list : np;  // paths k_path_bbox / k_band_entries walk
@@ -4097,15 +4172,19 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
         if (upto == 1) {  // (segments the pass skips keep a count of zero)
             if (int rc = b->seg_cnt.ensure((size_t)ns + 1)) return rc;
             if (int rc = b->seg_off.ensure((size_t)ns + 2)) return rc;
-            if (int rc = b->lane_off.ensure(((size_t)ns << FL_SUB) + 1)) return rc;
+            if (int rc = b->lane_off.ensure(((size_t)ns << fl_sub) + 1)) return rc;
             HIPCHK(hipMemsetAsync(b->seg_cnt.p, 0, sizeof(int) * ((size_t)ns + 1), st));
         }
-        if (ns > 0)
-            hipLaunchKernelGGL(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
-                               (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns,
-                               b->thr, (double*)nullptr, (int*)nullptr, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
-                               n_bands_vp, prow, seg_list, n_items, upto == 1 ? b->seg_cnt.p : (int*)nullptr, (const int*)nullptr, 0,
-                               upto == 1 ? b->lane_off.p : (int*)nullptr);
+        if (ns > 0) {
+            auto launch_cnt = [&](auto kern) {
+                hipLaunchKernelGGL(kern, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
+                                   (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns,
+                                   b->thr, (double*)nullptr, (int*)nullptr, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
+                                   n_bands_vp, prow, seg_list, n_items, upto == 1 ? b->seg_cnt.p : (int*)nullptr, (const int*)nullptr, 0,
+                                   upto == 1 ? b->lane_off.p : (int*)nullptr);
+            };
+            if (fl_sub == 6) launch_cnt(k_flatten<false, false, 6>); else launch_cnt(k_flatten<false, false, 5>);
+        }
         if (upto == 1)
             hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, st, (const int*)b->seg_cnt.p, ns, b->seg_off.p);
         if (upto == 0 || (upto == 1 && b->census_bbox))  // bboxes only (no edges stored): the union when there is no viewport; the two-pass plan's census
@@ -4124,8 +4203,12 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                                n_bands_vp, prow, seg_list, n_items, (int*)nullptr, (const int*)b->seg_off.p,
                                cap_i32(std::min(b->edge_path.cap, b->edges.cap / 4)), places);
         };
-        if (lane_places && b->lane_off.p && b->lane_off.cap >= ((size_t)ns << FL_SUB)) launch_fl(k_flatten<true, true>, b->lane_off.p);
-        else launch_fl(k_flatten<true, false>, (int*)nullptr);
+        const bool placed_fl = lane_places && b->lane_off.p && b->lane_off.cap >= ((size_t)ns << fl_sub);
+        if (fl_sub == 6) {
+            if (placed_fl) launch_fl(k_flatten<true, true, 6>, b->lane_off.p); else launch_fl(k_flatten<true, false, 6>, (int*)nullptr);
+        } else {
+            if (placed_fl) launch_fl(k_flatten<true, true, 5>, b->lane_off.p); else launch_fl(k_flatten<true, false, 5>, (int*)nullptr);
+        }
     }
     hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np_walk,
                        use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), b->planned ? 0 : 1, plist,
