@@ -33,8 +33,9 @@ extern "C" {
  *    no longer capped at 32; SVGR_RENDER_DETERMINISTIC
  * 3: SVGR_RENDER_SAME_GEOMETRY, SVGR_OUT_FILLS_F64, svgr_layer_convert_to, svgr_layer_scale_to, svgr_batch_render_windows added
  *    (nothing changed or removed)
- * 4: svgr_hash_buffers added (nothing changed or removed) */
-#define SVGR_ABI_VERSION 4
+ * 4: svgr_hash_buffers added (nothing changed or removed)
+ * 5: svgr_layer_compose_over, svgr_layer_convert_scale_to added (nothing changed or removed) */
+#define SVGR_ABI_VERSION 5
 
 typedef enum {
     SVGR_OK = 0,
@@ -249,6 +250,15 @@ int svgr_layer_background(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, const doub
 int svgr_layer_convert(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, unsigned ops);
 /* ... into another buffer (dst may be src) */
 int svgr_layer_convert_to(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t n_px, unsigned ops);
+/* Layer.opacity of a layer that still needs its Layer.convert (S:171-175: `convert(pre_alpha=True, ...)`, then image * opacity):
+ * both in one pass over n_px RGBA pixels, dst may be src */
+int svgr_layer_convert_scale_to(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t n_px, unsigned ops, double factor);
+/* Layer.compose(layers, COMPOSE_OVER) as ONE pass (S:177-207 -> canvas_merge_union, S:366-379): `out` (4ch, bbox = the union) is
+ * written whole -- no clear in front, no pass per layer.  Source i is (rows, cols, channels[i]) at src_bboxes[4 i ..]; the first
+ * is copied where it covers a pixel (S:374-375), the others go OVER (S:286); pixels no source covers are zero.  ops[i] (or NULL):
+ * the svgr_layer_convert ops source i still needs, applied to its pixels as they are read (4-channel sources only).            */
+int svgr_layer_compose_over(svgr_ctx* ctx, svgr_buf* out, const int64_t* out_bbox, int64_t n, svgr_buf* const* srcs,
+                            const int64_t* src_bboxes, const int32_t* channels, const uint32_t* ops);
 /* float64 -> float32 (optionally clipping to [0,1]) for presentation */
 int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst_f32, const svgr_buf* src_f64, int64_t n_values, int clip01);
 

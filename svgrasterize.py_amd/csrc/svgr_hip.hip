@@ -2354,6 +2354,26 @@ struct TileArgs {
     unsigned long long* dbg;                // diagnostic builds only
 };
 
+// svgr_batch_render_windows: ALL the windows of a render in ONE launch.  Every window is a rectangle of tiles with an output buffer
+// of its own; workgroup w of the launch draws tile w - tile0 of the window whose range [tile0, next tile0) it falls into.  The table
+// rides in the kernel argument (no upload, nothing to keep alive): the workgroup finds its window by a binary search of scalar
+// loads and takes the window's fields in the place of the launch's own (TileArgs::out, ct0 ... out_cols).
+struct WinRec {
+    void* out;
+    int tile0;                      // first workgroup of the window
+    int ct0, win_ct, band0, n_bands;
+    int win_r, win_c;
+    int win_rows, win_cols;
+    int pad;
+};
+static_assert(sizeof(WinRec) == 48, "WinRec is 48 bytes");
+constexpr int MAX_WINS = 64;        // windows per launch (the kernel argument segment holds 4 KiB)
+struct WinTable {
+    int n;                          // 0: the launch is one window, described by TileArgs itself
+    int pad[3];
+    WinRec w[MAX_WINS];
+};
+
 // OUT: 0 = canvas f32, 1 = canvas f64, 2 = mask f64 (single path), 3 = fill f64 (single path)
 // CLIP: the batch contains SVGR_PATH_CLIP_SOURCE / SVGR_PATH_CLIPPED paths (one more LDS tile: its own instantiation,
 // so that batches without clips keep their occupancy)
@@ -2436,8 +2456,20 @@ __device__ __forceinline__ void reload_tile_args(TileArgs& A) {
     A.own.rank = ka->own.rank; A.own.world = ka->own.world; A.own.strip = ka->own.strip;
     A.out_cols = ka->out_cols; A.clip01 = ka->clip01;
 }
-template <int OUT, bool CLIP, bool GROUPS, bool GRAD>
-__device__ __forceinline__ void tile_body(const TileArgs& a) {
+// ... and, in a launch of several windows (k_tile_render_windows), the window's fields in the place of the launch's
+typedef const WinTable __attribute__((address_space(4))) * KWinsPtr;
+constexpr int WINTABLE_KERNARG_OFFSET = (int)((sizeof(TileArgs) + 7) & ~(size_t)7);   // the second kernel argument
+__device__ __forceinline__ void patch_window_args(TileArgs& A, int win) {
+    KWinsPtr wt = (KWinsPtr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + WINTABLE_KERNARG_OFFSET);
+    asm volatile("" : "+s"(wt));
+    A.out = wt->w[win].out;
+    A.ct0 = wt->w[win].ct0; A.win_ct = wt->w[win].win_ct; A.band0 = wt->w[win].band0; A.n_bands = wt->w[win].n_bands;
+    A.win_r = wt->w[win].win_r; A.win_c = wt->w[win].win_c; A.win_rows = wt->w[win].win_rows; A.win_cols = wt->w[win].win_cols;
+    A.out_cols = wt->w[win].win_cols;
+    A.use_order = 0;
+}
+template <int OUT, bool CLIP, bool GROUPS, bool GRAD, bool WINS = false>
+__device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, const unsigned wg0 = 0u) {   // (WINS: window `win` of the launch's table, its first workgroup wg0; `a` = the launch's arguments with the window's fields)
     static_assert(!GROUPS || (CLIP && OUT <= 1), "groups live in the canvas variants with the clip tile");
     constexpr bool FIXED = OUT == 0 && !CLIP;   // the production variant: fixed load targets, persistent tile loop
     static_assert(!GRAD || GROUPS, "gradient entries live in the variant with the large register budget");
@@ -2467,7 +2499,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
     int by = 0, bx = 0, item0 = 0, n_items = 0, band = 0;
     int tile_r0 = 0, tile_c0 = 0, tile_c1 = 0;  // absolute row / column of the tile's first pixel, one past its last column
     const unsigned n_tiles_ = (unsigned)a.win_ct * (unsigned)a.n_bands;
-    unsigned pass_ = 0u, tile_ = blockIdx.x;
+    unsigned pass_ = 0u, tile_ = blockIdx.x - wg0;
     unsigned long long page01 = 0ull, page23 = 0ull;  // lane j < PAGE_ITEMS: item j of the tile's list {x, y}, {z, w}; lane PAGE_ITEMS: which tile
     if (a.use_order) {
         const uint4* const pp = a.pages + (size_t)tile_ * PAGE_STRIDE + (lane < PAGE_STRIDE ? lane : PAGE_ITEMS);
@@ -3370,6 +3402,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
     {
         TileArgs a0;
         reload_tile_args(a0);
+        if constexpr (WINS) patch_window_args(a0, win);
         begin_tile(a0);
     }
     bool pend = false;   // N_STORES store instructions (the previous tile's canvas) were issued behind the round's first loads
@@ -3462,6 +3495,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a) {
         const bool go = have_next_;
         TileArgs sw;   // (the launch's arguments, read again: reload_tile_args)
         reload_tile_args(sw);
+        if constexpr (WINS) patch_window_args(sw, win);
         store_tile_a(sw, s_by, s_bx, s_band);
 #ifdef SVGR_DBG_TIMELINE
         { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tl_ph_[3] += n_ - tl_mark_; tl_sub_ = n_; }
@@ -3527,6 +3561,21 @@ __global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SV
 template <>
 __global__ __launch_bounds__(NT, SVGR_WAVES_PER_EU) __attribute__((amdgpu_num_vgpr(SVGR_FIX0 / 2))) void k_tile_render<0, false, false, false>(const TileArgs a) {
     tile_body<0, false, false, false>(a);
+}
+// the canvas variants drawing several windows (WinTable): the variants a document's runs use -- every one but the production kernel,
+// whose launch is persistent and whole-canvas
+template <int OUT, bool CLIP = false, bool GROUPS = false, bool GRAD = false>
+__global__ __launch_bounds__(NT, GROUPS ? 2 : (CLIP ? SVGR_WAVES_PER_EU - 1 : SVGR_WAVES_PER_EU)) void k_tile_render_windows(const TileArgs a, const WinTable wt) {
+    static_assert(OUT <= 1, "windows exist in the canvas outputs");
+    int w = 0;
+#pragma unroll
+    for (int step = MAX_WINS / 2; step >= 1; step >>= 1) {   // the last window whose first workgroup is <= this one
+        const int c = w + step;
+        if (c < wt.n && (unsigned)wt.w[c].tile0 <= blockIdx.x) w = c;
+    }
+    TileArgs A = a;
+    patch_window_args(A, w);
+    tile_body<OUT, CLIP, GROUPS, GRAD, true>(A, w, (unsigned)wt.w[w].tile0);
 }
 
 // ======================================================================================
@@ -3685,12 +3734,8 @@ __global__ void k_layer_background(double* __restrict__ img, size_t n_px, double
     *reinterpret_cast<double4*>(img + 4 * i) = v;
 }
 
-__global__ void k_layer_convert(double* dst, const double* src, size_t n_px, unsigned ops) {   // (dst may be src)
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_px) return;
-    double* px = dst + 4 * i;
-    const double* sp = src + 4 * i;
-    double v[4] = {sp[0], sp[1], sp[2], sp[3]};
+// Layer.convert on one RGBA pixel (S:129-164): the ops of svgr_layer_convert, in their order
+__device__ __forceinline__ void convert_px(double* v, unsigned ops) {
     if (ops & 1u) {  // premultiplied -> straight, S:471-477 (divide where alpha > 1e-4, then clip all 4)
         double al = v[3];
         for (int c = 0; c < 4; ++c) {
@@ -3705,7 +3750,57 @@ __global__ void k_layer_convert(double* dst, const double* src, size_t n_px, uns
         for (int c = 0; c < 3; ++c) v[c] = v[c] <= 0.0031308 ? v[c] * 12.92 : 1.055 * pow(v[c], 1.0 / 2.4) - 0.055;
     if (ops & 8u)  // straight -> premultiplied, S:480-483
         for (int c = 0; c < 3; ++c) v[c] = v[c] * v[3];
+}
+
+// `scale`: Layer.opacity behind the conversion (S:171-175: `convert(pre_alpha=True)`, then image * opacity) in the same pass
+template <bool SCALE>
+__global__ void k_layer_convert(double* dst, const double* src, size_t n_px, unsigned ops, double f) {   // (dst may be src)
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_px) return;
+    double* px = dst + 4 * i;
+    const double* sp = src + 4 * i;
+    double v[4] = {sp[0], sp[1], sp[2], sp[3]};
+    convert_px(v, ops);
+    if (SCALE) { v[0] = v[0] * f; v[1] = v[1] * f; v[2] = v[2] * f; v[3] = v[3] * f; }
     px[0] = v[0]; px[1] = v[1]; px[2] = v[2]; px[3] = v[3];
+}
+
+// Layer.compose(layers, OVER) in ONE launch (canvas_merge_union, S:366-379 + S:286): every pixel of the union canvas walks the layers
+// in their order -- the first is copied where it covers the pixel (S:374-375), the others go OVER what is there (zero outside every
+// earlier layer) --, each source converted on the way in (`ops`: the Layer.convert a caller would have run as a pass of its own).
+// `accumulate`: the canvas holds the result of an earlier launch over the layers before these (more layers than one table holds).
+constexpr int OVER_SRCS = 24;
+struct OverSrc {
+    const double* p;
+    int r0, c0, rows, cols;
+    int ch;
+    unsigned ops;
+};
+struct OverTable {
+    int n, accumulate;
+    OverSrc s[OVER_SRCS];
+};
+__global__ __launch_bounds__(256) void k_layer_compose_over(double* __restrict__ out, int or0, int oc0, int orows, int ocols, const OverTable t) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)orows * ocols) return;
+    const int R = (int)(i / ocols) + or0, C = (int)(i % ocols) + oc0;
+    double d[4] = {0.0, 0.0, 0.0, 0.0};
+    if (t.accumulate) { const double4 v = ((const double4*)out)[i]; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+    for (int k = 0; k < t.n; ++k) {
+        const int r = R - t.s[k].r0, c = C - t.s[k].c0;
+        if (r < 0 || r >= t.s[k].rows || c < 0 || c >= t.s[k].cols) continue;
+        double v[4];
+        if (t.s[k].ch == 4) {
+            const double4 q = ((const double4*)t.s[k].p)[(size_t)r * t.s[k].cols + c];
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            convert_px(v, t.s[k].ops);
+        } else {
+            v[0] = v[1] = v[2] = v[3] = t.s[k].p[(size_t)r * t.s[k].cols + c];
+        }
+        if (k == 0 && !t.accumulate) { d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
+        else over_px(d, v[0], v[1], v[2], v[3]);
+    }
+    ((double4*)out)[i] = make_double4(d[0], d[1], d[2], d[3]);
 }
 
 __global__ void k_to_f32(float* __restrict__ dst, const double* __restrict__ src, size_t n, int clip01) {
@@ -5471,7 +5566,7 @@ static int get_event(svgr_batch* b, hipEvent_t* e) {
 
 // phase 0: geometry (unless it is current) and the tile launch; 1: the geometry part alone; 2: the tile launch alone, on `tile_st`
 static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags, const int32_t* window, int phase = 0,
-                             hipStream_t tile_st = nullptr);
+                             hipStream_t tile_st = nullptr, WinTable* wt = nullptr);
 int svgr_batch_render(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags) {
     return abi_guard("svgr_batch_render", [&]() { return batch_render_impl(b, out, out_kind, flags, nullptr); });
 }
@@ -5491,6 +5586,25 @@ int svgr_batch_render_windows(svgr_batch* b, int64_t n, svgr_buf* const* outs, i
         if (flags & (SVGR_RENDER_TIMED | SVGR_RENDER_DETERMINISTIC)) return fail(SVGR_E_INVALID, "timed / deterministic renders draw one window at a time");
         svgr_ctx* c = b->ctx;
         HIPCHK(enter_ctx(c));
+        // Every variant but the production kernel (whose launch is whole-canvas and persistent) draws the windows in ONE launch per
+        // MAX_WINS of them: a window is a few dozen workgroups that live as long as its deepest tile, and a document's runs are dozens
+        // of windows (icons.svg: 30 launches, 1.6 ms one after the other).  SVGR_WINDOWS_ON_STREAMS: the round-4 form, a launch per
+        // window on eight streams.
+        static const bool on_streams = getenv("SVGR_WINDOWS_ON_STREAMS") != nullptr;
+        const bool production = out_kind == SVGR_OUT_CANVAS_F32 && b->n_grads == 0 && b->n_groups == 0 && !b->has_clips;
+        if (!on_streams && !production && (out_kind == SVGR_OUT_CANVAS_F32 || out_kind == SVGR_OUT_CANVAS_F64) && b->own.world <= 1) {
+            if (int rc = batch_render_impl(b, outs[0], out_kind, flags, windows, 1)) return rc;
+            WinTable local;   // (3 KiB on the stack, copied into the launch's argument)
+            for (int64_t at = 0; at < n; at += MAX_WINS) {
+                local.n = 0; local.pad[0] = local.pad[1] = local.pad[2] = 0;
+                const int64_t end = std::min<int64_t>(n, at + MAX_WINS);
+                for (int64_t i = at; i < end; ++i)
+                    if (int rc = batch_render_impl(b, outs[i], out_kind, flags, windows + 4 * i, 3, nullptr, &local)) return rc;
+                for (int k = local.n; k < MAX_WINS; ++k) memset(&local.w[k], 0, sizeof(WinRec));
+                if (int rc = batch_render_impl(b, outs[at], out_kind, flags, windows + 4 * at, 4, nullptr, &local)) return rc;
+            }
+            return 0;
+        }
         if (!c->side_ready) {
             for (int k = 0; k < svgr_ctx::N_SIDE; ++k) {
                 if (!c->side[k]) HIPCHK(hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking));
@@ -5517,7 +5631,7 @@ int svgr_batch_render_windows(svgr_batch* b, int64_t n, svgr_buf* const* outs, i
     });
 }
 
-static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags, const int32_t* window, int phase, hipStream_t tile_st) {
+static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags, const int32_t* window, int phase, hipStream_t tile_st, WinTable* wt) {
     if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
     if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan must run before svgr_batch_render");
     if (out_kind < 0 || out_kind > 5) return fail(SVGR_E_INVALID, "unknown output kind %d", out_kind);
@@ -5582,8 +5696,11 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
     const bool det = (flags & SVGR_RENDER_DETERMINISTIC) != 0;
     // (SVGR_RENDER_SAME_GEOMETRY: another window of the canvas the previous render of this batch drew a window of -- the tile
     //  kernel only reads what the geometry kernels left, so the pass is not repeated; ignored when an input has changed since)
-    if (phase == 2 && !b->geometry_current) return fail(SVGR_E_STATE, "a tile launch without its geometry pass");
-    const bool same = phase == 2 || ((flags & SVGR_RENDER_SAME_GEOMETRY) != 0 && b->geometry_current && window != nullptr && !timed && !det);
+    // (phases of svgr_batch_render_windows -- 1: geometry only; 2: this window's tiles on `tile_st`; 3: this window into the table `wt`,
+    //  nothing launched; 4: the table's windows in one launch)
+    if (phase >= 2 && !b->geometry_current) return fail(SVGR_E_STATE, "a tile launch without its geometry pass");
+    if (phase >= 3 && (!wt || !window)) return fail(SVGR_E_INVALID, "a window table is needed");
+    const bool same = phase >= 2 || ((flags & SVGR_RENDER_SAME_GEOMETRY) != 0 && b->geometry_current && window != nullptr && !timed && !det);
     if (!(b->geometry_fresh && !timed && !det) && !same) {
         b->deterministic = det;
         b->geometry_current = false;
@@ -5663,6 +5780,16 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         // A whole-canvas launch is persistent: as many workgroups as the chip holds at once walk the tiles (k_tile_render);
         // how many a CU holds is the variant's register / LDS budget.  SVGR_TILE_WGS_PER_CU overrides it (0: a workgroup per tile).
         const unsigned n_tiles = (unsigned)a.win_ct * (unsigned)a.n_bands;
+        if (phase == 3) {
+            if (wt->n >= MAX_WINS) return fail(SVGR_E_INVALID, "window table full");
+            const long long first = wt->n ? (long long)wt->w[wt->n - 1].tile0 + (long long)wt->w[wt->n - 1].win_ct * wt->w[wt->n - 1].n_bands : 0ll;
+            if (first + (long long)n_tiles > 0x7fffffffll) return fail(SVGR_E_OVERFLOW, "too many tiles in one launch");
+            WinRec& r = wt->w[wt->n++];
+            r.out = out->ptr; r.tile0 = (int)first;
+            r.ct0 = a.ct0; r.win_ct = a.win_ct; r.band0 = a.band0; r.n_bands = a.n_bands;
+            r.win_r = a.win_r; r.win_c = a.win_c; r.win_rows = a.win_rows; r.win_cols = a.win_cols; r.pad = 0;
+            return 0;
+        }
         static const int wgs_env = getenv("SVGR_TILE_WGS_PER_CU") ? atoi(getenv("SVGR_TILE_WGS_PER_CU")) : -1;
         const int wgs_variant = std::min((SVGR_WAVES_PER_EU * 4) / NW, (160 * 1024) / (2 * DELTA_BYTES));   // (registers, LDS)
         const int wgs_per_cu = wgs_env >= 0 ? wgs_env : wgs_variant;
@@ -5679,6 +5806,26 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         }
         dim3 grid(n_wgs);
         hipStream_t lst = tile_st ? tile_st : st;   // (svgr_batch_render_windows: a stream per window)
+        if (phase == 4) {
+            // every window of the table in this one launch: a workgroup per tile, the windows' tiles one window after the other
+            if (wt->n <= 0 || production || out_kind > 1) return fail(SVGR_E_INVALID, "no window table for this launch");
+            const WinRec& last = wt->w[wt->n - 1];
+            const dim3 wgrid((unsigned)last.tile0 + (unsigned)last.win_ct * (unsigned)last.n_bands);
+            a.use_order = 0;
+            if (out_kind == 0) {
+                if (b->n_grads > 0) hipLaunchKernelGGL((k_tile_render_windows<0, true, true, true>), wgrid, dim3(NT), 0, lst, a, *wt);
+                else if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render_windows<0, true, true>), wgrid, dim3(NT), 0, lst, a, *wt);
+                else hipLaunchKernelGGL((k_tile_render_windows<0, true>), wgrid, dim3(NT), 0, lst, a, *wt);
+            } else {
+                if (b->n_grads > 0) hipLaunchKernelGGL((k_tile_render_windows<1, true, true, true>), wgrid, dim3(NT), 0, lst, a, *wt);
+                else if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render_windows<1, true, true>), wgrid, dim3(NT), 0, lst, a, *wt);
+                else if (b->has_clips) hipLaunchKernelGGL((k_tile_render_windows<1, true>), wgrid, dim3(NT), 0, lst, a, *wt);
+                else hipLaunchKernelGGL((k_tile_render_windows<1, false>), wgrid, dim3(NT), 0, lst, a, *wt);
+            }
+            b->arena_zeroed = true;
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
         static const int dyn_lds = getenv("SVGR_DBG_DYNLDS") ? atoi(getenv("SVGR_DBG_DYNLDS")) : 0;  // occupancy experiments
         switch (out_kind) {
             case 0:
@@ -5862,11 +6009,54 @@ int svgr_layer_convert_to(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int
         return fail(SVGR_E_INVALID, "svgr_layer_convert: bad arguments");
     if (n_px == 0 || (ops == 0 && dst->ptr == src->ptr)) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_layer_convert, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)dst->ptr, (const double*)src->ptr, (size_t)n_px, ops);
+    hipLaunchKernelGGL(k_layer_convert<false>, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)dst->ptr, (const double*)src->ptr, (size_t)n_px, ops, 1.0);
     HIPCHK(hipGetLastError());
     return 0;
 }
 int svgr_layer_convert(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, unsigned ops) { return svgr_layer_convert_to(ctx, img, img, n_px, ops); }
+
+int svgr_layer_convert_scale_to(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t n_px, unsigned ops, double factor) {
+    if (!ctx || !dst || !src || n_px < 0 || dst->bytes < (size_t)n_px * 32 || src->bytes < (size_t)n_px * 32 || (ops & ~15u))
+        return fail(SVGR_E_INVALID, "svgr_layer_convert_scale_to: bad arguments");
+    if (n_px == 0) return 0;
+    HIPCHK(enter_ctx(ctx));
+    hipLaunchKernelGGL(k_layer_convert<true>, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)dst->ptr, (const double*)src->ptr, (size_t)n_px, ops, factor);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int svgr_layer_compose_over(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, int64_t n, svgr_buf* const* srcs, const int64_t* sbs,
+                            const int32_t* chs, const uint32_t* ops) {
+    if (!ctx || !out || !bbox_ok(ob) || n <= 0 || !srcs || !sbs || !chs) return fail(SVGR_E_INVALID, "svgr_layer_compose_over: bad arguments");
+    const size_t n_out = (size_t)ob[2] * ob[3];
+    if (out->bytes < n_out * 32) return fail(SVGR_E_INVALID, "svgr_layer_compose_over: output buffer too small");
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t* sb = sbs + 4 * i;
+        if (!srcs[i] || !bbox_ok(sb) || (chs[i] != 1 && chs[i] != 4) || (ops && ((ops[i] & ~15u) || (ops[i] && chs[i] != 4))))
+            return fail(SVGR_E_INVALID, "svgr_layer_compose_over: bad source %lld", (long long)i);
+        if (srcs[i]->bytes < (size_t)sb[2] * sb[3] * 8 * chs[i]) return fail(SVGR_E_INVALID, "svgr_layer_compose_over: source %lld too small", (long long)i);
+        if (srcs[i]->ptr == out->ptr) return fail(SVGR_E_INVALID, "svgr_layer_compose_over: the output is one of the sources");
+    }
+    if (n_out == 0) return 0;
+    HIPCHK(enter_ctx(ctx));
+    for (int64_t at = 0; at < n; at += OVER_SRCS) {
+        OverTable t;
+        memset(&t, 0, sizeof t);
+        t.n = (int)std::min<int64_t>(OVER_SRCS, n - at);
+        t.accumulate = at > 0 ? 1 : 0;
+        for (int k = 0; k < t.n; ++k) {
+            const int64_t* sb = sbs + 4 * (at + k);
+            OverSrc& o = t.s[k];
+            o.p = (const double*)srcs[at + k]->ptr;
+            o.r0 = (int)sb[0]; o.c0 = (int)sb[1]; o.rows = (int)sb[2]; o.cols = (int)sb[3];
+            o.ch = chs[at + k]; o.ops = ops ? ops[at + k] : 0u;
+        }
+        hipLaunchKernelGGL(k_layer_compose_over, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
+                           (int)ob[3], t);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 
 int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t n, int clip01) {
     if (!ctx || !dst || !src || n < 0 || dst->bytes < (size_t)n * 4 || src->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_to_f32: bad arguments");

@@ -15,6 +15,8 @@ from typing import Sequence
 
 import warnings
 
+import ctypes as C
+
 import numpy as np
 
 from . import _abi
@@ -25,13 +27,14 @@ FLOAT = np.float64
 
 
 def _bbox_arr(offset, shape):
-    import ctypes as C
-
     return (C.c_int64 * 4)(int(offset[0]), int(offset[1]), int(shape[0]), int(shape[1]))
 
 
 class Layer:
-    __slots__ = ["_host", "_dev", "_shape", "offset", "pre_alpha", "linear_rgb"]
+    # `_ops`: the svgr_layer_convert ops the pixels in `_dev` still need to be what `pre_alpha` / `linear_rgb` say they are.  A
+    # conversion of a device-resident layer is first only this note: the kernel that reads the layer next (compose OVER, opacity)
+    # converts on the way in, everybody else gets the converted pixels from `_device()` / `.image` (one svgr_layer_convert_to).
+    __slots__ = ["_host", "_dev", "_shape", "offset", "pre_alpha", "linear_rgb", "_ops"]
 
     def __init__(self, image, offset, pre_alpha: bool, linear_rgb: bool):
         image = np.asarray(image)
@@ -43,9 +46,10 @@ class Layer:
         self.offset = offset
         self.pre_alpha = pre_alpha
         self.linear_rgb = linear_rgb
+        self._ops = 0
 
     @classmethod
-    def _from_device(cls, buf: "_abi.DeviceBuffer", shape, offset, pre_alpha, linear_rgb) -> "Layer":
+    def _from_device(cls, buf: "_abi.DeviceBuffer", shape, offset, pre_alpha, linear_rgb, ops: int = 0) -> "Layer":
         self = object.__new__(cls)
         self._host = None
         self._dev = buf
@@ -53,6 +57,7 @@ class Layer:
         self.offset = offset
         self.pre_alpha = pre_alpha
         self.linear_rgb = linear_rgb
+        self._ops = ops
         return self
 
     # -- NamedTuple compatibility ---------------------------------------------------------
@@ -71,7 +76,7 @@ class Layer:
     @property
     def image(self) -> np.ndarray:
         if self._host is None:
-            self._host = self._dev.download(self._shape, FLOAT)
+            self._host = self._device().download(self._shape, FLOAT)
             self._dev = None  # the host array may be mutated by the caller from now on
         return self._host
 
@@ -80,6 +85,11 @@ class Layer:
         """Device buffer holding the current pixels as float64 (uploads a host-resident image)."""
         if self._host is not None:
             return _abi.Context.get().from_host(np.ascontiguousarray(self._host, dtype=FLOAT))
+        if self._ops:   # (a noted conversion nobody folded into a kernel of their own: now)
+            ctx = _abi.Context.get()
+            buf = ctx.alloc(int(np.prod(self._shape)) * 8)
+            _abi._check(ctx.lib.svgr_layer_convert_to(ctx.handle, buf.handle, self._dev.handle, self._shape[0] * self._shape[1], self._ops))
+            self._dev, self._ops = buf, 0
         return self._dev
 
     @property
@@ -113,14 +123,14 @@ class Layer:
 
     def translate(self, x: int, y: int) -> "Layer":
         out = object.__new__(Layer)
-        out._host, out._dev, out._shape = self._host, self._dev, self._shape
+        out._host, out._dev, out._shape, out._ops = self._host, self._dev, self._shape, self._ops
         out.offset = (self.x + x, self.y + y)
         out.pre_alpha, out.linear_rgb = self.pre_alpha, self.linear_rgb
         return out
 
     def _retag(self, pre_alpha, linear_rgb) -> "Layer":
         out = object.__new__(Layer)
-        out._host, out._dev, out._shape = self._host, self._dev, self._shape
+        out._host, out._dev, out._shape, out._ops = self._host, self._dev, self._shape, self._ops
         out.offset, out.pre_alpha, out.linear_rgb = self.offset, pre_alpha, linear_rgb
         return out
 
@@ -130,7 +140,10 @@ class Layer:
             return ctx.from_host(np.ascontiguousarray(self._host, dtype=FLOAT))
         n = int(np.prod(self._shape))
         out = ctx.alloc(n * 8)
-        _abi._check(ctx.lib.svgr_buf_copy(ctx.handle, out.handle, self._dev.handle, n * 8))
+        if self._ops:   # (the copy is the conversion's output)
+            _abi._check(ctx.lib.svgr_layer_convert_to(ctx.handle, out.handle, self._dev.handle, self._shape[0] * self._shape[1], self._ops))
+        else:
+            _abi._check(ctx.lib.svgr_buf_copy(ctx.handle, out.handle, self._dev.handle, n * 8))
         return out
 
     # -- Layer.convert  S:129-164 ----------------------------------------------------------
@@ -158,10 +171,12 @@ class Layer:
         if self._host is not None:
             buf = self._copy_device()
             _abi._check(ctx.lib.svgr_layer_convert(ctx.handle, buf.handle, self._shape[0] * self._shape[1], ops))
-        else:   # (device-resident: converted straight into the new layer's buffer, no copy in front of an in-place pass)
-            buf = ctx.alloc(int(np.prod(self._shape)) * 8)
-            _abi._check(ctx.lib.svgr_layer_convert_to(ctx.handle, buf.handle, self._dev.handle, self._shape[0] * self._shape[1], ops))
-        return Layer._from_device(buf, self._shape, self.offset, pre_alpha, linear_rgb)
+            return Layer._from_device(buf, self._shape, self.offset, pre_alpha, linear_rgb)
+        # device-resident: noted, not run (`_ops`).  On top of an earlier note the two sets run as one pass when the kernel's order
+        # (1, 2, 4, 8) is theirs: every new op behind every noted one; otherwise the noted ones run now.
+        if self._ops and (self._ops.bit_length() > (ops & -ops).bit_length() - 1):
+            self._device()
+        return Layer._from_device(self._dev, self._shape, self.offset, pre_alpha, linear_rgb, self._ops | ops)
 
     # -- Layer.background  S:166-169 -------------------------------------------------------
     def background(self, color) -> "Layer":
@@ -190,6 +205,10 @@ class Layer:
         if layer._host is not None:
             buf = layer._copy_device()
             _abi._check(ctx.lib.svgr_layer_scale(ctx.handle, buf.handle, int(np.prod(layer._shape)), float(opacity)))
+        elif layer._ops:   # (the conversion and the factor in one pass)
+            buf = ctx.alloc(int(np.prod(layer._shape)) * 8)
+            _abi._check(ctx.lib.svgr_layer_convert_scale_to(ctx.handle, buf.handle, layer._dev.handle, layer._shape[0] * layer._shape[1],
+                                                            layer._ops, float(opacity)))
         else:
             buf = ctx.alloc(int(np.prod(layer._shape)) * 8)
             _abi._check(ctx.lib.svgr_layer_scale_to(ctx.handle, buf.handle, layer._dev.handle, int(np.prod(layer._shape)), float(opacity)))
@@ -309,12 +328,14 @@ class Layer:
             c1 = max(int(l.y) + l.width for l in conv)
             shape = (r1 - r0, c1 - c0, 4)
             out = ctx.alloc(shape[0] * shape[1] * 32)
-            out.zero()
-            dbb = _bbox_arr((r0, c0), shape)
-            for i, l in enumerate(conv):
-                src = l._device()
-                _abi._check(lib.svgr_layer_over(ctx.handle, out.handle, dbb, src.handle, _bbox_arr(l.offset, l._shape),
-                                                l.channels, int(i == 0)))
+            # one pass over the union: every layer read once, converted as it is read (svgr_layer_compose_over)
+            n = len(conv)
+            srcs = [l._dev if l._host is None else l._device() for l in conv]   # (uploads of host-resident layers stay referenced)
+            handles = (_abi._P * n)(*[b.handle for b in srcs])
+            bbs = (C.c_int64 * (4 * n))(*[int(v) for l in conv for v in (l.offset[0], l.offset[1], l._shape[0], l._shape[1])])
+            chs = (C.c_int32 * n)(*[l.channels for l in conv])
+            ops = (C.c_uint32 * n)(*[l._ops if l._host is None else 0 for l in conv])
+            _abi._check(lib.svgr_layer_compose_over(ctx.handle, out.handle, _bbox_arr((r0, c0), shape), n, handles, bbs, chs, ops))
             offset = (min(l.x for l in conv), min(l.y for l in conv))
             return Layer._from_device(out, shape, offset, True, linear_rgb)
         # COMPOSE_IN: intersection, S:382-416

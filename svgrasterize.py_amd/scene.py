@@ -1046,16 +1046,17 @@ def _run_window(leaves, batch):
     return win, in_hull
 
 
-# (off by default: it takes 0.85 ms of GPU time off an icons.svg render -- 30 window launches 1.59 -> 0.73 ms, four hardware queues
-#  deep -- but the render is bound by the host's walk and its 800 library calls, and there the up-front launches cost 0.1-0.2 ms)
-_PREFETCH_WINDOWS = __import__("os").environ.get("SVGR_WINDOW_PREFETCH") is not None
+# (round 4 drew the windows a launch each on eight streams: 1.59 -> 0.73 ms of GPU time for icons.svg's 30, off by default because the
+#  host was the bound and the up-front launches cost it 0.1-0.2 ms.  Round 5: ONE launch for up to 64 windows -- a window table in
+#  the kernel argument --, on by default; SVGR_NO_WINDOW_PREFETCH draws a run's window when the walk meets it)
+_PREFETCH_WINDOWS = __import__("os").environ.get("SVGR_NO_WINDOW_PREFETCH") is None
 _PREFETCH_MAX_BYTES = 4 << 30   # of run layers drawn ahead of the walk; beyond it the runs are drawn when the walk meets them
 
 
 def _prefetch_windows(run_plans):
-    """Draw the windows of all the runs that share a batch NOW, side by side (svgr_batch_render_windows): a run's window is a
-    launch of a few dozen workgroups that lasts as long as its heaviest tile -- icons.svg: 30 launches, 1.6 ms one after the
-    other, the longest alone 0.23 --, and no run depends on anything the walk produces.  `_render_run` hands the layers out."""
+    """Draw the windows of all the runs that share a batch NOW, in one launch (svgr_batch_render_windows): a run's window is a
+    few dozen workgroups that live as long as its heaviest tile -- icons.svg: 30 launches, 1.6 ms one after the other, the
+    longest alone 0.23 --, and no run depends on anything the walk produces.  `_render_run` hands the layers out."""
     if not _PREFETCH_WINDOWS or not run_plans:
         return
     ctx = _abi.Context.get()

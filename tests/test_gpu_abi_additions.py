@@ -77,6 +77,13 @@ def test_windows_side_by_side_are_the_windows_one_by_one(S):
         for w, o, ref in zip(wins, outs, one_by_one):
             got = o.download((w[2], w[3], 4), np.float64)
             assert np.abs(got - ref).max() <= 1e-12
+    # more windows than one launch's table holds (64): several launches, the same layers
+    many = [(r, c, 40, 50) for r in range(0, 480, 48) for c in range(0, 480, 60)][:70]
+    m_outs = [ctx.alloc(40 * 50 * 32) for _ in many]
+    batch.render_windows(m_outs, _abi.OUT_CANVAS_F64, many)
+    full = _window(ctx, batch, (0, 0, 512, 512))
+    for w, o in zip(many, m_outs):
+        assert np.abs(o.download((40, 50, 4), np.float64) - full[w[0]:w[0] + 40, w[1]:w[1] + 50]).max() <= 1e-12
     # behind the call the context's stream is behind the windows: an operation enqueued now sees them
     S.Layer._from_device(outs[3], (256, 256, 4), (0, 0), True, False).opacity(0.5)
     with pytest.raises(ValueError):
