@@ -34,7 +34,7 @@ extern "C" {
  * 3: SVGR_RENDER_SAME_GEOMETRY, SVGR_OUT_FILLS_F64, svgr_layer_convert_to, svgr_layer_scale_to, svgr_batch_render_windows added
  *    (nothing changed or removed)
  * 4: svgr_hash_buffers added (nothing changed or removed)
- * 5: svgr_layer_compose_over, svgr_layer_convert_scale_to added (nothing changed or removed) */
+ * 5: svgr_layer_compose_over, svgr_layer_convert_scale_to, svgr_layer_convolve_ops added (nothing changed or removed) */
 #define SVGR_ABI_VERSION 5
 
 typedef enum {
@@ -337,6 +337,10 @@ int svgr_pattern_fill(svgr_ctx* ctx, const svgr_pattern* pattern, const svgr_buf
  * kernel (blur_kernel, S:1903-1944, is built on the host); out is (rows + kw - 1, cols + kh - 1, 4).     */
 int svgr_layer_convolve(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, const double* kernel,
                         int64_t kw, int64_t kh);
+/* ... of a source that still needs its Layer.convert (the filter's `source.convert(pre_alpha=False, linear_rgb=True)`, S:1803):
+ * src_ops = the svgr_layer_convert ops, applied to the source's pixels as the first pass reads them */
+int svgr_layer_convolve_ops(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, const double* kernel,
+                            int64_t kw, int64_t kh, unsigned src_ops);
 
 /* -------------------------------------------------------------------------------------------- */
 /* Path.stroke (S:1105-1180), host side: stroke outline of a path as a fill path.               */

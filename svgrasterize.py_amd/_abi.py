@@ -124,6 +124,7 @@ _PROTOS = {
     "svgr_gradient_eval": (C.c_int, [_P, C.POINTER(Gradient), _P, C.c_int64, _P]),
     "svgr_pattern_fill": (C.c_int, [_P, C.POINTER(PatternArgs), _P, _P, _P, _P]),
     "svgr_layer_convolve": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64]),
+    "svgr_layer_convolve_ops": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_uint]),
     "svgr_path_stroke": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, C.c_int, C.c_int, C.POINTER(_P)]),
     "svgr_stroke_out_counts": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "svgr_stroke_out_copy": (C.c_int, [_P, _P, _P, _P]),

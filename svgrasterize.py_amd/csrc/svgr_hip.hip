@@ -3931,8 +3931,9 @@ __global__ void k_pattern_fill(const svgr_pattern pt, const double* __restrict__
 // --------------------------------------------------------------------------------------
 // full 2-D convolution of a (rows, cols, 4) image with a (kw, kh) kernel (Layer.convolve, S:106-118)
 // --------------------------------------------------------------------------------------
-__global__ void k_layer_convolve(double* __restrict__ out, const double* __restrict__ src, int rows, int cols,
-                                 const double* __restrict__ kern, int kw, int kh) {
+template <typename KernPtr>
+__device__ __forceinline__ void convolve_direct(double* __restrict__ out, const double* __restrict__ src, int rows, int cols,
+                                                KernPtr kern, int kw, int kh) {
     const int orows = rows + kw - 1, ocols = cols + kh - 1;
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)orows * ocols) return;
@@ -3942,7 +3943,7 @@ __global__ void k_layer_convolve(double* __restrict__ out, const double* __restr
     const int j_lo = C - cols + 1 > 0 ? C - cols + 1 : 0, j_hi = C < kh - 1 ? C : kh - 1;
     for (int i = i_lo; i <= i_hi; ++i) {
         const double* srow = src + 4 * ((size_t)(R - i) * cols);
-        const double* krow = kern + (size_t)i * kh;
+        const auto krow = kern + (size_t)i * kh;
         for (int j = j_lo; j <= j_hi; ++j) {
             const double w = krow[j];
             const double* px = srow + 4 * (C - j);
@@ -3954,6 +3955,10 @@ __global__ void k_layer_convolve(double* __restrict__ out, const double* __restr
     }
     double* o = out + 4 * idx;
     o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+}
+__global__ void k_layer_convolve(double* __restrict__ out, const double* __restrict__ src, int rows, int cols,
+                                 const double* __restrict__ kern, int kw, int kh) {
+    convolve_direct(out, src, rows, cols, kern, kw, kh);
 }
 
 // One axis of a separable kernel (full convolution along rows or along columns): out = sum_k w[k] * src[.. - k ..].
@@ -3988,16 +3993,31 @@ struct ConvW {
     int n, pad;
     double w[CONV_TAPS];
 };
-// along a row (AXIS 1): one workgroup = 256 consecutive output columns of one row, the source span staged in LDS
+// the direct stencil with a small kernel's weights in the kernel argument (nothing uploaded, nothing for the host to wait for)
+__global__ void k_layer_convolve_small(double* __restrict__ out, const double* __restrict__ src, int rows, int cols, const ConvW cw, int kw, int kh) {
+    convolve_direct(out, src, rows, cols, (const double*)cw.w, kw, kh);
+}
+// along a row (AXIS 1): one workgroup = 256 consecutive output columns of one row, the source span staged in LDS -- converted as it
+// is staged (`ops`: the Layer.convert the filter runs on its source, S:1803, folded into this pass: a pixel is converted once per
+// workgroup that needs it, (256 + n - 1) / 256 times)
 __global__ __launch_bounds__(256) void k_convolve_cols(double* __restrict__ out, const double* __restrict__ src, int rows, int cols,
-                                                       const ConvW cw) {
+                                                       const ConvW cw, unsigned ops) {
     __shared__ double4 s_px[256 + CONV_TAPS - 1];
     const int n = cw.n, ocols = cols + n - 1;
     const int R = blockIdx.y, C0 = blockIdx.x * 256, tid = threadIdx.x;
     const double4* srow = (const double4*)src + (size_t)R * cols;
     for (int i = tid; i < 256 + n - 1; i += 256) {
         const int c = C0 - (n - 1) + i;  // source column held at s_px[i]
-        s_px[i] = c >= 0 && c < cols ? srow[c] : make_double4(0.0, 0.0, 0.0, 0.0);
+        double4 q = make_double4(0.0, 0.0, 0.0, 0.0);
+        if (c >= 0 && c < cols) {
+            q = srow[c];
+            if (ops) {
+                double v[4] = {q.x, q.y, q.z, q.w};
+                convert_px(v, ops);
+                q = make_double4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        s_px[i] = q;
     }
     __syncthreads();
     const int C = C0 + tid;
@@ -4011,14 +4031,23 @@ __global__ __launch_bounds__(256) void k_convolve_cols(double* __restrict__ out,
     ((double4*)out)[(size_t)R * ocols + C] = make_double4(a0, a1, a2, a3);
 }
 // along a column (AXIS 0): one thread = CONV_RB consecutive output rows of one column; every source pixel of the
-// column span is loaded once (coalesced across the threads of a row) and feeds the outputs it reaches
+// column span is loaded once (coalesced across the threads of a row) and feeds the outputs it reaches.  The loop over the
+// source rows is a chain of loads, one per row, in a launch of a few hundred waves: CONV_U of them are asked for together
+// (round 5), and the weights are read from an LDS copy padded with CONV_RB zeros on either
+// side, so that a tap outside the kernel is a multiplication by zero instead of a branch.
 #ifndef SVGR_CONV_RB
 #define SVGR_CONV_RB 12        // (25-tap blur of a 2048x2048 layer: 8 -> 0.180 ms, 12 -> 0.171, 16 -> 0.176, 24 -> 0.203)
 #endif
-constexpr int CONV_RB = SVGR_CONV_RB;
+#ifndef SVGR_CONV_U
+#define SVGR_CONV_U 6
+#endif
+constexpr int CONV_RB = SVGR_CONV_RB, CONV_U = SVGR_CONV_U;
 __global__ __launch_bounds__(64) void k_convolve_rows(double* __restrict__ out, const double* __restrict__ src, int rows, int cols,
                                                       const ConvW cw) {
+    __shared__ double s_w[CONV_TAPS + 2 * CONV_RB + CONV_U];   // (+ CONV_U: the rows asked for beyond the span's first are multiplied too)
     const int n = cw.n, orows = rows + n - 1;
+    for (int i = threadIdx.x; i < n + 2 * CONV_RB + CONV_U; i += 64) s_w[i] = i >= CONV_RB && i < CONV_RB + n ? cw.w[i - CONV_RB] : 0.0;
+    __syncthreads();
     const int C = blockIdx.x * 64 + threadIdx.x, R0 = blockIdx.y * CONV_RB;
     if (C >= cols) return;
     double acc[CONV_RB][4];
@@ -4028,15 +4057,20 @@ __global__ __launch_bounds__(64) void k_convolve_rows(double* __restrict__ out, 
     int j_hi = R0 + CONV_RB - 1, j_lo = R0 - (n - 1);
     j_hi = j_hi < rows - 1 ? j_hi : rows - 1;
     j_lo = j_lo > 0 ? j_lo : 0;
-    for (int j = j_hi; j >= j_lo; --j) {
-        const double4 px = ((const double4*)src)[(size_t)j * cols + C];
+    for (int j = j_hi; j >= j_lo; j -= CONV_U) {
+        double4 px[CONV_U];
 #pragma unroll
-        for (int r = 0; r < CONV_RB; ++r) {
-            const int k = R0 + r - j;  // (wave-uniform)
-            if (k >= 0 && k < n) {
-                const double wk = cw.w[k];
-                acc[r][0] = fma(px.x, wk, acc[r][0]); acc[r][1] = fma(px.y, wk, acc[r][1]);
-                acc[r][2] = fma(px.z, wk, acc[r][2]); acc[r][3] = fma(px.w, wk, acc[r][3]);
+        for (int u = 0; u < CONV_U; ++u)
+            px[u] = j - u >= j_lo ? ((const double4*)src)[(size_t)(j - u) * cols + C] : make_double4(0.0, 0.0, 0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < CONV_U; ++u) {
+            // output row R0 + r takes tap k = R0 + r - (j - u) of this source row: s_w[CONV_RB + k] (zero outside 0 .. n - 1)
+            const double* const wr = s_w + (CONV_RB + R0 - (j - u));   // (>= s_w + 1; wr[CONV_RB - 1] inside the padded array)
+#pragma unroll
+            for (int r = 0; r < CONV_RB; ++r) {
+                const double wk = wr[r];
+                acc[r][0] = fma(px[u].x, wk, acc[r][0]); acc[r][1] = fma(px[u].y, wk, acc[r][1]);
+                acc[r][2] = fma(px[u].z, wk, acc[r][2]); acc[r][3] = fma(px[u].w, wk, acc[r][3]);
             }
         }
     }
@@ -6170,15 +6204,20 @@ int svgr_pattern_fill(svgr_ctx* ctx, const svgr_pattern* pt, const svgr_buf* til
 }
 
 static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, const double* kernel,
-                               int64_t kw, int64_t kh);
+                               int64_t kw, int64_t kh, unsigned src_ops);
 int svgr_layer_convolve(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, const double* kernel,
                         int64_t kw, int64_t kh) {
     // (the separability test builds host vectors: std::bad_alloc must not cross the ABI)
-    return abi_guard("svgr_layer_convolve", [&]() { return layer_convolve_impl(ctx, out, src, rows, cols, kernel, kw, kh); });
+    return abi_guard("svgr_layer_convolve", [&]() { return layer_convolve_impl(ctx, out, src, rows, cols, kernel, kw, kh, 0u); });
+}
+int svgr_layer_convolve_ops(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, const double* kernel,
+                            int64_t kw, int64_t kh, unsigned src_ops) {
+    if (src_ops & ~15u) return fail(SVGR_E_INVALID, "svgr_layer_convolve_ops: unknown conversion ops");
+    return abi_guard("svgr_layer_convolve_ops", [&]() { return layer_convolve_impl(ctx, out, src, rows, cols, kernel, kw, kh, src_ops); });
 }
 
 static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int64_t rows, int64_t cols, const double* kernel,
-                               int64_t kw, int64_t kh) {
+                               int64_t kw, int64_t kh, unsigned src_ops) {
     if (!ctx || !out || !src || !kernel || rows <= 0 || cols <= 0 || kw <= 0 || kh <= 0 || rows > (1 << 24) || cols > (1 << 24) ||
         kw > 4096 || kh > 4096)
         return fail(SVGR_E_INVALID, "svgr_layer_convolve: bad arguments");
@@ -6240,19 +6279,34 @@ static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src
     const double total = an->total;
     const bool separable = an->separable && getenv("SVGR_BLUR_DIRECT") == nullptr;
     hipError_t e = hipSuccess;
-    if (separable && kw <= CONV_TAPS && kh <= CONV_TAPS && rows + kw - 1 <= 65535) {  // (the row index rides in gridDim.y)
+    static const bool dbg_conv = getenv("SVGR_DBG_CONV") != nullptr;
+    const bool blocked = separable && kw <= CONV_TAPS && kh <= CONV_TAPS && rows <= 65535;  // (the row index rides in gridDim.y)
+    if (dbg_conv) fprintf(stderr, "[convolve] %lld x %lld layer, %lld x %lld kernel, ops %u: %s\n", (long long)rows, (long long)cols, (long long)kw,
+                          (long long)kh, src_ops, blocked ? "two blocked passes" : separable ? "two plain passes" : "direct");
+    // (the passes that do not convert as they read: the source converted first, into a block of its own)
+    double* conv_src = nullptr;
+    const double* src_px = (const double*)src->ptr;
+    if (src_ops && !blocked) {
+        HIPCHK(g_pool.alloc((void**)&conv_src, (size_t)rows * cols * 32, ctx->device));
+        hipLaunchKernelGGL(k_layer_convert<false>, grid1((size_t)rows * cols), dim3(256), 0, ctx->stream, conv_src, src_px, (size_t)rows * cols, src_ops, 1.0);
+        src_px = conv_src;
+    }
+    struct Release { double* p; ~Release() { if (p) g_pool.release(p); } } release_conv{conv_src};   // (stream order: behind the kernels below)
+    if (blocked) {
+        // along the rows first (the pass that stages its source in LDS converts it there), then down the columns
         for (auto& x : u) x /= total;  // K = (u / S) v^T
         ConvW cu{}, cv{};
         cu.n = (int)kw; cv.n = (int)kh;
         for (int64_t i = 0; i < kw; ++i) cu.w[i] = u[(size_t)i];
         for (int64_t j = 0; j < kh; ++j) cv.w[j] = v[(size_t)j];
         double* tmp = nullptr;
-        const size_t n_tmp = (size_t)(rows + kw - 1) * (size_t)cols;
+        const int64_t ocols = cols + kh - 1;
+        const size_t n_tmp = (size_t)rows * (size_t)ocols;
         HIPCHK(g_pool.alloc((void**)&tmp, n_tmp * 32, ctx->device));
-        hipLaunchKernelGGL(k_convolve_rows, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + kw - 1 + CONV_RB - 1) / CONV_RB)), dim3(64), 0,
-                           ctx->stream, tmp, (const double*)src->ptr, (int)rows, (int)cols, cu);
-        hipLaunchKernelGGL(k_convolve_cols, dim3((unsigned)((cols + kh - 1 + 255) / 256), (unsigned)(rows + kw - 1)), dim3(256), 0,
-                           ctx->stream, (double*)out->ptr, (const double*)tmp, (int)(rows + kw - 1), (int)cols, cv);
+        hipLaunchKernelGGL(k_convolve_cols, dim3((unsigned)((ocols + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, tmp, src_px,
+                           (int)rows, (int)cols, cv, src_ops);
+        hipLaunchKernelGGL(k_convolve_rows, dim3((unsigned)((ocols + 63) / 64), (unsigned)((rows + kw - 1 + CONV_RB - 1) / CONV_RB)), dim3(64), 0,
+                           ctx->stream, (double*)out->ptr, (const double*)tmp, (int)rows, (int)ocols, cu);
         e = hipGetLastError();
         g_pool.release(tmp);  // (stream order keeps the block's next user behind the two kernels)
     } else if (separable) {
@@ -6264,7 +6318,7 @@ static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src
         e = hipMemcpyAsync(dw, u.data(), sizeof(double) * (size_t)kw, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(dw + kw, v.data(), sizeof(double) * (size_t)kh, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_layer_convolve_1d<0>, grid1(n_tmp), dim3(256), 0, ctx->stream, tmp, (const double*)src->ptr, (int)rows,
+            hipLaunchKernelGGL(k_layer_convolve_1d<0>, grid1(n_tmp), dim3(256), 0, ctx->stream, tmp, src_px, (int)rows,
                                (int)cols, (const double*)dw, (int)kw);
             hipLaunchKernelGGL(k_layer_convolve_1d<1>, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)tmp,
                                (int)(rows + kw - 1), (int)cols, (const double*)(dw + kw), (int)kh);
@@ -6273,12 +6327,19 @@ static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src
         }
         g_pool.release(tmp);
         g_pool.release(dw);
+    } else if (kw * kh <= CONV_TAPS) {
+        ConvW ck{};
+        ck.n = (int)(kw * kh);
+        for (int64_t i = 0; i < kw * kh; ++i) ck.w[i] = kernel[i];
+        hipLaunchKernelGGL(k_layer_convolve_small, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, src_px, (int)rows, (int)cols, ck,
+                           (int)kw, (int)kh);
+        e = hipGetLastError();
     } else {
         double* dk = nullptr;
         HIPCHK(g_pool.alloc((void**)&dk, sizeof(double) * (size_t)kw * kh));
         e = hipMemcpyAsync(dk, kernel, sizeof(double) * (size_t)kw * kh, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_layer_convolve, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)src->ptr,
+            hipLaunchKernelGGL(k_layer_convolve, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, src_px,
                                (int)rows, (int)cols, (const double*)dk, (int)kw, (int)kh);
             e = hipStreamSynchronize(ctx->stream);
             if (e == hipSuccess) e = hipGetLastError();

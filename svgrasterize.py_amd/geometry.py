@@ -768,15 +768,23 @@ _PAINT_MEMO: dict = {}  # (4 doubles as bytes, linear_rgb) -> converted paint: d
 def solid_paint(paint: np.ndarray, linear_rgb: bool) -> np.ndarray:
     """The 4-vector colour step of Path.fill (S:1014-1018): premultiplied linear RGBA ->
     premultiplied RGBA of the compositing space.  Four numbers, done on the host in double."""
+    # (the memo's arrays are handed out as they are, read-only: a document's thousand fills share a handful of colours, and a copy
+    #  per fill was a third of this function)
+    if type(paint) is np.ndarray and paint.dtype == FLOAT:
+        key = (paint.tobytes(), linear_rgb is True or bool(linear_rgb))
+        hit = _PAINT_MEMO.get(key)
+        if hit is not None:
+            return hit
     out = np.array(paint, dtype=FLOAT)
     key = (out.tobytes(), bool(linear_rgb))
     hit = _PAINT_MEMO.get(key)
     if hit is not None:
-        return hit.copy()
+        return hit
     if len(_PAINT_MEMO) > 8192:
         _PAINT_MEMO.clear()
     out = _solid_paint(out, linear_rgb)
-    _PAINT_MEMO[key] = out.copy()
+    out.flags.writeable = False
+    _PAINT_MEMO[key] = out
     return out
 
 

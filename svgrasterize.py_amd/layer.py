@@ -53,7 +53,7 @@ class Layer:
         self = object.__new__(cls)
         self._host = None
         self._dev = buf
-        self._shape = tuple(int(s) for s in shape)
+        self._shape = tuple(map(int, shape))
         self.offset = offset
         self.pre_alpha = pre_alpha
         self.linear_rgb = linear_rgb
@@ -277,9 +277,12 @@ class Layer:
         rows, cols = layer.height, layer.width
         out_shape = (rows + kw - 1, cols + kh - 1, 4)
         out = ctx.alloc(out_shape[0] * out_shape[1] * 32)
-        src = layer._device()
-        _abi._check(ctx.lib.svgr_layer_convolve(ctx.handle, out.handle, src.handle, rows, cols,
-                                                kernel.ctypes.data_as(_abi._P), kw, kh))
+        if layer._host is None and layer._ops:   # (the conversion rides in the blur's first pass)
+            _abi._check(ctx.lib.svgr_layer_convolve_ops(ctx.handle, out.handle, layer._dev.handle, rows, cols,
+                                                        _abi.ptr(kernel), kw, kh, layer._ops))
+        else:
+            src = layer._device()
+            _abi._check(ctx.lib.svgr_layer_convolve(ctx.handle, out.handle, src.handle, rows, cols, _abi.ptr(kernel), kw, kh))
         offset = (int(layer.x - kw / 2), int(layer.y - kh / 2))
         return Layer._from_device(out, out_shape, offset, pre_alpha=False, linear_rgb=True)
 
