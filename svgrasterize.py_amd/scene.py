@@ -566,6 +566,24 @@ def _row_extent(leaf):
     return lo, hi
 
 
+def _row_extents(leaves):
+    """`_row_extent` of every leaf of a run as two arrays (lowest, highest row), or None when some leaf has none."""
+    boxes = [leaf[0].user_box() for leaf in leaves]
+    if None in boxes:
+        return None
+    n = len(leaves)
+    box = np.array(boxes, dtype=np.float64).reshape(n, 4)
+    m = np.concatenate([leaf[1] for leaf in leaves]).reshape(n, 6)
+    a, b, t = m[:, 0], m[:, 1], m[:, 2]
+    x0, y0, x1, y1 = box[:, 0], box[:, 1], box[:, 2], box[:, 3]
+    r = np.stack([a * x0 + b * y0 + t, a * x1 + b * y0 + t, a * x0 + b * y1 + t, a * x1 + b * y1 + t])
+    lo, hi = r.min(axis=0), r.max(axis=0)
+    # (NaN fails every comparison; the limits as in `_row_extent`)
+    if not bool(np.all((lo == lo) & (hi == hi) & (hi - lo <= 1e9) & (np.abs(lo) <= 1e9))):
+        return None
+    return lo, hi
+
+
 def _shift_leaf(leaf, shift):
     """The leaf moved down by `shift` rows (a whole number of bands)."""
     if shift == 0:
@@ -599,14 +617,18 @@ def _merge_runs(todo, viewport):
         lo, hi = float(v0), float(v1)
         ok = _MERGE_RUNS and len(todo) > 1
         if ok:
-            for leaf in leaves:
-                ext = _row_extent(leaf)
+            ext = _row_extents(leaves)
+            if ext is None:
+                ok = False
+            else:
+                e_lo, e_hi = ext
                 # (a two-circle gradient asks "any pixel of the fill's LAYER with det < 0" (S:1627), and the layer is the bbox
                 #  clipped to the batch's viewport: such a fill shares only when it lies inside the viewport's rows anyway)
-                if ext is None or (leaf[6] is not None and leaf[6][0].kind == 3 and (ext[0] < v0 + 1 or ext[1] > v1 - 1)):
-                    ok = False
-                    break
-                lo, hi = min(lo, ext[0]), max(hi, ext[1])
+                for i, leaf in enumerate(leaves):
+                    if leaf[6] is not None and leaf[6][0].kind == 3 and (e_lo[i] < v0 + 1 or e_hi[i] > v1 - 1):
+                        ok = False
+                        break
+                lo, hi = min(lo, float(e_lo.min())), max(hi, float(e_hi.max()))
             ok = ok and v0 - lo <= over and hi - v1 <= over
         if not ok:
             try:
@@ -636,12 +658,13 @@ def _merge_runs(todo, viewport):
             plans[key] = [leaves, batch]
             batches.append(batch)
             continue
-        merged, spans = [], []
+        merged, spans, shifts = [], [], []
         for key, leaves, shift in members:
             spans.append((key, leaves, len(merged), len(merged) + len(leaves), shift))
-            merged.extend(_shift_leaf(leaf, shift) for leaf in leaves)
+            merged.extend(leaves)                # (moved down by `shift` rows inside build_batch: one addition per column, not a leaf each)
+            shifts.extend([shift] * len(leaves))
         try:
-            batch = build_batch(merged, [0, int(viewport[1]), total, int(viewport[3])])
+            batch = build_batch(merged, [0, int(viewport[1]), total, int(viewport[3])], row_shift=shifts)
         except Exception:  # noqa: BLE001  (the runs then plan for themselves, on demand)
             continue
         shared = _SharedBatch(batch, len(spans))
@@ -924,8 +947,9 @@ def effective_bboxes(leaves, bboxes):
     return [(int(b[0]), int(b[1]), int(b[2] - b[0]), int(b[3] - b[1])) if k else None for b, k in zip(box, ok)]
 
 
-def build_batch(leaves, viewport, ctx=None) -> "_abi.Batch":
-    """Pack paint-ordered leaves [(path, m6, rule, paint4, flags[, group[, grad]])] into one device batch."""
+def build_batch(leaves, viewport, ctx=None, row_shift=None) -> "_abi.Batch":
+    """Pack paint-ordered leaves [(path, m6, rule, paint4, flags[, group[, grad]])] into one device batch.  `row_shift`: per leaf
+    the rows its geometry (and its gradient's frame) is moved down by (`_shift_leaf`, for all leaves at once)."""
     ctx = ctx or _abi.Context.get()
     n = len(leaves)
     # (comprehensions, not one loop with a dozen appends per leaf: material-design's 1 924 leaves were 3 ms of it)
@@ -933,12 +957,14 @@ def build_batch(leaves, viewport, ctx=None) -> "_abi.Batch":
     seg_list = [pk[0] for pk in packs]
     offs = np.zeros(n + 1, dtype=np.int64)
     if n:
-        np.cumsum(np.fromiter((len(sg) for sg in seg_list), dtype=np.int64, count=n), out=offs[1:])
+        np.cumsum(np.fromiter(map(len, seg_list), dtype=np.int64, count=n), out=offs[1:])
     segs = np.concatenate(seg_list) if n else np.zeros((0, 8))
     kinds = np.concatenate([pk[1] for pk in packs]) if n else np.zeros(0, dtype=np.uint8)
-    m6s = np.array([leaf[1] for leaf in leaves], dtype=np.float64).reshape(n, 6)
+    m6s = np.concatenate([leaf[1] for leaf in leaves]).astype(np.float64, copy=False).reshape(n, 6) if n else np.zeros((0, 6))
+    if row_shift is not None and n:
+        m6s[:, 2] += np.asarray(row_shift, dtype=np.float64)
     rules = np.fromiter((leaf[2] | (leaf[4] << 1) for leaf in leaves), dtype=np.uint8, count=n)  # SVGR_PATH_CLIP_SOURCE = 2, SVGR_PATH_CLIPPED = 4
-    paints = np.array([leaf[3] for leaf in leaves], dtype=np.float64).reshape(n, 4)
+    paints = np.concatenate([leaf[3] for leaf in leaves]).astype(np.float64, copy=False).reshape(n, 4) if n else np.zeros((0, 4))
     path_group, group_src, group_op, serial_to_gid = None, [], [], {}
     path_grad, grads, keep_alive = None, [], []
     if any(len(leaf) > 5 and leaf[5] is not None for leaf in leaves):
@@ -956,11 +982,13 @@ def build_batch(leaves, viewport, ctx=None) -> "_abi.Batch":
             path_group.append(gid)
     if any(len(leaf) > 6 and leaf[6] is not None for leaf in leaves):
         path_grad = []
-        for leaf in leaves:
+        for i, leaf in enumerate(leaves):
             grad = leaf[6] if len(leaf) > 6 else None
             if grad is None:
                 path_grad.append(-1)
             else:
+                if row_shift is not None and row_shift[i]:
+                    grad = _shift_leaf(leaf, row_shift[i])[6]   # (the gradient's frame moves with the path)
                 path_grad.append(len(grads))
                 grads.append(grad[0])
                 keep_alive.append(grad[1])
