@@ -136,3 +136,166 @@ def test_convert_and_scale_into_another_buffer(S):
     _abi._check(ctx.lib.svgr_layer_scale_to(ctx.handle, dst.handle, src.handle, n_px * 4, 0.375))
     assert np.array_equal(dst.download(img.shape, np.float64), inplace.download(img.shape, np.float64))
     assert np.array_equal(dst.download(img.shape, np.float64), img * 0.375)
+
+
+# ---- ABI 5: svgr_layer_compose_over, svgr_layer_convert_scale_to, svgr_layer_convolve_ops, against the calls they stand in for ----
+def _rand_layer(rng, rows, cols, ch=4):
+    img = rng.random((rows, cols, ch))
+    if ch == 4:
+        img[..., :3] *= img[..., 3:]
+    return img
+
+
+def _bb(r0, c0, rows, cols):
+    import ctypes as C
+
+    return (C.c_int64 * 4)(r0, c0, rows, cols)
+
+
+def test_compose_over_in_one_pass_is_the_pass_per_layer(S):
+    """svgr_layer_compose_over (converting sources as it reads them) = convert each source, clear the union, svgr_layer_over one
+    layer after the other: the same bits, for 3 and for 30 layers (more than one launch's table), 1- and 4-channel sources."""
+    import ctypes as C
+
+    from svgrasterize_amd import _abi
+
+    ctx = S.Context.get()
+    rng = np.random.default_rng(11)
+    for n in (1, 3, 30):
+        specs = []
+        for i in range(n):
+            rows, cols = int(rng.integers(5, 60)), int(rng.integers(5, 70))
+            r0, c0 = int(rng.integers(-20, 40)), int(rng.integers(-30, 50))
+            ch = 1 if i % 5 == 3 else 4
+            ops = 0 if ch == 1 else int(rng.choice([0, 0, 8, 4 | 8, 2 | 8, 1 | 2 | 8]))
+            img = _rand_layer(rng, rows, cols, ch)
+            if ops & 8 and not ops & 1:
+                img = rng.random((rows, cols, 4))   # (a straight-alpha source)
+            specs.append((img, (r0, c0, rows, cols), ch, ops))
+        u0 = min(s[1][0] for s in specs); v0 = min(s[1][1] for s in specs)
+        u1 = max(s[1][0] + s[1][2] for s in specs); v1 = max(s[1][1] + s[1][3] for s in specs)
+        shape = (u1 - u0, v1 - v0, 4)
+        obb = _bb(u0, v0, shape[0], shape[1])
+        # the pass per layer
+        ref = ctx.alloc(shape[0] * shape[1] * 32)
+        ref.zero()
+        for i, (img, bb, ch, ops) in enumerate(specs):
+            b = ctx.from_host(img)
+            if ops:
+                _abi._check(ctx.lib.svgr_layer_convert(ctx.handle, b.handle, bb[2] * bb[3], ops))
+            _abi._check(ctx.lib.svgr_layer_over(ctx.handle, ref.handle, obb, b.handle, _bb(*bb), ch, int(i == 0)))
+        # one pass
+        out = ctx.alloc(shape[0] * shape[1] * 32)
+        srcs = [ctx.from_host(s[0]) for s in specs]
+        handles = (_abi._P * n)(*[b.handle for b in srcs])
+        bbs = (C.c_int64 * (4 * n))(*[v for s in specs for v in s[1]])
+        chs = (C.c_int32 * n)(*[s[2] for s in specs])
+        opsa = (C.c_uint32 * n)(*[s[3] for s in specs])
+        # (the output need not be cleared: poison it)
+        out.upload(np.full(shape, np.nan))
+        _abi._check(ctx.lib.svgr_layer_compose_over(ctx.handle, out.handle, obb, n, handles, bbs, chs, opsa))
+        assert np.array_equal(out.download(shape, np.float64), ref.download(shape, np.float64)), n
+    with pytest.raises(ValueError):   # ops on a 1-channel source
+        one = ctx.from_host(np.zeros((4, 4, 1)))
+        _abi._check(ctx.lib.svgr_layer_compose_over(ctx.handle, out.handle, obb, 1, (_abi._P * 1)(one.handle), (C.c_int64 * 4)(0, 0, 4, 4),
+                                                    (C.c_int32 * 1)(1), (C.c_uint32 * 1)(8)))
+
+
+def test_convert_and_scale_in_one_pass(S):
+    from svgrasterize_amd import _abi
+
+    ctx = S.Context.get()
+    rng = np.random.default_rng(12)
+    img = _rand_layer(rng, 41, 29)
+    n_px = 41 * 29
+    src = ctx.from_host(img)
+    for ops in (0, 1, 8, 1 | 2 | 8, 1 | 4 | 8):
+        two = ctx.from_host(img)
+        _abi._check(ctx.lib.svgr_layer_convert(ctx.handle, two.handle, n_px, ops))
+        _abi._check(ctx.lib.svgr_layer_scale(ctx.handle, two.handle, n_px * 4, 0.3125))
+        one = ctx.alloc(n_px * 32)
+        _abi._check(ctx.lib.svgr_layer_convert_scale_to(ctx.handle, one.handle, src.handle, n_px, ops, 0.3125))
+        assert np.array_equal(one.download(img.shape, np.float64), two.download(img.shape, np.float64)), ops
+
+
+def test_blur_of_a_source_that_still_needs_its_conversion(S):
+    """svgr_layer_convolve_ops = svgr_layer_convert, then svgr_layer_convolve: the same bits (separable kernels in the two blocked
+    passes, a small non-separable one in the kernel argument, a large one through the uploaded stencil)."""
+    from svgrasterize_amd import _abi
+
+    ctx = S.Context.get()
+    rng = np.random.default_rng(13)
+    img = _rand_layer(rng, 57, 83)
+    rows, cols = 57, 83
+
+    def gauss(n, s):
+        x = np.arange(n) - (n - 1) / 2
+        g = np.exp(-x * x / (2 * s * s))
+        return g / g.sum()
+
+    kernels = [np.outer(gauss(9, 1.7), gauss(13, 2.4)), np.outer(gauss(45, 7.0), gauss(45, 7.0)), rng.random((3, 5)), rng.random((15, 17)),
+               np.outer(gauss(1, 1.0), gauss(7, 1.1)), np.outer(gauss(5, 0.9), gauss(1, 1.0))]
+    for k in kernels:
+        k = np.ascontiguousarray(k, dtype=np.float64)
+        kw, kh = k.shape
+        oshape = (rows + kw - 1, cols + kh - 1, 4)
+        for ops in (0, 1 | 2):
+            conv = ctx.from_host(img)
+            if ops:
+                _abi._check(ctx.lib.svgr_layer_convert(ctx.handle, conv.handle, rows * cols, ops))
+            ref = ctx.alloc(oshape[0] * oshape[1] * 32)
+            _abi._check(ctx.lib.svgr_layer_convolve(ctx.handle, ref.handle, conv.handle, rows, cols, _abi.ptr(k), kw, kh))
+            src = ctx.from_host(img)
+            out = ctx.alloc(oshape[0] * oshape[1] * 32)
+            _abi._check(ctx.lib.svgr_layer_convolve_ops(ctx.handle, out.handle, src.handle, rows, cols, _abi.ptr(k), kw, kh, ops))
+            assert np.array_equal(out.download(oshape, np.float64), ref.download(oshape, np.float64)), (k.shape, ops)
+            assert np.array_equal(src.download(img.shape, np.float64), img)
+            # ... and both are the full 2-D convolution (S:106-118) of the converted image
+            if kw * kh <= 255:
+                from scipy.signal import convolve as sp_convolve
+
+                want = sp_convolve(conv.download(img.shape, np.float64), k[..., None], mode="full", method="direct")
+                assert np.abs(out.download(oshape, np.float64) - want).max() <= 1e-14 * max(np.abs(want).max(), 1.0) * (kw * kh) ** 0.5
+
+
+def test_a_noted_conversion_is_the_conversion(S):
+    """Layer.convert of a device layer only notes the ops (`_ops`): whoever reads the layer -- `.image`, compose, opacity, another
+    convert that cannot be folded -- sees the converted pixels, bit for bit what the eager conversion gave."""
+    from svgrasterize_amd import _abi
+
+    ctx = S.Context.get()
+    rng = np.random.default_rng(14)
+    img = _rand_layer(rng, 33, 47)
+
+    def dev_layer():
+        return S.Layer._from_device(ctx.from_host(img), img.shape, (3, 5), True, False)
+
+    def eager(ops):
+        b = ctx.from_host(img)
+        _abi._check(ctx.lib.svgr_layer_convert(ctx.handle, b.handle, 33 * 47, ops))
+        return b.download(img.shape, np.float64)
+
+    lazy = dev_layer().convert(pre_alpha=False, linear_rgb=True)
+    assert lazy._ops == 3 and lazy.pre_alpha is False and lazy.linear_rgb is True
+    assert np.array_equal(lazy.image, eager(1 | 2))
+    # folded: straight linear -> premultiplied linear on top of the note (1, 2, then 8)
+    twice = dev_layer().convert(pre_alpha=False, linear_rgb=True).convert(pre_alpha=True, linear_rgb=True)
+    assert twice._ops == (1 | 2 | 8)
+    assert np.array_equal(twice.image, eager(1 | 2 | 8))
+    # not foldable: back to sRGB needs "premultiplied -> straight" behind "straight -> premultiplied"
+    back = dev_layer().convert(pre_alpha=False, linear_rgb=True).convert(pre_alpha=True, linear_rgb=True).convert(pre_alpha=True, linear_rgb=False)
+    first = ctx.from_host(eager(1 | 2 | 8))
+    _abi._check(ctx.lib.svgr_layer_convert(ctx.handle, first.handle, 33 * 47, 1 | 4 | 8))
+    assert np.array_equal(back.image, first.download(img.shape, np.float64))
+    # opacity and compose read through the note
+    faded = dev_layer().convert(pre_alpha=False, linear_rgb=True).opacity(0.25, linear_rgb=True)
+    assert np.array_equal(faded.image, eager(1 | 2 | 8) * 0.25)
+    other = S.Layer(_rand_layer(rng, 20, 60), (0, 0), True, True)
+    got = S.Layer.compose([other, dev_layer().convert(pre_alpha=False, linear_rgb=True)], linear_rgb=True)
+    want = S.Layer.compose([other, S.Layer(eager(1 | 2), (3, 5), False, True)], linear_rgb=True)
+    assert got.offset == want.offset and np.array_equal(got.image, want.image)
+    # the source layer is untouched by its converted views
+    src = dev_layer()
+    view = src.convert(pre_alpha=False, linear_rgb=True)
+    _ = view.image
+    assert np.array_equal(src.image, img)
