@@ -34,7 +34,8 @@ extern "C" {
  * 3: SVGR_RENDER_SAME_GEOMETRY, SVGR_OUT_FILLS_F64, svgr_layer_convert_to, svgr_layer_scale_to, svgr_batch_render_windows added
  *    (nothing changed or removed)
  * 4: svgr_hash_buffers added (nothing changed or removed)
- * 5: svgr_layer_compose_over, svgr_layer_convert_scale_to, svgr_layer_convolve_ops added (nothing changed or removed) */
+ * 5: svgr_layer_compose_over, svgr_layer_convert_scale_to, svgr_layer_convolve_ops, svgr_batch_get_extents added (nothing changed
+ *    or removed) */
 #define SVGR_ABI_VERSION 5
 
 typedef enum {
@@ -189,6 +190,13 @@ typedef struct {
 int svgr_batch_get_stats(const svgr_batch* batch, svgr_batch_stats* out);
 /* per-path clipped integer bbox {row0, col0, rows, cols}; rows <= 0 = empty (Path.mask -> None) */
 int svgr_batch_get_bboxes(const svgr_batch* batch, int32_t* out /* n_paths x 4 */);
+/* per-path extent of ALL its flattened points, unclipped, in presentation space: {min row, min col, max row, max col} doubles --
+ * the bounding box of ConvexHull(lines) (S:993, S:2010-2020) under a transform that keeps the axes apart, i.e. the frame of an
+ * objectBoundingBox paint (S:1023-1027) without fetching the hull.  Read from the plan's own geometry pass: valid between
+ * svgr_batch_plan and the first render (SVGR_E_STATE otherwise).  A path without edges: {+inf, +inf, -inf, -inf}.
+ * (svgr_batch_set_gradients with the same path -> gradient assignment and new descriptions -- those frames -- keeps the plan
+ * and its pass.) */
+int svgr_batch_get_extents(svgr_batch* batch, double* out /* n_paths x 4 */);
 /* flattened edges in presentation space, (E, 2, 2) doubles, grouped by path; edge_path may be NULL */
 int svgr_batch_get_edges(const svgr_batch* batch, double* edges, int32_t* edge_path, int64_t cap);
 /* ALL flattened edges of the batch, also those that cannot reach the viewport: the point set of Path.mask's

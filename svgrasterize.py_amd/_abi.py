@@ -96,6 +96,7 @@ _PROTOS = {
     "svgr_batch_get_stats": (C.c_int, [_P, C.POINTER(BatchStats)]),
     "svgr_batch_get_bboxes": (C.c_int, [_P, _P]),
     "svgr_batch_get_edges": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "svgr_batch_get_extents": (C.c_int, [_P, _P]),
     "svgr_batch_all_edges": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "svgr_batch_render": (C.c_int, [_P, _P, C.c_int, C.c_uint]),
     "svgr_batch_render_window": (C.c_int, [_P, _P, C.c_int, C.c_uint, _P]),
@@ -371,6 +372,13 @@ class Batch:
             raise ValueError("one clip source and one opacity per group")
         _check(self.ctx.lib.svgr_batch_set_groups(self.handle, C.c_void_p(ptr(pg)), len(cs), C.c_void_p(ptr(cs)), C.c_void_p(ptr(op))))
         self._stats = None
+
+    def extents(self) -> np.ndarray:
+        """(n_paths, 4) doubles {min row, min col, max row, max col} of every path's flattened points, unclipped
+        (svgr_batch_get_extents: between plan() and the first render)."""
+        out = np.empty((self.n_paths, 4), dtype=np.float64)
+        _check(self.ctx.lib.svgr_batch_get_extents(self.handle, C.c_void_p(ptr(out))))
+        return out
 
     def set_gradients(self, path_grad, grads):
         """Gradient paints inside the batch: path_grad[p] = index into `grads` (a list of `Gradient` structs, one per

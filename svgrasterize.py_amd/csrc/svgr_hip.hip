@@ -4111,6 +4111,7 @@ struct svgr_batch {
     DevArr<char> groups_dev;   // ... one block holding the three (views), filled by ONE upload
     std::vector<uint8_t> host_rule;  // the paths' rule / flag bytes (checked against the groups)
     int64_t n_grads = 0;       // gradient-painted paths (svgr_batch_set_gradients)
+    std::vector<int32_t> host_path_grad;   // ... which path has which (as last set)
     DevArr<GradDev> grads;
     DevArr<int> path_grad, grad_path, grad_flags;
     DevArr<char> grads_dev;    // grads / path_grad / grad_path as views of one block, filled by ONE upload
@@ -4906,7 +4907,7 @@ int svgr_batch_set_groups(svgr_batch* b, const int32_t* path_group, int64_t n_gr
 int svgr_batch_set_gradients(svgr_batch* b, const int32_t* path_grad, int64_t n_grads, const svgr_gradient* grads) {
     return abi_guard("svgr_batch_set_gradients", [&]() -> int {
         if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
-        if (n_grads == 0) { b->n_grads = 0; b->geometry_fresh = false; b->geometry_current = false; return 0; }
+        if (n_grads == 0) { b->n_grads = 0; b->host_path_grad.clear(); b->geometry_fresh = false; b->geometry_current = false; return 0; }
         if (n_grads < 0 || n_grads > b->n_paths || !path_grad || !grads) return fail(SVGR_E_INVALID, "svgr_batch_set_gradients: bad arguments");
         std::vector<GradDev> host((size_t)n_grads);
         std::vector<int> owner((size_t)n_grads, -1);
@@ -4952,9 +4953,15 @@ int svgr_batch_set_gradients(svgr_batch* b, const int32_t* path_grad, int64_t n_
             HIPCHK(hipMemcpyAsync(b->grads_dev.p, b->keep(blob.data(), total), total, hipMemcpyHostToDevice, st));
             HIPCHK(b->note_upload(st));
         }
+        // (the cell headers carry the gradient indices: a new assignment of gradients to paths needs the geometry pass again; new
+        //  descriptions for the same assignment -- the frames of objectBoundingBox paints, known once the plan has flattened their
+        //  paths -- do not, nor do they touch what the plan's pass left in the buffers)
+        const bool same_map = b->n_grads == n_grads && b->host_path_grad.size() == (size_t)b->n_paths &&
+                              memcmp(b->host_path_grad.data(), path_grad, sizeof(int32_t) * (size_t)b->n_paths) == 0 && b->has_focal == focal;
+        b->host_path_grad.assign(path_grad, path_grad + b->n_paths);
         b->n_grads = n_grads;
         b->has_focal = focal;
-        b->geometry_fresh = false; b->geometry_current = false;  // the cell headers carry the gradient indices
+        if (!same_map) { b->geometry_fresh = false; b->geometry_current = false; }
         return 0;
     });
 }
@@ -5509,6 +5516,31 @@ int svgr_batch_get_bboxes(const svgr_batch* b, int32_t* out) {
     if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan has not run");
     memcpy(out, b->host_bbox.data(), sizeof(int32_t) * 4 * (size_t)b->n_paths);
     return 0;
+}
+
+// The extent of every path's flattened points, unclipped and unrounded: {min row, min col, max row, max col} in device space --
+// what ConvexHull(lines).bbox (S:993, S:2010-2020) comes to under a transform that keeps the axes apart, and with it the frame of
+// an objectBoundingBox paint (S:1023-1027) without the hull.  The minima / maxima are those k_flatten folds for k_path_bbox (every
+// point of every segment, whatever the viewport: min / max keys in the counter arena), so they are the plan's own pass's: asked for
+// between svgr_batch_plan and the first render.  A path without edges reports {+inf, +inf, -inf, -inf}.
+int svgr_batch_get_extents(svgr_batch* b, double* out) {
+    return abi_guard("svgr_batch_get_extents", [&]() -> int {
+        if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
+        if (!b->planned || !b->geometry_fresh)
+            return fail(SVGR_E_STATE, "the extents are read from the plan's own geometry pass: call between svgr_batch_plan and the first render");
+        const size_t np = (size_t)b->n_paths;
+        if (np == 0) return 0;
+        HIPCHK(enter_ctx(b->ctx));
+        std::vector<unsigned long long> k(4 * np);
+        HIPCHK(hipMemcpyAsync(k.data(), b->pkeys(), sizeof(unsigned long long) * 4 * np, hipMemcpyDeviceToHost, b->ctx->stream));
+        HIPCHK(hipStreamSynchronize(b->ctx->stream));
+        for (size_t p = 0; p < np; ++p) {
+            double* o = out + 4 * p;
+            if (k[4 * p] == 0ull) { o[0] = o[1] = INFINITY; o[2] = o[3] = -INFINITY; continue; }
+            o[0] = key_f64(~k[4 * p]); o[1] = key_f64(~k[4 * p + 1]); o[2] = key_f64(k[4 * p + 2]); o[3] = key_f64(k[4 * p + 3]);
+        }
+        return 0;
+    });
 }
 
 int svgr_batch_get_edges(const svgr_batch* b, double* edges, int32_t* edge_path, int64_t cap) {

@@ -19,7 +19,7 @@ STROKE nodes are stroked by the native stroker (`Path.stroke`, csrc/svgr_stroke.
 from __future__ import annotations
 
 import gc
-
+import math
 import textwrap
 
 import numpy as np
@@ -324,6 +324,14 @@ class Scene(tuple):
 
     def _render(self, transform: Transform, mask_only: bool = False, viewport=None, linear_rgb: bool = False):
         kind, args = self
+        if _NODE_RUNS and kind != RENDER_GROUP and not mask_only and viewport is not None and STATE.leaf_memo is not None:
+            # Inside a top-level render, a node that is batch entries and nothing else -- the FILL under a FILTER, an OPACITY over a
+            # gradient fill, a CLIP of one path by another -- is a run of its own: a window of the document's shared batch, drawn
+            # with all the others, instead of a Path.fill / Path.mask with launches of its own (a GROUP cuts its children into runs
+            # itself, below).  `_collect_mask_jobs` routes the same way.
+            leaves = _leaves_memo(self, transform, linear_rgb)
+            if leaves is not None:
+                return _render_run(leaves, viewport, linear_rgb)
         if kind == RENDER_FILL:
             path, paint, fill_rule = args
             if mask_only:
@@ -435,6 +443,12 @@ def _collect_mask_jobs(scene: Scene, transform: Transform, mask_only: bool, line
     from .paint import needs_mask  # noqa: PLC0415
 
     kind, args = scene
+    if _NODE_RUNS and kind != RENDER_GROUP and not mask_only and runs is not None:
+        leaves = _leaves_memo(scene, transform, linear_rgb, store=True)   # (as Scene._render routes it)
+        if leaves is not None:
+            if leaves:
+                runs.append(leaves)
+            return
     if kind == RENDER_FILL:
         path, paint, rule = args
         if mask_only or needs_mask(paint):
@@ -489,15 +503,31 @@ MERGE_STATS = {"shared_batches": 0, "runs_sharing": 0, "runs_alone": 0}   # coun
 class _SharedBatch:
     """A batch several runs draw from."""
 
-    __slots__ = ("batch", "refs", "serial", "_bboxes", "_edges")
+    __slots__ = ("batch", "refs", "serial", "_bboxes", "_edges", "shifts", "vrows", "_view_boxes")
 
-    def __init__(self, batch, refs):
+    def __init__(self, batch, refs, shifts=None, vrows=None):
         self.batch, self.refs, self.serial, self._bboxes, self._edges = batch, refs, -1, None, None
+        self.shifts, self.vrows, self._view_boxes = shifts, vrows, None   # per leaf: the rows it was moved down by; the viewport's rows
 
     def bboxes(self):
         if self._bboxes is None:
             self._bboxes = self.batch.bboxes()
         return self._bboxes
+
+    def view_boxes(self):
+        """Every leaf's bbox in the viewport's own rows, clipped to them (the shared canvas is taller than the viewport): what
+        `_RunView.bboxes` hands out a slice of, computed for all runs at once."""
+        if self._view_boxes is None:
+            bb = self.bboxes().astype(np.int64)
+            r0 = bb[:, 0] - self.shifts
+            r1 = r0 + np.maximum(bb[:, 2], 0)
+            v0, v1 = self.vrows
+            c0, c1 = np.maximum(r0, v0), np.minimum(r1, v1)
+            out = bb.copy()
+            out[:, 0] = c0
+            out[:, 2] = np.where((bb[:, 2] > 0) & (c1 > c0), c1 - c0, 0)
+            self._view_boxes = out
+        return self._view_boxes
 
     def all_edges(self):
         if self._edges is None:
@@ -517,15 +547,7 @@ class _RunView:
 
     def bboxes(self):
         """The run's bboxes in the viewport's own rows, clipped to them (the shared canvas is taller than the viewport)."""
-        bb = self.shared.bboxes()[self.lo:self.hi].astype(np.int64)
-        r0 = bb[:, 0] - self.shift
-        r1 = r0 + np.maximum(bb[:, 2], 0)
-        v0, v1 = self.vrows
-        c0, c1 = np.maximum(r0, v0), np.minimum(r1, v1)
-        out = bb.copy()
-        out[:, 0] = c0
-        out[:, 2] = np.where((bb[:, 2] > 0) & (c1 > c0), c1 - c0, 0)
-        return out
+        return self.shared.view_boxes()[self.lo:self.hi]
 
     def all_edges(self):
         edges, edge_path = self.shared.all_edges()
@@ -617,7 +639,11 @@ def _merge_runs(todo, viewport):
         lo, hi = float(v0), float(v1)
         ok = _MERGE_RUNS and len(todo) > 1
         if ok:
-            ext = _row_extents(leaves)
+            if len(leaves) <= 6:   # (a run of a few leaves: the arrays cost more than the leaves)
+                exts = [_row_extent(leaf) for leaf in leaves]
+                ext = None if None in exts else (np.array([e[0] for e in exts]), np.array([e[1] for e in exts]))
+            else:
+                ext = _row_extents(leaves)
             if ext is None:
                 ok = False
             else:
@@ -625,7 +651,7 @@ def _merge_runs(todo, viewport):
                 # (a two-circle gradient asks "any pixel of the fill's LAYER with det < 0" (S:1627), and the layer is the bbox
                 #  clipped to the batch's viewport: such a fill shares only when it lies inside the viewport's rows anyway)
                 for i, leaf in enumerate(leaves):
-                    if leaf[6] is not None and leaf[6][0].kind == 3 and (e_lo[i] < v0 + 1 or e_hi[i] > v1 - 1):
+                    if leaf[6] is not None and _is_focal(leaf[6]) and (e_lo[i] < v0 + 1 or e_hi[i] > v1 - 1):
                         ok = False
                         break
                 lo, hi = min(lo, float(e_lo.min())), max(hi, float(e_hi.max()))
@@ -667,7 +693,7 @@ def _merge_runs(todo, viewport):
             batch = build_batch(merged, [0, int(viewport[1]), total, int(viewport[3])], row_shift=shifts)
         except Exception:  # noqa: BLE001  (the runs then plan for themselves, on demand)
             continue
-        shared = _SharedBatch(batch, len(spans))
+        shared = _SharedBatch(batch, len(spans), np.asarray(shifts, dtype=np.int64), (v0, v1))
         MERGE_STATS["shared_batches"] += 1
         MERGE_STATS["runs_sharing"] += len(spans)
         for key, leaves, lo_p, hi_p, shift in spans:
@@ -715,6 +741,8 @@ def _plan_runs(runs, fills, viewport, linear_rgb):
         fill_plans, fill_batches = {}, []
     try:
         _abi.Batch.plan_many(batches + fill_batches)
+        for b in batches:
+            _resolve_frames(b)
         geometry.finish_fill_plans(fill_plans)
     except Exception:  # noqa: BLE001  (one bad batch: let every run / fill plan for itself and report its own error)
         for b in batches + fill_batches:
@@ -778,12 +806,20 @@ def _gradient_leaf(path, paint, rule, transform: Transform, linear_rgb: bool, op
     stops than the device block carries.  Path.fill's gradient branch, S:1021-1047."""
     from .paint import _SPREAD  # noqa: PLC0415
 
-    if not _BATCH_GRADS or paint.bbox_units or not 1 <= len(paint.stops) <= 32:
+    if not _BATCH_GRADS or not 1 <= len(paint.stops) <= 32:
         return None
     if paint.linear_rgb is not None and bool(paint.linear_rgb) != bool(linear_rgb):
         return None
     if paint.spread not in _SPREAD:
         raise ValueError(f"invalid spread method: {paint.spread}")
+    if paint.bbox_units:
+        # objectBoundingBox units: the gradient's frame is the bounding box of the path's hull (S:1023-1027), known once the batch's
+        # plan has flattened the path (`_resolve_frames`: svgr_batch_get_extents, then the descriptions once more).  Only under a
+        # transform that keeps the axes apart is the hull's box in user space the box of its extreme device coordinates.
+        if not _BATCH_BBOX_GRADS or not _axes_apart(transform):
+            return None
+        mult = _ONES if opacity is None else _ONES * opacity
+        return _leaf(path, transform.m6(), _RULES[rule], mult, grad=(None, None, paint, transform, bool(linear_rgb)))
     # the ABI description of (this gradient, this transform) is a pure function of both: packed once (the struct is copied
     # by Batch.set_gradients, never written to)
     key = (id(paint), transform.key(), bool(linear_rgb))
@@ -797,6 +833,70 @@ def _gradient_leaf(path, paint, rule, transform: Transform, linear_rgb: bool, op
         _GRAD_ABI_MEMO[key] = (paint, g, keep)
     mult = _ONES if opacity is None else _ONES * opacity  # Layer.opacity over the leaf: image * opacity (S:174)
     return _leaf(path, transform.m6(), _RULES[rule], mult, grad=(g, keep, paint, transform, bool(linear_rgb)))
+
+
+_NODE_RUNS = __import__("os").environ.get("SVGR_NO_NODE_RUNS") is None  # (off: a batchable node outside a GROUP's children goes node by node)
+_BATCH_BBOX_GRADS = __import__("os").environ.get("SVGR_NO_BATCH_BBOX_GRADIENTS") is None  # (off: objectBoundingBox gradients go node by node)
+_AXES_MEMO: dict = {}
+
+
+def _axes_apart(transform: Transform) -> bool:
+    """The inverse of `transform` takes rows and columns to one user axis each (scales, translations, an x / y swap: every
+    entry it multiplies the other coordinate by is exactly zero).  Then `transform.invert(points)` is monotone per axis, rounding
+    included, and the hull's bounding box in user space (ConvexHull.bbox, S:2010-2016) is the box of the four corners of its
+    device-space extent."""
+    key = transform.key()
+    hit = _AXES_MEMO.get(key)
+    if hit is None:
+        inv = np.asarray(transform.invert.m, dtype=np.float64)
+        a, b, c, d = float(inv[0, 0]), float(inv[0, 1]), float(inv[1, 0]), float(inv[1, 1])
+        ok = all(math.isfinite(v) for v in (a, b, c, d, float(inv[0, 2]), float(inv[1, 2])))
+        hit = ok and ((b == 0.0 and c == 0.0 and a != 0.0 and d != 0.0) or (a == 0.0 and d == 0.0 and b != 0.0 and c != 0.0))
+        if len(_AXES_MEMO) > 8192:
+            _AXES_MEMO.clear()
+        _AXES_MEMO[key] = hit
+    return hit
+
+
+def _is_focal(grad) -> bool:
+    """A two-circle radial gradient (the description's kind 3; for a frame still pending, the paint says it)."""
+    if grad[0] is not None:
+        return grad[0].kind == 3
+    paint = grad[2]
+    return hasattr(paint, "fcenter") and not (paint.fcenter is None and paint.fradius is None)
+
+
+def _resolve_frames(batch) -> None:
+    """The objectBoundingBox gradients of a planned batch get their frames: hull.bbox_transform(transform) (S:1023-1027) from the
+    extent of the path's flattened points (svgr_batch_get_extents), the descriptions set once more (same assignment: the plan and
+    its geometry pass stay).  Between the plan and the batch's first render."""
+    fr = getattr(batch, "_frames", None)
+    if not fr:
+        return
+    batch._frames = None
+    path_grad, grads, pending = fr
+    ext = batch.extents()
+    keep = []
+    for gi, pi, paint, transform, lin, shift in pending:
+        r0, c0, r1, c1 = (float(v) for v in ext[pi])
+        if not all(math.isfinite(v) for v in (r0, c0, r1, c1)):
+            continue   # (no edge: nothing of the path is drawn)
+        if shift:      # (the run's rows inside a shared canvas: the frame is that of the document's own rows, moved like the path)
+            r0, r1 = r0 - shift, r1 - shift
+        pts = transform.invert(np.array([[r0, c0], [r0, c1], [r1, c0], [r1, c1]], dtype=np.float64))
+        min_x, min_y = pts.min(axis=0)
+        max_x, max_y = pts.max(axis=0)
+        w, h = max_x - min_x, max_y - min_y
+        frame = transform if (w <= 0 and h <= 0) else transform.translate(min_x, min_y).scale(w, h)   # ConvexHull.bbox_transform
+        g, k = paint.abi(frame.invert, lin)
+        if shift:
+            u = g.user_m6
+            u[2] -= u[0] * shift
+            u[5] -= u[3] * shift
+        grads[gi] = g
+        keep.append(k)
+    batch.set_gradients(path_grad, grads)
+    del keep
 
 
 def _new_group(opacity: float, clipped: bool):
@@ -966,7 +1066,7 @@ def build_batch(leaves, viewport, ctx=None, row_shift=None) -> "_abi.Batch":
     rules = np.fromiter((leaf[2] | (leaf[4] << 1) for leaf in leaves), dtype=np.uint8, count=n)  # SVGR_PATH_CLIP_SOURCE = 2, SVGR_PATH_CLIPPED = 4
     paints = np.concatenate([leaf[3] for leaf in leaves]).astype(np.float64, copy=False).reshape(n, 4) if n else np.zeros((0, 4))
     path_group, group_src, group_op, serial_to_gid = None, [], [], {}
-    path_grad, grads, keep_alive = None, [], []
+    path_grad, grads, keep_alive, pending = None, [], [], []
     if any(len(leaf) > 5 and leaf[5] is not None for leaf in leaves):
         path_group = []
         for i, leaf in enumerate(leaves):
@@ -987,8 +1087,19 @@ def build_batch(leaves, viewport, ctx=None, row_shift=None) -> "_abi.Batch":
             if grad is None:
                 path_grad.append(-1)
             else:
-                if row_shift is not None and row_shift[i]:
-                    grad = _shift_leaf(leaf, row_shift[i])[6]   # (the gradient's frame moves with the path)
+                shift = row_shift[i] if row_shift is not None else 0
+                if grad[0] is None:
+                    # (an objectBoundingBox frame: `_resolve_frames` fills it in behind the plan; until then a valid stand-in)
+                    _g0, _k0, paint, transform, lin = grad
+                    pkey = (id(paint), transform.key(), lin, "stand-in")
+                    hit = _GRAD_ABI_MEMO.get(pkey)
+                    if hit is None or hit[0] is not paint:
+                        g, keep = paint.abi(transform.invert, lin)
+                        _GRAD_ABI_MEMO[pkey] = hit = (paint, g, keep)
+                    pending.append((len(grads), i, paint, transform, lin, shift))
+                    grad = (hit[1], hit[2])
+                elif shift:
+                    grad = _shift_leaf(leaf, shift)[6]   # (the gradient's frame moves with the path)
                 path_grad.append(len(grads))
                 grads.append(grad[0])
                 keep_alive.append(grad[1])
@@ -998,6 +1109,8 @@ def build_batch(leaves, viewport, ctx=None, row_shift=None) -> "_abi.Batch":
         batch.set_groups(path_group, group_src, group_op)
     if grads:
         batch.set_gradients(path_grad, grads)  # (copies the descriptions to the device before it returns)
+        if pending:
+            batch._frames = (path_grad, grads, pending)
     del keep_alive
     return batch
 
@@ -1021,6 +1134,7 @@ def _render_run(leaves, viewport, linear_rgb):
             return None
         batch = build_batch(leaves, viewport, ctx)
         batch.plan()
+        _resolve_frames(batch)
         if retain is not None and rkey is not None:
             # (built on demand: kept as long as its key keeps coming back, _Retained.sweep_on_demand)
             pre = run_plans[rkey] = [leaves, batch, None, None, serial]
@@ -1061,6 +1175,12 @@ def _run_window(leaves, batch):
     in_hull = np.zeros(len(leaves), dtype=bool)
     if not len(leaves):
         return None, in_hull
+    if len(leaves) == 1 and leaves[0][4] == 0 and leaves[0][5] is None:   # (one plain leaf: its own bbox)
+        r0, c0, rows, cols = (int(v) for v in batch.bboxes()[0])
+        if rows <= 0 or cols <= 0:
+            return None, in_hull
+        in_hull[0] = True
+        return (r0, c0, rows, cols), in_hull
     painted, box, ok = _effective_boxes(leaves, batch.bboxes())
     win = None
     if ok.any():
@@ -1158,6 +1278,7 @@ def render_canvas(scene_or_leaves, transform: Transform | None, viewport, linear
     ctx = _abi.Context.get()
     batch = build_batch(leaves, viewport, ctx)
     st = batch.plan()
+    _resolve_frames(batch)
     rows, cols = int(viewport[2]), int(viewport[3])
     out = ctx.alloc(rows * cols * (32 if out_f64 else 16))
     batch.render(out, _abi.OUT_CANVAS_F64 if out_f64 else _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01 if clip01 else 0)

@@ -636,10 +636,14 @@ def test_gradient_fills_inside_the_batch_equal_the_per_node_route(S):
         assert np.abs(want.image).max() > 0.2
     bbox_grad = S.GradLinear(np.array([0.0, 0.0]), np.array([1.0, 0.0]), stops(2), None, "pad", True, None)
     own_space = S.GradLinear(np.array([0.0, 0.0]), np.array([100.0, 0.0]), stops(2), None, "pad", False, True)
-    for paint in (bbox_grad, own_space):   # these keep the per-node route (and still render)
+    # a colour space of the gradient's own keeps the per-node route, as does an objectBoundingBox gradient under a rotation (and
+    # both still render); under a transform that keeps the axes apart the latter is a batch entry (tests/test_gradient_blur.py)
+    for paint, tr_ in ((own_space, swap), (bbox_grad, swap.rotate(0.2))):
         node = S.Scene.group([S.Scene.fill(blob(100, 100, 60), paint), S.Scene.fill(blob(120, 100, 30), solid)])
-        assert sc._batchable_leaves(node, swap, False) is None
-        assert node.render(swap, viewport=[0, 0, 256, 256], linear_rgb=False) is not None
+        assert sc._batchable_leaves(node, tr_, False) is None
+        assert node.render(tr_, viewport=[0, 0, 256, 256], linear_rgb=False) is not None
+    node = S.Scene.group([S.Scene.fill(blob(100, 100, 60), bbox_grad), S.Scene.fill(blob(120, 100, 30), solid)])
+    assert sc._batchable_leaves(node, swap, False) is not None
 
 
 def test_render_window_equals_the_same_pixels_of_the_whole_canvas(S):

@@ -262,10 +262,11 @@ def test_gpu_runs_of_a_document_are_planned_together(monkeypatch):
     assert seen["hits"] == seen["planned"], seen            # every batch of the pre-pass was met by the walk
     assert seen["replanned"] == 0 or seen["runs"] > seen["hits"], seen
     assert seen["replanned"] == seen["runs"] - seen["hits"], seen   # only runs the pre-pass did not have plan for themselves
-    # the solid fills that go node by node (children of filter nodes ...) were planned in the same wait and all picked up
+    # the fills under filter nodes are runs of their own (round 5, `_NODE_RUNS`; before, the solid ones were planned in the same wait
+    # as single-path batches): planned with the others, all picked up, no node-by-node solid fill left
     from svgrasterize_amd import geometry as gm
 
-    assert seen["fills"] >= 5 and gm.STATE.fill_plans is None, seen
+    assert seen["fills"] == 0 and seen["planned"] >= 40 and gm.STATE.fill_plans is None, seen
     assert seen["single_plans"] <= 3, seen                          # (objectBoundingBox clips and the like plan on demand)
 
     monkeypatch.setattr(sm, "_plan_runs", lambda runs, fills, viewport, linear_rgb: ({}, {}))
@@ -343,6 +344,9 @@ def test_gpu_node_by_node_fills_sharing_one_batch_draw_what_their_own_batches_dr
         S.clear_render_cache()
         return out
 
+    from svgrasterize_amd import scene as sm
+
+    monkeypatch.setattr(sm, "_NODE_RUNS", False)   # (round 5 draws these fills as runs of the document's shared batch: the route under test is the one behind the switch)
     monkeypatch.setattr(gm, "_SHARE_FILLS", False)
     alone = draw()
     assert seen["views"] == 0
@@ -395,3 +399,89 @@ def test_gpu_run_windows_drawn_side_by_side_are_the_windows_drawn_one_by_one(mon
     for (o1, a), (o2, b) in zip(one_by_one, together):
         assert o1 == o2 and a.shape == b.shape
         assert float(np.abs(a - b).max(initial=0.0)) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_bounding_box_gradients_inside_the_batch_draw_what_they_draw_node_by_node(monkeypatch):
+    """objectBoundingBox gradients as batch entries (VERDICT r4 #5b): the frame comes from the extent of the path's flattened
+    points between the plan and the first render (svgr_batch_get_extents -> `_resolve_frames`), not from a hull fetched per
+    fill.  Same picture as the per-node route (Path.mask, hull.bbox_transform, svgr_gradient_fill, S:1021-1047) -- linear,
+    radial and two-circle gradients, pad / repeat / reflect, under a scale + x/y swap, with an opacity on top and inside a
+    clipped group.  icons.svg (its dump holds user-space gradients only) is drawn both ways as well, and with its 36 fills under
+    filter nodes as runs of the shared batch against the node-by-node route (`_NODE_RUNS`)."""
+    import svgrasterize_amd as S
+    from svgrasterize_amd import scenedump
+    from svgrasterize_amd import scene as sm
+
+    red, blue, green = np.array([1.0, 0.0, 0.0, 1.0]), np.array([0.0, 0.0, 1.0, 1.0]), np.array([0.0, 0.5, 0.0, 0.5])
+    stops = [(0.0, red), (0.4, green), (1.0, blue)]
+
+    def blob(cx, cy, r):
+        k = 0.5522847498 * r
+        return S.Path([[(S.PATH_CUBIC, [[cx + r, cy], [cx + r, cy + k], [cx + k, cy + r], [cx, cy + r]]),
+                        (S.PATH_CUBIC, [[cx, cy + r], [cx - k, cy + r], [cx - r, cy + k], [cx - r, cy]]),
+                        (S.PATH_CUBIC, [[cx - r, cy], [cx - r, cy - k], [cx - k, cy - r], [cx, cy - r]]),
+                        (S.PATH_CUBIC, [[cx, cy - r], [cx + k, cy - r], [cx + r, cy - k], [cx + r, cy]])]])
+
+    lin = S.GradLinear(np.array([0.0, 0.0]), np.array([1.0, 1.0]), stops, None, "pad", True, None)
+    lin_t = S.GradLinear(np.array([0.1, 0.0]), np.array([0.6, 0.2]), stops, S.Transform().rotate(0.4), "reflect", True, None)
+    rad = S.GradRadial(np.array([0.5, 0.5]), 0.5, None, None, stops, None, "repeat", True, None)
+    foc = S.GradRadial(np.array([0.5, 0.5]), 0.45, np.array([0.35, 0.4]), 0.05, stops, None, "pad", True, None)
+    user = S.GradLinear(np.array([10.0, 10.0]), np.array([90.0, 40.0]), stops, None, "pad", False, None)
+    fill = lambda p, paint: S.Scene.fill(p, paint)  # noqa: E731
+    grp = S.Scene.group([fill(blob(150, 60, 30), red), fill(blob(160, 70, 28), rad)])
+    scene = S.Scene.group([
+        fill(blob(40, 40, 30), lin), fill(blob(90, 50, 35), lin_t).opacity(0.6), fill(blob(60, 100, 38), rad), fill(blob(120, 110, 33), foc),
+        fill(blob(30, 120, 25), user), grp.clip(fill(blob(165, 65, 20), blue)), fill(blob(200, 100, 45), lin_t),   # (the last one hangs out of the viewport)
+    ])
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0).scale(2.5, 1.75)
+    vp = [0, 0, 300, 520]
+    resolved = {"n": 0}
+    orig = sm._resolve_frames
+
+    def resolve(batch):
+        if getattr(batch, "_frames", None):
+            resolved["n"] += len(batch._frames[2])
+        return orig(batch)
+
+    monkeypatch.setattr(sm, "_resolve_frames", resolve)
+
+    def draw(sc, t, view):
+        S.clear_render_cache()
+        layer, _hull = sc.render(t, viewport=view, linear_rgb=False)
+        return [int(v) for v in layer.offset], np.array(layer.image)
+
+    monkeypatch.setattr(sm, "_BATCH_BBOX_GRADS", False)
+    o1, a = draw(scene, tr, vp)
+    assert resolved["n"] == 0
+    monkeypatch.setattr(sm, "_BATCH_BBOX_GRADS", True)
+    o2, b = draw(scene, tr, vp)
+    assert resolved["n"] == 6, resolved
+    assert o1 == o2 and a.shape == b.shape and a.any()
+    assert float(np.abs(a - b).max()) <= 1e-11
+    # icons.svg, first and retained render
+    iscene, info, _z = scenedump.load_scene(os.path.join(GOLDEN, "scene_icons.npz"))
+    r = info["renders"][0]
+    hh, ww = r["size"]
+    itr = S.Transform().matrix(0, 1, 0, 1, 0, 0).scale(r["scale"])
+    monkeypatch.setattr(sm, "_BATCH_BBOX_GRADS", False)
+    o1, a = draw(iscene, itr, [0, 0, hh, ww])
+    n0 = resolved["n"]
+    monkeypatch.setattr(sm, "_BATCH_BBOX_GRADS", True)
+    o2, b = draw(iscene, itr, [0, 0, hh, ww])
+    assert resolved["n"] == n0   # (the dump's gradients are all in user space: nothing to resolve, nothing changed)
+    assert o1 == o2 and a.shape == b.shape
+    assert float(np.abs(a - b).max()) <= 1e-12
+    # ... and its fills under filter nodes (gradient and solid, some under an opacity) as runs of the shared batch against node by node
+    monkeypatch.setattr(sm, "_NODE_RUNS", False)
+    o3, c = draw(iscene, itr, [0, 0, hh, ww])
+    assert o3 == o2 and c.shape == b.shape
+    assert float(np.abs(c - b).max()) <= 1e-9   # (rows moved by whole bands inside the shared canvas)
+    monkeypatch.setattr(sm, "_NODE_RUNS", True)
+    S.set_render_cache(2)
+    try:
+        first = draw(iscene, itr, [0, 0, hh, ww])[1]
+        layer, _hull = iscene.render(itr, viewport=[0, 0, hh, ww], linear_rgb=False)   # (retained: the frames are the batch's)
+        assert float(np.abs(np.array(layer.image) - first).max()) <= 1e-12
+    finally:
+        S.set_render_cache(0)

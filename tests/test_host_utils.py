@@ -137,8 +137,12 @@ def test_batch_routing_of_scene_nodes_is_host_logic():
     assert [l[4] for l in faded] == [0, 0] and faded[0][5] is faded[1][5] and faded[0][5][1:] == (0.3, False)
     # what stays on the per-node route
     bbox_grad = S.GradLinear(np.array([0.0, 0.0]), np.array([1.0, 0.0]), [(0.0, red), (1.0, blue)], None, "pad", True, None)
-    for node in (fill(sq(0, 0, 4), bbox_grad),                                           # objectBoundingBox gradient
-                 S.Scene.group([grp.opacity(0.5), fill(sq(0, 0, 2), red)]).opacity(0.5),  # a group inside a group's opacity
+    # (an objectBoundingBox gradient is a batch entry whose frame is still to come -- under a transform that keeps the axes apart)
+    pending = sc._batchable_leaves(fill(sq(0, 0, 4), bbox_grad), tr, True)
+    assert len(pending) == 1 and pending[0][6][0] is None and pending[0][6][2] is bbox_grad
+    assert sc._batchable_leaves(fill(sq(0, 0, 4), bbox_grad), tr.rotate(0.3), True) is None
+    assert sc._axes_apart(tr) and sc._axes_apart(tr.scale(3.0, -0.5).translate(7, 9)) and not sc._axes_apart(tr.skew(0.1, 0.0))
+    for node in (S.Scene.group([grp.opacity(0.5), fill(sq(0, 0, 2), red)]).opacity(0.5),  # a group inside a group's opacity
                  grp.clip(S.Scene.group([fill(sq(0, 0, 2), red), fill(sq(1, 1, 2), red)])),  # a clip that is not one path
                  fill(sq(0, 0, 4), red).clip(fill(sq(0, 0, 2), red), bbox_units=True)):
         assert sc._batchable_leaves(node, tr, True) is None
