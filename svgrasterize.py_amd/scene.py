@@ -503,11 +503,37 @@ MERGE_STATS = {"shared_batches": 0, "runs_sharing": 0, "runs_alone": 0}   # coun
 class _SharedBatch:
     """A batch several runs draw from."""
 
-    __slots__ = ("batch", "refs", "serial", "_bboxes", "_edges", "shifts", "vrows", "_view_boxes")
+    __slots__ = ("batch", "refs", "serial", "_bboxes", "_edges", "shifts", "vrows", "_view_boxes", "leaves", "starts", "_windows")
 
-    def __init__(self, batch, refs, shifts=None, vrows=None):
+    def __init__(self, batch, refs, shifts=None, vrows=None, leaves=None, starts=None):
         self.batch, self.refs, self.serial, self._bboxes, self._edges = batch, refs, -1, None, None
         self.shifts, self.vrows, self._view_boxes = shifts, vrows, None   # per leaf: the rows it was moved down by; the viewport's rows
+        self.leaves, self.starts, self._windows = leaves, starts, None    # all the runs' leaves, the first leaf of every run
+
+    def run_windows(self):
+        """`_run_window` of every run at once: (first leaf of a run -> its window or None, hull membership of every leaf).  The runs
+        are independent stretches of one leaf list (a clip source stands in front of what it clips, inside its run), so the leaves'
+        effective boxes are one computation and a run's window the reduction of its stretch."""
+        if self._windows is None:
+            n = len(self.leaves)
+            painted, box, ok = _effective_boxes(self.leaves, self.view_boxes())
+            big = np.iinfo(np.int64).max
+            lo = np.full((n, 2), big, dtype=np.int64)
+            hi = np.full((n, 2), -big, dtype=np.int64)
+            idx = painted[ok]
+            lo[idx] = box[ok][:, :2]
+            hi[idx] = box[ok][:, 2:]
+            starts = np.asarray(self.starts, dtype=np.int64)
+            rlo = np.minimum.reduceat(lo, starts, axis=0)
+            rhi = np.maximum.reduceat(hi, starts, axis=0)
+            in_hull = np.zeros(n, dtype=bool)
+            in_hull[painted] = ok
+            wins = {}
+            for k, first in enumerate(self.starts):
+                r0, c0, r1, c1 = int(rlo[k, 0]), int(rlo[k, 1]), int(rhi[k, 0]), int(rhi[k, 1])
+                wins[first] = None if r0 == big else (r0, c0, r1 - r0, c1 - c0)
+            self._windows = (wins, in_hull)
+        return self._windows
 
     def bboxes(self):
         if self._bboxes is None:
@@ -693,7 +719,7 @@ def _merge_runs(todo, viewport):
             batch = build_batch(merged, [0, int(viewport[1]), total, int(viewport[3])], row_shift=shifts)
         except Exception:  # noqa: BLE001  (the runs then plan for themselves, on demand)
             continue
-        shared = _SharedBatch(batch, len(spans), np.asarray(shifts, dtype=np.int64), (v0, v1))
+        shared = _SharedBatch(batch, len(spans), np.asarray(shifts, dtype=np.int64), (v0, v1), merged, [sp[2] for sp in spans])
         MERGE_STATS["shared_batches"] += 1
         MERGE_STATS["runs_sharing"] += len(spans)
         for key, leaves, lo_p, hi_p, shift in spans:
@@ -1172,6 +1198,9 @@ def _render_run(leaves, viewport, linear_rgb):
 
 def _run_window(leaves, batch):
     """(window, hull membership) of a planned run: the union of its leaves' effective bboxes (None: nothing to draw)."""
+    if isinstance(batch, _RunView) and batch.shared.leaves is not None:   # (worked out for all runs of the shared batch together)
+        wins, hull_all = batch.shared.run_windows()
+        return wins[batch.lo], hull_all[batch.lo:batch.hi].copy()
     in_hull = np.zeros(len(leaves), dtype=bool)
     if not len(leaves):
         return None, in_hull
