@@ -299,3 +299,58 @@ def test_a_noted_conversion_is_the_conversion(S):
     view = src.convert(pre_alpha=False, linear_rgb=True)
     _ = view.image
     assert np.array_equal(src.image, img)
+
+
+@pytest.mark.parametrize("what", ["clips", "groups", "gradients"])
+def test_windows_in_one_launch_for_every_variant_and_both_canvas_types(S, what):
+    """The window table serves every variant of the tile kernel but the production one: batches with clip pairs, with isolated
+    groups, with gradient entries, float32 and float64 canvases -- each against the same windows drawn a launch each."""
+    from svgrasterize_amd import _abi
+    from svgrasterize_amd import scene as sm
+
+    ctx = S.Context.get()
+    rng = np.random.default_rng(21)
+
+    def blob(cx, cy, r):
+        k = 0.5522847498 * r
+        return S.Path([[(S.PATH_CUBIC, [[cx + r, cy], [cx + r, cy + k], [cx + k, cy + r], [cx, cy + r]]),
+                        (S.PATH_CUBIC, [[cx, cy + r], [cx - k, cy + r], [cx - r, cy + k], [cx - r, cy]]),
+                        (S.PATH_CUBIC, [[cx - r, cy], [cx - r, cy - k], [cx - k, cy - r], [cx, cy - r]]),
+                        (S.PATH_CUBIC, [[cx, cy - r], [cx + k, cy - r], [cx + r, cy - k], [cx + r, cy]])]])
+
+    def colour():
+        c = rng.random(4)
+        c[:3] *= c[3]
+        return c
+
+    nodes = []
+    for i in range(40):
+        cx, cy, r = rng.uniform(30, 370), rng.uniform(30, 370), rng.uniform(15, 60)
+        node = S.Scene.fill(blob(cx, cy, r), colour())
+        if what == "clips" and i % 3 == 0:
+            node = node.clip(S.Scene.fill(blob(cx + 10, cy - 5, r * 0.7), colour()))
+        if what == "groups" and i % 4 == 0:
+            node = S.Scene.group([node, S.Scene.fill(blob(cx + 12, cy + 9, r * 0.8), colour())]).opacity(0.6)
+        if what == "gradients" and i % 3 == 0:
+            grad = S.GradLinear(np.array([cx - r, cy]), np.array([cx + r, cy + r]), [(0.0, colour()), (1.0, colour())], None, "reflect", False, None)
+            node = S.Scene.fill(blob(cx, cy, r), grad)
+        nodes.append(node)
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+    leaves = sm._batchable_leaves(S.Scene.group(nodes), tr, True)
+    assert leaves is not None
+    batch = sm.build_batch(leaves, [0, 0, 400, 400], ctx)
+    batch.plan()
+    wins = [(0, 0, 400, 400), (13, 27, 200, 90), (100, 100, 64, 64), (350, 10, 50, 380), (1, 399, 398, 1), (200, 0, 16, 400)]
+    for kind, dt, px, tol in ((_abi.OUT_CANVAS_F64, np.float64, 32, 1e-12), (_abi.OUT_CANVAS_F32, np.float32, 16, 2.0 ** -22)):
+        one = []
+        for w in wins:
+            o = ctx.alloc(w[2] * w[3] * px)
+            batch.render(o, kind, 0, window=w)
+            one.append(o.download((w[2], w[3], 4), dt))
+        outs = [ctx.alloc(w[2] * w[3] * px) for w in wins]
+        batch.render_windows(outs, kind, wins)
+        for w, o, ref in zip(wins, outs, one):
+            got = o.download((w[2], w[3], 4), dt)
+            assert np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() <= tol, (what, kind, w)
+        assert any(r.any() for r in one)
+    batch.destroy()
