@@ -34,7 +34,7 @@ extern "C" {
  * 3: SVGR_RENDER_SAME_GEOMETRY, SVGR_OUT_FILLS_F64, svgr_layer_convert_to, svgr_layer_scale_to, svgr_batch_render_windows added
  *    (nothing changed or removed)
  * 4: svgr_hash_buffers added (nothing changed or removed)
- * 5: svgr_layer_compose_over, svgr_layer_convert_scale_to, svgr_layer_convolve_ops, svgr_batch_get_extents added (nothing changed
+ * 5: svgr_layer_compose_over / _in, svgr_layer_convert_scale_to, svgr_layer_convolve_ops, svgr_batch_get_extents added (nothing changed
  *    or removed) */
 #define SVGR_ABI_VERSION 5
 
@@ -267,6 +267,10 @@ int svgr_layer_convert_scale_to(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* sr
  * the svgr_layer_convert ops source i still needs, applied to its pixels as they are read (4-channel sources only).            */
 int svgr_layer_compose_over(svgr_ctx* ctx, svgr_buf* out, const int64_t* out_bbox, int64_t n, svgr_buf* const* srcs,
                             const int64_t* src_bboxes, const int32_t* channels, const uint32_t* ops);
+/* Layer.compose(layers, COMPOSE_IN) as ONE pass (canvas_merge_intersect, S:382-416): `out` (4ch, bbox = the intersection) =
+ * the first source cropped (1ch broadcast), then every other source times the alpha of what is there (S:290), in order; ops as above */
+int svgr_layer_compose_in(svgr_ctx* ctx, svgr_buf* out, const int64_t* out_bbox, int64_t n, svgr_buf* const* srcs,
+                          const int64_t* src_bboxes, const int32_t* channels, const uint32_t* ops);
 /* float64 -> float32 (optionally clipping to [0,1]) for presentation */
 int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst_f32, const svgr_buf* src_f64, int64_t n_values, int clip01);
 

@@ -115,6 +115,7 @@ _PROTOS = {
     "svgr_layer_convert_to": (C.c_int, [_P, _P, _P, C.c_int64, C.c_uint]),
     "svgr_layer_convert_scale_to": (C.c_int, [_P, _P, _P, C.c_int64, C.c_uint, C.c_double]),
     "svgr_layer_compose_over": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, _P]),
+    "svgr_layer_compose_in": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, _P]),
     "svgr_layer_to_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int]),
     "svgr_layer_to_rgba8": (C.c_int, [_P, _P, _P, C.c_int64]),
     "svgr_layer_blend": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),

@@ -3802,6 +3802,31 @@ __global__ __launch_bounds__(256) void k_layer_compose_over(double* __restrict__
     }
     ((double4*)out)[i] = make_double4(d[0], d[1], d[2], d[3]);
 }
+// Layer.compose(layers, IN) in one launch (canvas_merge_intersect, S:382-416 + S:290): the output is the intersection of the layers'
+// boxes; the first layer is cropped to it (a single channel broadcast), every other one multiplied by the alpha of what is there --
+// out = src * out_alpha, in the layers' order --, each source converted as it is read.
+__global__ __launch_bounds__(256) void k_layer_compose_in(double* __restrict__ out, int or0, int oc0, int orows, int ocols, const OverTable t) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)orows * ocols) return;
+    const int R = (int)(i / ocols) + or0, C = (int)(i % ocols) + oc0;
+    double d[4] = {0.0, 0.0, 0.0, 0.0};
+    if (t.accumulate) { const double4 v = ((const double4*)out)[i]; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+    for (int k = 0; k < t.n; ++k) {
+        const int r = R - t.s[k].r0, c = C - t.s[k].c0;
+        if (r < 0 || r >= t.s[k].rows || c < 0 || c >= t.s[k].cols) continue;   // (the first: stays zero, svgr_layer_crop4; the others: untouched, svgr_layer_in)
+        double v[4];
+        if (t.s[k].ch == 4) {
+            const double4 q = ((const double4*)t.s[k].p)[(size_t)r * t.s[k].cols + c];
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            convert_px(v, t.s[k].ops);
+        } else {
+            v[0] = v[1] = v[2] = v[3] = t.s[k].p[(size_t)r * t.s[k].cols + c];
+        }
+        if (k == 0 && !t.accumulate) { d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
+        else { const double da = d[3]; d[0] = v[0] * da; d[1] = v[1] * da; d[2] = v[2] * da; d[3] = v[3] * da; }
+    }
+    ((double4*)out)[i] = make_double4(d[0], d[1], d[2], d[3]);
+}
 
 __global__ void k_to_f32(float* __restrict__ dst, const double* __restrict__ src, size_t n, int clip01) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -6091,9 +6116,19 @@ int svgr_layer_convert_scale_to(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* sr
     return 0;
 }
 
+static int layer_compose_many(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, int64_t n, svgr_buf* const* srcs, const int64_t* sbs,
+                              const int32_t* chs, const uint32_t* ops, bool in_mode);
 int svgr_layer_compose_over(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, int64_t n, svgr_buf* const* srcs, const int64_t* sbs,
                             const int32_t* chs, const uint32_t* ops) {
-    if (!ctx || !out || !bbox_ok(ob) || n <= 0 || !srcs || !sbs || !chs) return fail(SVGR_E_INVALID, "svgr_layer_compose_over: bad arguments");
+    return layer_compose_many(ctx, out, ob, n, srcs, sbs, chs, ops, false);
+}
+int svgr_layer_compose_in(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, int64_t n, svgr_buf* const* srcs, const int64_t* sbs,
+                          const int32_t* chs, const uint32_t* ops) {
+    return layer_compose_many(ctx, out, ob, n, srcs, sbs, chs, ops, true);
+}
+static int layer_compose_many(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, int64_t n, svgr_buf* const* srcs, const int64_t* sbs,
+                              const int32_t* chs, const uint32_t* ops, bool in_mode) {
+    if (!ctx || !out || !bbox_ok(ob) || n <= 0 || !srcs || !sbs || !chs) return fail(SVGR_E_INVALID, "svgr_layer_compose_over / _in: bad arguments");
     const size_t n_out = (size_t)ob[2] * ob[3];
     if (out->bytes < n_out * 32) return fail(SVGR_E_INVALID, "svgr_layer_compose_over: output buffer too small");
     for (int64_t i = 0; i < n; ++i) {
@@ -6117,8 +6152,12 @@ int svgr_layer_compose_over(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, int
             o.r0 = (int)sb[0]; o.c0 = (int)sb[1]; o.rows = (int)sb[2]; o.cols = (int)sb[3];
             o.ch = chs[at + k]; o.ops = ops ? ops[at + k] : 0u;
         }
-        hipLaunchKernelGGL(k_layer_compose_over, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
-                           (int)ob[3], t);
+        if (in_mode)
+            hipLaunchKernelGGL(k_layer_compose_in, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
+                               (int)ob[3], t);
+        else
+            hipLaunchKernelGGL(k_layer_compose_over, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
+                               (int)ob[3], t);
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -350,15 +350,14 @@ class Layer:
             return None
         shape = (r1 - r0, c1 - c0, 4)
         out = ctx.alloc(shape[0] * shape[1] * 32)
-        obb = _bbox_arr((r0, c0), shape)
-        first = conv[0]
-        src = first._device()  # keep the (possibly temporary) buffer referenced while the kernel is enqueued
-        _abi._check(lib.svgr_layer_crop4(ctx.handle, out.handle, obb, src.handle,
-                                         _bbox_arr(first.offset, first._shape), first.channels))
-        for l in conv[1:]:
-            src = l._device()
-            _abi._check(lib.svgr_layer_in(ctx.handle, out.handle, obb, src.handle, _bbox_arr(l.offset, l._shape),
-                                          l.channels))
+        # one pass over the intersection: the first layer cropped, the others multiplied in, each converted as it is read
+        n = len(conv)
+        srcs = [l._dev if l._host is None else l._device() for l in conv]   # (uploads of host-resident layers stay referenced)
+        handles = (_abi._P * n)(*[b.handle for b in srcs])
+        bbs = (C.c_int64 * (4 * n))(*[int(v) for l in conv for v in (l.offset[0], l.offset[1], l._shape[0], l._shape[1])])
+        chs = (C.c_int32 * n)(*[l.channels for l in conv])
+        ops = (C.c_uint32 * n)(*[l._ops if l._host is None else 0 for l in conv])
+        _abi._check(lib.svgr_layer_compose_in(ctx.handle, out.handle, _bbox_arr((r0, c0), shape), n, handles, bbs, chs, ops))
         offset = (max(l.x for l in conv), max(l.y for l in conv))
         return Layer._from_device(out, shape, offset, True, linear_rgb)
 

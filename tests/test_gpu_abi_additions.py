@@ -354,3 +354,52 @@ def test_windows_in_one_launch_for_every_variant_and_both_canvas_types(S, what):
             assert np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() <= tol, (what, kind, w)
         assert any(r.any() for r in one)
     batch.destroy()
+
+
+def test_compose_in_in_one_pass_is_crop_then_in(S):
+    """svgr_layer_compose_in = convert each source, svgr_layer_crop4 of the first, svgr_layer_in of the others: the same bits
+    (a 1-channel mask first -- the clip route --, 4-channel layers, sources that still need a conversion, 30 layers)."""
+    import ctypes as C
+
+    from svgrasterize_amd import _abi
+
+    ctx = S.Context.get()
+    rng = np.random.default_rng(31)
+    for n, first_ch in ((2, 1), (2, 4), (3, 1), (30, 4)):
+        specs = []
+        for i in range(n):
+            rows, cols = int(rng.integers(40, 80)), int(rng.integers(40, 90))
+            r0, c0 = int(rng.integers(-10, 10)), int(rng.integers(-10, 10))
+            ch = first_ch if i == 0 else (1 if i % 7 == 5 else 4)
+            ops = 0 if ch == 1 else int(rng.choice([0, 8, 1 | 2 | 8, 4 | 8]))
+            specs.append((_rand_layer(rng, rows, cols, ch), (r0, c0, rows, cols), ch, ops))
+        u0 = max(s[1][0] for s in specs); v0 = max(s[1][1] for s in specs)
+        u1 = min(s[1][0] + s[1][2] for s in specs); v1 = min(s[1][1] + s[1][3] for s in specs)
+        assert u1 > u0 and v1 > v0
+        shape = (u1 - u0, v1 - v0, 4)
+        obb = _bb(u0, v0, shape[0], shape[1])
+        ref = ctx.alloc(shape[0] * shape[1] * 32)
+        for i, (img, bb, ch, ops) in enumerate(specs):
+            b = ctx.from_host(img)
+            if ops:
+                _abi._check(ctx.lib.svgr_layer_convert(ctx.handle, b.handle, bb[2] * bb[3], ops))
+            if i == 0:
+                _abi._check(ctx.lib.svgr_layer_crop4(ctx.handle, ref.handle, obb, b.handle, _bb(*bb), ch))
+            else:
+                _abi._check(ctx.lib.svgr_layer_in(ctx.handle, ref.handle, obb, b.handle, _bb(*bb), ch))
+        out = ctx.alloc(shape[0] * shape[1] * 32)
+        out.upload(np.full(shape, np.nan))
+        srcs = [ctx.from_host(s[0]) for s in specs]
+        _abi._check(ctx.lib.svgr_layer_compose_in(ctx.handle, out.handle, obb, n, (_abi._P * n)(*[b.handle for b in srcs]),
+                                                  (C.c_int64 * (4 * n))(*[v for s in specs for v in s[1]]), (C.c_int32 * n)(*[s[2] for s in specs]),
+                                                  (C.c_uint32 * n)(*[s[3] for s in specs])))
+        assert np.array_equal(out.download(shape, np.float64), ref.download(shape, np.float64)), (n, first_ch)
+    # through Layer.compose: a mask and a device layer with a noted conversion
+    mask = S.Layer(rng.random((50, 60, 1)), (2, 3), True, True)
+    img = _rand_layer(rng, 55, 58)
+    dev = S.Layer._from_device(ctx.from_host(img), img.shape, (0, 0), True, False).convert(pre_alpha=False, linear_rgb=True)
+    eager = ctx.from_host(img)
+    _abi._check(ctx.lib.svgr_layer_convert(ctx.handle, eager.handle, 55 * 58, 1 | 2))
+    got = S.Layer.compose([mask, dev], S.COMPOSE_IN, linear_rgb=True)
+    want = S.Layer.compose([mask, S.Layer(eager.download(img.shape, np.float64), (0, 0), False, True)], S.COMPOSE_IN, linear_rgb=True)
+    assert got.offset == want.offset and np.array_equal(got.image, want.image)
