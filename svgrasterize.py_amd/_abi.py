@@ -236,9 +236,14 @@ class Context:
 
 
 class DeviceBuffer:
+    # (freed by `__del__`, not by a weakref.finalize: a document's render makes and drops 150 of these, and a finalizer object
+    #  apiece was 0.3 ms of it.  svgr_buf_free does not touch the context -- the block goes back to the library's pool, which
+    #  outlives every context --, so the order of the interpreter's teardown does not matter)
+    __slots__ = ("ctx", "handle", "nbytes", "_free", "_parent", "__weakref__")   # (`_parent`: the buffer a view made by `wrap` lives in)
+
     def __init__(self, ctx: Context, handle, nbytes: int):
         self.ctx, self.handle, self.nbytes = ctx, handle, nbytes
-        self._fin = weakref.finalize(self, ctx.lib.svgr_buf_free, ctx.handle, handle)
+        self._free = ctx.lib.svgr_buf_free
 
     @property
     def ptr(self) -> int:
@@ -257,7 +262,15 @@ class DeviceBuffer:
         return out
 
     def free(self):
-        self._fin()
+        h = self.handle
+        if h is not None:
+            self.handle = None
+            try:
+                self._free(None, h)
+            except Exception:  # noqa: BLE001  (interpreter teardown)
+                pass
+
+    __del__ = free
 
 
 def _i64x4(v):

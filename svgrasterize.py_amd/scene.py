@@ -322,9 +322,10 @@ class Scene(tuple):
             if gc_paused:
                 gc.enable()
 
-    def _render(self, transform: Transform, mask_only: bool = False, viewport=None, linear_rgb: bool = False):
+    def _render(self, transform: Transform, mask_only: bool = False, viewport=None, linear_rgb: bool = False, _asked: bool = False):
         kind, args = self
-        if _NODE_RUNS and kind != RENDER_GROUP and not mask_only and viewport is not None and STATE.leaf_memo is not None:
+        # (`_asked`: the caller -- a GROUP's loop -- has asked `_leaves_memo` about this node already: it is not batch entries)
+        if _NODE_RUNS and not _asked and kind != RENDER_GROUP and not mask_only and viewport is not None and STATE.leaf_memo is not None:
             # Inside a top-level render, a node that is batch entries and nothing else -- the FILL under a FILTER, an OPACITY over a
             # gradient fill, a CLIP of one path by another -- is a run of its own: a window of the document's shared batch, drawn
             # with all the others, instead of a Path.fill / Path.mask with launches of its own (a GROUP cuts its children into runs
@@ -364,7 +365,7 @@ class Scene(tuple):
                     run.extend(leaves)
                     continue
                 flush()
-                res = child._render(transform, mask_only, viewport, linear_rgb)
+                res = child._render(transform, mask_only, viewport, linear_rgb, not mask_only)
                 if res is None:
                     continue
                 layers.append(res[0])
