@@ -787,7 +787,8 @@ def _leaves_memo(child: Scene, transform: Transform, linear_rgb: bool, store: bo
     key = (id(child), transform.key(), linear_rgb)
     if key in memo:
         return memo[key]
-    res = _batchable_leaves(child, transform, linear_rgb)
+    # (only GROUP nodes have a memo of their own in front of the analysis: `_batchable_leaves`)
+    res = _batchable_leaves(child, transform, linear_rgb) if child[0] == RENDER_GROUP else _batchable_leaves_(child, transform, linear_rgb)
     if store:
         memo[key] = res
     return res
@@ -998,7 +999,7 @@ def _batchable_leaves_(scene: Scene, transform: Transform, linear_rgb: bool, opa
         # CLIP whose target and clip are single paths: two consecutive batch entries, the clip path as a
         # coverage-only "clip source" and the fill multiplied by it (Layer.compose([mask, image], IN), S:698-715).
         # (A group under a clip is NOT the same as clipping each child: (A over B)*c != (A*c) over (B*c).)
-        target = _batchable_leaves(args[0], transform, linear_rgb)
+        target = _batchable_leaves_(args[0], transform, linear_rgb) if args[0][0] == RENDER_FILL else _batchable_leaves(args[0], transform, linear_rgb)
         clip_leaf = _single_mask_leaf(args[1], transform)
         if target is None or clip_leaf is None or not target:
             return None
