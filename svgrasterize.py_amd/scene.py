@@ -28,6 +28,7 @@ from . import _abi
 from ._state import STATE, next_serial
 from .geometry import ConvexHull, Path, Transform, solid_paint, _RULES, FLATNESS
 from .layer import COMPOSE_IN, COMPOSE_OVER, Layer
+from .paint import _SPREAD, is_gradient, needs_mask   # (paint.py imports nothing of this module)
 
 RENDER_FILL, RENDER_STROKE, RENDER_GROUP, RENDER_OPACITY = 0, 1, 2, 3
 RENDER_CLIP, RENDER_MASK, RENDER_TRANSFORM, RENDER_FILTER = 4, 5, 6, 7
@@ -441,8 +442,6 @@ def _collect_mask_jobs(scene: Scene, transform: Transform, mask_only: bool, line
     ``mask_only`` (clip subtrees) and gradient-filled leaves.  Mirrors the routing of `_render`; a wrong guess only
     costs an unused mask or an on-demand one.  `runs` (a list) also receives every run of batchable leaves a GROUP will
     flush, in the order of the walk; `fills` the solid fills that go node by node: (path, transform, rule, paint)."""
-    from .paint import needs_mask  # noqa: PLC0415
-
     kind, args = scene
     if _NODE_RUNS and kind != RENDER_GROUP and not mask_only and runs is not None:
         leaves = _leaves_memo(scene, transform, linear_rgb, store=True)   # (as Scene._render routes it)
@@ -832,7 +831,6 @@ def _gradient_leaf(path, paint, rule, transform: Transform, linear_rgb: bool, op
     """The batch entry of a gradient-filled path, or None when the fill has to go node by node: objectBoundingBox units
     (the frame comes from the path's hull), a colour space of its own (the fill layer is converted when composed), more
     stops than the device block carries.  Path.fill's gradient branch, S:1021-1047."""
-    from .paint import _SPREAD  # noqa: PLC0415
 
     if not _BATCH_GRADS or not 1 <= len(paint.stops) <= 32:
         return None
@@ -970,8 +968,6 @@ def _batchable_leaves_(scene: Scene, transform: Transform, linear_rgb: bool, opa
         if rule not in _RULES:
             raise ValueError(f"Invalid fill rule: {rule}")
         if not (isinstance(paint, np.ndarray) and paint.shape == (4,)):
-            from .paint import is_gradient  # noqa: PLC0415
-
             if not is_gradient(paint):
                 return None
             leaf = _gradient_leaf(path, paint, rule, transform, linear_rgb, opacity)
@@ -999,8 +995,17 @@ def _batchable_leaves_(scene: Scene, transform: Transform, linear_rgb: bool, opa
         # CLIP whose target and clip are single paths: two consecutive batch entries, the clip path as a
         # coverage-only "clip source" and the fill multiplied by it (Layer.compose([mask, image], IN), S:698-715).
         # (A group under a clip is NOT the same as clipping each child: (A over B)*c != (A*c) over (B*c).)
-        target = _batchable_leaves_(args[0], transform, linear_rgb) if args[0][0] == RENDER_FILL else _batchable_leaves(args[0], transform, linear_rgb)
-        clip_leaf = _single_mask_leaf(args[1], transform)
+        tgt, src = args[0], args[1]
+        if tgt[0] == RENDER_FILL and src[0] == RENDER_FILL:
+            # (a solid fill clipped by one path, both right here -- material-design's 935 icons --: the two entries made in
+            #  this frame, not in three more; what they are is what the general route below makes)
+            path, paint, rule = tgt[1]
+            spath, _spaint, srule = src[1]
+            if type(paint) is np.ndarray and paint.shape == (4,) and rule in _RULES and srule in _RULES:
+                m6 = transform.m6()
+                return [(spath, m6, _RULES[srule], _ZERO4, 1, None, None), (path, m6, _RULES[rule], solid_paint(paint, linear_rgb), 2, None, None)]
+        target = _batchable_leaves_(tgt, transform, linear_rgb) if tgt[0] == RENDER_FILL else _batchable_leaves(tgt, transform, linear_rgb)
+        clip_leaf = _single_mask_leaf(src, transform)
         if target is None or clip_leaf is None or not target:
             return None
         if len(target) == 1:
@@ -1018,7 +1023,8 @@ def _batchable_leaves_(scene: Scene, transform: Transform, linear_rgb: bool, opa
     if kind == RENDER_GROUP and opacity is None:
         out = []
         for child in args:
-            sub = _batchable_leaves(child, transform, linear_rgb)
+            # (only GROUP nodes have a memo in front of the analysis)
+            sub = _batchable_leaves(child, transform, linear_rgb) if child[0] == RENDER_GROUP else _batchable_leaves_(child, transform, linear_rgb)
             if sub is None:
                 return None
             out.extend(sub)
