@@ -586,6 +586,11 @@ __global__ __launch_bounds__(256) void k_seg_select(const int* __restrict__ seg_
 #ifndef SVGR_FL_SUB
 #define SVGR_FL_SUB 5
 #endif
+#ifndef SVGR_FL_TREE
+#define SVGR_FL_TREE 0      // 1: the top levels of a workgroup's segments packed into its first waves, every node split once -- built,
+                            // bit-identical, and SLOWER (44.5 against 28.8 us in one sweep4.sh call: five barriered levels, most of
+                            // them one wave's work, and 33 KB of LDS per workgroup); 0: every lane walks its own ancestors
+#endif
 constexpr int FL_SUB = SVGR_FL_SUB;       // 32 lanes per segment: the longest lane bounds the kernel, so cut subtrees small
 constexpr int FL_BLOCK = 256;     // (the waves are independent up to the last step: the segments of a workgroup fold their extents per path)
 // PLACED (with EMIT): the pass stores the edges at the places the plan's counting pass left PER LANE (`lane_off`: a lane's first
@@ -634,6 +639,85 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
         bb = bb > n_bands - 1 ? n_bands - 1 : bb;
         seg_ok = ba <= bb && owns_any(own, ba, bb);
     }
+#if SVGR_FL_TREE
+    // The top SUB levels of the workgroup's segments, every node ONCE ("shared levels").  A lane per leaf repeats its
+    // ancestors -- 2^SUB lanes x SUB levels for 2^SUB - 1 distinct nodes -- and a SIMD pays for an instruction whatever its lanes
+    // hold, so nothing is saved unless the nodes of a level are PACKED: level l of the workgroup's NSEG segments is NSEG << l
+    // nodes, handled by the first NSEG << l threads (one wave up to level 3), handed down through LDS -- the left child to slot
+    // 2 t, the right to 2 t + 1, which at level SUB is the lane the leaf-per-lane form gives the node to (path bits MSB first).
+    // A node that is flat stops: it travels down as its own left-most descendant (state 1) and arrives at the lane whose
+    // remaining bits are 0, as before.  Same splits of the same numbers: the same edges, bit for bit.
+    {
+        constexpr int NSEG_ = FL_BLOCK >> SUB;
+        __shared__ double s_nd[2][FL_BLOCK][8];
+        __shared__ unsigned char s_st[2][FL_BLOCK];
+        const int tid_ = (int)threadIdx.x;
+        double nd[8];
+        unsigned char st = 0;
+        if (tid_ < NSEG_) {   // level 0: this thread's segment is the workgroup's tid_-th (not the one its lane belongs to)
+            const int item_t = blockIdx.x * NSEG_ + tid_;
+            const int seg_t = seg_list ? (item_t < n_list ? seg_list[item_t] : n_segs) : item_t;
+            bool ok_t = seg_t < n_segs;
+            int p_t = 0;
+            if (ok_t) p_t = seg_path[seg_t];
+            if (ok_t && prow) {
+                const int lo = UNION_BIAS - (int)prow[2 * (size_t)p_t], hi = (int)prow[2 * (size_t)p_t + 1] - UNION_BIAS;
+                int ba = (lo - 2 - vr0) / TR, bb = (hi + 2 - vr0) / TR;
+                ba = lo - 2 - vr0 < 0 ? 0 : ba;
+                bb = bb > n_bands - 1 ? n_bands - 1 : bb;
+                ok_t = ba <= bb && owns_any(own, ba, bb);
+            }
+            if (ok_t && kind[seg_t] != SVGR_SEG_LINE) {
+                load_seg_points(segs, seg_t, path_m6 + 6 * (size_t)p_t, 4, nd);
+                st = 2;
+            }
+        }
+        int cur = 0;
+#pragma unroll
+        for (int l = 0; l < SUB; ++l) {
+            if (tid_ < (NSEG_ << l)) {
+                if (l > 0) {
+                    st = s_st[cur][tid_];
+                    if (st) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) nd[q] = s_nd[cur][tid_][q];
+                    }
+                }
+                unsigned char sl = 0, sr = 0;
+                if (st == 2 && !(cubic_flatness(nd) < thr)) {
+                    double rt[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rt[q] = nd[q];
+                    cubic_left_inplace(nd);
+                    cubic_right_inplace(rt);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { s_nd[cur ^ 1][2 * tid_][q] = nd[q]; s_nd[cur ^ 1][2 * tid_ + 1][q] = rt[q]; }
+                    sl = sr = 2;
+                } else if (st) {   // flat here, or flat further up: one edge, carried by the left-most descendant
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) s_nd[cur ^ 1][2 * tid_][q] = nd[q];
+                    sl = 1;
+                }
+                s_st[cur ^ 1][2 * tid_] = sl;
+                s_st[cur ^ 1][2 * tid_ + 1] = sr;
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+        const unsigned char fin = s_st[cur][tid_];
+        if (seg_ok && fin) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) node[q] = s_nd[cur][tid_][q];
+            mode = fin;   // (2: the subtree under this depth-SUB node; 1: the edge node[0..1] -> node[6..7])
+        }
+        if (seg_ok && kind[seg] == SVGR_SEG_LINE && sub == 0) {
+            double c[4];
+            load_seg_points(segs, seg, path_m6 + 6 * (size_t)p, 2, c);
+            node[0] = c[0]; node[1] = c[1]; node[6] = c[2]; node[7] = c[3];
+            mode = 1;
+        }
+    }
+#else
     if (seg_ok) {
         const double* m6 = path_m6 + 6 * (size_t)p;
         if (kind[seg] == SVGR_SEG_LINE) {
@@ -655,6 +739,7 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
             }
         }
     }
+#endif
     // Multi-GPU: a rank needs the exact bbox of every path it keeps (so the first traversal always runs and
     // tracks min/max over ALL segments of such a path), but it only stores the edges of segments that can
     // reach one of its own bands (the curve stays inside the row range of its control points; +-1 row of slack).
