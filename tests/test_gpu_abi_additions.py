@@ -403,3 +403,32 @@ def test_compose_in_in_one_pass_is_crop_then_in(S):
     got = S.Layer.compose([mask, dev], S.COMPOSE_IN, linear_rgb=True)
     want = S.Layer.compose([mask, S.Layer(eager.download(img.shape, np.float64), (0, 0), False, True)], S.COMPOSE_IN, linear_rgb=True)
     assert got.offset == want.offset and np.array_equal(got.image, want.image)
+
+
+def test_extents_are_the_bounds_of_all_flattened_points(S):
+    """svgr_batch_get_extents: per path the exact min / max of every flattened point, whatever the viewport clips -- the numbers
+    ConvexHull(lines).bbox is made from (S:993, S:2010-2016) -- against the unculled edge list (svgr_batch_all_edges); only between
+    the plan and the first render."""
+    from svgrasterize_amd import _abi, synth
+
+    sc = synth.make_scene(512, 96)
+    ctx = S.Context.get()
+    for vp in ([0, 0, 512, 512], [100, 60, 200, 300]):   # (the second viewport cuts most paths)
+        batch = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"], viewport=vp)
+        batch.plan()
+        ext = batch.extents()
+        edges, edge_path = batch.all_edges()
+        pts = edges.reshape(-1, 2, 2)
+        for p in range(batch.n_paths):
+            mine = pts[edge_path == p].reshape(-1, 2)
+            if len(mine) == 0:
+                assert np.isinf(ext[p]).all()
+                continue
+            want = np.array([mine[:, 0].min(), mine[:, 1].min(), mine[:, 0].max(), mine[:, 1].max()])
+            assert np.array_equal(ext[p], want), p
+        batch.plan()   # (all_edges left the counter arena dirty: plan again for a render)
+        out = ctx.alloc(vp[2] * vp[3] * 32)
+        batch.render(out, _abi.OUT_CANVAS_F64)
+        with pytest.raises(_abi.SvgrError):
+            batch.extents()   # (the keys are the plan's pass's: gone with the first render)
+        batch.destroy()
