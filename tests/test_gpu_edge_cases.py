@@ -643,7 +643,14 @@ def test_gradient_fills_inside_the_batch_equal_the_per_node_route(S):
         assert sc._batchable_leaves(node, tr_, False) is None
         assert node.render(tr_, viewport=[0, 0, 256, 256], linear_rgb=False) is not None
     node = S.Scene.group([S.Scene.fill(blob(100, 100, 60), bbox_grad), S.Scene.fill(blob(120, 100, 30), solid)])
-    assert sc._batchable_leaves(node, swap, False) is not None
+    old_bbox = sc._BATCH_BBOX_GRADS
+    try:
+        sc._BATCH_BBOX_GRADS = True    # (whatever the environment's switch says)
+        assert sc._batchable_leaves(node, swap, False) is not None
+        sc._BATCH_BBOX_GRADS = False
+        assert sc._batchable_leaves(node, swap, False) is None
+    finally:
+        sc._BATCH_BBOX_GRADS = old_bbox
 
 
 def test_render_window_equals_the_same_pixels_of_the_whole_canvas(S):

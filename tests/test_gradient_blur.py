@@ -256,6 +256,7 @@ def test_gpu_runs_of_a_document_are_planned_together(monkeypatch):
     monkeypatch.setattr(sm, "_plan_runs", plan_runs)
     monkeypatch.setattr(sm, "_render_run", render_run)
     monkeypatch.setattr(_abi.Batch, "plan", plan)
+    monkeypatch.setattr(sm, "_NODE_RUNS", True)   # (whatever the environment's switches say: the counts below are this route's)
     layer, _ = scene.render(tr, viewport=[0, 0, hh, ww], linear_rgb=False)
     together = layer.to_canvas_f32(hh, ww)
     assert seen["planned"] >= 10, seen                      # (icons.svg: the 37 filter nodes cut the paint order into runs)
