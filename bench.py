@@ -406,7 +406,7 @@ def contract_counts(got32, ref64):
 
 def launch_ranks(n, argv):
     """`bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): this process -- which has made no GPU
-    call and never makes one -- starts the N ranks itself, one fresh child per GPU with RANK / LOCAL_RANK / WORLD_SIZE /
+    kernel launch, allocation or context (counting the devices is the one runtime call it makes) and never re-execs -- starts the N ranks itself, one fresh child per GPU with RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT set exactly as `torch.distributed.run --nnodes=1 --nproc-per-node N` would, relays rank 0's one
     JSON line, and exits non-zero if any child does.  It refuses instead of printing a one-GPU line under `"n_gpus": 1`
     when the box does not have N devices (unless the run is the one-GPU rehearsal: SVGR_BENCH_DEVICE + SVGR_BENCH_BACKEND=gloo)."""
@@ -434,14 +434,40 @@ def launch_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # rank 0's stdout is drained on a thread while ALL children are polled: a rank that dies during start-up must not leave the
+    # others sitting in init_process_group or a barrier until torch's own timeout -- on the first non-zero exit the rest are
+    # terminated and the launcher fails at once
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    failed = False
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if not failed and any(c not in (None, 0) for c in codes):
+            failed = True
+            deadline = time.monotonic() + 10.0
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()   # (exactly the children this launcher started)
+        if failed and time.monotonic() > deadline:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.kill()
+        time.sleep(0.05)
+    reader.join(timeout=10.0)
+    out0 = chunks[0] if chunks else ""
     lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
     if any(codes):
         sys.stderr.write(f"[bench] rank exit codes {codes}\n")
         for ln in lines:
             sys.stderr.write(ln + "\n")
-        raise SystemExit(next(c for c in codes if c) if all(isinstance(c, int) for c in codes) else 1)
+        # (the code of the rank that failed by itself; a child this launcher terminated reports a negative one)
+        raise SystemExit(next((c for c in codes if c and c > 0), 1))
     js = [ln for ln in lines if ln.lstrip().startswith("{")]
     if len(js) != 1:
         sys.stderr.write("\n".join(lines) + "\n")

@@ -2,10 +2,15 @@
 
 The reference's `Scene.render` / `Path.mask` / `Path.fill` keep nothing between calls and nothing at module level
 ("no global state on the path").  What this package's walk adds -- the leaf memo, the pre-planned runs and fills,
-the mask pre-pass, the retained entry of the running top-level render -- lives in ONE object per thread: two threads
-rendering at the same time do not see each other's walk, and a render that raises leaves nothing behind (`Scene.render`
-resets the fields in a `finally`).  The only process-wide pieces are the retained cache itself (scene._RETAINED, behind a
-lock; an entry is taken OUT of it while a render uses it) and the serial numbers, which must be unique across threads."""
+the mask pre-pass, the retained entry of the running top-level render -- lives in ONE object per thread (`STATE`), and a render
+that raises leaves nothing behind (`Scene.render` resets the fields in a `finally`).
+
+What that does NOT make concurrent: the device side.  All threads of a process share one `Context` (one stream, one set of
+persistent-launch counters, side streams and events) and the native library takes no lock of its own -- calls on one context are
+serialised by the caller.  A top-level `Scene.render` therefore runs under `RENDER_LOCK`, a process-wide
+re-entrant lock: two threads may CALL it at the same time, the renders run one after the other.  Callers that enter the
+library below `Scene.render` from several threads (`Path.mask`, `Path.fill`, `Layer.compose`, `_abi.Batch`) serialise themselves,
+e.g. with the same lock.  The serial numbers (renders, isolated groups) come from one locked counter."""
 from __future__ import annotations
 
 import itertools
@@ -25,6 +30,7 @@ class RenderState(threading.local):
 STATE = RenderState()
 _SERIAL = itertools.count(1)
 _SERIAL_LOCK = threading.Lock()
+RENDER_LOCK = threading.RLock()   # held by a top-level Scene.render for its whole walk: one render at a time per process
 
 
 def next_serial() -> int:

@@ -114,18 +114,18 @@ class Transform:
         """The six numbers the C ABI takes: rows 0-1 of the matrix."""
         if self._m6 is None:
             m = self.m
-            if type(m) is np.ndarray and m.dtype == FLOAT and m.flags.c_contiguous and m.shape == (3, 3):
-                m6 = m.ravel()[:6]   # (a view: the matrix of a Transform does not change)
-            else:
-                m6 = np.ascontiguousarray(np.asarray(m)[:2, :], dtype=FLOAT).reshape(6)
+            # an OWNED copy, taken together with the key: a caller who edits `m` in place afterwards cannot make the six numbers
+            # the batches see and the bytes the memos are keyed by disagree (a Transform is a value; its methods return new ones)
+            m6 = np.array(np.asarray(m)[:2, :], dtype=FLOAT).reshape(6)
             m6.flags.writeable = False   # (handed out to many leaves)
+            self._key = m6.tobytes()
             self._m6 = m6
         return self._m6
 
     def key(self) -> bytes:
-        """The matrix as bytes (memo keys)."""
+        """The matrix as bytes (memo keys): the bytes of `m6()`, made in the same step."""
         if self._key is None:
-            self._key = self.m6().tobytes()
+            self.m6()
         return self._key
 
     def __repr__(self) -> str:

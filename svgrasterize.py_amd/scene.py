@@ -25,7 +25,7 @@ import textwrap
 import numpy as np
 
 from . import _abi
-from ._state import STATE, next_serial
+from ._state import RENDER_LOCK, STATE, next_serial
 from .geometry import ConvexHull, Path, Transform, solid_paint, _RULES, FLATNESS
 from .layer import COMPOSE_IN, COMPOSE_OVER, Layer
 from .paint import _SPREAD, is_gradient, needs_mask   # (paint.py imports nothing of this module)
@@ -257,11 +257,16 @@ class Scene(tuple):
         The outermost call first renders, in ONE batch, every ``Path.mask`` the per-node route is going to ask for
         (clip paths, gradient-filled paths): hundreds of single-path launches become one.  It also builds the batch of every
         run of fills the walk will meet and plans them all behind one wait (``svgr_batch_plan_many``)."""
+        # (one context, one stream, no lock in the library: the renders of a process run one after the other; the lock is re-entrant)
+        with RENDER_LOCK:
+            # (a render inside a render -- a pattern's tile -- walks without a pre-pass of its own: the outer call's state stays)
+            if STATE.leaf_memo is not None or STATE.mask_prefetch is not None or viewport is None or self[0] in (RENDER_FILL, RENDER_STROKE):
+                return self._render(transform, mask_only, viewport, linear_rgb)
+            return self._render_top(transform, mask_only, viewport, linear_rgb)
+
+    def _render_top(self, transform: Transform, mask_only: bool, viewport, linear_rgb: bool):
         from . import geometry  # noqa: PLC0415
 
-        # (a render inside a render -- a pattern's tile -- walks without a pre-pass of its own: the outer call's state stays)
-        if STATE.leaf_memo is not None or STATE.mask_prefetch is not None or viewport is None or self[0] in (RENDER_FILL, RENDER_STROKE):
-            return self._render(transform, mask_only, viewport, linear_rgb)
         key = (id(self), transform.key(), tuple(int(v) for v in viewport), bool(linear_rgb), bool(mask_only))
         st = None
         if _RETAINED_MAX > 0:
@@ -810,7 +815,6 @@ def _stroked(scene: Scene) -> Path:
     return out
 
 
-_GROUP_SERIAL = [0]
 _BATCH_GROUPS = __import__("os").environ.get("SVGR_NO_BATCH_GROUPS") is None  # (off: isolated groups take the per-node route)
 _BATCH_GRADS = __import__("os").environ.get("SVGR_NO_BATCH_GRADIENTS") is None  # (off: gradient fills take the per-node route)
 _ONES = np.ones(4)
@@ -927,8 +931,7 @@ def _resolve_frames(batch) -> None:
 
 def _new_group(opacity: float, clipped: bool):
     """Tag shared by the members of one isolated group: (serial, opacity, clipped by the clip source in front of it)."""
-    _GROUP_SERIAL[0] += 1
-    return (_GROUP_SERIAL[0], float(opacity), bool(clipped))
+    return (next_serial(), float(opacity), bool(clipped))   # (the process's one locked counter: unique across threads)
 
 
 def _plain(leaves) -> bool:

@@ -59,6 +59,24 @@ def test_launcher_fails_when_a_rank_fails(tmp_path):
     assert "exit codes" in r.stderr and r.stdout.strip() == ""
 
 
+HANG_STUB = """
+    import os, sys, time
+    if int(os.environ["RANK"]) == 1:
+        sys.exit(5)            # (dies during start-up: bad device, import error)
+    time.sleep(600)            # (rank 0 would sit in init_process_group / a barrier until torch's timeout)
+"""
+
+
+def test_launcher_does_not_wait_for_a_stuck_rank_when_another_died(tmp_path):
+    import time
+
+    t0 = time.monotonic()
+    r = _run(["--gpus", "3"], {"SVGR_BENCH_DEVICE": "0"}, tmp_path, HANG_STUB)
+    assert r.returncode == 5, (r.returncode, r.stderr)
+    assert time.monotonic() - t0 < 60, "the launcher waited for the ranks that were stuck"
+    assert "exit codes" in r.stderr and r.stdout.strip() == ""
+
+
 def test_launcher_refuses_more_gpus_than_the_box_has(tmp_path):
     import torch
 

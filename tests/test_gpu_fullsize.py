@@ -84,8 +84,15 @@ def test_synth_4096_properties(S):
     # idempotent: a second render of the same batch gives the same canvas up to LDS-atomic order (1 ULP ties)
     batch.render(out, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
     again = out.download((size, size, 4), np.float32)
-    diff = np.abs(full.astype(np.float64) - again)
-    assert (diff > 0).mean() < 1e-6 and diff.max() < 2e-7
+    # ... stated as the property it is: the few values that differ (order of the LDS float atomics inside a delta cell, decided at
+    # a float32 rounding tie) differ by EXACTLY one float32 ULP -- neighbouring float32 numbers -- and never by more
+    differs = full != again
+    n_diff = int(differs.sum())
+    assert n_diff <= full.size // 1_000_000, f"{n_diff} of {full.size} values differ between two renders"
+    if n_diff:
+        a, b = full[differs], again[differs]
+        lo, hi = np.minimum(a, b), np.maximum(a, b)
+        assert (np.nextafter(lo, np.float32(np.inf)) == hi).all(), "two renders differ by more than one float32 ULP somewhere"
     # sharding-invariant: rank 1 of 4 (strips of 16 bands) reproduces its rows of the full canvas
     tr = _abi.tile_rows()
     batch.set_bands(1, 4, 16)
@@ -94,8 +101,12 @@ def test_synth_4096_properties(S):
     batch.render(part, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
     part = part.download((batch.owned_rows(), size, 4), np.float32)
     for k, (r0, r1) in enumerate(sdist.owned_row_ranges(size, tr, 1, 4, 16)):
-        d = np.abs(part[k * tr: k * tr + (r1 - r0)].astype(np.float64) - full[r0:r1])
-        assert d.max() < 2e-7 and (d > 0).mean() < 1e-5
+        mine, theirs = part[k * tr: k * tr + (r1 - r0)], full[r0:r1]
+        dd = mine != theirs
+        assert dd.mean() < 1e-5
+        if dd.any():   # (same property: neighbouring float32 numbers)
+            lo, hi = np.minimum(mine[dd], theirs[dd]), np.maximum(mine[dd], theirs[dd])
+            assert (np.nextafter(lo, np.float32(np.inf)) == hi).all()
     # the WHOLE canvas against the CPU oracle (64 row strips through the reference's own viewport mechanism, S:968-971, on the
     # host's cores): every one of the 67 M values of the bench scene inside the float32 contract
     ref, P, _ = orc.render_solid(synth.presentation_segs(sc), sc["seg_kind"], sc["path_seg_off"], sc["path_rule"],

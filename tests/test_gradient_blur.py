@@ -120,7 +120,7 @@ def test_gpu_icons_scene():
     # blur goes through FFT in the reference (scipy picks it): absolute noise ~1e-16 there, so the float32 contract holds
     # except where that noise decides a float32 rounding tie or the 1e-6 coverage cut; the counts are recorded per class
     c = f32_contract_counts(canvas, z["s286_canvas"], "icons.svg @1114x286")
-    assert c["other"] == 0 and c["cut"] == 0 and c["tie"] <= 2 and c["max_err"] < 1e-6, c  # (measured: 0 of every class)
+    assert c["bad"] == 0 and c["max_err"] < 1e-6, c  # (no value outside the 1-ULP contract: no tie / cut allowance)
 
 
 @pytest.mark.gpu
@@ -171,7 +171,7 @@ def test_gpu_demo_icon_thumbnails(name):
     assert [int(v) for v in layer.offset] == r["layer_offset"]
     canvas = layer.to_canvas_f32(hh, ww)
     c = f32_contract_counts(canvas, z[f"{r['tag']}_canvas"], f"{name} @192")  # (classes: see tests/util.py; counts on file)
-    assert c["other"] == 0 and c["cut"] == 0 and c["tie"] <= 2 and c["max_err"] < 1e-6, c  # (measured: 0 of every class)
+    assert c["bad"] == 0 and c["max_err"] < 1e-6, c  # (no value outside the 1-ULP contract: no tie / cut allowance)
 
 
 @pytest.mark.gpu
@@ -215,7 +215,7 @@ def test_gpu_icons_4096():
     assert list(layer.image.shape) == info["full"]["layer_shape"]
     canvas = layer.to_canvas_f32(h, w)
     c = f32_contract_counts(canvas.reshape(-1, 4)[z["full_idx"]], z["full_val"], f"icons.svg @{w}x{h} ({len(z['full_idx'])} pins)")
-    assert c["other"] == 0 and c["cut"] == 0 and c["tie"] <= 2 and c["max_err"] < 1e-6, c  # (measured: 0 of every class)
+    assert c["bad"] == 0 and c["max_err"] < 1e-6, c  # (no value outside the 1-ULP contract: no tie / cut allowance)
 
 
 @pytest.mark.gpu

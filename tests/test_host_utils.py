@@ -159,3 +159,51 @@ def test_batch_routing_of_scene_nodes_is_host_logic():
            sc._leaf(sq(0, 0, 2), tr.m6(), 0, np.zeros(4), 1), sc._leaf(empty, tr.m6(), 0, red, 2), sc._leaf(empty, tr.m6(), 0, red)]
     kept = sc._drop_empty(run)
     assert len(kept) == 1 and kept[0] is run[2]
+
+
+def test_two_threads_share_nothing_but_the_lock(monkeypatch):
+    """The walk state is per thread, the serial numbers come from one locked counter, and top-level renders of a process run
+    one after the other (`_state.RENDER_LOCK`: the library has no lock and all threads share one context and stream)."""
+    import threading
+    import time
+
+    from svgrasterize_amd import Path, Scene, Transform, _state, scene as scene_mod
+
+    serials, seen_state, inside, overlap = [], [], [0], [0]
+    guard = threading.Lock()
+
+    def fake_render(self, transform, mask_only=False, viewport=None, linear_rgb=False, _asked=False):
+        with guard:
+            inside[0] += 1
+            overlap[0] = max(overlap[0], inside[0])
+        seen_state.append((threading.get_ident(), _state.STATE.serial, _state.STATE.leaf_memo is not None))
+        for _ in range(200):
+            serials.append(scene_mod._new_group(1.0, False)[0])
+        time.sleep(0.02)
+        with guard:
+            inside[0] -= 1
+        return None
+
+    monkeypatch.setattr(Scene, "_render", fake_render)
+    monkeypatch.setattr(scene_mod, "_collect_mask_jobs", lambda *a, **k: None)
+    sc = Scene.fill(Path.from_svg("M1,1 L5,1 L3,4 Z"), np.array([1.0, 0.0, 0.0, 1.0])).opacity(0.5)
+    tr = Transform()
+    errors = []
+
+    def work():
+        try:
+            for _ in range(3):
+                sc.render(tr, viewport=[0, 0, 8, 8])
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work) for _ in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert overlap[0] == 1, "two top-level renders ran at the same time"
+    assert len(serials) == len(set(serials)) == 4 * 3 * 200, "a group serial was handed out twice"
+    assert len({s for _, s, _ in seen_state}) == 12 and all(memo for _, _, memo in seen_state)
+    assert _state.STATE.leaf_memo is None and _state.STATE.retain is None   # (nothing left behind in this thread)
