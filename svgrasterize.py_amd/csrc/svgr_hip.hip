@@ -84,58 +84,10 @@ constexpr int NW = NT / 64;                // waves per workgroup
 #define SVGR_WAVES_PER_EU 4             // register budget of the tile kernel: 512 / 4 = 128 VGPRs
 #endif
 static_assert(NT % 64 == 0 && NT <= 1024, "tile kernel: whole waves, at most 1024 threads");
-// Round-4 forms of the tile kernel's inner pieces, each behind a switch so that one box can time them against each other
-// (profiles/sweep_trace.sh "name:-DSVGR_X_...=0|1"):
-#ifndef SVGR_X_SCANEXEC
-#define SVGR_X_SCANEXEC 1               // row scan: shifted values added under an EXEC mask instead of selected to zero first
-#endif
-#ifndef SVGR_X_CVTCLAMP
-#define SVGR_X_CVTCLAMP 1               // float32 canvas: clip(0, 1) as the clamp modifier of the f64 -> f32 conversion
-#endif
-#ifndef SVGR_X_C1FAST
-#define SVGR_X_C1FAST 1                 // class-1 items inside the layer's columns: coverage is constant along a lane's pixels
-#endif
-#ifndef SVGR_X_FRACT
-#define SVGR_X_FRACT 1                  // evenodd fold by v_fract_f64 (three instructions instead of seven)
-#endif
-#ifndef SVGR_X_SCATWAIT
-#define SVGR_X_SCATWAIT 1               // scatter: no compiler-visible load (and so no compiler-placed vmcnt(0)) in front of the adds
-#endif
-#ifndef SVGR_X_ADD12
-#define SVGR_X_ADD12 0                  // a TileAdd of 12 bytes {value, where} (no padding word): 46 MB less traffic per step, but entries straddle cache lines -- tile kernel +2.5 us, k_path_build -1 us (A/B twice): off
-#endif
-#ifndef SVGR_X_MASK64
-#define SVGR_X_MASK64 1                 // the scan's exec masks held as whole scalar pairs
-#endif
-#ifndef SVGR_X_BLEND2
-#define SVGR_X_BLEND2 1                 // the production blend: two pixels per asm statement (one class-1 test for both)
-#endif
-#ifndef SVGR_X_CARRY1
-#define SVGR_X_CARRY1 1                 // class-2 cells: the carry-in block of the header neither written (k_path_build) nor fetched (tile kernel)
-#endif
-#ifndef SVGR_X_SHDR
-#define SVGR_X_SHDR 0                   // production tile kernel: the uniform 64 bytes of an item's header by a SCALAR load (an item ahead) instead of 16 v_readlane of the vector load (measured in round 5: see DESIGN section 4)
-#endif
-#ifndef SVGR_X_CMPX
-#define SVGR_X_CMPX 1                   // the 1e-6 cut as v_cmpx around the pixel's block instead of a saveexec + branch
-#endif
 
 // One addition into a tile's LDS delta tile: everything the scatter phase of the tile kernel does for it is
 // `ds_add_f64 base + offset, v`.  A run of `len` consecutive tile columns with the same value (the middle pieces of a
 // long span, S:2286-2287) is one entry.  Written by k_pair_cells, per cell contiguous.
-#if SVGR_X_ADD12
-struct TileAdd {
-    unsigned v_lo, v_hi;   // the value (a double, at a 4-byte boundary; in front: a register tuple starts at an even register, and so must a double)
-    unsigned where;  // bits 0-15: byte offset of (tile row, tile column) in the padded delta tile; bits 16-21: len - 1;
-                     // bits 22-24: tile column & (PX - 1) of the first add (the run steps over the chunk padding)
-};
-static_assert(sizeof(TileAdd) == 12, "TileAdd is one dwordx3");
-typedef unsigned u32x3s_t __attribute__((ext_vector_type(3), aligned(4)));
-__device__ __forceinline__ void store_add(TileAdd* p, unsigned where, double v) {
-    const u32x3s_t w = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v), where};
-    *(u32x3s_t*)p = w;
-}
-#else
 struct TileAdd {
     unsigned where;
     unsigned zero;
@@ -147,7 +99,6 @@ __device__ __forceinline__ void store_add(TileAdd* p, unsigned where, double v) 
     t.where = where; t.zero = 0u; t.v = v;
     *p = t;
 }
-#endif
 // One (path, band, column tile) CELL = one work item of the tile kernel, written by k_pair_cells.
 // `carry[r]` = sum of every piece of the pair's row r that lies LEFT of the tile (the running sum the row
 // scan starts from, np.cumsum S:983); `cls` sorts the cells:
@@ -512,12 +463,7 @@ __device__ __forceinline__ void store_edge(double* __restrict__ edges, int at, d
     typedef double f64x2e_t __attribute__((ext_vector_type(2)));
     f64x2e_t lo = {r0, c0}, hi = {r1, c1};
     f64x2e_t* e = (f64x2e_t*)(edges + 4 * (size_t)at);
-#ifdef SVGR_NT_EDGES
-    __builtin_nontemporal_store(lo, e);
-    __builtin_nontemporal_store(hi, e + 1);
-#else
     e[0] = lo; e[1] = hi;
-#endif
 }
 __device__ __forceinline__ void load_seg_points(const double* __restrict__ segs, int s, const double* __restrict__ m6,
                                                 int npts, double* c) {
@@ -586,11 +532,6 @@ __global__ __launch_bounds__(256) void k_seg_select(const int* __restrict__ seg_
 #ifndef SVGR_FL_SUB
 #define SVGR_FL_SUB 5
 #endif
-#ifndef SVGR_FL_TREE
-#define SVGR_FL_TREE 0      // 1: the top levels of a workgroup's segments packed into its first waves, every node split once -- built,
-                            // bit-identical, and SLOWER (44.5 against 28.8 us in one sweep4.sh call: five barriered levels, most of
-                            // them one wave's work, and 33 KB of LDS per workgroup); 0: every lane walks its own ancestors
-#endif
 constexpr int FL_SUB = SVGR_FL_SUB;       // 32 lanes per segment: the longest lane bounds the kernel, so cut subtrees small
 constexpr int FL_BLOCK = 256;     // (the waves are independent up to the last step: the segments of a workgroup fold their extents per path)
 // PLACED (with EMIT): the pass stores the edges at the places the plan's counting pass left PER LANE (`lane_off`: a lane's first
@@ -639,85 +580,6 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
         bb = bb > n_bands - 1 ? n_bands - 1 : bb;
         seg_ok = ba <= bb && owns_any(own, ba, bb);
     }
-#if SVGR_FL_TREE
-    // The top SUB levels of the workgroup's segments, every node ONCE ("shared levels").  A lane per leaf repeats its
-    // ancestors -- 2^SUB lanes x SUB levels for 2^SUB - 1 distinct nodes -- and a SIMD pays for an instruction whatever its lanes
-    // hold, so nothing is saved unless the nodes of a level are PACKED: level l of the workgroup's NSEG segments is NSEG << l
-    // nodes, handled by the first NSEG << l threads (one wave up to level 3), handed down through LDS -- the left child to slot
-    // 2 t, the right to 2 t + 1, which at level SUB is the lane the leaf-per-lane form gives the node to (path bits MSB first).
-    // A node that is flat stops: it travels down as its own left-most descendant (state 1) and arrives at the lane whose
-    // remaining bits are 0, as before.  Same splits of the same numbers: the same edges, bit for bit.
-    {
-        constexpr int NSEG_ = FL_BLOCK >> SUB;
-        __shared__ double s_nd[2][FL_BLOCK][8];
-        __shared__ unsigned char s_st[2][FL_BLOCK];
-        const int tid_ = (int)threadIdx.x;
-        double nd[8];
-        unsigned char st = 0;
-        if (tid_ < NSEG_) {   // level 0: this thread's segment is the workgroup's tid_-th (not the one its lane belongs to)
-            const int item_t = blockIdx.x * NSEG_ + tid_;
-            const int seg_t = seg_list ? (item_t < n_list ? seg_list[item_t] : n_segs) : item_t;
-            bool ok_t = seg_t < n_segs;
-            int p_t = 0;
-            if (ok_t) p_t = seg_path[seg_t];
-            if (ok_t && prow) {
-                const int lo = UNION_BIAS - (int)prow[2 * (size_t)p_t], hi = (int)prow[2 * (size_t)p_t + 1] - UNION_BIAS;
-                int ba = (lo - 2 - vr0) / TR, bb = (hi + 2 - vr0) / TR;
-                ba = lo - 2 - vr0 < 0 ? 0 : ba;
-                bb = bb > n_bands - 1 ? n_bands - 1 : bb;
-                ok_t = ba <= bb && owns_any(own, ba, bb);
-            }
-            if (ok_t && kind[seg_t] != SVGR_SEG_LINE) {
-                load_seg_points(segs, seg_t, path_m6 + 6 * (size_t)p_t, 4, nd);
-                st = 2;
-            }
-        }
-        int cur = 0;
-#pragma unroll
-        for (int l = 0; l < SUB; ++l) {
-            if (tid_ < (NSEG_ << l)) {
-                if (l > 0) {
-                    st = s_st[cur][tid_];
-                    if (st) {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) nd[q] = s_nd[cur][tid_][q];
-                    }
-                }
-                unsigned char sl = 0, sr = 0;
-                if (st == 2 && !(cubic_flatness(nd) < thr)) {
-                    double rt[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) rt[q] = nd[q];
-                    cubic_left_inplace(nd);
-                    cubic_right_inplace(rt);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { s_nd[cur ^ 1][2 * tid_][q] = nd[q]; s_nd[cur ^ 1][2 * tid_ + 1][q] = rt[q]; }
-                    sl = sr = 2;
-                } else if (st) {   // flat here, or flat further up: one edge, carried by the left-most descendant
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) s_nd[cur ^ 1][2 * tid_][q] = nd[q];
-                    sl = 1;
-                }
-                s_st[cur ^ 1][2 * tid_] = sl;
-                s_st[cur ^ 1][2 * tid_ + 1] = sr;
-            }
-            __syncthreads();
-            cur ^= 1;
-        }
-        const unsigned char fin = s_st[cur][tid_];
-        if (seg_ok && fin) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) node[q] = s_nd[cur][tid_][q];
-            mode = fin;   // (2: the subtree under this depth-SUB node; 1: the edge node[0..1] -> node[6..7])
-        }
-        if (seg_ok && kind[seg] == SVGR_SEG_LINE && sub == 0) {
-            double c[4];
-            load_seg_points(segs, seg, path_m6 + 6 * (size_t)p, 2, c);
-            node[0] = c[0]; node[1] = c[1]; node[6] = c[2]; node[7] = c[3];
-            mode = 1;
-        }
-    }
-#else
     if (seg_ok) {
         const double* m6 = path_m6 + 6 * (size_t)p;
         if (kind[seg] == SVGR_SEG_LINE) {
@@ -739,7 +601,6 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
             }
         }
     }
-#endif
     // Multi-GPU: a rank needs the exact bbox of every path it keeps (so the first traversal always runs and
     // tracks min/max over ALL segments of such a path), but it only stores the edges of segments that can
     // reach one of its own bands (the curve stays inside the row range of its control points; +-1 row of slack).
@@ -875,9 +736,6 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
                     edge_path[base + k] = p;
                 }
         } else {
-#ifdef SVGR_DBG_NO_SECOND_TRAVERSAL
-            if (cnt > 1000000)  // diagnostic: what the second traversal costs (edges of long lanes are left unwritten)
-#endif
             {
             int i = 0;
             bool o2 = false;
@@ -911,11 +769,7 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
         s_mm[sidx][0] = mnr; s_mm[sidx][1] = mnc; s_mm[sidx][2] = mxr; s_mm[sidx][3] = mxc;
     }
     __syncthreads();
-#ifdef SVGR_DBG_FL_NOATOMIC
-    if (sub == 0 && s_mp[sidx] >= 0 && thr < 0.0) {   // diagnostic: what the per-path min / max atomics cost
-#else
     if (sub == 0 && s_mp[sidx] >= 0 && (sidx == 0 || s_mp[sidx - 1] != s_mp[sidx])) {   // (the first segment of a run of one path's)
-#endif
         for (int j = sidx + 1; j < NSEG && s_mp[j] == p; ++j) {
             mnr = s_mm[j][0] < mnr ? s_mm[j][0] : mnr; mnc = s_mm[j][1] < mnc ? s_mm[j][1] : mnc;
             mxr = s_mm[j][2] > mxr ? s_mm[j][2] : mxr; mxc = s_mm[j][3] > mxc ? s_mm[j][3] : mxc;
@@ -1187,11 +1041,7 @@ __global__ __launch_bounds__(64) void k_path_bbox(const unsigned long long* __re
     // One GPU (every band owned): the wave's slabs are dealt to its lanes one each -- slab i belongs to the lane whose run of slabs
     // it falls into -- instead of every lane writing its own path's one after the other (a large path is dozens of slabs: the
     // tiger @ 2048 spent 10 us here for 182 paths).
-#ifdef SVGR_DBG_NO_COOP_SLABS
-    const bool coop = false;
-#else
     const bool coop = slabs != nullptr && own.world <= 1;
-#endif
     if (coop) {
         const bool fits = n_slabs > 0 && slab0 + n_slabs <= slab_cap;
         int t_sl;
@@ -1581,11 +1431,7 @@ static_assert(PB_BANDS * SVGR_TR * PB_BATCH < (1 << 20) && PB_BATCH < (1 << 11),
 // The barriers of k_path_build order LDS traffic only -- nothing one wave writes to global memory is read by another inside the
 // kernel --, so they wait for the wave's LDS operations and not, as __syncthreads() does, for its global stores as well: behind
 // pass A those are the add lists on their way out, and a wave that waits for their acknowledgement stands still for a microsecond.
-#ifdef SVGR_DBG_PB_SYNCTHREADS
-__device__ __forceinline__ void pb_barrier() { __syncthreads(); }
-#else
 __device__ __forceinline__ void pb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
 template <bool PLANNED>
 __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const Slab* __restrict__ slabs, const double* __restrict__ edges,
                                                            const int* __restrict__ pair_idx, const double* __restrict__ path_paint,
@@ -1613,11 +1459,6 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     __shared__ __attribute__((aligned(8))) int2 s_info[PB_CELLS];   // per cell: adds in front of it in its band, class
     __shared__ unsigned s_rowm[PB_CELLS];                           // ... rows with a carry-in add | rows with a sentinel << 16
     __shared__ int s_ptot[PB_BANDS], s_pidx[PB_BANDS], s_base, s_ok;
-#ifdef SVGR_DBG_PB_PADLDS
-    __shared__ int s_padlds[SVGR_DBG_PB_PADLDS / 4];   // diagnostic: occupancy experiment
-    if (threadIdx.x == 0 && vr0 == -123456) s_padlds[blockIdx.x & 7] = 1;
-    if (vr0 == -123457) cell_cap = s_padlds[3];
-#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (the LDS tables are cleared whole, not just the slab's part of them: that needs nothing of the slab, so it runs while the
     //  slab record is on its way)
@@ -1831,9 +1672,6 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     // STORE (a planned render): the adds themselves too, at the cell's planned place + what the counter held.
     auto count_row = [&](const RowAt& ra, auto store) {
         constexpr bool STORE = decltype(store)::value;
-#ifdef SVGR_DBG_PB_NOCOUNT
-        if (ra.x0i != 123456789) return;
-#endif
         if (!((ra.where >> 16) & 1)) return;
         const int bl = ra.where & 0xff, trow = (ra.where >> 8) & 0xff;
         int kf, kl;
@@ -1860,11 +1698,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             const int pos = __hip_atomic_fetch_add(&s_cnt[ci], ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&s_sum[ci * TR + trow], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_or(&s_rowb[ci], 1u << trow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef SVGR_DBG_PB_NOSTORE
-            if (STORE && ra.x0i == 123456789) {
-#else
             if (STORE) {
-#endif
                 const int first = s_pos[ci];
                 // (more pieces than the plan counted here, or a cell the plan has no place for: the walk flags the cell)
                 if (first < 0 || pos + ne > s_plan_n[ci]) continue;
@@ -1901,9 +1735,6 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         total = stage(eb);
         PB_STAMP(1);
         n_rows += total;
-#ifdef SVGR_DBG_PB_NOTASK
-        total = 0;
-#endif
         if (PLANNED) for_rows(total, [&](const RowAt& ra) { count_row(ra, std::true_type{}); });
         else for_rows(total, [&](const RowAt& ra) { count_row(ra, std::false_type{}); });
     }
@@ -1911,9 +1742,6 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     pb_barrier();
     PB_STAMP(2);
     // ---- walk ----
-#ifdef SVGR_DBG_PB_NOSCAN
-    if (n_rows != 123456789) return;
-#endif
     // what one lane (tile row row_l) writes of a cell of class 1 or 2: its carry-in (class 1: into the header; class 2: an add at
     // the layer's first column in the tile, if any row piece lies left of the cell), its sentinel (behind the layer's last
     // column), and -- lane 0 of the cell -- the header and the entry-bitmask bits
@@ -1927,11 +1755,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             return false;
         }
         CellHdr* hd = cell_hdr + cell;
-#if SVGR_X_CARRY1
         if (cls == 1) hd->carry[row_l] = cin;   // (a class-2 cell's carry-ins are adds of its list: the tile kernel does not load this part of its header)
-#else
-        hd->carry[row_l] = cin;
-#endif
         const int cell_c0 = (sl.k0 + k) * TC + x_first;       // layer column of the tile's column 0
         const unsigned below = (1u << row_l) - 1u;
         const int n_carry = __popc(cm);
@@ -2069,9 +1893,6 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     pb_barrier();
 
     // ---- pass B ----  (PLANNED = false only)
-#ifdef SVGR_DBG_PB_NOB
-    return;
-#endif
     if (one_batch) {
         for_rows(total, emit_row);  // (the batch is still staged)
     } else {
@@ -2400,13 +2221,9 @@ __device__ __forceinline__ double dpp_ctrl(double v) {  // generic DPP move of a
 }
 
 // the lane's pixels, one macro call each (asm blocks with named operands cannot be written in a loop over a constexpr index)
-#if SVGR_PX == 16
-#define SVGR_ACC_PX(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
-#define SVGR_ACC_PX2(F) F(0) F(2) F(4) F(6) F(8) F(10) F(12) F(14)
-#else
+static_assert(SVGR_PX == 8, "the blend statements name a lane's eight pixels (16 px per lane / one wave per tile was built and measured slower: DESIGN section 4)");
 #define SVGR_ACC_PX(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
 #define SVGR_ACC_PX2(F) F(0) F(2) F(4) F(6)
-#endif
 
 struct TileArgs {
     const uint4* pages;             // whole-canvas launches: per workgroup, in launch order (k_tile_lists: heaviest first), its page
@@ -2499,31 +2316,8 @@ struct WinTable {
 #define SVGR_FP_67 "v[122:123]"
 #define SVGR_FP_89 "v[124:125]"
 #define SVGR_FP_1011 "v[126:127]"
-#define SVGR_FP_456 "v[120:122]"
-#define SVGR_FP_8910 "v[124:126]"
-#elif SVGR_WAVES_PER_EU == 2
-#define SVGR_FIX0 244
-#define SVGR_FR(k) SVGR_FR_##k
-#define SVGR_FR_0 "v244"
-#define SVGR_FR_1 "v245"
-#define SVGR_FR_2 "v246"
-#define SVGR_FR_3 "v247"
-#define SVGR_FR_4 "v248"
-#define SVGR_FR_5 "v249"
-#define SVGR_FR_6 "v250"
-#define SVGR_FR_7 "v251"
-#define SVGR_FR_8 "v252"
-#define SVGR_FR_9 "v253"
-#define SVGR_FR_10 "v254"
-#define SVGR_FR_11 "v255"
-#define SVGR_FP_45 "v[248:249]"
-#define SVGR_FP_67 "v[250:251]"
-#define SVGR_FP_89 "v[252:253]"
-#define SVGR_FP_1011 "v[254:255]"
-#define SVGR_FP_456 "v[248:250]"
-#define SVGR_FP_8910 "v[252:254]"
 #else
-#error "the tile kernel's fixed load targets are named for 4 or 2 waves per SIMD"
+#error "the tile kernel's fixed load targets are named for 4 waves per SIMD (128 VGPRs)"
 #endif
 // The launch's arguments read AGAIN from the kernel-argument segment: scalar loads that hit the scalar cache, in the place of two
 // dozen SGPRs held across the item loops (the persistent loop ran out of them).  The pointer passes through an empty asm so that
@@ -2603,7 +2397,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
     // first loads, [1] that wait, [2] the item rounds; tl_mark_: the last stamp
     unsigned long long tl_ph_[6] = {0, 0, 0, 0, 0, 0};   // ([3..5]: parts of [0]: registers -> LDS, next tile's loads issued, stores)
     unsigned long long tl_mark_ = tl_start_, tl_sub_ = tl_start_;
-    unsigned long long tl_wb_ = 0, tl_wi_ = 0;   // (SVGR_DBG_TL_WAITS) shader cycles in the loop's barrier / in the wait for the iteration's loads
 #define TL_PHASE(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); tl_ph_[i] += now_ - tl_mark_; tl_mark_ = now_; } while (0)
 #else
 #define TL_PHASE(i) do { } while (0)
@@ -2667,31 +2460,10 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
     auto hdr_ptr = [&](int j) -> const int* {
         if (j >= n_round) return (const int*)a.trash + hdr_lane;
         const unsigned cw = (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63);
-#if SVGR_X_CARRY1
         // (class 2: the lanes behind the 20 scalar dwords ask for dword 19 again -- the 128 bytes of carry-ins, which for this class
         //  are in the add list, are neither written nor fetched)
         const int hl = (cw >> 30) == 2u ? (hdr_lane < HDR_DWORDS ? hdr_lane : HDR_DWORDS - 1) : hdr_lane;
         return (const int*)(a.cell_hdr + (cw & 0x3fffffffu)) + hl;
-#else
-        return (const int*)(a.cell_hdr + (cw & 0x3fffffffu)) + hdr_lane;
-#endif
-    };
-    struct SHdr { int w[16]; };
-    // the first 64 bytes of the header of item j of the round, by scalar loads (past the round's end: of cell 0 -- any valid header)
-    auto load_shdr = [&](int j) -> SHdr {
-        SHdr o;
-        if constexpr (FIXED && SVGR_X_SHDR) {
-            typedef const int __attribute__((address_space(4))) * CIntPtr;
-            const unsigned cw = j < n_round ? (unsigned)__builtin_amdgcn_readlane((int)cells_v, j & 63) : 0u;
-            CIntPtr hp = (CIntPtr)(const int*)(a.cell_hdr + (cw & 0x3fffffffu));
-#pragma unroll
-            for (int q = 0; q < 16; ++q) o.w[q] = hp[q];
-            if (j >= n_round) o.w[12] = 0;   // (class 0: nothing to do)
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) o.w[q] = 0;
-        }
-        return o;
     };
     auto hdr_cls = [&](int h) { return (__builtin_amdgcn_readlane(h, 12) >> 3) & 3; };
     // class 2: this lane's first add of the item (its later ones, for lists longer than the workgroup, are loaded by the
@@ -2722,20 +2494,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
 #define hq_R SVGR_FR(2)
 #define hq_C SVGR_FR(2)
 #define ctr_R SVGR_FR(3)
-#if SVGR_X_ADD12
-#define wq0_R SVGR_FR(6)            // (an add lands in three registers: {value} {where})
-#define wq0_C SVGR_FR(6)
-#define aq0_R SVGR_FP_456
-#define vq0_R SVGR_FP_45
-#define vq0_C SVGR_FR(4), SVGR_FR(5)
-#define wq_R SVGR_FR(10)
-#define wq_C SVGR_FR(10)
-#define aq_R SVGR_FP_8910
-#define vq_R SVGR_FP_89
-#define vq_C SVGR_FR(8), SVGR_FR(9)
-#define SVGR_WMOV "v_mov_b32"
-    typedef unsigned addw_t;
-#else
 #define SVGR_WMOV "v_mov_b64"
     typedef unsigned long long addw_t;
 #define wq0_R SVGR_FP_45
@@ -2746,35 +2504,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
 #define vq0_C SVGR_FR(6), SVGR_FR(7)
 #define vq_R SVGR_FP_1011
 #define vq_C SVGR_FR(10), SVGR_FR(11)
-#endif
     static_assert(SVGR_FIX0 == 512 / SVGR_WAVES_PER_EU - 12, "the register names above: the top twelve of the budget");
-#ifdef SVGR_DBG_ADD_LOAD_NT
-#define SVGR_ADD_NT " nt"       // diagnostic: the add lists are read once -- a nontemporal load
-#else
 #define SVGR_ADD_NT ""
-#endif
 #define SVGR_HDR_LOAD(tgt, ptr)                                                                                        \
     do {                                                                                                               \
         if constexpr (FIXED) asm volatile("global_load_dword " tgt##_R ", %0, off" : : "v"(ptr) : "memory", tgt##_C);   \
         else asm volatile("global_load_dword %0, %1, off" : "=v"(tgt) : "v"(ptr) : "memory");                           \
     } while (0)
-#if SVGR_X_ADD12
-#ifdef SVGR_X_ADD12_SPLIT
-#define SVGR_ADD12_INS(tw, tv) "global_load_dwordx2 " tv##_R ", %0, off" SVGR_ADD_NT "\n\tglobal_load_dword " tw##_R ", %0, off offset:8" SVGR_ADD_NT
-#else
-#define SVGR_ADD12_INS(tw, tv) "global_load_dwordx3 " tw##_A ", %0, off" SVGR_ADD_NT
-#endif
-#define SVGR_ADD_LOAD(tw, tv, ptr)                                                                                     \
-    do {                                                                                                               \
-        if constexpr (FIXED)                                                                                           \
-            asm volatile(SVGR_ADD12_INS(tw, tv) : : "v"(ptr) : "memory", tw##_C, tv##_C);                            \
-        else                                                                                                           \
-            asm volatile("global_load_dword %0, %2, off offset:8" SVGR_ADD_NT "\n\tglobal_load_dwordx2 %1, %2, off" SVGR_ADD_NT \
-                         : "=&v"(tw), "=&v"(tv) : "v"(ptr) : "memory");                                                 \
-    } while (0)
-#define wq0_A aq0_R
-#define wq_A aq_R
-#else
 #define SVGR_ADD_LOAD(tw, tv, ptr)                                                                                     \
     do {                                                                                                               \
         if constexpr (FIXED)                                                                                           \
@@ -2784,16 +2520,11 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
             asm volatile("global_load_dwordx2 %0, %2, off" SVGR_ADD_NT "\n\tglobal_load_dwordx2 %1, %2, off offset:8" SVGR_ADD_NT \
                          : "=&v"(tw), "=&v"(tv) : "v"(ptr) : "memory");                                                 \
     } while (0)
-#endif
     // the wait at a round's start: ALL its first loads (the two headers and the add the first items need; header 2 and add 1, which
     // the loop starts with) -- n = what may stay in flight behind them: the previous tile's stores, or nothing
 #define SVGR_STR_(x) #x
 #define SVGR_STR(x) SVGR_STR_(x)
-#if SVGR_CH == 4
-#define SVGR_N_STORES 16
-#else
 #define SVGR_N_STORES 8
-#endif
 #define SVGR_ROUND_TAKE(n, d0, d1, dw0, dv0, d2, dw1, dv1)                                                             \
     do {                                                                                                               \
         if constexpr (FIXED)                                                                                           \
@@ -2819,16 +2550,10 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
     } while (0)
     // the adds of an item into delta tile `buf`
     auto scatter = [&](int h, addw_t first_w, double first_v, int buf) {
-#ifdef SVGR_DBG_NOSCATTER
-        return;
-#endif
         if (hdr_cls(h) != 2) return;
         if (a.det && wave != 0) return;
         int n_add = __builtin_amdgcn_readlane(h, 13);
         const int add0 = __builtin_amdgcn_readlane(h, 14);
-#ifdef SVGR_DBG_SCATTER_FIRST
-        n_add = n_add < NT ? n_add : NT;   // diagnostic: what the adds beyond a lane's first (loaded inside the scatter) cost
-#endif
         unsigned char* const base = s_mem + buf * DELTA_BYTES;
         const int i_step = a.det ? 64 : NT;
         auto one = [&](unsigned w, double v) {
@@ -2840,7 +2565,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
                 __hip_atomic_fetch_add((double*)(base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         };
-#if SVGR_X_SCATWAIT
         // The lane's first add is the one the pipeline brought.  Lists longer than the workgroup (rare) load the rest here, issued
         // and waited for by hand: a load the COMPILER sees makes it put `s_waitcnt vmcnt(0)` in front of every scatter's first
         // add -- also of the lists that load nothing --, and that waits for the header requested a moment ago: one exposed
@@ -2850,37 +2574,15 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
             addw_t w2;
             double v2;
             const TileAdd* const q = a.adds + (size_t)add0 + i;
-#if SVGR_X_ADD12
-            asm volatile("global_load_dword %0, %2, off offset:8\n\tglobal_load_dwordx2 %1, %2, off\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(w2), "=&v"(v2) : "v"(q) : "memory");
-#else
             asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:8\n\ts_waitcnt vmcnt(0)"
                          : "=&v"(w2), "=&v"(v2) : "v"(q) : "memory");
-#endif
             one((unsigned)w2, v2);
         }
-#else
-        for (int i = tid; i < n_add; i += i_step) {
-            unsigned w = (unsigned)first_w;
-            double v = first_v;
-            if (i != tid) {
-                const TileAdd t = a.adds[(size_t)add0 + i];
-                w = t.where;
-#if SVGR_X_ADD12
-                v = __hiloint2double((int)t.v_hi, (int)t.v_lo);
-#else
-                v = t.v;
-#endif
-            }
-            one(w, v);
-        }
-#endif
     };
 
     // ---- scan + fill rule + paint + source-over of the item whose deltas are in delta tile `buf` ----
     const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * (64 / CH);  // a wave owns 64 / CH tile rows
     const int wrow0_ = wrow0;
-#if SVGR_X_MASK64
     // the scan's three lane masks as whole scalar pairs, opaque to the compiler: as constants it keeps one half of each and builds
     // the pair again in front of every use (their halves are equal)
     unsigned long long sm1_, sm2_, sm4_;
@@ -2889,12 +2591,10 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
         sm1_ = rep * (CH == 8 ? 0xfeull : 0xeull); sm2_ = rep * (CH == 8 ? 0xfcull : 0xcull); sm4_ = rep * 0xf0ull;
         asm volatile("" : "+s"(sm1_), "+s"(sm2_), "+s"(sm4_));
     }
-#endif
-    // (SVGR_X_SHDR, production variant: the sixteen uniform dwords of the header come from a scalar load issued an item ahead --
-    //  `sh` -- instead of sixteen v_readlane of the vector load `h`, which then only carries the class-1 carry-ins)
-    auto process = [&](int h, const SHdr& sh, int buf) {
-        constexpr bool SH = FIXED && SVGR_X_SHDR;
-        auto hw = [&](int j) { return SH ? sh.w[j] : __builtin_amdgcn_readlane(h, j); };
+    // (the uniform part of an item's header comes out of the vector load `h` by v_readlane; a scalar load issued an item ahead was
+    //  built twice and measured equal: DESIGN section 4)
+    auto process = [&](int h, int buf) {
+        auto hw = [&](int j) { return __builtin_amdgcn_readlane(h, j); };
         const int bits = hw(12);
         const int cls = (bits >> 3) & 3;
         if (cls == 0) return;
@@ -2927,9 +2627,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
         const bool clip_missing = is_clipped && clip_tag != pid - 1;
         // skip the phase when the layer has no row among this wave's (its delta rows are untouched: nothing to read, zero
         // or composite).  A clip source always runs: its coverage tile must be rewritten whole.
-#ifdef SVGR_DBG_NOSCAN
-        return;
-#endif
         if (!(is_clip_src || (wrow0 + (64 / CH) > row_shift && wrow0 < row_shift + rows))) return;
 
         double* const my = my0 + buf * (DELTA_BYTES / 8);
@@ -2946,14 +2643,14 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
             //  allocator does not keep the canvas tile in place across two unrolled loops that both rewrite it)
             if (lo_c + col_shift <= 0 && hi_c + col_shift >= TC) {
                 // (the tile lies inside the layer's columns -- the usual case, a tile in the middle of a shape: no pixel tests)
-                if (SVGR_X_C1FAST && SVGR_X_CMPX && OUT == 0 && !CLIP && PX >= 5) {
+                if (OUT == 0 && !CLIP && PX >= 5) {
                     // The coverage is one value for all of the lane's pixels: src = mask * paint (S:1019) and 1 - src_a once per
                     // lane, then dst = fma(dst, 1 - src_a, src) (S:286) -- four fmas per pixel instead of eight, no comparison.
                     // A row below the cut gets src = 0 and 1 - src_a = 1: dst stays as it is, bit for bit.
                     // The five per-lane values ride in t[0..4] into the pixels' blocks below, which branch on `c1fast` INSIDE
                     // their asm statement: a second C++ loop over the canvas tile makes the register allocator copy the
                     // tile at the join (168 VGPRs and spills), one statement with two bodies does not.
-                    const double w = rule ? (SVGR_X_FRACT ? evenodd_fract_signed(cin1) : fill_evenodd_raw(cin1)) : cin1;
+                    const double w = rule ? evenodd_fract_signed(cin1) : cin1;
                     double mval;
                     asm("v_min_f64 %0, |%1|, 1.0" : "=v"(mval) : "v"(w));
                     mval = fabs(w) >= kZeroCut ? mval : 0.0;
@@ -2980,22 +2677,16 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
             for (int i = 1; i < PX; ++i) tot += t[i];
             double inc = tot;  // inclusive scan of the CH chunk totals of this tile row
             double run;
-            if (CH <= 8 && SVGR_X_SCANEXEC) {
+            if (CH <= 8) {
                 // a 16-lane DPP row holds 16 / CH tile rows: a shift must not carry a value across their borders.  The shifted
                 // value is added under an EXEC mask (a scalar move on either side of the add) instead of being selected to zero
                 // first (two VOP3 v_cndmask per step: a fifth of the scan's vector instructions).  The DPP moves themselves run
                 // with every lane enabled: a disabled lane would read as zero on the source side as well.
                 constexpr unsigned long long rep = CH == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
-#if SVGR_X_MASK64
                 (void)rep;
-#else
-                constexpr unsigned long long m1 = rep * (CH == 8 ? 0xfeull : 0xeull), m2 = rep * (CH == 8 ? 0xfcull : 0xcull), m4 = rep * 0xf0ull;
-#endif
                 double v;
                 const unsigned long long exec_all = __builtin_amdgcn_read_exec();   // (all ones: every branch above is wave-uniform)
-#if SVGR_X_MASK64
                 const unsigned long long m1 = sm1_, m2 = sm2_, m4 = sm4_;   // (whole scalar pairs made once: see their definition)
-#endif
 #define SVGR_MASKED_ADD(acc_, v_, m_) asm volatile("s_mov_b64 exec, %2\n\tv_add_f64 %0, %0, %1\n\ts_mov_b64 exec, %3" : "+v"(acc_) : "v"(v_), "s"(m_), "s"(exec_all))
                 v = dpp_row_shr<1>(inc); SVGR_MASKED_ADD(inc, v, m1);
                 v = dpp_row_shr<2>(inc); SVGR_MASKED_ADD(inc, v, m2);
@@ -3029,7 +2720,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
                     if ((lane & 31) == 0) run = 0.0;
                 }
             }
-            if (!(CH <= 8 && SVGR_X_SCANEXEC)) {
+            if (!(CH <= 8)) {
 #pragma unroll
                 for (int i = 0; i < PX; ++i) { run += t[i]; t[i] = run; }
             }
@@ -3064,12 +2755,11 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
                 // below), folded for evenodd (already in [0, 1])
                 if (rule && !c1fast) {
 #pragma unroll
-                    for (int i = 0; i < PX; ++i) t[i] = SVGR_X_FRACT ? evenodd_fract_signed(t[i]) : fill_evenodd_raw(t[i]);
+                    for (int i = 0; i < PX; ++i) t[i] = evenodd_fract_signed(t[i]);
                 }
                 // Then coverage = min(|t|, 1) where |t| >= 1e-6 (S:984-990): the comparison comes first because
                 // v_min_f64 turns the NaN of the layer-edge sentinel into 1.0.  Pixels below the cut are skipped
                 // under the exec mask: a tenth of the pixel slots of a wave have no visible lane at all.
-#if SVGR_X_CMPX
                 // ... as ONE block per pixel: v_cmpx narrows EXEC to the visible lanes, the block runs, a scalar move widens it
                 // again -- no saveexec / branch / restore triple per pixel (three quarters of the kernel's scalar instructions),
                 // no hole in the vector stream.  (EXEC is all ones here: every branch above is wave-uniform.)
@@ -3101,7 +2791,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
               [s3] "v"(t[4 % PX])                                                                                       \
             : "scc");                                                                                                  \
     }
-#if SVGR_X_C1FAST
                 // (the class-1 body sits out of line, behind the kernel's code: `.subsection 1` of the kernel's own section --
                 //  the general body runs without a taken branch)
 #define SVGR_BLEND_C1_HEAD "s_cmp_lg_u32 %[fast], 0\n\ts_cbranch_scc1 .Lc1f_%=\n\t"
@@ -3110,11 +2799,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
     "v_fma_f64 %[a0], %[a0], %[k], %[s0]\n\tv_fma_f64 %[a1], %[a1], %[k], %[s1]\n\t"                                    \
     "v_fma_f64 %[a2], %[a2], %[k], %[s2]\n\tv_fma_f64 %[a3], %[a3], %[k], %[s3]\n\t"                                    \
     "s_branch .Lc1b_%=\n\t.subsection 0"
-#else
-#define SVGR_BLEND_C1_HEAD
-#define SVGR_BLEND_C1_TAIL
-#endif
-#if SVGR_X_BLEND2
                 // two pixels per statement: one class-1 test (and, out of line, one way back) for both
 #define SVGR_BLEND_ONE(a0, a1, a2, a3, t)                                                                              \
             "v_cmpx_ge_f64_e64 %[vis], |%[" #t "]|, %[cut]\n\t"                                                         \
@@ -3156,23 +2840,10 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
 #undef SVGR_BLEND_2PX
 #undef SVGR_BLEND_ONE
 #undef SVGR_BLEND_FAST
-#else
-                SVGR_ACC_PX(SVGR_BLEND_PX)
-#endif
 #undef SVGR_BLEND_PX
 #undef SVGR_BLEND_C1_HEAD
 #undef SVGR_BLEND_C1_TAIL
                 (void)blend;
-#else
-#pragma unroll
-                for (int i = 0; i < PX; ++i) {
-                    if (__builtin_expect(fabs(t[i]) >= kZeroCut, 1)) {  // (visible falls through)
-                        double mval;  // min(|t|, 1): asm, because fmin() first canonicalises its operand (a v_max)
-                        asm("v_min_f64 %0, |%1|, 1.0" : "=v"(mval) : "v"(t[i]));
-                        blend(i, mval);
-                    }
-                }
-#endif
             } else {
                 bool vis[PX];  // the 1e-6 cut (S:990), as lane masks
                 if (rule) {
@@ -3256,7 +2927,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
         int lane = lane_, trow = trow_, chunk = chunk_, wrow0 = wrow0_;
         asm volatile("" : "+v"(lane), "+v"(trow), "+v"(chunk), "+s"(wrow0));
         // (and the launch's arguments were read again from the kernel-argument segment: reload_tile_args)
-        if (a.clip01 && !(OUT == 0 && SVGR_X_CVTCLAMP)) {
+        if (a.clip01 && OUT != 0) {
             // clip(0, 1) (S:326) as max / min: two instructions per channel (written as comparisons the compiler turns every
             // channel into two exec-masked branches).  A canvas value is never a NaN (the sentinel's never passes the
             // coverage test), so the NaN rule of v_max does not matter.
@@ -3265,9 +2936,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) asm("v_max_f64 %0, %0, 0\n\tv_min_f64 %0, %0, 1.0" : "+v"(acc[i][q]));
         }
-#ifdef SVGR_DBG_NOSTORE
-        if (acc[0][0] + acc[1][1] != 12345.678) return;
-#endif
         if (OUT == 0) {
             // float32: through an LDS transpose, so that one store instruction covers a whole 1-KiB tile row instead of
             // 64 separate 16-byte pieces 128 bytes apart.  A wave transposes its own rows: no workgroup barrier (the
@@ -3276,7 +2944,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
             constexpr int T_ROW = CH * (PX + 1);  // slots per transposed tile row
             static_assert(TR * T_ROW * 16 <= 2 * DELTA_BYTES, "the transposed tile fits the two delta tiles");
             float4* const tp = (float4*)s_mem;
-            if (SVGR_X_CVTCLAMP && a.clip01) {
+            if (a.clip01) {
                 // clip(0, 1) (S:326) rides on the conversion as its clamp modifier: rounding to float32 is monotone and 0 and 1
                 // are float32 values, so clamp(round(x)) == round(clamp(x)) -- and 128 double max / min per wave and tile
                 // (as much vector work as one and a half items) are gone
@@ -3313,9 +2981,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
     };
     auto store_tile_b = [&](const TileArgs& a, int by_, int bx_, int band_) {
         if (OUT != 0) return;
-#ifdef SVGR_DBG_NOSTORE
-        return;
-#endif
         int lane = lane_, wrow0 = wrow0_;
         asm volatile("" : "+v"(lane), "+s"(wrow0));
         {
@@ -3329,13 +2994,9 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
             const int col0 = (bx_ - a.ct0) * TC - a.win_c;
             // (the s_nop behind a store: a store of more than 8 bytes reads its data registers a moment AFTER it issues -- a VALU write
             //  to them in the next cycle lands in the stored value.  The compiler pads its own stores; it does not know these are.)
-#ifdef SVGR_DBG_PLAIN_STORE
-#define SVGR_ROW_STORE(dst, v) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory")
-#else
             // The canvas is written once and not read again by this launch: a NONTEMPORAL store (plain stores pushed the add
             // lists out of the caches the kernel reads them from: 162 -> 132 us).  Issued by hand: the count is what matters.
 #define SVGR_ROW_STORE(dst, v) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory")
-#endif
             if (vrow0 + 64 / CH <= a.vrows && orow0 >= 0 && orow0 + 64 / CH <= a.win_rows && col0 >= 0 && col0 + TC <= a.win_cols) {
                 // (the wave's rows lie inside the output -- every tile of a canvas whose size is a multiple of the tile's: no tests)
                 float4* dst = (float4*)a.out + ((size_t)orow0 * a.out_cols + col);
@@ -3398,11 +3059,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
         if (have_next_ && r0 + n_round >= n_items) {
             int ln = lane_;
             asm volatile("" : "+v"(ln));
-#if SVGR_X_ADD12
-            tail_ptr_ = (const unsigned*)(pages_ + (size_t)next_tile_ * PAGE_STRIDE + (ln < PAGE_STRIDE ? ln : PAGE_ITEMS)) + (ln == PAGE_STRIDE ? 1 : 0);
-#else
             tail_ptr_ = pages_ + (size_t)next_tile_ * PAGE_STRIDE + (ln < PAGE_STRIDE ? ln : PAGE_ITEMS);
-#endif
         }
         const int* q0 = hdr_ptr(0);
         const int* q1 = hdr_ptr(1);
@@ -3432,9 +3089,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
             item0 = __builtin_amdgcn_readfirstlane(ti.x);
             n_items = __builtin_amdgcn_readfirstlane(ti.y);
         }
-#ifdef SVGR_DBG_NOITEMS
-        n_items = 0;  // diagnostic: the tile's fixed cost alone
-#endif
         band = owned_band_at(a.own, by + a.band0);
         tile_r0 = a.vr0 + band * TR;
         tile_c0 = a.vc0 + bx * TC;
@@ -3534,7 +3188,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
                 }
             }
             scatter(h_p, w_s, v_s, 0);
-            SHdr sh_cur = load_shdr(0);
             for (int k = 0; k < n; ++k) {
                 // in hand: the headers of items k, k+1, k+2 and the add of item k+1; the adds of item k are on their way into
                 // delta tile k & 1
@@ -3543,28 +3196,15 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
                     SVGR_HDR_LOAD(hq, q);
                 }
                 // behind this barrier: every wave's adds of item k have landed; everybody's scan of item k-1 has zeroed its tile
-#if defined(SVGR_DBG_TIMELINE) && defined(SVGR_DBG_TL_WAITS)
-                const unsigned long long cb0_ = __builtin_readcyclecounter();
-#endif
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#if defined(SVGR_DBG_TIMELINE) && defined(SVGR_DBG_TL_WAITS)
-                tl_wb_ += __builtin_readcyclecounter() - cb0_;
-#endif
                 scatter(h_s, w_n, v_n, (k + 1) & 1);
                 {
                     const void* ap = add_ptr(k + 2);
                     SVGR_ADD_LOAD(wq, vq, ap);
                 }
-                process(h_p, sh_cur, k & 1);
-                sh_cur = load_shdr(k + 1);   // (asked for behind the item's last use of its own: one set of sixteen scalar registers)
+                process(h_p, k & 1);
                 h_p = h_s; h_s = h_a;
-#if defined(SVGR_DBG_TIMELINE) && defined(SVGR_DBG_TL_WAITS)
-                const unsigned long long ci0_ = __builtin_readcyclecounter();
-#endif
                 SVGR_ITER_TAKE(h_a, w_n, v_n);
-#if defined(SVGR_DBG_TIMELINE) && defined(SVGR_DBG_TL_WAITS)
-                tl_wi_ += __builtin_readcyclecounter() - ci0_;
-#endif
                 h_a = k + 3 < n ? h_a : 0;
             }
             // (nothing is in flight: the last iteration's wait)
@@ -3586,17 +3226,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
         { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); tl_ph_[3] += n_ - tl_mark_; tl_sub_ = n_; }
 #endif
         if (go) {
-#if SVGR_X_ADD12
-            {   // (a lane took 12 bytes of its page entry: {x, y, z}; what the tile's lane holds in w -- its item count -- came to the
-                //  lane behind it, which read from 4 bytes further on: tail_ptr_)
-                const unsigned n_ = (unsigned)__builtin_amdgcn_readlane((int)w_n, PAGE_ITEMS + 1);
-                page01 = (unsigned long long)__double_as_longlong(v_n);
-                page23 = (unsigned long long)w_n | ((unsigned long long)n_ << 32);
-            }
-#else
             page01 = w_n;
             page23 = (unsigned long long)__double_as_longlong(v_n);
-#endif
             tile_ = (unsigned)__builtin_amdgcn_readfirstlane((int)next_tile_);   // (scalars, said so: the compiler kept them in VGPRs -- and spilled them)
             pass_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(pass_ + 1u));
             next_tile_ = (unsigned)__builtin_amdgcn_readfirstlane((int)*(lds_vu32_t*)(s_mem + MAILBOX));
@@ -3613,9 +3244,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
 #endif
         if (!go) break;
         pend = OUT == 0;   // (the other outputs stored in front of the loads: their waits cover the stores anyway)
-#if defined(SVGR_DBG_NOPEND) || defined(SVGR_DBG_NOSTORE)
-        pend = false;      // diagnostic: the next tile's first waits also wait for the stores (NOSTORE: there are none to step over)
-#endif
     }
 
 #ifdef SVGR_DBG_TIMELINE
@@ -3633,7 +3261,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int win = 0, 
             p_[0] = tl_ph_[0]; p_[1] = tl_ph_[1]; p_[2] = tl_ph_[2]; p_[3] = (unsigned long long)(pass_ + 1u);
             // (the parts of the switch: a third table)
             unsigned long long* q_ = a.dbg + 8 + 8 * (size_t)(1u << 16) + 4 * (size_t)wg_;
-            q_[0] = tl_ph_[3]; q_[1] = tl_ph_[4]; q_[2] = tl_ph_[5]; q_[3] = (tl_wb_ & 0xffffffffull) | (tl_wi_ << 32);
+            q_[0] = tl_ph_[3]; q_[1] = tl_ph_[4]; q_[2] = tl_ph_[5]; q_[3] = 0ull;
         }
     }
 #endif
@@ -4206,13 +3834,14 @@ struct svgr_batch {
     bool planned = false;
     bool sized = false;           // a plan has succeeded with the viewport `sized_vp`: the buffers' capacities are a re-plan's guesses
     int sized_vp[4] = {0, 0, 0, 0};
-    bool no_band_reuse = false;   // SVGR_NO_BAND_REUSE as it stood when the plan was made (the A/B switches are read at plan time: all of them)
-    bool no_lane_places = false, always_entries = false;   // SVGR_NO_LANE_PLACES, SVGR_ALWAYS_BAND_ENTRIES: likewise
+    // SVGR_SAFE_PATH (a test hook, read when a plan is made): the renders take NO place from the plan -- slab places, band-list
+    // places, the kept band lists, the lanes' edge places, the cells' add places all come from the device's cursors and a second
+    // pass again, as in the plan's own passes.  Each of them was an A/B switch of its own while it was new; they have been
+    // bit-identical since (tests/test_gpu_fullsize.py::test_planned_slab_places_do_not_change_the_picture compares the two ends).
+    bool safe_path = false;
     void read_switches() {
-        no_band_reuse = getenv("SVGR_NO_BAND_REUSE") != nullptr;
-        no_lane_places = getenv("SVGR_NO_LANE_PLACES") != nullptr;
-        always_entries = getenv("SVGR_ALWAYS_BAND_ENTRIES") != nullptr;
-        add_places = getenv("SVGR_NO_ADD_PLACES") == nullptr;   // (every planner ends in a full pass: it left every cell's add places)
+        safe_path = getenv("SVGR_SAFE_PATH") != nullptr;
+        add_places = !safe_path;   // (every planner ends in a full pass: it left every cell's add places)
     }
     bool has_clips = false;    // any SVGR_PATH_CLIP_SOURCE / SVGR_PATH_CLIPPED path
     int64_t n_groups = 0;      // isolated groups (svgr_batch_set_groups)
@@ -4435,7 +4064,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     }
     if (ns > 0) {
         // (the counting pass that made `seg_off` left every lane's place inside its segment's slots beside it)
-        const bool lane_places = !b->no_lane_places;
+        const bool lane_places = !b->safe_path;
         auto launch_fl = [&](auto kern, int* places) {
             hipLaunchKernelGGL(kern, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                                (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
@@ -4460,13 +4089,13 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     // per owned band: its list of (path, band) pairs in paint order, and its first tile-list slot
     const int owned = count_owned_bands(b->own, b->n_bands);
     // (a planned render under the plan's places keeps the plan's band lists: k_tile_lists reads the paths' bboxes and bins itself)
-    const bool keep_lists = upto >= 4 && b->planned && b->slab_at_valid && use_vp && !b->no_band_reuse && !b->always_entries;
+    const bool keep_lists = upto >= 4 && b->planned && b->slab_at_valid && use_vp && !b->safe_path;
     if (owned > 0 && !keep_lists)
         hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(BE_BLOCK), 0, st, (const PathBin*)b->bins.p, np_walk, plist,
                            (const int*)b->bbox.p, b->band_start.p, b->band_count.p, b->band_item0.p, b->entries.p,
                            b->pair_idx.p, cap_i32(std::min(b->entries.cap, b->pair_idx.cap)),
                            upto >= 4 ? cap_i32(b->items.cap) : 0x7fffffff, b->vp[1], b->bd(), b->own,
-                           upto >= 4 && b->planned && use_vp && !b->no_band_reuse ? 1 : 0);
+                           upto >= 4 && b->planned && use_vp && !b->safe_path ? 1 : 0);
     if (upto == 3) return 0;
     // (the tiles read their mask words whether or not any pair exists: a batch without entries still needs them clear --
     //  a block from the cache is not zero)
@@ -5323,10 +4952,7 @@ int svgr_batch_plan_many(svgr_batch** batches, int64_t n) {
 // under a plan (set_transforms / set_bands invalidate it).
 static int plan_slab_order(svgr_batch* b) {
     b->slab_at_valid = false;
-#ifdef SVGR_DBG_NO_SLAB_ORDER
-    return 0;
-#endif
-    if (getenv("SVGR_NO_SLAB_ORDER")) return 0;  // (tests: the renders then take their slab places from the cursor, in arrival order)
+    if (getenv("SVGR_SAFE_PATH")) return 0;  // (tests: the renders then take their slab places from the cursor, in arrival order)
     const size_t np = (size_t)b->n_paths;
     if (np == 0 || b->host_bbox.size() < 4 * np || b->n_slabs <= 0 || b->vp[2] <= 0) return 0;
     std::vector<int> n_sl(np, 0), order;
@@ -5913,20 +5539,6 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         a.arena = (unsigned*)b->arena.p;
         a.arena_words = (unsigned)(b->arena_bytes / 4);
         a.dbg = nullptr;
-#ifdef SVGR_DBG_STAMP
-        {
-            static unsigned long long* dbg_buf = nullptr;
-            if (!dbg_buf) { (void)hipMalloc((void**)&dbg_buf, 64); (void)hipMemset(dbg_buf, 0, 64); }
-            a.dbg = dbg_buf;
-            unsigned long long h[8];
-            (void)hipMemcpy(h, dbg_buf, 64, hipMemcpyDeviceToHost);
-            if (h[5]) fprintf(stderr, "[stamp] ns per iteration (wave 0): dma_wait %.0f barA %.0f scatter %.0f barB %.0f scan %.0f | iterations %llu, WGs %llu, "
-                              "mean WG lifetime %.1f us, in-loop share %.2f\n",
-                              10.0 * h[0] / h[5], 10.0 * h[1] / h[5], 10.0 * h[2] / h[5], 10.0 * h[3] / h[5], 10.0 * h[4] / h[5], h[5], h[7],
-                              0.01 * h[6] / h[7], (double)(h[0] + h[1] + h[2] + h[3] + h[4]) / h[6]);
-            (void)hipMemset(dbg_buf, 0, 64);
-        }
-#endif
 #ifdef SVGR_DBG_TIMELINE
         {
             // the PREVIOUS render's per-workgroup timeline goes to the file $SVGR_DBG_TIMELINE (raw u64 quadruples)

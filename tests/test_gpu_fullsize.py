@@ -144,7 +144,7 @@ def test_deterministic_render_is_bit_reproducible(S):
 
 def test_planned_slab_places_do_not_change_the_picture(S, monkeypatch):
     """The staged plan hands every path its slabs' places in k_path_build's work list (heaviest first: host arithmetic that
-    must mirror k_path_bbox's).  With and without it (SVGR_NO_SLAB_ORDER: places from the device's cursor) a deterministic
+    must mirror k_path_bbox's).  With and without the plan's places (SVGR_SAFE_PATH: every place from the device's cursors) a deterministic
     render gives the same bits -- on the whole drawing and on one rank's bands of a two-rank sharding (slabs without an
     owned band are left out of both counts)."""
     from svgrasterize_amd import _abi, synth
@@ -168,39 +168,17 @@ def test_planned_slab_places_do_not_change_the_picture(S, monkeypatch):
         return got
 
     for bands in (None, (1, 2, 16)):
-        monkeypatch.delenv("SVGR_NO_SLAB_ORDER", raising=False)
-        monkeypatch.delenv("SVGR_NO_BAND_REUSE", raising=False)
+        monkeypatch.delenv("SVGR_SAFE_PATH", raising=False)
         a = render(bands)
-        monkeypatch.setenv("SVGR_NO_SLAB_ORDER", "1")
-        b = render(bands)
         assert np.abs(a).max() > 0
-        assert np.array_equal(a, b), f"slab places change the picture (bands {bands})"
-        # ... and the band lists' places taken from the plan (reuse) or from the device's cursors again (SVGR_NO_BAND_REUSE, read when
-        # the plan is made): the same bits, with the plan's slab and bin places and without them
-        monkeypatch.setenv("SVGR_NO_BAND_REUSE", "1")
-        c = render(bands)
-        assert np.array_equal(a, c), f"band places from the cursors change the picture (bands {bands})"
-        monkeypatch.delenv("SVGR_NO_SLAB_ORDER", raising=False)
-        d = render(bands)
-        assert np.array_equal(a, d), f"band places from the cursors change the picture under the plan's slab order (bands {bands})"
-        monkeypatch.delenv("SVGR_NO_BAND_REUSE", raising=False)
-        # ... and the cells' add places: a planned render stores every edge row's adds in ONE pass at the places the plan's own
-        # full pass left per cell (k_path_build<true>); with SVGR_NO_ADD_PLACES (read when the plan is made) it reserves them
-        # again and writes them in a second pass (k_path_build<false>): the same lists, the same bits
-        monkeypatch.setenv("SVGR_NO_ADD_PLACES", "1")
-        e = render(bands)
-        assert np.array_equal(a, e), f"add places from the plan change the picture (bands {bands})"
-        monkeypatch.delenv("SVGR_NO_ADD_PLACES", raising=False)
-        # ... the lanes' edge places in k_flatten (from the counting pass, or by a prefix sum again), and the band lists (kept from
-        # the plan, k_tile_lists reading bboxes and bins -- or k_band_entries launched in every render): the same bits
-        monkeypatch.setenv("SVGR_NO_LANE_PLACES", "1")
-        g = render(bands)
-        assert np.array_equal(a, g), f"lane places in k_flatten change the picture (bands {bands})"
-        monkeypatch.delenv("SVGR_NO_LANE_PLACES", raising=False)
-        monkeypatch.setenv("SVGR_ALWAYS_BAND_ENTRIES", "1")
-        h = render(bands)
-        assert np.array_equal(a, h), f"band lists kept from the plan change the picture (bands {bands})"
-        monkeypatch.delenv("SVGR_ALWAYS_BAND_ENTRIES", raising=False)
+        # every place a planned render takes from its plan -- the slabs' (heaviest first), the band lists' and the lists themselves
+        # (k_band_entries not launched), the lanes' edge places in k_flatten, the cells' add places (k_path_build<true>: one pass) --
+        # against the same render with all of them found again by the device's cursors and a second pass (SVGR_SAFE_PATH, read when
+        # the plan is made): the same lists, the same bits
+        monkeypatch.setenv("SVGR_SAFE_PATH", "1")
+        b = render(bands)
+        monkeypatch.delenv("SVGR_SAFE_PATH", raising=False)
+        assert np.array_equal(a, b), f"the plan's places change the picture (bands {bands})"
 
 
 def test_synth_8192_config4_windows(S):
