@@ -203,9 +203,10 @@ def bench_scene(args):
     }))
 
 
-def cpu_baseline(sc, budget_paths: int | None = None):
+def cpu_baseline(sc, budget_paths: int | None = None, strips_only: bool = False):
     """The CPU oracle (C restatement of the reference passes, oracle/svgr_oracle.c) timed on this
-    host, single thread, on the same scene (or its first `budget_paths` paths)."""
+    host, single thread, on the same scene (or its first `budget_paths` paths).  `strips_only`: just the canvas, rendered as
+    row strips on the host's cores (the checker of a second scene; nothing timed)."""
     import ctypes as C
 
     import numpy as np
@@ -241,6 +242,8 @@ def cpu_baseline(sc, budget_paths: int | None = None):
     dt_mt = time.perf_counter() - t0
     if rc != 0:
         raise RuntimeError(f"oracle (strips) failed: {rc}")
+    if strips_only:
+        return canvas, None, None
     P_mt = int(stats[0])
     # ... and whole, on one thread (this canvas is the one the GPU's is checked against); an untimed census on the side counts
     # the path-pixels that are visible at all (coverage not cut to zero, S:990): the composite's algorithmic work
@@ -634,11 +637,13 @@ def main():
     # ---- what a render that is NOT a replay costs (outside the timed region): the reference's only mode is a cold
     # render (S:3854-3864 times the whole of scene.render, every Path.mask flattens from scratch, S:948-957), the headline above
     # replays a plan made during warm-up
+    replan_canvas = replan_m6 = None
     if world == 1 and rank == 0:
         try:
-            # (three cold renders one after the other, each batch destroyed before the next is made -- a caller drawing frame after
+            # (three cold frames one after the other, each batch destroyed before the next is made -- a caller drawing frame after
             #  frame: the first asks the driver for fresh device memory, which is cleared before its first use; the later ones get
-            #  the blocks the library's pool took back.  `cold_ms` is the best of the three, `cold_fresh_memory_ms` the first)
+            #  the blocks the library's pool took back.  `cold_ms` is the best of the three, `cold_fresh_memory_ms` the first.
+            #  svgr_batch_draw = plan + render behind ONE wait; the two-call form it replaces is timed beside it)
             colds, cb = [], None
             for _ in range(3):
                 if cb is not None:
@@ -646,18 +651,29 @@ def main():
                 ctx.sync()
                 c0 = time.perf_counter()
                 cb = new_batch(sc)              # host arrays -> svgr_batch_create (packing + upload)
-                cb.plan()                       # two passes behind two read-backs (plan_two_pass)
-                cb.render(out, _abi.OUT_CANVAS_F32, flags)
-                ctx.sync()
+                cb.draw(out, _abi.OUT_CANVAS_F32, flags)   # census pass, wait, everything + the tile kernel, wait
                 colds.append((time.perf_counter() - c0) * 1e3)
             extras["cold_ms"] = round(min(colds), 4)
             extras["cold_fresh_memory_ms"] = round(colds[0], 4)
+            cb.destroy()
+            ctx.sync()
+            c0 = time.perf_counter()
+            cb = new_batch(sc)
+            cb.plan()
+            cb.render(out, _abi.OUT_CANVAS_F32, flags)
+            ctx.sync()
+            extras["cold_plan_then_render_ms"] = round((time.perf_counter() - c0) * 1e3, 4)
             m6 = np.array(sc["path_m6"], dtype=np.float64, copy=True)
-            reps, t_plan, t_replan = 5, 0.0, 0.0
-            for i in range(reps):
+
+            def moved(i):
                 m6p = m6.copy()
                 m6p[:, 2] += 0.125 * (i + 1)   # every path moved by an eighth of a pixel: new edges, new bboxes, same structure
                 m6p[:, 5] += 0.0625 * (i + 1)
+                return m6p
+
+            reps, t_plan, t_two = 5, 0.0, 0.0
+            for i in range(reps):           # the two-call form: set_transforms + plan (waits) + render + wait
+                m6p = moved(i)
                 ctx.sync()
                 r0 = time.perf_counter()
                 cb.set_transforms(m6p)      # (voids the plan)
@@ -666,14 +682,28 @@ def main():
                 t_plan += time.perf_counter() - p0
                 cb.render(out, _abi.OUT_CANVAS_F32, flags)
                 ctx.sync()
+                t_two += time.perf_counter() - r0
+            reps_d, t_replan = 10, 0.0
+            for i in range(reps_d):         # the frame with new geometry: set_transforms + svgr_batch_draw (one wait inside)
+                m6p = moved(reps + i)
+                ctx.sync()
+                r0 = time.perf_counter()
+                cb.set_transforms(m6p)
+                cb.draw(out, _abi.OUT_CANVAS_F32, flags)
                 t_replan += time.perf_counter() - r0
-            extras["replan_ms"] = round(t_replan / reps * 1e3, 4)
+            replan_m6 = m6p
+            replan_canvas = out.download((own_rows, cols, 4), np.float32)   # (the last re-planned frame: checked against the oracle below)
+            extras["replan_ms"] = round(t_replan / reps_d * 1e3, 4)
+            extras["value_replan"] = round(P / (t_replan / reps_d) / 1e6, 1)
+            extras["replan_plan_then_render_ms"] = round(t_two / reps * 1e3, 4)
             extras["plan_ms"] = round(t_plan / reps * 1e3, 4)
-            extras["replan_over_step"] = round((t_replan / reps) / (t_max / args.steps), 2)
-            extras["cold_replan_what"] = ("cold_ms: host arrays -> svgr_batch_create + plan + first render + sync, best of three in a row (each batch destroyed "
-                                          "before the next: device blocks recycled), cold_fresh_memory_ms the first of them; replan_ms: set_transforms "
-                                          "(every path moved by a fraction of a pixel) + plan + render + sync, mean of 5; plan_ms: the plan "
-                                          "call alone; none of them is inside the timed region")
+            extras["replan_over_step"] = round((t_replan / reps_d) / (t_max / args.steps), 2)
+            extras["cold_replan_what"] = ("a frame with NEW geometry (the reference's only mode, S:948-957), host clock, outside the timed region.  cold_ms: host "
+                                          "arrays -> svgr_batch_create + svgr_batch_draw (plan + render behind one wait at its end), best of three in a row "
+                                          "(each batch destroyed before the next: device blocks recycled), cold_fresh_memory_ms the first of them; "
+                                          "replan_ms: svgr_batch_set_transforms (every path moved by a fraction of a pixel) + svgr_batch_draw, mean of 10; "
+                                          "value_replan = path-pixels / replan_ms; *_plan_then_render_ms: the same with svgr_batch_plan + svgr_batch_render "
+                                          "+ sync (round 5's form); plan_ms: that plan call alone")
             cb.destroy()
             # (the canvas the parity check reads is the timed scene's: render it once more)
             batch.render(out, _abi.OUT_CANVAS_F32, flags)
@@ -753,7 +783,7 @@ def main():
         # (N > 1: the counters of rank 0 of an N-way sharding of the same drawing, collected on one GPU by profiles/collect_rank.sh)
         counters, counters_file = load_counters(args.workload if world == 1 else f"{args.workload}_w{world}")
         line = {
-            "metric": "Mpixels/sec AA coverage+composite (path-pixels/s; whole step: flatten+binning+coverage+composite)",
+            "metric": "Mpixels/sec AA coverage+composite (path-pixels/s; whole step: flatten+binning+coverage+composite; planned replay -- a frame with new geometry: value_replan)",
             "value": round(P / (t_max / args.steps) / 1e6, 1),
             "unit": "Mpixels/s",
             "n_gpus": world,
@@ -773,6 +803,16 @@ def main():
             ref_canvas, visible, line["cpu_baseline"] = cpu_baseline(sc, args.cpu_paths)
             if got_canvas is not None and ref_canvas is not None:
                 line["parity"] = contract_counts(got_canvas, ref_canvas)
+            if replan_canvas is not None and not args.cpu_paths:
+                # the last re-planned frame (every path moved, one flatten traversal, tile kernel behind the unvalidated pass) against
+                # the oracle's render of the MOVED scene: whole canvas
+                try:
+                    ref_moved, _vis, _cb = cpu_baseline(dict(sc, path_m6=replan_m6), None, strips_only=True)
+                    pr = contract_counts(replan_canvas, ref_moved)
+                    pr["what"] = "canvas of the last re-planned frame (svgr_batch_set_transforms + svgr_batch_draw), against the CPU oracle's render of the moved scene"
+                    line["parity_replan"] = pr
+                except Exception as exc:  # noqa: BLE001
+                    line["parity_replan"] = {"error": repr(exc)}
         if world > 1 and not args.no_cpu_baseline:
             # the first hardware record checks its own pixels (VERDICT r3 #4c): rank 0's strips against the oracle's render of
             # exactly those rows (the reference's own viewport cropping, S:968-971), and the CPU baseline on a bounded sample

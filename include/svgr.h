@@ -36,7 +36,7 @@ extern "C" {
  * 4: svgr_hash_buffers added (nothing changed or removed)
  * 5: svgr_layer_compose_over / _in, svgr_layer_convert_scale_to, svgr_layer_convolve_ops, svgr_batch_get_extents added (nothing changed
  *    or removed) */
-#define SVGR_ABI_VERSION 5
+#define SVGR_ABI_VERSION 6
 
 typedef enum {
     SVGR_OK = 0,
@@ -223,6 +223,15 @@ int svgr_batch_render_window(svgr_batch* batch, svgr_buf* out, int out_kind, uns
  * enqueued after it behind them.  Canvas outputs, unsharded batches; not with SVGR_RENDER_TIMED / _DETERMINISTIC. */
 int svgr_batch_render_windows(svgr_batch* batch, int64_t n, svgr_buf* const* outs, int out_kind, unsigned flags,
                               const int32_t* windows);
+
+/* Plan (when the batch has no valid plan: a new batch, or one whose transforms / bands were set since) AND render, behind ONE
+ * host wait: a frame with new geometry -- the reference's only mode: every `Path.mask` flattens and rasterises from scratch
+ * (S:948-957), `scene.render` is timed as a whole (S:3854-3864).  The tile kernel is enqueued right behind the plan's full
+ * geometry pass and the pass is validated when the call's single wait returns; a batch planned before takes ONE flatten
+ * traversal.  When a speculative capacity did not hold, svgr_batch_plan + svgr_batch_render run instead (same picture).
+ * On return the picture is in `out`, the stream has drained and the batch is planned (svgr_batch_get_stats / _bboxes are valid);
+ * a batch that was planned already is simply rendered, then waited for.  Same arguments as svgr_batch_render.           */
+int svgr_batch_draw(svgr_batch* batch, svgr_buf* out, int out_kind, unsigned flags);
 
 /* HIP-event timings accumulated over the SVGR_RENDER_TIMED renders since the last call
  * (synchronises).  ms_geometry = transform/flatten/bbox/binning kernels, ms_tile = the tile

@@ -99,6 +99,7 @@ _PROTOS = {
     "svgr_batch_get_extents": (C.c_int, [_P, _P]),
     "svgr_batch_all_edges": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "svgr_batch_render": (C.c_int, [_P, _P, C.c_int, C.c_uint]),
+    "svgr_batch_draw": (C.c_int, [_P, _P, C.c_int, C.c_uint]),
     "svgr_batch_render_window": (C.c_int, [_P, _P, C.c_int, C.c_uint, _P]),
     "svgr_batch_render_windows": (C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_uint, _P]),
     "svgr_batch_plan_many": (C.c_int, [_P, C.c_int64]),
@@ -347,7 +348,11 @@ class Batch:
     @property
     def stats(self) -> BatchStats:
         if self._stats is None:
-            self.plan()
+            st = BatchStats()
+            if self.ctx.lib.svgr_batch_get_stats(self.handle, C.byref(st)) == 0:   # (planned already, e.g. by draw())
+                self._stats = st
+            else:
+                self.plan()
         return self._stats
 
     def bboxes(self) -> np.ndarray:
@@ -422,6 +427,12 @@ class Batch:
         else:
             w = (C.c_int32 * 4)(*[int(v) for v in window])
             _check(self.ctx.lib.svgr_batch_render_window(self.handle, out.handle, kind, flags, w))
+
+    def draw(self, out: DeviceBuffer, kind: int, flags: int = 0):
+        """svgr_batch_draw: plan (if the batch has no valid plan) and render behind ONE wait -- a frame with new geometry, the
+        reference's only mode (S:948-957).  The picture is in `out` and the stream has drained when the call returns."""
+        _check(self.ctx.lib.svgr_batch_draw(self.handle, out.handle, kind, flags))
+        self._stats = None   # (whatever plan() returned before describes other geometry: `stats` asks again)
 
     def render_windows(self, outs, kind: int, windows, flags: int = 0):
         """svgr_batch_render_windows: `windows[i]` (row0, col0, rows, cols) into `outs[i]`, all from one geometry pass, side by side."""

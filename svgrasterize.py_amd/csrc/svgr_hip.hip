@@ -152,6 +152,13 @@ struct svgr_ctx {
     char name[128] = {0};
     void* pinned = nullptr;      // page-locked staging for read-backs that must not block the host (svgr_batch_plan_many)
     size_t pinned_bytes = 0;
+    // page-locked staging for a batch's input blob (svgr_batch_create, svgr_batch_set_transforms): packed straight into it and copied
+    // from it asynchronously -- a fresh pageable vector costs its page faults, its zero fill and the runtime's own staging copy
+    // (half of a cold frame's host time).  One upload at a time: `up_ev` marks the last copy enqueued from it.
+    void* up_stage = nullptr;
+    size_t up_stage_bytes = 0;
+    hipEvent_t up_ev = nullptr;
+    bool up_busy = false;
     int n_cu = 256;              // compute units: the tile kernel's persistent launch is sized by it
     void* trash = nullptr;       // 1 KiB of device memory nobody reads (TileArgs::trash)
     unsigned* tile_ctr = nullptr;  // two sets of eight tile counters (TileArgs::tile_ctr), used alternately by the launches of this stream
@@ -541,7 +548,15 @@ constexpr int FL_BLOCK = 256;     // (the waves are independent up to the last s
 // per segment repeat the upper levels for nothing (64 lanes: 39 against 28.8 us on the bench scene, round 4).  6 (a wave per
 // segment) when it does NOT -- a drawing of a few thousand segments, one rank's share of a large one: the launch then lasts as
 // long as its longest lane, and a lane of a 64-way cut has half the subtree (the tiger @ 2048: 31.5 us for 3 000 segments).
-template <bool EMIT, bool PLACED = false, int SUB = SVGR_FL_SUB>
+// SCAN (with EMIT, not PLACED): ONE traversal for a drawing whose edge places are not known yet -- a re-plan after
+// svgr_batch_set_transforms.  The counting flatten + k_seg_scan + the placed flatten become one launch: a workgroup counts its
+// lanes' pieces, finds where its segments' edges start by a decoupled look-back over the workgroups in front of it (`scan_state`:
+// per workgroup {1 | its own total} as soon as it is counted, {2 | the total of everything up to and including it} once known;
+// a wave reads 64 predecessors at a time), stores the edges there and leaves `seg_cnt / seg_off / lane_off` for the planned
+// renders that follow.  Workgroups are dispatched in index order, so the lowest unfinished one is always resident and finds every
+// predecessor finished: the chain cannot stall.  (A dead-man count ends a look-back that does not return all the same: error bit
+// 2, the staged plan takes over.)
+template <bool EMIT, bool PLACED = false, int SUB = SVGR_FL_SUB, bool SCAN = false>
 #ifndef SVGR_FL_WAVES
 #define SVGR_FL_WAVES 1
 #endif
@@ -553,8 +568,10 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
                                                  Owner own, int vr0, int n_bands, const unsigned* __restrict__ prow,
                                                  const int* __restrict__ seg_list, int n_list,
                                                  int* __restrict__ seg_cnt, const int* __restrict__ seg_off, int edge_cap,
-                                                 int* __restrict__ lane_off) {
+                                                 int* __restrict__ lane_off, int* __restrict__ seg_off_w = nullptr,
+                                                 unsigned long long* __restrict__ scan_state = nullptr) {
     static_assert(!PLACED || EMIT, "places are what an emitting pass takes");
+    static_assert(!SCAN || (EMIT && !PLACED), "the scanning pass counts, places and stores");
     // Where the edges go.  `seg_off` given (the renders and the plan's later passes): segment s owns the slots
     // [seg_off[s], seg_off[s + 1]) -- the exclusive prefix sums of the per-segment counts the plan's counting pass left in
     // `seg_cnt` -- and its lanes take them in curve order.  The edge array is then in (path, segment, curve) order whatever
@@ -699,7 +716,62 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
     }
     int base;
     bool fits;
-    if (seg_cnt || seg_off) {
+    if constexpr (SCAN) {
+        const int lane = threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+        constexpr int NWV = FL_BLOCK / 64;
+        __shared__ int s_wt[NWV];
+        __shared__ int s_base;
+        int wtot;
+        const int excl = wave_excl_scan(cnt, lane, wtot);
+        constexpr int SEGL = 1 << SUB;  // lanes per segment
+        const int seg_first = __shfl(excl, lane & ~(SEGL - 1)), seg_total = __shfl(excl + cnt, lane | (SEGL - 1)) - seg_first;
+        if (lane == 0) s_wt[wave] = wtot;
+        if (lane == 0 && wtot > 0) atomicAdd(&bd->shard[shard].cursor, wtot);   // (the shard cursors only count: their sum = the edges kept)
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { before += w < wave ? s_wt[w] : 0; all += s_wt[w]; }
+        if (wave == 0) {
+            const int me = (int)blockIdx.x;
+            if (lane == 0)
+                __hip_atomic_store(&scan_state[me], ((me == 0 ? 2ull : 1ull) << 32) | (unsigned long long)(unsigned)all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int acc = 0;
+            if (me > 0) {
+                int j0 = me - 1;
+                unsigned spins = 0;
+                bool dead = false;
+                for (;;) {
+                    const int j = j0 - lane;
+                    const unsigned long long sv = j >= 0 ? __hip_atomic_load(&scan_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 32);
+                    const unsigned status = (unsigned)(sv >> 32);
+                    const unsigned long long m2 = __ballot(status == 2u), m0 = __ballot(status == 0u);
+                    const int first2 = m2 ? __ffsll((long long)m2) - 1 : 64;   // the nearest predecessor whose running total is known
+                    const unsigned long long need = first2 >= 63 ? ~0ull : ((2ull << first2) - 1ull);
+                    if (m0 & need) {   // (somebody in front of it has not counted yet)
+                        if (++spins > (1u << 20)) { dead = true; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                        continue;
+                    }
+                    int tot;
+                    (void)wave_excl_scan(lane <= first2 ? (int)(unsigned)sv : 0, lane, tot);
+                    acc += tot;
+                    if (first2 < 64) break;
+                    j0 -= 64;
+                }
+                if (dead) { if (lane == 0) atomicOr(&bd->err, 2); acc = 0x3fffffff; }   // (nothing of this workgroup fits; the successors do not wait)
+                if (lane == 0)
+                    __hip_atomic_store(&scan_state[me], (2ull << 32) | (unsigned long long)(unsigned)(acc + all), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) s_base = acc;
+        }
+        __syncthreads();
+        const int wg_base = s_base;
+        base = wg_base + before + excl;
+        fits = base + cnt <= edge_cap && wg_base < 0x3fffffff;
+        if (seg_ok && sub == 0) { seg_cnt[seg] = seg_total; seg_off_w[seg] = wg_base + before + seg_first; }
+        if (seg_ok) lane_off[(size_t)seg * SEGL + sub] = excl - seg_first;
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) seg_off_w[n_segs] = wg_base + all;
+    } else if (seg_cnt || seg_off) {
         // this lane's place among the edges of its segment (the 32 lanes of a segment are half a wave), the segment's count
         const int lane = threadIdx.x & 63;
         int wtot;
@@ -3860,8 +3932,8 @@ struct svgr_batch {
     DevArr<uint8_t> seg_kind, path_rule;
     DevArr<int> seg_path;
     DevArr<unsigned char> in_dev;  // the one block the six input arrays above are views of
-    std::vector<char> in_host;     // its host image: source of the single asynchronous upload, alive as long as the batch
-    size_t o_segs = 0, o_m6 = 0, o_kind = 0, o_seg0 = 0;   // ... where its arrays start (the host-side size estimate of a first plan reads them)
+    std::vector<char> in_host;     // its host image, when the context's page-locked staging could not take it: source of the upload, alive as long as the batch
+    size_t o_m6 = 0;               // ... where the transforms start in it (svgr_batch_set_transforms)
     // Uploads never make the host wait for the STREAM (a document's walk enqueues one batch after the other and must stay
     // ahead of the device): what an asynchronous copy reads is a host copy kept by the batch, an event marks the last
     // upload enqueued, and only svgr_batch_destroy -- or the next upload into the same array -- waits, for that event alone.
@@ -3885,7 +3957,7 @@ struct svgr_batch {
     }
     // zeroed once per render: [BatchDev | per-path min/max keys | per-path row reach (multi-GPU)]
     DevArr<unsigned char> arena;
-    size_t arena_bytes = 0, off_pkeys = 0, off_prow = 0;
+    size_t arena_bytes = 0, off_pkeys = 0, off_prow = 0, off_scan = 0;
     // work arrays fully rewritten by every render
     DevArr<int> edge_path, bbox, band_start, band_count;
     DevArr<PathBin> bins;
@@ -3905,6 +3977,7 @@ struct svgr_batch {
     AddShards add_shards{};                 // where each shard's add slots live (the slabs of path p reserve in shard p % n)
     int64_t n_adds = 0;                     // add slots in all the shards
     bool count_adds_only = false;           // the plan's measuring run: k_path_build sizes the add lists, writes none
+    bool fl_scan = false;                   // this pass flattens in ONE traversal (k_flatten<.., SCAN>): a re-plan's single pass
     bool census_bbox = false;               // the two-pass plan's first pass: the counting flatten is followed by k_path_bbox (pairs, cells, slabs counted)
     bool deterministic = false;             // this pass runs for a SVGR_RENDER_DETERMINISTIC render
     // lay the add shards back to back: `need[k]` slots each plus slack (the sizes repeat from render to render except for
@@ -3930,6 +4003,7 @@ struct svgr_batch {
     DevArr<Slab> slabs;                     // work items of k_path_build (k_path_bbox)
     DevArr<int> slab_at;                    // per path: its first slab, heaviest paths first (staged plan; renders only)
     bool slab_at_valid = false;
+    bool slab_order_pending = false;        // svgr_batch_draw planned this batch and left the slab order to the first render that replays the plan
     std::vector<int> slab_at_host;
     int64_t n_slabs = 0;                    // ... the plan's count = the launch's grid
     DevArr<int> seg_cnt, seg_off;           // per segment: edges it flattens into (the plan's counting pass), their prefix sums
@@ -3977,11 +4051,13 @@ struct svgr_batch {
     BatchDev* bd() const { return (BatchDev*)arena.p; }
     unsigned long long* pkeys() const { return (unsigned long long*)(arena.p + off_pkeys); }
     unsigned* prow() const { return (unsigned*)(arena.p + off_prow); }
+    unsigned long long* scan_state() const { return (unsigned long long*)(arena.p + off_scan); }   // k_flatten<.., SCAN>: one word per workgroup
 
     int layout_arena() {
         off_pkeys = sizeof(BatchDev);
         off_prow = off_pkeys + sizeof(unsigned long long) * 4 * (size_t)n_paths;
-        arena_bytes = off_prow + sizeof(unsigned) * 2 * (size_t)n_paths;
+        off_scan = (off_prow + sizeof(unsigned) * 2 * (size_t)n_paths + 7) & ~(size_t)7;
+        arena_bytes = off_scan + sizeof(unsigned long long) * (((size_t)n_segs << 6) / FL_BLOCK + 2);   // (workgroups of the widest cut: 64 lanes per segment)
         arena_bytes = (arena_bytes + 255) & ~(size_t)255;
         arena_zeroed = false;  // (new size or new memory)
         return arena.ensure(arena_bytes);
@@ -4050,7 +4126,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                                    (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns,
                                    b->thr, (double*)nullptr, (int*)nullptr, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
                                    n_bands_vp, prow, seg_list, n_items, upto == 1 ? b->seg_cnt.p : (int*)nullptr, (const int*)nullptr, 0,
-                                   upto == 1 ? b->lane_off.p : (int*)nullptr);
+                                   upto == 1 ? b->lane_off.p : (int*)nullptr, (int*)nullptr, (unsigned long long*)nullptr);
             };
             if (fl_sub == 6) launch_cnt(k_flatten<false, false, 6>); else launch_cnt(k_flatten<false, false, 5>);
         }
@@ -4070,10 +4146,20 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                                (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
                                b->edges.p, b->edge_path.p, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
                                n_bands_vp, prow, seg_list, n_items, (int*)nullptr, (const int*)b->seg_off.p,
-                               cap_i32(std::min(b->edge_path.cap, b->edges.cap / 4)), places);
+                               cap_i32(std::min(b->edge_path.cap, b->edges.cap / 4)), places, (int*)nullptr, (unsigned long long*)nullptr);
         };
         const bool placed_fl = lane_places && b->lane_off.p && b->lane_off.cap >= ((size_t)ns << fl_sub);
-        if (fl_sub == 6) {
+        if (b->fl_scan) {
+            // ONE traversal: count, look back, store; leaves seg_cnt / seg_off / lane_off for the renders (needs: one GPU, no list)
+            auto launch_scan = [&](auto kern) {
+                hipLaunchKernelGGL(kern, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
+                                   (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
+                                   b->edges.p, b->edge_path.p, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
+                                   n_bands_vp, prow, seg_list, n_items, b->seg_cnt.p, (const int*)nullptr,
+                                   cap_i32(std::min(b->edge_path.cap, b->edges.cap / 4)), b->lane_off.p, b->seg_off.p, b->scan_state());
+            };
+            if (fl_sub == 6) launch_scan(k_flatten<true, false, 6, true>); else launch_scan(k_flatten<true, false, 5, true>);
+        } else if (fl_sub == 6) {
             if (placed_fl) launch_fl(k_flatten<true, true, 6>, b->lane_off.p); else launch_fl(k_flatten<true, false, 6>, (int*)nullptr);
         } else {
             if (placed_fl) launch_fl(k_flatten<true, true, 5>, b->lane_off.p); else launch_fl(k_flatten<true, false, 5>, (int*)nullptr);
@@ -4294,6 +4380,30 @@ int svgr_device_count(void) {
     return n;
 }
 
+// the context's page-locked upload staging, free to be written (the previous copy out of it has finished), at least `bytes` large;
+// nullptr when `bytes` is beyond what is worth pinning or the allocation fails: the caller then uploads from its own host copy
+static void* upload_stage(svgr_ctx* c, size_t bytes) {
+    constexpr size_t kMaxStage = 64u << 20;
+    if (bytes > kMaxStage) return nullptr;
+    if (c->up_busy && c->up_ev) { (void)hipEventSynchronize(c->up_ev); c->up_busy = false; }
+    if (c->up_stage_bytes < bytes) {
+        if (c->up_stage) (void)hipHostFree(c->up_stage);
+        c->up_stage = nullptr;
+        c->up_stage_bytes = 0;
+        const size_t want = std::min(std::max<size_t>(bytes + bytes / 2, 4u << 20), kMaxStage);
+        if (hipHostMalloc(&c->up_stage, want, hipHostMallocDefault) != hipSuccess) { c->up_stage = nullptr; (void)hipGetLastError(); return nullptr; }
+        c->up_stage_bytes = want;
+    }
+    if (!c->up_ev && hipEventCreateWithFlags(&c->up_ev, hipEventDisableTiming) != hipSuccess) { c->up_ev = nullptr; return nullptr; }
+    return c->up_stage;
+}
+static hipError_t upload_staged(svgr_ctx* c, void* dst, size_t bytes) {   // (`bytes` of the staging -> dst, on the context's stream)
+    hipError_t e = hipMemcpyAsync(dst, c->up_stage, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(c->up_ev, c->stream);
+    c->up_busy = true;
+    return e;
+}
+
 int svgr_init(int device_id, svgr_ctx** out) {
     if (!out) return fail(SVGR_E_INVALID, "svgr_init: out is NULL");
     *out = nullptr;
@@ -4324,6 +4434,10 @@ int svgr_init(int device_id, svgr_ctx** out) {
         delete c;
         return fail(SVGR_E_NOMEM, "out of device memory");
     }
+    // page-locked staging for the read-backs of svgr_batch_draw / svgr_batch_plan_many (grown on demand: a first frame should not pay for it)
+    if (hipHostMalloc(&c->pinned, 1u << 20, hipHostMallocDefault) == hipSuccess) c->pinned_bytes = 1u << 20;
+    else c->pinned = nullptr;
+    (void)upload_stage(c, 1);   // (the upload staging at its smallest size, 4 MiB: likewise)
     *out = c;
     return 0;
 }
@@ -4339,6 +4453,9 @@ int svgr_shutdown(svgr_ctx* ctx) {
     }
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->up_busy && ctx->up_ev) (void)hipEventSynchronize(ctx->up_ev);
+    if (ctx->up_stage) (void)hipHostFree(ctx->up_stage);
+    if (ctx->up_ev) (void)hipEventDestroy(ctx->up_ev);
     if (ctx->trash) (void)hipFree(ctx->trash);
     if (ctx->tile_ctr) (void)hipFree(ctx->tile_ctr);
     g_pool.close(ctx->id);  // (its cached blocks; what it still has out is freed on return)
@@ -4467,14 +4584,29 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
             return fail(SVGR_E_INVALID, "path %lld is marked clipped but path %lld is not a clip source", (long long)p, (long long)p - 1);
     }
     if (d->path_seg_off[0] != 0 || d->path_seg_off[d->n_paths] != d->n_segs) return fail(SVGR_E_INVALID, "path_seg_off does not span segs");
-    for (int64_t s = 0; s < d->n_segs; ++s) {
-        if (d->seg_kind[s] > 1) return fail(SVGR_E_INVALID, "unsupported path type: `%d`", (int)d->seg_kind[s]);  // S:945
-        int npts = d->seg_kind[s] == SVGR_SEG_CUBIC ? 8 : 4;
-        for (int k = 0; k < npts; ++k)
-            if (!std::isfinite(d->segs[8 * s + k])) return fail(SVGR_E_INVALID, "non-finite coordinate in segment %lld", (long long)s);
+    {
+        // (one pass without early exits -- the compiler vectorises it --; the slow loops below only name what it found)
+        auto nonfin = [](uint64_t x) -> uint64_t { return ((x >> 52) & 0x7ffu) == 0x7ffu; };
+        const uint64_t* u = (const uint64_t*)d->segs;
+        uint64_t bad = 0, bad_kind = 0;
+        for (int64_t s = 0; s < d->n_segs; ++s) {
+            const uint64_t lo = nonfin(u[8 * s]) | nonfin(u[8 * s + 1]) | nonfin(u[8 * s + 2]) | nonfin(u[8 * s + 3]);
+            const uint64_t hi = nonfin(u[8 * s + 4]) | nonfin(u[8 * s + 5]) | nonfin(u[8 * s + 6]) | nonfin(u[8 * s + 7]);
+            bad |= lo | (hi & (uint64_t)(d->seg_kind[s] == SVGR_SEG_CUBIC));
+            bad_kind |= (uint64_t)(d->seg_kind[s] > 1);
+        }
+        if (bad | bad_kind)
+            for (int64_t s = 0; s < d->n_segs; ++s) {
+                if (d->seg_kind[s] > 1) return fail(SVGR_E_INVALID, "unsupported path type: `%d`", (int)d->seg_kind[s]);  // S:945
+                int npts = d->seg_kind[s] == SVGR_SEG_CUBIC ? 8 : 4;
+                for (int k = 0; k < npts; ++k)
+                    if (!std::isfinite(d->segs[8 * s + k])) return fail(SVGR_E_INVALID, "non-finite coordinate in segment %lld", (long long)s);
+            }
+        const uint64_t* um = (const uint64_t*)d->path_m6;
+        uint64_t bad_m = 0;
+        for (int64_t i = 0; i < 6 * d->n_paths; ++i) bad_m |= nonfin(um[i]);
+        if (bad_m) return fail(SVGR_E_INVALID, "non-finite transform");
     }
-    for (int64_t i = 0; i < 6 * d->n_paths; ++i)
-        if (!std::isfinite(d->path_m6[i])) return fail(SVGR_E_INVALID, "non-finite transform");
     if (!(d->flatness > 0.0) || !std::isfinite(d->flatness)) return fail(SVGR_E_INVALID, "flatness must be positive");
     if (d->viewport[2] > 0 && (d->viewport[3] <= 0 || d->viewport[2] > (1 << 24) || d->viewport[3] > (1 << 24) ||
                                std::llabs(d->viewport[0]) > (1 << 28) || std::llabs(d->viewport[1]) > (1 << 28)))
@@ -4498,9 +4630,11 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_segs = 0, o_m6 = al(o_segs + ns * 64), o_paint = al(o_m6 + np * 48), o_spath = al(o_paint + np * 32),
                  o_kind = al(o_spath + ns * 4), o_rule = al(o_kind + ns), o_seg0 = al(o_rule + np), total = al(o_seg0 + (np + 1) * 4);
-    b->in_host.resize(total);
-    b->o_segs = o_segs; b->o_m6 = o_m6; b->o_kind = o_kind; b->o_seg0 = o_seg0;
-    char* const hb = b->in_host.data();
+    // (packed into the context's page-locked staging when there is one; else into a host image the batch keeps)
+    char* hb = (char*)upload_stage(ctx, total);
+    const bool staged = hb != nullptr;
+    if (!staged) { b->in_host.resize(total); hb = b->in_host.data(); }
+    b->o_m6 = o_m6;
     memcpy(hb + o_segs, d->segs, ns * 64);
     memcpy(hb + o_m6, d->path_m6, np * 48);
     memcpy(hb + o_paint, d->path_paint, np * 32);
@@ -4517,8 +4651,12 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
     }
     rc = b->in_dev.ensure(total);
     if (!rc) {
-        hipError_t e = hipMemcpyAsync(b->in_dev.p, hb, total, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = b->note_upload(ctx->stream);
+        hipError_t e;
+        if (staged) e = upload_staged(ctx, b->in_dev.p, total);
+        else {
+            e = hipMemcpyAsync(b->in_dev.p, hb, total, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = b->note_upload(ctx->stream);
+        }
         if (e != hipSuccess) rc = fail(SVGR_E_HIP, "upload: %s", hipGetErrorString(e));
     }
     if (!rc) {
@@ -4565,20 +4703,23 @@ int svgr_batch_set_transforms(svgr_batch* b, const double* path_m6) {
     for (int64_t i = 0; i < 6 * b->n_paths; ++i)
         if (!std::isfinite(path_m6[i])) return fail(SVGR_E_INVALID, "non-finite transform");
     HIPCHK(enter_ctx(b->ctx));
-    b->wait_uploads();
-    // (the batch's host image stays current: it is the source of this upload, and what a first plan's size estimate reads)
-    void* const hm = b->in_host.data() + b->o_m6;
-    memcpy(hm, path_m6, sizeof(double) * 6 * (size_t)b->n_paths);
-    HIPCHK(hipMemcpyAsync(b->path_m6.p, hm, sizeof(double) * 6 * b->n_paths, hipMemcpyHostToDevice, b->ctx->stream));
-    HIPCHK(b->note_upload(b->ctx->stream));
-    b->planned = false; b->slab_at_valid = false;
+    const size_t mbytes = sizeof(double) * 6 * (size_t)b->n_paths;
+    if (void* hs = upload_stage(b->ctx, mbytes)) {
+        memcpy(hs, path_m6, mbytes);
+        HIPCHK(upload_staged(b->ctx, b->path_m6.p, mbytes));
+    } else {
+        b->wait_uploads();
+        HIPCHK(hipMemcpyAsync(b->path_m6.p, b->keep(path_m6, mbytes), mbytes, hipMemcpyHostToDevice, b->ctx->stream));
+        HIPCHK(b->note_upload(b->ctx->stream));
+    }
+    b->planned = false; b->slab_at_valid = false; b->slab_order_pending = false;
     return 0;
 }
 
 int svgr_batch_set_bands(svgr_batch* b, int rank, int world, int strip_bands) {
     if (!b || world <= 0 || rank < 0 || rank >= world || strip_bands <= 0) return fail(SVGR_E_INVALID, "bad band selection");
     b->own = Owner{rank, world, strip_bands};
-    b->planned = false; b->slab_at_valid = false;  // the edge / record capacities are per rank
+    b->planned = false; b->slab_at_valid = false; b->slab_order_pending = false;  // the edge / record capacities are per rank
     b->sized = false;
     b->n_seg_list = -1;  // ... and so is the list of segments to flatten
     return 0;
@@ -4734,8 +4875,15 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr, bool again = false
         if (b->n_edges <= 0 || b->n_pb <= 0 || b->n_cells <= 0 || b->n_slabs <= 0 || b->edge_path.cap < (size_t)b->n_edges) return 0;
         int rc = b->layout_arena();
         if (rc) return rc;
-        if ((rc = run_geometry(b, 1, true))) return rc;
-        if ((rc = run_geometry(b, 4, true))) return rc;
+        // ONE flatten traversal (k_flatten<.., SCAN>: count, look-back, store) when the last plan left arrays for its by-products;
+        // else the counting pass + prefix sums in front of the storing one
+        const bool scan = !b->safe_path && getenv("SVGR_NO_SCAN_FLATTEN") == nullptr && b->seg_cnt.cap >= (size_t)ns + 1 &&
+                          b->seg_off.cap >= (size_t)ns + 2 && b->lane_off.cap >= ((size_t)ns << b->fl_sub) + 1;
+        if (!scan && (rc = run_geometry(b, 1, true))) return rc;
+        b->fl_scan = scan;
+        rc = run_geometry(b, 4, true);
+        b->fl_scan = false;
+        if (rc) return rc;
         if ((rc = issue_readback(b, true, staging))) return rc;
         return 1;
     }
@@ -4809,6 +4957,7 @@ static int spec_finish(svgr_batch* b) {
     if (int rc = eval_dev_err(b->host_bd.err, &cap_bits)) return rc;
     if (cap_bits) return 0;
     b->n_entries = b->host_bd.entry_cursor;
+    b->n_pb = b->host_bd.pb_cursor;    // (the pass ran on capacities: the statistics report what it found)
     b->n_slabs = b->host_bd.slab_cursor;
     b->n_edges_live = 0;
     for (int k = 0; k < NSH; ++k) b->n_edges_live += b->host_bd.shard[k].cursor;
@@ -4917,7 +5066,7 @@ int svgr_batch_plan_many(svgr_batch** batches, int64_t n) {
         for (int64_t i = 0; i < n; ++i) {
             svgr_batch* b = batches[i];
             HIPCHK(enter_ctx(b->ctx));
-            b->planned = false; b->slab_at_valid = false;
+            b->planned = false; b->slab_at_valid = false; b->slab_order_pending = false;
             b->geometry_fresh = false; b->geometry_current = false;
             const int is = no_spec ? 0 : spec_issue(b, (char*)b->ctx->pinned + stage_off[(size_t)i]);
             if (is < 0) return is;
@@ -5012,7 +5161,10 @@ static double now_ms() {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
 }
-static int plan_two_pass(svgr_batch* b) {
+// (`staging`: page-locked memory for pass 2's read-back -- svgr_batch_draw puts the tile kernel behind the pass and waits once;
+//  two_pass_finish then reads what arrived)
+static int two_pass_finish(svgr_batch* b, const void* staging);
+static int two_pass_issue(svgr_batch* b, void* staging) {
     const double t_0 = now_ms();
     if (!b->has_vp || b->own.world > 1 || b->n_segs <= 0 || b->vp[2] <= 0 || b->vp[3] <= 0) return 0;
     if (getenv("SVGR_NO_TWO_PASS_PLAN")) return 0;   // (tests: the staged plan stays exercised)
@@ -5103,23 +5255,28 @@ static int plan_two_pass(svgr_batch* b) {
     }
     const double t_3 = now_ms();
     if ((rc = run_geometry(b, 4, true))) return rc;
-    const double t_4 = now_ms();
+    if ((rc = issue_readback(b, true, staging))) return rc;
+    if (getenv("SVGR_DBG_PLAN"))
+        fprintf(stderr, "[plan] two passes, ms: pass 1 issued %.3f, drained %.3f, buffers sized %.3f, pass 2 issued %.3f | edges %lld, rows crossed %lld, pairs %lld, cells %lld, slabs %lld, add slots %lld, longest band list %d\n",
+                t_1 - t_0, t_2 - t_1, t_3 - t_2, now_ms() - t_3, n_edges, rows_x, (long long)b->n_pb, (long long)b->n_cells, (long long)b->n_slabs, (long long)b->n_adds, longest);
+    return 1;
+}
+// pass 2 has drained: validate it.  1 planned, 0 fall back (a guess was too small), < 0 error
+static int two_pass_finish(svgr_batch* b, const void* staging) {
+    if (staging) take_readback(b, staging);
+    HIPCHK(hipGetLastError());
+    if (b->host_bd.err) b->invalidate_work();
     int cap_bits = 0;
-    if ((rc = check_dev_err(b, &cap_bits, true, true))) return rc;
-    const double t_5 = now_ms();
+    if (int rc = eval_dev_err(b->host_bd.err, &cap_bits)) return rc;
     if (getenv("SVGR_DBG_PLAN")) {
-        fprintf(stderr, "[plan] two passes, ms: pass 1 issued %.3f, drained %.3f, buffers sized %.3f, pass 2 issued %.3f, drained %.3f\n", t_1 - t_0, t_2 - t_1, t_3 - t_2,
-                t_4 - t_3, t_5 - t_4);
         long long a = 0;
         for (int k = 0; k < NSH; ++k) a += b->host_bd.shard[k].add_cursor;
-        fprintf(stderr, "[plan] two passes: capacity bits %d | edges %lld, rows crossed %lld, pairs %lld, cells %lld, slabs %lld, adds %lld of %lld, longest band list %d\n",
-                cap_bits, n_edges, rows_x, (long long)b->n_pb, (long long)b->n_cells, (long long)b->n_slabs, a, (long long)b->n_adds, longest);
+        fprintf(stderr, "[plan] two passes: capacity bits %d | adds %lld of %lld\n", cap_bits, a, (long long)b->n_adds);
     }
     if (cap_bits) return 0;
     b->n_entries = b->host_bd.entry_cursor;
     b->n_edges_live = b->n_edges;
     b->n_bsegs = b->host_bd.bseg_cursor;
-    if ((rc = plan_slab_order(b))) return rc;
     b->planned = true;
     b->sized = true;
     for (int k = 0; k < 4; ++k) b->sized_vp[k] = b->vp[k];
@@ -5128,10 +5285,20 @@ static int plan_two_pass(svgr_batch* b) {
     return 1;
 }
 
+static int plan_two_pass(svgr_batch* b) {
+    const int is = two_pass_issue(b, nullptr);
+    if (is <= 0) return is;
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    const int fin = two_pass_finish(b, nullptr);
+    if (fin <= 0) return fin;
+    if (int rc = plan_slab_order(b)) return rc;
+    return 1;
+}
+
 static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
     if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
     HIPCHK(enter_ctx(b->ctx));
-    b->planned = false; b->slab_at_valid = false;
+    b->planned = false; b->slab_at_valid = false; b->slab_order_pending = false;
     b->geometry_fresh = false; b->geometry_current = false;
     {
         const bool no_spec = getenv("SVGR_NO_SPECULATIVE_PLAN") != nullptr;  // (tests exercise both planners)
@@ -5143,7 +5310,7 @@ static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
         const int tp = plan_two_pass(b);
         if (tp < 0) return tp;
         if (tp > 0) return 0;
-        b->planned = false; b->slab_at_valid = false;
+        b->planned = false; b->slab_at_valid = false; b->slab_order_pending = false;
         b->geometry_fresh = false; b->geometry_current = false;
     }
     if (int rc = b->layout_arena()) return rc;
@@ -5318,7 +5485,7 @@ static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path
     HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
     hipLaunchKernelGGL(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
                        (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr, (double*)nullptr, (int*)nullptr, b->shards,
-                       b->pkeys(), b->bd(), whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (const int*)nullptr, 0, (int*)nullptr);
+                       b->pkeys(), b->bd(), whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (int*)nullptr, (unsigned long long*)nullptr);
     BatchDev counts;
     HIPCHK(hipMemcpyAsync(&counts, b->bd(), sizeof counts, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -5342,7 +5509,7 @@ static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_flatten<true>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
                            (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr, d_edges, d_path, sh, b->pkeys(), b->bd(),
-                           whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (const int*)nullptr, 0, (int*)nullptr);
+                           whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (int*)nullptr, (unsigned long long*)nullptr);
         e = hipMemcpyAsync(edges, d_edges, sizeof(double) * 4 * (size_t)total, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && edge_path) e = hipMemcpyAsync(edge_path, d_path, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -5437,6 +5604,10 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
     if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
     if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan must run before svgr_batch_render");
     if (out_kind < 0 || out_kind > 5) return fail(SVGR_E_INVALID, "unknown output kind %d", out_kind);
+    if (b->slab_order_pending && !b->geometry_fresh) {   // (a replay of a plan svgr_batch_draw made: its places now, once)
+        b->slab_order_pending = false;
+        if (int rc = plan_slab_order(b)) return rc;
+    }
     const bool layers = out_kind == SVGR_OUT_MASKS_F64 || out_kind == SVGR_OUT_FILLS_F64;  // one mask / fill layer per path, back to back
     if (layers) out_kind = out_kind == SVGR_OUT_MASKS_F64 ? SVGR_OUT_MASK_F64 : SVGR_OUT_FILL_F64;
     const bool single = out_kind >= 2;
@@ -5639,6 +5810,81 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
     }
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+// page-locked staging of at least `bytes` for this context's read-backs (the stream is drained before a smaller one is replaced)
+static int ensure_pinned(svgr_ctx* c, size_t bytes) {
+    if (c->pinned_bytes >= bytes) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    c->pinned = nullptr;
+    c->pinned_bytes = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 1u << 20);
+    HIPCHK(hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+    c->pinned_bytes = want;
+    return 0;
+}
+
+// Plan (when the batch has no valid plan) AND render, behind ONE wait: what a caller pays for a frame with new geometry -- the
+// reference's only mode (every Path.mask flattens and rasterises from scratch, S:948-957).  svgr_batch_plan + svgr_batch_render
+// wait for the plan's last pass, sort the slabs on the host, and only then launch the tile kernel; here the tile kernel is
+// enqueued right behind the plan's full geometry pass (it reads nothing but what that pass leaves, and a pass whose capacities did
+// not hold has written nothing outside them), the pass's scalars and bboxes come back through page-locked memory, and the
+// call waits once, at its end, to validate them.  A batch planned before (svgr_batch_set_transforms) takes the single pass with
+// ONE flatten traversal (k_flatten<.., SCAN>), a new one the two-pass plan (census, then everything).  When a guess did not hold
+// the staged plan and an ordinary render follow.  The slab order of the plan is made by the first render that replays it.
+// On return the picture is in `out` (the stream has drained) and the batch is planned.
+static int batch_draw_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags) {
+    if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
+    HIPCHK(enter_ctx(b->ctx));
+    hipStream_t st = b->ctx->stream;
+    if (!b->planned) {
+        const bool canvas = out_kind == SVGR_OUT_CANVAS_F32 || out_kind == SVGR_OUT_CANVAS_F64;
+        const bool fast = canvas && b->has_vp && b->own.world <= 1 && b->n_segs > 0 && !(flags & (SVGR_RENDER_TIMED | SVGR_RENDER_DETERMINISTIC)) &&
+                          getenv("SVGR_NO_SPECULATIVE_PLAN") == nullptr && getenv("SVGR_NO_FUSED_DRAW") == nullptr;
+        int issued = 0;   // 1: the re-plan's single pass, 2: the two-pass plan's second pass
+        if (fast) {
+            const size_t stage_bytes = sizeof(BatchDev) + 16 * (size_t)b->n_paths + 256;
+            if (int rc = ensure_pinned(b->ctx, stage_bytes)) return rc;
+            b->slab_at_valid = false; b->slab_order_pending = false;
+            b->geometry_fresh = false; b->geometry_current = false;
+            int is = spec_issue(b, b->ctx->pinned, true);                 // (the buffers of the batch's last plan as the guesses)
+            if (is == 0) is = spec_issue(b, b->ctx->pinned, false);      // (a small batch: size models)
+            if (is < 0) return is;
+            if (is > 0) issued = 1;
+            else {
+                is = two_pass_issue(b, b->ctx->pinned);
+                if (is < 0) return is;
+                if (is > 0) issued = 2;
+            }
+        }
+        if (issued) {
+            // the tile kernel right behind the pass: the batch counts as planned with that pass's geometry until the pass is validated
+            b->planned = true; b->geometry_fresh = true; b->geometry_current = true;
+            int rc = batch_render_impl(b, out, out_kind, flags, nullptr);
+            b->planned = false; b->geometry_fresh = false; b->geometry_current = false;
+            hipError_t e = hipStreamSynchronize(st);
+            if (rc) return rc;
+            HIPCHK(e);
+            int fin;
+            if (issued == 1) { take_readback(b, b->ctx->pinned); HIPCHK(hipGetLastError()); fin = spec_finish(b); }
+            else fin = two_pass_finish(b, b->ctx->pinned);
+            if (fin < 0) return fin;
+            if (fin > 0) {
+                b->geometry_fresh = false;          // (consumed by the tile kernel above)
+                b->slab_order_pending = b->n_segs > 4096;   // (large batches: k_path_build's work list heaviest first, as svgr_batch_plan leaves it)
+                return 0;
+            }
+            b->planned = false; b->slab_at_valid = false; b->slab_order_pending = false;
+        }
+        if (int rc = batch_plan_impl(b, issued == 1)) return rc;
+    }
+    if (int rc = batch_render_impl(b, out, out_kind, flags, nullptr)) return rc;
+    HIPCHK(hipStreamSynchronize(st));
+    return check_dev_err(b, nullptr, false);
+}
+int svgr_batch_draw(svgr_batch* b, svgr_buf* out, int out_kind, unsigned flags) {
+    return abi_guard("svgr_batch_draw", [&]() { return batch_draw_impl(b, out, out_kind, flags); });
 }
 
 int svgr_batch_timings(svgr_batch* b, int* n_renders, double* ms_total, double* ms_geometry, double* ms_tile) {

@@ -119,7 +119,7 @@ def test_abi_exports_every_declared_symbol():
     missing = [name for name in sorted(declared) if not hasattr(lib, name)]
     assert not missing, missing
     assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
-    assert lib.svgr_abi_version() == 5
+    assert lib.svgr_abi_version() == 6
     assert lib.svgr_tile_rows() in (4, 8, 16, 32, 64) and lib.svgr_tile_cols() % 16 == 0
 
 
