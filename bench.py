@@ -203,6 +203,157 @@ def bench_scene(args):
     }))
 
 
+def baseline_configs(ctx, steps=5):
+    """The other BASELINE.json configurations in the driver's one line: 2 tiger @2048, 3 material-design @4096,
+    5 icons.svg @4096 through `Scene.render` (the drop-in boundary: host walk + every launch, result resident in HBM), and 4's
+    drawing (10 000 paths @8192) on this one GPU.  Per configuration:
+      ms_per_step   the DEFAULT render: nothing kept between renders (the retained-render cache is opt-in), mean of `steps`
+      warm_ms       the same render with the opt-in cache on (`set_render_cache`: leaf analysis and built + planned batches kept)
+      device_ms     DEVICE time of one warm render: its launches queued up behind a hold of the stream and run back to back
+                    (svgr_measure_begin / _end: HIP events on the library's stream; an upper bound if the render waits for the
+                    device somewhere in the middle)
+      launches      kernel launches of one default render / of one warm render (the library's own count)
+      parity        the picture against pins of the REFERENCE's own render at this size (tests/golden, sparse: 16-64 k values of
+                    the full canvas; float32 contract) -- config 4: rows of the canvas against the CPU oracle
+    The reference prints one wall-clock figure per render (S:3854-3864): BASELINE.md holds those."""
+    import numpy as np
+
+    import svgrasterize_amd as S
+    from svgrasterize_amd import _abi, scenedump, synth
+
+    out = []
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0)
+
+    def contract(got, ref32):
+        ref32 = np.asarray(ref32, dtype=np.float32)
+        a = np.abs(ref32)
+        ulp = np.maximum((np.nextafter(a, np.float32(np.inf)) - a).astype(np.float64), 2.0 ** -24)
+        err = np.abs(np.asarray(got, dtype=np.float64) - ref32.astype(np.float64))
+        return {"values": int(err.size), "bad": int((err > ulp).sum()), "max_err": float(err.max(initial=0.0))}
+
+    scenes = [("tiger2048", "scene_tiger.npz", "config 2: Ghostscript tiger @2048x2048 (182 solid fills incl. pre-stroked outlines)"),
+              ("material4096", "scene_material.npz", "config 3: demo/material-design.svg @4096x4096 (989 fills, 935 clips)"),
+              ("icons4096", "scene_icons4096.npz", "config 5: demo/icons.svg @4096x1051 (431 gradient fills, 36 blurs, 123 opacity groups)")]
+    for name, fname, desc in scenes:
+        rec = {"config": name, "workload": desc}
+        try:
+            scene, info, pins = scenedump.load_scene(os.path.join(ROOT, "tests", "golden", fname))
+            h, w = info["full"]["size"]
+            rec["canvas"] = [int(h), int(w)]
+
+            def step():
+                layer, _hull = scene.render(tr, viewport=[0, 0, h, w], linear_rgb=False)
+                layer._device()
+                return layer
+
+            S.set_render_cache(0)
+            S.clear_render_cache()
+            step()
+            ctx.sync()
+            ts = []
+            for _ in range(steps):
+                ctx.sync()
+                t0 = time.perf_counter()
+                step()
+                ctx.sync()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            n0 = ctx.launches()
+            step()
+            ctx.sync()
+            launches = ctx.launches() - n0
+            S.set_render_cache(4)
+            step()
+            ctx.sync()
+            tw = []
+            for _ in range(steps):
+                ctx.sync()
+                t0 = time.perf_counter()
+                step()
+                ctx.sync()
+                tw.append((time.perf_counter() - t0) * 1e3)
+            n0 = ctx.launches()
+            ctx.measure_begin(max(4.0 * (sum(tw) / len(tw)), 3.0))
+            layer = step()
+            dev_ms = ctx.measure_end()
+            warm_launches = ctx.launches() - n0 - 1   # (the hold is a launch)
+            rec.update({"ms_per_step": round(sum(ts) / len(ts), 3), "best_ms": round(min(ts), 3), "warm_ms": round(sum(tw) / len(tw), 3),
+                        "device_ms": round(dev_ms, 3), "launches": int(launches), "warm_launches": int(warm_launches),
+                        "canvas_mpixels_per_s": round(h * w / (sum(ts) / len(ts)) / 1e3, 1)})
+            got = layer.to_canvas_f32(h, w).reshape(-1, 4)[pins["full_idx"]]
+            par = contract(got, pins["full_val"])
+            par["what"] = ("pins of the REFERENCE's own render of this document at this size (sha256 of its float32 canvas "
+                           f"{str(info['full'].get('sha256_f32', ''))[:16]})")
+            rec["parity"] = par
+        except Exception as exc:  # noqa: BLE001
+            rec["error"] = repr(exc)
+        finally:
+            S.set_render_cache(0)
+            S.clear_render_cache()
+        out.append(rec)
+    # config 4's drawing on ONE GPU (its 8-GPU sharding is `bench.py --gpus 8`)
+    rec = {"config": "synth8192", "workload": "config 4: synthetic 10 000 random closed cubic paths @ 8192x8192 on ONE GPU (sharded over N: bench.py --gpus N)"}
+    try:
+        from oracle import oracle as orc
+
+        sc = synth.make_scene(8192, 10000)
+        rows, cols = int(sc["viewport"][2]), int(sc["viewport"][3])
+        rec["canvas"] = [rows, cols]
+        b = _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"], viewport=sc["viewport"])
+        outb = ctx.alloc(rows * cols * 16)
+        flags = _abi.RENDER_CLIP01
+        ctx.sync()
+        t0 = time.perf_counter()
+        b.draw(outb, _abi.OUT_CANVAS_F32, flags)
+        first_ms = (time.perf_counter() - t0) * 1e3
+        st = b.stats
+        m6 = np.array(sc["path_m6"], dtype=np.float64, copy=True)
+        tn = []
+        for i in range(steps):           # frames with new geometry: the reference's mode (default: nothing replayed)
+            m = m6.copy()
+            m[:, 2] += 0.125 * (i + 1)
+            ctx.sync()
+            t0 = time.perf_counter()
+            b.set_transforms(m)
+            b.draw(outb, _abi.OUT_CANVAS_F32, flags)
+            tn.append((time.perf_counter() - t0) * 1e3)
+        b.set_transforms(m6)
+        b.draw(outb, _abi.OUT_CANVAS_F32, flags)
+        for _ in range(3):
+            b.render(outb, _abi.OUT_CANVAS_F32, flags)
+        ctx.sync()
+        b.timings()
+        n0 = ctx.launches()
+        t0 = time.perf_counter()
+        k = 4 * steps
+        for i in range(k):
+            b.render(outb, _abi.OUT_CANVAS_F32, flags | (_abi.RENDER_TIMED if i % 4 == 0 else 0))
+        ctx.sync()
+        warm = (time.perf_counter() - t0) / k * 1e3
+        launches = (ctx.launches() - n0) // k
+        tm = b.timings()
+        rec.update({"ms_per_step": round(sum(tn) / len(tn), 4), "first_frame_ms": round(first_ms, 4), "warm_ms": round(warm, 4),
+                    "device_ms": round(tm["ms_total"] / max(tm["n"], 1), 4), "launches": 6, "warm_launches": int(launches),
+                    "path_pixels": int(st.path_pixels), "edges": int(st.n_edges),
+                    "value_warm_mpixels_per_s": round(int(st.path_pixels) / warm / 1e3, 1),
+                    "what": "ms_per_step: set_transforms + svgr_batch_draw (a frame with new geometry); warm_ms: the planned replay; device_ms: HIP events around a replay"})
+        acc = {"values": 0, "bad": 0, "max_err": 0.0}
+        pres = synth.presentation_segs(sc)
+        got_all = outb.download((rows, cols, 4), np.float32)
+        for r_lo in (0, 4032, 8064):
+            got = got_all[r_lo:r_lo + 128]
+            ref_s, _P, _E = orc.render_solid(pres, sc["seg_kind"], sc["path_seg_off"], sc["path_rule"], sc["path_paint"],
+                                             (int(sc["viewport"][0]) + r_lo, int(sc["viewport"][1]), 128, cols), clip01=True)
+            c = contract(got, ref_s.astype(np.float32))
+            acc["values"] += c["values"]; acc["bad"] += c["bad"]; acc["max_err"] = max(acc["max_err"], c["max_err"])
+        acc["what"] = "rows 0-127, 4032-4159, 8064-8191 of a replayed frame against the CPU oracle's render of those rows (the reference's viewport cropping, S:968-971)"
+        rec["parity"] = acc
+        b.destroy()
+    except Exception as exc:  # noqa: BLE001
+        rec["error"] = repr(exc)
+    out.append(rec)
+    return out
+
+
 def cpu_baseline(sc, budget_paths: int | None = None, strips_only: bool = False):
     """The CPU oracle (C restatement of the reference passes, oracle/svgr_oracle.c) timed on this
     host, single thread, on the same scene (or its first `budget_paths` paths).  `strips_only`: just the canvas, rendered as
@@ -486,6 +637,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, help="default: synth4096 on one GPU, synth8192 (config 4) on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the `configs` array (the other BASELINE configurations)")
     ap.add_argument("--no-companions", action="store_true", help="N > 1: skip the single-GPU reference and the weak-scaling run")
     ap.add_argument("--cpu-paths", type=int, default=None, help="limit the CPU baseline to the first N paths")
     ap.add_argument("--time-every", type=int, default=4,
@@ -683,14 +835,16 @@ def main():
                 cb.render(out, _abi.OUT_CANVAS_F32, flags)
                 ctx.sync()
                 t_two += time.perf_counter() - r0
-            reps_d, t_replan = 10, 0.0
+            reps_d, t_replan, frames = 10, 0.0, []
             for i in range(reps_d):         # the frame with new geometry: set_transforms + svgr_batch_draw (one wait inside)
                 m6p = moved(reps + i)
                 ctx.sync()
                 r0 = time.perf_counter()
                 cb.set_transforms(m6p)
                 cb.draw(out, _abi.OUT_CANVAS_F32, flags)
-                t_replan += time.perf_counter() - r0
+                frames.append(time.perf_counter() - r0)
+                t_replan += frames[-1]
+            extras["replan_frames_ms"] = [round(f * 1e3, 4) for f in frames]
             replan_m6 = m6p
             replan_canvas = out.download((own_rows, cols, 4), np.float32)   # (the last re-planned frame: checked against the oracle below)
             extras["replan_ms"] = round(t_replan / reps_d * 1e3, 4)
@@ -843,6 +997,13 @@ def main():
                 _rc, _vis, line["cpu_baseline"] = cpu_baseline(sc, args.cpu_paths or n_sample)
             except Exception as exc:  # noqa: BLE001
                 line["cpu_baseline"] = {"error": repr(exc)}
+        if world == 1 and args.workload == "synth4096" and not args.no_configs:
+            c0 = time.perf_counter()
+            try:
+                line["configs"] = baseline_configs(ctx)
+            except Exception as exc:  # noqa: BLE001
+                line["configs"] = {"error": repr(exc)}
+            line["configs_seconds"] = round(time.perf_counter() - c0, 1)
         line["roofline"] = roofline_block(tile_ms, geo_ms, tm["n"], every, P_rank, E_rank, own_rows * cols * 16, counters, counters_file,
                                           visible=visible)
         line.update(extras)

@@ -34,6 +34,7 @@ extern "C" {
  * 3: SVGR_RENDER_SAME_GEOMETRY, SVGR_OUT_FILLS_F64, svgr_layer_convert_to, svgr_layer_scale_to, svgr_batch_render_windows added
  *    (nothing changed or removed)
  * 4: svgr_hash_buffers added (nothing changed or removed)
+ * 6: svgr_batch_draw, svgr_measure_begin / _end / _launches added (nothing changed or removed)
  * 5: svgr_layer_compose_over / _in, svgr_layer_convert_scale_to, svgr_layer_convolve_ops, svgr_batch_get_extents added (nothing changed
  *    or removed) */
 #define SVGR_ABI_VERSION 6
@@ -105,6 +106,14 @@ int svgr_shutdown(svgr_ctx* ctx);
 int svgr_set_stream(svgr_ctx* ctx, void* hip_stream);
 int svgr_sync(svgr_ctx* ctx);
 int svgr_device_name(svgr_ctx* ctx, char* out, size_t cap);
+/* Measurement helpers (bench.py; the reference prints one wall-clock figure per render, S:3854-3864 -- these split it).
+ * svgr_measure_begin holds the context's stream busy for `hold_ms` (0: not at all) and marks the start behind the hold;
+ * svgr_measure_end marks the end, waits for it and returns the milliseconds of DEVICE time between the marks: what the caller
+ * enqueued in between has queued up behind the hold and run back to back, however long the host took to issue it (less than the
+ * hold).  svgr_measure_launches: kernel launches the library has made in this process so far. */
+int svgr_measure_begin(svgr_ctx* ctx, double hold_ms);
+int svgr_measure_end(svgr_ctx* ctx, double* ms);
+int svgr_measure_launches(uint64_t* out);
 /* Host only, no GPU involved: a 64-bit hash over the bytes of `n` host buffers (ptrs[i], nbytes[i]), in order.  What the
  * caller's retained renders guard themselves with: the reference's Scene.render (S:649-752) keeps nothing between calls, so a
  * paint or a segment array edited in place is simply drawn with its new values; a caller that keeps built batches between

@@ -76,6 +76,9 @@ _PROTOS = {
     "svgr_set_stream": (C.c_int, [_P, _P]),
     "svgr_sync": (C.c_int, [_P]),
     "svgr_device_name": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
+    "svgr_measure_begin": (C.c_int, [_P, C.c_double]),
+    "svgr_measure_end": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "svgr_measure_launches": (C.c_int, [C.POINTER(C.c_uint64)]),
     "svgr_buf_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "svgr_buf_wrap": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(_P)]),
     "svgr_buf_free": (C.c_int, [_P, _P]),
@@ -214,6 +217,20 @@ class Context:
 
     def sync(self):
         _check(self.lib.svgr_sync(self.handle))
+
+    # -- measurement helpers (bench.py) -------------------------------------------------------
+    def measure_begin(self, hold_ms: float = 0.0):
+        _check(self.lib.svgr_measure_begin(self.handle, float(hold_ms)))
+
+    def measure_end(self) -> float:
+        ms = C.c_double()
+        _check(self.lib.svgr_measure_end(self.handle, C.byref(ms)))
+        return ms.value
+
+    def launches(self) -> int:
+        n = C.c_uint64()
+        _check(self.lib.svgr_measure_launches(C.byref(n)))
+        return int(n.value)
 
     def set_stream(self, hip_stream: int):
         _check(self.lib.svgr_set_stream(self.handle, _P(hip_stream)))

@@ -53,6 +53,11 @@
 
 using namespace svgr;
 
+// every kernel launch of the library goes through this: a per-process count of them (svgr_measure_launches: what bench.py's
+// `launches` per render is) -- the stream itself has no such counter
+static std::atomic<unsigned long long> g_n_launches{0};
+#define SVGR_LAUNCH(...) do { g_n_launches.fetch_add(1, std::memory_order_relaxed); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 // ======================================================================================
 // tile geometry
 // ======================================================================================
@@ -159,6 +164,7 @@ struct svgr_ctx {
     size_t up_stage_bytes = 0;
     hipEvent_t up_ev = nullptr;
     bool up_busy = false;
+    hipEvent_t meas_ev[2] = {nullptr, nullptr};   // svgr_measure_begin / _end
     int n_cu = 256;              // compute units: the tile kernel's persistent launch is sized by it
     void* trash = nullptr;       // 1 KiB of device memory nobody reads (TileArgs::trash)
     unsigned* tile_ctr = nullptr;  // two sets of eight tile counters (TileArgs::tile_ctr), used alternately by the launches of this stream
@@ -741,6 +747,8 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
                 unsigned spins = 0;
                 bool dead = false;
                 for (;;) {
+                    // (one window of 64 predecessors per step; two per step with both loads in flight and no pause between polls measured
+                    //  SLOWER, 55 against 49 us: the polls of a thousand resident workgroups are what the counting ones wait behind)
                     const int j = j0 - lane;
                     const unsigned long long sv = j >= 0 ? __hip_atomic_load(&scan_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 32);
                     const unsigned status = (unsigned)(sv >> 32);
@@ -749,7 +757,7 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
                     const unsigned long long need = first2 >= 63 ? ~0ull : ((2ull << first2) - 1ull);
                     if (m0 & need) {   // (somebody in front of it has not counted yet)
                         if (++spins > (1u << 20)) { dead = true; break; }
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(8);
                         continue;
                     }
                     int tot;
@@ -1237,11 +1245,15 @@ __global__ __launch_bounds__(BE_BLOCK) void k_band_entries(const PathBin* __rest
                                                               int* __restrict__ band_item0,
                                                               TileEntry* __restrict__ entries, int* __restrict__ pair_idx,
                                                               int entry_cap, int item_cap, int vc0,
-                                                              BatchDev* __restrict__ bd, Owner own, int reuse) {
+                                                              BatchDev* __restrict__ bd, Owner own, int reuse,
+                                                              unsigned long long* __restrict__ clear_mask, int mask_span) {
     constexpr int NWV = BE_BLOCK / 64;
     __shared__ int s_n[NWV], s_c[NWV];
     __shared__ int s_ent0, s_ok;
     const int band = owned_band_at(own, blockIdx.x), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (a first pass over fresh memory: the band's entry bitmasks cleared here, in front of k_path_build, instead of by a memset launch)
+    if (clear_mask)
+        for (int i = tid; i < mask_span; i += BE_BLOCK) clear_mask[(size_t)band * mask_span + i] = 0ull;
     // `reuse` (a planned render): the band's places in the entry and item arrays are the ones the plan's own pass left in
     // band_start / band_item0 -- same geometry, same counts.  Asked for here, with the bins; the 256 bands' returning atomics on
     // two cursors were a quarter of this kernel (a hot address serves ~90 of them per microsecond).
@@ -3957,7 +3969,7 @@ struct svgr_batch {
     }
     // zeroed once per render: [BatchDev | per-path min/max keys | per-path row reach (multi-GPU)]
     DevArr<unsigned char> arena;
-    size_t arena_bytes = 0, off_pkeys = 0, off_prow = 0, off_scan = 0;
+    size_t arena_bytes = 0, arena_laid = 0, off_pkeys = 0, off_prow = 0, off_scan = 0;
     // work arrays fully rewritten by every render
     DevArr<int> edge_path, bbox, band_start, band_count;
     DevArr<PathBin> bins;
@@ -4048,19 +4060,27 @@ struct svgr_batch {
         masks_zeroed = false;
         return tile_mask.ensure(mask_bytes() / sizeof(unsigned long long) + 1);
     }
-    BatchDev* bd() const { return (BatchDev*)arena.p; }
+    // Two sets of device scalars at the head of the arena: the passes and the renders count into the first (its first word is the
+    // sticky error word), the two-pass plan's CENSUS into the second -- so the pass behind the census finds the first set still
+    // zero and needs no memset launch in between (4-5 us each: a cold frame had four).
+    bool census_set = false;
+    BatchDev* bd() const { return (BatchDev*)arena.p + (census_set ? 1 : 0); }
     unsigned long long* pkeys() const { return (unsigned long long*)(arena.p + off_pkeys); }
     unsigned* prow() const { return (unsigned*)(arena.p + off_prow); }
     unsigned long long* scan_state() const { return (unsigned long long*)(arena.p + off_scan); }   // k_flatten<.., SCAN>: one word per workgroup
 
     int layout_arena() {
-        off_pkeys = sizeof(BatchDev);
+        off_pkeys = 2 * sizeof(BatchDev);
         off_prow = off_pkeys + sizeof(unsigned long long) * 4 * (size_t)n_paths;
         off_scan = (off_prow + sizeof(unsigned) * 2 * (size_t)n_paths + 7) & ~(size_t)7;
         arena_bytes = off_scan + sizeof(unsigned long long) * (((size_t)n_segs << 6) / FL_BLOCK + 2);   // (workgroups of the widest cut: 64 lanes per segment)
         arena_bytes = (arena_bytes + 255) & ~(size_t)255;
-        arena_zeroed = false;  // (new size or new memory)
-        return arena.ensure(arena_bytes);
+        const unsigned char* const before = arena.p;
+        const size_t bytes_before = arena_laid;
+        const int rc = arena.ensure(arena_bytes);
+        if (arena.p != before || bytes_before != arena_bytes) arena_zeroed = false;  // (new size or new memory; else what the last tile kernel left stands)
+        arena_laid = arena_bytes;
+        return rc;
     }
 
     void release() {
@@ -4108,7 +4128,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     const int np_walk = listed ? (int)b->n_path_list : np;  // paths k_path_bbox / k_band_entries walk
     const unsigned* prow = nullptr;
     if (use_vp && b->own.world > 1 && ns > 0 && !listed) {
-        hipLaunchKernelGGL(k_path_rows, grid1((size_t)ns), dim3(256), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
+        SVGR_LAUNCH(k_path_rows, grid1((size_t)ns), dim3(256), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
                            (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->prow());
         prow = b->prow();
     }
@@ -4118,11 +4138,11 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
             if (int rc = b->seg_cnt.ensure((size_t)ns + 1)) return rc;
             if (int rc = b->seg_off.ensure((size_t)ns + 2)) return rc;
             if (int rc = b->lane_off.ensure(((size_t)ns << fl_sub) + 1)) return rc;
-            HIPCHK(hipMemsetAsync(b->seg_cnt.p, 0, sizeof(int) * ((size_t)ns + 1), st));
+            if (listed || prow) HIPCHK(hipMemsetAsync(b->seg_cnt.p, 0, sizeof(int) * ((size_t)ns + 1), st));   // (else every segment writes its count)
         }
         if (ns > 0) {
             auto launch_cnt = [&](auto kern) {
-                hipLaunchKernelGGL(kern, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
+                SVGR_LAUNCH(kern, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                                    (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns,
                                    b->thr, (double*)nullptr, (int*)nullptr, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
                                    n_bands_vp, prow, seg_list, n_items, upto == 1 ? b->seg_cnt.p : (int*)nullptr, (const int*)nullptr, 0,
@@ -4131,9 +4151,9 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
             if (fl_sub == 6) launch_cnt(k_flatten<false, false, 6>); else launch_cnt(k_flatten<false, false, 5>);
         }
         if (upto == 1)
-            hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, st, (const int*)b->seg_cnt.p, ns, b->seg_off.p);
+            SVGR_LAUNCH(k_seg_scan, dim3(1), dim3(1024), 0, st, (const int*)b->seg_cnt.p, ns, b->seg_off.p);
         if (upto == 0 || (upto == 1 && b->census_bbox))  // bboxes only (no edges stored): the union when there is no viewport; the two-pass plan's census
-            hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(),
+            SVGR_LAUNCH(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(),
                                np_walk, use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), 1, plist,
                                (Slab*)nullptr, 0, b->own, (const int*)nullptr, (const int*)nullptr, 0, (const int*)nullptr);
         return 0;
@@ -4142,7 +4162,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
         // (the counting pass that made `seg_off` left every lane's place inside its segment's slots beside it)
         const bool lane_places = !b->safe_path;
         auto launch_fl = [&](auto kern, int* places) {
-            hipLaunchKernelGGL(kern, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
+            SVGR_LAUNCH(kern, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                                (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
                                b->edges.p, b->edge_path.p, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
                                n_bands_vp, prow, seg_list, n_items, (int*)nullptr, (const int*)b->seg_off.p,
@@ -4152,7 +4172,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
         if (b->fl_scan) {
             // ONE traversal: count, look back, store; leaves seg_cnt / seg_off / lane_off for the renders (needs: one GPU, no list)
             auto launch_scan = [&](auto kern) {
-                hipLaunchKernelGGL(kern, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
+                SVGR_LAUNCH(kern, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                                    (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr,
                                    b->edges.p, b->edge_path.p, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
                                    n_bands_vp, prow, seg_list, n_items, b->seg_cnt.p, (const int*)nullptr,
@@ -4165,7 +4185,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
             if (placed_fl) launch_fl(k_flatten<true, true, 5>, b->lane_off.p); else launch_fl(k_flatten<true, false, 5>, (int*)nullptr);
         }
     }
-    hipLaunchKernelGGL(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np_walk,
+    SVGR_LAUNCH(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(), np_walk,
                        use_vp ? 1 : 0, b->vp[0], b->vp[1], b->vp[2], b->vp[3], b->bbox.p, b->bins.p, b->bd(), b->planned ? 0 : 1, plist,
                        upto >= 3 ? b->slabs.p : (Slab*)nullptr, (int)std::min<int64_t>(cap_i32(b->slabs.cap), b->n_slabs) /* = k_path_build's grid */, b->own,
                        (const int*)b->path_seg0.p, (const int*)b->seg_off.p,
@@ -4176,12 +4196,16 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     const int owned = count_owned_bands(b->own, b->n_bands);
     // (a planned render under the plan's places keeps the plan's band lists: k_tile_lists reads the paths' bboxes and bins itself)
     const bool keep_lists = upto >= 4 && b->planned && b->slab_at_valid && use_vp && !b->safe_path;
+    // (upto >= 4 on one GPU: the kernel also clears the tiles' entry bitmasks of its band when they are not clear yet)
+    const bool clear_in_be = owned > 0 && !keep_lists && upto >= 4 && !b->masks_zeroed && b->tile_mask.p && b->own.world <= 1;
     if (owned > 0 && !keep_lists)
-        hipLaunchKernelGGL(k_band_entries, dim3(owned), dim3(BE_BLOCK), 0, st, (const PathBin*)b->bins.p, np_walk, plist,
+        SVGR_LAUNCH(k_band_entries, dim3(owned), dim3(BE_BLOCK), 0, st, (const PathBin*)b->bins.p, np_walk, plist,
                            (const int*)b->bbox.p, b->band_start.p, b->band_count.p, b->band_item0.p, b->entries.p,
                            b->pair_idx.p, cap_i32(std::min(b->entries.cap, b->pair_idx.cap)),
                            upto >= 4 ? cap_i32(b->items.cap) : 0x7fffffff, b->vp[1], b->bd(), b->own,
-                           upto >= 4 && b->planned && use_vp && !b->safe_path ? 1 : 0);
+                           upto >= 4 && b->planned && use_vp && !b->safe_path ? 1 : 0,
+                           clear_in_be ? b->tile_mask.p : (unsigned long long*)nullptr, b->n_ctiles() * 2 * b->mask_words);
+    if (clear_in_be) b->masks_zeroed = true;
     if (upto == 3) return 0;
     // (the tiles read their mask words whether or not any pair exists: a batch without entries still needs them clear --
     //  a block from the cache is not zero)
@@ -4204,7 +4228,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
         // (the places are per cell: they hold as long as the paths keep the plan's cell places, i.e. under the plan's slab order)
         const bool placed = b->planned && b->add_places && b->slab_at_valid && !b->count_adds_only && b->cell_plan.p != nullptr;
         auto launch_pb = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)b->n_slabs), dim3(PB_THREADS), 0, st, (const Slab*)b->slabs.p, (const double*)b->edges.p,
+            SVGR_LAUNCH(kern, dim3((unsigned)b->n_slabs), dim3(PB_THREADS), 0, st, (const Slab*)b->slabs.p, (const double*)b->edges.p,
                                (const int*)b->pair_idx.p, (const double*)b->path_paint.p, (const uint8_t*)b->path_rule.p,
                                b->n_groups > 0 ? (const int*)b->path_group.p : (const int*)nullptr,
                                b->n_grads > 0 ? (const int*)b->path_grad.p : (const int*)nullptr, b->vp[0], b->vp[1], b->n_ctiles(), b->mask_words,
@@ -4239,7 +4263,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     }
     // per owned band: the tiles' item lists and the launch order of the tile kernel; clears the bitmasks again
     if (owned > 0 && b->n_ctiles() > 0) {
-        hipLaunchKernelGGL(k_tile_lists, dim3(owned), dim3(TL_BLOCK), 0, st, (const int*)b->band_start.p, (const int*)b->band_item0.p,
+        SVGR_LAUNCH(k_tile_lists, dim3(owned), dim3(TL_BLOCK), 0, st, (const int*)b->band_start.p, (const int*)b->band_item0.p,
                            (const TileEntry*)b->entries.p, b->tile_mask.p, b->mask_words, b->n_ctiles(), b->vp[1], b->own, owned,
                            b->tile_info.p, b->pages.p, b->items.p, (const CellHdr*)b->cell_hdr.p, cap_i32(b->items.cap), cap_i32(b->cell_hdr.cap), b->bd(),
                            keep_lists ? (const PathBin*)b->bins.p : (const PathBin*)nullptr, (const int*)b->bbox.p);
@@ -4452,6 +4476,7 @@ int svgr_shutdown(svgr_ctx* ctx) {
         if (ctx->side_ev[k]) (void)hipEventDestroy(ctx->side_ev[k]);
     }
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    for (auto e : ctx->meas_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->up_busy && ctx->up_ev) (void)hipEventSynchronize(ctx->up_ev);
     if (ctx->up_stage) (void)hipHostFree(ctx->up_stage);
@@ -4480,6 +4505,37 @@ int svgr_sync(svgr_ctx* ctx) {
     HIPCHK(enter_ctx(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- measurement helpers (bench.py): device time of a stretch of the context's stream, launches made ------------------------------
+__global__ void k_spin(unsigned long long ticks) {   // s_memrealtime counts at 100 MHz
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+int svgr_measure_launches(uint64_t* out) {
+    if (!out) return fail(SVGR_E_INVALID, "out is NULL");
+    *out = g_n_launches.load(std::memory_order_relaxed);
+    return 0;
+}
+int svgr_measure_begin(svgr_ctx* ctx, double hold_ms) {
+    if (!ctx || !(hold_ms >= 0.0) || hold_ms > 200.0) return fail(SVGR_E_INVALID, "bad arguments");
+    HIPCHK(enter_ctx(ctx));
+    if (!ctx->meas_ev[0]) { HIPCHK(hipEventCreate(&ctx->meas_ev[0])); HIPCHK(hipEventCreate(&ctx->meas_ev[1])); }
+    // (the stream is held busy for `hold_ms` so that everything the caller enqueues next queues up behind it and then runs back to back:
+    //  the time between the two events is DEVICE time, whatever the host took to issue it -- as long as it took less than the hold)
+    if (hold_ms > 0.0) SVGR_LAUNCH(k_spin, dim3(1), dim3(1), 0, ctx->stream, (unsigned long long)(hold_ms * 1e5));
+    HIPCHK(hipEventRecord(ctx->meas_ev[0], ctx->stream));
+    return 0;
+}
+int svgr_measure_end(svgr_ctx* ctx, double* ms) {
+    if (!ctx || !ms || !ctx->meas_ev[0]) return fail(SVGR_E_INVALID, "bad arguments");
+    HIPCHK(enter_ctx(ctx));
+    HIPCHK(hipEventRecord(ctx->meas_ev[1], ctx->stream));
+    HIPCHK(hipEventSynchronize(ctx->meas_ev[1]));
+    float f = 0.f;
+    HIPCHK(hipEventElapsedTime(&f, ctx->meas_ev[0], ctx->meas_ev[1]));
+    *ms = (double)f;
     return 0;
 }
 
@@ -4995,9 +5051,9 @@ static int build_seg_list(svgr_batch* b) {
     if (int rc = b->seg_list.ensure((size_t)ns)) return rc;
     HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
     b->arena_zeroed = false;
-    hipLaunchKernelGGL(k_path_rows, grid1((size_t)ns), dim3(256), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
+    SVGR_LAUNCH(k_path_rows, grid1((size_t)ns), dim3(256), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
                        (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->prow());
-    hipLaunchKernelGGL(k_seg_select, grid1((size_t)ns), dim3(256), 0, st, (const int*)b->seg_path.p, ns, (const unsigned*)b->prow(), b->own,
+    SVGR_LAUNCH(k_seg_select, grid1((size_t)ns), dim3(256), 0, st, (const int*)b->seg_path.p, ns, (const unsigned*)b->prow(), b->own,
                        b->vp[0], (b->vp[2] + TR - 1) / TR, b->seg_list.p, &b->bd()->edge_spare);
     int n = 0;
     std::vector<unsigned> reach(2 * (size_t)b->n_paths);
@@ -5171,11 +5227,25 @@ static int two_pass_issue(svgr_batch* b, void* staging) {
     if (int rc = b->layout_arena()) return rc;
     b->n_seg_list = -1;
     b->census_bbox = true;
+    b->census_set = true;      // (counts into the second set of scalars: the first stays zero for pass 2)
     int rc = run_geometry(b, 1, true);
     b->census_bbox = false;
+    if (!rc && staging) {   // (page-locked: the copy does not block, the wait below is the only one)
+        rc = issue_readback(b, true, staging);
+        if (!rc) {
+            hipError_t e = hipStreamSynchronize(b->ctx->stream);
+            if (e != hipSuccess) rc = fail(SVGR_E_HIP, "census: %s", hipGetErrorString(e));
+        }
+        if (!rc) {
+            take_readback(b, staging);
+            if (b->host_bd.err) b->invalidate_work();
+            rc = eval_dev_err(b->host_bd.err, nullptr);
+        }
+    } else if (!rc) rc = check_dev_err(b, nullptr, true, true);
+    b->census_set = false;
+    b->arena_zeroed = rc == 0;   // (the first set and the look-back state are untouched; the min / max keys hold what pass 2 finds again)
     if (rc) return rc;
     const double t_1 = now_ms();
-    if ((rc = check_dev_err(b, nullptr, true, true))) return rc;
     const double t_2 = now_ms();
     long long n_edges = 0, rows_x = 0;
     for (int k = 0; k < NSH; ++k) {
@@ -5483,7 +5553,7 @@ static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path
     b->geometry_fresh = false; b->geometry_current = false;
     b->arena_zeroed = false;
     HIPCHK(hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st));
-    hipLaunchKernelGGL(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
+    SVGR_LAUNCH(k_flatten<false>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
                        (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr, (double*)nullptr, (int*)nullptr, b->shards,
                        b->pkeys(), b->bd(), whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (int*)nullptr, (unsigned long long*)nullptr);
     BatchDev counts;
@@ -5507,7 +5577,7 @@ static int batch_all_edges_impl(svgr_batch* b, double* edges, int32_t* edge_path
     if (hipError_t e = g_pool.alloc((void**)&d_path, sizeof(int) * (size_t)total); e != hipSuccess) { g_pool.release(d_edges); HIPCHK(e); }
     hipError_t e = hipMemsetAsync(b->arena.p, 0, b->arena_bytes, st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_flatten<true>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
+        SVGR_LAUNCH(k_flatten<true>, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p, (const uint8_t*)b->seg_kind.p,
                            (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns, b->thr, d_edges, d_path, sh, b->pkeys(), b->bd(),
                            whole, 0, 0, (const unsigned*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (const int*)nullptr, 0, (int*)nullptr, (int*)nullptr, (unsigned long long*)nullptr);
         e = hipMemcpyAsync(edges, d_edges, sizeof(double) * 4 * (size_t)total, hipMemcpyDeviceToHost, st);
@@ -5697,7 +5767,7 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         if (b->n_grads > 0 && b->has_focal && !same) {   // (another window of the same picture: the flags are the previous render's)
             // focal radial gradients mask their `det < 0` pixels only if the fill's layer has any (S:1627): one flag per fill
             HIPCHK(hipMemsetAsync(b->grad_flags.p, 0, sizeof(int) * (size_t)b->n_grads, st));
-            hipLaunchKernelGGL(k_grad_detneg, dim3(64, (unsigned)b->n_grads), dim3(256), 0, st, (const GradDev*)b->grads.p,
+            SVGR_LAUNCH(k_grad_detneg, dim3(64, (unsigned)b->n_grads), dim3(256), 0, st, (const GradDev*)b->grads.p,
                                (const int*)b->grad_path.p, (const int*)b->bbox.p, b->grad_flags.p);
         }
         if (phase == 1) return 0;   // (the geometry kernels and the gradients' flags are on the stream: the windows follow)
@@ -5772,14 +5842,14 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
             const dim3 wgrid((unsigned)last.tile0 + (unsigned)last.win_ct * (unsigned)last.n_bands);
             a.use_order = 0;
             if (out_kind == 0) {
-                if (b->n_grads > 0) hipLaunchKernelGGL((k_tile_render_windows<0, true, true, true>), wgrid, dim3(NT), 0, lst, a, *wt);
-                else if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render_windows<0, true, true>), wgrid, dim3(NT), 0, lst, a, *wt);
-                else hipLaunchKernelGGL((k_tile_render_windows<0, true>), wgrid, dim3(NT), 0, lst, a, *wt);
+                if (b->n_grads > 0) SVGR_LAUNCH((k_tile_render_windows<0, true, true, true>), wgrid, dim3(NT), 0, lst, a, *wt);
+                else if (b->n_groups > 0) SVGR_LAUNCH((k_tile_render_windows<0, true, true>), wgrid, dim3(NT), 0, lst, a, *wt);
+                else SVGR_LAUNCH((k_tile_render_windows<0, true>), wgrid, dim3(NT), 0, lst, a, *wt);
             } else {
-                if (b->n_grads > 0) hipLaunchKernelGGL((k_tile_render_windows<1, true, true, true>), wgrid, dim3(NT), 0, lst, a, *wt);
-                else if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render_windows<1, true, true>), wgrid, dim3(NT), 0, lst, a, *wt);
-                else if (b->has_clips) hipLaunchKernelGGL((k_tile_render_windows<1, true>), wgrid, dim3(NT), 0, lst, a, *wt);
-                else hipLaunchKernelGGL((k_tile_render_windows<1, false>), wgrid, dim3(NT), 0, lst, a, *wt);
+                if (b->n_grads > 0) SVGR_LAUNCH((k_tile_render_windows<1, true, true, true>), wgrid, dim3(NT), 0, lst, a, *wt);
+                else if (b->n_groups > 0) SVGR_LAUNCH((k_tile_render_windows<1, true, true>), wgrid, dim3(NT), 0, lst, a, *wt);
+                else if (b->has_clips) SVGR_LAUNCH((k_tile_render_windows<1, true>), wgrid, dim3(NT), 0, lst, a, *wt);
+                else SVGR_LAUNCH((k_tile_render_windows<1, false>), wgrid, dim3(NT), 0, lst, a, *wt);
             }
             b->arena_zeroed = true;
             HIPCHK(hipGetLastError());
@@ -5788,19 +5858,19 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
         static const int dyn_lds = getenv("SVGR_DBG_DYNLDS") ? atoi(getenv("SVGR_DBG_DYNLDS")) : 0;  // occupancy experiments
         switch (out_kind) {
             case 0:
-                if (b->n_grads > 0) hipLaunchKernelGGL((k_tile_render<0, true, true, true>), grid, dim3(NT), 0, lst, a);
-                else if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render<0, true, true>), grid, dim3(NT), 0, lst, a);
-                else if (b->has_clips) hipLaunchKernelGGL((k_tile_render<0, true>), grid, dim3(NT), 0, lst, a);
-                else hipLaunchKernelGGL((k_tile_render<0, false>), grid, dim3(NT), dyn_lds, lst, a);
+                if (b->n_grads > 0) SVGR_LAUNCH((k_tile_render<0, true, true, true>), grid, dim3(NT), 0, lst, a);
+                else if (b->n_groups > 0) SVGR_LAUNCH((k_tile_render<0, true, true>), grid, dim3(NT), 0, lst, a);
+                else if (b->has_clips) SVGR_LAUNCH((k_tile_render<0, true>), grid, dim3(NT), 0, lst, a);
+                else SVGR_LAUNCH((k_tile_render<0, false>), grid, dim3(NT), dyn_lds, lst, a);
                 break;
             case 1:
-                if (b->n_grads > 0) hipLaunchKernelGGL((k_tile_render<1, true, true, true>), grid, dim3(NT), 0, lst, a);
-                else if (b->n_groups > 0) hipLaunchKernelGGL((k_tile_render<1, true, true>), grid, dim3(NT), 0, lst, a);
-                else if (b->has_clips) hipLaunchKernelGGL((k_tile_render<1, true>), grid, dim3(NT), 0, lst, a);
-                else hipLaunchKernelGGL((k_tile_render<1, false>), grid, dim3(NT), 0, lst, a);
+                if (b->n_grads > 0) SVGR_LAUNCH((k_tile_render<1, true, true, true>), grid, dim3(NT), 0, lst, a);
+                else if (b->n_groups > 0) SVGR_LAUNCH((k_tile_render<1, true, true>), grid, dim3(NT), 0, lst, a);
+                else if (b->has_clips) SVGR_LAUNCH((k_tile_render<1, true>), grid, dim3(NT), 0, lst, a);
+                else SVGR_LAUNCH((k_tile_render<1, false>), grid, dim3(NT), 0, lst, a);
                 break;
-            case 2: hipLaunchKernelGGL(k_tile_render<2>, grid, dim3(NT), 0, lst, a); break;
-            default: hipLaunchKernelGGL(k_tile_render<3>, grid, dim3(NT), 0, lst, a); break;
+            case 2: SVGR_LAUNCH(k_tile_render<2>, grid, dim3(NT), 0, lst, a); break;
+            default: SVGR_LAUNCH(k_tile_render<3>, grid, dim3(NT), 0, lst, a); break;
         }
         b->arena_zeroed = true;  // (done by that kernel, see TileArgs::arena)
     }
@@ -5925,7 +5995,7 @@ int svgr_layer_over(svgr_ctx* ctx, svgr_buf* dst, const int64_t* db, const svgr_
     if (dst->bytes < (size_t)db[2] * db[3] * 32 || src->bytes < n * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_over: buffer too small");
     if (n == 0) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_layer_over, grid1(n), dim3(256), 0, ctx->stream, (double*)dst->ptr, (int)db[0], (int)db[1], (int)db[2],
+    SVGR_LAUNCH(k_layer_over, grid1(n), dim3(256), 0, ctx->stream, (double*)dst->ptr, (int)db[0], (int)db[1], (int)db[2],
                        (int)db[3], (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch, first);
     HIPCHK(hipGetLastError());
     return 0;
@@ -5939,7 +6009,7 @@ int svgr_layer_blend(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr
     if (out->bytes < n * 32 || src->bytes < (size_t)sb[2] * sb[3] * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_blend: buffer too small");
     if (n == 0) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_layer_blend, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2], (int)ob[3],
+    SVGR_LAUNCH(k_layer_blend, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2], (int)ob[3],
                        (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch, mode, mode == 5 ? k4[0] : 0.0,
                        mode == 5 ? k4[1] : 0.0, mode == 5 ? k4[2] : 0.0, mode == 5 ? k4[3] : 0.0);
     HIPCHK(hipGetLastError());
@@ -5954,7 +6024,7 @@ int svgr_layer_color_matrix(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, const do
     HIPCHK(g_pool.alloc((void**)&dm, sizeof(double) * 20));
     hipError_t e = hipMemcpyAsync(dm, m20, sizeof(double) * 20, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_layer_color_matrix, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n_px, (const double*)dm);
+        SVGR_LAUNCH(k_layer_color_matrix, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n_px, (const double*)dm);
         e = hipStreamSynchronize(ctx->stream);  // (m20 is the caller's host memory)
         if (e == hipSuccess) e = hipGetLastError();
     }
@@ -5969,7 +6039,7 @@ int svgr_layer_morphology(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int
     const size_t n = (size_t)(rows - ky + 1) * (size_t)(cols - kx + 1);
     if (src->bytes < (size_t)rows * cols * 32 || out->bytes < n * 32) return fail(SVGR_E_INVALID, "svgr_layer_morphology: buffer too small");
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_layer_morphology, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)src->ptr, (int)rows, (int)cols,
+    SVGR_LAUNCH(k_layer_morphology, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)src->ptr, (int)rows, (int)cols,
                        (int)ky, (int)kx, is_max);
     HIPCHK(hipGetLastError());
     return 0;
@@ -5979,7 +6049,7 @@ int svgr_layer_luminance(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src, int6
     if (!ctx || !out || !src || n_px < 0 || out->bytes < (size_t)n_px * 8 || src->bytes < (size_t)n_px * 32) return fail(SVGR_E_INVALID, "svgr_layer_luminance: bad arguments");
     if (n_px == 0) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_layer_luminance, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)src->ptr, (size_t)n_px);
+    SVGR_LAUNCH(k_layer_luminance, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)src->ptr, (size_t)n_px);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -5990,7 +6060,7 @@ int svgr_layer_crop4(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr
     if (out->bytes < n * 32 || src->bytes < (size_t)sb[2] * sb[3] * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_crop4: buffer too small");
     if (n == 0) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_layer_crop4, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
+    SVGR_LAUNCH(k_layer_crop4, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
                        (int)ob[3], (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch);
     HIPCHK(hipGetLastError());
     return 0;
@@ -6002,7 +6072,7 @@ int svgr_layer_in(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, const svgr_bu
     if (out->bytes < n * 32 || src->bytes < (size_t)sb[2] * sb[3] * 8 * ch) return fail(SVGR_E_INVALID, "svgr_layer_in: buffer too small");
     if (n == 0) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_layer_in, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
+    SVGR_LAUNCH(k_layer_in, grid1(n), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
                        (int)ob[3], (const double*)src->ptr, (int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], ch);
     HIPCHK(hipGetLastError());
     return 0;
@@ -6013,7 +6083,7 @@ int svgr_layer_scale_to(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64
         return fail(SVGR_E_INVALID, "svgr_layer_scale: bad arguments");
     if (n == 0) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_layer_scale, grid1((size_t)n), dim3(256), 0, ctx->stream, (double*)dst->ptr, (const double*)src->ptr, (size_t)n, f);
+    SVGR_LAUNCH(k_layer_scale, grid1((size_t)n), dim3(256), 0, ctx->stream, (double*)dst->ptr, (const double*)src->ptr, (size_t)n, f);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -6023,7 +6093,7 @@ int svgr_layer_clip01(svgr_ctx* ctx, svgr_buf* img, int64_t n) {
     if (!ctx || !img || n < 0 || img->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_clip01: bad arguments");
     if (n == 0) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_layer_clip01, grid1((size_t)n), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n);
+    SVGR_LAUNCH(k_layer_clip01, grid1((size_t)n), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -6032,7 +6102,7 @@ int svgr_layer_background(svgr_ctx* ctx, svgr_buf* img, int64_t n_px, const doub
     if (!ctx || !img || !rgba || n_px < 0 || img->bytes < (size_t)n_px * 32) return fail(SVGR_E_INVALID, "svgr_layer_background: bad arguments");
     if (n_px == 0) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_layer_background, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n_px, rgba[0],
+    SVGR_LAUNCH(k_layer_background, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)img->ptr, (size_t)n_px, rgba[0],
                        rgba[1], rgba[2], rgba[3]);
     HIPCHK(hipGetLastError());
     return 0;
@@ -6043,7 +6113,7 @@ int svgr_layer_convert_to(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int
         return fail(SVGR_E_INVALID, "svgr_layer_convert: bad arguments");
     if (n_px == 0 || (ops == 0 && dst->ptr == src->ptr)) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_layer_convert<false>, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)dst->ptr, (const double*)src->ptr, (size_t)n_px, ops, 1.0);
+    SVGR_LAUNCH(k_layer_convert<false>, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)dst->ptr, (const double*)src->ptr, (size_t)n_px, ops, 1.0);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -6054,7 +6124,7 @@ int svgr_layer_convert_scale_to(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* sr
         return fail(SVGR_E_INVALID, "svgr_layer_convert_scale_to: bad arguments");
     if (n_px == 0) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_layer_convert<true>, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)dst->ptr, (const double*)src->ptr, (size_t)n_px, ops, factor);
+    SVGR_LAUNCH(k_layer_convert<true>, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (double*)dst->ptr, (const double*)src->ptr, (size_t)n_px, ops, factor);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -6096,10 +6166,10 @@ static int layer_compose_many(svgr_ctx* ctx, svgr_buf* out, const int64_t* ob, i
             o.ch = chs[at + k]; o.ops = ops ? ops[at + k] : 0u;
         }
         if (in_mode)
-            hipLaunchKernelGGL(k_layer_compose_in, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
+            SVGR_LAUNCH(k_layer_compose_in, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
                                (int)ob[3], t);
         else
-            hipLaunchKernelGGL(k_layer_compose_over, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
+            SVGR_LAUNCH(k_layer_compose_over, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (int)ob[0], (int)ob[1], (int)ob[2],
                                (int)ob[3], t);
     }
     HIPCHK(hipGetLastError());
@@ -6110,7 +6180,7 @@ int svgr_layer_to_f32(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64_t
     if (!ctx || !dst || !src || n < 0 || dst->bytes < (size_t)n * 4 || src->bytes < (size_t)n * 8) return fail(SVGR_E_INVALID, "svgr_layer_to_f32: bad arguments");
     if (n == 0) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_to_f32, grid1((size_t)n), dim3(256), 0, ctx->stream, (float*)dst->ptr, (const double*)src->ptr, (size_t)n, clip01);
+    SVGR_LAUNCH(k_to_f32, grid1((size_t)n), dim3(256), 0, ctx->stream, (float*)dst->ptr, (const double*)src->ptr, (size_t)n, clip01);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -6119,7 +6189,7 @@ int svgr_layer_to_rgba8(svgr_ctx* ctx, svgr_buf* dst, const svgr_buf* src, int64
     if (!ctx || !dst || !src || n_px < 0 || dst->bytes < (size_t)n_px * 4 || src->bytes < (size_t)n_px * 32) return fail(SVGR_E_INVALID, "svgr_layer_to_rgba8: bad arguments");
     if (n_px == 0) return 0;
     HIPCHK(enter_ctx(ctx));
-    hipLaunchKernelGGL(k_to_rgba8, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (uchar4*)dst->ptr, (const double4*)src->ptr, (size_t)n_px);
+    SVGR_LAUNCH(k_to_rgba8, grid1((size_t)n_px), dim3(256), 0, ctx->stream, (uchar4*)dst->ptr, (const double4*)src->ptr, (size_t)n_px);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -6157,15 +6227,15 @@ static int gradient_run(svgr_ctx* ctx, const svgr_gradient* g, const double* pts
         HIPCHK(g_pool.alloc((void**)&flag, 16));
         e = hipMemsetAsync(flag, 0, 16, ctx->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_gradient_detneg, ggrid, dim3(256), 0, ctx->stream, h, pts, (int)bbox[0], (int)bbox[1],
+            SVGR_LAUNCH(k_gradient_detneg, ggrid, dim3(256), 0, ctx->stream, h, pts, (int)bbox[0], (int)bbox[1],
                                (int)bbox[2], (int)bbox[3], flag);
-            hipLaunchKernelGGL(k_gradient_fill, ggrid, dim3(256), 0, ctx->stream, h, pts, mptr, (int)bbox[0], (int)bbox[1],
+            SVGR_LAUNCH(k_gradient_fill, ggrid, dim3(256), 0, ctx->stream, h, pts, mptr, (int)bbox[0], (int)bbox[1],
                                (int)bbox[2], (int)bbox[3], (const int*)flag, (double*)out->ptr);
             e = hipGetLastError();
         }
         g_pool.release(flag);  // (stream order keeps the word's next user behind the two kernels: nothing to wait for)
     } else {
-        hipLaunchKernelGGL(k_gradient_fill, ggrid, dim3(256), 0, ctx->stream, h, pts, mptr, (int)bbox[0], (int)bbox[1],
+        SVGR_LAUNCH(k_gradient_fill, ggrid, dim3(256), 0, ctx->stream, h, pts, mptr, (int)bbox[0], (int)bbox[1],
                            (int)bbox[2], (int)bbox[3], (const int*)nullptr, (double*)out->ptr);
         e = hipGetLastError();
     }
@@ -6205,7 +6275,7 @@ int svgr_pattern_fill(svgr_ctx* ctx, const svgr_pattern* pt, const svgr_buf* til
     int oob = 0;
     hipError_t e = hipMemsetAsync(flag, 0, 16, ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_pattern_fill, grid1(n), dim3(256), 0, ctx->stream, *pt, (const double*)tile->ptr, (const double*)mask->ptr,
+        SVGR_LAUNCH(k_pattern_fill, grid1(n), dim3(256), 0, ctx->stream, *pt, (const double*)tile->ptr, (const double*)mask->ptr,
                            (int)bbox[0], (int)bbox[1], (int)bbox[2], (int)bbox[3], flag, (double*)out->ptr);
         e = hipMemcpyAsync(&oob, flag, sizeof oob, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -6313,7 +6383,7 @@ static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src
     const double* src_px = (const double*)src->ptr;
     if (src_ops && !blocked) {
         HIPCHK(g_pool.alloc((void**)&conv_src, (size_t)rows * cols * 32, ctx->device));
-        hipLaunchKernelGGL(k_layer_convert<false>, grid1((size_t)rows * cols), dim3(256), 0, ctx->stream, conv_src, src_px, (size_t)rows * cols, src_ops, 1.0);
+        SVGR_LAUNCH(k_layer_convert<false>, grid1((size_t)rows * cols), dim3(256), 0, ctx->stream, conv_src, src_px, (size_t)rows * cols, src_ops, 1.0);
         src_px = conv_src;
     }
     struct Release { double* p; ~Release() { if (p) g_pool.release(p); } } release_conv{conv_src};   // (stream order: behind the kernels below)
@@ -6328,9 +6398,9 @@ static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src
         const int64_t ocols = cols + kh - 1;
         const size_t n_tmp = (size_t)rows * (size_t)ocols;
         HIPCHK(g_pool.alloc((void**)&tmp, n_tmp * 32, ctx->device));
-        hipLaunchKernelGGL(k_convolve_cols, dim3((unsigned)((ocols + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, tmp, src_px,
+        SVGR_LAUNCH(k_convolve_cols, dim3((unsigned)((ocols + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, tmp, src_px,
                            (int)rows, (int)cols, cv, src_ops);
-        hipLaunchKernelGGL(k_convolve_rows, dim3((unsigned)((ocols + 63) / 64), (unsigned)((rows + kw - 1 + CONV_RB - 1) / CONV_RB)), dim3(64), 0,
+        SVGR_LAUNCH(k_convolve_rows, dim3((unsigned)((ocols + 63) / 64), (unsigned)((rows + kw - 1 + CONV_RB - 1) / CONV_RB)), dim3(64), 0,
                            ctx->stream, (double*)out->ptr, (const double*)tmp, (int)rows, (int)ocols, cu);
         e = hipGetLastError();
         g_pool.release(tmp);  // (stream order keeps the block's next user behind the two kernels)
@@ -6343,9 +6413,9 @@ static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src
         e = hipMemcpyAsync(dw, u.data(), sizeof(double) * (size_t)kw, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(dw + kw, v.data(), sizeof(double) * (size_t)kh, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_layer_convolve_1d<0>, grid1(n_tmp), dim3(256), 0, ctx->stream, tmp, src_px, (int)rows,
+            SVGR_LAUNCH(k_layer_convolve_1d<0>, grid1(n_tmp), dim3(256), 0, ctx->stream, tmp, src_px, (int)rows,
                                (int)cols, (const double*)dw, (int)kw);
-            hipLaunchKernelGGL(k_layer_convolve_1d<1>, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)tmp,
+            SVGR_LAUNCH(k_layer_convolve_1d<1>, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, (const double*)tmp,
                                (int)(rows + kw - 1), (int)cols, (const double*)(dw + kw), (int)kh);
             e = hipStreamSynchronize(ctx->stream);  // (u, v are host vectors of this call)
             if (e == hipSuccess) e = hipGetLastError();
@@ -6356,7 +6426,7 @@ static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src
         ConvW ck{};
         ck.n = (int)(kw * kh);
         for (int64_t i = 0; i < kw * kh; ++i) ck.w[i] = kernel[i];
-        hipLaunchKernelGGL(k_layer_convolve_small, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, src_px, (int)rows, (int)cols, ck,
+        SVGR_LAUNCH(k_layer_convolve_small, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, src_px, (int)rows, (int)cols, ck,
                            (int)kw, (int)kh);
         e = hipGetLastError();
     } else {
@@ -6364,7 +6434,7 @@ static int layer_convolve_impl(svgr_ctx* ctx, svgr_buf* out, const svgr_buf* src
         HIPCHK(g_pool.alloc((void**)&dk, sizeof(double) * (size_t)kw * kh));
         e = hipMemcpyAsync(dk, kernel, sizeof(double) * (size_t)kw * kh, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_layer_convolve, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, src_px,
+            SVGR_LAUNCH(k_layer_convolve, grid1(n_out), dim3(256), 0, ctx->stream, (double*)out->ptr, src_px,
                                (int)rows, (int)cols, (const double*)dk, (int)kw, (int)kh);
             e = hipStreamSynchronize(ctx->stream);
             if (e == hipSuccess) e = hipGetLastError();
