@@ -265,7 +265,21 @@ class Scene(tuple):
             return self._render_top(transform, mask_only, viewport, linear_rgb)
 
     def _render_top(self, transform: Transform, mask_only: bool, viewport, linear_rgb: bool):
-        from . import geometry  # noqa: PLC0415
+        from . import displaylist, geometry  # noqa: PLC0415
+
+        # A scene that is batch entries and nothing else (solid fills / strokes under transforms, single-path clips, opacity and
+        # clip groups) is compiled ONCE to flat arrays -- nothing of it depends on the render transform but the leaves' matrices --
+        # and drawn from them: no tree walk, no leaf tuples, no per-leaf packing (displaylist.py).  Same batch, same picture.
+        if _RETAINED_MAX == 0 and not mask_only and (self[0] == RENDER_GROUP or _NODE_RUNS):
+            dl = displaylist.get(self, linear_rgb)
+            if dl is not None:
+                res = dl.render(transform, viewport, linear_rgb)
+                if self[0] != RENDER_GROUP or res is None:
+                    return res
+                group = Layer.compose([res[0]], COMPOSE_OVER, linear_rgb)   # (what the GROUP's own loop ends in, S:686-688)
+                if not group:
+                    return None
+                return group, ConvexHull.merge([res[1]])
 
         key = (id(self), transform.key(), tuple(int(v) for v in viewport), bool(linear_rgb), bool(mask_only))
         st = None
@@ -1055,6 +1069,13 @@ def _effective_boxes(leaves, bboxes):
     n = len(leaves)
     flags = np.fromiter((leaf[4] for leaf in leaves), dtype=np.int64, count=n)
     clipped = np.fromiter((leaf[4] == 2 or (leaf[5] is not None and leaf[5][2]) for leaf in leaves), dtype=bool, count=n)
+    return _effective_boxes_arrays(flags, clipped, bboxes)
+
+
+def _effective_boxes_arrays(flags, clipped, bboxes):
+    """`_effective_boxes` from the leaves' flags (0 painted, 1 clip source, 2 clipped) and "clipped by the source in front of it"
+    (a clipped fill, a member of a clipped group) as arrays: what a display list keeps of its leaves."""
+    n = len(flags)
     bb = np.asarray(bboxes, dtype=np.int64).reshape(n, 4)
     box = np.stack([bb[:, 0], bb[:, 1], bb[:, 0] + bb[:, 2], bb[:, 1] + bb[:, 3]], axis=1)
     ok = (bb[:, 2] > 0) & (bb[:, 3] > 0)
