@@ -165,6 +165,7 @@ struct svgr_ctx {
     hipEvent_t up_ev = nullptr;
     bool up_busy = false;
     hipEvent_t meas_ev[2] = {nullptr, nullptr};   // svgr_measure_begin / _end
+    hipEvent_t pin_ev = nullptr;                  // marks a read-back into `pinned` that the host waits for alone
     int n_cu = 256;              // compute units: the tile kernel's persistent launch is sized by it
     void* trash = nullptr;       // 1 KiB of device memory nobody reads (TileArgs::trash)
     unsigned* tile_ctr = nullptr;  // two sets of eight tile counters (TileArgs::tile_ctr), used alternately by the launches of this stream
@@ -3990,6 +3991,7 @@ struct svgr_batch {
     int64_t n_adds = 0;                     // add slots in all the shards
     bool count_adds_only = false;           // the plan's measuring run: k_path_build sizes the add lists, writes none
     bool fl_scan = false;                   // this pass flattens in ONE traversal (k_flatten<.., SCAN>): a re-plan's single pass
+    bool late_scan = false;                 // the counting pass leaves k_seg_scan to its caller (two_pass_issue: behind the census's read-back)
     bool census_bbox = false;               // the two-pass plan's first pass: the counting flatten is followed by k_path_bbox (pairs, cells, slabs counted)
     bool deterministic = false;             // this pass runs for a SVGR_RENDER_DETERMINISTIC render
     // lay the add shards back to back: `need[k]` slots each plus slack (the sizes repeat from render to render except for
@@ -4150,7 +4152,9 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
             };
             if (fl_sub == 6) launch_cnt(k_flatten<false, false, 6>); else launch_cnt(k_flatten<false, false, 5>);
         }
-        if (upto == 1)
+        // (the prefix sums are pass 2's input, not the census's: a census whose read-back waits for an event has them enqueued BEHIND the
+        //  read-back -- they run while the host sizes the buffers -- `late_scan`)
+        if (upto == 1 && !b->late_scan)
             SVGR_LAUNCH(k_seg_scan, dim3(1), dim3(1024), 0, st, (const int*)b->seg_cnt.p, ns, b->seg_off.p);
         if (upto == 0 || (upto == 1 && b->census_bbox))  // bboxes only (no edges stored): the union when there is no viewport; the two-pass plan's census
             SVGR_LAUNCH(k_path_bbox, grid1((size_t)std::max(np_walk, 1), 64), dim3(64), 0, st, (const unsigned long long*)b->pkeys(),
@@ -4461,6 +4465,7 @@ int svgr_init(int device_id, svgr_ctx** out) {
     // page-locked staging for the read-backs of svgr_batch_draw / svgr_batch_plan_many (grown on demand: a first frame should not pay for it)
     if (hipHostMalloc(&c->pinned, 1u << 20, hipHostMallocDefault) == hipSuccess) c->pinned_bytes = 1u << 20;
     else c->pinned = nullptr;
+    if (hipEventCreateWithFlags(&c->pin_ev, hipEventDisableTiming) != hipSuccess) c->pin_ev = nullptr;
     (void)upload_stage(c, 1);   // (the upload staging at its smallest size, 4 MiB: likewise)
     *out = c;
     return 0;
@@ -4477,6 +4482,7 @@ int svgr_shutdown(svgr_ctx* ctx) {
     }
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     for (auto e : ctx->meas_ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->pin_ev) (void)hipEventDestroy(ctx->pin_ev);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->up_busy && ctx->up_ev) (void)hipEventSynchronize(ctx->up_ev);
     if (ctx->up_stage) (void)hipHostFree(ctx->up_stage);
@@ -5228,12 +5234,21 @@ static int two_pass_issue(svgr_batch* b, void* staging) {
     b->n_seg_list = -1;
     b->census_bbox = true;
     b->census_set = true;      // (counts into the second set of scalars: the first stays zero for pass 2)
+    b->late_scan = staging != nullptr && b->ctx->pin_ev != nullptr;
     int rc = run_geometry(b, 1, true);
     b->census_bbox = false;
+    const bool late = b->late_scan;
+    b->late_scan = false;
     if (!rc && staging) {   // (page-locked: the copy does not block, the wait below is the only one)
         rc = issue_readback(b, true, staging);
         if (!rc) {
-            hipError_t e = hipStreamSynchronize(b->ctx->stream);
+            hipError_t e;
+            if (late) {
+                // the host waits for the read-back alone; the prefix sums pass 2 needs run meanwhile
+                e = hipEventRecord(b->ctx->pin_ev, b->ctx->stream);
+                SVGR_LAUNCH(k_seg_scan, dim3(1), dim3(1024), 0, b->ctx->stream, (const int*)b->seg_cnt.p, (int)b->n_segs, b->seg_off.p);
+                if (e == hipSuccess) e = hipEventSynchronize(b->ctx->pin_ev);
+            } else e = hipStreamSynchronize(b->ctx->stream);
             if (e != hipSuccess) rc = fail(SVGR_E_HIP, "census: %s", hipGetErrorString(e));
         }
         if (!rc) {
