@@ -166,6 +166,7 @@ struct svgr_ctx {
     bool up_busy = false;
     hipEvent_t meas_ev[2] = {nullptr, nullptr};   // svgr_measure_begin / _end
     hipEvent_t pin_ev = nullptr;                  // marks a read-back into `pinned` that the host waits for alone
+    struct WorkSpare* spare = nullptr;            // the work arrays of the last large batch destroyed on this context (below)
     int n_cu = 256;              // compute units: the tile kernel's persistent launch is sized by it
     void* trash = nullptr;       // 1 KiB of device memory nobody reads (TileArgs::trash)
     unsigned* tile_ctr = nullptr;  // two sets of eight tile counters (TileArgs::tile_ctr), used alternately by the launches of this stream
@@ -4102,11 +4103,82 @@ struct svgr_batch {
     }
 };
 
+// The work arrays of the last LARGE batch destroyed on a context, kept for the next batch made for the same viewport: a caller that
+// draws frame after frame from new batches (the reference's model: every call starts from the geometry, S:948-957) then plans its
+// frame like a re-plan -- ONE pass on the inherited CAPACITIES, flagged and planned in two passes when they do not hold -- instead of
+// a census, a host wait and a sizing step.  Nothing of the old batch's geometry or results is read: every array is rewritten by the
+// pass before anything reads it (the entry bitmasks are cleared again), and the counter arena is the new batch's own.
+struct WorkSpare {
+    int vp[4] = {0, 0, 0, 0};
+    int64_t n_segs = 0, n_paths = 0;
+    int mask_words = 1;
+    AddShards add_shards{};
+    int64_t n_adds = 0;
+    DevArr<int> edge_path, band_start, band_count, pair_idx, slab_at, seg_cnt, seg_off, lane_off, band_item0;
+    DevArr<TileEntry> entries;
+    DevArr<double> edges;
+    DevArr<CellHdr> cell_hdr;
+    DevArr<unsigned char> work_block;
+    DevArr<int2> cell_plan, tile_info;
+    DevArr<TileAdd> adds;
+    DevArr<uint4> items, pages;
+    DevArr<Slab> slabs;
+    DevArr<unsigned long long> tile_mask;
+    void release() {
+        edge_path.release(); band_start.release(); band_count.release(); pair_idx.release(); slab_at.release(); seg_cnt.release();
+        seg_off.release(); lane_off.release(); band_item0.release(); entries.release(); edges.release(); cell_hdr.release();
+        cell_plan.release(); tile_info.release(); adds.release(); items.release(); pages.release(); slabs.release(); tile_mask.release();
+        work_block.release();
+    }
+};
+#define SVGR_SPARE_ARRAYS(X) X(edge_path) X(band_start) X(band_count) X(pair_idx) X(slab_at) X(seg_cnt) X(seg_off) X(lane_off) X(band_item0) \
+    X(entries) X(edges) X(cell_hdr) X(work_block) X(cell_plan) X(tile_info) X(adds) X(items) X(pages) X(slabs) X(tile_mask)
+// a destroyed batch leaves its work arrays to its context (large planned batches with a viewport on one GPU only)
+static void spare_stash(svgr_batch* b) {
+    svgr_ctx* c = b->ctx;
+    if (!b->sized || !b->has_vp || b->own.world > 1 || b->n_segs <= 4096 || !b->edges.p || !b->cell_plan.p || getenv("SVGR_NO_SPARE")) return;
+    if (!c->spare) c->spare = new (std::nothrow) WorkSpare();
+    if (!c->spare) return;
+    WorkSpare& w = *c->spare;
+    w.release();
+    for (int k = 0; k < 4; ++k) w.vp[k] = b->sized_vp[k];
+    w.n_segs = b->n_segs; w.n_paths = b->n_paths; w.mask_words = b->mask_words; w.add_shards = b->add_shards; w.n_adds = b->n_adds;
+#define X(a) w.a = b->a; b->a.p = nullptr; b->a.cap = 0; b->a.view = false;
+    SVGR_SPARE_ARRAYS(X)
+#undef X
+}
+// ... and a new, never planned batch of about the same size for the same viewport takes them over.  true: taken
+static bool spare_adopt(svgr_batch* b) {
+    svgr_ctx* c = b->ctx;
+    WorkSpare* w = c->spare;
+    if (!w || !w->edges.p || b->sized || !b->has_vp || b->own.world > 1 || b->n_segs <= 4096) return false;
+    for (int k = 0; k < 4; ++k) if (w->vp[k] != b->vp[k]) return false;
+    if (b->n_segs * 2 < w->n_segs || b->n_segs > w->n_segs + w->n_segs / 2 || b->n_paths * 2 < w->n_paths || b->n_paths > w->n_paths + w->n_paths / 2) return false;
+    // (the capacities that are per path / per segment have to hold outright; the others are the pass's guesses)
+    if (w->slab_at.cap && w->slab_at.cap < (size_t)b->n_paths) return false;
+#define X(a) b->a.release(); b->a = w->a; w->a.p = nullptr; w->a.cap = 0; w->a.view = false;
+    SVGR_SPARE_ARRAYS(X)
+#undef X
+    b->mask_words = w->mask_words; b->add_shards = w->add_shards; b->n_adds = w->n_adds;
+    b->n_bands = (b->vp[2] + TR - 1) / TR;
+    b->masks_zeroed = false;   // (whatever the last render of the old batch left: cleared again)
+    b->slab_at_valid = false;
+    b->sized = true;
+    for (int k = 0; k < 4; ++k) b->sized_vp[k] = b->vp[k];
+    return true;
+}
+
 static inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 static inline int cap_i32(size_t n) { return (int)std::min<size_t>(n, 0x7fffffff); }
 
 // Geometry stages.  `upto`: 0 = flatten (count only) + bbox, 1 = flatten (count only: per-segment edge counts and their prefix
 // sums), 2 = flatten + emit + bbox, 3 = + band lists, 4 = everything.  `use_vp` = clip bboxes to b->vp and bin relative to it.
+// log2 of the lanes k_flatten cuts a segment over: 5, or 6 when a launch over `n_items` segments would not fill the chip
+static int choose_fl_sub(const svgr_batch* b, int n_items) {
+    static const int sub_env = getenv("SVGR_FL_SUB") ? atoi(getenv("SVGR_FL_SUB")) : 0;
+    const size_t waves32 = ((size_t)std::max(n_items, 1) << 5) / 64, slots = (size_t)b->ctx->n_cu * 4 * 6;   // (six waves per SIMD)
+    return sub_env == 5 || sub_env == 6 ? sub_env : (waves32 * 2 <= slots ? 6 : 5);
+}
 static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     hipStream_t st = b->ctx->stream;
     const int ns = (int)b->n_segs, np = (int)b->n_paths;
@@ -4118,11 +4190,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
     const int n_items = listed ? (int)b->n_seg_list : ns;
     // (how many lanes a segment is cut over: decided when the counting pass runs -- the per-lane places follow it -- and kept for
     //  the passes that use its places)
-    if (upto == 1) {
-        static const int sub_env = getenv("SVGR_FL_SUB") ? atoi(getenv("SVGR_FL_SUB")) : 0;
-        const size_t waves32 = ((size_t)std::max(n_items, 1) << 5) / 64, slots = (size_t)b->ctx->n_cu * 4 * 6;   // (six waves per SIMD)
-        b->fl_sub = sub_env == 5 || sub_env == 6 ? sub_env : (waves32 * 2 <= slots ? 6 : 5);
-    }
+    if (upto == 1) b->fl_sub = choose_fl_sub(b, n_items);
     const int fl_sub = b->fl_sub;
     const dim3 fgrid = grid1((size_t)std::max(n_items, 1) << fl_sub, FL_BLOCK);
     const int* seg_list = listed ? (const int*)b->seg_list.p : (const int*)nullptr;
@@ -4483,6 +4551,7 @@ int svgr_shutdown(svgr_ctx* ctx) {
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     for (auto e : ctx->meas_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->pin_ev) (void)hipEventDestroy(ctx->pin_ev);
+    if (ctx->spare) { ctx->spare->release(); delete ctx->spare; ctx->spare = nullptr; }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->up_busy && ctx->up_ev) (void)hipEventSynchronize(ctx->up_ev);
     if (ctx->up_stage) (void)hipHostFree(ctx->up_stage);
@@ -4744,6 +4813,7 @@ int svgr_batch_destroy(svgr_batch* b) {
     // (kernels still in flight only touch device blocks, and those go back to this context's cache, whose next user is behind
     //  them on the same stream; what must not go away under a running copy is the batch's HOST memory)
     b->wait_uploads();
+    spare_stash(b);
     b->release();
     delete b;
     return 0;
@@ -4923,6 +4993,7 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr, bool again = false
     const int64_t ns = b->n_segs;
     if (!b->has_vp || ns <= 0 || np <= 0 || b->own.world > 1) return 0;
     if (again) {
+        if (!b->sized) (void)spare_adopt(b);   // (a new batch: the work arrays of the context's last large batch, if they fit its shape)
         if (!b->sized || b->sized_vp[0] != b->vp[0] || b->sized_vp[1] != b->vp[1] || b->sized_vp[2] != b->vp[2] || b->sized_vp[3] != b->vp[3]) return 0;
         b->n_edges = (int64_t)(b->edges.cap / 4);
         for (int k = 0; k < NSH; ++k) {
@@ -4939,6 +5010,7 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr, bool again = false
         if (rc) return rc;
         // ONE flatten traversal (k_flatten<.., SCAN>: count, look-back, store) when the last plan left arrays for its by-products;
         // else the counting pass + prefix sums in front of the storing one
+        b->fl_sub = choose_fl_sub(b, (int)ns);   // (as the counting pass would choose it: the lanes' places follow it)
         const bool scan = !b->safe_path && getenv("SVGR_NO_SCAN_FLATTEN") == nullptr && b->seg_cnt.cap >= (size_t)ns + 1 &&
                           b->seg_off.cap >= (size_t)ns + 2 && b->lane_off.cap >= ((size_t)ns << b->fl_sub) + 1;
         if (!scan && (rc = run_geometry(b, 1, true))) return rc;

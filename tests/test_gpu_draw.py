@@ -153,3 +153,53 @@ def test_draw_falls_back_when_a_capacity_does_not_hold(S, monkeypatch):
     monkeypatch.delenv("SVGR_TWO_PASS_SHRINK")
     assert_close64(out.download((size, size, 4), np.float64), want, atol=1e-12, what="draw with an add-list guess that was too small")
     b.destroy()
+
+
+def test_frames_from_new_batches_inherit_capacities_not_contents(S, monkeypatch):
+    """A caller that makes a new batch per frame: a destroyed large batch leaves its work arrays to its context and the next batch
+    for the same viewport plans in ONE pass on the inherited capacities.  Nothing of the old batch may show: frames of a moving
+    drawing, then a DIFFERENT drawing (another seed, 1.4 times the paths: some capacity overflows and the two-pass plan takes over),
+    then a much smaller one (does not adopt), every one against a batch planned without inheritance."""
+    from svgrasterize_amd import _abi, synth
+
+    size = 1024
+    ctx = S.Context.get()
+    out = ctx.alloc(size * size * 32)
+
+    def reference(sc, m6):
+        monkeypatch.setenv("SVGR_NO_SPARE", "1")
+        b = _new(S, sc, m6)
+        st = b.plan()
+        ref_out = ctx.alloc(size * size * 32)
+        b.render(ref_out, _abi.OUT_CANVAS_F64)
+        img = ref_out.download((size, size, 4), np.float64)
+        bb, edges = b.bboxes().copy(), b.edges()
+        b.destroy()
+        monkeypatch.delenv("SVGR_NO_SPARE")
+        return st, img, bb, edges
+
+    scenes = [synth.make_scene(size, 1000)] * 4 + [synth.make_scene(size, 1400), synth.make_scene(size, 1000), synth.make_scene(size, 100)]
+    prev = None
+    for k, sc in enumerate(scenes):
+        m6 = _moved(sc, k)
+        b = _new(S, sc, m6)
+        if prev is not None:
+            prev.destroy()          # (the frame before leaves its arrays behind)
+        if k % 2:
+            b.draw(out, _abi.OUT_CANVAS_F64)
+        else:
+            b.plan()
+            b.render(out, _abi.OUT_CANVAS_F64)
+        got = out.download((size, size, 4), np.float64)
+        st_ref, want, bb_ref, (e_ref, ep_ref) = reference(sc, m6)
+        assert want.any()
+        assert_close64(got, want, atol=1e-12, what=f"frame {k} from a new batch")
+        st = b.stats
+        assert (st.n_edges, st.path_pixels) == (st_ref.n_edges, st_ref.path_pixels)
+        assert np.array_equal(b.bboxes(), bb_ref)
+        e, ep = b.edges()
+        assert np.array_equal(e, e_ref) and np.array_equal(ep, ep_ref)
+        b.render(out, _abi.OUT_CANVAS_F64)      # ... and replays like any other plan
+        assert_close64(out.download((size, size, 4), np.float64), want, atol=1e-12, what=f"replay of frame {k}")
+        prev = b
+    prev.destroy()
