@@ -794,10 +794,11 @@ def main():
         try:
             # (three cold frames one after the other, each batch destroyed before the next is made -- a caller drawing frame after
             #  frame: the first asks the driver for fresh device memory, which is cleared before its first use; the later ones get
-            #  the blocks the library's pool took back.  `cold_ms` is the best of the three, `cold_fresh_memory_ms` the first.
+            #  the blocks the library's pool took back and inherit the work arrays' capacities.  `cold_ms` is the best of the five,
+            #  `cold_fresh_memory_ms` the first.
             #  svgr_batch_draw = plan + render behind ONE wait; the two-call form it replaces is timed beside it)
             colds, cb = [], None
-            for _ in range(3):
+            for _ in range(5):
                 if cb is not None:
                     cb.destroy()
                 ctx.sync()
@@ -807,6 +808,7 @@ def main():
                 colds.append((time.perf_counter() - c0) * 1e3)
             extras["cold_ms"] = round(min(colds), 4)
             extras["cold_fresh_memory_ms"] = round(colds[0], 4)
+            extras["cold_frames_ms"] = [round(c, 4) for c in colds]
             cb.destroy()
             ctx.sync()
             c0 = time.perf_counter()
@@ -853,8 +855,9 @@ def main():
             extras["plan_ms"] = round(t_plan / reps * 1e3, 4)
             extras["replan_over_step"] = round((t_replan / reps_d) / (t_max / args.steps), 2)
             extras["cold_replan_what"] = ("a frame with NEW geometry (the reference's only mode, S:948-957), host clock, outside the timed region.  cold_ms: host "
-                                          "arrays -> svgr_batch_create + svgr_batch_draw (plan + render behind one wait at its end), best of three in a row "
-                                          "(each batch destroyed before the next: device blocks recycled), cold_fresh_memory_ms the first of them; "
+                                          "arrays -> svgr_batch_create + svgr_batch_draw (plan + render behind one wait at its end), best of five in a row "
+                                          "(cold_frames_ms; each batch destroyed before the next: its device blocks are recycled and its work arrays' CAPACITIES "
+                                          "inherited, so frames 2.. plan in one pass), cold_fresh_memory_ms the first of them (fresh device memory, two-pass plan); "
                                           "replan_ms: svgr_batch_set_transforms (every path moved by a fraction of a pixel) + svgr_batch_draw, mean of 10; "
                                           "value_replan = path-pixels / replan_ms; *_plan_then_render_ms: the same with svgr_batch_plan + svgr_batch_render "
                                           "+ sync (round 5's form); plan_ms: that plan call alone")

@@ -446,8 +446,9 @@ struct BatchDev {
     struct ShardLine {
         int cursor;         // edges (k_flatten)
         int add_cursor;     // add slots (k_path_build: the slabs of path p reserve in shard p % n)
-        unsigned rows_crossed;   // the plan's counting pass: rows the kept edges cross (sizes the add lists' first guess)
-        int pad[29];
+        unsigned rows_crossed;   // the plan's counting pass: rows the kept edges cross, + 1 per edge (sizes the add lists' first guess)
+        unsigned cols_crossed;   // ... and columns
+        int pad[28];
     } shard[16];
 };
 constexpr int NSH = 16;
@@ -696,23 +697,23 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
         if (seg_ok && sub == 0 && so1 > so0) atomicAdd(&bd->shard[(int)((blockIdx.x * (FL_BLOCK / 64) + (threadIdx.x >> 6)) % NSH)].cursor, so1 - so0);
     } else {
     const bool census = !EMIT && seg_cnt != nullptr;
-    double rows_x = 0.0;
+    double rows_x = 0.0, cols_x = 0.0;
     if (mode == 1) {
         cnt = 1;
         track(node[0], node[1]);
         track(node[6], node[7]);
-        if (census) rows_x = fabs(node[6] - node[0]);
+        if (census) { rows_x = fabs(node[6] - node[0]); cols_x = fabs(node[7] - node[1]); }
     } else if (mode == 2) {
         // pieces come in curve order and share end points: track the first start and every end.  The ends of the
         // first two pieces are remembered: nearly every lane has one or two, and then the second traversal is skipped.
         track(node[0], node[1]);
-        cnt = flatten_subtree<FL_ENDS>(node, thr, kMaxFlattenDepth - SUB, [&](double r0_, double, double r1, double c1) {
+        cnt = flatten_subtree<FL_ENDS>(node, thr, kMaxFlattenDepth - SUB, [&](double r0_, double c0_, double r1, double c1) {
             track(r1, c1);
-            if (census) rows_x += fabs(r1 - r0_);
+            if (census) { rows_x += fabs(r1 - r0_); cols_x += fabs(c1 - c0_); }
         }, ovf, qe);
     }
     if (ovf) atomicOr(&bd->err, 1);
-    if (!keep) { cnt = 0; rows_x = 0.0; }
+    if (!keep) { cnt = 0; rows_x = 0.0; cols_x = 0.0; }
     const int shard = (int)((blockIdx.x * (FL_BLOCK / 64) + (threadIdx.x >> 6)) % NSH);
     if (census) {
         // (a piece crosses |dr| + 1 rows at most; what lies outside the viewport's rows is counted too: a guess's upper side)
@@ -721,6 +722,13 @@ __global__ __launch_bounds__(FL_BLOCK, SVGR_FL_WAVES) void k_flatten(const doubl
         int wrows;
         (void)wave_excl_scan(mine < (1 << 24) ? mine : (1 << 24), threadIdx.x & 63, wrows);
         if ((threadIdx.x & 63) == 0 && wrows > 0) atomicAdd(&bd->shard[shard].rows_crossed, (unsigned)wrows);
+        // (columns: a piece cannot make adds beyond the viewport's columns -- what lies left of it folds into column 0, what lies right
+        //  of the layer is dropped --; `edge_cap`, unused by a counting pass, carries the viewport's width)
+        const double ccap = (double)(edge_cap > 0 ? (edge_cap + 8) * (cnt > 0 ? cnt : 1) : 1 << 22);
+        const int minec = cnt > 0 ? (int)(cols_x < ccap ? cols_x : ccap) : 0;
+        int wcols;
+        (void)wave_excl_scan(minec < (1 << 24) ? minec : (1 << 24), threadIdx.x & 63, wcols);
+        if ((threadIdx.x & 63) == 0 && wcols > 0) atomicAdd(&bd->shard[shard].cols_crossed, (unsigned)wcols);
     }
     int base;
     bool fits;
@@ -4215,7 +4223,8 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                 SVGR_LAUNCH(kern, fgrid, dim3(FL_BLOCK), 0, st, (const double*)b->segs.p,
                                    (const uint8_t*)b->seg_kind.p, (const int*)b->seg_path.p, (const double*)b->path_m6.p, ns,
                                    b->thr, (double*)nullptr, (int*)nullptr, b->shards, b->pkeys(), b->bd(), b->own, b->vp[0],
-                                   n_bands_vp, prow, seg_list, n_items, upto == 1 ? b->seg_cnt.p : (int*)nullptr, (const int*)nullptr, 0,
+                                   n_bands_vp, prow, seg_list, n_items, upto == 1 ? b->seg_cnt.p : (int*)nullptr, (const int*)nullptr,
+                                   use_vp ? b->vp[3] : 0 /* a counting pass: the viewport's width (bounds the columns it adds up) */,
                                    upto == 1 ? b->lane_off.p : (int*)nullptr, (int*)nullptr, (unsigned long long*)nullptr);
             };
             if (fl_sub == 6) launch_cnt(k_flatten<false, false, 6>); else launch_cnt(k_flatten<false, false, 5>);
@@ -4715,29 +4724,6 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
             return fail(SVGR_E_INVALID, "path %lld is marked clipped but path %lld is not a clip source", (long long)p, (long long)p - 1);
     }
     if (d->path_seg_off[0] != 0 || d->path_seg_off[d->n_paths] != d->n_segs) return fail(SVGR_E_INVALID, "path_seg_off does not span segs");
-    {
-        // (one pass without early exits -- the compiler vectorises it --; the slow loops below only name what it found)
-        auto nonfin = [](uint64_t x) -> uint64_t { return ((x >> 52) & 0x7ffu) == 0x7ffu; };
-        const uint64_t* u = (const uint64_t*)d->segs;
-        uint64_t bad = 0, bad_kind = 0;
-        for (int64_t s = 0; s < d->n_segs; ++s) {
-            const uint64_t lo = nonfin(u[8 * s]) | nonfin(u[8 * s + 1]) | nonfin(u[8 * s + 2]) | nonfin(u[8 * s + 3]);
-            const uint64_t hi = nonfin(u[8 * s + 4]) | nonfin(u[8 * s + 5]) | nonfin(u[8 * s + 6]) | nonfin(u[8 * s + 7]);
-            bad |= lo | (hi & (uint64_t)(d->seg_kind[s] == SVGR_SEG_CUBIC));
-            bad_kind |= (uint64_t)(d->seg_kind[s] > 1);
-        }
-        if (bad | bad_kind)
-            for (int64_t s = 0; s < d->n_segs; ++s) {
-                if (d->seg_kind[s] > 1) return fail(SVGR_E_INVALID, "unsupported path type: `%d`", (int)d->seg_kind[s]);  // S:945
-                int npts = d->seg_kind[s] == SVGR_SEG_CUBIC ? 8 : 4;
-                for (int k = 0; k < npts; ++k)
-                    if (!std::isfinite(d->segs[8 * s + k])) return fail(SVGR_E_INVALID, "non-finite coordinate in segment %lld", (long long)s);
-            }
-        const uint64_t* um = (const uint64_t*)d->path_m6;
-        uint64_t bad_m = 0;
-        for (int64_t i = 0; i < 6 * d->n_paths; ++i) bad_m |= nonfin(um[i]);
-        if (bad_m) return fail(SVGR_E_INVALID, "non-finite transform");
-    }
     if (!(d->flatness > 0.0) || !std::isfinite(d->flatness)) return fail(SVGR_E_INVALID, "flatness must be positive");
     if (d->viewport[2] > 0 && (d->viewport[3] <= 0 || d->viewport[2] > (1 << 24) || d->viewport[3] > (1 << 24) ||
                                std::llabs(d->viewport[0]) > (1 << 28) || std::llabs(d->viewport[1]) > (1 << 28)))
@@ -4779,6 +4765,29 @@ static int batch_create_impl(svgr_ctx* ctx, const svgr_batch_desc* d, svgr_batch
     {
         int* s0 = (int*)(hb + o_seg0);
         for (size_t p = 0; p <= np; ++p) s0[p] = (int)d->path_seg_off[p];
+    }
+    {
+        // non-finite input is refused here (one pass without early exits over the copy just made; the slow loops only name what it found)
+        auto nonfin = [](uint64_t x) -> uint64_t { return ((x >> 52) & 0x7ffu) == 0x7ffu; };
+        const uint64_t* u = (const uint64_t*)(hb + o_segs);   // (the copy just made: in the cache)
+        uint64_t bad = 0, bad_kind = 0;
+        for (int64_t s = 0; s < d->n_segs; ++s) {
+            const uint64_t lo = nonfin(u[8 * s]) | nonfin(u[8 * s + 1]) | nonfin(u[8 * s + 2]) | nonfin(u[8 * s + 3]);
+            const uint64_t hi = nonfin(u[8 * s + 4]) | nonfin(u[8 * s + 5]) | nonfin(u[8 * s + 6]) | nonfin(u[8 * s + 7]);
+            bad |= lo | (hi & (uint64_t)(d->seg_kind[s] == SVGR_SEG_CUBIC));
+            bad_kind |= (uint64_t)(d->seg_kind[s] > 1);
+        }
+        if (bad | bad_kind)
+            for (int64_t s = 0; s < d->n_segs; ++s) {
+                if (d->seg_kind[s] > 1) { b->release(); delete b; return fail(SVGR_E_INVALID, "unsupported path type: `%d`", (int)d->seg_kind[s]); }  // S:945
+                int npts = d->seg_kind[s] == SVGR_SEG_CUBIC ? 8 : 4;
+                for (int k = 0; k < npts; ++k)
+                    if (!std::isfinite(d->segs[8 * s + k])) { b->release(); delete b; return fail(SVGR_E_INVALID, "non-finite coordinate in segment %lld", (long long)s); }
+            }
+        const uint64_t* um = (const uint64_t*)(hb + o_m6);
+        uint64_t bad_m = 0;
+        for (int64_t i = 0; i < 6 * d->n_paths; ++i) bad_m |= nonfin(um[i]);
+        if (bad_m) { b->release(); delete b; return fail(SVGR_E_INVALID, "non-finite transform"); }
     }
     rc = b->in_dev.ensure(total);
     if (!rc) {
@@ -5334,10 +5343,11 @@ static int two_pass_issue(svgr_batch* b, void* staging) {
     if (rc) return rc;
     const double t_1 = now_ms();
     const double t_2 = now_ms();
-    long long n_edges = 0, rows_x = 0;
+    long long n_edges = 0, rows_x = 0, cols_x = 0;
     for (int k = 0; k < NSH; ++k) {
         n_edges += b->host_bd.shard[k].cursor;
         rows_x += b->host_bd.shard[k].rows_crossed;
+        cols_x += b->host_bd.shard[k].cols_crossed;
     }
     if (n_edges > 0x7fffffff / 4) return fail(SVGR_E_OVERFLOW, "%lld edges: beyond the 32-bit edge index", n_edges);
     b->n_edges = n_edges;
@@ -5363,13 +5373,16 @@ static int two_pass_issue(svgr_batch* b, void* staging) {
     int longest = 0, run = 0;
     for (int k = 0; k < b->n_bands; ++k) { run += diff[(size_t)k]; longest = std::max(longest, run); }
     {
-        // add slots: a few pieces per edge row (more for shallow rows: a piece per PX columns), up to 2 x TR carry-ins and
-        // sentinels per cell with pieces.  (synth4096: 7.6 M adds, 2.5 M edge rows, 0.8 M edges, 0.2 M cells: the guess is 11 M -- fresh device memory is cleared before its first use, a cold render pays for every megabyte it asks for)
-        double guess = 3.0 * (double)rows_x + 1.0 * (double)n_edges + 8.0 * (double)b->n_cells + 65536.0;
+        // add slots.  An edge row makes two adds (the pixel it lies in and the carry into the next) plus one per column border it
+        // crosses (fewer for long shallow spans: one per PX columns): pieces <= 2 x edge rows + columns crossed.  A cell with pieces
+        // adds up to TR carry-ins and TR sentinels: 9 per cell of the bbox on the bench scene, 12 budgeted.  (synth4096: 7.61 M adds;
+        // rows 2.17 M, columns 1.4 M, cells 0.21 M -> 8.3 M, x 1.15 per shard, x 1.125 by layout_adds: 10.7 M slots -- round 5 asked
+        // for 12.9 M; fresh device memory is cleared before its first use and a cold frame pays ~3.4 us per megabyte it asks for)
+        double guess = 2.0 * (double)rows_x + (double)cols_x + 12.0 * (double)b->n_cells + 65536.0;
         if (const char* sk = getenv("SVGR_TWO_PASS_SHRINK")) guess /= std::max(atof(sk), 1.0);   // (tests: a guess that is too small on purpose)
         if (guess > (double)(1ll << 29)) return 0;
         int need[NSH];
-        for (int k = 0; k < NSH; ++k) need[k] = (int)(guess * 1.25 / NSH) + 8192;
+        for (int k = 0; k < NSH; ++k) need[k] = (int)(guess * 1.15 / NSH) + 8192;
         if ((rc = b->layout_adds(need, NSH))) return rc;
     }
     b->mask_words = (int)std::max<int64_t>(((int64_t)std::max(longest, 1) + 63) / 64, 1);
@@ -5414,8 +5427,8 @@ static int two_pass_issue(svgr_batch* b, void* staging) {
     if ((rc = run_geometry(b, 4, true))) return rc;
     if ((rc = issue_readback(b, true, staging))) return rc;
     if (getenv("SVGR_DBG_PLAN"))
-        fprintf(stderr, "[plan] two passes, ms: pass 1 issued %.3f, drained %.3f, buffers sized %.3f, pass 2 issued %.3f | edges %lld, rows crossed %lld, pairs %lld, cells %lld, slabs %lld, add slots %lld, longest band list %d\n",
-                t_1 - t_0, t_2 - t_1, t_3 - t_2, now_ms() - t_3, n_edges, rows_x, (long long)b->n_pb, (long long)b->n_cells, (long long)b->n_slabs, (long long)b->n_adds, longest);
+        fprintf(stderr, "[plan] two passes, ms: pass 1 issued %.3f, drained %.3f, buffers sized %.3f, pass 2 issued %.3f | edges %lld, rows crossed %lld, columns %lld, pairs %lld, cells %lld, slabs %lld, add slots %lld, longest band list %d\n",
+                t_1 - t_0, t_2 - t_1, t_3 - t_2, now_ms() - t_3, n_edges, rows_x, cols_x, (long long)b->n_pb, (long long)b->n_cells, (long long)b->n_slabs, (long long)b->n_adds, longest);
     return 1;
 }
 // pass 2 has drained: validate it.  1 planned, 0 fall back (a guess was too small), < 0 error
