@@ -1526,7 +1526,15 @@ static_assert(PB_BANDS * SVGR_TR * PB_BATCH < (1 << 20) && PB_BATCH < (1 << 11),
 // kernel --, so they wait for the wave's LDS operations and not, as __syncthreads() does, for its global stores as well: behind
 // pass A those are the add lists on their way out, and a wave that waits for their acknowledgement stands still for a microsecond.
 __device__ __forceinline__ void pb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-template <bool PLANNED>
+// MODE 0: the exact two-pass form (PLANNED = false above).  MODE 1: a planned render (PLANNED = true above).
+// MODE 2 (BOUNDED, round 6): ONE pass over the edge rows WITHOUT a plan -- the pass of a re-plan or of a first plan, which used to be
+// MODE 0.  While a batch of edges is staged every edge adds, to each cell it can reach, an UPPER BOUND of the adds it can leave there
+// (rows in the band x the most pieces one of its rows can put into one tile); a cell's place is the prefix sum of the bounds (plus
+// room for its carry-ins and sentinels), the slab reserves that much in ONE atomic, and from there on the pass is MODE 1's: pieces
+// stored as they are computed, the walk writes the cells (and `cell_plan`: the planned renders that follow take these places).  The
+// lists keep the slack between them (memory, not traffic: only what is written is read).  A bound that did not hold is caught like
+// a plan that does not fit: the pieces are not stored, error bit 32, the staged plan (MODE 0, exact) takes over.
+template <int MODE>
 __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const Slab* __restrict__ slabs, const double* __restrict__ edges,
                                                            const int* __restrict__ pair_idx, const double* __restrict__ path_paint,
                                                            const uint8_t* __restrict__ path_rule, const int* __restrict__ path_group,
@@ -1540,6 +1548,8 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
 #else
 #define PB_STAMP(i) do { } while (0)
 #endif
+    constexpr bool PLANNED = MODE != 0;     // the cells' places are known BEFORE the rows' pieces are computed: one pass, the walk writes the cells
+    constexpr bool BOUNDED = MODE == 2;     // ... known from bounds this workgroup makes itself, not from a plan
     PB_STAMP(0);
     __shared__ __attribute__((aligned(16))) double s_sum[PB_CELLS * TR];
     __shared__ double s_left[TR];
@@ -1593,7 +1603,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     //  the entry-bitmask bits with: asked for here, a global load that has long landed when the walk starts)
     int my_pidx = 0;
     if ((tid & (TR - 1)) == 0 && tid / TR < sl.nb && owns_band(own, sl.band0 + tid / TR)) my_pidx = pair_idx[sl.pb_off + sl.band0 + tid / TR - sl.b0];
-    if (PLANNED) {
+    if (PLANNED && !BOUNDED) {
         if (tid < n_cell) {
             const int g = tid / sl.nk, k = tid - g * sl.nk;
             const int cell = cell_of(g, k);
@@ -1604,7 +1614,7 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
 
     // a batch of edges (slot = tid + j * PB_THREADS): set up, rows inside the slab counted; the edges that have any are kept,
     // in order, with the prefix sums of their row counts -> number of (edge, row) tasks of the batch
-    auto stage = [&](int eb) -> int {
+    auto stage = [&](int eb, bool bounds = false) -> int {
         int cnt[PB_EPL], eya[PB_EPL];
         EdgeLds el[PB_EPL];
 #pragma unroll
@@ -1640,6 +1650,44 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         if (PLANNED && plan_pending) {
             if (tid < PB_CELLS) { s_pos[tid] = my_plan.x; s_plan_n[tid] = my_plan.y; }
             plan_pending = false;
+        }
+        if (BOUNDED && bounds) {
+            // Every kept edge adds an upper bound of the adds it can leave to each cell it can reach: (its rows in the band) x (the most
+            // pieces ONE of its rows can put into ONE tile).  A row of an edge crosses n <= floor(|dx/dy|) + 2 column borders (dy <= 1):
+            // n + 1 pieces up to n = 3, beyond that four single ones and a run cut into chunks of PX columns (record_adds, run_pieces).
+            // The columns it can reach in a band: between its entry into the band's first row and its exit from the last, one column
+            // of slack on either side for the recurrence's rounding and one more on the right for the piece that carries into the
+            // next column; clamped like row_tiles clamps a row's.
+#pragma unroll
+            for (int j = 0; j < PB_EPL; ++j) {
+                if (cnt[j] <= 0) continue;
+                const int ya = eya[j] & 0x7fffffff, yb = ya + cnt[j];
+                const double dx = el[j].dxdy, adx = fabs(dx);
+                const int m = (adx < 65536.0 ? (int)adx : 65536) + 2;
+                const int per_row = m <= 3 ? m + 1 : 6 + ((m - 3 < TC ? m - 3 : TC) + PX - 1) / PX;
+                for (int y0 = ya; y0 < yb;) {
+                    const int vrow = r0 + y0 - vr0, band = vrow / TR;
+                    int y1 = y0 + TR - (vrow & (TR - 1));
+                    y1 = y1 < yb ? y1 : yb;
+                    if (owns_band(own, band)) {
+                        const double t0 = (double)(y0 > ya ? y0 - ya - 1 : 0), t1 = (double)(y1 - ya);
+                        const double xa = el[j].x + dx * t0, xb = el[j].x + dx * t1;
+                        const int lo = clamp_to_int(floor(xa < xb ? xa : xb)) - 1, hi = clamp_to_int(floor(xa < xb ? xb : xa)) + 2;
+                        if (lo < cols) {   // (rows wholly beyond the layer store nothing, S:2260)
+                            const int cf = lo > 0 ? lo : 0;
+                            int cl = hi > 0 ? hi : 0;
+                            cl = cl < cols - 1 ? cl : cols - 1;
+                            int kf = (cf - x_first) / TC, kl = (cl - x_first) / TC;
+                            kf = kf > sl.k0 ? kf : sl.k0;
+                            kl = kl < sl.k0 + sl.nk - 1 ? kl : sl.k0 + sl.nk - 1;
+                            const int room = (y1 - y0) * per_row;
+                            for (int k = kf; k <= kl; ++k)
+                                __hip_atomic_fetch_add(&s_plan_n[(band - sl.band0) * sl.nk + (k - sl.k0)], room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                    y0 = y1;
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < PB_EPL; ++j)
@@ -1825,6 +1873,48 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
     // ---- pass A ----
     const bool one_batch = e_end - e_begin <= PB_BATCH;
     int total = 0, n_rows = 0;
+    if (BOUNDED) {
+        // the bounds of every staged batch, then the cells' places from them (one reservation for the slab), then the rows' pass
+        for (int eb = e_begin; eb < e_end; eb += PB_BATCH) {
+            total = stage(eb, true);
+            n_rows += total;
+        }
+        PB_STAMP(1);
+        static_assert(PB_CELLS <= 128, "the cells' places: a prefix sum by the first two waves");
+        int room = 0, excl = 0;
+        if (tid < 128) {
+            const int bnd = tid < n_cell ? s_plan_n[tid] : 0;
+            // (+ its carry-in adds: TR at most; + its sentinels: TR at most, only in the column tile the layer ends in)
+            const int kk = tid < n_cell ? tid % sl.nk : 0;
+            const bool ends_here = cols - ((sl.k0 + kk) * TC + x_first) < TC;
+            room = bnd > 0 ? bnd + TR + (ends_here ? TR : 0) : 0;
+            int wt;
+            excl = wave_excl_scan(room, lane, wt);
+            if (lane == 0) s_ptot[wave] = wt;
+        }
+        pb_barrier();
+        if (tid == 0) {
+            const int all = s_ptot[0] + s_ptot[1];
+            const int sh = p % ash.n;
+            int at = 0;
+            if (all > 0) at = atomicAdd(&bd->shard[sh].add_cursor, all);
+            int ok = 1;
+            if ((long long)at + all > (long long)ash.cap[sh]) { atomicOr(&bd->err, 64); ok = 0; }
+            s_base = ash.base[sh] + at;
+            s_ok = ok;
+        }
+        pb_barrier();
+        if (tid < n_cell) s_pos[tid] = room > 0 && s_ok ? s_base + (wave ? s_ptot[0] : 0) + excl : (int)0x80000000;
+        pb_barrier();
+        if (one_batch) {
+            for_rows(total, [&](const RowAt& ra) { count_row(ra, std::true_type{}); });   // (the batch is still staged)
+        } else {
+            for (int eb = e_begin; eb < e_end; eb += PB_BATCH) {
+                const int tot = stage(eb);
+                for_rows(tot, [&](const RowAt& ra) { count_row(ra, std::true_type{}); });
+            }
+        }
+    } else
     for (int eb = e_begin; eb < e_end; eb += PB_BATCH) {
         total = stage(eb);
         PB_STAMP(1);
@@ -1913,7 +2003,11 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                 const int n_add = cls == 2 ? __popc(cm) + __popc(sm) + own_n : 0;
                 if (active) {
                     if (PLANNED) {
-                        if (row_l == 0 && own_n != s_plan_n[ci]) mismatch = true;
+                        if (row_l == 0 && (BOUNDED ? own_n > s_plan_n[ci] : own_n != s_plan_n[ci])) mismatch = true;   // (more pieces than the bound / not the plan's count)
+                        if (BOUNDED && row_l == 0) {   // (what the planned renders that follow take their places from)
+                            const int cell = cell_of(g, k);
+                            if (cell < cell_cap) cell_plan[cell] = make_int2(cls == 2 ? s_pos[ci] : (int)0x80000000, cls == 2 ? own_n : 0);
+                        }
                         if (cls != 0) write_cell(g, k, cls, cin, cm, sm, own_n, n_add, s_pos[ci], row_l, idx, true);
                     } else {
                         s_sum[ci * TR + row_l] = cin;
@@ -3999,6 +4093,7 @@ struct svgr_batch {
     AddShards add_shards{};                 // where each shard's add slots live (the slabs of path p reserve in shard p % n)
     int64_t n_adds = 0;                     // add slots in all the shards
     bool count_adds_only = false;           // the plan's measuring run: k_path_build sizes the add lists, writes none
+    bool adds_roomy = false;                // the add lists were sized by a guess with room for k_path_build<2>'s bounds (not measured exactly by the staged plan)
     bool fl_scan = false;                   // this pass flattens in ONE traversal (k_flatten<.., SCAN>): a re-plan's single pass
     bool late_scan = false;                 // the counting pass leaves k_seg_scan to its caller (two_pass_issue: behind the census's read-back)
     bool census_bbox = false;               // the two-pass plan's first pass: the counting flatten is followed by k_path_bbox (pairs, cells, slabs counted)
@@ -4122,6 +4217,7 @@ struct WorkSpare {
     int mask_words = 1;
     AddShards add_shards{};
     int64_t n_adds = 0;
+    bool adds_roomy = false;
     DevArr<int> edge_path, band_start, band_count, pair_idx, slab_at, seg_cnt, seg_off, lane_off, band_item0;
     DevArr<TileEntry> entries;
     DevArr<double> edges;
@@ -4150,7 +4246,7 @@ static void spare_stash(svgr_batch* b) {
     WorkSpare& w = *c->spare;
     w.release();
     for (int k = 0; k < 4; ++k) w.vp[k] = b->sized_vp[k];
-    w.n_segs = b->n_segs; w.n_paths = b->n_paths; w.mask_words = b->mask_words; w.add_shards = b->add_shards; w.n_adds = b->n_adds;
+    w.n_segs = b->n_segs; w.n_paths = b->n_paths; w.mask_words = b->mask_words; w.add_shards = b->add_shards; w.n_adds = b->n_adds; w.adds_roomy = b->adds_roomy;
 #define X(a) w.a = b->a; b->a.p = nullptr; b->a.cap = 0; b->a.view = false;
     SVGR_SPARE_ARRAYS(X)
 #undef X
@@ -4167,7 +4263,7 @@ static bool spare_adopt(svgr_batch* b) {
 #define X(a) b->a.release(); b->a = w->a; w->a.p = nullptr; w->a.cap = 0; w->a.view = false;
     SVGR_SPARE_ARRAYS(X)
 #undef X
-    b->mask_words = w->mask_words; b->add_shards = w->add_shards; b->n_adds = w->n_adds;
+    b->mask_words = w->mask_words; b->add_shards = w->add_shards; b->n_adds = w->n_adds; b->adds_roomy = w->adds_roomy;
     b->n_bands = (b->vp[2] + TR - 1) / TR;
     b->masks_zeroed = false;   // (whatever the last render of the old batch left: cleared again)
     b->slab_at_valid = false;
@@ -4317,7 +4413,9 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                                b->count_adds_only ? (TileAdd*)nullptr : b->adds.p, b->cell_plan.p, b->bd(), b->own, b->planned ? 0 : 1,
                                b->deterministic ? 1 : 0, pb_dbg);
         };
-        if (placed) launch_pb(k_path_build<true>); else launch_pb(k_path_build<false>);
+        // (an unplanned pass over add lists sized with room to spare: ONE pass on the workgroup's own bounds, MODE 2)
+        const bool bounded = !placed && !b->count_adds_only && b->adds.p && b->adds_roomy && !b->safe_path && !getenv("SVGR_NO_BOUNDED_BUILD");
+        if (placed) launch_pb(k_path_build<1>); else if (bounded) launch_pb(k_path_build<2>); else launch_pb(k_path_build<0>);
 #ifdef SVGR_DBG_PB_STAMP
         if (pb_dbg && b->planned && !b->count_adds_only) {
             static int n_dump = 0;
@@ -5076,6 +5174,7 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr, bool again = false
         int need[NSH];
         for (int k = 0; k < NSH; ++k) need[k] = (int)(std::min<int64_t>(4 * row_guess / (small ? 1 : 2) + 2048, 1 << 26) / shrink[3]);
         rc = b->size_adds(need, n_sh);
+        b->adds_roomy = true;
     }
     rc = rc ? rc : b->size_masks(np);
     if (rc) return rc;
@@ -5378,12 +5477,13 @@ static int two_pass_issue(svgr_batch* b, void* staging) {
         // adds up to TR carry-ins and TR sentinels: 9 per cell of the bbox on the bench scene, 12 budgeted.  (synth4096: 7.61 M adds;
         // rows 2.17 M, columns 1.4 M, cells 0.21 M -> 8.3 M, x 1.15 per shard, x 1.125 by layout_adds: 10.7 M slots -- round 5 asked
         // for 12.9 M; fresh device memory is cleared before its first use and a cold frame pays ~3.4 us per megabyte it asks for)
-        double guess = 2.0 * (double)rows_x + (double)cols_x + 12.0 * (double)b->n_cells + 65536.0;
+        double guess = 1.1 * (2.0 * (double)rows_x + (double)cols_x) + 14.0 * (double)b->n_cells + 65536.0;   // (k_path_build<2> reserves by BOUNDS: a tenth more than the pieces, TR (+ TR) per cell that can have any)
         if (const char* sk = getenv("SVGR_TWO_PASS_SHRINK")) guess /= std::max(atof(sk), 1.0);   // (tests: a guess that is too small on purpose)
         if (guess > (double)(1ll << 29)) return 0;
         int need[NSH];
         for (int k = 0; k < NSH; ++k) need[k] = (int)(guess * 1.15 / NSH) + 8192;
         if ((rc = b->layout_adds(need, NSH))) return rc;
+        b->adds_roomy = true;
     }
     b->mask_words = (int)std::max<int64_t>(((int64_t)std::max(longest, 1) + 63) / 64, 1);
     b->masks_zeroed = false;
@@ -5546,6 +5646,7 @@ static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
         int need[NSH];
         for (int k = 0; k < NSH; ++k) need[k] = b->host_bd.shard[k].add_cursor;
         if ((rc = b->size_adds(need, NSH))) return rc;
+        b->adds_roomy = false;   // (measured: the lists are dense, k_path_build<0> from here on)
     }
     // 4. full geometry once, to validate the capacities and fetch the bboxes
     if (int rc = run_geometry(b, 4, true)) return rc;
