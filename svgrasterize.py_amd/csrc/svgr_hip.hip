@@ -1652,35 +1652,48 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             plan_pending = false;
         }
         if (BOUNDED && bounds) {
-            // Every kept edge adds an upper bound of the adds it can leave to each cell it can reach: (its rows in the band) x (the most
-            // pieces ONE of its rows can put into ONE tile).  A row of an edge crosses n <= floor(|dx/dy|) + 2 column borders (dy <= 1):
-            // n + 1 pieces up to n = 3, beyond that four single ones and a run cut into chunks of PX columns (record_adds, run_pieces).
-            // The columns it can reach in a band: between its entry into the band's first row and its exit from the last, one column
-            // of slack on either side for the recurrence's rounding and one more on the right for the piece that carries into the
-            // next column; clamped like row_tiles clamps a row's.
+            // Every kept edge adds an upper bound of the adds it can leave to each cell it can reach.  A row of an edge leaves two
+            // pieces (the pixel it lies in, the carry into the next) plus one per column border it crosses (row_record: n + 1 pieces,
+            // n = borders + 1; fewer where a long span is cut into runs, record_adds); x runs monotonically along an edge, so over
+            // the edge's rows in ONE band that is 2 x rows + |floor(x at its exit from the band) - floor(x at its entry)| -- exactly.
+            // Entry and exit in closed form (the recurrence's sum of dy is yhi - ylo), widened by a relative 1e-9 so that a value the
+            // recurrence rounds to the other side of an integer is counted as crossing it.  The columns it can reach, for the TILES:
+            // one more on the right for the carry piece; clamped like row_tiles clamps a row's.  An edge that reaches two tiles of a
+            // band gives each the whole amount.
 #pragma unroll
             for (int j = 0; j < PB_EPL; ++j) {
                 if (cnt[j] <= 0) continue;
                 const int ya = eya[j] & 0x7fffffff, yb = ya + cnt[j];
-                const double dx = el[j].dxdy, adx = fabs(dx);
-                const int m = (adx < 65536.0 ? (int)adx : 65536) + 2;
-                const int per_row = m <= 3 ? m + 1 : 6 + ((m - 3 < TC ? m - 3 : TC) + PX - 1) / PX;
+                const double dx = el[j].dxdy;
+                const double ylo = (double)ya > el[j].p0y ? (double)ya : el[j].p0y;   // where the edge's first traced row in the slab starts
                 for (int y0 = ya; y0 < yb;) {
                     const int vrow = r0 + y0 - vr0, band = vrow / TR;
                     int y1 = y0 + TR - (vrow & (TR - 1));
                     y1 = y1 < yb ? y1 : yb;
                     if (owns_band(own, band)) {
-                        const double t0 = (double)(y0 > ya ? y0 - ya - 1 : 0), t1 = (double)(y1 - ya);
-                        const double xa = el[j].x + dx * t0, xb = el[j].x + dx * t1;
-                        const int lo = clamp_to_int(floor(xa < xb ? xa : xb)) - 1, hi = clamp_to_int(floor(xa < xb ? xb : xa)) + 2;
+                        const double ta = ((double)y0 > el[j].p0y ? (double)y0 : el[j].p0y) - ylo;
+                        const double tb = ((double)y1 < el[j].p1y ? (double)y1 : el[j].p1y) - ylo;
+                        const double xa = el[j].x + dx * ta, xb = el[j].x + dx * tb;
+                        double xlo = xa < xb ? xa : xb, xhi = xa < xb ? xb : xa;
+                        xlo -= 1e-9 * (1.0 + fabs(xlo)); xhi += 1e-9 * (1.0 + fabs(xhi));
+                        const int lo = clamp_to_int(floor(xlo)), hi = clamp_to_int(floor(xhi));
                         if (lo < cols) {   // (rows wholly beyond the layer store nothing, S:2260)
                             const int cf = lo > 0 ? lo : 0;
-                            int cl = hi > 0 ? hi : 0;
+                            int cl = hi + 1 > 0 ? hi + 1 : 0;
                             cl = cl < cols - 1 ? cl : cols - 1;
                             int kf = (cf - x_first) / TC, kl = (cl - x_first) / TC;
                             kf = kf > sl.k0 ? kf : sl.k0;
                             kl = kl < sl.k0 + sl.nk - 1 ? kl : sl.k0 + sl.nk - 1;
-                            const int room = (y1 - y0) * per_row;
+                            // (borders outside the layer make no piece of their own: right of it nothing is stored, left of it every piece
+                            //  folds into column 0 -- up to five adds there per row instead of two.  A long span is cut into runs: four
+                            //  single pieces and a run piece per PX columns, 13 per row and tile at most)
+                            const int lo_c = lo > -1 ? lo : -1;
+                            int hi_c = hi > -1 ? hi : -1;
+                            hi_c = hi_c < cols ? hi_c : cols;
+                            const int nr = y1 - y0, nc = hi_c - lo_c, fold = lo < 0 ? 3 * nr : 0;
+                            int room = 2 * nr + nc;
+                            room = room < 6 * nr + nc / PX + 1 ? room : 6 * nr + nc / PX + 1;
+                            room = (room < 13 * nr ? room : 13 * nr) + fold;
                             for (int k = kf; k <= kl; ++k)
                                 __hip_atomic_fetch_add(&s_plan_n[(band - sl.band0) * sl.nk + (k - sl.k0)], room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
@@ -1884,10 +1897,13 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
         int room = 0, excl = 0;
         if (tid < 128) {
             const int bnd = tid < n_cell ? s_plan_n[tid] : 0;
-            // (+ its carry-in adds: TR at most; + its sentinels: TR at most, only in the column tile the layer ends in)
-            const int kk = tid < n_cell ? tid % sl.nk : 0;
+            // (+ its carry-in adds: one per row of the layer in the band at most; + its sentinels: likewise, only in the column tile the
+            //  layer ends in)
+            const int gg = tid < n_cell ? tid / sl.nk : 0, kk = tid < n_cell ? tid - gg * sl.nk : 0;
             const bool ends_here = cols - ((sl.k0 + kk) * TC + x_first) < TC;
-            room = bnd > 0 ? bnd + TR + (ends_here ? TR : 0) : 0;
+            const int b_lo = vr0 + (sl.band0 + gg) * TR - r0;                       // the band's first row in layer rows
+            const int rin = (b_lo + TR < rows ? b_lo + TR : rows) - (b_lo > 0 ? b_lo : 0);   // rows of the layer in the band
+            room = bnd > 0 ? bnd + rin + (ends_here ? rin : 0) : 0;
             int wt;
             excl = wave_excl_scan(room, lane, wt);
             if (lane == 0) s_ptot[wave] = wt;
