@@ -4163,6 +4163,8 @@ struct svgr_batch {
     BatchDev host_bd{};
     EdgeShards shards{};       // plan result: where each flatten shard's edges live
     std::vector<int> host_bbox;
+    bool host_bbox_stale = false;   // svgr_batch_draw's re-plan left the bboxes on the device: fetched when somebody asks (ensure_host_bbox)
+    bool defer_bbox = false;        // ... this pass's read-back is the scalars alone
     std::vector<TimedEvents> events;
     std::vector<hipEvent_t> event_pool;
 
@@ -4486,8 +4488,9 @@ static int eval_dev_err(int e, int* capacity_bits) {
 static int issue_readback(svgr_batch* b, bool with_bboxes, void* staging = nullptr) {
     void* bd_dst = staging ? staging : (void*)&b->host_bd;
     HIPCHK(hipMemcpyAsync(bd_dst, b->bd(), sizeof(BatchDev), hipMemcpyDeviceToHost, b->ctx->stream));
-    if (with_bboxes) {
+    if (with_bboxes && !(b->defer_bbox && staging)) {
         b->host_bbox.resize(4 * (size_t)b->n_paths);
+        b->host_bbox_stale = false;
         void* bb_dst = staging ? (void*)((char*)staging + sizeof(BatchDev)) : (void*)b->host_bbox.data();
         HIPCHK(hipMemcpyAsync(bb_dst, b->bbox.p, sizeof(int) * 4 * (size_t)b->n_paths, hipMemcpyDeviceToHost, b->ctx->stream));
     }
@@ -4495,7 +4498,19 @@ static int issue_readback(svgr_batch* b, bool with_bboxes, void* staging = nullp
 }
 static void take_readback(svgr_batch* b, const void* staging) {
     memcpy(&b->host_bd, staging, sizeof(BatchDev));
+    if (b->defer_bbox) { b->host_bbox_stale = true; return; }
     memcpy(b->host_bbox.data(), (const char*)staging + sizeof(BatchDev), sizeof(int) * 4 * (size_t)b->n_paths);
+    b->host_bbox_stale = false;
+}
+// the per-path bboxes on the host (a re-plan through svgr_batch_draw leaves them on the device until somebody needs them: the copy
+// is a launch between the geometry pass and the tile kernel otherwise)
+static int ensure_host_bbox(svgr_batch* b) {
+    if (!b->host_bbox_stale) return 0;
+    b->host_bbox.resize(4 * (size_t)b->n_paths);
+    HIPCHK(hipMemcpyAsync(b->host_bbox.data(), b->bbox.p, sizeof(int) * 4 * (size_t)b->n_paths, hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    b->host_bbox_stale = false;
+    return 0;
 }
 static int check_dev_err(svgr_batch* b, int* capacity_bits = nullptr, bool whole = true, bool with_bboxes = false) {
     int e = 0;
@@ -5361,6 +5376,7 @@ static int plan_slab_order(svgr_batch* b) {
     b->slab_at_valid = false;
     if (getenv("SVGR_SAFE_PATH")) return 0;  // (tests: the renders then take their slab places from the cursor, in arrival order)
     const size_t np = (size_t)b->n_paths;
+    if (int rc = ensure_host_bbox(b)) return rc;
     if (np == 0 || b->host_bbox.size() < 4 * np || b->n_slabs <= 0 || b->vp[2] <= 0) return 0;
     std::vector<int> n_sl(np, 0), order;
     std::vector<float> w(np, 0.f);
@@ -5541,7 +5557,9 @@ static int two_pass_issue(svgr_batch* b, void* staging) {
     }
     const double t_3 = now_ms();
     if ((rc = run_geometry(b, 4, true))) return rc;
-    if ((rc = issue_readback(b, true, staging))) return rc;
+    // (pass 2 finds the bboxes the census found: with a staging, only its scalars come back -- a 64 KB copy in front of the tile
+    //  kernel costs a frame ~20 us)
+    if ((rc = issue_readback(b, staging == nullptr, staging))) return rc;
     if (getenv("SVGR_DBG_PLAN"))
         fprintf(stderr, "[plan] two passes, ms: pass 1 issued %.3f, drained %.3f, buffers sized %.3f, pass 2 issued %.3f | edges %lld, rows crossed %lld, columns %lld, pairs %lld, cells %lld, slabs %lld, add slots %lld, longest band list %d\n",
                 t_1 - t_0, t_2 - t_1, t_3 - t_2, now_ms() - t_3, n_edges, rows_x, cols_x, (long long)b->n_pb, (long long)b->n_cells, (long long)b->n_slabs, (long long)b->n_adds, longest);
@@ -5549,7 +5567,7 @@ static int two_pass_issue(svgr_batch* b, void* staging) {
 }
 // pass 2 has drained: validate it.  1 planned, 0 fall back (a guess was too small), < 0 error
 static int two_pass_finish(svgr_batch* b, const void* staging) {
-    if (staging) take_readback(b, staging);
+    if (staging) memcpy(&b->host_bd, staging, sizeof(BatchDev));   // (the bboxes on the host are the census's: the same geometry)
     HIPCHK(hipGetLastError());
     if (b->host_bd.err) b->invalidate_work();
     int cap_bits = 0;
@@ -5584,6 +5602,7 @@ static int plan_two_pass(svgr_batch* b) {
 static int batch_plan_impl(svgr_batch* b, bool skip_speculative) {
     if (!b) return fail(SVGR_E_INVALID, "batch is NULL");
     HIPCHK(enter_ctx(b->ctx));
+    b->defer_bbox = false;
     b->planned = false; b->slab_at_valid = false; b->slab_order_pending = false;
     b->geometry_fresh = false; b->geometry_current = false;
     {
@@ -5704,6 +5723,10 @@ int svgr_batch_get_stats(const svgr_batch* b, svgr_batch_stats* out) {
 int svgr_batch_get_bboxes(const svgr_batch* b, int32_t* out) {
     if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
     if (!b->planned) return fail(SVGR_E_STATE, "svgr_batch_plan has not run");
+    if (b->host_bbox_stale) {
+        HIPCHK(enter_ctx(b->ctx));
+        if (int rc = ensure_host_bbox(const_cast<svgr_batch*>(b))) return rc;
+    }
     memcpy(out, b->host_bbox.data(), sizeof(int32_t) * 4 * (size_t)b->n_paths);
     return 0;
 }
@@ -5914,6 +5937,8 @@ static int batch_render_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigne
     }
     HIPCHK(enter_ctx(b->ctx));
     hipStream_t st = b->ctx->stream;
+    if (single && b->host_bbox_stale)
+        if (int rc = ensure_host_bbox(b)) return rc;
 
     const int owned_bands = count_owned_bands(b->own, b->n_bands);
     const int n_ctiles = (b->vp[3] + TC - 1) / TC;
@@ -6125,6 +6150,7 @@ static int batch_draw_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned 
     if (!b || !out) return fail(SVGR_E_INVALID, "bad arguments");
     HIPCHK(enter_ctx(b->ctx));
     hipStream_t st = b->ctx->stream;
+    b->defer_bbox = false;
     if (!b->planned) {
         const bool canvas = out_kind == SVGR_OUT_CANVAS_F32 || out_kind == SVGR_OUT_CANVAS_F64;
         const bool fast = canvas && b->has_vp && b->own.world <= 1 && b->n_segs > 0 && !(flags & (SVGR_RENDER_TIMED | SVGR_RENDER_DETERMINISTIC)) &&
@@ -6135,7 +6161,9 @@ static int batch_draw_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned 
             if (int rc = ensure_pinned(b->ctx, stage_bytes)) return rc;
             b->slab_at_valid = false; b->slab_order_pending = false;
             b->geometry_fresh = false; b->geometry_current = false;
+            b->defer_bbox = true;                                       // (the bboxes stay on the device until somebody asks: ensure_host_bbox)
             int is = spec_issue(b, b->ctx->pinned, true);                 // (the buffers of the batch's last plan as the guesses)
+            b->defer_bbox = is > 0;
             if (is == 0) is = spec_issue(b, b->ctx->pinned, false);      // (a small batch: size models)
             if (is < 0) return is;
             if (is > 0) issued = 1;
@@ -6156,6 +6184,7 @@ static int batch_draw_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned 
             int fin;
             if (issued == 1) { take_readback(b, b->ctx->pinned); HIPCHK(hipGetLastError()); fin = spec_finish(b); }
             else fin = two_pass_finish(b, b->ctx->pinned);
+            b->defer_bbox = false;
             if (fin < 0) return fin;
             if (fin > 0) {
                 b->geometry_fresh = false;          // (consumed by the tile kernel above)
