@@ -4098,7 +4098,7 @@ struct svgr_batch {
     DevArr<CellHdr> cell_hdr;               // per (path, band, column tile) cell: header (classes 1 and 2)
     DevArr<unsigned char> work_block;       // a first plan's work arrays in ONE block (two dozen hipMallocs were half of a cold render): the arrays below are then views of it
     DevArr<int2> cell_plan;                 // ... and where its add list lives: {first add, pieces}, left by the plan's full pass (k_path_build)
-    bool add_places = false;                // `cell_plan` holds the places of the current plan: the renders take them (k_path_build<true>)
+    bool add_places = false;                // `cell_plan` holds the places of the current plan: the renders take them (k_path_build<1>)
     // a pass that ended with an error flag may have left any of the self-cleaning buffers dirty
     void invalidate_work() { masks_zeroed = false; arena_zeroed = false; }
     DevArr<TileAdd> adds;                   // the cells' add lists (k_path_build: a slab reserves its cells' lists in one piece)
@@ -5427,7 +5427,7 @@ static int plan_slab_order(svgr_batch* b) {
 //           columns the kept pieces cross) and k_path_bbox on its min / max keys: the bboxes, and with them -- the kernel's own
 //           reservations -- the exact numbers of (path, band) pairs, cells and slabs
 //   host    every buffer sized exactly, but the add lists: a guess from the rows / columns crossed and the cells
-//   pass 2  the whole geometry (k_path_build<false>: it leaves every cell's add places): validated by its own error word
+//   pass 2  the whole geometry (k_path_build<2>: one pass on its own bounds; it leaves every cell's add places): validated by its own error word
 // An add-list guess that was too small is flagged by the kernels and the staged plan (which MEASURES the lists) takes over.
 // 1 planned, 0 fall back, < 0 error.
 static double now_ms() {
