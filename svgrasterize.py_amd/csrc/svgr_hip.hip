@@ -4040,7 +4040,8 @@ struct svgr_batch {
     int sized_vp[4] = {0, 0, 0, 0};
     // SVGR_SAFE_PATH (a test hook, read when a plan is made): the renders take NO place from the plan -- slab places, band-list
     // places, the kept band lists, the lanes' edge places, the cells' add places all come from the device's cursors and a second
-    // pass again, as in the plan's own passes.  Each of them was an A/B switch of its own while it was new; they have been
+    // pass again, as in the staged plan's own passes -- and the round-6 shortcuts of a frame with new geometry are off as well: the
+    // one-traversal flatten, k_path_build<2>, svgr_batch_draw's single wait (it plans, then renders).  Each of them was an A/B switch of its own while it was new; they have been
     // bit-identical since (tests/test_gpu_fullsize.py::test_planned_slab_places_do_not_change_the_picture compares the two ends).
     bool safe_path = false;
     void read_switches() {
@@ -4432,7 +4433,7 @@ static int run_geometry(svgr_batch* b, int upto, bool use_vp) {
                                b->deterministic ? 1 : 0, pb_dbg);
         };
         // (an unplanned pass over add lists sized with room to spare: ONE pass on the workgroup's own bounds, MODE 2)
-        const bool bounded = !placed && !b->count_adds_only && b->adds.p && b->adds_roomy && !b->safe_path && !getenv("SVGR_NO_BOUNDED_BUILD");
+        const bool bounded = !placed && !b->count_adds_only && b->adds.p && b->adds_roomy && !b->safe_path && !getenv("SVGR_SAFE_PATH");
         if (placed) launch_pb(k_path_build<1>); else if (bounded) launch_pb(k_path_build<2>); else launch_pb(k_path_build<0>);
 #ifdef SVGR_DBG_PB_STAMP
         if (pb_dbg && b->planned && !b->count_adds_only) {
@@ -5149,7 +5150,7 @@ static int spec_issue(svgr_batch* b, void* staging = nullptr, bool again = false
         // ONE flatten traversal (k_flatten<.., SCAN>: count, look-back, store) when the last plan left arrays for its by-products;
         // else the counting pass + prefix sums in front of the storing one
         b->fl_sub = choose_fl_sub(b, (int)ns);   // (as the counting pass would choose it: the lanes' places follow it)
-        const bool scan = !b->safe_path && getenv("SVGR_NO_SCAN_FLATTEN") == nullptr && b->seg_cnt.cap >= (size_t)ns + 1 &&
+        const bool scan = !b->safe_path && getenv("SVGR_SAFE_PATH") == nullptr && b->seg_cnt.cap >= (size_t)ns + 1 &&
                           b->seg_off.cap >= (size_t)ns + 2 && b->lane_off.cap >= ((size_t)ns << b->fl_sub) + 1;
         if (!scan && (rc = run_geometry(b, 1, true))) return rc;
         b->fl_scan = scan;
@@ -6154,7 +6155,7 @@ static int batch_draw_impl(svgr_batch* b, svgr_buf* out, int out_kind, unsigned 
     if (!b->planned) {
         const bool canvas = out_kind == SVGR_OUT_CANVAS_F32 || out_kind == SVGR_OUT_CANVAS_F64;
         const bool fast = canvas && b->has_vp && b->own.world <= 1 && b->n_segs > 0 && !(flags & (SVGR_RENDER_TIMED | SVGR_RENDER_DETERMINISTIC)) &&
-                          getenv("SVGR_NO_SPECULATIVE_PLAN") == nullptr && getenv("SVGR_NO_FUSED_DRAW") == nullptr;
+                          getenv("SVGR_NO_SPECULATIVE_PLAN") == nullptr && getenv("SVGR_SAFE_PATH") == nullptr;
         int issued = 0;   // 1: the re-plan's single pass, 2: the two-pass plan's second pass
         if (fast) {
             const size_t stage_bytes = sizeof(BatchDev) + 16 * (size_t)b->n_paths + 256;
