@@ -184,6 +184,9 @@ def test_two_threads_share_nothing_but_the_lock(monkeypatch):
             inside[0] -= 1
         return None
 
+    from svgrasterize_amd import displaylist
+
+    monkeypatch.setattr(displaylist, "ENABLED", False)   # (the walk is what is under test: a scene of fills alone would be drawn from its display list)
     monkeypatch.setattr(Scene, "_render", fake_render)
     monkeypatch.setattr(scene_mod, "_collect_mask_jobs", lambda *a, **k: None)
     sc = Scene.fill(Path.from_svg("M1,1 L5,1 L3,4 Z"), np.array([1.0, 0.0, 0.0, 1.0])).opacity(0.5)
