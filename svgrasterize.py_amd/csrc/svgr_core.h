@@ -342,6 +342,32 @@ SVGR_HD RowPieces row_record(double x, double x_next, double d) {
     return r;
 }
 
+// k_path_build<2>: an UPPER BOUND of the adds the rows of one edge leave in ONE column tile of one band, from where the edge
+// enters the band (`x_in`, the column at the start of its first row there) and where it leaves it (`x_out`), over `nr` rows of a
+// layer `cols` wide whose tiles cut a run of equal pieces every `px` columns.  A row leaves two pieces (the pixel it lies in, the
+// carry into the next) plus one per column border it crosses (row_record: n + 1 pieces, n = borders + 1); x runs monotonically along
+// an edge, so over the rows that is 2 nr + |floor(x_out) - floor(x_in)| -- exactly; the closed-form ends are widened by a relative 1e-9
+// so that a value the row recurrence rounds to the other side of an integer counts as crossing it.  Borders outside the layer make
+// no piece of their own: right of it nothing is stored, left of it every piece folds into column 0 (up to five adds there per row
+// instead of two).  A long span is cut into runs: four single pieces and a run piece per `px` columns -- 6 nr + borders / px + 1 --,
+// 13 per row and tile at most (tiles are 64 columns, px = 8).  `lo` / `hi`: the first and last column the rows can touch (before the
+// carry piece's + 1), for the caller's tile range.  tests/test_core_host.py::test_band_room_bounds_every_cell checks it against
+// the pieces row_step / row_record / record_adds make, cell by cell, on millions of random edges.
+SVGR_HD int band_room(double x_in, double x_out, int nr, int cols, int px, int& lo, int& hi) {
+    double xlo = x_in < x_out ? x_in : x_out, xhi = x_in < x_out ? x_out : x_in;
+    xlo -= 1e-9 * (1.0 + fabs(xlo));
+    xhi += 1e-9 * (1.0 + fabs(xhi));
+    lo = clamp_to_int(floor(xlo));
+    hi = clamp_to_int(floor(xhi));
+    const int lo_c = lo > -1 ? lo : -1;
+    int hi_c = hi > -1 ? hi : -1;
+    hi_c = hi_c < cols ? hi_c : cols;
+    const int nc = hi_c - lo_c, fold = lo < 0 ? 3 * nr : 0;
+    int room = 2 * nr + nc;
+    room = room < 6 * nr + nc / px + 1 ? room : 6 * nr + nc / px + 1;
+    return (room < 13 * nr ? room : 13 * nr) + fold;
+}
+
 // feed the pieces of a record to `put(xi, v)` in increasing column order; put returns false to stop
 template <class Put>
 SVGR_HD void apply_record(int x0i, int n, const double* v, Put&& put) {

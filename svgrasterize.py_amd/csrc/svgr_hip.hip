@@ -1652,14 +1652,10 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
             plan_pending = false;
         }
         if (BOUNDED && bounds) {
-            // Every kept edge adds an upper bound of the adds it can leave to each cell it can reach.  A row of an edge leaves two
-            // pieces (the pixel it lies in, the carry into the next) plus one per column border it crosses (row_record: n + 1 pieces,
-            // n = borders + 1; fewer where a long span is cut into runs, record_adds); x runs monotonically along an edge, so over
-            // the edge's rows in ONE band that is 2 x rows + |floor(x at its exit from the band) - floor(x at its entry)| -- exactly.
-            // Entry and exit in closed form (the recurrence's sum of dy is yhi - ylo), widened by a relative 1e-9 so that a value the
-            // recurrence rounds to the other side of an integer is counted as crossing it.  The columns it can reach, for the TILES:
-            // one more on the right for the carry piece; clamped like row_tiles clamps a row's.  An edge that reaches two tiles of a
-            // band gives each the whole amount.
+            // Every kept edge adds, to each cell it can reach, an upper bound of the adds it can leave there: `band_room` (svgr_core.h) of
+            // where it enters and leaves the band -- in closed form: the recurrence's sum of dy is yhi - ylo.  The TILES: the columns it
+            // can touch, one more on the right for the carry piece, clamped like row_tiles clamps a row's; an edge that reaches two
+            // tiles of a band gives each the whole amount.
 #pragma unroll
             for (int j = 0; j < PB_EPL; ++j) {
                 if (cnt[j] <= 0) continue;
@@ -1673,10 +1669,8 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                     if (owns_band(own, band)) {
                         const double ta = ((double)y0 > el[j].p0y ? (double)y0 : el[j].p0y) - ylo;
                         const double tb = ((double)y1 < el[j].p1y ? (double)y1 : el[j].p1y) - ylo;
-                        const double xa = el[j].x + dx * ta, xb = el[j].x + dx * tb;
-                        double xlo = xa < xb ? xa : xb, xhi = xa < xb ? xb : xa;
-                        xlo -= 1e-9 * (1.0 + fabs(xlo)); xhi += 1e-9 * (1.0 + fabs(xhi));
-                        const int lo = clamp_to_int(floor(xlo)), hi = clamp_to_int(floor(xhi));
+                        int lo, hi;
+                        const int room = band_room(el[j].x + dx * ta, el[j].x + dx * tb, y1 - y0, cols, PX, lo, hi);
                         if (lo < cols) {   // (rows wholly beyond the layer store nothing, S:2260)
                             const int cf = lo > 0 ? lo : 0;
                             int cl = hi + 1 > 0 ? hi + 1 : 0;
@@ -1684,16 +1678,6 @@ __global__ __launch_bounds__(PB_THREADS, SVGR_PB_WAVES) void k_path_build(const 
                             int kf = (cf - x_first) / TC, kl = (cl - x_first) / TC;
                             kf = kf > sl.k0 ? kf : sl.k0;
                             kl = kl < sl.k0 + sl.nk - 1 ? kl : sl.k0 + sl.nk - 1;
-                            // (borders outside the layer make no piece of their own: right of it nothing is stored, left of it every piece
-                            //  folds into column 0 -- up to five adds there per row instead of two.  A long span is cut into runs: four
-                            //  single pieces and a run piece per PX columns, 13 per row and tile at most)
-                            const int lo_c = lo > -1 ? lo : -1;
-                            int hi_c = hi > -1 ? hi : -1;
-                            hi_c = hi_c < cols ? hi_c : cols;
-                            const int nr = y1 - y0, nc = hi_c - lo_c, fold = lo < 0 ? 3 * nr : 0;
-                            int room = 2 * nr + nc;
-                            room = room < 6 * nr + nc / PX + 1 ? room : 6 * nr + nc / PX + 1;
-                            room = (room < 13 * nr ? room : 13 * nr) + fold;
                             for (int k = kf; k <= kl; ++k)
                                 __hip_atomic_fetch_add(&s_plan_n[(band - sl.band0) * sl.nk + (k - sl.k0)], room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }

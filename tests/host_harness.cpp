@@ -82,4 +82,89 @@ void hh_over(double* dst, const double* src) { over_px(dst, src[0], src[1], src[
 unsigned long long hh_key(double v) { return f64_key(v); }
 double hh_unkey(unsigned long long k) { return key_f64(k); }
 
+
+// k_path_build<2>'s bound (svgr_core.h: band_room) against the adds the rows of an edge really leave in each (band, column tile)
+// cell: `iters` random edges (lengths 0.5 .. 100 px, every direction, integer and half-integer end points, vertical ones, far left
+// of and beyond the layer), layers of random size and tile phase.  The per-cell count restates record_adds / run_pieces of
+// svgr_hip.hip (device code: pinned by the GPU parity tests) for tiles of 64 columns cut into runs of 8.
+// out = {cells with adds, cells whose adds exceed their bound, 1e6 * the largest adds / bound}
+void hh_bound_check(unsigned long long seed, long iters, long long* out) {
+    const int TC = 64, PX = 8, TR = 16;
+    unsigned long long state = seed;
+    auto U = [&]() { state += 0x9E3779B97F4A7C15ull; unsigned long long z = state; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31; return (double)(z >> 11) * (1.0 / 9007199254740992.0); };
+    auto run_pieces = [&](int tcol, int len) { return ((tcol + len - 1) / PX) - (tcol / PX) + 1; };
+    long long cells = 0, bad = 0;
+    double worst = 0.0;
+    enum { MAXB = 32, MAXK = 16 };
+    for (long it = 0; it < iters; ++it) {
+        const int rows = 40 + (int)(U() * 200), cols = 40 + (int)(U() * 300);
+        const int x_first = -(int)(U() * 64), r_off = (int)(U() * 16);
+        double ar = U() * (rows + 20) - 10, ac = U() * (cols + 60) - 30;
+        const double len = pow(10.0, U() * 2.3 - 0.3), th = U() * 6.283185307179586;
+        if (it % 7 == 0) { ar = floor(ar); ac = floor(ac); }
+        double br = ar + len * sin(th), bc = ac + len * cos(th);
+        if (it % 11 == 0) bc = ac;
+        if (it % 13 == 0) { br = floor(br); bc = floor(bc) + 0.5; }
+        const EdgeSetup es = edge_setup(ar, ac, br, bc, rows);
+        const double cmin = ac < bc ? ac : bc;
+        if (!es.valid || cmin >= cols + 2.0) continue;
+        int act[MAXB][MAXK] = {}, bnd[MAXB][MAXK] = {};
+        RowState st;
+        st.x_next = es.x; st.x = es.x; st.d = 0.0;
+        for (int y = es.y_begin; y < es.y_end; ++y) {
+            row_step(st, y, es.p0y, es.p1y, es.dxdy, es.dir);
+            const RowPieces rp = row_record(st.x, st.x_next, st.d);
+            if (!(rp.x0i < cols)) continue;
+            const int band = (y + r_off) / TR;
+            const int xl = rp.x0i + (rp.n >= 2 ? rp.n : 1);
+            const int cf = rp.x0i > 0 ? rp.x0i : 0;
+            int cl = xl > 0 ? xl : 0;
+            cl = cl < cols - 1 ? cl : cols - 1;
+            for (int k = (cf - x_first) / TC; k <= (cl - x_first) / TC; ++k) {
+                int ca = k * TC + x_first, cb = ca + TC;
+                const int cell_c0 = ca;
+                ca = ca > 0 ? ca : 0; cb = cb < cols ? cb : cols;
+                int ne = 0;
+                auto one = [&](int xi) { const int c = xi > 0 ? xi : 0; if (c >= ca && c < cb) ++ne; };
+                one(rp.x0i); one(rp.x0i + 1);
+                if (rp.n >= 3) {
+                    const int xa = rp.x0i + 2, xb = rp.x0i + rp.n - 2;
+                    if (xa < 0 && ca == 0 && (xb < -1 ? xb : -1) - xa + 1 > 0) ++ne;
+                    int lo = xa > 0 ? xa : 0; lo = lo > ca ? lo : ca;
+                    const int hi = xb < cb - 1 ? xb : cb - 1;
+                    if (hi >= lo) ne += run_pieces(lo - cell_c0, hi - lo + 1);
+                    one(rp.x0i + rp.n - 1);
+                }
+                if (rp.n >= 2) one(rp.x0i + rp.n);
+                if (band < MAXB && k < MAXK) act[band][k] += ne;
+            }
+        }
+        const double ylo = (double)es.y_begin > es.p0y ? (double)es.y_begin : es.p0y;
+        for (int y0 = es.y_begin; y0 < es.y_end;) {
+            const int vrow = y0 + r_off, band = vrow / TR;
+            int y1 = y0 + TR - (vrow & (TR - 1));
+            y1 = y1 < es.y_end ? y1 : es.y_end;
+            const double ta = ((double)y0 > es.p0y ? (double)y0 : es.p0y) - ylo, tb = ((double)y1 < es.p1y ? (double)y1 : es.p1y) - ylo;
+            int lo, hi;
+            const int room = band_room(es.x + es.dxdy * ta, es.x + es.dxdy * tb, y1 - y0, cols, PX, lo, hi);
+            if (lo < cols) {
+                const int cf = lo > 0 ? lo : 0;
+                int cl = hi + 1 > 0 ? hi + 1 : 0;
+                cl = cl < cols - 1 ? cl : cols - 1;
+                for (int k = (cf - x_first) / TC; k <= (cl - x_first) / TC; ++k)
+                    if (band < MAXB && k < MAXK) bnd[band][k] += room;
+            }
+            y0 = y1;
+        }
+        for (int b = 0; b < MAXB; ++b)
+            for (int k = 0; k < MAXK; ++k)
+                if (act[b][k] > 0) {
+                    ++cells;
+                    if (act[b][k] > bnd[b][k]) ++bad;
+                    else if ((double)act[b][k] / bnd[b][k] > worst) worst = (double)act[b][k] / bnd[b][k];
+                }
+    }
+    out[0] = cells; out[1] = bad; out[2] = (long long)(worst * 1e6);
+}
 }  // extern "C"

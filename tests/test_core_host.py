@@ -36,7 +36,20 @@ def hh():
     L.hh_key.restype = C.c_uint64
     L.hh_unkey.argtypes = [C.c_uint64]
     L.hh_unkey.restype = C.c_double
+    L.hh_bound_check.argtypes = [C.c_ulonglong, C.c_long, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
     return L
+
+
+def test_band_room_bounds_every_cell(hh):
+    """k_path_build<2> places a cell's add list by an UPPER BOUND of its adds (svgr_core.h: band_room, summed over the edges that
+    reach the cell) instead of counting them in a pass of its own.  The bound against the adds the reference's row arithmetic
+    (edge_setup / row_step / row_record, S:2230-2303) leaves in every cell: a million random edges, no cell above its bound -- and
+    cells that fill theirs exactly (the bound is the count, not a guess, for an edge inside one tile)."""
+    out = np.zeros(3, dtype=np.int64)
+    for seed in (1, 0x5F3759DF):
+        hh.hh_bound_check(seed, 500000, out)
+        assert out[0] > 500000 and out[1] == 0, out
+        assert out[2] == 1000000, out
 
 
 def test_transform_and_flatness_bit_exact(hh):
