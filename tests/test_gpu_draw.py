@@ -203,3 +203,28 @@ def test_frames_from_new_batches_inherit_capacities_not_contents(S, monkeypatch)
         assert_close64(out.download((size, size, 4), np.float64), want, atol=1e-12, what=f"replay of frame {k}")
         prev = b
     prev.destroy()
+
+
+def test_measure_helpers_report_device_time_and_launches(S):
+    """svgr_measure_begin / _end: the device time of what is enqueued between them, behind a hold of the stream (so that the host's
+    pace does not show); svgr_measure_launches: the library's own count of kernel launches.  A planned render of the bench's kind is
+    five launches; its device time is a fraction of a millisecond and does not include the hold."""
+    from svgrasterize_amd import _abi, synth
+
+    size = 1024
+    sc = synth.make_scene(size, 1000)
+    ctx = S.Context.get()
+    b = _new(S, sc)
+    out = ctx.alloc(size * size * 16)
+    b.draw(out, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
+    b.render(out, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)     # (the first replay: the slab order)
+    ctx.sync()
+    n0 = ctx.launches()
+    ctx.measure_begin(3.0)
+    b.render(out, _abi.OUT_CANVAS_F32, _abi.RENDER_CLIP01)
+    ms = ctx.measure_end()
+    assert ctx.launches() - n0 == 1 + 5, "the hold + flatten, bbox, path build, tile lists, tile kernel"
+    assert 0.005 < ms < 1.0, ms
+    ctx.measure_begin(0.0)
+    assert ctx.measure_end() < 0.5
+    b.destroy()
