@@ -1,6 +1,9 @@
 // svgr_hip.hip -- MI355X (gfx950 / CDNA4) anti-aliased path rasterizer: HIP kernels + C ABI.
 //
-// Pipeline of one svgr_batch_render (6 launches on the context stream, no host read-back):
+// Pipeline of one svgr_batch_render (5 launches of a planned batch on the context stream -- k_band_entries only in a plan's own
+// pass --, no host read-back).  A frame with NEW geometry (svgr_batch_draw) runs the same kernels in their unplanned forms -- the
+// flatten in one traversal with a decoupled look-back (k_flatten<.., SCAN>), k_path_build<2> on its own per-cell bounds -- with the
+// tile kernel enqueued behind the pass and ONE host wait at the end:
 //
 //   [memsets]       zero-fill of the batch's counter arena and of the tiles' entry bitmasks: only for the first render
 //                   after a plan, later ones find both cleared by the previous render's kernels
@@ -9,8 +12,7 @@
 //                   plan's per-segment prefix sums -- (path, segment, curve) order, no returning atomic; endpoints
 //                   folded into per-path min/max keys
 //   k_path_bbox     per path: integer bbox (floor-1 / ceil+1, clipped to the viewport), band range, its (path, band)
-//                   pair slots and (path, band, column tile) cells, and its SLABS -- runs of <= 16 bands x <= 120
-//                   column tiles of cells -- at the plan's heaviest-first places
+//                   pair slots and (path, band, column tile) cells, and its SLABS -- runs of <= 16 bands, <= 80 cells -- at the plan's heaviest-first places
 //   k_band_entries  per band: the paths whose bbox reaches it, in paint order; the band's first item slot
 //   k_path_build    per slab, everything in LDS: per edge row the closed-form signed-area pieces (the reference's x
 //                   recurrence replayed from the edge's first row), per cell the carry-in of every tile row, its
