@@ -204,7 +204,8 @@ int svgr_batch_get_bboxes(const svgr_batch* batch, int32_t* out /* n_paths x 4 *
  * objectBoundingBox paint (S:1023-1027) without fetching the hull.  Read from the plan's own geometry pass: valid between
  * svgr_batch_plan and the first render (SVGR_E_STATE otherwise).  A path without edges: {+inf, +inf, -inf, -inf}.
  * (svgr_batch_set_gradients with the same path -> gradient assignment and new descriptions -- those frames -- keeps the plan
- * and its pass.) */
+ * and its pass.)  Defined for the paths this rank KEEPS: under svgr_batch_set_bands with world > 1 a path none of whose rows can
+ * reach an owned band is not flattened here and reports {+inf, +inf, -inf, -inf} like a path without edges. */
 int svgr_batch_get_extents(svgr_batch* batch, double* out /* n_paths x 4 */);
 /* flattened edges in presentation space, (E, 2, 2) doubles, grouped by path; edge_path may be NULL */
 int svgr_batch_get_edges(const svgr_batch* batch, double* edges, int32_t* edge_path, int64_t cap);

@@ -486,3 +486,55 @@ def test_gpu_bounding_box_gradients_inside_the_batch_draw_what_they_draw_node_by
         assert float(np.abs(np.array(layer.image) - first).max()) <= 1e-12
     finally:
         S.set_render_cache(0)
+
+
+@pytest.mark.gpu
+def test_gpu_bounding_box_gradients_in_runs_that_share_a_batch(monkeypatch):
+    """objectBoundingBox gradients in runs that SHARE a batch: a blur between two stretches of fills cuts the document
+    into runs, `_merge_runs` gives each a range of rows of one tall canvas (its leaves moved down by a whole number of bands), and
+    `_resolve_frames` takes a fill's frame from the extent of the MOVED geometry, minus the shift.  (t + shift) - shift is not t in
+    double, and the reference takes the hull's box from unshifted points (S:1023-1027, S:2010-2020): the picture against the
+    per-node route (`_BATCH_BBOX_GRADS` off: Path.mask, hull.bbox_transform, svgr_gradient_fill) under the float32 1-ULP contract,
+    and to 1e-10 in double."""
+    import svgrasterize_amd as S
+    from svgrasterize_amd import scene as sm
+
+    red, blue, green = np.array([1.0, 0.0, 0.0, 1.0]), np.array([0.0, 0.0, 1.0, 1.0]), np.array([0.0, 0.5, 0.0, 0.5])
+    stops = [(0.0, red), (0.4, green), (1.0, blue)]
+
+    def blob(cx, cy, r):
+        k = 0.5522847498 * r
+        return S.Path([[(S.PATH_CUBIC, [[cx + r, cy], [cx + r, cy + k], [cx + k, cy + r], [cx, cy + r]]),
+                        (S.PATH_CUBIC, [[cx, cy + r], [cx - k, cy + r], [cx - r, cy + k], [cx - r, cy]]),
+                        (S.PATH_CUBIC, [[cx - r, cy], [cx - r, cy - k], [cx - k, cy - r], [cx, cy - r]]),
+                        (S.PATH_CUBIC, [[cx, cy - r], [cx + k, cy - r], [cx + r, cy - k], [cx + r, cy]])]])
+
+    lin = S.GradLinear(np.array([0.0, 0.0]), np.array([1.0, 1.0]), stops, None, "pad", True, None)
+    rad = S.GradRadial(np.array([0.5, 0.5]), 0.5, None, None, stops, None, "repeat", True, None)
+    foc = S.GradRadial(np.array([0.5, 0.5]), 0.45, np.array([0.35, 0.4]), 0.05, stops, None, "reflect", True, None)
+    fill = lambda p, paint: S.Scene.fill(p, paint)  # noqa: E731
+    blurred = fill(blob(120.3, 90.7, 22), red).filter(S.Filter.empty().blur(1.5, 1.5))
+    runs = []
+    for j in range(3):   # three stretches of fills with a blurred node between them: three runs, three ranges of the shared canvas
+        dx, dy = 31.37 * j, 17.91 * j
+        runs.append([fill(blob(40.21 + dx, 40.6 + dy, 30.13), lin), fill(blob(95.5 + dx, 52.3 + dy, 33.7), rad).opacity(0.7),
+                     fill(blob(66.9 + dx, 101.2 + dy, 36.4), foc), fill(blob(150.1 + dx, 120.8 + dy, 20.2), blue)])
+    scene = S.Scene.group(runs[0] + [blurred] + runs[1] + [blurred.transform(S.Transform().translate(40, 20))] + runs[2])
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0).scale(2.25, 1.6)
+    vp = [0, 0, 420, 640]
+    before = dict(sm.MERGE_STATS)
+
+    def draw():
+        S.clear_render_cache()
+        layer, _hull = scene.render(tr, viewport=vp, linear_rgb=False)
+        return [int(v) for v in layer.offset], np.array(layer.image)
+
+    monkeypatch.setattr(sm, "_BATCH_BBOX_GRADS", False)
+    o1, a = draw()
+    monkeypatch.setattr(sm, "_BATCH_BBOX_GRADS", True)
+    o2, b = draw()
+    assert sm.MERGE_STATS["runs_sharing"] - before["runs_sharing"] >= 3, "the runs did not share a batch: nothing was moved"
+    assert o1 == o2 and a.shape == b.shape and a.any()
+    assert float(np.abs(a - b).max()) <= 1e-10
+    assert_f32_1ulp(b.astype(np.float32), a, what="bbox-units gradients in shifted runs vs the per-node route")
+
