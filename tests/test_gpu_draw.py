@@ -228,3 +228,66 @@ def test_measure_helpers_report_device_time_and_launches(S):
     ctx.measure_begin(0.0)
     assert ctx.measure_end() < 0.5
     b.destroy()
+
+
+def test_draw_with_groups_clips_bands_and_without_a_viewport(S, monkeypatch):
+    """svgr_batch_draw off the production variant: a document's batch with clip pairs and isolated groups (material-design: the
+    clip / group variants of the tile kernel behind the unvalidated pass), moved and drawn again; a batch WITHOUT a viewport and one
+    restricted to a rank's bands (no fast path: plan, render, wait); SVGR_RENDER_DETERMINISTIC (likewise).  Each against
+    svgr_batch_plan + svgr_batch_render of the same inputs."""
+    import os
+
+    from svgrasterize_amd import _abi, scenedump, synth
+    from svgrasterize_amd import scene as sm
+
+    ctx = S.Context.get()
+    scene, info, _z = scenedump.load_scene(os.path.join(os.path.dirname(__file__), "golden", "scene_material.npz"))
+    size = 1024
+    tr = S.Transform().matrix(0, 1, 0, 1, 0, 0).scale(size / info["full"]["size"][0])
+    leaves = sm._drop_empty(sm._batchable_leaves(scene, tr, False))
+    vp = [0, 0, size, size]
+    out = ctx.alloc(size * size * 32)
+    ref_out = ctx.alloc(size * size * 32)
+    b = sm.build_batch(leaves, vp)
+    ref = sm.build_batch(leaves, vp)
+    ref.plan()
+    ref.render(ref_out, _abi.OUT_CANVAS_F64)
+    want = ref_out.download((size, size, 4), np.float64)
+    b.draw(out, _abi.OUT_CANVAS_F64)
+    assert want.any()
+    assert_close64(out.download((size, size, 4), np.float64), want, atol=1e-12, what="draw of a batch with clips and groups")
+    m6 = np.array([lf[1] for lf in leaves], dtype=np.float64).reshape(len(leaves), 6).copy()
+    m6[:, 2] += 7.25
+    m6[:, 5] -= 3.5
+    for bb in (b, ref):
+        bb.set_transforms(m6)
+    ref.plan()
+    ref.render(ref_out, _abi.OUT_CANVAS_F64)
+    want = ref_out.download((size, size, 4), np.float64)
+    b.draw(out, _abi.OUT_CANVAS_F64)
+    assert_close64(out.download((size, size, 4), np.float64), want, atol=1e-12, what="re-planned draw of a batch with clips and groups")
+    assert np.array_equal(b.bboxes(), ref.bboxes())
+    b.destroy(); ref.destroy()
+    # no viewport: the union of the bboxes is the canvas (S:968); a rank's bands; a deterministic draw
+    sc = synth.make_scene(512, 160)
+    for mode in ("no viewport", "bands", "deterministic"):
+        def make():
+            return _abi.Batch(ctx, sc["segs"], sc["seg_kind"], sc["path_seg_off"], sc["path_m6"], sc["path_rule"], sc["path_paint"],
+                              viewport=None if mode == "no viewport" else list(sc["viewport"]))
+        a, r = make(), make()
+        flags = _abi.RENDER_DETERMINISTIC if mode == "deterministic" else 0
+        if mode == "bands":
+            a.set_bands(1, 2, 4); r.set_bands(1, 2, 4)
+        st = r.plan()
+        rows = int(r.owned_rows()) if mode == "bands" else int(st.bbox_union[2]) if mode == "no viewport" else 512
+        cols = int(st.bbox_union[3]) if mode == "no viewport" else 512
+        o1, o2 = ctx.alloc(max(rows * cols * 32, 32)), ctx.alloc(max(rows * cols * 32, 32))
+        r.render(o2, _abi.OUT_CANVAS_F64, flags)
+        a.draw(o1, _abi.OUT_CANVAS_F64, flags)
+        got, want = o1.download((rows, cols, 4), np.float64), o2.download((rows, cols, 4), np.float64)
+        assert want.any(), mode
+        if mode == "deterministic":
+            assert np.array_equal(got, want), mode
+        else:
+            assert_close64(got, want, atol=1e-12, what=f"draw, {mode}")
+        a.destroy(); r.destroy()
